@@ -1,0 +1,290 @@
+/*
+ * warpx_amd.h -- C-ABI of the MI355X-native PIC inner loop.
+ *
+ * This is the drop-in boundary: a plain-C interface
+ * (pointers + sizes, no torch / AMReX types) underneath the C++17 operator
+ * surface in warpx_amd/csrc/host/ that mirrors the reference's
+ * WarpXParticleContainer / MultiFab / FiniteDifferenceSolver methods.
+ *
+ * Every entry point names the reference interface it replaces
+ * (paths relative to the WarpX checkout @ 2024-10-24).
+ *
+ * Conventions
+ *  - all device pointers; all kernels are asynchronous on `stream`
+ *    (a hipStream_t passed as void*; NULL = the default stream);
+ *  - return value: WXA_OK (0) or a negative wxa_status;
+ *    no entry point allocates unless it takes a wxa_workspace;
+ *  - array layout = AMReX Array4: Fortran order, i fastest, guards included
+ *    (reference usage e.g. Source/FieldSolver/FiniteDifferenceSolver/EvolveE.cpp:148-156);
+ *  - fp64 throughout (amrex::Real = amrex::ParticleReal = double, the
+ *    reference's default build precision, CMakeLists.txt:109-118).
+ */
+#ifndef WARPX_AMD_H_
+#define WARPX_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (reference: WARPX_ABORT_WITH_MESSAGE -> amrex::Abort;
+ *      here an int so a foreign-language host can raise its own error) ---- */
+typedef enum wxa_status {
+    WXA_OK = 0,
+    WXA_ERR_INVALID_ARG = -1,   /* bad pointer / order / algo / box          */
+    WXA_ERR_HIP = -2,           /* a HIP runtime call or kernel launch failed */
+    WXA_ERR_UNSUPPORTED = -3,   /* valid in the reference, outside this path  */
+    WXA_ERR_NOMEM = -4,
+    WXA_ERR_COMM = -5
+} wxa_status;
+
+/* ---- enums crossing the boundary; same enumerator order as the reference
+ *      (Source/Utils/WarpXAlgorithmSelection.H:72-84, Source/Evolve/WarpXDtType.H:10-15) */
+enum { WXA_PUSHER_BORIS = 0, WXA_PUSHER_VAY = 1 };
+enum { WXA_DEPOSIT_ESIRKEPOV = 0, WXA_DEPOSIT_DIRECT = 1 };
+enum { WXA_DT_FULL = 0, WXA_DT_FIRST_HALF = 1, WXA_DT_SECOND_HALF = 2 };
+
+/* One staggered field component of one brick (= one amrex::FArrayBox of a
+ * MultiFab with its guard cells; Array4 semantics).
+ * Point (i,j,k) lives at p[(i-lo[0]) + (j-lo[1])*jstride + (k-lo[2])*kstride].
+ * Valid (non-guard) index box: [lo+ng, lo+n-ng) per direction; it holds
+ * ncell+stag points (a nodal direction has one more point than cells,
+ * Source/WarpX.cpp:2117-2125). */
+typedef struct wxa_field_view {
+    double* p;
+    int32_t lo[3];     /* index of the first allocated point (guards included) */
+    int32_t n[3];      /* allocated points per direction (guards included)     */
+    int32_t ng[3];     /* guard points per side                                */
+    int32_t stag[3];   /* 0 = cell-centred, 1 = nodal along that direction     */
+    int64_t jstride;   /* >= n[0]; rows may be padded for 128-B alignment      */
+    int64_t kstride;   /* >= jstride*n[1]                                      */
+} wxa_field_view;
+
+/* Pure-SoA particle tile, PIdx order x,y,z,w,ux,uy,uz (+ idcpu)
+ * (Source/Particles/NamedComponentParticleContainer.H:23-40). u = gamma*v [m/s]. */
+typedef struct wxa_particle_view {
+    double* x; double* y; double* z; double* w;
+    double* ux; double* uy; double* uz;
+    uint64_t* idcpu;   /* may be NULL */
+    int64_t np;
+} wxa_particle_view;
+
+/* Index-space origin used by gather and deposition:
+ * grid coordinate = (x - xyzmin)*dinv >= 0, array index = lo + that.
+ * The reference builds it from the tile box grown by the guard depth
+ * (Source/Particles/PhysicalParticleContainer.cpp:2575-2601,
+ *  Source/Particles/WarpXParticleContainer.cpp:439,477-479, Source/WarpX.cpp:2851-2875). */
+typedef struct wxa_grid_geom {
+    double xyzmin[3];
+    double dinv[3];
+    int32_t lo[3];
+} wxa_grid_geom;
+
+/* Per-device scratch (sort permutation, histograms, tile offsets, staging).
+ * Opaque; owned by the caller through create/destroy. */
+typedef struct wxa_workspace wxa_workspace;
+
+wxa_status wxa_workspace_create(wxa_workspace** ws);
+void       wxa_workspace_destroy(wxa_workspace* ws);
+
+const char* wxa_version(void);
+const char* wxa_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* Field solver (FDTD Yee)                                             */
+/* ------------------------------------------------------------------ */
+
+/* Replaces FiniteDifferenceSolver::EvolveB -> EvolveBCartesian<CartesianYeeAlgorithm>
+ * (Source/FieldSolver/FiniteDifferenceSolver/EvolveB.cpp:51-117,122-215).
+ * B += dt * curl-like upward differences of E over the valid boxes of Bx,By,Bz.
+ * dinv[d] = 1/dx_d (CartesianYeeAlgorithm.H:29-43). */
+wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3],
+                        double dt, const double dinv[3], void* stream);
+
+/* Replaces FiniteDifferenceSolver::EvolveE -> EvolveECartesian<CartesianYeeAlgorithm>
+ * (Source/FieldSolver/FiniteDifferenceSolver/EvolveE.cpp:53-115,120-250),
+ * without the EB mask and the grad(F) term (both off on this path). */
+wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3],
+                        const wxa_field_view J[3],
+                        double dt, const double dinv[3], void* stream);
+
+/* ------------------------------------------------------------------ */
+/* Particles                                                           */
+/* ------------------------------------------------------------------ */
+
+/* Replaces PhysicalParticleContainer::PushPX
+ * (Source/Particles/PhysicalParticleContainer.cpp:2549-2786): per particle
+ * doGatherShapeN<order,galerkin> (Source/Particles/Gather/FieldGather.H:36-424)
+ * -> doParticleMomentumPush (Source/Particles/Pusher/PushSelector.H:38-102;
+ * Boris: UpdateMomentumBoris.H:15-53, Vay: UpdateMomentumVay.H:19-62)
+ * -> UpdatePosition (Source/Particles/Pusher/UpdatePosition.H:24-45).
+ * order in {1,2,3}; galerkin in {0,1}. */
+wxa_status wxa_gather_push(const wxa_particle_view* p,
+                           const wxa_field_view E[3], const wxa_field_view B[3],
+                           const wxa_grid_geom* geom,
+                           double q, double m, double dt,
+                           int order, int galerkin, int pusher, void* stream);
+
+/* Replaces PhysicalParticleContainer::PushP (:2368-2516): gather + momentum
+ * push by a signed dt, positions untouched (first/last-step (de)synchronisation). */
+wxa_status wxa_push_p(const wxa_particle_view* p,
+                      const wxa_field_view E[3], const wxa_field_view B[3],
+                      const wxa_grid_geom* geom,
+                      double q, double m, double dt,
+                      int order, int galerkin, int pusher, void* stream);
+
+/* Replaces WarpXParticleContainer::DepositCurrent
+ * (Source/Particles/WarpXParticleContainer.cpp:352-827) for
+ * algo = Esirkepov: doEsirkepovDepositionShapeN<order>
+ *        (Source/Particles/Deposition/CurrentDeposition.H:642-907),
+ * algo = Direct:    doDepositionShapeN<order> (:48-335).
+ * J is accumulated into (J must be zeroed by the caller once per step,
+ * Source/Particles/MultiParticleContainer.cpp:470-472).
+ * geom is built from the box grown by ng_depos_J.  ws may be NULL
+ * (global-atomics variant); with a workspace holding a valid cell sort
+ * (wxa_sort_particles_by_cell on the same positions) the LDS-tile variant runs. */
+wxa_status wxa_deposit_current(const wxa_particle_view* p,
+                               const wxa_field_view J[3],
+                               const wxa_grid_geom* geom,
+                               double q, double dt, double relative_time,
+                               int order, int algo,
+                               wxa_workspace* ws, void* stream);
+
+/* Replaces doChargeDepositionShapeN<order>
+ * (Source/Particles/Deposition/ChargeDeposition.H:37-180); diagnostics only. */
+wxa_status wxa_deposit_charge(const wxa_particle_view* p,
+                              const wxa_field_view* rho,
+                              const wxa_grid_geom* geom,
+                              double q, int order, void* stream);
+
+/* Periodic wrap of particle positions into [plo, phi); the part of
+ * amrex ParticleContainer::Redistribute the periodic path needs
+ * (Source/Particles/MultiParticleContainer.cpp:651-654).
+ * periodic[d] != 0 selects the directions wrapped on this brick. */
+wxa_status wxa_enforce_periodic(const wxa_particle_view* p,
+                                const double plo[3], const double phi[3],
+                                const int periodic[3], void* stream);
+
+/* Replaces MultiParticleContainer::SortParticlesByBin (bin = 1 cell,
+ * Source/Particles/MultiParticleContainer.cpp:615-621 -> amrex SortParticlesByBin):
+ * counting sort by cell index inside the box [cell_lo, cell_lo+ncell).
+ * `dst` receives the sorted copy (out of place; same np).  Also records the
+ * per-cell offsets in ws for the tile-based deposition. */
+wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src,
+                                      const wxa_particle_view* dst,
+                                      const double plo[3], const double dinv[3],
+                                      const int32_t cell_lo[3], const int32_t ncell[3],
+                                      wxa_workspace* ws, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* Current filter and guard-cell exchange                              */
+/* ------------------------------------------------------------------ */
+
+/* Replaces BilinearFilter::ApplyStencil -> Filter::DoFilter with a 1-pass
+ * binomial stencil per direction (Source/Filter/BilinearFilter.cpp:26-94,
+ * Source/Filter/Filter.cpp:92-133): dst = filtered src over the whole
+ * allocated box, zero padding beyond it.  src and dst must not alias. */
+wxa_status wxa_filter_bilinear(const wxa_field_view* src, const wxa_field_view* dst,
+                               void* stream);
+
+/* Single-brick periodic FillBoundary: guard points within ng of the valid box
+ * take the value of their periodic image (amrex FabArray::FillBoundary with
+ * geom.periodicity(); Source/ablastr/utils/Communication.cpp:71-115 called
+ * from WarpX::FillBoundaryE/B, Source/Parallelization/WarpXComm.cpp:699-827).
+ * periodic[d] = 0 leaves direction d untouched (it is handled by the
+ * multi-brick exchange instead). */
+wxa_status wxa_fill_boundary_periodic(const wxa_field_view* f, const int ng[3],
+                                      const int periodic[3], void* stream);
+
+/* Single-brick periodic SumBoundary(src_ng): every point ends up holding the
+ * sum over all periodic images taken from valid + src_ng guard regions; all
+ * guards are refreshed (Source/Parallelization/WarpXSumGuardCells.cpp:17-37). */
+wxa_status wxa_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3],
+                                     const int periodic[3], void* stream);
+
+/* Multi-brick exchange helpers: copy a sub-box of a field to/from a dense
+ * staging buffer (i fastest).  box = [blo, bhi) in the field's index space.
+ * unpack mode: 0 = overwrite (FillBoundary), 1 = add (SumBoundary). */
+wxa_status wxa_pack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
+                        double* buf, void* stream);
+wxa_status wxa_unpack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
+                          const double* buf, int mode, void* stream);
+
+/* Zero a field including guards (MultiFab::setVal(0), MultiParticleContainer.cpp:470-472). */
+wxa_status wxa_field_set_zero(const wxa_field_view* f, void* stream);
+
+/* Blocking device<->host copies for hosts without their own HIP binding. */
+wxa_status wxa_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes);
+wxa_status wxa_copy_to_device(void* dst_dev, const void* src_host, int64_t bytes);
+wxa_status wxa_device_synchronize(void);
+
+/* ------------------------------------------------------------------ */
+/* Step-level API: the host layer (warpx_amd/csrc/host/) re-states      */
+/* WarpX::Evolve / OneStep_nosub on the explicit FDTD, single-level,    */
+/* periodic branch (Source/Evolve/WarpXEvolve.cpp:94-347,354-455) on    */
+/* top of the kernels above.  One wxa_sim = one brick on one GPU.       */
+/* ------------------------------------------------------------------ */
+
+typedef struct wxa_sim_config {
+    int32_t n_cell[3];           /* amr.n_cell, whole domain                    */
+    double  prob_lo[3];          /* geometry.prob_lo                            */
+    double  prob_hi[3];          /* geometry.prob_hi                            */
+    double  cfl;                 /* warpx.cfl (CartesianYeeAlgorithm.H:48-56)   */
+    int32_t nox;                 /* algo.particle_shape, 1..3                   */
+    int32_t galerkin;            /* WarpX::galerkin_interpolation (WarpX.cpp:154) */
+    int32_t particle_pusher;     /* WXA_PUSHER_*                                */
+    int32_t current_deposition;  /* WXA_DEPOSIT_*                               */
+    int32_t use_filter;          /* warpx.use_filter: 1-pass bilinear on J      */
+    int32_t sort_interval;       /* warpx.sort_intervals; <=0 = never           */
+    int32_t nbricks[3];          /* domain decomposition, one brick per GPU     */
+    int32_t coord[3];            /* this brick's coordinates                    */
+} wxa_sim_config;
+
+/* Neighbour exchange supplied by the host program (torch.distributed over
+ * RCCL in bench.py; absent = single brick, all directions self-periodic).
+ * Replaces the MPI layer under amrex FabArray::FillBoundary/SumBoundary and
+ * ParticleContainer::Redistribute.  `exchange` posts nmsg
+ * sends and nmsg receives of device buffers and returns when they are
+ * enqueued on `stream` (stream-ordered completion). */
+typedef struct wxa_comm {
+    void* ctx;
+    int32_t rank, nranks;
+    int (*exchange)(void* ctx, int nmsg,
+                    const int32_t* send_peer, void* const* send_buf, const int64_t* send_bytes,
+                    const int32_t* recv_peer, void* const* recv_buf, const int64_t* recv_bytes,
+                    void* stream);
+    /* small host-side all-to-neighbours count exchange (blocking) */
+    int (*exchange_counts)(void* ctx, int nmsg,
+                           const int32_t* send_peer, const int64_t* send_val,
+                           const int32_t* recv_peer, int64_t* recv_val);
+} wxa_comm;
+
+typedef struct wxa_sim wxa_sim;
+
+wxa_status wxa_sim_create(const wxa_sim_config* cfg, const wxa_comm* comm, wxa_sim** out);
+void       wxa_sim_destroy(wxa_sim* s);
+/* Adds a species (WarpXParticleContainer: charge, mass + SoA tile).
+ * Arrays are device pointers, copied; particles must lie inside this brick. */
+wxa_status wxa_sim_add_species(wxa_sim* s, double charge, double mass,
+                               const wxa_particle_view* init, int32_t* species_id);
+/* WarpX::Evolve(numsteps): first step de-synchronises u by PushP(-dt/2),
+ * the last one re-synchronises (WarpXEvolve.cpp:142-145,222-226). */
+wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
+double     wxa_sim_dt(const wxa_sim* s);
+int64_t    wxa_sim_istep(const wxa_sim* s);
+/* name in {"Ex","Ey","Ez","Bx","By","Bz","jx","jy","jz"} (MultiFabRegister::get,
+ * Source/ablastr/fields/MultiFabRegister.H:389-470). */
+wxa_status wxa_sim_get_field(wxa_sim* s, const char* name, wxa_field_view* out);
+wxa_status wxa_sim_get_particles(wxa_sim* s, int32_t species_id, wxa_particle_view* out);
+/* Per-phase accumulated device time in ms since the last reset, named after the
+ * reference's profiler regions: 0 GatherAndPush,
+ * 1 CurrentDeposition, 2 SyncCurrent(filter+SumBoundary), 3 EvolveB, 4 EvolveE,
+ * 5 FillBoundary, 6 Redistribute+Sort.  counts[i] = number of launches. */
+wxa_status wxa_sim_get_timers(wxa_sim* s, double ms[8], int64_t counts[8], int reset);
+wxa_status wxa_sim_enable_timers(wxa_sim* s, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WARPX_AMD_H_ */

@@ -1,0 +1,757 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+// See pic_kernels.hpp for the statement of purpose and the parity pin.
+//
+// This file: (1) kernel-level C entry points `orc_*` with the same signatures as
+// the product C-ABI (include/warpx_amd.h) but host pointers; (2) the
+// single-level periodic step schedule (`orc_sim_*`) restating
+// WarpX::Evolve / OneStep_nosub (Source/Evolve/WarpXEvolve.cpp:94-347,354-455);
+// (3) the diagnostics formulas that define the parity metric and the golden
+// checksums (FieldEnergy, ParticleEnergy, ParticleMomentum, cell-centred sum|Q|).
+#include "pic_kernels.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace orc;
+
+namespace {
+
+inline int vlo(const wxa_field_view& f, int d) { return f.lo[d] + f.ng[d]; }
+inline int vhi(const wxa_field_view& f, int d) { return f.lo[d] + f.n[d] - f.ng[d]; }  // exclusive
+inline int ncell_of(const wxa_field_view& f, int d) { return f.n[d] - 2 * f.ng[d] - f.stag[d]; }
+
+int max_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* orc_version(void) { return "warpx_amd oracle (CPU restatement), fp64"; }
+int orc_num_threads(void) { return max_threads(); }
+
+// Source/FieldSolver/FiniteDifferenceSolver/EvolveB.cpp:122-215 with
+// CartesianYeeAlgorithm::UpwardD{x,y,z} (CartesianYeeAlgorithm.H:69-101,125-167,191-225)
+int orc_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
+                 void*) {
+    const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]);
+    const double idx = dinv[0], idy = dinv[1], idz = dinv[2];
+#pragma omp parallel
+    {
+#pragma omp for nowait
+        for (int k = vlo(B[0], 2); k < vhi(B[0], 2); ++k)
+            for (int j = vlo(B[0], 1); j < vhi(B[0], 1); ++j)
+                for (int i = vlo(B[0], 0); i < vhi(B[0], 0); ++i)
+                    Bx(i, j, k) += dt * (idz * (Ey(i, j, k + 1) - Ey(i, j, k))) -
+                                   dt * (idy * (Ez(i, j + 1, k) - Ez(i, j, k)));
+#pragma omp for nowait
+        for (int k = vlo(B[1], 2); k < vhi(B[1], 2); ++k)
+            for (int j = vlo(B[1], 1); j < vhi(B[1], 1); ++j)
+                for (int i = vlo(B[1], 0); i < vhi(B[1], 0); ++i)
+                    By(i, j, k) += dt * (idx * (Ez(i + 1, j, k) - Ez(i, j, k))) -
+                                   dt * (idz * (Ex(i, j, k + 1) - Ex(i, j, k)));
+#pragma omp for nowait
+        for (int k = vlo(B[2], 2); k < vhi(B[2], 2); ++k)
+            for (int j = vlo(B[2], 1); j < vhi(B[2], 1); ++j)
+                for (int i = vlo(B[2], 0); i < vhi(B[2], 0); ++i)
+                    Bz(i, j, k) += dt * (idy * (Ex(i, j + 1, k) - Ex(i, j, k))) -
+                                   dt * (idx * (Ey(i + 1, j, k) - Ey(i, j, k)));
+    }
+    return 0;
+}
+
+// Source/FieldSolver/FiniteDifferenceSolver/EvolveE.cpp:120-250 (no EB, no F term)
+int orc_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
+                 double dt, const double dinv[3], void*) {
+    const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]), jx(J[0]), jy(J[1]), jz(J[2]);
+    const double idx = dinv[0], idy = dinv[1], idz = dinv[2];
+    constexpr double c2 = PhysConst::c * PhysConst::c;
+#pragma omp parallel
+    {
+#pragma omp for nowait
+        for (int k = vlo(E[0], 2); k < vhi(E[0], 2); ++k)
+            for (int j = vlo(E[0], 1); j < vhi(E[0], 1); ++j)
+                for (int i = vlo(E[0], 0); i < vhi(E[0], 0); ++i)
+                    Ex(i, j, k) += c2 * dt *
+                                   (-(idz * (By(i, j, k) - By(i, j, k - 1))) +
+                                    (idy * (Bz(i, j, k) - Bz(i, j - 1, k))) - PhysConst::mu0 * jx(i, j, k));
+#pragma omp for nowait
+        for (int k = vlo(E[1], 2); k < vhi(E[1], 2); ++k)
+            for (int j = vlo(E[1], 1); j < vhi(E[1], 1); ++j)
+                for (int i = vlo(E[1], 0); i < vhi(E[1], 0); ++i)
+                    Ey(i, j, k) += c2 * dt *
+                                   (-(idx * (Bz(i, j, k) - Bz(i - 1, j, k))) +
+                                    (idz * (Bx(i, j, k) - Bx(i, j, k - 1))) - PhysConst::mu0 * jy(i, j, k));
+#pragma omp for nowait
+        for (int k = vlo(E[2], 2); k < vhi(E[2], 2); ++k)
+            for (int j = vlo(E[2], 1); j < vhi(E[2], 1); ++j)
+                for (int i = vlo(E[2], 0); i < vhi(E[2], 0); ++i)
+                    Ez(i, j, k) += c2 * dt *
+                                   (-(idy * (Bx(i, j, k) - Bx(i, j - 1, k))) +
+                                    (idx * (By(i, j, k) - By(i - 1, j, k))) - PhysConst::mu0 * jz(i, j, k));
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <int O, int G, bool MOVE>
+void gather_push_impl(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                      const wxa_grid_geom* g, double q, double m, double dt, int pusher) {
+    const Arr ex(E[0]), ey(E[1]), ez(E[2]), bx(B[0]), by(B[1]), bz(B[2]);
+#pragma omp parallel for schedule(static)
+    for (int64_t ip = 0; ip < p->np; ++ip) {
+        double xp = p->x[ip], yp = p->y[ip], zp = p->z[ip];
+        double Exp = 0., Eyp = 0., Ezp = 0., Bxp = 0., Byp = 0., Bzp = 0.;  // external fields = 0
+        doGatherShapeN<O, G>(xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, ex, ey, ez, bx, by, bz,
+                             E[0].stag, E[1].stag, E[2].stag, B[0].stag, B[1].stag, B[2].stag,
+                             g->dinv, g->xyzmin, g->lo);
+        doParticleMomentumPush(p->ux[ip], p->uy[ip], p->uz[ip], Exp, Eyp, Ezp, Bxp, Byp, Bzp, m, q,
+                               pusher, dt);
+        if (MOVE) {
+            UpdatePosition(xp, yp, zp, p->ux[ip], p->uy[ip], p->uz[ip], dt);
+            p->x[ip] = xp; p->y[ip] = yp; p->z[ip] = zp;
+        }
+    }
+}
+
+template <bool MOVE>
+int gather_push_dispatch(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                         const wxa_grid_geom* g, double q, double m, double dt, int order, int galerkin,
+                         int pusher) {
+    // Source/Particles/Gather/FieldGather.H:1590-1664 (runtime dispatch on nox, galerkin)
+    if (galerkin) {
+        if (order == 1) gather_push_impl<1, 1, MOVE>(p, E, B, g, q, m, dt, pusher);
+        else if (order == 2) gather_push_impl<2, 1, MOVE>(p, E, B, g, q, m, dt, pusher);
+        else if (order == 3) gather_push_impl<3, 1, MOVE>(p, E, B, g, q, m, dt, pusher);
+        else return -1;
+    } else {
+        if (order == 1) gather_push_impl<1, 0, MOVE>(p, E, B, g, q, m, dt, pusher);
+        else if (order == 2) gather_push_impl<2, 0, MOVE>(p, E, B, g, q, m, dt, pusher);
+        else if (order == 3) gather_push_impl<3, 0, MOVE>(p, E, B, g, q, m, dt, pusher);
+        else return -1;
+    }
+    return 0;
+}
+
+// Thread-private J scratch + locked accumulate, the reference's CPU tiling path
+// (Source/Particles/WarpXParticleContainer.cpp:455-470,819-826).
+struct PrivJ {
+    std::vector<double> buf[3];
+    wxa_field_view v[3];
+};
+
+template <int O>
+void deposit_range(const wxa_particle_view* p, int64_t b, int64_t e, const wxa_field_view J[3],
+                   const wxa_grid_geom* g, double q, double dt, double rel, int algo) {
+    const Arr jx(J[0]), jy(J[1]), jz(J[2]);
+    for (int64_t ip = b; ip < e; ++ip) {
+        if (algo == WXA_DEPOSIT_ESIRKEPOV)
+            doEsirkepovDepositionShapeN_one<O>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], p->ux[ip], p->uy[ip],
+                                               p->uz[ip], jx, jy, jz, dt, rel, g->dinv, g->xyzmin, g->lo, q);
+        else
+            doDepositionShapeN_one<O>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], p->ux[ip], p->uy[ip],
+                                      p->uz[ip], jx, jy, jz, J[0].stag, J[1].stag, J[2].stag, rel, g->dinv,
+                                      g->xyzmin, g->lo, q);
+    }
+}
+
+template <int O>
+void deposit_impl(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* g, double q,
+                  double dt, double rel, int algo) {
+    const int nt = max_threads();
+    if (nt <= 1 || p->np < 4096) {
+        deposit_range<O>(p, 0, p->np, J, g, q, dt, rel, algo);
+        return;
+    }
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int t = 0, T = 1;
+#endif
+        PrivJ pj;
+        for (int c = 0; c < 3; ++c) {
+            pj.v[c] = J[c];
+            pj.buf[c].assign((size_t)J[c].kstride * J[c].n[2], 0.0);
+            pj.v[c].p = pj.buf[c].data();
+        }
+        const int64_t b = p->np * t / T, e = p->np * (t + 1) / T;
+        deposit_range<O>(p, b, e, pj.v, g, q, dt, rel, algo);
+#pragma omp critical
+        {
+            for (int c = 0; c < 3; ++c) {
+                const size_t n = pj.buf[c].size();
+                double* dst = J[c].p;
+                const double* src = pj.buf[c].data();
+                for (size_t i = 0; i < n; ++i) dst[i] += src[i];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Source/Particles/PhysicalParticleContainer.cpp:2549-2786 (PushPX), kernel :2687-2785
+int orc_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                    const wxa_grid_geom* g, double q, double m, double dt, int order, int galerkin,
+                    int pusher, void*) {
+    return gather_push_dispatch<true>(p, E, B, g, q, m, dt, order, galerkin, pusher);
+}
+
+// Source/Particles/PhysicalParticleContainer.cpp:2368-2516 (PushP), kernel :2454-2511
+int orc_push_p(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+               const wxa_grid_geom* g, double q, double m, double dt, int order, int galerkin, int pusher,
+               void*) {
+    return gather_push_dispatch<false>(p, E, B, g, q, m, dt, order, galerkin, pusher);
+}
+
+// Source/Particles/WarpXParticleContainer.cpp:352-827 (DepositCurrent dispatch :481-816)
+int orc_deposit_current(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* g,
+                        double q, double dt, double relative_time, int order, int algo, void*, void*) {
+    if (order == 1) deposit_impl<1>(p, J, g, q, dt, relative_time, algo);
+    else if (order == 2) deposit_impl<2>(p, J, g, q, dt, relative_time, algo);
+    else if (order == 3) deposit_impl<3>(p, J, g, q, dt, relative_time, algo);
+    else return -1;
+    return 0;
+}
+
+int orc_deposit_charge(const wxa_particle_view* p, const wxa_field_view* rho, const wxa_grid_geom* g,
+                       double q, int order, void*) {
+    const Arr r(*rho);
+    for (int64_t ip = 0; ip < p->np; ++ip) {
+        if (order == 1) doChargeDepositionShapeN_one<1>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], r, rho->stag, g->dinv, g->xyzmin, g->lo, q);
+        else if (order == 2) doChargeDepositionShapeN_one<2>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], r, rho->stag, g->dinv, g->xyzmin, g->lo, q);
+        else if (order == 3) doChargeDepositionShapeN_one<3>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], r, rho->stag, g->dinv, g->xyzmin, g->lo, q);
+        else return -1;
+    }
+    return 0;
+}
+
+// Periodic wrap applied by amrex ParticleContainer::Redistribute (AMReX not in tree;
+// restated contract: positions end up in [plo, phi]).
+int orc_enforce_periodic(const wxa_particle_view* p, const double plo[3], const double phi[3],
+                         const int periodic[3], void*) {
+    double* pos[3] = {p->x, p->y, p->z};
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d]) continue;
+        const double L = phi[d] - plo[d];
+        double* a = pos[d];
+#pragma omp parallel for
+        for (int64_t ip = 0; ip < p->np; ++ip) {
+            double v = a[ip];
+            if (v >= phi[d]) {
+                v -= L;
+                if (v < plo[d]) v = plo[d];
+            } else if (v < plo[d]) {
+                v += L;
+                if (v >= phi[d]) v = std::nextafter(phi[d], plo[d]);
+            }
+            a[ip] = v;
+        }
+    }
+    return 0;
+}
+
+// Source/Filter/BilinearFilter.cpp:26-94 (npass = 1 -> stencil {0.5*0.5, 0.25}) and
+// Source/Filter/Filter.cpp:92-133 (8 mirrored taps, zero padding outside the array).
+int orc_filter_bilinear(const wxa_field_view* src, const wxa_field_view* dst, void*) {
+    const Arr s(*src), d(*dst);
+    // compute_stencil(npass=1): old_s = {1,0} -> new_s[0] = 0.5, new_s[1] = 0.25; old_s[0] *= 0.5
+    const double st[2] = {0.25, 0.25};
+    const int lo0 = src->lo[0], lo1 = src->lo[1], lo2 = src->lo[2];
+    const int hi0 = lo0 + src->n[0], hi1 = lo1 + src->n[1], hi2 = lo2 + src->n[2];
+    auto zp = [&](int i, int j, int k) -> double {
+        return (i >= lo0 && i < hi0 && j >= lo1 && j < hi1 && k >= lo2 && k < hi2) ? s(i, j, k) : 0.0;
+    };
+#pragma omp parallel for collapse(2)
+    for (int k = lo2; k < hi2; ++k)
+        for (int j = lo1; j < hi1; ++j)
+            for (int i = lo0; i < hi0; ++i) {
+                double acc = 0.0;
+                for (int i2 = 0; i2 < 2; ++i2)
+                    for (int i1 = 0; i1 < 2; ++i1)
+                        for (int i0 = 0; i0 < 2; ++i0) {
+                            const double sss = st[i0] * st[i1] * st[i2];
+                            acc += sss * (zp(i - i0, j - i1, k - i2) + zp(i + i0, j - i1, k - i2) +
+                                          zp(i - i0, j + i1, k - i2) + zp(i + i0, j + i1, k - i2) +
+                                          zp(i - i0, j - i1, k + i2) + zp(i + i0, j - i1, k + i2) +
+                                          zp(i - i0, j + i1, k + i2) + zp(i + i0, j + i1, k + i2));
+                        }
+                d(i, j, k) = acc;
+            }
+    return 0;
+}
+
+// amrex FabArray::FillBoundary(ng, periodicity) on a single periodic brick
+// (contract: SURVEY.md Appendix B; call sites Source/ablastr/utils/Communication.cpp:108-113).
+// Direction by direction so that edges/corners are filled from already-filled lines.
+int orc_fill_boundary_periodic(const wxa_field_view* f, const int ng[3], const int periodic[3], void*) {
+    const Arr a(*f);
+    int lo[3], hi[3];  // region already consistent: starts as the valid box
+    for (int d = 0; d < 3; ++d) { lo[d] = vlo(*f, d); hi[d] = vhi(*f, d); }
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d] || ng[d] <= 0) continue;
+        const int nc = ncell_of(*f, d);
+        const int v0 = vlo(*f, d), v1 = vhi(*f, d);
+        int rl[3] = {lo[0], lo[1], lo[2]}, rh[3] = {hi[0], hi[1], hi[2]};
+        for (int side = 0; side < 2; ++side) {
+            for (int gi = 1; gi <= ng[d]; ++gi) {
+                const int dsti = side == 0 ? v0 - gi : v1 - 1 + gi;
+                const int srci = side == 0 ? dsti + nc : dsti - nc;
+                rl[d] = dsti; rh[d] = dsti + 1;
+                for (int k = rl[2]; k < rh[2]; ++k)
+                    for (int j = rl[1]; j < rh[1]; ++j)
+                        for (int i = rl[0]; i < rh[0]; ++i) {
+                            int s[3] = {i, j, k};
+                            s[d] = srci;
+                            a(i, j, k) = a(s[0], s[1], s[2]);
+                        }
+            }
+        }
+        lo[d] = v0 - ng[d]; hi[d] = v1 + ng[d];
+    }
+    return 0;
+}
+
+// FillBoundaryAndSync's extra step (Communication.cpp:99-101,109-110): shared nodal
+// points take their owner's value; on a single periodic brick the high-edge nodal
+// point duplicates the low-edge one.
+int orc_sync_nodal_periodic(const wxa_field_view* f, const int periodic[3], void*) {
+    const Arr a(*f);
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d] || !f->stag[d]) continue;
+        const int nc = ncell_of(*f, d);
+        int rl[3], rh[3];
+        for (int e = 0; e < 3; ++e) { rl[e] = vlo(*f, e); rh[e] = vhi(*f, e); }
+        rl[d] = vlo(*f, d) + nc; rh[d] = rl[d] + 1;
+        for (int k = rl[2]; k < rh[2]; ++k)
+            for (int j = rl[1]; j < rh[1]; ++j)
+                for (int i = rl[0]; i < rh[0]; ++i) {
+                    int s[3] = {i, j, k};
+                    s[d] -= nc;
+                    a(i, j, k) = a(s[0], s[1], s[2]);
+                }
+    }
+    return 0;
+}
+
+// amrex FabArray::SumBoundary(src_ng, dst_ng = all) on a single periodic brick:
+// every point = sum over periodic images of the values in valid + src_ng guards
+// (Source/Parallelization/WarpXSumGuardCells.cpp:17-37).
+int orc_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3], const int periodic[3], void*) {
+    const Arr a(*f);
+    std::vector<double> line;
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d]) continue;
+        const int nc = ncell_of(*f, d);
+        const int a0 = f->lo[d], a1 = f->lo[d] + f->n[d];
+        const int s0 = vlo(*f, d) - src_ng[d], s1 = vhi(*f, d) + src_ng[d];
+        const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+        line.resize(f->n[d]);
+        for (int u = f->lo[d2]; u < f->lo[d2] + f->n[d2]; ++u)
+            for (int v = f->lo[d1]; v < f->lo[d1] + f->n[d1]; ++v) {
+                int idx[3];
+                idx[d1] = v; idx[d2] = u;
+                for (int t = a0; t < a1; ++t) { idx[d] = t; line[t - a0] = a(idx[0], idx[1], idx[2]); }
+                for (int t = a0; t < a1; ++t) {
+                    double sum = 0.0;
+                    // images t + m*nc inside the source range, ascending
+                    const int first = s0 + (((t - s0) % nc) + nc) % nc;
+                    for (int s = first; s < s1; s += nc) sum += line[s - a0];
+                    idx[d] = t;
+                    a(idx[0], idx[1], idx[2]) = sum;
+                }
+            }
+    }
+    return 0;
+}
+
+int orc_field_set_zero(const wxa_field_view* f, void*) {
+    std::memset(f->p, 0, sizeof(double) * (size_t)f->kstride * f->n[2]);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Diagnostics that define the parity metric.
+
+// MultiFab::norm2(0, periodicity)^2: sum of squares over unique points
+// (Source/Diagnostics/ReducedDiags/FieldEnergy.cpp:121-129): nodal duplicates on
+// the high periodic edge are counted once.
+double orc_sum_sq_unique(const wxa_field_view* f) {
+    const Arr a(*f);
+    long double s = 0.0L;
+    int hi[3];
+    for (int d = 0; d < 3; ++d) hi[d] = vlo(*f, d) + ncell_of(*f, d);
+    for (int k = vlo(*f, 2); k < hi[2]; ++k)
+        for (int j = vlo(*f, 1); j < hi[1]; ++j)
+            for (int i = vlo(*f, 0); i < hi[0]; ++i) s += (long double)a(i, j, k) * a(i, j, k);
+    return (double)s;
+}
+
+// FieldEnergy.cpp:146-151: out[0] = total, out[1] = E part, out[2] = B part
+void orc_field_energy(const wxa_field_view E[3], const wxa_field_view B[3], const double dx[3],
+                      double out[3]) {
+    const double dV = dx[0] * dx[1] * dx[2];
+    const double Es = orc_sum_sq_unique(&E[0]) + orc_sum_sq_unique(&E[1]) + orc_sum_sq_unique(&E[2]);
+    const double Bs = orc_sum_sq_unique(&B[0]) + orc_sum_sq_unique(&B[1]) + orc_sum_sq_unique(&B[2]);
+    out[1] = 0.5 * Es * PhysConst::ep0 * dV;
+    out[2] = 0.5 * Bs / PhysConst::mu0 * dV;
+    out[0] = out[1] + out[2];
+}
+
+// Source/Diagnostics/ReducedDiags/ParticleEnergy.cpp:95-200 with
+// Source/Particles/Algorithms/KineticEnergy.H:31-45: sum_p w * m u^2 / (1 + gamma)
+double orc_particle_energy(const wxa_particle_view* p, double mass) {
+    constexpr double inv_c2 = 1.0 / (PhysConst::c * PhysConst::c);
+    long double s = 0.0L;
+    for (int64_t i = 0; i < p->np; ++i) {
+        const double u2 = p->ux[i] * p->ux[i] + p->uy[i] * p->uy[i] + p->uz[i] * p->uz[i];
+        const double gamma = std::sqrt(1.0 + u2 * inv_c2);
+        s += (long double)p->w[i] * (1.0 / (1.0 + gamma) * mass * u2);
+    }
+    return (double)s;
+}
+
+// Source/Diagnostics/ReducedDiags/ParticleMomentum.cpp: sum_p w * m * u
+void orc_particle_momentum(const wxa_particle_view* p, double mass, double out[3]) {
+    long double s[3] = {0, 0, 0};
+    for (int64_t i = 0; i < p->np; ++i) {
+        s[0] += (long double)p->w[i] * mass * p->ux[i];
+        s[1] += (long double)p->w[i] * mass * p->uy[i];
+        s[2] += (long double)p->w[i] * mass * p->uz[i];
+    }
+    out[0] = (double)s[0]; out[1] = (double)s[1]; out[2] = (double)s[2];
+}
+
+// Plotfile/checksum view: each field interpolated to cell centres
+// (Source/Diagnostics/ComputeDiagFunctors/CellCenterFunctor.cpp:20-29 ->
+// Source/ablastr/coarsen/sample.H:30-95 with cr = 1, sc = cell), then sum |Q| over the
+// covering grid (Regression/Checksum/checksum.py:62-217).
+double orc_cell_centered_abs_sum(const wxa_field_view* f) {
+    const Arr a(*f);
+    int np[3];
+    for (int l = 0; l < 3; ++l) np[l] = 1 + std::abs(f->stag[l] - 0);
+    const double wx = 1.0 / np[0], wy = 1.0 / np[1], wz = 1.0 / np[2];
+    long double s = 0.0L;
+    const int i0 = vlo(*f, 0), j0 = vlo(*f, 1), k0 = vlo(*f, 2);
+    for (int k = k0; k < k0 + ncell_of(*f, 2); ++k)
+        for (int j = j0; j < j0 + ncell_of(*f, 1); ++j)
+            for (int i = i0; i < i0 + ncell_of(*f, 0); ++i) {
+                double c = 0.0;  // idx_min = ic - sc*(1-sf) = ic for sc = 0
+                for (int kr = 0; kr < np[2]; ++kr)
+                    for (int jr = 0; jr < np[1]; ++jr)
+                        for (int ir = 0; ir < np[0]; ++ir) c += wx * wy * wz * a(i + ir, j + jr, k + kr);
+                s += std::fabs(c);
+            }
+    return (double)s;
+}
+
+double orc_abs_sum(const double* v, int64_t n, double scale) {
+    long double s = 0.0L;
+    for (int64_t i = 0; i < n; ++i) s += std::fabs(v[i] * scale);
+    return (double)s;
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// Step-level oracle: single brick, fully periodic.
+// ===========================================================================
+namespace {
+
+struct Field {
+    std::vector<double> data;
+    wxa_field_view v{};
+    void alloc(const int ncell[3], const int stag[3], const int ng[3]) {
+        for (int d = 0; d < 3; ++d) {
+            v.lo[d] = -ng[d]; v.ng[d] = ng[d]; v.stag[d] = stag[d];
+            v.n[d] = ncell[d] + stag[d] + 2 * ng[d];
+        }
+        v.jstride = v.n[0];
+        v.kstride = v.jstride * v.n[1];
+        data.assign((size_t)v.kstride * v.n[2], 0.0);
+        v.p = data.data();
+    }
+};
+
+struct Species {
+    double q, m;
+    std::vector<double> a[7];
+    std::vector<uint64_t> id;
+    wxa_particle_view view() {
+        wxa_particle_view p{};
+        p.x = a[0].data(); p.y = a[1].data(); p.z = a[2].data(); p.w = a[3].data();
+        p.ux = a[4].data(); p.uy = a[5].data(); p.uz = a[6].data();
+        p.idcpu = id.empty() ? nullptr : id.data();
+        p.np = (int64_t)a[0].size();
+        return p;
+    }
+};
+
+}  // namespace
+
+struct orc_sim {
+    wxa_sim_config cfg;
+    double dx[3], dinv[3], dt;
+    int ng_EB[3], ng_J[3], ng_depos_J[3], ng_gather[3], ng_solver[3], ng_rho[3];
+    Field E[3], B[3], J[3], Jtmp, rho;
+    std::vector<std::unique_ptr<Species>> species;
+    bool is_synchronized = true;
+    int64_t istep = 0;
+    double cur_time = 0.0;
+    double timers[8] = {0};
+    int64_t counts[8] = {0};
+    bool do_timers = false;
+
+    wxa_field_view Ev[3], Bv[3], Jv[3];
+    int periodic[3] = {1, 1, 1};
+
+    wxa_grid_geom geom_for(const int ng[3]) const {
+        // WarpX::LowerCorner(box.grow(ng)) = prob_lo + box.lo * dx (Source/WarpX.cpp:2851-2875)
+        wxa_grid_geom g{};
+        for (int d = 0; d < 3; ++d) {
+            g.lo[d] = -ng[d];
+            g.xyzmin[d] = cfg.prob_lo[d] + (double)(-ng[d]) * dx[d];
+            g.dinv[d] = dinv[d];
+        }
+        return g;
+    }
+};
+
+namespace {
+
+double now_ms() {
+#ifdef _OPENMP
+    return omp_get_wtime() * 1e3;
+#else
+    return 0.0;
+#endif
+}
+struct Tic {
+    orc_sim* s; int id; double t0;
+    Tic(orc_sim* s_, int id_) : s(s_), id(id_), t0(s_->do_timers ? now_ms() : 0.0) {}
+    ~Tic() { if (s->do_timers) { s->timers[id] += now_ms() - t0; s->counts[id]++; } }
+};
+
+void fill_boundary_EB(orc_sim* s, wxa_field_view* F, const int ng[3], bool sync) {
+    Tic t(s, 5);
+    for (int c = 0; c < 3; ++c) {
+        if (sync) orc_sync_nodal_periodic(&F[c], s->periodic, nullptr);
+        orc_fill_boundary_periodic(&F[c], ng, s->periodic, nullptr);
+    }
+}
+
+// Source/Particles/MultiParticleContainer.cpp:492-500 -> PhysicalParticleContainer::PushP
+void push_p_all(orc_sim* s, double dt) {
+    Tic t(s, 0);
+    const wxa_grid_geom g = s->geom_for(s->ng_EB);
+    for (auto& sp : s->species) {
+        wxa_particle_view p = sp->view();
+        orc_push_p(&p, s->Ev, s->Bv, &g, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
+                   s->cfg.particle_pusher, nullptr);
+    }
+}
+
+// WarpX::OneStep_nosub (Source/Evolve/WarpXEvolve.cpp:354-455), FDTD branch
+void one_step_nosub(orc_sim* s) {
+    const double dt = s->dt;
+    // PushParticlesandDeposit (:1101-1180) -> MultiParticleContainer::Evolve (:460-482)
+    for (int c = 0; c < 3; ++c) orc_field_set_zero(&s->Jv[c], nullptr);
+    const wxa_grid_geom gEB = s->geom_for(s->ng_EB);
+    const wxa_grid_geom gJ = s->geom_for(s->ng_depos_J);
+    for (auto& sp : s->species) {
+        wxa_particle_view p = sp->view();
+        {   // PhysicalParticleContainer::Evolve :1961 PushPX
+            Tic t(s, 0);
+            orc_gather_push(&p, s->Ev, s->Bv, &gEB, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
+                            s->cfg.particle_pusher, nullptr);
+        }
+        {   // :2029-2038 DepositCurrent with relative_time = -0.5*dt
+            Tic t(s, 1);
+            orc_deposit_current(&p, s->Jv, &gJ, sp->q, dt, -0.5 * dt, s->cfg.nox, s->cfg.current_deposition,
+                                nullptr, nullptr);
+        }
+    }
+    {   // SyncCurrentAndRho (:583-652) -> SyncCurrent (WarpXComm.cpp:1073-1240)
+        Tic t(s, 2);
+        for (int c = 0; c < 3; ++c) {
+            int src_ng[3];
+            if (s->cfg.use_filter) {
+                // ApplyFilterJ (WarpXComm.cpp:1357-1374): filter into a temp, copy back
+                s->Jtmp.v = s->Jv[c];
+                s->Jtmp.data.assign(s->J[c].data.size(), 0.0);
+                s->Jtmp.v.p = s->Jtmp.data.data();
+                orc_filter_bilinear(&s->Jv[c], &s->Jtmp.v, nullptr);
+                std::memcpy(s->Jv[c].p, s->Jtmp.v.p, sizeof(double) * s->J[c].data.size());
+            }
+            // SumBoundaryJ (WarpXComm.cpp:1386-1424): ng_depos_J (+ stencil_length-1 if filtered), capped
+            for (int d = 0; d < 3; ++d)
+                src_ng[d] = std::min(s->ng_depos_J[d] + (s->cfg.use_filter ? 1 : 0), s->ng_J[d]);
+            orc_sum_boundary_periodic(&s->Jv[c], src_ng, s->periodic, nullptr);
+        }
+    }
+    { Tic t(s, 3); orc_evolve_b(s->Ev, s->Bv, 0.5 * dt, s->dinv, nullptr); }   // :421
+    fill_boundary_EB(s, s->Bv, s->ng_solver, true);                             // :422
+    { Tic t(s, 4); orc_evolve_e(s->Ev, s->Bv, s->Jv, dt, s->dinv, nullptr); }   // :426
+    fill_boundary_EB(s, s->Ev, s->ng_solver, true);                             // :433
+    { Tic t(s, 3); orc_evolve_b(s->Ev, s->Bv, 0.5 * dt, s->dinv, nullptr); }   // :437
+    // (:441-449 FillBoundaryB(ng_alloc_EB) only when safe_guard_cells or PML; skipped)
+}
+
+}  // namespace
+
+extern "C" {
+
+int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** out) {
+    if (!cfg || !out) return -1;
+    if (cfg->nox < 1 || cfg->nox > 3) return -1;
+    if (cfg->nbricks[0] * cfg->nbricks[1] * cfg->nbricks[2] != 1) return -3;
+    auto* s = new orc_sim();
+    s->cfg = *cfg;
+    for (int d = 0; d < 3; ++d) {
+        s->dx[d] = (cfg->prob_hi[d] - cfg->prob_lo[d]) / cfg->n_cell[d];
+        s->dinv[d] = 1.0 / s->dx[d];
+    }
+    // Source/Evolve/WarpXComputeDt.cpp:41-102 + CartesianYeeAlgorithm::ComputeMaxDt (:48-56)
+    const double* dx = s->dx;
+    const double deltat = cfg->cfl * 1.0 /
+        (std::sqrt(1.0 / (dx[0] * dx[0]) + 1.0 / (dx[1] * dx[1]) + 1.0 / (dx[2] * dx[2])) * PhysConst::c);
+    s->dt = deltat;
+    // Source/Parallelization/GuardCellManager.cpp:62-172,276-278,314-316
+    const int nox = cfg->nox;
+    for (int d = 0; d < 3; ++d) {
+        const int ngt = nox;
+        s->ng_EB[d] = (ngt % 2) ? ngt + 1 : ngt;
+        int ngJ = ngt;
+        ngJ += (int)std::ceil(PhysConst::c * 0.5 * s->dt / dx[d]);
+        s->ng_depos_J[d] = ngJ;
+        s->ng_J[d] = ngJ + (cfg->use_filter ? 1 : 0);
+        s->ng_rho[d] = ngt + 1 + (int)std::ceil(PhysConst::c * s->dt / dx[d]);
+        s->ng_gather[d] = (nox + 1) / 2;
+        s->ng_solver[d] = 1;
+    }
+    // Yee staggering (Source/WarpX.cpp:2117-2125)
+    const int Es[3][3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
+    const int Bs[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int c = 0; c < 3; ++c) {
+        s->E[c].alloc(cfg->n_cell, Es[c], s->ng_EB);
+        s->B[c].alloc(cfg->n_cell, Bs[c], s->ng_EB);
+        s->J[c].alloc(cfg->n_cell, Es[c], s->ng_J);
+        s->Ev[c] = s->E[c].v; s->Bv[c] = s->B[c].v; s->Jv[c] = s->J[c].v;
+    }
+    const int nodal[3] = {1, 1, 1};
+    s->rho.alloc(cfg->n_cell, nodal, s->ng_rho);
+    *out = s;
+    return 0;
+}
+
+void orc_sim_destroy(orc_sim* s) { delete s; }
+
+int orc_sim_add_species(orc_sim* s, double charge, double mass, const wxa_particle_view* init, int32_t* id) {
+    auto sp = std::make_unique<Species>();
+    sp->q = charge; sp->m = mass;
+    const double* src[7] = {init->x, init->y, init->z, init->w, init->ux, init->uy, init->uz};
+    for (int c = 0; c < 7; ++c) sp->a[c].assign(src[c], src[c] + init->np);
+    if (init->idcpu) sp->id.assign(init->idcpu, init->idcpu + init->np);
+    if (id) *id = (int32_t)s->species.size();
+    s->species.push_back(std::move(sp));
+    return 0;
+}
+
+// WarpX::Evolve (Source/Evolve/WarpXEvolve.cpp:94-347)
+int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
+    for (int32_t step = 0; step < numsteps; ++step) {
+        // ExplicitFillBoundaryEBUpdateAux (:473-531)
+        if (s->is_synchronized) {
+            fill_boundary_EB(s, s->Ev, s->ng_EB, false);
+            fill_boundary_EB(s, s->Bv, s->ng_EB, false);
+            push_p_all(s, -0.5 * s->dt);
+            s->is_synchronized = false;
+        } else {
+            fill_boundary_EB(s, s->Ev, s->ng_gather, false);
+            fill_boundary_EB(s, s->Bv, s->ng_gather, false);
+        }
+        one_step_nosub(s);
+        if (step == numsteps - 1) {
+            // Synchronize (:65-93)
+            fill_boundary_EB(s, s->Ev, s->ng_gather, false);
+            fill_boundary_EB(s, s->Bv, s->ng_gather, false);
+            push_p_all(s, 0.5 * s->dt);
+            s->is_synchronized = true;
+        }
+        s->istep++;
+        s->cur_time += s->dt;
+        {   // HandleParticlesAtBoundaries (:533-581): periodic wrap in Redistribute
+            Tic t(s, 6);
+            for (auto& sp : s->species) {
+                wxa_particle_view p = sp->view();
+                orc_enforce_periodic(&p, s->cfg.prob_lo, s->cfg.prob_hi, s->periodic, nullptr);
+            }
+        }
+    }
+    return 0;
+}
+
+double orc_sim_dt(const orc_sim* s) { return s->dt; }
+int64_t orc_sim_istep(const orc_sim* s) { return s->istep; }
+
+int orc_sim_get_field(orc_sim* s, const char* name, wxa_field_view* out) {
+    const std::string n(name);
+    const char* comps = "xyz";
+    for (int c = 0; c < 3; ++c) {
+        if (n == std::string("E") + comps[c]) { *out = s->Ev[c]; return 0; }
+        if (n == std::string("B") + comps[c]) { *out = s->Bv[c]; return 0; }
+        if (n == std::string("j") + comps[c]) { *out = s->Jv[c]; return 0; }
+    }
+    if (n == "rho") { *out = s->rho.v; return 0; }
+    return -1;
+}
+
+int orc_sim_get_particles(orc_sim* s, int32_t id, wxa_particle_view* out) {
+    if (id < 0 || id >= (int32_t)s->species.size()) return -1;
+    *out = s->species[id]->view();
+    return 0;
+}
+
+// RhoFunctor (Source/Diagnostics/ComputeDiagFunctors/RhoFunctor.cpp:42-61):
+// GetChargeDensity (all species) + ApplyFilterandSumBoundaryRho
+int orc_sim_compute_rho(orc_sim* s) {
+    orc_field_set_zero(&s->rho.v, nullptr);
+    const wxa_grid_geom g = s->geom_for(s->ng_rho);
+    for (auto& sp : s->species) {
+        wxa_particle_view p = sp->view();
+        orc_deposit_charge(&p, &s->rho.v, &g, sp->q, s->cfg.nox, nullptr);
+    }
+    if (s->cfg.use_filter) {
+        Field tmp; tmp.v = s->rho.v; tmp.data.assign(s->rho.data.size(), 0.0); tmp.v.p = tmp.data.data();
+        orc_filter_bilinear(&s->rho.v, &tmp.v, nullptr);
+        s->rho.data = tmp.data; s->rho.v.p = s->rho.data.data();
+    }
+    orc_sum_boundary_periodic(&s->rho.v, s->ng_rho, s->periodic, nullptr);
+    return 0;
+}
+
+int orc_sim_get_timers(orc_sim* s, double ms[8], int64_t counts[8], int reset) {
+    for (int i = 0; i < 8; ++i) { ms[i] = s->timers[i]; counts[i] = s->counts[i]; }
+    if (reset) for (int i = 0; i < 8; ++i) { s->timers[i] = 0; s->counts[i] = 0; }
+    return 0;
+}
+int orc_sim_enable_timers(orc_sim* s, int e) { s->do_timers = e != 0; return 0; }
+
+}  // extern "C"

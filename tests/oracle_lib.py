@@ -1,0 +1,31 @@
+"""Loads oracle/liboracle.so (building it with the committed Makefile when absent).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this."""
+import os
+import subprocess
+
+from warpx_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+_oracle = None
+
+
+def build_oracle(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("pic_oracle.cpp", "pic_kernels.hpp")]
+    srcs.append(os.path.join(ROOT, "include", "warpx_amd.h"))
+    stale = (not os.path.exists(ORACLE_LIB)) or any(
+        os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return ORACLE_LIB
+
+
+def load_oracle():
+    global _oracle
+    if _oracle is None:
+        build_oracle()
+        _oracle = _capi.CLib(ORACLE_LIB, "orc_", _capi._ORACLE_SIGS)
+    return _oracle

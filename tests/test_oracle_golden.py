@@ -1,0 +1,111 @@
+"""Pins the CPU oracle against the reference's own golden vectors for this path
+(SURVEY.md 8(c)): the 3-D Langmuir multi-species checksum benchmark and the analytic
+Langmuir field test.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from warpx_amd import _capi, plasma
+from warpx_amd.containers import view_to_numpy
+from warpx_amd.sim import WarpXSim, field_energy, particle_moments
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def langmuir_run(oracle):
+    """Examples/Tests/langmuir/inputs_base_3d run for max_step = 40 on the oracle."""
+    n_cell = (64, 64, 64)
+    el, lo, hi = plasma.langmuir_3d(n_cell, sign=+1.0)
+    po, _, _ = plasma.langmuir_3d(n_cell, sign=-1.0)
+    sim = WarpXSim(oracle, n_cell, lo, hi, nox=1, galerkin=1,
+                   particle_pusher=_capi.PUSHER_BORIS,
+                   current_deposition=_capi.DEPOSIT_ESIRKEPOV, use_filter=0, cfl=1.0)
+    e = sim.add_species(-plasma.Q_E, plasma.M_E, el)
+    p = sim.add_species(+plasma.Q_E, plasma.M_E, po)
+    sim.evolve(40)
+    return sim, e, p
+
+
+def _cc_abs_sum(oracle, sim, name):
+    import ctypes as C
+    v = sim.field_view(name)
+    return oracle.cell_centered_abs_sum(C.byref(v))
+
+
+def test_dt_matches_reference_script(langmuir_run):
+    # Examples/Tests/langmuir/analysis_3d.py:205 quotes dt = 1.203645751e-15
+    sim, _, _ = langmuir_run
+    assert abs(sim.dt - 1.203645751e-15) / 1.203645751e-15 < 1e-9
+
+
+def test_golden_checksums(oracle, langmuir_run):
+    sim, e, p = langmuir_run
+    gold = json.load(open(os.path.join(HERE, "golden", "langmuir_multi_3d_checksums.json")))
+    rtol = gold["rtol"]
+    ref = gold["checksums"]
+    got = {}
+    for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz"):
+        got[name] = _cc_abs_sum(oracle, sim, name)
+    oracle.sim_compute_rho(sim._h)
+    got["rho"] = _cc_abs_sum(oracle, sim, "rho")
+    report = []
+    for name, val in got.items():
+        want = ref["lev=0"][name]
+        report.append((name, val, want, abs(val - want) / abs(want)))
+    me = particle_moments(sim, e)
+    mp = particle_moments(sim, p)
+    pe, pp = ref["electrons"], ref["positrons"]
+    report += [
+        ("e.px", me["abs_momentum"][0], pe["particle_momentum_x"], None),
+        ("e.x", me["abs_position"][0], pe["particle_position_x"], None),
+        ("e.y", me["abs_position"][1], pe["particle_position_y"], None),
+        ("e.z", me["abs_position"][2], pe["particle_position_z"], None),
+        ("e.w", me["weight"], pe["particle_weight"], None),
+        ("p.pz", mp["abs_momentum"][2], pp["particle_momentum_z"], None),
+        ("p.x", mp["abs_position"][0], pp["particle_position_x"], None),
+        ("p.y", mp["abs_position"][1], pp["particle_position_y"], None),
+        ("p.z", mp["abs_position"][2], pp["particle_position_z"], None),
+    ]
+    bad = []
+    for name, val, want, _ in report:
+        err = abs(val - want) / abs(want)
+        print(f"{name:6s} got {val:.16e} want {want:.16e} rel {err:.2e}")
+        if not np.isclose(val, want, rtol=rtol, atol=1e-40):
+            bad.append((name, val, want, err))
+    assert not bad, bad
+    assert ref["lev=0"]["part_per_cell"] == 2 * 64 ** 3
+
+
+def test_langmuir_analytic_field(langmuir_run):
+    # Examples/Tests/langmuir/analysis_3d.py:124-131,159-164: max-norm relative error < 5 %
+    sim, _, _ = langmuir_run
+    t = 40 * sim.dt
+    n_cell = (64, 64, 64)
+    Eth = plasma.langmuir_analytic_E(n_cell, 40e-6, 2e24, 0.01, t)
+    worst = 0.0
+    for name, th in zip(("Ex", "Ey", "Ez"), Eth):
+        v = sim.field_view(name)
+        a = view_to_numpy(v)
+        g = v.ng
+        a = a[g[0]: v.n[0] - g[0], g[1]: v.n[1] - g[1], g[2]: v.n[2] - g[2]]
+        # cell-centre (average the nodal directions), as the plotfile writer does
+        for d in range(3):
+            if v.stag[d]:
+                sl0 = [slice(None)] * 3
+                sl1 = [slice(None)] * 3
+                sl0[d] = slice(0, -1)
+                sl1[d] = slice(1, None)
+                a = 0.5 * (a[tuple(sl0)] + a[tuple(sl1)])
+        worst = max(worst, np.max(np.abs(a - th)) / np.max(np.abs(th)))
+    print("langmuir max-norm rel error", worst)
+    assert worst < 5e-2
+
+
+def test_energy_is_sane(langmuir_run):
+    sim, e, p = langmuir_run
+    ee, eb = field_energy(sim)
+    ke = particle_moments(sim, e)["ekin"] + particle_moments(sim, p)["ekin"]
+    assert ee > 0 and eb >= 0 and ke > 0

@@ -1,0 +1,215 @@
+"""ctypes binding of the C-ABI declared in include/warpx_amd.h.
+
+The binder is generic over (shared library, symbol prefix) so the test-suite can
+bind the CPU oracle (`orc_*`, oracle/liboracle.so) with the very same
+signatures; the product only ever loads `libwarpx_amd.so` (`wxa_*`) and raises
+if it is missing -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_HERE, "libwarpx_amd.so")
+
+
+class FieldView(C.Structure):
+    _fields_ = [
+        ("p", C.c_void_p),
+        ("lo", C.c_int32 * 3),
+        ("n", C.c_int32 * 3),
+        ("ng", C.c_int32 * 3),
+        ("stag", C.c_int32 * 3),
+        ("jstride", C.c_int64),
+        ("kstride", C.c_int64),
+    ]
+
+
+class ParticleView(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("w", C.c_void_p),
+        ("ux", C.c_void_p), ("uy", C.c_void_p), ("uz", C.c_void_p),
+        ("idcpu", C.c_void_p),
+        ("np", C.c_int64),
+    ]
+
+
+class GridGeom(C.Structure):
+    _fields_ = [
+        ("xyzmin", C.c_double * 3),
+        ("dinv", C.c_double * 3),
+        ("lo", C.c_int32 * 3),
+    ]
+
+
+class SimConfig(C.Structure):
+    _fields_ = [
+        ("n_cell", C.c_int32 * 3),
+        ("prob_lo", C.c_double * 3),
+        ("prob_hi", C.c_double * 3),
+        ("cfl", C.c_double),
+        ("nox", C.c_int32),
+        ("galerkin", C.c_int32),
+        ("particle_pusher", C.c_int32),
+        ("current_deposition", C.c_int32),
+        ("use_filter", C.c_int32),
+        ("sort_interval", C.c_int32),
+        ("nbricks", C.c_int32 * 3),
+        ("coord", C.c_int32 * 3),
+    ]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(
+    C.c_int, C.c_void_p, C.c_int,
+    C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+    C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+    C.c_void_p)
+EXCHANGE_COUNTS_FN = C.CFUNCTYPE(
+    C.c_int, C.c_void_p, C.c_int,
+    C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+    C.POINTER(C.c_int32), C.POINTER(C.c_int64))
+
+
+class Comm(C.Structure):
+    _fields_ = [
+        ("ctx", C.c_void_p),
+        ("rank", C.c_int32),
+        ("nranks", C.c_int32),
+        ("exchange", EXCHANGE_FN),
+        ("exchange_counts", EXCHANGE_COUNTS_FN),
+    ]
+
+
+PUSHER_BORIS, PUSHER_VAY = 0, 1
+DEPOSIT_ESIRKEPOV, DEPOSIT_DIRECT = 0, 1
+
+_FV3 = FieldView * 3
+_D3 = C.c_double * 3
+_I3 = C.c_int * 3
+_I32_3 = C.c_int32 * 3
+_PFV = C.POINTER(FieldView)
+_PPV = C.POINTER(ParticleView)
+_PGG = C.POINTER(GridGeom)
+
+# name -> (restype, argtypes); shared by the product (wxa_) and the oracle (orc_)
+_KERNEL_SIGS = {
+    "evolve_b": (C.c_int, [_FV3, _FV3, C.c_double, _D3, C.c_void_p]),
+    "evolve_e": (C.c_int, [_FV3, _FV3, _FV3, C.c_double, _D3, C.c_void_p]),
+    "gather_push": (C.c_int, [_PPV, _FV3, _FV3, _PGG, C.c_double, C.c_double, C.c_double,
+                              C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "push_p": (C.c_int, [_PPV, _FV3, _FV3, _PGG, C.c_double, C.c_double, C.c_double,
+                         C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "deposit_current": (C.c_int, [_PPV, _FV3, _PGG, C.c_double, C.c_double, C.c_double,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "deposit_charge": (C.c_int, [_PPV, _PFV, _PGG, C.c_double, C.c_int, C.c_void_p]),
+    "enforce_periodic": (C.c_int, [_PPV, _D3, _D3, _I3, C.c_void_p]),
+    "filter_bilinear": (C.c_int, [_PFV, _PFV, C.c_void_p]),
+    "fill_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
+    "sum_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
+    "field_set_zero": (C.c_int, [_PFV, C.c_void_p]),
+    "version": (C.c_char_p, []),
+}
+
+_SIM_SIGS = {
+    "sim_create": (C.c_int, [C.POINTER(SimConfig), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sim_destroy": (None, [C.c_void_p]),
+    "sim_add_species": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _PPV, C.POINTER(C.c_int32)]),
+    "sim_evolve": (C.c_int, [C.c_void_p, C.c_int32]),
+    "sim_dt": (C.c_double, [C.c_void_p]),
+    "sim_istep": (C.c_int64, [C.c_void_p]),
+    "sim_get_field": (C.c_int, [C.c_void_p, C.c_char_p, _PFV]),
+    "sim_get_particles": (C.c_int, [C.c_void_p, C.c_int32, _PPV]),
+    "sim_get_timers": (C.c_int, [C.c_void_p, C.c_double * 8, C.c_int64 * 8, C.c_int]),
+    "sim_enable_timers": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+# product-only entry points
+_PRODUCT_SIGS = {
+    "workspace_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "workspace_destroy": (None, [C.c_void_p]),
+    "last_error": (C.c_char_p, []),
+    "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
+    "pack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
+    "unpack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
+    "copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "device_synchronize": (C.c_int, []),
+}
+
+# oracle-only entry points (diagnostic formulas that define the parity metric)
+_ORACLE_SIGS = {
+    "sync_nodal_periodic": (C.c_int, [_PFV, _I3, C.c_void_p]),
+    "sum_sq_unique": (C.c_double, [_PFV]),
+    "field_energy": (None, [_FV3, _FV3, _D3, C.c_double * 3]),
+    "particle_energy": (C.c_double, [_PPV, C.c_double]),
+    "particle_momentum": (None, [_PPV, C.c_double, C.c_double * 3]),
+    "cell_centered_abs_sum": (C.c_double, [_PFV]),
+    "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
+    "sim_compute_rho": (C.c_int, [C.c_void_p]),
+    "num_threads": (C.c_int, []),
+}
+
+
+class WxaError(RuntimeError):
+    pass
+
+
+class CLib:
+    """A loaded C library whose symbols `<prefix><name>` follow include/warpx_amd.h."""
+
+    def __init__(self, path: str, prefix: str, extra_sigs: dict | None = None):
+        if not os.path.exists(path):
+            raise WxaError(
+                f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()')")
+        self.path = path
+        self.prefix = prefix
+        self._dll = C.CDLL(path, mode=C.RTLD_GLOBAL if prefix == "wxa_" else C.RTLD_LOCAL)
+        sigs = dict(_KERNEL_SIGS)
+        sigs.update(_SIM_SIGS)
+        if extra_sigs:
+            sigs.update(extra_sigs)
+        self.names = []
+        for name, (res, args) in sigs.items():
+            fn = getattr(self._dll, prefix + name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_" + name, fn)
+            self.names.append(prefix + name)
+
+    def __getattr__(self, name):
+        # checked call wrappers: lib.evolve_b(...) raises on a negative status
+        raw = object.__getattribute__(self, "_" + name)
+        if raw.restype is C.c_int:
+            def checked(*a):
+                rc = raw(*a)
+                if rc != 0:
+                    msg = ""
+                    if self.prefix == "wxa_":
+                        try:
+                            msg = (self._last_error() or b"").decode()
+                        except Exception:
+                            pass
+                    raise WxaError(f"{self.prefix}{name} failed with status {rc} {msg}")
+                return rc
+            return checked
+        return raw
+
+
+_product = None
+
+
+def load_product() -> CLib:
+    """The HIP library. Fails loudly when it has not been built (no CPU fallback)."""
+    global _product
+    if _product is None:
+        _product = CLib(PRODUCT_LIB, "wxa_", _PRODUCT_SIGS)
+    return _product
+
+
+def declared_symbols(header_path: str) -> list[str]:
+    """Every `wxa_*` function name declared in include/warpx_amd.h (for the symbol-export test)."""
+    import re
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wxa_[a-z0-9_]+)\s*\(", text)))

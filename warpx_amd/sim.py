@@ -1,0 +1,158 @@
+"""Python handle on the step-level C API (`<prefix>sim_*`, include/warpx_amd.h):
+the host layer's re-statement of WarpX::Evolve / OneStep_nosub
+(Source/Evolve/WarpXEvolve.cpp:94-347,354-455).
+
+`WarpXSim(lib, ...)` works with any library that exports the step-level symbols; the
+product passes `load_product()` (HIP, device pointers).  The test-suite also binds the
+CPU oracle through the same class -- the product never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .containers import ParticleArrays, particles_to_numpy, view_to_numpy
+
+
+class WarpXSim:
+    def __init__(self, lib: _capi.CLib, n_cell, prob_lo, prob_hi, nox=1, galerkin=1,
+                 particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
+                 use_filter=0, cfl=1.0, sort_interval=-1, nbricks=(1, 1, 1), coord=(0, 0, 0),
+                 comm: _capi.Comm | None = None):
+        self.lib = lib
+        self.on_device = lib.prefix == "wxa_"
+        cfg = _capi.SimConfig()
+        for d in range(3):
+            cfg.n_cell[d] = int(n_cell[d])
+            cfg.prob_lo[d] = float(prob_lo[d])
+            cfg.prob_hi[d] = float(prob_hi[d])
+            cfg.nbricks[d] = int(nbricks[d])
+            cfg.coord[d] = int(coord[d])
+        cfg.cfl = float(cfl)
+        cfg.nox = int(nox)
+        cfg.galerkin = int(galerkin)
+        cfg.particle_pusher = int(particle_pusher)
+        cfg.current_deposition = int(current_deposition)
+        cfg.use_filter = int(use_filter)
+        cfg.sort_interval = int(sort_interval)
+        self.cfg = cfg
+        self._comm = comm  # keep the callbacks alive
+        self._h = C.c_void_p()
+        lib.sim_create(C.byref(cfg), C.byref(comm) if comm is not None else None, C.byref(self._h))
+        self.species = []
+        self.dx = [(float(prob_hi[d]) - float(prob_lo[d])) / int(n_cell[d]) for d in range(3)]
+
+    def close(self):
+        if self._h:
+            self.lib.sim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- species ------------------------------------------------------------
+    def add_species(self, charge, mass, particles):
+        """`particles`: ParticleArrays living where the library expects them
+        (device for the product, host for the oracle) or a list of 7 numpy arrays."""
+        if not isinstance(particles, ParticleArrays):
+            particles = ParticleArrays.from_numpy(particles, "cuda" if self.on_device else "cpu")
+        sid = C.c_int32(-1)
+        v = particles.view
+        self.lib.sim_add_species(self._h, float(charge), float(mass), C.byref(v), C.byref(sid))
+        self.species.append((float(charge), float(mass)))
+        return sid.value
+
+    # ---- stepping -----------------------------------------------------------
+    def evolve(self, numsteps: int):
+        self.lib.sim_evolve(self._h, int(numsteps))
+
+    @property
+    def dt(self) -> float:
+        return self.lib.sim_dt(self._h)
+
+    @property
+    def istep(self) -> int:
+        return self.lib.sim_istep(self._h)
+
+    # ---- data access --------------------------------------------------------
+    def _d2h(self):
+        return self.lib.copy_to_host if self.on_device else None
+
+    def field_view(self, name: str) -> _capi.FieldView:
+        v = _capi.FieldView()
+        self.lib.sim_get_field(self._h, name.encode(), C.byref(v))
+        return v
+
+    def field(self, name: str) -> np.ndarray:
+        """Dense [i,j,k] host copy including guards."""
+        return view_to_numpy(self.field_view(name), self._d2h())
+
+    def field_valid(self, name: str) -> np.ndarray:
+        v = self.field_view(name)
+        a = view_to_numpy(v, self._d2h())
+        g = v.ng
+        return a[g[0]: v.n[0] - g[0], g[1]: v.n[1] - g[1], g[2]: v.n[2] - g[2]]
+
+    def particle_view(self, sid: int) -> _capi.ParticleView:
+        v = _capi.ParticleView()
+        self.lib.sim_get_particles(self._h, int(sid), C.byref(v))
+        return v
+
+    def particles(self, sid: int) -> np.ndarray:
+        """(7, np) host copy in PIdx order x,y,z,w,ux,uy,uz."""
+        return particles_to_numpy(self.particle_view(sid), self._d2h())
+
+    def enable_timers(self, on=True):
+        self.lib.sim_enable_timers(self._h, 1 if on else 0)
+
+    def timers(self, reset=False):
+        ms = (C.c_double * 8)()
+        cnt = (C.c_int64 * 8)()
+        self.lib.sim_get_timers(self._h, ms, cnt, 1 if reset else 0)
+        names = ["GatherAndPush", "CurrentDeposition", "SyncCurrent", "EvolveB", "EvolveE",
+                 "FillBoundary", "Redistribute", "other"]
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
+
+
+# ---- order-independent reductions that define the parity metric -------------------
+# (formulas: Source/Diagnostics/ReducedDiags/FieldEnergy.cpp:81-157,
+#  ParticleEnergy.cpp:95-200 + Source/Particles/Algorithms/KineticEnergy.H:31-45,
+#  ParticleMomentum.cpp; evaluated on host copies in extended precision so that both
+#  sides of a comparison are reduced the same way)
+
+def field_energy(sim: WarpXSim):
+    from .plasma import EP0, MU0
+    dV = sim.dx[0] * sim.dx[1] * sim.dx[2]
+
+    def sumsq(name):
+        v = sim.field_view(name)
+        a = view_to_numpy(v, sim._d2h())
+        g = v.ng
+        # unique points: drop the duplicated high-edge nodal point (norm2 with periodicity)
+        sl = tuple(slice(g[d], v.n[d] - g[d] - v.stag[d]) for d in range(3))
+        x = a[sl].astype(np.longdouble)
+        return float(np.sum(x * x))
+
+    Es = sumsq("Ex") + sumsq("Ey") + sumsq("Ez")
+    Bs = sumsq("Bx") + sumsq("By") + sumsq("Bz")
+    return 0.5 * Es * EP0 * dV, 0.5 * Bs / MU0 * dV
+
+
+def particle_moments(sim: WarpXSim, sid: int):
+    from .plasma import C_LIGHT
+    q, m = sim.species[sid]
+    p = sim.particles(sid).astype(np.longdouble)
+    w, ux, uy, uz = p[3], p[4], p[5], p[6]
+    u2 = ux * ux + uy * uy + uz * uz
+    gamma = np.sqrt(1.0 + u2 / (np.longdouble(C_LIGHT) ** 2))
+    ekin = float(np.sum(w * (m * u2 / (1.0 + gamma))))
+    mom = [float(np.sum(w * m * c)) for c in (ux, uy, uz)]
+    absmom = [float(np.sum(np.abs(m * c))) for c in (ux, uy, uz)]
+    abspos = [float(np.sum(np.abs(p[i]))) for i in range(3)]
+    return {"ekin": ekin, "momentum": mom, "abs_momentum": absmom, "abs_position": abspos,
+            "weight": float(np.sum(w))}
