@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""Benchmark of the PIC hot path (BASELINE.json config 2 at N=1: 3-D uniform plasma 256^3,
+8 ppc, Yee FDTD, order-3 shape, Esirkepov, Boris, 1-pass bilinear filter; weak scaling for
+N>1: one 256^3 brick per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full PIC step of the hot path (gather+push, current deposition, filter +
+guard-cell sum, EvolveB/E/B, guard-cell fills, periodic wrap/sort) over every particle and
+cell resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# algorithmic bytes per unit, fp64 (SURVEY.md 8(d) / BASELINE.md section 3)
+BYTES = {
+    "EvolveB": 72.0,            # per cell per call
+    "EvolveE": 96.0,            # per cell per call
+    "GatherAndPush": (96.0, 48.0),      # per particle, per cell
+    "CurrentDeposition": (56.0, 48.0),  # per particle, per cell
+}
+
+
+def device_uniform_plasma(n_cell, prob_lo, prob_hi, ppc, density, u_th, seed, box_lo, box_n, device):
+    """warpx_amd.plasma.uniform_plasma evaluated on the device (same lattice formula:
+    pos = prob_lo + (cell + (0.5+i)/ppc)*dx, weight = n*dV/ppc, u = u_th*c*N(0,1))."""
+    import torch
+    from warpx_amd import plasma
+    f64 = torch.float64
+    dx = [(prob_hi[d] - prob_lo[d]) / n_cell[d] for d in range(3)]
+    nx, ny, nz = ppc
+    nppc = nx * ny * nz
+    ip = torch.arange(nppc, device=device)
+    r = [(0.5 + (ip // (ny * nz)).to(f64)) / nx, (0.5 + ((ip % (ny * nz)) // nz).to(f64)) / ny,
+         (0.5 + (ip % nz).to(f64)) / nz]
+    ncells = box_n[0] * box_n[1] * box_n[2]
+    n = ncells * nppc
+    out = torch.empty((7, n), dtype=f64, device=device)
+    cell = torch.arange(ncells, device=device)
+    idx = [cell % box_n[0], (cell // box_n[0]) % box_n[1], cell // (box_n[0] * box_n[1])]
+    for d in range(3):
+        c = (idx[d] + box_lo[d]).to(f64)
+        out[d] = (prob_lo[d] + (c[:, None] + r[d][None, :]) * dx[d]).reshape(-1)
+    out[3] = density * dx[0] * dx[1] * dx[2] / nppc
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for d in range(3):
+        out[4 + d] = torch.randn(n, dtype=f64, device=device, generator=g) * (u_th * plasma.C_LIGHT)
+    return out
+
+
+def cpu_baseline(n_threads=None):
+    """The CPU oracle (our restatement of the reference's algorithms; the reference itself
+    cannot be built here: AMReX is not on disk) timed on a bounded sample of the same
+    workload: 64^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on."""
+    import numpy as np
+    from tests.oracle_lib import load_oracle
+    from warpx_amd import _capi, plasma
+    from warpx_amd.sim import WarpXSim
+    orc = load_oracle()
+    n_cell = (64, 64, 64)
+    L = 40e-6
+    parts = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (2, 2, 2), 1e25, 0.01, seed=12345)
+    sim = WarpXSim(orc, n_cell, (-L / 2,) * 3, (L / 2,) * 3, nox=3, galerkin=1,
+                   particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
+                   use_filter=1)
+    sim.add_species(-plasma.Q_E, plasma.M_E, parts)
+    npart = len(parts[0])
+    sim.evolve(1)
+    steps = 3
+    t0 = time.perf_counter()
+    sim.evolve(steps)
+    dt = time.perf_counter() - t0
+    sim.close()
+    return {"value": npart * steps / dt, "unit": "particle-steps/s", "cores": int(orc.num_threads()),
+            "kind": "port",
+            "sample": f"64^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on, {steps} steps "
+                      f"({npart} particles); {dt:.1f} s of CPU time; cell-updates/s = "
+                      f"{64 ** 3 * steps / dt:.3e}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ncell", type=int, default=256, help="cells per brick edge")
+    ap.add_argument("--ppc", type=int, default=2, help="particles per cell per direction")
+    ap.add_argument("--order", type=int, default=3)
+    ap.add_argument("--deposition", choices=["esirkepov", "direct"], default="esirkepov")
+    ap.add_argument("--pusher", choices=["boris", "vay"], default="boris")
+    ap.add_argument("--no-filter", action="store_true")
+    ap.add_argument("--sort-interval", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phase-pass", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from warpx_amd import _capi, load_product, plasma
+    from warpx_amd.sim import WarpXSim
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    lib = load_product()  # raises when the HIP library is missing: no fallback
+
+    transport = None
+    nbricks, coord = (1, 1, 1), (0, 0, 0)
+    if world > 1:
+        import torch.distributed as dist
+        from warpx_amd.distributed import TorchBrickTransport, brick_coord, brick_layout
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+        nbricks = brick_layout(world)
+        coord = brick_coord(rank, nbricks)
+        transport = TorchBrickTransport(on_device=True)
+
+    nb = args.ncell
+    n_cell = tuple(nb * nbricks[d] for d in range(3))
+    L0 = 40e-6
+    prob_lo = tuple(-L0 * nbricks[d] / 2 for d in range(3))
+    prob_hi = tuple(+L0 * nbricks[d] / 2 for d in range(3))
+    depos = _capi.DEPOSIT_ESIRKEPOV if args.deposition == "esirkepov" else _capi.DEPOSIT_DIRECT
+    pusher = _capi.PUSHER_BORIS if args.pusher == "boris" else _capi.PUSHER_VAY
+    sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=args.order, galerkin=1, particle_pusher=pusher,
+                   current_deposition=depos, use_filter=0 if args.no_filter else 1, cfl=1.0,
+                   sort_interval=args.sort_interval, nbricks=nbricks, coord=coord,
+                   comm=transport.comm if transport else None)
+    box_lo = tuple(coord[d] * nb for d in range(3))
+    parts = device_uniform_plasma(n_cell, prob_lo, prob_hi, (args.ppc,) * 3, 1e25, 0.01, 12345 + rank,
+                                  box_lo, (nb,) * 3, device)
+    from warpx_amd.containers import ParticleArrays
+    pa = ParticleArrays(parts.shape[1], device)
+    pa.data = parts
+    sim.add_species(-plasma.Q_E, plasma.M_E, pa)
+    np_local = parts.shape[1]
+    del parts, pa
+    torch.cuda.empty_cache()
+    ncells_local = nb ** 3
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    sim.evolve(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    sim.evolve(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # second, short pass with per-phase HIP-event timers (on the stream the kernels run on)
+    phases = {}
+    if not args.no_phase_pass:
+        sim.enable_timers(True)
+        sim.timers(reset=True)
+        nph = min(args.steps, 4)
+        sim.evolve(nph)
+        torch.cuda.synchronize()
+        phases = sim.timers(reset=True)
+        sim.enable_timers(False)
+
+    if rank == 0:
+        total_particles = np_local * world
+        total_cells = ncells_local * world
+        pps = total_particles * args.steps / elapsed
+        cps = total_cells * args.steps / elapsed
+        kernels = {}
+        dominant = None
+        for name, (ms, cnt) in phases.items():
+            if cnt == 0 or ms <= 0:
+                continue
+            avg_ms = ms / cnt
+            entry = {"avg_ms": avg_ms, "launches": int(cnt)}
+            if name in ("EvolveB", "EvolveE"):
+                algo_bytes = BYTES[name] * ncells_local
+            elif name in ("GatherAndPush", "CurrentDeposition"):
+                bp, bc = BYTES[name]
+                algo_bytes = bp * np_local + bc * ncells_local
+            else:
+                algo_bytes = None
+            if algo_bytes is not None:
+                entry["algorithmic_GB"] = algo_bytes / 1e9
+                entry["achieved_GBs"] = algo_bytes / 1e9 / (avg_ms * 1e-3)
+                entry["hbm_frac"] = entry["achieved_GBs"] / HBM_PEAK_GBS
+            kernels[name] = entry
+        # share of the step per phase (PushP of the (de)synchronisation is folded in GatherAndPush)
+        if kernels:
+            tot = {k: v["avg_ms"] * v["launches"] for k, v in kernels.items()}
+            dominant = max((k for k in tot if "achieved_GBs" in kernels[k]), key=lambda k: tot[k])
+        roofline = None
+        if dominant:
+            k = kernels[dominant]
+            roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": k["hbm_frac"], "traffic": None,
+                        "note": "particle kernels are VALU/LDS-atomic bound, not HBM bound (SURVEY.md 8(d)); "
+                                "the HBM-bound stencils are listed under kernels"}
+        out = {
+            "metric": "particle_steps_per_s", "value": pps, "unit": "particle-steps/s",
+            "cell_updates_per_s": cps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D uniform_plasma {n_cell[0]}x{n_cell[1]}x{n_cell[2]}, "
+                                   f"{args.ppc ** 3} ppc, Yee FDTD, order-{args.order} shape, {args.deposition}, "
+                                   f"{args.pusher}, filter {'off' if args.no_filter else 'on'}",
+                       "cells_per_gpu": ncells_local, "particles_per_gpu": np_local,
+                       "bricks": list(nbricks), "sort_interval": args.sort_interval},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the oracle is test infrastructure; never fail the bench on it
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,6 +177,13 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src,
                                       const int32_t cell_lo[3], const int32_t ncell[3],
                                       wxa_workspace* ws, void* stream);
 
+/* 3-way partition of a tile along `dim` for the brick-to-brick part of
+ * amrex ParticleContainer::Redistribute: dst = [stay | to-minus | to-plus] for positions
+ * in [lo,hi) / < lo / >= hi.  counts[3] (host) is valid on return (synchronises). */
+wxa_status wxa_partition_particles(const wxa_particle_view* src, const wxa_particle_view* dst,
+                                   int dim, double lo, double hi, int64_t counts[3],
+                                   wxa_workspace* ws, void* stream);
+
 /* ------------------------------------------------------------------ */
 /* Current filter and guard-cell exchange                              */
 /* ------------------------------------------------------------------ */
@@ -196,6 +203,11 @@ wxa_status wxa_filter_bilinear(const wxa_field_view* src, const wxa_field_view* 
  * multi-brick exchange instead). */
 wxa_status wxa_fill_boundary_periodic(const wxa_field_view* f, const int ng[3],
                                       const int periodic[3], void* stream);
+
+/* The extra step of FillBoundaryAndSync (Source/ablastr/utils/Communication.cpp:99-101,
+ * 109-110; WarpX::sync_nodal_points, Source/WarpX.H:1523) on a self-periodic direction:
+ * the high-edge nodal point takes the value of the low-edge one (its owner). */
+wxa_status wxa_sync_nodal_periodic(const wxa_field_view* f, const int periodic[3], void* stream);
 
 /* Single-brick periodic SumBoundary(src_ng): every point ends up holding the
  * sum over all periodic images taken from valid + src_ng guard regions; all

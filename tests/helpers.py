@@ -1,0 +1,100 @@
+"""Shared builders for the parity tests: identical seeded inputs for the CPU oracle
+(host arrays) and the HIP library (device arrays)."""
+import ctypes as C
+
+import numpy as np
+
+from warpx_amd import _capi, plasma
+from warpx_amd.containers import STAG, FieldArray, ParticleArrays, field_triplet, grid_geom
+
+LX = 40e-6
+
+
+def guard_depths(order, use_filter=False):
+    """Source/Parallelization/GuardCellManager.cpp:62-172 for cfl=1 cubic cells."""
+    ng_eb = order + (order % 2)
+    ng_depos = order + 1
+    ng_j = ng_depos + (1 if use_filter else 0)
+    return ng_eb, ng_depos, ng_j
+
+
+def random_fields(names, ncell, ng, seed, scale=1.0, device="cpu", pad=False):
+    rng = np.random.default_rng(seed)
+    out = []
+    for name in names:
+        f = FieldArray(ncell, STAG[name], (ng,) * 3, device="cpu")
+        f.from_numpy(rng.standard_normal(f.n) * scale)
+        out.append(f if device == "cpu" else f.copy_to(device, pad=pad))
+    return out
+
+
+def clone_fields(fields, device, pad=False):
+    return [f.copy_to(device, pad=pad) for f in fields]
+
+
+def random_particles(n, ncell, seed, u_scale=0.1, margin=0.0):
+    """Positions uniform in the domain [-LX/2, LX/2)^3 (shrunk by `margin` cells), momenta gaussian."""
+    rng = np.random.default_rng(seed)
+    dx = LX / np.asarray(ncell)
+    lo = -LX / 2 + margin * dx
+    hi = LX / 2 - margin * dx
+    pos = [lo[d] + (hi[d] - lo[d]) * rng.random(n) for d in range(3)]
+    w = 1e9 * (0.5 + rng.random(n))
+    u = [u_scale * plasma.C_LIGHT * rng.standard_normal(n) for _ in range(3)]
+    return pos + [w] + u
+
+
+def geom_for(ncell, ng):
+    dx = LX / np.asarray(ncell, dtype=np.float64)
+    return grid_geom((-LX / 2,) * 3, dx, (0, 0, 0), (ng,) * 3), dx
+
+
+def yee_dt(dx, cfl=1.0):
+    return cfl / (np.sqrt(np.sum(1.0 / np.asarray(dx) ** 2)) * plasma.C_LIGHT)
+
+
+def d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def max_rel_err(a, b):
+    scale = max(np.max(np.abs(b)), 1e-300)
+    return float(np.max(np.abs(a - b)) / scale)
+
+
+def continuity_residual(lib, device, order, ncell, nparts=3000, seed=33):
+    """max |(rho_new - rho_old)/dt + div J| / max|drho/dt| for an Esirkepov deposit, using the
+    library's own charge deposition at the old and new positions."""
+    _, ng_depos, ng_j = guard_depths(order)
+    g, dx = geom_for(ncell, ng_depos)
+    dt = yee_dt(dx)
+    parts = random_particles(nparts, ncell, seed, u_scale=2.0, margin=1.0)
+    q = plasma.Q_E
+    pn = ParticleArrays.from_numpy(parts, device)
+    J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, device) for n in ("jx", "jy", "jz")]
+    # relative_time = -dt/2: x_new = stored x, x_old = x - v dt
+    lib.deposit_current(C.byref(pn.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order,
+                        _capi.DEPOSIT_ESIRKEPOV, None, None)
+    rho_new = FieldArray(ncell, STAG["rho"], (ng_j,) * 3, device)
+    rho_old = FieldArray(ncell, STAG["rho"], (ng_j,) * 3, device)
+    lib.deposit_charge(C.byref(pn.view), C.byref(rho_new.view), C.byref(g), q, order, None)
+    p = np.array(parts)
+    gam = np.sqrt(1 + (p[4] ** 2 + p[5] ** 2 + p[6] ** 2) / plasma.C_LIGHT ** 2)
+    old = [p[0] - p[4] / gam * dt, p[1] - p[5] / gam * dt, p[2] - p[6] / gam * dt] + list(p[3:])
+    po = ParticleArrays.from_numpy(old, device)
+    lib.deposit_charge(C.byref(po.view), C.byref(rho_old.view), C.byref(g), q, order, None)
+    if device != "cpu":
+        lib.device_synchronize()
+    jx, jy, jz = (f.to_numpy() for f in J)
+    rn, ro = rho_new.to_numpy(), rho_old.to_numpy()
+    A, B, Cc = jx.shape[0], jy.shape[1], jz.shape[2]
+    dxJ = (jx[1:A] - jx[0:A - 1]) / dx[0]
+    dyJ = (jy[:, 1:B] - jy[:, 0:B - 1]) / dx[1]
+    dzJ = (jz[:, :, 1:Cc] - jz[:, :, 0:Cc - 1]) / dx[2]
+    div = dxJ[:, 1:B, 1:Cc] + dyJ[1:A, :, 1:Cc] + dzJ[1:A, 1:B, :]
+    drho = (rn - ro)[1:A, 1:B, 1:Cc] / dt
+    return float(np.max(np.abs(drho + div)) / np.max(np.abs(drho)))

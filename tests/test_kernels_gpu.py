@@ -1,0 +1,221 @@
+"""Kernel-level parity: every HIP entry point of the C-ABI against the CPU oracle on the
+same seeded inputs.  Field stencils, filter and guard-cell kernels keep the reference's
+operation order and must be bit-identical; per-particle kernels may differ by FMA
+contraction (tolerance 1e-12 of the field scale); deposition sums in a different order
+(atomics) and is compared per cell at 1e-12 of max|J|."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from warpx_amd import _capi, plasma
+from warpx_amd.containers import STAG, FieldArray, ParticleArrays, field_triplet
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+NCELL = (24, 20, 16)
+
+
+def _sync(product):
+    product.device_synchronize()
+
+
+@pytest.mark.parametrize("pad", [False, True])
+def test_evolve_b_bit_exact(oracle, product, pad):
+    ng = 2
+    E = H.random_fields(("Ex", "Ey", "Ez"), NCELL, ng, 1)
+    B = H.random_fields(("Bx", "By", "Bz"), NCELL, ng, 2)
+    Ed, Bd = H.clone_fields(E, DEV, pad), H.clone_fields(B, DEV, pad)
+    _, dx = H.geom_for(NCELL, ng)
+    dt = 0.5 * H.yee_dt(dx)
+    dinv = H.d3(1.0 / dx)
+    oracle.evolve_b(field_triplet(E), field_triplet(B), dt, dinv, None)
+    product.evolve_b(field_triplet(Ed), field_triplet(Bd), dt, dinv, None)
+    _sync(product)
+    for a, b in zip(Bd, B):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+
+
+@pytest.mark.parametrize("pad", [False, True])
+def test_evolve_e_bit_exact(oracle, product, pad):
+    ng = 2
+    E = H.random_fields(("Ex", "Ey", "Ez"), NCELL, ng, 3)
+    B = H.random_fields(("Bx", "By", "Bz"), NCELL, ng, 4, scale=1e-8)
+    J = H.random_fields(("jx", "jy", "jz"), NCELL, 3, 5, scale=1e3)
+    Ed, Bd, Jd = (H.clone_fields(x, DEV, pad) for x in (E, B, J))
+    _, dx = H.geom_for(NCELL, ng)
+    dt = H.yee_dt(dx)
+    dinv = H.d3(1.0 / dx)
+    oracle.evolve_e(field_triplet(E), field_triplet(B), field_triplet(J), dt, dinv, None)
+    product.evolve_e(field_triplet(Ed), field_triplet(Bd), field_triplet(Jd), dt, dinv, None)
+    _sync(product)
+    for a, b in zip(Ed, E):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+
+
+def test_evolve_unsupported_staggering(product):
+    f = [FieldArray(NCELL, (1, 1, 1), (2, 2, 2), DEV) for _ in range(6)]
+    with pytest.raises(_capi.WxaError):
+        product.evolve_b(field_triplet(f[:3]), field_triplet(f[3:]), 1e-16, H.d3((1, 1, 1)), None)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("galerkin", [1, 0])
+@pytest.mark.parametrize("pusher", [_capi.PUSHER_BORIS, _capi.PUSHER_VAY])
+def test_gather_push(oracle, product, order, galerkin, pusher):
+    ng, _, _ = H.guard_depths(order)
+    E = H.random_fields(("Ex", "Ey", "Ez"), NCELL, ng, 10, scale=1e11)
+    B = H.random_fields(("Bx", "By", "Bz"), NCELL, ng, 11, scale=1e3)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    parts = H.random_particles(5000, NCELL, 12)
+    ph = ParticleArrays.from_numpy(parts, "cpu")
+    pd = ParticleArrays.from_numpy(parts, DEV)
+    g, dx = H.geom_for(NCELL, ng)
+    dt = H.yee_dt(dx)
+    q, m = -plasma.Q_E, plasma.M_E
+    for fn in ("gather_push", "push_p"):
+        getattr(oracle, fn)(C.byref(ph.view), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt,
+                            order, galerkin, pusher, None)
+        getattr(product, fn)(C.byref(pd.view), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt,
+                             order, galerkin, pusher, None)
+        _sync(product)
+        a, b = pd.to_numpy(), ph.to_numpy()
+        for row in range(7):
+            assert H.max_rel_err(a[row], b[row]) < 1e-12, (fn, row)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
+def test_deposit_current(oracle, product, order, algo):
+    _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    J = [FieldArray(NCELL, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    Jd = H.clone_fields(J, DEV, True)
+    parts = H.random_particles(20000, NCELL, 20 + order, u_scale=1.0)
+    ph = ParticleArrays.from_numpy(parts, "cpu")
+    pd = ParticleArrays.from_numpy(parts, DEV)
+    g, dx = H.geom_for(NCELL, ng_depos)
+    dt = H.yee_dt(dx)
+    q = -plasma.Q_E
+    oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order, algo, None, None)
+    product.deposit_current(C.byref(pd.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, algo, None, None)
+    _sync(product)
+    for a, b in zip(Jd, J):
+        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
+    # empty input is a no-op
+    empty = ParticleArrays(0, DEV)
+    product.deposit_current(C.byref(empty.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, algo, None, None)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_esirkepov_continuity(product, order):
+    """Discrete continuity (rho_new - rho_old)/dt + div J = 0 to round-off (Esirkepov 2001):
+    an analytic property of the path that no reference test pins."""
+    resid = H.continuity_residual(product, DEV, order, NCELL)
+    assert resid < 1e-11
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_deposit_charge(oracle, product, order):
+    ng = order + 2
+    rho = FieldArray(NCELL, STAG["rho"], (ng,) * 3, "cpu")
+    rhod = rho.copy_to(DEV, True)
+    parts = H.random_particles(8000, NCELL, 40)
+    ph, pd = ParticleArrays.from_numpy(parts, "cpu"), ParticleArrays.from_numpy(parts, DEV)
+    g, _ = H.geom_for(NCELL, ng)
+    oracle.deposit_charge(C.byref(ph.view), C.byref(rho.view), C.byref(g), plasma.Q_E, order, None)
+    product.deposit_charge(C.byref(pd.view), C.byref(rhod.view), C.byref(g), plasma.Q_E, order, None)
+    _sync(product)
+    assert H.max_rel_err(rhod.to_numpy(), rho.to_numpy()) < 1e-12
+
+
+def test_filter_bit_exact(oracle, product):
+    (src,) = H.random_fields(("jx",), NCELL, 4, 50)
+    dst = src.like()
+    srcd, dstd = src.copy_to(DEV, True), src.like(DEV, True)
+    oracle.filter_bilinear(C.byref(src.view), C.byref(dst.view), None)
+    product.filter_bilinear(C.byref(srcd.view), C.byref(dstd.view), None)
+    _sync(product)
+    assert np.array_equal(dstd.to_numpy(), dst.to_numpy())
+    with pytest.raises(_capi.WxaError):
+        product.filter_bilinear(C.byref(srcd.view), C.byref(srcd.view), None)
+
+
+@pytest.mark.parametrize("name", ["Ex", "By", "rho"])
+@pytest.mark.parametrize("ng_fill", [1, 2, 4])
+def test_fill_boundary_bit_exact(oracle, product, name, ng_fill):
+    (f,) = H.random_fields((name,), NCELL, 4, 60)
+    fd = f.copy_to(DEV, True)
+    per = H.i3((1, 1, 1))
+    oracle.sync_nodal_periodic(C.byref(f.view), per, None)
+    oracle.fill_boundary_periodic(C.byref(f.view), H.i3((ng_fill,) * 3), per, None)
+    product.sync_nodal_periodic(C.byref(fd.view), per, None)
+    product.fill_boundary_periodic(C.byref(fd.view), H.i3((ng_fill,) * 3), per, None)
+    _sync(product)
+    assert np.array_equal(fd.to_numpy(), f.to_numpy())
+
+
+@pytest.mark.parametrize("name", ["jx", "jz", "rho"])
+@pytest.mark.parametrize("src_ng", [2, 4])
+def test_sum_boundary(oracle, product, name, src_ng):
+    (f,) = H.random_fields((name,), NCELL, 4, 70)
+    fd = f.copy_to(DEV, True)
+    per = H.i3((1, 1, 1))
+    oracle.sum_boundary_periodic(C.byref(f.view), H.i3((src_ng,) * 3), per, None)
+    product.sum_boundary_periodic(C.byref(fd.view), H.i3((src_ng,) * 3), per, None)
+    _sync(product)
+    assert np.array_equal(fd.to_numpy(), f.to_numpy())
+
+
+def test_pack_unpack_roundtrip(product):
+    import torch
+    (f,) = H.random_fields(("Ey",), NCELL, 3, 80)
+    fd = f.copy_to(DEV, True)
+    lo = (C.c_int32 * 3)(-2, 1, 0)
+    hi = (C.c_int32 * 3)(5, 9, 16)
+    n = 7 * 8 * 16
+    buf = torch.zeros(n, dtype=torch.float64, device=DEV)
+    product.pack_box(C.byref(fd.view), lo, hi, buf.data_ptr(), None)
+    a = f.to_numpy()
+    want = a[-2 + 3:5 + 3, 1 + 3:9 + 3, 0 + 3:16 + 3]
+    got = buf.cpu().numpy().reshape(16, 8, 7).transpose(2, 1, 0)
+    assert np.array_equal(got, want)
+    product.unpack_box(C.byref(fd.view), lo, hi, buf.data_ptr(), 1, None)
+    _sync(product)
+    b = fd.to_numpy()
+    assert np.array_equal(b[-2 + 3:5 + 3, 1 + 3:9 + 3, 0 + 3:16 + 3], 2 * want)
+
+
+def test_enforce_periodic_and_sort(oracle, product):
+    import torch
+    parts = H.random_particles(30000, NCELL, 90)
+    # push some particles outside by up to one cell
+    rng = np.random.default_rng(91)
+    dx = H.LX / np.asarray(NCELL)
+    for d in range(3):
+        parts[d] = parts[d] + dx[d] * (rng.random(parts[d].shape[0]) - 0.5) * 2.0
+    ph, pd = ParticleArrays.from_numpy(parts, "cpu"), ParticleArrays.from_numpy(parts, DEV)
+    plo, phi = H.d3((-H.LX / 2,) * 3), H.d3((H.LX / 2,) * 3)
+    per = H.i3((1, 1, 1))
+    oracle.enforce_periodic(C.byref(ph.view), plo, phi, per, None)
+    product.enforce_periodic(C.byref(pd.view), plo, phi, per, None)
+    _sync(product)
+    assert np.array_equal(pd.to_numpy(), ph.to_numpy())
+    a = pd.to_numpy()
+    assert np.all(a[:3] >= -H.LX / 2) and np.all(a[:3] < H.LX / 2)
+    # counting sort by cell: a permutation whose cell ids are non-decreasing
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    out = ParticleArrays(pd.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd.view), C.byref(out.view), plo, H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*NCELL), ws, None)
+    _sync(product)
+    s = out.to_numpy()
+    cell = [np.clip(np.floor((s[d] + H.LX / 2) / dx[d]).astype(np.int64), 0, NCELL[d] - 1) for d in range(3)]
+    key = cell[0] + NCELL[0] * (cell[1] + NCELL[1] * cell[2])
+    assert np.all(np.diff(key) >= 0)
+    order_a = np.lexsort(a[::-1])
+    order_s = np.lexsort(s[::-1])
+    assert np.array_equal(a[:, order_a], s[:, order_s])
+    product.workspace_destroy(ws)

@@ -1,7 +1,7 @@
 """ctypes binding of the C-ABI declared in include/warpx_amd.h.
 
 The binder is generic over (shared library, symbol prefix) so the test-suite can
-bind the CPU oracle (`orc_*`, oracle/liboracle.so) with the very same
+bind the CPU oracle's `orc_*` entry points with the very same
 signatures; the product only ever loads `libwarpx_amd.so` (`wxa_*`) and raises
 if it is missing -- there is no CPU fallback.
 """
@@ -107,6 +107,7 @@ _KERNEL_SIGS = {
     "filter_bilinear": (C.c_int, [_PFV, _PFV, C.c_void_p]),
     "fill_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
     "sum_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
+    "sync_nodal_periodic": (C.c_int, [_PFV, _I3, C.c_void_p]),
     "field_set_zero": (C.c_int, [_PFV, C.c_void_p]),
     "version": (C.c_char_p, []),
 }
@@ -130,6 +131,8 @@ _PRODUCT_SIGS = {
     "workspace_destroy": (None, [C.c_void_p]),
     "last_error": (C.c_char_p, []),
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
+    "partition_particles": (C.c_int, [_PPV, _PPV, C.c_int, C.c_double, C.c_double,
+                                      C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "pack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "unpack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
     "copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -139,7 +142,6 @@ _PRODUCT_SIGS = {
 
 # oracle-only entry points (diagnostic formulas that define the parity metric)
 _ORACLE_SIGS = {
-    "sync_nodal_periodic": (C.c_int, [_PFV, _I3, C.c_void_p]),
     "sum_sq_unique": (C.c_double, [_PFV]),
     "field_energy": (None, [_FV3, _FV3, _D3, C.c_double * 3]),
     "particle_energy": (C.c_double, [_PPV, C.c_double]),

@@ -1,0 +1,420 @@
+// FDTD Yee field kernels and guard-cell kernels for gfx950 (MI355X).
+//
+// EvolveB / EvolveE are pure HBM-bound stencils (0.17 flop/B): 72 B/cell and
+// 96 B/cell of algorithmic traffic.  Design:
+//  * one lane per i (the contiguous direction) -> every wave load is one
+//    coalesced 512-B line segment; TJ rows per workgroup so that the j+-1
+//    neighbour rows are served by the same CU's L1;
+//  * each lane marches KC planes in k and carries the k-neighbour in registers, so
+//    each array is read once per tile (+1/KC plane halo);
+//  * workgroup -> tile mapping is XCD-aware (contiguous k-slabs per XCD L2);
+//  * arithmetic keeps the reference's operation order and is compiled with
+//    -ffp-contract=off: results are bit-identical to the CPU path.
+#include "common.hpp"
+
+namespace wxa {
+
+constexpr int TI = 64;   // lanes along i (one wavefront per row)
+constexpr int TJ = 4;    // rows per workgroup
+constexpr int KC = 16;   // planes marched per workgroup
+
+struct TileGrid {
+    int nti, ntj, ntk;
+    long ntiles;
+};
+
+static TileGrid make_tiles(const Box3& ub) {
+    TileGrid t;
+    t.nti = (ub.hi[0] - ub.lo[0] + TI - 1) / TI;
+    t.ntj = (ub.hi[1] - ub.lo[1] + TJ - 1) / TJ;
+    t.ntk = (ub.hi[2] - ub.lo[2] + KC - 1) / KC;
+    t.ntiles = (long)t.nti * t.ntj * t.ntk;
+    return t;
+}
+
+__device__ inline bool in_ij(const Box3& b, int i, int j) {
+    return i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1];
+}
+
+// Source/FieldSolver/FiniteDifferenceSolver/EvolveB.cpp:164-186 (three fused lambdas)
+__global__ void __launch_bounds__(TI* TJ)
+evolve_b_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, Box3 bbx, Box3 bby,
+                Box3 bbz, TileGrid tg, double dt, double idx, double idy, double idz) {
+    const long tile = xcd_tile_id(blockIdx.x, tg.ntiles);
+    if (tile >= tg.ntiles) return;
+    const int ti = (int)(tile % tg.nti);
+    const int tj = (int)((tile / tg.nti) % tg.ntj);
+    const int tk = (int)(tile / ((long)tg.nti * tg.ntj));
+    const int i = ub.lo[0] + ti * TI + (int)threadIdx.x;
+    const int j = ub.lo[1] + tj * TJ + (int)threadIdx.y;
+    if (i >= ub.hi[0] || j >= ub.hi[1]) return;
+    const int k0 = ub.lo[2] + tk * KC;
+    const int k1 = min(k0 + KC, ub.hi[2]);
+    const bool px = in_ij(bbx, i, j), py = in_ij(bby, i, j), pz = in_ij(bbz, i, j);
+
+    const double* __restrict__ ex = Ex.p + Ex.off(i, j, k0);
+    const double* __restrict__ ey = Ey.p + Ey.off(i, j, k0);
+    const double* __restrict__ ez = Ez.p + Ez.off(i, j, k0);
+    double* __restrict__ bx = Bx.p + Bx.off(i, j, k0);
+    double* __restrict__ by = By.p + By.off(i, j, k0);
+    double* __restrict__ bz = Bz.p + Bz.off(i, j, k0);
+
+    double ex_k = ex[0], ey_k = ey[0];
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+        const double ex_k1 = ex[Ex.ks], ey_k1 = ey[Ey.ks];
+        const double ez_c = ez[0], ez_j1 = ez[Ez.js], ez_i1 = ez[1];
+        const double ex_j1 = ex[Ex.js], ey_i1 = ey[1];
+        if (px && k >= bbx.lo[2] && k < bbx.hi[2])
+            bx[0] += dt * (idz * (ey_k1 - ey_k)) - dt * (idy * (ez_j1 - ez_c));
+        if (py && k >= bby.lo[2] && k < bby.hi[2])
+            by[0] += dt * (idx * (ez_i1 - ez_c)) - dt * (idz * (ex_k1 - ex_k));
+        if (pz && k >= bbz.lo[2] && k < bbz.hi[2])
+            bz[0] += dt * (idy * (ex_j1 - ex_k)) - dt * (idx * (ey_i1 - ey_k));
+        ex_k = ex_k1; ey_k = ey_k1;
+        ex += Ex.ks; ey += Ey.ks; ez += Ez.ks; bx += Bx.ks; by += By.ks; bz += Bz.ks;
+    }
+}
+
+// Source/FieldSolver/FiniteDifferenceSolver/EvolveE.cpp:179-216
+__global__ void __launch_bounds__(TI* TJ)
+evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, DevF Jy, DevF Jz,
+                Box3 ub, Box3 bex, Box3 bey, Box3 bez, TileGrid tg, double dt, double idx, double idy,
+                double idz) {
+    const long tile = xcd_tile_id(blockIdx.x, tg.ntiles);
+    if (tile >= tg.ntiles) return;
+    const int ti = (int)(tile % tg.nti);
+    const int tj = (int)((tile / tg.nti) % tg.ntj);
+    const int tk = (int)(tile / ((long)tg.nti * tg.ntj));
+    const int i = ub.lo[0] + ti * TI + (int)threadIdx.x;
+    const int j = ub.lo[1] + tj * TJ + (int)threadIdx.y;
+    if (i >= ub.hi[0] || j >= ub.hi[1]) return;
+    const int k0 = ub.lo[2] + tk * KC;
+    const int k1 = min(k0 + KC, ub.hi[2]);
+    const bool px = in_ij(bex, i, j), py = in_ij(bey, i, j), pz = in_ij(bez, i, j);
+    constexpr double c2 = PhysConst::c * PhysConst::c;
+    constexpr double mu0 = PhysConst::mu0;
+
+    double* __restrict__ ex = Ex.p + Ex.off(i, j, k0);
+    double* __restrict__ ey = Ey.p + Ey.off(i, j, k0);
+    double* __restrict__ ez = Ez.p + Ez.off(i, j, k0);
+    const double* __restrict__ bx = Bx.p + Bx.off(i, j, k0);
+    const double* __restrict__ by = By.p + By.off(i, j, k0);
+    const double* __restrict__ bz = Bz.p + Bz.off(i, j, k0);
+    const double* __restrict__ jx = Jx.p + Jx.off(i, j, k0);
+    const double* __restrict__ jy = Jy.p + Jy.off(i, j, k0);
+    const double* __restrict__ jz = Jz.p + Jz.off(i, j, k0);
+
+    double bx_km = bx[-Bx.ks], by_km = by[-By.ks];
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+        const double bx_c = bx[0], by_c = by[0], bz_c = bz[0];
+        const double bz_jm = bz[-Bz.js], bz_im = bz[-1];
+        const double bx_jm = bx[-Bx.js], by_im = by[-1];
+        if (px && k >= bex.lo[2] && k < bex.hi[2])
+            ex[0] += c2 * dt * (-(idz * (by_c - by_km)) + (idy * (bz_c - bz_jm)) - mu0 * jx[0]);
+        if (py && k >= bey.lo[2] && k < bey.hi[2])
+            ey[0] += c2 * dt * (-(idx * (bz_c - bz_im)) + (idz * (bx_c - bx_km)) - mu0 * jy[0]);
+        if (pz && k >= bez.lo[2] && k < bez.hi[2])
+            ez[0] += c2 * dt * (-(idy * (bx_c - bx_jm)) + (idx * (by_c - by_im)) - mu0 * jz[0]);
+        bx_km = bx_c; by_km = by_c;
+        ex += Ex.ks; ey += Ey.ks; ez += Ez.ks; bx += Bx.ks; by += By.ks; bz += Bz.ks;
+        jx += Jx.ks; jy += Jy.ks; jz += Jz.ks;
+    }
+}
+
+// Source/Filter/Filter.cpp:105-133 with the 1-pass stencil of BilinearFilter.cpp:26-60
+// ({0.25, 0.25} per direction); same tap order as the reference -> bit-identical.
+__global__ void __launch_bounds__(256)
+filter_bilinear_kernel(DevF src, DevF dst) {
+    const int i = src.lo0 + (int)(blockIdx.x * 64 + threadIdx.x);
+    const int j = src.lo1 + (int)(blockIdx.y * 4 + threadIdx.y);
+    const int k = src.lo2 + (int)blockIdx.z;
+    if (i >= src.lo0 + src.n0 || j >= src.lo1 + src.n1) return;
+    const int hi0 = src.lo0 + src.n0, hi1 = src.lo1 + src.n1, hi2 = src.lo2 + src.n2;
+    auto zp = [&](int a, int b, int c) -> double {
+        return (a >= src.lo0 && a < hi0 && b >= src.lo1 && b < hi1 && c >= src.lo2 && c < hi2)
+                   ? src.p[src.off(a, b, c)] : 0.0;
+    };
+    double d = 0.0;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int i1 = 0; i1 < 2; ++i1)
+#pragma unroll
+            for (int i0 = 0; i0 < 2; ++i0) {
+                const double sss = 0.25 * 0.25 * 0.25;
+                d += sss * (zp(i - i0, j - i1, k - i2) + zp(i + i0, j - i1, k - i2) +
+                            zp(i - i0, j + i1, k - i2) + zp(i + i0, j + i1, k - i2) +
+                            zp(i - i0, j - i1, k + i2) + zp(i + i0, j - i1, k + i2) +
+                            zp(i - i0, j + i1, k + i2) + zp(i + i0, j + i1, k + i2));
+            }
+    dst.p[dst.off(i, j, k)] = d;
+}
+
+// generic box copy kernels -----------------------------------------------------
+struct BoxN {
+    int lo[3];
+    int n[3];
+};
+
+// dst(i,j,k) = src(i + shift) for (i,j,k) in box (periodic guard fill, one direction)
+__global__ void __launch_bounds__(256)
+shift_copy_kernel(DevF f, BoxN box, int s0, int s1, int s2) {
+    const long total = (long)box.n[0] * box.n[1] * box.n[2];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % box.n[0]);
+        const int b = (int)((t / box.n[0]) % box.n[1]);
+        const int c = (int)(t / ((long)box.n[0] * box.n[1]));
+        const int i = box.lo[0] + a, j = box.lo[1] + b, k = box.lo[2] + c;
+        f.p[f.off(i, j, k)] = f.p[f.off(i + s0, j + s1, k + s2)];
+    }
+}
+
+// SumBoundary along direction d: every residue class mod nc is summed over its
+// members in [s0,s1) and the total written to all members in the allocation.
+__global__ void __launch_bounds__(256)
+sum_periodic_kernel(DevF f, int d, int nc, int s0, int s1) {
+    const int lo[3] = {f.lo0, f.lo1, f.lo2};
+    const int n[3] = {f.n0, f.n1, f.n2};
+    const long st[3] = {1, f.js, f.ks};
+    // thread space: (fast, r, slow) where fast/slow are the other two directions
+    const int da = d == 0 ? 1 : 0;           // faster of the other two
+    const int db = d == 2 ? 1 : 2;           // slower of the other two
+    const long total = (long)n[da] * nc * n[db];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % n[da]);
+        const int r = (int)((t / n[da]) % nc);
+        const int b = (int)(t / ((long)n[da] * nc));
+        double* base = f.p + a * st[da] + b * st[db];
+        const int a0 = lo[d], a1 = lo[d] + n[d];
+        // first member of the class inside the allocation
+        int first = a0 + (((r - a0) % nc) + nc) % nc;
+        double sum = 0.0;
+        for (int m = first; m < a1; m += nc)
+            if (m >= s0 && m < s1) sum += base[(long)(m - a0) * st[d]];
+        for (int m = first; m < a1; m += nc) base[(long)(m - a0) * st[d]] = sum;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pack_kernel(DevF f, BoxN box, double* __restrict__ buf) {
+    const long total = (long)box.n[0] * box.n[1] * box.n[2];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % box.n[0]);
+        const int b = (int)((t / box.n[0]) % box.n[1]);
+        const int c = (int)(t / ((long)box.n[0] * box.n[1]));
+        buf[t] = f.p[f.off(box.lo[0] + a, box.lo[1] + b, box.lo[2] + c)];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+unpack_kernel(DevF f, BoxN box, const double* __restrict__ buf, int mode) {
+    const long total = (long)box.n[0] * box.n[1] * box.n[2];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % box.n[0]);
+        const int b = (int)((t / box.n[0]) % box.n[1]);
+        const int c = (int)(t / ((long)box.n[0] * box.n[1]));
+        double* q = &f.p[f.off(box.lo[0] + a, box.lo[1] + b, box.lo[2] + c)];
+        if (mode == 0) *q = buf[t]; else *q += buf[t];
+    }
+}
+
+static inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+    long g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+static bool box_inside(const wxa_field_view& v, const int32_t blo[3], const int32_t bhi[3]) {
+    for (int d = 0; d < 3; ++d)
+        if (blo[d] < v.lo[d] || bhi[d] > v.lo[d] + v.n[d] || bhi[d] < blo[d]) return false;
+    return true;
+}
+
+}  // namespace wxa
+
+using namespace wxa;
+
+extern "C" {
+
+wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
+                        const double dinv[3], void* stream) {
+    WXA_REQUIRE(E && B && dinv, "null argument");
+    for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
+    if (!yee_E(E) || !yee_B(B)) {
+        set_last_error("wxa_evolve_b: only the Yee staggering is supported");
+        return WXA_ERR_UNSUPPORTED;
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int d = 0; d < 3; ++d) WXA_REQUIRE(E[c].ng[d] >= 1, "EvolveB needs >= 1 guard point on E");
+    const Box3 bx = valid_box(B[0]), by = valid_box(B[1]), bz = valid_box(B[2]);
+    Box3 ub;
+    for (int d = 0; d < 3; ++d) {
+        ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
+        ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
+    }
+    const TileGrid tg = make_tiles(ub);
+    if (tg.ntiles <= 0) return WXA_OK;
+    hipLaunchKernelGGL(evolve_b_kernel, dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(TI, TJ), 0,
+                       (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
+                       make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, tg, dt,
+                       dinv[0], dinv[1], dinv[2]);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
+                        double dt, const double dinv[3], void* stream) {
+    WXA_REQUIRE(E && B && J && dinv, "null argument");
+    for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]) && view_ok(J[c]), "bad field view");
+    if (!yee_E(E) || !yee_B(B) || !yee_E(J)) {
+        set_last_error("wxa_evolve_e: only the Yee staggering is supported");
+        return WXA_ERR_UNSUPPORTED;
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int d = 0; d < 3; ++d) WXA_REQUIRE(B[c].ng[d] >= 1, "EvolveE needs >= 1 guard point on B");
+    const Box3 bx = valid_box(E[0]), by = valid_box(E[1]), bz = valid_box(E[2]);
+    for (int c = 0; c < 3; ++c) {
+        const Box3 bj = valid_box(J[c]);
+        const Box3 be = valid_box(E[c]);
+        for (int d = 0; d < 3; ++d)
+            WXA_REQUIRE(bj.lo[d] == be.lo[d] && bj.hi[d] == be.hi[d], "J and E valid boxes differ");
+    }
+    Box3 ub;
+    for (int d = 0; d < 3; ++d) {
+        ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
+        ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
+    }
+    const TileGrid tg = make_tiles(ub);
+    if (tg.ntiles <= 0) return WXA_OK;
+    hipLaunchKernelGGL(evolve_e_kernel, dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(TI, TJ), 0,
+                       (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
+                       make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), make_devf(J[0]),
+                       make_devf(J[1]), make_devf(J[2]), ub, bx, by, bz, tg, dt, dinv[0], dinv[1], dinv[2]);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_filter_bilinear(const wxa_field_view* src, const wxa_field_view* dst, void* stream) {
+    WXA_REQUIRE(src && dst && view_ok(*src) && view_ok(*dst), "bad field view");
+    WXA_REQUIRE(src->p != dst->p, "src and dst must not alias");
+    for (int d = 0; d < 3; ++d)
+        WXA_REQUIRE(src->lo[d] == dst->lo[d] && src->n[d] == dst->n[d], "src/dst boxes differ");
+    dim3 grid((src->n[0] + 63) / 64, (src->n[1] + 3) / 4, src->n[2]);
+    hipLaunchKernelGGL(filter_bilinear_kernel, grid, dim3(64, 4), 0, (hipStream_t)stream, make_devf(*src),
+                       make_devf(*dst));
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_fill_boundary_periodic(const wxa_field_view* f, const int ng[3], const int periodic[3],
+                                      void* stream) {
+    WXA_REQUIRE(f && view_ok(*f) && ng && periodic, "bad argument");
+    const DevF df = make_devf(*f);
+    int lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) {
+        WXA_REQUIRE(ng[d] <= f->ng[d], "ng exceeds allocated guards");
+        lo[d] = f->lo[d] + f->ng[d];
+        hi[d] = f->lo[d] + f->n[d] - f->ng[d];
+    }
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d] || ng[d] <= 0) continue;
+        const int nc = f->n[d] - 2 * f->ng[d] - f->stag[d];
+        WXA_REQUIRE(ng[d] <= nc, "guard depth exceeds the period");
+        const int v0 = f->lo[d] + f->ng[d], v1 = f->lo[d] + f->n[d] - f->ng[d];
+        for (int side = 0; side < 2; ++side) {
+            BoxN b;
+            for (int e = 0; e < 3; ++e) { b.lo[e] = lo[e]; b.n[e] = hi[e] - lo[e]; }
+            b.lo[d] = side == 0 ? v0 - ng[d] : v1;
+            b.n[d] = ng[d];
+            int s[3] = {0, 0, 0};
+            s[d] = side == 0 ? nc : -nc;
+            const long total = (long)b.n[0] * b.n[1] * b.n[2];
+            hipLaunchKernelGGL(shift_copy_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                               df, b, s[0], s[1], s[2]);
+        }
+        lo[d] = v0 - ng[d];
+        hi[d] = v1 + ng[d];
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_sync_nodal_periodic(const wxa_field_view* f, const int periodic[3], void* stream) {
+    WXA_REQUIRE(f && view_ok(*f) && periodic, "bad argument");
+    const DevF df = make_devf(*f);
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d] || !f->stag[d]) continue;
+        const int nc = f->n[d] - 2 * f->ng[d] - f->stag[d];
+        BoxN b;
+        for (int e = 0; e < 3; ++e) { b.lo[e] = f->lo[e] + f->ng[e]; b.n[e] = f->n[e] - 2 * f->ng[e]; }
+        b.lo[d] = f->lo[d] + f->ng[d] + nc;
+        b.n[d] = 1;
+        int s[3] = {0, 0, 0};
+        s[d] = -nc;
+        const long total = (long)b.n[0] * b.n[1] * b.n[2];
+        if (total <= 0) continue;
+        hipLaunchKernelGGL(shift_copy_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, df, b,
+                           s[0], s[1], s[2]);
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3], const int periodic[3],
+                                     void* stream) {
+    WXA_REQUIRE(f && view_ok(*f) && src_ng && periodic, "bad argument");
+    const DevF df = make_devf(*f);
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d]) continue;
+        WXA_REQUIRE(src_ng[d] <= f->ng[d], "src_ng exceeds allocated guards");
+        const int nc = f->n[d] - 2 * f->ng[d] - f->stag[d];
+        const int s0 = f->lo[d] + f->ng[d] - src_ng[d];
+        const int s1 = f->lo[d] + f->n[d] - f->ng[d] + src_ng[d];
+        const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+        const long total = (long)f->n[da] * nc * f->n[db];
+        hipLaunchKernelGGL(sum_periodic_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, df, d,
+                           nc, s0, s1);
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_pack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], double* buf,
+                        void* stream) {
+    WXA_REQUIRE(f && view_ok(*f) && buf, "bad argument");
+    WXA_REQUIRE(box_inside(*f, blo, bhi), "box outside the allocation");
+    BoxN b;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = blo[d]; b.n[d] = bhi[d] - blo[d]; }
+    const long total = (long)b.n[0] * b.n[1] * b.n[2];
+    if (total == 0) return WXA_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(*f), b,
+                       buf);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_unpack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
+                          const double* buf, int mode, void* stream) {
+    WXA_REQUIRE(f && view_ok(*f) && buf, "bad argument");
+    WXA_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (copy) or 1 (add)");
+    WXA_REQUIRE(box_inside(*f, blo, bhi), "box outside the allocation");
+    BoxN b;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = blo[d]; b.n[d] = bhi[d] - blo[d]; }
+    const long total = (long)b.n[0] * b.n[1] * b.n[2];
+    if (total == 0) return WXA_OK;
+    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(*f), b,
+                       buf, mode);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_field_set_zero(const wxa_field_view* f, void* stream) {
+    WXA_REQUIRE(f && view_ok(*f), "bad field view");
+    WXA_HIP_CHECK(hipMemsetAsync(f->p, 0, sizeof(double) * (size_t)f->kstride * f->n[2], (hipStream_t)stream));
+    return WXA_OK;
+}
+
+}  // extern "C"

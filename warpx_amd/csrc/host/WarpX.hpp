@@ -1,0 +1,312 @@
+// class WarpX of the host layer: the per-step schedule of the explicit FDTD,
+// single-level, periodic branch, with the reference's method names and call order
+// (Source/Evolve/WarpXEvolve.cpp:94-347 Evolve, :354-455 OneStep_nosub,
+//  :473-531 ExplicitFillBoundaryEBUpdateAux, :533-581 HandleParticlesAtBoundaries,
+//  :583-652 SyncCurrentAndRho, :65-93 Synchronize; Source/FieldSolver/WarpXPushFieldsEM.cpp:877-1011;
+//  Source/Parallelization/WarpXComm.cpp:699-827,1073-1240,1357-1424).
+#ifndef WXA_HOST_WARPX_HPP_
+#define WXA_HOST_WARPX_HPP_
+
+#include "WarpXParticleContainer.hpp"
+
+namespace wxa::host {
+
+// Source/Parallelization/GuardCellManager.{H,cpp}: guard depths, 3-D FDTD subset of Init (:33-344)
+struct guardCellManager {
+    amrex::IntVect ng_alloc_EB, ng_alloc_J, ng_depos_J, ng_FieldSolver, ng_FieldGather, ng_UpdateAux;
+
+    void Init(const amrex::Real dt, const std::array<amrex::Real, 3>& dx, const int nox, const bool use_filter,
+              const amrex::IntVect& bilinear_filter_stencil_length) {
+        constexpr double c = 299'792'458.;
+        for (int d = 0; d < 3; ++d) {
+            const int ng_tmp = nox;                                   // :62-64 (no subcycling / MR)
+            ng_alloc_EB[d] = (ng_tmp % 2) ? ng_tmp + 1 : ng_tmp;      // :83-85 always even
+            int ngJ = ng_tmp;                                         // :96-98
+            ngJ += static_cast<int>(std::ceil(c * 0.5 * dt / dx[d])); // :161 half a step of motion
+            ng_depos_J[d] = ngJ;                                      // :166
+            ng_alloc_J[d] = ngJ + (use_filter ? bilinear_filter_stencil_length[d] - 1 : 0);  // :169-172
+            ng_FieldSolver[d] = 1;                                    // :276-278 Yee: GetMaxGuardCell
+            ng_FieldGather[d] = (nox + 1) / 2;                        // :314-316 (staggered, galerkin: +0)
+            ng_UpdateAux[d] = 0;
+        }
+        ng_FieldGather = amrex::min(ng_FieldGather, ng_alloc_EB);     // :337
+    }
+};
+
+// Source/FieldSolver/FiniteDifferenceSolver/FiniteDifferenceSolver.{H,cpp} (Yee, Cartesian)
+class FiniteDifferenceSolver {
+public:
+    FiniteDifferenceSolver(WarpXContext* ctx, const std::array<amrex::Real, 3>& cell_size) : m_ctx(ctx) {
+        // CartesianYeeAlgorithm::InitializeStencilCoefficients (CartesianYeeAlgorithm.H:29-43)
+        for (int d = 0; d < 3; ++d) m_stencil_coefs[d] = 1.0 / cell_size[d];
+    }
+    // FiniteDifferenceSolver.H:55-59
+    void EvolveB(ablastr::fields::MultiFabRegister& fields, int lev, PatchType patch_type, amrex::Real dt) {
+        using warpx::fields::FieldType;
+        if (patch_type != PatchType::fine) throw std::runtime_error("single level: fine patch only");
+        auto E = fields.get_alldirs(FieldType::Efield_fp, lev);
+        auto B = fields.get_alldirs(FieldType::Bfield_fp, lev);
+        const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
+        const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
+        check(m_ctx->be->evolve_b(Ev, Bv, dt, m_stencil_coefs.data(), m_ctx->stream), "evolve_b");
+    }
+    // FiniteDifferenceSolver.H:61-66
+    void EvolveE(ablastr::fields::MultiFabRegister& fields, int lev, PatchType patch_type,
+                 const ablastr::fields::VectorField& Efield, amrex::Real dt) {
+        using warpx::fields::FieldType;
+        if (patch_type != PatchType::fine) throw std::runtime_error("single level: fine patch only");
+        auto B = fields.get_alldirs(FieldType::Bfield_fp, lev);
+        auto J = fields.get_alldirs(FieldType::current_fp, lev);
+        const wxa_field_view Ev[3] = {Efield[0]->view(), Efield[1]->view(), Efield[2]->view()};
+        const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
+        const wxa_field_view Jv[3] = {J[0]->view(), J[1]->view(), J[2]->view()};
+        check(m_ctx->be->evolve_e(Ev, Bv, Jv, dt, m_stencil_coefs.data(), m_ctx->stream), "evolve_e");
+    }
+
+private:
+    WarpXContext* m_ctx;
+    std::array<amrex::Real, 3> m_stencil_coefs{};
+};
+
+class WarpX {
+public:
+    static constexpr bool sync_nodal_points = true;  // Source/WarpX.H:1523
+
+    WarpX(const Backend* be, const wxa_sim_config& cfg, const wxa_comm* comm)
+        : m_be(be), m_cfg(cfg), m_fields(be), mypc(std::make_unique<MultiParticleContainer>(&m_ctx)) {
+        using warpx::fields::FieldType;
+        using ablastr::fields::Direction;
+        if (cfg.nox < 1 || cfg.nox > 3) throw std::runtime_error("algo.particle_shape must be 1..3");
+        m_ctx.be = be;
+        m_ctx.nox = cfg.nox;
+        m_ctx.galerkin_interpolation = cfg.galerkin != 0;
+        m_ctx.particle_pusher_algo = (ParticlePusherAlgo)cfg.particle_pusher;
+        m_ctx.current_deposition_algo = (CurrentDepositionAlgo)cfg.current_deposition;
+        amrex::IntVect blo, bhi;
+        for (int d = 0; d < 3; ++d) {
+            if (cfg.nbricks[d] < 1 || cfg.coord[d] < 0 || cfg.coord[d] >= cfg.nbricks[d])
+                throw std::runtime_error("bad brick decomposition");
+            if (cfg.n_cell[d] % cfg.nbricks[d] != 0) throw std::runtime_error("n_cell must divide evenly into bricks");
+            m_ctx.prob_lo[d] = cfg.prob_lo[d];
+            m_ctx.prob_hi[d] = cfg.prob_hi[d];
+            m_ctx.dx[d] = (cfg.prob_hi[d] - cfg.prob_lo[d]) / cfg.n_cell[d];
+            m_ctx.dinv[d] = 1.0 / m_ctx.dx[d];
+            const int nb = cfg.n_cell[d] / cfg.nbricks[d];
+            blo[d] = cfg.coord[d] * nb;
+            bhi[d] = blo[d] + nb - 1;
+            m_ctx.brick_plo[d] = cfg.prob_lo[d] + blo[d] * m_ctx.dx[d];
+            m_ctx.brick_phi[d] = (cfg.coord[d] == cfg.nbricks[d] - 1) ? cfg.prob_hi[d]
+                                                                       : cfg.prob_lo[d] + (bhi[d] + 1) * m_ctx.dx[d];
+        }
+        m_ctx.brick_box = amrex::Box(blo, bhi);
+        ComputeDt();
+        // warpx.use_filter: 1-pass bilinear, stencil length npass+1 = 2 (BilinearFilter.cpp:63-68)
+        use_filter = cfg.use_filter != 0;
+        guard_cells.Init(dt[0], m_ctx.dx, cfg.nox, use_filter, amrex::IntVect(2));
+        m_ctx.ng_alloc_EB = guard_cells.ng_alloc_EB;
+        m_ctx.ng_depos_J = guard_cells.ng_depos_J;
+        for (int d = 0; d < 3; ++d)
+            if (m_ctx.brick_box.length(d) < guard_cells.ng_alloc_J[d] + 1)
+                throw std::runtime_error("brick thinner than the guard depth");
+        m_comm = std::make_unique<BrickComm>(be, comm, cfg.nbricks, cfg.coord);
+
+        // AllocLevelMFs (Source/WarpX.cpp:2078-2700): Yee nodal flags :2117-2125
+        const amrex::IntVect Etype[3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
+        const amrex::IntVect Btype[3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int d = 0; d < 3; ++d) {
+            m_fields.alloc_init(FieldType::Efield_fp, Direction{d}, 0, m_ctx.brick_box, Etype[d], guard_cells.ng_alloc_EB);
+            m_fields.alloc_init(FieldType::Bfield_fp, Direction{d}, 0, m_ctx.brick_box, Btype[d], guard_cells.ng_alloc_EB);
+            m_fields.alloc_init(FieldType::current_fp, Direction{d}, 0, m_ctx.brick_box, Etype[d], guard_cells.ng_alloc_J);
+            // aux = alias of fp at level 0 (Source/WarpX.cpp:2489-2501)
+            m_fields.alias_init(FieldType::Efield_aux, FieldType::Efield_fp, Direction{d}, 0);
+            m_fields.alias_init(FieldType::Bfield_aux, FieldType::Bfield_fp, Direction{d}, 0);
+        }
+        if (use_filter)
+            m_filter_tmp = std::make_unique<amrex::MultiFab>(be, m_ctx.brick_box, amrex::IntVect(1, 1, 1), guard_cells.ng_alloc_J);
+        m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, m_ctx.dx);
+        sort_intervals = cfg.sort_interval;
+    }
+
+    // Source/Evolve/WarpXComputeDt.cpp:41-102 with CartesianYeeAlgorithm::ComputeMaxDt (:48-56)
+    void ComputeDt() {
+        constexpr double c = 299'792'458.;
+        const auto& dx = m_ctx.dx;
+        const amrex::Real deltat =
+            m_cfg.cfl * 1.0 / (std::sqrt(1.0 / (dx[0] * dx[0]) + 1.0 / (dx[1] * dx[1]) + 1.0 / (dx[2] * dx[2])) * c);
+        dt.assign(1, deltat);
+    }
+
+    // Source/Evolve/WarpXEvolve.cpp:94-347
+    void Evolve(int numsteps) {
+        const int numsteps_max = numsteps;
+        for (int step = 0; step < numsteps_max; ++step) {
+            // :142-145 if synchronized, push velocity backward one half step
+            ExplicitFillBoundaryEBUpdateAux();
+            // :157-166 ionization / collisions / QED: not on this path
+            OneStep_nosub(cur_time);
+            // :222-226 at the end of the last step, push p by 0.5*dt to synchronize
+            if (step == numsteps_max - 1) Synchronize();
+            ++istep;
+            cur_time += dt[0];
+            // :246 MoveWindow: off
+            HandleParticlesAtBoundaries(step, cur_time, 0);  // :256
+        }
+        m_be->stream_sync(m_ctx.stream);
+    }
+
+    // :354-455
+    void OneStep_nosub(amrex::Real a_cur_time) {
+        PushParticlesandDeposit(a_cur_time);                     // :366
+        SyncCurrentAndRho();                                     // :373
+        // :416-419 EvolveF/G: no-ops
+        EvolveB(0.5 * dt[0], DtType::FirstHalf);                 // :421
+        FillBoundaryB(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);  // :422
+        EvolveE(dt[0]);                                          // :426
+        FillBoundaryE(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);  // :433
+        EvolveB(0.5 * dt[0], DtType::SecondHalf);                // :437
+    }
+
+    // :1101-1180
+    void PushParticlesandDeposit(amrex::Real a_cur_time, bool skip_current = false,
+                                 PushType push_type = PushType::Explicit) {
+        mypc->Evolve(m_fields, 0, "current_fp", a_cur_time, dt[0], DtType::Full, skip_current, push_type);
+    }
+
+    // :583-652 -> SyncCurrent (WarpXComm.cpp:1073-1240), single level
+    void SyncCurrentAndRho() {
+        PhaseTimer t(&m_ctx, kSyncCurrent);  // "WarpX::SyncCurrent()"
+        using warpx::fields::FieldType;
+        auto J = m_fields.get_alldirs(FieldType::current_fp, 0);
+        for (int idim = 0; idim < 3; ++idim) {
+            if (use_filter) ApplyFilterJ(J, 0, idim);  // WarpXComm.cpp:1233-1236
+            SumBoundaryJ(J, 0, idim);                  // :1237
+        }
+    }
+
+    // WarpXComm.cpp:1357-1374: filter into a temporary with the same guards, copy back
+    void ApplyFilterJ(const ablastr::fields::VectorField& current, int /*lev*/, int idim) {
+        amrex::MultiFab& J = *current[idim];
+        // the temporary only provides storage: re-type its view to this component
+        wxa_field_view tmp = J.view();
+        tmp.p = m_filter_tmp->view().p;
+        if (m_filter_tmp->bytes() < sizeof(double) * (size_t)tmp.kstride * tmp.n[2])
+            throw std::runtime_error("filter scratch too small");
+        check(m_be->filter_bilinear(&J.view(), &tmp, m_ctx.stream), "filter_bilinear");
+        check(m_be->memcpy_async(J.view().p, tmp.p, sizeof(double) * (size_t)tmp.kstride * tmp.n[2], m_ctx.stream),
+              "memcpy");
+    }
+
+    // WarpXComm.cpp:1386-1424 -> WarpXSumGuardCells (WarpXSumGuardCells.cpp:17-24)
+    void SumBoundaryJ(const ablastr::fields::VectorField& current, int /*lev*/, int idim) {
+        amrex::MultiFab& J = *current[idim];
+        amrex::IntVect ng_depos_J = guard_cells.ng_depos_J;
+        if (use_filter) ng_depos_J = ng_depos_J + amrex::IntVect(2) - amrex::IntVect(1);  // :1413-1416
+        ng_depos_J = amrex::min(ng_depos_J, J.nGrowVect());                               // :1417-1420
+        m_comm->SumBoundary(J, ng_depos_J, /*refresh_guards=*/safe_guard_cells, m_ctx.stream);
+    }
+
+    // Source/FieldSolver/WarpXPushFieldsEM.cpp:877-927
+    void EvolveB(amrex::Real a_dt, DtType /*a_dt_type*/) {
+        PhaseTimer t(&m_ctx, kEvolveB);  // "WarpX::EvolveB()"
+        m_fdtd_solver_fp->EvolveB(m_fields, 0, PatchType::fine, a_dt);
+    }
+    // :930-1011
+    void EvolveE(amrex::Real a_dt) {
+        PhaseTimer t(&m_ctx, kEvolveE);  // "WarpX::EvolveE()"
+        using warpx::fields::FieldType;
+        m_fdtd_solver_fp->EvolveE(m_fields, 0, PatchType::fine, m_fields.get_alldirs(FieldType::Efield_fp, 0), a_dt);
+    }
+
+    // Source/Parallelization/WarpXComm.cpp:644-660,699-827 -> ablastr FillBoundary (Communication.cpp:71-115)
+    void FillBoundaryE(const amrex::IntVect& ng, std::optional<bool> nodal_sync = std::nullopt) {
+        FillBoundaryVector(warpx::fields::FieldType::Efield_fp, ng, nodal_sync.value_or(false));
+    }
+    void FillBoundaryB(const amrex::IntVect& ng, std::optional<bool> nodal_sync = std::nullopt) {
+        FillBoundaryVector(warpx::fields::FieldType::Bfield_fp, ng, nodal_sync.value_or(false));
+    }
+    void FillBoundaryAux(const amrex::IntVect& /*ng*/) {}
+    // WarpXComm.cpp:387-419: aux aliases fp at level 0 -> nothing to copy
+    void UpdateAuxilaryData() {}
+
+    // WarpXEvolve.cpp:473-531
+    void ExplicitFillBoundaryEBUpdateAux() {
+        using warpx::fields::FieldType;
+        if (is_synchronized) {
+            FillBoundaryE(guard_cells.ng_alloc_EB);
+            FillBoundaryB(guard_cells.ng_alloc_EB);
+            UpdateAuxilaryData();
+            FillBoundaryAux(guard_cells.ng_UpdateAux);
+            auto E = m_fields.get_alldirs(FieldType::Efield_aux, 0);
+            auto B = m_fields.get_alldirs(FieldType::Bfield_aux, 0);
+            mypc->PushP(0, -0.5 * dt[0], *E[0], *E[1], *E[2], *B[0], *B[1], *B[2]);
+            is_synchronized = false;
+        } else {
+            FillBoundaryE(guard_cells.ng_FieldGather);
+            FillBoundaryB(guard_cells.ng_FieldGather);
+            UpdateAuxilaryData();
+            FillBoundaryAux(guard_cells.ng_UpdateAux);
+        }
+    }
+
+    // WarpXEvolve.cpp:65-93
+    void Synchronize() {
+        using warpx::fields::FieldType;
+        FillBoundaryE(guard_cells.ng_FieldGather);
+        FillBoundaryB(guard_cells.ng_FieldGather);
+        UpdateAuxilaryData();
+        FillBoundaryAux(guard_cells.ng_UpdateAux);
+        auto E = m_fields.get_alldirs(FieldType::Efield_aux, 0);
+        auto B = m_fields.get_alldirs(FieldType::Bfield_aux, 0);
+        mypc->PushP(0, 0.5 * dt[0], *E[0], *E[1], *E[2], *B[0], *B[1], *B[2]);
+        is_synchronized = true;
+    }
+
+    // WarpXEvolve.cpp:533-581
+    void HandleParticlesAtBoundaries(int step, amrex::Real /*cur_time*/, int num_moved) {
+        PhaseTimer t(&m_ctx, kRedistribute);
+        // ApplyBoundaryConditions: early return, all particle boundaries periodic
+        mypc->RedistributeLocal(num_moved + 1, *m_comm);                      // :559
+        if (sort_intervals > 0 && ((step + 1) % sort_intervals == 0))          // :575-580
+            mypc->SortParticlesByBin(amrex::IntVect(1));
+    }
+
+    // ---- accessors used by the C API ----
+    ablastr::fields::MultiFabRegister& fields() { return m_fields; }
+    MultiParticleContainer& GetPartContainer() { return *mypc; }
+    WarpXContext& context() { return m_ctx; }
+    amrex::Real getdt(int lev) const { return dt[lev]; }
+    int64_t getistep() const { return istep; }
+    BrickComm& comm() { return *m_comm; }
+
+    guardCellManager guard_cells;
+    bool use_filter = true;          // Source/WarpX.cpp:158
+    bool safe_guard_cells = false;   // warpx.safe_guard_cells
+    bool is_synchronized = true;     // Source/WarpX.H:1520
+    int sort_intervals = -1;         // Source/WarpX.cpp:1335 (GPU default 4; set by the config)
+
+private:
+    void FillBoundaryVector(warpx::fields::FieldType ft, const amrex::IntVect& ng, bool nodal_sync) {
+        PhaseTimer t(&m_ctx, kFillBoundary);
+        auto F = m_fields.get_alldirs(ft, 0);
+        for (int d = 0; d < 3; ++d) {
+            if (!ng.allLE(F[d]->nGrowVect()))  // WarpXComm.cpp:755-759
+                throw std::runtime_error("Error: in FillBoundary, requested more guard cells than allocated");
+            m_comm->FillBoundary(*F[d], ng, nodal_sync, m_ctx.stream);
+        }
+    }
+
+    const Backend* m_be;
+    wxa_sim_config m_cfg;
+    WarpXContext m_ctx;
+    ablastr::fields::MultiFabRegister m_fields;
+    std::unique_ptr<MultiParticleContainer> mypc;
+    std::unique_ptr<FiniteDifferenceSolver> m_fdtd_solver_fp;
+    std::unique_ptr<BrickComm> m_comm;
+    std::unique_ptr<amrex::MultiFab> m_filter_tmp;
+    std::vector<amrex::Real> dt;
+    amrex::Real cur_time = 0.0;
+    int64_t istep = 0;
+};
+
+}  // namespace wxa::host
+#endif

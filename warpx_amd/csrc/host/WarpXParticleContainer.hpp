@@ -1,0 +1,339 @@
+// Particle containers of the host layer: the operator surface that
+// Source/Evolve/WarpXEvolve.cpp drives on the explicit FDTD branch
+// (WarpXParticleContainer / PhysicalParticleContainer / MultiParticleContainer;
+// Source/Particles/WarpXParticleContainer.H:111-509,
+// Source/Particles/PhysicalParticleContainer.cpp:1812-2095,2368-2516,2549-2786,
+// Source/Particles/MultiParticleContainer.cpp:460-500,615-654).
+// One brick per process: a container holds one pure-SoA tile on the device.
+#ifndef WXA_HOST_PARTICLES_HPP_
+#define WXA_HOST_PARTICLES_HPP_
+
+#include "BrickComm.hpp"
+
+namespace wxa::host {
+
+// What the reference reads from `WarpX::` statics inside the particle operators
+// (WarpXParticleContainer.cpp:481-816, PhysicalParticleContainer.cpp:2603-2604,2656).
+struct WarpXContext {
+    const Backend* be = nullptr;
+    int nox = 1;
+    bool galerkin_interpolation = true;
+    ParticlePusherAlgo particle_pusher_algo = ParticlePusherAlgo::Boris;
+    CurrentDepositionAlgo current_deposition_algo = CurrentDepositionAlgo::Esirkepov;
+    std::array<double, 3> prob_lo{}, prob_hi{}, dx{}, dinv{};
+    amrex::Box brick_box;              // this brick's cells in global index space
+    std::array<double, 3> brick_plo{}, brick_phi{};
+    amrex::IntVect ng_alloc_EB, ng_depos_J;
+    void* stream = nullptr;
+    // per-phase device timers, named after the reference's profiler regions
+    bool timers_on = false;
+    double ms[8] = {0};
+    int64_t counts[8] = {0};
+
+    // WarpX::LowerCorner(box.grow(ng)) + lbound (Source/WarpX.cpp:2851-2875)
+    wxa_grid_geom geom(const amrex::IntVect& ng) const {
+        wxa_grid_geom g{};
+        for (int d = 0; d < 3; ++d) {
+            const int lo = brick_box.lo[d] - ng[d];
+            g.lo[d] = lo;
+            g.xyzmin[d] = prob_lo[d] + (double)lo * dx[d];
+            g.dinv[d] = dinv[d];
+        }
+        return g;
+    }
+};
+
+enum Phase { kGatherAndPush = 0, kCurrentDeposition = 1, kSyncCurrent = 2, kEvolveB = 3, kEvolveE = 4,
+             kFillBoundary = 5, kRedistribute = 6, kOther = 7 };
+
+// RAII region timer (HIP events); mirrors WARPX_PROFILE regions
+struct PhaseTimer {
+    WarpXContext* c; int id; void* e0 = nullptr; void* e1 = nullptr;
+    PhaseTimer(WarpXContext* ctx, int phase) : c(ctx), id(phase) {
+        if (c->timers_on && c->be->event_create) {
+            e0 = c->be->event_create(); e1 = c->be->event_create();
+            c->be->event_record(e0, c->stream);
+        }
+    }
+    ~PhaseTimer() {
+        if (e0) {
+            c->be->event_record(e1, c->stream);
+            c->ms[id] += c->be->event_elapsed_ms(e0, e1);
+            c->counts[id] += 1;
+            c->be->event_destroy(e0); c->be->event_destroy(e1);
+        }
+    }
+};
+
+inline void check(int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + " returned status " + std::to_string(rc));
+}
+
+// Pure-SoA tile on the device, PIdx order (NamedComponentParticleContainer.H:23-40)
+class ParticleTile {
+public:
+    explicit ParticleTile(const Backend* be) : m_be(be) {}
+    ~ParticleTile() { release(); }
+    ParticleTile(const ParticleTile&) = delete;
+    ParticleTile& operator=(const ParticleTile&) = delete;
+
+    int64_t numParticles() const { return m_np; }
+    int64_t capacity() const { return m_cap; }
+    void reserve(int64_t n) {
+        if (n <= m_cap) return;
+        const int64_t cap = n + n / 16 + 1024;
+        double* nd = static_cast<double*>(m_be->dmalloc(sizeof(double) * 7 * (size_t)cap));
+        uint64_t* ni = static_cast<uint64_t*>(m_be->dmalloc(sizeof(uint64_t) * (size_t)cap));
+        if (!nd || !ni) throw std::runtime_error("ParticleTile: allocation failed");
+        if (m_np > 0) {
+            for (int c = 0; c < 7; ++c)
+                m_be->memcpy_async(nd + c * cap, m_data + c * m_cap, sizeof(double) * (size_t)m_np, nullptr);
+            m_be->memcpy_async(ni, m_id, sizeof(uint64_t) * (size_t)m_np, nullptr);
+            m_be->stream_sync(nullptr);
+        }
+        release();
+        m_data = nd; m_id = ni; m_cap = cap;
+    }
+    void resize(int64_t n) { reserve(n); m_np = n; }
+    double* comp(int c) const { return m_data + (int64_t)c * m_cap; }
+    uint64_t* idcpu() const { return m_id; }
+    wxa_particle_view view(int64_t offset = 0, int64_t count = -1) const {
+        wxa_particle_view v{};
+        v.x = comp(0) + offset; v.y = comp(1) + offset; v.z = comp(2) + offset; v.w = comp(3) + offset;
+        v.ux = comp(4) + offset; v.uy = comp(5) + offset; v.uz = comp(6) + offset;
+        v.idcpu = m_id ? m_id + offset : nullptr;
+        v.np = count < 0 ? m_np - offset : count;
+        return v;
+    }
+    void swap(ParticleTile& o) {
+        std::swap(m_data, o.m_data); std::swap(m_id, o.m_id); std::swap(m_cap, o.m_cap); std::swap(m_np, o.m_np);
+    }
+
+private:
+    void release() {
+        if (m_data) m_be->dfree(m_data);
+        if (m_id) m_be->dfree(m_id);
+        m_data = nullptr; m_id = nullptr; m_cap = 0;
+    }
+    const Backend* m_be;
+    double* m_data = nullptr;
+    uint64_t* m_id = nullptr;
+    int64_t m_cap = 0, m_np = 0;
+};
+
+class WarpXParticleContainer {
+public:
+    WarpXParticleContainer(WarpXContext* ctx, double charge, double mass)
+        : m_ctx(ctx), m_tile(ctx->be), m_spare(ctx->be), charge(charge), mass(mass) {
+        m_sendbuf.be = ctx->be; m_recvbuf.be = ctx->be;
+        check(ctx->be->workspace_create(&m_ws), "workspace_create");
+    }
+    virtual ~WarpXParticleContainer() { if (m_ws) m_ctx->be->workspace_destroy(m_ws); }
+
+    // Source/Particles/WarpXParticleContainer.H:150-154
+    virtual void Evolve(ablastr::fields::MultiFabRegister& fields, int lev, const std::string& current_fp_string,
+                        amrex::Real t, amrex::Real dt, DtType a_dt_type = DtType::Full,
+                        bool skip_deposition = false, PushType push_type = PushType::Explicit) = 0;
+    // :180-186
+    virtual void PushP(int lev, amrex::Real dt, const amrex::MultiFab& Ex, const amrex::MultiFab& Ey,
+                       const amrex::MultiFab& Ez, const amrex::MultiFab& Bx, const amrex::MultiFab& By,
+                       const amrex::MultiFab& Bz) = 0;
+
+    // Source/Particles/WarpXParticleContainer.cpp:352-827 (single tile = whole brick)
+    void DepositCurrent(amrex::MultiFab* jx, amrex::MultiFab* jy, amrex::MultiFab* jz, amrex::Real dt,
+                        amrex::Real relative_time) {
+        if (m_tile.numParticles() == 0) return;
+        const wxa_field_view J[3] = {jx->view(), jy->view(), jz->view()};
+        const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_depos_J);
+        const wxa_particle_view p = m_tile.view();
+        check(m_ctx->be->deposit_current(&p, J, &g, charge, dt, relative_time, m_ctx->nox,
+                                         (int)m_ctx->current_deposition_algo, m_ws, m_ctx->stream),
+              "deposit_current");
+    }
+
+    // amrex SortParticlesByBin with bin = one cell (MultiParticleContainer.cpp:615-621)
+    void SortParticlesByBin(const amrex::IntVect& /*bin_size*/) {
+        const int64_t np = m_tile.numParticles();
+        if (np == 0) return;
+        m_spare.resize(np);
+        const wxa_particle_view src = m_tile.view(), dst = m_spare.view();
+        int32_t lo[3], nc[3];
+        for (int d = 0; d < 3; ++d) { lo[d] = m_ctx->brick_box.lo[d]; nc[d] = m_ctx->brick_box.length(d); }
+        check(m_ctx->be->sort_particles_by_cell(&src, &dst, m_ctx->brick_plo.data(), m_ctx->dinv.data(), lo, nc,
+                                                m_ws, m_ctx->stream),
+              "sort_particles_by_cell");
+        m_tile.swap(m_spare);
+    }
+
+    // amrex ParticleContainer::Redistribute restricted to what the periodic brick
+    // decomposition needs: periodic wrap, then hand particles that left the brick to the
+    // +/- neighbour, direction by direction (a particle moves < 1 cell per step).
+    void Redistribute(BrickComm& comm) {
+        const Backend* be = m_ctx->be;
+        int periodic[3] = {1, 1, 1};
+        if (m_tile.numParticles() > 0) {
+            const wxa_particle_view p = m_tile.view();
+            check(be->enforce_periodic(&p, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic, m_ctx->stream),
+                  "enforce_periodic");
+        }
+        for (int d = 0; d < 3; ++d) {
+            if (comm.self_periodic(d)) continue;
+            const int64_t np = m_tile.numParticles();
+            int64_t cnt[3] = {np, 0, 0};
+            m_spare.resize(np);
+            if (np > 0) {
+                const wxa_particle_view src = m_tile.view(), dst = m_spare.view();
+                check(be->partition_particles(&src, &dst, d, m_ctx->brick_plo[d], m_ctx->brick_phi[d], cnt, m_ws,
+                                              m_ctx->stream),
+                      "partition_particles");
+                m_tile.swap(m_spare);  // m_tile = [stay | to-minus | to-plus]
+            }
+            int64_t from_plus = 0, from_minus = 0;
+            comm.exchange_counts(d, cnt[1], cnt[2], from_plus, from_minus);
+            const int64_t nstay = cnt[0], nsend = cnt[1] + cnt[2], nrecv = from_plus + from_minus;
+            // staging: one message per peer = 8 SoA rows (7 reals + idcpu) of n entries
+            m_sendbuf.reserve(64 * (size_t)std::max<int64_t>(nsend, 1));
+            m_recvbuf.reserve(64 * (size_t)std::max<int64_t>(nrecv, 1));
+            char* smb = static_cast<char*>(m_sendbuf.p);
+            auto pack_msg = [&](char* dstb, int64_t off, int64_t n) {
+                for (int c = 0; c < 7; ++c)
+                    be->memcpy_async(dstb + 8 * (int64_t)c * n, m_tile.comp(c) + off, 8 * (size_t)n, m_ctx->stream);
+                be->memcpy_async(dstb + 8 * 7 * n, m_tile.idcpu() + off, 8 * (size_t)n, m_ctx->stream);
+            };
+            char* msg_minus = smb;
+            char* msg_plus = smb + 64 * cnt[1];
+            if (cnt[1] > 0) pack_msg(msg_minus, nstay, cnt[1]);
+            if (cnt[2] > 0) pack_msg(msg_plus, nstay + cnt[1], cnt[2]);
+            char* rb = static_cast<char*>(m_recvbuf.p);
+            char* rmsg_plus = rb;
+            char* rmsg_minus = rb + 64 * from_plus;
+            comm.exchange_raw(d, msg_minus, 64 * cnt[1], msg_plus, 64 * cnt[2], rmsg_plus, 64 * from_plus,
+                              rmsg_minus, 64 * from_minus, m_ctx->stream);
+            m_tile.resize(nstay);          // drop the leavers
+            m_tile.reserve(nstay + nrecv);
+            auto unpack_msg = [&](const char* srcb, int64_t off, int64_t n) {
+                for (int c = 0; c < 7; ++c)
+                    be->memcpy_async(m_tile.comp(c) + off, srcb + 8 * (int64_t)c * n, 8 * (size_t)n, m_ctx->stream);
+                be->memcpy_async(m_tile.idcpu() + off, srcb + 8 * 7 * n, 8 * (size_t)n, m_ctx->stream);
+            };
+            // reserve() may have reallocated: it preserves the first numParticles() entries
+            if (from_plus > 0) unpack_msg(rmsg_plus, nstay, from_plus);
+            if (from_minus > 0) unpack_msg(rmsg_minus, nstay + from_plus, from_minus);
+            m_tile.resize(nstay + nrecv);
+            be->stream_sync(m_ctx->stream);
+        }
+    }
+
+    ParticleTile& tile() { return m_tile; }
+    amrex::Long TotalNumberOfParticles() const { return m_tile.numParticles(); }
+
+protected:
+    WarpXContext* m_ctx;
+    ParticleTile m_tile, m_spare;
+    DeviceBuffer m_sendbuf, m_recvbuf;
+    void* m_ws = nullptr;
+
+public:
+    amrex::ParticleReal charge, mass;
+};
+
+class PhysicalParticleContainer : public WarpXParticleContainer {
+public:
+    using WarpXParticleContainer::WarpXParticleContainer;
+
+    // Source/Particles/PhysicalParticleContainer.cpp:1812-2095: PushPX then DepositCurrent
+    void Evolve(ablastr::fields::MultiFabRegister& fields, int lev, const std::string& current_fp_string,
+                amrex::Real /*t*/, amrex::Real dt, DtType /*a_dt_type*/ = DtType::Full, bool skip_deposition = false,
+                PushType push_type = PushType::Explicit) override {
+        using warpx::fields::FieldType;
+        if (push_type != PushType::Explicit) throw std::runtime_error("only the explicit push is supported");
+        if (current_fp_string != "current_fp") throw std::runtime_error("unknown current field");
+        auto E = fields.get_alldirs(FieldType::Efield_aux, lev);
+        auto B = fields.get_alldirs(FieldType::Bfield_aux, lev);
+        auto J = fields.get_alldirs(FieldType::current_fp, lev);
+        {
+            PhaseTimer t(m_ctx, kGatherAndPush);  // "PhysicalParticleContainer::Evolve::GatherAndPush"
+            PushPX(*E[0], *E[1], *E[2], *B[0], *B[1], *B[2], dt);
+        }
+        if (!skip_deposition) {
+            PhaseTimer t(m_ctx, kCurrentDeposition);  // "...::DepositCurrent::CurrentDeposition"
+            // :2029 relative_time = -0.5*dt: deposit at the half step
+            DepositCurrent(J[0], J[1], J[2], dt, -0.5 * dt);
+        }
+    }
+
+    // :2549-2786
+    void PushPX(const amrex::MultiFab& Ex, const amrex::MultiFab& Ey, const amrex::MultiFab& Ez,
+                const amrex::MultiFab& Bx, const amrex::MultiFab& By, const amrex::MultiFab& Bz, amrex::Real dt) {
+        if (m_tile.numParticles() == 0) return;
+        const wxa_field_view E[3] = {Ex.view(), Ey.view(), Ez.view()};
+        const wxa_field_view B[3] = {Bx.view(), By.view(), Bz.view()};
+        const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
+        const wxa_particle_view p = m_tile.view();
+        check(m_ctx->be->gather_push(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
+                                     (int)m_ctx->particle_pusher_algo, m_ctx->stream),
+              "gather_push");
+    }
+
+    // :2368-2516
+    void PushP(int /*lev*/, amrex::Real dt, const amrex::MultiFab& Ex, const amrex::MultiFab& Ey,
+               const amrex::MultiFab& Ez, const amrex::MultiFab& Bx, const amrex::MultiFab& By,
+               const amrex::MultiFab& Bz) override {
+        if (m_tile.numParticles() == 0) return;
+        const wxa_field_view E[3] = {Ex.view(), Ey.view(), Ez.view()};
+        const wxa_field_view B[3] = {Bx.view(), By.view(), Bz.view()};
+        const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
+        const wxa_particle_view p = m_tile.view();
+        check(m_ctx->be->push_p(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
+                                (int)m_ctx->particle_pusher_algo, m_ctx->stream),
+              "push_p");
+    }
+};
+
+// Source/Particles/MultiParticleContainer.{H,cpp}
+class MultiParticleContainer {
+public:
+    explicit MultiParticleContainer(WarpXContext* ctx) : m_ctx(ctx) {}
+
+    int AddSpecies(double charge, double mass) {
+        allcontainers.push_back(std::make_unique<PhysicalParticleContainer>(m_ctx, charge, mass));
+        return (int)allcontainers.size() - 1;
+    }
+    WarpXParticleContainer& GetParticleContainer(int i) { return *allcontainers.at(i); }
+    int nSpecies() const { return (int)allcontainers.size(); }
+
+    // MultiParticleContainer.cpp:460-482: zero J once, then every species
+    void Evolve(ablastr::fields::MultiFabRegister& fields, int lev, const std::string& current_fp_string,
+                amrex::Real t, amrex::Real dt, DtType a_dt_type = DtType::Full, bool skip_deposition = false,
+                PushType push_type = PushType::Explicit) {
+        using warpx::fields::FieldType;
+        if (!skip_deposition) {
+            for (int d = 0; d < 3; ++d)
+                fields.get(FieldType::current_fp, ablastr::fields::Direction{d}, lev)->setVal(0.0, m_ctx->stream);
+        }
+        for (auto& pc : allcontainers)
+            pc->Evolve(fields, lev, current_fp_string, t, dt, a_dt_type, skip_deposition, push_type);
+    }
+    // :492-500
+    void PushP(int lev, amrex::Real dt, const amrex::MultiFab& Ex, const amrex::MultiFab& Ey,
+               const amrex::MultiFab& Ez, const amrex::MultiFab& Bx, const amrex::MultiFab& By,
+               const amrex::MultiFab& Bz) {
+        PhaseTimer t(m_ctx, kOther);  // (de)synchronisation half-pushes, twice per Evolve call
+        for (auto& pc : allcontainers) pc->PushP(lev, dt, Ex, Ey, Ez, Bx, By, Bz);
+    }
+    // :651-654
+    void RedistributeLocal(int /*num_ghost*/, BrickComm& comm) {
+        for (auto& pc : allcontainers) pc->Redistribute(comm);
+    }
+    // :615-621
+    void SortParticlesByBin(const amrex::IntVect& bin_size) {
+        for (auto& pc : allcontainers) pc->SortParticlesByBin(bin_size);
+    }
+
+private:
+    WarpXContext* m_ctx;
+    std::vector<std::unique_ptr<WarpXParticleContainer>> allcontainers;
+};
+
+}  // namespace wxa::host
+#endif

@@ -1,0 +1,65 @@
+// Kernel/memory backend table used by the C++17 host layer.
+//
+// The host layer (MultiFab / MultiFabRegister / WarpXParticleContainer /
+// FiniteDifferenceSolver / WarpX shims and the step schedule) is plain C++ and talks to
+// the device only through this table, whose kernel entries have exactly the C-ABI
+// signatures of include/warpx_amd.h.  The product library fills it with the HIP
+// kernels (warpx_host.hip).  The test-suite compiles the same host sources against the
+// CPU oracle's entry points to exercise the multi-brick exchange logic over gloo on a
+// machine without a GPU (tests/host_cpu/); that build is never shipped.
+#ifndef WXA_HOST_BACKEND_HPP_
+#define WXA_HOST_BACKEND_HPP_
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../../include/warpx_amd.h"
+
+namespace wxa::host {
+
+struct Backend {
+    const char* name;
+    // ---- kernels (C-ABI signatures) ----
+    int (*evolve_b)(const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
+    int (*evolve_e)(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double,
+                    const double*, void*);
+    int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
+                       const wxa_grid_geom*, double, double, double, int, int, int, void*);
+    int (*push_p)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
+                  const wxa_grid_geom*, double, double, double, int, int, int, void*);
+    int (*deposit_current)(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double,
+                           double, double, int, int, void* ws, void*);
+    int (*filter_bilinear)(const wxa_field_view*, const wxa_field_view*, void*);
+    int (*fill_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);
+    int (*sync_nodal_periodic)(const wxa_field_view*, const int*, void*);
+    int (*sum_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);
+    int (*pack_box)(const wxa_field_view*, const int32_t*, const int32_t*, double*, void*);
+    int (*unpack_box)(const wxa_field_view*, const int32_t*, const int32_t*, const double*, int, void*);
+    int (*field_set_zero)(const wxa_field_view*, void*);
+    int (*enforce_periodic)(const wxa_particle_view*, const double*, const double*, const int*, void*);
+    int (*sort_particles_by_cell)(const wxa_particle_view*, const wxa_particle_view*, const double*,
+                                  const double*, const int32_t*, const int32_t*, void* ws, void*);
+    // Stable 3-way partition of a tile along `dim` for Redistribute: dst = [stay | to-minus | to-plus]
+    // for positions in [lo,hi) / < lo / >= hi; counts (host, 3 entries) valid on return.
+    int (*partition_particles)(const wxa_particle_view*, const wxa_particle_view*, int dim, double lo,
+                               double hi, int64_t* counts, void* ws, void*);
+    // ---- workspace ----
+    int (*workspace_create)(void** ws);
+    void (*workspace_destroy)(void* ws);
+    // ---- memory / streams ----
+    void* (*dmalloc)(size_t bytes);
+    void (*dfree)(void* p);
+    int (*memset_async)(void* p, int value, size_t bytes, void* stream);
+    int (*memcpy_async)(void* dst, const void* src, size_t bytes, void* stream);  // device <-> device
+    int (*memcpy_h2d)(void* dst, const void* src, size_t bytes);
+    int (*memcpy_d2h)(void* dst, const void* src, size_t bytes);
+    int (*stream_sync)(void* stream);
+    // ---- timing (may be null) ----
+    void* (*event_create)();
+    void (*event_destroy)(void* ev);
+    void (*event_record)(void* ev, void* stream);
+    float (*event_elapsed_ms)(void* start, void* stop);  // synchronises on stop
+};
+
+}  // namespace wxa::host
+#endif

@@ -1,0 +1,146 @@
+// Step-level C API (`<prefix>sim_*`, include/warpx_amd.h) over class WarpX.
+// WXA_SIM_CAPI(prefix, backend_getter) instantiates the entry points; the product uses
+// prefix wxa_ with the HIP backend (warpx_host.hip).
+#ifndef WXA_HOST_SIM_CAPI_HPP_
+#define WXA_HOST_SIM_CAPI_HPP_
+
+#include <cstring>
+
+#include "WarpX.hpp"
+
+namespace wxa::host {
+
+struct SimHandle {
+    std::unique_ptr<WarpX> warpx;
+    std::string error;
+};
+
+inline int sim_create(const Backend* be, const wxa_sim_config* cfg, const wxa_comm* comm, SimHandle** out,
+                      std::string& err) {
+    if (!cfg || !out) return WXA_ERR_INVALID_ARG;
+    try {
+        auto h = std::make_unique<SimHandle>();
+        h->warpx = std::make_unique<WarpX>(be, *cfg, comm);
+        *out = h.release();
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        err = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
+inline int sim_add_species(SimHandle* h, double charge, double mass, const wxa_particle_view* init, int32_t* id) {
+    if (!h || !init || init->np < 0) return WXA_ERR_INVALID_ARG;
+    try {
+        WarpX& w = *h->warpx;
+        const int sid = w.GetPartContainer().AddSpecies(charge, mass);
+        ParticleTile& t = w.GetPartContainer().GetParticleContainer(sid).tile();
+        t.resize(init->np);
+        const Backend* be = w.context().be;
+        const double* src[7] = {init->x, init->y, init->z, init->w, init->ux, init->uy, init->uz};
+        if (init->np > 0) {
+            for (int c = 0; c < 7; ++c)
+                be->memcpy_async(t.comp(c), src[c], sizeof(double) * (size_t)init->np, w.context().stream);
+            if (init->idcpu)
+                be->memcpy_async(t.idcpu(), init->idcpu, sizeof(uint64_t) * (size_t)init->np, w.context().stream);
+            else
+                be->memset_async(t.idcpu(), 0, sizeof(uint64_t) * (size_t)init->np, w.context().stream);
+            be->stream_sync(w.context().stream);
+        }
+        if (id) *id = sid;
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
+inline int sim_evolve(SimHandle* h, int32_t numsteps) {
+    if (!h || numsteps < 0) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->Evolve(numsteps);
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_HIP;
+    }
+}
+
+inline int sim_get_field(SimHandle* h, const char* name, wxa_field_view* out) {
+    using warpx::fields::FieldType;
+    using ablastr::fields::Direction;
+    if (!h || !name || !out || std::strlen(name) != 2) return WXA_ERR_INVALID_ARG;
+    const char* comps = "xyz";
+    const char* cp = std::strchr(comps, name[1]);
+    if (!cp) return WXA_ERR_INVALID_ARG;
+    const int d = (int)(cp - comps);
+    FieldType ft;
+    if (name[0] == 'E') ft = FieldType::Efield_fp;
+    else if (name[0] == 'B') ft = FieldType::Bfield_fp;
+    else if (name[0] == 'j') ft = FieldType::current_fp;
+    else return WXA_ERR_INVALID_ARG;
+    *out = h->warpx->fields().get(ft, Direction{d}, 0)->view();
+    return WXA_OK;
+}
+
+inline int sim_get_particles(SimHandle* h, int32_t id, wxa_particle_view* out) {
+    if (!h || !out || id < 0 || id >= h->warpx->GetPartContainer().nSpecies()) return WXA_ERR_INVALID_ARG;
+    *out = h->warpx->GetPartContainer().GetParticleContainer(id).tile().view();
+    return WXA_OK;
+}
+
+inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int reset) {
+    if (!h) return WXA_ERR_INVALID_ARG;
+    WarpXContext& c = h->warpx->context();
+    for (int i = 0; i < 8; ++i) { ms[i] = c.ms[i]; counts[i] = c.counts[i]; }
+    if (reset) for (int i = 0; i < 8; ++i) { c.ms[i] = 0; c.counts[i] = 0; }
+    return WXA_OK;
+}
+
+}  // namespace wxa::host
+
+#define WXA_SIM_CAPI(PFX, RET, SIMTYPE, BACKEND_GETTER, SET_ERROR)                                          \
+    extern "C" {                                                                                       \
+    RET PFX##sim_create(const wxa_sim_config* cfg, const wxa_comm* comm, SIMTYPE** out) {              \
+        std::string err;                                                                               \
+        wxa::host::SimHandle* h = nullptr;                                                             \
+        int rc = wxa::host::sim_create(BACKEND_GETTER(), cfg, comm, &h, err);                          \
+        if (rc != 0) { SET_ERROR(err.c_str()); return (RET)rc; }                                            \
+        *out = reinterpret_cast<SIMTYPE*>(h);                                                          \
+        return (RET)0;                                                                                   \
+    }                                                                                                  \
+    void PFX##sim_destroy(SIMTYPE* s) { delete reinterpret_cast<wxa::host::SimHandle*>(s); }           \
+    RET PFX##sim_add_species(SIMTYPE* s, double q, double m, const wxa_particle_view* init, int32_t* id) { \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        int rc = wxa::host::sim_add_species(h, q, m, init, id);                                        \
+        if (rc != 0 && h) SET_ERROR(h->error.c_str());                                                 \
+        return (RET)rc;                                                                                     \
+    }                                                                                                  \
+    RET PFX##sim_evolve(SIMTYPE* s, int32_t n) {                                                       \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        int rc = wxa::host::sim_evolve(h, n);                                                          \
+        if (rc != 0 && h) SET_ERROR(h->error.c_str());                                                 \
+        return (RET)rc;                                                                                     \
+    }                                                                                                  \
+    double PFX##sim_dt(const SIMTYPE* s) {                                                             \
+        return reinterpret_cast<const wxa::host::SimHandle*>(s)->warpx->getdt(0);                      \
+    }                                                                                                  \
+    int64_t PFX##sim_istep(const SIMTYPE* s) {                                                         \
+        return reinterpret_cast<const wxa::host::SimHandle*>(s)->warpx->getistep();                    \
+    }                                                                                                  \
+    RET PFX##sim_get_field(SIMTYPE* s, const char* name, wxa_field_view* out) {                        \
+        return (RET)wxa::host::sim_get_field(reinterpret_cast<wxa::host::SimHandle*>(s), name, out);        \
+    }                                                                                                  \
+    RET PFX##sim_get_particles(SIMTYPE* s, int32_t id, wxa_particle_view* out) {                       \
+        return (RET)wxa::host::sim_get_particles(reinterpret_cast<wxa::host::SimHandle*>(s), id, out);      \
+    }                                                                                                  \
+    RET PFX##sim_get_timers(SIMTYPE* s, double ms[8], int64_t counts[8], int reset) {                  \
+        return (RET)wxa::host::sim_get_timers(reinterpret_cast<wxa::host::SimHandle*>(s), ms, counts, reset); \
+    }                                                                                                  \
+    RET PFX##sim_enable_timers(SIMTYPE* s, int enable) {                                               \
+        if (!s) return (RET)-1;                                                                            \
+        reinterpret_cast<wxa::host::SimHandle*>(s)->warpx->context().timers_on = enable != 0;          \
+        return (RET)0;                                                                                   \
+    }                                                                                                  \
+    }
+#endif

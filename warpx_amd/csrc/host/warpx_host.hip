@@ -1,0 +1,118 @@
+// Product instantiation of the host layer: HIP backend table + the wxa_sim_* C API.
+#include <hip/hip_runtime.h>
+
+#include "../common.hpp"
+#include "sim_capi.hpp"
+
+namespace {
+
+using wxa::host::Backend;
+
+void* hip_dmalloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) {
+        wxa::set_last_error("hipMalloc of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+void hip_dfree(void* p) { if (p) (void)hipFree(p); }
+int hip_memset_async(void* p, int v, size_t n, void* st) {
+    return hipMemsetAsync(p, v, n, (hipStream_t)st) == hipSuccess ? 0 : WXA_ERR_HIP;
+}
+int hip_memcpy_async(void* d, const void* s, size_t n, void* st) {
+    if (n == 0) return 0;
+    return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st) == hipSuccess ? 0 : WXA_ERR_HIP;
+}
+int hip_memcpy_h2d(void* d, const void* s, size_t n) {
+    return hipMemcpy(d, s, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : WXA_ERR_HIP;
+}
+int hip_memcpy_d2h(void* d, const void* s, size_t n) {
+    return hipMemcpy(d, s, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : WXA_ERR_HIP;
+}
+int hip_stream_sync(void* st) { return hipStreamSynchronize((hipStream_t)st) == hipSuccess ? 0 : WXA_ERR_HIP; }
+void* hip_event_create() {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+void hip_event_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+void hip_event_record(void* e, void* st) { (void)hipEventRecord((hipEvent_t)e, (hipStream_t)st); }
+float hip_event_elapsed(void* a, void* b) {
+    float ms = 0.f;
+    (void)hipEventSynchronize((hipEvent_t)b);
+    (void)hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b);
+    return ms;
+}
+
+int ws_create(void** ws) { return wxa_workspace_create(reinterpret_cast<wxa_workspace**>(ws)); }
+void ws_destroy(void* ws) { wxa_workspace_destroy(static_cast<wxa_workspace*>(ws)); }
+int k_deposit(const wxa_particle_view* p, const wxa_field_view* J, const wxa_grid_geom* g, double q, double dt,
+              double rel, int order, int algo, void* ws, void* st) {
+    return wxa_deposit_current(p, J, g, q, dt, rel, order, algo, static_cast<wxa_workspace*>(ws), st);
+}
+int k_sort(const wxa_particle_view* s, const wxa_particle_view* d, const double* plo, const double* dinv,
+           const int32_t* lo, const int32_t* nc, void* ws, void* st) {
+    return wxa_sort_particles_by_cell(s, d, plo, dinv, lo, nc, static_cast<wxa_workspace*>(ws), st);
+}
+int k_partition(const wxa_particle_view* s, const wxa_particle_view* d, int dim, double lo, double hi,
+                int64_t* counts, void* ws, void* st) {
+    return wxa_partition_particles(s, d, dim, lo, hi, counts, static_cast<wxa_workspace*>(ws), st);
+}
+
+const Backend* hip_backend() {
+    static const Backend be = [] {
+        Backend b{};
+        b.name = "hip-gfx950";
+        b.evolve_b = [](const wxa_field_view* E, const wxa_field_view* B, double dt, const double* di, void* st) -> int {
+            return wxa_evolve_b(E, B, dt, di, st); };
+        b.evolve_e = [](const wxa_field_view* E, const wxa_field_view* B, const wxa_field_view* J, double dt,
+                        const double* di, void* st) -> int { return wxa_evolve_e(E, B, J, dt, di, st); };
+        b.gather_push = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
+                           const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void* st) -> int {
+            return wxa_gather_push(p, E, B, g, q, m, dt, o, ga, pu, st); };
+        b.push_p = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
+                      const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void* st) -> int {
+            return wxa_push_p(p, E, B, g, q, m, dt, o, ga, pu, st); };
+        b.deposit_current = k_deposit;
+        b.filter_bilinear = [](const wxa_field_view* s, const wxa_field_view* d, void* st) -> int {
+            return wxa_filter_bilinear(s, d, st); };
+        b.fill_boundary_periodic = [](const wxa_field_view* f, const int* ng, const int* per, void* st) -> int {
+            return wxa_fill_boundary_periodic(f, ng, per, st); };
+        b.sync_nodal_periodic = [](const wxa_field_view* f, const int* per, void* st) -> int {
+            return wxa_sync_nodal_periodic(f, per, st); };
+        b.sum_boundary_periodic = [](const wxa_field_view* f, const int* ng, const int* per, void* st) -> int {
+            return wxa_sum_boundary_periodic(f, ng, per, st); };
+        b.pack_box = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, double* buf, void* st) -> int {
+            return wxa_pack_box(f, lo, hi, buf, st); };
+        b.unpack_box = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, const double* buf, int mode,
+                          void* st) -> int { return wxa_unpack_box(f, lo, hi, buf, mode, st); };
+        b.field_set_zero = [](const wxa_field_view* f, void* st) -> int { return wxa_field_set_zero(f, st); };
+        b.enforce_periodic = [](const wxa_particle_view* p, const double* lo, const double* hi, const int* per,
+                                void* st) -> int { return wxa_enforce_periodic(p, lo, hi, per, st); };
+        b.sort_particles_by_cell = k_sort;
+        b.partition_particles = k_partition;
+        b.workspace_create = ws_create;
+        b.workspace_destroy = ws_destroy;
+        b.dmalloc = hip_dmalloc;
+        b.dfree = hip_dfree;
+        b.memset_async = hip_memset_async;
+        b.memcpy_async = hip_memcpy_async;
+        b.memcpy_h2d = hip_memcpy_h2d;
+        b.memcpy_d2h = hip_memcpy_d2h;
+        b.stream_sync = hip_stream_sync;
+        b.event_create = hip_event_create;
+        b.event_destroy = hip_event_destroy;
+        b.event_record = hip_event_record;
+        b.event_elapsed_ms = hip_event_elapsed;
+        return b;
+    }();
+    return &be;
+}
+
+void set_err(const char* msg) { wxa::set_last_error("%s", msg); }
+
+}  // namespace
+
+struct wxa_sim {};
+WXA_SIM_CAPI(wxa_, wxa_status, wxa_sim, hip_backend, set_err)

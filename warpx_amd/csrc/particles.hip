@@ -1,0 +1,528 @@
+// Particle kernels for gfx950: gather + push (PushPX / PushP), current and charge
+// deposition (global-atomics variants; the LDS-tile variants live in deposit_tile.hip),
+// periodic wrap, counting sort by cell.
+#include "shapes.hpp"
+#include "workspace.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+namespace wxa {
+
+struct PV {
+    double* __restrict__ x; double* __restrict__ y; double* __restrict__ z; double* __restrict__ w;
+    double* __restrict__ ux; double* __restrict__ uy; double* __restrict__ uz;
+    uint64_t* __restrict__ id;
+    long np;
+};
+static inline PV make_pv(const wxa_particle_view& p) {
+    return PV{p.x, p.y, p.z, p.w, p.ux, p.uy, p.uz, p.idcpu, (long)p.np};
+}
+static inline bool pv_ok(const wxa_particle_view* p) {
+    return p && p->np >= 0 && (p->np == 0 || (p->x && p->y && p->z && p->w && p->ux && p->uy && p->uz));
+}
+
+// ---------------------------------------------------------------------------
+// Gather on the Yee grid.  doGatherShapeN<O,G> (Source/Particles/Gather/FieldGather.H:36-424)
+// specialised to the Yee index types: per direction only two weight arrays occur, the
+// order-O nodal one and the order-(O-G) cell-centred one (:98-121,135-158,171-194).
+template <int NX, int NY, int NZ>
+__device__ __forceinline__ double gather_one(const DevF& f, const double* __restrict__ sx,
+                                             const double* __restrict__ sy,
+                                             const double* __restrict__ sz, int i0, int j0, int k0) {
+    const double* __restrict__ base = f.p + f.off(i0, j0, k0);
+    double acc = 0.0;
+#pragma unroll
+    for (int iz = 0; iz < NZ; ++iz) {
+#pragma unroll
+        for (int iy = 0; iy < NY; ++iy) {
+            const double* __restrict__ row = base + iy * f.js + iz * f.ks;
+            double r = 0.0;
+#pragma unroll
+            for (int ix = 0; ix < NX; ++ix) r += sx[ix] * row[ix];
+            acc += (sy[iy] * sz[iz]) * r;
+        }
+    }
+    return acc;
+}
+
+template <int O, int G, int PUSHER, bool MOVE>
+__global__ void __launch_bounds__(256)
+gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Geom g, double q,
+                   double m, double dt) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.np) return;
+    constexpr int NN = O + 1;        // nodal weights
+    constexpr int NC = O + 1 - G;    // cell-centred (galerkin-lowered) weights
+    double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
+
+    const double x = (xp - g.xmin) * g.dxi;
+    const double y = (yp - g.ymin) * g.dyi;
+    const double z = (zp - g.zmin) * g.dzi;
+    double sxn[NN], sxc[NC], syn[NN], syc[NC], szn[NN], szc[NC];
+    const int jn = g.lo0 + shape_factor<O>(sxn, x);
+    const int jc = g.lo0 + shape_factor<O - G>(sxc, x - 0.5);
+    const int kn = g.lo1 + shape_factor<O>(syn, y);
+    const int kc = g.lo1 + shape_factor<O - G>(syc, y - 0.5);
+    const int ln = g.lo2 + shape_factor<O>(szn, z);
+    const int lc = g.lo2 + shape_factor<O - G>(szc, z - 0.5);
+
+    // Yee: Ex(c,n,n) Ey(n,c,n) Ez(n,n,c) Bx(n,c,c) By(c,n,c) Bz(c,c,n)
+    const double Exp = gather_one<NC, NN, NN>(Ex, sxc, syn, szn, jc, kn, ln);
+    const double Eyp = gather_one<NN, NC, NN>(Ey, sxn, syc, szn, jn, kc, ln);
+    const double Ezp = gather_one<NN, NN, NC>(Ez, sxn, syn, szc, jn, kn, lc);
+    const double Bzp = gather_one<NC, NC, NN>(Bz, sxc, syc, szn, jc, kc, ln);
+    const double Byp = gather_one<NC, NN, NC>(By, sxc, syn, szc, jc, kn, lc);
+    const double Bxp = gather_one<NN, NC, NC>(Bx, sxn, syc, szc, jn, kc, lc);
+
+    double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
+    // doParticleMomentumPush (Source/Particles/Pusher/PushSelector.H:38-102), ion_lev = 1
+    if constexpr (PUSHER == WXA_PUSHER_BORIS) push_boris(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+    else push_vay(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
+    if constexpr (MOVE) {
+        update_position(xp, yp, zp, ux, uy, uz, dt);
+        p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Esirkepov, one lane per particle, global fp64 atomics
+// (Source/Particles/Deposition/CurrentDeposition.H:683-824, 3-D branch).
+template <int O>
+__global__ void __launch_bounds__(256)
+deposit_esirkepov_global_kernel(PV p, DevF Jx, DevF Jy, DevF Jz, Geom g, double q, double dt,
+                                double relative_time) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.np) return;
+    const double invdtd_x = (1.0 / dt) * g.dyi * g.dzi;
+    const double invdtd_y = (1.0 / dt) * g.dxi * g.dzi;
+    const double invdtd_z = (1.0 / dt) * g.dxi * g.dyi;
+    constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
+    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
+    const double uxp = p.ux[ip], uyp = p.uy[ip], uzp = p.uz[ip];
+    const double gaminv = 1.0 / sqrt(1.0 + uxp * uxp * clightsq + uyp * uyp * clightsq + uzp * uzp * clightsq);
+    const double wq = q * p.w[ip];
+    const double x_new = (p.x[ip] - g.xmin + (relative_time + 0.5 * dt) * uxp * gaminv) * g.dxi;
+    const double x_old = x_new - dt * g.dxi * uxp * gaminv;
+    const double y_new = (p.y[ip] - g.ymin + (relative_time + 0.5 * dt) * uyp * gaminv) * g.dyi;
+    const double y_old = y_new - dt * g.dyi * uyp * gaminv;
+    const double z_new = (p.z[ip] - g.zmin + (relative_time + 0.5 * dt) * uzp * gaminv) * g.dzi;
+    const double z_old = z_new - dt * g.dzi * uzp * gaminv;
+
+    double sx_new[O + 3] = {0.}, sx_old[O + 3] = {0.};
+    double sy_new[O + 3] = {0.}, sy_old[O + 3] = {0.};
+    double sz_new[O + 3] = {0.}, sz_old[O + 3] = {0.};
+    const int i_new = shape_factor<O>(sx_new + 1, x_new);
+    const int i_old = shifted_shape_factor<O>(sx_old, x_old, i_new);
+    const int j_new = shape_factor<O>(sy_new + 1, y_new);
+    const int j_old = shifted_shape_factor<O>(sy_old, y_old, j_new);
+    const int k_new = shape_factor<O>(sz_new + 1, z_new);
+    const int k_old = shifted_shape_factor<O>(sz_old, z_old, k_new);
+    const int dil = (i_old < i_new) ? 0 : 1, diu = (i_old > i_new) ? 0 : 1;
+    const int djl = (j_old < j_new) ? 0 : 1, dju = (j_old > j_new) ? 0 : 1;
+    const int dkl = (k_old < k_new) ? 0 : 1, dku = (k_old > k_new) ? 0 : 1;
+
+    const int bi = g.lo0 + i_new - 1, bj = g.lo1 + j_new - 1, bk = g.lo2 + k_new - 1;
+    double* __restrict__ jx = Jx.p + Jx.off(bi, bj, bk);
+    double* __restrict__ jy = Jy.p + Jy.off(bi, bj, bk);
+    double* __restrict__ jz = Jz.p + Jz.off(bi, bj, bk);
+
+    for (int k = dkl; k <= O + 2 - dku; k++)
+        for (int j = djl; j <= O + 2 - dju; j++) {
+            double sdxi = 0.;
+            for (int i = dil; i <= O + 1 - diu; i++) {
+                sdxi += wq * invdtd_x * (sx_old[i] - sx_new[i]) *
+                        (one_third * (sy_new[j] * sz_new[k] + sy_old[j] * sz_old[k]) +
+                         one_sixth * (sy_new[j] * sz_old[k] + sy_old[j] * sz_new[k]));
+                atomic_add_f64(jx + i + j * Jx.js + k * Jx.ks, sdxi);
+            }
+        }
+    for (int k = dkl; k <= O + 2 - dku; k++)
+        for (int i = dil; i <= O + 2 - diu; i++) {
+            double sdyj = 0.;
+            for (int j = djl; j <= O + 1 - dju; j++) {
+                sdyj += wq * invdtd_y * (sy_old[j] - sy_new[j]) *
+                        (one_third * (sx_new[i] * sz_new[k] + sx_old[i] * sz_old[k]) +
+                         one_sixth * (sx_new[i] * sz_old[k] + sx_old[i] * sz_new[k]));
+                atomic_add_f64(jy + i + j * Jy.js + k * Jy.ks, sdyj);
+            }
+        }
+    for (int j = djl; j <= O + 2 - dju; j++)
+        for (int i = dil; i <= O + 2 - diu; i++) {
+            double sdzk = 0.;
+            for (int k = dkl; k <= O + 1 - dku; k++) {
+                sdzk += wq * invdtd_z * (sz_old[k] - sz_new[k]) *
+                        (one_third * (sx_new[i] * sy_new[j] + sx_old[i] * sy_old[j]) +
+                         one_sixth * (sx_new[i] * sy_old[j] + sx_old[i] * sy_new[j]));
+                atomic_add_f64(jz + i + j * Jz.js + k * Jz.ks, sdzk);
+            }
+        }
+}
+
+// Direct deposition on the Yee grid, one lane per particle, global atomics
+// (Source/Particles/Deposition/CurrentDeposition.H:48-249,309-334).
+// J staggering: jx(c,n,n) jy(n,c,n) jz(n,n,c).
+template <int O>
+__global__ void __launch_bounds__(256)
+deposit_direct_global_kernel(PV p, DevF Jx, DevF Jy, DevF Jz, Geom g, double q, double relative_time) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.np) return;
+    const double invvol = g.dxi * g.dyi * g.dzi;
+    const double clightsq = 1.0 / PhysConst::c / PhysConst::c;
+    const double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
+    const double gaminv = 1.0 / sqrt(1.0 + ux * ux * clightsq + uy * uy * clightsq + uz * uz * clightsq);
+    const double vx = ux * gaminv, vy = uy * gaminv, vz = uz * gaminv;
+    const double wq = q * p.w[ip];
+    const double wqx = wq * invvol * vx, wqy = wq * invvol * vy, wqz = wq * invvol * vz;
+    const double xmid = ((p.x[ip] - g.xmin) + relative_time * vx) * g.dxi;
+    const double ymid = ((p.y[ip] - g.ymin) + relative_time * vy) * g.dyi;
+    const double zmid = ((p.z[ip] - g.zmin) + relative_time * vz) * g.dzi;
+    double sxn[O + 1], sxc[O + 1], syn[O + 1], syc[O + 1], szn[O + 1], szc[O + 1];
+    const int jn = g.lo0 + shape_factor<O>(sxn, xmid), jc = g.lo0 + shape_factor<O>(sxc, xmid - 0.5);
+    const int kn = g.lo1 + shape_factor<O>(syn, ymid), kc = g.lo1 + shape_factor<O>(syc, ymid - 0.5);
+    const int ln = g.lo2 + shape_factor<O>(szn, zmid), lc = g.lo2 + shape_factor<O>(szc, zmid - 0.5);
+    double* __restrict__ jx = Jx.p + Jx.off(jc, kn, ln);
+    double* __restrict__ jy = Jy.p + Jy.off(jn, kc, ln);
+    double* __restrict__ jz = Jz.p + Jz.off(jn, kn, lc);
+#pragma unroll
+    for (int iz = 0; iz <= O; iz++)
+#pragma unroll
+        for (int iy = 0; iy <= O; iy++)
+#pragma unroll
+            for (int ix = 0; ix <= O; ix++) {
+                atomic_add_f64(jx + ix + iy * Jx.js + iz * Jx.ks, sxc[ix] * syn[iy] * szn[iz] * wqx);
+                atomic_add_f64(jy + ix + iy * Jy.js + iz * Jy.ks, sxn[ix] * syc[iy] * szn[iz] * wqy);
+                atomic_add_f64(jz + ix + iy * Jz.js + iz * Jz.ks, sxn[ix] * syn[iy] * szc[iz] * wqz);
+            }
+}
+
+// Source/Particles/Deposition/ChargeDeposition.H:37-180 (3-D), rho of any staggering
+template <int O>
+__global__ void __launch_bounds__(256)
+deposit_charge_kernel(PV p, DevF rho, int s0, int s1, int s2, Geom g, double q) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.np) return;
+    const double invvol = g.dxi * g.dyi * g.dzi;
+    const double wq = q * p.w[ip] * invvol;
+    const double x = (p.x[ip] - g.xmin) * g.dxi;
+    const double y = (p.y[ip] - g.ymin) * g.dyi;
+    const double z = (p.z[ip] - g.zmin) * g.dzi;
+    double sx[O + 1], sy[O + 1], sz[O + 1];
+    const int i = g.lo0 + shape_factor<O>(sx, s0 ? x : x - 0.5);
+    const int j = g.lo1 + shape_factor<O>(sy, s1 ? y : y - 0.5);
+    const int k = g.lo2 + shape_factor<O>(sz, s2 ? z : z - 0.5);
+    double* __restrict__ r = rho.p + rho.off(i, j, k);
+#pragma unroll
+    for (int iz = 0; iz <= O; iz++)
+#pragma unroll
+        for (int iy = 0; iy <= O; iy++)
+#pragma unroll
+            for (int ix = 0; ix <= O; ix++)
+                atomic_add_f64(r + ix + iy * rho.js + iz * rho.ks, sx[ix] * sy[iy] * sz[iz] * wq);
+}
+
+__global__ void __launch_bounds__(256)
+enforce_periodic_kernel(double* __restrict__ a, long np, double plo, double phi) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= np) return;
+    const double L = phi - plo;
+    double v = a[ip];
+    if (v >= phi) {
+        v -= L;
+        if (v < plo) v = plo;
+    } else if (v < plo) {
+        v += L;
+        if (v >= phi) v = nextafter(phi, plo);
+    }
+    a[ip] = v;
+}
+
+// ---- counting sort by cell ---------------------------------------------------
+struct SortGeom {
+    double plo[3];
+    double dinv[3];
+    int nc[3];
+};
+
+__device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, double z) {
+    int i = (int)floor((x - s.plo[0]) * s.dinv[0]);
+    int j = (int)floor((y - s.plo[1]) * s.dinv[1]);
+    int k = (int)floor((z - s.plo[2]) * s.dinv[2]);
+    i = min(max(i, 0), s.nc[0] - 1);
+    j = min(max(j, 0), s.nc[1] - 1);
+    k = min(max(k, 0), s.nc[2] - 1);
+    return i + s.nc[0] * (j + s.nc[1] * k);
+}
+
+__global__ void __launch_bounds__(256)
+sort_count_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                  const double* __restrict__ z, long np, SortGeom s, int* __restrict__ cell,
+                  int* __restrict__ rank, int* __restrict__ hist) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= np) return;
+    const int c = cell_of(s, x[ip], y[ip], z[ip]);
+    cell[ip] = c;
+    rank[ip] = atomicAdd(&hist[c], 1);
+}
+
+__global__ void __launch_bounds__(256)
+sort_scatter_kernel(PV src, PV dst, const int* __restrict__ cell, const int* __restrict__ rank,
+                    const int* __restrict__ offsets) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= src.np) return;
+    const long d = (long)offsets[cell[ip]] + rank[ip];
+    dst.x[d] = src.x[ip]; dst.y[d] = src.y[ip]; dst.z[d] = src.z[ip]; dst.w[d] = src.w[ip];
+    dst.ux[d] = src.ux[ip]; dst.uy[d] = src.uy[ip]; dst.uz[d] = src.uz[ip];
+    if (src.id && dst.id) dst.id[d] = src.id[ip];
+}
+
+// ---- 3-way partition for Redistribute ---------------------------------------------
+__global__ void __launch_bounds__(256)
+partition_flag_kernel(const double* __restrict__ pos, long np, double lo, double hi, int* __restrict__ stay,
+                      unsigned long long* __restrict__ counters) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= np) return;
+    const double v = pos[ip];
+    const int key = v < lo ? 1 : (v >= hi ? 2 : 0);
+    stay[ip] = key == 0 ? 1 : 0;
+    if (key) atomicAdd(&counters[key], 1ULL);
+}
+
+__global__ void __launch_bounds__(256)
+partition_scatter_kernel(PV src, PV dst, const double* __restrict__ pos, double lo, double hi,
+                         const int* __restrict__ stay_scan, long nstay, long nminus,
+                         unsigned long long* __restrict__ cursors) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= src.np) return;
+    const double v = pos[ip];
+    long d;
+    if (v < lo) d = nstay + (long)atomicAdd(&cursors[1], 1ULL);
+    else if (v >= hi) d = nstay + nminus + (long)atomicAdd(&cursors[2], 1ULL);
+    else d = stay_scan[ip];
+    dst.x[d] = src.x[ip]; dst.y[d] = src.y[ip]; dst.z[d] = src.z[ip]; dst.w[d] = src.w[ip];
+    dst.ux[d] = src.ux[ip]; dst.uy[d] = src.uy[ip]; dst.uz[d] = src.uz[ip];
+    if (src.id && dst.id) dst.id[d] = src.id[ip];
+}
+
+static inline unsigned blocks_for(long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+template <int PUSHER, bool MOVE>
+static wxa_status launch_gather_push(const PV& pv, const wxa_field_view E[3], const wxa_field_view B[3],
+                                     const Geom& g, double q, double m, double dt, int order, int galerkin,
+                                     hipStream_t st) {
+    const DevF ex = make_devf(E[0]), ey = make_devf(E[1]), ez = make_devf(E[2]);
+    const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
+    const dim3 grid(blocks_for(pv.np)), block(256);
+#define WXA_GP(O, G)                                                                              \
+    hipLaunchKernelGGL((gather_push_kernel<O, G, PUSHER, MOVE>), grid, block, 0, st, pv, ex, ey, ez, bx, by, \
+                       bz, g, q, m, dt)
+    if (galerkin) {
+        if (order == 1) WXA_GP(1, 1); else if (order == 2) WXA_GP(2, 1); else WXA_GP(3, 1);
+    } else {
+        if (order == 1) WXA_GP(1, 0); else if (order == 2) WXA_GP(2, 0); else WXA_GP(3, 0);
+    }
+#undef WXA_GP
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+static wxa_status check_gather_args(const wxa_particle_view* p, const wxa_field_view E[3],
+                                    const wxa_field_view B[3], const wxa_grid_geom* geom, int order,
+                                    int galerkin, int pusher) {
+    WXA_REQUIRE(pv_ok(p), "bad particle view");
+    WXA_REQUIRE(E && B && geom, "null argument");
+    for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
+    WXA_REQUIRE(order >= 1 && order <= 3, "particle shape order must be 1..3");
+    WXA_REQUIRE(galerkin == 0 || galerkin == 1, "galerkin must be 0 or 1");
+    WXA_REQUIRE(pusher == WXA_PUSHER_BORIS || pusher == WXA_PUSHER_VAY, "pusher must be Boris or Vay");
+    if (!yee_E(E) || !yee_B(B)) {
+        set_last_error("gather: only the Yee staggering is supported");
+        return WXA_ERR_UNSUPPORTED;
+    }
+    return WXA_OK;
+}
+
+}  // namespace wxa
+
+using namespace wxa;
+
+extern "C" {
+
+wxa_status wxa_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                           const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                           int pusher, void* stream) {
+    wxa_status rc = check_gather_args(p, E, B, geom, order, galerkin, pusher);
+    if (rc != WXA_OK) return rc;
+    if (p->np == 0) return WXA_OK;
+    const PV pv = make_pv(*p);
+    const Geom g = make_geom(*geom);
+    if (pusher == WXA_PUSHER_BORIS)
+        return launch_gather_push<WXA_PUSHER_BORIS, true>(pv, E, B, g, q, m, dt, order, galerkin, (hipStream_t)stream);
+    return launch_gather_push<WXA_PUSHER_VAY, true>(pv, E, B, g, q, m, dt, order, galerkin, (hipStream_t)stream);
+}
+
+wxa_status wxa_push_p(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                      const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                      int pusher, void* stream) {
+    wxa_status rc = check_gather_args(p, E, B, geom, order, galerkin, pusher);
+    if (rc != WXA_OK) return rc;
+    if (p->np == 0) return WXA_OK;
+    const PV pv = make_pv(*p);
+    const Geom g = make_geom(*geom);
+    if (pusher == WXA_PUSHER_BORIS)
+        return launch_gather_push<WXA_PUSHER_BORIS, false>(pv, E, B, g, q, m, dt, order, galerkin, (hipStream_t)stream);
+    return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, (hipStream_t)stream);
+}
+
+wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
+                               double q, double dt, double relative_time, int order, int algo,
+                               wxa_workspace* ws, void* stream) {
+    WXA_REQUIRE(pv_ok(p), "bad particle view");
+    WXA_REQUIRE(J && geom, "null argument");
+    for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(J[c]), "bad field view");
+    WXA_REQUIRE(order >= 1 && order <= 3, "particle shape order must be 1..3");
+    WXA_REQUIRE(algo == WXA_DEPOSIT_ESIRKEPOV || algo == WXA_DEPOSIT_DIRECT, "unknown deposition algorithm");
+    WXA_REQUIRE(dt > 0.0 || algo == WXA_DEPOSIT_DIRECT, "dt must be positive");
+    if (!yee_E(J)) {
+        set_last_error("deposit_current: only the Yee staggering is supported");
+        return WXA_ERR_UNSUPPORTED;
+    }
+    if (p->np == 0) return WXA_OK;
+    if (ws && deposit_tile_available(ws, p)) {
+        return deposit_current_tiled(p, J, geom, q, dt, relative_time, order, algo, ws, (hipStream_t)stream);
+    }
+    const PV pv = make_pv(*p);
+    const Geom g = make_geom(*geom);
+    const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
+    const dim3 grid(blocks_for(pv.np)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (algo == WXA_DEPOSIT_ESIRKEPOV) {
+        if (order == 1) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<1>, grid, block, 0, st, pv, jx, jy, jz, g, q, dt, relative_time);
+        else if (order == 2) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<2>, grid, block, 0, st, pv, jx, jy, jz, g, q, dt, relative_time);
+        else hipLaunchKernelGGL(deposit_esirkepov_global_kernel<3>, grid, block, 0, st, pv, jx, jy, jz, g, q, dt, relative_time);
+    } else {
+        if (order == 1) hipLaunchKernelGGL(deposit_direct_global_kernel<1>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
+        else if (order == 2) hipLaunchKernelGGL(deposit_direct_global_kernel<2>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
+        else hipLaunchKernelGGL(deposit_direct_global_kernel<3>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_deposit_charge(const wxa_particle_view* p, const wxa_field_view* rho, const wxa_grid_geom* geom,
+                              double q, int order, void* stream) {
+    WXA_REQUIRE(pv_ok(p), "bad particle view");
+    WXA_REQUIRE(rho && geom && view_ok(*rho), "bad argument");
+    WXA_REQUIRE(order >= 1 && order <= 3, "particle shape order must be 1..3");
+    if (p->np == 0) return WXA_OK;
+    const PV pv = make_pv(*p);
+    const Geom g = make_geom(*geom);
+    const DevF r = make_devf(*rho);
+    const dim3 grid(blocks_for(pv.np)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (order == 1) hipLaunchKernelGGL(deposit_charge_kernel<1>, grid, block, 0, st, pv, r, rho->stag[0], rho->stag[1], rho->stag[2], g, q);
+    else if (order == 2) hipLaunchKernelGGL(deposit_charge_kernel<2>, grid, block, 0, st, pv, r, rho->stag[0], rho->stag[1], rho->stag[2], g, q);
+    else hipLaunchKernelGGL(deposit_charge_kernel<3>, grid, block, 0, st, pv, r, rho->stag[0], rho->stag[1], rho->stag[2], g, q);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_enforce_periodic(const wxa_particle_view* p, const double plo[3], const double phi[3],
+                                const int periodic[3], void* stream) {
+    WXA_REQUIRE(pv_ok(p) && plo && phi && periodic, "bad argument");
+    if (p->np == 0) return WXA_OK;
+    double* pos[3] = {p->x, p->y, p->z};
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d]) continue;
+        WXA_REQUIRE(phi[d] > plo[d], "empty domain");
+        hipLaunchKernelGGL(enforce_periodic_kernel, dim3(blocks_for(p->np)), dim3(256), 0, (hipStream_t)stream,
+                           pos[d], (long)p->np, plo[d], phi[d]);
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_particle_view* dst,
+                                      const double plo[3], const double dinv[3], const int32_t cell_lo[3],
+                                      const int32_t ncell[3], wxa_workspace* ws, void* stream) {
+    WXA_REQUIRE(pv_ok(src) && pv_ok(dst) && plo && dinv && cell_lo && ncell && ws, "bad argument");
+    WXA_REQUIRE(src->np == dst->np, "src/dst particle counts differ");
+    WXA_REQUIRE(src->x != dst->x, "sort is out of place");
+    const long ncells = (long)ncell[0] * ncell[1] * ncell[2];
+    WXA_REQUIRE(ncells > 0 && ncells < (1L << 31) - 2 && src->np < (1L << 31) - 2, "sizes exceed 32-bit sort keys");
+    hipStream_t st = (hipStream_t)stream;
+    ws->sorted_valid = false;
+    if (src->np == 0) return WXA_OK;
+    wxa_status rc;
+    if ((rc = ws->cell.reserve(sizeof(int) * src->np)) != WXA_OK) return rc;
+    if ((rc = ws->rank.reserve(sizeof(int) * src->np)) != WXA_OK) return rc;
+    if ((rc = ws->hist.reserve(sizeof(int) * (ncells + 1))) != WXA_OK) return rc;
+    if ((rc = ws->offsets.reserve(sizeof(int) * (ncells + 1))) != WXA_OK) return rc;
+    int* cell = (int*)ws->cell.p; int* rank = (int*)ws->rank.p;
+    int* hist = (int*)ws->hist.p; int* offsets = (int*)ws->offsets.p;
+    WXA_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (ncells + 1), st));
+    SortGeom sg;
+    for (int d = 0; d < 3; ++d) {
+        // physical lower corner of the brick's cell box; cells are numbered from cell_lo
+        sg.plo[d] = plo[d];
+        sg.dinv[d] = dinv[d];
+        sg.nc[d] = ncell[d];
+    }
+    (void)cell_lo;
+    const PV s = make_pv(*src), d = make_pv(*dst);
+    hipLaunchKernelGGL(sort_count_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s.x, s.y, s.z, s.np, sg, cell,
+                       rank, hist);
+    size_t tmp_bytes = 0;
+    WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hist, offsets, (int)(ncells + 1), st));
+    if ((rc = ws->scan_tmp.reserve(tmp_bytes)) != WXA_OK) return rc;
+    WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, hist, offsets, (int)(ncells + 1), st));
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s, d, cell, rank, offsets);
+    WXA_LAUNCH_CHECK();
+    ws->sorted_valid = true;
+    ws->sorted_np = src->np;
+    ws->sorted_x = dst->x;
+    for (int e = 0; e < 3; ++e) {
+        ws->sort_nc[e] = ncell[e];
+        ws->sort_cell_lo[e] = cell_lo[e];
+        ws->sort_plo[e] = plo[e];
+        ws->sort_dinv[e] = dinv[e];
+    }
+    return WXA_OK;
+}
+
+wxa_status wxa_partition_particles(const wxa_particle_view* src, const wxa_particle_view* dst, int dim,
+                                   double lo, double hi, int64_t counts[3], wxa_workspace* ws, void* stream) {
+    WXA_REQUIRE(pv_ok(src) && pv_ok(dst) && counts && ws, "bad argument");
+    WXA_REQUIRE(dim >= 0 && dim < 3, "dim must be 0..2");
+    WXA_REQUIRE(src->np == dst->np && (src->np == 0 || src->x != dst->x), "partition is out of place, equal sizes");
+    WXA_REQUIRE(src->np < (1L << 31) - 2, "tile too large for 32-bit scan");
+    hipStream_t st = (hipStream_t)stream;
+    counts[0] = counts[1] = counts[2] = 0;
+    ws->sorted_valid = false;
+    if (src->np == 0) return WXA_OK;
+    wxa_status rc;
+    if ((rc = ws->cell.reserve(sizeof(int) * (src->np + 1))) != WXA_OK) return rc;
+    if ((rc = ws->rank.reserve(sizeof(int) * (src->np + 1))) != WXA_OK) return rc;
+    if ((rc = ws->hist.reserve(sizeof(unsigned long long) * 8)) != WXA_OK) return rc;
+    int* stay = (int*)ws->cell.p; int* scan = (int*)ws->rank.p;
+    unsigned long long* ctr = (unsigned long long*)ws->hist.p;
+    WXA_HIP_CHECK(hipMemsetAsync(ctr, 0, sizeof(unsigned long long) * 8, st));
+    const PV s = make_pv(*src), d = make_pv(*dst);
+    const double* pos = dim == 0 ? s.x : (dim == 1 ? s.y : s.z);
+    hipLaunchKernelGGL(partition_flag_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, pos, s.np, lo, hi, stay, ctr);
+    size_t tmp_bytes = 0;
+    WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, stay, scan, (int)s.np, st));
+    if ((rc = ws->scan_tmp.reserve(tmp_bytes)) != WXA_OK) return rc;
+    WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, stay, scan, (int)s.np, st));
+    unsigned long long h[3] = {0, 0, 0};
+    WXA_HIP_CHECK(hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, st));
+    WXA_HIP_CHECK(hipStreamSynchronize(st));
+    const long nminus = (long)h[1], nplus = (long)h[2], nstay = s.np - nminus - nplus;
+    hipLaunchKernelGGL(partition_scatter_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s, d, pos, lo, hi, scan,
+                       nstay, nminus, ctr + 3);
+    WXA_LAUNCH_CHECK();
+    counts[0] = nstay; counts[1] = nminus; counts[2] = nplus;
+    return WXA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// Library runtime: error string, workspace lifetime, blocking copies.
+#include "workspace.hpp"
+
+#include <stdarg.h>
+#include <string.h>
+
+namespace wxa {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace wxa
+
+extern "C" {
+
+const char* wxa_version(void) { return "warpx_amd 0.1.0 (gfx950, fp64)"; }
+const char* wxa_last_error(void) { return wxa::g_err; }
+
+wxa_status wxa_workspace_create(wxa_workspace** ws) {
+    if (!ws) return WXA_ERR_INVALID_ARG;
+    *ws = new wxa_workspace();
+    return WXA_OK;
+}
+
+void wxa_workspace_destroy(wxa_workspace* ws) {
+    if (!ws) return;
+    ws->cell.release(); ws->rank.release(); ws->hist.release(); ws->offsets.release();
+    ws->scan_tmp.release(); ws->tile_offsets.release();
+    delete ws;
+}
+
+wxa_status wxa_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes) {
+    WXA_REQUIRE(bytes >= 0 && (bytes == 0 || (dst_host && src_dev)), "bad copy arguments");
+    if (bytes == 0) return WXA_OK;
+    WXA_HIP_CHECK(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return WXA_OK;
+}
+
+wxa_status wxa_copy_to_device(void* dst_dev, const void* src_host, int64_t bytes) {
+    WXA_REQUIRE(bytes >= 0 && (bytes == 0 || (dst_dev && src_host)), "bad copy arguments");
+    if (bytes == 0) return WXA_OK;
+    WXA_HIP_CHECK(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+    return WXA_OK;
+}
+
+wxa_status wxa_device_synchronize(void) {
+    WXA_HIP_CHECK(hipDeviceSynchronize());
+    return WXA_OK;
+}
+
+}  // extern "C"

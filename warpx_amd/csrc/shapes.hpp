@@ -1,0 +1,151 @@
+// Device restatement of the particle arithmetic (shape factors, gather on the Yee
+// grid, Boris/Vay pushers, position update).  Formulas follow the reference headers
+// cited at each function; the code organisation (Yee-specialised gather with two shape
+// arrays per direction, register-resident weights) is this project's own.
+#ifndef WXA_SHAPES_HPP_
+#define WXA_SHAPES_HPP_
+
+#include "common.hpp"
+
+namespace wxa {
+
+// B-spline weights, Source/Particles/ShapeFactors.H:27-84. Returns the leftmost index.
+// x >= 0 is guaranteed by the guard-grown index origin, so truncation == floor.
+template <int ORDER>
+__device__ __forceinline__ int shape_factor(double* __restrict__ s, const double x) {
+    if constexpr (ORDER == 0) {
+        const int j = (int)(x + 0.5);
+        s[0] = 1.0;
+        return j;
+    } else if constexpr (ORDER == 1) {
+        const int j = (int)x;
+        const double xi = x - (double)j;
+        s[0] = 1.0 - xi;
+        s[1] = xi;
+        return j;
+    } else if constexpr (ORDER == 2) {
+        const int j = (int)(x + 0.5);
+        const double xi = x - (double)j;
+        s[0] = 0.5 * (0.5 - xi) * (0.5 - xi);
+        s[1] = 0.75 - xi * xi;
+        s[2] = 0.5 * (0.5 + xi) * (0.5 + xi);
+        return j - 1;
+    } else {
+        static_assert(ORDER == 3, "orders 0..3");
+        const int j = (int)x;
+        const double xi = x - (double)j;
+        const double om = 1.0 - xi;
+        s[0] = (1.0 / 6.0) * om * om * om;
+        s[1] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);
+        s[2] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);
+        s[3] = (1.0 / 6.0) * xi * xi * xi;
+        return j - 1;
+    }
+}
+
+// Old-position weights on the slots of the new position (Esirkepov),
+// Source/Particles/ShapeFactors.H:93-156.  s has ORDER+3 pre-zeroed entries.
+template <int ORDER>
+__device__ __forceinline__ int shifted_shape_factor(double* __restrict__ s, const double x_old,
+                                                    const int i_new) {
+    if constexpr (ORDER == 1) {
+        const int i = (int)floor(x_old);
+        const int sh = i - i_new;
+        const double xi = x_old - (double)i;
+        s[1 + sh] = 1.0 - xi;
+        s[2 + sh] = xi;
+        return i;
+    } else if constexpr (ORDER == 2) {
+        const int i = (int)(x_old + 0.5);
+        const int sh = i - (i_new + 1);
+        const double xi = x_old - (double)i;
+        s[1 + sh] = 0.5 * (0.5 - xi) * (0.5 - xi);
+        s[2 + sh] = 0.75 - xi * xi;
+        s[3 + sh] = 0.5 * (0.5 + xi) * (0.5 + xi);
+        return i - 1;
+    } else {
+        static_assert(ORDER == 3, "orders 1..3");
+        const int i = (int)x_old;
+        const int sh = i - (i_new + 1);
+        const double xi = x_old - (double)i;
+        const double om = 1.0 - xi;
+        s[1 + sh] = (1.0 / 6.0) * om * om * om;
+        s[2 + sh] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);
+        s[3 + sh] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);
+        s[4 + sh] = (1.0 / 6.0) * xi * xi * xi;
+        return i - 1;
+    }
+}
+
+// Source/Particles/Pusher/UpdateMomentumBoris.H:15-53
+__device__ __forceinline__ void push_boris(double& ux, double& uy, double& uz, const double Ex,
+                                           const double Ey, const double Ez, const double Bx,
+                                           const double By, const double Bz, const double q,
+                                           const double m, const double dt) {
+    const double econst = 0.5 * q * dt / m;
+    ux += econst * Ex; uy += econst * Ey; uz += econst * Ez;
+    constexpr double inv_c2 = 1. / (PhysConst::c * PhysConst::c);
+    const double inv_gamma = 1. / sqrt(1. + (ux * ux + uy * uy + uz * uz) * inv_c2);
+    const double tx = econst * inv_gamma * Bx;
+    const double ty = econst * inv_gamma * By;
+    const double tz = econst * inv_gamma * Bz;
+    const double tsqi = 2. / (1. + tx * tx + ty * ty + tz * tz);
+    const double sx = tx * tsqi, sy = ty * tsqi, sz = tz * tsqi;
+    const double ux_p = ux + uy * tz - uz * ty;
+    const double uy_p = uy + uz * tx - ux * tz;
+    const double uz_p = uz + ux * ty - uy * tx;
+    ux += uy_p * sz - uz_p * sy;
+    uy += uz_p * sx - ux_p * sz;
+    uz += ux_p * sy - uy_p * sx;
+    ux += econst * Ex; uy += econst * Ey; uz += econst * Ez;
+}
+
+// Source/Particles/Pusher/UpdateMomentumVay.H:19-62
+__device__ __forceinline__ void push_vay(double& ux, double& uy, double& uz, const double Ex,
+                                         const double Ey, const double Ez, const double Bx,
+                                         const double By, const double Bz, const double q,
+                                         const double m, const double dt) {
+    const double econst = q * dt / m;
+    const double bconst = 0.5 * q * dt / m;
+    constexpr double invclight = 1. / PhysConst::c;
+    constexpr double invclightsq = 1. / (PhysConst::c * PhysConst::c);
+    const double inv_gamma = 1. / sqrt(1. + (ux * ux + uy * uy + uz * uz) * invclightsq);
+    const double taux = bconst * Bx, tauy = bconst * By, tauz = bconst * Bz;
+    const double tausq = taux * taux + tauy * tauy + tauz * tauz;
+    const double uxpr = ux + econst * Ex + (uy * tauz - uz * tauy) * inv_gamma;
+    const double uypr = uy + econst * Ey + (uz * taux - ux * tauz) * inv_gamma;
+    const double uzpr = uz + econst * Ez + (ux * tauy - uy * taux) * inv_gamma;
+    const double gprsq = (1. + (uxpr * uxpr + uypr * uypr + uzpr * uzpr) * invclightsq);
+    const double ust = (uxpr * taux + uypr * tauy + uzpr * tauz) * invclight;
+    const double sigma = gprsq - tausq;
+    const double gisq = 2. / (sigma + sqrt(sigma * sigma + 4. * (tausq + ust * ust)));
+    const double bg = bconst * sqrt(gisq);
+    const double tx = bg * Bx, ty = bg * By, tz = bg * Bz;
+    const double s = 1. / (1. + tausq * gisq);
+    const double tu = tx * uxpr + ty * uypr + tz * uzpr;
+    ux = s * (uxpr + tx * tu + uypr * tz - uzpr * ty);
+    uy = s * (uypr + ty * tu + uzpr * tx - uxpr * tz);
+    uz = s * (uzpr + tz * tu + uxpr * ty - uypr * tx);
+}
+
+// Source/Particles/Pusher/UpdatePosition.H:24-45
+__device__ __forceinline__ void update_position(double& x, double& y, double& z, const double ux,
+                                                const double uy, const double uz, const double dt) {
+    constexpr double inv_c2 = 1. / (PhysConst::c * PhysConst::c);
+    const double inv_gamma = 1. / sqrt(1. + (ux * ux + uy * uy + uz * uz) * inv_c2);
+    x += ux * inv_gamma * dt;
+    y += uy * inv_gamma * dt;
+    z += uz * inv_gamma * dt;
+}
+
+struct Geom {
+    double xmin, ymin, zmin;
+    double dxi, dyi, dzi;
+    int lo0, lo1, lo2;
+};
+inline Geom make_geom(const wxa_grid_geom& g) {
+    return Geom{g.xyzmin[0], g.xyzmin[1], g.xyzmin[2], g.dinv[0], g.dinv[1], g.dinv[2], g.lo[0], g.lo[1], g.lo[2]};
+}
+
+}  // namespace wxa
+#endif

@@ -1,0 +1,48 @@
+// Per-device scratch owned by the caller through wxa_workspace_create/destroy.
+#ifndef WXA_WORKSPACE_HPP_
+#define WXA_WORKSPACE_HPP_
+
+#include "common.hpp"
+
+namespace wxa {
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    wxa_status reserve(size_t bytes) {
+        if (bytes <= cap) return WXA_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            set_last_error("hipMalloc of %zu bytes failed", want);
+            return WXA_ERR_NOMEM;
+        }
+        cap = want;
+        return WXA_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace wxa
+
+struct wxa_workspace {
+    wxa::DevBuf cell, rank, hist, offsets, scan_tmp, tile_offsets;
+    // description of the last cell sort (consumed by the tile-based deposition)
+    bool sorted_valid = false;
+    int64_t sorted_np = 0;
+    const double* sorted_x = nullptr;   // identity of the sorted particle array
+    int32_t sort_nc[3] = {0, 0, 0};
+    int32_t sort_cell_lo[3] = {0, 0, 0};
+    double sort_plo[3] = {0, 0, 0};
+    double sort_dinv[3] = {0, 0, 0};
+};
+
+namespace wxa {
+// LDS-tile deposition (deposit_tile.hip)
+bool deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p);
+wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_view J[3],
+                                 const wxa_grid_geom* geom, double q, double dt, double relative_time,
+                                 int order, int algo, wxa_workspace* ws, hipStream_t stream);
+}  // namespace wxa
+#endif
