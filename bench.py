@@ -83,7 +83,7 @@ def cpu_baseline(n_threads=None):
     sim.evolve(steps)
     dt = time.perf_counter() - t0
     sim.close()
-    return {"value": npart * steps / dt, "unit": "particle-steps/s", "cores": int(orc.num_threads()),
+    return {"value": npart * steps / dt, "unit": "particle-steps/s", "cores": int(orc._num_threads()),
             "kind": "port",
             "sample": f"64^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on, {steps} steps "
                       f"({npart} particles); {dt:.1f} s of CPU time; cell-updates/s = "

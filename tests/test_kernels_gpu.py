@@ -213,9 +213,48 @@ def test_enforce_periodic_and_sort(oracle, product):
     _sync(product)
     s = out.to_numpy()
     cell = [np.clip(np.floor((s[d] + H.LX / 2) / dx[d]).astype(np.int64), 0, NCELL[d] - 1) for d in range(3)]
-    key = cell[0] + NCELL[0] * (cell[1] + NCELL[1] * cell[2])
+    T = 8  # tile-major cell key (WXA_TILE): tiles of 8^3 cells, cells i-fastest inside a tile
+    nt = [(n + T - 1) // T for n in NCELL]
+    tile = cell[0] // T + nt[0] * (cell[1] // T + nt[1] * (cell[2] // T))
+    key = tile * T ** 3 + cell[0] % T + T * (cell[1] % T + T * (cell[2] % T))
     assert np.all(np.diff(key) >= 0)
     order_a = np.lexsort(a[::-1])
     order_s = np.lexsort(s[::-1])
     assert np.array_equal(a[:, order_a], s[:, order_s])
+    product.workspace_destroy(ws)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
+@pytest.mark.parametrize("stale", [False, True])
+def test_deposit_current_lds_tiles(oracle, product, order, algo, stale):
+    """LDS-tile variant (needs a cell sort in the workspace) against the oracle; `stale` moves the
+    particles by up to 0.9 cell after the sort (and outside the domain) so that part of the
+    stencils leave their tile and take the global-atomic path."""
+    ncell = (24, 20, 16)
+    _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    parts = H.random_particles(40000, ncell, 200 + order, u_scale=1.0)
+    dx = H.LX / np.asarray(ncell)
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    srt = ParticleArrays(pd0.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    if stale:
+        rng = np.random.default_rng(5)
+        for d in range(3):
+            srt.data[d] += __import__("torch").from_numpy(dx[d] * 0.9 * (2 * rng.random(srt.np) - 1)).to(DEV)
+    ph = ParticleArrays.from_numpy(list(srt.to_numpy()), "cpu")
+    J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    Jd = H.clone_fields(J, DEV, True)
+    g, _ = H.geom_for(ncell, ng_depos)
+    dt = H.yee_dt(dx)
+    q = -plasma.Q_E
+    oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order, algo, None, None)
+    product.deposit_current(C.byref(srt.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, algo, ws, None)
+    _sync(product)
+    for a, b in zip(Jd, J):
+        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
     product.workspace_destroy(ws)

@@ -142,6 +142,9 @@ public:
         for (int step = 0; step < numsteps_max; ++step) {
             // :142-145 if synchronized, push velocity backward one half step
             ExplicitFillBoundaryEBUpdateAux();
+            // warpx.sort_intervals (Source/WarpX.cpp:1335): the sort itself runs inside
+            // PhysicalParticleContainer::Evolve, between push and deposition
+            m_ctx.sort_now = sort_intervals > 0 && (istep % sort_intervals == 0);
             // :157-166 ionization / collisions / QED: not on this path
             OneStep_nosub(cur_time);
             // :222-226 at the end of the last step, push p by 0.5*dt to synchronize
@@ -266,8 +269,7 @@ public:
         PhaseTimer t(&m_ctx, kRedistribute);
         // ApplyBoundaryConditions: early return, all particle boundaries periodic
         mypc->RedistributeLocal(num_moved + 1, *m_comm);                      // :559
-        if (sort_intervals > 0 && ((step + 1) % sort_intervals == 0))          // :575-580
-            mypc->SortParticlesByBin(amrex::IntVect(1));
+        (void)step;  // :575-580 SortParticlesByBin: done between push and deposition (see Evolve)
     }
 
     // ---- accessors used by the C API ----

@@ -25,6 +25,7 @@ struct WarpXContext {
     std::array<double, 3> brick_plo{}, brick_phi{};
     amrex::IntVect ng_alloc_EB, ng_depos_J;
     void* stream = nullptr;
+    bool sort_now = false;             // this step re-sorts the tiles (sort_intervals)
     // per-phase device timers, named after the reference's profiler regions
     bool timers_on = false;
     double ms[8] = {0};
@@ -254,6 +255,15 @@ public:
         {
             PhaseTimer t(m_ctx, kGatherAndPush);  // "PhysicalParticleContainer::Evolve::GatherAndPush"
             PushPX(*E[0], *E[1], *E[2], *B[0], *B[1], *B[2], dt);
+        }
+        // Cell sort (amrex SortParticlesByBin, called by the reference from
+        // HandleParticlesAtBoundaries, WarpXEvolve.cpp:575-580).  Sorting only permutes the
+        // tile, so it is placed here, between push and deposition: the deposition then sees
+        // positions that match the sort exactly (every stencil inside its LDS tile) and so does
+        // the next step's gather.
+        if (m_ctx->sort_now) {
+            PhaseTimer t(m_ctx, kRedistribute);
+            SortParticlesByBin(amrex::IntVect(1));
         }
         if (!skip_deposition) {
             PhaseTimer t(m_ctx, kCurrentDeposition);  // "...::DepositCurrent::CurrentDeposition"

@@ -1,7 +1,7 @@
 // Particle kernels for gfx950: gather + push (PushPX / PushP), current and charge
 // deposition (global-atomics variants; the LDS-tile variants live in deposit_tile.hip),
 // periodic wrap, counting sort by cell.
-#include "shapes.hpp"
+#include "deposit_body.hpp"
 #include "workspace.hpp"
 
 #include <hipcub/hipcub.hpp>
@@ -86,114 +86,33 @@ gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, G
 }
 
 // ---------------------------------------------------------------------------
-// Esirkepov, one lane per particle, global fp64 atomics
-// (Source/Particles/Deposition/CurrentDeposition.H:683-824, 3-D branch).
+// One lane per particle, global fp64 atomics (the reference's GPU strategy,
+// Source/Particles/Deposition/CurrentDeposition.H:309-334,683-824); used when no cell sort
+// is available.  Bodies in deposit_body.hpp.
 template <int O>
 __global__ void __launch_bounds__(256)
 deposit_esirkepov_global_kernel(PV p, DevF Jx, DevF Jy, DevF Jz, Geom g, double q, double dt,
                                 double relative_time) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= p.np) return;
-    const double invdtd_x = (1.0 / dt) * g.dyi * g.dzi;
-    const double invdtd_y = (1.0 / dt) * g.dxi * g.dzi;
-    const double invdtd_z = (1.0 / dt) * g.dxi * g.dyi;
-    constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
-    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
-    const double uxp = p.ux[ip], uyp = p.uy[ip], uzp = p.uz[ip];
-    const double gaminv = 1.0 / sqrt(1.0 + uxp * uxp * clightsq + uyp * uyp * clightsq + uzp * uzp * clightsq);
-    const double wq = q * p.w[ip];
-    const double x_new = (p.x[ip] - g.xmin + (relative_time + 0.5 * dt) * uxp * gaminv) * g.dxi;
-    const double x_old = x_new - dt * g.dxi * uxp * gaminv;
-    const double y_new = (p.y[ip] - g.ymin + (relative_time + 0.5 * dt) * uyp * gaminv) * g.dyi;
-    const double y_old = y_new - dt * g.dyi * uyp * gaminv;
-    const double z_new = (p.z[ip] - g.zmin + (relative_time + 0.5 * dt) * uzp * gaminv) * g.dzi;
-    const double z_old = z_new - dt * g.dzi * uzp * gaminv;
-
-    double sx_new[O + 3] = {0.}, sx_old[O + 3] = {0.};
-    double sy_new[O + 3] = {0.}, sy_old[O + 3] = {0.};
-    double sz_new[O + 3] = {0.}, sz_old[O + 3] = {0.};
-    const int i_new = shape_factor<O>(sx_new + 1, x_new);
-    const int i_old = shifted_shape_factor<O>(sx_old, x_old, i_new);
-    const int j_new = shape_factor<O>(sy_new + 1, y_new);
-    const int j_old = shifted_shape_factor<O>(sy_old, y_old, j_new);
-    const int k_new = shape_factor<O>(sz_new + 1, z_new);
-    const int k_old = shifted_shape_factor<O>(sz_old, z_old, k_new);
-    const int dil = (i_old < i_new) ? 0 : 1, diu = (i_old > i_new) ? 0 : 1;
-    const int djl = (j_old < j_new) ? 0 : 1, dju = (j_old > j_new) ? 0 : 1;
-    const int dkl = (k_old < k_new) ? 0 : 1, dku = (k_old > k_new) ? 0 : 1;
-
-    const int bi = g.lo0 + i_new - 1, bj = g.lo1 + j_new - 1, bk = g.lo2 + k_new - 1;
-    double* __restrict__ jx = Jx.p + Jx.off(bi, bj, bk);
-    double* __restrict__ jy = Jy.p + Jy.off(bi, bj, bk);
-    double* __restrict__ jz = Jz.p + Jz.off(bi, bj, bk);
-
-    for (int k = dkl; k <= O + 2 - dku; k++)
-        for (int j = djl; j <= O + 2 - dju; j++) {
-            double sdxi = 0.;
-            for (int i = dil; i <= O + 1 - diu; i++) {
-                sdxi += wq * invdtd_x * (sx_old[i] - sx_new[i]) *
-                        (one_third * (sy_new[j] * sz_new[k] + sy_old[j] * sz_old[k]) +
-                         one_sixth * (sy_new[j] * sz_old[k] + sy_old[j] * sz_new[k]));
-                atomic_add_f64(jx + i + j * Jx.js + k * Jx.ks, sdxi);
-            }
-        }
-    for (int k = dkl; k <= O + 2 - dku; k++)
-        for (int i = dil; i <= O + 2 - diu; i++) {
-            double sdyj = 0.;
-            for (int j = djl; j <= O + 1 - dju; j++) {
-                sdyj += wq * invdtd_y * (sy_old[j] - sy_new[j]) *
-                        (one_third * (sx_new[i] * sz_new[k] + sx_old[i] * sz_old[k]) +
-                         one_sixth * (sx_new[i] * sz_old[k] + sx_old[i] * sz_new[k]));
-                atomic_add_f64(jy + i + j * Jy.js + k * Jy.ks, sdyj);
-            }
-        }
-    for (int j = djl; j <= O + 2 - dju; j++)
-        for (int i = dil; i <= O + 2 - diu; i++) {
-            double sdzk = 0.;
-            for (int k = dkl; k <= O + 1 - dku; k++) {
-                sdzk += wq * invdtd_z * (sz_old[k] - sz_new[k]) *
-                        (one_third * (sx_new[i] * sy_new[j] + sx_old[i] * sy_old[j]) +
-                         one_sixth * (sx_new[i] * sy_old[j] + sx_old[i] * sy_new[j]));
-                atomic_add_f64(jz + i + j * Jz.js + k * Jz.ks, sdzk);
-            }
-        }
+    const ParticleState ps{p.x[ip], p.y[ip], p.z[ip], p.w[ip], p.ux[ip], p.uy[ip], p.uz[ip]};
+    EsirkepovShapes<O> s;
+    esirkepov_shapes<O>(ps, g, q, dt, relative_time, s);
+    GlobalSink sink = make_global_sink(Jx, Jy, Jz);
+    sink.bi = s.bi; sink.bj = s.bj; sink.bk = s.bk;
+    esirkepov_accumulate<O>(s, g, dt, sink);
 }
 
-// Direct deposition on the Yee grid, one lane per particle, global atomics
-// (Source/Particles/Deposition/CurrentDeposition.H:48-249,309-334).
-// J staggering: jx(c,n,n) jy(n,c,n) jz(n,n,c).
 template <int O>
 __global__ void __launch_bounds__(256)
 deposit_direct_global_kernel(PV p, DevF Jx, DevF Jy, DevF Jz, Geom g, double q, double relative_time) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= p.np) return;
-    const double invvol = g.dxi * g.dyi * g.dzi;
-    const double clightsq = 1.0 / PhysConst::c / PhysConst::c;
-    const double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
-    const double gaminv = 1.0 / sqrt(1.0 + ux * ux * clightsq + uy * uy * clightsq + uz * uz * clightsq);
-    const double vx = ux * gaminv, vy = uy * gaminv, vz = uz * gaminv;
-    const double wq = q * p.w[ip];
-    const double wqx = wq * invvol * vx, wqy = wq * invvol * vy, wqz = wq * invvol * vz;
-    const double xmid = ((p.x[ip] - g.xmin) + relative_time * vx) * g.dxi;
-    const double ymid = ((p.y[ip] - g.ymin) + relative_time * vy) * g.dyi;
-    const double zmid = ((p.z[ip] - g.zmin) + relative_time * vz) * g.dzi;
-    double sxn[O + 1], sxc[O + 1], syn[O + 1], syc[O + 1], szn[O + 1], szc[O + 1];
-    const int jn = g.lo0 + shape_factor<O>(sxn, xmid), jc = g.lo0 + shape_factor<O>(sxc, xmid - 0.5);
-    const int kn = g.lo1 + shape_factor<O>(syn, ymid), kc = g.lo1 + shape_factor<O>(syc, ymid - 0.5);
-    const int ln = g.lo2 + shape_factor<O>(szn, zmid), lc = g.lo2 + shape_factor<O>(szc, zmid - 0.5);
-    double* __restrict__ jx = Jx.p + Jx.off(jc, kn, ln);
-    double* __restrict__ jy = Jy.p + Jy.off(jn, kc, ln);
-    double* __restrict__ jz = Jz.p + Jz.off(jn, kn, lc);
-#pragma unroll
-    for (int iz = 0; iz <= O; iz++)
-#pragma unroll
-        for (int iy = 0; iy <= O; iy++)
-#pragma unroll
-            for (int ix = 0; ix <= O; ix++) {
-                atomic_add_f64(jx + ix + iy * Jx.js + iz * Jx.ks, sxc[ix] * syn[iy] * szn[iz] * wqx);
-                atomic_add_f64(jy + ix + iy * Jy.js + iz * Jy.ks, sxn[ix] * syc[iy] * szn[iz] * wqy);
-                atomic_add_f64(jz + ix + iy * Jz.js + iz * Jz.ks, sxn[ix] * syn[iy] * szc[iz] * wqz);
-            }
+    const ParticleState ps{p.x[ip], p.y[ip], p.z[ip], p.w[ip], p.ux[ip], p.uy[ip], p.uz[ip]};
+    DirectShapes<O> s;
+    direct_shapes<O>(ps, g, q, relative_time, s);
+    GlobalSink sink = make_global_sink(Jx, Jy, Jz);
+    direct_accumulate<O>(s, sink);
 }
 
 // Source/Particles/Deposition/ChargeDeposition.H:37-180 (3-D), rho of any staggering
@@ -244,6 +163,8 @@ struct SortGeom {
     int nc[3];
 };
 
+// Tile-major cell key: tiles of WXA_TILE^3 cells, cells i-fastest inside a tile, so that a
+// tile's particles are contiguous (LDS-tile kernels) and still grouped by cell.
 __device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, double z) {
     int i = (int)floor((x - s.plo[0]) * s.dinv[0]);
     int j = (int)floor((y - s.plo[1]) * s.dinv[1]);
@@ -251,7 +172,10 @@ __device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, do
     i = min(max(i, 0), s.nc[0] - 1);
     j = min(max(j, 0), s.nc[1] - 1);
     k = min(max(k, 0), s.nc[2] - 1);
-    return i + s.nc[0] * (j + s.nc[1] * k);
+    constexpr int T = WXA_TILE;
+    const int nti = (s.nc[0] + T - 1) / T, ntj = (s.nc[1] + T - 1) / T;
+    const int tile = (i / T) + nti * ((j / T) + ntj * (k / T));
+    return tile * (T * T * T) + (i % T) + T * ((j % T) + T * (k % T));
 }
 
 __global__ void __launch_bounds__(256)
@@ -448,7 +372,9 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     WXA_REQUIRE(pv_ok(src) && pv_ok(dst) && plo && dinv && cell_lo && ncell && ws, "bad argument");
     WXA_REQUIRE(src->np == dst->np, "src/dst particle counts differ");
     WXA_REQUIRE(src->x != dst->x, "sort is out of place");
-    const long ncells = (long)ncell[0] * ncell[1] * ncell[2];
+    WXA_REQUIRE(ncell[0] > 0 && ncell[1] > 0 && ncell[2] > 0, "empty cell box");
+    const long ncells = (long)((ncell[0] + WXA_TILE - 1) / WXA_TILE) * ((ncell[1] + WXA_TILE - 1) / WXA_TILE) *
+                        ((ncell[2] + WXA_TILE - 1) / WXA_TILE) * (WXA_TILE * WXA_TILE * WXA_TILE);
     WXA_REQUIRE(ncells > 0 && ncells < (1L << 31) - 2 && src->np < (1L << 31) - 2, "sizes exceed 32-bit sort keys");
     hipStream_t st = (hipStream_t)stream;
     ws->sorted_valid = false;

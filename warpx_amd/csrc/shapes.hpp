@@ -44,37 +44,51 @@ __device__ __forceinline__ int shape_factor(double* __restrict__ s, const double
 }
 
 // Old-position weights on the slots of the new position (Esirkepov),
-// Source/Particles/ShapeFactors.H:93-156.  s has ORDER+3 pre-zeroed entries.
+// Source/Particles/ShapeFactors.H:93-156.  s has ORDER+3 entries, all written here.
+// The reference stores the ORDER+1 weights at the run-time offset 1+i_shift; a run-time
+// register index would spill the array to scratch memory on gfx950, so every slot is
+// selected from the (at most three) candidate weights instead.
 template <int ORDER>
 __device__ __forceinline__ int shifted_shape_factor(double* __restrict__ s, const double x_old,
                                                     const int i_new) {
+    double w[ORDER + 1];
+    int i, sh, ret;
     if constexpr (ORDER == 1) {
-        const int i = (int)floor(x_old);
-        const int sh = i - i_new;
+        i = (int)floor(x_old);
+        sh = i - i_new;
         const double xi = x_old - (double)i;
-        s[1 + sh] = 1.0 - xi;
-        s[2 + sh] = xi;
-        return i;
+        w[0] = 1.0 - xi;
+        w[1] = xi;
+        ret = i;
     } else if constexpr (ORDER == 2) {
-        const int i = (int)(x_old + 0.5);
-        const int sh = i - (i_new + 1);
+        i = (int)(x_old + 0.5);
+        sh = i - (i_new + 1);
         const double xi = x_old - (double)i;
-        s[1 + sh] = 0.5 * (0.5 - xi) * (0.5 - xi);
-        s[2 + sh] = 0.75 - xi * xi;
-        s[3 + sh] = 0.5 * (0.5 + xi) * (0.5 + xi);
-        return i - 1;
+        w[0] = 0.5 * (0.5 - xi) * (0.5 - xi);
+        w[1] = 0.75 - xi * xi;
+        w[2] = 0.5 * (0.5 + xi) * (0.5 + xi);
+        ret = i - 1;
     } else {
         static_assert(ORDER == 3, "orders 1..3");
-        const int i = (int)x_old;
-        const int sh = i - (i_new + 1);
+        i = (int)x_old;
+        sh = i - (i_new + 1);
         const double xi = x_old - (double)i;
         const double om = 1.0 - xi;
-        s[1 + sh] = (1.0 / 6.0) * om * om * om;
-        s[2 + sh] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);
-        s[3 + sh] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);
-        s[4 + sh] = (1.0 / 6.0) * xi * xi * xi;
-        return i - 1;
+        w[0] = (1.0 / 6.0) * om * om * om;
+        w[1] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);
+        w[2] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);
+        w[3] = (1.0 / 6.0) * xi * xi * xi;
+        ret = i - 1;
     }
+    // slot a holds w[a - 1 - sh] when that index exists (sh in {-1,0,+1} under the CFL limit)
+#pragma unroll
+    for (int a = 0; a < ORDER + 3; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b <= ORDER; ++b) v = (a - 1 - sh == b) ? w[b] : v;
+        s[a] = v;
+    }
+    return ret;
 }
 
 // Source/Particles/Pusher/UpdateMomentumBoris.H:15-53

@@ -4,6 +4,8 @@
 
 #include "common.hpp"
 
+#define WXA_TILE 8   // tile edge (cells) of the tile-major cell sort and of the LDS-tile kernels
+
 namespace wxa {
 
 // grow-only device buffer
