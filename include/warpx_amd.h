@@ -134,6 +134,17 @@ wxa_status wxa_push_p(const wxa_particle_view* p,
                       double q, double m, double dt,
                       int order, int galerkin, int pusher, void* stream);
 
+/* The same two operators with a workspace: when `ws` holds a valid cell sort of exactly these
+ * particle arrays (wxa_sort_particles_by_cell), the LDS-tile variant runs (fields of each
+ * 8x8x8-cell tile staged in LDS); otherwise identical to the two calls above.
+ * move != 0 -> PushPX, move == 0 -> PushP. */
+wxa_status wxa_gather_push_ws(const wxa_particle_view* p,
+                              const wxa_field_view E[3], const wxa_field_view B[3],
+                              const wxa_grid_geom* geom,
+                              double q, double m, double dt,
+                              int order, int galerkin, int pusher, int move,
+                              wxa_workspace* ws, void* stream);
+
 /* Replaces WarpXParticleContainer::DepositCurrent
  * (Source/Particles/WarpXParticleContainer.cpp:352-827) for
  * algo = Esirkepov: doEsirkepovDepositionShapeN<order>

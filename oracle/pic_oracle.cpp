@@ -176,6 +176,10 @@ void deposit_impl(const wxa_particle_view* p, const wxa_field_view J[3], const w
         deposit_range<O>(p, 0, p->np, J, g, q, dt, rel, algo);
         return;
     }
+    // Thread-private J scratch + accumulate (WarpXParticleContainer.cpp:455-470,819-826).  Each
+    // thread takes a contiguous particle range; its scratch only spans the k-planes that range can
+    // touch (the range's z extent + the stencil reach), so memory stays bounded on many-core hosts.
+    const int reach = O + 3;
 #pragma omp parallel
     {
 #ifdef _OPENMP
@@ -183,21 +187,32 @@ void deposit_impl(const wxa_particle_view* p, const wxa_field_view J[3], const w
 #else
         const int t = 0, T = 1;
 #endif
-        PrivJ pj;
-        for (int c = 0; c < 3; ++c) {
-            pj.v[c] = J[c];
-            pj.buf[c].assign((size_t)J[c].kstride * J[c].n[2], 0.0);
-            pj.v[c].p = pj.buf[c].data();
-        }
         const int64_t b = p->np * t / T, e = p->np * (t + 1) / T;
-        deposit_range<O>(p, b, e, pj.v, g, q, dt, rel, algo);
-#pragma omp critical
-        {
+        if (e > b) {
+            double zmin = p->z[b], zmax = p->z[b];
+            for (int64_t i = b; i < e; ++i) { zmin = std::min(zmin, p->z[i]); zmax = std::max(zmax, p->z[i]); }
+            int k0 = g->lo[2] + (int)std::floor((zmin - g->xyzmin[2]) * g->dinv[2]) - reach;
+            int k1 = g->lo[2] + (int)std::floor((zmax - g->xyzmin[2]) * g->dinv[2]) + reach + 1;
+            PrivJ pj;
+            for (int c = 0; c < 3; ++c) {
+                const int lo = std::max(k0, J[c].lo[2]), hi = std::min(k1, J[c].lo[2] + J[c].n[2]);
+                pj.v[c] = J[c];
+                pj.v[c].lo[2] = lo;
+                pj.v[c].n[2] = std::max(hi - lo, 0);
+                pj.buf[c].assign((size_t)J[c].kstride * pj.v[c].n[2], 0.0);
+                pj.v[c].p = pj.buf[c].data();
+            }
+            deposit_range<O>(p, b, e, pj.v, g, q, dt, rel, algo);
             for (int c = 0; c < 3; ++c) {
                 const size_t n = pj.buf[c].size();
-                double* dst = J[c].p;
+                double* dst = J[c].p + (size_t)(pj.v[c].lo[2] - J[c].lo[2]) * J[c].kstride;
                 const double* src = pj.buf[c].data();
-                for (size_t i = 0; i < n; ++i) dst[i] += src[i];
+                for (size_t i = 0; i < n; ++i) {
+                    if (src[i] != 0.0) {
+#pragma omp atomic
+                        dst[i] += src[i];
+                    }
+                }
             }
         }
     }
@@ -384,6 +399,75 @@ int orc_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3], cons
 
 int orc_field_set_zero(const wxa_field_view* f, void*) {
     std::memset(f->p, 0, sizeof(double) * (size_t)f->kstride * f->n[2]);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Host-side counterparts of the exchange helpers, used only when the test-suite runs the
+// product's C++ host layer on CPU (tests/host_cpu) to exercise the multi-brick logic.
+int orc_pack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], double* buf, void*) {
+    const Arr a(*f);
+    int64_t t = 0;
+    for (int k = blo[2]; k < bhi[2]; ++k)
+        for (int j = blo[1]; j < bhi[1]; ++j)
+            for (int i = blo[0]; i < bhi[0]; ++i) buf[t++] = a(i, j, k);
+    return 0;
+}
+
+int orc_unpack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], const double* buf,
+                   int mode, void*) {
+    const Arr a(*f);
+    int64_t t = 0;
+    for (int k = blo[2]; k < bhi[2]; ++k)
+        for (int j = blo[1]; j < bhi[1]; ++j)
+            for (int i = blo[0]; i < bhi[0]; ++i) {
+                if (mode == 0) a(i, j, k) = buf[t++];
+                else a(i, j, k) += buf[t++];
+            }
+    return 0;
+}
+
+int orc_partition_particles(const wxa_particle_view* src, const wxa_particle_view* dst, int dim, double lo,
+                            double hi, int64_t counts[3], void*, void*) {
+    const double* pos = dim == 0 ? src->x : (dim == 1 ? src->y : src->z);
+    const double* s[7] = {src->x, src->y, src->z, src->w, src->ux, src->uy, src->uz};
+    double* d[7] = {dst->x, dst->y, dst->z, dst->w, dst->ux, dst->uy, dst->uz};
+    counts[0] = counts[1] = counts[2] = 0;
+    for (int64_t i = 0; i < src->np; ++i) counts[pos[i] < lo ? 1 : (pos[i] >= hi ? 2 : 0)]++;
+    int64_t cur[3] = {0, counts[0], counts[0] + counts[1]};
+    for (int64_t i = 0; i < src->np; ++i) {
+        const int key = pos[i] < lo ? 1 : (pos[i] >= hi ? 2 : 0);
+        const int64_t t = cur[key]++;
+        for (int c = 0; c < 7; ++c) d[c][t] = s[c][i];
+        if (src->idcpu && dst->idcpu) dst->idcpu[t] = src->idcpu[i];
+    }
+    return 0;
+}
+
+// stable counting sort by cell (i fastest); any grouping by cell is a valid SortParticlesByBin
+int orc_sort_particles_by_cell(const wxa_particle_view* src, const wxa_particle_view* dst, const double plo[3],
+                               const double dinv[3], const int32_t*, const int32_t ncell[3], void*, void*) {
+    const int64_t nc = (int64_t)ncell[0] * ncell[1] * ncell[2];
+    std::vector<int64_t> off(nc + 1, 0);
+    std::vector<int64_t> key(src->np);
+    for (int64_t p = 0; p < src->np; ++p) {
+        int c[3];
+        const double pos[3] = {src->x[p], src->y[p], src->z[p]};
+        for (int d = 0; d < 3; ++d) {
+            c[d] = (int)std::floor((pos[d] - plo[d]) * dinv[d]);
+            c[d] = std::min(std::max(c[d], 0), ncell[d] - 1);
+        }
+        key[p] = c[0] + (int64_t)ncell[0] * (c[1] + (int64_t)ncell[1] * c[2]);
+        off[key[p] + 1]++;
+    }
+    for (int64_t c = 0; c < nc; ++c) off[c + 1] += off[c];
+    const double* s[7] = {src->x, src->y, src->z, src->w, src->ux, src->uy, src->uz};
+    double* d[7] = {dst->x, dst->y, dst->z, dst->w, dst->ux, dst->uy, dst->uz};
+    for (int64_t p = 0; p < src->np; ++p) {
+        const int64_t t = off[key[p]]++;
+        for (int c = 0; c < 7; ++c) d[c][t] = s[c][p];
+        if (src->idcpu && dst->idcpu) dst->idcpu[t] = src->idcpu[p];
+    }
     return 0;
 }
 

@@ -1,0 +1,82 @@
+// TEST INFRASTRUCTURE ONLY.  Compiles the product's C++17 host layer
+// (warpx_amd/csrc/host/*.hpp: MultiFab/MultiFabRegister/WarpXParticleContainer/
+// FiniteDifferenceSolver/BrickComm/WarpX) against the CPU oracle's entry points, so that the
+// multi-brick exchange and migration logic can be exercised with torch.distributed/gloo on a
+// machine without a GPU.  Exports `hst_sim_*`.  Never linked into libwarpx_amd.so.
+#include <cstdlib>
+#include <cstring>
+
+#include "../../warpx_amd/csrc/host/sim_capi.hpp"
+
+extern "C" {
+int orc_evolve_b(const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
+int orc_evolve_e(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
+int orc_gather_push(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
+                    double, double, double, int, int, int, void*);
+int orc_push_p(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
+               double, double, double, int, int, int, void*);
+int orc_deposit_current(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, double,
+                        double, int, int, void*, void*);
+int orc_filter_bilinear(const wxa_field_view*, const wxa_field_view*, void*);
+int orc_fill_boundary_periodic(const wxa_field_view*, const int*, const int*, void*);
+int orc_sync_nodal_periodic(const wxa_field_view*, const int*, void*);
+int orc_sum_boundary_periodic(const wxa_field_view*, const int*, const int*, void*);
+int orc_pack_box(const wxa_field_view*, const int32_t*, const int32_t*, double*, void*);
+int orc_unpack_box(const wxa_field_view*, const int32_t*, const int32_t*, const double*, int, void*);
+int orc_field_set_zero(const wxa_field_view*, void*);
+int orc_enforce_periodic(const wxa_particle_view*, const double*, const double*, const int*, void*);
+int orc_sort_particles_by_cell(const wxa_particle_view*, const wxa_particle_view*, const double*, const double*,
+                               const int32_t*, const int32_t*, void*, void*);
+int orc_partition_particles(const wxa_particle_view*, const wxa_particle_view*, int, double, double, int64_t*,
+                            void*, void*);
+}
+
+namespace {
+
+using wxa::host::Backend;
+
+int ws_create(void** ws) { *ws = std::malloc(8); return 0; }
+void ws_destroy(void* ws) { std::free(ws); }
+void* h_malloc(size_t n) { return std::malloc(n ? n : 8); }
+void h_free(void* p) { std::free(p); }
+int h_memset(void* p, int v, size_t n, void*) { std::memset(p, v, n); return 0; }
+int h_memcpy(void* d, const void* s, size_t n, void*) { if (n) std::memmove(d, s, n); return 0; }
+int h_memcpy2(void* d, const void* s, size_t n) { if (n) std::memmove(d, s, n); return 0; }
+int h_sync(void*) { return 0; }
+
+const Backend* cpu_backend() {
+    static const Backend be = [] {
+        Backend b{};
+        b.name = "cpu-oracle (tests only)";
+        b.evolve_b = orc_evolve_b; b.evolve_e = orc_evolve_e;
+        b.gather_push = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
+                           const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, int move,
+                           void*, void* st) -> int {
+            return move ? orc_gather_push(p, E, B, g, q, m, dt, o, ga, pu, st)
+                        : orc_push_p(p, E, B, g, q, m, dt, o, ga, pu, st); };
+        b.deposit_current = orc_deposit_current;
+        b.filter_bilinear = orc_filter_bilinear;
+        b.fill_boundary_periodic = orc_fill_boundary_periodic;
+        b.sync_nodal_periodic = orc_sync_nodal_periodic;
+        b.sum_boundary_periodic = orc_sum_boundary_periodic;
+        b.pack_box = orc_pack_box; b.unpack_box = orc_unpack_box;
+        b.field_set_zero = orc_field_set_zero;
+        b.enforce_periodic = orc_enforce_periodic;
+        b.sort_particles_by_cell = orc_sort_particles_by_cell;
+        b.partition_particles = orc_partition_particles;
+        b.workspace_create = ws_create; b.workspace_destroy = ws_destroy;
+        b.dmalloc = h_malloc; b.dfree = h_free;
+        b.memset_async = h_memset; b.memcpy_async = h_memcpy;
+        b.memcpy_h2d = h_memcpy2; b.memcpy_d2h = h_memcpy2;
+        b.stream_sync = h_sync;
+        return b;
+    }();
+    return &be;
+}
+
+void set_err(const char* msg) { std::fprintf(stderr, "[host_cpu] %s\n", msg); }
+
+}  // namespace
+
+struct hst_sim {};
+WXA_SIM_CAPI(hst_, int, hst_sim, cpu_backend, set_err)

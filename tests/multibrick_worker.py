@@ -1,0 +1,90 @@
+"""Worker for the multi-brick CPU tests: every rank owns one brick, runs the product's host
+layer (CPU build, oracle kernels) with the torch.distributed transport over gloo, and rank 0
+compares the reassembled result with a single-domain run of the independent oracle stepper.
+
+    python -m torch.distributed.run --nproc-per-node N tests/multibrick_worker.py NBX NBY NBZ ORDER FILTER OUT
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from tests.oracle_lib import load_host_cpu, load_oracle  # noqa: E402
+from warpx_amd import _capi, plasma  # noqa: E402
+from warpx_amd.distributed import TorchBrickTransport, brick_coord  # noqa: E402
+from warpx_amd.sim import WarpXSim, field_energy, particle_moments  # noqa: E402
+
+L = 40e-6
+FIELDS = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz")
+
+
+def main():
+    nb = tuple(int(v) for v in sys.argv[1:4])
+    order, filt, out = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    steps = 6
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == nb[0] * nb[1] * nb[2]
+    n_cell = (16, 16, 16)
+    prob_lo, prob_hi = (-L / 2,) * 3, (L / 2,) * 3
+    # hot plasma so that particles cross brick boundaries within a few steps
+    parts = np.array(plasma.uniform_plasma(n_cell, prob_lo, prob_hi, (1, 2, 1), 1e25, 0.3, seed=11))
+    coord = brick_coord(rank, nb)
+    bn = [n_cell[d] // nb[d] for d in range(3)]
+    dx = [L / n_cell[d] for d in range(3)]
+    lo = [prob_lo[d] + coord[d] * bn[d] * dx[d] for d in range(3)]
+    hi = [prob_lo[d] + (coord[d] + 1) * bn[d] * dx[d] for d in range(3)]
+    mine = np.ones(parts.shape[1], dtype=bool)
+    for d in range(3):
+        mine &= (parts[d] >= lo[d]) & (parts[d] < hi[d])
+    transport = TorchBrickTransport(on_device=False)
+    lib = load_host_cpu()
+    sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, sort_interval=2,
+                   nbricks=nb, coord=coord, comm=transport.comm)
+    sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
+    sim.evolve(steps)
+    # ---- collect on rank 0 ----
+    local = {n: sim.field_valid(n) for n in FIELDS}
+    mom = particle_moments(sim, sid)
+    p_local = sim.particles(sid)
+    inside = all(np.all((p_local[d] >= lo[d]) & (p_local[d] < hi[d])) for d in range(3))
+    payload = {"coord": coord, "fields": local, "ekin": mom["ekin"], "np": p_local.shape[1],
+               "abs_p": mom["abs_momentum"], "inside": bool(inside), "exchanges": transport.n_exchanges}
+    gathered = [None] * world
+    dist.gather_object(payload, gathered if rank == 0 else None, dst=0)
+    if rank == 0:
+        orc = load_oracle()
+        ref = WarpXSim(orc, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt)
+        rid = ref.add_species(-plasma.Q_E, plasma.M_E, list(parts))
+        ref.evolve(steps)
+        rmom = particle_moments(ref, rid)
+        report = {"ok": True, "errors": {}, "np_total": sum(g["np"] for g in gathered),
+                  "np_ref": int(parts.shape[1]), "inside": all(g["inside"] for g in gathered),
+                  "exchanges": gathered[0]["exchanges"]}
+        for n in FIELDS:
+            full = ref.field_valid(n)
+            worst = 0.0
+            for g in gathered:
+                c = g["coord"]
+                a = g["fields"][n]
+                sl = tuple(slice(c[d] * bn[d], c[d] * bn[d] + a.shape[d]) for d in range(3))
+                worst = max(worst, float(np.max(np.abs(a - full[sl])) / max(np.max(np.abs(full)), 1e-300)))
+            report["errors"][n] = worst
+        ek = sum(g["ekin"] for g in gathered)
+        report["ekin_rel"] = abs(ek - rmom["ekin"]) / rmom["ekin"]
+        ap = np.sum([g["abs_p"] for g in gathered], axis=0)
+        report["abs_p_rel"] = float(np.max(np.abs(ap - np.array(rmom["abs_momentum"])) / np.array(rmom["abs_momentum"])))
+        json.dump(report, open(out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

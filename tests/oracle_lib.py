@@ -29,3 +29,18 @@ def load_oracle():
         build_oracle()
         _oracle = _capi.CLib(ORACLE_LIB, "orc_", _capi._ORACLE_SIGS)
     return _oracle
+
+
+HOST_CPU_DIR = os.path.join(ROOT, "tests", "host_cpu")
+HOST_CPU_LIB = os.path.join(HOST_CPU_DIR, "libhost_cpu.so")
+_host_cpu = None
+
+
+def load_host_cpu():
+    """The product's C++ host layer compiled against the oracle kernels (CPU, tests only):
+    `hst_sim_*` has the step-level API of include/warpx_amd.h with host pointers."""
+    global _host_cpu
+    if _host_cpu is None:
+        subprocess.check_call(["make", "-C", HOST_CPU_DIR, "libhost_cpu.so"], stdout=subprocess.DEVNULL)
+        _host_cpu = _capi.CLib(HOST_CPU_LIB, "hst_", None, kernels=False)
+    return _host_cpu

@@ -258,3 +258,63 @@ def test_deposit_current_lds_tiles(oracle, product, order, algo, stale):
     for a, b in zip(Jd, J):
         assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
     product.workspace_destroy(ws)
+
+
+@pytest.mark.parametrize("order,galerkin", [(1, 1), (2, 1), (3, 1), (3, 0)])
+@pytest.mark.parametrize("stale", [False, True])
+def test_gather_push_lds_tiles(oracle, product, order, galerkin, stale):
+    """LDS-tile gather (needs a cell sort in the workspace) against the oracle; `stale` moves the
+    particles after the sort so that some stencils leave the staged range (global-load path)."""
+    import torch
+    ncell = (24, 20, 16)
+    ng, _, _ = H.guard_depths(order)
+    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, ng, 10, scale=1e11)
+    B = H.random_fields(("Bx", "By", "Bz"), ncell, ng, 11, scale=1e3)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    parts = H.random_particles(30000, ncell, 300 + order)
+    dx = H.LX / np.asarray(ncell)
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    srt = ParticleArrays(pd0.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    if stale:
+        rng = np.random.default_rng(6)
+        for d in range(3):
+            srt.data[d] += torch.from_numpy(dx[d] * 0.9 * (2 * rng.random(srt.np) - 1)).to(DEV)
+            # keep the particles inside the domain, as the step loop guarantees at gather time
+            srt.data[d].clamp_(-H.LX / 2, H.LX / 2 - 1e-12)
+    ph = ParticleArrays.from_numpy(list(srt.to_numpy()), "cpu")
+    g, _ = H.geom_for(ncell, ng)
+    dt = H.yee_dt(dx)
+    q, m = -plasma.Q_E, plasma.M_E
+    for move, fn in ((1, "gather_push"), (0, "push_p")):
+        getattr(oracle, fn)(C.byref(ph.view), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt,
+                            order, galerkin, _capi.PUSHER_BORIS, None)
+        product.gather_push_ws(C.byref(srt.view), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt,
+                               order, galerkin, _capi.PUSHER_BORIS, move, ws, None)
+        _sync(product)
+        a, b = srt.to_numpy(), ph.to_numpy()
+        for row in range(7):
+            assert H.max_rel_err(a[row], b[row]) < 1e-12, (fn, row)
+    product.workspace_destroy(ws)
+
+
+def test_device_pointer_wrapping(product):
+    """The torch.distributed transport wraps raw device pointers handed out by the C++ host layer
+    (warpx_amd/distributed.py::_as_tensor); check the view aliases the memory."""
+    import torch
+    from warpx_amd.distributed import _as_tensor
+    f = FieldArray(NCELL, STAG["Ex"], (2, 2, 2), DEV)
+    nbytes = 8 * 16
+    t = _as_tensor(f.view.p, nbytes, True)
+    assert t.is_cuda and t.numel() == nbytes
+    t.view(torch.float64).fill_(3.5)
+    torch.cuda.synchronize()
+    assert np.all(f.storage[f.front:f.front + 16].cpu().numpy() == 3.5)
+    u = _as_tensor(f.view.p + 8 * 16, nbytes, True)
+    u.copy_(t)
+    torch.cuda.synchronize()
+    assert np.all(f.storage[f.front + 16:f.front + 32].cpu().numpy() == 3.5)

@@ -1,0 +1,39 @@
+"""N>1 path on CPU: world_size-2/4 gloo runs of the product host layer (bricks, guard-cell
+exchange, particle migration through the torch.distributed transport) against a single-domain
+run of the oracle.  Covers the code bench.py uses over RCCL on the 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(nb, order, filt, tmp_path, port):
+    out = str(tmp_path / "report.json")
+    n = nb[0] * nb[1] * nb[2]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "multibrick_worker.py"), *[str(v) for v in nb], str(order), str(filt), out]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("nb,order,filt,port", [
+    ((1, 1, 2), 3, 1, 29611),   # the 2-GPU layout of bench.py
+    ((2, 1, 1), 1, 0, 29612),   # split along the contiguous direction
+    ((1, 2, 2), 2, 1, 29613),   # the 4-GPU layout: edges/corners through two exchanged directions
+])
+def test_bricks_match_single_domain(nb, order, filt, port, tmp_path):
+    rep = _run(nb, order, filt, tmp_path, port)
+    print(rep)
+    assert rep["np_total"] == rep["np_ref"]          # no particle lost or duplicated in migration
+    assert rep["inside"]                              # every particle ended in its owner brick
+    assert rep["exchanges"] > 0
+    for name, err in rep["errors"].items():
+        assert err < 1e-10, (name, err)
+    assert rep["ekin_rel"] < 1e-11 and rep["abs_p_rel"] < 1e-11

@@ -131,6 +131,8 @@ _PRODUCT_SIGS = {
     "workspace_destroy": (None, [C.c_void_p]),
     "last_error": (C.c_char_p, []),
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
+    "gather_push_ws": (C.c_int, [_PPV, _FV3, _FV3, _PGG, C.c_double, C.c_double, C.c_double,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "partition_particles": (C.c_int, [_PPV, _PPV, C.c_int, C.c_double, C.c_double,
                                       C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "pack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
@@ -160,14 +162,14 @@ class WxaError(RuntimeError):
 class CLib:
     """A loaded C library whose symbols `<prefix><name>` follow include/warpx_amd.h."""
 
-    def __init__(self, path: str, prefix: str, extra_sigs: dict | None = None):
+    def __init__(self, path: str, prefix: str, extra_sigs: dict | None = None, kernels: bool = True):
         if not os.path.exists(path):
             raise WxaError(
                 f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()')")
         self.path = path
         self.prefix = prefix
         self._dll = C.CDLL(path, mode=C.RTLD_GLOBAL if prefix == "wxa_" else C.RTLD_LOCAL)
-        sigs = dict(_KERNEL_SIGS)
+        sigs = dict(_KERNEL_SIGS) if kernels else {}
         sigs.update(_SIM_SIGS)
         if extra_sigs:
             sigs.update(extra_sigs)

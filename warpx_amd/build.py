@@ -25,6 +25,7 @@ SOURCES = [
     ("fields.hip", ["-ffp-contract=off"]),
     ("particles.hip", []),
     ("deposit_tile.hip", []),
+    ("gather_tile.hip", []),
     ("host/warpx_host.hip", []),
 ]
 

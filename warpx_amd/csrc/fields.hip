@@ -171,25 +171,32 @@ shift_copy_kernel(DevF f, BoxN box, int s0, int s1, int s2) {
     }
 }
 
-// SumBoundary along direction d: every residue class mod nc is summed over its
-// members in [s0,s1) and the total written to all members in the allocation.
+// SumBoundary along direction d: every residue class mod nc is summed over its members in
+// [s0,s1) and the total written to all members in the allocation.  Only the classes with more
+// than one member inside the allocation can change (the n[d]-nc = stag+2*ng lowest points and
+// their images); the interior of the array is never touched.
 __global__ void __launch_bounds__(256)
 sum_periodic_kernel(DevF f, int d, int nc, int s0, int s1) {
     const int lo[3] = {f.lo0, f.lo1, f.lo2};
     const int n[3] = {f.n0, f.n1, f.n2};
     const long st[3] = {1, f.js, f.ks};
-    // thread space: (fast, r, slow) where fast/slow are the other two directions
     const int da = d == 0 ? 1 : 0;           // faster of the other two
     const int db = d == 2 ? 1 : 2;           // slower of the other two
-    const long total = (long)n[da] * nc * n[db];
+    const int nr = n[d] - nc;                // classes with >= 2 members in the allocation
+    if (nr <= 0) return;
+    // thread space: (fast a, class r, slow b); for d == 0 the class index is made the fastest so
+    // that neighbouring lanes touch neighbouring addresses
+    const long total = (long)n[da] * nr * n[db];
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int a = (int)(t % n[da]);
-        const int r = (int)((t / n[da]) % nc);
-        const int b = (int)(t / ((long)n[da] * nc));
+        int a, r, b;
+        if (d == 0) {
+            r = (int)(t % nr); a = (int)((t / nr) % n[da]); b = (int)(t / ((long)nr * n[da]));
+        } else {
+            a = (int)(t % n[da]); r = (int)((t / n[da]) % nr); b = (int)(t / ((long)n[da] * nr));
+        }
         double* base = f.p + a * st[da] + b * st[db];
         const int a0 = lo[d], a1 = lo[d] + n[d];
-        // first member of the class inside the allocation
-        int first = a0 + (((r - a0) % nc) + nc) % nc;
+        const int first = a0 + r;
         double sum = 0.0;
         for (int m = first; m < a1; m += nc)
             if (m >= s0 && m < s1) sum += base[(long)(m - a0) * st[d]];
@@ -373,8 +380,9 @@ wxa_status wxa_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3
         const int nc = f->n[d] - 2 * f->ng[d] - f->stag[d];
         const int s0 = f->lo[d] + f->ng[d] - src_ng[d];
         const int s1 = f->lo[d] + f->n[d] - f->ng[d] + src_ng[d];
+        WXA_REQUIRE(nc >= f->stag[d] + 2 * f->ng[d], "brick thinner than its guard cells");
         const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
-        const long total = (long)f->n[da] * nc * f->n[db];
+        const long total = (long)f->n[da] * (f->n[d] - nc) * f->n[db];
         hipLaunchKernelGGL(sum_periodic_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, df, d,
                            nc, s0, s1);
     }

@@ -1,0 +1,149 @@
+// LDS-tile gather + push for gfx950.
+//
+// The plain gather (particles.hip) issues 252 global loads per particle at order 3; with
+// cell-sorted particles they hit L1, but the texture-address path moves 64 lanes x 8 B per
+// instruction at ~40 B/clk, which bounds the kernel (rocprof: ~13 clk per wave load, VALU 25 %
+// busy).  Here one workgroup owns one 8x8x8-cell tile of the tile-major cell sort, stages the six
+// staggered field components of the tile plus the stencil halo in LDS once
+// (6 x 11^3 x 8 B = 63.9 KB with the energy-conserving gather, 2 workgroups per CU) and serves the
+// gathers with ds_read_b64 (256 B/clk, same-cell lanes broadcast).  Particles whose stencil leaves
+// the staged range (stale sort, particles wrapped across the periodic boundary) use the global
+// path, so correctness never depends on the sort being fresh.
+#include "gather_body.hpp"
+#include "workspace.hpp"
+
+namespace wxa {
+
+constexpr int GT_TS = WXA_TILE;
+constexpr int GT_THREADS = 256;
+
+template <int G>
+struct GatherTileDims {
+    static constexpr int LO = G ? -1 : -2;           // first staged point relative to the tile's first cell
+    static constexpr int N = GT_TS + (G ? 3 : 4);    // staged points per direction
+    static constexpr int NPTS = N * N * N;
+};
+
+struct GTileGeom {
+    int nt[3];
+    int cell_lo[3];
+};
+
+template <int N>
+struct LdsField {
+    const double* base;
+    __device__ __forceinline__ const double* at(int i, int j, int k) const { return base + i + N * (j + N * k); }
+    static constexpr long js = N, ks = N * N;
+};
+
+template <int O, int G, int PUSHER, bool MOVE>
+__global__ void __launch_bounds__(GT_THREADS)
+gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
+                        DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt) {
+    constexpr int N = GatherTileDims<G>::N;
+    constexpr int NPTS = GatherTileDims<G>::NPTS;
+    __shared__ double F[6 * NPTS];
+    const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
+    const long tile = xcd_tile_id(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    constexpr int TC = GT_TS * GT_TS * GT_TS;
+    const int start = offsets[tile * TC];
+    const int end = offsets[(tile + 1) * TC];
+    if (end <= start) return;
+    const int tid = threadIdx.x;
+    const int ti = (int)(tile % tg.nt[0]);
+    const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
+    const int tk = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
+    const int o0 = tg.cell_lo[0] + ti * GT_TS + GatherTileDims<G>::LO;
+    const int o1 = tg.cell_lo[1] + tj * GT_TS + GatherTileDims<G>::LO;
+    const int o2 = tg.cell_lo[2] + tk * GT_TS + GatherTileDims<G>::LO;
+    const DevF* fld[6] = {&Ex, &Ey, &Ez, &Bx, &By, &Bz};
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const DevF& f = *fld[c];
+        for (int a = tid; a < NPTS; a += GT_THREADS) {
+            const int i = o0 + a % N, j = o1 + (a / N) % N, k = o2 + a / (N * N);
+            const bool in = i >= f.lo0 && i < f.lo0 + f.n0 && j >= f.lo1 && j < f.lo1 + f.n1 && k >= f.lo2 &&
+                            k < f.lo2 + f.n2;
+            F[c * NPTS + a] = in ? f.p[f.off(i, j, k)] : 0.0;
+        }
+    }
+    __syncthreads();
+
+    for (int ip = start + tid; ip < end; ip += GT_THREADS) {
+        double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
+        GatherShapes<O, G> s;
+        gather_shapes<O, G>(xp, yp, zp, g, s);
+        // staged range check on the extreme points of the node / cell stencils
+        constexpr int NN = O + 1, NC = O + 1 - G;
+        const int lo_i = min(s.jn, s.jc) - o0, hi_i = max(s.jn + NN, s.jc + NC) - 1 - o0;
+        const int lo_j = min(s.kn, s.kc) - o1, hi_j = max(s.kn + NN, s.kc + NC) - 1 - o1;
+        const int lo_k = min(s.ln, s.lc) - o2, hi_k = max(s.ln + NN, s.lc + NC) - 1 - o2;
+        double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
+        if (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N) {
+            const int jn = s.jn - o0, jc = s.jc - o0, kn = s.kn - o1, kc = s.kc - o1, ln = s.ln - o2, lc = s.lc - o2;
+            Exp = gather_rows<NC, NN, NN>(F + 0 * NPTS + jc + N * (kn + N * ln), N, N * N, s.sxc, s.syn, s.szn);
+            Eyp = gather_rows<NN, NC, NN>(F + 1 * NPTS + jn + N * (kc + N * ln), N, N * N, s.sxn, s.syc, s.szn);
+            Ezp = gather_rows<NN, NN, NC>(F + 2 * NPTS + jn + N * (kn + N * lc), N, N * N, s.sxn, s.syn, s.szc);
+            Bzp = gather_rows<NC, NC, NN>(F + 5 * NPTS + jc + N * (kc + N * ln), N, N * N, s.sxc, s.syc, s.szn);
+            Byp = gather_rows<NC, NN, NC>(F + 4 * NPTS + jc + N * (kn + N * lc), N, N * N, s.sxc, s.syn, s.szc);
+            Bxp = gather_rows<NN, NC, NC>(F + 3 * NPTS + jn + N * (kc + N * lc), N, N * N, s.sxn, s.syc, s.szc);
+        } else {
+            gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
+        }
+        double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
+        if constexpr (PUSHER == WXA_PUSHER_BORIS) push_boris(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+        else push_vay(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+        p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
+        if constexpr (MOVE) {
+            update_position(xp, yp, zp, ux, uy, uz, dt);
+            p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp;
+        }
+    }
+}
+
+bool gather_tile_available(const wxa_workspace* ws, const wxa_particle_view* p) {
+    return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np == p->np;
+}
+
+template <int PUSHER, bool MOVE>
+static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                         const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                         wxa_workspace* ws, hipStream_t st) {
+    GTileGeom tg;
+    for (int d = 0; d < 3; ++d) {
+        tg.nt[d] = (ws->sort_nc[d] + GT_TS - 1) / GT_TS;
+        tg.cell_lo[d] = ws->sort_cell_lo[d];
+    }
+    const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
+    const PV pv = make_pv(*p);
+    const Geom g = make_geom(*geom);
+    const int* offsets = (const int*)ws->offsets.p;
+    const DevF ex = make_devf(E[0]), ey = make_devf(E[1]), ez = make_devf(E[2]);
+    const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
+    const dim3 grid((unsigned)xcd_grid_size(ntiles)), block(GT_THREADS);
+#define WXA_GT(O, G)                                                                                        \
+    hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE>), grid, block, 0, st, pv, offsets, ex, ey, \
+                       ez, bx, by, bz, g, tg, q, m, dt)
+    if (galerkin) {
+        if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else WXA_GT(3, 1);
+    } else {
+        if (order == 1) WXA_GT(1, 0); else if (order == 2) WXA_GT(2, 0); else WXA_GT(3, 0);
+    }
+#undef WXA_GT
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status gather_push_tiled(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                             const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                             int pusher, bool move, wxa_workspace* ws, hipStream_t st) {
+    if (pusher == WXA_PUSHER_BORIS) {
+        if (move) return launch<WXA_PUSHER_BORIS, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+        return launch<WXA_PUSHER_BORIS, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    }
+    if (move) return launch<WXA_PUSHER_VAY, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    return launch<WXA_PUSHER_VAY, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+}
+
+}  // namespace wxa

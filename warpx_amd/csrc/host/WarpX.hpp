@@ -122,7 +122,11 @@ public:
             m_fields.alias_init(FieldType::Bfield_aux, FieldType::Bfield_fp, Direction{d}, 0);
         }
         if (use_filter)
-            m_filter_tmp = std::make_unique<amrex::MultiFab>(be, m_ctx.brick_box, amrex::IntVect(1, 1, 1), guard_cells.ng_alloc_J);
+            for (int d = 0; d < 3; ++d)
+                m_filter_tmp[d] = std::make_unique<amrex::MultiFab>(be, m_ctx.brick_box, Etype[d], guard_cells.ng_alloc_J);
+        for (int d = 0; d < 3; ++d)   // the device SumBoundary of a self-periodic direction needs this
+            if (cfg.nbricks[d] == 1 && m_ctx.brick_box.length(d) < 2 * guard_cells.ng_alloc_J[d] + 1)
+                throw std::runtime_error("periodic direction shorter than twice the guard depth");
         m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, m_ctx.dx);
         sort_intervals = cfg.sort_interval;
     }
@@ -186,17 +190,13 @@ public:
         }
     }
 
-    // WarpXComm.cpp:1357-1374: filter into a temporary with the same guards, copy back
+    // WarpXComm.cpp:1357-1374: filter into a temporary with the same guards, then "copy back":
+    // here the two arrays simply exchange their storage (no copy)
     void ApplyFilterJ(const ablastr::fields::VectorField& current, int /*lev*/, int idim) {
         amrex::MultiFab& J = *current[idim];
-        // the temporary only provides storage: re-type its view to this component
-        wxa_field_view tmp = J.view();
-        tmp.p = m_filter_tmp->view().p;
-        if (m_filter_tmp->bytes() < sizeof(double) * (size_t)tmp.kstride * tmp.n[2])
-            throw std::runtime_error("filter scratch too small");
-        check(m_be->filter_bilinear(&J.view(), &tmp, m_ctx.stream), "filter_bilinear");
-        check(m_be->memcpy_async(J.view().p, tmp.p, sizeof(double) * (size_t)tmp.kstride * tmp.n[2], m_ctx.stream),
-              "memcpy");
+        amrex::MultiFab& tmp = *m_filter_tmp[idim];
+        check(m_be->filter_bilinear(&J.view(), &tmp.view(), m_ctx.stream), "filter_bilinear");
+        J.swap_storage(tmp);
     }
 
     // WarpXComm.cpp:1386-1424 -> WarpXSumGuardCells (WarpXSumGuardCells.cpp:17-24)
@@ -304,7 +304,7 @@ private:
     std::unique_ptr<MultiParticleContainer> mypc;
     std::unique_ptr<FiniteDifferenceSolver> m_fdtd_solver_fp;
     std::unique_ptr<BrickComm> m_comm;
-    std::unique_ptr<amrex::MultiFab> m_filter_tmp;
+    std::unique_ptr<amrex::MultiFab> m_filter_tmp[3];
     std::vector<amrex::Real> dt;
     amrex::Real cur_time = 0.0;
     int64_t istep = 0;

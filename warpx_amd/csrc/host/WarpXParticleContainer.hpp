@@ -281,7 +281,7 @@ public:
         const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
         const wxa_particle_view p = m_tile.view();
         check(m_ctx->be->gather_push(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
-                                     (int)m_ctx->particle_pusher_algo, m_ctx->stream),
+                                     (int)m_ctx->particle_pusher_algo, /*move=*/1, m_ws, m_ctx->stream),
               "gather_push");
     }
 
@@ -294,8 +294,8 @@ public:
         const wxa_field_view B[3] = {Bx.view(), By.view(), Bz.view()};
         const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
         const wxa_particle_view p = m_tile.view();
-        check(m_ctx->be->push_p(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
-                                (int)m_ctx->particle_pusher_algo, m_ctx->stream),
+        check(m_ctx->be->gather_push(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
+                                     (int)m_ctx->particle_pusher_algo, /*move=*/0, m_ws, m_ctx->stream),
               "push_p");
     }
 };

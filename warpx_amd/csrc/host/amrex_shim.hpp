@@ -95,6 +95,16 @@ public:
         m_be->field_set_zero(&m_view, stream);
     }
     size_t bytes() const { return m_bytes; }
+    // exchange the storage of two identically shaped MultiFabs (used instead of a copy-back)
+    void swap_storage(MultiFab& o) {
+        for (int d = 0; d < 3; ++d)
+            if (m_view.n[d] != o.m_view.n[d] || m_view.lo[d] != o.m_view.lo[d])
+                throw std::runtime_error("MultiFab::swap_storage: shapes differ");
+        if (m_view.jstride != o.m_view.jstride || m_view.kstride != o.m_view.kstride || m_bytes != o.m_bytes)
+            throw std::runtime_error("MultiFab::swap_storage: layouts differ");
+        std::swap(m_alloc, o.m_alloc);
+        std::swap(m_view.p, o.m_view.p);
+    }
 
 private:
     const wxa::host::Backend* m_be;

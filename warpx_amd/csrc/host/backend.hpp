@@ -23,10 +23,9 @@ struct Backend {
     int (*evolve_b)(const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
     int (*evolve_e)(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double,
                     const double*, void*);
+    // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace
     int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
-                       const wxa_grid_geom*, double, double, double, int, int, int, void*);
-    int (*push_p)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
-                  const wxa_grid_geom*, double, double, double, int, int, int, void*);
+                       const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);
     int (*deposit_current)(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double,
                            double, double, int, int, void* ws, void*);
     int (*filter_bilinear)(const wxa_field_view*, const wxa_field_view*, void*);

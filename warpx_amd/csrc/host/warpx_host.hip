@@ -69,11 +69,9 @@ const Backend* hip_backend() {
         b.evolve_e = [](const wxa_field_view* E, const wxa_field_view* B, const wxa_field_view* J, double dt,
                         const double* di, void* st) -> int { return wxa_evolve_e(E, B, J, dt, di, st); };
         b.gather_push = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
-                           const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void* st) -> int {
-            return wxa_gather_push(p, E, B, g, q, m, dt, o, ga, pu, st); };
-        b.push_p = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
-                      const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void* st) -> int {
-            return wxa_push_p(p, E, B, g, q, m, dt, o, ga, pu, st); };
+                           const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, int move,
+                           void* ws, void* st) -> int {
+            return wxa_gather_push_ws(p, E, B, g, q, m, dt, o, ga, pu, move, static_cast<wxa_workspace*>(ws), st); };
         b.deposit_current = k_deposit;
         b.filter_bilinear = [](const wxa_field_view* s, const wxa_field_view* d, void* st) -> int {
             return wxa_filter_bilinear(s, d, st); };

@@ -2,48 +2,12 @@
 // deposition (global-atomics variants; the LDS-tile variants live in deposit_tile.hip),
 // periodic wrap, counting sort by cell.
 #include "deposit_body.hpp"
+#include "gather_body.hpp"
 #include "workspace.hpp"
 
 #include <hipcub/hipcub.hpp>
 
 namespace wxa {
-
-struct PV {
-    double* __restrict__ x; double* __restrict__ y; double* __restrict__ z; double* __restrict__ w;
-    double* __restrict__ ux; double* __restrict__ uy; double* __restrict__ uz;
-    uint64_t* __restrict__ id;
-    long np;
-};
-static inline PV make_pv(const wxa_particle_view& p) {
-    return PV{p.x, p.y, p.z, p.w, p.ux, p.uy, p.uz, p.idcpu, (long)p.np};
-}
-static inline bool pv_ok(const wxa_particle_view* p) {
-    return p && p->np >= 0 && (p->np == 0 || (p->x && p->y && p->z && p->w && p->ux && p->uy && p->uz));
-}
-
-// ---------------------------------------------------------------------------
-// Gather on the Yee grid.  doGatherShapeN<O,G> (Source/Particles/Gather/FieldGather.H:36-424)
-// specialised to the Yee index types: per direction only two weight arrays occur, the
-// order-O nodal one and the order-(O-G) cell-centred one (:98-121,135-158,171-194).
-template <int NX, int NY, int NZ>
-__device__ __forceinline__ double gather_one(const DevF& f, const double* __restrict__ sx,
-                                             const double* __restrict__ sy,
-                                             const double* __restrict__ sz, int i0, int j0, int k0) {
-    const double* __restrict__ base = f.p + f.off(i0, j0, k0);
-    double acc = 0.0;
-#pragma unroll
-    for (int iz = 0; iz < NZ; ++iz) {
-#pragma unroll
-        for (int iy = 0; iy < NY; ++iy) {
-            const double* __restrict__ row = base + iy * f.js + iz * f.ks;
-            double r = 0.0;
-#pragma unroll
-            for (int ix = 0; ix < NX; ++ix) r += sx[ix] * row[ix];
-            acc += (sy[iy] * sz[iz]) * r;
-        }
-    }
-    return acc;
-}
 
 template <int O, int G, int PUSHER, bool MOVE>
 __global__ void __launch_bounds__(256)
@@ -51,28 +15,11 @@ gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, G
                    double m, double dt) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= p.np) return;
-    constexpr int NN = O + 1;        // nodal weights
-    constexpr int NC = O + 1 - G;    // cell-centred (galerkin-lowered) weights
     double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
-
-    const double x = (xp - g.xmin) * g.dxi;
-    const double y = (yp - g.ymin) * g.dyi;
-    const double z = (zp - g.zmin) * g.dzi;
-    double sxn[NN], sxc[NC], syn[NN], syc[NC], szn[NN], szc[NC];
-    const int jn = g.lo0 + shape_factor<O>(sxn, x);
-    const int jc = g.lo0 + shape_factor<O - G>(sxc, x - 0.5);
-    const int kn = g.lo1 + shape_factor<O>(syn, y);
-    const int kc = g.lo1 + shape_factor<O - G>(syc, y - 0.5);
-    const int ln = g.lo2 + shape_factor<O>(szn, z);
-    const int lc = g.lo2 + shape_factor<O - G>(szc, z - 0.5);
-
-    // Yee: Ex(c,n,n) Ey(n,c,n) Ez(n,n,c) Bx(n,c,c) By(c,n,c) Bz(c,c,n)
-    const double Exp = gather_one<NC, NN, NN>(Ex, sxc, syn, szn, jc, kn, ln);
-    const double Eyp = gather_one<NN, NC, NN>(Ey, sxn, syc, szn, jn, kc, ln);
-    const double Ezp = gather_one<NN, NN, NC>(Ez, sxn, syn, szc, jn, kn, lc);
-    const double Bzp = gather_one<NC, NC, NN>(Bz, sxc, syc, szn, jc, kc, ln);
-    const double Byp = gather_one<NC, NN, NC>(By, sxc, syn, szc, jc, kn, lc);
-    const double Bxp = gather_one<NN, NC, NC>(Bx, sxn, syc, szc, jn, kc, lc);
+    GatherShapes<O, G> s;
+    gather_shapes<O, G>(xp, yp, zp, g, s);
+    double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
+    gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
 
     double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
     // doParticleMomentumPush (Source/Particles/Pusher/PushSelector.H:38-102), ion_lev = 1
@@ -140,12 +87,8 @@ deposit_charge_kernel(PV p, DevF rho, int s0, int s1, int s2, Geom g, double q) 
                 atomic_add_f64(r + ix + iy * rho.js + iz * rho.ks, sx[ix] * sy[iy] * sz[iz] * wq);
 }
 
-__global__ void __launch_bounds__(256)
-enforce_periodic_kernel(double* __restrict__ a, long np, double plo, double phi) {
-    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ip >= np) return;
+__device__ __forceinline__ double wrap_periodic(double v, double plo, double phi) {
     const double L = phi - plo;
-    double v = a[ip];
     if (v >= phi) {
         v -= L;
         if (v < plo) v = plo;
@@ -153,7 +96,22 @@ enforce_periodic_kernel(double* __restrict__ a, long np, double plo, double phi)
         v += L;
         if (v >= phi) v = nextafter(phi, plo);
     }
-    a[ip] = v;
+    return v;
+}
+
+struct PeriodicBox {
+    double plo[3], phi[3];
+    int on[3];
+};
+
+__global__ void __launch_bounds__(256)
+enforce_periodic_kernel(double* __restrict__ x, double* __restrict__ y, double* __restrict__ z, long np,
+                        PeriodicBox pb) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= np) return;
+    if (pb.on[0]) { const double v = x[ip], w = wrap_periodic(v, pb.plo[0], pb.phi[0]); if (w != v) x[ip] = w; }
+    if (pb.on[1]) { const double v = y[ip], w = wrap_periodic(v, pb.plo[1], pb.phi[1]); if (w != v) y[ip] = w; }
+    if (pb.on[2]) { const double v = z[ip], w = wrap_periodic(v, pb.plo[2], pb.phi[2]); if (w != v) z[ip] = w; }
 }
 
 // ---- counting sort by cell ---------------------------------------------------
@@ -178,15 +136,31 @@ __device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, do
     return tile * (T * T * T) + (i % T) + T * ((j % T) + T * (k % T));
 }
 
+// Histogram + rank.  The input is usually almost sorted (a few % of the particles changed cell
+// since the last sort), so equal keys sit in neighbouring lanes: each run of equal keys inside a
+// wave issues ONE atomic for the whole run instead of one per particle.
 __global__ void __launch_bounds__(256)
 sort_count_kernel(const double* __restrict__ x, const double* __restrict__ y,
                   const double* __restrict__ z, long np, SortGeom s, int* __restrict__ cell,
                   int* __restrict__ rank, int* __restrict__ hist) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ip >= np) return;
-    const int c = cell_of(s, x[ip], y[ip], z[ip]);
-    cell[ip] = c;
-    rank[ip] = atomicAdd(&hist[c], 1);
+    const int lane = threadIdx.x & 63;
+    const bool valid = ip < np;
+    const int c = valid ? cell_of(s, x[ip], y[ip], z[ip]) : -1;
+    const int prev = __shfl_up(c, 1);
+    const bool head = (lane == 0) || (c != prev);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = (2ULL << lane) - 1ULL;          // bits 0..lane (all ones at lane 63)
+    const int hl = 63 - __clzll(heads & upto);                      // head lane of my run
+    const unsigned long long above = heads & ~upto;
+    const int nh = above ? (__ffsll((long long)above) - 1) : 64;    // first lane of the next run
+    int base = 0;
+    if (head && c >= 0) base = atomicAdd(&hist[c], nh - lane);
+    base = __shfl(base, hl);
+    if (valid) {
+        cell[ip] = c;
+        rank[ip] = base + (lane - hl);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -272,30 +246,35 @@ using namespace wxa;
 
 extern "C" {
 
-wxa_status wxa_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
-                           const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
-                           int pusher, void* stream) {
+wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                              const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                              int pusher, int move, wxa_workspace* ws, void* stream) {
     wxa_status rc = check_gather_args(p, E, B, geom, order, galerkin, pusher);
     if (rc != WXA_OK) return rc;
     if (p->np == 0) return WXA_OK;
+    if (gather_tile_available(ws, p))
+        return gather_push_tiled(p, E, B, geom, q, m, dt, order, galerkin, pusher, move != 0, ws, (hipStream_t)stream);
     const PV pv = make_pv(*p);
     const Geom g = make_geom(*geom);
-    if (pusher == WXA_PUSHER_BORIS)
-        return launch_gather_push<WXA_PUSHER_BORIS, true>(pv, E, B, g, q, m, dt, order, galerkin, (hipStream_t)stream);
-    return launch_gather_push<WXA_PUSHER_VAY, true>(pv, E, B, g, q, m, dt, order, galerkin, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (pusher == WXA_PUSHER_BORIS) {
+        if (move) return launch_gather_push<WXA_PUSHER_BORIS, true>(pv, E, B, g, q, m, dt, order, galerkin, st);
+        return launch_gather_push<WXA_PUSHER_BORIS, false>(pv, E, B, g, q, m, dt, order, galerkin, st);
+    }
+    if (move) return launch_gather_push<WXA_PUSHER_VAY, true>(pv, E, B, g, q, m, dt, order, galerkin, st);
+    return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, st);
+}
+
+wxa_status wxa_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                           const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                           int pusher, void* stream) {
+    return wxa_gather_push_ws(p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, nullptr, stream);
 }
 
 wxa_status wxa_push_p(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
                       const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
                       int pusher, void* stream) {
-    wxa_status rc = check_gather_args(p, E, B, geom, order, galerkin, pusher);
-    if (rc != WXA_OK) return rc;
-    if (p->np == 0) return WXA_OK;
-    const PV pv = make_pv(*p);
-    const Geom g = make_geom(*geom);
-    if (pusher == WXA_PUSHER_BORIS)
-        return launch_gather_push<WXA_PUSHER_BORIS, false>(pv, E, B, g, q, m, dt, order, galerkin, (hipStream_t)stream);
-    return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, (hipStream_t)stream);
+    return wxa_gather_push_ws(p, E, B, geom, q, m, dt, order, galerkin, pusher, 0, nullptr, stream);
 }
 
 wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
@@ -355,13 +334,15 @@ wxa_status wxa_enforce_periodic(const wxa_particle_view* p, const double plo[3],
                                 const int periodic[3], void* stream) {
     WXA_REQUIRE(pv_ok(p) && plo && phi && periodic, "bad argument");
     if (p->np == 0) return WXA_OK;
-    double* pos[3] = {p->x, p->y, p->z};
+    PeriodicBox pb;
+    bool any = false;
     for (int d = 0; d < 3; ++d) {
-        if (!periodic[d]) continue;
-        WXA_REQUIRE(phi[d] > plo[d], "empty domain");
-        hipLaunchKernelGGL(enforce_periodic_kernel, dim3(blocks_for(p->np)), dim3(256), 0, (hipStream_t)stream,
-                           pos[d], (long)p->np, plo[d], phi[d]);
+        pb.plo[d] = plo[d]; pb.phi[d] = phi[d]; pb.on[d] = periodic[d] ? 1 : 0;
+        if (periodic[d]) { WXA_REQUIRE(phi[d] > plo[d], "empty domain"); any = true; }
     }
+    if (!any) return WXA_OK;
+    hipLaunchKernelGGL(enforce_periodic_kernel, dim3(blocks_for(p->np)), dim3(256), 0, (hipStream_t)stream, p->x,
+                       p->y, p->z, (long)p->np, pb);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
