@@ -52,6 +52,23 @@ __device__ __forceinline__ void esirkepov_shapes(const ParticleState& p, const G
     s.bi = g.lo0 + i_new - 1; s.bj = g.lo1 + j_new - 1; s.bk = g.lo2 + k_new - 1;
 }
 
+// Slot-0 grid index of a particle's Esirkepov frame without the weights (same arithmetic as
+// esirkepov_shapes, so the two always agree).
+template <int O>
+__device__ __forceinline__ void esirkepov_frame(const ParticleState& p, const Geom& g, double dt,
+                                                double relative_time, int& bi, int& bj, int& bk) {
+    constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
+    const double gaminv =
+        1.0 / sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
+    const double x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
+    const double y_new = (p.y - g.ymin + (relative_time + 0.5 * dt) * p.uy * gaminv) * g.dyi;
+    const double z_new = (p.z - g.zmin + (relative_time + 0.5 * dt) * p.uz * gaminv) * g.dzi;
+    double tmp[O + 1];
+    bi = g.lo0 + shape_factor<O>(tmp, x_new) - 1;
+    bj = g.lo1 + shape_factor<O>(tmp, y_new) - 1;
+    bk = g.lo2 + shape_factor<O>(tmp, z_new) - 1;
+}
+
 // Sink concept: void add(int comp, int i, int j, int k, double v) with i,j,k relative to slot 0.
 //
 // Loop structure: all loops run over the full static slot range so that every register
@@ -60,6 +77,32 @@ __device__ __forceinline__ void esirkepov_shapes(const ParticleState& p, const G
 // shape arrays are exactly zero, so a transverse row is skipped when its weight T is zero
 // and the longitudinal ends are predicated on dil/diu -- the set of non-zero deposits and
 // the arithmetic of each one are those of the reference.
+// One transverse row of the Esirkepov deposit: running sum along the longitudinal direction
+// (CurrentDeposition.H:794-799).  Slots 1..O are inside the trimmed range for every particle;
+// slot 0 / slot O+1 only for particles that moved down / up one cell, so those two are issued
+// only when some lane of the wave needs them (any_lo / any_hi are wave-uniform): an LDS atomic
+// with an empty exec mask would still cost an issue slot on the (binding) LDS pipe.
+template <int O, int COMP, class Sink>
+__device__ __forceinline__ void esirkepov_row(Sink& sink, const double (&d)[O + 2], double T, int dl, int du,
+                                              bool any_lo, bool any_hi, int a, int b) {
+    double sd[O + 2];
+    double run = 0.;
+#pragma unroll
+    for (int l = 0; l <= O + 1; l++) {
+        run += d[l] * T;
+        sd[l] = run;
+    }
+    auto put = [&](int l, double v) {
+        if constexpr (COMP == 0) sink.add(0, l, a, b, v);        // row (j=a, k=b), running along i
+        else if constexpr (COMP == 1) sink.add(1, a, l, b, v);   // row (i=a, k=b), running along j
+        else sink.add(2, a, b, l, v);                            // row (i=a, j=b), running along k
+    };
+#pragma unroll
+    for (int l = 1; l <= O; l++) put(l, sd[l]);
+    if (any_lo) { if (dl == 0) put(0, sd[0]); }
+    if (any_hi) { if (du == 0) put(O + 1, sd[O + 1]); }
+}
+
 template <int O, class Sink>
 __device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s, const Geom& g, double dt,
                                                      Sink& sink) {
@@ -75,20 +118,16 @@ __device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s
         dy_[a] = wq * invdtd_y * (s.sy_old[a] - s.sy_new[a]);
         dz_[a] = wq * invdtd_z * (s.sz_old[a] - s.sz_new[a]);
     }
+    const bool xl = __builtin_amdgcn_ballot_w64(s.dil == 0) != 0, xh = __builtin_amdgcn_ballot_w64(s.diu == 0) != 0;
+    const bool yl = __builtin_amdgcn_ballot_w64(s.djl == 0) != 0, yh = __builtin_amdgcn_ballot_w64(s.dju == 0) != 0;
+    const bool zl = __builtin_amdgcn_ballot_w64(s.dkl == 0) != 0, zh = __builtin_amdgcn_ballot_w64(s.dku == 0) != 0;
 #pragma unroll
     for (int k = 0; k <= O + 2; k++) {
 #pragma unroll
         for (int j = 0; j <= O + 2; j++) {
             const double T = one_third * (s.sy_new[j] * s.sz_new[k] + s.sy_old[j] * s.sz_old[k]) +
                              one_sixth * (s.sy_new[j] * s.sz_old[k] + s.sy_old[j] * s.sz_new[k]);
-            if (T != 0.0) {
-                double sdxi = 0.;
-#pragma unroll
-                for (int i = 0; i <= O + 1; i++) {
-                    sdxi += dx_[i] * T;
-                    if (i >= s.dil && i <= O + 1 - s.diu) sink.add(0, i, j, k, sdxi);
-                }
-            }
+            if (T != 0.0) esirkepov_row<O, 0>(sink, dx_, T, s.dil, s.diu, xl, xh, j, k);
         }
     }
 #pragma unroll
@@ -97,14 +136,7 @@ __device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s
         for (int i = 0; i <= O + 2; i++) {
             const double T = one_third * (s.sx_new[i] * s.sz_new[k] + s.sx_old[i] * s.sz_old[k]) +
                              one_sixth * (s.sx_new[i] * s.sz_old[k] + s.sx_old[i] * s.sz_new[k]);
-            if (T != 0.0) {
-                double sdyj = 0.;
-#pragma unroll
-                for (int j = 0; j <= O + 1; j++) {
-                    sdyj += dy_[j] * T;
-                    if (j >= s.djl && j <= O + 1 - s.dju) sink.add(1, i, j, k, sdyj);
-                }
-            }
+            if (T != 0.0) esirkepov_row<O, 1>(sink, dy_, T, s.djl, s.dju, yl, yh, i, k);
         }
     }
 #pragma unroll
@@ -113,13 +145,136 @@ __device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s
         for (int i = 0; i <= O + 2; i++) {
             const double T = one_third * (s.sx_new[i] * s.sy_new[j] + s.sx_old[i] * s.sy_old[j]) +
                              one_sixth * (s.sx_new[i] * s.sy_old[j] + s.sx_old[i] * s.sy_new[j]);
-            if (T != 0.0) {
-                double sdzk = 0.;
+            if (T != 0.0) esirkepov_row<O, 2>(sink, dz_, T, s.dkl, s.dku, zl, zh, i, j);
+        }
+    }
+}
+
+// ---- two particles of the same frame merged before the atomics --------------------------
+// Cell-sorted neighbours usually share the slot frame (same i_new,j_new,k_new).  Their row
+// values are summed in registers and deposited with ONE atomic per slot: the LDS atomic pipe
+// is the binding resource of this kernel (rocprof: ~12 LDS cycles per ds_add_f64 wave
+// instruction, LDS 67 % busy), so this halves its load.  Each particle keeps its own trimmed
+// range: an end slot receives only the particles that crossed a cell in that direction, so the
+// set of deposits per particle is the reference's.
+template <int O, int COMP, class Sink>
+__device__ __forceinline__ void esirkepov_row2(Sink& sink, const double (&d1)[O + 2], const double (&d2)[O + 2],
+                                               double T1, double T2, int dl1, int du1, int dl2, int du2,
+                                               bool any_lo, bool any_hi, int a, int b) {
+    auto put = [&](int l, double v) {
+        if constexpr (COMP == 0) sink.add(0, l, a, b, v);
+        else if constexpr (COMP == 1) sink.add(1, a, l, b, v);
+        else sink.add(2, a, b, l, v);
+    };
+    double r1 = d1[0] * T1, r2 = d2[0] * T2;   // running sums at slot 0
+    if (any_lo) {
+        const double v = (dl1 == 0 ? r1 : 0.0) + (dl2 == 0 ? r2 : 0.0);
+        if (dl1 == 0 || dl2 == 0) put(0, v);
+    }
 #pragma unroll
-                for (int k = 0; k <= O + 1; k++) {
-                    sdzk += dz_[k] * T;
-                    if (k >= s.dkl && k <= O + 1 - s.dku) sink.add(2, i, j, k, sdzk);
-                }
+    for (int l = 1; l <= O; l++) {
+        r1 += d1[l] * T1;
+        r2 += d2[l] * T2;
+        put(l, r1 + r2);
+    }
+    if (any_hi) {
+        r1 += d1[O + 1] * T1;
+        r2 += d2[O + 1] * T2;
+        const double v = (du1 == 0 ? r1 : 0.0) + (du2 == 0 ? r2 : 0.0);
+        if (du1 == 0 || du2 == 0) put(O + 1, v);
+    }
+}
+
+template <int O>
+__device__ __forceinline__ double esirkepov_T(const double* an, const double* ao, const double* bn,
+                                              const double* bo, int a, int b) {
+    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
+    return one_third * (an[a] * bn[b] + ao[a] * bo[b]) + one_sixth * (an[a] * bo[b] + ao[a] * bn[b]);
+}
+
+// s1 and s2 must have the same (bi,bj,bk), unless null2: then particle 2 is ignored (its terms
+// are exact zeros) and the call deposits particle 1 alone.
+// Slots where no lane of the wave has any weight (slot 0 / O+2 unless some particle crossed a
+// cell) are skipped with wave-uniform branches before the transverse weight is even computed.
+template <int O, class Sink>
+__device__ __forceinline__ void esirkepov_accumulate_pair(const EsirkepovShapes<O>& s1, const EsirkepovShapes<O>& s2,
+                                                          bool null2, const Geom& g, double dt, Sink& sink) {
+    const double invdtd[3] = {(1.0 / dt) * g.dyi * g.dzi, (1.0 / dt) * g.dxi * g.dzi, (1.0 / dt) * g.dxi * g.dyi};
+    const double wq2 = null2 ? 0.0 : s2.wq;
+    bool ux[O + 3], uy[O + 3], uz[O + 3];   // wave-uniform: some lane has weight on this slot
+#pragma unroll
+    for (int a = 0; a < O + 3; ++a) {
+        ux[a] = __builtin_amdgcn_ballot_w64(s1.sx_new[a] != 0.0 || s1.sx_old[a] != 0.0 ||
+                                            (!null2 && (s2.sx_new[a] != 0.0 || s2.sx_old[a] != 0.0))) != 0;
+        uy[a] = __builtin_amdgcn_ballot_w64(s1.sy_new[a] != 0.0 || s1.sy_old[a] != 0.0 ||
+                                            (!null2 && (s2.sy_new[a] != 0.0 || s2.sy_old[a] != 0.0))) != 0;
+        uz[a] = __builtin_amdgcn_ballot_w64(s1.sz_new[a] != 0.0 || s1.sz_old[a] != 0.0 ||
+                                            (!null2 && (s2.sz_new[a] != 0.0 || s2.sz_old[a] != 0.0))) != 0;
+    }
+    double d1[O + 2], d2[O + 2];
+    {   // Jx: rows (j,k), running along i
+#pragma unroll
+        for (int a = 0; a < O + 2; ++a) {
+            d1[a] = s1.wq * invdtd[0] * (s1.sx_old[a] - s1.sx_new[a]);
+            d2[a] = wq2 * invdtd[0] * (s2.sx_old[a] - s2.sx_new[a]);
+        }
+        const bool lo = __builtin_amdgcn_ballot_w64(s1.dil == 0 || (!null2 && s2.dil == 0)) != 0;
+        const bool hi = __builtin_amdgcn_ballot_w64(s1.diu == 0 || (!null2 && s2.diu == 0)) != 0;
+#pragma unroll
+        for (int k = 0; k <= O + 2; k++) {
+            if (!uz[k]) continue;
+#pragma unroll
+            for (int j = 0; j <= O + 2; j++) {
+                if (!uy[j]) continue;
+                const double T1 = esirkepov_T<O>(s1.sy_new, s1.sy_old, s1.sz_new, s1.sz_old, j, k);
+                const double T2 = null2 ? 0.0 : esirkepov_T<O>(s2.sy_new, s2.sy_old, s2.sz_new, s2.sz_old, j, k);
+                if (T1 != 0.0 || T2 != 0.0)
+                    esirkepov_row2<O, 0>(sink, d1, d2, T1, T2, s1.dil, s1.diu, null2 ? 1 : s2.dil,
+                                         null2 ? 1 : s2.diu, lo, hi, j, k);
+            }
+        }
+    }
+    {   // Jy: rows (i,k), running along j
+#pragma unroll
+        for (int a = 0; a < O + 2; ++a) {
+            d1[a] = s1.wq * invdtd[1] * (s1.sy_old[a] - s1.sy_new[a]);
+            d2[a] = wq2 * invdtd[1] * (s2.sy_old[a] - s2.sy_new[a]);
+        }
+        const bool lo = __builtin_amdgcn_ballot_w64(s1.djl == 0 || (!null2 && s2.djl == 0)) != 0;
+        const bool hi = __builtin_amdgcn_ballot_w64(s1.dju == 0 || (!null2 && s2.dju == 0)) != 0;
+#pragma unroll
+        for (int k = 0; k <= O + 2; k++) {
+            if (!uz[k]) continue;
+#pragma unroll
+            for (int i = 0; i <= O + 2; i++) {
+                if (!ux[i]) continue;
+                const double T1 = esirkepov_T<O>(s1.sx_new, s1.sx_old, s1.sz_new, s1.sz_old, i, k);
+                const double T2 = null2 ? 0.0 : esirkepov_T<O>(s2.sx_new, s2.sx_old, s2.sz_new, s2.sz_old, i, k);
+                if (T1 != 0.0 || T2 != 0.0)
+                    esirkepov_row2<O, 1>(sink, d1, d2, T1, T2, s1.djl, s1.dju, null2 ? 1 : s2.djl,
+                                         null2 ? 1 : s2.dju, lo, hi, i, k);
+            }
+        }
+    }
+    {   // Jz: rows (i,j), running along k
+#pragma unroll
+        for (int a = 0; a < O + 2; ++a) {
+            d1[a] = s1.wq * invdtd[2] * (s1.sz_old[a] - s1.sz_new[a]);
+            d2[a] = wq2 * invdtd[2] * (s2.sz_old[a] - s2.sz_new[a]);
+        }
+        const bool lo = __builtin_amdgcn_ballot_w64(s1.dkl == 0 || (!null2 && s2.dkl == 0)) != 0;
+        const bool hi = __builtin_amdgcn_ballot_w64(s1.dku == 0 || (!null2 && s2.dku == 0)) != 0;
+#pragma unroll
+        for (int j = 0; j <= O + 2; j++) {
+            if (!uy[j]) continue;
+#pragma unroll
+            for (int i = 0; i <= O + 2; i++) {
+                if (!ux[i]) continue;
+                const double T1 = esirkepov_T<O>(s1.sx_new, s1.sx_old, s1.sy_new, s1.sy_old, i, j);
+                const double T2 = null2 ? 0.0 : esirkepov_T<O>(s2.sx_new, s2.sx_old, s2.sy_new, s2.sy_old, i, j);
+                if (T1 != 0.0 || T2 != 0.0)
+                    esirkepov_row2<O, 2>(sink, d1, d2, T1, T2, s1.dkl, s1.dku, null2 ? 1 : s2.dkl,
+                                         null2 ? 1 : s2.dku, lo, hi, i, j);
             }
         }
     }

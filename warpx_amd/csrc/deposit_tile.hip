@@ -4,16 +4,16 @@
 // Source/Particles/Deposition/CurrentDeposition.H:453-616) handles only the direct scheme,
 // one component per pass.  Here one workgroup owns one tile of 8x8x8 cells of the
 // tile-major cell sort (wxa_sort_particles_by_cell), keeps all three J components of the
-// tile plus its stencil halo in LDS as fp64 (3 x 13^3 x 8 B = 52.7 KB -> 3 workgroups per
-// CU), accumulates with ds_add_f64, and writes each non-zero LDS point back to HBM with
-// one global fp64 atomic.  Particles whose stencil leaves the LDS tile (drift since the
-// last sort, domain-edge particles before the periodic wrap) take the global-atomic path,
-// so correctness never depends on the sort being fresh.
-//
-// Lanes walk the tile's particle range in chunks (lane l handles particles
-// l*chunk .. l*chunk+chunk-1): at any instant the lanes of a wave work on particles of
-// different cells, which spreads the LDS atomics over different addresses instead of
-// serialising the ~8 same-cell particles of a cell-sorted wave on one address.
+// tile plus its stencil halo (and one point of drift margin) in LDS as fp64
+// (3 x 15^3 x 8 B = 81 KB), accumulates with ds_add_f64, and writes each non-zero LDS point
+// back to HBM with one global fp64 atomic.  Particles are staged through LDS in coalesced
+// batches of 1024 (56 KB) and handed to the lanes as neighbouring PAIRS with a strided walk:
+// the two particles of a pair usually share the cell (merged before the atomics, halving the
+// load on the binding LDS-atomic pipe), while the 64 lanes of a wave work on different cells
+// (no same-address serialisation).  Particles whose stencil leaves the LDS tile (drift of more
+// than a cell since the last sort, particles outside the domain before the periodic wrap) are
+// queued and deposited with global atomics by a second kernel, so correctness never depends
+// on the sort being fresh.
 #include "deposit_body.hpp"
 #include "workspace.hpp"
 
@@ -46,7 +46,16 @@ struct TileGeom {
 };
 
 constexpr int DT_THREADS = 512;   // 8 waves: one workgroup per CU (LDS-limited), 2 waves per SIMD
-constexpr int DT_BATCH = 512;     // particles staged in LDS per round (7 x 512 x 8 B = 28 KB)
+constexpr int DT_BATCH = 1024;    // particles staged in LDS per round (7 x 1024 x 8 B = 56 KB)
+
+// Particles whose stencil leaves the LDS tile (stale sort, particles outside the domain before
+// the periodic wrap) are queued and deposited by deposit_stragglers_kernel with global atomics:
+// keeping that path out of the tile kernel saves registers and instruction cache.
+struct StragglerQueue {
+    int* __restrict__ idx;
+    unsigned* __restrict__ count;
+    __device__ __forceinline__ void push(int ip) const { idx[atomicAdd(count, 1u)] = ip; }
+};
 
 template <int O, int ALGO, int M>
 __global__ void __launch_bounds__(DT_THREADS)
@@ -54,11 +63,16 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                     const double* __restrict__ pz, const double* __restrict__ pw,
                     const double* __restrict__ pux, const double* __restrict__ puy,
                     const double* __restrict__ puz, const int* __restrict__ offsets, DevF Jx, DevF Jy,
-                    DevF Jz, Geom g, TileGeom tg, double q, double dt, double relative_time) {
+                    DevF Jz, Geom g, TileGeom tg, double q, double dt, double relative_time,
+                    StragglerQueue sq) {
     constexpr int N = TileDims<M>::N;
     constexpr int NPTS = TileDims<M>::NPTS;
+    constexpr int PAIRED = 1 << 30;
     __shared__ double lds[3 * NPTS];
     __shared__ double stage[7][DT_BATCH];
+    __shared__ int keys[DT_BATCH + 1];
+    __shared__ int items[DT_BATCH];
+    __shared__ int nitems;
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long tile = xcd_tile_id(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
@@ -74,45 +88,75 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     const int o0 = tg.cell_lo[0] + ti * TS + TileDims<M>::LO;
     const int o1 = tg.cell_lo[1] + tj * TS + TileDims<M>::LO;
     const int o2 = tg.cell_lo[2] + tk * TS + TileDims<M>::LO;
-    GlobalSink gs = make_global_sink(Jx, Jy, Jz);
-    // staged slot handled by this lane: a stride-8 walk, so that the 64 lanes of a wave hold
-    // particles ~8 apart in the cell-sorted order (different cells at ~8 ppc) and their LDS
-    // atomics fall on different addresses
-    const int slot = (tid * 8) % DT_BATCH + (tid * 8) / DT_BATCH;
+    const int wave = tid >> 6, lane = tid & 63;
 
     for (int b0 = start; b0 < end; b0 += DT_BATCH) {
         const int nb = min(DT_BATCH, end - b0);
         __syncthreads();   // previous round's readers are done (and the zero fill on round 0)
-        if (tid < nb) {    // coalesced: consecutive lanes read consecutive particles
-            const int ip = b0 + tid;
-            stage[0][tid] = px[ip]; stage[1][tid] = py[ip]; stage[2][tid] = pz[ip]; stage[3][tid] = pw[ip];
-            stage[4][tid] = pux[ip]; stage[5][tid] = puy[ip]; stage[6][tid] = puz[ip];
+        // ---- stage the batch (coalesced) and key every particle by its stencil frame ----
+        for (int a = tid; a < nb; a += DT_THREADS) {
+            const int ip = b0 + a;
+            const ParticleState p{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+            stage[0][a] = p.x; stage[1][a] = p.y; stage[2][a] = p.z; stage[3][a] = p.w;
+            stage[4][a] = p.ux; stage[5][a] = p.uy; stage[6][a] = p.uz;
+            int key;
+            if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
+                int bi, bj, bk;
+                esirkepov_frame<O>(p, g, dt, relative_time, bi, bj, bk);
+                const int li = bi - o0, lj = bj - o1, lk = bk - o2;
+                const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N && lk + O + 3 <= N;
+                key = in ? (li | (lj << 8) | (lk << 16)) : -1;
+            } else {
+                DirectShapes<O> s;
+                direct_shapes<O>(p, g, q, relative_time, s);
+                const int lo_i = min(s.jn, s.jc) - o0, lo_j = min(s.kn, s.kc) - o1, lo_k = min(s.ln, s.lc) - o2;
+                const int hi_i = max(s.jn, s.jc) - o0 + O, hi_j = max(s.kn, s.kc) - o1 + O, hi_k = max(s.ln, s.lc) - o2 + O;
+                key = (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N) ? 0 : -1;
+            }
+            if (key < 0) { sq.push(ip); key = -2 - a; }   // straggler: a key no neighbour shares
+            keys[a] = key;
+        }
+        if (tid == 0) { nitems = 0; keys[nb] = -1; }
+        __syncthreads();
+        // ---- work items: runs of equal frames are cut into pairs (+ one single if odd) ----
+        for (int a = tid; a < nb; a += DT_THREADS) {
+            const int key = keys[a];
+            if (key < 0) continue;
+            if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
+                int c = 0;
+                for (int b = a; b > 0 && keys[b - 1] == key; --b) ++c;
+                if ((c & 1) == 0) items[atomicAdd(&nitems, 1)] = a | (keys[a + 1] == key ? PAIRED : 0);
+            } else {
+                items[atomicAdd(&nitems, 1)] = a;
+            }
         }
         __syncthreads();
-        if (slot >= nb) continue;
-        ParticleState p{stage[0][slot], stage[1][slot], stage[2][slot], stage[3][slot],
-                        stage[4][slot], stage[5][slot], stage[6][slot]};
-        if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
-            EsirkepovShapes<O> s;
-            esirkepov_shapes<O>(p, g, q, dt, relative_time, s);
-            const int li = s.bi - o0, lj = s.bj - o1, lk = s.bk - o2;
-            if (li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N && lk + O + 3 <= N) {
-                LdsSink<M> sink{lds, li, lj, lk};
-                esirkepov_accumulate<O>(s, g, dt, sink);
+        // ---- deposit: lane l of wave w takes item l*W + w (+8, ...): the lanes of a wave hold items
+        //      W apart in the cell order, i.e. different cells -> their LDS atomics do not collide
+        const int total = nitems;
+        const int W = (total + 63) >> 6;
+        for (int w2 = wave; w2 < W; w2 += DT_THREADS / 64) {
+            const int it = lane * W + w2;
+            if (it >= total) continue;
+            const int e = items[it];
+            const int a = e & (PAIRED - 1);
+            const bool paired = (e & PAIRED) != 0;
+            const ParticleState p1{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
+                                   stage[4][a], stage[5][a], stage[6][a]};
+            if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
+                const int a2 = paired ? a + 1 : a;
+                const ParticleState p2{stage[0][a2], stage[1][a2], stage[2][a2], stage[3][a2],
+                                       stage[4][a2], stage[5][a2], stage[6][a2]};
+                EsirkepovShapes<O> s1, s2;
+                esirkepov_shapes<O>(p1, g, q, dt, relative_time, s1);
+                esirkepov_shapes<O>(p2, g, q, dt, relative_time, s2);
+                LdsSink<M> sink{lds, s1.bi - o0, s1.bj - o1, s1.bk - o2};
+                esirkepov_accumulate_pair<O>(s1, s2, /*null2=*/!paired, g, dt, sink);
             } else {
-                gs.bi = s.bi; gs.bj = s.bj; gs.bk = s.bk;
-                esirkepov_accumulate<O>(s, g, dt, gs);
-            }
-        } else {
-            DirectShapes<O> s;
-            direct_shapes<O>(p, g, q, relative_time, s);
-            const int lo_i = min(s.jn, s.jc) - o0, lo_j = min(s.kn, s.kc) - o1, lo_k = min(s.ln, s.lc) - o2;
-            const int hi_i = max(s.jn, s.jc) - o0 + O, hi_j = max(s.kn, s.kc) - o1 + O, hi_k = max(s.ln, s.lc) - o2 + O;
-            if (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N) {
+                DirectShapes<O> s;
+                direct_shapes<O>(p1, g, q, relative_time, s);
                 LdsSink<M> sink{lds, -o0, -o1, -o2};
                 direct_accumulate<O>(s, sink);
-            } else {
-                direct_accumulate<O>(s, gs);
             }
         }
     }
@@ -134,6 +178,32 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     }
 }
 
+template <int O, int ALGO>
+__global__ void __launch_bounds__(256)
+deposit_stragglers_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                          const double* __restrict__ pz, const double* __restrict__ pw,
+                          const double* __restrict__ pux, const double* __restrict__ puy,
+                          const double* __restrict__ puz, const int* __restrict__ idx,
+                          const unsigned* __restrict__ count, DevF Jx, DevF Jy, DevF Jz, Geom g, double q,
+                          double dt, double relative_time) {
+    const unsigned n = *count;
+    GlobalSink gs = make_global_sink(Jx, Jy, Jz);
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int ip = idx[t];
+        const ParticleState p{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+        if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
+            EsirkepovShapes<O> s;
+            esirkepov_shapes<O>(p, g, q, dt, relative_time, s);
+            gs.bi = s.bi; gs.bj = s.bj; gs.bk = s.bk;
+            esirkepov_accumulate<O>(s, g, dt, gs);
+        } else {
+            DirectShapes<O> s;
+            direct_shapes<O>(p, g, q, relative_time, s);
+            direct_accumulate<O>(s, gs);
+        }
+    }
+}
+
 bool deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p) {
     return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np == p->np;
 }
@@ -150,12 +220,20 @@ static wxa_status launch_tile(const wxa_particle_view* p, const wxa_field_view J
     const Geom g = make_geom(*geom);
     const int* offsets = (const int*)ws->offsets.p;
     const dim3 grid((unsigned)xcd_grid_size(ntiles)), block(DT_THREADS);
-    // Esirkepov with relative_time = -dt/2 deposits at the sorted positions: no margin needed;
-    // otherwise (direct at the half step, or a stale sort) keep one extra point per side.
-    constexpr int M = (ALGO == WXA_DEPOSIT_ESIRKEPOV) ? 0 : 1;
+    wxa_status rc;
+    if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
+    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
+    WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
+    const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
+    // One extra LDS point per side beyond the exact stencil reach: particles may have drifted up
+    // to one cell since the last sort (sort_intervals > 1) before they have to take the
+    // straggler path (global atomics, ~7 ns per particle).  3 x 15^3 x 8 B = 81 KB + 56 KB stage.
+    constexpr int M = 1;
     hipLaunchKernelGGL((deposit_tile_kernel<O, ALGO, M>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                       p->uy, p->uz, offsets, make_devf(J[0]), make_devf(J[1]), make_devf(J[2]), g, tg, q, dt,
-                       relative_time);
+                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, dt, relative_time, sq);
+    hipLaunchKernelGGL((deposit_stragglers_kernel<O, ALGO>), dim3(512), dim3(256), 0, st, p->x, p->y, p->z, p->w,
+                       p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, dt, relative_time);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }

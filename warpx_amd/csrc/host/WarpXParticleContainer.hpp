@@ -30,6 +30,16 @@ struct WarpXContext {
     bool timers_on = false;
     double ms[8] = {0};
     int64_t counts[8] = {0};
+    struct PendingInterval { int id; void* e0; void* e1; };
+    std::vector<PendingInterval> pending;
+    void resolve_timers() {
+        for (auto& p : pending) {
+            ms[p.id] += be->event_elapsed_ms(p.e0, p.e1);   // synchronises on e1
+            counts[p.id] += 1;
+            be->event_destroy(p.e0); be->event_destroy(p.e1);
+        }
+        pending.clear();
+    }
 
     // WarpX::LowerCorner(box.grow(ng)) + lbound (Source/WarpX.cpp:2851-2875)
     wxa_grid_geom geom(const amrex::IntVect& ng) const {
@@ -47,7 +57,10 @@ struct WarpXContext {
 enum Phase { kGatherAndPush = 0, kCurrentDeposition = 1, kSyncCurrent = 2, kEvolveB = 3, kEvolveE = 4,
              kFillBoundary = 5, kRedistribute = 6, kOther = 7 };
 
-// RAII region timer (HIP events); mirrors WARPX_PROFILE regions
+// RAII region timer (HIP events on the kernels' stream); mirrors WARPX_PROFILE regions
+// (SURVEY.md section 5).  The event pairs are only recorded here and resolved later
+// (WarpXContext::resolve_timers), so that timing never drains the queue: an interval then
+// starts when the previous kernel finishes on the device, free of host launch latency.
 struct PhaseTimer {
     WarpXContext* c; int id; void* e0 = nullptr; void* e1 = nullptr;
     PhaseTimer(WarpXContext* ctx, int phase) : c(ctx), id(phase) {
@@ -59,9 +72,7 @@ struct PhaseTimer {
     ~PhaseTimer() {
         if (e0) {
             c->be->event_record(e1, c->stream);
-            c->ms[id] += c->be->event_elapsed_ms(e0, e1);
-            c->counts[id] += 1;
-            c->be->event_destroy(e0); c->be->event_destroy(e1);
+            c->pending.push_back({id, e0, e1});
         }
     }
 };

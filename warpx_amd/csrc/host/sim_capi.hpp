@@ -92,6 +92,7 @@ inline int sim_get_particles(SimHandle* h, int32_t id, wxa_particle_view* out) {
 inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int reset) {
     if (!h) return WXA_ERR_INVALID_ARG;
     WarpXContext& c = h->warpx->context();
+    c.resolve_timers();
     for (int i = 0; i < 8; ++i) { ms[i] = c.ms[i]; counts[i] = c.counts[i]; }
     if (reset) for (int i = 0; i < 8; ++i) { c.ms[i] = 0; c.counts[i] = 0; }
     return WXA_OK;

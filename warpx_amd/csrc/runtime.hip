@@ -31,7 +31,7 @@ wxa_status wxa_workspace_create(wxa_workspace** ws) {
 void wxa_workspace_destroy(wxa_workspace* ws) {
     if (!ws) return;
     ws->cell.release(); ws->rank.release(); ws->hist.release(); ws->offsets.release();
-    ws->scan_tmp.release(); ws->tile_offsets.release();
+    ws->scan_tmp.release(); ws->tile_offsets.release(); ws->stragglers.release(); ws->counters.release();
     delete ws;
 }
 

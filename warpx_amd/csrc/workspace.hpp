@@ -29,7 +29,7 @@ struct DevBuf {
 }  // namespace wxa
 
 struct wxa_workspace {
-    wxa::DevBuf cell, rank, hist, offsets, scan_tmp, tile_offsets;
+    wxa::DevBuf cell, rank, hist, offsets, scan_tmp, tile_offsets, stragglers, counters;
     // description of the last cell sort (consumed by the tile-based deposition)
     bool sorted_valid = false;
     int64_t sorted_np = 0;
