@@ -6,16 +6,19 @@
 // busy).  Here one workgroup owns one 8x8x8-cell tile of the tile-major cell sort, stages the six
 // staggered field components of the tile plus the stencil halo in LDS once
 // (6 x 11^3 x 8 B = 63.9 KB with the energy-conserving gather, 2 workgroups per CU) and serves the
-// gathers with ds_read_b64 (256 B/clk, same-cell lanes broadcast).  Particles whose stencil leaves
-// the staged range (stale sort, particles wrapped across the periodic boundary) use the global
-// path, so correctness never depends on the sort being fresh.
+// gathers from LDS (same-cell lanes broadcast).  Particles whose stencil leaves the staged range
+// (stale sort, particles wrapped across the periodic boundary) are queued and handled by a second
+// kernel with global loads, so correctness never depends on the sort being fresh.
+// (Tried and rejected: reading the rows with inline-asm single ds_read_b64 to avoid the
+// half-rate ds_read2_b64 the compiler emits -- the coarse s_waitcnt it needs cost more than the
+// LDS cycles it saved: 6.3 ms vs 5.6 ms per launch at 256^3 x 8 ppc.)
 #include "gather_body.hpp"
 #include "workspace.hpp"
 
 namespace wxa {
 
 constexpr int GT_TS = WXA_TILE;
-constexpr int GT_THREADS = 256;
+constexpr int GT_THREADS = 512;
 
 template <int G>
 struct GatherTileDims {
@@ -36,10 +39,32 @@ struct LdsField {
     static constexpr long js = N, ks = N * N;
 };
 
+struct GatherStragglers {
+    int* __restrict__ idx;
+    unsigned* __restrict__ count;
+    __device__ __forceinline__ void push(int ip) const { idx[atomicAdd(count, 1u)] = ip; }
+};
+
+template <int PUSHER, bool MOVE>
+__device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, double yp, double zp, double Exp,
+                                               double Eyp, double Ezp, double Bxp, double Byp, double Bzp, double q,
+                                               double m, double dt) {
+    double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
+    if constexpr (PUSHER == WXA_PUSHER_BORIS) push_boris(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+    else push_vay(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
+    if constexpr (MOVE) {
+        update_position(xp, yp, zp, ux, uy, uz, dt);
+        p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp;
+    }
+}
+
+// 512 threads per tile and no global-load fallback inside (127 VGPRs at order 3): two workgroups
+// per CU = 4 waves per SIMD, which is what hides the LDS read latency of the 252-point gather.
 template <int O, int G, int PUSHER, bool MOVE>
 __global__ void __launch_bounds__(GT_THREADS)
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
-                        DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt) {
+                        DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq) {
     constexpr int N = GatherTileDims<G>::N;
     constexpr int NPTS = GatherTileDims<G>::NPTS;
     __shared__ double F[6 * NPTS];
@@ -71,7 +96,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     __syncthreads();
 
     for (int ip = start + tid; ip < end; ip += GT_THREADS) {
-        double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
+        const double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
         GatherShapes<O, G> s;
         gather_shapes<O, G>(xp, yp, zp, g, s);
         // staged range check on the extreme points of the node / cell stencils
@@ -79,26 +104,34 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const int lo_i = min(s.jn, s.jc) - o0, hi_i = max(s.jn + NN, s.jc + NC) - 1 - o0;
         const int lo_j = min(s.kn, s.kc) - o1, hi_j = max(s.kn + NN, s.kc + NC) - 1 - o1;
         const int lo_k = min(s.ln, s.lc) - o2, hi_k = max(s.ln + NN, s.lc + NC) - 1 - o2;
+        if (!(lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N)) {
+            sq.push(ip);   // stencil leaves the staged tile: handled by gather_push_stragglers_kernel
+            continue;
+        }
+        const int jn = s.jn - o0, jc = s.jc - o0, kn = s.kn - o1, kc = s.kc - o1, ln = s.ln - o2, lc = s.lc - o2;
+        const double Exp = gather_rows<NC, NN, NN>(F + 0 * NPTS + jc + N * (kn + N * ln), N, N * N, s.sxc, s.syn, s.szn);
+        const double Eyp = gather_rows<NN, NC, NN>(F + 1 * NPTS + jn + N * (kc + N * ln), N, N * N, s.sxn, s.syc, s.szn);
+        const double Ezp = gather_rows<NN, NN, NC>(F + 2 * NPTS + jn + N * (kn + N * lc), N, N * N, s.sxn, s.syn, s.szc);
+        const double Bzp = gather_rows<NC, NC, NN>(F + 5 * NPTS + jc + N * (kc + N * ln), N, N * N, s.sxc, s.syc, s.szn);
+        const double Byp = gather_rows<NC, NN, NC>(F + 4 * NPTS + jc + N * (kn + N * lc), N, N * N, s.sxc, s.syn, s.szc);
+        const double Bxp = gather_rows<NN, NC, NC>(F + 3 * NPTS + jn + N * (kc + N * lc), N, N * N, s.sxn, s.syc, s.szc);
+        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+    }
+}
+
+template <int O, int G, int PUSHER, bool MOVE>
+__global__ void __launch_bounds__(256)
+gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned* __restrict__ count, DevF Ex,
+                              DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Geom g, double q, double m, double dt) {
+    const unsigned n = *count;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int ip = idx[t];
+        const double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
+        GatherShapes<O, G> s;
+        gather_shapes<O, G>(xp, yp, zp, g, s);
         double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
-        if (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N) {
-            const int jn = s.jn - o0, jc = s.jc - o0, kn = s.kn - o1, kc = s.kc - o1, ln = s.ln - o2, lc = s.lc - o2;
-            Exp = gather_rows<NC, NN, NN>(F + 0 * NPTS + jc + N * (kn + N * ln), N, N * N, s.sxc, s.syn, s.szn);
-            Eyp = gather_rows<NN, NC, NN>(F + 1 * NPTS + jn + N * (kc + N * ln), N, N * N, s.sxn, s.syc, s.szn);
-            Ezp = gather_rows<NN, NN, NC>(F + 2 * NPTS + jn + N * (kn + N * lc), N, N * N, s.sxn, s.syn, s.szc);
-            Bzp = gather_rows<NC, NC, NN>(F + 5 * NPTS + jc + N * (kc + N * ln), N, N * N, s.sxc, s.syc, s.szn);
-            Byp = gather_rows<NC, NN, NC>(F + 4 * NPTS + jc + N * (kn + N * lc), N, N * N, s.sxc, s.syn, s.szc);
-            Bxp = gather_rows<NN, NC, NC>(F + 3 * NPTS + jn + N * (kc + N * lc), N, N * N, s.sxn, s.syc, s.szc);
-        } else {
-            gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
-        }
-        double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
-        if constexpr (PUSHER == WXA_PUSHER_BORIS) push_boris(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
-        else push_vay(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
-        p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
-        if constexpr (MOVE) {
-            update_position(xp, yp, zp, ux, uy, uz, dt);
-            p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp;
-        }
+        gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
+        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
     }
 }
 
@@ -122,9 +155,18 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
     const DevF ex = make_devf(E[0]), ey = make_devf(E[1]), ez = make_devf(E[2]);
     const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
     const dim3 grid((unsigned)xcd_grid_size(ntiles)), block(GT_THREADS);
+    wxa_status rc;
+    if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
+    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    GatherStragglers sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p + 16};
+    WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
 #define WXA_GT(O, G)                                                                                        \
-    hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE>), grid, block, 0, st, pv, offsets, ex, ey, \
-                       ez, bx, by, bz, g, tg, q, m, dt)
+    do {                                                                                                    \
+        hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE>), grid, block, 0, st, pv, offsets, ex, \
+                           ey, ez, bx, by, bz, g, tg, q, m, dt, sq);                                        \
+        hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
+                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt);                          \
+    } while (0)
     if (galerkin) {
         if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else WXA_GT(3, 1);
     } else {
