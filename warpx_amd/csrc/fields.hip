@@ -125,31 +125,62 @@ evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, D
 
 // Source/Filter/Filter.cpp:105-133 with the 1-pass stencil of BilinearFilter.cpp:26-60
 // ({0.25, 0.25} per direction); same tap order as the reference -> bit-identical.
-__global__ void __launch_bounds__(256)
-filter_bilinear_kernel(DevF src, DevF dst) {
-    const int i = src.lo0 + (int)(blockIdx.x * 64 + threadIdx.x);
-    const int j = src.lo1 + (int)(blockIdx.y * 4 + threadIdx.y);
-    const int k = src.lo2 + (int)blockIdx.z;
-    if (i >= src.lo0 + src.n0 || j >= src.lo1 + src.n1) return;
+// A workgroup filters a 64 x 4 column of points and marches FK planes in k with a rolling
+// window of three (64+2) x (4+2) input planes in LDS: every input point is read from HBM/L2
+// ~1.5 times instead of 27 (64 taps) through L1.
+constexpr int FI = 64, FJ = 4, FK = 16;
+
+__global__ void __launch_bounds__(FI* FJ)
+filter_bilinear_kernel(DevF src, DevF dst, int nti, int ntj, int ntk) {
+    __shared__ double pl[3][FJ + 2][FI + 2];
+    const long ntiles = (long)nti * ntj * ntk;
+    const long tile = xcd_tile_id(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int ti = (int)(tile % nti), tj = (int)((tile / nti) % ntj), tk = (int)(tile / ((long)nti * ntj));
+    const int i0 = src.lo0 + ti * FI, j0 = src.lo1 + tj * FJ, k0 = src.lo2 + tk * FK;
     const int hi0 = src.lo0 + src.n0, hi1 = src.lo1 + src.n1, hi2 = src.lo2 + src.n2;
-    auto zp = [&](int a, int b, int c) -> double {
-        return (a >= src.lo0 && a < hi0 && b >= src.lo1 && b < hi1 && c >= src.lo2 && c < hi2)
-                   ? src.p[src.off(a, b, c)] : 0.0;
+    const int k1 = min(k0 + FK, hi2);
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FI + tx;
+    // zero padding beyond the allocated box (Filter.cpp:109-114)
+    auto load_plane = [&](int slot, int k) {
+        for (int a = tid; a < (FJ + 2) * (FI + 2); a += FI * FJ) {
+            const int li = a % (FI + 2), lj = a / (FI + 2);
+            const int i = i0 - 1 + li, j = j0 - 1 + lj;
+            const bool in = i >= src.lo0 && i < hi0 && j >= src.lo1 && j < hi1 && k >= src.lo2 && k < hi2;
+            pl[slot][lj][li] = in ? src.p[src.off(i, j, k)] : 0.0;
+        }
     };
-    double d = 0.0;
+    load_plane(0, k0 - 1);
+    load_plane(1, k0);
+    const int i = i0 + tx, j = j0 + ty;
+    const bool active = i < hi0 && j < hi1;
+    for (int k = k0; k < k1; ++k) {
+        const int sm = (k - k0) % 3, sc = (k - k0 + 1) % 3, sp = (k - k0 + 2) % 3;
+        load_plane(sp, k + 1);
+        __syncthreads();
+        if (active) {
+            const int x = tx + 1, y = ty + 1;
+            // tap(di,dj,dk): slot by dk, then row/column offsets
+            auto tap = [&](int di, int dj, int dk) -> double {
+                const int slot = dk < 0 ? sm : (dk > 0 ? sp : sc);
+                return pl[slot][y + dj][x + di];
+            };
+            double d = 0.0;
 #pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
+            for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-        for (int i1 = 0; i1 < 2; ++i1)
+                for (int i1 = 0; i1 < 2; ++i1)
 #pragma unroll
-            for (int i0 = 0; i0 < 2; ++i0) {
-                const double sss = 0.25 * 0.25 * 0.25;
-                d += sss * (zp(i - i0, j - i1, k - i2) + zp(i + i0, j - i1, k - i2) +
-                            zp(i - i0, j + i1, k - i2) + zp(i + i0, j + i1, k - i2) +
-                            zp(i - i0, j - i1, k + i2) + zp(i + i0, j - i1, k + i2) +
-                            zp(i - i0, j + i1, k + i2) + zp(i + i0, j + i1, k + i2));
-            }
-    dst.p[dst.off(i, j, k)] = d;
+                    for (int i0_ = 0; i0_ < 2; ++i0_) {
+                        const double sss = 0.25 * 0.25 * 0.25;
+                        d += sss * (tap(-i0_, -i1, -i2) + tap(+i0_, -i1, -i2) + tap(-i0_, +i1, -i2) +
+                                    tap(+i0_, +i1, -i2) + tap(-i0_, -i1, +i2) + tap(+i0_, -i1, +i2) +
+                                    tap(-i0_, +i1, +i2) + tap(+i0_, +i1, +i2));
+                    }
+            dst.p[dst.off(i, j, k)] = d;
+        }
+        __syncthreads();
+    }
 }
 
 // generic box copy kernels -----------------------------------------------------
@@ -309,9 +340,10 @@ wxa_status wxa_filter_bilinear(const wxa_field_view* src, const wxa_field_view* 
     WXA_REQUIRE(src->p != dst->p, "src and dst must not alias");
     for (int d = 0; d < 3; ++d)
         WXA_REQUIRE(src->lo[d] == dst->lo[d] && src->n[d] == dst->n[d], "src/dst boxes differ");
-    dim3 grid((src->n[0] + 63) / 64, (src->n[1] + 3) / 4, src->n[2]);
-    hipLaunchKernelGGL(filter_bilinear_kernel, grid, dim3(64, 4), 0, (hipStream_t)stream, make_devf(*src),
-                       make_devf(*dst));
+    const int nti = (src->n[0] + FI - 1) / FI, ntj = (src->n[1] + FJ - 1) / FJ, ntk = (src->n[2] + FK - 1) / FK;
+    const long ntiles = (long)nti * ntj * ntk;
+    hipLaunchKernelGGL(filter_bilinear_kernel, dim3((unsigned)xcd_grid_size(ntiles)), dim3(FI, FJ), 0,
+                       (hipStream_t)stream, make_devf(*src), make_devf(*dst), nti, ntj, ntk);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
