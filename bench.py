@@ -60,16 +60,19 @@ def device_uniform_plasma(n_cell, prob_lo, prob_hi, ppc, density, u_th, seed, bo
     return out
 
 
-def cpu_baseline(n_threads=None):
+def cpu_baseline():
     """The CPU oracle (our restatement of the reference's algorithms; the reference itself
     cannot be built here: AMReX is not on disk) timed on a bounded sample of the same
-    workload: 64^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on."""
-    import numpy as np
+    workload: 128^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on, OpenMP over all host cores
+    (thread-private J scratch + accumulate, as the reference's CPU path)."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from tests.oracle_lib import load_oracle
     from warpx_amd import _capi, plasma
     from warpx_amd.sim import WarpXSim
     orc = load_oracle()
-    n_cell = (64, 64, 64)
+    n = 128
+    n_cell = (n, n, n)
     L = 40e-6
     parts = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (2, 2, 2), 1e25, 0.01, seed=12345)
     sim = WarpXSim(orc, n_cell, (-L / 2,) * 3, (L / 2,) * 3, nox=3, galerkin=1,
@@ -77,17 +80,44 @@ def cpu_baseline(n_threads=None):
                    use_filter=1)
     sim.add_species(-plasma.Q_E, plasma.M_E, parts)
     npart = len(parts[0])
+    del parts
     sim.evolve(1)
-    steps = 3
+    steps = 4
     t0 = time.perf_counter()
     sim.evolve(steps)
     dt = time.perf_counter() - t0
     sim.close()
     return {"value": npart * steps / dt, "unit": "particle-steps/s", "cores": int(orc._num_threads()),
             "kind": "port",
-            "sample": f"64^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on, {steps} steps "
-                      f"({npart} particles); {dt:.1f} s of CPU time; cell-updates/s = "
-                      f"{64 ** 3 * steps / dt:.3e}"}
+            "sample": f"{n}^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on, {steps} steps "
+                      f"({npart} particles); {dt:.1f} s wall on the host cores; cell-updates/s = "
+                      f"{n ** 3 * steps / dt:.3e}"}
+
+
+def stencil_microbench(sim, reps=20):
+    """EvolveB / EvolveE launched `reps` times back to back on the simulation's own fields between
+    one pair of events on the kernels' stream (dt = 0 leaves the fields unchanged): the per-launch
+    average without the event overhead that a single 0.25-ms launch carries."""
+    import ctypes as C
+    import torch
+    from warpx_amd import _capi
+    lib = sim.lib
+    E = (_capi.FieldView * 3)(*[sim.field_view(n) for n in ("Ex", "Ey", "Ez")])
+    B = (_capi.FieldView * 3)(*[sim.field_view(n) for n in ("Bx", "By", "Bz")])
+    J = (_capi.FieldView * 3)(*[sim.field_view(n) for n in ("jx", "jy", "jz")])
+    dinv = (C.c_double * 3)(*[1.0 / d for d in sim.dx])
+    out = {}
+    for name, call in (("EvolveB", lambda: lib.evolve_b(E, B, 0.0, dinv, None)),
+                       ("EvolveE", lambda: lib.evolve_e(E, B, J, 0.0, dinv, None))):
+        call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        e1.synchronize()
+        out[name] = e0.elapsed_time(e1) / reps
+    return out
 
 
 def main():
@@ -189,6 +219,7 @@ def main():
         cps = total_cells * args.steps / elapsed
         kernels = {}
         dominant = None
+        micro = {} if args.no_phase_pass else stencil_microbench(sim)
         for name, (ms, cnt) in phases.items():
             if cnt == 0 or ms <= 0:
                 continue
@@ -196,6 +227,9 @@ def main():
             entry = {"avg_ms": avg_ms, "launches": int(cnt)}
             if name in ("EvolveB", "EvolveE"):
                 algo_bytes = BYTES[name] * ncells_local
+                if name in micro:
+                    entry["avg_ms_back_to_back"] = micro[name]
+                    entry["hbm_frac_back_to_back"] = algo_bytes / 1e9 / (micro[name] * 1e-3) / HBM_PEAK_GBS
             elif name in ("GatherAndPush", "CurrentDeposition"):
                 bp, bc = BYTES[name]
                 algo_bytes = bp * np_local + bc * ncells_local
