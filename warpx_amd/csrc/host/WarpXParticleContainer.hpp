@@ -8,6 +8,9 @@
 #ifndef WXA_HOST_PARTICLES_HPP_
 #define WXA_HOST_PARTICLES_HPP_
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "BrickComm.hpp"
 
 namespace wxa::host {
@@ -34,7 +37,9 @@ struct WarpXContext {
     std::vector<PendingInterval> pending;
     void resolve_timers() {
         for (auto& p : pending) {
-            ms[p.id] += be->event_elapsed_ms(p.e0, p.e1);   // synchronises on e1
+            const double t = be->event_elapsed_ms(p.e0, p.e1);   // synchronises on e1
+            if (std::getenv("WXA_TIMER_TRACE")) std::fprintf(stderr, "[wxa timer] phase %d: %.3f ms\n", p.id, t);
+            ms[p.id] += t;
             counts[p.id] += 1;
             be->event_destroy(p.e0); be->event_destroy(p.e1);
         }

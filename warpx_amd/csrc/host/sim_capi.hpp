@@ -46,6 +46,8 @@ inline int sim_add_species(SimHandle* h, double charge, double mass, const wxa_p
             else
                 be->memset_async(t.idcpu(), 0, sizeof(uint64_t) * (size_t)init->np, w.context().stream);
             be->stream_sync(w.context().stream);
+            // start from a sorted tile so that the very first gather/deposit use the LDS-tile kernels
+            if (w.sort_intervals > 0) w.GetPartContainer().GetParticleContainer(sid).SortParticlesByBin(amrex::IntVect(1));
         }
         if (id) *id = sid;
         return WXA_OK;
