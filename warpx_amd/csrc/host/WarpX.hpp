@@ -179,15 +179,16 @@ public:
         mypc->Evolve(m_fields, 0, "current_fp", a_cur_time, dt[0], DtType::Full, skip_current, push_type);
     }
 
-    // :583-652 -> SyncCurrent (WarpXComm.cpp:1073-1240), single level
+    // :583-652 -> SyncCurrent (WarpXComm.cpp:1073-1240), single level.  The reference loops
+    // filter + SumBoundary per component (:1233-1237); here the three components are filtered
+    // first and then summed together so that their guard slabs share one message per neighbour.
     void SyncCurrentAndRho() {
         PhaseTimer t(&m_ctx, kSyncCurrent);  // "WarpX::SyncCurrent()"
         using warpx::fields::FieldType;
         auto J = m_fields.get_alldirs(FieldType::current_fp, 0);
-        for (int idim = 0; idim < 3; ++idim) {
-            if (use_filter) ApplyFilterJ(J, 0, idim);  // WarpXComm.cpp:1233-1236
-            SumBoundaryJ(J, 0, idim);                  // :1237
-        }
+        if (use_filter)
+            for (int idim = 0; idim < 3; ++idim) ApplyFilterJ(J, 0, idim);
+        SumBoundaryJ(J, 0);
     }
 
     // WarpXComm.cpp:1357-1374: filter into a temporary with the same guards, then "copy back":
@@ -200,12 +201,12 @@ public:
     }
 
     // WarpXComm.cpp:1386-1424 -> WarpXSumGuardCells (WarpXSumGuardCells.cpp:17-24)
-    void SumBoundaryJ(const ablastr::fields::VectorField& current, int /*lev*/, int idim) {
-        amrex::MultiFab& J = *current[idim];
+    void SumBoundaryJ(const ablastr::fields::VectorField& current, int /*lev*/) {
         amrex::IntVect ng_depos_J = guard_cells.ng_depos_J;
         if (use_filter) ng_depos_J = ng_depos_J + amrex::IntVect(2) - amrex::IntVect(1);  // :1413-1416
-        ng_depos_J = amrex::min(ng_depos_J, J.nGrowVect());                               // :1417-1420
-        m_comm->SumBoundary(J, ng_depos_J, /*refresh_guards=*/safe_guard_cells, m_ctx.stream);
+        ng_depos_J = amrex::min(ng_depos_J, current[0]->nGrowVect());                     // :1417-1420
+        m_comm->SumBoundary({current[0], current[1], current[2]}, ng_depos_J, /*refresh_guards=*/safe_guard_cells,
+                            m_ctx.stream);
     }
 
     // Source/FieldSolver/WarpXPushFieldsEM.cpp:877-927
@@ -235,8 +236,7 @@ public:
     void ExplicitFillBoundaryEBUpdateAux() {
         using warpx::fields::FieldType;
         if (is_synchronized) {
-            FillBoundaryE(guard_cells.ng_alloc_EB);
-            FillBoundaryB(guard_cells.ng_alloc_EB);
+            FillBoundaryEB(guard_cells.ng_alloc_EB);   // FillBoundaryE + FillBoundaryB (:487-488)
             UpdateAuxilaryData();
             FillBoundaryAux(guard_cells.ng_UpdateAux);
             auto E = m_fields.get_alldirs(FieldType::Efield_aux, 0);
@@ -244,8 +244,7 @@ public:
             mypc->PushP(0, -0.5 * dt[0], *E[0], *E[1], *E[2], *B[0], *B[1], *B[2]);
             is_synchronized = false;
         } else {
-            FillBoundaryE(guard_cells.ng_FieldGather);
-            FillBoundaryB(guard_cells.ng_FieldGather);
+            FillBoundaryEB(guard_cells.ng_FieldGather);   // FillBoundaryE + FillBoundaryB (:515-516)
             UpdateAuxilaryData();
             FillBoundaryAux(guard_cells.ng_UpdateAux);
         }
@@ -254,8 +253,7 @@ public:
     // WarpXEvolve.cpp:65-93
     void Synchronize() {
         using warpx::fields::FieldType;
-        FillBoundaryE(guard_cells.ng_FieldGather);
-        FillBoundaryB(guard_cells.ng_FieldGather);
+        FillBoundaryEB(guard_cells.ng_FieldGather);   // FillBoundaryE + FillBoundaryB (:68-69)
         UpdateAuxilaryData();
         FillBoundaryAux(guard_cells.ng_UpdateAux);
         auto E = m_fields.get_alldirs(FieldType::Efield_aux, 0);
@@ -290,11 +288,21 @@ private:
     void FillBoundaryVector(warpx::fields::FieldType ft, const amrex::IntVect& ng, bool nodal_sync) {
         PhaseTimer t(&m_ctx, kFillBoundary);
         auto F = m_fields.get_alldirs(ft, 0);
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < 3; ++d)
             if (!ng.allLE(F[d]->nGrowVect()))  // WarpXComm.cpp:755-759
                 throw std::runtime_error("Error: in FillBoundary, requested more guard cells than allocated");
-            m_comm->FillBoundary(*F[d], ng, nodal_sync, m_ctx.stream);
-        }
+        m_comm->FillBoundary({F[0], F[1], F[2]}, ng, nodal_sync, m_ctx.stream);
+    }
+    // FillBoundaryE(ng) followed by FillBoundaryB(ng): the six components share the messages
+    void FillBoundaryEB(const amrex::IntVect& ng) {
+        PhaseTimer t(&m_ctx, kFillBoundary);
+        using warpx::fields::FieldType;
+        auto E = m_fields.get_alldirs(FieldType::Efield_fp, 0);
+        auto B = m_fields.get_alldirs(FieldType::Bfield_fp, 0);
+        for (int d = 0; d < 3; ++d)
+            if (!ng.allLE(E[d]->nGrowVect()) || !ng.allLE(B[d]->nGrowVect()))
+                throw std::runtime_error("Error: in FillBoundary, requested more guard cells than allocated");
+        m_comm->FillBoundary({E[0], E[1], E[2], B[0], B[1], B[2]}, ng, false, m_ctx.stream);
     }
 
     const Backend* m_be;

@@ -46,14 +46,27 @@ class _DevPtr:
             "shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None}
 
 
+_tensor_cache = {}
+
+
 def _as_tensor(ptr, nbytes, on_device):
+    """uint8 tensor aliasing [ptr, ptr+nbytes).  The host layer's staging buffers keep their
+    addresses from step to step, so the wrappers are cached (wrapping costs ~20 us each)."""
     import torch
     if nbytes == 0:
         return torch.empty(0, dtype=torch.uint8, device="cuda" if on_device else "cpu")
-    if on_device:
-        return torch.as_tensor(_DevPtr(ptr, nbytes), device="cuda")
-    buf = (C.c_uint8 * nbytes).from_address(int(ptr))
-    return torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
+    key = (int(ptr), int(nbytes), bool(on_device))
+    t = _tensor_cache.get(key)
+    if t is None:
+        if on_device:
+            t = torch.as_tensor(_DevPtr(ptr, nbytes), device="cuda")
+        else:
+            buf = (C.c_uint8 * nbytes).from_address(int(ptr))
+            t = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
+        if len(_tensor_cache) > 256:
+            _tensor_cache.clear()
+        _tensor_cache[key] = t
+    return t
 
 
 class TorchBrickTransport:
