@@ -318,3 +318,34 @@ def test_device_pointer_wrapping(product):
     u.copy_(t)
     torch.cuda.synchronize()
     assert np.all(f.storage[f.front + 16:f.front + 32].cpu().numpy() == 3.5)
+
+
+@pytest.mark.parametrize("ncell", [(24, 20, 16), (25, 9, 7), (130, 6, 5), (64, 8, 8)])
+def test_evolve_two_point_kernels_bit_exact(oracle, product, ncell):
+    """The 16-byte-per-lane stencil kernels (padded, 16-B aligned rows) on odd/even and multi-tile
+    row lengths, bit for bit against the oracle (opt-in variant, WXA_STENCIL_V2=1)."""
+    import os
+    os.environ["WXA_STENCIL_V2"] = "1"
+    try:
+        _two_point_body(oracle, product, ncell)
+    finally:
+        del os.environ["WXA_STENCIL_V2"]
+
+
+def _two_point_body(oracle, product, ncell):
+    ng = 2
+    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, ng, 101)
+    B = H.random_fields(("Bx", "By", "Bz"), ncell, ng, 102, scale=1e-8)
+    J = H.random_fields(("jx", "jy", "jz"), ncell, 3, 103, scale=1e3)
+    Ed, Bd, Jd = (H.clone_fields(x, DEV, True) for x in (E, B, J))
+    dx = H.LX / np.asarray(ncell, dtype=np.float64)
+    dt = H.yee_dt(dx)
+    dinv = H.d3(1.0 / dx)
+    for _ in range(2):
+        oracle.evolve_b(field_triplet(E), field_triplet(B), 0.5 * dt, dinv, None)
+        product.evolve_b(field_triplet(Ed), field_triplet(Bd), 0.5 * dt, dinv, None)
+        oracle.evolve_e(field_triplet(E), field_triplet(B), field_triplet(J), dt, dinv, None)
+        product.evolve_e(field_triplet(Ed), field_triplet(Bd), field_triplet(Jd), dt, dinv, None)
+    _sync(product)
+    for a, b in zip(Ed + Bd, E + B):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
