@@ -99,3 +99,104 @@ def test_langmuir_golden_on_gpu(oracle, product):
     ex = sim.field_valid("Ex")
     exc = 0.25 * (ex[:, :-1, :-1] + ex[:, 1:, :-1] + ex[:, :-1, 1:] + ex[:, 1:, 1:])
     assert np.max(np.abs(exc - Eth[0])) / np.max(np.abs(Eth[0])) < 5e-2
+
+
+def test_langmuir_256_two_species_full_size(product):
+    """BASELINE.json config 3 at full size (256^3, e-/e+, 8 ppc, Esirkepov, order 3, 40 steps) through
+    size-independent properties -- the CPU oracle cannot run 2.7e8 particles in test time:
+    (i) the reference's analytic gate (Examples/Tests/langmuir/analysis_3d.py: max-norm error < 5 %),
+    (ii) Gauss' law div E = rho/eps0 kept to round-off by the charge-conserving deposition,
+    (iii) total energy conserved to 1e-3 over the run, (iv) particle count and weights unchanged."""
+    import ctypes as C
+    import torch
+    from warpx_amd.containers import STAG, FieldArray, ParticleArrays, grid_geom
+    n = 256
+    n_cell = (n, n, n)
+    L = 40e-6
+    lo, hi = (-L / 2,) * 3, (L / 2,) * 3
+    dev = "cuda"
+
+    def species(sign):
+        # plasma.langmuir_3d evaluated on the device (same formulas)
+        k = 2.0 * 2.0 * np.pi / L
+        wp = np.sqrt(2.0 * 2e24 * plasma.Q_E ** 2 / (plasma.EP0 * plasma.M_E))
+        a = sign * 0.01 * k / (wp / plasma.C_LIGHT)
+        dx = L / n
+        ppc = 2
+        cell = torch.arange(n ** 3, device=dev)
+        ip = torch.arange(ppc ** 3, device=dev)
+        f64 = torch.float64
+        r = [(0.5 + (ip // (ppc * ppc)).to(f64)) / ppc, (0.5 + ((ip % (ppc * ppc)) // ppc).to(f64)) / ppc,
+             (0.5 + (ip % ppc).to(f64)) / ppc]
+        idx = [cell % n, (cell // n) % n, cell // (n * n)]
+        out = torch.empty((7, n ** 3 * ppc ** 3), dtype=f64, device=dev)
+        for d in range(3):
+            out[d] = (lo[d] + (idx[d].to(f64)[:, None] + r[d][None, :]) * dx).reshape(-1)
+        out[3] = 2e24 * dx ** 3 / ppc ** 3
+        sx, cx = torch.sin(k * out[0]), torch.cos(k * out[0])
+        sy, cy = torch.sin(k * out[1]), torch.cos(k * out[1])
+        sz, cz = torch.sin(k * out[2]), torch.cos(k * out[2])
+        out[4] = a * sx * cy * cz * plasma.C_LIGHT
+        out[5] = a * cx * sy * cz * plasma.C_LIGHT
+        out[6] = a * cx * cy * sz * plasma.C_LIGHT
+        pa = ParticleArrays(out.shape[1], dev)
+        pa.data = out
+        return pa
+
+    sim = WarpXSim(product, n_cell, lo, hi, nox=3, galerkin=1, use_filter=0, sort_interval=4)
+    ids = [sim.add_species(-plasma.Q_E, plasma.M_E, species(+1.0)),
+           sim.add_species(+plasma.Q_E, plasma.M_E, species(-1.0))]
+    torch.cuda.empty_cache()
+
+    def total_energy():
+        e = 0.0
+        dV = (L / n) ** 3
+        for name, c in (("Ex", plasma.EP0), ("Ey", plasma.EP0), ("Ez", plasma.EP0),
+                        ("Bx", 1 / plasma.MU0), ("By", 1 / plasma.MU0), ("Bz", 1 / plasma.MU0)):
+            a = sim.field_valid(name)
+            sl = tuple(slice(0, n) for _ in range(3))   # unique points of the periodic grid
+            e += 0.5 * c * dV * float(np.sum(a[sl].astype(np.longdouble) ** 2))
+        for i in ids:
+            v = sim.particle_view(i)
+            npart = int(v.np)
+            u2 = torch.zeros(npart, dtype=torch.float64, device=dev)
+            from warpx_amd.distributed import _as_tensor
+            w = _as_tensor(v.w, 8 * npart, True).view(torch.float64)
+            for ptr in (v.ux, v.uy, v.uz):
+                c_ = _as_tensor(ptr, 8 * npart, True).view(torch.float64)
+                u2 += c_ * c_
+            gamma = torch.sqrt(1.0 + u2 / plasma.C_LIGHT ** 2)
+            e += float(torch.sum(w * plasma.M_E * u2 / (1.0 + gamma)))
+        return e
+
+    e0 = total_energy()
+    sim.evolve(40)
+    e1 = total_energy()
+    assert abs(e1 - e0) / e0 < 1e-3, (e0, e1)
+    for i in ids:
+        assert int(sim.particle_view(i).np) == n ** 3 * 8
+    # (i) analytic field
+    Eth = plasma.langmuir_analytic_E(n_cell, L, 2e24, 0.01, 40 * sim.dt)
+    ex = sim.field_valid("Ex")
+    exc = 0.25 * (ex[:, :-1, :-1] + ex[:, 1:, :-1] + ex[:, :-1, 1:] + ex[:, 1:, 1:])
+    err = np.max(np.abs(exc - Eth[0])) / np.max(np.abs(Eth[0]))
+    print("langmuir 256^3 max-norm rel error", err)
+    assert err < 5e-2
+    # (ii) Gauss' law on the nodes: div E - rho/eps0 = 0 to round-off
+    ng = 5
+    rho = FieldArray(n_cell, STAG["rho"], (ng,) * 3, dev)
+    g = grid_geom(lo, (L / n,) * 3, (0, 0, 0), (ng,) * 3)
+    for i, q in zip(ids, (-plasma.Q_E, plasma.Q_E)):
+        v = sim.particle_view(i)
+        product.deposit_charge(C.byref(v), C.byref(rho.view), C.byref(g), q, 3, None)
+    product.sum_boundary_periodic(C.byref(rho.view), (C.c_int * 3)(ng, ng, ng), (C.c_int * 3)(1, 1, 1), None)
+    product.device_synchronize()
+    r = rho.valid()[:n, :n, :n]
+    ey, ez = sim.field_valid("Ey"), sim.field_valid("Ez")
+    dx = L / n
+    # node (i,j,k): (Ex(i,j,k) - Ex(i-1,j,k))/dx + ... with periodic wrap of the cell-centred direction
+    div = ((ex[:n, :n, :n] - np.roll(ex[:n, :n, :n], 1, axis=0)) + (ey[:n, :n, :n] - np.roll(ey[:n, :n, :n], 1, axis=1))
+           + (ez[:n, :n, :n] - np.roll(ez[:n, :n, :n], 1, axis=2))) / dx
+    resid = np.max(np.abs(div - r / plasma.EP0)) / np.max(np.abs(r / plasma.EP0))
+    print("gauss residual", resid)
+    assert resid < 1e-7
