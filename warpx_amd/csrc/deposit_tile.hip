@@ -89,6 +89,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     const int o1 = tg.cell_lo[1] + tj * TS + TileDims<M>::LO;
     const int o2 = tg.cell_lo[2] + tk * TS + TileDims<M>::LO;
     const int wave = tid >> 6, lane = tid & 63;
+    const bool at_position = (relative_time + 0.5 * dt) == 0.0;   // wave-uniform
 
     for (int b0 = start; b0 < end; b0 += DT_BATCH) {
         const int nb = min(DT_BATCH, end - b0);
@@ -102,7 +103,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             int key;
             if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
                 int bi, bj, bk;
-                esirkepov_frame<O>(p, g, dt, relative_time, bi, bj, bk);
+                esirkepov_frame<O>(p, g, dt, relative_time, at_position, bi, bj, bk);
                 const int li = bi - o0, lj = bj - o1, lk = bk - o2;
                 const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N && lk + O + 3 <= N;
                 key = in ? (li | (lj << 8) | (lk << 16)) : -1;
