@@ -135,9 +135,12 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
         // ---- deposit: lane l of wave w takes item l*W + w (+8, ...): the lanes of a wave hold items
         //      W apart in the cell order, i.e. different cells -> their LDS atomics do not collide
         const int total = nitems;
-        const int W = (total + 63) >> 6;
-        for (int w2 = wave; w2 < W; w2 += DT_THREADS / 64) {
-            const int it = lane * W + w2;
+        // chunk c covers items {round*64*IPC + lane*IPC + s}: neighbouring lanes are IPC items apart,
+        // i.e. one cell apart at the nominal 2*IPC particles per cell -> consecutive LDS addresses
+        constexpr int IPC = 4;
+        const int nchunks = ((total + 64 * IPC - 1) / (64 * IPC)) * IPC;
+        for (int c = wave; c < nchunks; c += DT_THREADS / 64) {
+            const int it = (c / IPC) * (64 * IPC) + lane * IPC + (c % IPC);
             if (it >= total) continue;
             const int e = items[it];
             const int a = e & (PAIRED - 1);
