@@ -227,13 +227,15 @@ def test_enforce_periodic_and_sort(oracle, product):
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
 @pytest.mark.parametrize("stale", [False, True])
-def test_deposit_current_lds_tiles(oracle, product, order, algo, stale):
+@pytest.mark.parametrize("u_scale", [1.0, 0.003])
+def test_deposit_current_lds_tiles(oracle, product, order, algo, stale, u_scale):
     """LDS-tile variant (needs a cell sort in the workspace) against the oracle; `stale` moves the
     particles by up to 0.9 cell after the sort (and outside the domain) so that part of the
     stencils leave their tile and take the global-atomic path."""
     ncell = (24, 20, 16)
     _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
-    parts = H.random_particles(40000, ncell, 200 + order, u_scale=1.0)
+    # u_scale = 1: most particles cross a cell (general path); 0.003: almost none (fast path)
+    parts = H.random_particles(40000, ncell, 200 + order, u_scale=u_scale)
     dx = H.LX / np.asarray(ncell)
     pd0 = ParticleArrays.from_numpy(parts, DEV)
     ws = C.c_void_p()
@@ -255,8 +257,11 @@ def test_deposit_current_lds_tiles(oracle, product, order, algo, stale):
     oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order, algo, None, None)
     product.deposit_current(C.byref(srt.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, algo, ws, None)
     _sync(product)
+    # slow particles: J is a difference of nearly equal shape weights (S_new - S_old ~ 1e-3 S), so
+    # the summation-order rounding is amplified by ~1/u_scale; still far inside the 1e-10 gate
+    tol = 1e-12 if u_scale == 1.0 else 2e-11
     for a, b in zip(Jd, J):
-        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
+        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < tol
     product.workspace_destroy(ws)
 
 

@@ -31,11 +31,12 @@ struct TileDims {
 
 template <int M>
 struct LdsSink {
-    double* lds;
-    int oi, oj, ok;   // local index of slot 0 (relative form) or of grid index 0 (absolute form)
+    double* base;   // LDS address of slot 0 of component 0: every deposit is base + a compile-time offset
+    __device__ __forceinline__ LdsSink(double* lds, int oi, int oj, int ok)
+        : base(lds + oi + TileDims<M>::N * (oj + TileDims<M>::N * ok)) {}
     __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
         constexpr int N = TileDims<M>::N;
-        atomic_add_f64(lds + c * TileDims<M>::NPTS + (oi + i) + N * ((oj + j) + N * (ok + k)), v);
+        atomic_add_f64(base + (c * TileDims<M>::NPTS + i + N * (j + N * k)), v);
     }
     __device__ __forceinline__ void add_abs(int c, int gi, int gj, int gk, double v) { add(c, gi, gj, gk, v); }
 };
@@ -47,6 +48,8 @@ struct TileGeom {
 
 constexpr int DT_THREADS = 512;   // 8 waves: one workgroup per CU (LDS-limited), 2 waves per SIMD
 constexpr int DT_BATCH = 1024;    // particles staged in LDS per round (7 x 1024 x 8 B = 56 KB)
+constexpr int DT_DEFER = 1024;    // capacity of the per-tile list of deferred (cell-crossing) pairs
+constexpr int DT_DENSE = 256;     // a batch with this many crossing pairs runs the general path at once
 
 // Particles whose stencil leaves the LDS tile (stale sort, particles outside the domain before
 // the periodic wrap) are queued and deposited by deposit_stragglers_kernel with global atomics:
@@ -72,7 +75,10 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     __shared__ double stage[7][DT_BATCH];
     __shared__ int keys[DT_BATCH + 1];
     __shared__ int items[DT_BATCH];
-    __shared__ int nitems;
+    __shared__ unsigned char crossing[DT_BATCH + 1];
+    __shared__ int nitems, nslow;
+    __shared__ unsigned deferred[DT_DEFER];   // pairs with a cell crossing, kept for one dense pass
+    __shared__ int ndeferred;
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long tile = xcd_tile_id(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
@@ -89,10 +95,12 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     const int o1 = tg.cell_lo[1] + tj * TS + TileDims<M>::LO;
     const int o2 = tg.cell_lo[2] + tk * TS + TileDims<M>::LO;
     const int wave = tid >> 6, lane = tid & 63;
-    const bool at_position = (relative_time + 0.5 * dt) == 0.0;   // wave-uniform
-
-    for (int b0 = start; b0 < end; b0 += DT_BATCH) {
-        const int nb = min(DT_BATCH, end - b0);
+    if (tid == 0) ndeferred = 0;
+    // One extra trip after the last batch only flushes the deferred list, so that the (large)
+    // general-path code exists once in the kernel.
+    for (int b0 = start; b0 < end + DT_BATCH; b0 += DT_BATCH) {
+        const bool last = b0 >= end;
+        const int nb = last ? 0 : min(DT_BATCH, end - b0);
         __syncthreads();   // previous round's readers are done (and the zero fill on round 0)
         // ---- stage the batch (coalesced) and key every particle by its stencil frame ----
         for (int a = tid; a < nb; a += DT_THREADS) {
@@ -103,10 +111,11 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             int key;
             if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
                 int bi, bj, bk;
-                esirkepov_frame<O>(p, g, dt, relative_time, at_position, bi, bj, bk);
+                const bool cross = esirkepov_frame_cross<O>(p, g, dt, relative_time, bi, bj, bk);
                 const int li = bi - o0, lj = bj - o1, lk = bk - o2;
                 const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N && lk + O + 3 <= N;
                 key = in ? (li | (lj << 8) | (lk << 16)) : -1;
+                crossing[a] = cross ? 1 : 0;
             } else {
                 DirectShapes<O> s;
                 direct_shapes<O>(p, g, q, relative_time, s);
@@ -117,8 +126,11 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             if (key < 0) { sq.push(ip); key = -2 - a; }   // straggler: a key no neighbour shares
             keys[a] = key;
         }
-        if (tid == 0) { nitems = 0; keys[nb] = -1; }
+        if (tid == 0) { nitems = 0; nslow = 0; keys[nb] = -1; }
         __syncthreads();
+        // Nobody appends to the deferred list between the barrier above and the one below, so this
+        // snapshot is the same in every thread (the flush decision further down must be uniform).
+        const int nd0 = ndeferred;
         // ---- work items: runs of equal frames are cut into pairs (+ one single if odd) ----
         for (int a = tid; a < nb; a += DT_THREADS) {
             const int key = keys[a];
@@ -126,40 +138,92 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
                 int c = 0;
                 for (int b = a; b > 0 && keys[b - 1] == key; --b) ++c;
-                if ((c & 1) == 0) items[atomicAdd(&nitems, 1)] = a | (keys[a + 1] == key ? PAIRED : 0);
+                if ((c & 1) == 0) {
+                    const bool paired = keys[a + 1] == key;
+                    const bool slow = crossing[a] || (paired && crossing[a + 1]);
+                    const int e = a | (paired ? PAIRED : 0);
+                    // pairs without a cell crossing fill the list from the front (fast path),
+                    // the others from the back (general path)
+                    if (slow) items[DT_BATCH - 1 - atomicAdd(&nslow, 1)] = e;
+                    else items[atomicAdd(&nitems, 1)] = e;
+                }
             } else {
                 items[atomicAdd(&nitems, 1)] = a;
             }
         }
         __syncthreads();
-        // ---- deposit: lane l of wave w takes item l*W + w (+8, ...): the lanes of a wave hold items
-        //      W apart in the cell order, i.e. different cells -> their LDS atomics do not collide
-        const int total = nitems;
         // chunk c covers items {round*64*IPC + lane*IPC + s}: neighbouring lanes are IPC items apart,
         // i.e. one cell apart at the nominal 2*IPC particles per cell -> consecutive LDS addresses
         constexpr int IPC = 4;
-        const int nchunks = ((total + 64 * IPC - 1) / (64 * IPC)) * IPC;
-        for (int c = wave; c < nchunks; c += DT_THREADS / 64) {
-            const int it = (c / IPC) * (64 * IPC) + lane * IPC + (c % IPC);
-            if (it >= total) continue;
-            const int e = items[it];
-            const int a = e & (PAIRED - 1);
-            const bool paired = (e & PAIRED) != 0;
-            const ParticleState p1{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
-                                   stage[4][a], stage[5][a], stage[6][a]};
-            if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
+        if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
+            const int nfast = nitems;
+            const int nfchunks = ((nfast + 64 * IPC - 1) / (64 * IPC)) * IPC;
+            for (int c = wave; c < nfchunks; c += DT_THREADS / 64) {       // pairs that stay in their cell
+                const int it = (c / IPC) * (64 * IPC) + lane * IPC + (c % IPC);
+                if (it >= nfast) continue;
+                const int e = items[it];
+                const int a = e & (PAIRED - 1);
+                const bool paired = (e & PAIRED) != 0;
                 const int a2 = paired ? a + 1 : a;
+                const ParticleState p1{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
+                                       stage[4][a], stage[5][a], stage[6][a]};
                 const ParticleState p2{stage[0][a2], stage[1][a2], stage[2][a2], stage[3][a2],
                                        stage[4][a2], stage[5][a2], stage[6][a2]};
-                EsirkepovShapes<O> s1, s2;
-                esirkepov_shapes<O>(p1, g, q, dt, relative_time, s1);
-                esirkepov_shapes<O>(p2, g, q, dt, relative_time, s2);
-                LdsSink<M> sink{lds, s1.bi - o0, s1.bj - o1, s1.bk - o2};
-                esirkepov_accumulate_pair<O>(s1, s2, /*null2=*/!paired, g, dt, sink);
-            } else {
+                EsirkepovNC<O> s1, s2;
+                esirkepov_nc_shapes<O>(p1, g, q, dt, relative_time, s1);
+                esirkepov_nc_shapes<O>(p2, g, q, dt, relative_time, s2);
+                const int key = keys[a];
+                LdsSink<M> sink(lds, key & 255, (key >> 8) & 255, (key >> 16) & 255);
+                esirkepov_accumulate_pair_nc<O>(s1, s2, /*null2=*/!paired, g, dt, sink);
+            }
+            // Pairs with a cell crossing take the general path, whose cost per wave does not depend
+            // on how many lanes are active.  A handful per batch (thermal plasma: ~3 %) would cost
+            // every batch a full pass, so they are deferred (as global particle indices) and run in
+            // dense passes: when the list would overflow (hot / relativistic plasma: every batch)
+            // and once at the end of the tile, spread over the 8 waves.
+            const int nsl = last ? 0 : nslow;
+            if (last || nd0 + nsl > DT_DEFER) {   // block-uniform
+                const int total = nd0;
+                for (int it = lane * (DT_THREADS / 64) + wave; it < total; it += DT_THREADS) {
+                    const unsigned e = deferred[it];
+                    const int ip = (int)(e & 0x7fffffffu);
+                    const bool paired = (e & 0x80000000u) != 0;
+                    const int ip2 = paired ? ip + 1 : ip;
+                    const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+                    const ParticleState p2{px[ip2], py[ip2], pz[ip2], pw[ip2], pux[ip2], puy[ip2], puz[ip2]};
+                    EsirkepovShapes<O> s1, s2;
+                    esirkepov_shapes<O>(p1, g, q, dt, relative_time, s1);
+                    esirkepov_shapes<O>(p2, g, q, dt, relative_time, s2);
+                    LdsSink<M> sink(lds, s1.bi - o0, s1.bj - o1, s1.bk - o2);
+                    esirkepov_accumulate_pair<O>(s1, s2, /*null2=*/!paired, g, dt, sink);
+                }
+                __syncthreads();
+                if (tid == 0) ndeferred = 0;
+                __syncthreads();
+            }
+            if (tid < nsl) {
+                const int e = items[DT_BATCH - 1 - tid];
+                deferred[atomicAdd(&ndeferred, 1)] =
+                    (unsigned)(b0 + (e & (PAIRED - 1))) | ((e & PAIRED) ? 0x80000000u : 0u);
+            }
+            for (int it = tid + DT_THREADS; it < nsl; it += DT_THREADS) {   // nsl can reach DT_BATCH
+                const int e = items[DT_BATCH - 1 - it];
+                deferred[atomicAdd(&ndeferred, 1)] =
+                    (unsigned)(b0 + (e & (PAIRED - 1))) | ((e & PAIRED) ? 0x80000000u : 0u);
+            }
+        } else {
+            if (last) break;
+            const int total = nitems;
+            const int nchunks = ((total + 64 * IPC - 1) / (64 * IPC)) * IPC;
+            for (int c = wave; c < nchunks; c += DT_THREADS / 64) {
+                const int it = (c / IPC) * (64 * IPC) + lane * IPC + (c % IPC);
+                if (it >= total) continue;
+                const int a = items[it];
+                const ParticleState p1{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
+                                       stage[4][a], stage[5][a], stage[6][a]};
                 DirectShapes<O> s;
                 direct_shapes<O>(p1, g, q, relative_time, s);
-                LdsSink<M> sink{lds, -o0, -o1, -o2};
+                LdsSink<M> sink(lds, -o0, -o1, -o2);
                 direct_accumulate<O>(s, sink);
             }
         }

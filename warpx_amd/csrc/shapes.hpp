@@ -43,6 +43,35 @@ __device__ __forceinline__ int shape_factor(double* __restrict__ s, const double
     }
 }
 
+// The same weights with the reference node j imposed by the caller (xint = x - j) instead of
+// derived from x: used for the old position of a particle that the caller has classified as
+// "same cell as the new position".  When x sits on a cell boundary to within an ulp the two
+// evaluations of (int)x can disagree; the spline pieces are continuous there, so imposing j
+// changes the weights by O(ulp) while keeping them on the slots the caller expects.
+template <int ORDER>
+__device__ __forceinline__ void shape_weights_at(double* __restrict__ s, const double x, const int j) {
+    const double xi = x - (double)j;
+    if constexpr (ORDER == 1) {
+        s[0] = 1.0 - xi;
+        s[1] = xi;
+    } else if constexpr (ORDER == 2) {
+        s[0] = 0.5 * (0.5 - xi) * (0.5 - xi);
+        s[1] = 0.75 - xi * xi;
+        s[2] = 0.5 * (0.5 + xi) * (0.5 + xi);
+    } else {
+        static_assert(ORDER == 3, "orders 1..3");
+        const double om = 1.0 - xi;
+        s[0] = (1.0 / 6.0) * om * om * om;
+        s[1] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);
+        s[2] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);
+        s[3] = (1.0 / 6.0) * xi * xi * xi;
+    }
+}
+
+// reference node j of shape_factor<ORDER> from its return value (leftmost index)
+template <int ORDER>
+__device__ __forceinline__ int shape_node(int leftmost) { return ORDER == 1 ? leftmost : leftmost + 1; }
+
 // Old-position weights on the slots of the new position (Esirkepov),
 // Source/Particles/ShapeFactors.H:93-156.  s has ORDER+3 entries, all written here.
 // The reference stores the ORDER+1 weights at the run-time offset 1+i_shift; a run-time
