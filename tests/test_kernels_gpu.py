@@ -213,10 +213,11 @@ def test_enforce_periodic_and_sort(oracle, product):
     _sync(product)
     s = out.to_numpy()
     cell = [np.clip(np.floor((s[d] + H.LX / 2) / dx[d]).astype(np.int64), 0, NCELL[d] - 1) for d in range(3)]
-    T = 8  # tile-major cell key (WXA_TILE): tiles of 8^3 cells, cells i-fastest inside a tile
+    T = 8  # tile-major cell key (WXA_TILE): tiles of 8^3 cells; inside a tile i, then parity of k, then j, then k//2
     nt = [(n + T - 1) // T for n in NCELL]
     tile = cell[0] // T + nt[0] * (cell[1] // T + nt[1] * (cell[2] // T))
-    key = tile * T ** 3 + cell[0] % T + T * (cell[1] % T + T * (cell[2] % T))
+    kt = cell[2] % T
+    key = tile * T ** 3 + cell[0] % T + T * ((kt & 1) + 2 * (cell[1] % T + T * (kt >> 1)))
     assert np.all(np.diff(key) >= 0)
     order_a = np.lexsort(a[::-1])
     order_s = np.lexsort(s[::-1])

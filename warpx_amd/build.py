@@ -18,6 +18,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
           "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
+if os.environ.get("WXA_DEPOSIT_PROFILE") == "1":   # phase clocks in the deposition tile kernel
+    COMMON.append("-DWXA_DEPOSIT_PROFILE")
+COMMON += os.environ.get("WXA_EXTRA_DEFS", "").split()   # experiment switches (scripts/microbench)
+LIB = os.environ.get("WXA_LIB_OUT", LIB)
+
 # (source, extra flags).  The field kernels keep the reference's operation order and
 # are compiled without FMA contraction so that they are bit-identical to the CPU path.
 SOURCES = [

@@ -112,51 +112,56 @@ __device__ __forceinline__ void esirkepov_row(Sink& sink, const double (&d)[O + 
     if (any_hi) { if (du == 0) put(O + 1, sd[O + 1]); }
 }
 
+// One component (COMP = 0,1,2 -> Jx,Jy,Jz) of one particle.  Separate so that the tile kernel can
+// spread the three components of its (rare) cell-crossing particles over different waves.
+// The loop over the slow transverse direction b is NOT unrolled: this path runs once per tile on
+// a handful of particles, and as straight-line code (~15 KB per component) it was bound by
+// instruction fetch, not by arithmetic.  The rows inside one b are static as before.
+template <int O, int COMP, class Sink>
+__device__ __forceinline__ void esirkepov_accumulate_comp(const EsirkepovShapes<O>& s, const Geom& g, double dt,
+                                                          Sink& sink) {
+    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
+    // longitudinal direction L, transverse directions A (fast index of the row) and B
+    const double* Ln = COMP == 0 ? s.sx_new : COMP == 1 ? s.sy_new : s.sz_new;
+    const double* Lo = COMP == 0 ? s.sx_old : COMP == 1 ? s.sy_old : s.sz_old;
+    const double* An = COMP == 0 ? s.sy_new : s.sx_new;
+    const double* Ao = COMP == 0 ? s.sy_old : s.sx_old;
+    const double* Bn = COMP == 2 ? s.sy_new : s.sz_new;
+    const double* Bo = COMP == 2 ? s.sy_old : s.sz_old;
+    const double invdtd = COMP == 0 ? (1.0 / dt) * g.dyi * g.dzi
+                                    : COMP == 1 ? (1.0 / dt) * g.dxi * g.dzi : (1.0 / dt) * g.dxi * g.dyi;
+    const int dl = COMP == 0 ? s.dil : COMP == 1 ? s.djl : s.dkl;
+    const int du = COMP == 0 ? s.diu : COMP == 1 ? s.dju : s.dku;
+    double d[O + 2];
+#pragma unroll
+    for (int a = 0; a < O + 2; ++a) d[a] = s.wq * invdtd * (Lo[a] - Ln[a]);
+    const bool lo = __builtin_amdgcn_ballot_w64(dl == 0) != 0, hi = __builtin_amdgcn_ballot_w64(du == 0) != 0;
+    double an[O + 3], ao[O + 3], bnv[O + 3], bov[O + 3];   // by value: the run-time loop must not see the struct
+#pragma unroll
+    for (int a = 0; a < O + 3; ++a) { an[a] = An[a]; ao[a] = Ao[a]; bnv[a] = Bn[a]; bov[a] = Bo[a]; }
+#pragma unroll 1
+    for (int b = 0; b <= O + 2; b++) {
+        // slot b sits in element 0: the arrays are shifted down once per trip, so that every register
+        // index stays a compile-time constant (a run-time index would move them to scratch memory)
+        const double bn = bnv[0], bo = bov[0];
+#pragma unroll
+        for (int i = 0; i < O + 2; ++i) { bnv[i] = bnv[i + 1]; bov[i] = bov[i + 1]; }
+        if (__builtin_amdgcn_ballot_w64(bn != 0.0 || bo != 0.0) != 0) {   // some lane has weight on this plane
+#pragma unroll
+            for (int a = 0; a <= O + 2; a++) {
+                const double T = one_third * (an[a] * bn + ao[a] * bo) + one_sixth * (an[a] * bo + ao[a] * bn);
+                if (T != 0.0) esirkepov_row<O, COMP>(sink, d, T, dl, du, lo, hi, a, b);
+            }
+        }
+    }
+}
+
 template <int O, class Sink>
 __device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s, const Geom& g, double dt,
                                                      Sink& sink) {
-    const double invdtd_x = (1.0 / dt) * g.dyi * g.dzi;
-    const double invdtd_y = (1.0 / dt) * g.dxi * g.dzi;
-    const double invdtd_z = (1.0 / dt) * g.dxi * g.dyi;
-    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
-    const double wq = s.wq;
-    double dx_[O + 2], dy_[O + 2], dz_[O + 2];
-#pragma unroll
-    for (int a = 0; a < O + 2; ++a) {
-        dx_[a] = wq * invdtd_x * (s.sx_old[a] - s.sx_new[a]);
-        dy_[a] = wq * invdtd_y * (s.sy_old[a] - s.sy_new[a]);
-        dz_[a] = wq * invdtd_z * (s.sz_old[a] - s.sz_new[a]);
-    }
-    const bool xl = __builtin_amdgcn_ballot_w64(s.dil == 0) != 0, xh = __builtin_amdgcn_ballot_w64(s.diu == 0) != 0;
-    const bool yl = __builtin_amdgcn_ballot_w64(s.djl == 0) != 0, yh = __builtin_amdgcn_ballot_w64(s.dju == 0) != 0;
-    const bool zl = __builtin_amdgcn_ballot_w64(s.dkl == 0) != 0, zh = __builtin_amdgcn_ballot_w64(s.dku == 0) != 0;
-#pragma unroll
-    for (int k = 0; k <= O + 2; k++) {
-#pragma unroll
-        for (int j = 0; j <= O + 2; j++) {
-            const double T = one_third * (s.sy_new[j] * s.sz_new[k] + s.sy_old[j] * s.sz_old[k]) +
-                             one_sixth * (s.sy_new[j] * s.sz_old[k] + s.sy_old[j] * s.sz_new[k]);
-            if (T != 0.0) esirkepov_row<O, 0>(sink, dx_, T, s.dil, s.diu, xl, xh, j, k);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k <= O + 2; k++) {
-#pragma unroll
-        for (int i = 0; i <= O + 2; i++) {
-            const double T = one_third * (s.sx_new[i] * s.sz_new[k] + s.sx_old[i] * s.sz_old[k]) +
-                             one_sixth * (s.sx_new[i] * s.sz_old[k] + s.sx_old[i] * s.sz_new[k]);
-            if (T != 0.0) esirkepov_row<O, 1>(sink, dy_, T, s.djl, s.dju, yl, yh, i, k);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j <= O + 2; j++) {
-#pragma unroll
-        for (int i = 0; i <= O + 2; i++) {
-            const double T = one_third * (s.sx_new[i] * s.sy_new[j] + s.sx_old[i] * s.sy_old[j]) +
-                             one_sixth * (s.sx_new[i] * s.sy_old[j] + s.sx_old[i] * s.sy_new[j]);
-            if (T != 0.0) esirkepov_row<O, 2>(sink, dz_, T, s.dkl, s.dku, zl, zh, i, j);
-        }
-    }
+    esirkepov_accumulate_comp<O, 0>(s, g, dt, sink);
+    esirkepov_accumulate_comp<O, 1>(s, g, dt, sink);
+    esirkepov_accumulate_comp<O, 2>(s, g, dt, sink);
 }
 
 // ---- two particles of the same frame merged before the atomics --------------------------

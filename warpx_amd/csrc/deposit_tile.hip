@@ -26,20 +26,55 @@ template <int M>
 struct TileDims {
     static constexpr int LO = -2 - M;            // first LDS point relative to the tile's first cell
     static constexpr int N = TS + 5 + 2 * M;     // points per direction
-    static constexpr int NPTS = N * N * N;
+    // Plane stride padded to 8 (mod 16): with the row stride N = 15 = -1 (mod 16) the LDS bank of
+    // point (i,j,k) is (i - j + 8k) mod 16, so the 16 cells {8 i} x {k, k+1} of one row j sit on
+    // 16 different banks (see the lane assignment in the kernel and cell_of in particles.hip).
+    static constexpr int PS = N * N + ((8 - (N * N) % 16) + 16) % 16;
+    static constexpr int NPTS = N * PS;          // doubles per component (incl. padding)
 };
 
 template <int M>
 struct LdsSink {
     double* base;   // LDS address of slot 0 of component 0: every deposit is base + a compile-time offset
     __device__ __forceinline__ LdsSink(double* lds, int oi, int oj, int ok)
-        : base(lds + oi + TileDims<M>::N * (oj + TileDims<M>::N * ok)) {}
+        : base(lds + oi + TileDims<M>::N * oj + TileDims<M>::PS * ok) {}
     __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
         constexpr int N = TileDims<M>::N;
-        atomic_add_f64(base + (c * TileDims<M>::NPTS + i + N * (j + N * k)), v);
+        atomic_add_f64(base + (c * TileDims<M>::NPTS + i + N * j + TileDims<M>::PS * k), v);
     }
     __device__ __forceinline__ void add_abs(int c, int gi, int gj, int gk, double v) { add(c, gi, gj, gk, v); }
 };
+
+// Phase clocks of the tile kernel (opt-in: WXA_DEPOSIT_PROFILE=1 python -m warpx_amd.build --force;
+// read with scripts/deposit_profile.py).  Thread 0 of every workgroup accumulates the cycles
+// between marks; a barrier before the mark makes the interval the workgroup's, not wave 0's.
+#ifdef WXA_DEPOSIT_PROFILE
+__device__ unsigned long long wxa_dep_prof[16];
+// accumulated in registers of thread 0, added to the global counters once per workgroup (a global
+// atomic per mark would serialise on the 16 addresses and distort the very thing measured)
+#define DPROF_INIT                                  \
+    long long prof_t = clock64();                   \
+    unsigned long long prof_acc[16];                \
+    _Pragma("unroll") for (int prof_i = 0; prof_i < 16; ++prof_i) prof_acc[prof_i] = 0;
+#define DPROF(n)                                                  \
+    do {                                                          \
+        __syncthreads();                                          \
+        const long long prof_n = clock64();                       \
+        prof_acc[n] += (unsigned long long)(prof_n - prof_t);     \
+        prof_t = prof_n;                                          \
+    } while (0)
+#define DCOUNT(n, v) prof_acc[n] += (unsigned long long)(v)
+#define DPROF_FINISH                                                                        \
+    if (threadIdx.x == 0) {                                                                 \
+        _Pragma("unroll") for (int prof_i = 0; prof_i < 16; ++prof_i)                       \
+            if (prof_acc[prof_i]) atomicAdd(&wxa_dep_prof[prof_i], prof_acc[prof_i]);       \
+    }
+#else
+#define DPROF_INIT
+#define DPROF(n)
+#define DCOUNT(n, v)
+#define DPROF_FINISH
+#endif
 
 struct TileGeom {
     int nt[3];        // tiles per direction
@@ -48,8 +83,9 @@ struct TileGeom {
 
 constexpr int DT_THREADS = 512;   // 8 waves: one workgroup per CU (LDS-limited), 2 waves per SIMD
 constexpr int DT_BATCH = 1024;    // particles staged in LDS per round (7 x 1024 x 8 B = 56 KB)
+constexpr int NBANK = 16;         // LDS banks (8-byte wide) seen by one step of a ds_add_f64
+constexpr int ROWS = 512 / NBANK; // quarter-waves of a workgroup = rows of the lane-assignment table
 constexpr int DT_DEFER = 1024;    // capacity of the per-tile list of deferred (cell-crossing) pairs
-constexpr int DT_DENSE = 256;     // a batch with this many crossing pairs runs the general path at once
 
 // Particles whose stencil leaves the LDS tile (stale sort, particles outside the domain before
 // the periodic wrap) are queued and deposited by deposit_stragglers_kernel with global atomics:
@@ -70,13 +106,19 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                     StragglerQueue sq) {
     constexpr int N = TileDims<M>::N;
     constexpr int NPTS = TileDims<M>::NPTS;
+    constexpr int PS = TileDims<M>::PS;
     constexpr int PAIRED = 1 << 30;
     __shared__ double lds[3 * NPTS];
     __shared__ double stage[7][DT_BATCH];
     __shared__ int keys[DT_BATCH + 1];
     __shared__ int items[DT_BATCH];
     __shared__ unsigned char crossing[DT_BATCH + 1];
-    __shared__ int nitems, nslow;
+    __shared__ int nitems;
+    __shared__ int segcnt[2][DT_BATCH / 64];   // fast / slow items per 64-particle segment
+    __shared__ int cut_a, cut_nslow;           // set by the thread holding the first fast item beyond the cap
+    __shared__ int pf_scratch[64];             // landing zone of the L2 prefetch loads
+    __shared__ int slots[DT_THREADS];          // fast item of every lane (row = quarter-wave, column = LDS bank)
+    __shared__ int bcnt[NBANK], novf;
     __shared__ unsigned deferred[DT_DEFER];   // pairs with a cell crossing, kept for one dense pass
     __shared__ int ndeferred;
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
@@ -86,6 +128,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     const int end = offsets[(tile + 1) * TILE_CELLS];
     if (end <= start) return;
     const int tid = threadIdx.x;
+    DPROF_INIT
     for (int a = tid; a < 3 * NPTS; a += DT_THREADS) lds[a] = 0.0;
     const int ti = (int)(tile % tg.nt[0]);
     const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
@@ -96,72 +139,186 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     const int o2 = tg.cell_lo[2] + tk * TS + TileDims<M>::LO;
     const int wave = tid >> 6, lane = tid & 63;
     if (tid == 0) ndeferred = 0;
+    constexpr bool ESIRKEPOV = ALGO == WXA_DEPOSIT_ESIRKEPOV;
+    constexpr int ROUNDS = DT_BATCH / DT_THREADS;   // particles per thread and batch
+    constexpr int WAVES = DT_THREADS / 64;
+    constexpr int NSEG = DT_BATCH / 64;             // 64-particle segments of a batch (one ballot each)
+    constexpr int FAST_CAP = DT_THREADS;            // one fast item per lane: the fast pass is ONE pass
+    const double* const parr[7] = {px, py, pz, pw, pux, puy, puz};
+    int nb_cap = DT_BATCH;   // particles staged per batch; shrinks when the item cap cuts batches short
+    int b0 = start;
     // One extra trip after the last batch only flushes the deferred list, so that the (large)
     // general-path code exists once in the kernel.
-    for (int b0 = start; b0 < end + DT_BATCH; b0 += DT_BATCH) {
+    for (;;) {
         const bool last = b0 >= end;
-        const int nb = last ? 0 : min(DT_BATCH, end - b0);
+        if constexpr (!ESIRKEPOV) {
+            if (last) break;
+        }
+        const int nb = last ? 0 : min(nb_cap, end - b0);
         __syncthreads();   // previous round's readers are done (and the zero fill on round 0)
-        // ---- stage the batch (coalesced) and key every particle by its stencil frame ----
-        for (int a = tid; a < nb; a += DT_THREADS) {
-            const int ip = b0 + a;
-            const ParticleState p{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-            stage[0][a] = p.x; stage[1][a] = p.y; stage[2][a] = p.z; stage[3][a] = p.w;
-            stage[4][a] = p.ux; stage[5][a] = p.uy; stage[6][a] = p.uz;
-            int key;
-            if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
-                int bi, bj, bk;
-                const bool cross = esirkepov_frame_cross<O>(p, g, dt, relative_time, bi, bj, bk);
-                const int li = bi - o0, lj = bj - o1, lk = bk - o2;
-                const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N && lk + O + 3 <= N;
-                key = in ? (li | (lj << 8) | (lk << 16)) : -1;
-                crossing[a] = cross ? 1 : 0;
-            } else {
-                DirectShapes<O> s;
-                direct_shapes<O>(p, g, q, relative_time, s);
-                const int lo_i = min(s.jn, s.jc) - o0, lo_j = min(s.kn, s.kc) - o1, lo_k = min(s.ln, s.lc) - o2;
-                const int hi_i = max(s.jn, s.jc) - o0 + O, hi_j = max(s.kn, s.kc) - o1 + O, hi_k = max(s.ln, s.lc) - o2 + O;
-                key = (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N) ? 0 : -1;
-            }
-            if (key < 0) { sq.push(ip); key = -2 - a; }   // straggler: a key no neighbour shares
-            keys[a] = key;
-        }
-        if (tid == 0) { nitems = 0; nslow = 0; keys[nb] = -1; }
-        __syncthreads();
-        // Nobody appends to the deferred list between the barrier above and the one below, so this
-        // snapshot is the same in every thread (the flush decision further down must be uniform).
-        const int nd0 = ndeferred;
-        // ---- work items: runs of equal frames are cut into pairs (+ one single if odd) ----
-        for (int a = tid; a < nb; a += DT_THREADS) {
-            const int key = keys[a];
-            if (key < 0) continue;
-            if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
-                int c = 0;
-                for (int b = a; b > 0 && keys[b - 1] == key; --b) ++c;
-                if ((c & 1) == 0) {
-                    const bool paired = keys[a + 1] == key;
-                    const bool slow = crossing[a] || (paired && crossing[a + 1]);
-                    const int e = a | (paired ? PAIRED : 0);
-                    // pairs without a cell crossing fill the list from the front (fast path),
-                    // the others from the back (general path)
-                    if (slow) items[DT_BATCH - 1 - atomicAdd(&nslow, 1)] = e;
-                    else items[atomicAdd(&nitems, 1)] = e;
+        // ---- stage the batch (coalesced, all loads in flight together) and key every particle
+        //      by its stencil frame ----
+        {
+            double r[ROUNDS][7];
+#pragma unroll
+            for (int rr = 0; rr < ROUNDS; ++rr) {
+                const int a = tid + rr * DT_THREADS;
+                if (a < nb) {
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) r[rr][c] = parr[c][b0 + a];
                 }
-            } else {
-                items[atomicAdd(&nitems, 1)] = a;
+            }
+#pragma unroll
+            for (int rr = 0; rr < ROUNDS; ++rr) {
+                const int a = tid + rr * DT_THREADS;
+                if (a < nb) {
+                    const ParticleState p{r[rr][0], r[rr][1], r[rr][2], r[rr][3], r[rr][4], r[rr][5], r[rr][6]};
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) stage[c][a] = r[rr][c];
+                    int key;
+                    if constexpr (ESIRKEPOV) {
+                        int bi, bj, bk;
+                        const bool cross = esirkepov_frame_cross<O>(p, g, dt, relative_time, bi, bj, bk);
+                        const int li = bi - o0, lj = bj - o1, lk = bk - o2;
+                        const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N &&
+                                        lk + O + 3 <= N;
+                        // outside the LDS tile: straggler (a key no neighbour shares); queued below,
+                        // once it is known that this batch consumes the particle
+                        key = in ? (li | (lj << 8) | (lk << 16)) : -2 - a;
+                        crossing[a] = cross ? 1 : 0;
+                    } else {
+                        DirectShapes<O> sh;
+                        direct_shapes<O>(p, g, q, relative_time, sh);
+                        const int lo_i = min(sh.jn, sh.jc) - o0, lo_j = min(sh.kn, sh.kc) - o1,
+                                  lo_k = min(sh.ln, sh.lc) - o2;
+                        const int hi_i = max(sh.jn, sh.jc) - o0 + O, hi_j = max(sh.kn, sh.kc) - o1 + O,
+                                  hi_k = max(sh.ln, sh.lc) - o2 + O;
+                        key = (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N) ? 0 : -1;
+                        if (key < 0) sq.push(b0 + a);
+                    }
+                    keys[a] = key;
+                }
             }
         }
+        if (tid == 0) { nitems = 0; keys[nb] = -1; cut_a = nb; cut_nslow = -1; novf = 0; }
+        if (tid < NBANK) bcnt[tid] = 0;
         __syncthreads();
-        // chunk c covers items {round*64*IPC + lane*IPC + s}: neighbouring lanes are IPC items apart,
-        // i.e. one cell apart at the nominal 2*IPC particles per cell -> consecutive LDS addresses
-        constexpr int IPC = 4;
-        if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
-            const int nfast = nitems;
-            const int nfchunks = ((nfast + 64 * IPC - 1) / (64 * IPC)) * IPC;
-            for (int c = wave; c < nfchunks; c += DT_THREADS / 64) {       // pairs that stay in their cell
-                const int it = (c / IPC) * (64 * IPC) + lane * IPC + (c % IPC);
-                if (it >= nfast) continue;
-                const int e = items[it];
+        DPROF(0);   // zero fill (first trip) + stage + key
+        if constexpr (ESIRKEPOV) {
+            // Nobody appends to the deferred list before the flush decision below.
+            const int nd0 = ndeferred;
+            // ---- work items.  A run of equal frames (the particles of one cell, cut at the
+            // 64-particle segments) is split into pairs (+ one single if odd); an item is "slow" if
+            // one of its particles crosses a cell.  Ranks come from ballots and a 16-entry prefix,
+            // so both lists keep the cell order of the sort (neighbouring lanes -> neighbouring
+            // LDS addresses).  At most FAST_CAP fast items are taken: the batch ends where the
+            // next one would start (a_cut) and the rest is staged again by the next trip.
+            bool is_item[ROUNDS], is_slow[ROUNDS], is_pair[ROUNDS];
+            int key_r[ROUNDS];
+            int rank_f[ROUNDS], rank_s[ROUNDS];
+            const unsigned long long le = ~0ull >> (63 - lane), lt = le >> 1;
+#pragma unroll
+            for (int rr = 0; rr < ROUNDS; ++rr) {
+                const int a = tid + rr * DT_THREADS;
+                const int key = a < nb ? keys[a] : -1;
+                const bool cr = crossing[a] != 0;
+                // a crossing particle is a run of its own (slow single); pairs form among the others
+                const bool head = lane == 0 || keys[a - 1] != key || cr || crossing[a - 1] != 0;
+                const unsigned long long H = __ballot(head);
+                const int run_start = 63 - __clzll((long long)(H & le));   // lane 0 is always a head
+                const bool it = key >= 0 && ((lane - run_start) & 1) == 0;
+                const bool pr = it && !cr && lane < 63 && keys[a + 1] == key && crossing[a + 1] == 0;
+                const bool sl = it && cr;
+                const unsigned long long F = __ballot(it && !sl), S = __ballot(sl);
+                rank_f[rr] = __popcll(F & lt);
+                rank_s[rr] = __popcll(S & lt);
+                if (lane == 0) {
+                    segcnt[0][wave + rr * WAVES] = __popcll(F);
+                    segcnt[1][wave + rr * WAVES] = __popcll(S);
+                }
+                is_item[rr] = it; is_slow[rr] = sl; is_pair[rr] = pr; key_r[rr] = key;
+            }
+            __syncthreads();
+            int tot_f = 0, tot_s = 0;
+            {
+                int pre_f[ROUNDS], pre_s[ROUNDS];
+#pragma unroll
+                for (int rr = 0; rr < ROUNDS; ++rr) pre_f[rr] = pre_s[rr] = 0;
+#pragma unroll
+                for (int sg = 0; sg < NSEG; ++sg) {
+                    const int cf = segcnt[0][sg], cs = segcnt[1][sg];
+#pragma unroll
+                    for (int rr = 0; rr < ROUNDS; ++rr)
+                        if (sg < wave + rr * WAVES) { pre_f[rr] += cf; pre_s[rr] += cs; }
+                    tot_f += cf; tot_s += cs;
+                }
+                // Lane assignment of the fast items.  ds_add_f64 serves 16 lanes (a quarter-wave) per
+                // step from 16 banks of 8 bytes (scripts/microbench/lds_*_bench.hip), and ANY two
+                // lanes on one bank double the cost of the step; every deposit of a lane is (frame
+                // base + compile-time offset), so lanes conflict exactly when their frame bases share
+                // a bank.  Items are therefore bucketed by the bank of their frame base: column =
+                // bank, row (= quarter-wave) = rank in the bucket.  All items of a cell land in one
+                // column, so two lanes of a quarter-wave never hit the same address either.
+#pragma unroll
+                for (int rr = 0; rr < ROUNDS; ++rr) {
+                    const int a = tid + rr * DT_THREADS;
+                    const int e = a | (is_pair[rr] ? PAIRED : 0);
+                    const int rank = pre_f[rr] + rank_f[rr];
+                    const bool fast = is_item[rr] && !is_slow[rr] && rank < FAST_CAP;
+                    const int kk = key_r[rr];
+                    const int bank = fast ? ((kk & 255) + N * ((kk >> 8) & 255) + PS * (kk >> 16)) & (NBANK - 1) : -1;
+                    // (a wave-aggregated rank -- 16 ballots, one atomic per wave and bank -- was slower)
+                    const int row = fast ? atomicAdd(&bcnt[bank], 1) : 0;
+                    if (fast) {
+                        if (row < ROWS) slots[row * NBANK + bank] = e;
+                        else items[atomicAdd(&novf, 1)] = e;   // bucket full: takes a free slot below
+                    }
+                    if (is_item[rr]) {
+                        if (is_slow[rr]) items[DT_BATCH - 1 - (pre_s[rr] + rank_s[rr])] = e;   // from the back
+                        else if (rank == FAST_CAP) { cut_a = a; cut_nslow = pre_s[rr] + rank_s[rr]; }
+                    }
+                }
+            }
+            __syncthreads();
+            {   // Free slots (row >= bucket size) go to the items of overfull buckets, the rest stay
+                // empty.  Free slots are numbered column by column, so that consecutive overflow
+                // items (same bucket, often the same cell) land in different quarter-waves: each
+                // one then conflicts with a single lane.
+                const int col = tid & (NBANK - 1), row = tid / NBANK;
+                if (row >= bcnt[col]) {
+                    int m = row - bcnt[col];
+#pragma unroll
+                    for (int c2 = 0; c2 < NBANK; ++c2)
+                        if (c2 < col) m += ROWS - min(bcnt[c2], ROWS);
+                    slots[tid] = m < novf ? items[m] : -1;
+                }
+            }
+            __syncthreads();
+            DPROF(1);   // work-item lists
+            const int a_cut = cut_a;                              // particles consumed by this trip
+            const int nfast = min(tot_f, FAST_CAP);
+            const int nsl = cut_nslow >= 0 ? cut_nslow : tot_s;   // slow items before a_cut
+            if (a_cut < nb) nb_cap = min(DT_BATCH, ((a_cut + 127) >> 6) << 6);
+            else if (nb == nb_cap && nb_cap < DT_BATCH && tot_f < FAST_CAP - 32) nb_cap += 64;
+#pragma unroll
+            for (int rr = 0; rr < ROUNDS; ++rr) {
+                const int a = tid + rr * DT_THREADS;
+                if (a < a_cut && keys[a] <= -2) sq.push(b0 + a);
+            }
+            // Pull the next batch towards the L2 while this one is deposited: one 4-byte load per
+            // 128-byte line, straight into an LDS scratch word (no register, no wait until the
+            // next barrier).  Wave w touches array w.
+            if (!last && wave < 7) {
+                const int nx0 = b0 + a_cut;
+                const int nxn = min(nb_cap, end - nx0);
+                if (lane * 16 < nxn)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(parr[wave] + nx0 + lane * 16),
+                        (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
+            }
+            DCOUNT(15, novf);
+            const int e = slots[tid];
+            if (e >= 0) {   // pairs (and singles) that stay in their cell
                 const int a = e & (PAIRED - 1);
                 const bool paired = (e & PAIRED) != 0;
                 const int a2 = paired ? a + 1 : a;
@@ -176,59 +333,68 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                 LdsSink<M> sink(lds, key & 255, (key >> 8) & 255, (key >> 16) & 255);
                 esirkepov_accumulate_pair_nc<O>(s1, s2, /*null2=*/!paired, g, dt, sink);
             }
-            // Pairs with a cell crossing take the general path, whose cost per wave does not depend
-            // on how many lanes are active.  A handful per batch (thermal plasma: ~3 %) would cost
-            // every batch a full pass, so they are deferred (as global particle indices) and run in
-            // dense passes: when the list would overflow (hot / relativistic plasma: every batch)
-            // and once at the end of the tile, spread over the 8 waves.
-            const int nsl = last ? 0 : nslow;
+            DPROF(2);   // fast pass
+            // Particles with a cell crossing take the general path (alone: merging two of them would
+            // double its already long instruction stream), whose cost per wave does not depend on how
+            // many lanes are active.  A handful per batch (thermal plasma: ~1.5 %) would cost every
+            // batch a full pass, so they are deferred (as global particle indices) and run packed
+            // 64 to a wave, the three J components on different waves: when the list would overflow
+            // (hot / relativistic plasma: every batch) and once at the end of the tile.
+            int nd_base = nd0;
+            DCOUNT(8, nfast); DCOUNT(9, nsl); DCOUNT(10, 1); DCOUNT(11, a_cut); DCOUNT(12, nb);
             if (last || nd0 + nsl > DT_DEFER) {   // block-uniform
-                const int total = nd0;
-                for (int it = lane * (DT_THREADS / 64) + wave; it < total; it += DT_THREADS) {
-                    const unsigned e = deferred[it];
-                    const int ip = (int)(e & 0x7fffffffu);
-                    const bool paired = (e & 0x80000000u) != 0;
-                    const int ip2 = paired ? ip + 1 : ip;
+                DCOUNT(13, 1); DCOUNT(14, nd0);
+                // work unit = (64 deferred particles, one J component); units go round the waves
+                const int nunits = 3 * ((nd0 + 63) >> 6);
+                for (int u = wave; u < nunits; u += WAVES) {
+                    const int it = (u / 3) * 64 + lane;
+                    if (it >= nd0) continue;
+                    const int ip = (int)deferred[it];
                     const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-                    const ParticleState p2{px[ip2], py[ip2], pz[ip2], pw[ip2], pux[ip2], puy[ip2], puz[ip2]};
-                    EsirkepovShapes<O> s1, s2;
+                    EsirkepovShapes<O> s1;
                     esirkepov_shapes<O>(p1, g, q, dt, relative_time, s1);
-                    esirkepov_shapes<O>(p2, g, q, dt, relative_time, s2);
                     LdsSink<M> sink(lds, s1.bi - o0, s1.bj - o1, s1.bk - o2);
-                    esirkepov_accumulate_pair<O>(s1, s2, /*null2=*/!paired, g, dt, sink);
+                    switch (u % 3) {
+                        case 0: esirkepov_accumulate_comp<O, 0>(s1, g, dt, sink); break;
+                        case 1: esirkepov_accumulate_comp<O, 1>(s1, g, dt, sink); break;
+                        default: esirkepov_accumulate_comp<O, 2>(s1, g, dt, sink); break;
+                    }
                 }
-                __syncthreads();
-                if (tid == 0) ndeferred = 0;
-                __syncthreads();
+                nd_base = 0;
+                __syncthreads();   // the list is free again
             }
-            if (tid < nsl) {
-                const int e = items[DT_BATCH - 1 - tid];
-                deferred[atomicAdd(&ndeferred, 1)] =
-                    (unsigned)(b0 + (e & (PAIRED - 1))) | ((e & PAIRED) ? 0x80000000u : 0u);
+            DPROF(3);   // deferred general-path flush
+            for (int rk = tid; rk < nsl; rk += DT_THREADS) {
+                const int e = items[DT_BATCH - 1 - rk];
+                deferred[nd_base + rk] = (unsigned)(b0 + (e & (PAIRED - 1)));   // slow items are singles
             }
-            for (int it = tid + DT_THREADS; it < nsl; it += DT_THREADS) {   // nsl can reach DT_BATCH
-                const int e = items[DT_BATCH - 1 - it];
-                deferred[atomicAdd(&ndeferred, 1)] =
-                    (unsigned)(b0 + (e & (PAIRED - 1))) | ((e & PAIRED) ? 0x80000000u : 0u);
-            }
-        } else {
+            if (tid == 0) ndeferred = nd_base + nsl;
             if (last) break;
+            b0 += a_cut;
+        } else {
+            for (int a = tid; a < nb; a += DT_THREADS)
+                if (keys[a] >= 0) items[atomicAdd(&nitems, 1)] = a;
+            __syncthreads();
+            DPROF(1);
+            constexpr int IPC = 4;
             const int total = nitems;
             const int nchunks = ((total + 64 * IPC - 1) / (64 * IPC)) * IPC;
-            for (int c = wave; c < nchunks; c += DT_THREADS / 64) {
+            for (int c = wave; c < nchunks; c += WAVES) {
                 const int it = (c / IPC) * (64 * IPC) + lane * IPC + (c % IPC);
                 if (it >= total) continue;
                 const int a = items[it];
                 const ParticleState p1{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
                                        stage[4][a], stage[5][a], stage[6][a]};
-                DirectShapes<O> s;
-                direct_shapes<O>(p1, g, q, relative_time, s);
+                DirectShapes<O> sh;
+                direct_shapes<O>(p1, g, q, relative_time, sh);
                 LdsSink<M> sink(lds, -o0, -o1, -o2);
-                direct_accumulate<O>(s, sink);
+                direct_accumulate<O>(sh, sink);
             }
+            b0 += nb;
         }
     }
     __syncthreads();
+    DPROF(4);   // append to the deferred list / direct pass
     // write-back: one global atomic per non-zero LDS point (tiles overlap on their halos)
     const DevF* Jc[3] = {&Jx, &Jy, &Jz};
 #pragma unroll
@@ -237,13 +403,16 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
         for (int a = tid; a < NPTS; a += DT_THREADS) {
             const double v = lds[c * NPTS + a];
             if (v != 0.0) {
-                const int i = o0 + a % N, j = o1 + (a / N) % N, k = o2 + a / (N * N);
+                // a = i + N j + PS k; the padding words of a plane (a % PS >= N N) stay zero
+                const int i = o0 + (a % PS) % N, j = o1 + (a % PS) / N, k = o2 + a / PS;
                 if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
                     k < J.lo2 + J.n2)
                     atomic_add_f64(J.p + J.off(i, j, k), v);
             }
         }
     }
+    DPROF(5);   // write-back
+    DPROF_FINISH
 }
 
 template <int O, int ALGO>
@@ -320,3 +489,15 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
 }
 
 }  // namespace wxa
+
+#ifdef WXA_DEPOSIT_PROFILE
+extern "C" int wxa_debug_deposit_profile(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(wxa::wxa_dep_prof), sizeof(wxa::wxa_dep_prof)) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wxa::wxa_dep_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

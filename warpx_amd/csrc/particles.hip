@@ -121,8 +121,11 @@ struct SortGeom {
     int nc[3];
 };
 
-// Tile-major cell key: tiles of WXA_TILE^3 cells, cells i-fastest inside a tile, so that a
-// tile's particles are contiguous (LDS-tile kernels) and still grouped by cell.
+// Tile-major cell key: tiles of WXA_TILE^3 cells, so that a tile's particles are contiguous
+// (LDS-tile kernels) and still grouped by cell.  Inside a tile the order is i fastest, then the
+// parity of k, then j, then k/2: any 16 consecutive cells (8 i x 2 k-parities) start on 16
+// different LDS banks of the deposition tile (deposit_tile.hip, plane stride = 8 mod 16), which
+// keeps its bank buckets evenly filled.
 __device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, double z) {
     int i = (int)floor((x - s.plo[0]) * s.dinv[0]);
     int j = (int)floor((y - s.plo[1]) * s.dinv[1]);
@@ -133,7 +136,8 @@ __device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, do
     constexpr int T = WXA_TILE;
     const int nti = (s.nc[0] + T - 1) / T, ntj = (s.nc[1] + T - 1) / T;
     const int tile = (i / T) + nti * ((j / T) + ntj * (k / T));
-    return tile * (T * T * T) + (i % T) + T * ((j % T) + T * (k % T));
+    const int kt = k % T;
+    return tile * (T * T * T) + (i % T) + T * ((kt & 1) + 2 * ((j % T) + T * (kt >> 1)));
 }
 
 // Histogram + rank.  The input is usually almost sorted (a few % of the particles changed cell
