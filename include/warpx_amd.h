@@ -181,7 +181,8 @@ wxa_status wxa_enforce_periodic(const wxa_particle_view* p,
  * Source/Particles/MultiParticleContainer.cpp:615-621 -> amrex SortParticlesByBin):
  * counting sort by cell index inside the box [cell_lo, cell_lo+ncell).
  * `dst` receives the sorted copy (out of place; same np).  Also records the
- * per-cell offsets in ws for the tile-based deposition. */
+ * per-cell offsets in ws for the tile-based deposition.  Retired particles
+ * (idcpu == WXA_IDCPU_RETIRED, see wxa_pack_leavers) are moved behind the live ones. */
 wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src,
                                       const wxa_particle_view* dst,
                                       const double plo[3], const double dinv[3],
@@ -194,6 +195,48 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src,
 wxa_status wxa_partition_particles(const wxa_particle_view* src, const wxa_particle_view* dst,
                                    int dim, double lo, double hi, int64_t counts[3],
                                    wxa_workspace* ws, void* stream);
+
+/* ---- brick-to-brick Redistribute without moving the tile ------------------------------
+ * amrex ParticleContainer::Redistribute (called from MultiParticleContainer::Redistribute,
+ * Source/Particles/MultiParticleContainer.cpp:651-654, once per step from
+ * Source/Evolve/WarpXEvolve.cpp:514-537) re-buckets every particle.  Per step only ~1e-5 of a
+ * brick's particles cross a face, so here the tile keeps its (cell-sorted) order between sorts:
+ *   1. wxa_wrap_and_classify scans the positions once: periodic wrap, plus six index lists of
+ *      the particles that left the brick, by the FIRST split direction d in which they are outside
+ *      (list 2d = towards minus, 2d+1 = towards plus; decided before the wrap);
+ *   2. wxa_pack_leavers copies the listed particles into a message (8 rows of n entries:
+ *      x,y,z,w,ux,uy,uz,idcpu) and retires them in place: weight 0, momentum 0, position clamped
+ *      into the brick, idcpu = WXA_IDCPU_RETIRED.  A retired particle deposits exact zeros and
+ *      is dropped by the next wxa_sort_particles_by_cell;
+ *   3. arrivals are appended behind the sorted part of the tile; the LDS-tile kernels cover the
+ *      sorted part and the global-memory kernels the tail (wxa_gather_push_ws / wxa_deposit_current
+ *      do this split themselves when ws holds a sort of the same array).
+ * Needs p->idcpu != NULL (it carries the retired mark). */
+#define WXA_IDCPU_RETIRED 0xFFFFFFFFFFFFFFFFull
+
+/* Scans particles [first, first+count).  split[d] != 0: the brick has distinct neighbours along d
+ * (leavers are listed); periodic[d] != 0: wrap positions into [prob_lo, prob_hi) along d.
+ * lists: 6 device arrays of `capacity` int32 each (lists[c] + ... contiguous: list c starts at
+ * lists + c*capacity); entries are indices relative to the view.  counts[6] (host) is valid on
+ * return (synchronises); a count above `capacity` means the list was truncated: call again with
+ * a larger capacity (positions are only wrapped once, the call is idempotent). */
+wxa_status wxa_wrap_and_classify(const wxa_particle_view* p, int64_t first, int64_t count,
+                                 const double prob_lo[3], const double prob_hi[3],
+                                 const int periodic[3], const double brick_lo[3],
+                                 const double brick_hi[3], const int split[3], int32_t* lists,
+                                 int64_t capacity, int64_t counts[6], wxa_workspace* ws,
+                                 void* stream);
+
+/* Writes the n listed particles into entries [offset, offset+n) of a message of 8 rows of
+ * row_len doubles/uint64 each (row r at msg + 8*r*row_len bytes), so that several lists can
+ * share one message.  retire != 0: see above. */
+wxa_status wxa_pack_leavers(const wxa_particle_view* p, const int32_t* list, int64_t n, void* msg,
+                            int64_t row_len, int64_t offset, int retire, const double brick_lo[3],
+                            const double brick_hi[3], void* stream);
+
+/* Number of particles of the last wxa_sort_particles_by_cell on ws that were NOT retired: they
+ * occupy dst[0, n); the retired ones follow.  Synchronises. */
+wxa_status wxa_sort_live_count(wxa_workspace* ws, int64_t* n, void* stream);
 
 /* ------------------------------------------------------------------ */
 /* Current filter and guard-cell exchange                              */

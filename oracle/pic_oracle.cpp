@@ -444,11 +444,13 @@ int orc_partition_particles(const wxa_particle_view* src, const wxa_particle_vie
     return 0;
 }
 
-// stable counting sort by cell (i fastest); any grouping by cell is a valid SortParticlesByBin
+// stable counting sort by cell (i fastest); any grouping by cell is a valid SortParticlesByBin.
+// Retired particles (idcpu == WXA_IDCPU_RETIRED, see orc_pack_leavers) go behind the live ones;
+// if ws is given it receives the live count (one int64).
 int orc_sort_particles_by_cell(const wxa_particle_view* src, const wxa_particle_view* dst, const double plo[3],
-                               const double dinv[3], const int32_t*, const int32_t ncell[3], void*, void*) {
+                               const double dinv[3], const int32_t*, const int32_t ncell[3], void* ws, void*) {
     const int64_t nc = (int64_t)ncell[0] * ncell[1] * ncell[2];
-    std::vector<int64_t> off(nc + 1, 0);
+    std::vector<int64_t> off(nc + 2, 0);
     std::vector<int64_t> key(src->np);
     for (int64_t p = 0; p < src->np; ++p) {
         int c[3];
@@ -458,15 +460,68 @@ int orc_sort_particles_by_cell(const wxa_particle_view* src, const wxa_particle_
             c[d] = std::min(std::max(c[d], 0), ncell[d] - 1);
         }
         key[p] = c[0] + (int64_t)ncell[0] * (c[1] + (int64_t)ncell[1] * c[2]);
+        if (src->idcpu && src->idcpu[p] == WXA_IDCPU_RETIRED) key[p] = nc;
         off[key[p] + 1]++;
     }
-    for (int64_t c = 0; c < nc; ++c) off[c + 1] += off[c];
+    for (int64_t c = 0; c <= nc; ++c) off[c + 1] += off[c];
+    if (ws) *static_cast<int64_t*>(ws) = off[nc];
     const double* s[7] = {src->x, src->y, src->z, src->w, src->ux, src->uy, src->uz};
     double* d[7] = {dst->x, dst->y, dst->z, dst->w, dst->ux, dst->uy, dst->uz};
     for (int64_t p = 0; p < src->np; ++p) {
         const int64_t t = off[key[p]]++;
         for (int c = 0; c < 7; ++c) d[c][t] = s[c][p];
         if (src->idcpu && dst->idcpu) dst->idcpu[t] = src->idcpu[p];
+    }
+    return 0;
+}
+
+int orc_sort_live_count(void* ws, int64_t* n, void*) {
+    if (!ws || !n) return -1;
+    *n = *static_cast<int64_t*>(ws);
+    return 0;
+}
+
+// The brick-to-brick part of amrex ParticleContainer::Redistribute as the host layer drives it
+// (include/warpx_amd.h, "Redistribute without moving the tile"): periodic wrap plus the lists of
+// particles that left the brick, by the first split direction in which they are outside (decided
+// on the unwrapped position).
+int orc_wrap_and_classify(const wxa_particle_view* p, int64_t first, int64_t count, const double prob_lo[3],
+                          const double prob_hi[3], const int periodic[3], const double brick_lo[3],
+                          const double brick_hi[3], const int split[3], int32_t* lists, int64_t capacity,
+                          int64_t counts[6], void*, void*) {
+    for (int c = 0; c < 6; ++c) counts[c] = 0;
+    double* pos[3] = {p->x, p->y, p->z};
+    for (int64_t ip = first; ip < first + count; ++ip) {
+        int code = -1;
+        for (int d = 0; d < 3 && code < 0; ++d)
+            if (split[d]) code = pos[d][ip] < brick_lo[d] ? 2 * d : (pos[d][ip] >= brick_hi[d] ? 2 * d + 1 : -1);
+        if (code >= 0 && p->idcpu[ip] == WXA_IDCPU_RETIRED) code = -1;
+        if (code >= 0) {
+            if (counts[code] < capacity) lists[code * capacity + counts[code]] = (int32_t)ip;
+            counts[code]++;
+        }
+    }
+    wxa_particle_view r = *p;
+    r.x += first; r.y += first; r.z += first;
+    r.np = count;
+    return orc_enforce_periodic(&r, prob_lo, prob_hi, periodic, nullptr);
+}
+
+int orc_pack_leavers(const wxa_particle_view* p, const int32_t* list, int64_t n, void* msg, int64_t row_len,
+                     int64_t offset, int retire, const double brick_lo[3], const double brick_hi[3], void*) {
+    double* m = static_cast<double*>(msg) + offset;
+    const double* s[7] = {p->x, p->y, p->z, p->w, p->ux, p->uy, p->uz};
+    double* pos[3] = {p->x, p->y, p->z};
+    for (int64_t t = 0; t < n; ++t) {
+        const int64_t ip = list[t];
+        for (int c = 0; c < 7; ++c) m[c * row_len + t] = s[c][ip];
+        reinterpret_cast<uint64_t*>(m)[7 * row_len + t] = p->idcpu[ip];
+        if (retire) {
+            for (int d = 0; d < 3; ++d)
+                pos[d][ip] = std::min(std::max(pos[d][ip], brick_lo[d]), std::nextafter(brick_hi[d], brick_lo[d]));
+            p->w[ip] = 0.0; p->ux[ip] = 0.0; p->uy[ip] = 0.0; p->uz[ip] = 0.0;
+            p->idcpu[ip] = WXA_IDCPU_RETIRED;
+        }
     }
     return 0;
 }

@@ -29,6 +29,11 @@ int orc_sort_particles_by_cell(const wxa_particle_view*, const wxa_particle_view
                                const int32_t*, const int32_t*, void*, void*);
 int orc_partition_particles(const wxa_particle_view*, const wxa_particle_view*, int, double, double, int64_t*,
                             void*, void*);
+int orc_wrap_and_classify(const wxa_particle_view*, int64_t, int64_t, const double*, const double*, const int*,
+                          const double*, const double*, const int*, int32_t*, int64_t, int64_t*, void*, void*);
+int orc_pack_leavers(const wxa_particle_view*, const int32_t*, int64_t, void*, int64_t, int64_t, int, const double*,
+                     const double*, void*);
+int orc_sort_live_count(void*, int64_t*, void*);
 }
 
 namespace {
@@ -64,6 +69,9 @@ const Backend* cpu_backend() {
         b.enforce_periodic = orc_enforce_periodic;
         b.sort_particles_by_cell = orc_sort_particles_by_cell;
         b.partition_particles = orc_partition_particles;
+        b.wrap_and_classify = orc_wrap_and_classify;
+        b.pack_leavers = orc_pack_leavers;
+        b.sort_live_count = orc_sort_live_count;
         b.workspace_create = ws_create; b.workspace_destroy = ws_destroy;
         b.dmalloc = h_malloc; b.dfree = h_free;
         b.memset_async = h_memset; b.memcpy_async = h_memcpy;

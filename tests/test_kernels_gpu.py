@@ -355,3 +355,132 @@ def _two_point_body(oracle, product, ncell):
     _sync(product)
     for a, b in zip(Ed + Bd, E + B):
         assert np.array_equal(a.to_numpy(), b.to_numpy())
+
+
+RETIRED = 0xFFFFFFFFFFFFFFFF
+
+
+def _view_n(pa, n):
+    """The first n particles of a ParticleArrays as a view."""
+    v = pa.view
+    v.np = n
+    return v
+
+
+def test_redistribute_ops(oracle, product):
+    """wxa_wrap_and_classify / wxa_pack_leavers / retired particles in the sort against the CPU
+    restatement: same leaver sets per list, same wrapped positions, same messages, same retirement."""
+    import torch
+    ncell = (24, 20, 16)
+    n = 50000
+    rng = np.random.default_rng(77)
+    dx = H.LX / np.asarray(ncell)
+    plo, phi = np.full(3, -H.LX / 2), np.full(3, H.LX / 2)
+    blo = np.array([plo[0], plo[1], plo[2]])
+    bhi = np.array([0.0, phi[1], 0.0])          # the brick: lower half in x and z, all of y
+    # positions around the brick, up to one cell outside it (and outside the domain on the low side)
+    pos = [blo[d] - dx[d] + (bhi[d] - blo[d] + 2 * dx[d]) * rng.random(n) for d in range(3)]
+    parts = pos + [1e9 * (0.5 + rng.random(n))] + [1e6 * rng.standard_normal(n) for _ in range(3)]
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    ids[rng.random(n) < 0.02] = RETIRED         # retired earlier: never listed again
+    pc = ParticleArrays.from_numpy(parts, "cpu", ids.copy())
+    pd = ParticleArrays.from_numpy(parts, DEV, ids.view(np.int64))
+    periodic, split = H.i3((1, 1, 1)), H.i3((1, 0, 1))
+    cap = n
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    lists_d = torch.zeros(6 * cap, dtype=torch.int32, device=DEV)
+    lists_c = np.zeros(6 * cap, dtype=np.int32)
+    cnt_d, cnt_c = (C.c_int64 * 6)(), (C.c_int64 * 6)()
+    product.wrap_and_classify(C.byref(pd.view), 0, n, H.d3(plo), H.d3(phi), periodic, H.d3(blo), H.d3(bhi), split,
+                              lists_d.data_ptr(), cap, cnt_d, ws, None)
+    oracle.wrap_and_classify(C.byref(pc.view), 0, n, H.d3(plo), H.d3(phi), periodic, H.d3(blo), H.d3(bhi), split,
+                             lists_c.ctypes.data, cap, cnt_c, None, None)
+    assert list(cnt_d) == list(cnt_c)
+    assert cnt_d[2] == 0 and cnt_d[3] == 0 and sum(cnt_d) > 1000       # y is not split
+    ld = lists_d.cpu().numpy()
+    for c in range(6):
+        assert np.array_equal(np.sort(ld[c * cap:c * cap + cnt_d[c]]), np.sort(lists_c[c * cap:c * cap + cnt_c[c]]))
+    assert np.array_equal(pd.to_numpy(), pc.to_numpy())                 # wrapped positions, bit for bit
+    # pack + retire list 1 (towards +x), in the product's list order on both sides
+    m = int(cnt_d[1])
+    lst = np.ascontiguousarray(ld[cap:cap + m])
+    row_len, off = m + 7, 5
+    msg_d = torch.zeros(8 * row_len, dtype=torch.float64, device=DEV)
+    msg_c = np.zeros(8 * row_len, dtype=np.float64)
+    product.pack_leavers(C.byref(pd.view), lists_d.data_ptr() + 4 * cap, m, msg_d.data_ptr(), row_len, off, 1,
+                         H.d3(blo), H.d3(bhi), None)
+    oracle.pack_leavers(C.byref(pc.view), lst.ctypes.data, m, msg_c.ctypes.data, row_len, off, 1, H.d3(blo),
+                        H.d3(bhi), None)
+    _sync(product)
+    assert np.array_equal(msg_d.cpu().numpy().view(np.uint64), msg_c.view(np.uint64))
+    assert np.array_equal(pd.to_numpy(), pc.to_numpy())
+    ids_d = pd.idcpu.cpu().numpy().view(np.uint64)
+    assert np.array_equal(ids_d, pc.idcpu)
+    assert int((ids_d == RETIRED).sum()) == int((ids == RETIRED).sum()) + m
+    a = pd.to_numpy()
+    assert np.all(a[3, lst] == 0.0) and np.all(a[4:7, lst] == 0.0)
+    for d in range(3):
+        assert np.all(a[d, lst] >= blo[d]) and np.all(a[d, lst] < bhi[d])
+    # the sort drops the retired particles behind the live ones
+    out = ParticleArrays(n, DEV, with_id=True)
+    bn = (12, 20, 8)
+    product.sort_particles_by_cell(C.byref(pd.view), C.byref(out.view), H.d3(blo), H.d3(1.0 / dx), H.i3((0, 0, 0)),
+                                   (C.c_int32 * 3)(*bn), ws, None)
+    live = C.c_int64()
+    product.sort_live_count(ws, C.byref(live), None)
+    nlive = int((ids_d != RETIRED).sum())
+    assert live.value == nlive
+    oid = out.idcpu.cpu().numpy().view(np.uint64)
+    assert np.all(oid[:nlive] != RETIRED) and np.all(oid[nlive:] == RETIRED)
+    assert np.array_equal(np.sort(oid[:nlive]), np.sort(ids_d[ids_d != RETIRED]))
+    product.workspace_destroy(ws)
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_tile_kernels_with_appended_tail(oracle, product, order):
+    """Arrivals appended behind the sorted part of a tile (Redistribute between two sorts): the
+    LDS-tile kernels cover the sorted part, the global-memory kernels the tail; together they must
+    equal the CPU result over all particles."""
+    import torch
+    ncell = (24, 20, 16)
+    nsorted, ntail = 30000, 700
+    ng_eb, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    dx = H.LX / np.asarray(ncell)
+    head = H.random_particles(nsorted, ncell, 301, u_scale=0.3)
+    tail = H.random_particles(ntail, ncell, 302, u_scale=0.3)
+    src = ParticleArrays.from_numpy(head, DEV)
+    allp = ParticleArrays(nsorted + ntail, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    v_sorted = _view_n(allp, nsorted)
+    product.sort_particles_by_cell(C.byref(src.view), C.byref(v_sorted), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   H.i3((0, 0, 0)), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    allp.data[:, nsorted:] = torch.from_numpy(np.stack(tail)).to(DEV)
+    ph = ParticleArrays.from_numpy(list(allp.to_numpy()), "cpu")
+    # deposition
+    J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    Jd = H.clone_fields(J, DEV, True)
+    g, _ = H.geom_for(ncell, ng_depos)
+    dt = H.yee_dt(dx)
+    q = -plasma.Q_E
+    oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order, 0, None, None)
+    product.deposit_current(C.byref(allp.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, 0, ws, None)
+    _sync(product)
+    for a, b in zip(Jd, J):
+        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
+    # gather + push
+    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, ng_eb, 11, 1e9)
+    B = H.random_fields(("Bx", "By", "Bz"), ncell, ng_eb, 12, 1.0)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    ge, _ = H.geom_for(ncell, ng_eb)
+    oracle.gather_push(C.byref(ph.view), field_triplet(E), field_triplet(B), C.byref(ge), q, plasma.M_E, dt, order, 1,
+                       0, None)
+    product.gather_push_ws(C.byref(allp.view), field_triplet(Ed), field_triplet(Bd), C.byref(ge), q, plasma.M_E, dt,
+                           order, 1, 0, 1, ws, None)
+    _sync(product)
+    a, b = allp.to_numpy(), ph.to_numpy()
+    for r in range(7):
+        assert H.max_rel_err(a[r], b[r]) < 1e-13
+    product.workspace_destroy(ws)

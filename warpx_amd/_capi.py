@@ -135,6 +135,11 @@ _PRODUCT_SIGS = {
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "partition_particles": (C.c_int, [_PPV, _PPV, C.c_int, C.c_double, C.c_double,
                                       C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "wrap_and_classify": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,
+                                    C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "pack_leavers": (C.c_int, [_PPV, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _D3, _D3,
+                               C.c_void_p]),
+    "sort_live_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "pack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "unpack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
     "copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -152,6 +157,11 @@ _ORACLE_SIGS = {
     "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
     "sim_compute_rho": (C.c_int, [C.c_void_p]),
     "num_threads": (C.c_int, []),
+    # CPU counterparts of the Redistribute entry points (host-layer tests, parity tests)
+    "wrap_and_classify": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,
+                                    C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "pack_leavers": (C.c_int, [_PPV, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _D3, _D3,
+                               C.c_void_p]),
 }
 
 

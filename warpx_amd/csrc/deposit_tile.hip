@@ -442,7 +442,7 @@ deposit_stragglers_kernel(const double* __restrict__ px, const double* __restric
 }
 
 bool deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p) {
-    return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np == p->np;
+    return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np <= p->np;
 }
 
 template <int O, int ALGO>

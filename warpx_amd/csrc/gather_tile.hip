@@ -136,7 +136,7 @@ gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned*
 }
 
 bool gather_tile_available(const wxa_workspace* ws, const wxa_particle_view* p) {
-    return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np == p->np;
+    return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np <= p->np;
 }
 
 template <int PUSHER, bool MOVE>

@@ -142,7 +142,8 @@ class WarpXParticleContainer {
 public:
     WarpXParticleContainer(WarpXContext* ctx, double charge, double mass)
         : m_ctx(ctx), m_tile(ctx->be), m_spare(ctx->be), charge(charge), mass(mass) {
-        m_sendbuf.be = ctx->be; m_recvbuf.be = ctx->be;
+        m_sendbuf.be = ctx->be; m_recvbuf.be = ctx->be; m_lists.be = ctx->be;
+        for (auto& b : m_arrival_lists) b.be = ctx->be;
         check(ctx->be->workspace_create(&m_ws), "workspace_create");
     }
     virtual ~WarpXParticleContainer() { if (m_ws) m_ctx->be->workspace_destroy(m_ws); }
@@ -168,7 +169,9 @@ public:
               "deposit_current");
     }
 
-    // amrex SortParticlesByBin with bin = one cell (MultiParticleContainer.cpp:615-621)
+    // amrex SortParticlesByBin with bin = one cell (MultiParticleContainer.cpp:615-621).  Also
+    // drops the particles retired by Redistribute and merges the arrivals appended since the
+    // last sort into the cell order.
     void SortParticlesByBin(const amrex::IntVect& /*bin_size*/) {
         const int64_t np = m_tile.numParticles();
         if (np == 0) return;
@@ -180,74 +183,128 @@ public:
                                                 m_ws, m_ctx->stream),
               "sort_particles_by_cell");
         m_tile.swap(m_spare);
+        if (m_nretired > 0) {
+            int64_t live = np;
+            check(m_ctx->be->sort_live_count(m_ws, &live, m_ctx->stream), "sort_live_count");
+            if (live != np - m_nretired) throw std::runtime_error("SortParticlesByBin: retired-particle count mismatch");
+            m_tile.resize(live);
+            m_nretired = 0;
+        }
     }
 
-    // amrex ParticleContainer::Redistribute restricted to what the periodic brick
-    // decomposition needs: periodic wrap, then hand particles that left the brick to the
-    // +/- neighbour, direction by direction (a particle moves < 1 cell per step).
+    // amrex ParticleContainer::Redistribute restricted to what the periodic brick decomposition
+    // needs: periodic wrap, then hand the particles that left the brick to the +/- neighbour,
+    // direction by direction (a particle moves < 1 cell per step, so corners take up to three
+    // hops).  The tile is NOT re-bucketed: per step only ~1e-5 of a brick's particles cross a
+    // face, so one scan lists them, they are packed and retired in place (weight 0, dropped by the
+    // next sort) and arrivals are appended behind the sorted part -- the cell order that the
+    // LDS-tile kernels rely on survives between sorts.
     void Redistribute(BrickComm& comm) {
         const Backend* be = m_ctx->be;
-        int periodic[3] = {1, 1, 1};
-        if (m_tile.numParticles() > 0) {
+        const int periodic[3] = {1, 1, 1};
+        const int none[3] = {0, 0, 0};
+        int split[3];
+        bool any_split = false;
+        for (int d = 0; d < 3; ++d) { split[d] = comm.self_periodic(d) ? 0 : 1; any_split = any_split || split[d]; }
+        const int64_t np0 = m_tile.numParticles();
+        if (!any_split) {
+            if (np0 > 0) {
+                const wxa_particle_view p = m_tile.view();
+                check(be->enforce_periodic(&p, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic, m_ctx->stream),
+                      "enforce_periodic");
+            }
+            return;
+        }
+        // one scan of the whole tile: wrap + six leaver lists (by first split direction)
+        struct Segment { const int32_t* list; int64_t n; };
+        std::vector<Segment> seg[6];
+        const int64_t cap = np0 / 4 + 4096;
+        m_lists.reserve(sizeof(int32_t) * 6 * (size_t)cap);
+        int32_t* lists = static_cast<int32_t*>(m_lists.p);
+        int64_t cnt[6] = {0, 0, 0, 0, 0, 0};
+        if (np0 > 0) {
             const wxa_particle_view p = m_tile.view();
-            check(be->enforce_periodic(&p, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic, m_ctx->stream),
-                  "enforce_periodic");
+            check(be->wrap_and_classify(&p, 0, np0, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic,
+                                        m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), split, lists, cap, cnt, m_ws,
+                                        m_ctx->stream),
+                  "wrap_and_classify");
+            for (int c = 0; c < 6; ++c) {
+                if (cnt[c] > cap) throw std::runtime_error("Redistribute: leaver list overflow");
+                if (cnt[c] > 0) seg[c].push_back({lists + c * cap, cnt[c]});
+            }
         }
         for (int d = 0; d < 3; ++d) {
-            if (comm.self_periodic(d)) continue;
-            const int64_t np = m_tile.numParticles();
-            int64_t cnt[3] = {np, 0, 0};
-            m_spare.resize(np);
-            if (np > 0) {
-                const wxa_particle_view src = m_tile.view(), dst = m_spare.view();
-                check(be->partition_particles(&src, &dst, d, m_ctx->brick_plo[d], m_ctx->brick_phi[d], cnt, m_ws,
-                                              m_ctx->stream),
-                      "partition_particles");
-                m_tile.swap(m_spare);  // m_tile = [stay | to-minus | to-plus]
-            }
+            if (!split[d]) continue;
+            int64_t nsend[2] = {0, 0};
+            for (int s = 0; s < 2; ++s)
+                for (const Segment& g : seg[2 * d + s]) nsend[s] += g.n;
             int64_t from_plus = 0, from_minus = 0;
-            comm.exchange_counts(d, cnt[1], cnt[2], from_plus, from_minus);
-            const int64_t nstay = cnt[0], nsend = cnt[1] + cnt[2], nrecv = from_plus + from_minus;
+            comm.exchange_counts(d, nsend[0], nsend[1], from_plus, from_minus);
+            const int64_t nrecv = from_plus + from_minus;
             // staging: one message per peer = 8 SoA rows (7 reals + idcpu) of n entries
-            m_sendbuf.reserve(64 * (size_t)std::max<int64_t>(nsend, 1));
+            m_sendbuf.reserve(64 * (size_t)std::max<int64_t>(nsend[0] + nsend[1], 1));
             m_recvbuf.reserve(64 * (size_t)std::max<int64_t>(nrecv, 1));
-            char* smb = static_cast<char*>(m_sendbuf.p);
-            auto pack_msg = [&](char* dstb, int64_t off, int64_t n) {
-                for (int c = 0; c < 7; ++c)
-                    be->memcpy_async(dstb + 8 * (int64_t)c * n, m_tile.comp(c) + off, 8 * (size_t)n, m_ctx->stream);
-                be->memcpy_async(dstb + 8 * 7 * n, m_tile.idcpu() + off, 8 * (size_t)n, m_ctx->stream);
-            };
-            char* msg_minus = smb;
-            char* msg_plus = smb + 64 * cnt[1];
-            if (cnt[1] > 0) pack_msg(msg_minus, nstay, cnt[1]);
-            if (cnt[2] > 0) pack_msg(msg_plus, nstay + cnt[1], cnt[2]);
+            char* msg[2] = {static_cast<char*>(m_sendbuf.p), static_cast<char*>(m_sendbuf.p) + 64 * nsend[0]};
+            const wxa_particle_view p = m_tile.view();
+            for (int s = 0; s < 2; ++s) {
+                int64_t off = 0;
+                for (const Segment& g : seg[2 * d + s]) {
+                    check(be->pack_leavers(&p, g.list, g.n, msg[s], nsend[s], off, /*retire=*/1,
+                                           m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), m_ctx->stream),
+                          "pack_leavers");
+                    off += g.n;
+                }
+            }
+            m_nretired += nsend[0] + nsend[1];
             char* rb = static_cast<char*>(m_recvbuf.p);
             char* rmsg_plus = rb;
             char* rmsg_minus = rb + 64 * from_plus;
-            comm.exchange_raw(d, msg_minus, 64 * cnt[1], msg_plus, 64 * cnt[2], rmsg_plus, 64 * from_plus,
-                              rmsg_minus, 64 * from_minus, m_ctx->stream);
-            m_tile.resize(nstay);          // drop the leavers
-            m_tile.reserve(nstay + nrecv);
+            comm.exchange_raw(d, msg[0], 64 * nsend[0], msg[1], 64 * nsend[1], rmsg_plus, 64 * from_plus, rmsg_minus,
+                              64 * from_minus, m_ctx->stream);
+            if (nrecv == 0) continue;
+            const int64_t n0 = m_tile.numParticles();
+            m_tile.resize(n0 + nrecv);   // appends behind the sorted part (reallocation keeps the contents)
             auto unpack_msg = [&](const char* srcb, int64_t off, int64_t n) {
                 for (int c = 0; c < 7; ++c)
                     be->memcpy_async(m_tile.comp(c) + off, srcb + 8 * (int64_t)c * n, 8 * (size_t)n, m_ctx->stream);
                 be->memcpy_async(m_tile.idcpu() + off, srcb + 8 * 7 * n, 8 * (size_t)n, m_ctx->stream);
             };
-            // reserve() may have reallocated: it preserves the first numParticles() entries
-            if (from_plus > 0) unpack_msg(rmsg_plus, nstay, from_plus);
-            if (from_minus > 0) unpack_msg(rmsg_minus, nstay + from_plus, from_minus);
-            m_tile.resize(nstay + nrecv);
-            be->stream_sync(m_ctx->stream);
+            if (from_plus > 0) unpack_msg(rmsg_plus, n0, from_plus);
+            if (from_minus > 0) unpack_msg(rmsg_minus, n0 + from_plus, from_minus);
+            // arrivals may have to travel on along the remaining directions (edges and corners)
+            int later[3] = {0, 0, 0};
+            bool any_later = false;
+            for (int e = d + 1; e < 3; ++e) { later[e] = split[e]; any_later = any_later || split[e]; }
+            if (any_later) {
+                DeviceBuffer& al = m_arrival_lists[d];
+                al.reserve(sizeof(int32_t) * 6 * (size_t)nrecv);
+                int32_t* alist = static_cast<int32_t*>(al.p);
+                int64_t acnt[6];
+                const wxa_particle_view pa = m_tile.view();
+                check(be->wrap_and_classify(&pa, n0, nrecv, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), none,
+                                            m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), later, alist, nrecv, acnt,
+                                            m_ws, m_ctx->stream),
+                      "wrap_and_classify(arrivals)");
+                for (int c = 0; c < 6; ++c)
+                    if (acnt[c] > 0) seg[c].push_back({alist + c * nrecv, acnt[c]});
+            }
         }
+        be->stream_sync(m_ctx->stream);
     }
 
-    ParticleTile& tile() { return m_tile; }
-    amrex::Long TotalNumberOfParticles() const { return m_tile.numParticles(); }
+    // The tile without retired particles (compacts by sorting if Redistribute retired some since
+    // the last sort): what diagnostics and callers outside the step loop should look at.
+    ParticleTile& tile() {
+        if (m_nretired > 0) SortParticlesByBin(amrex::IntVect(1));
+        return m_tile;
+    }
+    amrex::Long TotalNumberOfParticles() const { return m_tile.numParticles() - m_nretired; }
 
 protected:
     WarpXContext* m_ctx;
     ParticleTile m_tile, m_spare;
-    DeviceBuffer m_sendbuf, m_recvbuf;
+    DeviceBuffer m_sendbuf, m_recvbuf, m_lists, m_arrival_lists[3];
+    int64_t m_nretired = 0;            // retired by Redistribute since the last sort (still in the tile)
     void* m_ws = nullptr;
 
 public:

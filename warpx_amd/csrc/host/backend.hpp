@@ -42,6 +42,15 @@ struct Backend {
     // for positions in [lo,hi) / < lo / >= hi; counts (host, 3 entries) valid on return.
     int (*partition_particles)(const wxa_particle_view*, const wxa_particle_view*, int dim, double lo,
                                double hi, int64_t* counts, void* ws, void*);
+    // Redistribute without moving the tile (include/warpx_amd.h): wrap + leaver lists, pack + retire,
+    // and the live count of the last sort
+    int (*wrap_and_classify)(const wxa_particle_view*, int64_t first, int64_t count, const double* prob_lo,
+                             const double* prob_hi, const int* periodic, const double* brick_lo,
+                             const double* brick_hi, const int* split, int32_t* lists, int64_t capacity,
+                             int64_t* counts, void* ws, void*);
+    int (*pack_leavers)(const wxa_particle_view*, const int32_t* list, int64_t n, void* msg, int64_t row_len,
+                        int64_t offset, int retire, const double* brick_lo, const double* brick_hi, void*);
+    int (*sort_live_count)(void* ws, int64_t* n, void*);
     // ---- workspace ----
     int (*workspace_create)(void** ws);
     void (*workspace_destroy)(void* ws);

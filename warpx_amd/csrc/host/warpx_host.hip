@@ -90,6 +90,17 @@ const Backend* hip_backend() {
                                 void* st) -> int { return wxa_enforce_periodic(p, lo, hi, per, st); };
         b.sort_particles_by_cell = k_sort;
         b.partition_particles = k_partition;
+        b.wrap_and_classify = [](const wxa_particle_view* p, int64_t first, int64_t count, const double* plo,
+                                 const double* phi, const int* per, const double* blo, const double* bhi,
+                                 const int* split, int32_t* lists, int64_t cap, int64_t* counts, void* ws,
+                                 void* st) -> int {
+            return wxa_wrap_and_classify(p, first, count, plo, phi, per, blo, bhi, split, lists, cap, counts,
+                                         static_cast<wxa_workspace*>(ws), st); };
+        b.pack_leavers = [](const wxa_particle_view* p, const int32_t* list, int64_t n, void* msg, int64_t row_len,
+                            int64_t offset, int retire, const double* blo, const double* bhi, void* st) -> int {
+            return wxa_pack_leavers(p, list, n, msg, row_len, offset, retire, blo, bhi, st); };
+        b.sort_live_count = [](void* ws, int64_t* n, void* st) -> int {
+            return wxa_sort_live_count(static_cast<wxa_workspace*>(ws), n, st); };
         b.workspace_create = ws_create;
         b.workspace_destroy = ws_destroy;
         b.dmalloc = hip_dmalloc;

@@ -119,6 +119,7 @@ struct SortGeom {
     double plo[3];
     double dinv[3];
     int nc[3];
+    int retired_bin;   // key of retired particles (= number of cell bins): they end up behind the live ones
 };
 
 // Tile-major cell key: tiles of WXA_TILE^3 cells, so that a tile's particles are contiguous
@@ -145,12 +146,13 @@ __device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, do
 // wave issues ONE atomic for the whole run instead of one per particle.
 __global__ void __launch_bounds__(256)
 sort_count_kernel(const double* __restrict__ x, const double* __restrict__ y,
-                  const double* __restrict__ z, long np, SortGeom s, int* __restrict__ cell,
-                  int* __restrict__ rank, int* __restrict__ hist) {
+                  const double* __restrict__ z, const uint64_t* __restrict__ id, long np, SortGeom s,
+                  int* __restrict__ cell, int* __restrict__ rank, int* __restrict__ hist) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = ip < np;
-    const int c = valid ? cell_of(s, x[ip], y[ip], z[ip]) : -1;
+    int c = valid ? cell_of(s, x[ip], y[ip], z[ip]) : -1;
+    if (valid && id && id[ip] == WXA_IDCPU_RETIRED) c = s.retired_bin;
     const int prev = __shfl_up(c, 1);
     const bool head = (lane == 0) || (c != prev);
     const unsigned long long heads = __ballot(head);
@@ -208,6 +210,67 @@ partition_scatter_kernel(PV src, PV dst, const double* __restrict__ pos, double 
 
 static inline unsigned blocks_for(long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
+static inline wxa_particle_view tail_view(const wxa_particle_view& p, int64_t first) {
+    wxa_particle_view t = p;
+    t.x += first; t.y += first; t.z += first; t.w += first; t.ux += first; t.uy += first; t.uz += first;
+    if (t.idcpu) t.idcpu += first;
+    t.np = p.np - first;
+    return t;
+}
+
+// ---- Redistribute without moving the tile (see include/warpx_amd.h) --------------------
+struct ClassifyGeom {
+    double plo[3], phi[3], blo[3], bhi[3];
+    int periodic[3], split[3];
+};
+
+__global__ void __launch_bounds__(256)
+wrap_classify_kernel(double* __restrict__ x, double* __restrict__ y, double* __restrict__ z,
+                     const uint64_t* __restrict__ id, long first, long count, ClassifyGeom cg,
+                     int* __restrict__ lists, long cap, unsigned* __restrict__ counts) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const long ip = first + t;
+    double v[3] = {x[ip], y[ip], z[ip]};
+    int code = -1;   // first split direction in which the particle is outside, before the wrap
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (cg.split[d] && code < 0) code = v[d] < cg.blo[d] ? 2 * d : (v[d] >= cg.bhi[d] ? 2 * d + 1 : -1);
+    if (code >= 0 && id[ip] == WXA_IDCPU_RETIRED) code = -1;
+    if (cg.periodic[0]) { const double w = wrap_periodic(v[0], cg.plo[0], cg.phi[0]); if (w != v[0]) x[ip] = w; }
+    if (cg.periodic[1]) { const double w = wrap_periodic(v[1], cg.plo[1], cg.phi[1]); if (w != v[1]) y[ip] = w; }
+    if (cg.periodic[2]) { const double w = wrap_periodic(v[2], cg.plo[2], cg.phi[2]); if (w != v[2]) z[ip] = w; }
+    if (code >= 0) {
+        const unsigned slot = atomicAdd(&counts[code], 1u);
+        if ((long)slot < cap) lists[code * cap + slot] = (int)ip;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pack_leavers_kernel(PV p, const int* __restrict__ list, long n, double* __restrict__ msg, long row_len,
+                    long offset, int retire, ClassifyGeom cg) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const long ip = list[t];
+    double* m = msg + offset + t;
+    m[0 * row_len] = p.x[ip]; m[1 * row_len] = p.y[ip]; m[2 * row_len] = p.z[ip]; m[3 * row_len] = p.w[ip];
+    m[4 * row_len] = p.ux[ip]; m[5 * row_len] = p.uy[ip]; m[6 * row_len] = p.uz[ip];
+    reinterpret_cast<uint64_t*>(m)[7 * row_len] = p.id[ip];
+    if (retire) {
+        // inert from here on: deposits exact zeros, stays inside the brick (and inside the reach of
+        // its tile), and is dropped by the next sort
+        double* pos[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double v = pos[d][ip];
+            const double inside = fmin(fmax(v, cg.blo[d]), nextafter(cg.bhi[d], cg.blo[d]));
+            if (inside != v) pos[d][ip] = inside;
+        }
+        p.w[ip] = 0.0; p.ux[ip] = 0.0; p.uy[ip] = 0.0; p.uz[ip] = 0.0;
+        p.id[ip] = WXA_IDCPU_RETIRED;
+    }
+}
+
 template <int PUSHER, bool MOVE>
 static wxa_status launch_gather_push(const PV& pv, const wxa_field_view E[3], const wxa_field_view B[3],
                                      const Geom& g, double q, double m, double dt, int order, int galerkin,
@@ -256,9 +319,20 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E
     wxa_status rc = check_gather_args(p, E, B, geom, order, galerkin, pusher);
     if (rc != WXA_OK) return rc;
     if (p->np == 0) return WXA_OK;
-    if (gather_tile_available(ws, p))
-        return gather_push_tiled(p, E, B, geom, q, m, dt, order, galerkin, pusher, move != 0, ws, (hipStream_t)stream);
-    const PV pv = make_pv(*p);
+    wxa_particle_view rest = *p;
+    if (gather_tile_available(ws, p)) {
+        // sorted part on the LDS tiles; particles appended since the sort (arrivals from the
+        // neighbouring bricks) take the global-memory kernel below
+        wxa_particle_view head = *p;
+        head.np = ws->sorted_np;
+        if (head.np > 0 &&
+            (rc = gather_push_tiled(&head, E, B, geom, q, m, dt, order, galerkin, pusher, move != 0, ws,
+                                    (hipStream_t)stream)) != WXA_OK)
+            return rc;
+        rest = tail_view(*p, ws->sorted_np);
+        if (rest.np == 0) return WXA_OK;
+    }
+    const PV pv = make_pv(rest);
     const Geom g = make_geom(*geom);
     hipStream_t st = (hipStream_t)stream;
     if (pusher == WXA_PUSHER_BORIS) {
@@ -295,10 +369,18 @@ wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view 
         return WXA_ERR_UNSUPPORTED;
     }
     if (p->np == 0) return WXA_OK;
+    wxa_particle_view rest = *p;
     if (ws && deposit_tile_available(ws, p)) {
-        return deposit_current_tiled(p, J, geom, q, dt, relative_time, order, algo, ws, (hipStream_t)stream);
+        wxa_particle_view head = *p;
+        head.np = ws->sorted_np;
+        wxa_status rc;
+        if (head.np > 0 && (rc = deposit_current_tiled(&head, J, geom, q, dt, relative_time, order, algo, ws,
+                                                       (hipStream_t)stream)) != WXA_OK)
+            return rc;
+        rest = tail_view(*p, ws->sorted_np);   // arrivals since the sort: global atomics
+        if (rest.np == 0) return WXA_OK;
     }
-    const PV pv = make_pv(*p);
+    const PV pv = make_pv(rest);
     const Geom g = make_geom(*geom);
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const dim3 grid(blocks_for(pv.np)), block(256);
@@ -367,11 +449,12 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     wxa_status rc;
     if ((rc = ws->cell.reserve(sizeof(int) * src->np)) != WXA_OK) return rc;
     if ((rc = ws->rank.reserve(sizeof(int) * src->np)) != WXA_OK) return rc;
-    if ((rc = ws->hist.reserve(sizeof(int) * (ncells + 1))) != WXA_OK) return rc;
-    if ((rc = ws->offsets.reserve(sizeof(int) * (ncells + 1))) != WXA_OK) return rc;
+    // bins: the cells, the retired particles, and one closing entry for the scan
+    if ((rc = ws->hist.reserve(sizeof(int) * (ncells + 2))) != WXA_OK) return rc;
+    if ((rc = ws->offsets.reserve(sizeof(int) * (ncells + 2))) != WXA_OK) return rc;
     int* cell = (int*)ws->cell.p; int* rank = (int*)ws->rank.p;
     int* hist = (int*)ws->hist.p; int* offsets = (int*)ws->offsets.p;
-    WXA_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (ncells + 1), st));
+    WXA_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (ncells + 2), st));
     SortGeom sg;
     for (int d = 0; d < 3; ++d) {
         // physical lower corner of the brick's cell box; cells are numbered from cell_lo
@@ -379,18 +462,20 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
         sg.dinv[d] = dinv[d];
         sg.nc[d] = ncell[d];
     }
+    sg.retired_bin = (int)ncells;
     (void)cell_lo;
     const PV s = make_pv(*src), d = make_pv(*dst);
-    hipLaunchKernelGGL(sort_count_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s.x, s.y, s.z, s.np, sg, cell,
-                       rank, hist);
+    hipLaunchKernelGGL(sort_count_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s.x, s.y, s.z, s.id, s.np, sg,
+                       cell, rank, hist);
     size_t tmp_bytes = 0;
-    WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hist, offsets, (int)(ncells + 1), st));
+    WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
     if ((rc = ws->scan_tmp.reserve(tmp_bytes)) != WXA_OK) return rc;
-    WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, hist, offsets, (int)(ncells + 1), st));
+    WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s, d, cell, rank, offsets);
     WXA_LAUNCH_CHECK();
     ws->sorted_valid = true;
-    ws->sorted_np = src->np;
+    ws->sorted_np = src->np;   // wxa_sort_live_count lowers it to the live count
+    ws->sorted_bins = ncells;
     ws->sorted_x = dst->x;
     for (int e = 0; e < 3; ++e) {
         ws->sort_nc[e] = ncell[e];
@@ -433,6 +518,68 @@ wxa_status wxa_partition_particles(const wxa_particle_view* src, const wxa_parti
                        nstay, nminus, ctr + 3);
     WXA_LAUNCH_CHECK();
     counts[0] = nstay; counts[1] = nminus; counts[2] = nplus;
+    return WXA_OK;
+}
+
+wxa_status wxa_wrap_and_classify(const wxa_particle_view* p, int64_t first, int64_t count, const double prob_lo[3],
+                                 const double prob_hi[3], const int periodic[3], const double brick_lo[3],
+                                 const double brick_hi[3], const int split[3], int32_t* lists, int64_t capacity,
+                                 int64_t counts[6], wxa_workspace* ws, void* stream) {
+    WXA_REQUIRE(pv_ok(p) && prob_lo && prob_hi && periodic && brick_lo && brick_hi && split && counts && ws,
+                "bad argument");
+    WXA_REQUIRE(first >= 0 && count >= 0 && first + count <= p->np, "range outside the tile");
+    WXA_REQUIRE(capacity >= 0 && (capacity == 0 || lists), "null list storage");
+    const bool any_split = split[0] || split[1] || split[2];
+    WXA_REQUIRE(!any_split || p->idcpu, "idcpu is needed to recognise retired particles");
+    for (int c = 0; c < 6; ++c) counts[c] = 0;
+    if (count == 0) return WXA_OK;
+    ClassifyGeom cg;
+    for (int d = 0; d < 3; ++d) {
+        cg.plo[d] = prob_lo[d]; cg.phi[d] = prob_hi[d]; cg.blo[d] = brick_lo[d]; cg.bhi[d] = brick_hi[d];
+        cg.periodic[d] = periodic[d] ? 1 : 0; cg.split[d] = split[d] ? 1 : 0;
+        if (periodic[d]) WXA_REQUIRE(prob_hi[d] > prob_lo[d], "empty domain");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    wxa_status rc;
+    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    unsigned* dcount = (unsigned*)ws->counters.p + 32;
+    WXA_HIP_CHECK(hipMemsetAsync(dcount, 0, 6 * sizeof(unsigned), st));
+    hipLaunchKernelGGL(wrap_classify_kernel, dim3(blocks_for(count)), dim3(256), 0, st, p->x, p->y, p->z, p->idcpu,
+                       (long)first, (long)count, cg, lists, (long)capacity, dcount);
+    WXA_LAUNCH_CHECK();
+    if (!any_split) return WXA_OK;   // nothing can be listed: no need to wait
+    unsigned h[6];
+    WXA_HIP_CHECK(hipMemcpyAsync(h, dcount, sizeof(h), hipMemcpyDeviceToHost, st));
+    WXA_HIP_CHECK(hipStreamSynchronize(st));
+    for (int c = 0; c < 6; ++c) counts[c] = h[c];
+    return WXA_OK;
+}
+
+wxa_status wxa_pack_leavers(const wxa_particle_view* p, const int32_t* list, int64_t n, void* msg, int64_t row_len,
+                            int64_t offset, int retire, const double brick_lo[3], const double brick_hi[3],
+                            void* stream) {
+    WXA_REQUIRE(pv_ok(p) && p->idcpu && brick_lo && brick_hi, "bad argument");
+    WXA_REQUIRE(n >= 0 && (n == 0 || (list && msg)), "null list or message");
+    WXA_REQUIRE(offset >= 0 && offset + n <= row_len, "list does not fit the message rows");
+    if (n == 0) return WXA_OK;
+    ClassifyGeom cg{};
+    for (int d = 0; d < 3; ++d) { cg.blo[d] = brick_lo[d]; cg.bhi[d] = brick_hi[d]; }
+    hipLaunchKernelGGL(pack_leavers_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, make_pv(*p),
+                       list, (long)n, (double*)msg, (long)row_len, (long)offset, retire, cg);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_sort_live_count(wxa_workspace* ws, int64_t* n, void* stream) {
+    WXA_REQUIRE(ws && n, "null argument");
+    WXA_REQUIRE(ws->sorted_valid, "no sort recorded in this workspace");
+    int live = 0;
+    hipStream_t st = (hipStream_t)stream;
+    WXA_HIP_CHECK(hipMemcpyAsync(&live, (const int*)ws->offsets.p + ws->sorted_bins, sizeof(int),
+                                 hipMemcpyDeviceToHost, st));
+    WXA_HIP_CHECK(hipStreamSynchronize(st));
+    ws->sorted_np = live;
+    *n = live;
     return WXA_OK;
 }
 

@@ -32,7 +32,8 @@ struct wxa_workspace {
     wxa::DevBuf cell, rank, hist, offsets, scan_tmp, tile_offsets, stragglers, counters;
     // description of the last cell sort (consumed by the tile-based deposition)
     bool sorted_valid = false;
-    int64_t sorted_np = 0;
+    int64_t sorted_np = 0;              // particles covered by the tile offsets (live ones after wxa_sort_live_count)
+    int64_t sorted_bins = 0;            // number of cell bins of that sort (the retired bin follows)
     const double* sorted_x = nullptr;   // identity of the sorted particle array
     int32_t sort_nc[3] = {0, 0, 0};
     int32_t sort_cell_lo[3] = {0, 0, 0};
