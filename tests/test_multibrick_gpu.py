@@ -1,0 +1,144 @@
+"""Multi-brick path on the HIP kernels with ONE GPU: the bricks are threads of this process that
+share the device, and a test-only in-process transport stands in for torch.distributed (same
+wxa_comm callbacks as warpx_amd.distributed.TorchBrickTransport).  Covers what the gloo tests on the
+CPU build cannot: device-side halo pack/unpack, leaver lists / retirement / arrivals as tile tails,
+the LDS-tile kernels on a tile that Redistribute has touched.  Reference: single-domain CPU oracle."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from warpx_amd import _capi, plasma
+from warpx_amd.distributed import _as_tensor, brick_coord
+from warpx_amd.sim import WarpXSim, particle_moments
+
+pytestmark = pytest.mark.gpu
+L = 40e-6
+FIELDS = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz")
+
+
+class ThreadBrickTransport:
+    """Mailbox + barrier exchange between the bricks (threads) of one process."""
+
+    def __init__(self, rank, nranks, shared):
+        self.rank, self.nranks, self.shared = rank, nranks, shared
+        self.n_exchanges = 0
+        self._exchange_cb = _capi.EXCHANGE_FN(self._exchange)
+        self._counts_cb = _capi.EXCHANGE_COUNTS_FN(self._exchange_counts)
+        self.comm = _capi.Comm()
+        self.comm.ctx = None
+        self.comm.rank, self.comm.nranks = rank, nranks
+        self.comm.exchange, self.comm.exchange_counts = self._exchange_cb, self._counts_cb
+
+    def _wait(self):
+        self.shared["barrier"].wait(timeout=120)
+
+    def _exchange(self, ctx, nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf, recv_bytes, stream):
+        try:
+            import torch
+            torch.cuda.synchronize()
+            box = self.shared["box"]
+            for i in range(nmsg):
+                n = int(send_bytes[i])
+                box[(self.rank, int(send_peer[i]), i)] = _as_tensor(send_buf[i], n, True).clone() if n else None
+            self._wait()
+            for i in range(nmsg):
+                n = int(recv_bytes[i])
+                t = box[(int(recv_peer[i]), self.rank, i)]
+                assert (t.numel() if t is not None else 0) == n
+                if n:
+                    _as_tensor(recv_buf[i], n, True).copy_(t)
+            torch.cuda.synchronize()
+            self._wait()
+            self.n_exchanges += 1
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print(f"[ThreadBrickTransport] exchange failed on rank {self.rank}: {e!r}", flush=True)
+            self.shared["barrier"].abort()
+            return -1
+
+    def _exchange_counts(self, ctx, nmsg, send_peer, send_val, recv_peer, recv_val):
+        try:
+            box = self.shared["cbox"]
+            for i in range(nmsg):
+                box[(self.rank, int(send_peer[i]), i)] = int(send_val[i])
+            self._wait()
+            for i in range(nmsg):
+                recv_val[i] = box[(int(recv_peer[i]), self.rank, i)]
+            self._wait()
+            return 0
+        except Exception as e:
+            print(f"[ThreadBrickTransport] exchange_counts failed on rank {self.rank}: {e!r}", flush=True)
+            self.shared["barrier"].abort()
+            return -1
+
+
+@pytest.mark.parametrize("nb,order,filt", [
+    ((1, 1, 2), 3, 1),   # the 2-GPU layout of bench.py
+    ((1, 2, 2), 3, 1),   # the 4-GPU layout: edges/corners travel through two exchanged directions
+    ((2, 1, 1), 2, 0),
+])
+def test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, order, filt):
+    n_cell = (32, 32, 32)
+    steps = 7
+    nranks = nb[0] * nb[1] * nb[2]
+    prob_lo, prob_hi = (-L / 2,) * 3, (L / 2,) * 3
+    # hot plasma: particles cross brick faces (and tile boundaries) within a few steps
+    parts = np.array(plasma.uniform_plasma(n_cell, prob_lo, prob_hi, (1, 2, 1), 1e25, 0.3, seed=11))
+    bn = [n_cell[d] // nb[d] for d in range(3)]
+    dx = [L / n_cell[d] for d in range(3)]
+    shared = {"box": {}, "cbox": {}, "barrier": threading.Barrier(nranks)}
+    results, errors = [None] * nranks, []
+
+    def brick(rank):
+        try:
+            coord = brick_coord(rank, nb)
+            lo = [prob_lo[d] + coord[d] * bn[d] * dx[d] for d in range(3)]
+            hi = [prob_lo[d] + (coord[d] + 1) * bn[d] * dx[d] for d in range(3)]
+            mine = np.ones(parts.shape[1], dtype=bool)
+            for d in range(3):
+                mine &= (parts[d] >= lo[d]) & (parts[d] < hi[d])
+            tr = ThreadBrickTransport(rank, nranks, shared)
+            sim = WarpXSim(product, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, sort_interval=3,
+                           nbricks=nb, coord=coord, comm=tr.comm)
+            sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
+            sim.evolve(steps)
+            p = sim.particles(sid)
+            mom = particle_moments(sim, sid)
+            results[rank] = {
+                "coord": coord, "fields": {n: sim.field_valid(n) for n in FIELDS}, "np": p.shape[1],
+                "inside": all(np.all((p[d] >= lo[d]) & (p[d] < hi[d])) for d in range(3)),
+                "live": bool(np.all(p[3] > 0.0)), "ekin": mom["ekin"], "abs_p": mom["abs_momentum"],
+                "exchanges": tr.n_exchanges}
+            sim.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            shared["barrier"].abort()
+
+    threads = [threading.Thread(target=brick, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+
+    ref = WarpXSim(oracle, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt)
+    rid = ref.add_species(-plasma.Q_E, plasma.M_E, list(parts))
+    ref.evolve(steps)
+    rmom = particle_moments(ref, rid)
+    assert sum(r["np"] for r in results) == parts.shape[1]      # nobody lost, duplicated or left retired
+    assert all(r["inside"] and r["live"] for r in results)
+    assert results[0]["exchanges"] > 0
+    for n in FIELDS:
+        full = ref.field_valid(n)
+        scale = max(np.max(np.abs(full)), 1e-300)
+        for r in results:
+            c, a = r["coord"], r["fields"][n]
+            sl = tuple(slice(c[d] * bn[d], c[d] * bn[d] + a.shape[d]) for d in range(3))
+            assert float(np.max(np.abs(a - full[sl])) / scale) < 1e-10, n
+    ek = sum(r["ekin"] for r in results)
+    assert abs(ek - rmom["ekin"]) / rmom["ekin"] < 1e-11
+    ap = np.sum([r["abs_p"] for r in results], axis=0)
+    assert np.max(np.abs(ap - np.array(rmom["abs_momentum"])) / np.array(rmom["abs_momentum"])) < 1e-11
