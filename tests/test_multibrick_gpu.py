@@ -32,7 +32,14 @@ class ThreadBrickTransport:
         self.comm.exchange, self.comm.exchange_counts = self._exchange_cb, self._counts_cb
 
     def _wait(self):
-        self.shared["barrier"].wait(timeout=120)
+        # One brick at a time runs native code (the lock is handed over only at the exchange points):
+        # the bricks of a real run are separate processes, concurrency inside one process is not
+        # what this test is about.
+        self.shared["turn"].release()
+        try:
+            self.shared["barrier"].wait(timeout=120)
+        finally:
+            self.shared["turn"].acquire()
 
     def _exchange(self, ctx, nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf, recv_bytes, stream):
         try:
@@ -88,10 +95,11 @@ def test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, order, filt)
     parts = np.array(plasma.uniform_plasma(n_cell, prob_lo, prob_hi, (1, 2, 1), 1e25, 0.3, seed=11))
     bn = [n_cell[d] // nb[d] for d in range(3)]
     dx = [L / n_cell[d] for d in range(3)]
-    shared = {"box": {}, "cbox": {}, "barrier": threading.Barrier(nranks)}
+    shared = {"box": {}, "cbox": {}, "barrier": threading.Barrier(nranks), "turn": threading.Lock()}
     results, errors = [None] * nranks, []
 
     def brick(rank):
+        shared["turn"].acquire()
         try:
             coord = brick_coord(rank, nb)
             lo = [prob_lo[d] + coord[d] * bn[d] * dx[d] for d in range(3)]
@@ -115,6 +123,8 @@ def test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, order, filt)
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
             shared["barrier"].abort()
+        finally:
+            shared["turn"].release()
 
     threads = [threading.Thread(target=brick, args=(r,)) for r in range(nranks)]
     for t in threads:
