@@ -60,6 +60,23 @@ def device_uniform_plasma(n_cell, prob_lo, prob_hi, ppc, density, u_th, seed, bo
     return out
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of each phase's kernel from the committed rocprofv3 PMC passes
+    (profiles/round1/r1c_pmc_traffic.json), for the workload they were collected on; {} otherwise.
+    bench.py cannot collect PMC counters itself: they need their own rocprofv3 runs."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "r1c_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return {}
+    w = rec["workload"]
+    same = (w["ncell"] == args.ncell and w["ppc"] == args.ppc and w["order"] == args.order and
+            w["deposition"] == args.deposition and w["pusher"] == args.pusher and w["filter"] == (not args.no_filter))
+    if not same:
+        return {}
+    return {k: (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1e9 for k, v in rec["KiB_per_dispatch"].items()}
+
+
 def cpu_baseline():
     """The CPU oracle (our restatement of the reference's algorithms; the reference itself
     cannot be built here: AMReX is not on disk) timed on a bounded sample of the same
@@ -225,6 +242,7 @@ def main():
         cps = total_cells * args.steps / elapsed
         kernels = {}
         dominant = None
+        traffic = pmc_traffic(args) if world == 1 else {}
         micro = {} if args.no_phase_pass else stencil_microbench(sim)
         for name, (ms, cnt) in phases.items():
             if cnt == 0 or ms <= 0:
@@ -245,6 +263,8 @@ def main():
                 entry["algorithmic_GB"] = algo_bytes / 1e9
                 entry["achieved_GBs"] = algo_bytes / 1e9 / (avg_ms * 1e-3)
                 entry["hbm_frac"] = entry["achieved_GBs"] / HBM_PEAK_GBS
+            if name in traffic:
+                entry["pmc_traffic_GB"] = traffic[name]
             kernels[name] = entry
         # share of the step per phase (PushP of the (de)synchronisation is folded in GatherAndPush)
         if kernels:
@@ -254,7 +274,9 @@ def main():
         if dominant:
             k = kernels[dominant]
             roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": k["hbm_frac"], "traffic": None,
+                        "unit": "GB/s", "frac": k["hbm_frac"], "traffic": k.get("pmc_traffic_GB"),
+                        "traffic_unit": "GB per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, "
+                                        "profiles/round1/r1c_pmc_traffic.json)",
                         "note": "particle kernels are VALU/LDS-atomic bound, not HBM bound (SURVEY.md 8(d)); "
                                 "the HBM-bound stencils are listed under kernels"}
         out = {
