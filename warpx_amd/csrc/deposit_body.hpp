@@ -52,32 +52,6 @@ __device__ __forceinline__ void esirkepov_shapes(const ParticleState& p, const G
     s.bi = g.lo0 + i_new - 1; s.bj = g.lo1 + j_new - 1; s.bk = g.lo2 + k_new - 1;
 }
 
-// Slot-0 grid index of a particle's Esirkepov frame without the weights (same arithmetic as
-// esirkepov_shapes, so the two always agree).  at_position: relative_time + dt/2 == 0, the usual
-// call (WarpXParticleContainer::DepositCurrent with relative_time = -dt/2): the new position is the
-// stored one and the velocity (a sqrt and a division) is not needed for the frame.
-template <int O>
-__device__ __forceinline__ void esirkepov_frame(const ParticleState& p, const Geom& g, double dt,
-                                                double relative_time, bool at_position, int& bi, int& bj, int& bk) {
-    double x_new, y_new, z_new;
-    if (at_position) {
-        x_new = (p.x - g.xmin) * g.dxi;
-        y_new = (p.y - g.ymin) * g.dyi;
-        z_new = (p.z - g.zmin) * g.dzi;
-    } else {
-        constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
-        const double gaminv =
-            1.0 / sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
-        x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
-        y_new = (p.y - g.ymin + (relative_time + 0.5 * dt) * p.uy * gaminv) * g.dyi;
-        z_new = (p.z - g.zmin + (relative_time + 0.5 * dt) * p.uz * gaminv) * g.dzi;
-    }
-    double tmp[O + 1];
-    bi = g.lo0 + shape_factor<O>(tmp, x_new) - 1;
-    bj = g.lo1 + shape_factor<O>(tmp, y_new) - 1;
-    bk = g.lo2 + shape_factor<O>(tmp, z_new) - 1;
-}
-
 // Sink concept: void add(int comp, int i, int j, int k, double v) with i,j,k relative to slot 0.
 //
 // Loop structure: all loops run over the full static slot range so that every register
@@ -164,14 +138,17 @@ __device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s
     esirkepov_accumulate_comp<O, 2>(s, g, dt, sink);
 }
 
-// ---- two particles of the same frame merged before the atomics --------------------------
-// Cell-sorted neighbours usually share the slot frame (same i_new,j_new,k_new).  Their row
-// values are summed in registers and deposited with ONE atomic per slot: the LDS atomic pipe
-// is the binding resource of this kernel (rocprof: ~12 LDS cycles per ds_add_f64 wave
-// instruction), so this halves its load.  Each particle keeps its own trimmed range: an end slot
-// receives only the particles that crossed a cell in that direction, so the set of deposits per
-// particle is the reference's.
+// ---- fast path: particles that stay in their cell during the step ---------------------------
+// For a particle with i_old == i_new in all three directions the old and the new weights sit on
+// the same O+1 slots (1..O+1 of the frame), the trimmed ranges are the static dil = diu = 1, and
+// every loop bound is a compile-time constant: (O+1)^2 rows of O deposits per component, no
+// masks, no ballots, no zero tests.  In a thermal plasma ~98 % of the particles qualify
+// (u_th = 0.01 c moves a particle 0.006 cell per step), so the tile kernel routes them here and
+// keeps the general code above for the particles with a cell crossing.
 //
+// Two particles of the same frame are merged before the atomics: cell-sorted neighbours share
+// the slot frame (same i_new, j_new, k_new), their row values are summed in registers and
+// deposited with ONE atomic per slot, which halves the load on the LDS-atomic pipe.
 // Arithmetic, per component (here Jx; rows (j,k), running along i), per particle p:
 //   D_p[l]   = sum_{l'<=l} wq invdtd.x (sx_old[l'] - sx_new[l'])           (running sum, once per component)
 //   T_p(j,k) = sy_new[j] (1/3 sz_new[k] + 1/6 sz_old[k]) + sy_old[j] (1/3 sz_old[k] + 1/6 sz_new[k])
@@ -179,137 +156,6 @@ __device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s
 // which is the reference's sdxi (CurrentDeposition.H:794-799) with the sums re-associated: the
 // transverse weight is factored through the z-dependent pair (computed once per k), and the running
 // sum is taken over D instead of over D*T.  Differences are at round-off (tests: 1e-12 of max|J|).
-template <int O, int COMP, class Sink>
-__device__ __forceinline__ void esirkepov_row2(Sink& sink, const double (&D1)[O + 2], const double (&D2)[O + 2],
-                                               double T1, double T2, int dl1, int du1, int dl2, int du2,
-                                               bool any_lo, bool any_hi, int a, int b) {
-    auto put = [&](int l, double v) {
-        if constexpr (COMP == 0) sink.add(0, l, a, b, v);
-        else if constexpr (COMP == 1) sink.add(1, a, l, b, v);
-        else sink.add(2, a, b, l, v);
-    };
-    if (any_lo) {
-        const double v = (dl1 == 0 ? D1[0] * T1 : 0.0) + (dl2 == 0 ? D2[0] * T2 : 0.0);
-        if (dl1 == 0 || dl2 == 0) put(0, v);
-    }
-#pragma unroll
-    for (int l = 1; l <= O; l++) put(l, D1[l] * T1 + D2[l] * T2);
-    if (any_hi) {
-        const double v = (du1 == 0 ? D1[O + 1] * T1 : 0.0) + (du2 == 0 ? D2[O + 1] * T2 : 0.0);
-        if (du1 == 0 || du2 == 0) put(O + 1, v);
-    }
-}
-
-template <int O>
-__device__ __forceinline__ void esirkepov_D(double (&D)[O + 2], const double* so, const double* sn, double c) {
-    double run = 0.0;
-#pragma unroll
-    for (int a = 0; a < O + 2; ++a) {
-        run += c * (so[a] - sn[a]);
-        D[a] = run;
-    }
-}
-
-// s1 and s2 must have the same (bi,bj,bk), unless null2: then particle 2 is ignored (its terms
-// are exact zeros) and the call deposits particle 1 alone.
-// Slots where no lane of the wave has any weight (slot 0 / O+2 unless some particle crossed a
-// cell) are skipped with wave-uniform branches before the transverse weight is even computed.
-template <int O, class Sink>
-__device__ __forceinline__ void esirkepov_accumulate_pair(const EsirkepovShapes<O>& s1, const EsirkepovShapes<O>& s2,
-                                                          bool null2, const Geom& g, double dt, Sink& sink) {
-    const double invdtd[3] = {(1.0 / dt) * g.dyi * g.dzi, (1.0 / dt) * g.dxi * g.dzi, (1.0 / dt) * g.dxi * g.dyi};
-    const double wq2 = null2 ? 0.0 : s2.wq;
-    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
-    bool ux[O + 3], uy[O + 3], uz[O + 3];   // wave-uniform: some lane has weight on this slot
-#pragma unroll
-    for (int a = 0; a < O + 3; ++a) {
-        ux[a] = __builtin_amdgcn_ballot_w64(s1.sx_new[a] != 0.0 || s1.sx_old[a] != 0.0 ||
-                                            (!null2 && (s2.sx_new[a] != 0.0 || s2.sx_old[a] != 0.0))) != 0;
-        uy[a] = __builtin_amdgcn_ballot_w64(s1.sy_new[a] != 0.0 || s1.sy_old[a] != 0.0 ||
-                                            (!null2 && (s2.sy_new[a] != 0.0 || s2.sy_old[a] != 0.0))) != 0;
-        uz[a] = __builtin_amdgcn_ballot_w64(s1.sz_new[a] != 0.0 || s1.sz_old[a] != 0.0 ||
-                                            (!null2 && (s2.sz_new[a] != 0.0 || s2.sz_old[a] != 0.0))) != 0;
-    }
-    double D1[O + 2], D2[O + 2];
-    {   // Jx: rows (j,k), running along i
-        esirkepov_D<O>(D1, s1.sx_old, s1.sx_new, s1.wq * invdtd[0]);
-        esirkepov_D<O>(D2, s2.sx_old, s2.sx_new, wq2 * invdtd[0]);
-        const bool lo = __builtin_amdgcn_ballot_w64(s1.dil == 0 || (!null2 && s2.dil == 0)) != 0;
-        const bool hi = __builtin_amdgcn_ballot_w64(s1.diu == 0 || (!null2 && s2.diu == 0)) != 0;
-#pragma unroll
-        for (int k = 0; k <= O + 2; k++) {
-            if (!uz[k]) continue;
-            const double p1 = one_third * s1.sz_new[k] + one_sixth * s1.sz_old[k];
-            const double q1 = one_third * s1.sz_old[k] + one_sixth * s1.sz_new[k];
-            const double p2 = one_third * s2.sz_new[k] + one_sixth * s2.sz_old[k];
-            const double q2 = one_third * s2.sz_old[k] + one_sixth * s2.sz_new[k];
-#pragma unroll
-            for (int j = 0; j <= O + 2; j++) {
-                if (!uy[j]) continue;
-                const double T1 = s1.sy_new[j] * p1 + s1.sy_old[j] * q1;
-                const double T2 = null2 ? 0.0 : s2.sy_new[j] * p2 + s2.sy_old[j] * q2;
-                if (T1 != 0.0 || T2 != 0.0)
-                    esirkepov_row2<O, 0>(sink, D1, D2, T1, T2, s1.dil, s1.diu, null2 ? 1 : s2.dil,
-                                         null2 ? 1 : s2.diu, lo, hi, j, k);
-            }
-        }
-    }
-    {   // Jy: rows (i,k), running along j
-        esirkepov_D<O>(D1, s1.sy_old, s1.sy_new, s1.wq * invdtd[1]);
-        esirkepov_D<O>(D2, s2.sy_old, s2.sy_new, wq2 * invdtd[1]);
-        const bool lo = __builtin_amdgcn_ballot_w64(s1.djl == 0 || (!null2 && s2.djl == 0)) != 0;
-        const bool hi = __builtin_amdgcn_ballot_w64(s1.dju == 0 || (!null2 && s2.dju == 0)) != 0;
-#pragma unroll
-        for (int k = 0; k <= O + 2; k++) {
-            if (!uz[k]) continue;
-            const double p1 = one_third * s1.sz_new[k] + one_sixth * s1.sz_old[k];
-            const double q1 = one_third * s1.sz_old[k] + one_sixth * s1.sz_new[k];
-            const double p2 = one_third * s2.sz_new[k] + one_sixth * s2.sz_old[k];
-            const double q2 = one_third * s2.sz_old[k] + one_sixth * s2.sz_new[k];
-#pragma unroll
-            for (int i = 0; i <= O + 2; i++) {
-                if (!ux[i]) continue;
-                const double T1 = s1.sx_new[i] * p1 + s1.sx_old[i] * q1;
-                const double T2 = null2 ? 0.0 : s2.sx_new[i] * p2 + s2.sx_old[i] * q2;
-                if (T1 != 0.0 || T2 != 0.0)
-                    esirkepov_row2<O, 1>(sink, D1, D2, T1, T2, s1.djl, s1.dju, null2 ? 1 : s2.djl,
-                                         null2 ? 1 : s2.dju, lo, hi, i, k);
-            }
-        }
-    }
-    {   // Jz: rows (i,j), running along k
-        esirkepov_D<O>(D1, s1.sz_old, s1.sz_new, s1.wq * invdtd[2]);
-        esirkepov_D<O>(D2, s2.sz_old, s2.sz_new, wq2 * invdtd[2]);
-        const bool lo = __builtin_amdgcn_ballot_w64(s1.dkl == 0 || (!null2 && s2.dkl == 0)) != 0;
-        const bool hi = __builtin_amdgcn_ballot_w64(s1.dku == 0 || (!null2 && s2.dku == 0)) != 0;
-#pragma unroll
-        for (int j = 0; j <= O + 2; j++) {
-            if (!uy[j]) continue;
-            const double p1 = one_third * s1.sy_new[j] + one_sixth * s1.sy_old[j];
-            const double q1 = one_third * s1.sy_old[j] + one_sixth * s1.sy_new[j];
-            const double p2 = one_third * s2.sy_new[j] + one_sixth * s2.sy_old[j];
-            const double q2 = one_third * s2.sy_old[j] + one_sixth * s2.sy_new[j];
-#pragma unroll
-            for (int i = 0; i <= O + 2; i++) {
-                if (!ux[i]) continue;
-                const double T1 = s1.sx_new[i] * p1 + s1.sx_old[i] * q1;
-                const double T2 = null2 ? 0.0 : s2.sx_new[i] * p2 + s2.sx_old[i] * q2;
-                if (T1 != 0.0 || T2 != 0.0)
-                    esirkepov_row2<O, 2>(sink, D1, D2, T1, T2, s1.dkl, s1.dku, null2 ? 1 : s2.dkl,
-                                         null2 ? 1 : s2.dku, lo, hi, i, j);
-            }
-        }
-    }
-}
-
-// ---- fast path: particles that stay in their cell during the step ---------------------------
-// For a particle with i_old == i_new in all three directions the old and the new weights sit on
-// the same O+1 slots (1..O+1 of the frame), the trimmed ranges are the static dil = diu = 1, and
-// every loop bound is a compile-time constant: (O+1)^2 rows of O deposits per component, no
-// masks, no ballots, no zero tests.  In a thermal plasma ~97 % of the pairs qualify
-// (u_th = 0.01 c moves a particle 0.006 cell per step), so the kernel routes them here and keeps
-// the general code above for the pairs with a cell crossing.  Same formulas as
-// esirkepov_accumulate_pair, of which this is the restriction to sh = 0.
 template <int O>
 struct EsirkepovNC {
     double n[3][O + 1], o[3][O + 1];   // new / old weights per direction on slots 1..O+1

@@ -5,15 +5,20 @@
 // one component per pass.  Here one workgroup owns one tile of 8x8x8 cells of the
 // tile-major cell sort (wxa_sort_particles_by_cell), keeps all three J components of the
 // tile plus its stencil halo (and one point of drift margin) in LDS as fp64
-// (3 x 15^3 x 8 B = 81 KB), accumulates with ds_add_f64, and writes each non-zero LDS point
-// back to HBM with one global fp64 atomic.  Particles are staged through LDS in coalesced
-// batches of 1024 (56 KB) and handed to the lanes as neighbouring PAIRS with a strided walk:
-// the two particles of a pair usually share the cell (merged before the atomics, halving the
-// load on the binding LDS-atomic pipe), while the 64 lanes of a wave work on different cells
-// (no same-address serialisation).  Particles whose stencil leaves the LDS tile (drift of more
-// than a cell since the last sort, particles outside the domain before the periodic wrap) are
-// queued and deposited with global atomics by a second kernel, so correctness never depends
-// on the sort being fresh.
+// (3 x 15 x 232 x 8 B = 83.5 KB), accumulates with ds_add_f64, and writes each non-zero LDS
+// point back to HBM with one global fp64 atomic.
+//
+// Per trip the workgroup stages up to 1024 particles through LDS (coalesced, 56 KB), keys them by
+// stencil frame, and builds work items: two neighbours of one cell that do not cross a cell form
+// a PAIR (merged in registers before the atomics), a particle that crosses a cell is a slow
+// single.  At most 512 fast items are taken per trip -- one per lane, so the pass over them is a
+// single pass for every wave -- and each goes to the lane (quarter-wave, LDS bank of its frame
+// base): the 16 lanes that a ds_add_f64 serves together then always hit 16 different banks.
+// Slow singles are deferred per tile and run once through the general Esirkepov body, 64 to a
+// wave, the three components on different waves.  Particles whose stencil leaves the LDS tile
+// (drift of more than a cell since the last sort, particles outside the domain before the
+// periodic wrap) are queued and deposited with global atomics by a second kernel, so correctness
+// never depends on the sort being fresh.  DESIGN.md section 3 has the measurements behind each step.
 #include "deposit_body.hpp"
 #include "workspace.hpp"
 
@@ -112,7 +117,6 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     __shared__ double stage[7][DT_BATCH];
     __shared__ int keys[DT_BATCH + 1];
     __shared__ int items[DT_BATCH];
-    __shared__ unsigned char crossing[DT_BATCH + 1];
     __shared__ int nitems;
     __shared__ int segcnt[2][DT_BATCH / 64];   // fast / slow items per 64-particle segment
     __shared__ int cut_a, cut_nslow;           // set by the thread holding the first fast item beyond the cap
@@ -158,11 +162,14 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
         __syncthreads();   // previous round's readers are done (and the zero fill on round 0)
         // ---- stage the batch (coalesced, all loads in flight together) and key every particle
         //      by its stencil frame ----
+        int key_r[ROUNDS];     // stencil frame of this thread's particles (< 0: none / straggler)
+        bool cross_r[ROUNDS];  // the particle crosses a cell during the step
         {
             double r[ROUNDS][7];
 #pragma unroll
             for (int rr = 0; rr < ROUNDS; ++rr) {
                 const int a = tid + rr * DT_THREADS;
+                key_r[rr] = -1; cross_r[rr] = false;
                 if (a < nb) {
 #pragma unroll
                     for (int c = 0; c < 7; ++c) r[rr][c] = parr[c][b0 + a];
@@ -185,7 +192,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                         // outside the LDS tile: straggler (a key no neighbour shares); queued below,
                         // once it is known that this batch consumes the particle
                         key = in ? (li | (lj << 8) | (lk << 16)) : -2 - a;
-                        crossing[a] = cross ? 1 : 0;
+                        cross_r[rr] = cross;
                     } else {
                         DirectShapes<O> sh;
                         direct_shapes<O>(p, g, q, relative_time, sh);
@@ -197,13 +204,16 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                         if (key < 0) sq.push(b0 + a);
                     }
                     keys[a] = key;
+                    key_r[rr] = key;
                 }
             }
         }
-        if (tid == 0) { nitems = 0; keys[nb] = -1; cut_a = nb; cut_nslow = -1; novf = 0; }
+        if (tid == 0) { nitems = 0; cut_a = nb; cut_nslow = -1; novf = 0; }
         if (tid < NBANK) bcnt[tid] = 0;
-        __syncthreads();
-        DPROF(0);   // zero fill (first trip) + stage + key
+        if constexpr (!ESIRKEPOV) {
+            __syncthreads();
+            DPROF(0);
+        }
         if constexpr (ESIRKEPOV) {
             // Nobody appends to the deferred list before the flush decision below.
             const int nd0 = ndeferred;
@@ -214,20 +224,22 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             // LDS addresses).  At most FAST_CAP fast items are taken: the batch ends where the
             // next one would start (a_cut) and the rest is staged again by the next trip.
             bool is_item[ROUNDS], is_slow[ROUNDS], is_pair[ROUNDS];
-            int key_r[ROUNDS];
             int rank_f[ROUNDS], rank_s[ROUNDS];
             const unsigned long long le = ~0ull >> (63 - lane), lt = le >> 1;
 #pragma unroll
             for (int rr = 0; rr < ROUNDS; ++rr) {
-                const int a = tid + rr * DT_THREADS;
-                const int key = a < nb ? keys[a] : -1;
-                const bool cr = crossing[a] != 0;
+                // the neighbours' keys come from the neighbouring lanes (runs are cut at the wave's
+                // 64 particles anyway), so this needs no barrier after the staging
+                const int key = key_r[rr];
+                const bool cr = cross_r[rr];
+                const int kprev = __shfl_up(key, 1), knext = __shfl_down(key, 1);
+                const bool cprev = __shfl_up((int)cr, 1) != 0, cnext = __shfl_down((int)cr, 1) != 0;
                 // a crossing particle is a run of its own (slow single); pairs form among the others
-                const bool head = lane == 0 || keys[a - 1] != key || cr || crossing[a - 1] != 0;
+                const bool head = lane == 0 || kprev != key || cr || cprev;
                 const unsigned long long H = __ballot(head);
                 const int run_start = 63 - __clzll((long long)(H & le));   // lane 0 is always a head
                 const bool it = key >= 0 && ((lane - run_start) & 1) == 0;
-                const bool pr = it && !cr && lane < 63 && keys[a + 1] == key && crossing[a + 1] == 0;
+                const bool pr = it && !cr && lane < 63 && knext == key && !cnext;
                 const bool sl = it && cr;
                 const unsigned long long F = __ballot(it && !sl), S = __ballot(sl);
                 rank_f[rr] = __popcll(F & lt);
@@ -236,9 +248,10 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                     segcnt[0][wave + rr * WAVES] = __popcll(F);
                     segcnt[1][wave + rr * WAVES] = __popcll(S);
                 }
-                is_item[rr] = it; is_slow[rr] = sl; is_pair[rr] = pr; key_r[rr] = key;
+                is_item[rr] = it; is_slow[rr] = sl; is_pair[rr] = pr;
             }
             __syncthreads();
+            DPROF(0);   // zero fill (first trip) + stage + key + item flags
             int tot_f = 0, tot_s = 0;
             {
                 int pre_f[ROUNDS], pre_s[ROUNDS];
@@ -280,20 +293,6 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                 }
             }
             __syncthreads();
-            {   // Free slots (row >= bucket size) go to the items of overfull buckets, the rest stay
-                // empty.  Free slots are numbered column by column, so that consecutive overflow
-                // items (same bucket, often the same cell) land in different quarter-waves: each
-                // one then conflicts with a single lane.
-                const int col = tid & (NBANK - 1), row = tid / NBANK;
-                if (row >= bcnt[col]) {
-                    int m = row - bcnt[col];
-#pragma unroll
-                    for (int c2 = 0; c2 < NBANK; ++c2)
-                        if (c2 < col) m += ROWS - min(bcnt[c2], ROWS);
-                    slots[tid] = m < novf ? items[m] : -1;
-                }
-            }
-            __syncthreads();
             DPROF(1);   // work-item lists
             const int a_cut = cut_a;                              // particles consumed by this trip
             const int nfast = min(tot_f, FAST_CAP);
@@ -303,7 +302,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 #pragma unroll
             for (int rr = 0; rr < ROUNDS; ++rr) {
                 const int a = tid + rr * DT_THREADS;
-                if (a < a_cut && keys[a] <= -2) sq.push(b0 + a);
+                if (a < a_cut && key_r[rr] <= -2) sq.push(b0 + a);
             }
             // Pull the next batch towards the L2 while this one is deposited: one 4-byte load per
             // 128-byte line, straight into an LDS scratch word (no register, no wait until the
@@ -317,7 +316,23 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                         (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
             }
             DCOUNT(15, novf);
-            const int e = slots[tid];
+            // This lane's fast item: slot (row, column) = (quarter-wave, bank) of the table if its
+            // bucket reaches this row, else one of the items of overfull buckets.  Free slots are
+            // numbered column by column, so that consecutive overflow items (same bucket, often the
+            // same cell) land in different quarter-waves: each one then conflicts with a single lane.
+            int e;
+            {
+                const int col = tid & (NBANK - 1), row = tid / NBANK;
+                if (row < bcnt[col]) {
+                    e = slots[tid];
+                } else {
+                    int m = row - bcnt[col];
+#pragma unroll
+                    for (int c2 = 0; c2 < NBANK; ++c2)
+                        if (c2 < col) m += ROWS - min(bcnt[c2], ROWS);
+                    e = m < novf ? items[m] : -1;
+                }
+            }
             if (e >= 0) {   // pairs (and singles) that stay in their cell
                 const int a = e & (PAIRED - 1);
                 const bool paired = (e & PAIRED) != 0;
