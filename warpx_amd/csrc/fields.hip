@@ -368,6 +368,25 @@ shift_copy_kernel(DevF f, BoxN box, int s0, int s1, int s2) {
     }
 }
 
+// Both guard slabs of one direction in one launch: box_lo takes src(i + shift), box_hi takes
+// src(i - shift).  The boxes have the same extents; sources are valid points, destinations guard
+// points, so the two halves are independent.
+__global__ void __launch_bounds__(256)
+shift_copy_sides_kernel(DevF f, BoxN box_lo, BoxN box_hi, int s0, int s1, int s2) {
+    const long half = (long)box_lo.n[0] * box_lo.n[1] * box_lo.n[2];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < 2 * half; t += (long)gridDim.x * blockDim.x) {
+        const bool hi = t >= half;
+        const long u = hi ? t - half : t;
+        const BoxN& box = hi ? box_hi : box_lo;
+        const int sg = hi ? -1 : 1;
+        const int a = (int)(u % box.n[0]);
+        const int b = (int)((u / box.n[0]) % box.n[1]);
+        const int c = (int)(u / ((long)box.n[0] * box.n[1]));
+        const int i = box.lo[0] + a, j = box.lo[1] + b, k = box.lo[2] + c;
+        f.p[f.off(i, j, k)] = f.p[f.off(i + sg * s0, j + sg * s1, k + sg * s2)];
+    }
+}
+
 // SumBoundary along direction d: every residue class mod nc is summed over its members in
 // [s0,s1) and the total written to all members in the allocation.  Only the classes with more
 // than one member inside the allocation can change (the n[d]-nc = stag+2*ng lowest points and
@@ -557,17 +576,16 @@ wxa_status wxa_fill_boundary_periodic(const wxa_field_view* f, const int ng[3], 
         const int nc = f->n[d] - 2 * f->ng[d] - f->stag[d];
         WXA_REQUIRE(ng[d] <= nc, "guard depth exceeds the period");
         const int v0 = f->lo[d] + f->ng[d], v1 = f->lo[d] + f->n[d] - f->ng[d];
-        for (int side = 0; side < 2; ++side) {
-            BoxN b;
-            for (int e = 0; e < 3; ++e) { b.lo[e] = lo[e]; b.n[e] = hi[e] - lo[e]; }
-            b.lo[d] = side == 0 ? v0 - ng[d] : v1;
-            b.n[d] = ng[d];
-            int s[3] = {0, 0, 0};
-            s[d] = side == 0 ? nc : -nc;
-            const long total = (long)b.n[0] * b.n[1] * b.n[2];
-            hipLaunchKernelGGL(shift_copy_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                               df, b, s[0], s[1], s[2]);
-        }
+        BoxN blo, bhi;
+        for (int e = 0; e < 3; ++e) { blo.lo[e] = bhi.lo[e] = lo[e]; blo.n[e] = bhi.n[e] = hi[e] - lo[e]; }
+        blo.lo[d] = v0 - ng[d]; bhi.lo[d] = v1;
+        blo.n[d] = bhi.n[d] = ng[d];
+        int sh[3] = {0, 0, 0};
+        sh[d] = nc;
+        const long total = 2 * (long)blo.n[0] * blo.n[1] * blo.n[2];
+        if (total > 0)
+            hipLaunchKernelGGL(shift_copy_sides_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, df,
+                               blo, bhi, sh[0], sh[1], sh[2]);
         lo[d] = v0 - ng[d];
         hi[d] = v1 + ng[d];
     }
