@@ -217,7 +217,8 @@ def load_product() -> CLib:
     """The HIP library. Fails loudly when it has not been built (no CPU fallback)."""
     global _product
     if _product is None:
-        _product = CLib(PRODUCT_LIB, "wxa_", _PRODUCT_SIGS)
+        # WXA_PRODUCT_LIB: another build of the same library (kernel experiments, scripts/)
+        _product = CLib(os.environ.get("WXA_PRODUCT_LIB", PRODUCT_LIB), "wxa_", _PRODUCT_SIGS)
     return _product
 
 

@@ -16,9 +16,21 @@
 
 namespace wxa {
 
+// Tile shape, measured on MI355X at 256^3 (EvolveB / EvolveE, ms back to back, same box):
+//   TJ x KC = 4 x 16: 0.247 / 0.323    4 x 4: 0.233 / 0.305    2 x 4: 0.228 / 0.311
+//   2 x 2: 0.233 / 0.308    1 x 4: 0.231 / 0.312    8 x 4: 0.247 / 0.310    4 x 32: 0.295 / 0.378
+// Short marches win: the k-halo re-read of a 4-plane tile is served by the XCD's L2 (the tile order
+// keeps k-neighbours on one XCD), and 4x more workgroups keep more loads in flight.
+// (-DWXA_TJ / -DWXA_KC override them for such sweeps.)
 constexpr int TI = 64;   // lanes along i (one wavefront per row)
-constexpr int TJ = 4;    // rows per workgroup
-constexpr int KC = 16;   // planes marched per workgroup
+#ifndef WXA_TJ
+#define WXA_TJ 2
+#endif
+constexpr int TJ = WXA_TJ;    // rows per workgroup
+#ifndef WXA_KC
+#define WXA_KC 4
+#endif
+constexpr int KC = WXA_KC;   // planes marched per workgroup
 
 struct TileGrid {
     int nti, ntj, ntk;
