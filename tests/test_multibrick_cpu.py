@@ -27,6 +27,7 @@ def _run(nb, order, filt, tmp_path, port):
     ((1, 1, 2), 3, 1, 29611),   # the 2-GPU layout of bench.py
     ((2, 1, 1), 1, 0, 29612),   # split along the contiguous direction
     ((1, 2, 2), 2, 1, 29613),   # the 4-GPU layout: edges/corners through two exchanged directions
+    ((2, 2, 2), 3, 1, 29614),   # the 8-GPU layout: corners travel through all three directions
 ])
 def test_bricks_match_single_domain(nb, order, filt, port, tmp_path):
     rep = _run(nb, order, filt, tmp_path, port)

@@ -85,6 +85,7 @@ class ThreadBrickTransport:
     ((1, 1, 2), 3, 1),   # the 2-GPU layout of bench.py
     ((1, 2, 2), 3, 1),   # the 4-GPU layout: edges/corners travel through two exchanged directions
     ((2, 1, 1), 2, 0),
+    ((2, 2, 2), 3, 1),   # the 8-GPU layout: corners travel through all three directions
 ])
 def test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, order, filt):
     n_cell = (32, 32, 32)
