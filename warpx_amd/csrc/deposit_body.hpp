@@ -28,7 +28,7 @@ __device__ __forceinline__ void esirkepov_shapes(const ParticleState& p, const G
                                                  double relative_time, EsirkepovShapes<O>& s) {
     constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
     const double gaminv =
-        1.0 / sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
+        inv_sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
     s.wq = q * p.w;
     const double x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
     const double x_old = x_new - dt * g.dxi * p.ux * gaminv;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void esirkepov_nc_shapes(const ParticleState& p, cons
                                                     double relative_time, EsirkepovNC<O>& s) {
     constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
     const double gaminv =
-        1.0 / sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
+        inv_sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
     s.wq = q * p.w;
     const double x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
     const double x_old = x_new - dt * g.dxi * p.ux * gaminv;
@@ -196,7 +196,7 @@ __device__ __forceinline__ bool esirkepov_frame_cross(const ParticleState& p, co
                                                       double relative_time, int& bi, int& bj, int& bk) {
     constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
     const double gaminv =
-        1.0 / sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
+        inv_sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
     const double x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
     const double x_old = x_new - dt * g.dxi * p.ux * gaminv;
     const double y_new = (p.y - g.ymin + (relative_time + 0.5 * dt) * p.uy * gaminv) * g.dyi;
@@ -271,7 +271,7 @@ __device__ __forceinline__ void direct_shapes(const ParticleState& p, const Geom
     const double invvol = g.dxi * g.dyi * g.dzi;
     const double clightsq = 1.0 / PhysConst::c / PhysConst::c;
     const double gaminv =
-        1.0 / sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
+        inv_sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
     const double vx = p.ux * gaminv, vy = p.uy * gaminv, vz = p.uz * gaminv;
     const double wq = q * p.w;
     s.wqx = wq * invvol * vx; s.wqy = wq * invvol * vy; s.wqz = wq * invvol * vz;

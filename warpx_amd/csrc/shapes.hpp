@@ -120,6 +120,12 @@ __device__ __forceinline__ int shifted_shape_factor(double* __restrict__ s, cons
     return ret;
 }
 
+// 1/sqrt(x) as one reciprocal-square-root evaluation (v_rsq_f64 + refinement, 12 instructions,
+// within 1 ulp) instead of a correctly rounded square root followed by a correctly rounded
+// division (34 instructions).  The Lorentz factor is taken once per particle in the pusher, the
+// position update and the deposition: ~10 % of the gather's and ~5 % of the deposition's arithmetic.
+__device__ __forceinline__ double inv_sqrt(const double x) { return rsqrt(x); }
+
 // Source/Particles/Pusher/UpdateMomentumBoris.H:15-53
 __device__ __forceinline__ void push_boris(double& ux, double& uy, double& uz, const double Ex,
                                            const double Ey, const double Ez, const double Bx,
@@ -128,7 +134,7 @@ __device__ __forceinline__ void push_boris(double& ux, double& uy, double& uz, c
     const double econst = 0.5 * q * dt / m;
     ux += econst * Ex; uy += econst * Ey; uz += econst * Ez;
     constexpr double inv_c2 = 1. / (PhysConst::c * PhysConst::c);
-    const double inv_gamma = 1. / sqrt(1. + (ux * ux + uy * uy + uz * uz) * inv_c2);
+    const double inv_gamma = inv_sqrt(1. + (ux * ux + uy * uy + uz * uz) * inv_c2);
     const double tx = econst * inv_gamma * Bx;
     const double ty = econst * inv_gamma * By;
     const double tz = econst * inv_gamma * Bz;
@@ -152,7 +158,7 @@ __device__ __forceinline__ void push_vay(double& ux, double& uy, double& uz, con
     const double bconst = 0.5 * q * dt / m;
     constexpr double invclight = 1. / PhysConst::c;
     constexpr double invclightsq = 1. / (PhysConst::c * PhysConst::c);
-    const double inv_gamma = 1. / sqrt(1. + (ux * ux + uy * uy + uz * uz) * invclightsq);
+    const double inv_gamma = inv_sqrt(1. + (ux * ux + uy * uy + uz * uz) * invclightsq);
     const double taux = bconst * Bx, tauy = bconst * By, tauz = bconst * Bz;
     const double tausq = taux * taux + tauy * tauy + tauz * tauz;
     const double uxpr = ux + econst * Ex + (uy * tauz - uz * tauy) * inv_gamma;
@@ -175,7 +181,7 @@ __device__ __forceinline__ void push_vay(double& ux, double& uy, double& uz, con
 __device__ __forceinline__ void update_position(double& x, double& y, double& z, const double ux,
                                                 const double uy, const double uz, const double dt) {
     constexpr double inv_c2 = 1. / (PhysConst::c * PhysConst::c);
-    const double inv_gamma = 1. / sqrt(1. + (ux * ux + uy * uy + uz * uz) * inv_c2);
+    const double inv_gamma = inv_sqrt(1. + (ux * ux + uy * uy + uz * uz) * inv_c2);
     x += ux * inv_gamma * dt;
     y += uy * inv_gamma * dt;
     z += uz * inv_gamma * dt;
