@@ -1,0 +1,95 @@
+"""The CPU restatement of the Redistribute primitives (oracle/pic_oracle.cpp: orc_wrap_and_classify,
+orc_pack_leavers, retired particles in orc_sort_particles_by_cell) against plain numpy: these are the
+checkers of tests/test_kernels_gpu.py::test_redistribute_ops and the backend of the gloo multi-brick
+tests, so they are pinned on their own here."""
+import ctypes as C
+
+import numpy as np
+
+from tests import helpers as H
+from warpx_amd.containers import ParticleArrays
+
+RETIRED = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _particles(n, seed, blo, bhi, dx):
+    rng = np.random.default_rng(seed)
+    pos = [blo[d] - dx[d] + (bhi[d] - blo[d] + 2 * dx[d]) * rng.random(n) for d in range(3)]
+    parts = pos + [1e9 * (0.5 + rng.random(n))] + [1e6 * rng.standard_normal(n) for _ in range(3)]
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    ids[rng.random(n) < 0.03] = RETIRED
+    return parts, ids
+
+
+def test_wrap_and_classify_against_numpy(oracle):
+    ncell = (24, 20, 16)
+    dx = H.LX / np.asarray(ncell)
+    plo, phi = np.full(3, -H.LX / 2), np.full(3, H.LX / 2)
+    blo, bhi = plo.copy(), np.array([0.0, phi[1], 0.0])
+    n = 20000
+    parts, ids = _particles(n, 5, blo, bhi, dx)
+    pc = ParticleArrays.from_numpy(parts, "cpu", ids.copy())
+    split = (1, 0, 1)
+    lists = np.full(6 * n, -1, dtype=np.int32)
+    cnt = (C.c_int64 * 6)()
+    oracle.wrap_and_classify(C.byref(pc.view), 0, n, H.d3(plo), H.d3(phi), H.i3((1, 1, 1)), H.d3(blo), H.d3(bhi),
+                             H.i3(split), lists.ctypes.data, n, cnt, None, None)
+    x = np.array(parts[:3])
+    code = np.full(n, -1)
+    for d in (2, 1, 0):   # first split direction wins: assign in reverse order
+        if split[d]:
+            code = np.where(x[d] >= bhi[d], 2 * d + 1, code)
+            code = np.where(x[d] < blo[d], 2 * d, code)
+    code[ids == RETIRED] = -1
+    for c in range(6):
+        want = np.nonzero(code == c)[0]
+        assert cnt[c] == want.size
+        assert np.array_equal(lists[c * n:c * n + cnt[c]], want)        # the CPU version keeps index order
+    L = phi - plo
+    wrapped = np.array([np.where(x[d] >= phi[d], x[d] - L[d], np.where(x[d] < plo[d], x[d] + L[d], x[d]))
+                        for d in range(3)])
+    got = pc.to_numpy()
+    assert np.array_equal(got[:3], wrapped)
+    assert np.all(got[:3] >= plo[:, None]) and np.all(got[:3] < phi[:, None])
+    assert np.array_equal(got[3:], np.array(parts[3:]))
+
+
+def test_pack_retire_and_sort(oracle):
+    ncell = (12, 20, 8)
+    dx = H.LX / np.asarray((24, 20, 16))
+    plo = np.full(3, -H.LX / 2)
+    blo, bhi = plo.copy(), np.array([0.0, H.LX / 2, 0.0])
+    n = 5000
+    parts, ids = _particles(n, 6, blo, bhi, dx)
+    pc = ParticleArrays.from_numpy(parts, "cpu", ids.copy())
+    before = pc.to_numpy()
+    lst = np.ascontiguousarray(np.nonzero((before[0] >= bhi[0]) & (ids != RETIRED))[0].astype(np.int32))
+    m = lst.size
+    assert m > 50
+    row_len, off = m + 3, 2
+    msg = np.zeros(8 * row_len)
+    oracle.pack_leavers(C.byref(pc.view), lst.ctypes.data, m, msg.ctypes.data, row_len, off, 1, H.d3(blo), H.d3(bhi),
+                        None)
+    rows = msg.reshape(8, row_len)
+    assert np.array_equal(rows[:7, off:off + m], before[:, lst])
+    assert np.array_equal(rows[7, off:off + m].view(np.uint64), ids[lst])
+    assert np.all(rows[:, :off] == 0) and np.all(rows[:, off + m:] == 0)
+    after = pc.to_numpy()
+    assert np.all(after[3:, lst] == 0.0) and np.all(pc.idcpu[lst] == RETIRED)
+    for d in range(3):
+        assert np.all(after[d, lst] >= blo[d]) and np.all(after[d, lst] < bhi[d])
+    keep = np.setdiff1d(np.arange(n), lst)
+    assert np.array_equal(after[:, keep], before[:, keep])
+    # sort: live particles first (grouped by cell), the retired ones behind them
+    out = ParticleArrays(n, "cpu", with_id=True)
+    live = np.zeros(1, dtype=np.int64)
+    oracle.sort_particles_by_cell(C.byref(pc.view), C.byref(out.view), H.d3(blo), H.d3(1.0 / dx), H.i3((0, 0, 0)),
+                                  (C.c_int32 * 3)(*ncell), live.ctypes.data, None)
+    nlive = int((pc.idcpu != RETIRED).sum())
+    assert live[0] == nlive
+    assert np.all(out.idcpu[:nlive] != RETIRED) and np.all(out.idcpu[nlive:] == RETIRED)
+    assert np.array_equal(np.sort(out.idcpu[:nlive]), np.sort(pc.idcpu[pc.idcpu != RETIRED]))
+    s = out.to_numpy()[:, :nlive]
+    cell = [np.clip(np.floor((s[d] - blo[d]) / dx[d]).astype(np.int64), 0, ncell[d] - 1) for d in range(3)]
+    key = cell[0] + ncell[0] * (cell[1] + ncell[1] * cell[2])
+    assert np.all(np.diff(key) >= 0)

@@ -158,6 +158,7 @@ _ORACLE_SIGS = {
     "sim_compute_rho": (C.c_int, [C.c_void_p]),
     "num_threads": (C.c_int, []),
     # CPU counterparts of the Redistribute entry points (host-layer tests, parity tests)
+    "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "wrap_and_classify": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,
                                     C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "pack_leavers": (C.c_int, [_PPV, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _D3, _D3,
