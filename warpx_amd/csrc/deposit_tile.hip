@@ -90,7 +90,7 @@ constexpr int DT_THREADS = 512;   // 8 waves: one workgroup per CU (LDS-limited)
 constexpr int DT_BATCH = 1024;    // particles staged in LDS per round (7 x 1024 x 8 B = 56 KB)
 constexpr int NBANK = 16;         // LDS banks (8-byte wide) seen by one step of a ds_add_f64
 constexpr int ROWS = 512 / NBANK; // quarter-waves of a workgroup = rows of the lane-assignment table
-constexpr int DT_DEFER = 1024;    // capacity of the per-tile list of deferred (cell-crossing) pairs
+constexpr int DT_DEFER = 1024;    // capacity of the per-tile list of deferred (cell-crossing) particles
 
 // Particles whose stencil leaves the LDS tile (stale sort, particles outside the domain before
 // the periodic wrap) are queued and deposited by deposit_stragglers_kernel with global atomics:
@@ -123,7 +123,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     __shared__ int pf_scratch[64];             // landing zone of the L2 prefetch loads
     __shared__ int slots[DT_THREADS];          // fast item of every lane (row = quarter-wave, column = LDS bank)
     __shared__ int bcnt[NBANK], novf;
-    __shared__ unsigned deferred[DT_DEFER];   // pairs with a cell crossing, kept for one dense pass
+    __shared__ unsigned deferred[DT_DEFER];   // particles with a cell crossing (global indices), kept for one dense pass
     __shared__ int ndeferred;
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long tile = xcd_tile_id(blockIdx.x, ntiles);
