@@ -239,6 +239,29 @@ wxa_status wxa_pack_leavers(const wxa_particle_view* p, const int32_t* list, int
 wxa_status wxa_sort_live_count(wxa_workspace* ws, int64_t* n, void* stream);
 
 /* ------------------------------------------------------------------ */
+/* Field boundary conditions (first "next" row of SURVEY.md 8(f))       */
+/* ------------------------------------------------------------------ */
+
+#define WXA_BOUNDARY_PERIODIC 0   /* boundary.field_lo/hi = periodic */
+#define WXA_BOUNDARY_PEC      1   /* boundary.field_lo/hi = pec      */
+
+/* Replace PEC::ApplyPECtoEfield / PEC::ApplyPECtoBfield
+ * (Source/BoundaryConditions/WarpX_PEC.cpp:457-538 / :540-626; point rules SetEfieldOnPEC :117-196,
+ * SetBfieldOnPEC :256-331), called at the end of WarpX::EvolveE / EvolveB
+ * (Source/FieldSolver/WarpXPushFieldsEM.cpp:990 / :926).  On every point of the valid box of each
+ * component grown by ng (= ng_FieldGather): E components tangential to a PEC face are zeroed on the
+ * face and odd-mirrored into the guard cells behind it, normal components even-mirrored; for B the
+ * normal component is zeroed / odd-mirrored and the tangential ones even-mirrored.
+ * dom_lo/dom_hi: cell-centred index box of the whole domain (both inclusive, amrex Box::smallEnd /
+ * bigEnd); pec_lo[d] / pec_hi[d] != 0 marks the PEC faces.  The views are this brick's arrays. */
+wxa_status wxa_apply_pec_e(const wxa_field_view E[3], const int32_t dom_lo[3],
+                           const int32_t dom_hi[3], const int32_t pec_lo[3],
+                           const int32_t pec_hi[3], const int32_t ng[3], void* stream);
+wxa_status wxa_apply_pec_b(const wxa_field_view B[3], const int32_t dom_lo[3],
+                           const int32_t dom_hi[3], const int32_t pec_lo[3],
+                           const int32_t pec_hi[3], const int32_t ng[3], void* stream);
+
+/* ------------------------------------------------------------------ */
 /* Current filter and guard-cell exchange                              */
 /* ------------------------------------------------------------------ */
 
@@ -305,6 +328,9 @@ typedef struct wxa_sim_config {
     int32_t sort_interval;       /* warpx.sort_intervals; <=0 = never           */
     int32_t nbricks[3];          /* domain decomposition, one brick per GPU     */
     int32_t coord[3];            /* this brick's coordinates                    */
+    int32_t field_boundary_lo[3];/* boundary.field_lo: WXA_BOUNDARY_* (0 = periodic, the default) */
+    int32_t field_boundary_hi[3];/* boundary.field_hi; PEC only along unsplit directions, fields only:
+                                    particles must not reach a PEC face yet (no J/rho reflection)  */
 } wxa_sim_config;
 
 /* Neighbour exchange supplied by the host program (torch.distributed over

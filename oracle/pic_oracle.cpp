@@ -344,6 +344,78 @@ int orc_fill_boundary_periodic(const wxa_field_view* f, const int ng[3], const i
     return 0;
 }
 
+}  // extern "C"
+
+// ---- PEC field boundary (Source/BoundaryConditions/WarpX_PEC.cpp) -------------------------
+namespace {
+// get_cell_count_to_boundary (:41-49): how many grid points `ijk` lies beyond the face; the high
+// face sits between cells dom_hi and dom_hi+1, i.e. on node dom_hi+1 of a nodal direction.
+inline int cells_beyond_face(const int32_t dom_lo[3], const int32_t dom_hi[3], const int ijk[3], const int nodal[3],
+                             int idim, int iside) {
+    return iside == 0 ? dom_lo[idim] - ijk[idim] : ijk[idim] - (dom_hi[idim] + nodal[idim]);
+}
+
+// SetEfieldOnPEC (:117-196) for IS_E, SetBfieldOnPEC (:256-331) otherwise: the two differ only in
+// which components are "flagged" at a face -- the tangential ones for E, the normal one for B.
+// A flagged component is zero on the face (if it lives on it) and odd across it; the others are even.
+template <bool IS_E>
+inline void set_field_on_pec(int icomp, const int32_t dom_lo[3], const int32_t dom_hi[3], const int ijk[3],
+                             const Arr& f, const int nodal[3], const int32_t pec_lo[3], const int32_t pec_hi[3]) {
+    int mirror[3] = {ijk[0], ijk[1], ijk[2]};
+    bool on_face = false, guard = false;
+    double sign = 1.0;
+    for (int idim = 0; idim < 3; ++idim)
+        for (int iside = 0; iside < 2; ++iside) {
+            if (!(iside == 0 ? pec_lo[idim] : pec_hi[idim])) continue;
+            const bool flagged = IS_E ? (icomp != idim) : (icomp == idim);
+            const int ig = cells_beyond_face(dom_lo, dom_hi, ijk, nodal, idim, iside);
+            if (ig == 0) {
+                if (flagged && nodal[idim] == 1) on_face = true;
+            } else if (ig > 0) {
+                mirror[idim] = iside == 0 ? dom_lo[idim] + ig - (1 - nodal[idim]) : dom_hi[idim] + 1 - ig;
+                guard = true;
+                if (flagged) sign *= -1.0;
+            }
+        }
+    if (on_face) f(ijk[0], ijk[1], ijk[2]) = 0.0;
+    else if (guard) f(ijk[0], ijk[1], ijk[2]) = sign * f(mirror[0], mirror[1], mirror[2]);
+}
+
+// ApplyPECtoEfield (:457-538) / ApplyPECtoBfield (:540-626): every point of tilebox(ixType, ng)
+template <bool IS_E>
+int apply_pec(const wxa_field_view F[3], const int32_t dom_lo[3], const int32_t dom_hi[3], const int32_t pec_lo[3],
+              const int32_t pec_hi[3], const int32_t ng[3]) {
+    for (int c = 0; c < 3; ++c) {
+        const Arr a(F[c]);
+        const int nodal[3] = {F[c].stag[0], F[c].stag[1], F[c].stag[2]};
+        int lo[3], hi[3];
+        for (int d = 0; d < 3; ++d) {
+            if (ng[d] > F[c].ng[d]) return -1;
+            lo[d] = vlo(F[c], d) - ng[d];
+            hi[d] = vhi(F[c], d) + ng[d];
+        }
+        for (int k = lo[2]; k < hi[2]; ++k)
+            for (int j = lo[1]; j < hi[1]; ++j)
+                for (int i = lo[0]; i < hi[0]; ++i) {
+                    const int ijk[3] = {i, j, k};
+                    set_field_on_pec<IS_E>(c, dom_lo, dom_hi, ijk, a, nodal, pec_lo, pec_hi);
+                }
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int orc_apply_pec_e(const wxa_field_view E[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
+                    const int32_t pec_lo[3], const int32_t pec_hi[3], const int32_t ng[3], void*) {
+    return apply_pec<true>(E, dom_lo, dom_hi, pec_lo, pec_hi, ng);
+}
+int orc_apply_pec_b(const wxa_field_view B[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
+                    const int32_t pec_lo[3], const int32_t pec_hi[3], const int32_t ng[3], void*) {
+    return apply_pec<false>(B, dom_lo, dom_hi, pec_lo, pec_hi, ng);
+}
+
 // FillBoundaryAndSync's extra step (Communication.cpp:99-101,109-110): shared nodal
 // points take their owner's value; on a single periodic brick the high-edge nodal
 // point duplicates the low-edge one.
@@ -660,6 +732,10 @@ struct orc_sim {
 
     wxa_field_view Ev[3], Bv[3], Jv[3];
     int periodic[3] = {1, 1, 1};
+    // boundary.field_lo/hi = pec (fields only)
+    bool any_pec = false;
+    int32_t pec_lo[3] = {0, 0, 0}, pec_hi[3] = {0, 0, 0}, dom_lo[3] = {0, 0, 0}, dom_hi[3] = {0, 0, 0};
+    int32_t ng_gather32[3] = {0, 0, 0};
 
     wxa_grid_geom geom_for(const int ng[3]) const {
         // WarpX::LowerCorner(box.grow(ng)) = prob_lo + box.lo * dx (Source/WarpX.cpp:2851-2875)
@@ -745,11 +821,22 @@ void one_step_nosub(orc_sim* s) {
             orc_sum_boundary_periodic(&s->Jv[c], src_ng, s->periodic, nullptr);
         }
     }
-    { Tic t(s, 3); orc_evolve_b(s->Ev, s->Bv, 0.5 * dt, s->dinv, nullptr); }   // :421
+    // WarpX::EvolveB / EvolveE end with ApplyBfieldBoundary / ApplyEfieldBoundary
+    // (Source/FieldSolver/WarpXPushFieldsEM.cpp:926,990 -> WarpXFieldBoundaries.cpp:51-135)
+    auto evolve_b = [&](double a_dt) {
+        Tic t(s, 3);
+        orc_evolve_b(s->Ev, s->Bv, a_dt, s->dinv, nullptr);
+        if (s->any_pec) orc_apply_pec_b(s->Bv, s->dom_lo, s->dom_hi, s->pec_lo, s->pec_hi, s->ng_gather32, nullptr);
+    };
+    evolve_b(0.5 * dt);                                                         // :421
     fill_boundary_EB(s, s->Bv, s->ng_solver, true);                             // :422
-    { Tic t(s, 4); orc_evolve_e(s->Ev, s->Bv, s->Jv, dt, s->dinv, nullptr); }   // :426
+    {   // :426
+        Tic t(s, 4);
+        orc_evolve_e(s->Ev, s->Bv, s->Jv, dt, s->dinv, nullptr);
+        if (s->any_pec) orc_apply_pec_e(s->Ev, s->dom_lo, s->dom_hi, s->pec_lo, s->pec_hi, s->ng_gather32, nullptr);
+    }
     fill_boundary_EB(s, s->Ev, s->ng_solver, true);                             // :433
-    { Tic t(s, 3); orc_evolve_b(s->Ev, s->Bv, 0.5 * dt, s->dinv, nullptr); }   // :437
+    evolve_b(0.5 * dt);                                                         // :437
     // (:441-449 FillBoundaryB(ng_alloc_EB) only when safe_guard_cells or PML; skipped)
 }
 
@@ -784,6 +871,22 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
         s->ng_rho[d] = ngt + 1 + (int)std::ceil(PhysConst::c * s->dt / dx[d]);
         s->ng_gather[d] = (nox + 1) / 2;
         s->ng_solver[d] = 1;
+        // GuardCellManager.cpp:338: ng_FieldGather = max(ng_FieldGather, ng_FieldSolver)
+        s->ng_gather[d] = std::max(s->ng_gather[d], s->ng_solver[d]);
+        s->ng_gather32[d] = s->ng_gather[d];
+        s->dom_lo[d] = 0;
+        s->dom_hi[d] = cfg->n_cell[d] - 1;
+        const int blo = cfg->field_boundary_lo[d], bhi = cfg->field_boundary_hi[d];
+        if ((blo != WXA_BOUNDARY_PERIODIC && blo != WXA_BOUNDARY_PEC) ||
+            (bhi != WXA_BOUNDARY_PERIODIC && bhi != WXA_BOUNDARY_PEC) ||
+            ((blo == WXA_BOUNDARY_PERIODIC) != (bhi == WXA_BOUNDARY_PERIODIC))) {
+            delete s;
+            return -2;   // a direction is periodic on both sides or on neither
+        }
+        s->pec_lo[d] = blo == WXA_BOUNDARY_PEC;
+        s->pec_hi[d] = bhi == WXA_BOUNDARY_PEC;
+        s->periodic[d] = blo == WXA_BOUNDARY_PERIODIC;
+        s->any_pec = s->any_pec || s->pec_lo[d] || s->pec_hi[d];
     }
     // Yee staggering (Source/WarpX.cpp:2117-2125)
     const int Es[3][3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};

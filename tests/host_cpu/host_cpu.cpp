@@ -34,6 +34,10 @@ int orc_wrap_and_classify(const wxa_particle_view*, int64_t, int64_t, const doub
 int orc_pack_leavers(const wxa_particle_view*, const int32_t*, int64_t, void*, int64_t, int64_t, int, const double*,
                      const double*, void*);
 int orc_sort_live_count(void*, int64_t*, void*);
+int orc_apply_pec_e(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                    void*);
+int orc_apply_pec_b(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                    void*);
 }
 
 namespace {
@@ -72,6 +76,8 @@ const Backend* cpu_backend() {
         b.wrap_and_classify = orc_wrap_and_classify;
         b.pack_leavers = orc_pack_leavers;
         b.sort_live_count = orc_sort_live_count;
+        b.apply_pec_e = orc_apply_pec_e;
+        b.apply_pec_b = orc_apply_pec_b;
         b.workspace_create = ws_create; b.workspace_destroy = ws_destroy;
         b.dmalloc = h_malloc; b.dfree = h_free;
         b.memset_async = h_memset; b.memcpy_async = h_memcpy;

@@ -484,3 +484,23 @@ def test_tile_kernels_with_appended_tail(oracle, product, order):
     for r in range(7):
         assert H.max_rel_err(a[r], b[r]) < 1e-13
     product.workspace_destroy(ws)
+
+
+@pytest.mark.parametrize("pec", [((0, 0, 1), (0, 0, 1)), ((1, 0, 1), (1, 0, 1)), ((0, 1, 0), (0, 0, 0))])
+@pytest.mark.parametrize("ng", [0, 1, 2])
+def test_apply_pec_fields(oracle, product, pec, ng):
+    """wxa_apply_pec_e / wxa_apply_pec_b (PEC::ApplyPECtoEfield / ApplyPECtoBfield) on random fields, one, two
+    and one-sided PEC directions, guard depths 0..2: bit-identical to the CPU restatement, guards included."""
+    ncell = (12, 10, 14)
+    ngalloc = 2
+    dom_lo, dom_hi = (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*[n - 1 for n in ncell])
+    plo, phi = (C.c_int32 * 3)(*pec[0]), (C.c_int32 * 3)(*pec[1])
+    g3 = (C.c_int32 * 3)(ng, ng, ng)
+    for names, fn in ((("Ex", "Ey", "Ez"), "apply_pec_e"), (("Bx", "By", "Bz"), "apply_pec_b")):
+        F = H.random_fields(names, ncell, ngalloc, 7)
+        Fd = H.clone_fields(F, DEV, True)
+        getattr(oracle, fn)(field_triplet(F), dom_lo, dom_hi, plo, phi, g3, None)
+        getattr(product, fn)(field_triplet(Fd), dom_lo, dom_hi, plo, phi, g3, None)
+        _sync(product)
+        for a, b in zip(Fd, F):
+            assert np.array_equal(a.to_numpy(), b.to_numpy())

@@ -71,7 +71,6 @@ def test_uniform_plasma_parity(oracle, product, order, depos, pusher, filt):
 def test_langmuir_golden_on_gpu(oracle, product):
     """The reference's own golden checksums (64^3 Langmuir, 40 steps) reproduced by the HIP path."""
     import ctypes as C
-    from warpx_amd.containers import FieldArray
     n_cell = (64, 64, 64)
     el, lo, hi = plasma.langmuir_3d(n_cell, sign=+1.0)
     po, _, _ = plasma.langmuir_3d(n_cell, sign=-1.0)
@@ -200,3 +199,26 @@ def test_langmuir_256_two_species_full_size(product):
     resid = np.max(np.abs(div - r / plasma.EP0)) / np.max(np.abs(r / plasma.EP0))
     print("gauss residual", resid)
     assert resid < 1e-7
+
+
+def test_pec_field_golden_on_gpu(oracle, product):
+    """Examples/Tests/pec/inputs_test_3d_pec_field on the HIP path: the reference's golden checksums at the
+    reference's tolerance, its analysis (standing wave of twice the amplitude, Ey = 0 on the walls), and the
+    CPU stepper bit for bit (stencils and boundary kernels keep the reference's operation order)."""
+    import ctypes as C
+
+    from tests import pec_case
+    sim = pec_case.make_sim(product)
+    sim.evolve(pec_case.MAX_STEP)
+    gold = json.load(open(os.path.join(HERE, "golden", "pec_field_3d_checksums.json")))
+    ref = pec_case.make_sim(oracle)
+    ref.evolve(pec_case.MAX_STEP)
+    for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz"):
+        assert np.array_equal(sim.field(name), ref.field(name)), name
+    for name, want in gold["checksums"]["lev=0"].items():
+        got = oracle.cell_centered_abs_sum(C.byref(ref.field_view(name)))   # == the GPU field, checked above
+        assert abs(got - want) / want < gold["rtol"]
+    ey = sim.field_valid("Ey")
+    e_th = 2.0 * pec_case.EY_IN
+    assert abs(ey.max() - e_th) / e_th < 0.01 and abs(ey.min() + e_th) / e_th < 0.01
+    assert np.all(ey[:, :, 0] == 0.0) and np.all(ey[:, :, -1] == 0.0)

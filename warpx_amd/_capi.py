@@ -57,6 +57,8 @@ class SimConfig(C.Structure):
         ("sort_interval", C.c_int32),
         ("nbricks", C.c_int32 * 3),
         ("coord", C.c_int32 * 3),
+        ("field_boundary_lo", C.c_int32 * 3),
+        ("field_boundary_hi", C.c_int32 * 3),
     ]
 
 
@@ -83,6 +85,7 @@ class Comm(C.Structure):
 
 PUSHER_BORIS, PUSHER_VAY = 0, 1
 DEPOSIT_ESIRKEPOV, DEPOSIT_DIRECT = 0, 1
+BOUNDARY_PERIODIC, BOUNDARY_PEC = 0, 1
 
 _FV3 = FieldView * 3
 _D3 = C.c_double * 3
@@ -104,6 +107,8 @@ _KERNEL_SIGS = {
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "deposit_charge": (C.c_int, [_PPV, _PFV, _PGG, C.c_double, C.c_int, C.c_void_p]),
     "enforce_periodic": (C.c_int, [_PPV, _D3, _D3, _I3, C.c_void_p]),
+    "apply_pec_e": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
+    "apply_pec_b": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "filter_bilinear": (C.c_int, [_PFV, _PFV, C.c_void_p]),
     "fill_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
     "sum_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),

@@ -380,6 +380,54 @@ shift_copy_kernel(DevF f, BoxN box, int s0, int s1, int s2) {
     }
 }
 
+// ---- PEC field boundary (Source/BoundaryConditions/WarpX_PEC.cpp) --------------------------
+struct PecGeom {
+    int dom_lo[3], dom_hi[3];   // cell-centred domain box, both inclusive
+    int pec_lo[3], pec_hi[3];   // which faces are PEC
+    int nodal[3];               // staggering of the component
+};
+
+// SetEfieldOnPEC (:117-196) for IS_E, SetBfieldOnPEC (:256-331) otherwise, on the points of `box`.
+// The two rules differ only in which components are "flagged" at a face: the tangential ones for E,
+// the normal one for B.  A flagged component is zero on the face (if it lives on it) and odd across
+// it, the others are even.  The mirror point is strictly inside the domain along every PEC
+// direction, so applying the rule slab by slab (one launch per PEC face) is idempotent on the
+// points that two slabs share.
+template <bool IS_E>
+__global__ void __launch_bounds__(256)
+apply_pec_kernel(DevF f, int icomp, BoxN box, PecGeom pg) {
+    const long total = (long)box.n[0] * box.n[1] * box.n[2];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        int ijk[3];
+        ijk[0] = box.lo[0] + (int)(t % box.n[0]);
+        ijk[1] = box.lo[1] + (int)((t / box.n[0]) % box.n[1]);
+        ijk[2] = box.lo[2] + (int)(t / ((long)box.n[0] * box.n[1]));
+        int mirror[3] = {ijk[0], ijk[1], ijk[2]};
+        bool on_face = false, guard = false;
+        double sign = 1.0;
+#pragma unroll
+        for (int idim = 0; idim < 3; ++idim) {
+#pragma unroll
+            for (int iside = 0; iside < 2; ++iside) {
+                if (!(iside == 0 ? pg.pec_lo[idim] : pg.pec_hi[idim])) continue;
+                const bool flagged = IS_E ? (icomp != idim) : (icomp == idim);
+                // get_cell_count_to_boundary (:41-49)
+                const int ig = iside == 0 ? pg.dom_lo[idim] - ijk[idim]
+                                          : ijk[idim] - (pg.dom_hi[idim] + pg.nodal[idim]);
+                if (ig == 0) {
+                    if (flagged && pg.nodal[idim] == 1) on_face = true;
+                } else if (ig > 0) {
+                    mirror[idim] = iside == 0 ? pg.dom_lo[idim] + ig - (1 - pg.nodal[idim]) : pg.dom_hi[idim] + 1 - ig;
+                    guard = true;
+                    if (flagged) sign = -sign;
+                }
+            }
+        }
+        if (on_face) f(ijk[0], ijk[1], ijk[2]) = 0.0;
+        else if (guard) f(ijk[0], ijk[1], ijk[2]) = sign * f(mirror[0], mirror[1], mirror[2]);
+    }
+}
+
 // Both guard slabs of one direction in one launch: box_lo takes src(i + shift), box_hi takes
 // src(i - shift).  The boxes have the same extents; sources are valid points, destinations guard
 // points, so the two halves are independent.
@@ -674,6 +722,64 @@ wxa_status wxa_unpack_box(const wxa_field_view* f, const int32_t blo[3], const i
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
+
+}  // extern "C"
+
+// ApplyPECtoEfield (:457-538) / ApplyPECtoBfield (:540-626): the rule above on tilebox(ixType, ng);
+// only the slabs at and behind the PEC faces can change, so only they are launched.
+template <bool IS_E>
+static wxa_status apply_pec(const wxa_field_view F[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
+                            const int32_t pec_lo[3], const int32_t pec_hi[3], const int32_t ng[3], void* stream) {
+    WXA_REQUIRE(F && dom_lo && dom_hi && pec_lo && pec_hi && ng, "null argument");
+    for (int c = 0; c < 3; ++c) {
+        WXA_REQUIRE(view_ok(F[c]), "bad field view");
+        for (int d = 0; d < 3; ++d) {
+            WXA_REQUIRE(ng[d] >= 0 && ng[d] <= F[c].ng[d], "ng exceeds allocated guards");
+            WXA_REQUIRE(dom_hi[d] >= dom_lo[d], "empty domain");
+        }
+    }
+    for (int c = 0; c < 3; ++c) {
+        const wxa_field_view& f = F[c];
+        PecGeom pg;
+        int glo[3], ghi[3];   // tilebox(ixType, ng) of this brick, hi exclusive
+        for (int d = 0; d < 3; ++d) {
+            pg.dom_lo[d] = dom_lo[d]; pg.dom_hi[d] = dom_hi[d];
+            pg.pec_lo[d] = pec_lo[d] ? 1 : 0; pg.pec_hi[d] = pec_hi[d] ? 1 : 0;
+            pg.nodal[d] = f.stag[d];
+            glo[d] = f.lo[d] + f.ng[d] - ng[d];
+            ghi[d] = f.lo[d] + f.n[d] - f.ng[d] + ng[d];
+        }
+        const DevF df = make_devf(f);
+        for (int d = 0; d < 3; ++d)
+            for (int side = 0; side < 2; ++side) {
+                if (!(side == 0 ? pg.pec_lo[d] : pg.pec_hi[d])) continue;
+                BoxN b;
+                for (int e = 0; e < 3; ++e) { b.lo[e] = glo[e]; b.n[e] = ghi[e] - glo[e]; }
+                // points with ig >= 0: at or beyond the face
+                const int lo_d = side == 0 ? glo[d] : std::max(glo[d], dom_hi[d] + f.stag[d]);
+                const int hi_d = side == 0 ? std::min(ghi[d], dom_lo[d] + 1) : ghi[d];
+                b.lo[d] = lo_d; b.n[d] = hi_d - lo_d;
+                const long total = (long)b.n[0] * b.n[1] * b.n[2];
+                if (b.n[d] <= 0 || total <= 0) continue;   // this brick does not touch the face
+                hipLaunchKernelGGL((apply_pec_kernel<IS_E>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                   df, c, b, pg);
+            }
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_apply_pec_e(const wxa_field_view E[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
+                           const int32_t pec_lo[3], const int32_t pec_hi[3], const int32_t ng[3], void* stream) {
+    return apply_pec<true>(E, dom_lo, dom_hi, pec_lo, pec_hi, ng, stream);
+}
+
+wxa_status wxa_apply_pec_b(const wxa_field_view B[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
+                           const int32_t pec_lo[3], const int32_t pec_hi[3], const int32_t ng[3], void* stream) {
+    return apply_pec<false>(B, dom_lo, dom_hi, pec_lo, pec_hi, ng, stream);
+}
+
+extern "C" {
 
 wxa_status wxa_field_set_zero(const wxa_field_view* f, void* stream) {
     WXA_REQUIRE(f && view_ok(*f), "bad field view");

@@ -51,6 +51,15 @@ public:
     }
 
     bool self_periodic(int d) const { return m_nb[d] == 1; }
+    // boundary.field_lo/hi: a non-periodic direction (PEC) must be unsplit; nothing is exchanged
+    // or wrapped along it (amrex FillBoundary/SumBoundary only act across periodic or interior faces)
+    void set_periodic(const int periodic[3]) {
+        for (int d = 0; d < 3; ++d) {
+            if (!periodic[d] && m_nb[d] != 1) throw std::runtime_error("BrickComm: a non-periodic direction must be unsplit");
+            m_periodic[d] = periodic[d] != 0;
+        }
+    }
+    bool periodic(int d) const { return m_periodic[d]; }
     int rank_of(const int c[3]) const { return c[0] + m_nb[0] * (c[1] + m_nb[1] * c[2]); }
     int neighbor(int d, int side) const {  // side 0 = minus, 1 = plus
         int c[3] = {m_coord[0], m_coord[1], m_coord[2]};
@@ -77,6 +86,7 @@ public:
             }
         }
         for (int d = 0; d < 3; ++d) {
+            if (!m_periodic[d]) continue;   // guards behind a physical boundary belong to the boundary condition
             if (self_periodic(d)) {
                 for (size_t c = 0; c < nf; ++c) {
                     const wxa_field_view& f = mfs[c]->view();
@@ -120,6 +130,7 @@ public:
                      void* stream) {
         const size_t nf = mfs.size();
         for (int d = 0; d < 3; ++d) {
+            if (!m_periodic[d]) continue;
             if (self_periodic(d)) {
                 for (size_t c = 0; c < nf; ++c) {
                     int per[3] = {0, 0, 0}, g[3] = {0, 0, 0};
@@ -248,6 +259,7 @@ private:
     wxa_comm m_comm{};
     bool m_has_comm = false;
     int m_nb[3], m_coord[3];
+    bool m_periodic[3] = {true, true, true};
     DeviceBuffer m_send[2], m_recv[2];
 };
 

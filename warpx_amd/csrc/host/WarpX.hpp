@@ -29,7 +29,8 @@ struct guardCellManager {
             ng_FieldGather[d] = (nox + 1) / 2;                        // :314-316 (staggered, galerkin: +0)
             ng_UpdateAux[d] = 0;
         }
-        ng_FieldGather = amrex::min(ng_FieldGather, ng_alloc_EB);     // :337
+        ng_FieldGather = amrex::min(ng_FieldGather, ng_alloc_EB);     // :333
+        for (int d = 0; d < 3; ++d) ng_FieldGather[d] = std::max(ng_FieldGather[d], ng_FieldSolver[d]);   // :338
     }
 };
 
@@ -109,6 +110,22 @@ public:
             if (m_ctx.brick_box.length(d) < guard_cells.ng_alloc_J[d] + 1)
                 throw std::runtime_error("brick thinner than the guard depth");
         m_comm = std::make_unique<BrickComm>(be, comm, cfg.nbricks, cfg.coord);
+        // boundary.field_lo / field_hi (Source/WarpX.cpp, ReadBoundaryConditions): periodic or PEC
+        int periodic[3];
+        for (int d = 0; d < 3; ++d) {
+            const int lo = cfg.field_boundary_lo[d], hi = cfg.field_boundary_hi[d];
+            const bool ok = (lo == WXA_BOUNDARY_PERIODIC || lo == WXA_BOUNDARY_PEC) &&
+                            (hi == WXA_BOUNDARY_PERIODIC || hi == WXA_BOUNDARY_PEC) &&
+                            ((lo == WXA_BOUNDARY_PERIODIC) == (hi == WXA_BOUNDARY_PERIODIC));
+            if (!ok) throw std::runtime_error("field boundary: a direction is periodic on both sides or on neither");
+            periodic[d] = lo == WXA_BOUNDARY_PERIODIC;
+            m_pec_lo[d] = lo == WXA_BOUNDARY_PEC;
+            m_pec_hi[d] = hi == WXA_BOUNDARY_PEC;
+            m_any_pec = m_any_pec || m_pec_lo[d] || m_pec_hi[d];
+            m_dom_lo[d] = 0;
+            m_dom_hi[d] = cfg.n_cell[d] - 1;
+        }
+        m_comm->set_periodic(periodic);   // throws if a PEC direction is split into bricks
 
         // AllocLevelMFs (Source/WarpX.cpp:2078-2700): Yee nodal flags :2117-2125
         const amrex::IntVect Etype[3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
@@ -125,7 +142,8 @@ public:
             for (int d = 0; d < 3; ++d)
                 m_filter_tmp[d] = std::make_unique<amrex::MultiFab>(be, m_ctx.brick_box, Etype[d], guard_cells.ng_alloc_J);
         for (int d = 0; d < 3; ++d)   // the device SumBoundary of a self-periodic direction needs this
-            if (cfg.nbricks[d] == 1 && m_ctx.brick_box.length(d) < 2 * guard_cells.ng_alloc_J[d] + 1)
+            if (cfg.nbricks[d] == 1 && m_comm->periodic(d) &&
+                m_ctx.brick_box.length(d) < 2 * guard_cells.ng_alloc_J[d] + 1)
                 throw std::runtime_error("periodic direction shorter than twice the guard depth");
         m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, m_ctx.dx);
         sort_intervals = cfg.sort_interval;
@@ -213,12 +231,34 @@ public:
     void EvolveB(amrex::Real a_dt, DtType /*a_dt_type*/) {
         PhaseTimer t(&m_ctx, kEvolveB);  // "WarpX::EvolveB()"
         m_fdtd_solver_fp->EvolveB(m_fields, 0, PatchType::fine, a_dt);
+        ApplyBfieldBoundary(0, PatchType::fine);                        // :926
     }
     // :930-1011
     void EvolveE(amrex::Real a_dt) {
         PhaseTimer t(&m_ctx, kEvolveE);  // "WarpX::EvolveE()"
         using warpx::fields::FieldType;
         m_fdtd_solver_fp->EvolveE(m_fields, 0, PatchType::fine, m_fields.get_alldirs(FieldType::Efield_fp, 0), a_dt);
+        ApplyEfieldBoundary(0, PatchType::fine);                        // :990
+    }
+
+    // Source/BoundaryConditions/WarpXFieldBoundaries.cpp:51-106 -> PEC::ApplyPECtoEfield
+    // (WarpX_PEC.cpp:457-538) with get_ng_fieldgather(); periodic faces: nothing to do
+    void ApplyEfieldBoundary(int /*lev*/, PatchType /*patch_type*/) {
+        if (!m_any_pec) return;
+        auto E = m_fields.get_alldirs(warpx::fields::FieldType::Efield_fp, 0);
+        const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
+        const int32_t ng[3] = {guard_cells.ng_FieldGather[0], guard_cells.ng_FieldGather[1], guard_cells.ng_FieldGather[2]};
+        if (m_be->apply_pec_e(Ev, m_dom_lo, m_dom_hi, m_pec_lo, m_pec_hi, ng, m_ctx.stream) != 0)
+            throw std::runtime_error("apply_pec_e failed");
+    }
+    // :108-135 -> PEC::ApplyPECtoBfield (WarpX_PEC.cpp:540-626)
+    void ApplyBfieldBoundary(int /*lev*/, PatchType /*patch_type*/) {
+        if (!m_any_pec) return;
+        auto B = m_fields.get_alldirs(warpx::fields::FieldType::Bfield_fp, 0);
+        const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
+        const int32_t ng[3] = {guard_cells.ng_FieldGather[0], guard_cells.ng_FieldGather[1], guard_cells.ng_FieldGather[2]};
+        if (m_be->apply_pec_b(Bv, m_dom_lo, m_dom_hi, m_pec_lo, m_pec_hi, ng, m_ctx.stream) != 0)
+            throw std::runtime_error("apply_pec_b failed");
     }
 
     // Source/Parallelization/WarpXComm.cpp:644-660,699-827 -> ablastr FillBoundary (Communication.cpp:71-115)
@@ -283,6 +323,9 @@ public:
     bool safe_guard_cells = false;   // warpx.safe_guard_cells
     bool is_synchronized = true;     // Source/WarpX.H:1520
     int sort_intervals = -1;         // Source/WarpX.cpp:1335 (GPU default 4; set by the config)
+    // WarpX::field_boundary_lo / field_boundary_hi restricted to periodic | PEC
+    int32_t m_pec_lo[3] = {0, 0, 0}, m_pec_hi[3] = {0, 0, 0}, m_dom_lo[3] = {0, 0, 0}, m_dom_hi[3] = {0, 0, 0};
+    bool m_any_pec = false;
 
 private:
     void FillBoundaryVector(warpx::fields::FieldType ft, const amrex::IntVect& ng, bool nodal_sync) {

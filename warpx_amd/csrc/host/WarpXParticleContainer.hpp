@@ -201,7 +201,8 @@ public:
     // LDS-tile kernels rely on survives between sorts.
     void Redistribute(BrickComm& comm) {
         const Backend* be = m_ctx->be;
-        const int periodic[3] = {1, 1, 1};
+        // particles wrap only along the periodic directions (nothing handles them at a PEC face yet)
+        const int periodic[3] = {comm.periodic(0) ? 1 : 0, comm.periodic(1) ? 1 : 0, comm.periodic(2) ? 1 : 0};
         const int none[3] = {0, 0, 0};
         int split[3];
         bool any_split = false;

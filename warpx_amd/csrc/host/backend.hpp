@@ -28,6 +28,11 @@ struct Backend {
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);
     int (*deposit_current)(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double,
                            double, double, int, int, void* ws, void*);
+    // PEC field boundary (wxa_apply_pec_e / wxa_apply_pec_b)
+    int (*apply_pec_e)(const wxa_field_view*, const int32_t* dom_lo, const int32_t* dom_hi, const int32_t* pec_lo,
+                       const int32_t* pec_hi, const int32_t* ng, void*);
+    int (*apply_pec_b)(const wxa_field_view*, const int32_t* dom_lo, const int32_t* dom_hi, const int32_t* pec_lo,
+                       const int32_t* pec_hi, const int32_t* ng, void*);
     int (*filter_bilinear)(const wxa_field_view*, const wxa_field_view*, void*);
     int (*fill_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);
     int (*sync_nodal_periodic)(const wxa_field_view*, const int*, void*);

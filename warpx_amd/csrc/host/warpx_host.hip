@@ -99,6 +99,12 @@ const Backend* hip_backend() {
         b.pack_leavers = [](const wxa_particle_view* p, const int32_t* list, int64_t n, void* msg, int64_t row_len,
                             int64_t offset, int retire, const double* blo, const double* bhi, void* st) -> int {
             return wxa_pack_leavers(p, list, n, msg, row_len, offset, retire, blo, bhi, st); };
+        b.apply_pec_e = [](const wxa_field_view* E, const int32_t* dlo, const int32_t* dhi, const int32_t* plo,
+                           const int32_t* phi, const int32_t* ng, void* st) -> int {
+            return wxa_apply_pec_e(E, dlo, dhi, plo, phi, ng, st); };
+        b.apply_pec_b = [](const wxa_field_view* B, const int32_t* dlo, const int32_t* dhi, const int32_t* plo,
+                           const int32_t* phi, const int32_t* ng, void* st) -> int {
+            return wxa_apply_pec_b(B, dlo, dhi, plo, phi, ng, st); };
         b.sort_live_count = [](void* ws, int64_t* n, void* st) -> int {
             return wxa_sort_live_count(static_cast<wxa_workspace*>(ws), n, st); };
         b.workspace_create = ws_create;

@@ -20,7 +20,7 @@ class WarpXSim:
     def __init__(self, lib: _capi.CLib, n_cell, prob_lo, prob_hi, nox=1, galerkin=1,
                  particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
                  use_filter=0, cfl=1.0, sort_interval=-1, nbricks=(1, 1, 1), coord=(0, 0, 0),
-                 comm: _capi.Comm | None = None):
+                 comm: _capi.Comm | None = None, field_boundary_lo=(0, 0, 0), field_boundary_hi=(0, 0, 0)):
         self.lib = lib
         self.on_device = lib.prefix == "wxa_"
         cfg = _capi.SimConfig()
@@ -30,6 +30,8 @@ class WarpXSim:
             cfg.prob_hi[d] = float(prob_hi[d])
             cfg.nbricks[d] = int(nbricks[d])
             cfg.coord[d] = int(coord[d])
+            cfg.field_boundary_lo[d] = int(field_boundary_lo[d])   # _capi.BOUNDARY_PERIODIC / BOUNDARY_PEC
+            cfg.field_boundary_hi[d] = int(field_boundary_hi[d])
         cfg.cfl = float(cfl)
         cfg.nox = int(nox)
         cfg.galerkin = int(galerkin)
@@ -91,6 +93,20 @@ class WarpXSim:
     def field(self, name: str) -> np.ndarray:
         """Dense [i,j,k] host copy including guards."""
         return view_to_numpy(self.field_view(name), self._d2h())
+
+    def set_field(self, name: str, values: np.ndarray):
+        """Overwrites a field (guards included) with a dense [i,j,k] array shaped like `field(name)`:
+        the stand-in for warpx.E/B_ext_grid_init_style = parse_*_ext_grid_function."""
+        v = self.field_view(name)
+        n = tuple(v.n)
+        assert values.shape == n, (values.shape, n)
+        buf = np.zeros((n[2], n[1], int(v.jstride)), dtype=np.float64)
+        buf[:, :, : n[0]] = np.transpose(values, (2, 1, 0))
+        buf = np.ascontiguousarray(buf).reshape(-1)[: int(v.kstride) * n[2]]
+        if self.on_device:
+            self.lib.copy_to_device(v.p, buf.ctypes.data, 8 * buf.size)
+        else:
+            C.memmove(v.p, buf.ctypes.data, 8 * buf.size)
 
     def field_valid(self, name: str) -> np.ndarray:
         v = self.field_view(name)
