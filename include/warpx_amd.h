@@ -261,6 +261,17 @@ wxa_status wxa_apply_pec_b(const wxa_field_view B[3], const int32_t dom_lo[3],
                            const int32_t dom_hi[3], const int32_t pec_lo[3],
                            const int32_t pec_hi[3], const int32_t ng[3], void* stream);
 
+/* Replaces PEC::ApplyReflectiveBoundarytoJfield (Source/BoundaryConditions/WarpX_PEC.cpp:713-900, point
+ * rule SetRhoOrJfieldFromPEC :354-420), called from WarpX::SyncCurrentAndRho after SyncCurrent
+ * (Source/Evolve/WarpXEvolve.cpp:625-640), for PEC field boundaries with absorbing particle
+ * boundaries: the current deposited in the guard cells behind a PEC wall is folded onto its mirror
+ * cell inside with the sign of an image charge (-1 for the components tangential to the wall, +1 for
+ * the normal one), a component living on the wall is zeroed there, and the guard cells then receive
+ * the image of the updated interior values (odd / even).  dom_lo/dom_hi: cell-centred domain box. */
+wxa_status wxa_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3],
+                           const int32_t dom_hi[3], const int32_t pec_lo[3],
+                           const int32_t pec_hi[3], void* stream);
+
 /* ------------------------------------------------------------------ */
 /* Current filter and guard-cell exchange                              */
 /* ------------------------------------------------------------------ */
@@ -329,8 +340,9 @@ typedef struct wxa_sim_config {
     int32_t nbricks[3];          /* domain decomposition, one brick per GPU     */
     int32_t coord[3];            /* this brick's coordinates                    */
     int32_t field_boundary_lo[3];/* boundary.field_lo: WXA_BOUNDARY_* (0 = periodic, the default) */
-    int32_t field_boundary_hi[3];/* boundary.field_hi; PEC only along unsplit directions, fields only:
-                                    particles must not reach a PEC face yet (no J/rho reflection)  */
+    int32_t field_boundary_hi[3];/* boundary.field_hi; PEC only along unsplit directions.  Particles may sit
+                                    next to a PEC wall (J is folded back, wxa_apply_pec_j) but must not
+                                    reach it: the absorbing particle boundary is not there yet       */
 } wxa_sim_config;
 
 /* Neighbour exchange supplied by the host program (torch.distributed over

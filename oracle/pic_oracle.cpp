@@ -407,6 +407,56 @@ int apply_pec(const wxa_field_view F[3], const int32_t dom_lo[3], const int32_t 
 
 extern "C" {
 
+// PEC::ApplyReflectiveBoundarytoJfield (:713-900) with SetRhoOrJfieldFromPEC (:354-420), for PEC field
+// boundaries with absorbing particle boundaries (the default next to a PEC wall): the current
+// deposited in the guard cells behind the wall is folded back onto its mirror cell with the sign of an
+// image charge (psign = -1 for the components tangential to the wall, +1 for the normal one), a
+// component living on the wall is zeroed there, and the guard cells then receive the image of the
+// updated interior values (odd for tangential, even for normal components).
+int orc_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
+                    const int32_t pec_lo[3], const int32_t pec_hi[3], void*) {
+    for (int c = 0; c < 3; ++c) {
+        const wxa_field_view& f = J[c];
+        const Arr a(f);
+        int mirrorfac[3][2];
+        double psign[3];
+        bool tangent[3];
+        for (int d = 0; d < 3; ++d) {
+            // the domain box made nodal: [dom_lo, dom_hi + 1]  (:729-733, :800-805)
+            mirrorfac[d][0] = 2 * dom_lo[d] - (1 - f.stag[d]);
+            mirrorfac[d][1] = 2 * (dom_hi[d] + 1) - (1 - f.stag[d]);
+            tangent[d] = c != d;
+            psign[d] = tangent[d] ? -1.0 : 1.0;
+        }
+        auto in_fab = [&](const int v[3]) {
+            for (int d = 0; d < 3; ++d)
+                if (v[d] < f.lo[d] || v[d] >= f.lo[d] + f.n[d]) return false;
+            return true;
+        };
+        for (int k = vlo(f, 2); k < vhi(f, 2); ++k)
+            for (int j = vlo(f, 1); j < vhi(f, 1); ++j)
+                for (int i = vlo(f, 0); i < vhi(f, 0); ++i) {
+                    const int ijk[3] = {i, j, k};
+                    for (int d = 0; d < 3; ++d)
+                        for (int side = 0; side < 2; ++side) {
+                            if (!(side == 0 ? pec_lo[d] : pec_hi[d])) continue;
+                            int m[3] = {i, j, k};
+                            m[d] = mirrorfac[d][side] - ijk[d];
+                            if (m[d] == ijk[d]) a(i, j, k) = 0.0;
+                            else if (in_fab(m)) a(i, j, k) += psign[d] * a(m[0], m[1], m[2]);
+                        }
+                    for (int d = 0; d < 3; ++d)
+                        for (int side = 0; side < 2; ++side) {
+                            if (!(side == 0 ? pec_lo[d] : pec_hi[d])) continue;
+                            int m[3] = {i, j, k};
+                            m[d] = mirrorfac[d][side] - ijk[d];
+                            if (m[d] != ijk[d] && in_fab(m)) a(m[0], m[1], m[2]) = tangent[d] ? -a(i, j, k) : a(i, j, k);
+                        }
+                }
+    }
+    return 0;
+}
+
 int orc_apply_pec_e(const wxa_field_view E[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
                     const int32_t pec_lo[3], const int32_t pec_hi[3], const int32_t ng[3], void*) {
     return apply_pec<true>(E, dom_lo, dom_hi, pec_lo, pec_hi, ng);
@@ -820,6 +870,8 @@ void one_step_nosub(orc_sim* s) {
                 src_ng[d] = std::min(s->ng_depos_J[d] + (s->cfg.use_filter ? 1 : 0), s->ng_J[d]);
             orc_sum_boundary_periodic(&s->Jv[c], src_ng, s->periodic, nullptr);
         }
+        // :625-640 reflect the current density over PEC boundaries (ApplyJfieldBoundary)
+        if (s->any_pec) orc_apply_pec_j(s->Jv, s->dom_lo, s->dom_hi, s->pec_lo, s->pec_hi, nullptr);
     }
     // WarpX::EvolveB / EvolveE end with ApplyBfieldBoundary / ApplyEfieldBoundary
     // (Source/FieldSolver/WarpXPushFieldsEM.cpp:926,990 -> WarpXFieldBoundaries.cpp:51-135)

@@ -38,6 +38,7 @@ int orc_apply_pec_e(const wxa_field_view*, const int32_t*, const int32_t*, const
                     void*);
 int orc_apply_pec_b(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                     void*);
+int orc_apply_pec_j(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
 }
 
 namespace {
@@ -78,6 +79,7 @@ const Backend* cpu_backend() {
         b.sort_live_count = orc_sort_live_count;
         b.apply_pec_e = orc_apply_pec_e;
         b.apply_pec_b = orc_apply_pec_b;
+        b.apply_pec_j = orc_apply_pec_j;
         b.workspace_create = ws_create; b.workspace_destroy = ws_destroy;
         b.dmalloc = h_malloc; b.dfree = h_free;
         b.memset_async = h_memset; b.memcpy_async = h_memcpy;

@@ -34,3 +34,26 @@ def make_sim(lib):
     prof = -EY_IN * np.sin(2 * np.pi * z / WAVELENGTH) / C_LIGHT * (z < Z2) * (z > Z1)
     sim.set_field("Bx", np.broadcast_to(prof[None, None, :], n).copy())
     return sim
+
+
+# ---- Examples/Tests/pec/inputs_test_3d_pec_particle ---------------------------------------------
+# Two unit-weight particles 0.004 cell from a PEC wall in x (periodic in y, z), order 3, Vay pusher,
+# filter on: an "electron" at rest (with the proton mass) and a proton moving along the wall with
+# u_y = -2 c.  Their order-3 stencils reach behind the wall, so every step exercises the image-charge
+# fold of J (ApplyReflectiveBoundarytoJfield) and the mirrored E/B guard cells in the gather.
+P_N_CELL = (128, 64, 64)
+P_PROB_LO, P_PROB_HI = (-32e-6,) * 3, (32e-6,) * 3
+P_MAX_STEP = 20
+Q_E, M_P = 1.602176634e-19, 1.67262192369e-27
+
+
+def make_particle_sim(lib):
+    sim = WarpXSim(lib, P_N_CELL, P_PROB_LO, P_PROB_HI, nox=3, galerkin=1, particle_pusher=_capi.PUSHER_VAY,
+                   current_deposition=_capi.DEPOSIT_ESIRKEPOV, use_filter=1, cfl=0.9, sort_interval=4,
+                   field_boundary_lo=(_capi.BOUNDARY_PEC, _capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PERIODIC),
+                   field_boundary_hi=(_capi.BOUNDARY_PEC, _capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PERIODIC))
+    one = lambda v: np.array([v], dtype=np.float64)
+    pos = [one(31.998e-6), one(0.0), one(0.0)]
+    electron = sim.add_species(-Q_E, M_P, pos + [one(1.0), one(0.0), one(0.0), one(0.0)])
+    proton = sim.add_species(+Q_E, M_P, pos + [one(1.0), one(0.0), one(-2.0 * C_LIGHT), one(0.0)])
+    return sim, electron, proton

@@ -504,3 +504,19 @@ def test_apply_pec_fields(oracle, product, pec, ng):
         _sync(product)
         for a, b in zip(Fd, F):
             assert np.array_equal(a.to_numpy(), b.to_numpy())
+
+
+@pytest.mark.parametrize("pec", [((1, 0, 0), (1, 0, 0)), ((0, 1, 1), (0, 1, 1)), ((0, 0, 1), (0, 0, 0))])
+def test_apply_pec_j(oracle, product, pec):
+    """wxa_apply_pec_j (PEC::ApplyReflectiveBoundarytoJfield, absorbing particle boundaries) on random J with
+    one, two and one-sided PEC directions: bit-identical to the CPU restatement, guards included."""
+    ncell = (12, 10, 14)
+    dom_lo, dom_hi = (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*[n - 1 for n in ncell])
+    plo, phi = (C.c_int32 * 3)(*pec[0]), (C.c_int32 * 3)(*pec[1])
+    J = H.random_fields(("jx", "jy", "jz"), ncell, 4, 9)
+    Jd = H.clone_fields(J, DEV, True)
+    oracle.apply_pec_j(field_triplet(J), dom_lo, dom_hi, plo, phi, None)
+    product.apply_pec_j(field_triplet(Jd), dom_lo, dom_hi, plo, phi, None)
+    _sync(product)
+    for a, b in zip(Jd, J):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())

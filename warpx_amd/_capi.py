@@ -109,6 +109,7 @@ _KERNEL_SIGS = {
     "enforce_periodic": (C.c_int, [_PPV, _D3, _D3, _I3, C.c_void_p]),
     "apply_pec_e": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_pec_b": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
+    "apply_pec_j": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "filter_bilinear": (C.c_int, [_PFV, _PFV, C.c_void_p]),
     "fill_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
     "sum_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),

@@ -12,6 +12,8 @@
 //    -ffp-contract=off: results are bit-identical to the CPU path.
 #include "common.hpp"
 
+#include <algorithm>
+#include <climits>
 #include <cstdlib>
 
 namespace wxa {
@@ -428,6 +430,66 @@ apply_pec_kernel(DevF f, int icomp, BoxN box, PecGeom pg) {
     }
 }
 
+// SetRhoOrJfieldFromPEC (:354-420) for one J component over its valid box, PEC walls with absorbing
+// particle boundaries.  Every valid point touches only itself and its own mirror guard cells, so one
+// thread per valid point is race-free; points farther than the guard depth from every PEC wall do
+// nothing (their mirror lies outside the array), which is most of them: no memory traffic there.
+__global__ void __launch_bounds__(256)
+apply_pec_j_kernel(DevF f, int icomp, Box3 vb, PecGeom pg) {
+    const int n0 = vb.hi[0] - vb.lo[0], n1 = vb.hi[1] - vb.lo[1], n2 = vb.hi[2] - vb.lo[2];
+    const long total = (long)n0 * n1 * n2;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        int ijk[3];
+        ijk[0] = vb.lo[0] + (int)(t % n0);
+        ijk[1] = vb.lo[1] + (int)((t / n0) % n1);
+        ijk[2] = vb.lo[2] + (int)(t / ((long)n0 * n1));
+        const int flo[3] = {f.lo0, f.lo1, f.lo2}, fn[3] = {f.n0, f.n1, f.n2};
+        // mirror index along d for side s, or INT_MIN if that wall is not PEC / the mirror is outside the array
+        int mir[3][2];
+        bool any = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                mir[d][s] = INT_MIN;
+                if (!(s == 0 ? pg.pec_lo[d] : pg.pec_hi[d])) continue;
+                // the domain box made nodal: [dom_lo, dom_hi + 1]  (:729-733, :800-805)
+                const int fac = (s == 0 ? 2 * pg.dom_lo[d] : 2 * (pg.dom_hi[d] + 1)) - (1 - pg.nodal[d]);
+                const int m = fac - ijk[d];
+                if (m == ijk[d] || (m >= flo[d] && m < flo[d] + fn[d])) { mir[d][s] = m; any = true; }
+            }
+        }
+        if (!any) continue;
+        double v = f(ijk[0], ijk[1], ijk[2]);
+        // 1) fold the guard deposits onto the interior point (zero on the wall)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int m = mir[d][s];
+                if (m == INT_MIN) continue;
+                if (m == ijk[d]) { v = 0.0; continue; }
+                int q[3] = {ijk[0], ijk[1], ijk[2]};
+                q[d] = m;
+                v += (icomp != d ? -1.0 : 1.0) * f(q[0], q[1], q[2]);
+            }
+        }
+        f(ijk[0], ijk[1], ijk[2]) = v;
+        // 2) the guard cells take the image of the updated interior value
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int m = mir[d][s];
+                if (m == INT_MIN || m == ijk[d]) continue;
+                int q[3] = {ijk[0], ijk[1], ijk[2]};
+                q[d] = m;
+                f(q[0], q[1], q[2]) = icomp != d ? -v : v;
+            }
+        }
+    }
+}
+
 // Both guard slabs of one direction in one launch: box_lo takes src(i + shift), box_hi takes
 // src(i - shift).  The boxes have the same extents; sources are valid points, destinations guard
 // points, so the two halves are independent.
@@ -764,6 +826,31 @@ static wxa_status apply_pec(const wxa_field_view F[3], const int32_t dom_lo[3], 
                 hipLaunchKernelGGL((apply_pec_kernel<IS_E>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                                    df, c, b, pg);
             }
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
+                           const int32_t pec_lo[3], const int32_t pec_hi[3], void* stream) {
+    WXA_REQUIRE(J && dom_lo && dom_hi && pec_lo && pec_hi, "null argument");
+    for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(J[c]), "bad field view");
+    for (int c = 0; c < 3; ++c) {
+        const wxa_field_view& f = J[c];
+        PecGeom pg;
+        Box3 vb;
+        for (int d = 0; d < 3; ++d) {
+            WXA_REQUIRE(dom_hi[d] >= dom_lo[d], "empty domain");
+            pg.dom_lo[d] = dom_lo[d]; pg.dom_hi[d] = dom_hi[d];
+            pg.pec_lo[d] = pec_lo[d] ? 1 : 0; pg.pec_hi[d] = pec_hi[d] ? 1 : 0;
+            pg.nodal[d] = f.stag[d];
+            vb.lo[d] = f.lo[d] + f.ng[d];
+            vb.hi[d] = f.lo[d] + f.n[d] - f.ng[d];
+        }
+        const long total = (long)(vb.hi[0] - vb.lo[0]) * (vb.hi[1] - vb.lo[1]) * (vb.hi[2] - vb.lo[2]);
+        if (total <= 0) continue;
+        hipLaunchKernelGGL(apply_pec_j_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(f), c,
+                           vb, pg);
     }
     WXA_LAUNCH_CHECK();
     return WXA_OK;

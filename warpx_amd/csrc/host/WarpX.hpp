@@ -207,6 +207,18 @@ public:
         if (use_filter)
             for (int idim = 0; idim < 3; ++idim) ApplyFilterJ(J, 0, idim);
         SumBoundaryJ(J, 0);
+        // :625-640 reflect the current density over PEC boundaries
+        ApplyJfieldBoundary(0, J[0], J[1], J[2], PatchType::fine);
+    }
+
+    // Source/BoundaryConditions/WarpXFieldBoundaries.cpp:175-188 -> PEC::ApplyReflectiveBoundarytoJfield
+    // (WarpX_PEC.cpp:713-900) with absorbing particle boundaries next to the PEC walls
+    void ApplyJfieldBoundary(int /*lev*/, amrex::MultiFab* Jx, amrex::MultiFab* Jy, amrex::MultiFab* Jz,
+                             PatchType /*patch_type*/) {
+        if (!m_any_pec) return;
+        const wxa_field_view Jv[3] = {Jx->view(), Jy->view(), Jz->view()};
+        if (m_be->apply_pec_j(Jv, m_dom_lo, m_dom_hi, m_pec_lo, m_pec_hi, m_ctx.stream) != 0)
+            throw std::runtime_error("apply_pec_j failed");
     }
 
     // WarpXComm.cpp:1357-1374: filter into a temporary with the same guards, then "copy back":

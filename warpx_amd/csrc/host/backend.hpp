@@ -33,6 +33,8 @@ struct Backend {
                        const int32_t* pec_hi, const int32_t* ng, void*);
     int (*apply_pec_b)(const wxa_field_view*, const int32_t* dom_lo, const int32_t* dom_hi, const int32_t* pec_lo,
                        const int32_t* pec_hi, const int32_t* ng, void*);
+    int (*apply_pec_j)(const wxa_field_view*, const int32_t* dom_lo, const int32_t* dom_hi, const int32_t* pec_lo,
+                       const int32_t* pec_hi, void*);
     int (*filter_bilinear)(const wxa_field_view*, const wxa_field_view*, void*);
     int (*fill_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);
     int (*sync_nodal_periodic)(const wxa_field_view*, const int*, void*);

@@ -105,6 +105,8 @@ const Backend* hip_backend() {
         b.apply_pec_b = [](const wxa_field_view* B, const int32_t* dlo, const int32_t* dhi, const int32_t* plo,
                            const int32_t* phi, const int32_t* ng, void* st) -> int {
             return wxa_apply_pec_b(B, dlo, dhi, plo, phi, ng, st); };
+        b.apply_pec_j = [](const wxa_field_view* J, const int32_t* dlo, const int32_t* dhi, const int32_t* plo,
+                           const int32_t* phi, void* st) -> int { return wxa_apply_pec_j(J, dlo, dhi, plo, phi, st); };
         b.sort_live_count = [](void* ws, int64_t* n, void* st) -> int {
             return wxa_sort_live_count(static_cast<wxa_workspace*>(ws), n, st); };
         b.workspace_create = ws_create;
