@@ -261,6 +261,25 @@ wxa_status wxa_apply_pec_b(const wxa_field_view B[3], const int32_t dom_lo[3],
                            const int32_t dom_hi[3], const int32_t pec_lo[3],
                            const int32_t pec_hi[3], const int32_t ng[3], void* stream);
 
+#define WXA_PBOUNDARY_DEFAULT    0   /* periodic where the field boundary is periodic, absorbing where it is PEC */
+#define WXA_PBOUNDARY_ABSORBING  1   /* boundary.particle_lo/hi = absorbing  */
+#define WXA_PBOUNDARY_REFLECTING 2   /* boundary.particle_lo/hi = reflecting */
+#define WXA_PBOUNDARY_PERIODIC   3   /* boundary.particle_lo/hi = periodic   */
+
+/* Replaces WarpXParticleContainer::ApplyBoundaryConditions (Source/Particles/WarpXParticleContainer.cpp:
+ * 1574-1660) with ApplyParticleBoundaries::apply_boundaries (Source/Particles/ParticleBoundaries_K.H:
+ * 20-175), absorbing (reflection probability 0) and reflecting walls; periodic directions are left to
+ * wxa_enforce_periodic / wxa_wrap_and_classify.  A particle beyond a reflecting wall (x < lo or x > hi)
+ * is mirrored, x = 2 wall - x, and the momentum component normal to the wall changes sign; beyond an
+ * absorbing wall it is lost: retired in place as wxa_pack_leavers does (idcpu = WXA_IDCPU_RETIRED,
+ * weight and momentum 0, position clamped into the domain), to be dropped by the next sort.
+ * bc_lo/bc_hi[d]: WXA_PBOUNDARY_ABSORBING / _REFLECTING act, anything else is ignored.
+ * *n_lost (host) is valid on return (synchronises) unless NULL.  Needs p->idcpu. */
+wxa_status wxa_apply_particle_boundaries(const wxa_particle_view* p, const double prob_lo[3],
+                                         const double prob_hi[3], const int32_t bc_lo[3],
+                                         const int32_t bc_hi[3], int64_t* n_lost,
+                                         wxa_workspace* ws, void* stream);
+
 /* Replaces PEC::ApplyReflectiveBoundarytoJfield (Source/BoundaryConditions/WarpX_PEC.cpp:713-900, point
  * rule SetRhoOrJfieldFromPEC :354-420), called from WarpX::SyncCurrentAndRho after SyncCurrent
  * (Source/Evolve/WarpXEvolve.cpp:625-640), for PEC field boundaries with absorbing particle
@@ -340,9 +359,10 @@ typedef struct wxa_sim_config {
     int32_t nbricks[3];          /* domain decomposition, one brick per GPU     */
     int32_t coord[3];            /* this brick's coordinates                    */
     int32_t field_boundary_lo[3];/* boundary.field_lo: WXA_BOUNDARY_* (0 = periodic, the default) */
-    int32_t field_boundary_hi[3];/* boundary.field_hi; PEC only along unsplit directions.  Particles may sit
-                                    next to a PEC wall (J is folded back, wxa_apply_pec_j) but must not
-                                    reach it: the absorbing particle boundary is not there yet       */
+    int32_t field_boundary_hi[3];/* boundary.field_hi; PEC only along unsplit directions (J next to a wall
+                                    is folded back with the image-charge sign of an absorbing wall) */
+    int32_t particle_boundary_lo[3]; /* boundary.particle_lo: WXA_PBOUNDARY_* (0 = default)              */
+    int32_t particle_boundary_hi[3]; /* boundary.particle_hi                                             */
 } wxa_sim_config;
 
 /* Neighbour exchange supplied by the host program (torch.distributed over

@@ -603,6 +603,45 @@ int orc_sort_live_count(void* ws, int64_t* n, void*) {
     return 0;
 }
 
+// WarpXParticleContainer::ApplyBoundaryConditions (Source/Particles/WarpXParticleContainer.cpp:1574-1660)
+// with apply_boundary / apply_boundaries (Source/Particles/ParticleBoundaries_K.H:20-175): reflecting and
+// absorbing (reflection probability 0) walls.  A lost particle is retired in place (the reference
+// invalidates its id and lets Redistribute drop it).
+int orc_apply_particle_boundaries(const wxa_particle_view* p, const double prob_lo[3], const double prob_hi[3],
+                                  const int32_t bc_lo[3], const int32_t bc_hi[3], int64_t* n_lost, void*, void*) {
+    double* pos[3] = {p->x, p->y, p->z};
+    double* u[3] = {p->ux, p->uy, p->uz};
+    int64_t lost_total = 0;
+    for (int64_t ip = 0; ip < p->np; ++ip) {
+        if (p->idcpu[ip] == WXA_IDCPU_RETIRED) continue;   // :1617-1618 skip particles already flagged
+        bool lost = false, flip[3] = {false, false, false};
+        for (int d = 0; d < 3; ++d) {
+            double& x = pos[d][ip];
+            if (x < prob_lo[d]) {
+                if (bc_lo[d] == WXA_PBOUNDARY_ABSORBING) lost = true;
+                else if (bc_lo[d] == WXA_PBOUNDARY_REFLECTING) { x = 2 * prob_lo[d] - x; flip[d] = true; }
+            } else if (x > prob_hi[d]) {
+                if (bc_hi[d] == WXA_PBOUNDARY_ABSORBING) lost = true;
+                else if (bc_hi[d] == WXA_PBOUNDARY_REFLECTING) { x = 2 * prob_hi[d] - x; flip[d] = true; }
+            }
+        }
+        if (lost) {
+            for (int d = 0; d < 3; ++d) {
+                pos[d][ip] = std::min(std::max(pos[d][ip], prob_lo[d]), std::nextafter(prob_hi[d], prob_lo[d]));
+                u[d][ip] = 0.0;
+            }
+            p->w[ip] = 0.0;
+            p->idcpu[ip] = WXA_IDCPU_RETIRED;
+            ++lost_total;
+        } else {
+            for (int d = 0; d < 3; ++d)
+                if (flip[d]) u[d][ip] = -u[d][ip];   // ParticleBoundaries_K.H:160-170 (reflect_all_velocities off)
+        }
+    }
+    if (n_lost) *n_lost = lost_total;
+    return 0;
+}
+
 // The brick-to-brick part of amrex ParticleContainer::Redistribute as the host layer drives it
 // (include/warpx_amd.h, "Redistribute without moving the tile"): periodic wrap plus the lists of
 // particles that left the brick, by the first split direction in which they are outside (decided
@@ -786,6 +825,10 @@ struct orc_sim {
     bool any_pec = false;
     int32_t pec_lo[3] = {0, 0, 0}, pec_hi[3] = {0, 0, 0}, dom_lo[3] = {0, 0, 0}, dom_hi[3] = {0, 0, 0};
     int32_t ng_gather32[3] = {0, 0, 0};
+    // boundary.particle_lo/hi resolved (WXA_PBOUNDARY_ABSORBING / _REFLECTING / _PERIODIC)
+    int32_t pbc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
+    int32_t pbc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
+    bool any_particle_wall = false;
 
     wxa_grid_geom geom_for(const int ng[3]) const {
         // WarpX::LowerCorner(box.grow(ng)) = prob_lo + box.lo * dx (Source/WarpX.cpp:2851-2875)
@@ -939,6 +982,19 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
         s->pec_hi[d] = bhi == WXA_BOUNDARY_PEC;
         s->periodic[d] = blo == WXA_BOUNDARY_PERIODIC;
         s->any_pec = s->any_pec || s->pec_lo[d] || s->pec_hi[d];
+        // boundary.particle_lo/hi: default = periodic with a periodic field boundary, absorbing otherwise;
+        // periodic particles need a periodic field boundary and vice versa (WarpX::ReadBoundaryConditions)
+        for (int side = 0; side < 2; ++side) {
+            int32_t want = side == 0 ? cfg->particle_boundary_lo[d] : cfg->particle_boundary_hi[d];
+            const bool fper = s->periodic[d] != 0;
+            if (want == WXA_PBOUNDARY_DEFAULT) want = fper ? WXA_PBOUNDARY_PERIODIC : WXA_PBOUNDARY_ABSORBING;
+            const bool ok = (want == WXA_PBOUNDARY_PERIODIC) == fper &&
+                            (want == WXA_PBOUNDARY_PERIODIC || want == WXA_PBOUNDARY_ABSORBING ||
+                             want == WXA_PBOUNDARY_REFLECTING);
+            if (!ok) { delete s; return -2; }
+            (side == 0 ? s->pbc_lo[d] : s->pbc_hi[d]) = want;
+            s->any_particle_wall = s->any_particle_wall || want != WXA_PBOUNDARY_PERIODIC;
+        }
     }
     // Yee staggering (Source/WarpX.cpp:2117-2125)
     const int Es[3][3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
@@ -991,9 +1047,27 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
         }
         s->istep++;
         s->cur_time += s->dt;
-        {   // HandleParticlesAtBoundaries (:533-581): periodic wrap in Redistribute
+        {   // HandleParticlesAtBoundaries (:533-581): ApplyBoundaryConditions, then the periodic wrap of Redistribute
             Tic t(s, 6);
             for (auto& sp : s->species) {
+                if (s->any_particle_wall) {
+                    if (sp->id.empty()) sp->id.assign(sp->a[0].size(), 0);
+                    wxa_particle_view p = sp->view();
+                    int64_t lost = 0;
+                    orc_apply_particle_boundaries(&p, s->cfg.prob_lo, s->cfg.prob_hi, s->pbc_lo, s->pbc_hi, &lost,
+                                                  nullptr, nullptr);
+                    if (lost > 0) {   // Redistribute drops the invalidated particles
+                        size_t keep = 0;
+                        for (size_t ip = 0; ip < sp->id.size(); ++ip) {
+                            if (sp->id[ip] == WXA_IDCPU_RETIRED) continue;
+                            for (int c = 0; c < 7; ++c) sp->a[c][keep] = sp->a[c][ip];
+                            sp->id[keep] = sp->id[ip];
+                            ++keep;
+                        }
+                        for (int c = 0; c < 7; ++c) sp->a[c].resize(keep);
+                        sp->id.resize(keep);
+                    }
+                }
                 wxa_particle_view p = sp->view();
                 orc_enforce_periodic(&p, s->cfg.prob_lo, s->cfg.prob_hi, s->periodic, nullptr);
             }

@@ -39,6 +39,8 @@ int orc_apply_pec_e(const wxa_field_view*, const int32_t*, const int32_t*, const
 int orc_apply_pec_b(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                     void*);
 int orc_apply_pec_j(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
+int orc_apply_particle_boundaries(const wxa_particle_view*, const double*, const double*, const int32_t*, const int32_t*,
+                                  int64_t*, void*, void*);
 }
 
 namespace {
@@ -80,6 +82,7 @@ const Backend* cpu_backend() {
         b.apply_pec_e = orc_apply_pec_e;
         b.apply_pec_b = orc_apply_pec_b;
         b.apply_pec_j = orc_apply_pec_j;
+        b.apply_particle_boundaries = orc_apply_particle_boundaries;
         b.workspace_create = ws_create; b.workspace_destroy = ws_destroy;
         b.dmalloc = h_malloc; b.dfree = h_free;
         b.memset_async = h_memset; b.memcpy_async = h_memcpy;

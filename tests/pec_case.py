@@ -57,3 +57,32 @@ def make_particle_sim(lib):
     electron = sim.add_species(-Q_E, M_P, pos + [one(1.0), one(0.0), one(0.0), one(0.0)])
     proton = sim.add_species(+Q_E, M_P, pos + [one(1.0), one(0.0), one(-2.0 * C_LIGHT), one(0.0)])
     return sim, electron, proton
+
+
+# ---- Examples/Tests/boundaries/inputs_test_3d_particle_boundaries -----------------------------------
+# Chargeless particles flying into reflecting (x), absorbing (y) and periodic (z) walls: pure kinematics of
+# WarpXParticleContainer::ApplyBoundaryConditions + the periodic wrap.
+B_N_CELL = (16, 16, 16)
+B_PROB_LO, B_PROB_HI = (-1.0,) * 3, (1.0,) * 3
+B_MAX_STEP = 8
+M_E = 9.1093837015e-31
+
+
+def make_boundaries_sim(lib):
+    P, A, R = _capi.PBOUNDARY_PERIODIC, _capi.PBOUNDARY_ABSORBING, _capi.PBOUNDARY_REFLECTING
+    sim = WarpXSim(lib, B_N_CELL, B_PROB_LO, B_PROB_HI, nox=1, galerkin=1, use_filter=1, cfl=1.0, sort_interval=4,
+                   field_boundary_lo=(_capi.BOUNDARY_PEC, _capi.BOUNDARY_PEC, _capi.BOUNDARY_PERIODIC),
+                   field_boundary_hi=(_capi.BOUNDARY_PEC, _capi.BOUNDARY_PEC, _capi.BOUNDARY_PERIODIC),
+                   particle_boundary_lo=(R, A, P), particle_boundary_hi=(R, A, P))
+
+    def species(pos, u):
+        n = len(pos)
+        cols = [np.array([p[d] for p in pos], dtype=np.float64) for d in range(3)]
+        cols += [np.ones(n)]
+        cols += [C_LIGHT * np.array([v[d] for v in u], dtype=np.float64) for d in range(3)]
+        return sim.add_species(0.0, M_E, cols)
+
+    refl = species([(-0.9, 0, 0), (0.91, 0, 0)], [(-0.9, 0, 0), (0.91, 0, 0)])
+    absb = species([(0, -0.92, 0), (0, 0.93, 0), (0, 0, 0)], [(0, -0.92, 0), (0, 0.93, 0), (0, 0, 0)])
+    peri = species([(0, 0, -0.94), (0, 0, 0.95)], [(0, 0, -0.94), (0, 0, 0.95)])
+    return sim, refl, absb, peri

@@ -59,6 +59,8 @@ class SimConfig(C.Structure):
         ("coord", C.c_int32 * 3),
         ("field_boundary_lo", C.c_int32 * 3),
         ("field_boundary_hi", C.c_int32 * 3),
+        ("particle_boundary_lo", C.c_int32 * 3),
+        ("particle_boundary_hi", C.c_int32 * 3),
     ]
 
 
@@ -86,6 +88,7 @@ class Comm(C.Structure):
 PUSHER_BORIS, PUSHER_VAY = 0, 1
 DEPOSIT_ESIRKEPOV, DEPOSIT_DIRECT = 0, 1
 BOUNDARY_PERIODIC, BOUNDARY_PEC = 0, 1
+PBOUNDARY_DEFAULT, PBOUNDARY_ABSORBING, PBOUNDARY_REFLECTING, PBOUNDARY_PERIODIC = 0, 1, 2, 3
 
 _FV3 = FieldView * 3
 _D3 = C.c_double * 3
@@ -110,6 +113,8 @@ _KERNEL_SIGS = {
     "apply_pec_e": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_pec_b": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_pec_j": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
+    "apply_particle_boundaries": (C.c_int, [_PPV, _D3, _D3, _I32_3, _I32_3, C.POINTER(C.c_int64), C.c_void_p,
+                                            C.c_void_p]),
     "filter_bilinear": (C.c_int, [_PFV, _PFV, C.c_void_p]),
     "fill_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
     "sum_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),

@@ -126,6 +126,21 @@ public:
             m_dom_hi[d] = cfg.n_cell[d] - 1;
         }
         m_comm->set_periodic(periodic);   // throws if a PEC direction is split into bricks
+        // boundary.particle_lo / particle_hi: default = periodic with a periodic field boundary, absorbing
+        // otherwise; periodic particles need a periodic field boundary and vice versa
+        for (int d = 0; d < 3; ++d)
+            for (int side = 0; side < 2; ++side) {
+                int32_t want = side == 0 ? cfg.particle_boundary_lo[d] : cfg.particle_boundary_hi[d];
+                const bool fper = periodic[d] != 0;
+                if (want == WXA_PBOUNDARY_DEFAULT) want = fper ? WXA_PBOUNDARY_PERIODIC : WXA_PBOUNDARY_ABSORBING;
+                const bool ok = (want == WXA_PBOUNDARY_PERIODIC) == fper &&
+                                (want == WXA_PBOUNDARY_PERIODIC || want == WXA_PBOUNDARY_ABSORBING ||
+                                 want == WXA_PBOUNDARY_REFLECTING);
+                if (!ok) throw std::runtime_error("particle boundary: periodic if and only if the field boundary is");
+                (side == 0 ? m_ctx.particle_bc_lo[d] : m_ctx.particle_bc_hi[d]) = want;
+                m_ctx.any_particle_wall = m_ctx.any_particle_wall || want != WXA_PBOUNDARY_PERIODIC;
+                m_any_reflecting_wall = m_any_reflecting_wall || want == WXA_PBOUNDARY_REFLECTING;
+            }
 
         // AllocLevelMFs (Source/WarpX.cpp:2078-2700): Yee nodal flags :2117-2125
         const amrex::IntVect Etype[3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
@@ -317,7 +332,7 @@ public:
     // WarpXEvolve.cpp:533-581
     void HandleParticlesAtBoundaries(int step, amrex::Real /*cur_time*/, int num_moved) {
         PhaseTimer t(&m_ctx, kRedistribute);
-        // ApplyBoundaryConditions: early return, all particle boundaries periodic
+        mypc->ApplyBoundaryConditions();                                      // :537
         mypc->RedistributeLocal(num_moved + 1, *m_comm);                      // :559
         (void)step;  // :575-580 SortParticlesByBin: done between push and deposition (see Evolve)
     }
@@ -329,6 +344,7 @@ public:
     amrex::Real getdt(int lev) const { return dt[lev]; }
     int64_t getistep() const { return istep; }
     BrickComm& comm() { return *m_comm; }
+    bool any_reflecting_wall() const { return m_any_reflecting_wall; }
 
     guardCellManager guard_cells;
     bool use_filter = true;          // Source/WarpX.cpp:158
@@ -338,6 +354,7 @@ public:
     // WarpX::field_boundary_lo / field_boundary_hi restricted to periodic | PEC
     int32_t m_pec_lo[3] = {0, 0, 0}, m_pec_hi[3] = {0, 0, 0}, m_dom_lo[3] = {0, 0, 0}, m_dom_hi[3] = {0, 0, 0};
     bool m_any_pec = false;
+    bool m_any_reflecting_wall = false;
 
 private:
     void FillBoundaryVector(warpx::fields::FieldType ft, const amrex::IntVect& ng, bool nodal_sync) {

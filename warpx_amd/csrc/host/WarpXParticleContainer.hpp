@@ -29,6 +29,10 @@ struct WarpXContext {
     amrex::IntVect ng_alloc_EB, ng_depos_J;
     void* stream = nullptr;
     bool sort_now = false;             // this step re-sorts the tiles (sort_intervals)
+    // boundary.particle_lo/hi resolved to WXA_PBOUNDARY_PERIODIC / _ABSORBING / _REFLECTING
+    int32_t particle_bc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
+    int32_t particle_bc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
+    bool any_particle_wall = false;
     // per-phase device timers, named after the reference's profiler regions
     bool timers_on = false;
     double ms[8] = {0};
@@ -192,6 +196,19 @@ public:
         }
     }
 
+    // WarpXParticleContainer::ApplyBoundaryConditions (WarpXParticleContainer.cpp:1574-1660): reflecting and
+    // absorbing walls; absorbed particles are retired in place and dropped by the next sort, like the
+    // particles handed to a neighbour brick
+    void ApplyBoundaryConditions() {
+        if (!m_ctx->any_particle_wall || m_tile.numParticles() == 0) return;   // :1578 all periodic
+        const wxa_particle_view p = m_tile.view();
+        int64_t lost = 0;
+        check(m_ctx->be->apply_particle_boundaries(&p, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), m_ctx->particle_bc_lo,
+                                                   m_ctx->particle_bc_hi, &lost, m_ws, m_ctx->stream),
+              "apply_particle_boundaries");
+        m_nretired += lost;
+    }
+
     // amrex ParticleContainer::Redistribute restricted to what the periodic brick decomposition
     // needs: periodic wrap, then hand the particles that left the brick to the +/- neighbour,
     // direction by direction (a particle moves < 1 cell per step, so corners take up to three
@@ -201,7 +218,7 @@ public:
     // LDS-tile kernels rely on survives between sorts.
     void Redistribute(BrickComm& comm) {
         const Backend* be = m_ctx->be;
-        // particles wrap only along the periodic directions (nothing handles them at a PEC face yet)
+        // particles wrap only along the periodic directions (walls: ApplyBoundaryConditions)
         const int periodic[3] = {comm.periodic(0) ? 1 : 0, comm.periodic(1) ? 1 : 0, comm.periodic(2) ? 1 : 0};
         const int none[3] = {0, 0, 0};
         int split[3];
@@ -404,6 +421,10 @@ public:
                const amrex::MultiFab& Bz) {
         PhaseTimer t(m_ctx, kOther);  // (de)synchronisation half-pushes, twice per Evolve call
         for (auto& pc : allcontainers) pc->PushP(lev, dt, Ex, Ey, Ez, Bx, By, Bz);
+    }
+    // Source/Particles/MultiParticleContainer.cpp (ApplyBoundaryConditions over all species)
+    void ApplyBoundaryConditions() {
+        for (auto& pc : allcontainers) pc->ApplyBoundaryConditions();
     }
     // :651-654
     void RedistributeLocal(int /*num_ghost*/, BrickComm& comm) {

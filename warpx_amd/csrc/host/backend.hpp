@@ -58,6 +58,9 @@ struct Backend {
     int (*pack_leavers)(const wxa_particle_view*, const int32_t* list, int64_t n, void* msg, int64_t row_len,
                         int64_t offset, int retire, const double* brick_lo, const double* brick_hi, void*);
     int (*sort_live_count)(void* ws, int64_t* n, void*);
+    // WarpXParticleContainer::ApplyBoundaryConditions (reflecting / absorbing walls); *n_lost valid on return
+    int (*apply_particle_boundaries)(const wxa_particle_view*, const double* prob_lo, const double* prob_hi,
+                                     const int32_t* bc_lo, const int32_t* bc_hi, int64_t* n_lost, void* ws, void*);
     // ---- workspace ----
     int (*workspace_create)(void** ws);
     void (*workspace_destroy)(void* ws);

@@ -33,6 +33,9 @@ inline int sim_add_species(SimHandle* h, double charge, double mass, const wxa_p
     if (!h || !init || init->np < 0) return WXA_ERR_INVALID_ARG;
     try {
         WarpX& w = *h->warpx;
+        if (charge != 0.0 && w.any_reflecting_wall())
+            throw std::runtime_error("charged species with a reflecting particle boundary: the current fold at the "
+                                     "walls has the image-charge sign of absorbing walls only");
         const int sid = w.GetPartContainer().AddSpecies(charge, mass);
         ParticleTile& t = w.GetPartContainer().GetParticleContainer(sid).tile();
         t.resize(init->np);

@@ -107,6 +107,10 @@ const Backend* hip_backend() {
             return wxa_apply_pec_b(B, dlo, dhi, plo, phi, ng, st); };
         b.apply_pec_j = [](const wxa_field_view* J, const int32_t* dlo, const int32_t* dhi, const int32_t* plo,
                            const int32_t* phi, void* st) -> int { return wxa_apply_pec_j(J, dlo, dhi, plo, phi, st); };
+        b.apply_particle_boundaries = [](const wxa_particle_view* p, const double* plo, const double* phi,
+                                         const int32_t* blo, const int32_t* bhi, int64_t* n_lost, void* ws,
+                                         void* st) -> int {
+            return wxa_apply_particle_boundaries(p, plo, phi, blo, bhi, n_lost, static_cast<wxa_workspace*>(ws), st); };
         b.sort_live_count = [](void* ws, int64_t* n, void* st) -> int {
             return wxa_sort_live_count(static_cast<wxa_workspace*>(ws), n, st); };
         b.workspace_create = ws_create;

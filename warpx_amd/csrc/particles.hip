@@ -218,6 +218,46 @@ static inline wxa_particle_view tail_view(const wxa_particle_view& p, int64_t fi
     return t;
 }
 
+// ---- particle walls: WarpXParticleContainer::ApplyBoundaryConditions -------------------------------
+struct WallGeom {
+    double lo[3], hi[3];
+    int bc_lo[3], bc_hi[3];   // WXA_PBOUNDARY_*
+};
+
+// apply_boundary / apply_boundaries (Source/Particles/ParticleBoundaries_K.H:20-175): beyond a reflecting
+// wall the position is mirrored and the normal momentum flips; beyond an absorbing wall the particle is
+// lost = retired in place (weight and momentum 0, position clamped into the domain, idcpu marked).
+__global__ void __launch_bounds__(256)
+particle_walls_kernel(PV p, WallGeom wg, unsigned* __restrict__ n_lost) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.np) return;
+    if (p.id[ip] == WXA_IDCPU_RETIRED) return;
+    double x[3] = {p.x[ip], p.y[ip], p.z[ip]};
+    bool lost = false, flip[3] = {false, false, false}, moved = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (x[d] < wg.lo[d]) {
+            if (wg.bc_lo[d] == WXA_PBOUNDARY_ABSORBING) lost = true;
+            else if (wg.bc_lo[d] == WXA_PBOUNDARY_REFLECTING) { x[d] = 2 * wg.lo[d] - x[d]; flip[d] = true; moved = true; }
+        } else if (x[d] > wg.hi[d]) {
+            if (wg.bc_hi[d] == WXA_PBOUNDARY_ABSORBING) lost = true;
+            else if (wg.bc_hi[d] == WXA_PBOUNDARY_REFLECTING) { x[d] = 2 * wg.hi[d] - x[d]; flip[d] = true; moved = true; }
+        }
+    }
+    if (lost) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) x[d] = fmin(fmax(x[d], wg.lo[d]), nextafter(wg.hi[d], wg.lo[d]));
+        p.x[ip] = x[0]; p.y[ip] = x[1]; p.z[ip] = x[2];
+        p.w[ip] = 0.0; p.ux[ip] = 0.0; p.uy[ip] = 0.0; p.uz[ip] = 0.0;
+        p.id[ip] = WXA_IDCPU_RETIRED;
+        atomicAdd(n_lost, 1u);
+    } else if (moved) {
+        if (flip[0]) { p.x[ip] = x[0]; p.ux[ip] = -p.ux[ip]; }
+        if (flip[1]) { p.y[ip] = x[1]; p.uy[ip] = -p.uy[ip]; }
+        if (flip[2]) { p.z[ip] = x[2]; p.uz[ip] = -p.uz[ip]; }
+    }
+}
+
 // ---- Redistribute without moving the tile (see include/warpx_amd.h) --------------------
 struct ClassifyGeom {
     double plo[3], phi[3], blo[3], bhi[3];
@@ -567,6 +607,38 @@ wxa_status wxa_pack_leavers(const wxa_particle_view* p, const int32_t* list, int
     hipLaunchKernelGGL(pack_leavers_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, make_pv(*p),
                        list, (long)n, (double*)msg, (long)row_len, (long)offset, retire, cg);
     WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_apply_particle_boundaries(const wxa_particle_view* p, const double prob_lo[3],
+                                         const double prob_hi[3], const int32_t bc_lo[3], const int32_t bc_hi[3],
+                                         int64_t* n_lost, wxa_workspace* ws, void* stream) {
+    WXA_REQUIRE(pv_ok(p) && prob_lo && prob_hi && bc_lo && bc_hi && ws, "bad argument");
+    if (n_lost) *n_lost = 0;
+    bool any = false;
+    WallGeom wg;
+    for (int d = 0; d < 3; ++d) {
+        WXA_REQUIRE(prob_hi[d] > prob_lo[d], "empty domain");
+        wg.lo[d] = prob_lo[d]; wg.hi[d] = prob_hi[d];
+        wg.bc_lo[d] = bc_lo[d]; wg.bc_hi[d] = bc_hi[d];
+        any = any || bc_lo[d] == WXA_PBOUNDARY_ABSORBING || bc_lo[d] == WXA_PBOUNDARY_REFLECTING ||
+              bc_hi[d] == WXA_PBOUNDARY_ABSORBING || bc_hi[d] == WXA_PBOUNDARY_REFLECTING;
+    }
+    if (!any || p->np == 0) return WXA_OK;
+    WXA_REQUIRE(p->idcpu, "idcpu is needed to retire absorbed particles");
+    hipStream_t st = (hipStream_t)stream;
+    wxa_status rc;
+    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    unsigned* dcount = (unsigned*)ws->counters.p + 48;
+    WXA_HIP_CHECK(hipMemsetAsync(dcount, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(particle_walls_kernel, dim3(blocks_for(p->np)), dim3(256), 0, st, make_pv(*p), wg, dcount);
+    WXA_LAUNCH_CHECK();
+    if (n_lost) {
+        unsigned h = 0;
+        WXA_HIP_CHECK(hipMemcpyAsync(&h, dcount, sizeof(h), hipMemcpyDeviceToHost, st));
+        WXA_HIP_CHECK(hipStreamSynchronize(st));
+        *n_lost = h;
+    }
     return WXA_OK;
 }
 

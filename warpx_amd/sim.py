@@ -20,7 +20,8 @@ class WarpXSim:
     def __init__(self, lib: _capi.CLib, n_cell, prob_lo, prob_hi, nox=1, galerkin=1,
                  particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
                  use_filter=0, cfl=1.0, sort_interval=-1, nbricks=(1, 1, 1), coord=(0, 0, 0),
-                 comm: _capi.Comm | None = None, field_boundary_lo=(0, 0, 0), field_boundary_hi=(0, 0, 0)):
+                 comm: _capi.Comm | None = None, field_boundary_lo=(0, 0, 0), field_boundary_hi=(0, 0, 0),
+                 particle_boundary_lo=(0, 0, 0), particle_boundary_hi=(0, 0, 0)):
         self.lib = lib
         self.on_device = lib.prefix == "wxa_"
         cfg = _capi.SimConfig()
@@ -32,6 +33,8 @@ class WarpXSim:
             cfg.coord[d] = int(coord[d])
             cfg.field_boundary_lo[d] = int(field_boundary_lo[d])   # _capi.BOUNDARY_PERIODIC / BOUNDARY_PEC
             cfg.field_boundary_hi[d] = int(field_boundary_hi[d])
+            cfg.particle_boundary_lo[d] = int(particle_boundary_lo[d])   # _capi.PBOUNDARY_*
+            cfg.particle_boundary_hi[d] = int(particle_boundary_hi[d])
         cfg.cfl = float(cfl)
         cfg.nox = int(nox)
         cfg.galerkin = int(galerkin)
