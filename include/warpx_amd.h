@@ -365,6 +365,37 @@ typedef struct wxa_sim_config {
     int32_t particle_boundary_hi[3]; /* boundary.particle_hi                                             */
 } wxa_sim_config;
 
+/* ---- second "next" row: moving window, continuous plasma injection, laser antenna -----------------
+ * (what Examples/Physics_applications/laser_acceleration needs on top of the PEC walls; CPU
+ * restatement pinned to the reference's test_3d_laser_acceleration golden checksums) */
+
+/* warpx.do_moving_window / moving_window_dir / moving_window_v (Source/Utils/WarpXMovingWindow.cpp:138-476):
+ * after every step the window position advances by v c dt; when it has crossed whole cells the
+ * fields are shifted by that many cells (zeros enter), prob_lo/hi move, and species with continuous
+ * injection receive new plasma in the cells that entered.  The window direction must be unsplit. */
+typedef struct wxa_moving_window {
+    int32_t dir;     /* 0,1,2 */
+    double  v;       /* in units of c (> 0: towards +dir) */
+} wxa_moving_window;
+
+/* <species>.injection_style = NUniformPerCell with a constant density, at rest, inside
+ * [lo, hi) (xmin..zmax), <species>.do_continuous_injection = 1
+ * (PhysicalParticleContainer::AddPlasma, Source/Particles/PhysicalParticleContainer.cpp:924-1333;
+ * ContinuousInjection :2518-2528) */
+typedef struct wxa_plasma_injector {
+    double  density;        /* <species>.density, m^-3              */
+    int32_t ppc[3];         /* num_particles_per_cell_each_dim      */
+    double  lo[3], hi[3];   /* xmin,ymin,zmin / xmax,ymax,zmax (+-1e300 = unbounded) */
+} wxa_plasma_injector;
+
+/* lasers.names / <laser>.profile = Gaussian (Source/Particles/LaserParticleContainer.cpp,
+ * Source/Laser/LaserProfilesImpl/LaserProfileGaussian.cpp), lab frame, no space-time couplings */
+typedef struct wxa_laser_antenna {
+    double position[3], direction[3], polarization[3];
+    double e_max, wavelength;
+    double waist, duration, t_peak, focal_distance;   /* profile_* */
+} wxa_laser_antenna;
+
 /* Neighbour exchange supplied by the host program (torch.distributed over
  * RCCL in bench.py; absent = single brick, all directions self-periodic).
  * Replaces the MPI layer under amrex FabArray::FillBoundary/SumBoundary and

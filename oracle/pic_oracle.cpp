@@ -9,6 +9,8 @@
 // checksums (FieldEnergy, ParticleEnergy, ParticleMomentum, cell-centred sum|Q|).
 #include "pic_kernels.hpp"
 
+#include <climits>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -413,47 +415,71 @@ extern "C" {
 // image charge (psign = -1 for the components tangential to the wall, +1 for the normal one), a
 // component living on the wall is zeroed there, and the guard cells then receive the image of the
 // updated interior values (odd for tangential, even for normal components).
+}  // extern "C"
+
+namespace {
+// SetRhoOrJfieldFromPEC (:354-420) over the valid box of one array; tangent[d]: odd image along d
+// (psign -1), otherwise even (psign +1) -- absorbing particle boundaries
+void reflect_over_pec(const wxa_field_view& f, const bool tangent[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
+                      const int32_t pec_lo[3], const int32_t pec_hi[3]) {
+    const Arr a(f);
+    int mirrorfac[3][2];
+    for (int d = 0; d < 3; ++d) {
+        // the domain box made nodal: [dom_lo, dom_hi + 1]  (:729-733, :800-805; rho :640-676)
+        mirrorfac[d][0] = 2 * dom_lo[d] - (1 - f.stag[d]);
+        mirrorfac[d][1] = 2 * (dom_hi[d] + 1) - (1 - f.stag[d]);
+    }
+    auto in_fab = [&](const int v[3]) {
+        for (int d = 0; d < 3; ++d)
+            if (v[d] < f.lo[d] || v[d] >= f.lo[d] + f.n[d]) return false;
+        return true;
+    };
+    for (int k = vlo(f, 2); k < vhi(f, 2); ++k)
+        for (int j = vlo(f, 1); j < vhi(f, 1); ++j)
+            for (int i = vlo(f, 0); i < vhi(f, 0); ++i) {
+                const int ijk[3] = {i, j, k};
+                for (int d = 0; d < 3; ++d)
+                    for (int side = 0; side < 2; ++side) {
+                        if (!(side == 0 ? pec_lo[d] : pec_hi[d])) continue;
+                        int m[3] = {i, j, k};
+                        m[d] = mirrorfac[d][side] - ijk[d];
+                        if (m[d] == ijk[d]) a(i, j, k) = 0.0;
+                        else if (in_fab(m)) a(i, j, k) += (tangent[d] ? -1.0 : 1.0) * a(m[0], m[1], m[2]);
+                    }
+                for (int d = 0; d < 3; ++d)
+                    for (int side = 0; side < 2; ++side) {
+                        if (!(side == 0 ? pec_lo[d] : pec_hi[d])) continue;
+                        int m[3] = {i, j, k};
+                        m[d] = mirrorfac[d][side] - ijk[d];
+                        if (m[d] != ijk[d] && in_fab(m)) a(m[0], m[1], m[2]) = tangent[d] ? -a(i, j, k) : a(i, j, k);
+                    }
+            }
+}
+}  // namespace
+
+extern "C" {
+
+// PEC::ApplyReflectiveBoundarytoJfield (:713-900) with SetRhoOrJfieldFromPEC (:354-420), for PEC field
+// boundaries with absorbing particle boundaries (the default next to a PEC wall): the current
+// deposited in the guard cells behind the wall is folded back onto its mirror cell with the sign of an
+// image charge (psign = -1 for the components tangential to the wall, +1 for the normal one), a
+// component living on the wall is zeroed there, and the guard cells then receive the image of the
+// updated interior values (odd for tangential, even for normal components).
 int orc_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
                     const int32_t pec_lo[3], const int32_t pec_hi[3], void*) {
     for (int c = 0; c < 3; ++c) {
-        const wxa_field_view& f = J[c];
-        const Arr a(f);
-        int mirrorfac[3][2];
-        double psign[3];
-        bool tangent[3];
-        for (int d = 0; d < 3; ++d) {
-            // the domain box made nodal: [dom_lo, dom_hi + 1]  (:729-733, :800-805)
-            mirrorfac[d][0] = 2 * dom_lo[d] - (1 - f.stag[d]);
-            mirrorfac[d][1] = 2 * (dom_hi[d] + 1) - (1 - f.stag[d]);
-            tangent[d] = c != d;
-            psign[d] = tangent[d] ? -1.0 : 1.0;
-        }
-        auto in_fab = [&](const int v[3]) {
-            for (int d = 0; d < 3; ++d)
-                if (v[d] < f.lo[d] || v[d] >= f.lo[d] + f.n[d]) return false;
-            return true;
-        };
-        for (int k = vlo(f, 2); k < vhi(f, 2); ++k)
-            for (int j = vlo(f, 1); j < vhi(f, 1); ++j)
-                for (int i = vlo(f, 0); i < vhi(f, 0); ++i) {
-                    const int ijk[3] = {i, j, k};
-                    for (int d = 0; d < 3; ++d)
-                        for (int side = 0; side < 2; ++side) {
-                            if (!(side == 0 ? pec_lo[d] : pec_hi[d])) continue;
-                            int m[3] = {i, j, k};
-                            m[d] = mirrorfac[d][side] - ijk[d];
-                            if (m[d] == ijk[d]) a(i, j, k) = 0.0;
-                            else if (in_fab(m)) a(i, j, k) += psign[d] * a(m[0], m[1], m[2]);
-                        }
-                    for (int d = 0; d < 3; ++d)
-                        for (int side = 0; side < 2; ++side) {
-                            if (!(side == 0 ? pec_lo[d] : pec_hi[d])) continue;
-                            int m[3] = {i, j, k};
-                            m[d] = mirrorfac[d][side] - ijk[d];
-                            if (m[d] != ijk[d] && in_fab(m)) a(m[0], m[1], m[2]) = tangent[d] ? -a(i, j, k) : a(i, j, k);
-                        }
-                }
+        const bool tangent[3] = {c != 0, c != 1, c != 2};
+        reflect_over_pec(J[c], tangent, dom_lo, dom_hi, pec_lo, pec_hi);
     }
+    return 0;
+}
+
+// PEC::ApplyReflectiveBoundarytoRhofield (:628-711): rho is treated like a tangential component along
+// every direction (:664-666)
+int orc_apply_pec_rho(const wxa_field_view* rho, const int32_t dom_lo[3], const int32_t dom_hi[3],
+                      const int32_t pec_lo[3], const int32_t pec_hi[3], void*) {
+    const bool tangent[3] = {true, true, true};
+    reflect_over_pec(*rho, tangent, dom_lo, dom_hi, pec_lo, pec_hi);
     return 0;
 }
 
@@ -794,6 +820,10 @@ struct Species {
     double q, m;
     std::vector<double> a[7];
     std::vector<uint64_t> id;
+    // <species>.do_continuous_injection with a NUniformPerCell constant-density injector
+    bool inject = false;
+    wxa_plasma_injector inj{};
+    double inj_pos = 0.0;   // WarpXParticleContainer::m_current_injection_position
     wxa_particle_view view() {
         wxa_particle_view p{};
         p.x = a[0].data(); p.y = a[1].data(); p.z = a[2].data(); p.w = a[3].data();
@@ -805,6 +835,17 @@ struct Species {
 };
 
 }  // namespace
+
+// LaserParticleContainer (Source/Particles/LaserParticleContainer.cpp): pairs of +-weight macro-particles
+// on the antenna plane, moved with a prescribed velocity proportional to the field to emit, depositing
+// current like any other species (charge 1, infinite mass).
+struct LaserAntenna {
+    wxa_laser_antenna cfg{};
+    double nvec[3], p_X[3], p_Y[3];   // plane normal, polarization, second polarization vector
+    double position[3];
+    double S_X = 0, S_Y = 0, mobility = 0, weight = 0;
+    Species parts;                    // q = 1 (:86), m irrelevant (never pushed by the fields)
+};
 
 struct orc_sim {
     wxa_sim_config cfg;
@@ -829,13 +870,21 @@ struct orc_sim {
     int32_t pbc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     int32_t pbc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     bool any_particle_wall = false;
+    // current physical domain (moves with the moving window)
+    double plo[3] = {0, 0, 0}, phi[3] = {0, 0, 0};
+    // warpx.do_moving_window
+    bool mw_on = false;
+    int mw_dir = 2;
+    double mw_v = 0.0;   // m/s
+    double mw_x = 0.0;   // WarpX::moving_window_x
+    std::vector<std::unique_ptr<struct LaserAntenna>> lasers;
 
     wxa_grid_geom geom_for(const int ng[3]) const {
         // WarpX::LowerCorner(box.grow(ng)) = prob_lo + box.lo * dx (Source/WarpX.cpp:2851-2875)
         wxa_grid_geom g{};
         for (int d = 0; d < 3; ++d) {
             g.lo[d] = -ng[d];
-            g.xyzmin[d] = cfg.prob_lo[d] + (double)(-ng[d]) * dx[d];
+            g.xyzmin[d] = plo[d] + (double)(-ng[d]) * dx[d];
             g.dinv[d] = dinv[d];
         }
         return g;
@@ -856,6 +905,218 @@ struct Tic {
     Tic(orc_sim* s_, int id_) : s(s_), id(id_), t0(s_->do_timers ? now_ms() : 0.0) {}
     ~Tic() { if (s->do_timers) { s->timers[id] += now_ms() - t0; s->counts[id]++; } }
 };
+
+
+// ---- plasma injection: PhysicalParticleContainer::AddPlasma (PhysicalParticleContainer.cpp:924-1333)
+// restricted to NUniformPerCell, constant density, at rest, lab frame, one box ------------------------
+void add_plasma(orc_sim* s, Species& sp, const double part_lo[3], const double part_hi[3]) {
+    const wxa_plasma_injector& in = sp.inj;
+    // find_overlap (Source/Particles/AddPlasmaUtilities.cpp:12-43) with tile_realbox = the whole domain
+    double olo[3], ohi[3];
+    int nov[3];
+    for (int d = 0; d < 3; ++d) {
+        const double tlo = s->plo[d], thi = s->phi[d], dx = s->dx[d];
+        if (!(tlo <= part_hi[d])) return;
+        olo[d] = part_lo[d] + std::max(std::floor((tlo - part_lo[d]) / dx), 0.0) * dx;
+        if (!(thi >= part_lo[d])) return;
+        ohi[d] = part_hi[d] - std::max(std::floor((part_hi[d] - thi) / dx), 0.0) * dx;
+        nov[d] = (int)std::round((ohi[d] - olo[d]) / dx);   // cells 0 .. nov-1
+    }
+    const int nppc = in.ppc[0] * in.ppc[1] * in.ppc[2];
+    const double scale_fac = s->dx[0] * s->dx[1] * s->dx[2] / nppc;   // compute_scale_fac_volume
+    auto inside = [&](double x, double y, double z) {   // InjectorPosition::insideBounds
+        return x < in.hi[0] && x >= in.lo[0] && y < in.hi[1] && y >= in.lo[1] && z < in.hi[2] && z >= in.lo[2];
+    };
+    for (int k = 0; k < nov[2]; ++k)
+        for (int j = 0; j < nov[1]; ++j)
+            for (int i = 0; i < nov[0]; ++i) {
+                const int iv[3] = {i, j, k};
+                double lo[3], hi[3];
+                for (int d = 0; d < 3; ++d) { lo[d] = olo[d] + (iv[d] + 0.0) * s->dx[d]; hi[d] = olo[d] + (iv[d] + 1.0) * s->dx[d]; }
+                // InjectorPosition::overlapsWith (:225-233): the cell overlaps the plasma region
+                bool overlaps = true;
+                for (int d = 0; d < 3; ++d) overlaps = overlaps && !(lo[d] > in.hi[d] || hi[d] < in.lo[d]);
+                if (!overlaps) continue;
+                // :1030-1048 corners or centre with non-zero density (constant density: inside bounds)
+                bool any = false;
+                for (int a = 0; a < 3 && !any; ++a)
+                    for (int b = 0; b < 3 && !any; ++b)
+                        for (int c = 0; c < 3 && !any; ++c) {
+                            const double x = a == 0 ? lo[0] : (a == 1 ? (lo[0] + hi[0]) / 2. : hi[0]);
+                            const double y = b == 0 ? lo[1] : (b == 1 ? (lo[1] + hi[1]) / 2. : hi[1]);
+                            const double z = c == 0 ? lo[2] : (c == 1 ? (lo[2] + hi[2]) / 2. : hi[2]);
+                            any = inside(x, y, z) && in.density > 0;
+                        }
+                if (!any) continue;
+                for (int ip = 0; ip < nppc; ++ip) {
+                    // InjectorPositionRegular::getPositionUnitBox (Source/Initialization/InjectorPosition.H:74-92)
+                    const int nx = in.ppc[0], ny = in.ppc[1], nz = in.ppc[2];
+                    const int ix_part = ip / (ny * nz);
+                    const int iz_part = (ip - ix_part * (ny * nz)) / ny;
+                    const int iy_part = (ip - ix_part * (ny * nz)) - ny * iz_part;
+                    const double r[3] = {(0.5 + ix_part) / nx, (0.5 + iy_part) / ny, (0.5 + iz_part) / nz};
+                    double pos[3];
+                    for (int d = 0; d < 3; ++d) pos[d] = olo[d] + (iv[d] + r[d]) * s->dx[d];   // getCellCoords
+                    // tile_realbox.contains (amrex RealBox::contains: strictly inside)
+                    bool in_tile = true;
+                    for (int d = 0; d < 3; ++d) in_tile = in_tile && pos[d] > s->plo[d] && pos[d] < s->phi[d];
+                    if (!in_tile || !inside(pos[0], pos[1], pos[2])) continue;
+                    for (int d = 0; d < 3; ++d) sp.a[d].push_back(pos[d]);
+                    sp.a[3].push_back(in.density * scale_fac);
+                    for (int d = 4; d < 7; ++d) sp.a[d].push_back(0.0);
+                    if (!sp.id.empty() || s->any_particle_wall) sp.id.resize(sp.a[0].size(), 0);
+                }
+            }
+}
+
+// ---- moving window: WarpX::shiftMF (Source/Utils/WarpXMovingWindow.cpp:478-648), zero external field ----
+void shift_field(orc_sim* s, Field& f, int num_shift, int dir) {
+    wxa_field_view& v = f.v;
+    std::vector<double> tmpdata(f.data);   // MultiFab::Copy(tmpmf, mf, ..., ng)
+    wxa_field_view tv = v;
+    tv.p = tmpdata.data();
+    // FillBoundary(tmpmf, ng_mw, periodicity): one guard cell, num_shift along the window direction
+    int ng_mw[3] = {1, 1, 1};
+    ng_mw[dir] = num_shift;
+    for (int d = 0; d < 3; ++d) ng_mw[d] = std::min(ng_mw[d], (int)v.ng[d]);
+    orc_fill_boundary_periodic(&tv, ng_mw, s->periodic, nullptr);
+    const Arr src(tv), dst(v);
+    // the region the window moved into takes the external field (0): adjCellHi(domain, dir, ng) in the
+    // field's index type, without the boundary node of a nodal direction, grown by ng transversally
+    const int vhi_d = vhi(v, dir);   // exclusive end of the valid points along dir
+    int zlo[3], zhi[3];
+    for (int d = 0; d < 3; ++d) { zlo[d] = v.lo[d]; zhi[d] = v.lo[d] + v.n[d]; }
+    zlo[dir] = vhi_d;                // first point beyond the domain (cell dom_hi+1 / node dom_hi+2)
+    zhi[dir] = vhi_d + v.ng[dir];
+    for (int k = zlo[2]; k < zhi[2]; ++k)
+        for (int j = zlo[1]; j < zhi[1]; ++j)
+            for (int i = zlo[0]; i < zhi[0]; ++i) src(i, j, k) = 0.0;
+    // dst(i) = src(i + shift) on the fab box shrunk by num_shift on the high side
+    int dlo[3], dhi[3];
+    for (int d = 0; d < 3; ++d) { dlo[d] = v.lo[d]; dhi[d] = v.lo[d] + v.n[d]; }
+    dhi[dir] -= num_shift;
+    int sh[3] = {0, 0, 0};
+    sh[dir] = num_shift;
+    for (int k = dlo[2]; k < dhi[2]; ++k)
+        for (int j = dlo[1]; j < dhi[1]; ++j)
+            for (int i = dlo[0]; i < dhi[0]; ++i) dst(i, j, k) = src(i + sh[0], j + sh[1], k + sh[2]);
+}
+
+// WarpX::MoveWindow (:138-476): forward window, lab frame, plasma at rest
+int move_window(orc_sim* s, bool move_j) {
+    if (!s->mw_on) return 0;
+    s->mw_x += s->mw_v * s->dt;                                   // :158
+    const int dir = s->mw_dir;
+    const double cdx = s->dx[dir];
+    const int num_shift = (int)((s->mw_x - s->plo[dir]) / cdx);   // :171
+    if (num_shift == 0) return 0;
+    s->plo[dir] += num_shift * cdx;                               // :181-184
+    s->phi[dir] += num_shift * cdx;
+    for (int c = 0; c < 3; ++c) {                                 // :222-246
+        shift_field(s, s->B[c], num_shift, dir);
+        shift_field(s, s->E[c], num_shift, dir);
+        if (move_j) shift_field(s, s->J[c], num_shift, dir);
+    }
+    if (move_j) shift_field(s, s->rho, num_shift, dir);           // :365-375
+    for (auto& sp : s->species) {                                 // :392-437 continuous injection
+        if (!sp->inject) continue;
+        const double new_pos = sp->inj_pos + std::floor((s->phi[dir] - sp->inj_pos) / cdx) * cdx;
+        double blo[3] = {s->plo[0], s->plo[1], s->plo[2]}, bhi[3] = {s->phi[0], s->phi[1], s->phi[2]};
+        blo[dir] = sp->inj_pos;
+        bhi[dir] = new_pos;
+        if (bhi[dir] > blo[dir] && sp->inj_pos != new_pos) {      // particleBox.ok()
+            add_plasma(s, *sp, blo, bhi);
+            sp->inj_pos = new_pos;
+        }
+    }
+    return num_shift;
+}
+
+// ---- laser antenna --------------------------------------------------------------------------------
+// LaserParticleContainer::InitData (:360-559), 3-D, one process
+void laser_init(orc_sim* s, LaserAntenna& L) {
+    // ComputeSpacing (:727-762): eps = dx * 1e-50 vanishes next to |u| = 1 or keeps dx/eps huge for |u| = 0
+    const double eps = s->dx[0] * 1e-50;
+    auto spacing = [&](const double u[3]) {
+        return std::min(std::min(s->dx[0] / (std::abs(u[0]) + eps), s->dx[1] / (std::abs(u[1]) + eps)),
+                        s->dx[2] / (std::abs(u[2]) + eps));
+    };
+    L.S_X = spacing(L.p_X);
+    L.S_Y = spacing(L.p_Y);
+    // ComputeWeightMobility (:764-781)
+    L.mobility = 0.05 / L.cfg.e_max;
+    L.weight = PhysConst::ep0 / L.mobility;
+    L.weight *= L.S_X * L.S_Y;
+    // plane index range from the corners of the injection box (:418-457), truncation towards zero
+    int plo[2] = {INT_MAX, INT_MAX}, phi[2] = {INT_MIN, INT_MIN};
+    for (int c = 0; c < 8; ++c) {
+        const double pos[3] = {(c & 1) ? s->phi[0] : s->plo[0], (c & 2) ? s->phi[1] : s->plo[1],
+                               (c & 4) ? s->phi[2] : s->plo[2]};
+        double X = 0, Y = 0;
+        for (int d = 0; d < 3; ++d) { X += L.p_X[d] * (pos[d] - L.position[d]); Y += L.p_Y[d] * (pos[d] - L.position[d]); }
+        const int i = (int)(X / L.S_X), j = (int)(Y / L.S_Y);
+        plo[0] = std::min(plo[0], i); plo[1] = std::min(plo[1], j);
+        phi[0] = std::max(phi[0], i); phi[1] = std::max(phi[1], j);
+    }
+    // Box::next order: first index fastest (:503)
+    for (int j = plo[1]; j <= phi[1]; ++j)
+        for (int i = plo[0]; i <= phi[0]; ++i) {
+            double pos[3];
+            for (int d = 0; d < 3; ++d)   // Transform (:389-398)
+                pos[d] = L.position[d] + (L.S_X * ((double)i + 0.5)) * L.p_X[d] + (L.S_Y * ((double)j + 0.5)) * L.p_Y[d];
+            bool inside = true;           // RealBox::contains: strictly inside
+            for (int d = 0; d < 3; ++d) inside = inside && pos[d] > s->plo[d] && pos[d] < s->phi[d];
+            if (!inside) continue;
+            for (int k = 0; k < 2; ++k) {
+                for (int d = 0; d < 3; ++d) L.parts.a[d].push_back(pos[d]);
+                L.parts.a[3].push_back(k == 0 ? L.weight : -L.weight);
+                for (int d = 4; d < 7; ++d) L.parts.a[d].push_back(0.0);
+            }
+        }
+    if (s->any_particle_wall) L.parts.id.assign(L.parts.a[0].size(), 0);
+}
+
+// LaserParticleContainer::Evolve (:563-713): plane coordinates, Gaussian amplitude
+// (LaserProfileGaussian.cpp:104-161 with zeta = beta = phi2 = phi0 = 0), update_laser_particle (:850-951)
+void laser_push(orc_sim* s, LaserAntenna& L, double t, double dt) {
+    using cplx = std::complex<double>;
+    const cplx I(0, 1);
+    const wxa_laser_antenna& c = L.cfg;
+    const double k0 = 2. * M_PI / c.wavelength;
+    const double inv_tau2 = 1. / (c.duration * c.duration);
+    const double oscillation_phase = k0 * PhysConst::c * (t - c.t_peak) + 0.0;
+    const cplx diffract_factor = 1. + I * c.focal_distance * 2. / (k0 * c.waist * c.waist);
+    const cplx inv_complex_waist_2 = 1. / (c.waist * c.waist * diffract_factor);
+    const cplx stretch_factor = 1. + 4. * (0.0 + 0.0 * c.focal_distance * inv_tau2) * (0.0 + 0.0 * c.focal_distance * inv_complex_waist_2) +
+                                2. * I * (0.0 - 0.0 * 0.0 * k0 * c.focal_distance) * inv_tau2;
+    const cplx t_prefactor = c.e_max * std::exp(I * oscillation_phase);
+    const cplx prefactor = t_prefactor / diffract_factor;
+    const int64_t np = (int64_t)L.parts.a[0].size();
+    for (int64_t i = 0; i < np; ++i) {
+        double x = L.parts.a[0][i], y = L.parts.a[1][i], z = L.parts.a[2][i];
+        // calculate_laser_plane_coordinates (:795-847)
+        const double Xp = L.p_X[0] * (x - L.position[0]) + L.p_X[1] * (y - L.position[1]) + L.p_X[2] * (z - L.position[2]);
+        const double Yp = L.p_Y[0] * (x - L.position[0]) + L.p_Y[1] * (y - L.position[1]) + L.p_Y[2] * (z - L.position[2]);
+        const cplx arg = t - c.t_peak - 0.0 * k0 * (Xp * 1.0 + Yp * 0.0) -
+                         2. * I * (Xp * 1.0 + Yp * 0.0) * (0.0 - 0.0 * c.focal_distance) * inv_complex_waist_2;
+        const cplx stc_exponent = 1. / stretch_factor * inv_tau2 * (arg * arg);
+        const cplx stcfactor = prefactor * std::exp(-stc_exponent);
+        const cplx exp_argument = -(Xp * Xp + Yp * Yp) * inv_complex_waist_2;
+        const double amplitude = (stcfactor * std::exp(exp_argument)).real();
+        // update_laser_particle
+        const double sign_charge = (L.parts.a[3][i] > 0) ? -1 : 1;
+        const double v_over_c = sign_charge * L.mobility * amplitude;
+        const double vx = PhysConst::c * v_over_c * L.p_X[0];
+        const double vy = PhysConst::c * v_over_c * L.p_X[1];
+        const double vz = PhysConst::c * v_over_c * L.p_X[2];
+        const double gamma = 1. / std::sqrt(1. - v_over_c * v_over_c);
+        L.parts.a[4][i] = gamma * vx;
+        L.parts.a[5][i] = gamma * vy;
+        L.parts.a[6][i] = gamma * vz;
+        x += vx * dt; y += vy * dt; z += vz * dt;
+        L.parts.a[0][i] = x; L.parts.a[1][i] = y; L.parts.a[2][i] = z;
+    }
+}
 
 void fill_boundary_EB(orc_sim* s, wxa_field_view* F, const int ng[3], bool sync) {
     Tic t(s, 5);
@@ -895,6 +1156,11 @@ void one_step_nosub(orc_sim* s) {
             orc_deposit_current(&p, s->Jv, &gJ, sp->q, dt, -0.5 * dt, s->cfg.nox, s->cfg.current_deposition,
                                 nullptr, nullptr);
         }
+    }
+    for (auto& L : s->lasers) {   // LaserParticleContainer::Evolve (:563-713): lasers come after the species
+        laser_push(s, *L, s->cur_time, dt);
+        wxa_particle_view p = L->parts.view();
+        orc_deposit_current(&p, s->Jv, &gJ, 1.0, dt, -0.5 * dt, s->cfg.nox, s->cfg.current_deposition, nullptr, nullptr);
     }
     {   // SyncCurrentAndRho (:583-652) -> SyncCurrent (WarpXComm.cpp:1073-1240)
         Tic t(s, 2);
@@ -947,6 +1213,8 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
     s->cfg = *cfg;
     for (int d = 0; d < 3; ++d) {
         s->dx[d] = (cfg->prob_hi[d] - cfg->prob_lo[d]) / cfg->n_cell[d];
+        s->plo[d] = cfg->prob_lo[d];
+        s->phi[d] = cfg->prob_hi[d];
         s->dinv[d] = 1.0 / s->dx[d];
     }
     // Source/Evolve/WarpXComputeDt.cpp:41-102 + CartesianYeeAlgorithm::ComputeMaxDt (:48-56)
@@ -1047,6 +1315,11 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
         }
         s->istep++;
         s->cur_time += s->dt;
+        move_window(s, /*move_j=*/s->is_synchronized);   // :246 MoveWindow(step+1, move_j)
+        for (auto& L : s->lasers) {   // lasers are particle containers too: periodic wrap (they never reach a wall)
+            wxa_particle_view p = L->parts.view();
+            orc_enforce_periodic(&p, s->plo, s->phi, s->periodic, nullptr);
+        }
         {   // HandleParticlesAtBoundaries (:533-581): ApplyBoundaryConditions, then the periodic wrap of Redistribute
             Tic t(s, 6);
             for (auto& sp : s->species) {
@@ -1054,7 +1327,7 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
                     if (sp->id.empty()) sp->id.assign(sp->a[0].size(), 0);
                     wxa_particle_view p = sp->view();
                     int64_t lost = 0;
-                    orc_apply_particle_boundaries(&p, s->cfg.prob_lo, s->cfg.prob_hi, s->pbc_lo, s->pbc_hi, &lost,
+                    orc_apply_particle_boundaries(&p, s->plo, s->phi, s->pbc_lo, s->pbc_hi, &lost,
                                                   nullptr, nullptr);
                     if (lost > 0) {   // Redistribute drops the invalidated particles
                         size_t keep = 0;
@@ -1069,10 +1342,55 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
                     }
                 }
                 wxa_particle_view p = sp->view();
-                orc_enforce_periodic(&p, s->cfg.prob_lo, s->cfg.prob_hi, s->periodic, nullptr);
+                orc_enforce_periodic(&p, s->plo, s->phi, s->periodic, nullptr);
             }
         }
     }
+    return 0;
+}
+
+// warpx.do_moving_window (Source/WarpX.cpp:640-660): the window starts at prob_lo
+int orc_sim_set_moving_window(orc_sim* s, const wxa_moving_window* mw) {
+    if (!s || !mw || mw->dir < 0 || mw->dir > 2 || !(mw->v > 0.0)) return -1;
+    if (s->periodic[mw->dir]) return -2;   // the window direction cannot be periodic
+    s->mw_on = true;
+    s->mw_dir = mw->dir;
+    s->mw_v = mw->v * PhysConst::c;
+    s->mw_x = s->plo[mw->dir];
+    for (auto& sp : s->species) sp->inj_pos = s->phi[mw->dir];   // Source/WarpX.cpp:301
+    return 0;
+}
+
+// <species>.injection_style = NUniformPerCell, profile = constant, momentum at_rest (+ continuous injection):
+// add_initial != 0 fills the current domain now (PhysicalParticleContainer::InitData -> AddParticles)
+int orc_sim_set_injection(orc_sim* s, int32_t id, const wxa_plasma_injector* inj, int add_initial, int continuous) {
+    if (!s || !inj || id < 0 || id >= (int32_t)s->species.size()) return -1;
+    Species& sp = *s->species[id];
+    sp.inj = *inj;
+    sp.inject = continuous != 0;
+    sp.inj_pos = s->mw_on ? s->phi[s->mw_dir] : 0.0;
+    if (add_initial) add_plasma(s, sp, s->plo, s->phi);
+    return 0;
+}
+
+int orc_sim_add_laser(orc_sim* s, const wxa_laser_antenna* la) {
+    if (!s || !la || !(la->e_max > 0) || !(la->wavelength > 0)) return -1;
+    auto L = std::make_unique<LaserAntenna>();
+    L->cfg = *la;
+    L->parts.q = 1.0; L->parts.m = 1e300;
+    double n = 0, p = 0;
+    for (int d = 0; d < 3; ++d) { n += la->direction[d] * la->direction[d]; p += la->polarization[d] * la->polarization[d]; }
+    const double sn = 1.0 / std::sqrt(n), spx = 1.0 / std::sqrt(p);
+    for (int d = 0; d < 3; ++d) { L->nvec[d] = la->direction[d] * sn; L->p_X[d] = la->polarization[d] * spx; L->position[d] = la->position[d]; }
+    double dp = 0;
+    for (int d = 0; d < 3; ++d) dp += L->nvec[d] * L->p_X[d];
+    if (std::abs(dp) >= 1e-14) return -2;   // polarization must lie in the antenna plane
+    // p_Y = nvec x p_X (:222)
+    L->p_Y[0] = L->nvec[1] * L->p_X[2] - L->nvec[2] * L->p_X[1];
+    L->p_Y[1] = L->nvec[2] * L->p_X[0] - L->nvec[0] * L->p_X[2];
+    L->p_Y[2] = L->nvec[0] * L->p_X[1] - L->nvec[1] * L->p_X[0];
+    laser_init(s, *L);
+    s->lasers.push_back(std::move(L));
     return 0;
 }
 
@@ -1106,6 +1424,13 @@ int orc_sim_compute_rho(orc_sim* s) {
         wxa_particle_view p = sp->view();
         orc_deposit_charge(&p, &s->rho.v, &g, sp->q, s->cfg.nox, nullptr);
     }
+    for (auto& L : s->lasers) {
+        wxa_particle_view p = L->parts.view();
+        orc_deposit_charge(&p, &s->rho.v, &g, 1.0, s->cfg.nox, nullptr);
+    }
+    // WarpXParticleContainer::DepositCharge (:1285-1290): each species' rho is reflected over the PEC walls
+    // right after its deposition (linear: done once on the total), before the filter and the sum
+    if (s->any_pec) orc_apply_pec_rho(&s->rho.v, s->dom_lo, s->dom_hi, s->pec_lo, s->pec_hi, nullptr);
     if (s->cfg.use_filter) {
         Field tmp; tmp.v = s->rho.v; tmp.data.assign(s->rho.data.size(), 0.0); tmp.v.p = tmp.data.data();
         orc_filter_bilinear(&s->rho.v, &tmp.v, nullptr);

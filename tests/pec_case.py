@@ -86,3 +86,44 @@ def make_boundaries_sim(lib):
     absb = species([(0, -0.92, 0), (0, 0.93, 0), (0, 0, 0)], [(0, -0.92, 0), (0, 0.93, 0), (0, 0, 0)])
     peri = species([(0, 0, -0.94), (0, 0, 0.95)], [(0, 0, -0.94), (0, 0, 0.95)])
     return sim, refl, absb, peri
+
+
+# ---- Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration ----------------
+# Laser-wakefield stage in a window moving at c: PEC walls in z, Gaussian laser antenna, electrons at rest
+# injected continuously as the window advances (order 3, filter, cfl 1, 100 steps).
+L_N_CELL = (32, 32, 256)
+L_PROB_LO, L_PROB_HI = (-30e-6, -30e-6, -56e-6), (30e-6, 30e-6, 12e-6)
+L_MAX_STEP = 100
+M_E_ = 9.1093837015e-31
+
+
+def make_lwfa_sim(lib):
+    """Only the CPU restatement has these features so far (lib = the oracle)."""
+    import ctypes as C
+    sim = WarpXSim(lib, L_N_CELL, L_PROB_LO, L_PROB_HI, nox=3, galerkin=1, use_filter=1, cfl=1.0, sort_interval=4,
+                   field_boundary_lo=(_capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PEC),
+                   field_boundary_hi=(_capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PEC))
+    mw = _capi.MovingWindow(dir=2, v=1.0)
+    lib.sim_set_moving_window(sim._h, C.byref(mw))
+    empty = [np.zeros(0) for _ in range(7)]
+    electrons = sim.add_species(-Q_E, M_E_, empty)
+    inj = _capi.PlasmaInjector()
+    inj.density = 2e23
+    for d in range(3):
+        inj.ppc[d] = 1
+    big = 1e300
+    inj.lo[0], inj.hi[0] = -20e-6, 20e-6
+    inj.lo[1], inj.hi[1] = -20e-6, 20e-6
+    inj.lo[2], inj.hi[2] = 0.0, big
+    lib.sim_set_injection(sim._h, electrons, C.byref(inj), 1, 1)
+    la = _capi.LaserAntenna()
+    for d, v in enumerate((0.0, 0.0, 9e-6)):
+        la.position[d] = v
+    for d, v in enumerate((0.0, 0.0, 1.0)):
+        la.direction[d] = v
+    for d, v in enumerate((0.0, 1.0, 0.0)):
+        la.polarization[d] = v
+    la.e_max, la.wavelength = 16e12, 0.8e-6
+    la.waist, la.duration, la.t_peak, la.focal_distance = 5e-6, 15e-15, 30e-15, 100e-6
+    lib.sim_add_laser(sim._h, C.byref(la))
+    return sim, electrons

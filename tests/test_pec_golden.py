@@ -139,3 +139,40 @@ def test_particle_boundaries_golden(oracle, which):
     sim.evolve(pec_case.B_MAX_STEP)
     _check_boundaries(_boundaries_report(sim, (r, a, p)))
     assert sim.particles(a).shape[1] == 1      # two of the three absorbing_particles were lost
+
+
+# ---- moving window + continuous injection + laser antenna + PEC walls:
+#      Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration ---------------
+def _lwfa_report(oracle, sim, electrons):
+    from warpx_amd.sim import particle_moments
+    oracle.sim_compute_rho(sim._h)
+    out = {"lev=0": {}, "electrons": {}}
+    for name in ("Bx", "By", "Bz", "Ex", "Ey", "Ez", "jx", "jy", "jz", "rho"):
+        out["lev=0"][name] = oracle.cell_centered_abs_sum(C.byref(sim.field_view(name)))
+    m = particle_moments(sim, electrons)
+    for i, ax in enumerate("xyz"):
+        out["electrons"]["particle_momentum_" + ax] = m["abs_momentum"][i]
+        out["electrons"]["particle_position_" + ax] = m["abs_position"][i]
+    out["electrons"]["particle_weight"] = m["weight"]
+    return out
+
+
+def test_laser_acceleration_golden(oracle):
+    """The reference's 3-D laser-wakefield regression (BASELINE config 5 in small: 32x32x256, order 3, window
+    moving at c, Gaussian antenna, continuous injection, PEC walls, filter) on the oracle stepper: every
+    field, current, rho and particle checksum of the golden file at the reference's tolerance."""
+    sim, e = pec_case.make_lwfa_sim(oracle)
+    assert sim.particles(e).shape[1] == 21780          # 22 x 22 columns x 45 planes with 0 <= z < 12 um
+    sim.evolve(pec_case.L_MAX_STEP)
+    gold = json.load(open(os.path.join(HERE, "golden", "laser_acceleration_3d_checksums.json")))
+    got = _lwfa_report(oracle, sim, e)
+    worst = 0.0
+    for group in ("lev=0", "electrons"):
+        for key, val in got[group].items():
+            want = gold["checksums"][group][key]
+            rel = abs(val - want) / abs(want)
+            worst = max(worst, rel)
+            print(f"{group}.{key}: got {val:.16e} want {want:.16e} rel {rel:.2e}")
+            assert rel < gold["rtol"], (group, key, val, want)
+    assert sim.particles(e).shape[1] == 69212           # 98 planes injected while the window advanced
+    print("worst relative deviation", worst)

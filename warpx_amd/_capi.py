@@ -64,6 +64,20 @@ class SimConfig(C.Structure):
     ]
 
 
+class MovingWindow(C.Structure):
+    _fields_ = [("dir", C.c_int32), ("v", C.c_double)]
+
+
+class PlasmaInjector(C.Structure):
+    _fields_ = [("density", C.c_double), ("ppc", C.c_int32 * 3), ("lo", C.c_double * 3), ("hi", C.c_double * 3)]
+
+
+class LaserAntenna(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("direction", C.c_double * 3), ("polarization", C.c_double * 3),
+                ("e_max", C.c_double), ("wavelength", C.c_double), ("waist", C.c_double), ("duration", C.c_double),
+                ("t_peak", C.c_double), ("focal_distance", C.c_double)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(
     C.c_int, C.c_void_p, C.c_int,
     C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -167,6 +181,10 @@ _ORACLE_SIGS = {
     "cell_centered_abs_sum": (C.c_double, [_PFV]),
     "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
     "sim_compute_rho": (C.c_int, [C.c_void_p]),
+    # moving window / continuous injection / laser antenna: CPU restatement only so far
+    "sim_set_moving_window": (C.c_int, [C.c_void_p, C.POINTER(MovingWindow)]),
+    "sim_set_injection": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PlasmaInjector), C.c_int, C.c_int]),
+    "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
     "num_threads": (C.c_int, []),
     # CPU counterparts of the Redistribute entry points (host-layer tests, parity tests)
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
