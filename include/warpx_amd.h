@@ -396,6 +396,28 @@ typedef struct wxa_laser_antenna {
     double waist, duration, t_peak, focal_distance;   /* profile_* */
 } wxa_laser_antenna;
 
+/* Replaces WarpX::shiftMF (Source/Utils/WarpXMovingWindow.cpp:478-648) for a zero external field and a
+ * forward window: f(i) <- f(i + num_shift along dir) over the whole array (guards included) except its
+ * top num_shift layers, after (1) refreshing one guard cell of the periodic directions and (2) zeroing
+ * everything beyond the domain on the high side, both on a scratch copy `tmp` (a second array of the same
+ * shape, contents irrelevant).  num_shift <= the guard depth along dir. */
+wxa_status wxa_shift_field_window(const wxa_field_view* f, double* tmp, int32_t dir, int32_t num_shift,
+                                  const int periodic[3], void* stream);
+
+/* The laser antenna push: LaserParticleContainer::calculate_laser_plane_coordinates,
+ * GaussianLaserProfile::fill_amplitude (no space-time couplings) and update_laser_particle
+ * (Source/Particles/LaserParticleContainer.cpp:795-951, Source/Laser/LaserProfilesImpl/
+ * LaserProfileGaussian.cpp:104-161), lab frame: the antenna particles get the velocity
+ * -/+ mobility * E(X, Y, t) c along the polarization (sign opposite to the sign of their weight), their
+ * momentum gamma v, and move by v dt.  p_X, p_Y: unit polarization vectors (p_Y = n x p_X). */
+typedef struct wxa_laser_push_params {
+    double position[3], p_X[3], p_Y[3];
+    double mobility;                                  /* ComputeWeightMobility: 0.05 / e_max */
+    double e_max, wavelength, waist, duration, t_peak, focal_distance;
+} wxa_laser_push_params;
+wxa_status wxa_laser_push(const wxa_particle_view* p, const wxa_laser_push_params* par, double t,
+                          double dt, void* stream);
+
 /* Neighbour exchange supplied by the host program (torch.distributed over
  * RCCL in bench.py; absent = single brick, all directions self-periodic).
  * Replaces the MPI layer under amrex FabArray::FillBoundary/SumBoundary and

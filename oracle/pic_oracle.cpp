@@ -483,6 +483,79 @@ int orc_apply_pec_rho(const wxa_field_view* rho, const int32_t dom_lo[3], const 
     return 0;
 }
 
+// WarpX::shiftMF (Source/Utils/WarpXMovingWindow.cpp:478-648), zero external field, forward window
+int orc_shift_field_window(const wxa_field_view* f, double* tmp, int32_t dir, int32_t num_shift, const int periodic[3],
+                           void*) {
+    const wxa_field_view& v = *f;
+    if (dir < 0 || dir > 2 || num_shift < 0 || num_shift > v.ng[dir]) return -1;
+    if (num_shift == 0) return 0;
+    const size_t count = (size_t)v.kstride * v.n[2];
+    std::memcpy(tmp, v.p, sizeof(double) * count);   // MultiFab::Copy(tmpmf, mf, ..., ng)
+    wxa_field_view tv = v;
+    tv.p = tmp;
+    // FillBoundary(tmpmf, ng_mw, periodicity): one guard cell, num_shift along the window direction
+    int ng_mw[3] = {1, 1, 1};
+    ng_mw[dir] = num_shift;
+    for (int d = 0; d < 3; ++d) ng_mw[d] = std::min(ng_mw[d], (int)v.ng[d]);
+    orc_fill_boundary_periodic(&tv, ng_mw, periodic, nullptr);
+    const Arr src(tv), dst(v);
+    // the region the window moved into takes the external field (0): adjCellHi(domain, dir, ng) in the
+    // field's index type, without the boundary node of a nodal direction, grown by ng transversally
+    const int vhi_d = vhi(v, dir);   // exclusive end of the valid points along dir
+    int zlo[3], zhi[3];
+    for (int d = 0; d < 3; ++d) { zlo[d] = v.lo[d]; zhi[d] = v.lo[d] + v.n[d]; }
+    zlo[dir] = vhi_d;                // first point beyond the domain (cell dom_hi+1 / node dom_hi+2)
+    zhi[dir] = vhi_d + v.ng[dir];
+    for (int k = zlo[2]; k < zhi[2]; ++k)
+        for (int j = zlo[1]; j < zhi[1]; ++j)
+            for (int i = zlo[0]; i < zhi[0]; ++i) src(i, j, k) = 0.0;
+    // dst(i) = src(i + shift) on the fab box shrunk by num_shift on the high side
+    int dlo[3], dhi[3];
+    for (int d = 0; d < 3; ++d) { dlo[d] = v.lo[d]; dhi[d] = v.lo[d] + v.n[d]; }
+    dhi[dir] -= num_shift;
+    int sh[3] = {0, 0, 0};
+    sh[dir] = num_shift;
+    for (int k = dlo[2]; k < dhi[2]; ++k)
+        for (int j = dlo[1]; j < dhi[1]; ++j)
+            for (int i = dlo[0]; i < dhi[0]; ++i) dst(i, j, k) = src(i + sh[0], j + sh[1], k + sh[2]);
+    return 0;
+}
+
+// calculate_laser_plane_coordinates (LaserParticleContainer.cpp:795-847), GaussianLaserProfile::fill_amplitude
+// (LaserProfileGaussian.cpp:104-161 with zeta = beta = phi2 = phi0 = 0, theta_stc = 0), update_laser_particle
+// (:850-951), lab frame
+int orc_laser_push(const wxa_particle_view* p, const wxa_laser_push_params* c, double t, double dt, void*) {
+    using cplx = std::complex<double>;
+    const cplx I(0, 1);
+    const double k0 = 2. * M_PI / c->wavelength;
+    const double inv_tau2 = 1. / (c->duration * c->duration);
+    const double oscillation_phase = k0 * PhysConst::c * (t - c->t_peak) + 0.0;
+    const cplx diffract_factor = 1. + I * c->focal_distance * 2. / (k0 * c->waist * c->waist);
+    const cplx inv_complex_waist_2 = 1. / (c->waist * c->waist * diffract_factor);
+    const cplx stretch_factor = 1.;   // 1 + 4 (zeta + beta f / tau^2)(...) + 2 i (phi2 - ...) / tau^2 with zeta = beta = phi2 = 0
+    const cplx t_prefactor = c->e_max * std::exp(I * oscillation_phase);
+    const cplx prefactor = t_prefactor / diffract_factor;
+    for (int64_t i = 0; i < p->np; ++i) {
+        double x = p->x[i], y = p->y[i], z = p->z[i];
+        const double Xp = c->p_X[0] * (x - c->position[0]) + c->p_X[1] * (y - c->position[1]) + c->p_X[2] * (z - c->position[2]);
+        const double Yp = c->p_Y[0] * (x - c->position[0]) + c->p_Y[1] * (y - c->position[1]) + c->p_Y[2] * (z - c->position[2]);
+        const cplx arg = t - c->t_peak;
+        const cplx stc_exponent = 1. / stretch_factor * inv_tau2 * (arg * arg);
+        const cplx stcfactor = prefactor * std::exp(-stc_exponent);
+        const cplx exp_argument = -(Xp * Xp + Yp * Yp) * inv_complex_waist_2;
+        const double amplitude = (stcfactor * std::exp(exp_argument)).real();
+        const double sign_charge = (p->w[i] > 0) ? -1 : 1;
+        const double v_over_c = sign_charge * c->mobility * amplitude;
+        const double vx = PhysConst::c * v_over_c * c->p_X[0];
+        const double vy = PhysConst::c * v_over_c * c->p_X[1];
+        const double vz = PhysConst::c * v_over_c * c->p_X[2];
+        const double gamma = 1. / std::sqrt(1. - v_over_c * v_over_c);
+        p->ux[i] = gamma * vx; p->uy[i] = gamma * vy; p->uz[i] = gamma * vz;
+        p->x[i] = x + vx * dt; p->y[i] = y + vy * dt; p->z[i] = z + vz * dt;
+    }
+    return 0;
+}
+
 int orc_apply_pec_e(const wxa_field_view E[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
                     const int32_t pec_lo[3], const int32_t pec_hi[3], const int32_t ng[3], void*) {
     return apply_pec<true>(E, dom_lo, dom_hi, pec_lo, pec_hi, ng);
@@ -969,37 +1042,10 @@ void add_plasma(orc_sim* s, Species& sp, const double part_lo[3], const double p
             }
 }
 
-// ---- moving window: WarpX::shiftMF (Source/Utils/WarpXMovingWindow.cpp:478-648), zero external field ----
+// ---- moving window: WarpX::shiftMF through the exported kernel (orc_shift_field_window below) ----
 void shift_field(orc_sim* s, Field& f, int num_shift, int dir) {
-    wxa_field_view& v = f.v;
-    std::vector<double> tmpdata(f.data);   // MultiFab::Copy(tmpmf, mf, ..., ng)
-    wxa_field_view tv = v;
-    tv.p = tmpdata.data();
-    // FillBoundary(tmpmf, ng_mw, periodicity): one guard cell, num_shift along the window direction
-    int ng_mw[3] = {1, 1, 1};
-    ng_mw[dir] = num_shift;
-    for (int d = 0; d < 3; ++d) ng_mw[d] = std::min(ng_mw[d], (int)v.ng[d]);
-    orc_fill_boundary_periodic(&tv, ng_mw, s->periodic, nullptr);
-    const Arr src(tv), dst(v);
-    // the region the window moved into takes the external field (0): adjCellHi(domain, dir, ng) in the
-    // field's index type, without the boundary node of a nodal direction, grown by ng transversally
-    const int vhi_d = vhi(v, dir);   // exclusive end of the valid points along dir
-    int zlo[3], zhi[3];
-    for (int d = 0; d < 3; ++d) { zlo[d] = v.lo[d]; zhi[d] = v.lo[d] + v.n[d]; }
-    zlo[dir] = vhi_d;                // first point beyond the domain (cell dom_hi+1 / node dom_hi+2)
-    zhi[dir] = vhi_d + v.ng[dir];
-    for (int k = zlo[2]; k < zhi[2]; ++k)
-        for (int j = zlo[1]; j < zhi[1]; ++j)
-            for (int i = zlo[0]; i < zhi[0]; ++i) src(i, j, k) = 0.0;
-    // dst(i) = src(i + shift) on the fab box shrunk by num_shift on the high side
-    int dlo[3], dhi[3];
-    for (int d = 0; d < 3; ++d) { dlo[d] = v.lo[d]; dhi[d] = v.lo[d] + v.n[d]; }
-    dhi[dir] -= num_shift;
-    int sh[3] = {0, 0, 0};
-    sh[dir] = num_shift;
-    for (int k = dlo[2]; k < dhi[2]; ++k)
-        for (int j = dlo[1]; j < dhi[1]; ++j)
-            for (int i = dlo[0]; i < dhi[0]; ++i) dst(i, j, k) = src(i + sh[0], j + sh[1], k + sh[2]);
+    std::vector<double> tmp(f.data.size());
+    orc_shift_field_window(&f.v, tmp.data(), dir, num_shift, s->periodic, nullptr);
 }
 
 // WarpX::MoveWindow (:138-476): forward window, lab frame, plasma at rest
@@ -1076,46 +1122,15 @@ void laser_init(orc_sim* s, LaserAntenna& L) {
     if (s->any_particle_wall) L.parts.id.assign(L.parts.a[0].size(), 0);
 }
 
-// LaserParticleContainer::Evolve (:563-713): plane coordinates, Gaussian amplitude
-// (LaserProfileGaussian.cpp:104-161 with zeta = beta = phi2 = phi0 = 0), update_laser_particle (:850-951)
-void laser_push(orc_sim* s, LaserAntenna& L, double t, double dt) {
-    using cplx = std::complex<double>;
-    const cplx I(0, 1);
-    const wxa_laser_antenna& c = L.cfg;
-    const double k0 = 2. * M_PI / c.wavelength;
-    const double inv_tau2 = 1. / (c.duration * c.duration);
-    const double oscillation_phase = k0 * PhysConst::c * (t - c.t_peak) + 0.0;
-    const cplx diffract_factor = 1. + I * c.focal_distance * 2. / (k0 * c.waist * c.waist);
-    const cplx inv_complex_waist_2 = 1. / (c.waist * c.waist * diffract_factor);
-    const cplx stretch_factor = 1. + 4. * (0.0 + 0.0 * c.focal_distance * inv_tau2) * (0.0 + 0.0 * c.focal_distance * inv_complex_waist_2) +
-                                2. * I * (0.0 - 0.0 * 0.0 * k0 * c.focal_distance) * inv_tau2;
-    const cplx t_prefactor = c.e_max * std::exp(I * oscillation_phase);
-    const cplx prefactor = t_prefactor / diffract_factor;
-    const int64_t np = (int64_t)L.parts.a[0].size();
-    for (int64_t i = 0; i < np; ++i) {
-        double x = L.parts.a[0][i], y = L.parts.a[1][i], z = L.parts.a[2][i];
-        // calculate_laser_plane_coordinates (:795-847)
-        const double Xp = L.p_X[0] * (x - L.position[0]) + L.p_X[1] * (y - L.position[1]) + L.p_X[2] * (z - L.position[2]);
-        const double Yp = L.p_Y[0] * (x - L.position[0]) + L.p_Y[1] * (y - L.position[1]) + L.p_Y[2] * (z - L.position[2]);
-        const cplx arg = t - c.t_peak - 0.0 * k0 * (Xp * 1.0 + Yp * 0.0) -
-                         2. * I * (Xp * 1.0 + Yp * 0.0) * (0.0 - 0.0 * c.focal_distance) * inv_complex_waist_2;
-        const cplx stc_exponent = 1. / stretch_factor * inv_tau2 * (arg * arg);
-        const cplx stcfactor = prefactor * std::exp(-stc_exponent);
-        const cplx exp_argument = -(Xp * Xp + Yp * Yp) * inv_complex_waist_2;
-        const double amplitude = (stcfactor * std::exp(exp_argument)).real();
-        // update_laser_particle
-        const double sign_charge = (L.parts.a[3][i] > 0) ? -1 : 1;
-        const double v_over_c = sign_charge * L.mobility * amplitude;
-        const double vx = PhysConst::c * v_over_c * L.p_X[0];
-        const double vy = PhysConst::c * v_over_c * L.p_X[1];
-        const double vz = PhysConst::c * v_over_c * L.p_X[2];
-        const double gamma = 1. / std::sqrt(1. - v_over_c * v_over_c);
-        L.parts.a[4][i] = gamma * vx;
-        L.parts.a[5][i] = gamma * vy;
-        L.parts.a[6][i] = gamma * vz;
-        x += vx * dt; y += vy * dt; z += vz * dt;
-        L.parts.a[0][i] = x; L.parts.a[1][i] = y; L.parts.a[2][i] = z;
-    }
+// LaserParticleContainer::Evolve (:563-713) through the exported kernel (orc_laser_push below)
+void laser_push(orc_sim* /*s*/, LaserAntenna& L, double t, double dt) {
+    wxa_laser_push_params par{};
+    for (int d = 0; d < 3; ++d) { par.position[d] = L.position[d]; par.p_X[d] = L.p_X[d]; par.p_Y[d] = L.p_Y[d]; }
+    par.mobility = L.mobility;
+    par.e_max = L.cfg.e_max; par.wavelength = L.cfg.wavelength; par.waist = L.cfg.waist;
+    par.duration = L.cfg.duration; par.t_peak = L.cfg.t_peak; par.focal_distance = L.cfg.focal_distance;
+    wxa_particle_view p = L.parts.view();
+    orc_laser_push(&p, &par, t, dt, nullptr);
 }
 
 void fill_boundary_EB(orc_sim* s, wxa_field_view* F, const int ng[3], bool sync) {

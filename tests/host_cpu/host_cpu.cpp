@@ -39,6 +39,8 @@ int orc_apply_pec_e(const wxa_field_view*, const int32_t*, const int32_t*, const
 int orc_apply_pec_b(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                     void*);
 int orc_apply_pec_j(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
+int orc_shift_field_window(const wxa_field_view*, double*, int32_t, int32_t, const int*, void*);
+int orc_laser_push(const wxa_particle_view*, const wxa_laser_push_params*, double, double, void*);
 int orc_apply_particle_boundaries(const wxa_particle_view*, const double*, const double*, const int32_t*, const int32_t*,
                                   int64_t*, void*, void*);
 }
@@ -83,6 +85,8 @@ const Backend* cpu_backend() {
         b.apply_pec_b = orc_apply_pec_b;
         b.apply_pec_j = orc_apply_pec_j;
         b.apply_particle_boundaries = orc_apply_particle_boundaries;
+        b.shift_field_window = orc_shift_field_window;
+        b.laser_push = orc_laser_push;
         b.workspace_create = ws_create; b.workspace_destroy = ws_destroy;
         b.dmalloc = h_malloc; b.dfree = h_free;
         b.memset_async = h_memset; b.memcpy_async = h_memcpy;

@@ -98,7 +98,7 @@ M_E_ = 9.1093837015e-31
 
 
 def make_lwfa_sim(lib):
-    """Only the CPU restatement has these features so far (lib = the oracle)."""
+    """inputs_test_3d_laser_acceleration: moving window at c along z, electrons injected continuously, Gaussian antenna."""
     import ctypes as C
     sim = WarpXSim(lib, L_N_CELL, L_PROB_LO, L_PROB_HI, nox=3, galerkin=1, use_filter=1, cfl=1.0, sort_interval=4,
                    field_boundary_lo=(_capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PEC),

@@ -556,3 +556,60 @@ def test_apply_particle_boundaries(oracle, product):
     assert np.array_equal(pd.to_numpy(), pc.to_numpy())
     assert np.array_equal(pd.idcpu.cpu().numpy().view(np.uint64), pc.idcpu)
     product.workspace_destroy(ws)
+
+
+@UNVERIFIED
+@pytest.mark.parametrize("direction,num_shift", [(2, 1), (2, 2), (0, 1), (1, 3)])
+def test_shift_field_window(oracle, product, direction, num_shift):
+    """wxa_shift_field_window (WarpX::shiftMF, zero external field): every staggering, window along each axis,
+    the other two periodic, shifts of 1..3 cells on padded device rows: bit-identical to the CPU restatement,
+    guards included."""
+    import torch
+    ncell = (12, 10, 14)
+    periodic = [1, 1, 1]
+    periodic[direction] = 0
+    names = ("Ex", "Ey", "Ez", "Bx", "By", "Bz")
+    F = H.random_fields(names, ncell, 4, 21)
+    Fd = H.clone_fields(F, DEV, True)
+    for f, fd in zip(F, Fd):
+        tmp_c = np.zeros(f.view.kstride * f.view.n[2])
+        tmp_d = torch.zeros(fd.view.kstride * fd.view.n[2], dtype=torch.float64, device=DEV)
+        rc = oracle.shift_field_window(C.byref(f.view), tmp_c.ctypes.data, direction, num_shift, H.i3(periodic), None)
+        assert rc == 0
+        product.shift_field_window(C.byref(fd.view), tmp_d.data_ptr(), direction, num_shift, H.i3(periodic), None)
+        _sync(product)
+        assert np.array_equal(fd.to_numpy(), f.to_numpy())
+
+
+@UNVERIFIED
+def test_laser_push(oracle, product):
+    """wxa_laser_push (LaserParticleContainer::Evolve: plane coordinates, Gaussian profile with a focal distance,
+    update_laser_particle) on an antenna plane of +/- weighted macro-particles at three times around the peak:
+    positions and momenta within 1e-13 of the CPU restatement (device exp/sin/cos differ from libm by ulps)."""
+    n = 30000
+    rng = np.random.default_rng(11)
+    par = _capi.LaserPushParams()
+    for d, v in enumerate((0.0, 0.0, 9e-6)):
+        par.position[d] = v
+    for d, v in enumerate((0.0, 1.0, 0.0)):
+        par.p_X[d] = v
+    for d, v in enumerate((-1.0, 0.0, 0.0)):
+        par.p_Y[d] = v
+    par.e_max, par.wavelength, par.waist = 16e12, 0.8e-6, 5e-6
+    par.duration, par.t_peak, par.focal_distance = 15e-15, 30e-15, 100e-6
+    par.mobility = 4e-14                       # |v/c| <= 0.64
+    x, y = (rng.random(n) - 0.5) * 30e-6, (rng.random(n) - 0.5) * 30e-6
+    w = np.where(rng.random(n) < 0.5, 1.0, -1.0) * 1e5
+    parts = [x, y, np.full(n, 9e-6), w, np.zeros(n), np.zeros(n), np.zeros(n)]
+    dt = 1.3e-16
+    for t in (10e-15, 30.2e-15, 47e-15):
+        pc = ParticleArrays.from_numpy(parts, "cpu")
+        pd = ParticleArrays.from_numpy(parts, DEV)
+        assert oracle.laser_push(C.byref(pc.view), C.byref(par), t, dt, None) == 0
+        product.laser_push(C.byref(pd.view), C.byref(par), t, dt, None)
+        _sync(product)
+        a, b = pd.to_numpy(), pc.to_numpy()
+        assert np.max(np.abs(b[5])) > 0            # the antenna moves along the polarisation
+        for row in range(7):
+            scale = max(np.max(np.abs(b[row])), 1e-300)
+            assert np.max(np.abs(a[row] - b[row])) <= 1e-13 * scale, (t, row)

@@ -143,11 +143,14 @@ def test_particle_boundaries_golden(oracle, which):
 
 # ---- moving window + continuous injection + laser antenna + PEC walls:
 #      Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration ---------------
-def _lwfa_report(oracle, sim, electrons):
+def _lwfa_report(oracle, sim, electrons, with_rho=True):
     from warpx_amd.sim import particle_moments
-    oracle.sim_compute_rho(sim._h)
     out = {"lev=0": {}, "electrons": {}}
-    for name in ("Bx", "By", "Bz", "Ex", "Ey", "Ez", "jx", "jy", "jz", "rho"):
+    names = ["Bx", "By", "Bz", "Ex", "Ey", "Ez", "jx", "jy", "jz"]
+    if with_rho:
+        oracle.sim_compute_rho(sim._h)
+        names.append("rho")
+    for name in names:
         out["lev=0"][name] = oracle.cell_centered_abs_sum(C.byref(sim.field_view(name)))
     m = particle_moments(sim, electrons)
     for i, ax in enumerate("xyz"):
@@ -157,15 +160,8 @@ def _lwfa_report(oracle, sim, electrons):
     return out
 
 
-def test_laser_acceleration_golden(oracle):
-    """The reference's 3-D laser-wakefield regression (BASELINE config 5 in small: 32x32x256, order 3, window
-    moving at c, Gaussian antenna, continuous injection, PEC walls, filter) on the oracle stepper: every
-    field, current, rho and particle checksum of the golden file at the reference's tolerance."""
-    sim, e = pec_case.make_lwfa_sim(oracle)
-    assert sim.particles(e).shape[1] == 21780          # 22 x 22 columns x 45 planes with 0 <= z < 12 um
-    sim.evolve(pec_case.L_MAX_STEP)
+def check_lwfa_against_golden(got):
     gold = json.load(open(os.path.join(HERE, "golden", "laser_acceleration_3d_checksums.json")))
-    got = _lwfa_report(oracle, sim, e)
     worst = 0.0
     for group in ("lev=0", "electrons"):
         for key, val in got[group].items():
@@ -174,5 +170,22 @@ def test_laser_acceleration_golden(oracle):
             worst = max(worst, rel)
             print(f"{group}.{key}: got {val:.16e} want {want:.16e} rel {rel:.2e}")
             assert rel < gold["rtol"], (group, key, val, want)
-    assert sim.particles(e).shape[1] == 69212           # 98 planes injected while the window advanced
     print("worst relative deviation", worst)
+
+
+@pytest.mark.parametrize("which", ["oracle", "host_layer"])
+def test_laser_acceleration_golden(oracle, which):
+    """The reference's 3-D laser-wakefield regression (BASELINE config 5 in small: 32x32x256, order 3, window
+    moving at c, Gaussian antenna, continuous injection, PEC walls, filter): every field, current, rho and
+    particle checksum of the golden file at the reference's tolerance, on the oracle stepper and on the
+    product's C++ host layer driving the CPU restatement's kernels (the host layer has no rho diagnostic)."""
+    if which == "oracle":
+        lib = oracle
+    else:
+        from tests.oracle_lib import load_host_cpu
+        lib = load_host_cpu()
+    sim, e = pec_case.make_lwfa_sim(lib)
+    assert sim.particles(e).shape[1] == 21780          # 22 x 22 columns x 45 planes with 0 <= z < 12 um
+    sim.evolve(pec_case.L_MAX_STEP)
+    check_lwfa_against_golden(_lwfa_report(oracle, sim, e, with_rho=(which == "oracle")))
+    assert sim.particles(e).shape[1] == 69212           # 98 planes injected while the window advanced

@@ -273,3 +273,30 @@ def test_particle_boundaries_golden_on_gpu(product):
     sim.evolve(pec_case.B_MAX_STEP)
     _check_boundaries(_boundaries_report(sim, (r, a, p)))
     assert sim.particles(a).shape[1] == 1
+
+
+@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
+                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (the same case "
+                           "passes on the oracle stepper and on the CPU build of the host layer, "
+                           "tests/test_pec_golden.py); WXA_UNVERIFIED_GPU_TESTS=1 runs it")
+def test_laser_acceleration_golden_on_gpu(oracle, product):
+    """Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration on the HIP path (moving
+    window at c, continuous injection, Gaussian antenna, PEC walls, filter, order 3): the reference's golden field,
+    current and particle checksums at the reference's tolerance."""
+    from tests import pec_case
+    from tests.test_pec_golden import check_lwfa_against_golden
+    sim, e = pec_case.make_lwfa_sim(product)
+    sim.evolve(pec_case.L_MAX_STEP)
+    ref, _ = pec_case.make_lwfa_sim(oracle)            # only as the host-side array the checksum reducer reads
+    got = {"lev=0": {}, "electrons": {}}
+    import ctypes as C
+    for name in ("Bx", "By", "Bz", "Ex", "Ey", "Ez", "jx", "jy", "jz"):
+        ref.set_field(name, sim.field(name))
+        got["lev=0"][name] = oracle.cell_centered_abs_sum(C.byref(ref.field_view(name)))
+    m = particle_moments(sim, e)
+    for i, ax in enumerate("xyz"):
+        got["electrons"]["particle_momentum_" + ax] = m["abs_momentum"][i]
+        got["electrons"]["particle_position_" + ax] = m["abs_position"][i]
+    got["electrons"]["particle_weight"] = m["weight"]
+    check_lwfa_against_golden(got)
+    assert sim.particles(e).shape[1] == 69212

@@ -78,6 +78,12 @@ class LaserAntenna(C.Structure):
                 ("t_peak", C.c_double), ("focal_distance", C.c_double)]
 
 
+class LaserPushParams(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("p_X", C.c_double * 3), ("p_Y", C.c_double * 3),
+                ("mobility", C.c_double), ("e_max", C.c_double), ("wavelength", C.c_double), ("waist", C.c_double),
+                ("duration", C.c_double), ("t_peak", C.c_double), ("focal_distance", C.c_double)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(
     C.c_int, C.c_void_p, C.c_int,
     C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -129,6 +135,8 @@ _KERNEL_SIGS = {
     "apply_pec_j": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_particle_boundaries": (C.c_int, [_PPV, _D3, _D3, _I32_3, _I32_3, C.POINTER(C.c_int64), C.c_void_p,
                                             C.c_void_p]),
+    "shift_field_window": (C.c_int, [_PFV, C.c_void_p, C.c_int32, C.c_int32, _I3, C.c_void_p]),
+    "laser_push": (C.c_int, [_PPV, C.POINTER(LaserPushParams), C.c_double, C.c_double, C.c_void_p]),
     "filter_bilinear": (C.c_int, [_PFV, _PFV, C.c_void_p]),
     "fill_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
     "sum_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
@@ -148,6 +156,10 @@ _SIM_SIGS = {
     "sim_get_particles": (C.c_int, [C.c_void_p, C.c_int32, _PPV]),
     "sim_get_timers": (C.c_int, [C.c_void_p, C.c_double * 8, C.c_int64 * 8, C.c_int]),
     "sim_enable_timers": (C.c_int, [C.c_void_p, C.c_int]),
+    # moving window / continuous injection / laser antenna
+    "sim_set_moving_window": (C.c_int, [C.c_void_p, C.POINTER(MovingWindow)]),
+    "sim_set_injection": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PlasmaInjector), C.c_int, C.c_int]),
+    "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
 }
 
 # product-only entry points
@@ -181,10 +193,7 @@ _ORACLE_SIGS = {
     "cell_centered_abs_sum": (C.c_double, [_PFV]),
     "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
     "sim_compute_rho": (C.c_int, [C.c_void_p]),
-    # moving window / continuous injection / laser antenna: CPU restatement only so far
-    "sim_set_moving_window": (C.c_int, [C.c_void_p, C.POINTER(MovingWindow)]),
-    "sim_set_injection": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PlasmaInjector), C.c_int, C.c_int]),
-    "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
+
     "num_threads": (C.c_int, []),
     # CPU counterparts of the Redistribute entry points (host-layer tests, parity tests)
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),

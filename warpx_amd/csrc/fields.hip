@@ -490,6 +490,30 @@ apply_pec_j_kernel(DevF f, int icomp, Box3 vb, PecGeom pg) {
     }
 }
 
+// ---- moving window: WarpX::shiftMF (Source/Utils/WarpXMovingWindow.cpp:478-648) ------------------------
+__global__ void __launch_bounds__(256)
+set_box_kernel(DevF f, BoxN box, double value) {
+    const long total = (long)box.n[0] * box.n[1] * box.n[2];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int i = box.lo[0] + (int)(t % box.n[0]);
+        const int j = box.lo[1] + (int)((t / box.n[0]) % box.n[1]);
+        const int k = box.lo[2] + (int)(t / ((long)box.n[0] * box.n[1]));
+        f.p[f.off(i, j, k)] = value;
+    }
+}
+
+// dst(i,j,k) = src(i + s0, j + s1, k + s2) on box; src and dst are different arrays of the same shape
+__global__ void __launch_bounds__(256)
+shifted_copy_kernel(DevF dst, DevF src, BoxN box, int s0, int s1, int s2) {
+    const long total = (long)box.n[0] * box.n[1] * box.n[2];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int i = box.lo[0] + (int)(t % box.n[0]);
+        const int j = box.lo[1] + (int)((t / box.n[0]) % box.n[1]);
+        const int k = box.lo[2] + (int)(t / ((long)box.n[0] * box.n[1]));
+        dst.p[dst.off(i, j, k)] = src.p[src.off(i + s0, j + s1, k + s2)];
+    }
+}
+
 // Both guard slabs of one direction in one launch: box_lo takes src(i + shift), box_hi takes
 // src(i - shift).  The boxes have the same extents; sources are valid points, destinations guard
 // points, so the two halves are independent.
@@ -827,6 +851,46 @@ static wxa_status apply_pec(const wxa_field_view F[3], const int32_t dom_lo[3], 
                                    df, c, b, pg);
             }
     }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_shift_field_window(const wxa_field_view* f, double* tmp, int32_t dir, int32_t num_shift,
+                                  const int periodic[3], void* stream) {
+    WXA_REQUIRE(f && view_ok(*f) && tmp && periodic, "bad argument");
+    WXA_REQUIRE(dir >= 0 && dir < 3, "dir must be 0..2");
+    WXA_REQUIRE(num_shift >= 0 && num_shift <= f->ng[dir], "shift exceeds the guard depth");
+    WXA_REQUIRE(tmp != f->p, "the scratch array must be a different array");
+    if (num_shift == 0) return WXA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t count = (size_t)f->kstride * (size_t)f->n[2];
+    // MultiFab::Copy(tmpmf, mf, 0, 0, nc, ng)
+    WXA_HIP_CHECK(hipMemcpyAsync(tmp, f->p, sizeof(double) * count, hipMemcpyDeviceToDevice, st));
+    wxa_field_view tv = *f;
+    tv.p = tmp;
+    // FillBoundary(tmpmf, ng_mw, periodicity): one guard cell, num_shift along the window direction
+    int ng_mw[3] = {1, 1, 1};
+    ng_mw[dir] = num_shift;
+    for (int d = 0; d < 3; ++d) ng_mw[d] = std::min(ng_mw[d], (int)f->ng[d]);
+    wxa_status rc = wxa_fill_boundary_periodic(&tv, ng_mw, periodic, stream);
+    if (rc != WXA_OK) return rc;
+    const DevF dsrc = make_devf(tv), ddst = make_devf(*f);
+    // everything beyond the domain on the high side takes the external field (0)
+    BoxN z;
+    for (int d = 0; d < 3; ++d) { z.lo[d] = f->lo[d]; z.n[d] = f->n[d]; }
+    z.lo[dir] = f->lo[dir] + f->n[dir] - f->ng[dir];
+    z.n[dir] = f->ng[dir];
+    long total = (long)z.n[0] * z.n[1] * z.n[2];
+    if (total > 0) hipLaunchKernelGGL(set_box_kernel, dim3(grid_for(total)), dim3(256), 0, st, dsrc, z, 0.0);
+    // dst(i) = src(i + shift) on the array box shrunk by num_shift on the high side
+    BoxN b;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = f->lo[d]; b.n[d] = f->n[d]; }
+    b.n[dir] -= num_shift;
+    int sh[3] = {0, 0, 0};
+    sh[dir] = num_shift;
+    total = (long)b.n[0] * b.n[1] * b.n[2];
+    if (total > 0)
+        hipLaunchKernelGGL(shifted_copy_kernel, dim3(grid_for(total)), dim3(256), 0, st, ddst, dsrc, b, sh[0], sh[1], sh[2]);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }

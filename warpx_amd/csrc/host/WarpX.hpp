@@ -162,6 +162,7 @@ public:
                 throw std::runtime_error("periodic direction shorter than twice the guard depth");
         m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, m_ctx.dx);
         sort_intervals = cfg.sort_interval;
+        m_ctx.sort_intervals_on = sort_intervals > 0;
     }
 
     // Source/Evolve/WarpXComputeDt.cpp:41-102 with CartesianYeeAlgorithm::ComputeMaxDt (:48-56)
@@ -188,10 +189,79 @@ public:
             if (step == numsteps_max - 1) Synchronize();
             ++istep;
             cur_time += dt[0];
-            // :246 MoveWindow: off
-            HandleParticlesAtBoundaries(step, cur_time, 0);  // :256
+            const bool move_j = is_synchronized;
+            const int num_moved = MoveWindow(istep, move_j);     // :246 MoveWindow(step+1, move_j)
+            HandleParticlesAtBoundaries(step, cur_time, num_moved);  // :256
         }
         m_be->stream_sync(m_ctx.stream);
+    }
+
+    // warpx.do_moving_window / moving_window_dir / moving_window_v (Source/WarpX.cpp:620-660): forward window, lab frame
+    void SetMovingWindow(int dir, amrex::Real v_over_c) {
+        if (dir < 0 || dir > 2 || !(v_over_c > 0.0)) throw std::runtime_error("moving window: direction 0..2, v > 0");
+        if (m_comm->periodic(dir)) throw std::runtime_error("the moving window direction cannot be periodic");
+        if (m_comm->nbricks()[dir] != 1) throw std::runtime_error("the moving window direction must be unsplit");
+        do_moving_window = true;
+        moving_window_dir = dir;
+        moving_window_v = v_over_c * 299'792'458.;
+        moving_window_x = m_ctx.prob_lo[dir];                                       // :649
+    }
+
+    // WarpX::MoveWindow (Source/Utils/WarpXMovingWindow.cpp:138-476): window position, whole-cell field shift,
+    // new domain bounds, continuous injection into the cells that entered
+    int MoveWindow(int /*step*/, bool move_j) {
+        if (!do_moving_window) return 0;                                            // :151 moving_window_active
+        using warpx::fields::FieldType;
+        using ablastr::fields::Direction;
+        // WarpX::InitData (:301): injection starts at the upper domain bound as it is when the container first
+        // meets the window (containers may be added after SetMovingWindow)
+        for (int i = 0; i < mypc->nContainers(); ++i) {
+            WarpXParticleContainer& pc = mypc->GetParticleContainer(i);
+            if (std::isnan(pc.m_current_injection_position)) pc.m_current_injection_position = m_ctx.prob_hi[moving_window_dir];
+        }
+        moving_window_x += moving_window_v * dt[0];                                 // :158
+        const int dir = moving_window_dir;
+        const amrex::Real cdx = m_ctx.dx[dir];
+        const int num_shift_base = static_cast<int>((moving_window_x - m_ctx.prob_lo[dir]) / cdx);   // :171
+        if (num_shift_base == 0) return 0;
+        m_ctx.prob_lo[dir] += num_shift_base * cdx;                                 // :181-186 ResetProbDomain
+        m_ctx.prob_hi[dir] += num_shift_base * cdx;
+        m_ctx.brick_plo[dir] = m_ctx.prob_lo[dir];                                  // the window direction is unsplit
+        m_ctx.brick_phi[dir] = m_ctx.prob_hi[dir];
+        for (int dim = 0; dim < 3; ++dim) {                                         // :222-246
+            shiftMF(*m_fields.get(FieldType::Bfield_fp, Direction{dim}, 0), num_shift_base, dir);
+            shiftMF(*m_fields.get(FieldType::Efield_fp, Direction{dim}, 0), num_shift_base, dir);
+            if (move_j) shiftMF(*m_fields.get(FieldType::current_fp, Direction{dim}, 0), num_shift_base, dir);
+        }
+        for (int i = 0; i < mypc->nContainers(); ++i) {                             // :388-437
+            WarpXParticleContainer& pc = mypc->GetParticleContainer(i);
+            if (!pc.doContinuousInjection()) continue;
+            const amrex::Real new_injection_position =
+                pc.m_current_injection_position + std::floor((m_ctx.prob_hi[dir] - pc.m_current_injection_position) / cdx) * cdx;
+            double blo[3] = {m_ctx.prob_lo[0], m_ctx.prob_lo[1], m_ctx.prob_lo[2]};
+            double bhi[3] = {m_ctx.prob_hi[0], m_ctx.prob_hi[1], m_ctx.prob_hi[2]};
+            blo[dir] = pc.m_current_injection_position;
+            bhi[dir] = new_injection_position;
+            if (bhi[dir] > blo[dir] && pc.m_current_injection_position != new_injection_position) {
+                pc.ContinuousInjection(blo, bhi);
+                pc.m_current_injection_position = new_injection_position;
+            }
+        }
+        // every particle's cell index along the window moved with the domain: the tile-major order of the
+        // last sort no longer lines up with the tiles, so sort now instead of at the next interval
+        if (sort_intervals > 0) mypc->SortParticlesByBin(amrex::IntVect(1));
+        return num_shift_base;
+    }
+
+    // WarpX::shiftMF (:478-648), zero external field
+    void shiftMF(amrex::MultiFab& mf, int num_shift, int dir) {
+        const wxa_field_view& v = mf.view();
+        if (num_shift > v.ng[dir]) throw std::runtime_error("shiftMF: shift exceeds the guard depth");   // :491
+        m_shift_tmp.be = m_be;
+        m_shift_tmp.reserve(sizeof(double) * (size_t)v.kstride * (size_t)v.n[2]);
+        const int periodic[3] = {m_comm->periodic(0) ? 1 : 0, m_comm->periodic(1) ? 1 : 0, m_comm->periodic(2) ? 1 : 0};
+        if (m_be->shift_field_window(&v, static_cast<double*>(m_shift_tmp.p), dir, num_shift, periodic, m_ctx.stream) != 0)
+            throw std::runtime_error("shift_field_window failed");
     }
 
     // :354-455
@@ -355,6 +425,11 @@ public:
     int32_t m_pec_lo[3] = {0, 0, 0}, m_pec_hi[3] = {0, 0, 0}, m_dom_lo[3] = {0, 0, 0}, m_dom_hi[3] = {0, 0, 0};
     bool m_any_pec = false;
     bool m_any_reflecting_wall = false;
+    // WarpX::do_moving_window, moving_window_dir, moving_window_v (m/s), moving_window_x
+    bool do_moving_window = false;
+    int moving_window_dir = 2;
+    amrex::Real moving_window_v = 0.0, moving_window_x = 0.0;
+    DeviceBuffer m_shift_tmp;
 
 private:
     void FillBoundaryVector(warpx::fields::FieldType ft, const amrex::IntVect& ng, bool nodal_sync) {

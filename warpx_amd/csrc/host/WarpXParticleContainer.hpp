@@ -8,7 +8,10 @@
 #ifndef WXA_HOST_PARTICLES_HPP_
 #define WXA_HOST_PARTICLES_HPP_
 
+#include <climits>
+#include <cmath>
 #include <cstdio>
+#include <limits>
 #include <cstdlib>
 
 #include "BrickComm.hpp"
@@ -29,6 +32,7 @@ struct WarpXContext {
     amrex::IntVect ng_alloc_EB, ng_depos_J;
     void* stream = nullptr;
     bool sort_now = false;             // this step re-sorts the tiles (sort_intervals)
+    bool sort_intervals_on = false;    // warpx.sort_intervals > 0
     // boundary.particle_lo/hi resolved to WXA_PBOUNDARY_PERIODIC / _ABSORBING / _REFLECTING
     int32_t particle_bc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     int32_t particle_bc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
@@ -310,6 +314,24 @@ public:
         be->stream_sync(m_ctx->stream);
     }
 
+    // AddNParticles restricted to what injection needs: host columns x,y,z,w,ux,uy,uz appended behind the
+    // tile (ids 0); like arrivals from a neighbour brick they are the tile's tail until the next sort
+    void AppendFromHost(const std::vector<double> (&cols)[7]) {
+        const int64_t n = (int64_t)cols[0].size();
+        if (n == 0) return;
+        const Backend* be = m_ctx->be;
+        const int64_t n0 = m_tile.numParticles();
+        m_tile.resize(n0 + n);
+        for (int c = 0; c < 7; ++c) be->memcpy_h2d(m_tile.comp(c) + n0, cols[c].data(), sizeof(double) * (size_t)n);
+        be->memset_async(m_tile.idcpu() + n0, 0, sizeof(uint64_t) * (size_t)n, m_ctx->stream);
+        be->stream_sync(m_ctx->stream);
+    }
+
+    // WarpXParticleContainer::doContinuousInjection / ContinuousInjection / m_current_injection_position
+    virtual bool doContinuousInjection() const { return false; }
+    virtual void ContinuousInjection(const double* /*box_lo*/, const double* /*box_hi*/) {}
+    amrex::Real m_current_injection_position = std::numeric_limits<amrex::Real>::quiet_NaN();   // unset
+
     // The tile without retired particles (compacts by sorting if Redistribute retired some since
     // the last sort): what diagnostics and callers outside the step loop should look at.
     ParticleTile& tile() {
@@ -332,6 +354,89 @@ public:
 class PhysicalParticleContainer : public WarpXParticleContainer {
 public:
     using WarpXParticleContainer::WarpXParticleContainer;
+
+    // <species>.injection_style = NUniformPerCell, profile = constant, momentum at_rest
+    void SetPlasmaInjector(const wxa_plasma_injector& inj, bool continuous) {
+        if (inj.ppc[0] < 1 || inj.ppc[1] < 1 || inj.ppc[2] < 1 || !(inj.density >= 0.0))
+            throw std::runtime_error("plasma injector: bad density or particles per cell");
+        m_inj = inj;
+        m_has_injector = true;
+        m_do_continuous_injection = continuous;
+    }
+    bool doContinuousInjection() const override { return m_has_injector && m_do_continuous_injection; }
+    // PhysicalParticleContainer::ContinuousInjection (PhysicalParticleContainer.cpp:2518-2528)
+    void ContinuousInjection(const double* box_lo, const double* box_hi) override { AddPlasma(box_lo, box_hi); }
+
+    // PhysicalParticleContainer::AddPlasma (:924-1333) for one box per brick, lab frame, plasma at rest: the
+    // cells of part_box that overlap this brick (find_overlap, Source/Particles/AddPlasmaUtilities.cpp:12-43),
+    // positions from InjectorPositionRegular, weight = density * cell volume / particles per cell.
+    // Generated on the host (a slab of one or two cell layers per step in a moving window) and appended.
+    void AddPlasma(const double* part_lo, const double* part_hi) {
+        if (!m_has_injector) return;
+        const wxa_plasma_injector& in = m_inj;
+        double olo[3], ohi[3];
+        int nov[3];
+        for (int d = 0; d < 3; ++d) {
+            const double tlo = m_ctx->brick_plo[d], thi = m_ctx->brick_phi[d], dx = m_ctx->dx[d];
+            if (!(tlo <= part_hi[d])) return;
+            olo[d] = part_lo[d] + std::max(std::floor((tlo - part_lo[d]) / dx), 0.0) * dx;
+            if (!(thi >= part_lo[d])) return;
+            ohi[d] = part_hi[d] - std::max(std::floor((part_hi[d] - thi) / dx), 0.0) * dx;
+            nov[d] = (int)std::round((ohi[d] - olo[d]) / dx);
+        }
+        const int nppc = in.ppc[0] * in.ppc[1] * in.ppc[2];
+        const double scale_fac = m_ctx->dx[0] * m_ctx->dx[1] * m_ctx->dx[2] / nppc;   // compute_scale_fac_volume
+        auto inside = [&](double x, double y, double z) {   // InjectorPosition::insideBounds
+            return x < in.hi[0] && x >= in.lo[0] && y < in.hi[1] && y >= in.lo[1] && z < in.hi[2] && z >= in.lo[2];
+        };
+        std::vector<double> cols[7];
+        for (int k = 0; k < nov[2]; ++k)
+            for (int j = 0; j < nov[1]; ++j)
+                for (int i = 0; i < nov[0]; ++i) {
+                    const int iv[3] = {i, j, k};
+                    double lo[3], hi[3];
+                    bool overlaps = true;   // InjectorPosition::overlapsWith
+                    for (int d = 0; d < 3; ++d) {
+                        lo[d] = olo[d] + (iv[d] + 0.0) * m_ctx->dx[d];
+                        hi[d] = olo[d] + (iv[d] + 1.0) * m_ctx->dx[d];
+                        overlaps = overlaps && !(lo[d] > in.hi[d] || hi[d] < in.lo[d]);
+                    }
+                    if (!overlaps) continue;
+                    bool any = false;       // :1030-1048 a corner, edge midpoint or the centre has density
+                    for (int a = 0; a < 27 && !any; ++a) {
+                        const int t[3] = {a % 3, (a / 3) % 3, a / 9};
+                        double q[3];
+                        for (int d = 0; d < 3; ++d) q[d] = t[d] == 0 ? lo[d] : (t[d] == 1 ? (lo[d] + hi[d]) / 2. : hi[d]);
+                        any = inside(q[0], q[1], q[2]) && in.density > 0;
+                    }
+                    if (!any) continue;
+                    for (int ip = 0; ip < nppc; ++ip) {
+                        // InjectorPositionRegular::getPositionUnitBox (Source/Initialization/InjectorPosition.H:74-92)
+                        const int nx = in.ppc[0], ny = in.ppc[1], nz = in.ppc[2];
+                        const int ix_part = ip / (ny * nz);
+                        const int iz_part = (ip - ix_part * (ny * nz)) / ny;
+                        const int iy_part = (ip - ix_part * (ny * nz)) - ny * iz_part;
+                        const double r[3] = {(0.5 + ix_part) / nx, (0.5 + iy_part) / ny, (0.5 + iz_part) / nz};
+                        double pos[3];
+                        bool in_tile = true;   // tile_realbox.contains: strictly inside
+                        for (int d = 0; d < 3; ++d) {
+                            pos[d] = olo[d] + (iv[d] + r[d]) * m_ctx->dx[d];   // getCellCoords
+                            in_tile = in_tile && pos[d] > m_ctx->brick_plo[d] && pos[d] < m_ctx->brick_phi[d];
+                        }
+                        if (!in_tile || !inside(pos[0], pos[1], pos[2])) continue;
+                        for (int d = 0; d < 3; ++d) cols[d].push_back(pos[d]);
+                        cols[3].push_back(in.density * scale_fac);
+                        for (int d = 4; d < 7; ++d) cols[d].push_back(0.0);
+                    }
+                }
+        AppendFromHost(cols);
+    }
+
+private:
+    wxa_plasma_injector m_inj{};
+    bool m_has_injector = false, m_do_continuous_injection = false;
+
+public:
 
     // Source/Particles/PhysicalParticleContainer.cpp:1812-2095: PushPX then DepositCurrent
     void Evolve(ablastr::fields::MultiFabRegister& fields, int lev, const std::string& current_fp_string,
@@ -391,17 +496,127 @@ public:
     }
 };
 
+// Source/Particles/LaserParticleContainer.{H,cpp}: the antenna, pairs of +-weight macro-particles on a plane,
+// moved with the velocity that radiates the requested field and depositing current like any species
+// (charge 1); lab frame, Gaussian profile
+class LaserParticleContainer : public WarpXParticleContainer {
+public:
+    LaserParticleContainer(WarpXContext* ctx, const wxa_laser_antenna& la)
+        : WarpXParticleContainer(ctx, /*charge=*/1.0, /*mass=*/std::numeric_limits<double>::max()), m_cfg(la) {   // :86-87
+        if (!(la.e_max > 0.0) || !(la.wavelength > 0.0)) throw std::runtime_error("laser: e_max and wavelength must be > 0");
+        double n = 0, p = 0;
+        for (int d = 0; d < 3; ++d) { n += la.direction[d] * la.direction[d]; p += la.polarization[d] * la.polarization[d]; }
+        const double sn = 1.0 / std::sqrt(n), sp = 1.0 / std::sqrt(p);                          // :197-214
+        for (int d = 0; d < 3; ++d) { m_nvec[d] = la.direction[d] * sn; m_p_X[d] = la.polarization[d] * sp; m_position[d] = la.position[d]; }
+        double dp = 0;
+        for (int d = 0; d < 3; ++d) dp += m_nvec[d] * m_p_X[d];
+        if (std::abs(dp) >= 1.0e-14) throw std::runtime_error("Laser plane vector is not perpendicular to the main polarization vector");
+        m_p_Y[0] = m_nvec[1] * m_p_X[2] - m_nvec[2] * m_p_X[1];                                  // :222 CrossProduct
+        m_p_Y[1] = m_nvec[2] * m_p_X[0] - m_nvec[0] * m_p_X[2];
+        m_p_Y[2] = m_nvec[0] * m_p_X[1] - m_nvec[1] * m_p_X[0];
+    }
+
+    // InitData (:360-559), 3-D: one pair of particles per cell of the antenna plane inside the domain
+    void InitData() {
+        const auto& dx = m_ctx->dx;
+        const double eps = dx[0] * 1e-50;                                                        // ComputeSpacing :727-762
+        auto spacing = [&](const double u[3]) {
+            return std::min(std::min(dx[0] / (std::abs(u[0]) + eps), dx[1] / (std::abs(u[1]) + eps)),
+                            dx[2] / (std::abs(u[2]) + eps));
+        };
+        m_S_X = spacing(m_p_X);
+        m_S_Y = spacing(m_p_Y);
+        m_mobility = 0.05 / m_cfg.e_max;                                                         // ComputeWeightMobility :764-781
+        m_weight = 8.8541878128e-12 / m_mobility;
+        m_weight *= m_S_X * m_S_Y;
+        int plo[2] = {INT_MAX, INT_MAX}, phi[2] = {INT_MIN, INT_MIN};
+        for (int c = 0; c < 8; ++c) {                                                           // :418-457
+            const double pos[3] = {(c & 1) ? m_ctx->prob_hi[0] : m_ctx->prob_lo[0], (c & 2) ? m_ctx->prob_hi[1] : m_ctx->prob_lo[1],
+                                   (c & 4) ? m_ctx->prob_hi[2] : m_ctx->prob_lo[2]};
+            double X = 0, Y = 0;
+            for (int d = 0; d < 3; ++d) { X += m_p_X[d] * (pos[d] - m_position[d]); Y += m_p_Y[d] * (pos[d] - m_position[d]); }
+            const int i = (int)(X / m_S_X), j = (int)(Y / m_S_Y);
+            plo[0] = std::min(plo[0], i); plo[1] = std::min(plo[1], j);
+            phi[0] = std::max(phi[0], i); phi[1] = std::max(phi[1], j);
+        }
+        std::vector<double> cols[7];
+        for (int j = plo[1]; j <= phi[1]; ++j)
+            for (int i = plo[0]; i <= phi[0]; ++i) {
+                double pos[3];
+                bool inside = true;   // injection box (the domain) strictly contains the point, and it is this brick's
+                for (int d = 0; d < 3; ++d) {
+                    pos[d] = m_position[d] + (m_S_X * ((double)i + 0.5)) * m_p_X[d] + (m_S_Y * ((double)j + 0.5)) * m_p_Y[d];
+                    inside = inside && pos[d] > m_ctx->prob_lo[d] && pos[d] < m_ctx->prob_hi[d] &&
+                             pos[d] >= m_ctx->brick_plo[d] && pos[d] < m_ctx->brick_phi[d];
+                }
+                if (!inside) continue;
+                for (int k = 0; k < 2; ++k) {
+                    for (int d = 0; d < 3; ++d) cols[d].push_back(pos[d]);
+                    cols[3].push_back(k == 0 ? m_weight : -m_weight);
+                    for (int d = 4; d < 7; ++d) cols[d].push_back(0.0);
+                }
+            }
+        AppendFromHost(cols);
+        if (m_ctx->sort_intervals_on && m_tile.numParticles() > 0) SortParticlesByBin(amrex::IntVect(1));
+    }
+
+    // Evolve (:563-713): push the antenna particles with the field to emit at time t, deposit at t_{n+1/2}
+    void Evolve(ablastr::fields::MultiFabRegister& fields, int lev, const std::string& current_fp_string, amrex::Real t,
+                amrex::Real dt, DtType /*a_dt_type*/ = DtType::Full, bool skip_deposition = false,
+                PushType push_type = PushType::Explicit) override {
+        using warpx::fields::FieldType;
+        if (push_type != PushType::Explicit) throw std::runtime_error("only the explicit push is supported");
+        if (current_fp_string != "current_fp") throw std::runtime_error("unknown current field");
+        if (m_tile.numParticles() == 0) return;
+        wxa_laser_push_params par{};
+        for (int d = 0; d < 3; ++d) { par.position[d] = m_position[d]; par.p_X[d] = m_p_X[d]; par.p_Y[d] = m_p_Y[d]; }
+        par.mobility = m_mobility;
+        par.e_max = m_cfg.e_max; par.wavelength = m_cfg.wavelength; par.waist = m_cfg.waist;
+        par.duration = m_cfg.duration; par.t_peak = m_cfg.t_peak; par.focal_distance = m_cfg.focal_distance;
+        {
+            PhaseTimer tm(m_ctx, kGatherAndPush);   // "LaserParticleContainer::Evolve::ParticlePush"
+            const wxa_particle_view p = m_tile.view();
+            check(m_ctx->be->laser_push(&p, &par, t, dt, m_ctx->stream), "laser_push");
+        }
+        if (m_ctx->sort_now) SortParticlesByBin(amrex::IntVect(1));
+        if (!skip_deposition) {
+            PhaseTimer tm(m_ctx, kCurrentDeposition);
+            auto J = fields.get_alldirs(FieldType::current_fp, lev);
+            DepositCurrent(J[0], J[1], J[2], dt, -0.5 * dt);
+        }
+    }
+
+    // :783-789 nothing to do
+    void PushP(int, amrex::Real, const amrex::MultiFab&, const amrex::MultiFab&, const amrex::MultiFab&, const amrex::MultiFab&,
+               const amrex::MultiFab&, const amrex::MultiFab&) override {}
+
+private:
+    wxa_laser_antenna m_cfg;
+    double m_nvec[3], m_p_X[3], m_p_Y[3], m_position[3];
+    double m_S_X = 0, m_S_Y = 0, m_mobility = 0, m_weight = 0;
+};
+
 // Source/Particles/MultiParticleContainer.{H,cpp}
 class MultiParticleContainer {
 public:
     explicit MultiParticleContainer(WarpXContext* ctx) : m_ctx(ctx) {}
 
     int AddSpecies(double charge, double mass) {
+        if (m_nlasers > 0) throw std::runtime_error("species must be added before the lasers (the antennas come last)");
         allcontainers.push_back(std::make_unique<PhysicalParticleContainer>(m_ctx, charge, mass));
         return (int)allcontainers.size() - 1;
     }
+    // lasers.names: the antennas follow the species in allcontainers (MultiParticleContainer.cpp:95-105)
+    int AddLaser(const wxa_laser_antenna& la) {
+        auto pc = std::make_unique<LaserParticleContainer>(m_ctx, la);
+        pc->InitData();
+        allcontainers.push_back(std::move(pc));
+        ++m_nlasers;
+        return (int)allcontainers.size() - 1;
+    }
     WarpXParticleContainer& GetParticleContainer(int i) { return *allcontainers.at(i); }
-    int nSpecies() const { return (int)allcontainers.size(); }
+    int nSpecies() const { return (int)allcontainers.size() - m_nlasers; }
+    int nContainers() const { return (int)allcontainers.size(); }
 
     // MultiParticleContainer.cpp:460-482: zero J once, then every species
     void Evolve(ablastr::fields::MultiFabRegister& fields, int lev, const std::string& current_fp_string,
@@ -438,6 +653,7 @@ public:
 private:
     WarpXContext* m_ctx;
     std::vector<std::unique_ptr<WarpXParticleContainer>> allcontainers;
+    int m_nlasers = 0;
 };
 
 }  // namespace wxa::host

@@ -35,6 +35,10 @@ struct Backend {
                        const int32_t* pec_hi, const int32_t* ng, void*);
     int (*apply_pec_j)(const wxa_field_view*, const int32_t* dom_lo, const int32_t* dom_hi, const int32_t* pec_lo,
                        const int32_t* pec_hi, void*);
+    // moving window field shift (scratch: a second array of the same shape) and the laser antenna push
+    int (*shift_field_window)(const wxa_field_view*, double* tmp, int32_t dir, int32_t num_shift, const int* periodic,
+                              void*);
+    int (*laser_push)(const wxa_particle_view*, const wxa_laser_push_params*, double t, double dt, void*);
     int (*filter_bilinear)(const wxa_field_view*, const wxa_field_view*, void*);
     int (*fill_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);
     int (*sync_nodal_periodic)(const wxa_field_view*, const int*, void*);

@@ -60,6 +60,48 @@ inline int sim_add_species(SimHandle* h, double charge, double mass, const wxa_p
     }
 }
 
+inline int sim_set_moving_window(SimHandle* h, const wxa_moving_window* mw) {
+    if (!h || !mw) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->SetMovingWindow(mw->dir, mw->v);
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
+// <species>.injection_style = NUniformPerCell (...): add_initial fills the current domain now
+// (PhysicalParticleContainer::InitData -> AddParticles -> AddPlasma), continuous keeps injecting behind a moving window
+inline int sim_set_injection(SimHandle* h, int32_t id, const wxa_plasma_injector* inj, int add_initial, int continuous) {
+    if (!h || !inj || id < 0 || id >= h->warpx->GetPartContainer().nSpecies()) return WXA_ERR_INVALID_ARG;
+    try {
+        WarpX& w = *h->warpx;
+        auto* pc = dynamic_cast<PhysicalParticleContainer*>(&w.GetPartContainer().GetParticleContainer(id));
+        if (!pc) return WXA_ERR_INVALID_ARG;
+        pc->SetPlasmaInjector(*inj, continuous != 0);
+        if (add_initial) {
+            pc->AddPlasma(w.context().prob_lo.data(), w.context().prob_hi.data());
+            if (w.sort_intervals > 0 && pc->TotalNumberOfParticles() > 0) pc->SortParticlesByBin(amrex::IntVect(1));
+        }
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
+inline int sim_add_laser(SimHandle* h, const wxa_laser_antenna* la) {
+    if (!h || !la) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->GetPartContainer().AddLaser(*la);
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
 inline int sim_evolve(SimHandle* h, int32_t numsteps) {
     if (!h || numsteps < 0) return WXA_ERR_INVALID_ARG;
     try {
@@ -136,6 +178,17 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     }                                                                                                  \
     RET PFX##sim_get_field(SIMTYPE* s, const char* name, wxa_field_view* out) {                        \
         return (RET)wxa::host::sim_get_field(reinterpret_cast<wxa::host::SimHandle*>(s), name, out);        \
+    }                                                                                                  \
+    RET PFX##sim_set_moving_window(SIMTYPE* s, const wxa_moving_window* mw) {                          \
+        return (RET)wxa::host::sim_set_moving_window(reinterpret_cast<wxa::host::SimHandle*>(s), mw);    \
+    }                                                                                                  \
+    RET PFX##sim_set_injection(SIMTYPE* s, int32_t id, const wxa_plasma_injector* inj, int add_initial, \
+                               int continuous) {                                                       \
+        return (RET)wxa::host::sim_set_injection(reinterpret_cast<wxa::host::SimHandle*>(s), id, inj,    \
+                                                 add_initial, continuous);                             \
+    }                                                                                                  \
+    RET PFX##sim_add_laser(SIMTYPE* s, const wxa_laser_antenna* la) {                                  \
+        return (RET)wxa::host::sim_add_laser(reinterpret_cast<wxa::host::SimHandle*>(s), la);            \
     }                                                                                                  \
     RET PFX##sim_get_particles(SIMTYPE* s, int32_t id, wxa_particle_view* out) {                       \
         return (RET)wxa::host::sim_get_particles(reinterpret_cast<wxa::host::SimHandle*>(s), id, out);      \

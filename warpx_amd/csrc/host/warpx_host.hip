@@ -107,6 +107,10 @@ const Backend* hip_backend() {
             return wxa_apply_pec_b(B, dlo, dhi, plo, phi, ng, st); };
         b.apply_pec_j = [](const wxa_field_view* J, const int32_t* dlo, const int32_t* dhi, const int32_t* plo,
                            const int32_t* phi, void* st) -> int { return wxa_apply_pec_j(J, dlo, dhi, plo, phi, st); };
+        b.shift_field_window = [](const wxa_field_view* f, double* tmp, int32_t dir, int32_t n, const int* per,
+                                  void* st) -> int { return wxa_shift_field_window(f, tmp, dir, n, per, st); };
+        b.laser_push = [](const wxa_particle_view* p, const wxa_laser_push_params* par, double t, double dt,
+                          void* st) -> int { return wxa_laser_push(p, par, t, dt, st); };
         b.apply_particle_boundaries = [](const wxa_particle_view* p, const double* plo, const double* phi,
                                          const int32_t* blo, const int32_t* bhi, int64_t* n_lost, void* ws,
                                          void* st) -> int {

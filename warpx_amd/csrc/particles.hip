@@ -2,6 +2,8 @@
 // deposition (global-atomics variants; the LDS-tile variants live in deposit_tile.hip),
 // periodic wrap, counting sort by cell.
 #include "deposit_body.hpp"
+#include <complex>
+
 #include "gather_body.hpp"
 #include "workspace.hpp"
 
@@ -216,6 +218,39 @@ static inline wxa_particle_view tail_view(const wxa_particle_view& p, int64_t fi
     if (t.idcpu) t.idcpu += first;
     t.np = p.np - first;
     return t;
+}
+
+// ---- laser antenna push (LaserParticleContainer.cpp:795-951, LaserProfileGaussian.cpp:104-161) -------------
+// Everything that does not depend on the particle is folded on the host into a complex prefactor
+// P = e_max exp(i phase) / D * exp(-(t - t_peak)^2 / tau^2) and the complex inverse waist 1 / (w^2 D),
+// D = 1 + 2 i f / (k0 w^2); the amplitude at (X, Y) is Re[P exp(-(X^2 + Y^2) / (w^2 D))].
+struct LaserPushGeom {
+    double position[3], p_X[3], p_Y[3];
+    double mobility;
+    double pre_re, pre_im;     // P
+    double iw2_re, iw2_im;     // 1 / (w^2 D)
+};
+
+__global__ void __launch_bounds__(256)
+laser_push_kernel(PV p, LaserPushGeom lg, double dt) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.np) return;
+    const double x = p.x[i], y = p.y[i], z = p.z[i];
+    const double Xp = lg.p_X[0] * (x - lg.position[0]) + lg.p_X[1] * (y - lg.position[1]) + lg.p_X[2] * (z - lg.position[2]);
+    const double Yp = lg.p_Y[0] * (x - lg.position[0]) + lg.p_Y[1] * (y - lg.position[1]) + lg.p_Y[2] * (z - lg.position[2]);
+    const double r2 = Xp * Xp + Yp * Yp;
+    // exp(-(r2) (a + i b)) = exp(-r2 a) (cos(r2 b) - i sin(r2 b))
+    const double mag = exp(-r2 * lg.iw2_re);
+    const double er = mag * cos(r2 * lg.iw2_im), ei = -mag * sin(r2 * lg.iw2_im);
+    const double amplitude = lg.pre_re * er - lg.pre_im * ei;
+    const double sign_charge = (p.w[i] > 0) ? -1.0 : 1.0;
+    const double v_over_c = sign_charge * lg.mobility * amplitude;
+    const double vx = PhysConst::c * v_over_c * lg.p_X[0];
+    const double vy = PhysConst::c * v_over_c * lg.p_X[1];
+    const double vz = PhysConst::c * v_over_c * lg.p_X[2];
+    const double gamma = 1.0 / sqrt(1.0 - v_over_c * v_over_c);
+    p.ux[i] = gamma * vx; p.uy[i] = gamma * vy; p.uz[i] = gamma * vz;
+    p.x[i] = x + vx * dt; p.y[i] = y + vy * dt; p.z[i] = z + vz * dt;
 }
 
 // ---- particle walls: WarpXParticleContainer::ApplyBoundaryConditions -------------------------------
@@ -606,6 +641,30 @@ wxa_status wxa_pack_leavers(const wxa_particle_view* p, const int32_t* list, int
     for (int d = 0; d < 3; ++d) { cg.blo[d] = brick_lo[d]; cg.bhi[d] = brick_hi[d]; }
     hipLaunchKernelGGL(pack_leavers_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, make_pv(*p),
                        list, (long)n, (double*)msg, (long)row_len, (long)offset, retire, cg);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_laser_push(const wxa_particle_view* p, const wxa_laser_push_params* c, double t, double dt,
+                          void* stream) {
+    WXA_REQUIRE(pv_ok(p) && c, "bad argument");
+    WXA_REQUIRE(c->wavelength > 0 && c->waist > 0 && c->duration > 0, "laser: wavelength, waist and duration must be > 0");
+    if (p->np == 0) return WXA_OK;
+    using cplx = std::complex<double>;
+    const cplx I(0, 1);
+    const double k0 = 2. * M_PI / c->wavelength;
+    const double inv_tau2 = 1. / (c->duration * c->duration);
+    const double oscillation_phase = k0 * PhysConst::c * (t - c->t_peak);
+    const cplx diffract_factor = 1. + I * c->focal_distance * 2. / (k0 * c->waist * c->waist);
+    const cplx inv_complex_waist_2 = 1. / (c->waist * c->waist * diffract_factor);
+    const cplx prefactor = c->e_max * std::exp(I * oscillation_phase) / diffract_factor;
+    const cplx stcfactor = prefactor * std::exp(-cplx(inv_tau2 * (t - c->t_peak) * (t - c->t_peak), 0.0));
+    LaserPushGeom lg;
+    for (int d = 0; d < 3; ++d) { lg.position[d] = c->position[d]; lg.p_X[d] = c->p_X[d]; lg.p_Y[d] = c->p_Y[d]; }
+    lg.mobility = c->mobility;
+    lg.pre_re = stcfactor.real(); lg.pre_im = stcfactor.imag();
+    lg.iw2_re = inv_complex_waist_2.real(); lg.iw2_im = inv_complex_waist_2.imag();
+    hipLaunchKernelGGL(laser_push_kernel, dim3(blocks_for(p->np)), dim3(256), 0, (hipStream_t)stream, make_pv(*p), lg, dt);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
