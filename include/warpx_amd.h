@@ -291,6 +291,13 @@ wxa_status wxa_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3],
                            const int32_t dom_hi[3], const int32_t pec_lo[3],
                            const int32_t pec_hi[3], void* stream);
 
+/* Replaces PEC::ApplyReflectiveBoundarytoRhofield (WarpX_PEC.cpp:628-711): rho behaves like a component
+ * tangential to every wall (:664-666).  Called by WarpXParticleContainer::DepositCharge right after the
+ * deposition (Source/Particles/WarpXParticleContainer.cpp:1285-1290), before the filter and the sum. */
+wxa_status wxa_apply_pec_rho(const wxa_field_view* rho, const int32_t dom_lo[3],
+                             const int32_t dom_hi[3], const int32_t pec_lo[3],
+                             const int32_t pec_hi[3], void* stream);
+
 /* ------------------------------------------------------------------ */
 /* Current filter and guard-cell exchange                              */
 /* ------------------------------------------------------------------ */
@@ -448,6 +455,10 @@ wxa_status wxa_sim_add_species(wxa_sim* s, double charge, double mass,
 /* WarpX::Evolve(numsteps): first step de-synchronises u by PushP(-dt/2),
  * the last one re-synchronises (WarpXEvolve.cpp:142-145,222-226). */
 wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
+/* RhoFunctor::operator() (Source/Diagnostics/ComputeDiagFunctors/RhoFunctor.cpp:42-61): total charge
+ * density of all species (and laser antennas) at the current positions, mirrored over PEC walls,
+ * filtered and summed over guards / bricks; readable afterwards as field "rho" (nodal). */
+wxa_status wxa_sim_compute_rho(wxa_sim* s);
 double     wxa_sim_dt(const wxa_sim* s);
 int64_t    wxa_sim_istep(const wxa_sim* s);
 /* name in {"Ex","Ey","Ez","Bx","By","Bz","jx","jy","jz"} (MultiFabRegister::get,

@@ -39,6 +39,8 @@ int orc_apply_pec_e(const wxa_field_view*, const int32_t*, const int32_t*, const
 int orc_apply_pec_b(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                     void*);
 int orc_apply_pec_j(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
+int orc_apply_pec_rho(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
+int orc_deposit_charge(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, int, void*);
 int orc_shift_field_window(const wxa_field_view*, double*, int32_t, int32_t, const int*, void*);
 int orc_laser_push(const wxa_particle_view*, const wxa_laser_push_params*, double, double, void*);
 int orc_apply_particle_boundaries(const wxa_particle_view*, const double*, const double*, const int32_t*, const int32_t*,
@@ -84,6 +86,8 @@ const Backend* cpu_backend() {
         b.apply_pec_e = orc_apply_pec_e;
         b.apply_pec_b = orc_apply_pec_b;
         b.apply_pec_j = orc_apply_pec_j;
+        b.apply_pec_rho = orc_apply_pec_rho;
+        b.deposit_charge = orc_deposit_charge;
         b.apply_particle_boundaries = orc_apply_particle_boundaries;
         b.shift_field_window = orc_shift_field_window;
         b.laser_push = orc_laser_push;

@@ -22,7 +22,7 @@ from warpx_amd.distributed import TorchBrickTransport, brick_coord  # noqa: E402
 from warpx_amd.sim import WarpXSim, field_energy, particle_moments  # noqa: E402
 
 L = 40e-6
-FIELDS = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz")
+FIELDS = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho")
 
 
 def main():
@@ -50,6 +50,7 @@ def main():
                    nbricks=nb, coord=coord, comm=transport.comm)
     sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
     sim.evolve(steps)
+    sim.compute_rho()           # charge deposition + filter + guard sum across bricks
     # ---- collect on rank 0 ----
     local = {n: sim.field_valid(n) for n in FIELDS}
     mom = particle_moments(sim, sid)
@@ -64,6 +65,7 @@ def main():
         ref = WarpXSim(orc, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt)
         rid = ref.add_species(-plasma.Q_E, plasma.M_E, list(parts))
         ref.evolve(steps)
+        ref.compute_rho()
         rmom = particle_moments(ref, rid)
         report = {"ok": True, "errors": {}, "np_total": sum(g["np"] for g in gathered),
                   "np_ref": int(parts.shape[1]), "inside": all(g["inside"] for g in gathered),

@@ -30,8 +30,9 @@ def test_single_brick_schedule_matches_oracle(oracle, host_cpu, order, filt, sor
         sid = sim.add_species(-plasma.Q_E, plasma.M_E, parts)
         sim.evolve(3)
         sim.evolve(2)   # a second Evolve call: de-synchronise again, same schedule as the reference
+        sim.compute_rho()
         res.append((field_energy(sim), particle_moments(sim, sid),
-                    {n: sim.field_valid(n) for n in ("Ex", "By", "jz")}))
+                    {n: sim.field_valid(n) for n in ("Ex", "By", "jz", "rho")}))
         sim.close()
     (fa, ma, Fa), (fb, mb, Fb) = res
     assert np.allclose(fa, fb, rtol=1e-11)

@@ -613,3 +613,19 @@ def test_laser_push(oracle, product):
         for row in range(7):
             scale = max(np.max(np.abs(b[row])), 1e-300)
             assert np.max(np.abs(a[row] - b[row])) <= 1e-13 * scale, (t, row)
+
+
+@UNVERIFIED
+@pytest.mark.parametrize("pec", [((1, 0, 0), (1, 0, 0)), ((0, 1, 1), (0, 1, 1)), ((0, 0, 1), (0, 0, 0))])
+def test_apply_pec_rho(oracle, product, pec):
+    """wxa_apply_pec_rho (PEC::ApplyReflectiveBoundarytoRhofield): the J kernel with the sign of a component
+    tangential to every wall, on a random nodal rho: bit-identical to the CPU restatement, guards included."""
+    ncell = (12, 10, 14)
+    dom_lo, dom_hi = (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*[n - 1 for n in ncell])
+    plo, phi = (C.c_int32 * 3)(*pec[0]), (C.c_int32 * 3)(*pec[1])
+    (rho,) = H.random_fields(("rho",), ncell, 5, 13)
+    (rho_d,) = H.clone_fields([rho], DEV, True)
+    oracle.apply_pec_rho(C.byref(rho.view), dom_lo, dom_hi, plo, phi, None)
+    product.apply_pec_rho(C.byref(rho_d.view), dom_lo, dom_hi, plo, phi, None)
+    _sync(product)
+    assert np.array_equal(rho_d.to_numpy(), rho.to_numpy())

@@ -143,14 +143,11 @@ def test_particle_boundaries_golden(oracle, which):
 
 # ---- moving window + continuous injection + laser antenna + PEC walls:
 #      Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration ---------------
-def _lwfa_report(oracle, sim, electrons, with_rho=True):
+def _lwfa_report(oracle, sim, electrons):
     from warpx_amd.sim import particle_moments
     out = {"lev=0": {}, "electrons": {}}
-    names = ["Bx", "By", "Bz", "Ex", "Ey", "Ez", "jx", "jy", "jz"]
-    if with_rho:
-        oracle.sim_compute_rho(sim._h)
-        names.append("rho")
-    for name in names:
+    sim.compute_rho()
+    for name in ("Bx", "By", "Bz", "Ex", "Ey", "Ez", "jx", "jy", "jz", "rho"):
         out["lev=0"][name] = oracle.cell_centered_abs_sum(C.byref(sim.field_view(name)))
     m = particle_moments(sim, electrons)
     for i, ax in enumerate("xyz"):
@@ -178,7 +175,7 @@ def test_laser_acceleration_golden(oracle, which):
     """The reference's 3-D laser-wakefield regression (BASELINE config 5 in small: 32x32x256, order 3, window
     moving at c, Gaussian antenna, continuous injection, PEC walls, filter): every field, current, rho and
     particle checksum of the golden file at the reference's tolerance, on the oracle stepper and on the
-    product's C++ host layer driving the CPU restatement's kernels (the host layer has no rho diagnostic)."""
+    product's C++ host layer driving the CPU restatement's kernels."""
     if which == "oracle":
         lib = oracle
     else:
@@ -187,5 +184,5 @@ def test_laser_acceleration_golden(oracle, which):
     sim, e = pec_case.make_lwfa_sim(lib)
     assert sim.particles(e).shape[1] == 21780          # 22 x 22 columns x 45 planes with 0 <= z < 12 um
     sim.evolve(pec_case.L_MAX_STEP)
-    check_lwfa_against_golden(_lwfa_report(oracle, sim, e, with_rho=(which == "oracle")))
+    check_lwfa_against_golden(_lwfa_report(oracle, sim, e))
     assert sim.particles(e).shape[1] == 69212           # 98 planes injected while the window advanced

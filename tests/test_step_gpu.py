@@ -282,7 +282,7 @@ def test_particle_boundaries_golden_on_gpu(product):
 def test_laser_acceleration_golden_on_gpu(oracle, product):
     """Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration on the HIP path (moving
     window at c, continuous injection, Gaussian antenna, PEC walls, filter, order 3): the reference's golden field,
-    current and particle checksums at the reference's tolerance."""
+    current, charge-density and particle checksums at the reference's tolerance."""
     from tests import pec_case
     from tests.test_pec_golden import check_lwfa_against_golden
     sim, e = pec_case.make_lwfa_sim(product)
@@ -290,7 +290,9 @@ def test_laser_acceleration_golden_on_gpu(oracle, product):
     ref, _ = pec_case.make_lwfa_sim(oracle)            # only as the host-side array the checksum reducer reads
     got = {"lev=0": {}, "electrons": {}}
     import ctypes as C
-    for name in ("Bx", "By", "Bz", "Ex", "Ey", "Ez", "jx", "jy", "jz"):
+    sim.compute_rho()
+    ref.compute_rho()                                  # creates the oracle-side rho array that is overwritten below
+    for name in ("Bx", "By", "Bz", "Ex", "Ey", "Ez", "jx", "jy", "jz", "rho"):
         ref.set_field(name, sim.field(name))
         got["lev=0"][name] = oracle.cell_centered_abs_sum(C.byref(ref.field_view(name)))
     m = particle_moments(sim, e)

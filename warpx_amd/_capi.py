@@ -135,6 +135,7 @@ _KERNEL_SIGS = {
     "apply_pec_j": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_particle_boundaries": (C.c_int, [_PPV, _D3, _D3, _I32_3, _I32_3, C.POINTER(C.c_int64), C.c_void_p,
                                             C.c_void_p]),
+    "apply_pec_rho": (C.c_int, [_PFV, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "shift_field_window": (C.c_int, [_PFV, C.c_void_p, C.c_int32, C.c_int32, _I3, C.c_void_p]),
     "laser_push": (C.c_int, [_PPV, C.POINTER(LaserPushParams), C.c_double, C.c_double, C.c_void_p]),
     "filter_bilinear": (C.c_int, [_PFV, _PFV, C.c_void_p]),
@@ -157,6 +158,7 @@ _SIM_SIGS = {
     "sim_get_timers": (C.c_int, [C.c_void_p, C.c_double * 8, C.c_int64 * 8, C.c_int]),
     "sim_enable_timers": (C.c_int, [C.c_void_p, C.c_int]),
     # moving window / continuous injection / laser antenna
+    "sim_compute_rho": (C.c_int, [C.c_void_p]),
     "sim_set_moving_window": (C.c_int, [C.c_void_p, C.POINTER(MovingWindow)]),
     "sim_set_injection": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PlasmaInjector), C.c_int, C.c_int]),
     "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
@@ -192,7 +194,6 @@ _ORACLE_SIGS = {
     "particle_momentum": (None, [_PPV, C.c_double, C.c_double * 3]),
     "cell_centered_abs_sum": (C.c_double, [_PFV]),
     "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
-    "sim_compute_rho": (C.c_int, [C.c_void_p]),
 
     "num_threads": (C.c_int, []),
     # CPU counterparts of the Redistribute entry points (host-layer tests, parity tests)

@@ -306,6 +306,35 @@ public:
             throw std::runtime_error("apply_pec_j failed");
     }
 
+    // RhoFunctor::operator() (Source/Diagnostics/ComputeDiagFunctors/RhoFunctor.cpp:42-61):
+    // MultiParticleContainer::GetChargeDensity (all species and antennas at their current positions; each
+    // species' rho is mirrored over the PEC walls right after its deposition, WarpXParticleContainer.cpp:
+    // 1285-1290 -- linear, so once on the total) + ApplyFilterandSumBoundaryRho (WarpXComm.cpp:1426-1470).
+    // Diagnostics only: the arrays are created at the first call.
+    amrex::MultiFab& ComputeRho() {
+        if (!m_rho) {
+            amrex::IntVect ng_rho;                                                  // GuardCellManager.cpp:62-172
+            for (int d = 0; d < 3; ++d)
+                ng_rho[d] = m_ctx.nox + 1 + static_cast<int>(std::ceil(299'792'458. * dt[0] / m_ctx.dx[d]));
+            m_rho = std::make_unique<amrex::MultiFab>(m_be, m_ctx.brick_box, amrex::IntVect(1), ng_rho);
+            if (use_filter) m_rho_tmp = std::make_unique<amrex::MultiFab>(m_be, m_ctx.brick_box, amrex::IntVect(1), ng_rho);
+        }
+        amrex::MultiFab& rho = *m_rho;
+        rho.setVal(0.0, m_ctx.stream);
+        for (int i = 0; i < mypc->nContainers(); ++i) mypc->GetParticleContainer(i).DepositCharge(&rho);
+        if (m_any_pec &&
+            m_be->apply_pec_rho(&rho.view(), m_dom_lo, m_dom_hi, m_pec_lo, m_pec_hi, m_ctx.stream) != 0)
+            throw std::runtime_error("apply_pec_rho failed");
+        if (use_filter) {
+            check(m_be->filter_bilinear(&rho.view(), &m_rho_tmp->view(), m_ctx.stream), "filter_bilinear");
+            rho.swap_storage(*m_rho_tmp);
+        }
+        m_comm->SumBoundary(rho, rho.nGrowVect(), /*refresh_guards=*/false, m_ctx.stream);
+        m_be->stream_sync(m_ctx.stream);
+        return rho;
+    }
+    amrex::MultiFab* rho() { return m_rho.get(); }
+
     // WarpXComm.cpp:1357-1374: filter into a temporary with the same guards, then "copy back":
     // here the two arrays simply exchange their storage (no copy)
     void ApplyFilterJ(const ablastr::fields::VectorField& current, int /*lev*/, int idim) {
@@ -460,6 +489,7 @@ private:
     std::unique_ptr<FiniteDifferenceSolver> m_fdtd_solver_fp;
     std::unique_ptr<BrickComm> m_comm;
     std::unique_ptr<amrex::MultiFab> m_filter_tmp[3];
+    std::unique_ptr<amrex::MultiFab> m_rho, m_rho_tmp;   // ComputeRho (diagnostics)
     std::vector<amrex::Real> dt;
     amrex::Real cur_time = 0.0;
     int64_t istep = 0;

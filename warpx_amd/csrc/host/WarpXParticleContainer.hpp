@@ -177,6 +177,15 @@ public:
               "deposit_current");
     }
 
+    // WarpXParticleContainer::DepositCharge (Source/Particles/WarpXParticleContainer.cpp:1180-1295), the
+    // box grown by the guards of rho; retired particles carry zero weight
+    void DepositCharge(amrex::MultiFab* rho) {
+        if (m_tile.numParticles() == 0) return;
+        const wxa_grid_geom g = m_ctx->geom(rho->nGrowVect());
+        const wxa_particle_view p = m_tile.view();
+        check(m_ctx->be->deposit_charge(&p, &rho->view(), &g, charge, m_ctx->nox, m_ctx->stream), "deposit_charge");
+    }
+
     // amrex SortParticlesByBin with bin = one cell (MultiParticleContainer.cpp:615-621).  Also
     // drops the particles retired by Redistribute and merges the arrivals appended since the
     // last sort into the cell order.

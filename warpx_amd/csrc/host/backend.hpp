@@ -28,6 +28,8 @@ struct Backend {
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);
     int (*deposit_current)(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double,
                            double, double, int, int, void* ws, void*);
+    // diagnostics: doChargeDepositionShapeN
+    int (*deposit_charge)(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, int, void*);
     // PEC field boundary (wxa_apply_pec_e / wxa_apply_pec_b)
     int (*apply_pec_e)(const wxa_field_view*, const int32_t* dom_lo, const int32_t* dom_hi, const int32_t* pec_lo,
                        const int32_t* pec_hi, const int32_t* ng, void*);
@@ -35,6 +37,8 @@ struct Backend {
                        const int32_t* pec_hi, const int32_t* ng, void*);
     int (*apply_pec_j)(const wxa_field_view*, const int32_t* dom_lo, const int32_t* dom_hi, const int32_t* pec_lo,
                        const int32_t* pec_hi, void*);
+    int (*apply_pec_rho)(const wxa_field_view*, const int32_t* dom_lo, const int32_t* dom_hi, const int32_t* pec_lo,
+                         const int32_t* pec_hi, void*);
     // moving window field shift (scratch: a second array of the same shape) and the laser antenna push
     int (*shift_field_window)(const wxa_field_view*, double* tmp, int32_t dir, int32_t num_shift, const int* periodic,
                               void*);

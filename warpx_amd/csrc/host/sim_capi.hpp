@@ -116,7 +116,13 @@ inline int sim_evolve(SimHandle* h, int32_t numsteps) {
 inline int sim_get_field(SimHandle* h, const char* name, wxa_field_view* out) {
     using warpx::fields::FieldType;
     using ablastr::fields::Direction;
-    if (!h || !name || !out || std::strlen(name) != 2) return WXA_ERR_INVALID_ARG;
+    if (!h || !name || !out) return WXA_ERR_INVALID_ARG;
+    if (std::strcmp(name, "rho") == 0) {                       // valid after sim_compute_rho
+        if (!h->warpx->rho()) return WXA_ERR_INVALID_ARG;
+        *out = h->warpx->rho()->view();
+        return WXA_OK;
+    }
+    if (std::strlen(name) != 2) return WXA_ERR_INVALID_ARG;
     const char* comps = "xyz";
     const char* cp = std::strchr(comps, name[1]);
     if (!cp) return WXA_ERR_INVALID_ARG;
@@ -128,6 +134,17 @@ inline int sim_get_field(SimHandle* h, const char* name, wxa_field_view* out) {
     else return WXA_ERR_INVALID_ARG;
     *out = h->warpx->fields().get(ft, Direction{d}, 0)->view();
     return WXA_OK;
+}
+
+inline int sim_compute_rho(SimHandle* h) {
+    if (!h) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->ComputeRho();
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_HIP;
+    }
 }
 
 inline int sim_get_particles(SimHandle* h, int32_t id, wxa_particle_view* out) {
@@ -178,6 +195,12 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     }                                                                                                  \
     RET PFX##sim_get_field(SIMTYPE* s, const char* name, wxa_field_view* out) {                        \
         return (RET)wxa::host::sim_get_field(reinterpret_cast<wxa::host::SimHandle*>(s), name, out);        \
+    }                                                                                                  \
+    RET PFX##sim_compute_rho(SIMTYPE* s) {                                                             \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        int rc = wxa::host::sim_compute_rho(h);                                                        \
+        if (rc != 0 && h) SET_ERROR(h->error.c_str());                                                 \
+        return (RET)rc;                                                                                \
     }                                                                                                  \
     RET PFX##sim_set_moving_window(SIMTYPE* s, const wxa_moving_window* mw) {                          \
         return (RET)wxa::host::sim_set_moving_window(reinterpret_cast<wxa::host::SimHandle*>(s), mw);    \

@@ -107,6 +107,10 @@ const Backend* hip_backend() {
             return wxa_apply_pec_b(B, dlo, dhi, plo, phi, ng, st); };
         b.apply_pec_j = [](const wxa_field_view* J, const int32_t* dlo, const int32_t* dhi, const int32_t* plo,
                            const int32_t* phi, void* st) -> int { return wxa_apply_pec_j(J, dlo, dhi, plo, phi, st); };
+        b.apply_pec_rho = [](const wxa_field_view* r, const int32_t* dlo, const int32_t* dhi, const int32_t* plo,
+                             const int32_t* phi, void* st) -> int { return wxa_apply_pec_rho(r, dlo, dhi, plo, phi, st); };
+        b.deposit_charge = [](const wxa_particle_view* p, const wxa_field_view* r, const wxa_grid_geom* g, double q,
+                              int order, void* st) -> int { return wxa_deposit_charge(p, r, g, q, order, st); };
         b.shift_field_window = [](const wxa_field_view* f, double* tmp, int32_t dir, int32_t n, const int* per,
                                   void* st) -> int { return wxa_shift_field_window(f, tmp, dir, n, per, st); };
         b.laser_push = [](const wxa_particle_view* p, const wxa_laser_push_params* par, double t, double dt,

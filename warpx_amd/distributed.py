@@ -138,22 +138,26 @@ class TorchBrickTransport:
             for i in range(nmsg):
                 if int(send_peer[i]) == self.rank:
                     recv_val[i] = send_val[i]
+            # one staging tensor each way: a single host->device copy before and a single device->host copy
+            # (the only synchronisation) after the batch
+            sbuf = torch.tensor([int(send_val[i]) for i in range(nmsg)], dtype=torch.int64).to(dev)
+            rbuf = torch.zeros(nmsg, dtype=torch.int64, device=dev)
             for i in range(nmsg):
                 sp = int(send_peer[i])
                 if sp != self.rank:
-                    t = torch.tensor([int(send_val[i])], dtype=torch.int64, device=dev)
-                    ops.append(dist.P2POp(dist.isend, t, sp, self.group, tag=100 + i))
+                    ops.append(dist.P2POp(dist.isend, sbuf[i:i + 1], sp, self.group, tag=100 + i))
             for i in range(nmsg):
                 rp = int(recv_peer[i])
                 if rp != self.rank:
-                    t = torch.zeros(1, dtype=torch.int64, device=dev)
-                    outs.append((i, t))
-                    ops.append(dist.P2POp(dist.irecv, t, rp, self.group, tag=100 + i))
+                    outs.append(i)
+                    ops.append(dist.P2POp(dist.irecv, rbuf[i:i + 1], rp, self.group, tag=100 + i))
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
-            for i, t in outs:
-                recv_val[i] = int(t.item())
+            if outs:
+                got = rbuf.cpu()
+                for i in outs:
+                    recv_val[i] = int(got[i])
             return 0
         except Exception as e:
             import traceback

@@ -88,6 +88,10 @@ class WarpXSim:
     def _d2h(self):
         return self.lib.copy_to_host if self.on_device else None
 
+    def compute_rho(self):
+        """RhoFunctor: total charge density at the current positions -> field "rho"."""
+        self.lib.sim_compute_rho(self._h)
+
     def field_view(self, name: str) -> _capi.FieldView:
         v = _capi.FieldView()
         self.lib.sim_get_field(self._h, name.encode(), C.byref(v))
