@@ -352,6 +352,8 @@ wxa_status wxa_device_synchronize(void);
 /* top of the kernels above.  One wxa_sim = one brick on one GPU.       */
 /* ------------------------------------------------------------------ */
 
+enum { WXA_GRID_STAGGERED = 0, WXA_GRID_COLLOCATED = 1 };
+
 typedef struct wxa_sim_config {
     int32_t n_cell[3];           /* amr.n_cell, whole domain                    */
     double  prob_lo[3];          /* geometry.prob_lo                            */
@@ -370,6 +372,9 @@ typedef struct wxa_sim_config {
                                     is folded back with the image-charge sign of an absorbing wall) */
     int32_t particle_boundary_lo[3]; /* boundary.particle_lo: WXA_PBOUNDARY_* (0 = default)              */
     int32_t particle_boundary_hi[3]; /* boundary.particle_hi                                             */
+    int32_t grid_type;           /* warpx.grid_type: WXA_GRID_STAGGERED (0, the default).  WXA_GRID_COLLOCATED exists
+                                    in the CPU restatement only (it pins the direct deposition to the reference's
+                                    test_3d_langmuir_multi_nodal checksums); the library refuses it              */
 } wxa_sim_config;
 
 /* ---- second "next" row: moving window, continuous plasma injection, laser antenna -----------------

@@ -6,10 +6,15 @@
 // and only as the checker.  Paths cited are relative to the WarpX checkout
 // @ 2024-10-24 (/root/reference).
 //
-// Parity pin: the step-level driver in pic_oracle.cpp reproduces
-// Regression/Checksum/benchmarks_json/test_3d_langmuir_multi.json to 1e-9
-// (tests/test_oracle_golden.py).  The per-kernel outputs are not pinned by any
-// reference test (the reference has no unit tests).
+// Parity pin: the step-level driver in pic_oracle.cpp reproduces, at the
+// reference's own tolerance (rtol 1e-9), the golden checksums under
+// Regression/Checksum/benchmarks_json/ of
+//   test_3d_langmuir_multi        (Esirkepov order 1, Boris, Yee; tests/test_oracle_golden.py)
+//   test_3d_langmuir_multi_nodal  (direct deposition, gather without Galerkin shapes; same file)
+//   test_3d_pec_field, test_3d_pec_particle (order 3, Vay, filter, PEC), test_3d_particle_boundaries,
+//   test_3d_laser_acceleration    (moving window, injection, antenna; tests/test_pec_golden.py).
+// The per-kernel outputs are not pinned by any reference test (the reference has
+// no unit tests).
 //
 // AMReX itself (containers, FillBoundary, SumBoundary, Redistribute) is not in
 // the reference tree (cmake/dependencies/AMReX.cmake:283-288 fetches commit

@@ -35,6 +35,51 @@ int max_threads() {
 #endif
 }
 
+// CartesianNodalAlgorithm::UpwardD{x,y,z} == DownwardD{x,y,z} (CartesianNodalAlgorithm.H:71-180): centred
+// differences on the collocated grid (warpx.grid_type = collocated)
+struct NodalD {
+    double idx, idy, idz;
+    double Dx(const Arr& F, int i, int j, int k) const { return 0.5 * idx * (F(i + 1, j, k) - F(i - 1, j, k)); }
+    double Dy(const Arr& F, int i, int j, int k) const { return 0.5 * idy * (F(i, j + 1, k) - F(i, j - 1, k)); }
+    double Dz(const Arr& F, int i, int j, int k) const { return 0.5 * idz * (F(i, j, k + 1) - F(i, j, k - 1)); }
+};
+
+inline bool all_nodal(const wxa_field_view F[3]) {
+    for (int c = 0; c < 3; ++c)
+        for (int d = 0; d < 3; ++d)
+            if (!F[c].stag[d]) return false;
+    return true;
+}
+
+// EvolveBCartesian / EvolveECartesian with T_Algo = CartesianNodalAlgorithm (EvolveB.cpp:164-186, EvolveE.cpp:179-216)
+void evolve_b_nodal(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3]) {
+    const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]);
+    const NodalD D{dinv[0], dinv[1], dinv[2]};
+#pragma omp parallel for
+    for (int k = vlo(B[0], 2); k < vhi(B[0], 2); ++k)
+        for (int j = vlo(B[0], 1); j < vhi(B[0], 1); ++j)
+            for (int i = vlo(B[0], 0); i < vhi(B[0], 0); ++i) {
+                Bx(i, j, k) += dt * D.Dz(Ey, i, j, k) - dt * D.Dy(Ez, i, j, k);
+                By(i, j, k) += dt * D.Dx(Ez, i, j, k) - dt * D.Dz(Ex, i, j, k);
+                Bz(i, j, k) += dt * D.Dy(Ex, i, j, k) - dt * D.Dx(Ey, i, j, k);
+            }
+}
+
+void evolve_e_nodal(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3], double dt,
+                    const double dinv[3]) {
+    const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]), jx(J[0]), jy(J[1]), jz(J[2]);
+    const NodalD D{dinv[0], dinv[1], dinv[2]};
+    constexpr double c2 = PhysConst::c * PhysConst::c;
+#pragma omp parallel for
+    for (int k = vlo(E[0], 2); k < vhi(E[0], 2); ++k)
+        for (int j = vlo(E[0], 1); j < vhi(E[0], 1); ++j)
+            for (int i = vlo(E[0], 0); i < vhi(E[0], 0); ++i) {
+                Ex(i, j, k) += c2 * dt * (-D.Dz(By, i, j, k) + D.Dy(Bz, i, j, k) - PhysConst::mu0 * jx(i, j, k));
+                Ey(i, j, k) += c2 * dt * (-D.Dx(Bz, i, j, k) + D.Dz(Bx, i, j, k) - PhysConst::mu0 * jy(i, j, k));
+                Ez(i, j, k) += c2 * dt * (-D.Dy(Bx, i, j, k) + D.Dx(By, i, j, k) - PhysConst::mu0 * jz(i, j, k));
+            }
+}
+
 }  // namespace
 
 extern "C" {
@@ -46,6 +91,7 @@ int orc_num_threads(void) { return max_threads(); }
 // CartesianYeeAlgorithm::UpwardD{x,y,z} (CartesianYeeAlgorithm.H:69-101,125-167,191-225)
 int orc_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
                  void*) {
+    if (all_nodal(E) && all_nodal(B)) { evolve_b_nodal(E, B, dt, dinv); return 0; }
     const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]);
     const double idx = dinv[0], idy = dinv[1], idz = dinv[2];
 #pragma omp parallel
@@ -75,6 +121,7 @@ int orc_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt
 // Source/FieldSolver/FiniteDifferenceSolver/EvolveE.cpp:120-250 (no EB, no F term)
 int orc_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
                  double dt, const double dinv[3], void*) {
+    if (all_nodal(E) && all_nodal(B) && all_nodal(J)) { evolve_e_nodal(E, B, J, dt, dinv); return 0; }
     const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]), jx(J[0]), jy(J[1]), jz(J[2]);
     const double idx = dinv[0], idy = dinv[1], idz = dinv[2];
     constexpr double c2 = PhysConst::c * PhysConst::c;
@@ -1279,9 +1326,15 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
             s->any_particle_wall = s->any_particle_wall || want != WXA_PBOUNDARY_PERIODIC;
         }
     }
-    // Yee staggering (Source/WarpX.cpp:2117-2125)
-    const int Es[3][3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
-    const int Bs[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    // Yee staggering (Source/WarpX.cpp:2117-2125); warpx.grid_type = collocated: everything nodal (:2140-2152)
+    // and the same shape factors in all directions for the gather (:967)
+    int Es[3][3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
+    int Bs[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (cfg->grid_type == WXA_GRID_COLLOCATED) {
+        for (int c = 0; c < 3; ++c)
+            for (int d = 0; d < 3; ++d) Es[c][d] = Bs[c][d] = 1;
+        s->cfg.galerkin = 0;
+    } else if (cfg->grid_type != WXA_GRID_STAGGERED) { delete s; return -2; }
     for (int c = 0; c < 3; ++c) {
         s->E[c].alloc(cfg->n_cell, Es[c], s->ng_EB);
         s->B[c].alloc(cfg->n_cell, Bs[c], s->ng_EB);

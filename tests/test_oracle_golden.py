@@ -43,7 +43,30 @@ def test_dt_matches_reference_script(langmuir_run):
 
 def test_golden_checksums(oracle, langmuir_run):
     sim, e, p = langmuir_run
-    gold = json.load(open(os.path.join(HERE, "golden", "langmuir_multi_3d_checksums.json")))
+    _check_langmuir_golden(oracle, sim, e, p, "langmuir_multi_3d_checksums.json")
+
+
+def test_nodal_golden_checksums_pin_direct_deposition(oracle):
+    """Examples/Tests/langmuir/inputs_test_3d_langmuir_multi_nodal (direct current deposition, collocated grid,
+    same shape factors in all directions for the gather): the only 3-D FDTD golden file of the reference that
+    runs doDepositionShapeN.  The collocated grid and its centred-difference solver exist in the CPU
+    restatement for this pin only; the deposition and gather routines are the ones the Yee runs use (they
+    take the staggering of the arrays they are handed, as the reference's do)."""
+    n_cell = (64, 64, 64)
+    el, lo, hi = plasma.langmuir_3d(n_cell, sign=+1.0)
+    po, _, _ = plasma.langmuir_3d(n_cell, sign=-1.0)
+    sim = WarpXSim(oracle, n_cell, lo, hi, nox=1, galerkin=1, particle_pusher=_capi.PUSHER_BORIS,
+                   current_deposition=_capi.DEPOSIT_DIRECT, use_filter=0, cfl=1.0,
+                   grid_type=_capi.GRID_COLLOCATED)
+    e = sim.add_species(-plasma.Q_E, plasma.M_E, el)
+    p = sim.add_species(+plasma.Q_E, plasma.M_E, po)
+    sim.evolve(40)
+    assert tuple(sim.field_view("Ex").stag) == (1, 1, 1) and tuple(sim.field_view("jz").stag) == (1, 1, 1)
+    _check_langmuir_golden(oracle, sim, e, p, "langmuir_multi_nodal_3d_checksums.json")
+
+
+def _check_langmuir_golden(oracle, sim, e, p, golden_file):
+    gold = json.load(open(os.path.join(HERE, "golden", golden_file)))
     rtol = gold["rtol"]
     ref = gold["checksums"]
     got = {}

@@ -43,6 +43,9 @@ class GridGeom(C.Structure):
     ]
 
 
+GRID_STAGGERED, GRID_COLLOCATED = 0, 1
+
+
 class SimConfig(C.Structure):
     _fields_ = [
         ("n_cell", C.c_int32 * 3),
@@ -61,6 +64,7 @@ class SimConfig(C.Structure):
         ("field_boundary_hi", C.c_int32 * 3),
         ("particle_boundary_lo", C.c_int32 * 3),
         ("particle_boundary_hi", C.c_int32 * 3),
+        ("grid_type", C.c_int32),
     ]
 
 

@@ -100,6 +100,8 @@ public:
                                                                        : cfg.prob_lo[d] + (bhi[d] + 1) * m_ctx.dx[d];
         }
         m_ctx.brick_box = amrex::Box(blo, bhi);
+        if (cfg.grid_type != WXA_GRID_STAGGERED)   // warpx.grid_type: the kernels are written for the Yee grid
+            throw std::runtime_error("warpx.grid_type: only the staggered (Yee) grid is on this path");
         ComputeDt();
         // warpx.use_filter: 1-pass bilinear, stencil length npass+1 = 2 (BilinearFilter.cpp:63-68)
         use_filter = cfg.use_filter != 0;

@@ -21,7 +21,8 @@ class WarpXSim:
                  particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
                  use_filter=0, cfl=1.0, sort_interval=-1, nbricks=(1, 1, 1), coord=(0, 0, 0),
                  comm: _capi.Comm | None = None, field_boundary_lo=(0, 0, 0), field_boundary_hi=(0, 0, 0),
-                 particle_boundary_lo=(0, 0, 0), particle_boundary_hi=(0, 0, 0)):
+                 particle_boundary_lo=(0, 0, 0), particle_boundary_hi=(0, 0, 0),
+                 grid_type=_capi.GRID_STAGGERED):
         self.lib = lib
         self.on_device = lib.prefix == "wxa_"
         cfg = _capi.SimConfig()
@@ -42,6 +43,7 @@ class WarpXSim:
         cfg.current_deposition = int(current_deposition)
         cfg.use_filter = int(use_filter)
         cfg.sort_interval = int(sort_interval)
+        cfg.grid_type = int(grid_type)   # collocated: CPU restatement only
         self.cfg = cfg
         self._comm = comm  # keep the callbacks alive
         self._h = C.c_void_p()
