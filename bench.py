@@ -191,7 +191,7 @@ def main():
     prob_hi = tuple(+L0 * nbricks[d] / 2 for d in range(3))
     depos = _capi.DEPOSIT_ESIRKEPOV if args.deposition == "esirkepov" else _capi.DEPOSIT_DIRECT
     pusher = _capi.PUSHER_BORIS if args.pusher == "boris" else _capi.PUSHER_VAY
-    sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=args.order, galerkin=1, particle_pusher=pusher,
+    sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=args.order, galerkin=None, particle_pusher=pusher,
                    current_deposition=depos, use_filter=0 if args.no_filter else 1, cfl=1.0,
                    sort_interval=args.sort_interval, nbricks=nbricks, coord=coord,
                    comm=transport.comm if transport else None)

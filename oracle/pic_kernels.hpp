@@ -10,7 +10,8 @@
 // reference's own tolerance (rtol 1e-9), the golden checksums under
 // Regression/Checksum/benchmarks_json/ of
 //   test_3d_langmuir_multi        (Esirkepov order 1, Boris, Yee; tests/test_oracle_golden.py)
-//   test_3d_langmuir_multi_nodal  (direct deposition, gather without Galerkin shapes; same file)
+//   test_3d_langmuir_multi_picmi  (direct deposition on the Yee grid, filter, 8 ppc, gather without
+//                                  Galerkin shapes; same file), test_3d_langmuir_multi_nodal (collocated),
 //   test_3d_pec_field, test_3d_pec_particle (order 3, Vay, filter, PEC), test_3d_particle_boundaries,
 //   test_3d_laser_acceleration    (moving window, injection, antenna; tests/test_pec_golden.py).
 // The per-kernel outputs are not pinned by any reference test (the reference has

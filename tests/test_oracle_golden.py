@@ -65,6 +65,46 @@ def test_nodal_golden_checksums_pin_direct_deposition(oracle):
     _check_langmuir_golden(oracle, sim, e, p, "langmuir_multi_nodal_3d_checksums.json")
 
 
+def picmi_langmuir_sim(lib, device=None):
+    """inputs_test_3d_langmuir_multi_picmi.py as the reference resolves it (see the golden file's _source)."""
+    parts, lo, hi = plasma.half_domain_beam()
+    sim = WarpXSim(lib, (64, 64, 64), lo, hi, nox=1, particle_pusher=_capi.PUSHER_BORIS,
+                   current_deposition=_capi.DEPOSIT_DIRECT, use_filter=1, cfl=1.0, sort_interval=4)
+    assert sim.cfg.galerkin == 0
+    return sim, sim.add_species(-plasma.Q_E, plasma.M_E, parts)
+
+
+def check_picmi_langmuir_golden(oracle, sim, e, cc_abs_sum=None):
+    gold = json.load(open(os.path.join(HERE, "golden", "langmuir_multi_picmi_3d_checksums.json")))
+    cc = cc_abs_sum or (lambda name: _cc_abs_sum(oracle, sim, name))
+    m = particle_moments(sim, e)
+    got = {"lev=0": {"Ex": cc("Ex"), "jx": cc("jx")},
+           "electrons": {"particle_momentum_x": m["abs_momentum"][0], "particle_position_x": m["abs_position"][0],
+                         "particle_position_y": m["abs_position"][1], "particle_position_z": m["abs_position"][2],
+                         "particle_weight": m["weight"]}}
+    for group, vals in got.items():
+        for key, val in vals.items():
+            want = gold["checksums"][group][key]
+            rel = abs(val - want) / abs(want)
+            print(f"{group}.{key}: got {val:.16e} want {want:.16e} rel {rel:.2e}")
+            assert rel < gold["rtol"], (group, key, val, want)
+
+
+@pytest.mark.parametrize("which", ["oracle", "host_layer"])
+def test_picmi_golden_checksums_pin_direct_deposition_on_the_yee_grid(oracle, which):
+    """Examples/Tests/langmuir/inputs_test_3d_langmuir_multi_picmi.py: direct deposition on the staggered grid
+    with the bilinear filter, 8 particles per cell, a plasma edge inside the domain -- the hot path's
+    `direct` variant exactly as the reference runs it (gather without Galerkin shapes)."""
+    if which == "oracle":
+        lib = oracle
+    else:
+        from tests.oracle_lib import load_host_cpu
+        lib = load_host_cpu()
+    sim, e = picmi_langmuir_sim(lib)
+    sim.evolve(40)
+    check_picmi_langmuir_golden(oracle, sim, e)
+
+
 def _check_langmuir_golden(oracle, sim, e, p, golden_file):
     gold = json.load(open(os.path.join(HERE, "golden", golden_file)))
     rtol = gold["rtol"]

@@ -302,3 +302,24 @@ def test_laser_acceleration_golden_on_gpu(oracle, product):
     got["electrons"]["particle_weight"] = m["weight"]
     check_lwfa_against_golden(got)
     assert sim.particles(e).shape[1] == 69212
+
+
+@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
+                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (the same case "
+                           "passes on the oracle stepper and on the CPU build of the host layer, "
+                           "tests/test_oracle_golden.py); WXA_UNVERIFIED_GPU_TESTS=1 runs it")
+def test_picmi_langmuir_golden_on_gpu(oracle, product):
+    """Examples/Tests/langmuir/inputs_test_3d_langmuir_multi_picmi.py on the HIP path: direct deposition on the
+    Yee grid (LDS tiles), bilinear filter, gather without Galerkin shapes, 8 ppc, sorted every 4 steps: the
+    reference's golden checksums at the reference's tolerance."""
+    import ctypes as C
+
+    from tests.test_oracle_golden import check_picmi_langmuir_golden, picmi_langmuir_sim
+    sim, e = picmi_langmuir_sim(product)
+    sim.evolve(40)
+    ref, _ = picmi_langmuir_sim(oracle)                # host-side arrays for the checksum reducer
+
+    def cc(name):
+        ref.set_field(name, sim.field(name))
+        return oracle.cell_centered_abs_sum(C.byref(ref.field_view(name)))
+    check_picmi_langmuir_golden(oracle, sim, e, cc)

@@ -96,3 +96,16 @@ def langmuir_analytic_E(n_cell, lx, n0, epsilon, t):
     Ey = E0 * np.cos(k * X) * np.sin(k * Y) * np.cos(k * Z)
     Ez = E0 * np.cos(k * X) * np.cos(k * Y) * np.sin(k * Z)
     return Ex, Ey, Ez
+
+
+def half_domain_beam(n_cell=(64, 64, 64), lx=40.e-6, density=1.e25, ppc=(2, 2, 2), u_x=0.1):
+    """Examples/Tests/langmuir/inputs_test_3d_langmuir_multi_picmi.py: cold electrons filling x < 0
+    (UniformDistribution with upper_bound = [0, None, None]) with u = (u_x c, 0, 0), GriddedLayout."""
+    prob_lo = (-lx / 2.0,) * 3
+    prob_hi = (lx / 2.0,) * 3
+    x, y, z, dx, nppc = lattice_positions(n_cell, prob_lo, prob_hi, ppc)
+    keep = x < 0.0
+    x, y, z = x[keep], y[keep], z[keep]
+    n = x.shape[0]
+    w = np.full(n, density * dx[0] * dx[1] * dx[2] / nppc)
+    return [x, y, z, w, np.full(n, u_x * C_LIGHT), np.zeros(n), np.zeros(n)], prob_lo, prob_hi

@@ -17,7 +17,7 @@ from .containers import ParticleArrays, particles_to_numpy, view_to_numpy
 
 
 class WarpXSim:
-    def __init__(self, lib: _capi.CLib, n_cell, prob_lo, prob_hi, nox=1, galerkin=1,
+    def __init__(self, lib: _capi.CLib, n_cell, prob_lo, prob_hi, nox=1, galerkin=None,
                  particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
                  use_filter=0, cfl=1.0, sort_interval=-1, nbricks=(1, 1, 1), coord=(0, 0, 0),
                  comm: _capi.Comm | None = None, field_boundary_lo=(0, 0, 0), field_boundary_hi=(0, 0, 0),
@@ -38,6 +38,11 @@ class WarpXSim:
             cfg.particle_boundary_hi[d] = int(particle_boundary_hi[d])
         cfg.cfl = float(cfl)
         cfg.nox = int(nox)
+        if galerkin is None:
+            # the reference's resolution of WarpX::galerkin_interpolation (Source/WarpX.cpp:967,1208-1214): the same
+            # shape factors in all directions on a collocated grid and with direct deposition + an EM solver
+            galerkin = 0 if (int(current_deposition) == _capi.DEPOSIT_DIRECT or
+                             int(grid_type) == _capi.GRID_COLLOCATED) else 1
         cfg.galerkin = int(galerkin)
         cfg.particle_pusher = int(particle_pusher)
         cfg.current_deposition = int(current_deposition)
