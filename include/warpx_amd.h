@@ -460,6 +460,32 @@ wxa_status wxa_sim_add_species(wxa_sim* s, double charge, double mass,
 /* WarpX::Evolve(numsteps): first step de-synchronises u by PushP(-dt/2),
  * the last one re-synchronises (WarpXEvolve.cpp:142-145,222-226). */
 wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
+/* ---- input-deck front end -------------------------------------------------
+ * Builds the simulation a WarpX inputs file describes (amrex::ParmParse syntax, FILE includes,
+ * my_constants, math expressions; WarpX::ReadParameters' defaults) for the parameters on this path:
+ * 3-D Cartesian, Yee, periodic / PEC field and periodic / absorbing / reflecting particle boundaries,
+ * Esirkepov / direct deposition, Boris / Vay, bilinear filter, moving window, species injected as
+ * NUniformPerCell (constant density; at rest, constant or parsed momentum; continuous injection),
+ * SingleParticle, MultipleParticles, Gaussian laser antennas, E/B initialised by constants or parsed
+ * functions.  Any other parameter that is not plain output / AMReX box sizing is an error, by name.
+ * overrides: "name=value" strings applied after the file, like the reference's command line.
+ * nbricks / coord: this library's decomposition (NULL = one brick); the deck's amr.max_grid_size and
+ * blocking_factor describe AMReX boxes and are ignored. */
+wxa_status wxa_sim_create_from_inputs(const char* inputs_path, int32_t n_overrides,
+                                      const char* const* overrides, const wxa_comm* comm,
+                                      const int32_t* nbricks, const int32_t* coord, wxa_sim** out);
+int32_t     wxa_sim_max_step(const wxa_sim* s);                 /* the deck's max_step, -1 if unset */
+int32_t     wxa_sim_num_species(const wxa_sim* s);
+const char* wxa_sim_species_name(const wxa_sim* s, int32_t id); /* particles.species_names[id]      */
+/* The reference's regression checksum (Regression/Checksum/checksum.py) of the current state as JSON
+ * text: "lev=0" sums of |cell-centred field| for E, B, j, rho and per species sums of |x|, |m u|, w
+ * (this brick's share).  Returns the text length (buf may be NULL to ask for it) or < 0. */
+int64_t     wxa_sim_checksum_json(wxa_sim* s, char* buf, int64_t capacity);
+/* The decks' expression evaluator (what the reference gets from amrex::Parser): value of `expr` with
+ * the named variables bound to `values`; q_e, m_e, m_p, m_u, epsilon0, mu0, clight, kb, pi predefined. */
+wxa_status  wxa_parser_eval(const char* expr, int32_t nvars, const char* const* names,
+                            const double* values, double* out);
+
 /* RhoFunctor::operator() (Source/Diagnostics/ComputeDiagFunctors/RhoFunctor.cpp:42-61): total charge
  * density of all species (and laser antennas) at the current positions, mirrored over PEC walls,
  * filtered and summed over guards / bricks; readable afterwards as field "rho" (nodal). */

@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "../../warpx_amd/csrc/host/sim_capi.hpp"
+#include "../../warpx_amd/csrc/host/WarpXInputs.hpp"
 
 extern "C" {
 int orc_evolve_b(const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
@@ -101,9 +101,12 @@ const Backend* cpu_backend() {
     return &be;
 }
 
-void set_err(const char* msg) { std::fprintf(stderr, "[host_cpu] %s\n", msg); }
+std::string g_last_error;
+void set_err(const char* msg) { g_last_error = msg; std::fprintf(stderr, "[host_cpu] %s\n", msg); }
 
 }  // namespace
 
 struct hst_sim {};
+extern "C" const char* hst_last_error(void) { return g_last_error.c_str(); }
 WXA_SIM_CAPI(hst_, int, hst_sim, cpu_backend, set_err)
+WXA_INPUTS_CAPI(hst_, int, hst_sim, cpu_backend, set_err)

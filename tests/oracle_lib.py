@@ -42,5 +42,5 @@ def load_host_cpu():
     global _host_cpu
     if _host_cpu is None:
         subprocess.check_call(["make", "-C", HOST_CPU_DIR, "libhost_cpu.so"], stdout=subprocess.DEVNULL)
-        _host_cpu = _capi.CLib(HOST_CPU_LIB, "hst_", None, kernels=False)
+        _host_cpu = _capi.CLib(HOST_CPU_LIB, "hst_", _capi._INPUTS_SIGS, kernels=False)
     return _host_cpu

@@ -1,0 +1,180 @@
+"""The input-deck front end of the host layer (warpx_amd/csrc/host/WarpXInputs.hpp, Parser.hpp, Checksum.hpp)
+on the CPU build of the host layer: expression evaluator, deck syntax, refusal of parameters outside the
+path, and whole decks -- ours under tests/decks and, when the reference checkout is present, the
+reference's own example decks unmodified -- run to the reference's golden checksums with the library's own
+checksum writer (no oracle reducer in the loop)."""
+import ctypes as C
+import json
+import math
+import os
+
+import pytest
+
+from tests.oracle_lib import load_host_cpu
+from warpx_amd import _capi
+from warpx_amd.sim import WarpXSim
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DECKS = os.path.join(HERE, "decks")
+REFERENCE = "/root/reference"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return load_host_cpu()
+
+
+def _eval(lib, expr, **variables):
+    names = (C.c_char_p * max(len(variables), 1))(*[k.encode() for k in variables])
+    vals = (C.c_double * max(len(variables), 1))(*variables.values())
+    out = C.c_double()
+    lib.parser_eval(expr.encode(), len(variables), names, vals, C.byref(out))
+    return out.value
+
+
+@pytest.mark.parametrize("expr,want", [
+    ("1+2*3", 7.0), ("(1+2)*3", 9.0), ("2**3**2", 512.0), ("2^3", 8.0), ("-2^2", -4.0), ("2^-1", 0.5),
+    ("10/4/5", 0.5), ("1.e-6*2", 2e-6), ("3 - -2", 5.0), ("+4", 4.0), ("1 - 2 - 3", -4.0),
+    ("(3>2) * (2<1)", 0.0), ("(3>=3) + (2<=1) + (1==1) + (1!=1)", 2.0), ("1 < 2 and 2 < 3", 1.0), ("0 or 0", 0.0),
+    ("sqrt(16) + abs(-2) + fabs(-1)", 7.0), ("if(2>1, 10, 20)", 10.0), ("if(0, 10, 20)", 20.0),
+    ("min(3, 4) + max(3, 4) + pow(2, 10)", 1031.0), ("heaviside(-1, 0.5) + heaviside(0, 0.5) + heaviside(2, 0.5)", 1.5),
+    ("floor(2.7) + ceil(2.2)", 5.0), ("fmod(7, 4)", 3.0),
+    ("sin(pi/2) + cos(0) + exp(0) + log(1) + log10(100) + tanh(0) + atan2(0, 1)", 5.0),
+    ("2*pi*clight/clight", 2 * math.pi), ("q_e/m_e", 1.602176634e-19 / 9.1093837015e-31),
+    ("epsilon0*mu0*clight^2", 8.8541878128e-12 * 1.25663706212e-06 * 299792458.0 ** 2),
+])
+def test_parser_values(lib, expr, want):
+    assert _eval(lib, expr) == pytest.approx(want, rel=1e-15, abs=1e-300)
+
+
+def test_parser_variables_and_errors(lib):
+    k = 2.0 * 2.0 * math.pi / 40e-6
+    got = _eval(lib, "0.01 * sin(k*x) * cos(k*y) * cos(k*z)", k=k, x=3e-6, y=-7e-6, z=1.1e-5)
+    assert got == pytest.approx(0.01 * math.sin(k * 3e-6) * math.cos(k * -7e-6) * math.cos(k * 1.1e-5), rel=1e-15)
+    assert _eval(lib, "((1.e5*sin(2*pi*(z)/wavelength)) * (z<z2) * (z>z1))", z=1e-7, wavelength=1e-6, z1=-2e-6, z2=2e-6) \
+        == pytest.approx(1e5 * math.sin(2 * math.pi * 1e-7 / 1e-6), rel=1e-15)
+    for bad in ("1 +", "foo(1)", "unknown_name * 2", "(1", "sqrt(1, 2)", "1 2"):
+        with pytest.raises(_capi.WxaError):
+            _eval(lib, bad)
+
+
+def _write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+MINIMAL = """
+max_step = 2
+amr.n_cell = 8 8 8
+geometry.dims = 3
+geometry.prob_lo = -1. -1. -1.
+geometry.prob_hi =  1.  1.  1.
+boundary.field_lo = periodic periodic periodic
+boundary.field_hi = periodic periodic periodic
+"""
+
+
+def test_deck_syntax_includes_overrides_and_constants(lib, tmp_path):
+    _write(tmp_path, "base.inputs", MINIMAL + "my_constants.n = 4*m   # m is defined by the including file\n")
+    deck = _write(tmp_path, "top.inputs", "FILE = base.inputs\nmy_constants.m = 3\namr.n_cell = n n 2*n  # overrides the base\n"
+                                          "warpx.cfl=0.5\n")
+    sim = WarpXSim.from_inputs(lib, deck)
+    v = sim.field_view("Ex")
+    assert (v.n[0] - 2 * v.ng[0], v.n[1] - 2 * v.ng[1] - 1, v.n[2] - 2 * v.ng[2] - 1) == (12, 12, 24)
+    dt_half = sim.dt
+    assert sim.max_step == 2 and sim.species_names == []
+    sim.close()
+    sim = WarpXSim.from_inputs(lib, deck, overrides=["warpx.cfl = 1.0", "max_step=7"])
+    assert sim.dt == pytest.approx(2 * dt_half, rel=1e-14) and sim.max_step == 7
+    sim.close()
+
+
+@pytest.mark.parametrize("extra,needle", [
+    ("algo.maxwell_solver = ckc", "maxwell_solver"),
+    ("warpx.gamma_boost = 10.", "gamma_boost"),
+    ("boundary.field_lo = pml pml pml", "pml"),
+    ("warpx.do_pml = 1", "do_pml"),
+    ("amr.max_level = 1", "max_level"),
+    ("geometry.dims = 2", "dims"),
+    ("warpx.grid_type = collocated", "grid_type"),
+    ("algo.field_gathering = momentum-conserving", "field_gathering"),
+    ("particles.species_names = e\ne.charge = -q_e\ne.mass = m_e\ne.injection_style = gaussian_beam\nalgo.particle_shape = 1",
+     "injection_style"),
+    ("particles.species_names = e\ne.charge = -q_e\ne.mass = m_e\ne.injection_style = nuniformpercell\n"
+     "e.num_particles_per_cell_each_dim = 1 1 1\ne.profile = constant\ne.density = 1.\n"
+     "e.momentum_distribution_type = gaussian\nalgo.particle_shape = 1", "momentum_distribution_type"),
+    ("particles.species_names = e\ne.charge = -q_e\ne.mass = m_e\ne.injection_style = singleparticle\n"
+     "e.single_particle_pos = 0 0 0\ne.single_particle_u = 0 0 0\ne.single_particle_weight = 1", "particle_shape"),
+    ("warpx.some_new_feature = 1", "some_new_feature"),
+    ("my_constants.a = b\nmy_constants.b = a", "my_constants"),
+])
+def test_parameters_outside_the_path_are_refused_by_name(lib, tmp_path, extra, needle):
+    deck = _write(tmp_path, "bad.inputs", MINIMAL + extra + "\n")
+    with pytest.raises(_capi.WxaError) as e:
+        WarpXSim.from_inputs(lib, deck)
+    assert needle in str(e.value)
+
+
+# golden fixture, quantities excluded because they are round-off residue in the reference itself
+OUR_DECKS = [
+    ("langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", ()),
+    ("langmuir_beam_direct_3d.inputs", "langmuir_multi_picmi_3d_checksums.json", ()),
+    ("pec_standing_wave_3d.inputs", "pec_field_3d_checksums.json", ()),
+    ("pec_two_particles_3d.inputs", "pec_particle_3d_checksums.json",
+     ("By", "jx", "jz", "particle_momentum_z", "particle_position_z")),
+    ("particle_walls_3d.inputs", "particle_boundaries_3d_checksums.json", ()),
+    ("laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", ()),
+]
+
+
+def compare_with_golden(got, gold_checksums, rtol, skip=()):
+    worst = 0.0
+    for group, vals in gold_checksums.items():
+        for key, want in vals.items():
+            if key in skip or key in ("particle_initialenergy", "particle_regionofinterest"):
+                continue
+            val = got[group][key]
+            rel = abs(val - want) / abs(want) if want != 0 else abs(val)
+            worst = max(worst, rel)
+            assert rel < rtol, (group, key, val, want, rel)
+    return worst
+
+
+@pytest.mark.parametrize("deck,golden,skip", OUR_DECKS)
+def test_decks_reach_the_reference_golden_checksums(lib, deck, golden, skip):
+    gold = json.load(open(os.path.join(HERE, "golden", golden)))
+    sim = WarpXSim.from_inputs(lib, os.path.join(DECKS, deck))
+    sim.evolve(sim.max_step)
+    worst = compare_with_golden(sim.checksum(), gold["checksums"], gold["rtol"], skip)
+    print(deck, "worst relative deviation", worst)
+    sim.close()
+
+
+REFERENCE_DECKS = [
+    ("Examples/Tests/langmuir/inputs_test_3d_langmuir_multi", "test_3d_langmuir_multi", ()),
+    ("Examples/Tests/pec/inputs_test_3d_pec_field", "test_3d_pec_field", ()),
+    ("Examples/Tests/pec/inputs_test_3d_pec_particle", "test_3d_pec_particle",
+     ("By", "jx", "jz", "particle_momentum_z", "particle_position_z")),
+    ("Examples/Tests/boundaries/inputs_test_3d_particle_boundaries", "test_3d_particle_boundaries", ()),
+    ("Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration", "test_3d_laser_acceleration", ()),
+]
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference checkout is not on this machine")
+@pytest.mark.parametrize("deck,name,skip", REFERENCE_DECKS)
+def test_the_reference_decks_run_unmodified(lib, deck, name, skip):
+    """The reference's own example inputs files, read where they lie, against its own golden JSON files."""
+    gold = json.load(open(os.path.join(REFERENCE, "Regression/Checksum/benchmarks_json", name + ".json")))
+    sim = WarpXSim.from_inputs(lib, os.path.join(REFERENCE, deck))
+    sim.evolve(sim.max_step)
+    compare_with_golden(sim.checksum(), gold, 1e-9, skip)
+    sim.close()
+
+
+def test_a_reference_deck_outside_the_path_is_refused(lib):
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference checkout is not on this machine")
+    with pytest.raises(_capi.WxaError) as e:   # PSATD, collocated grid
+        WarpXSim.from_inputs(lib, os.path.join(REFERENCE, "Examples/Tests/langmuir/inputs_test_3d_langmuir_multi_psatd_nodal"))
+    assert "maxwell_solver" in str(e.value) or "grid_type" in str(e.value)

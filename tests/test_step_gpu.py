@@ -323,3 +323,27 @@ def test_picmi_langmuir_golden_on_gpu(oracle, product):
         ref.set_field(name, sim.field(name))
         return oracle.cell_centered_abs_sum(C.byref(ref.field_view(name)))
     check_picmi_langmuir_golden(oracle, sim, e, cc)
+
+
+@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
+                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (the same decks "
+                           "pass on the CPU build of the host layer, tests/test_inputs_cpu.py); "
+                           "WXA_UNVERIFIED_GPU_TESTS=1 runs it")
+@pytest.mark.parametrize("deck,golden,skip", [
+    ("langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", ()),
+    ("langmuir_beam_direct_3d.inputs", "langmuir_multi_picmi_3d_checksums.json", ()),
+    ("pec_standing_wave_3d.inputs", "pec_field_3d_checksums.json", ()),
+    ("pec_two_particles_3d.inputs", "pec_particle_3d_checksums.json",
+     ("By", "jx", "jz", "particle_momentum_z", "particle_position_z")),
+    ("particle_walls_3d.inputs", "particle_boundaries_3d_checksums.json", ()),
+    ("laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", ()),
+])
+def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden, skip):
+    """tests/decks/*.inputs through wxa_sim_create_from_inputs, wxa_sim_evolve and wxa_sim_checksum_json on the HIP
+    path: the reference's golden checksums at the reference's tolerance, with no oracle code in the loop."""
+    from tests.test_inputs_cpu import compare_with_golden
+    gold = json.load(open(os.path.join(HERE, "golden", golden)))
+    sim = WarpXSim.from_inputs(product, os.path.join(HERE, "decks", deck))
+    sim.evolve(sim.max_step)
+    compare_with_golden(sim.checksum(), gold["checksums"], gold["rtol"], skip)
+    sim.close()

@@ -150,6 +150,19 @@ _KERNEL_SIGS = {
     "version": (C.c_char_p, []),
 }
 
+# the input-deck front end of the host layer (product and its CPU test build; not in the oracle)
+_INPUTS_SIGS = {
+    "sim_create_from_inputs": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(Comm),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "sim_max_step": (C.c_int32, [C.c_void_p]),
+    "sim_num_species": (C.c_int32, [C.c_void_p]),
+    "sim_species_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
+    "sim_checksum_json": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "parser_eval": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double)]),
+    "last_error": (C.c_char_p, []),
+}
+
 _SIM_SIGS = {
     "sim_create": (C.c_int, [C.POINTER(SimConfig), C.c_void_p, C.POINTER(C.c_void_p)]),
     "sim_destroy": (None, [C.c_void_p]),
@@ -213,6 +226,10 @@ class WxaError(RuntimeError):
     pass
 
 
+# int-returning entry points whose result is a value, not a status
+_RETURNS_A_VALUE = {"sim_max_step", "sim_num_species", "num_threads"}
+
+
 class CLib:
     """A loaded C library whose symbols `<prefix><name>` follow include/warpx_amd.h."""
 
@@ -238,12 +255,12 @@ class CLib:
     def __getattr__(self, name):
         # checked call wrappers: lib.evolve_b(...) raises on a negative status
         raw = object.__getattribute__(self, "_" + name)
-        if raw.restype is C.c_int:
+        if raw.restype is C.c_int and name not in _RETURNS_A_VALUE:
             def checked(*a):
                 rc = raw(*a)
                 if rc != 0:
                     msg = ""
-                    if self.prefix == "wxa_":
+                    if hasattr(self, "_last_error"):
                         try:
                             msg = (self._last_error() or b"").decode()
                         except Exception:
@@ -262,7 +279,7 @@ def load_product() -> CLib:
     global _product
     if _product is None:
         # WXA_PRODUCT_LIB: another build of the same library (kernel experiments, scripts/)
-        _product = CLib(os.environ.get("WXA_PRODUCT_LIB", PRODUCT_LIB), "wxa_", _PRODUCT_SIGS)
+        _product = CLib(os.environ.get("WXA_PRODUCT_LIB", PRODUCT_LIB), "wxa_", {**_PRODUCT_SIGS, **_INPUTS_SIGS})
     return _product
 
 

@@ -1,0 +1,629 @@
+// Input-deck front end: reads a WarpX inputs file (the `key = values` format of amrex::ParmParse with
+// WarpX's FILE includes, my_constants and math expressions) and builds the simulation the deck describes,
+// for the part of the parameter space this library covers.  Restates what WarpX::ReadParameters
+// (Source/WarpX.cpp:480-1440), PlasmaInjector (Source/Initialization/PlasmaInjector.cpp), WarpX::InitData
+// (Source/Initialization/WarpXInitData.cpp) and LaserParticleContainer's constructor
+// (Source/Particles/LaserParticleContainer.cpp:70-250) read, with the reference's defaults.
+// A key that is neither understood nor known to be harmless (diagnostics, AMReX box sizes, verbosity)
+// is an error: a deck that asks for something outside this path must not run silently without it.
+#ifndef WXA_HOST_WARPX_INPUTS_HPP_
+#define WXA_HOST_WARPX_INPUTS_HPP_
+
+#include <algorithm>
+#include <fstream>
+#include <map>
+#include <set>
+#include <sstream>
+
+#include "Parser.hpp"
+#include "sim_capi.hpp"
+
+namespace wxa::host {
+
+// ---- amrex::ParmParse (table of `name = value value ...` definitions; the last definition wins) ----------
+class ParmParse {
+public:
+    void load_file(const std::string& path) {
+        std::ifstream in(path);
+        if (!in) throw std::runtime_error("inputs: cannot open " + path);
+        std::stringstream ss;
+        ss << in.rdbuf();
+        const size_t slash = path.find_last_of('/');
+        add_text(ss.str(), slash == std::string::npos ? std::string(".") : path.substr(0, slash));
+    }
+    // command-line style override: "name=value value"
+    void add_override(const std::string& def) { add_text(def, "."); }
+
+    bool contains(const std::string& key) const { return m_table.count(key) != 0; }
+    bool queryarr(const std::string& key, std::vector<std::string>& out) {
+        const auto it = m_table.find(key);
+        if (it == m_table.end()) return false;
+        m_used.insert(key);
+        out = it->second;
+        return true;
+    }
+    bool query(const std::string& key, std::string& out) {
+        std::vector<std::string> v;
+        if (!queryarr(key, v) || v.empty()) return false;
+        out = v[0];
+        return true;
+    }
+    // enum-like words are matched case-insensitively with '-' and '_' ignored (query_enum_sloppy)
+    bool query_word(const std::string& key, std::string& out) {
+        std::string v;
+        if (!query(key, v)) return false;
+        out.clear();
+        for (char c : v)
+            if (c != '-' && c != '_') out.push_back((char)std::tolower((unsigned char)c));
+        return true;
+    }
+    // utils::parser::queryWithParser / queryArrWithParser (Source/Utils/Parser/ParserUtils.H): every value is an
+    // expression of the user constants
+    bool queryArrWithParser(const std::string& key, std::vector<double>& out) {
+        std::vector<std::string> v;
+        if (!queryarr(key, v)) return false;
+        out.clear();
+        for (const std::string& e : v) out.push_back(evaluate(e));
+        return true;
+    }
+    bool queryWithParser(const std::string& key, double& out) {
+        std::vector<double> v;
+        if (!queryArrWithParser(key, v) || v.empty()) return false;
+        out = v[0];
+        return true;
+    }
+    bool queryWithParser(const std::string& key, int& out) {
+        double v;
+        if (!queryWithParser(key, v)) return false;
+        out = safe_int(v, key);
+        return true;
+    }
+    void getArrWithParser(const std::string& key, std::vector<double>& out, size_t n) {
+        if (!queryArrWithParser(key, out)) throw std::runtime_error("inputs: " + key + " must be set");
+        if (out.size() != n) throw std::runtime_error("inputs: " + key + " needs " + std::to_string(n) + " values");
+    }
+    double getWithParser(const std::string& key) {
+        double v;
+        if (!queryWithParser(key, v)) throw std::runtime_error("inputs: " + key + " must be set");
+        return v;
+    }
+    static int safe_int(double v, const std::string& what) {   // safeCastToInt(std::round(x))
+        const double r = std::round(v);
+        if (!(std::fabs(r) < 2.0e9)) throw std::runtime_error("inputs: " + what + " does not fit an integer");
+        return (int)r;
+    }
+
+    double evaluate(const std::string& expr) { return Parser(expr, {}, constants()).eval(); }
+    Parser makeParser(const std::string& expr, const std::vector<std::string>& vars) {
+        return Parser(expr, vars, constants());
+    }
+
+    // q_e, m_e, ... (Source/Utils/Parser/ParserUtils.cpp:120-135) + my_constants.*, which may use each other
+    const std::map<std::string, double>& constants() {
+        if (m_constants_ready) return m_constants;
+        m_constants = {{"clight", 299'792'458.},        {"epsilon0", 8.8541878128e-12}, {"mu0", 1.25663706212e-06},
+                       {"q_e", 1.602176634e-19},        {"m_e", 9.1093837015e-31},      {"m_p", 1.67262192369e-27},
+                       {"m_u", 1.66053906660e-27},      {"kb", 1.380649e-23},           {"pi", 3.14159265358979323846}};
+        std::map<std::string, std::string> todo;
+        const std::string prefix = "my_constants.";
+        for (const auto& kv : m_table)
+            if (kv.first.compare(0, prefix.size(), prefix) == 0 && !kv.second.empty()) {
+                todo[kv.first.substr(prefix.size())] = kv.second[0];
+                m_used.insert(kv.first);
+            }
+        while (!todo.empty()) {
+            bool progress = false;
+            std::string last_error;
+            for (auto it = todo.begin(); it != todo.end();) {
+                try {
+                    const double v = Parser(it->second, {}, m_constants).eval();
+                    m_constants[it->first] = v;
+                    it = todo.erase(it);
+                    progress = true;
+                } catch (const std::exception& e) {
+                    last_error = e.what();
+                    ++it;
+                }
+            }
+            if (!progress) throw std::runtime_error("inputs: cannot resolve my_constants: " + last_error);
+        }
+        m_constants_ready = true;
+        return m_constants;
+    }
+
+    void ignore(const std::string& key) { if (contains(key)) m_used.insert(key); }
+    void ignore_prefix(const std::string& prefix) {
+        for (const auto& kv : m_table)
+            if (kv.first.compare(0, prefix.size(), prefix) == 0) m_used.insert(kv.first);
+    }
+    std::vector<std::string> unused() const {
+        std::vector<std::string> out;
+        for (const auto& kv : m_table)
+            if (!m_used.count(kv.first)) out.push_back(kv.first);
+        return out;
+    }
+
+private:
+    // tokens: whitespace separated, "quoted strings" kept whole, '#' starts a comment, '=' stands alone
+    void add_text(const std::string& text, const std::string& dir) {
+        std::vector<std::string> tok;
+        std::vector<bool> quoted;
+        size_t i = 0;
+        const size_t n = text.size();
+        while (i < n) {
+            const char c = text[i];
+            if (std::isspace((unsigned char)c)) { ++i; continue; }
+            if (c == '#') { while (i < n && text[i] != '\n') ++i; continue; }
+            if (c == '=') { tok.emplace_back("="); quoted.push_back(false); ++i; continue; }
+            if (c == '"') {
+                const size_t e = text.find('"', i + 1);
+                if (e == std::string::npos) throw std::runtime_error("inputs: unterminated string");
+                tok.push_back(text.substr(i + 1, e - i - 1));
+                quoted.push_back(true);
+                i = e + 1;
+                continue;
+            }
+            size_t e = i;
+            int depth = 0;   // a name such as f(x,y,z) keeps its parentheses
+            while (e < n && (depth > 0 || (!std::isspace((unsigned char)text[e]) && text[e] != '=' && text[e] != '#'))) {
+                if (text[e] == '(') ++depth;
+                if (text[e] == ')') --depth;
+                if (text[e] == '"') break;
+                ++e;
+            }
+            tok.push_back(text.substr(i, e - i));
+            quoted.push_back(false);
+            i = e;
+        }
+        for (size_t t = 0; t < tok.size();) {
+            if (t + 1 >= tok.size() || tok[t + 1] != "=" || quoted[t + 1] || quoted[t])
+                throw std::runtime_error("inputs: expected 'name = value' near '" + tok[t] + "'");
+            const std::string name = tok[t];
+            t += 2;
+            std::vector<std::string> vals;
+            while (t < tok.size() && !(t + 1 < tok.size() && tok[t + 1] == "=" && !quoted[t + 1])) vals.push_back(tok[t++]);
+            if (name == "FILE") {   // include, relative to the including file
+                for (const std::string& f : vals) load_file(f[0] == '/' ? f : dir + "/" + f);
+                continue;
+            }
+            m_table[name] = vals;
+            m_constants_ready = false;
+        }
+    }
+
+    std::map<std::string, std::vector<std::string>> m_table;
+    std::set<std::string> m_used;
+    std::map<std::string, double> m_constants;
+    bool m_constants_ready = false;
+};
+
+// ---- the deck -> simulation builder ----------------------------------------------------------------------
+namespace inputs_detail {
+
+inline int axis_of(const std::string& w, const std::string& key) {
+    if (w == "x") return 0;
+    if (w == "y") return 1;
+    if (w == "z") return 2;
+    throw std::runtime_error("inputs: " + key + " must be x, y or z");
+}
+
+// WarpX::ComputeExternalFieldOnGridUsingParser (Source/Initialization/WarpXInitData.cpp:1062-1180): the whole
+// array, guards included, at x = i dx + prob_lo + (1 - nodal) dx / 2
+inline void fill_from_parser(const Backend* be, amrex::MultiFab& mf, const Parser& f, const WarpXContext& ctx) {
+    const wxa_field_view& v = mf.view();
+    std::vector<double> host((size_t)v.kstride * (size_t)v.n[2], 0.0);
+    double fac[3];
+    for (int d = 0; d < 3; ++d) fac[d] = (1.0 - v.stag[d]) * ctx.dx[d] * 0.5;
+    for (int k = 0; k < v.n[2]; ++k)
+        for (int j = 0; j < v.n[1]; ++j)
+            for (int i = 0; i < v.n[0]; ++i) {
+                const double xyzt[4] = {(i + v.lo[0]) * ctx.dx[0] + ctx.prob_lo[0] + fac[0],
+                                        (j + v.lo[1]) * ctx.dx[1] + ctx.prob_lo[1] + fac[1],
+                                        (k + v.lo[2]) * ctx.dx[2] + ctx.prob_lo[2] + fac[2], 0.0};
+                host[(size_t)i + (size_t)j * v.jstride + (size_t)k * v.kstride] = f.eval(xyzt);
+            }
+    if (be->memcpy_h2d(v.p, host.data(), sizeof(double) * host.size()) != 0)
+        throw std::runtime_error("inputs: copying an external field to the device failed");
+}
+
+}  // namespace inputs_detail
+
+struct DeckInfo {
+    int max_step = -1;
+    std::vector<std::string> species_names;
+};
+
+// nbricks / coord: this library's decomposition (one brick per GPU), not the deck's amr.max_grid_size
+inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::string& path,
+                                                  const std::vector<std::string>& overrides, const wxa_comm* comm,
+                                                  const int32_t nbricks[3], const int32_t coord[3], DeckInfo& info) {
+    using namespace inputs_detail;
+    ParmParse pp;
+    pp.load_file(path);
+    for (const std::string& o : overrides) pp.add_override(o);
+
+    wxa_sim_config cfg{};
+    // ---- geometry, amr (WarpX.cpp:480-560; AmrCore) ----
+    int dims = 3, max_level = 0;
+    pp.queryWithParser("geometry.dims", dims);
+    pp.queryWithParser("amr.max_level", max_level);
+    if (dims != 3) throw std::runtime_error("inputs: only geometry.dims = 3 is on this path");
+    if (max_level != 0) throw std::runtime_error("inputs: mesh refinement (amr.max_level > 0) is not on this path");
+    std::vector<double> v;
+    pp.getArrWithParser("amr.n_cell", v, 3);
+    for (int d = 0; d < 3; ++d) cfg.n_cell[d] = ParmParse::safe_int(v[d], "amr.n_cell");
+    pp.getArrWithParser("geometry.prob_lo", v, 3);
+    for (int d = 0; d < 3; ++d) cfg.prob_lo[d] = v[d];
+    pp.getArrWithParser("geometry.prob_hi", v, 3);
+    for (int d = 0; d < 3; ++d) cfg.prob_hi[d] = v[d];
+    for (int d = 0; d < 3; ++d) { cfg.nbricks[d] = nbricks ? nbricks[d] : 1; cfg.coord[d] = coord ? coord[d] : 0; }
+    std::string w;
+    if (pp.query_word("geometry.coord_sys", w) && w != "0" && w != "cartesian")
+        throw std::runtime_error("inputs: only cartesian geometry is on this path");
+
+    // ---- boundaries (WarpX.cpp ReadBoundaryConditions, Source/Utils/WarpXAlgorithmSelection.cpp) ----
+    std::vector<std::string> words;
+    auto field_bc = [&](const char* key, int32_t out[3]) {
+        if (!pp.queryarr(key, words)) throw std::runtime_error(std::string("inputs: ") + key + " must be set");
+        if (words.size() != 3) throw std::runtime_error(std::string("inputs: ") + key + " needs 3 values");
+        for (int d = 0; d < 3; ++d) {
+            std::string b = words[d];
+            std::transform(b.begin(), b.end(), b.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+            if (b == "periodic") out[d] = WXA_BOUNDARY_PERIODIC;
+            else if (b == "pec") out[d] = WXA_BOUNDARY_PEC;
+            else throw std::runtime_error("inputs: field boundary '" + words[d] + "' is not on this path (periodic, pec)");
+        }
+    };
+    field_bc("boundary.field_lo", cfg.field_boundary_lo);
+    field_bc("boundary.field_hi", cfg.field_boundary_hi);
+    auto particle_bc = [&](const char* key, int32_t out[3]) {
+        for (int d = 0; d < 3; ++d) out[d] = WXA_PBOUNDARY_DEFAULT;
+        if (!pp.queryarr(key, words)) return;
+        if (words.size() != 3) throw std::runtime_error(std::string("inputs: ") + key + " needs 3 values");
+        for (int d = 0; d < 3; ++d) {
+            std::string b = words[d];
+            std::transform(b.begin(), b.end(), b.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+            if (b == "periodic") out[d] = WXA_PBOUNDARY_PERIODIC;
+            else if (b == "absorbing") out[d] = WXA_PBOUNDARY_ABSORBING;
+            else if (b == "reflecting") out[d] = WXA_PBOUNDARY_REFLECTING;
+            else throw std::runtime_error("inputs: particle boundary '" + words[d] + "' is not on this path");
+        }
+    };
+    particle_bc("boundary.particle_lo", cfg.particle_boundary_lo);
+    particle_bc("boundary.particle_hi", cfg.particle_boundary_hi);
+
+    // ---- algorithms (WarpX.cpp:1100-1330) with the reference's defaults ----
+    cfg.cfl = 0.999;                                            // WarpX.H: cfl
+    pp.queryWithParser("warpx.cfl", cfg.cfl);
+    if (pp.query_word("algo.maxwell_solver", w) && w != "yee")
+        throw std::runtime_error("inputs: algo.maxwell_solver = " + w + " is not on this path (yee)");
+    cfg.grid_type = WXA_GRID_STAGGERED;
+    if (pp.query_word("warpx.grid_type", w) && w != "staggered")
+        throw std::runtime_error("inputs: warpx.grid_type = " + w + " is not on this path (staggered)");
+    cfg.current_deposition = WXA_DEPOSIT_ESIRKEPOV;             // default with an FDTD solver
+    if (pp.query_word("algo.current_deposition", w)) {
+        if (w == "esirkepov") cfg.current_deposition = WXA_DEPOSIT_ESIRKEPOV;
+        else if (w == "direct") cfg.current_deposition = WXA_DEPOSIT_DIRECT;
+        else throw std::runtime_error("inputs: algo.current_deposition = " + w + " is not on this path");
+    }
+    if (pp.query_word("algo.charge_deposition", w) && w != "standard")
+        throw std::runtime_error("inputs: algo.charge_deposition = " + w + " is not on this path");
+    cfg.particle_pusher = WXA_PUSHER_BORIS;
+    if (pp.query_word("algo.particle_pusher", w)) {
+        if (w == "boris") cfg.particle_pusher = WXA_PUSHER_BORIS;
+        else if (w == "vay") cfg.particle_pusher = WXA_PUSHER_VAY;
+        else throw std::runtime_error("inputs: algo.particle_pusher = " + w + " is not on this path (boris, vay)");
+    }
+    // same shape factors in all directions with direct deposition and an EM solver (WarpX.cpp:1208-1214)
+    cfg.galerkin = cfg.current_deposition == WXA_DEPOSIT_DIRECT ? 0 : 1;
+    if (pp.query_word("algo.field_gathering", w) && w != "energyconserving")
+        throw std::runtime_error("inputs: algo.field_gathering = " + w + " is not on this path (energy-conserving)");
+    int galerkin_scheme = cfg.galerkin;
+    if (pp.queryWithParser("interpolation.galerkin_scheme", galerkin_scheme)) cfg.galerkin = galerkin_scheme != 0;
+    cfg.nox = 0;
+    const bool has_shape = pp.queryWithParser("algo.particle_shape", cfg.nox);
+    int use_filter = 1;                                         // WarpX.cpp:158
+    pp.queryWithParser("warpx.use_filter", use_filter);
+    cfg.use_filter = use_filter != 0;
+    if (pp.queryArrWithParser("warpx.filter_npass_each_dir", v))
+        for (double np : v)
+            if (np != 1.0) throw std::runtime_error("inputs: only one bilinear filter pass per direction is on this path");
+    int flag = 0;
+    if (pp.queryWithParser("warpx.use_filter_compensation", flag) && flag)
+        throw std::runtime_error("inputs: warpx.use_filter_compensation is not on this path");
+    cfg.sort_interval = 4;                                      // WarpX.cpp:168 (GPU default)
+    if (pp.query("warpx.sort_intervals", w)) cfg.sort_interval = ParmParse::safe_int(pp.evaluate(w), "warpx.sort_intervals");
+    for (const char* key : {"warpx.do_dive_cleaning", "warpx.do_divb_cleaning", "warpx.do_subcycling", "warpx.do_pml",
+                            "particles.use_fdtd_nci_corr", "warpx.do_electrostatic", "warpx.do_multi_J"})
+        if (pp.queryWithParser(key, flag) && flag)
+            throw std::runtime_error(std::string("inputs: ") + key + " = 1 is not on this path");
+    double gamma_boost = 1.0;
+    if (pp.queryWithParser("warpx.gamma_boost", gamma_boost) && gamma_boost > 1.0)
+        throw std::runtime_error("inputs: a boosted frame (warpx.gamma_boost) is not on this path");
+
+    info.max_step = -1;
+    pp.queryWithParser("max_step", info.max_step);
+    if (pp.contains("stop_time")) throw std::runtime_error("inputs: stop_time is not supported, use max_step");
+
+    // ---- species and lasers present? (algo.particle_shape is mandatory then, WarpX.cpp:1283-1325) ----
+    std::vector<std::string> species_names, laser_names;
+    pp.queryarr("particles.species_names", species_names);
+    pp.queryarr("lasers.names", laser_names);
+    if (!species_names.empty() || !laser_names.empty()) {
+        if (!has_shape) throw std::runtime_error("inputs: algo.particle_shape must be set");
+    } else if (!has_shape) {
+        cfg.nox = 1;   // no particles: the guard depths only need a valid order
+    }
+
+    auto h = std::make_unique<SimHandle>();
+    h->warpx = std::make_unique<WarpX>(be, cfg, comm);
+    WarpX& wx = *h->warpx;
+    const WarpXContext& ctx = wx.context();
+
+    // ---- moving window (WarpX.cpp:620-660) ----
+    int do_moving_window = 0;
+    pp.queryWithParser("warpx.do_moving_window", do_moving_window);
+    if (do_moving_window) {
+        if (!pp.query_word("warpx.moving_window_dir", w)) throw std::runtime_error("inputs: warpx.moving_window_dir must be set");
+        wx.SetMovingWindow(axis_of(w, "warpx.moving_window_dir"), pp.getWithParser("warpx.moving_window_v"));
+    } else {
+        pp.ignore("warpx.moving_window_dir");
+        pp.ignore("warpx.moving_window_v");
+    }
+
+    // ---- external fields on the grid (WarpXInitData.cpp:940-1060) ----
+    using warpx::fields::FieldType;
+    using ablastr::fields::Direction;
+    for (const char* eb : {"E", "B"}) {
+        const std::string style_key = std::string("warpx.") + eb + "_ext_grid_init_style";
+        const FieldType ft = eb[0] == 'E' ? FieldType::Efield_fp : FieldType::Bfield_fp;
+        if (!pp.query_word(style_key, w) || w == "default") continue;
+        if (w == "constant") {
+            pp.getArrWithParser(std::string("warpx.") + eb + "_external_grid", v, 3);
+            for (int d = 0; d < 3; ++d) wx.fields().get(ft, Direction{d}, 0)->setVal(v[d], ctx.stream);
+        } else if (w == std::string("parse") + (char)std::tolower(eb[0]) + "extgridfunction") {
+            for (int d = 0; d < 3; ++d) {
+                const std::string key = std::string("warpx.") + eb + "xyz"[d] + "_external_grid_function(x,y,z)";
+                std::string expr;
+                if (!pp.query(key, expr)) throw std::runtime_error("inputs: " + key + " must be set");
+                fill_from_parser(be, *wx.fields().get(ft, Direction{d}, 0), pp.makeParser(expr, {"x", "y", "z", "t"}), ctx);
+            }
+        } else {
+            throw std::runtime_error("inputs: " + style_key + " = " + w + " is not on this path");
+        }
+    }
+    for (const char* key : {"particles.E_ext_particle_init_style", "particles.B_ext_particle_init_style"})
+        if (pp.query_word(key, w) && w != "none" && w != "default")
+            throw std::runtime_error(std::string("inputs: ") + key + " is not on this path");
+
+    // ---- species (PlasmaInjector.cpp, PhysicalParticleContainer::AddParticles) ----
+    const double c = 299'792'458.;
+    for (const std::string& name : species_names) {
+        double charge = 0.0, mass = 0.0;
+        bool have_q = false, have_m = false;
+        if (pp.query_word(name + ".species_type", w)) {   // Source/Particles/SpeciesPhysicalProperties.H
+            const auto& k = pp.constants();
+            if (w == "electron") { charge = -k.at("q_e"); mass = k.at("m_e"); }
+            else if (w == "positron") { charge = k.at("q_e"); mass = k.at("m_e"); }
+            else if (w == "proton") { charge = k.at("q_e"); mass = k.at("m_p"); }
+            else throw std::runtime_error("inputs: " + name + ".species_type = " + w + " is not on this path");
+            have_q = have_m = true;
+        }
+        have_q = pp.queryWithParser(name + ".charge", charge) || have_q;
+        have_m = pp.queryWithParser(name + ".mass", mass) || have_m;
+        if (!have_q || !have_m) throw std::runtime_error("inputs: " + name + ".charge and .mass (or .species_type) must be set");
+        if (charge != 0.0 && wx.any_reflecting_wall())
+            throw std::runtime_error("inputs: charged species with a reflecting particle boundary are not on this path");
+        for (const char* off : {".do_not_push", ".do_not_deposit", ".do_not_gather", ".do_field_ionization", ".do_qed_quantum_sync",
+                                ".do_qed_breit_wheeler", ".do_classical_radiation_reaction", ".do_backward_propagation",
+                                ".rigid_advance", ".initialize_self_fields", ".do_resampling"})
+            if (pp.queryWithParser(name + off, flag) && flag)
+                throw std::runtime_error("inputs: " + name + off + " is not on this path");
+        pp.ignore(name + ".addIntegerAttributes");   // extra per-particle attributes are diagnostics only
+        pp.ignore(name + ".addRealAttributes");
+        pp.ignore_prefix(name + ".attribute.");
+
+        const int sid = wx.GetPartContainer().AddSpecies(charge, mass);
+        auto* pc = dynamic_cast<PhysicalParticleContainer*>(&wx.GetPartContainer().GetParticleContainer(sid));
+        if (!pp.query_word(name + ".injection_style", w)) throw std::runtime_error("inputs: " + name + ".injection_style must be set");
+        std::vector<double> cols[7];
+        auto add_if_mine = [&](const double pos[3], const double u[3], double weight) {
+            // AddNParticles keeps the particles of this rank's boxes: here [brick_plo, brick_phi)
+            for (int d = 0; d < 3; ++d)
+                if (!(pos[d] >= ctx.brick_plo[d] && pos[d] < ctx.brick_phi[d])) return;
+            for (int d = 0; d < 3; ++d) cols[d].push_back(pos[d]);
+            cols[3].push_back(weight);
+            for (int d = 0; d < 3; ++d) cols[4 + d].push_back(u[d] * c);   // setupSingleParticle: u *= c
+        };
+        if (w == "nuniformpercell") {
+            wxa_plasma_injector inj{};
+            pp.getArrWithParser(name + ".num_particles_per_cell_each_dim", v, 3);
+            for (int d = 0; d < 3; ++d) inj.ppc[d] = ParmParse::safe_int(v[d], name + ".num_particles_per_cell_each_dim");
+            const char* lo_keys[3] = {".xmin", ".ymin", ".zmin"};
+            const char* hi_keys[3] = {".xmax", ".ymax", ".zmax"};
+            for (int d = 0; d < 3; ++d) {
+                inj.lo[d] = -std::numeric_limits<double>::max();   // PlasmaInjector.cpp:70-80
+                inj.hi[d] = std::numeric_limits<double>::max();
+                pp.queryWithParser(name + lo_keys[d], inj.lo[d]);
+                pp.queryWithParser(name + hi_keys[d], inj.hi[d]);
+            }
+            if (!pp.query_word(name + ".profile", w) || w != "constant")
+                throw std::runtime_error("inputs: " + name + ".profile must be constant on this path");
+            inj.density = pp.getWithParser(name + ".density");
+            std::string mom = "atrest";
+            pp.query_word(name + ".momentum_distribution_type", mom);
+            if (mom == "constant") {
+                double u[3] = {0.0, 0.0, 0.0};
+                pp.queryWithParser(name + ".ux", u[0]);
+                pp.queryWithParser(name + ".uy", u[1]);
+                pp.queryWithParser(name + ".uz", u[2]);
+                pc->SetMomentumFunction([u0 = u[0], u1 = u[1], u2 = u[2]](double, double, double, double* out) {
+                    out[0] = u0; out[1] = u1; out[2] = u2;
+                });
+            } else if (mom == "parsemomentumfunction") {
+                Parser f[3];
+                for (int d = 0; d < 3; ++d) {
+                    const std::string key = name + ".momentum_function_u" + "xyz"[d] + "(x,y,z)";
+                    std::string expr;
+                    if (!pp.query(key, expr)) throw std::runtime_error("inputs: " + key + " must be set");
+                    f[d] = pp.makeParser(expr, {"x", "y", "z"});
+                }
+                pc->SetMomentumFunction([f0 = f[0], f1 = f[1], f2 = f[2]](double x, double y, double z, double* out) {
+                    const double xyz[3] = {x, y, z};
+                    out[0] = f0.eval(xyz); out[1] = f1.eval(xyz); out[2] = f2.eval(xyz);
+                });
+            } else if (mom != "atrest") {
+                throw std::runtime_error("inputs: " + name + ".momentum_distribution_type = " + mom +
+                                         " is not on this path (at_rest, constant, parse_momentum_function)");
+            }
+            int continuous = 0;
+            pp.queryWithParser(name + ".do_continuous_injection", continuous);
+            pc->SetPlasmaInjector(inj, continuous != 0);
+            pc->AddPlasma(ctx.prob_lo.data(), ctx.prob_hi.data());
+        } else if (w == "singleparticle") {
+            std::vector<double> pos, u;
+            pp.getArrWithParser(name + ".single_particle_pos", pos, 3);
+            pp.getArrWithParser(name + ".single_particle_u", u, 3);
+            add_if_mine(pos.data(), u.data(), pp.getWithParser(name + ".single_particle_weight"));
+            pc->AppendFromHost(cols);
+        } else if (w == "multipleparticles") {
+            std::vector<double> q[7];
+            const char* keys[7] = {".multiple_particles_pos_x", ".multiple_particles_pos_y", ".multiple_particles_pos_z",
+                                   ".multiple_particles_weight", ".multiple_particles_ux", ".multiple_particles_uy",
+                                   ".multiple_particles_uz"};
+            for (int a = 0; a < 7; ++a)
+                if (!pp.queryArrWithParser(name + keys[a], q[a])) throw std::runtime_error("inputs: " + name + keys[a] + " must be set");
+            for (int a = 1; a < 7; ++a)
+                if (q[a].size() != q[0].size()) throw std::runtime_error("inputs: " + name + ".multiple_particles_* lengths differ");
+            for (size_t i = 0; i < q[0].size(); ++i) {
+                const double pos[3] = {q[0][i], q[1][i], q[2][i]}, u[3] = {q[4][i], q[5][i], q[6][i]};
+                add_if_mine(pos, u, q[3][i]);
+            }
+            pc->AppendFromHost(cols);
+        } else {
+            throw std::runtime_error("inputs: " + name + ".injection_style = " + w +
+                                     " is not on this path (NUniformPerCell, SingleParticle, MultipleParticles)");
+        }
+        if (wx.sort_intervals > 0 && pc->TotalNumberOfParticles() > 0) pc->SortParticlesByBin(amrex::IntVect(1));
+        info.species_names.push_back(name);
+    }
+
+    // ---- laser antennas (LaserParticleContainer.cpp:70-250) ----
+    for (const std::string& name : laser_names) {
+        if (!pp.query_word(name + ".profile", w) || w != "gaussian")
+            throw std::runtime_error("inputs: " + name + ".profile must be Gaussian on this path");
+        wxa_laser_antenna la{};
+        pp.getArrWithParser(name + ".position", v, 3);
+        for (int d = 0; d < 3; ++d) la.position[d] = v[d];
+        pp.getArrWithParser(name + ".direction", v, 3);
+        for (int d = 0; d < 3; ++d) la.direction[d] = v[d];
+        pp.getArrWithParser(name + ".polarization", v, 3);
+        for (int d = 0; d < 3; ++d) la.polarization[d] = v[d];
+        la.e_max = pp.getWithParser(name + ".e_max");
+        la.wavelength = pp.getWithParser(name + ".wavelength");
+        la.waist = pp.getWithParser(name + ".profile_waist");
+        la.duration = pp.getWithParser(name + ".profile_duration");
+        la.t_peak = pp.getWithParser(name + ".profile_t_peak");
+        la.focal_distance = pp.getWithParser(name + ".profile_focal_distance");
+        for (const char* zero : {".zeta", ".beta", ".phi2", ".phi0", ".stc_direction"})
+            if (pp.contains(name + zero)) throw std::runtime_error("inputs: " + name + zero + " is not on this path");
+        wx.GetPartContainer().AddLaser(la);
+    }
+
+    // ---- harmless: output, AMReX box sizes, verbosity ----
+    std::vector<std::string> diag_names, rdiag_names;
+    pp.queryarr("diagnostics.diags_names", diag_names);
+    pp.queryarr("warpx.reduced_diags_names", rdiag_names);
+    for (const std::string& d : diag_names) pp.ignore_prefix(d + ".");
+    for (const std::string& d : rdiag_names) pp.ignore_prefix(d + ".");
+    pp.ignore_prefix("diagnostics.");
+    pp.ignore_prefix("amrex.");
+    for (const char* key : {"amr.max_grid_size", "amr.max_grid_size_x", "amr.max_grid_size_y", "amr.max_grid_size_z",
+                            "amr.blocking_factor", "amr.blocking_factor_x", "amr.blocking_factor_y", "amr.blocking_factor_z",
+                            "warpx.verbose", "warpx.serialize_initial_conditions", "warpx.do_dynamic_scheduling",
+                            "warpx.numprocs", "warpx.random_seed", "algo.load_balance_intervals", "warpx.always_warn_immediately",
+                            "warpx.abort_on_warning_threshold"})
+        pp.ignore(key);
+    const std::vector<std::string> left = pp.unused();
+    if (!left.empty()) {
+        std::string msg = "inputs: parameters that this library does not understand:";
+        for (const std::string& k : left) msg += " " + k;
+        throw std::runtime_error(msg);
+    }
+    be->stream_sync(ctx.stream);
+    return h;
+}
+
+}  // namespace wxa::host
+
+#include "Checksum.hpp"
+
+// C entry points of the deck front end (include/warpx_amd.h), instantiated next to WXA_SIM_CAPI
+#define WXA_INPUTS_CAPI(PFX, RET, SIMTYPE, BACKEND_GETTER, SET_ERROR)                                   \
+    extern "C" {                                                                                       \
+    RET PFX##sim_create_from_inputs(const char* path, int32_t n_overrides, const char* const* overrides, \
+                                    const wxa_comm* comm, const int32_t* nbricks, const int32_t* coord, \
+                                    SIMTYPE** out) {                                                   \
+        if (!path || !out || n_overrides < 0 || (n_overrides > 0 && !overrides)) return (RET)WXA_ERR_INVALID_ARG; \
+        try {                                                                                          \
+            std::vector<std::string> ov;                                                               \
+            for (int32_t i = 0; i < n_overrides; ++i) ov.emplace_back(overrides[i]);                   \
+            wxa::host::DeckInfo info;                                                                  \
+            auto h = wxa::host::sim_from_inputs(BACKEND_GETTER(), path, ov, comm, nbricks, coord, info); \
+            h->max_step = info.max_step;                                                               \
+            h->species_names = info.species_names;                                                     \
+            *out = reinterpret_cast<SIMTYPE*>(h.release());                                            \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
+    }                                                                                                  \
+    int32_t PFX##sim_max_step(const SIMTYPE* s) {                                                      \
+        return s ? reinterpret_cast<const wxa::host::SimHandle*>(s)->max_step : -1;                    \
+    }                                                                                                  \
+    int32_t PFX##sim_num_species(const SIMTYPE* s) {                                                   \
+        if (!s) return -1;                                                                             \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(const_cast<SIMTYPE*>(s));                    \
+        return h->warpx->GetPartContainer().nSpecies();                                                \
+    }                                                                                                  \
+    const char* PFX##sim_species_name(const SIMTYPE* s, int32_t id) {                                  \
+        if (!s) return nullptr;                                                                        \
+        const auto* h = reinterpret_cast<const wxa::host::SimHandle*>(s);                              \
+        return (id >= 0 && id < (int32_t)h->species_names.size()) ? h->species_names[id].c_str() : nullptr; \
+    }                                                                                                  \
+    /* writes the JSON text (NUL-terminated) into buf; returns the length needed (without the NUL) or < 0 */ \
+    int64_t PFX##sim_checksum_json(SIMTYPE* s, char* buf, int64_t capacity) {                          \
+        if (!s) return -1;                                                                             \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        try {                                                                                          \
+            const std::string js = wxa::host::checksum_json(*h, h->species_names);                     \
+            if (buf && capacity > 0) {                                                                 \
+                const size_t n = std::min((size_t)capacity - 1, js.size());                            \
+                std::memcpy(buf, js.data(), n);                                                        \
+                buf[n] = 0;                                                                            \
+            }                                                                                          \
+            return (int64_t)js.size();                                                                 \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return -2;                                                                                 \
+        }                                                                                              \
+    }                                                                                                  \
+    /* the expression evaluator of the decks, for tests and tools */                                   \
+    RET PFX##parser_eval(const char* expr, int32_t nvars, const char* const* names, const double* values, \
+                         double* out) {                                                                \
+        if (!expr || !out || nvars < 0) return (RET)WXA_ERR_INVALID_ARG;                               \
+        try {                                                                                          \
+            std::vector<std::string> vars;                                                             \
+            for (int32_t i = 0; i < nvars; ++i) vars.emplace_back(names[i]);                           \
+            wxa::host::ParmParse pp;                                                                   \
+            *out = wxa::host::Parser(expr, vars, pp.constants()).eval(values);                         \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
+    }                                                                                                  \
+    }
+
+#endif

@@ -11,6 +11,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <functional>
 #include <limits>
 #include <cstdlib>
 
@@ -435,15 +436,22 @@ public:
                         if (!in_tile || !inside(pos[0], pos[1], pos[2])) continue;
                         for (int d = 0; d < 3; ++d) cols[d].push_back(pos[d]);
                         cols[3].push_back(in.density * scale_fac);
-                        for (int d = 4; d < 7; ++d) cols[d].push_back(0.0);
+                        double u[3] = {0.0, 0.0, 0.0};                       // at_rest
+                        if (m_momentum) m_momentum(pos[0], pos[1], pos[2], u);   // InjectorMomentum::getMomentum
+                        for (int d = 0; d < 3; ++d) cols[4 + d].push_back(u[d] * 299'792'458.);   // :1271-1273
                     }
                 }
         AppendFromHost(cols);
     }
 
+    // <species>.momentum_distribution_type = constant | parse_momentum_function: u (in units of c) at a position
+    // (InjectorMomentumConstant / InjectorMomentumParser, Source/Initialization/InjectorMomentum.H)
+    void SetMomentumFunction(std::function<void(double, double, double, double*)> f) { m_momentum = std::move(f); }
+
 private:
     wxa_plasma_injector m_inj{};
     bool m_has_injector = false, m_do_continuous_injection = false;
+    std::function<void(double, double, double, double*)> m_momentum;
 
 public:
 

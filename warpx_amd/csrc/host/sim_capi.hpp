@@ -13,6 +13,9 @@ namespace wxa::host {
 struct SimHandle {
     std::unique_ptr<WarpX> warpx;
     std::string error;
+    // set when the simulation was built from an inputs file (WarpXInputs.hpp)
+    int max_step = -1;
+    std::vector<std::string> species_names;
 };
 
 inline int sim_create(const Backend* be, const wxa_sim_config* cfg, const wxa_comm* comm, SimHandle** out,

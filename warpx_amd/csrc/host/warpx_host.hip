@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../common.hpp"
-#include "sim_capi.hpp"
+#include "WarpXInputs.hpp"
 
 namespace {
 
@@ -145,3 +145,4 @@ void set_err(const char* msg) { wxa::set_last_error("%s", msg); }
 
 struct wxa_sim {};
 WXA_SIM_CAPI(wxa_, wxa_status, wxa_sim, hip_backend, set_err)
+WXA_INPUTS_CAPI(wxa_, wxa_status, wxa_sim, hip_backend, set_err)

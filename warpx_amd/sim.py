@@ -56,6 +56,39 @@ class WarpXSim:
         self.species = []
         self.dx = [(float(prob_hi[d]) - float(prob_lo[d])) / int(n_cell[d]) for d in range(3)]
 
+    @classmethod
+    def from_inputs(cls, lib: _capi.CLib, inputs_path, overrides=(), nbricks=None, coord=None,
+                    comm: _capi.Comm | None = None):
+        """The simulation a WarpX inputs file describes (wxa_sim_create_from_inputs): `overrides` are
+        "name=value" strings like the reference's command line; raises WxaError naming any parameter that is
+        outside this library's path."""
+        self = cls.__new__(cls)
+        self.lib = lib
+        self.on_device = lib.prefix == "wxa_"
+        self.cfg = None
+        self._comm = comm
+        self._h = C.c_void_p()
+        ov = (C.c_char_p * max(len(overrides), 1))(*[o.encode() for o in overrides])
+        nb = (C.c_int32 * 3)(*nbricks) if nbricks is not None else None
+        co = (C.c_int32 * 3)(*coord) if coord is not None else None
+        lib.sim_create_from_inputs(str(inputs_path).encode(), len(overrides), ov,
+                                   C.byref(comm) if comm is not None else None, nb, co, C.byref(self._h))
+        self.max_step = lib.sim_max_step(self._h)
+        self.species_names = [lib.sim_species_name(self._h, i).decode() for i in range(lib.sim_num_species(self._h))]
+        self.species = [None] * len(self.species_names)
+        self.dx = None
+        return self
+
+    def checksum(self) -> dict:
+        """The reference's regression checksum of the current state (wxa_sim_checksum_json), this brick's share."""
+        import json
+        n = self.lib.sim_checksum_json(self._h, None, 0)
+        if n < 0:
+            raise _capi.WxaError("sim_checksum_json failed")
+        buf = C.create_string_buffer(n + 1)
+        self.lib.sim_checksum_json(self._h, buf, n + 1)
+        return json.loads(buf.value.decode())
+
     def close(self):
         if self._h:
             self.lib.sim_destroy(self._h)
