@@ -293,7 +293,9 @@ wxa_status wxa_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3],
 
 /* Replaces PEC::ApplyReflectiveBoundarytoRhofield (WarpX_PEC.cpp:628-711): rho behaves like a component
  * tangential to every wall (:664-666).  Called by WarpXParticleContainer::DepositCharge right after the
- * deposition (Source/Particles/WarpXParticleContainer.cpp:1285-1290), before the filter and the sum. */
+ * deposition (Source/Particles/WarpXParticleContainer.cpp:1285-1290), before the filter and the sum.
+ * The guard columns of the directions without a wall are folded as well (the reference folds each
+ * box's valid points only, which makes its rho next to a wall depend on the box decomposition). */
 wxa_status wxa_apply_pec_rho(const wxa_field_view* rho, const int32_t dom_lo[3],
                              const int32_t dom_hi[3], const int32_t pec_lo[3],
                              const int32_t pec_hi[3], void* stream);

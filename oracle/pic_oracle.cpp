@@ -467,8 +467,9 @@ extern "C" {
 namespace {
 // SetRhoOrJfieldFromPEC (:354-420) over the valid box of one array; tangent[d]: odd image along d
 // (psign -1), otherwise even (psign +1) -- absorbing particle boundaries
+// transverse_guards: also fold the guard columns of the directions that have no PEC wall (see orc_apply_pec_rho)
 void reflect_over_pec(const wxa_field_view& f, const bool tangent[3], const int32_t dom_lo[3], const int32_t dom_hi[3],
-                      const int32_t pec_lo[3], const int32_t pec_hi[3]) {
+                      const int32_t pec_lo[3], const int32_t pec_hi[3], bool transverse_guards = false) {
     const Arr a(f);
     int mirrorfac[3][2];
     for (int d = 0; d < 3; ++d) {
@@ -481,9 +482,15 @@ void reflect_over_pec(const wxa_field_view& f, const bool tangent[3], const int3
             if (v[d] < f.lo[d] || v[d] >= f.lo[d] + f.n[d]) return false;
         return true;
     };
-    for (int k = vlo(f, 2); k < vhi(f, 2); ++k)
-        for (int j = vlo(f, 1); j < vhi(f, 1); ++j)
-            for (int i = vlo(f, 0); i < vhi(f, 0); ++i) {
+    int blo[3], bhi[3];
+    for (int d = 0; d < 3; ++d) {
+        const bool grow = transverse_guards && !pec_lo[d] && !pec_hi[d];
+        blo[d] = grow ? f.lo[d] : vlo(f, d);
+        bhi[d] = grow ? f.lo[d] + f.n[d] : vhi(f, d);
+    }
+    for (int k = blo[2]; k < bhi[2]; ++k)
+        for (int j = blo[1]; j < bhi[1]; ++j)
+            for (int i = blo[0]; i < bhi[0]; ++i) {
                 const int ijk[3] = {i, j, k};
                 for (int d = 0; d < 3; ++d)
                     for (int side = 0; side < 2; ++side) {
@@ -522,11 +529,16 @@ int orc_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3], const in
 }
 
 // PEC::ApplyReflectiveBoundarytoRhofield (:628-711): rho is treated like a tangential component along
-// every direction (:664-666)
+// every direction (:664-666).  One departure: the reference folds the valid points of each box only
+// (:697), although it runs before the guard sum -- charge deposited in a box's transverse guard
+// columns (towards a periodic image or a neighbour box) then misses its image, so its rho next to a
+// wall depends on the box decomposition.  Here the guard columns of the wall-free directions are
+// folded too, which is what the fold after the sum would give; the two agree whenever no particle
+// sits within a stencil of both a wall and a box edge (all of the reference's golden runs).
 int orc_apply_pec_rho(const wxa_field_view* rho, const int32_t dom_lo[3], const int32_t dom_hi[3],
                       const int32_t pec_lo[3], const int32_t pec_hi[3], void*) {
     const bool tangent[3] = {true, true, true};
-    reflect_over_pec(*rho, tangent, dom_lo, dom_hi, pec_lo, pec_hi);
+    reflect_over_pec(*rho, tangent, dom_lo, dom_hi, pec_lo, pec_hi, /*transverse_guards=*/true);
     return 0;
 }
 

@@ -38,3 +38,25 @@ def test_bricks_match_single_domain(nb, order, filt, port, tmp_path):
     for name, err in rep["errors"].items():
         assert err < 1e-10, (name, err)
     assert rep["ekin_rel"] < 1e-11 and rep["abs_p_rel"] < 1e-11
+
+
+@pytest.mark.parametrize("nb,deck,golden,port", [
+    # window along z (unsplit), bricks along x and y: continuous injection, the antenna and the PEC walls per brick
+    ((2, 1, 1), "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29621),
+    ((2, 2, 1), "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29622),
+    ((1, 1, 2), "langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", 29623),
+])
+def test_deck_on_bricks_reaches_the_golden_checksums(nb, deck, golden, port, tmp_path):
+    """A whole inputs file on several bricks (gloo): the per-brick checksums add up to the reference's golden
+    values.  (Sums of |cell-centred value| split exactly over bricks: every cell belongs to one brick.)"""
+    out = str(tmp_path / "sum.json")
+    n = nb[0] * nb[1] * nb[2]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
+           *[str(v) for v in nb], os.path.join(ROOT, "tests", "decks", deck), out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    from tests.test_inputs_cpu import compare_with_golden
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", golden)))
+    worst = compare_with_golden(json.load(open(out)), gold["checksums"], gold["rtol"])
+    print("worst relative deviation", worst)

@@ -898,7 +898,7 @@ wxa_status wxa_shift_field_window(const wxa_field_view* f, double* tmp, int32_t 
 // one launch over the valid box of f; icomp = the vector component f is (sign +1 across the walls it is
 // normal to), or 3 for a scalar that is tangential to every wall (rho)
 static wxa_status pec_reflect(const wxa_field_view& f, int icomp, const int32_t dom_lo[3], const int32_t dom_hi[3],
-                              const int32_t pec_lo[3], const int32_t pec_hi[3], void* stream) {
+                              const int32_t pec_lo[3], const int32_t pec_hi[3], bool transverse_guards, void* stream) {
     PecGeom pg;
     Box3 vb;
     for (int d = 0; d < 3; ++d) {
@@ -906,8 +906,10 @@ static wxa_status pec_reflect(const wxa_field_view& f, int icomp, const int32_t 
         pg.dom_lo[d] = dom_lo[d]; pg.dom_hi[d] = dom_hi[d];
         pg.pec_lo[d] = pec_lo[d] ? 1 : 0; pg.pec_hi[d] = pec_hi[d] ? 1 : 0;
         pg.nodal[d] = f.stag[d];
-        vb.lo[d] = f.lo[d] + f.ng[d];
-        vb.hi[d] = f.lo[d] + f.n[d] - f.ng[d];
+        // the guard columns of a wall-free direction are folded too when asked (rho: before the guard sum)
+        const bool grow = transverse_guards && !pec_lo[d] && !pec_hi[d];
+        vb.lo[d] = grow ? f.lo[d] : f.lo[d] + f.ng[d];
+        vb.hi[d] = grow ? f.lo[d] + f.n[d] : f.lo[d] + f.n[d] - f.ng[d];
     }
     const long total = (long)(vb.hi[0] - vb.lo[0]) * (vb.hi[1] - vb.lo[1]) * (vb.hi[2] - vb.lo[2]);
     if (total <= 0) return WXA_OK;
@@ -921,7 +923,7 @@ wxa_status wxa_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3], c
     WXA_REQUIRE(J && dom_lo && dom_hi && pec_lo && pec_hi, "null argument");
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(J[c]), "bad field view");
     for (int c = 0; c < 3; ++c) {
-        const wxa_status rc = pec_reflect(J[c], c, dom_lo, dom_hi, pec_lo, pec_hi, stream);
+        const wxa_status rc = pec_reflect(J[c], c, dom_lo, dom_hi, pec_lo, pec_hi, false, stream);
         if (rc != WXA_OK) return rc;
     }
     WXA_LAUNCH_CHECK();
@@ -932,7 +934,7 @@ wxa_status wxa_apply_pec_rho(const wxa_field_view* rho, const int32_t dom_lo[3],
                              const int32_t pec_lo[3], const int32_t pec_hi[3], void* stream) {
     WXA_REQUIRE(rho && dom_lo && dom_hi && pec_lo && pec_hi, "null argument");
     WXA_REQUIRE(view_ok(*rho), "bad field view");
-    const wxa_status rc = pec_reflect(*rho, 3, dom_lo, dom_hi, pec_lo, pec_hi, stream);
+    const wxa_status rc = pec_reflect(*rho, 3, dom_lo, dom_hi, pec_lo, pec_hi, true, stream);
     if (rc != WXA_OK) return rc;
     WXA_LAUNCH_CHECK();
     return WXA_OK;
