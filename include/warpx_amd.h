@@ -471,8 +471,10 @@ wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
  * SingleParticle, MultipleParticles, Gaussian laser antennas, E/B initialised by constants or parsed
  * functions.  Any other parameter that is not plain output / AMReX box sizing is an error, by name.
  * overrides: "name=value" strings applied after the file, like the reference's command line.
- * nbricks / coord: this library's decomposition (NULL = one brick); the deck's amr.max_grid_size and
- * blocking_factor describe AMReX boxes and are ignored. */
+ * nbricks / coord: this library's decomposition; nbricks = NULL lets the library split the domain into
+ * comm->nranks bricks (one brick without a comm) along its periodic, window-free directions, with
+ * rank = cx + nbx (cy + nby cz).  The deck's amr.max_grid_size and blocking_factor describe AMReX
+ * boxes and are ignored. */
 wxa_status wxa_sim_create_from_inputs(const char* inputs_path, int32_t n_overrides,
                                       const char* const* overrides, const wxa_comm* comm,
                                       const int32_t* nbricks, const int32_t* coord, wxa_sim** out);

@@ -24,9 +24,12 @@ def main():
     deck, out = sys.argv[4], sys.argv[5]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    assert world == nb[0] * nb[1] * nb[2]
     transport = TorchBrickTransport(on_device=False)
-    sim = WarpXSim.from_inputs(load_host_cpu(), deck, nbricks=nb, coord=brick_coord(rank, nb), comm=transport.comm)
+    if nb == (0, 0, 0):     # let the library choose the bricks for comm.nranks
+        sim = WarpXSim.from_inputs(load_host_cpu(), deck, comm=transport.comm)
+    else:
+        assert world == nb[0] * nb[1] * nb[2]
+        sim = WarpXSim.from_inputs(load_host_cpu(), deck, nbricks=nb, coord=brick_coord(rank, nb), comm=transport.comm)
     sim.evolve(sim.max_step)
     gathered = [None] * world
     dist.gather_object(sim.checksum(), gathered if rank == 0 else None, dst=0)

@@ -226,6 +226,33 @@ inline void fill_from_parser(const Backend* be, amrex::MultiFab& mf, const Parse
         throw std::runtime_error("inputs: copying an external field to the device failed");
 }
 
+// One brick per rank: the prime factors of nranks, largest first, go one by one to the splittable direction
+// whose bricks are currently the thickest (and still divisible); rank = cx + nbx (cy + nby cz) as in
+// BrickComm::rank_of.  Periodic directions only: a wall or the moving window must stay inside one brick.
+inline void choose_bricks(int nranks, int rank, const int32_t n_cell[3], const bool splittable[3], int32_t nb[3],
+                          int32_t coord[3]) {
+    for (int d = 0; d < 3; ++d) nb[d] = 1;
+    std::vector<int> factors;
+    for (int n = nranks, f = 2; n > 1;) {
+        if (n % f == 0) { factors.push_back(f); n /= f; } else { ++f; }
+    }
+    std::sort(factors.rbegin(), factors.rend());
+    for (int f : factors) {
+        int best = -1;
+        for (int d = 2; d >= 0; --d) {   // ties go to z, then y (contiguous x rows stay long)
+            if (!splittable[d] || (n_cell[d] / nb[d]) % f != 0) continue;
+            if (best < 0 || n_cell[d] / nb[d] > n_cell[best] / nb[best]) best = d;
+        }
+        if (best < 0)
+            throw std::runtime_error("inputs: cannot split the domain into " + std::to_string(nranks) +
+                                     " bricks along its periodic, window-free directions");
+        nb[best] *= f;
+    }
+    coord[0] = rank % nb[0];
+    coord[1] = (rank / nb[0]) % nb[1];
+    coord[2] = rank / (nb[0] * nb[1]);
+}
+
 }  // namespace inputs_detail
 
 struct DeckInfo {
@@ -256,7 +283,6 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     for (int d = 0; d < 3; ++d) cfg.prob_lo[d] = v[d];
     pp.getArrWithParser("geometry.prob_hi", v, 3);
     for (int d = 0; d < 3; ++d) cfg.prob_hi[d] = v[d];
-    for (int d = 0; d < 3; ++d) { cfg.nbricks[d] = nbricks ? nbricks[d] : 1; cfg.coord[d] = coord ? coord[d] : 0; }
     std::string w;
     if (pp.query_word("geometry.coord_sys", w) && w != "0" && w != "cartesian")
         throw std::runtime_error("inputs: only cartesian geometry is on this path");
@@ -355,17 +381,31 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         cfg.nox = 1;   // no particles: the guard depths only need a valid order
     }
 
+    // ---- decomposition: given, or chosen here for comm->nranks bricks ----
+    int do_moving_window = 0, window_dir = -1;
+    pp.queryWithParser("warpx.do_moving_window", do_moving_window);
+    if (do_moving_window) {
+        if (!pp.query_word("warpx.moving_window_dir", w)) throw std::runtime_error("inputs: warpx.moving_window_dir must be set");
+        window_dir = axis_of(w, "warpx.moving_window_dir");
+    }
+    if (nbricks) {
+        for (int d = 0; d < 3; ++d) { cfg.nbricks[d] = nbricks[d]; cfg.coord[d] = coord ? coord[d] : 0; }
+    } else {
+        bool splittable[3];
+        for (int d = 0; d < 3; ++d)
+            splittable[d] = cfg.field_boundary_lo[d] == WXA_BOUNDARY_PERIODIC &&
+                            cfg.field_boundary_hi[d] == WXA_BOUNDARY_PERIODIC && d != window_dir;
+        choose_bricks(comm ? comm->nranks : 1, comm ? comm->rank : 0, cfg.n_cell, splittable, cfg.nbricks, cfg.coord);
+    }
+
     auto h = std::make_unique<SimHandle>();
     h->warpx = std::make_unique<WarpX>(be, cfg, comm);
     WarpX& wx = *h->warpx;
     const WarpXContext& ctx = wx.context();
 
     // ---- moving window (WarpX.cpp:620-660) ----
-    int do_moving_window = 0;
-    pp.queryWithParser("warpx.do_moving_window", do_moving_window);
     if (do_moving_window) {
-        if (!pp.query_word("warpx.moving_window_dir", w)) throw std::runtime_error("inputs: warpx.moving_window_dir must be set");
-        wx.SetMovingWindow(axis_of(w, "warpx.moving_window_dir"), pp.getWithParser("warpx.moving_window_v"));
+        wx.SetMovingWindow(window_dir, pp.getWithParser("warpx.moving_window_v"));
     } else {
         pp.ignore("warpx.moving_window_dir");
         pp.ignore("warpx.moving_window_v");

@@ -22,21 +22,46 @@ def main(argv=None):
     ap.add_argument("--max-step", type=int, default=None, help="instead of the deck's max_step")
     args = ap.parse_args(argv)
 
+    import os
+
+    import torch
+
     from . import load_product
     from .sim import WarpXSim
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     lib = load_product()   # raises when the HIP library is missing: no fallback
-    sim = WarpXSim.from_inputs(lib, args.inputs, args.overrides)
+    comm = None
+    if world > 1:          # one process per GPU (python -m torch.distributed.run --nproc-per-node N -m warpx_amd.run ...)
+        import torch.distributed as dist
+
+        from .distributed import TorchBrickTransport
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        transport = TorchBrickTransport(on_device=True)
+        comm = transport.comm
+    sim = WarpXSim.from_inputs(lib, args.inputs, args.overrides, comm=comm)   # the library chooses the bricks
     steps = args.max_step if args.max_step is not None else sim.max_step
     if steps is None or steps < 0:
         raise SystemExit("max_step is not set in the inputs file: pass --max-step")
     sim.evolve(steps)
-    text = json.dumps(sim.checksum(), indent=2)
-    if args.checksum:
-        with open(args.checksum, "w") as f:
-            f.write(text + "\n")
-    else:
-        print(text)
+    total = sim.checksum()                    # this brick's share of every sum
+    if world > 1:
+        parts = [None] * world
+        dist.gather_object(total, parts if rank == 0 else None, dst=0)
+        if rank == 0:
+            total = {g: {k: sum(p[g][k] for p in parts) for k in vals} for g, vals in parts[0].items()}
+    if rank == 0:
+        text = json.dumps(total, indent=2)
+        if args.checksum:
+            with open(args.checksum, "w") as f:
+                f.write(text + "\n")
+        else:
+            print(text)
     sim.close()
+    if world > 1:
+        dist.destroy_process_group()
     return 0
 
 
