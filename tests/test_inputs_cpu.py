@@ -103,7 +103,7 @@ def test_deck_syntax_includes_overrides_and_constants(lib, tmp_path):
      "injection_style"),
     ("particles.species_names = e\ne.charge = -q_e\ne.mass = m_e\ne.injection_style = nuniformpercell\n"
      "e.num_particles_per_cell_each_dim = 1 1 1\ne.profile = constant\ne.density = 1.\n"
-     "e.momentum_distribution_type = gaussian\nalgo.particle_shape = 1", "momentum_distribution_type"),
+     "e.momentum_distribution_type = maxwell_boltzmann\nalgo.particle_shape = 1", "momentum_distribution_type"),
     ("particles.species_names = e\ne.charge = -q_e\ne.mass = m_e\ne.injection_style = singleparticle\n"
      "e.single_particle_pos = 0 0 0\ne.single_particle_u = 0 0 0\ne.single_particle_weight = 1", "particle_shape"),
     ("warpx.some_new_feature = 1", "some_new_feature"),
@@ -178,3 +178,42 @@ def test_a_reference_deck_outside_the_path_is_refused(lib):
     with pytest.raises(_capi.WxaError) as e:   # PSATD, collocated grid
         WarpXSim.from_inputs(lib, os.path.join(REFERENCE, "Examples/Tests/langmuir/inputs_test_3d_langmuir_multi_psatd_nodal"))
     assert "maxwell_solver" in str(e.value) or "grid_type" in str(e.value)
+
+
+def test_uniform_plasma_deck_with_random_momenta(lib):
+    """The headline workload's own deck (Examples/Physics_applications/uniform_plasma): gaussian momenta come
+    from a random stream that no other program reproduces, so the reference's golden
+    file is matched exactly where it is deterministic (weight) and statistically elsewhere."""
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference checkout is not on this machine")
+    gold = json.load(open(os.path.join(REFERENCE, "Regression/Checksum/benchmarks_json/test_3d_uniform_plasma.json")))
+    deck = os.path.join(REFERENCE, "Examples/Physics_applications/uniform_plasma/inputs_test_3d_uniform_plasma")
+    sim = WarpXSim.from_inputs(lib, deck)
+    assert sim.max_step == 10
+    sim.evolve(sim.max_step)
+    got = sim.checksum()
+    e, ge = got["electrons"], gold["electrons"]
+    assert abs(e["particle_weight"] - ge["particle_weight"]) / ge["particle_weight"] < 1e-12
+    for ax in "xyz":   # 131072 particles: sums of |.| fluctuate by a few 1e-3
+        assert abs(e["particle_momentum_" + ax] - ge["particle_momentum_" + ax]) / ge["particle_momentum_" + ax] < 0.02
+        assert abs(e["particle_position_" + ax] - ge["particle_position_" + ax]) / ge["particle_position_" + ax] < 0.01
+    for name in ("Ex", "Ey", "Ez", "jx", "jy", "jz", "rho"):   # noise-driven fields: same scale
+        assert 0.5 < got["lev=0"][name] / gold["lev=0"][name] < 2.0, name
+    again = WarpXSim.from_inputs(lib, deck)
+    again.evolve(again.max_step)
+    assert again.checksum() == got          # the stream is seeded: a rerun is identical
+    sim.close()
+    again.close()
+
+
+def test_headline_workload_deck_in_small(lib):
+    """tests/decks/uniform_plasma_3d.inputs (BASELINE configs[1]) with the grid overridden to 16^3, like a
+    command-line override of the reference: builds, steps, conserves the particle count and the weight."""
+    sim = WarpXSim.from_inputs(lib, os.path.join(DECKS, "uniform_plasma_3d.inputs"),
+                               overrides=['amr.n_cell = 16 16 16', "max_step = 3"])
+    sim.evolve(sim.max_step)
+    got = sim.checksum()
+    assert got["lev=0"]["part_per_cell"] == 8 * 16 ** 3
+    assert got["electrons"]["particle_weight"] == pytest.approx(1e25 * (40e-6) ** 3, rel=1e-12)
+    assert got["lev=0"]["jx"] > 0 and got["lev=0"]["Ex"] > 0
+    sim.close()

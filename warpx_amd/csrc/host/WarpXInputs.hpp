@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <fstream>
 #include <map>
+#include <memory>
+#include <random>
 #include <set>
 #include <sstream>
 
@@ -512,9 +514,28 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                     const double xyz[3] = {x, y, z};
                     out[0] = f0.eval(xyz); out[1] = f1.eval(xyz); out[2] = f2.eval(xyz);
                 });
+            } else if (mom == "gaussian") {
+                // InjectorMomentumGaussian: u = u_m + u_th N(0,1) per component.  The reference draws from
+                // AMReX's generator, which no other program reproduces; this stream is std::mt19937_64 seeded
+                // from warpx.random_seed (default 1), the species index and the brick, so a run is repeatable
+                // and statistically the same plasma.
+                double um[3] = {0.0, 0.0, 0.0}, uth[3] = {0.0, 0.0, 0.0};
+                const char* mk[3] = {".ux_m", ".uy_m", ".uz_m"};
+                const char* tk[3] = {".ux_th", ".uy_th", ".uz_th"};
+                for (int d = 0; d < 3; ++d) { pp.queryWithParser(name + mk[d], um[d]); pp.queryWithParser(name + tk[d], uth[d]); }
+                std::string seed_word = "default";
+                pp.query("warpx.random_seed", seed_word);
+                const uint64_t seed = seed_word == "default" ? 1u : (seed_word == "random" ? (uint64_t)std::random_device{}()
+                                                                                            : (uint64_t)pp.evaluate(seed_word));
+                const uint64_t brick = (uint64_t)cfg.coord[0] + 1024u * ((uint64_t)cfg.coord[1] + 1024u * (uint64_t)cfg.coord[2]);
+                auto rng = std::make_shared<std::mt19937_64>(seed * 0x9E3779B97F4A7C15ull + 1000003ull * (uint64_t)sid + brick);
+                auto normal = std::make_shared<std::normal_distribution<double>>(0.0, 1.0);
+                pc->SetMomentumFunction([=](double, double, double, double* out) {
+                    for (int d = 0; d < 3; ++d) out[d] = um[d] + uth[d] * (*normal)(*rng);
+                });
             } else if (mom != "atrest") {
                 throw std::runtime_error("inputs: " + name + ".momentum_distribution_type = " + mom +
-                                         " is not on this path (at_rest, constant, parse_momentum_function)");
+                                         " is not on this path (at_rest, constant, gaussian, parse_momentum_function)");
             }
             int continuous = 0;
             pp.queryWithParser(name + ".do_continuous_injection", continuous);
