@@ -155,6 +155,9 @@ def main():
                     help="untimed steps before the warmup: the regular-lattice start is atypically cheap "
                          "(no particle crosses a cell for ~20 steps), the timed region must see the "
                          "thermalised steady state")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="1: guard exchanges of the field solve on a second stream behind the interior update "
+                         "(N > 1 only; off until it has been measured on the 8-GPU node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-pass", action="store_true")
     args = ap.parse_args()
@@ -194,7 +197,7 @@ def main():
     sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=args.order, galerkin=None, particle_pusher=pusher,
                    current_deposition=depos, use_filter=0 if args.no_filter else 1, cfl=1.0,
                    sort_interval=args.sort_interval, nbricks=nbricks, coord=coord,
-                   comm=transport.comm if transport else None)
+                   comm=transport.comm if transport else None, overlap_halo=args.overlap)
     box_lo = tuple(coord[d] * nb for d in range(3))
     parts = device_uniform_plasma(n_cell, prob_lo, prob_hi, (args.ppc,) * 3, 1e25, 0.01, 12345 + rank,
                                   box_lo, (nb,) * 3, device)
@@ -292,7 +295,7 @@ def main():
                                    f"{args.pusher}, filter {'off' if args.no_filter else 'on'}",
                        "cells_per_gpu": ncells_local, "particles_per_gpu": np_local,
                        "bricks": list(nbricks), "sort_interval": args.sort_interval,
-                       "preroll_steps": args.preroll},
+                       "preroll_steps": args.preroll, "overlap_halo": bool(sim.halo_overlap)},
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -109,6 +109,17 @@ wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3],
                         const wxa_field_view J[3],
                         double dt, const double dinv[3], void* stream);
 
+/* The same updates restricted to the points whose index lies in the box [lo, hi) (global index space,
+ * every component clipped in its own staggered index range): the shell and interior pieces of a halo
+ * exchange overlapped with the interior update (the reference's FillBoundary blocks).
+ * A set of disjoint boxes covering the valid range gives bit for bit the result of one full call. */
+wxa_status wxa_evolve_b_box(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
+                            const double inv_dx[3], const int32_t lo[3], const int32_t hi[3],
+                            void* stream);
+wxa_status wxa_evolve_e_box(const wxa_field_view E[3], const wxa_field_view B[3],
+                            const wxa_field_view J[3], double dt, const double inv_dx[3],
+                            const int32_t lo[3], const int32_t hi[3], void* stream);
+
 /* ------------------------------------------------------------------ */
 /* Particles                                                           */
 /* ------------------------------------------------------------------ */
@@ -374,6 +385,8 @@ typedef struct wxa_sim_config {
                                     is folded back with the image-charge sign of an absorbing wall) */
     int32_t particle_boundary_lo[3]; /* boundary.particle_lo: WXA_PBOUNDARY_* (0 = default)              */
     int32_t particle_boundary_hi[3]; /* boundary.particle_hi                                             */
+    int32_t overlap_halo;        /* 1: on split directions the guard exchanges inside the field solve travel on a
+                                    second stream while the interior points are updated (all-periodic runs)   */
     int32_t grid_type;           /* warpx.grid_type: WXA_GRID_STAGGERED (0, the default).  WXA_GRID_COLLOCATED exists
                                     in the CPU restatement only (it pins the direct deposition to the reference's
                                     test_3d_langmuir_multi_nodal checksums); the library refuses it              */
@@ -437,7 +450,8 @@ wxa_status wxa_laser_push(const wxa_particle_view* p, const wxa_laser_push_param
  * Replaces the MPI layer under amrex FabArray::FillBoundary/SumBoundary and
  * ParticleContainer::Redistribute.  `exchange` posts nmsg
  * sends and nmsg receives of device buffers and returns when they are
- * enqueued on `stream` (stream-ordered completion). */
+ * enqueued on `stream` (stream-ordered completion; `stream` is the library's
+ * main stream, or its exchange stream when overlap_halo is set). */
 typedef struct wxa_comm {
     void* ctx;
     int32_t rank, nranks;
@@ -489,6 +503,10 @@ int64_t     wxa_sim_checksum_json(wxa_sim* s, char* buf, int64_t capacity);
  * the named variables bound to `values`; q_e, m_e, m_p, m_u, epsilon0, mu0, clight, kb, pi predefined. */
 wxa_status  wxa_parser_eval(const char* expr, int32_t nvars, const char* const* names,
                             const double* values, double* out);
+
+/* 1 if wxa_sim_config::overlap_halo took effect (needs a split direction, all-periodic boundaries and
+ * bricks of at least 6 cells per direction). */
+int32_t wxa_sim_halo_overlap(const wxa_sim* s);
 
 /* RhoFunctor::operator() (Source/Diagnostics/ComputeDiagFunctors/RhoFunctor.cpp:42-61): total charge
  * density of all species (and laser antennas) at the current positions, mirrored over PEC walls,

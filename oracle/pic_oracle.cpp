@@ -26,6 +26,8 @@ namespace {
 inline int vlo(const wxa_field_view& f, int d) { return f.lo[d] + f.ng[d]; }
 inline int vhi(const wxa_field_view& f, int d) { return f.lo[d] + f.n[d] - f.ng[d]; }  // exclusive
 inline int ncell_of(const wxa_field_view& f, int d) { return f.n[d] - 2 * f.ng[d] - f.stag[d]; }
+inline int clo_(const wxa_field_view& f, int d, const int32_t* c) { return c ? std::max(vlo(f, d), (int)c[d]) : vlo(f, d); }
+inline int chi_(const wxa_field_view& f, int d, const int32_t* c) { return c ? std::min(vhi(f, d), (int)c[d]) : vhi(f, d); }
 
 int max_threads() {
 #ifdef _OPENMP
@@ -89,29 +91,29 @@ int orc_num_threads(void) { return max_threads(); }
 
 // Source/FieldSolver/FiniteDifferenceSolver/EvolveB.cpp:122-215 with
 // CartesianYeeAlgorithm::UpwardD{x,y,z} (CartesianYeeAlgorithm.H:69-101,125-167,191-225)
-int orc_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
-                 void*) {
-    if (all_nodal(E) && all_nodal(B)) { evolve_b_nodal(E, B, dt, dinv); return 0; }
+static int evolve_b_clipped(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
+                            const int32_t* clo, const int32_t* chi) {
+    if (all_nodal(E) && all_nodal(B)) { if (clo) return -3; evolve_b_nodal(E, B, dt, dinv); return 0; }
     const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]);
     const double idx = dinv[0], idy = dinv[1], idz = dinv[2];
 #pragma omp parallel
     {
 #pragma omp for nowait
-        for (int k = vlo(B[0], 2); k < vhi(B[0], 2); ++k)
-            for (int j = vlo(B[0], 1); j < vhi(B[0], 1); ++j)
-                for (int i = vlo(B[0], 0); i < vhi(B[0], 0); ++i)
+        for (int k = clo_(B[0], 2, clo); k < chi_(B[0], 2, chi); ++k)
+            for (int j = clo_(B[0], 1, clo); j < chi_(B[0], 1, chi); ++j)
+                for (int i = clo_(B[0], 0, clo); i < chi_(B[0], 0, chi); ++i)
                     Bx(i, j, k) += dt * (idz * (Ey(i, j, k + 1) - Ey(i, j, k))) -
                                    dt * (idy * (Ez(i, j + 1, k) - Ez(i, j, k)));
 #pragma omp for nowait
-        for (int k = vlo(B[1], 2); k < vhi(B[1], 2); ++k)
-            for (int j = vlo(B[1], 1); j < vhi(B[1], 1); ++j)
-                for (int i = vlo(B[1], 0); i < vhi(B[1], 0); ++i)
+        for (int k = clo_(B[1], 2, clo); k < chi_(B[1], 2, chi); ++k)
+            for (int j = clo_(B[1], 1, clo); j < chi_(B[1], 1, chi); ++j)
+                for (int i = clo_(B[1], 0, clo); i < chi_(B[1], 0, chi); ++i)
                     By(i, j, k) += dt * (idx * (Ez(i + 1, j, k) - Ez(i, j, k))) -
                                    dt * (idz * (Ex(i, j, k + 1) - Ex(i, j, k)));
 #pragma omp for nowait
-        for (int k = vlo(B[2], 2); k < vhi(B[2], 2); ++k)
-            for (int j = vlo(B[2], 1); j < vhi(B[2], 1); ++j)
-                for (int i = vlo(B[2], 0); i < vhi(B[2], 0); ++i)
+        for (int k = clo_(B[2], 2, clo); k < chi_(B[2], 2, chi); ++k)
+            for (int j = clo_(B[2], 1, clo); j < chi_(B[2], 1, chi); ++j)
+                for (int i = clo_(B[2], 0, clo); i < chi_(B[2], 0, chi); ++i)
                     Bz(i, j, k) += dt * (idy * (Ex(i, j + 1, k) - Ex(i, j, k))) -
                                    dt * (idx * (Ey(i + 1, j, k) - Ey(i, j, k)));
     }
@@ -119,37 +121,55 @@ int orc_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt
 }
 
 // Source/FieldSolver/FiniteDifferenceSolver/EvolveE.cpp:120-250 (no EB, no F term)
-int orc_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
-                 double dt, const double dinv[3], void*) {
-    if (all_nodal(E) && all_nodal(B) && all_nodal(J)) { evolve_e_nodal(E, B, J, dt, dinv); return 0; }
+static int evolve_e_clipped(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
+                            double dt, const double dinv[3], const int32_t* clo, const int32_t* chi) {
+    if (all_nodal(E) && all_nodal(B) && all_nodal(J)) { if (clo) return -3; evolve_e_nodal(E, B, J, dt, dinv); return 0; }
     const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]), jx(J[0]), jy(J[1]), jz(J[2]);
     const double idx = dinv[0], idy = dinv[1], idz = dinv[2];
     constexpr double c2 = PhysConst::c * PhysConst::c;
 #pragma omp parallel
     {
 #pragma omp for nowait
-        for (int k = vlo(E[0], 2); k < vhi(E[0], 2); ++k)
-            for (int j = vlo(E[0], 1); j < vhi(E[0], 1); ++j)
-                for (int i = vlo(E[0], 0); i < vhi(E[0], 0); ++i)
+        for (int k = clo_(E[0], 2, clo); k < chi_(E[0], 2, chi); ++k)
+            for (int j = clo_(E[0], 1, clo); j < chi_(E[0], 1, chi); ++j)
+                for (int i = clo_(E[0], 0, clo); i < chi_(E[0], 0, chi); ++i)
                     Ex(i, j, k) += c2 * dt *
                                    (-(idz * (By(i, j, k) - By(i, j, k - 1))) +
                                     (idy * (Bz(i, j, k) - Bz(i, j - 1, k))) - PhysConst::mu0 * jx(i, j, k));
 #pragma omp for nowait
-        for (int k = vlo(E[1], 2); k < vhi(E[1], 2); ++k)
-            for (int j = vlo(E[1], 1); j < vhi(E[1], 1); ++j)
-                for (int i = vlo(E[1], 0); i < vhi(E[1], 0); ++i)
+        for (int k = clo_(E[1], 2, clo); k < chi_(E[1], 2, chi); ++k)
+            for (int j = clo_(E[1], 1, clo); j < chi_(E[1], 1, chi); ++j)
+                for (int i = clo_(E[1], 0, clo); i < chi_(E[1], 0, chi); ++i)
                     Ey(i, j, k) += c2 * dt *
                                    (-(idx * (Bz(i, j, k) - Bz(i - 1, j, k))) +
                                     (idz * (Bx(i, j, k) - Bx(i, j, k - 1))) - PhysConst::mu0 * jy(i, j, k));
 #pragma omp for nowait
-        for (int k = vlo(E[2], 2); k < vhi(E[2], 2); ++k)
-            for (int j = vlo(E[2], 1); j < vhi(E[2], 1); ++j)
-                for (int i = vlo(E[2], 0); i < vhi(E[2], 0); ++i)
+        for (int k = clo_(E[2], 2, clo); k < chi_(E[2], 2, chi); ++k)
+            for (int j = clo_(E[2], 1, clo); j < chi_(E[2], 1, chi); ++j)
+                for (int i = clo_(E[2], 0, clo); i < chi_(E[2], 0, chi); ++i)
                     Ez(i, j, k) += c2 * dt *
                                    (-(idy * (Bx(i, j, k) - Bx(i, j - 1, k))) +
                                     (idx * (By(i, j, k) - By(i - 1, j, k))) - PhysConst::mu0 * jz(i, j, k));
     }
     return 0;
+}
+
+
+int orc_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3], void*) {
+    return evolve_b_clipped(E, B, dt, dinv, nullptr, nullptr);
+}
+int orc_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3], double dt,
+                 const double dinv[3], void*) {
+    return evolve_e_clipped(E, B, J, dt, dinv, nullptr, nullptr);
+}
+// the shell / interior pieces of an overlapped halo exchange: only the points inside the index box [lo, hi)
+int orc_evolve_b_box(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
+                     const int32_t lo[3], const int32_t hi[3], void*) {
+    return evolve_b_clipped(E, B, dt, dinv, lo, hi);
+}
+int orc_evolve_e_box(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3], double dt,
+                     const double dinv[3], const int32_t lo[3], const int32_t hi[3], void*) {
+    return evolve_e_clipped(E, B, J, dt, dinv, lo, hi);
 }
 
 }  // extern "C"
@@ -1497,6 +1517,8 @@ int orc_sim_get_particles(orc_sim* s, int32_t id, wxa_particle_view* out) {
 
 // RhoFunctor (Source/Diagnostics/ComputeDiagFunctors/RhoFunctor.cpp:42-61):
 // GetChargeDensity (all species) + ApplyFilterandSumBoundaryRho
+int32_t orc_sim_halo_overlap(const orc_sim*) { return 0; }   // one brick: nothing to overlap
+
 int orc_sim_compute_rho(orc_sim* s) {
     orc_field_set_zero(&s->rho.v, nullptr);
     const wxa_grid_geom g = s->geom_for(s->ng_rho);

@@ -28,6 +28,7 @@ FIELDS = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho")
 def main():
     nb = tuple(int(v) for v in sys.argv[1:4])
     order, filt, out = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    overlap = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     steps = 6
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -47,7 +48,8 @@ def main():
     transport = TorchBrickTransport(on_device=False)
     lib = load_host_cpu()
     sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, sort_interval=2,
-                   nbricks=nb, coord=coord, comm=transport.comm)
+                   nbricks=nb, coord=coord, comm=transport.comm, overlap_halo=overlap)
+    assert sim.halo_overlap == bool(overlap)
     sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
     sim.evolve(steps)
     sim.compute_rho()           # charge deposition + filter + guard sum across bricks
@@ -67,7 +69,12 @@ def main():
         ref.evolve(steps)
         ref.compute_rho()
         rmom = particle_moments(ref, rid)
-        report = {"ok": True, "errors": {}, "np_total": sum(g["np"] for g in gathered),
+        import hashlib
+        digest = hashlib.sha256()
+        for g in sorted(gathered, key=lambda g: g["coord"]):
+            for n in FIELDS:
+                digest.update(np.ascontiguousarray(g["fields"][n]).tobytes())
+        report = {"ok": True, "errors": {}, "digest": digest.hexdigest(), "np_total": sum(g["np"] for g in gathered),
                   "np_ref": int(parts.shape[1]), "inside": all(g["inside"] for g in gathered),
                   "exchanges": gathered[0]["exchanges"]}
         for n in FIELDS:

@@ -64,6 +64,7 @@ class SimConfig(C.Structure):
         ("field_boundary_hi", C.c_int32 * 3),
         ("particle_boundary_lo", C.c_int32 * 3),
         ("particle_boundary_hi", C.c_int32 * 3),
+        ("overlap_halo", C.c_int32),
         ("grid_type", C.c_int32),
     ]
 
@@ -139,6 +140,8 @@ _KERNEL_SIGS = {
     "apply_pec_j": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_particle_boundaries": (C.c_int, [_PPV, _D3, _D3, _I32_3, _I32_3, C.POINTER(C.c_int64), C.c_void_p,
                                             C.c_void_p]),
+    "evolve_b_box": (C.c_int, [_FV3, _FV3, C.c_double, _D3, _I32_3, _I32_3, C.c_void_p]),
+    "evolve_e_box": (C.c_int, [_FV3, _FV3, _FV3, C.c_double, _D3, _I32_3, _I32_3, C.c_void_p]),
     "apply_pec_rho": (C.c_int, [_PFV, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "shift_field_window": (C.c_int, [_PFV, C.c_void_p, C.c_int32, C.c_int32, _I3, C.c_void_p]),
     "laser_push": (C.c_int, [_PPV, C.POINTER(LaserPushParams), C.c_double, C.c_double, C.c_void_p]),
@@ -176,6 +179,7 @@ _SIM_SIGS = {
     "sim_enable_timers": (C.c_int, [C.c_void_p, C.c_int]),
     # moving window / continuous injection / laser antenna
     "sim_compute_rho": (C.c_int, [C.c_void_p]),
+    "sim_halo_overlap": (C.c_int32, [C.c_void_p]),
     "sim_set_moving_window": (C.c_int, [C.c_void_p, C.POINTER(MovingWindow)]),
     "sim_set_injection": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PlasmaInjector), C.c_int, C.c_int]),
     "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
@@ -227,7 +231,7 @@ class WxaError(RuntimeError):
 
 
 # int-returning entry points whose result is a value, not a status
-_RETURNS_A_VALUE = {"sim_max_step", "sim_num_species", "num_threads"}
+_RETURNS_A_VALUE = {"sim_max_step", "sim_num_species", "num_threads", "sim_halo_overlap"}
 
 
 class CLib:

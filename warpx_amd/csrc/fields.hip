@@ -606,10 +606,29 @@ static bool box_inside(const wxa_field_view& v, const int32_t blo[3], const int3
 
 using namespace wxa;
 
-extern "C" {
+// clip (index box [lo, hi), may be null): only the points of each component inside it are updated -- the
+// shell / interior pieces of an overlapped halo exchange (wxa_evolve_b_box / wxa_evolve_e_box)
+static bool clip_boxes(Box3& bx, Box3& by, Box3& bz, Box3& ub, const int32_t* clo, const int32_t* chi) {
+    Box3* bs[3] = {&bx, &by, &bz};
+    bool any = false;
+    for (Box3* b : bs) {
+        bool empty = false;
+        for (int d = 0; d < 3; ++d) {
+            if (clo) { b->lo[d] = std::max(b->lo[d], (int)clo[d]); b->hi[d] = std::min(b->hi[d], (int)chi[d]); }
+            empty = empty || b->hi[d] <= b->lo[d];
+        }
+        if (empty) { for (int d = 0; d < 3; ++d) b->hi[d] = b->lo[d]; continue; }
+        for (int d = 0; d < 3; ++d) {
+            ub.lo[d] = any ? std::min(ub.lo[d], b->lo[d]) : b->lo[d];
+            ub.hi[d] = any ? std::max(ub.hi[d], b->hi[d]) : b->hi[d];
+        }
+        any = true;
+    }
+    return any;
+}
 
-wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
-                        const double dinv[3], void* stream) {
+static wxa_status evolve_b_impl(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
+                                const double dinv[3], const int32_t* clo, const int32_t* chi, void* stream) {
     WXA_REQUIRE(E && B && dinv, "null argument");
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
     if (!yee_E(E) || !yee_B(B)) {
@@ -618,15 +637,12 @@ wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], do
     }
     for (int c = 0; c < 3; ++c)
         for (int d = 0; d < 3; ++d) WXA_REQUIRE(E[c].ng[d] >= 1, "EvolveB needs >= 1 guard point on E");
-    const Box3 bx = valid_box(B[0]), by = valid_box(B[1]), bz = valid_box(B[2]);
+    Box3 bx = valid_box(B[0]), by = valid_box(B[1]), bz = valid_box(B[2]);
     Box3 ub;
-    for (int d = 0; d < 3; ++d) {
-        ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
-        ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
-    }
+    if (!clip_boxes(bx, by, bz, ub, clo, chi)) return WXA_OK;
     {
         const wxa_field_view* vs[6] = {&E[0], &E[1], &E[2], &B[0], &B[1], &B[2]};
-        if (v2_ok(vs, 6, ub)) {
+        if (!clo && v2_ok(vs, 6, ub)) {
             TileGrid t2 = make_tiles(ub);
             t2.nti = (ub.hi[0] - ub.lo[0] + TI2 - 1) / TI2;
             t2.ntiles = (long)t2.nti * t2.ntj * t2.ntk;
@@ -648,8 +664,8 @@ wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], do
     return WXA_OK;
 }
 
-wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
-                        double dt, const double dinv[3], void* stream) {
+static wxa_status evolve_e_impl(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
+                                double dt, const double dinv[3], const int32_t* clo, const int32_t* chi, void* stream) {
     WXA_REQUIRE(E && B && J && dinv, "null argument");
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]) && view_ok(J[c]), "bad field view");
     if (!yee_E(E) || !yee_B(B) || !yee_E(J)) {
@@ -658,7 +674,7 @@ wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], co
     }
     for (int c = 0; c < 3; ++c)
         for (int d = 0; d < 3; ++d) WXA_REQUIRE(B[c].ng[d] >= 1, "EvolveE needs >= 1 guard point on B");
-    const Box3 bx = valid_box(E[0]), by = valid_box(E[1]), bz = valid_box(E[2]);
+    Box3 bx = valid_box(E[0]), by = valid_box(E[1]), bz = valid_box(E[2]);
     for (int c = 0; c < 3; ++c) {
         const Box3 bj = valid_box(J[c]);
         const Box3 be = valid_box(E[c]);
@@ -666,13 +682,10 @@ wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], co
             WXA_REQUIRE(bj.lo[d] == be.lo[d] && bj.hi[d] == be.hi[d], "J and E valid boxes differ");
     }
     Box3 ub;
-    for (int d = 0; d < 3; ++d) {
-        ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
-        ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
-    }
+    if (!clip_boxes(bx, by, bz, ub, clo, chi)) return WXA_OK;
     {
         const wxa_field_view* vs[9] = {&E[0], &E[1], &E[2], &B[0], &B[1], &B[2], &J[0], &J[1], &J[2]};
-        if (v2_ok(vs, 9, ub)) {
+        if (!clo && v2_ok(vs, 9, ub)) {
             TileGrid t2 = make_tiles(ub);
             t2.nti = (ub.hi[0] - ub.lo[0] + TI2 - 1) / TI2;
             t2.ntiles = (long)t2.nti * t2.ntj * t2.ntk;
@@ -692,6 +705,27 @@ wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], co
                        make_devf(J[1]), make_devf(J[2]), ub, bx, by, bz, tg, dt, dinv[0], dinv[1], dinv[2]);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
+}
+
+extern "C" {
+
+wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
+                        void* stream) {
+    return evolve_b_impl(E, B, dt, dinv, nullptr, nullptr, stream);
+}
+wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3], double dt,
+                        const double dinv[3], void* stream) {
+    return evolve_e_impl(E, B, J, dt, dinv, nullptr, nullptr, stream);
+}
+wxa_status wxa_evolve_b_box(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
+                            const int32_t lo[3], const int32_t hi[3], void* stream) {
+    WXA_REQUIRE(lo && hi, "null box");
+    return evolve_b_impl(E, B, dt, dinv, lo, hi, stream);
+}
+wxa_status wxa_evolve_e_box(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3], double dt,
+                            const double dinv[3], const int32_t lo[3], const int32_t hi[3], void* stream) {
+    WXA_REQUIRE(lo && hi, "null box");
+    return evolve_e_impl(E, B, J, dt, dinv, lo, hi, stream);
 }
 
 wxa_status wxa_filter_bilinear(const wxa_field_view* src, const wxa_field_view* dst, void* stream) {

@@ -51,6 +51,25 @@ public:
         const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
         check(m_ctx->be->evolve_b(Ev, Bv, dt, m_stencil_coefs.data(), m_ctx->stream), "evolve_b");
     }
+    // the same on the points inside an index box (pieces of an overlapped halo exchange)
+    void EvolveB(ablastr::fields::MultiFabRegister& fields, int lev, amrex::Real dt, const int32_t lo[3], const int32_t hi[3]) {
+        using warpx::fields::FieldType;
+        auto E = fields.get_alldirs(FieldType::Efield_fp, lev);
+        auto B = fields.get_alldirs(FieldType::Bfield_fp, lev);
+        const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
+        const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
+        check(m_ctx->be->evolve_b_box(Ev, Bv, dt, m_stencil_coefs.data(), lo, hi, m_ctx->stream), "evolve_b_box");
+    }
+    void EvolveE(ablastr::fields::MultiFabRegister& fields, int lev, amrex::Real dt, const int32_t lo[3], const int32_t hi[3]) {
+        using warpx::fields::FieldType;
+        auto E = fields.get_alldirs(FieldType::Efield_fp, lev);
+        auto B = fields.get_alldirs(FieldType::Bfield_fp, lev);
+        auto J = fields.get_alldirs(FieldType::current_fp, lev);
+        const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
+        const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
+        const wxa_field_view Jv[3] = {J[0]->view(), J[1]->view(), J[2]->view()};
+        check(m_ctx->be->evolve_e_box(Ev, Bv, Jv, dt, m_stencil_coefs.data(), lo, hi, m_ctx->stream), "evolve_e_box");
+    }
     // FiniteDifferenceSolver.H:61-66
     void EvolveE(ablastr::fields::MultiFabRegister& fields, int lev, PatchType patch_type,
                  const ablastr::fields::VectorField& Efield, amrex::Real dt) {
@@ -128,6 +147,7 @@ public:
             m_dom_hi[d] = cfg.n_cell[d] - 1;
         }
         m_comm->set_periodic(periodic);   // throws if a PEC direction is split into bricks
+        SetUpHaloOverlap(cfg.overlap_halo != 0);
         // boundary.particle_lo / particle_hi: default = periodic with a periodic field boundary, absorbing
         // otherwise; periodic particles need a periodic field boundary and vice versa
         for (int d = 0; d < 3; ++d)
@@ -271,11 +291,101 @@ public:
         PushParticlesandDeposit(a_cur_time);                     // :366
         SyncCurrentAndRho();                                     // :373
         // :416-419 EvolveF/G: no-ops
+        if (m_overlap) { FieldSolveOverlapped(); return; }
         EvolveB(0.5 * dt[0], DtType::FirstHalf);                 // :421
         FillBoundaryB(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);  // :422
         EvolveE(dt[0]);                                          // :426
         FillBoundaryE(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);  // :433
         EvolveB(0.5 * dt[0], DtType::SecondHalf);                // :437
+    }
+
+    // ---- halo exchange overlapped with the interior field update ---------------------------
+    // The five calls above with the same arithmetic on every point, in another order.  On a split direction
+    // a brick sends its two outermost layers (FillBoundary with ng_FieldSolver = 1 plus the shared nodal
+    // plane) and reads one guard layer, so each update is cut into the shell -- the points within two
+    // layers of any face of the brick (the wrap of an unsplit periodic direction reads and writes whole
+    // faces like an exchange does) -- and the interior.  The shell goes first, its exchange then travels on a
+    // second stream while the main stream updates the interior; the next field's shell waits for it:
+    //   main:  B shell | B interior, E interior        | E shell | B' interior  | B' shell
+    //   comm:          | FillBoundaryB                 |         | FillBoundaryE |
+    // Interior points read nothing an exchange writes (guards and shared planes are at least two layers
+    // away).  Only for all-periodic runs: a wall's boundary kernels touch the guards the exchange fills.
+    ~WarpX() {
+        if (m_be->event_destroy)
+            for (void* e : m_halo_events)
+                if (e) m_be->event_destroy(e);
+        if (m_comm_stream && m_be->stream_destroy) m_be->stream_destroy(m_comm_stream);
+    }
+    void SetUpHaloOverlap(bool want) {
+        m_overlap = false;
+        if (!want || m_any_pec) return;
+        bool any_split = false;
+        for (int d = 0; d < 3; ++d) {
+            any_split = any_split || !m_comm->self_periodic(d);
+            if (m_ctx.brick_box.length(d) < 6) return;   // shells would meet
+        }
+        if (!any_split || !m_be->stream_create || !m_be->evolve_b_box || !m_be->evolve_e_box) return;
+        m_comm_stream = m_be->stream_create();
+        if (!m_comm_stream) return;
+        if (m_be->event_create)
+            for (auto& e : m_halo_events) e = m_be->event_create();
+        // disjoint boxes covering every component's valid range [lo, lo + n + 1) (the nodal extra point included)
+        int32_t cur_lo[3], cur_hi[3];
+        for (int d = 0; d < 3; ++d) { cur_lo[d] = m_ctx.brick_box.lo[d]; cur_hi[d] = m_ctx.brick_box.lo[d] + m_ctx.brick_box.length(d) + 1; }
+        for (int d = 2; d >= 0; --d) {   // every direction: a fill (exchange or on-device wrap) reads all of a face
+            const int lo = m_ctx.brick_box.lo[d], n = m_ctx.brick_box.length(d);
+            IndexBox low, high;
+            for (int e = 0; e < 3; ++e) { low.lo[e] = high.lo[e] = cur_lo[e]; low.hi[e] = high.hi[e] = cur_hi[e]; }
+            low.lo[d] = lo;          low.hi[d] = lo + 2;
+            high.lo[d] = lo + n - 1; high.hi[d] = lo + n + 1;
+            m_shell.push_back(low);
+            m_shell.push_back(high);
+            cur_lo[d] = lo + 2;
+            cur_hi[d] = lo + n - 1;
+        }
+        for (int e = 0; e < 3; ++e) { m_interior.lo[e] = cur_lo[e]; m_interior.hi[e] = cur_hi[e]; }
+        m_overlap = true;
+    }
+    bool halo_overlap() const { return m_overlap; }
+
+    void FieldSolveOverlapped() {
+        using warpx::fields::FieldType;
+        const amrex::Real hdt = 0.5 * dt[0];
+        auto order = [&](void* waiting_stream, int ev, void* recorded_stream) {   // waiting_stream continues after recorded_stream
+            if (!m_halo_events[ev]) return;   // a backend without streams runs in program order
+            m_be->event_record(m_halo_events[ev], recorded_stream);
+            m_be->stream_wait_event(waiting_stream, m_halo_events[ev]);
+        };
+        {
+            PhaseTimer t(&m_ctx, kEvolveB);
+            for (const IndexBox& b : m_shell) m_fdtd_solver_fp->EvolveB(m_fields, 0, hdt, b.lo, b.hi);
+        }
+        order(m_comm_stream, 0, m_ctx.stream);
+        FillBoundaryVector(FieldType::Bfield_fp, guard_cells.ng_FieldSolver, WarpX::sync_nodal_points, m_comm_stream);
+        {
+            PhaseTimer t(&m_ctx, kEvolveB);
+            m_fdtd_solver_fp->EvolveB(m_fields, 0, hdt, m_interior.lo, m_interior.hi);
+        }
+        {
+            PhaseTimer t(&m_ctx, kEvolveE);
+            m_fdtd_solver_fp->EvolveE(m_fields, 0, dt[0], m_interior.lo, m_interior.hi);
+        }
+        order(m_ctx.stream, 1, m_comm_stream);
+        {
+            PhaseTimer t(&m_ctx, kEvolveE);
+            for (const IndexBox& b : m_shell) m_fdtd_solver_fp->EvolveE(m_fields, 0, dt[0], b.lo, b.hi);
+        }
+        order(m_comm_stream, 2, m_ctx.stream);
+        FillBoundaryVector(FieldType::Efield_fp, guard_cells.ng_FieldSolver, WarpX::sync_nodal_points, m_comm_stream);
+        {
+            PhaseTimer t(&m_ctx, kEvolveB);
+            m_fdtd_solver_fp->EvolveB(m_fields, 0, hdt, m_interior.lo, m_interior.hi);
+        }
+        order(m_ctx.stream, 3, m_comm_stream);
+        {
+            PhaseTimer t(&m_ctx, kEvolveB);
+            for (const IndexBox& b : m_shell) m_fdtd_solver_fp->EvolveB(m_fields, 0, hdt, b.lo, b.hi);
+        }
     }
 
     // :1101-1180
@@ -463,6 +573,10 @@ public:
     DeviceBuffer m_shift_tmp;
 
 private:
+    void FillBoundaryVector(warpx::fields::FieldType ft, const amrex::IntVect& ng, bool nodal_sync, void* stream) {
+        auto F = m_fields.get_alldirs(ft, 0);
+        m_comm->FillBoundary({F[0], F[1], F[2]}, ng, nodal_sync, stream);
+    }
     void FillBoundaryVector(warpx::fields::FieldType ft, const amrex::IntVect& ng, bool nodal_sync) {
         PhaseTimer t(&m_ctx, kFillBoundary);
         auto F = m_fields.get_alldirs(ft, 0);
@@ -492,6 +606,13 @@ private:
     std::unique_ptr<BrickComm> m_comm;
     std::unique_ptr<amrex::MultiFab> m_filter_tmp[3];
     std::unique_ptr<amrex::MultiFab> m_rho, m_rho_tmp;   // ComputeRho (diagnostics)
+    // overlapped halo exchange: second stream, ordering events, shell / interior boxes
+    struct IndexBox { int32_t lo[3], hi[3]; };
+    bool m_overlap = false;
+    void* m_comm_stream = nullptr;
+    void* m_halo_events[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<IndexBox> m_shell;
+    IndexBox m_interior{};
     std::vector<amrex::Real> dt;
     amrex::Real cur_time = 0.0;
     int64_t istep = 0;

@@ -23,6 +23,11 @@ struct Backend {
     int (*evolve_b)(const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
     int (*evolve_e)(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double,
                     const double*, void*);
+    // the same restricted to an index box (shell / interior pieces of an overlapped halo exchange)
+    int (*evolve_b_box)(const wxa_field_view*, const wxa_field_view*, double, const double*, const int32_t* lo,
+                        const int32_t* hi, void*);
+    int (*evolve_e_box)(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double, const double*,
+                        const int32_t* lo, const int32_t* hi, void*);
     // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace
     int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);
@@ -80,6 +85,10 @@ struct Backend {
     int (*memcpy_h2d)(void* dst, const void* src, size_t bytes);
     int (*memcpy_d2h)(void* dst, const void* src, size_t bytes);
     int (*stream_sync)(void* stream);
+    // a second stream and cross-stream ordering for the overlapped halo exchange (may be null: no overlap)
+    void* (*stream_create)();
+    void (*stream_destroy)(void* stream);
+    void (*stream_wait_event)(void* stream, void* ev);
     // ---- timing (may be null) ----
     void* (*event_create)();
     void (*event_destroy)(void* ev);

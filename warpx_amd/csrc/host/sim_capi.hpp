@@ -199,6 +199,9 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     RET PFX##sim_get_field(SIMTYPE* s, const char* name, wxa_field_view* out) {                        \
         return (RET)wxa::host::sim_get_field(reinterpret_cast<wxa::host::SimHandle*>(s), name, out);        \
     }                                                                                                  \
+    int32_t PFX##sim_halo_overlap(const SIMTYPE* s) {                                                  \
+        return s && reinterpret_cast<const wxa::host::SimHandle*>(s)->warpx->halo_overlap() ? 1 : 0;     \
+    }                                                                                                  \
     RET PFX##sim_compute_rho(SIMTYPE* s) {                                                             \
         auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
         int rc = wxa::host::sim_compute_rho(h);                                                        \

@@ -36,6 +36,12 @@ void* hip_event_create() {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
+void* hip_stream_create() {
+    hipStream_t st = nullptr;   // non-blocking: no implicit ordering with the null stream the kernels run on
+    return hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess ? (void*)st : nullptr;
+}
+void hip_stream_destroy(void* st) { if (st) (void)hipStreamDestroy((hipStream_t)st); }
+void hip_stream_wait_event(void* st, void* e) { (void)hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)e, 0); }
 void hip_event_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
 void hip_event_record(void* e, void* st) { (void)hipEventRecord((hipEvent_t)e, (hipStream_t)st); }
 float hip_event_elapsed(void* a, void* b) {
@@ -130,6 +136,15 @@ const Backend* hip_backend() {
         b.memcpy_h2d = hip_memcpy_h2d;
         b.memcpy_d2h = hip_memcpy_d2h;
         b.stream_sync = hip_stream_sync;
+        b.stream_create = hip_stream_create;
+        b.stream_destroy = hip_stream_destroy;
+        b.stream_wait_event = hip_stream_wait_event;
+        b.evolve_b_box = [](const wxa_field_view* E, const wxa_field_view* B, double dt, const double* dinv,
+                            const int32_t* lo, const int32_t* hi, void* st) -> int {
+            return wxa_evolve_b_box(E, B, dt, dinv, lo, hi, st); };
+        b.evolve_e_box = [](const wxa_field_view* E, const wxa_field_view* B, const wxa_field_view* J, double dt,
+                            const double* dinv, const int32_t* lo, const int32_t* hi, void* st) -> int {
+            return wxa_evolve_e_box(E, B, J, dt, dinv, lo, hi, st); };
         b.event_create = hip_event_create;
         b.event_destroy = hip_event_destroy;
         b.event_record = hip_event_record;

@@ -80,6 +80,7 @@ class TorchBrickTransport:
         self.nranks = dist.get_world_size(group)
         self.on_device = on_device
         self.n_exchanges = 0
+        self._streams = {}
         self.bytes_sent = 0
         self._exchange_cb = _capi.EXCHANGE_FN(self._exchange)
         self._counts_cb = _capi.EXCHANGE_COUNTS_FN(self._exchange_counts)
@@ -90,10 +91,23 @@ class TorchBrickTransport:
         self.comm.exchange = self._exchange_cb
         self.comm.exchange_counts = self._counts_cb
 
+    def _external_stream(self, ptr):
+        import torch
+        s = self._streams.get(int(ptr))
+        if s is None:
+            s = self._streams[int(ptr)] = torch.cuda.ExternalStream(int(ptr))
+        return s
+
     # nmsg sends + nmsg receives; peers equal to this rank are handled by a local copy
     def _exchange(self, ctx, nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf, recv_bytes, stream):
         try:
             import torch
+            if self.on_device and stream:
+                # the library's exchange stream (overlap_halo): RCCL orders its transfers behind the *current*
+                # torch stream, so make that stream current for the duration of the call
+                with torch.cuda.stream(self._external_stream(stream)):
+                    return self._exchange(ctx, nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf,
+                                          recv_bytes, None)
             dist = self.dist
             ops = []
             keep = []

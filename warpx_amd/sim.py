@@ -22,7 +22,7 @@ class WarpXSim:
                  use_filter=0, cfl=1.0, sort_interval=-1, nbricks=(1, 1, 1), coord=(0, 0, 0),
                  comm: _capi.Comm | None = None, field_boundary_lo=(0, 0, 0), field_boundary_hi=(0, 0, 0),
                  particle_boundary_lo=(0, 0, 0), particle_boundary_hi=(0, 0, 0),
-                 grid_type=_capi.GRID_STAGGERED):
+                 grid_type=_capi.GRID_STAGGERED, overlap_halo=0):
         self.lib = lib
         self.on_device = lib.prefix == "wxa_"
         cfg = _capi.SimConfig()
@@ -49,6 +49,7 @@ class WarpXSim:
         cfg.use_filter = int(use_filter)
         cfg.sort_interval = int(sort_interval)
         cfg.grid_type = int(grid_type)   # collocated: CPU restatement only
+        cfg.overlap_halo = int(overlap_halo)
         self.cfg = cfg
         self._comm = comm  # keep the callbacks alive
         self._h = C.c_void_p()
@@ -115,6 +116,11 @@ class WarpXSim:
     # ---- stepping -----------------------------------------------------------
     def evolve(self, numsteps: int):
         self.lib.sim_evolve(self._h, int(numsteps))
+
+    @property
+    def halo_overlap(self) -> bool:
+        """Whether overlap_halo took effect (split direction, all-periodic, bricks thick enough)."""
+        return bool(self.lib.sim_halo_overlap(self._h))
 
     @property
     def dt(self) -> float:
