@@ -62,3 +62,33 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(root, fn), errors="ignore").read()
                 assert "liboracle" not in text and "oracle_lib" not in text, fn
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The ctypes mirrors in warpx_amd/_capi.py have the size and field offsets the C compiler gives the structs
+    of include/warpx_amd.h (a field added on one side only would shift everything behind it)."""
+    import ctypes as C
+    import subprocess
+    pairs = [("wxa_sim_config", _capi.SimConfig), ("wxa_field_view", _capi.FieldView),
+             ("wxa_particle_view", _capi.ParticleView), ("wxa_grid_geom", _capi.GridGeom),
+             ("wxa_moving_window", _capi.MovingWindow), ("wxa_plasma_injector", _capi.PlasmaInjector),
+             ("wxa_laser_antenna", _capi.LaserAntenna), ("wxa_laser_push_params", _capi.LaserPushParams),
+             ("wxa_comm", _capi.Comm)]
+    lines = ['#include "warpx_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines.append("  return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().splitlines()
+    for (cname, cls), line in zip(pairs, out):
+        parts = line.split()
+        assert parts[0] == cname
+        want = [int(v) for v in parts[1:]]
+        got = [C.sizeof(cls)] + [getattr(cls, f[0]).offset for f in cls._fields_]
+        assert got == want, (cname, got, want)
