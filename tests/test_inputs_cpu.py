@@ -125,6 +125,7 @@ OUR_DECKS = [
      ("By", "jx", "jz", "particle_momentum_z", "particle_position_z")),
     ("particle_walls_3d.inputs", "particle_boundaries_3d_checksums.json", ()),
     ("laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", ()),
+    ("laser_injection_3d.inputs", "laser_injection_3d_checksums.json", ()),
 ]
 
 
@@ -158,6 +159,7 @@ REFERENCE_DECKS = [
      ("By", "jx", "jz", "particle_momentum_z", "particle_position_z")),
     ("Examples/Tests/boundaries/inputs_test_3d_particle_boundaries", "test_3d_particle_boundaries", ()),
     ("Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration", "test_3d_laser_acceleration", ()),
+    ("Examples/Tests/laser_injection/inputs_test_3d_laser_injection", "test_3d_laser_injection", ()),
 ]
 
 

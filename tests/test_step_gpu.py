@@ -337,6 +337,7 @@ def test_picmi_langmuir_golden_on_gpu(oracle, product):
      ("By", "jx", "jz", "particle_momentum_z", "particle_position_z")),
     ("particle_walls_3d.inputs", "particle_boundaries_3d_checksums.json", ()),
     ("laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", ()),
+    ("laser_injection_3d.inputs", "laser_injection_3d_checksums.json", ()),
 ])
 def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden, skip):
     """tests/decks/*.inputs through wxa_sim_create_from_inputs, wxa_sim_evolve and wxa_sim_checksum_json on the HIP
