@@ -109,16 +109,15 @@ wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3],
                         const wxa_field_view J[3],
                         double dt, const double dinv[3], void* stream);
 
-/* The same updates restricted to the points whose index lies in the box [lo, hi) (global index space,
- * every component clipped in its own staggered index range): the shell and interior pieces of a halo
- * exchange overlapped with the interior update (the reference's FillBoundary blocks).
- * A set of disjoint boxes covering the valid range gives bit for bit the result of one full call. */
-wxa_status wxa_evolve_b_box(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
-                            const double inv_dx[3], const int32_t lo[3], const int32_t hi[3],
-                            void* stream);
-wxa_status wxa_evolve_e_box(const wxa_field_view E[3], const wxa_field_view B[3],
-                            const wxa_field_view J[3], double dt, const double inv_dx[3],
-                            const int32_t lo[3], const int32_t hi[3], void* stream);
+/* The first guard layer of B, updated with the same formula from the guard points of E and B already
+ * present, next to the faces of the directions with grow[d] != 0: the points EvolveE reads beyond the
+ * valid box are those of the components cell-centred along d at the indices lo - 1 and lo + ncell
+ * (faces only).  Called after wxa_evolve_b when the guards of E and B were filled since their last
+ * update, it stands in for the FillBoundaryB that the reference issues between EvolveB and EvolveE
+ * (Source/Evolve/WarpXEvolve.cpp:421-426): a neighbour brick, or the periodic image, computes the same
+ * numbers from the same operands, so nothing has to be exchanged.  Needs 2 guard points on E. */
+wxa_status wxa_evolve_b_guard_layer(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
+                                    const double inv_dx[3], const int32_t grow[3], void* stream);
 
 /* ------------------------------------------------------------------ */
 /* Particles                                                           */
@@ -385,8 +384,8 @@ typedef struct wxa_sim_config {
                                     is folded back with the image-charge sign of an absorbing wall) */
     int32_t particle_boundary_lo[3]; /* boundary.particle_lo: WXA_PBOUNDARY_* (0 = default)              */
     int32_t particle_boundary_hi[3]; /* boundary.particle_hi                                             */
-    int32_t overlap_halo;        /* 1: on split directions the guard exchanges inside the field solve travel on a
-                                    second stream while the interior points are updated (all-periodic runs)   */
+    int32_t overlap_halo;        /* 1: the guard sum of J travels on a second stream while B gets its first half
+                                    update (bricks, all-periodic runs)                                        */
     int32_t grid_type;           /* warpx.grid_type: WXA_GRID_STAGGERED (0, the default).  WXA_GRID_COLLOCATED exists
                                     in the CPU restatement only (it pins the direct deposition to the reference's
                                     test_3d_langmuir_multi_nodal checksums); the library refuses it              */
@@ -505,7 +504,7 @@ wxa_status  wxa_parser_eval(const char* expr, int32_t nvars, const char* const* 
                             const double* values, double* out);
 
 /* 1 if wxa_sim_config::overlap_halo took effect (needs a split direction, all-periodic boundaries and
- * bricks of at least 6 cells per direction). */
+ * the library's second stream). */
 int32_t wxa_sim_halo_overlap(const wxa_sim* s);
 
 /* RhoFunctor::operator() (Source/Diagnostics/ComputeDiagFunctors/RhoFunctor.cpp:42-61): total charge

@@ -120,6 +120,40 @@ static int evolve_b_clipped(const wxa_field_view E[3], const wxa_field_view B[3]
     return 0;
 }
 
+// The first guard layer of B next to the faces of the directions with grow[d] != 0, updated like the valid
+// points from the guard points already present (see include/warpx_amd.h): components cell-centred along d,
+// indices lo - 1 and lo + ncell, the component's valid range in the other two directions.
+int orc_evolve_b_guard_layer(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
+                             const int32_t grow[3], void*) {
+    const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]);
+    const double idx = dinv[0], idy = dinv[1], idz = dinv[2];
+    for (int d = 0; d < 3; ++d) {
+        if (!grow[d]) continue;
+        for (int side = 0; side < 2; ++side)
+            for (int c = 0; c < 3; ++c) {
+                if (B[c].stag[d]) continue;
+                int lo[3], hi[3];
+                for (int e = 0; e < 3; ++e) { lo[e] = vlo(B[c], e); hi[e] = vhi(B[c], e); }
+                const int layer = side == 0 ? lo[d] - 1 : hi[d];
+                lo[d] = layer; hi[d] = layer + 1;
+                for (int k = lo[2]; k < hi[2]; ++k)
+                    for (int j = lo[1]; j < hi[1]; ++j)
+                        for (int i = lo[0]; i < hi[0]; ++i) {
+                            if (c == 0)
+                                Bx(i, j, k) += dt * (idz * (Ey(i, j, k + 1) - Ey(i, j, k))) -
+                                               dt * (idy * (Ez(i, j + 1, k) - Ez(i, j, k)));
+                            else if (c == 1)
+                                By(i, j, k) += dt * (idx * (Ez(i + 1, j, k) - Ez(i, j, k))) -
+                                               dt * (idz * (Ex(i, j, k + 1) - Ex(i, j, k)));
+                            else
+                                Bz(i, j, k) += dt * (idy * (Ex(i, j + 1, k) - Ex(i, j, k))) -
+                                               dt * (idx * (Ey(i + 1, j, k) - Ey(i, j, k)));
+                        }
+            }
+    }
+    return 0;
+}
+
 // Source/FieldSolver/FiniteDifferenceSolver/EvolveE.cpp:120-250 (no EB, no F term)
 static int evolve_e_clipped(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
                             double dt, const double dinv[3], const int32_t* clo, const int32_t* chi) {

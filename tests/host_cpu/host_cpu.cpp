@@ -38,9 +38,7 @@ int orc_apply_pec_e(const wxa_field_view*, const int32_t*, const int32_t*, const
                     void*);
 int orc_apply_pec_b(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                     void*);
-int orc_evolve_b_box(const wxa_field_view*, const wxa_field_view*, double, const double*, const int32_t*, const int32_t*, void*);
-int orc_evolve_e_box(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double, const double*,
-                     const int32_t*, const int32_t*, void*);
+int orc_evolve_b_guard_layer(const wxa_field_view*, const wxa_field_view*, double, const double*, const int32_t*, void*);
 int orc_apply_pec_j(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
 int orc_apply_pec_rho(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
 int orc_deposit_charge(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, int, void*);
@@ -89,8 +87,7 @@ const Backend* cpu_backend() {
         b.apply_pec_e = orc_apply_pec_e;
         b.apply_pec_b = orc_apply_pec_b;
         b.apply_pec_j = orc_apply_pec_j;
-        b.evolve_b_box = orc_evolve_b_box;
-        b.evolve_e_box = orc_evolve_e_box;
+        b.evolve_b_guard_layer = orc_evolve_b_guard_layer;
         // streams are not a thing here: the "second stream" is a tag, ordering is program order
         b.stream_create = []() -> void* { static int tag; return &tag; };
         b.stream_destroy = [](void*) {};

@@ -632,29 +632,25 @@ def test_apply_pec_rho(oracle, product, pec):
 
 
 @UNVERIFIED
-def test_evolve_boxes_cover_the_full_update(product):
-    """wxa_evolve_b_box / wxa_evolve_e_box: disjoint index boxes (the shell and interior pieces of the overlapped
-    halo exchange, an odd cut through the tiles) give bit for bit what one full call gives."""
+@pytest.mark.parametrize("grow", [(1, 1, 1), (0, 0, 1), (1, 0, 0)])
+def test_evolve_b_guard_layer(oracle, product, grow):
+    """wxa_evolve_b_guard_layer after wxa_evolve_b: every point of B, guards included, bit for bit what the CPU
+    restatement gives; the valid points are untouched and the face guard layers of the components that are
+    cell-centred along a grown direction did change."""
     ncell = (40, 12, 14)
-    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, 2, 1, device=DEV, pad=True)
-    B = H.random_fields(("Bx", "By", "Bz"), ncell, 2, 2, device=DEV, pad=True)
-    J = H.random_fields(("jx", "jy", "jz"), ncell, 3, 3, device=DEV, pad=True)
-    E2, B2 = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
     dinv, dt = H.d3((1e6, 2e6, 3e6)), 1e-15
-    nx, ny, nz = ncell
-    boxes = [((0, 0, 0), (nx + 1, ny + 1, 2)), ((0, 0, nz - 1), (nx + 1, ny + 1, nz + 1)),
-             ((0, 0, 2), (nx + 1, 2, nz - 1)), ((0, ny - 1, 2), (nx + 1, ny + 1, nz - 1)),
-             ((0, 2, 2), (3, ny - 1, nz - 1)), ((3, 2, 2), (nx + 1, ny - 1, nz - 1))]
-    product.evolve_b(field_triplet(E), field_triplet(B), dt, dinv, None)
-    for lo, hi in boxes:
-        product.evolve_b_box(field_triplet(E2), field_triplet(B2), dt, dinv, (C.c_int32 * 3)(*lo), (C.c_int32 * 3)(*hi), None)
+    g3 = (C.c_int32 * 3)(*grow)
+    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, 2, 1)
+    B = H.random_fields(("Bx", "By", "Bz"), ncell, 2, 2)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    oracle.evolve_b(field_triplet(E), field_triplet(B), dt, dinv, None)
+    before = [b.to_numpy().copy() for b in B]
+    oracle.evolve_b_guard_layer(field_triplet(E), field_triplet(B), dt, dinv, g3, None)
+    product.evolve_b(field_triplet(Ed), field_triplet(Bd), dt, dinv, None)
+    product.evolve_b_guard_layer(field_triplet(Ed), field_triplet(Bd), dt, dinv, g3, None)
     _sync(product)
-    for a, b in zip(B, B2):
+    for a, b, b0 in zip(Bd, B, before):
         assert np.array_equal(a.to_numpy(), b.to_numpy())
-    product.evolve_e(field_triplet(E), field_triplet(B), field_triplet(J), dt, dinv, None)
-    for lo, hi in boxes:
-        product.evolve_e_box(field_triplet(E2), field_triplet(B2), field_triplet(J), dt, dinv,
-                             (C.c_int32 * 3)(*lo), (C.c_int32 * 3)(*hi), None)
-    _sync(product)
-    for a, b in zip(E, E2):
-        assert np.array_equal(a.to_numpy(), b.to_numpy())
+        assert np.array_equal(b.to_numpy()[2:-2, 2:-2, 2:-2], b0[2:-2, 2:-2, 2:-2])
+        touched = any(g and not st for g, st in zip(grow, b.stag))
+        assert np.array_equal(b.to_numpy(), b0) != touched

@@ -65,9 +65,8 @@ def test_deck_on_bricks_reaches_the_golden_checksums(nb, deck, golden, port, tmp
 
 @pytest.mark.parametrize("nb,order,port", [((1, 1, 2), 3, 29631), ((2, 2, 2), 2, 29633)])
 def test_overlapped_halo_exchange_is_the_same_arithmetic(nb, order, port, tmp_path):
-    """overlap_halo = 1: the field solve cut into shell and interior pieces with the guard exchanges issued
-    on the second stream (order of the pieces, box clipping, exchange timing) gives every field of every
-    brick bit for bit what the plain schedule gives."""
+    """overlap_halo = 1 (J's guard sum issued on the second stream, EvolveE ordered behind it) gives every field of
+    every brick bit for bit what the plain schedule gives."""
     plain = _run(nb, order, 1, tmp_path, port, overlap=0)
     over = _run(nb, order, 1, tmp_path, port + 1, overlap=1)
     assert over["digest"] == plain["digest"]

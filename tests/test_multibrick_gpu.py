@@ -88,7 +88,7 @@ class ThreadBrickTransport:
                            "WXA_UNVERIFIED_GPU_TESTS=1 runs it")
 @pytest.mark.parametrize("nb", [(1, 1, 2), (2, 2, 2)])
 def test_bricks_with_overlapped_halo_exchange(oracle, product, nb):
-    """overlap_halo = 1 on the HIP path: shell / interior stencil launches, the exchange stream and its events."""
+    """overlap_halo = 1 on the HIP path: J's guard sum on the exchange stream behind the first half update of B."""
     test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, 3, 1, overlap=1)
 
 

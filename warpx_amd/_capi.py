@@ -140,8 +140,7 @@ _KERNEL_SIGS = {
     "apply_pec_j": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_particle_boundaries": (C.c_int, [_PPV, _D3, _D3, _I32_3, _I32_3, C.POINTER(C.c_int64), C.c_void_p,
                                             C.c_void_p]),
-    "evolve_b_box": (C.c_int, [_FV3, _FV3, C.c_double, _D3, _I32_3, _I32_3, C.c_void_p]),
-    "evolve_e_box": (C.c_int, [_FV3, _FV3, _FV3, C.c_double, _D3, _I32_3, _I32_3, C.c_void_p]),
+    "evolve_b_guard_layer": (C.c_int, [_FV3, _FV3, C.c_double, _D3, _I32_3, C.c_void_p]),
     "apply_pec_rho": (C.c_int, [_PFV, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "shift_field_window": (C.c_int, [_PFV, C.c_void_p, C.c_int32, C.c_int32, _I3, C.c_void_p]),
     "laser_push": (C.c_int, [_PPV, C.POINTER(LaserPushParams), C.c_double, C.c_double, C.c_void_p]),

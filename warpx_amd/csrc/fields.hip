@@ -606,29 +606,10 @@ static bool box_inside(const wxa_field_view& v, const int32_t blo[3], const int3
 
 using namespace wxa;
 
-// clip (index box [lo, hi), may be null): only the points of each component inside it are updated -- the
-// shell / interior pieces of an overlapped halo exchange (wxa_evolve_b_box / wxa_evolve_e_box)
-static bool clip_boxes(Box3& bx, Box3& by, Box3& bz, Box3& ub, const int32_t* clo, const int32_t* chi) {
-    Box3* bs[3] = {&bx, &by, &bz};
-    bool any = false;
-    for (Box3* b : bs) {
-        bool empty = false;
-        for (int d = 0; d < 3; ++d) {
-            if (clo) { b->lo[d] = std::max(b->lo[d], (int)clo[d]); b->hi[d] = std::min(b->hi[d], (int)chi[d]); }
-            empty = empty || b->hi[d] <= b->lo[d];
-        }
-        if (empty) { for (int d = 0; d < 3; ++d) b->hi[d] = b->lo[d]; continue; }
-        for (int d = 0; d < 3; ++d) {
-            ub.lo[d] = any ? std::min(ub.lo[d], b->lo[d]) : b->lo[d];
-            ub.hi[d] = any ? std::max(ub.hi[d], b->hi[d]) : b->hi[d];
-        }
-        any = true;
-    }
-    return any;
-}
+extern "C" {
 
-static wxa_status evolve_b_impl(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
-                                const double dinv[3], const int32_t* clo, const int32_t* chi, void* stream) {
+wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
+                        const double dinv[3], void* stream) {
     WXA_REQUIRE(E && B && dinv, "null argument");
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
     if (!yee_E(E) || !yee_B(B)) {
@@ -637,12 +618,15 @@ static wxa_status evolve_b_impl(const wxa_field_view E[3], const wxa_field_view 
     }
     for (int c = 0; c < 3; ++c)
         for (int d = 0; d < 3; ++d) WXA_REQUIRE(E[c].ng[d] >= 1, "EvolveB needs >= 1 guard point on E");
-    Box3 bx = valid_box(B[0]), by = valid_box(B[1]), bz = valid_box(B[2]);
+    const Box3 bx = valid_box(B[0]), by = valid_box(B[1]), bz = valid_box(B[2]);
     Box3 ub;
-    if (!clip_boxes(bx, by, bz, ub, clo, chi)) return WXA_OK;
+    for (int d = 0; d < 3; ++d) {
+        ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
+        ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
+    }
     {
         const wxa_field_view* vs[6] = {&E[0], &E[1], &E[2], &B[0], &B[1], &B[2]};
-        if (!clo && v2_ok(vs, 6, ub)) {
+        if (v2_ok(vs, 6, ub)) {
             TileGrid t2 = make_tiles(ub);
             t2.nti = (ub.hi[0] - ub.lo[0] + TI2 - 1) / TI2;
             t2.ntiles = (long)t2.nti * t2.ntj * t2.ntk;
@@ -664,8 +648,55 @@ static wxa_status evolve_b_impl(const wxa_field_view E[3], const wxa_field_view 
     return WXA_OK;
 }
 
-static wxa_status evolve_e_impl(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
-                                double dt, const double dinv[3], const int32_t* clo, const int32_t* chi, void* stream) {
+// The first guard layer of B next to the faces of the directions with grow[d] != 0, updated like the valid
+// points (EvolveB.cpp:164-186) from the guard points of E and B already present: the points EvolveE reads
+// beyond the valid box are those of the components cell-centred along d, at the indices lo - 1 and
+// lo + ncell (faces only).  Replaces the FillBoundaryB that follows the update (wxa_evolve_b_guard_layer).
+wxa_status wxa_evolve_b_guard_layer(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
+                                    const double dinv[3], const int32_t grow[3], void* stream) {
+    WXA_REQUIRE(E && B && dinv && grow, "null argument");
+    for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
+    if (!yee_E(E) || !yee_B(B)) {
+        set_last_error("wxa_evolve_b_guard_layer: only the Yee staggering is supported");
+        return WXA_ERR_UNSUPPORTED;
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int d = 0; d < 3; ++d)
+            WXA_REQUIRE(!grow[d] || (E[c].ng[d] >= 2 && B[c].ng[d] >= 1), "guard layer update needs 2 guard points on E, 1 on B");
+    for (int d = 0; d < 3; ++d) {
+        if (!grow[d]) continue;
+        for (int side = 0; side < 2; ++side) {
+            Box3 bc[3];
+            Box3 ub;
+            bool any = false;
+            for (int c = 0; c < 3; ++c) {
+                bc[c] = valid_box(B[c]);
+                if (B[c].stag[d]) { bc[c].hi[d] = bc[c].lo[d]; continue; }   // nodal along d: no guard point is read
+                const int layer = side == 0 ? bc[c].lo[d] - 1 : bc[c].hi[d];
+                bc[c].lo[d] = layer; bc[c].hi[d] = layer + 1;
+                for (int e = 0; e < 3; ++e) {
+                    ub.lo[e] = any ? std::min(ub.lo[e], bc[c].lo[e]) : bc[c].lo[e];
+                    ub.hi[e] = any ? std::max(ub.hi[e], bc[c].hi[e]) : bc[c].hi[e];
+                }
+                any = true;
+            }
+            if (!any) continue;
+            for (int c = 0; c < 3; ++c)   // an empty box must still lie inside the union for the membership tests
+                if (bc[c].hi[d] == bc[c].lo[d]) bc[c].lo[d] = bc[c].hi[d] = ub.lo[d];
+            const TileGrid tg = make_tiles(ub);
+            if (tg.ntiles <= 0) continue;
+            hipLaunchKernelGGL(evolve_b_kernel, dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(TI, TJ), 0,
+                               (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
+                               make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bc[0], bc[1], bc[2], tg, dt,
+                               dinv[0], dinv[1], dinv[2]);
+        }
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3],
+                        double dt, const double dinv[3], void* stream) {
     WXA_REQUIRE(E && B && J && dinv, "null argument");
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]) && view_ok(J[c]), "bad field view");
     if (!yee_E(E) || !yee_B(B) || !yee_E(J)) {
@@ -674,7 +705,7 @@ static wxa_status evolve_e_impl(const wxa_field_view E[3], const wxa_field_view 
     }
     for (int c = 0; c < 3; ++c)
         for (int d = 0; d < 3; ++d) WXA_REQUIRE(B[c].ng[d] >= 1, "EvolveE needs >= 1 guard point on B");
-    Box3 bx = valid_box(E[0]), by = valid_box(E[1]), bz = valid_box(E[2]);
+    const Box3 bx = valid_box(E[0]), by = valid_box(E[1]), bz = valid_box(E[2]);
     for (int c = 0; c < 3; ++c) {
         const Box3 bj = valid_box(J[c]);
         const Box3 be = valid_box(E[c]);
@@ -682,10 +713,13 @@ static wxa_status evolve_e_impl(const wxa_field_view E[3], const wxa_field_view 
             WXA_REQUIRE(bj.lo[d] == be.lo[d] && bj.hi[d] == be.hi[d], "J and E valid boxes differ");
     }
     Box3 ub;
-    if (!clip_boxes(bx, by, bz, ub, clo, chi)) return WXA_OK;
+    for (int d = 0; d < 3; ++d) {
+        ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
+        ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
+    }
     {
         const wxa_field_view* vs[9] = {&E[0], &E[1], &E[2], &B[0], &B[1], &B[2], &J[0], &J[1], &J[2]};
-        if (!clo && v2_ok(vs, 9, ub)) {
+        if (v2_ok(vs, 9, ub)) {
             TileGrid t2 = make_tiles(ub);
             t2.nti = (ub.hi[0] - ub.lo[0] + TI2 - 1) / TI2;
             t2.ntiles = (long)t2.nti * t2.ntj * t2.ntk;
@@ -705,27 +739,6 @@ static wxa_status evolve_e_impl(const wxa_field_view E[3], const wxa_field_view 
                        make_devf(J[1]), make_devf(J[2]), ub, bx, by, bz, tg, dt, dinv[0], dinv[1], dinv[2]);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
-}
-
-extern "C" {
-
-wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
-                        void* stream) {
-    return evolve_b_impl(E, B, dt, dinv, nullptr, nullptr, stream);
-}
-wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3], double dt,
-                        const double dinv[3], void* stream) {
-    return evolve_e_impl(E, B, J, dt, dinv, nullptr, nullptr, stream);
-}
-wxa_status wxa_evolve_b_box(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3],
-                            const int32_t lo[3], const int32_t hi[3], void* stream) {
-    WXA_REQUIRE(lo && hi, "null box");
-    return evolve_b_impl(E, B, dt, dinv, lo, hi, stream);
-}
-wxa_status wxa_evolve_e_box(const wxa_field_view E[3], const wxa_field_view B[3], const wxa_field_view J[3], double dt,
-                            const double dinv[3], const int32_t lo[3], const int32_t hi[3], void* stream) {
-    WXA_REQUIRE(lo && hi, "null box");
-    return evolve_e_impl(E, B, J, dt, dinv, lo, hi, stream);
 }
 
 wxa_status wxa_filter_bilinear(const wxa_field_view* src, const wxa_field_view* dst, void* stream) {

@@ -51,25 +51,6 @@ public:
         const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
         check(m_ctx->be->evolve_b(Ev, Bv, dt, m_stencil_coefs.data(), m_ctx->stream), "evolve_b");
     }
-    // the same on the points inside an index box (pieces of an overlapped halo exchange)
-    void EvolveB(ablastr::fields::MultiFabRegister& fields, int lev, amrex::Real dt, const int32_t lo[3], const int32_t hi[3]) {
-        using warpx::fields::FieldType;
-        auto E = fields.get_alldirs(FieldType::Efield_fp, lev);
-        auto B = fields.get_alldirs(FieldType::Bfield_fp, lev);
-        const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
-        const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
-        check(m_ctx->be->evolve_b_box(Ev, Bv, dt, m_stencil_coefs.data(), lo, hi, m_ctx->stream), "evolve_b_box");
-    }
-    void EvolveE(ablastr::fields::MultiFabRegister& fields, int lev, amrex::Real dt, const int32_t lo[3], const int32_t hi[3]) {
-        using warpx::fields::FieldType;
-        auto E = fields.get_alldirs(FieldType::Efield_fp, lev);
-        auto B = fields.get_alldirs(FieldType::Bfield_fp, lev);
-        auto J = fields.get_alldirs(FieldType::current_fp, lev);
-        const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
-        const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
-        const wxa_field_view Jv[3] = {J[0]->view(), J[1]->view(), J[2]->view()};
-        check(m_ctx->be->evolve_e_box(Ev, Bv, Jv, dt, m_stencil_coefs.data(), lo, hi, m_ctx->stream), "evolve_e_box");
-    }
     // FiniteDifferenceSolver.H:61-66
     void EvolveE(ablastr::fields::MultiFabRegister& fields, int lev, PatchType patch_type,
                  const ablastr::fields::VectorField& Efield, amrex::Real dt) {
@@ -81,6 +62,15 @@ public:
         const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
         const wxa_field_view Jv[3] = {J[0]->view(), J[1]->view(), J[2]->view()};
         check(m_ctx->be->evolve_e(Ev, Bv, Jv, dt, m_stencil_coefs.data(), m_ctx->stream), "evolve_e");
+    }
+    // the first guard layer of B from the guards already present (wxa_evolve_b_guard_layer)
+    void EvolveBGuardLayer(ablastr::fields::MultiFabRegister& fields, int lev, amrex::Real dt, const int32_t grow[3]) {
+        using warpx::fields::FieldType;
+        auto E = fields.get_alldirs(FieldType::Efield_fp, lev);
+        auto B = fields.get_alldirs(FieldType::Bfield_fp, lev);
+        const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
+        const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
+        check(m_ctx->be->evolve_b_guard_layer(Ev, Bv, dt, m_stencil_coefs.data(), grow, m_ctx->stream), "evolve_b_guard_layer");
     }
 
 private:
@@ -291,94 +281,44 @@ public:
         PushParticlesandDeposit(a_cur_time);                     // :366
         SyncCurrentAndRho();                                     // :373
         // :416-419 EvolveF/G: no-ops
-        if (m_overlap) { FieldSolveOverlapped(); return; }
         EvolveB(0.5 * dt[0], DtType::FirstHalf);                 // :421
-        FillBoundaryB(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);  // :422
+        // :422 FillBoundaryB(ng_FieldSolver, sync): only when the guard layer was not computed above (PEC walls)
+        if (!m_grown_b) FillBoundaryB(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);
+        if (m_overlap) order_streams(m_ctx.stream, 1, m_comm_stream);   // J's guard sum has arrived
         EvolveE(dt[0]);                                          // :426
         // :433 FillBoundaryE(ng_FieldSolver, sync) is not issued: the Yee update of B reads no guard point of E,
         // the copies of a shared nodal plane are computed from bit-identical operands (so the sync changes
         // nothing), and FillBoundaryE/B(ng_FieldGather) refills every guard before the next reader (the gather).
-        // One exchange in five per direction and step saved; fields bit for bit the same (tests/test_multibrick_cpu.py).
+        // Fields bit for bit the same (tests/test_multibrick_cpu.py).
         EvolveB(0.5 * dt[0], DtType::SecondHalf);                // :437
     }
 
-    // ---- halo exchange overlapped with the interior field update ---------------------------
-    // The calls above with the same arithmetic on every point, in another order.  On a split direction
-    // a brick sends its two outermost layers (FillBoundary with ng_FieldSolver = 1 plus the shared nodal
-    // plane) and reads one guard layer, so each update is cut into the shell -- the points within two
-    // layers of any face of the brick (the wrap of an unsplit periodic direction reads and writes whole
-    // faces like an exchange does) -- and the interior.  The shell goes first, its exchange then travels on a
-    // second stream while the main stream updates the interior; the next field's shell waits for it:
-    //   main:  B shell | B interior, E interior | E shell, B' (full)
-    //   comm:          | FillBoundaryB          |
-    // Interior points read nothing an exchange writes (guards and shared planes are at least two layers
-    // away).  Only for all-periodic runs: a wall's boundary kernels touch the guards the exchange fills.
-    ~WarpX() {
-        if (m_be->event_destroy)
-            for (void* e : m_halo_events)
-                if (e) m_be->event_destroy(e);
-        if (m_comm_stream && m_be->stream_destroy) m_be->stream_destroy(m_comm_stream);
-    }
+    // ---- exchanges of the field solve ---------------------------------------------------------
+    // All-periodic runs issue none: the first half update of B is followed by the same update of the first guard layer, from the
+    // guards the gather-depth fill of the step start left (E and B have not changed since), so EvolveE finds the
+    // guard points it reads without FillBoundaryB -- the neighbour computes the same numbers from the same
+    // operands, bit for bit.  With overlap_halo the one exchange left between deposition and EvolveE, the guard
+    // sum of J, travels on a second stream while the main stream does that first half update of B:
+    //   main:  filter J | B (valid + 1 guard layer)        | E, B'
+    //   comm:           | SumBoundaryJ (pack, RCCL, unpack) |
     void SetUpHaloOverlap(bool want) {
+        m_grown_b = !m_any_pec && m_be->evolve_b_guard_layer != nullptr;   // a wall's boundary kernel owns the guards behind it
         m_overlap = false;
-        if (!want || m_any_pec) return;
         bool any_split = false;
-        for (int d = 0; d < 3; ++d) {
-            any_split = any_split || !m_comm->self_periodic(d);
-            if (m_ctx.brick_box.length(d) < 6) return;   // shells would meet
-        }
-        if (!any_split || !m_be->stream_create || !m_be->evolve_b_box || !m_be->evolve_e_box) return;
+        for (int d = 0; d < 3; ++d) any_split = any_split || !m_comm->self_periodic(d);
+        if (!want || !m_grown_b || !any_split || !m_be->stream_create) return;
         m_comm_stream = m_be->stream_create();
         if (!m_comm_stream) return;
         if (m_be->event_create)
             for (auto& e : m_halo_events) e = m_be->event_create();
-        // disjoint boxes covering every component's valid range [lo, lo + n + 1) (the nodal extra point included)
-        int32_t cur_lo[3], cur_hi[3];
-        for (int d = 0; d < 3; ++d) { cur_lo[d] = m_ctx.brick_box.lo[d]; cur_hi[d] = m_ctx.brick_box.lo[d] + m_ctx.brick_box.length(d) + 1; }
-        for (int d = 2; d >= 0; --d) {   // every direction: a fill (exchange or on-device wrap) reads all of a face
-            const int lo = m_ctx.brick_box.lo[d], n = m_ctx.brick_box.length(d);
-            IndexBox low, high;
-            for (int e = 0; e < 3; ++e) { low.lo[e] = high.lo[e] = cur_lo[e]; low.hi[e] = high.hi[e] = cur_hi[e]; }
-            low.lo[d] = lo;          low.hi[d] = lo + 2;
-            high.lo[d] = lo + n - 1; high.hi[d] = lo + n + 1;
-            m_shell.push_back(low);
-            m_shell.push_back(high);
-            cur_lo[d] = lo + 2;
-            cur_hi[d] = lo + n - 1;
-        }
-        for (int e = 0; e < 3; ++e) { m_interior.lo[e] = cur_lo[e]; m_interior.hi[e] = cur_hi[e]; }
         m_overlap = true;
     }
     bool halo_overlap() const { return m_overlap; }
-
-    void FieldSolveOverlapped() {
-        using warpx::fields::FieldType;
-        const amrex::Real hdt = 0.5 * dt[0];
-        auto order = [&](void* waiting_stream, int ev, void* recorded_stream) {   // waiting_stream continues after recorded_stream
-            if (!m_halo_events[ev]) return;   // a backend without streams runs in program order
-            m_be->event_record(m_halo_events[ev], recorded_stream);
-            m_be->stream_wait_event(waiting_stream, m_halo_events[ev]);
-        };
-        {
-            PhaseTimer t(&m_ctx, kEvolveB);
-            for (const IndexBox& b : m_shell) m_fdtd_solver_fp->EvolveB(m_fields, 0, hdt, b.lo, b.hi);
-        }
-        order(m_comm_stream, 0, m_ctx.stream);
-        FillBoundaryVector(FieldType::Bfield_fp, guard_cells.ng_FieldSolver, WarpX::sync_nodal_points, m_comm_stream);
-        {
-            PhaseTimer t(&m_ctx, kEvolveB);
-            m_fdtd_solver_fp->EvolveB(m_fields, 0, hdt, m_interior.lo, m_interior.hi);
-        }
-        {
-            PhaseTimer t(&m_ctx, kEvolveE);
-            m_fdtd_solver_fp->EvolveE(m_fields, 0, dt[0], m_interior.lo, m_interior.hi);
-        }
-        order(m_ctx.stream, 1, m_comm_stream);
-        {
-            PhaseTimer t(&m_ctx, kEvolveE);
-            for (const IndexBox& b : m_shell) m_fdtd_solver_fp->EvolveE(m_fields, 0, dt[0], b.lo, b.hi);
-        }
-        EvolveB(hdt, DtType::SecondHalf);   // reads valid points of E only: one full launch
+    // waiting_stream continues after what recorded_stream holds now (a backend without streams runs in program order)
+    void order_streams(void* waiting_stream, int ev, void* recorded_stream) {
+        if (!m_halo_events[ev]) return;
+        m_be->event_record(m_halo_events[ev], recorded_stream);
+        m_be->stream_wait_event(waiting_stream, m_halo_events[ev]);
     }
 
     // :1101-1180
@@ -396,6 +336,11 @@ public:
         auto J = m_fields.get_alldirs(FieldType::current_fp, 0);
         if (use_filter)
             for (int idim = 0; idim < 3; ++idim) ApplyFilterJ(J, 0, idim);
+        if (m_overlap) {   // the sum travels on the exchange stream; OneStep_nosub waits for it before EvolveE
+            order_streams(m_comm_stream, 0, m_ctx.stream);
+            SumBoundaryJ(J, 0, m_comm_stream);
+            return;        // no PEC in this mode: nothing to reflect
+        }
         SumBoundaryJ(J, 0);
         // :625-640 reflect the current density over PEC boundaries
         ApplyJfieldBoundary(0, J[0], J[1], J[2], PatchType::fine);
@@ -450,18 +395,26 @@ public:
     }
 
     // WarpXComm.cpp:1386-1424 -> WarpXSumGuardCells (WarpXSumGuardCells.cpp:17-24)
-    void SumBoundaryJ(const ablastr::fields::VectorField& current, int /*lev*/) {
+    void SumBoundaryJ(const ablastr::fields::VectorField& current, int lev) { SumBoundaryJ(current, lev, m_ctx.stream); }
+    void SumBoundaryJ(const ablastr::fields::VectorField& current, int /*lev*/, void* stream) {
         amrex::IntVect ng_depos_J = guard_cells.ng_depos_J;
         if (use_filter) ng_depos_J = ng_depos_J + amrex::IntVect(2) - amrex::IntVect(1);  // :1413-1416
         ng_depos_J = amrex::min(ng_depos_J, current[0]->nGrowVect());                     // :1417-1420
         m_comm->SumBoundary({current[0], current[1], current[2]}, ng_depos_J, /*refresh_guards=*/safe_guard_cells,
-                            m_ctx.stream);
+                            stream);
     }
 
     // Source/FieldSolver/WarpXPushFieldsEM.cpp:877-927
-    void EvolveB(amrex::Real a_dt, DtType /*a_dt_type*/) {
-        PhaseTimer t(&m_ctx, kEvolveB);  // "WarpX::EvolveB()"
-        m_fdtd_solver_fp->EvolveB(m_fields, 0, PatchType::fine, a_dt);
+    void EvolveB(amrex::Real a_dt, DtType a_dt_type) {
+        {
+            PhaseTimer t(&m_ctx, kEvolveB);  // "WarpX::EvolveB()"
+            m_fdtd_solver_fp->EvolveB(m_fields, 0, PatchType::fine, a_dt);
+        }
+        if (a_dt_type == DtType::FirstHalf && m_grown_b) {   // instead of the FillBoundaryB that would follow
+            PhaseTimer t(&m_ctx, kFillBoundary);
+            const int32_t grow[3] = {1, 1, 1};
+            m_fdtd_solver_fp->EvolveBGuardLayer(m_fields, 0, a_dt, grow);
+        }
         ApplyBfieldBoundary(0, PatchType::fine);                        // :926
     }
     // :930-1011
@@ -599,13 +552,10 @@ private:
     std::unique_ptr<BrickComm> m_comm;
     std::unique_ptr<amrex::MultiFab> m_filter_tmp[3];
     std::unique_ptr<amrex::MultiFab> m_rho, m_rho_tmp;   // ComputeRho (diagnostics)
-    // overlapped halo exchange: second stream, ordering events, shell / interior boxes
-    struct IndexBox { int32_t lo[3], hi[3]; };
-    bool m_overlap = false;
+    // field-solve exchanges: guard layer of B computed redundantly; J's guard sum on a second stream
+    bool m_grown_b = false, m_overlap = false;
     void* m_comm_stream = nullptr;
     void* m_halo_events[2] = {nullptr, nullptr};
-    std::vector<IndexBox> m_shell;
-    IndexBox m_interior{};
     std::vector<amrex::Real> dt;
     amrex::Real cur_time = 0.0;
     int64_t istep = 0;

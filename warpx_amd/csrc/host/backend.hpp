@@ -23,11 +23,9 @@ struct Backend {
     int (*evolve_b)(const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
     int (*evolve_e)(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double,
                     const double*, void*);
-    // the same restricted to an index box (shell / interior pieces of an overlapped halo exchange)
-    int (*evolve_b_box)(const wxa_field_view*, const wxa_field_view*, double, const double*, const int32_t* lo,
-                        const int32_t* hi, void*);
-    int (*evolve_e_box)(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double, const double*,
-                        const int32_t* lo, const int32_t* hi, void*);
+    // first guard layer of B from the guards already present (instead of FillBoundaryB after the update)
+    int (*evolve_b_guard_layer)(const wxa_field_view*, const wxa_field_view*, double, const double*, const int32_t* grow,
+                                void*);
     // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace
     int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);

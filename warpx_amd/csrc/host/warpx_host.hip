@@ -139,12 +139,9 @@ const Backend* hip_backend() {
         b.stream_create = hip_stream_create;
         b.stream_destroy = hip_stream_destroy;
         b.stream_wait_event = hip_stream_wait_event;
-        b.evolve_b_box = [](const wxa_field_view* E, const wxa_field_view* B, double dt, const double* dinv,
-                            const int32_t* lo, const int32_t* hi, void* st) -> int {
-            return wxa_evolve_b_box(E, B, dt, dinv, lo, hi, st); };
-        b.evolve_e_box = [](const wxa_field_view* E, const wxa_field_view* B, const wxa_field_view* J, double dt,
-                            const double* dinv, const int32_t* lo, const int32_t* hi, void* st) -> int {
-            return wxa_evolve_e_box(E, B, J, dt, dinv, lo, hi, st); };
+        b.evolve_b_guard_layer = [](const wxa_field_view* E, const wxa_field_view* B, double dt, const double* dinv,
+                                    const int32_t* grow, void* st) -> int {
+            return wxa_evolve_b_guard_layer(E, B, dt, dinv, grow, st); };
         b.event_create = hip_event_create;
         b.event_destroy = hip_event_destroy;
         b.event_record = hip_event_record;
