@@ -156,8 +156,8 @@ def main():
                          "(no particle crosses a cell for ~20 steps), the timed region must see the "
                          "thermalised steady state")
     ap.add_argument("--overlap", type=int, default=0,
-                    help="1: guard exchanges of the field solve on a second stream behind the interior update "
-                         "(N > 1 only; off until it has been measured on the 8-GPU node)")
+                    help="1: the guard exchanges of E+B and of J on a second stream, behind the push of the interior "
+                         "tiles and B's half update (N > 1 only; off until it has been measured on the 8-GPU node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-pass", action="store_true")
     args = ap.parse_args()

@@ -155,6 +155,20 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p,
                               int order, int galerkin, int pusher, int move,
                               wxa_workspace* ws, void* stream);
 
+/* PushPX in two parts, so that the guard exchange of E and B can travel while most particles are pushed:
+ * WXA_PART_INTERIOR = the particles of the tiles of the last cell sort that touch no face of the sorted
+ * box (they read no guard point; nothing without a valid sort), WXA_PART_REST = all the others (the tiles
+ * on the faces and the particles appended since the sort).  The two calls together do exactly what one
+ * wxa_gather_push_ws(move = 1) does.  Needs a cell sort at least every few steps: a particle must stay
+ * within a tile width (8 cells) minus the stencil of the tile it was sorted into. */
+enum { WXA_PART_INTERIOR = 1, WXA_PART_REST = 2 };
+wxa_status wxa_gather_push_part(const wxa_particle_view* p,
+                                const wxa_field_view E[3], const wxa_field_view B[3],
+                                const wxa_grid_geom* geom,
+                                double q, double m, double dt,
+                                int order, int galerkin, int pusher,
+                                wxa_workspace* ws, int part, void* stream);
+
 /* Replaces WarpXParticleContainer::DepositCurrent
  * (Source/Particles/WarpXParticleContainer.cpp:352-827) for
  * algo = Esirkepov: doEsirkepovDepositionShapeN<order>
@@ -384,8 +398,8 @@ typedef struct wxa_sim_config {
                                     is folded back with the image-charge sign of an absorbing wall) */
     int32_t particle_boundary_lo[3]; /* boundary.particle_lo: WXA_PBOUNDARY_* (0 = default)              */
     int32_t particle_boundary_hi[3]; /* boundary.particle_hi                                             */
-    int32_t overlap_halo;        /* 1: the guard sum of J travels on a second stream while B gets its first half
-                                    update (bricks, all-periodic runs)                                        */
+    int32_t overlap_halo;        /* 1 (bricks, all-periodic runs): the guard exchanges travel on a second stream --
+                                    E and B behind the push of the interior tiles, J behind B's half update  */
     int32_t grid_type;           /* warpx.grid_type: WXA_GRID_STAGGERED (0, the default).  WXA_GRID_COLLOCATED exists
                                     in the CPU restatement only (it pins the direct deposition to the reference's
                                     test_3d_langmuir_multi_nodal checksums); the library refuses it              */

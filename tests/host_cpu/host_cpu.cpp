@@ -71,6 +71,11 @@ const Backend* cpu_backend() {
                            void*, void* st) -> int {
             return move ? orc_gather_push(p, E, B, g, q, m, dt, o, ga, pu, st)
                         : orc_push_p(p, E, B, g, q, m, dt, o, ga, pu, st); };
+        // no tiles on this backend: the interior part is empty, the rest is everything (a valid split)
+        b.gather_push_part = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
+                                const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void*,
+                                int part, void* st) -> int {
+            return part == WXA_PART_INTERIOR ? 0 : orc_gather_push(p, E, B, g, q, m, dt, o, ga, pu, st); };
         b.deposit_current = orc_deposit_current;
         b.filter_bilinear = orc_filter_bilinear;
         b.fill_boundary_periodic = orc_fill_boundary_periodic;

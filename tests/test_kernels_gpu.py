@@ -654,3 +654,54 @@ def test_evolve_b_guard_layer(oracle, product, grow):
         assert np.array_equal(b.to_numpy()[2:-2, 2:-2, 2:-2], b0[2:-2, 2:-2, 2:-2])
         touched = any(g and not st for g, st in zip(grow, b.stag))
         assert np.array_equal(b.to_numpy(), b0) != touched
+
+
+@UNVERIFIED
+@pytest.mark.parametrize("order,pusher", [(3, _capi.PUSHER_BORIS), (1, _capi.PUSHER_VAY)])
+def test_gather_push_in_two_parts(product, order, pusher):
+    """wxa_gather_push_part: the interior tiles, then the rest (face tiles + the particles appended since the sort),
+    give every particle bit for bit what one wxa_gather_push_ws call gives; the interior part alone moves a
+    share of the particles and none that sits in a face tile."""
+    import torch
+    ncell = (40, 32, 24)   # 5 x 4 x 3 tiles: 6 of them touch no face
+    ng, _, _ = H.guard_depths(order)
+    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, ng, 10, scale=1e11, device=DEV, pad=True)
+    B = H.random_fields(("Bx", "By", "Bz"), ncell, ng, 11, scale=1e3, device=DEV, pad=True)
+    parts = H.random_particles(40000, ncell, 77)
+    dx = H.LX / np.asarray(ncell)
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    ntail = 500
+    full = ParticleArrays(pd0.np + ntail, DEV)        # room for a tail behind the sorted part
+    srt_view = _capi.ParticleView.from_buffer_copy(full.view)
+    srt_view.np = pd0.np
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt_view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    full.data[:, pd0.np:] = pd0.data[:, :ntail]       # arrivals since the sort: anywhere in the box
+    start = full.data.clone()
+    g, _ = H.geom_for(ncell, ng)
+    dt = H.yee_dt(dx)
+    q, m = -plasma.Q_E, plasma.M_E
+    product.gather_push_ws(C.byref(full.view), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt, order, 1,
+                           pusher, 1, ws, None)
+    _sync(product)
+    whole = full.data.clone()
+    full.data.copy_(start)
+    product.gather_push_part(C.byref(full.view), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt, order, 1,
+                             pusher, ws, _capi.PART_INTERIOR, None)
+    _sync(product)
+    moved = (full.data[0] != start[0]).cpu().numpy()
+    assert 0 < moved.sum() < pd0.np and not moved[pd0.np:].any()
+    cell = np.floor((start[:3].cpu().numpy() + H.LX / 2) / dx[:, None]).astype(int)
+    face = np.zeros(full.np, dtype=bool)
+    for d in range(3):
+        nt = (ncell[d] + 7) // 8
+        face |= (cell[d] // 8 == 0) | (cell[d] // 8 == nt - 1)
+    assert not (moved & face).any() and moved[:pd0.np][~face[:pd0.np]].all()
+    product.gather_push_part(C.byref(full.view), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt, order, 1,
+                             pusher, ws, _capi.PART_REST, None)
+    _sync(product)
+    assert torch.equal(full.data, whole)
+    product.workspace_destroy(ws)

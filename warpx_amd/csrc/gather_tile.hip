@@ -61,7 +61,11 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 
 // 512 threads per tile and no global-load fallback inside (127 VGPRs at order 3): two workgroups
 // per CU = 4 waves per SIMD, which is what hides the LDS read latency of the 252-point gather.
-template <int O, int G, int PUSHER, bool MOVE>
+// PART: 0 = every tile; 1 = only the tiles that touch no face of the sorted box (their particles read no guard
+// point, even as stragglers: a particle is at most a few cells from the tile it was sorted into); 2 = only
+// the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
+// (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
+template <int O, int G, int PUSHER, bool MOVE, int PART = 0>
 __global__ void __launch_bounds__(GT_THREADS)
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq) {
@@ -79,6 +83,10 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     const int ti = (int)(tile % tg.nt[0]);
     const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
     const int tk = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
+    if constexpr (PART != 0) {
+        const bool face = ti == 0 || ti == tg.nt[0] - 1 || tj == 0 || tj == tg.nt[1] - 1 || tk == 0 || tk == tg.nt[2] - 1;
+        if (face != (PART == 2)) return;
+    }
     const int o0 = tg.cell_lo[0] + ti * GT_TS + GatherTileDims<G>::LO;
     const int o1 = tg.cell_lo[1] + tj * GT_TS + GatherTileDims<G>::LO;
     const int o2 = tg.cell_lo[2] + tk * GT_TS + GatherTileDims<G>::LO;
@@ -139,7 +147,7 @@ bool gather_tile_available(const wxa_workspace* ws, const wxa_particle_view* p) 
     return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np <= p->np;
 }
 
-template <int PUSHER, bool MOVE>
+template <int PUSHER, bool MOVE, int PART = 0>
 static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
                          const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
                          wxa_workspace* ws, hipStream_t st) {
@@ -162,7 +170,7 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
 #define WXA_GT(O, G)                                                                                        \
     do {                                                                                                    \
-        hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE>), grid, block, 0, st, pv, offsets, ex, \
+        hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE, PART>), grid, block, 0, st, pv, offsets, ex, \
                            ey, ez, bx, by, bz, g, tg, q, m, dt, sq);                                        \
         hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt);                          \
@@ -186,6 +194,18 @@ wxa_status gather_push_tiled(const wxa_particle_view* p, const wxa_field_view E[
     }
     if (move) return launch<WXA_PUSHER_VAY, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
     return launch<WXA_PUSHER_VAY, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+}
+
+// PushPX on one part of the tiles (part = 1 interior, 2 faces), see the kernel
+wxa_status gather_push_tiled_part(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                                  const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                                  int pusher, int part, wxa_workspace* ws, hipStream_t st) {
+    if (pusher == WXA_PUSHER_BORIS) {
+        if (part == 1) return launch<WXA_PUSHER_BORIS, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+        return launch<WXA_PUSHER_BORIS, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    }
+    if (part == 1) return launch<WXA_PUSHER_VAY, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    return launch<WXA_PUSHER_VAY, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
 }
 
 }  // namespace wxa

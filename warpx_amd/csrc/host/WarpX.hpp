@@ -297,10 +297,10 @@ public:
     // All-periodic runs issue none: the first half update of B is followed by the same update of the first guard layer, from the
     // guards the gather-depth fill of the step start left (E and B have not changed since), so EvolveE finds the
     // guard points it reads without FillBoundaryB -- the neighbour computes the same numbers from the same
-    // operands, bit for bit.  With overlap_halo the one exchange left between deposition and EvolveE, the guard
-    // sum of J, travels on a second stream while the main stream does that first half update of B:
-    //   main:  filter J | B (valid + 1 guard layer)        | E, B'
-    //   comm:           | SumBoundaryJ (pack, RCCL, unpack) |
+    // operands, bit for bit.  With overlap_halo the two field exchanges of a step travel on a second stream:
+    //   main:  push of the interior tiles | push of the rest, deposit, filter J | B (valid + guard layer) | E, B'
+    //   comm:  FillBoundary E+B (gather)  |                                     | SumBoundaryJ            |
+    // (the tiles that touch no face of the brick read no guard point; EvolveE is the first reader of the summed J)
     void SetUpHaloOverlap(bool want) {
         m_grown_b = !m_any_pec && m_be->evolve_b_guard_layer != nullptr;   // a wall's boundary kernel owns the guards behind it
         m_overlap = false;
@@ -324,6 +324,11 @@ public:
     // :1101-1180
     void PushParticlesandDeposit(amrex::Real a_cur_time, bool skip_current = false,
                                  PushType push_type = PushType::Explicit) {
+        if (m_eb_fill_in_flight) {
+            mypc->PushInterior(m_fields, dt[0]);               // reads no guard point
+            order_streams(m_ctx.stream, 3, m_comm_stream);     // the guards of E and B have arrived
+            m_eb_fill_in_flight = false;
+        }
         mypc->Evolve(m_fields, 0, "current_fp", a_cur_time, dt[0], DtType::Full, skip_current, push_type);
     }
 
@@ -468,7 +473,13 @@ public:
             mypc->PushP(0, -0.5 * dt[0], *E[0], *E[1], *E[2], *B[0], *B[1], *B[2]);
             is_synchronized = false;
         } else {
-            FillBoundaryEB(guard_cells.ng_FieldGather);   // FillBoundaryE + FillBoundaryB (:515-516)
+            if (m_overlap) {   // on the exchange stream; PushParticlesandDeposit pushes the interior tiles meanwhile
+                order_streams(m_comm_stream, 2, m_ctx.stream);
+                FillBoundaryEB(guard_cells.ng_FieldGather, m_comm_stream);
+                m_eb_fill_in_flight = true;
+            } else {
+                FillBoundaryEB(guard_cells.ng_FieldGather);   // FillBoundaryE + FillBoundaryB (:515-516)
+            }
             UpdateAuxilaryData();
             FillBoundaryAux(guard_cells.ng_UpdateAux);
         }
@@ -534,13 +545,16 @@ private:
     // FillBoundaryE(ng) followed by FillBoundaryB(ng): the six components share the messages
     void FillBoundaryEB(const amrex::IntVect& ng) {
         PhaseTimer t(&m_ctx, kFillBoundary);
+        FillBoundaryEB(ng, m_ctx.stream);
+    }
+    void FillBoundaryEB(const amrex::IntVect& ng, void* stream) {
         using warpx::fields::FieldType;
         auto E = m_fields.get_alldirs(FieldType::Efield_fp, 0);
         auto B = m_fields.get_alldirs(FieldType::Bfield_fp, 0);
         for (int d = 0; d < 3; ++d)
             if (!ng.allLE(E[d]->nGrowVect()) || !ng.allLE(B[d]->nGrowVect()))
                 throw std::runtime_error("Error: in FillBoundary, requested more guard cells than allocated");
-        m_comm->FillBoundary({E[0], E[1], E[2], B[0], B[1], B[2]}, ng, false, m_ctx.stream);
+        m_comm->FillBoundary({E[0], E[1], E[2], B[0], B[1], B[2]}, ng, false, stream);
     }
 
     const Backend* m_be;
@@ -555,7 +569,8 @@ private:
     // field-solve exchanges: guard layer of B computed redundantly; J's guard sum on a second stream
     bool m_grown_b = false, m_overlap = false;
     void* m_comm_stream = nullptr;
-    void* m_halo_events[2] = {nullptr, nullptr};
+    void* m_halo_events[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool m_eb_fill_in_flight = false;
     std::vector<amrex::Real> dt;
     amrex::Real cur_time = 0.0;
     int64_t istep = 0;

@@ -337,6 +337,9 @@ public:
         be->stream_sync(m_ctx->stream);
     }
 
+    // see PhysicalParticleContainer::PushInterior; containers that gather nothing have nothing to do
+    virtual void PushInterior(ablastr::fields::MultiFabRegister& /*fields*/, amrex::Real /*dt*/) {}
+
     // WarpXParticleContainer::doContinuousInjection / ContinuousInjection / m_current_injection_position
     virtual bool doContinuousInjection() const { return false; }
     virtual void ContinuousInjection(const double* /*box_lo*/, const double* /*box_hi*/) {}
@@ -452,6 +455,7 @@ private:
     wxa_plasma_injector m_inj{};
     bool m_has_injector = false, m_do_continuous_injection = false;
     std::function<void(double, double, double, double*)> m_momentum;
+    bool m_interior_pushed = false;
 
 public:
 
@@ -493,9 +497,34 @@ public:
         const wxa_field_view B[3] = {Bx.view(), By.view(), Bz.view()};
         const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
         const wxa_particle_view p = m_tile.view();
+        if (m_interior_pushed) {   // PushInterior ran on these particles already: the rest
+            m_interior_pushed = false;
+            check(m_ctx->be->gather_push_part(&p, E, B, &g, charge, mass, dt, m_ctx->nox,
+                                              m_ctx->galerkin_interpolation ? 1 : 0, (int)m_ctx->particle_pusher_algo, m_ws,
+                                              WXA_PART_REST, m_ctx->stream),
+                  "gather_push_part");
+            return;
+        }
         check(m_ctx->be->gather_push(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
                                      (int)m_ctx->particle_pusher_algo, /*move=*/1, m_ws, m_ctx->stream),
               "gather_push");
+    }
+    // PushPX of the particles that read no guard point of E and B (the interior tiles of the last sort), issued
+    // while the guard exchange of this step is still in flight; the PushPX of this step's Evolve then does the rest
+    void PushInterior(ablastr::fields::MultiFabRegister& fields, amrex::Real dt) override {
+        if (m_tile.numParticles() == 0 || !m_ctx->be->gather_push_part) return;
+        using warpx::fields::FieldType;
+        PhaseTimer t(m_ctx, kGatherAndPush);
+        auto Ef = fields.get_alldirs(FieldType::Efield_aux, 0);
+        auto Bf = fields.get_alldirs(FieldType::Bfield_aux, 0);
+        const wxa_field_view E[3] = {Ef[0]->view(), Ef[1]->view(), Ef[2]->view()};
+        const wxa_field_view B[3] = {Bf[0]->view(), Bf[1]->view(), Bf[2]->view()};
+        const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
+        const wxa_particle_view p = m_tile.view();
+        check(m_ctx->be->gather_push_part(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
+                                          (int)m_ctx->particle_pusher_algo, m_ws, WXA_PART_INTERIOR, m_ctx->stream),
+              "gather_push_part");
+        m_interior_pushed = true;
     }
 
     // :2368-2516
@@ -653,6 +682,9 @@ public:
                const amrex::MultiFab& Bz) {
         PhaseTimer t(m_ctx, kOther);  // (de)synchronisation half-pushes, twice per Evolve call
         for (auto& pc : allcontainers) pc->PushP(lev, dt, Ex, Ey, Ez, Bx, By, Bz);
+    }
+    void PushInterior(ablastr::fields::MultiFabRegister& fields, amrex::Real dt) {
+        for (auto& pc : allcontainers) pc->PushInterior(fields, dt);
     }
     // Source/Particles/MultiParticleContainer.cpp (ApplyBoundaryConditions over all species)
     void ApplyBoundaryConditions() {

@@ -29,6 +29,9 @@ struct Backend {
     // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace
     int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);
+    // PushPX on the interior tiles / on the rest (wxa_gather_push_part)
+    int (*gather_push_part)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
+                            const wxa_grid_geom*, double, double, double, int, int, int, void* ws, int part, void*);
     int (*deposit_current)(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double,
                            double, double, int, int, void* ws, void*);
     // diagnostics: doChargeDepositionShapeN

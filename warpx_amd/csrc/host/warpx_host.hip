@@ -78,6 +78,10 @@ const Backend* hip_backend() {
                            const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, int move,
                            void* ws, void* st) -> int {
             return wxa_gather_push_ws(p, E, B, g, q, m, dt, o, ga, pu, move, static_cast<wxa_workspace*>(ws), st); };
+        b.gather_push_part = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
+                                const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void* ws,
+                                int part, void* st) -> int {
+            return wxa_gather_push_part(p, E, B, g, q, m, dt, o, ga, pu, static_cast<wxa_workspace*>(ws), part, st); };
         b.deposit_current = k_deposit;
         b.filter_bilinear = [](const wxa_field_view* s, const wxa_field_view* d, void* st) -> int {
             return wxa_filter_bilinear(s, d, st); };

@@ -418,6 +418,29 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E
     return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, st);
 }
 
+wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                                const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                                int pusher, wxa_workspace* ws, int part, void* stream) {
+    wxa_status rc = check_gather_args(p, E, B, geom, order, galerkin, pusher);
+    if (rc != WXA_OK) return rc;
+    WXA_REQUIRE(part == WXA_PART_INTERIOR || part == WXA_PART_REST, "part must be WXA_PART_INTERIOR or WXA_PART_REST");
+    if (p->np == 0) return WXA_OK;
+    if (!gather_tile_available(ws, p)) {   // no tiles: the interior part is empty, the rest is everything
+        if (part == WXA_PART_INTERIOR) return WXA_OK;
+        return wxa_gather_push_ws(p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, nullptr, stream);
+    }
+    wxa_particle_view head = *p;
+    head.np = ws->sorted_np;
+    if (head.np > 0 &&
+        (rc = gather_push_tiled_part(&head, E, B, geom, q, m, dt, order, galerkin, pusher, part, ws,
+                                     (hipStream_t)stream)) != WXA_OK)
+        return rc;
+    if (part == WXA_PART_INTERIOR) return WXA_OK;
+    const wxa_particle_view rest = tail_view(*p, ws->sorted_np);   // arrivals since the sort may sit anywhere
+    if (rest.np == 0) return WXA_OK;
+    return wxa_gather_push_ws(&rest, E, B, geom, q, m, dt, order, galerkin, pusher, 1, nullptr, stream);
+}
+
 wxa_status wxa_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
                            const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
                            int pusher, void* stream) {

@@ -52,5 +52,8 @@ bool gather_tile_available(const wxa_workspace* ws, const wxa_particle_view* p);
 wxa_status gather_push_tiled(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
                              const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
                              int pusher, bool move, wxa_workspace* ws, hipStream_t stream);
+wxa_status gather_push_tiled_part(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                                  const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                                  int pusher, int part, wxa_workspace* ws, hipStream_t stream);
 }  // namespace wxa
 #endif
