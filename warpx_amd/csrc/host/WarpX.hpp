@@ -302,7 +302,8 @@ public:
     //   comm:  FillBoundary E+B (gather)  |                                     | SumBoundaryJ            |
     // (the tiles that touch no face of the brick read no guard point; EvolveE is the first reader of the summed J)
     void SetUpHaloOverlap(bool want) {
-        m_grown_b = !m_any_pec && m_be->evolve_b_guard_layer != nullptr;   // a wall's boundary kernel owns the guards behind it
+        // a wall's boundary kernel owns the guards behind it; WXA_NO_GUARD_LAYER=1 brings the exchange back (debugging)
+        m_grown_b = !m_any_pec && m_be->evolve_b_guard_layer != nullptr && !std::getenv("WXA_NO_GUARD_LAYER");
         m_overlap = false;
         bool any_split = false;
         for (int d = 0; d < 3; ++d) any_split = any_split || !m_comm->self_periodic(d);
