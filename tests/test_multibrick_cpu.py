@@ -40,18 +40,20 @@ def test_bricks_match_single_domain(nb, order, filt, port, tmp_path):
     assert rep["ekin_rel"] < 1e-11 and rep["abs_p_rel"] < 1e-11
 
 
-@pytest.mark.parametrize("nb,deck,golden,port", [
-    # window along z (unsplit), bricks along x and y: continuous injection, the antenna and the PEC walls per brick
-    ((2, 1, 1), "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29621),
-    ((1, 1, 2), "langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", 29623),
-    # (0, 0, 0): the library chooses the bricks for the 4 ranks -- x and y here (PEC walls and the window along z)
-    ((0, 0, 0), "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29624),
+@pytest.mark.parametrize("nb,nranks,deck,golden,port", [
+    # window along z (unsplit), bricks along x: continuous injection, the antenna and the PEC walls per brick
+    ((2, 1, 1), 2, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29621),
+    ((1, 1, 2), 2, "langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", 29623),
+    # (0, 0, 0): the library chooses the bricks -- x and y for the wakefield deck (PEC walls and the window along z),
+    # 2 x 2 x 2 for the all-periodic Langmuir deck on 8 ranks
+    ((0, 0, 0), 4, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29624),
+    ((0, 0, 0), 8, "langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", 29625),
 ])
-def test_deck_on_bricks_reaches_the_golden_checksums(nb, deck, golden, port, tmp_path):
+def test_deck_on_bricks_reaches_the_golden_checksums(nb, nranks, deck, golden, port, tmp_path):
     """A whole inputs file on several bricks (gloo): the per-brick checksums add up to the reference's golden
     values.  (Sums of |cell-centred value| split exactly over bricks: every cell belongs to one brick.)"""
     out = str(tmp_path / "sum.json")
-    n = nb[0] * nb[1] * nb[2] or 4
+    n = nranks
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
            *[str(v) for v in nb], os.path.join(ROOT, "tests", "decks", deck), out]
