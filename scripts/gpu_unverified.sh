@@ -22,7 +22,7 @@ for t in \
     "tests/test_kernels_gpu.py::test_gather_push_in_two_parts" \
     "tests/test_multibrick_gpu.py::test_bricks_with_overlapped_halo_exchange"; do
     echo "=== $t" >> $OUT
-    timeout 300 python -m pytest "$t" -x -q 2>&1 | tail -15 >> $OUT
+    timeout 600 python -m pytest "$t" -q 2>&1 | tail -15 >> $OUT
 done
 unset WXA_UNVERIFIED_GPU_TESTS
 echo "=== full suite" >> $OUT
