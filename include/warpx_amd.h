@@ -428,6 +428,17 @@ typedef struct wxa_plasma_injector {
     double  lo[3], hi[3];   /* xmin,ymin,zmin / xmax,ymax,zmax (+-1e300 = unbounded) */
 } wxa_plasma_injector;
 
+/* PhysicalParticleContainer::AddPlasma on the device for that injector: the particles of the `ncells` cells
+ * whose low corner is `corner` (InjectorPositionRegular lattice, weight = density dV / ppc, momentum
+ * u c with u constant -- NULL = at rest) that lie inside the injector's bounds and strictly inside the
+ * brick [brick_lo, brick_hi], written into the free slots `dst` (dst->np = room available; idcpu = 0).
+ * *n_added (host) is valid on return (synchronises); the order of the new particles is not specified
+ * (the cell sort that follows an injection fixes it).  WXA_ERR_NOMEM if dst is too small. */
+wxa_status wxa_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj,
+                          const double corner[3], const int32_t ncells[3], const double dx[3],
+                          const double brick_lo[3], const double brick_hi[3], const double u[3],
+                          int64_t* n_added, wxa_workspace* ws, void* stream);
+
 /* lasers.names / <laser>.profile = Gaussian (Source/Particles/LaserParticleContainer.cpp,
  * Source/Laser/LaserProfilesImpl/LaserProfileGaussian.cpp), lab frame, no space-time couplings */
 typedef struct wxa_laser_antenna {

@@ -634,6 +634,55 @@ int orc_shift_field_window(const wxa_field_view* f, double* tmp, int32_t dir, in
     return 0;
 }
 
+// PhysicalParticleContainer::AddPlasma (:924-1333) for the cells [0, ncells) above `corner`, NUniformPerCell with a
+// constant density, momentum u c (NULL = at rest): the counterpart of wxa_add_plasma, in lattice order
+int orc_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj, const double corner[3],
+                   const int32_t ncells[3], const double dx[3], const double brick_lo[3], const double brick_hi[3],
+                   const double u[3], int64_t* n_added, void*, void*) {
+    *n_added = 0;
+    if (!(inj->density > 0)) return 0;
+    const int nppc = inj->ppc[0] * inj->ppc[1] * inj->ppc[2];
+    const double weight = inj->density * (dx[0] * dx[1] * dx[2] / nppc);
+    int64_t n = 0;
+    for (int k = 0; k < ncells[2]; ++k)
+        for (int j = 0; j < ncells[1]; ++j)
+            for (int i = 0; i < ncells[0]; ++i) {
+                const int iv[3] = {i, j, k};
+                bool cell_ok = true;
+                for (int d = 0; d < 3; ++d) {
+                    const double clo = corner[d] + (iv[d] + 0.0) * dx[d], chi = corner[d] + (iv[d] + 1.0) * dx[d];
+                    const double mid = (clo + chi) / 2.;
+                    const bool sample = (clo < inj->hi[d] && clo >= inj->lo[d]) || (mid < inj->hi[d] && mid >= inj->lo[d]) ||
+                                        (chi < inj->hi[d] && chi >= inj->lo[d]);
+                    cell_ok = cell_ok && !(clo > inj->hi[d] || chi < inj->lo[d]) && sample;
+                }
+                if (!cell_ok) continue;
+                for (int ip = 0; ip < nppc; ++ip) {
+                    const int ny = inj->ppc[1], nz = inj->ppc[2];
+                    const int ix_part = ip / (ny * nz);
+                    const int iz_part = (ip - ix_part * (ny * nz)) / ny;
+                    const int iy_part = (ip - ix_part * (ny * nz)) - ny * iz_part;
+                    const double r[3] = {(0.5 + ix_part) / inj->ppc[0], (0.5 + iy_part) / inj->ppc[1], (0.5 + iz_part) / inj->ppc[2]};
+                    double pos[3];
+                    bool ok = true;
+                    for (int d = 0; d < 3; ++d) {
+                        pos[d] = corner[d] + (iv[d] + r[d]) * dx[d];
+                        ok = ok && pos[d] > brick_lo[d] && pos[d] < brick_hi[d] && pos[d] < inj->hi[d] && pos[d] >= inj->lo[d];
+                    }
+                    if (!ok) continue;
+                    if (n >= dst->np) return -4;
+                    dst->x[n] = pos[0]; dst->y[n] = pos[1]; dst->z[n] = pos[2]; dst->w[n] = weight;
+                    dst->ux[n] = u ? u[0] * PhysConst::c : 0.0;
+                    dst->uy[n] = u ? u[1] * PhysConst::c : 0.0;
+                    dst->uz[n] = u ? u[2] * PhysConst::c : 0.0;
+                    if (dst->idcpu) dst->idcpu[n] = 0;
+                    ++n;
+                }
+            }
+    *n_added = n;
+    return 0;
+}
+
 // calculate_laser_plane_coordinates (LaserParticleContainer.cpp:795-847), GaussianLaserProfile::fill_amplitude
 // (LaserProfileGaussian.cpp:104-161 with zeta = beta = phi2 = phi0 = 0, theta_stc = 0), update_laser_particle
 // (:850-951), lab frame

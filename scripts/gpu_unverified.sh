@@ -20,6 +20,7 @@ for t in \
     "tests/test_step_gpu.py::test_decks_reach_the_reference_golden_checksums_on_gpu" \
     "tests/test_kernels_gpu.py::test_evolve_b_guard_layer" \
     "tests/test_kernels_gpu.py::test_gather_push_in_two_parts" \
+    "tests/test_kernels_gpu.py::test_add_plasma" \
     "tests/test_multibrick_gpu.py::test_bricks_with_overlapped_halo_exchange"; do
     echo "=== $t" >> $OUT
     timeout 600 python -m pytest "$t" -q 2>&1 | tail -15 >> $OUT

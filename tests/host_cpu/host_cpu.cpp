@@ -39,6 +39,8 @@ int orc_apply_pec_e(const wxa_field_view*, const int32_t*, const int32_t*, const
 int orc_apply_pec_b(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                     void*);
 int orc_evolve_b_guard_layer(const wxa_field_view*, const wxa_field_view*, double, const double*, const int32_t*, void*);
+int orc_add_plasma(const wxa_particle_view*, const wxa_plasma_injector*, const double*, const int32_t*, const double*,
+                   const double*, const double*, const double*, int64_t*, void*, void*);
 int orc_apply_pec_j(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
 int orc_apply_pec_rho(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
 int orc_deposit_charge(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, int, void*);
@@ -76,6 +78,7 @@ const Backend* cpu_backend() {
                                 const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void*,
                                 int part, void* st) -> int {
             return part == WXA_PART_INTERIOR ? 0 : orc_gather_push(p, E, B, g, q, m, dt, o, ga, pu, st); };
+        b.add_plasma = orc_add_plasma;
         b.deposit_current = orc_deposit_current;
         b.filter_bilinear = orc_filter_bilinear;
         b.fill_boundary_periodic = orc_fill_boundary_periodic;

@@ -705,3 +705,39 @@ def test_gather_push_in_two_parts(product, order, pusher):
     _sync(product)
     assert torch.equal(full.data, whole)
     product.workspace_destroy(ws)
+
+
+@UNVERIFIED
+@pytest.mark.parametrize("ppc,u", [((1, 1, 1), None), ((2, 1, 3), (0.1, -0.2, 0.0))])
+def test_add_plasma(oracle, product, ppc, u):
+    """wxa_add_plasma (PhysicalParticleContainer::AddPlasma on the device): injector bounds cutting through cells,
+    a brick smaller than the cell box, at rest and with a constant momentum: the same particles as the CPU
+    restatement, bit for bit (as a set: the device does not promise an order)."""
+    inj = _capi.PlasmaInjector()
+    inj.density = 2e23
+    for d in range(3):
+        inj.ppc[d] = ppc[d]
+    lo, hi = (-3.3e-6, -1e300, 0.4e-6), (2.1e-6, 1e300, 1e300)
+    for d in range(3):
+        inj.lo[d], inj.hi[d] = lo[d], hi[d]
+    dx = (0.5e-6, 0.4e-6, 0.25e-6)
+    corner, ncells = (-4e-6, -2e-6, 0.0), (16, 10, 12)
+    brick_lo, brick_hi = (-4e-6, -2e-6, 0.0), (1.5e-6, 2e-6, 3e-6)
+    room = 16 * 10 * 12 * ppc[0] * ppc[1] * ppc[2]
+    uarr = (C.c_double * 3)(*u) if u else None
+    pc, pd = ParticleArrays(room, "cpu", with_id=True), ParticleArrays(room, DEV, with_id=True)
+    nc, nd = C.c_int64(), C.c_int64()
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    args = (C.byref(inj), H.d3(corner), (C.c_int32 * 3)(*ncells), H.d3(dx), H.d3(brick_lo), H.d3(brick_hi), uarr)
+    oracle.add_plasma(C.byref(pc.view), *args, C.byref(nc), None, None)
+    product.add_plasma(C.byref(pd.view), *args, C.byref(nd), ws, None)
+    _sync(product)
+    assert nc.value == nd.value and 0 < nc.value < room
+    a, b = pd.to_numpy()[:, :nd.value], pc.to_numpy()[:, :nc.value]
+    ka, kb = np.lexsort(a[:3]), np.lexsort(b[:3])
+    assert np.array_equal(a[:, ka], b[:, kb])
+    small = ParticleArrays(nc.value - 1, DEV, with_id=True)        # too little room is an error, not an overrun
+    with pytest.raises(_capi.WxaError):
+        product.add_plasma(C.byref(small.view), *args, C.byref(nd), ws, None)
+    product.workspace_destroy(ws)

@@ -193,6 +193,8 @@ _PRODUCT_SIGS = {
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "gather_push_ws": (C.c_int, [_PPV, _FV3, _FV3, _PGG, C.c_double, C.c_double, C.c_double,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "add_plasma": (C.c_int, [_PPV, C.POINTER(PlasmaInjector), _D3, _I32_3, _D3, _D3, _D3, C.c_void_p,
+                             C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "gather_push_part": (C.c_int, [_PPV, _FV3, _FV3, _PGG, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "partition_particles": (C.c_int, [_PPV, _PPV, C.c_int, C.c_double, C.c_double,
@@ -219,6 +221,8 @@ _ORACLE_SIGS = {
     "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
 
     "num_threads": (C.c_int, []),
+    "add_plasma": (C.c_int, [_PPV, C.POINTER(PlasmaInjector), _D3, _I32_3, _D3, _D3, _D3, C.c_void_p,
+                             C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     # CPU counterparts of the Redistribute entry points (host-layer tests, parity tests)
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "wrap_and_classify": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,

@@ -499,9 +499,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                 pp.queryWithParser(name + ".ux", u[0]);
                 pp.queryWithParser(name + ".uy", u[1]);
                 pp.queryWithParser(name + ".uz", u[2]);
-                pc->SetMomentumFunction([u0 = u[0], u1 = u[1], u2 = u[2]](double, double, double, double* out) {
-                    out[0] = u0; out[1] = u1; out[2] = u2;
-                });
+                pc->SetConstantMomentum(u[0], u[1], u[2]);
             } else if (mom == "parsemomentumfunction") {
                 Parser f[3];
                 for (int d = 0; d < 3; ++d) {

@@ -398,6 +398,21 @@ public:
             nov[d] = (int)std::round((ohi[d] - olo[d]) / dx);
         }
         const int nppc = in.ppc[0] * in.ppc[1] * in.ppc[2];
+        if (m_ctx->be->add_plasma && (!m_momentum || m_momentum_is_constant)) {
+            // on the device: no host arrays, no copy (a plane of a moving window at 256^2 x 8 ppc is 30 MB)
+            const int64_t room = (int64_t)nov[0] * nov[1] * nov[2] * nppc;
+            if (room == 0) return;
+            const int64_t n0 = m_tile.numParticles();
+            m_tile.resize(n0 + room);
+            const wxa_particle_view dst = m_tile.view(n0, room);
+            const int32_t nc[3] = {nov[0], nov[1], nov[2]};
+            int64_t added = 0;
+            check(m_ctx->be->add_plasma(&dst, &in, olo, nc, m_ctx->dx.data(), m_ctx->brick_plo.data(), m_ctx->brick_phi.data(),
+                                        m_momentum_is_constant ? m_constant_u : nullptr, &added, m_ws, m_ctx->stream),
+                  "add_plasma");
+            m_tile.resize(n0 + added);
+            return;
+        }
         const double scale_fac = m_ctx->dx[0] * m_ctx->dx[1] * m_ctx->dx[2] / nppc;   // compute_scale_fac_volume
         auto inside = [&](double x, double y, double z) {   // InjectorPosition::insideBounds
             return x < in.hi[0] && x >= in.lo[0] && y < in.hi[1] && y >= in.lo[1] && z < in.hi[2] && z >= in.lo[2];
@@ -449,13 +464,23 @@ public:
 
     // <species>.momentum_distribution_type = constant | parse_momentum_function: u (in units of c) at a position
     // (InjectorMomentumConstant / InjectorMomentumParser, Source/Initialization/InjectorMomentum.H)
-    void SetMomentumFunction(std::function<void(double, double, double, double*)> f) { m_momentum = std::move(f); }
+    void SetMomentumFunction(std::function<void(double, double, double, double*)> f) {
+        m_momentum = std::move(f);
+        m_momentum_is_constant = false;
+    }
+    void SetConstantMomentum(double ux, double uy, double uz) {   // InjectorMomentumConstant
+        m_constant_u[0] = ux; m_constant_u[1] = uy; m_constant_u[2] = uz;
+        m_momentum = [ux, uy, uz](double, double, double, double* out) { out[0] = ux; out[1] = uy; out[2] = uz; };
+        m_momentum_is_constant = true;
+    }
 
 private:
     wxa_plasma_injector m_inj{};
     bool m_has_injector = false, m_do_continuous_injection = false;
     std::function<void(double, double, double, double*)> m_momentum;
     bool m_interior_pushed = false;
+    bool m_momentum_is_constant = false;
+    double m_constant_u[3] = {0.0, 0.0, 0.0};
 
 public:
 

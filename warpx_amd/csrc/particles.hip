@@ -253,6 +253,59 @@ laser_push_kernel(PV p, LaserPushGeom lg, double dt) {
     p.x[i] = x + vx * dt; p.y[i] = y + vy * dt; p.z[i] = z + vz * dt;
 }
 
+// ---- plasma injection: PhysicalParticleContainer::AddPlasma (PhysicalParticleContainer.cpp:924-1333) ---------
+struct InjectGeom {
+    double corner[3], dx[3], blo[3], bhi[3], lo[3], hi[3], u[3];
+    int nc[3], ppc[3];
+    double weight;
+};
+
+// one thread per lattice point; accepted points take consecutive slots (one atomic per wave)
+__global__ void __launch_bounds__(256)
+add_plasma_kernel(PV dst, InjectGeom ig, long npoints, unsigned long long* __restrict__ count) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = t < npoints;
+    double pos[3] = {0.0, 0.0, 0.0};
+    if (ok) {
+        const int nppc = ig.ppc[0] * ig.ppc[1] * ig.ppc[2];
+        const long cell = t / nppc;
+        const int ip = (int)(t % nppc);
+        const int iv[3] = {(int)(cell % ig.nc[0]), (int)((cell / ig.nc[0]) % ig.nc[1]), (int)(cell / ((long)ig.nc[0] * ig.nc[1]))};
+        // InjectorPositionRegular::getPositionUnitBox (Source/Initialization/InjectorPosition.H:74-92)
+        const int ny = ig.ppc[1], nz = ig.ppc[2];
+        const int ix_part = ip / (ny * nz);
+        const int iz_part = (ip - ix_part * (ny * nz)) / ny;
+        const int iy_part = (ip - ix_part * (ny * nz)) - ny * iz_part;
+        const double r[3] = {(0.5 + ix_part) / ig.ppc[0], (0.5 + iy_part) / ig.ppc[1], (0.5 + iz_part) / ig.ppc[2]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double clo = ig.corner[d] + (iv[d] + 0.0) * ig.dx[d], chi = ig.corner[d] + (iv[d] + 1.0) * ig.dx[d];
+            // overlapsWith, and :1030-1048: a corner, an edge midpoint or the centre of the cell has density
+            const double mid = (clo + chi) / 2.;
+            const bool sample = (clo < ig.hi[d] && clo >= ig.lo[d]) || (mid < ig.hi[d] && mid >= ig.lo[d]) ||
+                                (chi < ig.hi[d] && chi >= ig.lo[d]);
+            ok = ok && !(clo > ig.hi[d] || chi < ig.lo[d]) && sample;
+            pos[d] = ig.corner[d] + (iv[d] + r[d]) * ig.dx[d];                        // getCellCoords
+            ok = ok && pos[d] > ig.blo[d] && pos[d] < ig.bhi[d];                      // tile_realbox.contains
+            ok = ok && pos[d] < ig.hi[d] && pos[d] >= ig.lo[d];                       // insideBounds
+        }
+    }
+    const unsigned long long mask = __ballot(ok);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader);
+    if (!ok) return;
+    const long slot = (long)(base + __popcll(mask & ((1ULL << lane) - 1ULL)));
+    if (slot >= dst.np) return;   // the host sees count > room and reports it
+    dst.x[slot] = pos[0]; dst.y[slot] = pos[1]; dst.z[slot] = pos[2];
+    dst.w[slot] = ig.weight;
+    dst.ux[slot] = ig.u[0]; dst.uy[slot] = ig.u[1]; dst.uz[slot] = ig.u[2];
+    if (dst.id) dst.id[slot] = 0;
+}
+
 // ---- particle walls: WarpXParticleContainer::ApplyBoundaryConditions -------------------------------
 struct WallGeom {
     double lo[3], hi[3];
@@ -665,6 +718,45 @@ wxa_status wxa_pack_leavers(const wxa_particle_view* p, const int32_t* list, int
     hipLaunchKernelGGL(pack_leavers_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, make_pv(*p),
                        list, (long)n, (double*)msg, (long)row_len, (long)offset, retire, cg);
     WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj, const double corner[3],
+                          const int32_t ncells[3], const double dx[3], const double brick_lo[3],
+                          const double brick_hi[3], const double u[3], int64_t* n_added, wxa_workspace* ws,
+                          void* stream) {
+    WXA_REQUIRE(dst && inj && corner && ncells && dx && brick_lo && brick_hi && n_added && ws, "null argument");
+    WXA_REQUIRE(dst->np >= 0 && (dst->np == 0 || (dst->x && dst->y && dst->z && dst->w && dst->ux && dst->uy && dst->uz)),
+                "bad particle view");
+    WXA_REQUIRE(inj->ppc[0] >= 1 && inj->ppc[1] >= 1 && inj->ppc[2] >= 1 && inj->density >= 0.0, "bad injector");
+    *n_added = 0;
+    InjectGeom ig;
+    long npoints = (long)inj->ppc[0] * inj->ppc[1] * inj->ppc[2];
+    for (int d = 0; d < 3; ++d) {
+        WXA_REQUIRE(ncells[d] >= 0 && dx[d] > 0, "bad cell box");
+        ig.corner[d] = corner[d]; ig.dx[d] = dx[d]; ig.blo[d] = brick_lo[d]; ig.bhi[d] = brick_hi[d];
+        ig.lo[d] = inj->lo[d]; ig.hi[d] = inj->hi[d]; ig.nc[d] = ncells[d]; ig.ppc[d] = inj->ppc[d];
+        ig.u[d] = u ? u[d] * PhysConst::c : 0.0;
+        npoints *= ncells[d];
+    }
+    if (npoints == 0 || !(inj->density > 0)) return WXA_OK;
+    ig.weight = inj->density * (dx[0] * dx[1] * dx[2] / (inj->ppc[0] * inj->ppc[1] * inj->ppc[2]));   // compute_scale_fac_volume
+    hipStream_t st = (hipStream_t)stream;
+    wxa_status rc;
+    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    unsigned long long* dcount = (unsigned long long*)((unsigned*)ws->counters.p + 56);   // 0: deposit, 16: gather, 32: classify, 48: walls
+    WXA_HIP_CHECK(hipMemsetAsync(dcount, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(add_plasma_kernel, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, st, make_pv(*dst), ig, npoints,
+                       dcount);
+    WXA_LAUNCH_CHECK();
+    unsigned long long h = 0;
+    WXA_HIP_CHECK(hipMemcpyAsync(&h, dcount, sizeof(h), hipMemcpyDeviceToHost, st));
+    WXA_HIP_CHECK(hipStreamSynchronize(st));
+    if ((int64_t)h > dst->np) {
+        set_last_error("wxa_add_plasma: not enough room for the injected particles");
+        return WXA_ERR_NOMEM;
+    }
+    *n_added = (int64_t)h;
     return WXA_OK;
 }
 
