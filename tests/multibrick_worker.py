@@ -29,7 +29,7 @@ def main():
     nb = tuple(int(v) for v in sys.argv[1:4])
     order, filt, out = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     overlap = int(sys.argv[7]) if len(sys.argv) > 7 else 0
-    steps = 6
+    steps = int(os.environ.get("WXA_TEST_STEPS", "6"))
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     assert world == nb[0] * nb[1] * nb[2]
