@@ -430,13 +430,24 @@ typedef struct wxa_plasma_injector {
 
 /* PhysicalParticleContainer::AddPlasma on the device for that injector: the particles of the `ncells` cells
  * whose low corner is `corner` (InjectorPositionRegular lattice, weight = density dV / ppc, momentum
- * u c with u constant -- NULL = at rest) that lie inside the injector's bounds and strictly inside the
+ * (u_mean + u_th N(0,1)) c per component -- NULL = at rest; the normal draws are a counter-based stream
+ * (Philox4x32-10 keyed by `seed`, counter = the particle's integer coordinates on the global lattice of
+ * injection points, Box-Muller), so a particle gets the same momentum whatever the brick layout; the reference draws from AMReX's
+ * generator, which no other program reproduces) that lie inside the injector's bounds and strictly inside the
  * brick [brick_lo, brick_hi], written into the free slots `dst` (dst->np = room available; idcpu = 0).
  * *n_added (host) is valid on return (synchronises); the order of the new particles is not specified
  * (the cell sort that follows an injection fixes it).  WXA_ERR_NOMEM if dst is too small. */
+typedef struct wxa_injected_momentum {
+    double   u_mean[3];   /* ux_m, uy_m, uz_m (gamma beta; also the value of momentum_distribution_type = constant) */
+    double   u_th[3];     /* ux_th, uy_th, uz_th of momentum_distribution_type = gaussian; 0 = no spread        */
+    uint64_t seed;        /* stream of the gaussian draws (warpx.random_seed mixed with the species index)     */
+    double   origin[3];   /* a corner of the cell lattice that never changes (geometry.prob_lo at t = 0): the
+                             draws are numbered by the particle's lattice coordinates relative to it          */
+} wxa_injected_momentum;
 wxa_status wxa_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj,
                           const double corner[3], const int32_t ncells[3], const double dx[3],
-                          const double brick_lo[3], const double brick_hi[3], const double u[3],
+                          const double brick_lo[3], const double brick_hi[3],
+                          const wxa_injected_momentum* momentum,
                           int64_t* n_added, wxa_workspace* ws, void* stream);
 
 /* lasers.names / <laser>.profile = Gaussian (Source/Particles/LaserParticleContainer.cpp,

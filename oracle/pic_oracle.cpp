@@ -636,9 +636,31 @@ int orc_shift_field_window(const wxa_field_view* f, double* tmp, int32_t dir, in
 
 // PhysicalParticleContainer::AddPlasma (:924-1333) for the cells [0, ncells) above `corner`, NUniformPerCell with a
 // constant density, momentum u c (NULL = at rest): the counterpart of wxa_add_plasma, in lattice order
+namespace {
+// Philox4x32-10 + Box-Muller: the stream include/warpx_amd.h specifies for the injected gaussian momenta
+void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+double uniform53(uint32_t hi, uint32_t lo) { return ((double)((((uint64_t)hi << 32) | lo) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+void normal3(uint64_t seed, int sx, int sy, int sz, double n[3]) {
+    uint32_t a[4] = {(uint32_t)sx, (uint32_t)sy, (uint32_t)sz, 0u}, b[4] = {(uint32_t)sx, (uint32_t)sy, (uint32_t)sz, 1u};
+    philox4x32_10(a, (uint32_t)seed, (uint32_t)(seed >> 32));
+    philox4x32_10(b, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double r0 = std::sqrt(-2.0 * std::log(uniform53(a[0], a[1]))), t0 = 2.0 * M_PI * uniform53(a[2], a[3]);
+    const double r1 = std::sqrt(-2.0 * std::log(uniform53(b[0], b[1]))), t1 = 2.0 * M_PI * uniform53(b[2], b[3]);
+    n[0] = r0 * std::cos(t0); n[1] = r0 * std::sin(t0); n[2] = r1 * std::cos(t1);
+}
+}  // namespace
+
 int orc_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj, const double corner[3],
                    const int32_t ncells[3], const double dx[3], const double brick_lo[3], const double brick_hi[3],
-                   const double u[3], int64_t* n_added, void*, void*) {
+                   const wxa_injected_momentum* mom, int64_t* n_added, void*, void*) {
+    const bool thermal = mom && (mom->u_th[0] != 0.0 || mom->u_th[1] != 0.0 || mom->u_th[2] != 0.0);
     *n_added = 0;
     if (!(inj->density > 0)) return 0;
     const int nppc = inj->ppc[0] * inj->ppc[1] * inj->ppc[2];
@@ -672,9 +694,15 @@ int orc_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj,
                     if (!ok) continue;
                     if (n >= dst->np) return -4;
                     dst->x[n] = pos[0]; dst->y[n] = pos[1]; dst->z[n] = pos[2]; dst->w[n] = weight;
-                    dst->ux[n] = u ? u[0] * PhysConst::c : 0.0;
-                    dst->uy[n] = u ? u[1] * PhysConst::c : 0.0;
-                    dst->uz[n] = u ? u[2] * PhysConst::c : 0.0;
+                    double u[3] = {mom ? mom->u_mean[0] : 0.0, mom ? mom->u_mean[1] : 0.0, mom ? mom->u_mean[2] : 0.0};
+                    if (thermal) {
+                        double nrm[3];
+                        normal3(mom->seed, (int)std::floor((pos[0] - mom->origin[0]) / dx[0] * inj->ppc[0]),
+                                (int)std::floor((pos[1] - mom->origin[1]) / dx[1] * inj->ppc[1]),
+                                (int)std::floor((pos[2] - mom->origin[2]) / dx[2] * inj->ppc[2]), nrm);
+                        for (int d = 0; d < 3; ++d) u[d] += mom->u_th[d] * nrm[d];
+                    }
+                    dst->ux[n] = u[0] * PhysConst::c; dst->uy[n] = u[1] * PhysConst::c; dst->uz[n] = u[2] * PhysConst::c;
                     if (dst->idcpu) dst->idcpu[n] = 0;
                     ++n;
                 }

@@ -40,7 +40,7 @@ int orc_apply_pec_b(const wxa_field_view*, const int32_t*, const int32_t*, const
                     void*);
 int orc_evolve_b_guard_layer(const wxa_field_view*, const wxa_field_view*, double, const double*, const int32_t*, void*);
 int orc_add_plasma(const wxa_particle_view*, const wxa_plasma_injector*, const double*, const int32_t*, const double*,
-                   const double*, const double*, const double*, int64_t*, void*, void*);
+                   const double*, const double*, const wxa_injected_momentum*, int64_t*, void*, void*);
 int orc_apply_pec_j(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
 int orc_apply_pec_rho(const wxa_field_view*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, void*);
 int orc_deposit_charge(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, int, void*);

@@ -72,7 +72,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     pairs = [("wxa_sim_config", _capi.SimConfig), ("wxa_field_view", _capi.FieldView),
              ("wxa_particle_view", _capi.ParticleView), ("wxa_grid_geom", _capi.GridGeom),
              ("wxa_moving_window", _capi.MovingWindow), ("wxa_plasma_injector", _capi.PlasmaInjector),
-             ("wxa_laser_antenna", _capi.LaserAntenna), ("wxa_laser_push_params", _capi.LaserPushParams),
+             ("wxa_laser_antenna", _capi.LaserAntenna), ("wxa_injected_momentum", _capi.InjectedMomentum), ("wxa_laser_push_params", _capi.LaserPushParams),
              ("wxa_comm", _capi.Comm)]
     lines = ['#include "warpx_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, cls in pairs:

@@ -708,11 +708,13 @@ def test_gather_push_in_two_parts(product, order, pusher):
 
 
 @UNVERIFIED
-@pytest.mark.parametrize("ppc,u", [((1, 1, 1), None), ((2, 1, 3), (0.1, -0.2, 0.0))])
-def test_add_plasma(oracle, product, ppc, u):
+@pytest.mark.parametrize("ppc,u,uth", [((1, 1, 1), None, None), ((2, 1, 3), (0.1, -0.2, 0.0), None),
+                                       ((2, 2, 2), (0.0, 0.0, 0.3), (0.01, 0.02, 0.03))])
+def test_add_plasma(oracle, product, ppc, u, uth):
     """wxa_add_plasma (PhysicalParticleContainer::AddPlasma on the device): injector bounds cutting through cells,
-    a brick smaller than the cell box, at rest and with a constant momentum: the same particles as the CPU
-    restatement, bit for bit (as a set: the device does not promise an order)."""
+    a brick smaller than the cell box; at rest and with a constant momentum the same particles as the CPU
+    restatement bit for bit (as a set: the device does not promise an order), with gaussian momenta the same
+    draws to 1e-13 of the spread (device log / sin / cos differ from libm by ulps) and unit variance."""
     inj = _capi.PlasmaInjector()
     inj.density = 2e23
     for d in range(3):
@@ -724,19 +726,35 @@ def test_add_plasma(oracle, product, ppc, u):
     corner, ncells = (-4e-6, -2e-6, 0.0), (16, 10, 12)
     brick_lo, brick_hi = (-4e-6, -2e-6, 0.0), (1.5e-6, 2e-6, 3e-6)
     room = 16 * 10 * 12 * ppc[0] * ppc[1] * ppc[2]
-    uarr = (C.c_double * 3)(*u) if u else None
+    mom = None
+    if u is not None:
+        mom = _capi.InjectedMomentum()
+        for d in range(3):
+            mom.u_mean[d] = u[d]
+            mom.u_th[d] = uth[d] if uth else 0.0
+        mom.seed = 12345
+        for d in range(3):
+            mom.origin[d] = corner[d]
+    pmom = C.byref(mom) if mom is not None else None
     pc, pd = ParticleArrays(room, "cpu", with_id=True), ParticleArrays(room, DEV, with_id=True)
     nc, nd = C.c_int64(), C.c_int64()
     ws = C.c_void_p()
     product.workspace_create(C.byref(ws))
-    args = (C.byref(inj), H.d3(corner), (C.c_int32 * 3)(*ncells), H.d3(dx), H.d3(brick_lo), H.d3(brick_hi), uarr)
+    args = (C.byref(inj), H.d3(corner), (C.c_int32 * 3)(*ncells), H.d3(dx), H.d3(brick_lo), H.d3(brick_hi), pmom)
     oracle.add_plasma(C.byref(pc.view), *args, C.byref(nc), None, None)
     product.add_plasma(C.byref(pd.view), *args, C.byref(nd), ws, None)
     _sync(product)
     assert nc.value == nd.value and 0 < nc.value < room
     a, b = pd.to_numpy()[:, :nd.value], pc.to_numpy()[:, :nc.value]
-    ka, kb = np.lexsort(a[:3]), np.lexsort(b[:3])
-    assert np.array_equal(a[:, ka], b[:, kb])
+    a, b = a[:, np.lexsort(a[:3])], b[:, np.lexsort(b[:3])]
+    assert np.array_equal(a[:4], b[:4])
+    if uth is None:
+        assert np.array_equal(a, b)
+    else:
+        for d in range(3):
+            assert np.max(np.abs(a[4 + d] - b[4 + d])) <= 1e-13 * uth[d] * plasma.C_LIGHT * 8
+            z = (b[4 + d] / plasma.C_LIGHT - u[d]) / uth[d]
+            assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05
     small = ParticleArrays(nc.value - 1, DEV, with_id=True)        # too little room is an error, not an overrun
     with pytest.raises(_capi.WxaError):
         product.add_plasma(C.byref(small.view), *args, C.byref(nd), ws, None)

@@ -75,3 +75,25 @@ def test_overlapped_halo_exchange_is_the_same_arithmetic(nb, order, port, tmp_pa
     assert over["np_total"] == plain["np_total"] and over["exchanges"] == plain["exchanges"]
     for name, err in over["errors"].items():
         assert err < 1e-10, (name, err)
+
+
+def test_random_momenta_do_not_depend_on_the_brick_layout(tmp_path):
+    """Gaussian momenta come from a counter-based stream keyed by the particle's position: the headline deck (in
+    small) starts from the same particles on 1 brick and on 4 -- the sums of |m u| agree to round-off."""
+    from tests.oracle_lib import load_host_cpu
+    from warpx_amd.sim import WarpXSim
+    deck = tmp_path / "small.inputs"
+    deck.write_text(f"FILE = {os.path.join(ROOT, 'tests', 'decks', 'uniform_plasma_3d.inputs')}\n"
+                    "amr.n_cell = 16 16 16\nmax_step = 0\n")
+    one = WarpXSim.from_inputs(load_host_cpu(), str(deck))
+    want = one.checksum()["electrons"]
+    one.close()
+    out = str(tmp_path / "sum.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+           "--master-addr", "127.0.0.1", "--master-port", "29627", os.path.join(ROOT, "tests", "deck_worker.py"),
+           "0", "0", "0", str(deck), out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = json.load(open(out))["electrons"]
+    for key, val in want.items():
+        assert abs(got[key] - val) <= 1e-13 * abs(val), key

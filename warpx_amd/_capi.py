@@ -78,6 +78,10 @@ class PlasmaInjector(C.Structure):
     _fields_ = [("density", C.c_double), ("ppc", C.c_int32 * 3), ("lo", C.c_double * 3), ("hi", C.c_double * 3)]
 
 
+class InjectedMomentum(C.Structure):
+    _fields_ = [("u_mean", C.c_double * 3), ("u_th", C.c_double * 3), ("seed", C.c_uint64), ("origin", C.c_double * 3)]
+
+
 class LaserAntenna(C.Structure):
     _fields_ = [("position", C.c_double * 3), ("direction", C.c_double * 3), ("polarization", C.c_double * 3),
                 ("e_max", C.c_double), ("wavelength", C.c_double), ("waist", C.c_double), ("duration", C.c_double),
@@ -193,8 +197,8 @@ _PRODUCT_SIGS = {
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "gather_push_ws": (C.c_int, [_PPV, _FV3, _FV3, _PGG, C.c_double, C.c_double, C.c_double,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "add_plasma": (C.c_int, [_PPV, C.POINTER(PlasmaInjector), _D3, _I32_3, _D3, _D3, _D3, C.c_void_p,
-                             C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "add_plasma": (C.c_int, [_PPV, C.POINTER(PlasmaInjector), _D3, _I32_3, _D3, _D3, _D3,
+                             C.POINTER(InjectedMomentum), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "gather_push_part": (C.c_int, [_PPV, _FV3, _FV3, _PGG, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "partition_particles": (C.c_int, [_PPV, _PPV, C.c_int, C.c_double, C.c_double,
@@ -221,8 +225,8 @@ _ORACLE_SIGS = {
     "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
 
     "num_threads": (C.c_int, []),
-    "add_plasma": (C.c_int, [_PPV, C.POINTER(PlasmaInjector), _D3, _I32_3, _D3, _D3, _D3, C.c_void_p,
-                             C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "add_plasma": (C.c_int, [_PPV, C.POINTER(PlasmaInjector), _D3, _I32_3, _D3, _D3, _D3,
+                             C.POINTER(InjectedMomentum), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     # CPU counterparts of the Redistribute entry points (host-layer tests, parity tests)
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "wrap_and_classify": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,

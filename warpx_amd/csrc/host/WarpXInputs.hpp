@@ -499,7 +499,8 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                 pp.queryWithParser(name + ".ux", u[0]);
                 pp.queryWithParser(name + ".uy", u[1]);
                 pp.queryWithParser(name + ".uz", u[2]);
-                pc->SetConstantMomentum(u[0], u[1], u[2]);
+                const double none[3] = {0.0, 0.0, 0.0};
+                pc->SetGaussianMomentum(u, none, 0);
             } else if (mom == "parsemomentumfunction") {
                 Parser f[3];
                 for (int d = 0; d < 3; ++d) {
@@ -514,9 +515,9 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                 });
             } else if (mom == "gaussian") {
                 // InjectorMomentumGaussian: u = u_m + u_th N(0,1) per component.  The reference draws from
-                // AMReX's generator, which no other program reproduces; this stream is std::mt19937_64 seeded
-                // from warpx.random_seed (default 1), the species index and the brick, so a run is repeatable
-                // and statistically the same plasma.
+                // AMReX's generator, which no other program reproduces; here a counter-based stream keyed by
+                // warpx.random_seed (default 1) and the species index gives every lattice point its draws, so a
+                // run is repeatable, the same on any brick layout, and statistically the same plasma.
                 double um[3] = {0.0, 0.0, 0.0}, uth[3] = {0.0, 0.0, 0.0};
                 const char* mk[3] = {".ux_m", ".uy_m", ".uz_m"};
                 const char* tk[3] = {".ux_th", ".uy_th", ".uz_th"};
@@ -525,12 +526,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                 pp.query("warpx.random_seed", seed_word);
                 const uint64_t seed = seed_word == "default" ? 1u : (seed_word == "random" ? (uint64_t)std::random_device{}()
                                                                                             : (uint64_t)pp.evaluate(seed_word));
-                const uint64_t brick = (uint64_t)cfg.coord[0] + 1024u * ((uint64_t)cfg.coord[1] + 1024u * (uint64_t)cfg.coord[2]);
-                auto rng = std::make_shared<std::mt19937_64>(seed * 0x9E3779B97F4A7C15ull + 1000003ull * (uint64_t)sid + brick);
-                auto normal = std::make_shared<std::normal_distribution<double>>(0.0, 1.0);
-                pc->SetMomentumFunction([=](double, double, double, double* out) {
-                    for (int d = 0; d < 3; ++d) out[d] = um[d] + uth[d] * (*normal)(*rng);
-                });
+                pc->SetGaussianMomentum(um, uth, seed * 0x9E3779B97F4A7C15ull + 1000003ull * (uint64_t)sid);
             } else if (mom != "atrest") {
                 throw std::runtime_error("inputs: " + name + ".momentum_distribution_type = " + mom +
                                          " is not on this path (at_rest, constant, gaussian, parse_momentum_function)");

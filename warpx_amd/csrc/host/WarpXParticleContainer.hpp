@@ -398,7 +398,7 @@ public:
             nov[d] = (int)std::round((ohi[d] - olo[d]) / dx);
         }
         const int nppc = in.ppc[0] * in.ppc[1] * in.ppc[2];
-        if (m_ctx->be->add_plasma && (!m_momentum || m_momentum_is_constant)) {
+        if (m_ctx->be->add_plasma && (!m_momentum || m_momentum_on_device)) {
             // on the device: no host arrays, no copy (a plane of a moving window at 256^2 x 8 ppc is 30 MB)
             const int64_t room = (int64_t)nov[0] * nov[1] * nov[2] * nppc;
             if (room == 0) return;
@@ -408,7 +408,7 @@ public:
             const int32_t nc[3] = {nov[0], nov[1], nov[2]};
             int64_t added = 0;
             check(m_ctx->be->add_plasma(&dst, &in, olo, nc, m_ctx->dx.data(), m_ctx->brick_plo.data(), m_ctx->brick_phi.data(),
-                                        m_momentum_is_constant ? m_constant_u : nullptr, &added, m_ws, m_ctx->stream),
+                                        m_momentum_on_device ? &m_device_momentum : nullptr, &added, m_ws, m_ctx->stream),
                   "add_plasma");
             m_tile.resize(n0 + added);
             return;
@@ -464,14 +464,20 @@ public:
 
     // <species>.momentum_distribution_type = constant | parse_momentum_function: u (in units of c) at a position
     // (InjectorMomentumConstant / InjectorMomentumParser, Source/Initialization/InjectorMomentum.H)
-    void SetMomentumFunction(std::function<void(double, double, double, double*)> f) {
+    void SetMomentumFunction(std::function<void(double, double, double, double*)> f) {   // evaluated on the host
         m_momentum = std::move(f);
-        m_momentum_is_constant = false;
+        m_momentum_on_device = false;
     }
-    void SetConstantMomentum(double ux, double uy, double uz) {   // InjectorMomentumConstant
-        m_constant_u[0] = ux; m_constant_u[1] = uy; m_constant_u[2] = uz;
-        m_momentum = [ux, uy, uz](double, double, double, double* out) { out[0] = ux; out[1] = uy; out[2] = uz; };
-        m_momentum_is_constant = true;
+    // InjectorMomentumConstant (u_th = 0) / InjectorMomentumGaussian: drawn on the device (wxa_add_plasma)
+    void SetGaussianMomentum(const double u_mean[3], const double u_th[3], uint64_t seed) {
+        for (int d = 0; d < 3; ++d) {
+            m_device_momentum.u_mean[d] = u_mean[d];
+            m_device_momentum.u_th[d] = u_th[d];
+            m_device_momentum.origin[d] = m_ctx->prob_lo[d];   // the lattice of this moment; a moving window shifts by whole cells
+        }
+        m_device_momentum.seed = seed;
+        m_momentum = [](double, double, double, double*) { throw std::runtime_error("AddPlasma: no backend entry for the injection"); };
+        m_momentum_on_device = true;
     }
 
 private:
@@ -479,8 +485,8 @@ private:
     bool m_has_injector = false, m_do_continuous_injection = false;
     std::function<void(double, double, double, double*)> m_momentum;
     bool m_interior_pushed = false;
-    bool m_momentum_is_constant = false;
-    double m_constant_u[3] = {0.0, 0.0, 0.0};
+    bool m_momentum_on_device = false;
+    wxa_injected_momentum m_device_momentum{};
 
 public:
 

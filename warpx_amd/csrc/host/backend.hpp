@@ -34,9 +34,10 @@ struct Backend {
                             const wxa_grid_geom*, double, double, double, int, int, int, void* ws, int part, void*);
     int (*deposit_current)(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double,
                            double, double, int, int, void* ws, void*);
-    // PhysicalParticleContainer::AddPlasma on the device (constant density, at rest or constant momentum)
+    // PhysicalParticleContainer::AddPlasma on the device (constant density; at rest, constant or gaussian momentum)
     int (*add_plasma)(const wxa_particle_view* dst, const wxa_plasma_injector*, const double* corner, const int32_t* ncells,
-                      const double* dx, const double* brick_lo, const double* brick_hi, const double* u, int64_t* n_added,
+                      const double* dx, const double* brick_lo, const double* brick_hi, const wxa_injected_momentum* momentum,
+                      int64_t* n_added,
                       void* ws, void*);
     // diagnostics: doChargeDepositionShapeN
     int (*deposit_charge)(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, int, void*);

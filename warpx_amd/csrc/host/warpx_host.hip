@@ -83,8 +83,8 @@ const Backend* hip_backend() {
                                 int part, void* st) -> int {
             return wxa_gather_push_part(p, E, B, g, q, m, dt, o, ga, pu, static_cast<wxa_workspace*>(ws), part, st); };
         b.add_plasma = [](const wxa_particle_view* dst, const wxa_plasma_injector* inj, const double* corner,
-                          const int32_t* nc, const double* dx, const double* blo, const double* bhi, const double* u,
-                          int64_t* n, void* ws, void* st) -> int {
+                          const int32_t* nc, const double* dx, const double* blo, const double* bhi,
+                          const wxa_injected_momentum* u, int64_t* n, void* ws, void* st) -> int {
             return wxa_add_plasma(dst, inj, corner, nc, dx, blo, bhi, u, n, static_cast<wxa_workspace*>(ws), st); };
         b.deposit_current = k_deposit;
         b.filter_bilinear = [](const wxa_field_view* s, const wxa_field_view* d, void* st) -> int {

@@ -255,10 +255,35 @@ laser_push_kernel(PV p, LaserPushGeom lg, double dt) {
 
 // ---- plasma injection: PhysicalParticleContainer::AddPlasma (PhysicalParticleContainer.cpp:924-1333) ---------
 struct InjectGeom {
-    double corner[3], dx[3], blo[3], bhi[3], lo[3], hi[3], u[3];
+    double corner[3], dx[3], blo[3], bhi[3], lo[3], hi[3], u[3], uth[3], origin[3];
     int nc[3], ppc[3];
     double weight;
+    unsigned long long seed;
+    int thermal;
 };
+
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a particle's draws depend on its position only
+__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ double uniform53(unsigned hi, unsigned lo) {   // (0, 1)
+    return ((double)((((unsigned long long)hi << 32) | lo) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+// three standard normal draws for the injection point with the global lattice coordinates (sx, sy, sz)
+__device__ __forceinline__ void normal3(unsigned long long seed, int sx, int sy, int sz, double n[3]) {
+    unsigned a[4] = {(unsigned)sx, (unsigned)sy, (unsigned)sz, 0u}, b[4] = {(unsigned)sx, (unsigned)sy, (unsigned)sz, 1u};
+    philox4x32_10(a, (unsigned)seed, (unsigned)(seed >> 32));
+    philox4x32_10(b, (unsigned)seed, (unsigned)(seed >> 32));
+    const double r0 = sqrt(-2.0 * log(uniform53(a[0], a[1]))), t0 = 2.0 * M_PI * uniform53(a[2], a[3]);
+    const double r1 = sqrt(-2.0 * log(uniform53(b[0], b[1]))), t1 = 2.0 * M_PI * uniform53(b[2], b[3]);
+    n[0] = r0 * cos(t0); n[1] = r0 * sin(t0); n[2] = r1 * cos(t1);
+}
 
 // one thread per lattice point; accepted points take consecutive slots (one atomic per wave)
 __global__ void __launch_bounds__(256)
@@ -302,7 +327,16 @@ add_plasma_kernel(PV dst, InjectGeom ig, long npoints, unsigned long long* __res
     if (slot >= dst.np) return;   // the host sees count > room and reports it
     dst.x[slot] = pos[0]; dst.y[slot] = pos[1]; dst.z[slot] = pos[2];
     dst.w[slot] = ig.weight;
-    dst.ux[slot] = ig.u[0]; dst.uy[slot] = ig.u[1]; dst.uz[slot] = ig.u[2];
+    double u[3] = {ig.u[0], ig.u[1], ig.u[2]};
+    if (ig.thermal) {
+        double n[3];
+        // lattice coordinate = cell * ppc + sub-point: (pos - origin) / dx * ppc = integer + 1/2, robust to round-off
+        normal3(ig.seed, (int)floor((pos[0] - ig.origin[0]) / ig.dx[0] * ig.ppc[0]),
+                (int)floor((pos[1] - ig.origin[1]) / ig.dx[1] * ig.ppc[1]),
+                (int)floor((pos[2] - ig.origin[2]) / ig.dx[2] * ig.ppc[2]), n);
+        u[0] += ig.uth[0] * n[0]; u[1] += ig.uth[1] * n[1]; u[2] += ig.uth[2] * n[2];
+    }
+    dst.ux[slot] = u[0] * PhysConst::c; dst.uy[slot] = u[1] * PhysConst::c; dst.uz[slot] = u[2] * PhysConst::c;
     if (dst.id) dst.id[slot] = 0;
 }
 
@@ -723,8 +757,8 @@ wxa_status wxa_pack_leavers(const wxa_particle_view* p, const int32_t* list, int
 
 wxa_status wxa_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj, const double corner[3],
                           const int32_t ncells[3], const double dx[3], const double brick_lo[3],
-                          const double brick_hi[3], const double u[3], int64_t* n_added, wxa_workspace* ws,
-                          void* stream) {
+                          const double brick_hi[3], const wxa_injected_momentum* mom, int64_t* n_added,
+                          wxa_workspace* ws, void* stream) {
     WXA_REQUIRE(dst && inj && corner && ncells && dx && brick_lo && brick_hi && n_added && ws, "null argument");
     WXA_REQUIRE(dst->np >= 0 && (dst->np == 0 || (dst->x && dst->y && dst->z && dst->w && dst->ux && dst->uy && dst->uz)),
                 "bad particle view");
@@ -736,9 +770,13 @@ wxa_status wxa_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injecto
         WXA_REQUIRE(ncells[d] >= 0 && dx[d] > 0, "bad cell box");
         ig.corner[d] = corner[d]; ig.dx[d] = dx[d]; ig.blo[d] = brick_lo[d]; ig.bhi[d] = brick_hi[d];
         ig.lo[d] = inj->lo[d]; ig.hi[d] = inj->hi[d]; ig.nc[d] = ncells[d]; ig.ppc[d] = inj->ppc[d];
-        ig.u[d] = u ? u[d] * PhysConst::c : 0.0;
+        ig.u[d] = mom ? mom->u_mean[d] : 0.0;
+        ig.uth[d] = mom ? mom->u_th[d] : 0.0;
+        ig.origin[d] = mom ? mom->origin[d] : 0.0;
         npoints *= ncells[d];
     }
+    ig.seed = mom ? mom->seed : 0;
+    ig.thermal = mom && (mom->u_th[0] != 0.0 || mom->u_th[1] != 0.0 || mom->u_th[2] != 0.0);
     if (npoints == 0 || !(inj->density > 0)) return WXA_OK;
     ig.weight = inj->density * (dx[0] * dx[1] * dx[2] / (inj->ppc[0] * inj->ppc[1] * inj->ppc[2]));   // compute_scale_fac_volume
     hipStream_t st = (hipStream_t)stream;
