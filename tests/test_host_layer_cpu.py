@@ -20,13 +20,19 @@ def _species(n_cell, ppc=(1, 1, 2), seed=3):
     return plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, ppc, 1e25, 0.05, seed=seed)
 
 
-@pytest.mark.parametrize("order,filt,sort", [(1, 1, -1), (3, 1, 2), (2, 0, 1)])
-def test_single_brick_schedule_matches_oracle(oracle, host_cpu, order, filt, sort):
+@pytest.mark.parametrize("order,filt,sort,pusher,depos", [
+    (1, 1, -1, _capi.PUSHER_BORIS, _capi.DEPOSIT_ESIRKEPOV), (3, 1, 2, _capi.PUSHER_BORIS, _capi.DEPOSIT_ESIRKEPOV),
+    (2, 0, 1, _capi.PUSHER_BORIS, _capi.DEPOSIT_ESIRKEPOV), (3, 1, 3, _capi.PUSHER_VAY, _capi.DEPOSIT_DIRECT),
+    (1, 0, 4, _capi.PUSHER_VAY, _capi.DEPOSIT_ESIRKEPOV), (2, 1, -1, _capi.PUSHER_BORIS, _capi.DEPOSIT_DIRECT)])
+def test_single_brick_schedule_matches_oracle(oracle, host_cpu, order, filt, sort, pusher, depos):
+    """The product's schedule (no exchange inside the field solve: guard layer of B computed, solver-depth fill of E
+    dropped) against the oracle stepper, which keeps the reference's five fills."""
     n_cell = (16, 12, 12)
     parts = _species(n_cell)
     res = []
     for lib in (host_cpu, oracle):
-        sim = WarpXSim(lib, n_cell, (-L / 2,) * 3, (L / 2,) * 3, nox=order, use_filter=filt, sort_interval=sort)
+        sim = WarpXSim(lib, n_cell, (-L / 2,) * 3, (L / 2,) * 3, nox=order, use_filter=filt, sort_interval=sort,
+                       particle_pusher=pusher, current_deposition=depos)
         sid = sim.add_species(-plasma.Q_E, plasma.M_E, parts)
         sim.evolve(3)
         sim.evolve(2)   # a second Evolve call: de-synchronise again, same schedule as the reference
