@@ -24,6 +24,9 @@ def product():
     """The HIP library; GPU tests fail loudly if it is missing or no GPU is visible."""
     import torch
     from warpx_amd import load_product
+    if os.environ.get("WXA_HIP_ON_CPU") == "1":   # logic check without a GPU, see tests/hipcpu
+        from tests.oracle_lib import load_hip_on_cpu
+        return load_hip_on_cpu()
     lib = load_product()
     assert torch.cuda.is_available(), "gpu-marked test without a visible GPU"
     return lib

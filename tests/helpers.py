@@ -1,6 +1,7 @@
 """Shared builders for the parity tests: identical seeded inputs for the CPU oracle
 (host arrays) and the HIP library (device arrays)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -8,6 +9,19 @@ from warpx_amd import _capi, plasma
 from warpx_amd.containers import STAG, FieldArray, ParticleArrays, field_triplet, grid_geom
 
 LX = 40e-6
+
+# WXA_HIP_ON_CPU=1: the `-m gpu` tests run the product's .hip sources on the HIP-on-CPU execution model of
+# tests/hipcpu (a logic check for a container without a GPU); "device" buffers are then host buffers.
+HIP_ON_CPU = os.environ.get("WXA_HIP_ON_CPU") == "1"
+ON_GPU = not HIP_ON_CPU
+DEVICE = "cuda" if ON_GPU else "cpu:0"   # "cpu:0": torch tensors in host memory (the containers keep "cpu" for numpy)
+
+
+def device_sync():
+    if ON_GPU:
+        import torch
+        torch.cuda.synchronize()
+
 
 
 def guard_depths(order, use_filter=False):

@@ -44,3 +44,18 @@ def load_host_cpu():
         subprocess.check_call(["make", "-C", HOST_CPU_DIR, "libhost_cpu.so"], stdout=subprocess.DEVNULL)
         _host_cpu = _capi.CLib(HOST_CPU_LIB, "hst_", _capi._INPUTS_SIGS, kernels=False)
     return _host_cpu
+
+
+HIPCPU_DIR = os.path.join(ROOT, "tests", "hipcpu")
+HIPCPU_LIB = os.path.join(HIPCPU_DIR, "libwarpx_amd_hipcpu.so")
+_hip_on_cpu = None
+
+
+def load_hip_on_cpu():
+    """The product's .hip sources, unmodified, compiled against the HIP-on-CPU execution model of
+    tests/hipcpu (tests only; a logic check of the kernels and launches where there is no GPU)."""
+    global _hip_on_cpu
+    if _hip_on_cpu is None:
+        subprocess.check_call(["make", "-C", HIPCPU_DIR, "-j8", "libwarpx_amd_hipcpu.so"], stdout=subprocess.DEVNULL)
+        _hip_on_cpu = _capi.CLib(HIPCPU_LIB, "wxa_", {**_capi._PRODUCT_SIGS, **_capi._INPUTS_SIGS}, memory="cpu:0")
+    return _hip_on_cpu

@@ -10,6 +10,7 @@ import threading
 import numpy as np
 import pytest
 
+from tests import helpers as H
 from warpx_amd import _capi, plasma
 from warpx_amd.distributed import _as_tensor, brick_coord
 from warpx_amd.sim import WarpXSim, particle_moments
@@ -45,19 +46,19 @@ class ThreadBrickTransport:
     def _exchange(self, ctx, nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf, recv_bytes, stream):
         try:
             import torch
-            torch.cuda.synchronize()
+            H.device_sync()
             box = self.shared["box"]
             for i in range(nmsg):
                 n = int(send_bytes[i])
-                box[(self.rank, int(send_peer[i]), i)] = _as_tensor(send_buf[i], n, True).clone() if n else None
+                box[(self.rank, int(send_peer[i]), i)] = _as_tensor(send_buf[i], n, H.ON_GPU).clone() if n else None
             self._wait()
             for i in range(nmsg):
                 n = int(recv_bytes[i])
                 t = box[(int(recv_peer[i]), self.rank, i)]
                 assert (t.numel() if t is not None else 0) == n
                 if n:
-                    _as_tensor(recv_buf[i], n, True).copy_(t)
-            torch.cuda.synchronize()
+                    _as_tensor(recv_buf[i], n, H.ON_GPU).copy_(t)
+            H.device_sync()
             self._wait()
             self.n_exchanges += 1
             return 0

@@ -100,6 +100,7 @@ def test_langmuir_golden_on_gpu(oracle, product):
     assert np.max(np.abs(exc - Eth[0])) / np.max(np.abs(Eth[0])) < 5e-2
 
 
+@pytest.mark.skipif(os.environ.get("WXA_HIP_ON_CPU") == "1", reason="full size: needs the GPU")
 def test_langmuir_256_two_species_full_size(product):
     """BASELINE.json config 3 at full size (256^3, e-/e+, 8 ppc, Esirkepov, order 3, 40 steps) through
     size-independent properties -- the CPU oracle cannot run 2.7e8 particles in test time:

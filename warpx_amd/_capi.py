@@ -247,7 +247,10 @@ _RETURNS_A_VALUE = {"sim_max_step", "sim_num_species", "num_threads", "sim_halo_
 class CLib:
     """A loaded C library whose symbols `<prefix><name>` follow include/warpx_amd.h."""
 
-    def __init__(self, path: str, prefix: str, extra_sigs: dict | None = None, kernels: bool = True):
+    def __init__(self, path: str, prefix: str, extra_sigs: dict | None = None, kernels: bool = True,
+                 memory: str | None = None):
+        # where the library expects the buffers it is handed: device memory for the product
+        self.memory = memory or ("cuda" if prefix == "wxa_" else "cpu")
         if not os.path.exists(path):
             raise WxaError(
                 f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()')")

@@ -163,7 +163,7 @@ class ParticleArrays:
     def to_numpy(self) -> np.ndarray:
         if self.device == "cpu":
             return self.data.copy()
-        return self.data.cpu().numpy()
+        return np.array(self.data.cpu().numpy())   # an owned copy wherever the tensor lives
 
     def copy_to(self, device):
         ids = None

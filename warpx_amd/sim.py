@@ -106,7 +106,7 @@ class WarpXSim:
         """`particles`: ParticleArrays living where the library expects them
         (device for the product, host for the oracle) or a list of 7 numpy arrays."""
         if not isinstance(particles, ParticleArrays):
-            particles = ParticleArrays.from_numpy(particles, "cuda" if self.on_device else "cpu")
+            particles = ParticleArrays.from_numpy(particles, self.lib.memory)
         sid = C.c_int32(-1)
         v = particles.view
         self.lib.sim_add_species(self._h, float(charge), float(mass), C.byref(v), C.byref(sid))
