@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from warpx_amd import _capi, plasma
+from warpx_amd.containers import FieldArray
 from warpx_amd.sim import WarpXSim, field_energy, particle_moments
 
 pytestmark = pytest.mark.gpu
