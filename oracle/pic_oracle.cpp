@@ -945,7 +945,13 @@ int orc_wrap_and_classify(const wxa_particle_view* p, int64_t first, int64_t cou
         int code = -1;
         for (int d = 0; d < 3 && code < 0; ++d)
             if (split[d]) code = pos[d][ip] < brick_lo[d] ? 2 * d : (pos[d][ip] >= brick_hi[d] ? 2 * d + 1 : -1);
-        if (code >= 0 && p->idcpu[ip] == WXA_IDCPU_RETIRED) code = -1;
+        if (code >= 0 && p->idcpu[ip] == WXA_IDCPU_RETIRED) {
+            // parked again on the brick's side of the faces (mirror of wrap_classify_kernel)
+            code = -1;
+            for (int d = 0; d < 3; ++d)
+                if (split[d])
+                    pos[d][ip] = std::min(std::max(pos[d][ip], brick_lo[d]), std::nextafter(brick_hi[d], brick_lo[d]));
+        }
         if (code >= 0) {
             if (counts[code] < capacity) lists[code * capacity + counts[code]] = (int32_t)ip;
             counts[code]++;

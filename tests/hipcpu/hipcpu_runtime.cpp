@@ -162,6 +162,10 @@ const uint64_t* wave_exchange(int kind, uint64_t v, uint64_t* mask, int* lane) {
 
 void run_grid(dim3 grid, dim3 block, void (*entry)(void*), void* closure, const char* name) {
     std::lock_guard<std::recursive_mutex> lock(g_launch_lock);
+    static const bool trace = std::getenv("HIPCPU_TRACE") != nullptr;   // the last line names a crashing kernel
+    if (trace)
+        std::fprintf(stderr, "[hipcpu] %s grid (%u,%u,%u) block (%u,%u,%u)\n", name, grid.x, grid.y, grid.z, block.x,
+                     block.y, block.z);
     const long n = (long)block.x * block.y * block.z;
     if (n <= 0 || n > MAX_LANES) {
         std::fprintf(stderr, "[hipcpu] %s: workgroup of %ld work-items (limit %d)\n", name, n, MAX_LANES);
@@ -238,13 +242,51 @@ void run_grid(dim3 grid, dim3 block, void (*entry)(void*), void* closure, const 
 struct hipcpu_stream { int dummy; };
 struct hipcpu_event { std::chrono::steady_clock::time_point t; };
 
+// HIPCPU_GUARD_PAGES=1: every allocation ends on an inaccessible page and starts behind one, so that a kernel
+// reading or writing outside a buffer it was handed faults instead of touching a neighbour allocation (on the
+// device such an access is silent as long as it stays inside mapped memory).
+namespace {
+const bool g_guard_pages = std::getenv("HIPCPU_GUARD_PAGES") != nullptr;
+constexpr size_t PAGE = 4096;
+struct GuardHeader { void* base; size_t total; };
+}
 hipError_t hipMalloc(void** p, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    if (g_guard_pages) {
+        const size_t body = (bytes + 255) / 256 * 256;                      // keeps hipMalloc's 256-B alignment
+        const size_t inner = (body + sizeof(GuardHeader) + PAGE - 1) / PAGE * PAGE;
+        const size_t total = inner + 2 * PAGE;
+        char* base = static_cast<char*>(mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+        if (base == MAP_FAILED) return hipErrorOutOfMemory;
+        char* user = base + PAGE + inner - body;                            // the buffer ends where the last page starts
+        GuardHeader* h = reinterpret_cast<GuardHeader*>(base + PAGE);
+        if (reinterpret_cast<char*>(h + 1) > user) { munmap(base, total); return hipErrorOutOfMemory; }
+        *h = {base, total};
+        mprotect(base, PAGE, PROT_NONE);
+        mprotect(base + PAGE + inner, PAGE, PROT_NONE);
+        *p = user;
+        return hipSuccess;
+    }
     void* q = nullptr;
-    if (posix_memalign(&q, 256, bytes ? bytes : 8) != 0) return hipErrorOutOfMemory;
+    if (posix_memalign(&q, 256, bytes) != 0) return hipErrorOutOfMemory;
     *p = q;
     return hipSuccess;
 }
-hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipFree(void* p) {
+    if (!p) return hipSuccess;
+    if (g_guard_pages) {
+        char* page = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(p) / PAGE * PAGE);
+        // the header sits at the start of the first accessible page of the mapping: walk back to it
+        while (true) {
+            GuardHeader* h = reinterpret_cast<GuardHeader*>(page);
+            if (h->base == page - PAGE && h->total >= 3 * PAGE && (h->total % PAGE) == 0) { munmap(h->base, h->total); break; }
+            page -= PAGE;
+        }
+        return hipSuccess;
+    }
+    std::free(p);
+    return hipSuccess;
+}
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) std::memset(d, v, n); return hipSuccess; }

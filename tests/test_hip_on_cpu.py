@@ -48,3 +48,11 @@ def test_gpu_only_modules_bind_every_global_they_read():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "undefined_names.py")], cwd=ROOT,
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_smoke_body_on_the_cpu_execution_model():
+    """__graft_entry__.smoke() minus the device selection."""
+    code = ("import __graft_entry__ as g; from tests.oracle_lib import load_hip_on_cpu; "
+            "g._smoke(load_hip_on_cpu())")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "[smoke] HIP vs oracle" in r.stdout, (r.stdout + r.stderr)[-2000:]

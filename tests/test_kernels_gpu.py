@@ -404,6 +404,16 @@ def test_redistribute_ops(oracle, product):
     for c in range(6):
         assert np.array_equal(np.sort(ld[c * cap:c * cap + cnt_d[c]]), np.sort(lists_c[c * cap:c * cap + cnt_c[c]]))
     assert np.array_equal(pd.to_numpy(), pc.to_numpy())                 # wrapped positions, bit for bit
+    # particles retired earlier are still pushed until the next sort: one that the push carried over a face of the
+    # brick is parked inside again instead of being wrapped a whole domain away (its stencils must stay in reach)
+    a = pd.to_numpy()
+    was_retired = ids == RETIRED
+    outside = np.zeros(n, dtype=bool)
+    for d in (0, 2):
+        outside |= (np.asarray(parts[d]) < blo[d]) | (np.asarray(parts[d]) >= bhi[d])
+    assert (was_retired & outside).sum() > 50
+    for d in (0, 2):
+        assert np.all(a[d, was_retired] >= blo[d]) and np.all(a[d, was_retired] < bhi[d])
     # pack + retire list 1 (towards +x), in the product's list order on both sides
     m = int(cnt_d[1])
     lst = np.ascontiguousarray(ld[cap:cap + m])

@@ -46,6 +46,12 @@ def test_wrap_and_classify_against_numpy(oracle):
         assert cnt[c] == want.size
         assert np.array_equal(lists[c * n:c * n + cnt[c]], want)        # the CPU version keeps index order
     L = phi - plo
+    # retired particles outside the brick along a split direction are parked on its side of the faces (not wrapped)
+    ret_out = (ids == RETIRED) & np.any([(x[d] < blo[d]) | (x[d] >= bhi[d]) for d in range(3) if split[d]], axis=0)
+    assert ret_out.sum() > 20
+    for d in range(3):
+        if split[d]:
+            x[d] = np.where(ret_out, np.minimum(np.maximum(x[d], blo[d]), np.nextafter(bhi[d], blo[d])), x[d])
     wrapped = np.array([np.where(x[d] >= phi[d], x[d] - L[d], np.where(x[d] < plo[d], x[d] + L[d], x[d]))
                         for d in range(3)])
     got = pc.to_numpy()

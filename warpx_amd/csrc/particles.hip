@@ -398,7 +398,19 @@ wrap_classify_kernel(double* __restrict__ x, double* __restrict__ y, double* __r
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (cg.split[d] && code < 0) code = v[d] < cg.blo[d] ? 2 * d : (v[d] >= cg.bhi[d] ? 2 * d + 1 : -1);
-    if (code >= 0 && id[ip] == WXA_IDCPU_RETIRED) code = -1;
+    if (code >= 0 && id[ip] == WXA_IDCPU_RETIRED) {
+        // A retired particle is still pushed until the next sort drops it (weight 0: it deposits zeros).  It was
+        // parked on the brick's side of the face it left through, so the push can carry it across again; if
+        // that face is the domain boundary the periodic wrap would send it a whole domain away, where its
+        // stencils lie outside this brick's arrays.  Park it again instead.
+        code = -1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (cg.split[d]) v[d] = fmin(fmax(v[d], cg.blo[d]), nextafter(cg.bhi[d], cg.blo[d]));
+        if (v[0] != x[ip]) x[ip] = v[0];
+        if (v[1] != y[ip]) y[ip] = v[1];
+        if (v[2] != z[ip]) z[ip] = v[2];
+    }
     if (cg.periodic[0]) { const double w = wrap_periodic(v[0], cg.plo[0], cg.phi[0]); if (w != v[0]) x[ip] = w; }
     if (cg.periodic[1]) { const double w = wrap_periodic(v[1], cg.plo[1], cg.phi[1]); if (w != v[1]) y[ip] = w; }
     if (cg.periodic[2]) { const double w = wrap_periodic(v[2], cg.plo[2], cg.phi[2]); if (w != v[2]) z[ip] = w; }
