@@ -56,6 +56,9 @@ def load_hip_on_cpu():
     tests/hipcpu (tests only; a logic check of the kernels and launches where there is no GPU)."""
     global _hip_on_cpu
     if _hip_on_cpu is None:
-        subprocess.check_call(["make", "-C", HIPCPU_DIR, "-j8", "libwarpx_amd_hipcpu.so"], stdout=subprocess.DEVNULL)
-        _hip_on_cpu = _capi.CLib(HIPCPU_LIB, "wxa_", {**_capi._PRODUCT_SIGS, **_capi._INPUTS_SIGS}, memory="cpu:0")
+        # WXA_HIP_ON_CPU_FMA=1: the build that contracts a*b+c in the kernels like the gfx950 compiler does
+        fma = os.environ.get("WXA_HIP_ON_CPU_FMA") == "1"
+        lib = HIPCPU_LIB.replace(".so", "_fma.so") if fma else HIPCPU_LIB
+        subprocess.check_call(["make", "-C", HIPCPU_DIR, "-j8"] + (["FMA=1"] if fma else []), stdout=subprocess.DEVNULL)
+        _hip_on_cpu = _capi.CLib(lib, "wxa_", {**_capi._PRODUCT_SIGS, **_capi._INPUTS_SIGS}, memory="cpu:0")
     return _hip_on_cpu

@@ -292,6 +292,9 @@ add_plasma_kernel(PV dst, InjectGeom ig, long npoints, unsigned long long* __res
     bool ok = t < npoints;
     double pos[3] = {0.0, 0.0, 0.0};
     if (ok) {
+        // the reference's roundings, one per operation: a fused corner + (i + r) * dx differs in the last bit, which
+        // moves particles off the reference's lattice and can flip the bounds tests below at a box edge
+#pragma clang fp contract(off)
         const int nppc = ig.ppc[0] * ig.ppc[1] * ig.ppc[2];
         const long cell = t / nppc;
         const int ip = (int)(t % nppc);
