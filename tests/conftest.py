@@ -10,6 +10,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "first_gpu_run: no MI355X has executed this test yet (runs last)")
+
+
+def pytest_collection_modifyitems(config, items):
+    first = [it for it in items if it.get_closest_marker("first_gpu_run")]
+    if not first:
+        return
+    if os.environ.get("WXA_SKIP_FIRST_GPU_RUN") == "1":
+        for it in first:
+            it.add_marker(pytest.mark.skip(reason="WXA_SKIP_FIRST_GPU_RUN=1"))
+    rest = [it for it in items if not it.get_closest_marker("first_gpu_run")]
+    items[:] = rest + first
 
 
 @pytest.fixture(scope="session")

@@ -534,11 +534,7 @@ def test_apply_pec_j(oracle, product, pec):
         assert np.array_equal(a.to_numpy(), b.to_numpy())
 
 
-UNVERIFIED = pytest.mark.skipif(
-    os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
-    reason="written after round 1's GPU budget was spent and never run on a GPU yet; the CPU restatement it "
-           "compares with is pinned to the reference's golden vectors (tests/test_pec_golden.py); "
-           "WXA_UNVERIFIED_GPU_TESTS=1 runs it")
+UNVERIFIED = H.FIRST_GPU_RUN   # see tests/helpers.py
 
 
 @UNVERIFIED

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from tests import helpers as H
 from warpx_amd import _capi, plasma
 from warpx_amd.containers import FieldArray
 from warpx_amd.sim import WarpXSim, field_energy, particle_moments
@@ -226,11 +227,7 @@ def test_pec_field_golden_on_gpu(oracle, product):
     assert np.all(ey[:, :, 0] == 0.0) and np.all(ey[:, :, -1] == 0.0)
 
 
-@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
-                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (its pieces are: "
-                           "wxa_apply_pec_e/b/j bit-identical to the oracle on the GPU, the PEC field golden run on "
-                           "the GPU, and this same case on the CPU build of the host layer); set "
-                           "WXA_UNVERIFIED_GPU_TESTS=1 to run it")
+@H.FIRST_GPU_RUN
 def test_pec_particle_golden_on_gpu(oracle, product):
     """Examples/Tests/pec/inputs_test_3d_pec_particle on the HIP path: two particles 0.004 cell from a PEC
     wall (image-charge fold of J, mirrored E/B guards in the gather, LDS tiles reaching behind the wall)
@@ -262,10 +259,7 @@ def test_pec_particle_golden_on_gpu(oracle, product):
             assert abs(got - want) / want < gold["rtol"], (species, key)
 
 
-@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
-                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (the same case "
-                           "passes on the oracle stepper and on the CPU build of the host layer, "
-                           "tests/test_pec_golden.py); WXA_UNVERIFIED_GPU_TESTS=1 runs it")
+@H.FIRST_GPU_RUN
 def test_particle_boundaries_golden_on_gpu(product):
     """Examples/Tests/boundaries/inputs_test_3d_particle_boundaries on the HIP path: the reference's golden
     particle checksums (reflecting, absorbing, periodic walls) at the reference's tolerance."""
@@ -277,10 +271,7 @@ def test_particle_boundaries_golden_on_gpu(product):
     assert sim.particles(a).shape[1] == 1
 
 
-@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
-                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (the same case "
-                           "passes on the oracle stepper and on the CPU build of the host layer, "
-                           "tests/test_pec_golden.py); WXA_UNVERIFIED_GPU_TESTS=1 runs it")
+@H.FIRST_GPU_RUN
 def test_laser_acceleration_golden_on_gpu(oracle, product):
     """Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration on the HIP path (moving
     window at c, continuous injection, Gaussian antenna, PEC walls, filter, order 3): the reference's golden field,
@@ -306,10 +297,7 @@ def test_laser_acceleration_golden_on_gpu(oracle, product):
     assert sim.particles(e).shape[1] == 69212
 
 
-@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
-                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (the same case "
-                           "passes on the oracle stepper and on the CPU build of the host layer, "
-                           "tests/test_oracle_golden.py); WXA_UNVERIFIED_GPU_TESTS=1 runs it")
+@H.FIRST_GPU_RUN
 def test_picmi_langmuir_golden_on_gpu(oracle, product):
     """Examples/Tests/langmuir/inputs_test_3d_langmuir_multi_picmi.py on the HIP path: direct deposition on the
     Yee grid (LDS tiles), bilinear filter, gather without Galerkin shapes, 8 ppc, sorted every 4 steps: the
@@ -327,10 +315,7 @@ def test_picmi_langmuir_golden_on_gpu(oracle, product):
     check_picmi_langmuir_golden(oracle, sim, e, cc)
 
 
-@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
-                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (the same decks "
-                           "pass on the CPU build of the host layer, tests/test_inputs_cpu.py); "
-                           "WXA_UNVERIFIED_GPU_TESTS=1 runs it")
+@H.FIRST_GPU_RUN
 @pytest.mark.parametrize("deck,golden,skip", [
     ("langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", ()),
     ("langmuir_beam_direct_3d.inputs", "langmuir_multi_picmi_3d_checksums.json", ()),
