@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from tests.oracle_lib import load_host_cpu, load_oracle  # noqa: E402
+from tests.oracle_lib import load_hip_on_cpu, load_host_cpu, load_oracle  # noqa: E402
 from warpx_amd import _capi, plasma  # noqa: E402
 from warpx_amd.distributed import TorchBrickTransport, brick_coord  # noqa: E402
 from warpx_amd.sim import WarpXSim, field_energy, particle_moments  # noqa: E402
@@ -33,7 +33,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     assert world == nb[0] * nb[1] * nb[2]
-    n_cell = (16, 16, 16)
+    n_cell = tuple(int(v) for v in os.environ.get("WXA_TEST_NCELL", "16 16 16").split())
     prob_lo, prob_hi = (-L / 2,) * 3, (L / 2,) * 3
     # hot plasma so that particles cross brick boundaries within a few steps
     parts = np.array(plasma.uniform_plasma(n_cell, prob_lo, prob_hi, (1, 2, 1), 1e25, 0.3, seed=11))
@@ -46,8 +46,9 @@ def main():
     for d in range(3):
         mine &= (parts[d] >= lo[d]) & (parts[d] < hi[d])
     transport = TorchBrickTransport(on_device=False)
-    lib = load_host_cpu()
-    sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, sort_interval=2,
+    # WXA_WORKER_LIB=hipcpu: the HIP kernels themselves (tests/hipcpu execution model) instead of the oracle kernels
+    lib = load_hip_on_cpu() if os.environ.get("WXA_WORKER_LIB") == "hipcpu" else load_host_cpu()
+    sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, sort_interval=int(os.environ.get("WXA_TEST_SORT", "2")),
                    nbricks=nb, coord=coord, comm=transport.comm, overlap_halo=overlap)
     assert sim.halo_overlap == bool(overlap)
     sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
