@@ -42,3 +42,42 @@ def product():
     lib = load_product()
     assert torch.cuda.is_available(), "gpu-marked test without a visible GPU"
     return lib
+
+
+def _guarded_device_tensors():
+    """WXA_HIP_ON_CPU=1 HIPCPU_GUARD_PAGES=1: the "device" tensors the tests allocate (torch.zeros(..., device="cpu:0"))
+    come from the execution model's hipMalloc, i.e. they end on an inaccessible page: a kernel that reads or writes
+    past a buffer it was handed faults instead of touching whatever the allocator placed next to it."""
+    import ctypes as C
+    import torch
+    from tests.oracle_lib import load_hip_on_cpu
+    dll = load_hip_on_cpu()._dll
+    hip_malloc = getattr(dll, "_Z9hipMallocPPvm")
+    hip_malloc.restype, hip_malloc.argtypes = C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]
+    plain_zeros = torch.zeros
+
+    def zeros(*size, **kw):
+        if str(kw.get("device", "cpu")) != "cpu:0":
+            return plain_zeros(*size, **kw)
+        dtype = kw.get("dtype", torch.float32)
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+        n = 1
+        for v in shape:
+            n *= int(v)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        if nbytes == 0:
+            return plain_zeros(*size, **kw)
+        # end-aligned only up to 256 B: pad the request so that the tensor's last element is the buffer's last
+        nalloc = (nbytes + 255) // 256 * 256
+        p = C.c_void_p()
+        assert hip_malloc(C.byref(p), nalloc) == 0
+        buf = (C.c_uint8 * nalloc).from_address(p.value)
+        t = torch.frombuffer(buf, dtype=torch.uint8)[nalloc - nbytes:].view(dtype).reshape(shape)
+        t.zero_()
+        return t
+
+    torch.zeros = zeros
+
+
+if os.environ.get("WXA_HIP_ON_CPU") == "1" and os.environ.get("HIPCPU_GUARD_PAGES"):
+    _guarded_device_tensors()

@@ -37,6 +37,13 @@ def test_kernel_parity_tests_pass_on_the_cpu_execution_model():
     assert int(summary.split(" passed")[0].split()[-1]) >= 110, summary
 
 
+def test_kernel_tests_with_guard_pages_and_fma_contraction():
+    """The same tests on the build that contracts a*b+c like hipcc does for device code, every "device" buffer
+    (the tests' and the library's) ending on an inaccessible page: no kernel touches memory outside the arrays it
+    is handed, and no comparison with the oracle relies on unfused arithmetic."""
+    _run(["tests/test_kernels_gpu.py"], {"HIPCPU_GUARD_PAGES": "1", "WXA_HIP_ON_CPU_FMA": "1"})
+
+
 def test_short_step_parity_on_the_cpu_execution_model():
     """The whole product schedule (host layer + HIP kernels) against the oracle stepper: order 1 and 3."""
     _run(["tests/test_step_gpu.py", "-k", "test_uniform_plasma_parity"])
