@@ -119,6 +119,21 @@ wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3],
 wxa_status wxa_evolve_b_guard_layer(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
                                     const double inv_dx[3], const int32_t grow[3], void* stream);
 
+/* algo.maxwell_solver = ckc (first piece): the Cole-Karkkainen-Cowan solver.
+ * wxa_ckc_stencil_coefficients replaces CartesianCKCAlgorithm::InitializeStencilCoefficients
+ * (Source/FieldSolver/FiniteDifferenceSolver/FiniteDifferenceAlgorithms/CartesianCKCAlgorithm.H:28-102, 3-D branch):
+ * coefs_d = {1/dx_d, alpha_d, beta_d(first transverse), beta_d(second transverse), gamma_d / dx_d} in the
+ * reference's order (x: betaxy, betaxz; y: betayz, betayx; z: betazx, betazy).
+ * wxa_evolve_b_ckc replaces FiniteDifferenceSolver::EvolveB -> EvolveBCartesian<CartesianCKCAlgorithm>
+ * (EvolveB.cpp:102-105,122-215): the upward differences of E extended over the transverse neighbours
+ * (UpwardDx/Dy/Dz, CartesianCKCAlgorithm.H:129-160,183-214,237-272); it reads one guard point of E in every
+ * direction.  The update of E is the Yee one (the downward differences are the same, :164-181): wxa_evolve_e.
+ * wxa_ckc_max_dt: CartesianCKCAlgorithm::ComputeMaxDt (:107-120) = min(dx) / c. */
+void wxa_ckc_stencil_coefficients(const double cell_size[3], double coefs_x[5], double coefs_y[5], double coefs_z[5]);
+double wxa_ckc_max_dt(const double cell_size[3]);
+wxa_status wxa_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3], double dt,
+                            const double coefs_x[5], const double coefs_y[5], const double coefs_z[5], void* stream);
+
 /* ------------------------------------------------------------------ */
 /* Particles                                                           */
 /* ------------------------------------------------------------------ */
@@ -379,6 +394,7 @@ wxa_status wxa_device_synchronize(void);
 /* ------------------------------------------------------------------ */
 
 enum { WXA_GRID_STAGGERED = 0, WXA_GRID_COLLOCATED = 1 };
+enum { WXA_SOLVER_YEE = 0, WXA_SOLVER_CKC = 1 };   /* algo.maxwell_solver */
 
 typedef struct wxa_sim_config {
     int32_t n_cell[3];           /* amr.n_cell, whole domain                    */
@@ -403,6 +419,9 @@ typedef struct wxa_sim_config {
     int32_t grid_type;           /* warpx.grid_type: WXA_GRID_STAGGERED (0, the default).  WXA_GRID_COLLOCATED exists
                                     in the CPU restatement only (it pins the direct deposition to the reference's
                                     test_3d_langmuir_multi_nodal checksums); the library refuses it              */
+    int32_t maxwell_solver;      /* algo.maxwell_solver: WXA_SOLVER_YEE (0, the default) or WXA_SOLVER_CKC; with CKC
+                                    dt = cfl min(dx)/c and every field exchange of the reference's schedule is issued
+                                    (the B update reads guard points of E)                                        */
 } wxa_sim_config;
 
 /* ---- second "next" row: moving window, continuous plasma injection, laser antenna -----------------

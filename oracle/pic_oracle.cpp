@@ -189,6 +189,98 @@ static int evolve_e_clipped(const wxa_field_view E[3], const wxa_field_view B[3]
 }
 
 
+// ---- algo.maxwell_solver = ckc ---------------------------------------------------------------------------------
+// CartesianCKCAlgorithm::InitializeStencilCoefficients, 3-D branch
+// (Source/FieldSolver/FiniteDifferenceSolver/FiniteDifferenceAlgorithms/CartesianCKCAlgorithm.H:36-101)
+void orc_ckc_stencil_coefficients(const double cell_size[3], double cx[5], double cy[5], double cz[5]) {
+    const double inv_dx = 1. / cell_size[0], inv_dy = 1. / cell_size[1], inv_dz = 1. / cell_size[2];
+    const double delta = std::max({inv_dx, inv_dy, inv_dz});
+    const double rx = (inv_dx / delta) * (inv_dx / delta);
+    const double ry = (inv_dy / delta) * (inv_dy / delta);
+    const double rz = (inv_dz / delta) * (inv_dz / delta);
+    const double beta = 0.125 * (1. - rx * ry * rz / (ry * rz + rz * rx + rx * ry));
+    const double betaxy = ry * beta * inv_dx, betaxz = rz * beta * inv_dx;
+    const double betayx = rx * beta * inv_dy, betayz = rz * beta * inv_dy;
+    const double betazx = rx * beta * inv_dz, betazy = ry * beta * inv_dz;
+    const double inv_r_fac = (1. / (ry * rz + rz * rx + rx * ry));
+    const double gammax = ry * rz * (0.0625 - 0.125 * ry * rz * inv_r_fac);
+    const double gammay = rx * rz * (0.0625 - 0.125 * rx * rz * inv_r_fac);
+    const double gammaz = rx * ry * (0.0625 - 0.125 * rx * ry * inv_r_fac);
+    const double alphax = (1. - 2. * ry * beta - 2. * rz * beta - 4. * gammax) * inv_dx;
+    const double alphay = (1. - 2. * rx * beta - 2. * rz * beta - 4. * gammay) * inv_dy;
+    const double alphaz = (1. - 2. * rx * beta - 2. * ry * beta - 4. * gammaz) * inv_dz;
+    cx[0] = inv_dx; cx[1] = alphax; cx[2] = betaxy; cx[3] = betaxz; cx[4] = gammax * inv_dx;
+    cy[0] = inv_dy; cy[1] = alphay; cy[2] = betayz; cy[3] = betayx; cy[4] = gammay * inv_dy;
+    cz[0] = inv_dz; cz[1] = alphaz; cz[2] = betazx; cz[3] = betazy; cz[4] = gammaz * inv_dz;
+}
+// CartesianCKCAlgorithm::ComputeMaxDt (:107-120)
+double orc_ckc_max_dt(const double cell_size[3]) {
+    return std::min(cell_size[0], std::min(cell_size[1], cell_size[2])) / PhysConst::c;
+}
+namespace ckc {
+// UpwardDx / UpwardDy / UpwardDz (:129-160, :183-214, :237-272), term by term in the reference's order
+inline double up_x(const Arr& F, const double* c, int i, int j, int k) {
+    const double alphax = c[1], betaxy = c[2], betaxz = c[3], gammax = c[4];
+    return alphax * (F(i + 1, j, k) - F(i, j, k))
+         + betaxy * (F(i + 1, j + 1, k) - F(i, j + 1, k)
+                  +  F(i + 1, j - 1, k) - F(i, j - 1, k))
+         + betaxz * (F(i + 1, j, k + 1) - F(i, j, k + 1)
+                  +  F(i + 1, j, k - 1) - F(i, j, k - 1))
+         + gammax * (F(i + 1, j + 1, k + 1) - F(i, j + 1, k + 1)
+                  +  F(i + 1, j - 1, k + 1) - F(i, j - 1, k + 1)
+                  +  F(i + 1, j + 1, k - 1) - F(i, j + 1, k - 1)
+                  +  F(i + 1, j - 1, k - 1) - F(i, j - 1, k - 1));
+}
+inline double up_y(const Arr& F, const double* c, int i, int j, int k) {
+    const double alphay = c[1], betayz = c[2], betayx = c[3], gammay = c[4];
+    return alphay * (F(i, j + 1, k) - F(i, j, k))
+         + betayx * (F(i + 1, j + 1, k) - F(i + 1, j, k)
+                  +  F(i - 1, j + 1, k) - F(i - 1, j, k))
+         + betayz * (F(i, j + 1, k + 1) - F(i, j, k + 1)
+                  +  F(i, j + 1, k - 1) - F(i, j, k - 1))
+         + gammay * (F(i + 1, j + 1, k + 1) - F(i + 1, j, k + 1)
+                  +  F(i - 1, j + 1, k + 1) - F(i - 1, j, k + 1)
+                  +  F(i + 1, j + 1, k - 1) - F(i + 1, j, k - 1)
+                  +  F(i - 1, j + 1, k - 1) - F(i - 1, j, k - 1));
+}
+inline double up_z(const Arr& F, const double* c, int i, int j, int k) {
+    const double alphaz = c[1], betazx = c[2], betazy = c[3], gammaz = c[4];
+    return alphaz * (F(i, j, k + 1) - F(i, j, k))
+         + betazx * (F(i + 1, j, k + 1) - F(i + 1, j, k)
+                  +  F(i - 1, j, k + 1) - F(i - 1, j, k))
+         + betazy * (F(i, j + 1, k + 1) - F(i, j + 1, k)
+                  +  F(i, j - 1, k + 1) - F(i, j - 1, k))
+         + gammaz * (F(i + 1, j + 1, k + 1) - F(i + 1, j + 1, k)
+                  +  F(i - 1, j + 1, k + 1) - F(i - 1, j + 1, k)
+                  +  F(i + 1, j - 1, k + 1) - F(i + 1, j - 1, k)
+                  +  F(i - 1, j - 1, k + 1) - F(i - 1, j - 1, k));
+}
+}  // namespace ckc
+// EvolveBCartesian<CartesianCKCAlgorithm> (EvolveB.cpp:164-186 with T_Algo = CKC)
+int orc_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double cx[5],
+                     const double cy[5], const double cz[5], void*) {
+    const Arr Ex(E[0]), Ey(E[1]), Ez(E[2]), Bx(B[0]), By(B[1]), Bz(B[2]);
+#pragma omp parallel
+    {
+#pragma omp for nowait
+        for (int k = clo_(B[0], 2, nullptr); k < chi_(B[0], 2, nullptr); ++k)
+            for (int j = clo_(B[0], 1, nullptr); j < chi_(B[0], 1, nullptr); ++j)
+                for (int i = clo_(B[0], 0, nullptr); i < chi_(B[0], 0, nullptr); ++i)
+                    Bx(i, j, k) += dt * ckc::up_z(Ey, cz, i, j, k) - dt * ckc::up_y(Ez, cy, i, j, k);
+#pragma omp for nowait
+        for (int k = clo_(B[1], 2, nullptr); k < chi_(B[1], 2, nullptr); ++k)
+            for (int j = clo_(B[1], 1, nullptr); j < chi_(B[1], 1, nullptr); ++j)
+                for (int i = clo_(B[1], 0, nullptr); i < chi_(B[1], 0, nullptr); ++i)
+                    By(i, j, k) += dt * ckc::up_x(Ez, cx, i, j, k) - dt * ckc::up_z(Ex, cz, i, j, k);
+#pragma omp for nowait
+        for (int k = clo_(B[2], 2, nullptr); k < chi_(B[2], 2, nullptr); ++k)
+            for (int j = clo_(B[2], 1, nullptr); j < chi_(B[2], 1, nullptr); ++j)
+                for (int i = clo_(B[2], 0, nullptr); i < chi_(B[2], 0, nullptr); ++i)
+                    Bz(i, j, k) += dt * ckc::up_y(Ex, cy, i, j, k) - dt * ckc::up_x(Ey, cx, i, j, k);
+    }
+    return 0;
+}
+
 int orc_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double dinv[3], void*) {
     return evolve_b_clipped(E, B, dt, dinv, nullptr, nullptr);
 }
@@ -1119,6 +1211,7 @@ struct LaserAntenna {
 struct orc_sim {
     wxa_sim_config cfg;
     double dx[3], dinv[3], dt;
+    double ckc_x[5] = {0}, ckc_y[5] = {0}, ckc_z[5] = {0};   // algo.maxwell_solver = ckc
     int ng_EB[3], ng_J[3], ng_depos_J[3], ng_gather[3], ng_solver[3], ng_rho[3];
     Field E[3], B[3], J[3], Jtmp, rho;
     std::vector<std::unique_ptr<Species>> species;
@@ -1397,7 +1490,8 @@ void one_step_nosub(orc_sim* s) {
     // (Source/FieldSolver/WarpXPushFieldsEM.cpp:926,990 -> WarpXFieldBoundaries.cpp:51-135)
     auto evolve_b = [&](double a_dt) {
         Tic t(s, 3);
-        orc_evolve_b(s->Ev, s->Bv, a_dt, s->dinv, nullptr);
+        if (s->cfg.maxwell_solver == WXA_SOLVER_CKC) orc_evolve_b_ckc(s->Ev, s->Bv, a_dt, s->ckc_x, s->ckc_y, s->ckc_z, nullptr);
+        else orc_evolve_b(s->Ev, s->Bv, a_dt, s->dinv, nullptr);
         if (s->any_pec) orc_apply_pec_b(s->Bv, s->dom_lo, s->dom_hi, s->pec_lo, s->pec_hi, s->ng_gather32, nullptr);
     };
     evolve_b(0.5 * dt);                                                         // :421
@@ -1430,8 +1524,13 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
     }
     // Source/Evolve/WarpXComputeDt.cpp:41-102 + CartesianYeeAlgorithm::ComputeMaxDt (:48-56)
     const double* dx = s->dx;
-    const double deltat = cfg->cfl * 1.0 /
+    double deltat = cfg->cfl * 1.0 /
         (std::sqrt(1.0 / (dx[0] * dx[0]) + 1.0 / (dx[1] * dx[1]) + 1.0 / (dx[2] * dx[2])) * PhysConst::c);
+    if (cfg->maxwell_solver == WXA_SOLVER_CKC) {   // CartesianCKCAlgorithm::ComputeMaxDt, InitializeStencilCoefficients
+        if (cfg->grid_type != WXA_GRID_STAGGERED) { delete s; return -2; }
+        deltat = cfg->cfl * orc_ckc_max_dt(dx);
+        orc_ckc_stencil_coefficients(dx, s->ckc_x, s->ckc_y, s->ckc_z);
+    } else if (cfg->maxwell_solver != WXA_SOLVER_YEE) { delete s; return -2; }
     s->dt = deltat;
     // Source/Parallelization/GuardCellManager.cpp:62-172,276-278,314-316
     const int nox = cfg->nox;

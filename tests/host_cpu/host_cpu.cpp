@@ -11,6 +11,10 @@
 extern "C" {
 int orc_evolve_b(const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
 int orc_evolve_e(const wxa_field_view*, const wxa_field_view*, const wxa_field_view*, double, const double*, void*);
+void orc_ckc_stencil_coefficients(const double*, double*, double*, double*);
+double orc_ckc_max_dt(const double*);
+int orc_evolve_b_ckc(const wxa_field_view*, const wxa_field_view*, double, const double*, const double*, const double*,
+                     void*);
 int orc_gather_push(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
                     double, double, double, int, int, int, void*);
 int orc_push_p(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
@@ -68,6 +72,8 @@ const Backend* cpu_backend() {
         Backend b{};
         b.name = "cpu-oracle (tests only)";
         b.evolve_b = orc_evolve_b; b.evolve_e = orc_evolve_e;
+        b.ckc_stencil_coefficients = orc_ckc_stencil_coefficients; b.ckc_max_dt = orc_ckc_max_dt;
+        b.evolve_b_ckc = orc_evolve_b_ckc;
         b.gather_push = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
                            const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, int move,
                            void*, void* st) -> int {

@@ -30,6 +30,7 @@ def main():
     order, filt, out = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     overlap = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     steps = int(os.environ.get("WXA_TEST_STEPS", "6"))
+    solver = int(os.environ.get("WXA_TEST_SOLVER", "0"))   # _capi.SOLVER_YEE / SOLVER_CKC
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     assert world == nb[0] * nb[1] * nb[2]
@@ -49,7 +50,7 @@ def main():
     # WXA_WORKER_LIB=hipcpu: the HIP kernels themselves (tests/hipcpu execution model) instead of the oracle kernels
     lib = load_hip_on_cpu() if os.environ.get("WXA_WORKER_LIB") == "hipcpu" else load_host_cpu()
     sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, sort_interval=int(os.environ.get("WXA_TEST_SORT", "2")),
-                   nbricks=nb, coord=coord, comm=transport.comm, overlap_halo=overlap)
+                   nbricks=nb, coord=coord, comm=transport.comm, overlap_halo=overlap, maxwell_solver=solver)
     assert sim.halo_overlap == bool(overlap)
     sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
     sim.evolve(steps)
@@ -65,7 +66,7 @@ def main():
     dist.gather_object(payload, gathered if rank == 0 else None, dst=0)
     if rank == 0:
         orc = load_oracle()
-        ref = WarpXSim(orc, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt)
+        ref = WarpXSim(orc, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, maxwell_solver=solver)
         rid = ref.add_species(-plasma.Q_E, plasma.M_E, list(parts))
         ref.evolve(steps)
         ref.compute_rho()

@@ -48,6 +48,29 @@ def test_single_brick_schedule_matches_oracle(oracle, host_cpu, order, filt, sor
         assert np.max(np.abs(Fa[n] - Fb[n])) <= 1e-11 * np.max(np.abs(Fb[n])), n
 
 
+@pytest.mark.parametrize("order,filt", [(1, 0), (3, 1)])
+def test_ckc_schedule_matches_oracle(oracle, host_cpu, order, filt):
+    """algo.maxwell_solver = ckc: dt = min(dx)/c, the extended update of B, and the solver-depth fill of E that the
+    Yee schedule drops (the CKC update of B reads guard points of E) -- against the oracle stepper."""
+    n_cell = (16, 12, 14)
+    parts = _species(n_cell)
+    res = []
+    for lib in (host_cpu, oracle):
+        sim = WarpXSim(lib, n_cell, (-L / 2,) * 3, (L / 2, L / 2 * 1.1, L / 2 * 0.9), nox=order, use_filter=filt,
+                       sort_interval=2, maxwell_solver=_capi.SOLVER_CKC, cfl=0.95)
+        sid = sim.add_species(-plasma.Q_E, plasma.M_E, parts)
+        sim.evolve(5)
+        res.append((sim.dt, field_energy(sim), particle_moments(sim, sid),
+                    {n: sim.field_valid(n) for n in ("Ex", "By", "Bz", "jz")}))
+        sim.close()
+    (da, fa, ma, Fa), (db, fb, mb, Fb) = res
+    assert da == db
+    assert np.allclose(fa, fb, rtol=1e-11)
+    assert np.isclose(ma["ekin"], mb["ekin"], rtol=1e-12)
+    for n in Fa:
+        assert np.max(np.abs(Fa[n] - Fb[n])) <= 1e-11 * np.max(np.abs(Fb[n])), n
+
+
 def test_error_conventions(host_cpu):
     with pytest.raises(_capi.WxaError):   # particle shape out of range
         WarpXSim(host_cpu, (8, 8, 8), (-L / 2,) * 3, (L / 2,) * 3, nox=5)

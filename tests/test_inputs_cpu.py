@@ -90,8 +90,19 @@ def test_deck_syntax_includes_overrides_and_constants(lib, tmp_path):
     sim.close()
 
 
+def test_ckc_solver_from_the_inputs_file(lib, tmp_path):
+    """algo.maxwell_solver = ckc: dt = cfl min(dx) / c (CartesianCKCAlgorithm::ComputeMaxDt)."""
+    deck = _write(tmp_path, "ckc.inputs", MINIMAL + "algo.maxwell_solver = ckc\nwarpx.cfl = 0.9\n")
+    sim = WarpXSim.from_inputs(lib, deck)
+    assert sim.dt == pytest.approx(0.9 * 0.25 / 299792458.0, rel=1e-15)
+    sim_yee = WarpXSim.from_inputs(lib, _write(tmp_path, "yee.inputs", MINIMAL + "warpx.cfl = 0.9\n"))
+    assert sim.dt > sim_yee.dt * 1.5          # cubic cells: sqrt(3) apart
+    sim.close()
+    sim_yee.close()
+
+
 @pytest.mark.parametrize("extra,needle", [
-    ("algo.maxwell_solver = ckc", "maxwell_solver"),
+    ("algo.maxwell_solver = psatd", "maxwell_solver"),
     ("warpx.gamma_boost = 10.", "gamma_boost"),
     ("boundary.field_lo = pml pml pml", "pml"),
     ("warpx.do_pml = 1", "do_pml"),

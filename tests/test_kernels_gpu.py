@@ -766,3 +766,31 @@ def test_add_plasma(oracle, product, ppc, u, uth):
     with pytest.raises(_capi.WxaError):
         product.add_plasma(C.byref(small.view), *args, C.byref(nd), ws, None)
     product.workspace_destroy(ws)
+
+
+@UNVERIFIED
+@pytest.mark.parametrize("cells", [(1.0, 1.0, 1.0), (1.0, 1.5, 0.8)])
+def test_evolve_b_ckc_bit_exact(oracle, product, cells):
+    """wxa_evolve_b_ckc (EvolveBCartesian<CartesianCKCAlgorithm>) and its coefficients against the CPU restatement:
+    same operation order, no contraction -> bit-identical, on cubic and on anisotropic cells."""
+    ng = 2
+    E = H.random_fields(("Ex", "Ey", "Ez"), NCELL, ng, 61)
+    B = H.random_fields(("Bx", "By", "Bz"), NCELL, ng, 62, scale=1e-8)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    dx = np.array(cells) * 0.4e-6
+    co = [(C.c_double * 5)() for _ in range(3)]
+    cp = [(C.c_double * 5)() for _ in range(3)]
+    oracle.ckc_stencil_coefficients(H.d3(dx), *co)
+    product.ckc_stencil_coefficients(H.d3(dx), *cp)
+    assert all(list(a) == list(b) for a, b in zip(co, cp))
+    assert oracle.ckc_max_dt(H.d3(dx)) == product.ckc_max_dt(H.d3(dx))
+    dt = 0.5 * product.ckc_max_dt(H.d3(dx))
+    oracle.evolve_b_ckc(field_triplet(E), field_triplet(B), dt, *co, None)
+    product.evolve_b_ckc(field_triplet(Ed), field_triplet(Bd), dt, *cp, None)
+    _sync(product)
+    for a, b in zip(Bd, B):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+    # one guard point of E is a precondition, not an overrun
+    E0 = [FieldArray(NCELL, STAG[n], (0, 0, 0), DEV) for n in ("Ex", "Ey", "Ez")]
+    with pytest.raises(_capi.WxaError):
+        product.evolve_b_ckc(field_triplet(E0), field_triplet(Bd), dt, *cp, None)

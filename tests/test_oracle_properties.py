@@ -120,3 +120,62 @@ def test_vay_force_free_orbit(oracle):
         out[pusher] = abs(drift)
     assert out[_capi.PUSHER_VAY] < 1e-9
     assert out[_capi.PUSHER_BORIS] > 1e3 * max(out[_capi.PUSHER_VAY], 1e-15)
+
+
+# ---- algo.maxwell_solver = ckc (no deterministic 3-D golden file of the reference uses it) ----
+
+def test_ckc_coefficients_cubic_cells(oracle):
+    """Cowan et al., PRST-AB 16, 041303 (2013): cubic cells give alpha = 7/12, beta = 1/12, gamma = 1/48 (in units of
+    1/dx), and alpha + 4 beta + 4 gamma = 1 (a field uniform in the transverse plane sees the plain difference)."""
+    dx = 0.3e-6
+    cx, cy, cz = ((C.c_double * 5)() for _ in range(3))
+    oracle.ckc_stencil_coefficients(H.d3((dx, dx, dx)), cx, cy, cz)
+    for c in (cx, cy, cz):
+        assert np.allclose(np.array(c[:]) * dx, [1.0, 7.0 / 12.0, 1.0 / 12.0, 1.0 / 12.0, 1.0 / 48.0], rtol=1e-15)
+    assert oracle.ckc_max_dt(H.d3((dx, 2 * dx, 3 * dx))) == dx / plasma.C_LIGHT
+    # anisotropic cells: the transverse sums still add up to 1/dx_d
+    oracle.ckc_stencil_coefficients(H.d3((dx, 1.5 * dx, 0.8 * dx)), cx, cy, cz)
+    for c in (cx, cy, cz):
+        assert np.isclose(c[1] + 2 * c[2] + 2 * c[3] + 4 * c[4], c[0], rtol=1e-14)
+
+
+@pytest.mark.parametrize("axis", [0, 2])
+def test_ckc_vacuum_pulse_travels_one_cell_per_step(oracle, axis):
+    """The reason the solver exists: at cfl = 1 (c dt = dx) a plane wave along a grid axis has no numerical
+    dispersion.  A pulse started on the discrete mode of the leapfrog (B = the average of its two neighbours of E / c)
+    is translated by exactly one cell per step; the Yee solver on the same grid (c dt = dx / sqrt 3) disperses it."""
+    from warpx_amd.sim import WarpXSim
+    n = 24
+    n_cell = [4, 4, 4]
+    n_cell[axis] = n
+    Lbox = [4 * 1e-6, 4 * 1e-6, 4 * 1e-6]
+    Lbox[axis] = n * 1e-6
+    lo, hi = tuple(-0.5 * v for v in Lbox), tuple(0.5 * v for v in Lbox)
+    k = np.arange(n)
+    f = 1e9 * np.exp(-((k - 7.0) / 2.5) ** 2) * np.cos(2 * np.pi * k / 6.0)          # E at the nodes along the axis
+    steps = 9
+    res = {}
+    for solver in (_capi.SOLVER_CKC, _capi.SOLVER_YEE):
+        sim = WarpXSim(oracle, n_cell, lo, hi, nox=1, use_filter=0, maxwell_solver=solver)
+        # wave along +axis: (E, B) = (Ey, -Bx) along z, (Ez, -By) along x  [E x B parallel to the axis]
+        en, bn = ("Ey", "Bx") if axis == 2 else ("Ez", "By")
+        sign = -1.0
+        E, B = sim.field(en), sim.field(bn)
+        ge, gb = sim.field_view(en).ng[axis], sim.field_view(bn).ng[axis]
+        idx_e = (np.arange(E.shape[axis]) - ge) % n          # node index of every point along the axis (periodic)
+        idx_b = (np.arange(B.shape[axis]) - gb) % n          # cell index
+        shape = [1, 1, 1]
+        shape[axis] = -1
+        E[...] = f[idx_e].reshape(shape)
+        B[...] = sign * (0.5 * (f[idx_b] + f[(idx_b + 1) % n]) / plasma.C_LIGHT).reshape(shape)
+        sim.set_field(en, E)
+        sim.set_field(bn, B)
+        sim.evolve(steps)
+        out = sim.field_valid(en)
+        line = np.moveaxis(out, axis, 0)[:n, 1, 1]
+        res[solver] = np.max(np.abs(line - np.roll(f, steps))) / np.max(np.abs(f))
+        if solver == _capi.SOLVER_CKC:
+            assert np.isclose(sim.dt, 1e-6 / plasma.C_LIGHT, rtol=1e-15)
+        sim.close()
+    assert res[_capi.SOLVER_CKC] < 1e-12, res
+    assert res[_capi.SOLVER_YEE] > 1e-2, res          # same grid, Yee: the pulse lags and disperses

@@ -335,3 +335,22 @@ def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden
     sim.evolve(sim.max_step)
     compare_with_golden(sim.checksum(), gold["checksums"], gold["rtol"], skip)
     sim.close()
+
+
+@H.FIRST_GPU_RUN
+@pytest.mark.parametrize("order,filt", [(3, 1), (1, 0)])
+def test_ckc_uniform_plasma_parity(oracle, product, order, filt):
+    """algo.maxwell_solver = ckc on the HIP path (dt = min(dx)/c, wxa_evolve_b_ckc, every field exchange of the
+    reference's schedule) against the oracle stepper: the same 1e-10 gate as the Yee runs."""
+    n_cell = (16, 16, 16)
+    L = 40e-6
+    parts = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (1, 1, 2), 1e25, 0.01, seed=12345)
+    species = [(-plasma.Q_E, plasma.M_E, parts)]
+    kw = dict(nox=order, use_filter=filt, sort_interval=4, maxwell_solver=_capi.SOLVER_CKC, cfl=0.98)
+    so, io = _run(oracle, n_cell, species, 10, **kw)
+    sg, ig = _run(product, n_cell, species, 10, **kw)
+    assert abs(so.dt - sg.dt) == 0.0
+    _compare(_metrics(sg, ig), _metrics(so, io))
+    for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz"):
+        a, b = sg.field_valid(name), so.field_valid(name)
+        assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), name

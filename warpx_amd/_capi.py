@@ -44,6 +44,7 @@ class GridGeom(C.Structure):
 
 
 GRID_STAGGERED, GRID_COLLOCATED = 0, 1
+SOLVER_YEE, SOLVER_CKC = 0, 1
 PART_INTERIOR, PART_REST = 1, 2
 
 
@@ -67,6 +68,7 @@ class SimConfig(C.Structure):
         ("particle_boundary_hi", C.c_int32 * 3),
         ("overlap_halo", C.c_int32),
         ("grid_type", C.c_int32),
+        ("maxwell_solver", C.c_int32),
     ]
 
 
@@ -146,6 +148,9 @@ _KERNEL_SIGS = {
     "apply_particle_boundaries": (C.c_int, [_PPV, _D3, _D3, _I32_3, _I32_3, C.POINTER(C.c_int64), C.c_void_p,
                                             C.c_void_p]),
     "evolve_b_guard_layer": (C.c_int, [_FV3, _FV3, C.c_double, _D3, _I32_3, C.c_void_p]),
+    "evolve_b_ckc": (C.c_int, [_FV3, _FV3, C.c_double, C.c_double * 5, C.c_double * 5, C.c_double * 5, C.c_void_p]),
+    "ckc_stencil_coefficients": (None, [_D3, C.c_double * 5, C.c_double * 5, C.c_double * 5]),
+    "ckc_max_dt": (C.c_double, [_D3]),
     "apply_pec_rho": (C.c_int, [_PFV, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "shift_field_window": (C.c_int, [_PFV, C.c_void_p, C.c_int32, C.c_int32, _I3, C.c_void_p]),
     "laser_push": (C.c_int, [_PPV, C.POINTER(LaserPushParams), C.c_double, C.c_double, C.c_void_p]),

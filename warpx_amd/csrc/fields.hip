@@ -589,6 +589,67 @@ unpack_kernel(DevF f, BoxN box, const double* __restrict__ buf, int mode) {
     }
 }
 
+// ---- algo.maxwell_solver = ckc ---------------------------------------------------------------------------------
+// CartesianCKCAlgorithm::UpwardDx / UpwardDy / UpwardDz (CartesianCKCAlgorithm.H:129-160,183-214,237-272), term by
+// term in the reference's order (this file is compiled without FMA contraction: bit-identical to the CPU path).
+struct CkcCoefs { double x[5], y[5], z[5]; };
+
+__device__ __forceinline__ double ckc_up_x(const DevF& F, const double* c, int i, int j, int k) {
+    const double alphax = c[1], betaxy = c[2], betaxz = c[3], gammax = c[4];
+    return alphax * (F(i + 1, j, k) - F(i, j, k))
+         + betaxy * (F(i + 1, j + 1, k) - F(i, j + 1, k)
+                  +  F(i + 1, j - 1, k) - F(i, j - 1, k))
+         + betaxz * (F(i + 1, j, k + 1) - F(i, j, k + 1)
+                  +  F(i + 1, j, k - 1) - F(i, j, k - 1))
+         + gammax * (F(i + 1, j + 1, k + 1) - F(i, j + 1, k + 1)
+                  +  F(i + 1, j - 1, k + 1) - F(i, j - 1, k + 1)
+                  +  F(i + 1, j + 1, k - 1) - F(i, j + 1, k - 1)
+                  +  F(i + 1, j - 1, k - 1) - F(i, j - 1, k - 1));
+}
+__device__ __forceinline__ double ckc_up_y(const DevF& F, const double* c, int i, int j, int k) {
+    const double alphay = c[1], betayz = c[2], betayx = c[3], gammay = c[4];
+    return alphay * (F(i, j + 1, k) - F(i, j, k))
+         + betayx * (F(i + 1, j + 1, k) - F(i + 1, j, k)
+                  +  F(i - 1, j + 1, k) - F(i - 1, j, k))
+         + betayz * (F(i, j + 1, k + 1) - F(i, j, k + 1)
+                  +  F(i, j + 1, k - 1) - F(i, j, k - 1))
+         + gammay * (F(i + 1, j + 1, k + 1) - F(i + 1, j, k + 1)
+                  +  F(i - 1, j + 1, k + 1) - F(i - 1, j, k + 1)
+                  +  F(i + 1, j + 1, k - 1) - F(i + 1, j, k - 1)
+                  +  F(i - 1, j + 1, k - 1) - F(i - 1, j, k - 1));
+}
+__device__ __forceinline__ double ckc_up_z(const DevF& F, const double* c, int i, int j, int k) {
+    const double alphaz = c[1], betazx = c[2], betazy = c[3], gammaz = c[4];
+    return alphaz * (F(i, j, k + 1) - F(i, j, k))
+         + betazx * (F(i + 1, j, k + 1) - F(i + 1, j, k)
+                  +  F(i - 1, j, k + 1) - F(i - 1, j, k))
+         + betazy * (F(i, j + 1, k + 1) - F(i, j + 1, k)
+                  +  F(i, j - 1, k + 1) - F(i, j - 1, k))
+         + gammaz * (F(i + 1, j + 1, k + 1) - F(i + 1, j + 1, k)
+                  +  F(i - 1, j + 1, k + 1) - F(i - 1, j + 1, k)
+                  +  F(i + 1, j - 1, k + 1) - F(i + 1, j - 1, k)
+                  +  F(i - 1, j - 1, k + 1) - F(i - 1, j - 1, k));
+}
+
+__device__ inline bool in_box(const Box3& b, int i, int j, int k) {
+    return i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1] && k >= b.lo[2] && k < b.hi[2];
+}
+
+// EvolveBCartesian<CartesianCKCAlgorithm> (EvolveB.cpp:164-186).  First correct version: one lane per point of the
+// union of the three valid boxes, i fastest (coalesced rows; the 3 x 18 neighbour reads of a point are served by
+// L1/L2: each E value is read by up to 16 points of three components).  Not tuned: no MI355X has timed it yet.
+__global__ void __launch_bounds__(256)
+evolve_b_ckc_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, Box3 bbx, Box3 bby, Box3 bbz,
+                    double dt, CkcCoefs c) {
+    const int i = ub.lo[0] + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int j = ub.lo[1] + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+    const int k = ub.lo[2] + (int)blockIdx.z;
+    if (i >= ub.hi[0] || j >= ub.hi[1]) return;
+    if (in_box(bbx, i, j, k)) Bx(i, j, k) += dt * ckc_up_z(Ey, c.z, i, j, k) - dt * ckc_up_y(Ez, c.y, i, j, k);
+    if (in_box(bby, i, j, k)) By(i, j, k) += dt * ckc_up_x(Ez, c.x, i, j, k) - dt * ckc_up_z(Ex, c.z, i, j, k);
+    if (in_box(bbz, i, j, k)) Bz(i, j, k) += dt * ckc_up_y(Ex, c.y, i, j, k) - dt * ckc_up_x(Ey, c.x, i, j, k);
+}
+
 static inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
     long g = (total + block - 1) / block;
     if (g < 1) g = 1;
@@ -691,6 +752,63 @@ wxa_status wxa_evolve_b_guard_layer(const wxa_field_view E[3], const wxa_field_v
                                dinv[0], dinv[1], dinv[2]);
         }
     }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+// CartesianCKCAlgorithm::InitializeStencilCoefficients, 3-D branch (CartesianCKCAlgorithm.H:36-101)
+void wxa_ckc_stencil_coefficients(const double cell_size[3], double cx[5], double cy[5], double cz[5]) {
+    const double inv_dx = 1. / cell_size[0], inv_dy = 1. / cell_size[1], inv_dz = 1. / cell_size[2];
+    const double delta = std::max({inv_dx, inv_dy, inv_dz});
+    const double rx = (inv_dx / delta) * (inv_dx / delta);
+    const double ry = (inv_dy / delta) * (inv_dy / delta);
+    const double rz = (inv_dz / delta) * (inv_dz / delta);
+    const double beta = 0.125 * (1. - rx * ry * rz / (ry * rz + rz * rx + rx * ry));
+    const double betaxy = ry * beta * inv_dx, betaxz = rz * beta * inv_dx;
+    const double betayx = rx * beta * inv_dy, betayz = rz * beta * inv_dy;
+    const double betazx = rx * beta * inv_dz, betazy = ry * beta * inv_dz;
+    const double inv_r_fac = (1. / (ry * rz + rz * rx + rx * ry));
+    const double gammax = ry * rz * (0.0625 - 0.125 * ry * rz * inv_r_fac);
+    const double gammay = rx * rz * (0.0625 - 0.125 * rx * rz * inv_r_fac);
+    const double gammaz = rx * ry * (0.0625 - 0.125 * rx * ry * inv_r_fac);
+    const double alphax = (1. - 2. * ry * beta - 2. * rz * beta - 4. * gammax) * inv_dx;
+    const double alphay = (1. - 2. * rx * beta - 2. * rz * beta - 4. * gammay) * inv_dy;
+    const double alphaz = (1. - 2. * rx * beta - 2. * ry * beta - 4. * gammaz) * inv_dz;
+    cx[0] = inv_dx; cx[1] = alphax; cx[2] = betaxy; cx[3] = betaxz; cx[4] = gammax * inv_dx;
+    cy[0] = inv_dy; cy[1] = alphay; cy[2] = betayz; cy[3] = betayx; cy[4] = gammay * inv_dy;
+    cz[0] = inv_dz; cz[1] = alphaz; cz[2] = betazx; cz[3] = betazy; cz[4] = gammaz * inv_dz;
+}
+
+// CartesianCKCAlgorithm::ComputeMaxDt (:107-120)
+double wxa_ckc_max_dt(const double cell_size[3]) {
+    return std::min(cell_size[0], std::min(cell_size[1], cell_size[2])) / PhysConst::c;
+}
+
+wxa_status wxa_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3], double dt, const double cx[5],
+                            const double cy[5], const double cz[5], void* stream) {
+    WXA_REQUIRE(E && B && cx && cy && cz, "null argument");
+    for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
+    if (!yee_E(E) || !yee_B(B)) {
+        set_last_error("wxa_evolve_b_ckc: only the Yee staggering is supported");
+        return WXA_ERR_UNSUPPORTED;
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int d = 0; d < 3; ++d) WXA_REQUIRE(E[c].ng[d] >= 1, "the CKC update of B needs >= 1 guard point on E");
+    const Box3 bx = valid_box(B[0]), by = valid_box(B[1]), bz = valid_box(B[2]);
+    Box3 ub;
+    for (int d = 0; d < 3; ++d) {
+        ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
+        ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
+        if (ub.hi[d] <= ub.lo[d]) return WXA_OK;
+    }
+    CkcCoefs cc;
+    for (int n = 0; n < 5; ++n) { cc.x[n] = cx[n]; cc.y[n] = cy[n]; cc.z[n] = cz[n]; }
+    const dim3 block(64, 4);
+    const dim3 grid((unsigned)((ub.hi[0] - ub.lo[0] + 63) / 64), (unsigned)((ub.hi[1] - ub.lo[1] + 3) / 4),
+                    (unsigned)(ub.hi[2] - ub.lo[2]));
+    WXA_REQUIRE(grid.z <= 65535u, "more than 65535 planes");
+    hipLaunchKernelGGL(evolve_b_ckc_kernel, grid, block, 0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]),
+                       make_devf(E[2]), make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, dt, cc);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }

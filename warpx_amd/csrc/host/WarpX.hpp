@@ -37,9 +37,19 @@ struct guardCellManager {
 // Source/FieldSolver/FiniteDifferenceSolver/FiniteDifferenceSolver.{H,cpp} (Yee, Cartesian)
 class FiniteDifferenceSolver {
 public:
-    FiniteDifferenceSolver(WarpXContext* ctx, const std::array<amrex::Real, 3>& cell_size) : m_ctx(ctx) {
+    // FiniteDifferenceSolver::FiniteDifferenceSolver (FiniteDifferenceSolver.cpp:29-79): the stencil coefficients of
+    // the chosen algorithm (ElectromagneticSolverAlgo::Yee or ::CKC)
+    FiniteDifferenceSolver(WarpXContext* ctx, int fdtd_algo, const std::array<amrex::Real, 3>& cell_size)
+        : m_ctx(ctx), m_fdtd_algo(fdtd_algo) {
         // CartesianYeeAlgorithm::InitializeStencilCoefficients (CartesianYeeAlgorithm.H:29-43)
         for (int d = 0; d < 3; ++d) m_stencil_coefs[d] = 1.0 / cell_size[d];
+        if (m_fdtd_algo == WXA_SOLVER_CKC) {
+            if (!ctx->be->evolve_b_ckc) throw std::runtime_error("algo.maxwell_solver = ckc: not in this backend");
+            // CartesianCKCAlgorithm::InitializeStencilCoefficients (CartesianCKCAlgorithm.H:28-102)
+            ctx->be->ckc_stencil_coefficients(cell_size.data(), m_ckc_x.data(), m_ckc_y.data(), m_ckc_z.data());
+        } else if (m_fdtd_algo != WXA_SOLVER_YEE) {
+            throw std::runtime_error("algo.maxwell_solver: yee or ckc");
+        }
     }
     // FiniteDifferenceSolver.H:55-59
     void EvolveB(ablastr::fields::MultiFabRegister& fields, int lev, PatchType patch_type, amrex::Real dt) {
@@ -49,7 +59,11 @@ public:
         auto B = fields.get_alldirs(FieldType::Bfield_fp, lev);
         const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
         const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
-        check(m_ctx->be->evolve_b(Ev, Bv, dt, m_stencil_coefs.data(), m_ctx->stream), "evolve_b");
+        if (m_fdtd_algo == WXA_SOLVER_CKC)   // EvolveB.cpp:102-105
+            check(m_ctx->be->evolve_b_ckc(Ev, Bv, dt, m_ckc_x.data(), m_ckc_y.data(), m_ckc_z.data(), m_ctx->stream),
+                  "evolve_b_ckc");
+        else
+            check(m_ctx->be->evolve_b(Ev, Bv, dt, m_stencil_coefs.data(), m_ctx->stream), "evolve_b");
     }
     // FiniteDifferenceSolver.H:61-66
     void EvolveE(ablastr::fields::MultiFabRegister& fields, int lev, PatchType patch_type,
@@ -75,7 +89,9 @@ public:
 
 private:
     WarpXContext* m_ctx;
-    std::array<amrex::Real, 3> m_stencil_coefs{};
+    int m_fdtd_algo = WXA_SOLVER_YEE;
+    std::array<amrex::Real, 3> m_stencil_coefs{};          // 1/dx: Yee, and the downward differences of CKC
+    std::array<amrex::Real, 5> m_ckc_x{}, m_ckc_y{}, m_ckc_z{};
 };
 
 class WarpX {
@@ -172,17 +188,23 @@ public:
             if (cfg.nbricks[d] == 1 && m_comm->periodic(d) &&
                 m_ctx.brick_box.length(d) < 2 * guard_cells.ng_alloc_J[d] + 1)
                 throw std::runtime_error("periodic direction shorter than twice the guard depth");
-        m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, m_ctx.dx);
+        m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, cfg.maxwell_solver, m_ctx.dx);
         sort_intervals = cfg.sort_interval;
         m_ctx.sort_intervals_on = sort_intervals > 0;
     }
 
-    // Source/Evolve/WarpXComputeDt.cpp:41-102 with CartesianYeeAlgorithm::ComputeMaxDt (:48-56)
+    // Source/Evolve/WarpXComputeDt.cpp:41-102 with CartesianYeeAlgorithm::ComputeMaxDt (:48-56) or
+    // CartesianCKCAlgorithm::ComputeMaxDt (CartesianCKCAlgorithm.H:107-120)
     void ComputeDt() {
         constexpr double c = 299'792'458.;
         const auto& dx = m_ctx.dx;
-        const amrex::Real deltat =
-            m_cfg.cfl * 1.0 / (std::sqrt(1.0 / (dx[0] * dx[0]) + 1.0 / (dx[1] * dx[1]) + 1.0 / (dx[2] * dx[2])) * c);
+        amrex::Real deltat;
+        if (m_cfg.maxwell_solver == WXA_SOLVER_CKC) {
+            if (!m_be->ckc_max_dt) throw std::runtime_error("algo.maxwell_solver = ckc: not in this backend");
+            deltat = m_cfg.cfl * m_be->ckc_max_dt(dx.data());
+        } else {
+            deltat = m_cfg.cfl * 1.0 / (std::sqrt(1.0 / (dx[0] * dx[0]) + 1.0 / (dx[1] * dx[1]) + 1.0 / (dx[2] * dx[2])) * c);
+        }
         dt.assign(1, deltat);
     }
 
@@ -289,7 +311,9 @@ public:
         // :433 FillBoundaryE(ng_FieldSolver, sync) is not issued: the Yee update of B reads no guard point of E,
         // the copies of a shared nodal plane are computed from bit-identical operands (so the sync changes
         // nothing), and FillBoundaryE/B(ng_FieldGather) refills every guard before the next reader (the gather).
-        // Fields bit for bit the same (tests/test_multibrick_cpu.py).
+        // Fields bit for bit the same (tests/test_multibrick_cpu.py).  The CKC update of B does read guard points of
+        // E (the transverse neighbours of its extended differences): there the exchange is issued.
+        if (m_cfg.maxwell_solver == WXA_SOLVER_CKC) FillBoundaryE(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);
         EvolveB(0.5 * dt[0], DtType::SecondHalf);                // :437
     }
 
@@ -303,7 +327,9 @@ public:
     // (the tiles that touch no face of the brick read no guard point; EvolveE is the first reader of the summed J)
     void SetUpHaloOverlap(bool want) {
         // a wall's boundary kernel owns the guards behind it; WXA_NO_GUARD_LAYER=1 brings the exchange back (debugging)
-        m_grown_b = !m_any_pec && m_be->evolve_b_guard_layer != nullptr && !std::getenv("WXA_NO_GUARD_LAYER");
+        // (the guard-layer kernel is the Yee update: with CKC the reference's exchange stays)
+        m_grown_b = !m_any_pec && m_be->evolve_b_guard_layer != nullptr && m_cfg.maxwell_solver == WXA_SOLVER_YEE &&
+                    !std::getenv("WXA_NO_GUARD_LAYER");
         m_overlap = false;
         bool any_split = false;
         for (int d = 0; d < 3; ++d) any_split = any_split || !m_comm->self_periodic(d);

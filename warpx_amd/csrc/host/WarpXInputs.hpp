@@ -323,8 +323,12 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     // ---- algorithms (WarpX.cpp:1100-1330) with the reference's defaults ----
     cfg.cfl = 0.999;                                            // WarpX.H: cfl
     pp.queryWithParser("warpx.cfl", cfg.cfl);
-    if (pp.query_word("algo.maxwell_solver", w) && w != "yee")
-        throw std::runtime_error("inputs: algo.maxwell_solver = " + w + " is not on this path (yee)");
+    cfg.maxwell_solver = WXA_SOLVER_YEE;
+    if (pp.query_word("algo.maxwell_solver", w)) {
+        if (w == "ckc") cfg.maxwell_solver = WXA_SOLVER_CKC;
+        else if (w != "yee")
+            throw std::runtime_error("inputs: algo.maxwell_solver = " + w + " is not on this path (yee, ckc)");
+    }
     cfg.grid_type = WXA_GRID_STAGGERED;
     if (pp.query_word("warpx.grid_type", w) && w != "staggered")
         throw std::runtime_error("inputs: warpx.grid_type = " + w + " is not on this path (staggered)");

@@ -26,6 +26,11 @@ struct Backend {
     // first guard layer of B from the guards already present (instead of FillBoundaryB after the update)
     int (*evolve_b_guard_layer)(const wxa_field_view*, const wxa_field_view*, double, const double*, const int32_t* grow,
                                 void*);
+    // algo.maxwell_solver = ckc: stencil coefficients, time-step limit, update of B (wxa_evolve_b_ckc)
+    void (*ckc_stencil_coefficients)(const double* cell_size, double* cx, double* cy, double* cz);
+    double (*ckc_max_dt)(const double* cell_size);
+    int (*evolve_b_ckc)(const wxa_field_view*, const wxa_field_view*, double, const double* cx, const double* cy,
+                        const double* cz, void*);
     // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace
     int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);

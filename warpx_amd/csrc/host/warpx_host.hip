@@ -74,6 +74,10 @@ const Backend* hip_backend() {
             return wxa_evolve_b(E, B, dt, di, st); };
         b.evolve_e = [](const wxa_field_view* E, const wxa_field_view* B, const wxa_field_view* J, double dt,
                         const double* di, void* st) -> int { return wxa_evolve_e(E, B, J, dt, di, st); };
+        b.ckc_stencil_coefficients = wxa_ckc_stencil_coefficients;
+        b.ckc_max_dt = wxa_ckc_max_dt;
+        b.evolve_b_ckc = [](const wxa_field_view* E, const wxa_field_view* B, double dt, const double* cx, const double* cy,
+                            const double* cz, void* st) -> int { return wxa_evolve_b_ckc(E, B, dt, cx, cy, cz, st); };
         b.gather_push = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
                            const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, int move,
                            void* ws, void* st) -> int {

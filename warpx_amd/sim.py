@@ -22,7 +22,7 @@ class WarpXSim:
                  use_filter=0, cfl=1.0, sort_interval=-1, nbricks=(1, 1, 1), coord=(0, 0, 0),
                  comm: _capi.Comm | None = None, field_boundary_lo=(0, 0, 0), field_boundary_hi=(0, 0, 0),
                  particle_boundary_lo=(0, 0, 0), particle_boundary_hi=(0, 0, 0),
-                 grid_type=_capi.GRID_STAGGERED, overlap_halo=0):
+                 grid_type=_capi.GRID_STAGGERED, overlap_halo=0, maxwell_solver=_capi.SOLVER_YEE):
         self.lib = lib
         self.on_device = lib.prefix == "wxa_"
         cfg = _capi.SimConfig()
@@ -49,6 +49,7 @@ class WarpXSim:
         cfg.use_filter = int(use_filter)
         cfg.sort_interval = int(sort_interval)
         cfg.grid_type = int(grid_type)   # collocated: CPU restatement only
+        cfg.maxwell_solver = int(maxwell_solver)   # algo.maxwell_solver: SOLVER_YEE or SOLVER_CKC
         cfg.overlap_halo = int(overlap_halo)
         self.cfg = cfg
         self._comm = comm  # keep the callbacks alive
