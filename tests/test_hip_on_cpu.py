@@ -82,3 +82,19 @@ def test_bricks_over_gloo_with_the_hip_kernels(tmp_path):
     assert rep["np_total"] == rep["np_ref"] and rep["inside"] and rep["exchanges"] > 0
     assert all(err < 1e-10 for err in rep["errors"].values()), rep["errors"]
     assert rep["ekin_rel"] < 1e-11 and rep["abs_p_rel"] < 1e-11
+
+
+def test_bench_control_flow_on_the_cpu_execution_model():
+    """bench.py, unmodified, through scripts/bench_on_cpu.py (tiny grid): the JSON line carries the contract's keys.
+    A dry run of the control flow only -- the numbers mean nothing."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_on_cpu.py"), "--ncell", "16", "--steps", "2",
+                        "--warmup", "1", "--preroll", "2", "--no-cpu-baseline"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "kernels"):
+        assert key in line, key
+    assert line["roofline"]["bound"] == "hbm" and line["config"]["workload"].startswith("3D uniform_plasma")
+    assert {"EvolveB", "EvolveE", "GatherAndPush", "CurrentDeposition"} <= set(line["kernels"])
