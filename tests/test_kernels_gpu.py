@@ -794,3 +794,52 @@ def test_evolve_b_ckc_bit_exact(oracle, product, cells):
     E0 = [FieldArray(NCELL, STAG[n], (0, 0, 0), DEV) for n in ("Ex", "Ey", "Ez")]
     with pytest.raises(_capi.WxaError):
         product.evolve_b_ckc(field_triplet(E0), field_triplet(Bd), dt, *cp, None)
+
+
+@UNVERIFIED
+def test_empty_inputs_are_no_ops(product):
+    """np = 0 through every per-particle entry point (a brick in vacuum, a species before injection): status OK,
+    nothing launched with an empty grid, fields untouched."""
+    import torch
+    ncell = (16, 16, 16)
+    E = H.clone_fields(H.random_fields(("Ex", "Ey", "Ez"), ncell, 4, 1), DEV, True)
+    B = H.clone_fields(H.random_fields(("Bx", "By", "Bz"), ncell, 4, 2), DEV, True)
+    J = H.clone_fields(H.random_fields(("jx", "jy", "jz"), ncell, 5, 3), DEV, True)
+    (rho,) = H.clone_fields(H.random_fields(("rho",), ncell, 5, 4), DEV, True)
+    before = [f.to_numpy() for f in J + [rho]]
+    g, dx = H.geom_for(ncell, 4)
+    gj, _ = H.geom_for(ncell, 5)
+    dt = H.yee_dt(dx)
+    room_a, room_b = ParticleArrays(4, DEV, with_id=True), ParticleArrays(4, DEV, with_id=True)
+    empty, out = room_a.view, room_b.view
+    empty.np = 0
+    out.np = 0
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    q, m = -plasma.Q_E, plasma.M_E
+    lo, hi = H.d3((-H.LX / 2,) * 3), H.d3((H.LX / 2,) * 3)
+    for order in (1, 2, 3):
+        for pusher in (_capi.PUSHER_BORIS, _capi.PUSHER_VAY):
+            product.gather_push(C.byref(empty), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt, order, 1, pusher, None)
+            product.push_p(C.byref(empty), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt, order, 1, pusher, None)
+        for algo in (_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT):
+            product.deposit_current(C.byref(empty), field_triplet(J), C.byref(gj), q, dt, -0.5 * dt, order, algo, ws, None)
+        product.deposit_charge(C.byref(empty), C.byref(rho.view), C.byref(gj), q, order, None)
+    product.enforce_periodic(C.byref(empty), lo, hi, H.i3((1, 1, 1)), None)
+    product.sort_particles_by_cell(C.byref(empty), C.byref(out), lo, H.d3(1.0 / dx), (C.c_int32 * 3)(0, 0, 0),
+                                   (C.c_int32 * 3)(*ncell), ws, None)
+    # (an empty sort records nothing: the tile kernels are not selected, the global-memory path sees np = 0)
+    product.deposit_current(C.byref(out), field_triplet(J), C.byref(gj), q, dt, -0.5 * dt, 3, _capi.DEPOSIT_ESIRKEPOV, ws, None)
+    cnt = (C.c_int64 * 6)()
+    lists = torch.zeros(6, dtype=torch.int32, device=DEV)
+    product.wrap_and_classify(C.byref(empty), 0, 0, lo, hi, H.i3((1, 1, 1)), lo, H.d3((0.0, H.LX / 2, 0.0)), H.i3((1, 0, 1)),
+                              lists.data_ptr(), 1, cnt, ws, None)
+    assert list(cnt) == [0] * 6
+    n_lost = C.c_int64(-1)
+    product.apply_particle_boundaries(C.byref(empty), lo, hi, (C.c_int32 * 3)(1, 0, 0), (C.c_int32 * 3)(1, 0, 0),
+                                      C.byref(n_lost), ws, None)
+    assert n_lost.value == 0
+    _sync(product)
+    for f, a in zip(J + [rho], before):
+        assert np.array_equal(f.to_numpy(), a)
+    product.workspace_destroy(ws)
