@@ -41,7 +41,7 @@ typedef enum wxa_status {
 
 /* ---- enums crossing the boundary; same enumerator order as the reference
  *      (Source/Utils/WarpXAlgorithmSelection.H:72-84, Source/Evolve/WarpXDtType.H:10-15) */
-enum { WXA_PUSHER_BORIS = 0, WXA_PUSHER_VAY = 1 };
+enum { WXA_PUSHER_BORIS = 0, WXA_PUSHER_VAY = 1, WXA_PUSHER_HC = 2 };   /* algo.particle_pusher: boris, vay, higuera */
 enum { WXA_DEPOSIT_ESIRKEPOV = 0, WXA_DEPOSIT_DIRECT = 1 };
 enum { WXA_DT_FULL = 0, WXA_DT_FIRST_HALF = 1, WXA_DT_SECOND_HALF = 2 };
 
@@ -87,6 +87,11 @@ typedef struct wxa_workspace wxa_workspace;
 
 wxa_status wxa_workspace_create(wxa_workspace** ws);
 void       wxa_workspace_destroy(wxa_workspace* ws);
+/* particles.E_external_particle / particles.B_external_particle with *_ext_particle_init_style = constant
+ * (members m_E_external_particle / m_B_external_particle of the container,
+ * Source/Particles/PhysicalParticleContainer.cpp:2589-2596,2705-2710): added to the gathered fields by
+ * wxa_gather_push_ws / wxa_gather_push_part when they are handed this workspace.  Zero by default. */
+wxa_status wxa_workspace_set_external_particle_fields(wxa_workspace* ws, const double E[3], const double B[3]);
 
 const char* wxa_version(void);
 const char* wxa_last_error(void);
@@ -530,6 +535,9 @@ wxa_status wxa_sim_add_species(wxa_sim* s, double charge, double mass,
 /* WarpX::Evolve(numsteps): first step de-synchronises u by PushP(-dt/2),
  * the last one re-synchronises (WarpXEvolve.cpp:142-145,222-226). */
 wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
+/* particles.E_external_particle / particles.B_external_particle (constant external fields on the particles of
+ * species `id`; the reference keeps them per container and reads them from the `particles.` block) */
+wxa_status wxa_sim_set_external_particle_fields(wxa_sim* s, int32_t id, const double E[3], const double B[3]);
 /* ---- input-deck front end -------------------------------------------------
  * Builds the simulation a WarpX inputs file describes (amrex::ParmParse syntax, FILE includes,
  * my_constants, math expressions; WarpX::ReadParameters' defaults) for the parameters on this path:

@@ -332,7 +332,39 @@ inline void UpdateMomentumVay(double& ux, double& uy, double& uz,
     uz = s * (uzpr + tz * tu + uxpr * ty - uypr * tx);
 }
 
-// Source/Particles/Pusher/PushSelector.H:38-102 (Boris / Vay branches; ion_lev = 1)
+// Source/Particles/Pusher/UpdateMomentumHigueraCary.H:20-68
+inline void UpdateMomentumHigueraCary(double& ux, double& uy, double& uz,
+                                      const double Ex, const double Ey, const double Ez,
+                                      const double Bx, const double By, const double Bz,
+                                      const double q, const double m, const double dt) {
+    const double qmt = 0.5 * q * dt / m;
+    constexpr double invclight = 1. / PhysConst::c;
+    constexpr double invclightsq = 1. / (PhysConst::c * PhysConst::c);
+    const double umx = ux + qmt * Ex;
+    const double umy = uy + qmt * Ey;
+    const double umz = uz + qmt * Ez;
+    double gamma = 1. + (umx * umx + umy * umy + umz * umz) * invclightsq;
+    const double betax = qmt * Bx;
+    const double betay = qmt * By;
+    const double betaz = qmt * Bz;
+    const double betam = betax * betax + betay * betay + betaz * betaz;
+    const double sigma = gamma - betam;
+    const double ust = (umx * betax + umy * betay + umz * betaz) * invclight;
+    gamma = 1. / std::sqrt(0.5 * (sigma + std::sqrt(sigma * sigma + 4. * (betam + ust * ust))));
+    const double tx = gamma * betax;
+    const double ty = gamma * betay;
+    const double tz = gamma * betaz;
+    const double s = 1. / (1. + (tx * tx + ty * ty + tz * tz));
+    const double umt = umx * tx + umy * ty + umz * tz;
+    const double upx = s * (umx + umt * tx + umy * tz - umz * ty);
+    const double upy = s * (umy + umt * ty + umz * tx - umx * tz);
+    const double upz = s * (umz + umt * tz + umx * ty - umy * tx);
+    ux = upx + qmt * Ex + upy * tz - upz * ty;
+    uy = upy + qmt * Ey + upz * tx - upx * tz;
+    uz = upz + qmt * Ez + upx * ty - upy * tx;
+}
+
+// Source/Particles/Pusher/PushSelector.H:38-102 (Boris / Vay / Higuera-Cary branches; ion_lev = 1)
 inline void doParticleMomentumPush(double& ux, double& uy, double& uz,
                                    const double Ex, const double Ey, const double Ez,
                                    const double Bx, const double By, const double Bz,
@@ -344,6 +376,8 @@ inline void doParticleMomentumPush(double& ux, double& uy, double& uz,
         UpdateMomentumBoris(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, qp, m, dt);
     } else if (pusher_algo == WXA_PUSHER_VAY) {
         UpdateMomentumVay(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, qp, m, dt);
+    } else if (pusher_algo == WXA_PUSHER_HC) {
+        UpdateMomentumHigueraCary(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, qp, m, dt);
     }
 }
 

@@ -304,12 +304,16 @@ namespace {
 
 template <int O, int G, bool MOVE>
 void gather_push_impl(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
-                      const wxa_grid_geom* g, double q, double m, double dt, int pusher) {
+                      const wxa_grid_geom* g, double q, double m, double dt, int pusher, const double* ext) {
     const Arr ex(E[0]), ey(E[1]), ez(E[2]), bx(B[0]), by(B[1]), bz(B[2]);
+    // particles.E/B_external_particle (constant): the sums of the gather start from them
+    // (PhysicalParticleContainer.cpp:2589-2596,2705-2710)
+    const double e0 = ext ? ext[0] : 0., e1 = ext ? ext[1] : 0., e2 = ext ? ext[2] : 0.;
+    const double b0 = ext ? ext[3] : 0., b1 = ext ? ext[4] : 0., b2 = ext ? ext[5] : 0.;
 #pragma omp parallel for schedule(static)
     for (int64_t ip = 0; ip < p->np; ++ip) {
         double xp = p->x[ip], yp = p->y[ip], zp = p->z[ip];
-        double Exp = 0., Eyp = 0., Ezp = 0., Bxp = 0., Byp = 0., Bzp = 0.;  // external fields = 0
+        double Exp = e0, Eyp = e1, Ezp = e2, Bxp = b0, Byp = b1, Bzp = b2;
         doGatherShapeN<O, G>(xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, ex, ey, ez, bx, by, bz,
                              E[0].stag, E[1].stag, E[2].stag, B[0].stag, B[1].stag, B[2].stag,
                              g->dinv, g->xyzmin, g->lo);
@@ -325,17 +329,17 @@ void gather_push_impl(const wxa_particle_view* p, const wxa_field_view E[3], con
 template <bool MOVE>
 int gather_push_dispatch(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
                          const wxa_grid_geom* g, double q, double m, double dt, int order, int galerkin,
-                         int pusher) {
+                         int pusher, const double* ext = nullptr) {
     // Source/Particles/Gather/FieldGather.H:1590-1664 (runtime dispatch on nox, galerkin)
     if (galerkin) {
-        if (order == 1) gather_push_impl<1, 1, MOVE>(p, E, B, g, q, m, dt, pusher);
-        else if (order == 2) gather_push_impl<2, 1, MOVE>(p, E, B, g, q, m, dt, pusher);
-        else if (order == 3) gather_push_impl<3, 1, MOVE>(p, E, B, g, q, m, dt, pusher);
+        if (order == 1) gather_push_impl<1, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
+        else if (order == 2) gather_push_impl<2, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
+        else if (order == 3) gather_push_impl<3, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
         else return -1;
     } else {
-        if (order == 1) gather_push_impl<1, 0, MOVE>(p, E, B, g, q, m, dt, pusher);
-        else if (order == 2) gather_push_impl<2, 0, MOVE>(p, E, B, g, q, m, dt, pusher);
-        else if (order == 3) gather_push_impl<3, 0, MOVE>(p, E, B, g, q, m, dt, pusher);
+        if (order == 1) gather_push_impl<1, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
+        else if (order == 2) gather_push_impl<2, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
+        else if (order == 3) gather_push_impl<3, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
         else return -1;
     }
     return 0;
@@ -422,6 +426,14 @@ int orc_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const
                     const wxa_grid_geom* g, double q, double m, double dt, int order, int galerkin,
                     int pusher, void*) {
     return gather_push_dispatch<true>(p, E, B, g, q, m, dt, order, galerkin, pusher);
+}
+
+// PushPX (move != 0) / PushP with the container's constant external fields ext = {Ex,Ey,Ez,Bx,By,Bz} (or null)
+int orc_gather_push_ext(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                        const wxa_grid_geom* g, double q, double m, double dt, int order, int galerkin, int pusher,
+                        int move, const double* ext) {
+    return move ? gather_push_dispatch<true>(p, E, B, g, q, m, dt, order, galerkin, pusher, ext)
+                : gather_push_dispatch<false>(p, E, B, g, q, m, dt, order, galerkin, pusher, ext);
 }
 
 // Source/Particles/PhysicalParticleContainer.cpp:2368-2516 (PushP), kernel :2454-2511
@@ -1185,6 +1197,7 @@ struct Species {
     bool inject = false;
     wxa_plasma_injector inj{};
     double inj_pos = 0.0;   // WarpXParticleContainer::m_current_injection_position
+    double ext_eb[6] = {0, 0, 0, 0, 0, 0};   // m_E_external_particle, m_B_external_particle
     wxa_particle_view view() {
         wxa_particle_view p{};
         p.x = a[0].data(); p.y = a[1].data(); p.z = a[2].data(); p.w = a[3].data();
@@ -1436,8 +1449,8 @@ void push_p_all(orc_sim* s, double dt) {
     const wxa_grid_geom g = s->geom_for(s->ng_EB);
     for (auto& sp : s->species) {
         wxa_particle_view p = sp->view();
-        orc_push_p(&p, s->Ev, s->Bv, &g, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
-                   s->cfg.particle_pusher, nullptr);
+        orc_gather_push_ext(&p, s->Ev, s->Bv, &g, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
+                            s->cfg.particle_pusher, /*move=*/0, sp->ext_eb);
     }
 }
 
@@ -1452,8 +1465,8 @@ void one_step_nosub(orc_sim* s) {
         wxa_particle_view p = sp->view();
         {   // PhysicalParticleContainer::Evolve :1961 PushPX
             Tic t(s, 0);
-            orc_gather_push(&p, s->Ev, s->Bv, &gEB, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
-                            s->cfg.particle_pusher, nullptr);
+            orc_gather_push_ext(&p, s->Ev, s->Bv, &gEB, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
+                                s->cfg.particle_pusher, /*move=*/1, sp->ext_eb);
         }
         {   // :2029-2038 DepositCurrent with relative_time = -0.5*dt
             Tic t(s, 1);
@@ -1686,6 +1699,12 @@ int orc_sim_set_injection(orc_sim* s, int32_t id, const wxa_plasma_injector* inj
     sp.inject = continuous != 0;
     sp.inj_pos = s->mw_on ? s->phi[s->mw_dir] : 0.0;
     if (add_initial) add_plasma(s, sp, s->plo, s->phi);
+    return 0;
+}
+
+int orc_sim_set_external_particle_fields(orc_sim* s, int32_t id, const double E[3], const double B[3]) {
+    if (!s || !E || !B || id < 0 || id >= (int32_t)s->species.size()) return -1;
+    for (int d = 0; d < 3; ++d) { s->species[id]->ext_eb[d] = E[d]; s->species[id]->ext_eb[3 + d] = B[d]; }
     return 0;
 }
 

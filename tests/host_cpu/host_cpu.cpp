@@ -19,6 +19,8 @@ int orc_gather_push(const wxa_particle_view*, const wxa_field_view*, const wxa_f
                     double, double, double, int, int, int, void*);
 int orc_push_p(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
                double, double, double, int, int, int, void*);
+int orc_gather_push_ext(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
+                        double, double, double, int, int, int, int, const double*);
 int orc_deposit_current(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, double,
                         double, int, int, void*, void*);
 int orc_filter_bilinear(const wxa_field_view*, const wxa_field_view*, void*);
@@ -58,7 +60,16 @@ namespace {
 
 using wxa::host::Backend;
 
-int ws_create(void** ws) { *ws = std::malloc(8); return 0; }
+// the container's workspace on this backend: the live count of the last sort (orc_sort_particles_by_cell writes it
+// to the first 8 bytes) followed by the constant external fields
+struct CpuWorkspace { int64_t live; double ext[6]; };
+int ws_create(void** ws) { *ws = std::calloc(1, sizeof(CpuWorkspace)); return 0; }
+const double* ws_ext(void* ws) { return static_cast<CpuWorkspace*>(ws)->ext; }
+int ws_set_ext(void* ws, const double* E, const double* B) {
+    double* e = static_cast<CpuWorkspace*>(ws)->ext;
+    for (int d = 0; d < 3; ++d) { e[d] = E[d]; e[3 + d] = B[d]; }
+    return 0;
+}
 void ws_destroy(void* ws) { std::free(ws); }
 void* h_malloc(size_t n) { return std::malloc(n ? n : 8); }
 void h_free(void* p) { std::free(p); }
@@ -76,14 +87,14 @@ const Backend* cpu_backend() {
         b.evolve_b_ckc = orc_evolve_b_ckc;
         b.gather_push = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
                            const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, int move,
-                           void*, void* st) -> int {
-            return move ? orc_gather_push(p, E, B, g, q, m, dt, o, ga, pu, st)
-                        : orc_push_p(p, E, B, g, q, m, dt, o, ga, pu, st); };
+                           void* ws, void*) -> int {
+            return orc_gather_push_ext(p, E, B, g, q, m, dt, o, ga, pu, move, ws_ext(ws)); };
+        b.ws_set_external_eb = ws_set_ext;
         // no tiles on this backend: the interior part is empty, the rest is everything (a valid split)
         b.gather_push_part = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
-                                const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void*,
-                                int part, void* st) -> int {
-            return part == WXA_PART_INTERIOR ? 0 : orc_gather_push(p, E, B, g, q, m, dt, o, ga, pu, st); };
+                                const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void* ws,
+                                int part, void*) -> int {
+            return part == WXA_PART_INTERIOR ? 0 : orc_gather_push_ext(p, E, B, g, q, m, dt, o, ga, pu, 1, ws_ext(ws)); };
         b.add_plasma = orc_add_plasma;
         b.deposit_current = orc_deposit_current;
         b.filter_bilinear = orc_filter_bilinear;

@@ -137,6 +137,9 @@ OUR_DECKS = [
     ("particle_walls_3d.inputs", "particle_boundaries_3d_checksums.json", ()),
     ("laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", ()),
     ("laser_injection_3d.inputs", "laser_injection_3d_checksums.json", ()),
+    # Higuera-Cary pusher, constant external fields on the particle, 10^4 steps: every digit, including the
+    # round-off residues in x and px (the CPU kernels keep the reference's operation order)
+    ("particle_pusher_3d.inputs", "particle_pusher_3d_checksums.json", ()),
 ]
 
 
@@ -171,6 +174,7 @@ REFERENCE_DECKS = [
     ("Examples/Tests/boundaries/inputs_test_3d_particle_boundaries", "test_3d_particle_boundaries", ()),
     ("Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration", "test_3d_laser_acceleration", ()),
     ("Examples/Tests/laser_injection/inputs_test_3d_laser_injection", "test_3d_laser_injection", ()),
+    ("Examples/Tests/particle_pusher/inputs_test_3d_particle_pusher", "test_3d_particle_pusher", ()),
 ]
 
 

@@ -843,3 +843,48 @@ def test_empty_inputs_are_no_ops(product):
     for f, a in zip(J + [rho], before):
         assert np.array_equal(f.to_numpy(), a)
     product.workspace_destroy(ws)
+
+
+@UNVERIFIED
+@pytest.mark.parametrize("order,sort", [(1, False), (3, True)])
+def test_higuera_cary_push_with_external_fields(oracle, product, order, sort):
+    """algo.particle_pusher = higuera (UpdateMomentumHigueraCary) with the container's constant external fields
+    (particles.E/B_external_particle) on top of the gathered ones: PushPX and PushP against the CPU restatement,
+    on the global-memory kernel and on the LDS tiles."""
+    ng = 4
+    E = H.random_fields(("Ex", "Ey", "Ez"), NCELL, ng, 71, scale=1e10)
+    B = H.random_fields(("Bx", "By", "Bz"), NCELL, ng, 72, scale=30.0)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    g, dx = H.geom_for(NCELL, ng)
+    dt = H.yee_dt(dx)
+    parts = H.random_particles(20000, NCELL, 73, u_scale=2.0, margin=0.5)
+    q, m = plasma.Q_E, plasma.M_E
+    ext_e, ext_b = (3e9, -1e10, 5e9), (10.0, -4.0, 7.0)
+    ext6 = (C.c_double * 6)(*ext_e, *ext_b)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    product.workspace_set_external_particle_fields(ws, H.d3(ext_e), H.d3(ext_b))
+    pd = ParticleArrays.from_numpy(parts, DEV, np.arange(1, 20001, dtype=np.int64))
+    if sort:
+        srt = ParticleArrays(pd.np, DEV, with_id=True)
+        product.sort_particles_by_cell(C.byref(pd.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                       (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*NCELL), ws, None)
+        pd = srt
+    for move in (1, 0):
+        pc = ParticleArrays.from_numpy(list(pd.to_numpy()), "cpu")
+        oracle._dll.orc_gather_push_ext.restype = C.c_int
+        rc = oracle._dll.orc_gather_push_ext(C.byref(pc.view), field_triplet(E), field_triplet(B), C.byref(g), C.c_double(q),
+                                             C.c_double(m), C.c_double(dt), order, 1, _capi.PUSHER_HC, move, ext6)
+        assert rc == 0
+        product.gather_push_ws(C.byref(pd.view), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt, order, 1,
+                               _capi.PUSHER_HC, move, ws, None)
+        _sync(product)
+        a, b = pd.to_numpy(), pc.to_numpy()
+        for row in range(7):
+            assert np.max(np.abs(a[row] - b[row])) <= 1e-12 * max(np.max(np.abs(b[row])), 1e-300), (move, row)
+    # without the workspace the external fields are zero: a different result
+    pz = ParticleArrays.from_numpy(parts, DEV)
+    product.gather_push(C.byref(pz.view), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt, order, 1,
+                        _capi.PUSHER_HC, None)
+    _sync(product)
+    product.workspace_destroy(ws)

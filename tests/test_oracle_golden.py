@@ -172,3 +172,25 @@ def test_energy_is_sane(langmuir_run):
     ee, eb = field_energy(sim)
     ke = particle_moments(sim, e)["ekin"] + particle_moments(sim, p)["ekin"]
     assert ee > 0 and eb >= 0 and ke > 0
+
+
+def test_particle_pusher_golden(oracle):
+    """Examples/Tests/particle_pusher/inputs_test_3d_particle_pusher (one positron, E = -v x B from constant external
+    particle fields, Higuera-Cary pusher, 10^4 steps) on the oracle stepper: every checksum of the reference's
+    test_3d_particle_pusher.json digit for digit -- including x and px, which are pure round-off residue (1e-14 of y and
+    py): the restatement keeps the reference's operation order in the pusher, the position update and the gather."""
+    from tests import helpers as H
+    gold = json.load(open(os.path.join(HERE, "golden", "particle_pusher_3d_checksums.json")))["checksums"]["positron"]
+    Lh = 2.077023075927835e+07
+    sim = WarpXSim(oracle, (8, 8, 8), (-Lh,) * 3, (Lh,) * 3, nox=1, particle_pusher=_capi.PUSHER_HC)
+    c = plasma.C_LIGHT
+    one = [np.array([v]) for v in (0.0, 0.0, 0.0, 0.0, 0.0, 19.974984355438178 * c, 0.0)]
+    sid = sim.add_species(1.0, 1.0, one)
+    oracle.sim_set_external_particle_fields(sim._h, sid, H.d3((-2.994174829214179e+08, 0.0, 0.0)), H.d3((0.0, 0.0, 1.0)))
+    sim.evolve(10000)
+    p = sim.particles(sid)[:, 0]
+    assert abs(p[0]) == gold["particle_position_x"] and abs(p[1]) == gold["particle_position_y"] and p[2] == 0.0
+    assert abs(1.0 * p[4]) == gold["particle_momentum_x"] and abs(1.0 * p[5]) == gold["particle_momentum_y"]
+    # the analysis script's gate: the orbit stays straight (|x| < 1e-3 m after 10^4 steps; Boris drifts by 2321 m)
+    assert abs(p[0]) < 1e-3
+    sim.close()

@@ -325,6 +325,9 @@ def test_picmi_langmuir_golden_on_gpu(oracle, product):
     ("particle_walls_3d.inputs", "particle_boundaries_3d_checksums.json", ()),
     ("laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", ()),
     ("laser_injection_3d.inputs", "laser_injection_3d_checksums.json", ()),
+    # Higuera-Cary, constant external fields, 10^4 steps: x and px are pure round-off residue (1e-14 of y and py),
+    # reproduced digit for digit by the CPU kernels but not by contracted / rsqrt device arithmetic
+    ("particle_pusher_3d.inputs", "particle_pusher_3d_checksums.json", ("particle_momentum_x", "particle_position_x")),
 ])
 def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden, skip):
     """tests/decks/*.inputs through wxa_sim_create_from_inputs, wxa_sim_evolve and wxa_sim_checksum_json on the HIP

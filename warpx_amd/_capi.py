@@ -117,7 +117,7 @@ class Comm(C.Structure):
     ]
 
 
-PUSHER_BORIS, PUSHER_VAY = 0, 1
+PUSHER_BORIS, PUSHER_VAY, PUSHER_HC = 0, 1, 2
 DEPOSIT_ESIRKEPOV, DEPOSIT_DIRECT = 0, 1
 BOUNDARY_PERIODIC, BOUNDARY_PEC = 0, 1
 PBOUNDARY_DEFAULT, PBOUNDARY_ABSORBING, PBOUNDARY_REFLECTING, PBOUNDARY_PERIODIC = 0, 1, 2, 3
@@ -191,11 +191,13 @@ _SIM_SIGS = {
     "sim_halo_overlap": (C.c_int32, [C.c_void_p]),
     "sim_set_moving_window": (C.c_int, [C.c_void_p, C.POINTER(MovingWindow)]),
     "sim_set_injection": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PlasmaInjector), C.c_int, C.c_int]),
+    "sim_set_external_particle_fields": (C.c_int, [C.c_void_p, C.c_int32, _D3, _D3]),
     "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
 }
 
 # product-only entry points
 _PRODUCT_SIGS = {
+    "workspace_set_external_particle_fields": (C.c_int, [C.c_void_p, _D3, _D3]),
     "workspace_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "workspace_destroy": (None, [C.c_void_p]),
     "last_error": (C.c_char_p, []),

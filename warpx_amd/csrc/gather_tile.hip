@@ -50,8 +50,7 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
                                                double Eyp, double Ezp, double Bxp, double Byp, double Bzp, double q,
                                                double m, double dt) {
     double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
-    if constexpr (PUSHER == WXA_PUSHER_BORIS) push_boris(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
-    else push_vay(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+    push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
     if constexpr (MOVE) {
         update_position(xp, yp, zp, ux, uy, uz, dt);
@@ -68,7 +67,7 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 template <int O, int G, int PUSHER, bool MOVE, int PART = 0>
 __global__ void __launch_bounds__(GT_THREADS)
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
-                        DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq) {
+                        DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext) {
     constexpr int N = GatherTileDims<G>::N;
     constexpr int NPTS = GatherTileDims<G>::NPTS;
     __shared__ double F[6 * NPTS];
@@ -123,14 +122,16 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const double Bzp = gather_rows<NC, NC, NN>(F + 5 * NPTS + jc + N * (kc + N * ln), N, N * N, s.sxc, s.syc, s.szn);
         const double Byp = gather_rows<NC, NN, NC>(F + 4 * NPTS + jc + N * (kn + N * lc), N, N * N, s.sxc, s.syn, s.szc);
         const double Bxp = gather_rows<NN, NC, NC>(F + 3 * NPTS + jn + N * (kc + N * lc), N, N * N, s.sxn, s.syc, s.szc);
-        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, Exp + ext.ex, Eyp + ext.ey, Ezp + ext.ez, Bxp + ext.bx, Byp + ext.by,
+                                     Bzp + ext.bz, q, m, dt);
     }
 }
 
 template <int O, int G, int PUSHER, bool MOVE>
 __global__ void __launch_bounds__(256)
 gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned* __restrict__ count, DevF Ex,
-                              DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Geom g, double q, double m, double dt) {
+                              DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Geom g, double q, double m, double dt,
+                              ExtEB ext) {
     const unsigned n = *count;
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const int ip = idx[t];
@@ -139,7 +140,8 @@ gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned*
         gather_shapes<O, G>(xp, yp, zp, g, s);
         double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
         gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
-        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, Exp + ext.ex, Eyp + ext.ey, Ezp + ext.ez, Bxp + ext.bx, Byp + ext.by,
+                                     Bzp + ext.bz, q, m, dt);
     }
 }
 
@@ -167,13 +169,14 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
     if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
     GatherStragglers sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p + 16};
+    const ExtEB ext = ext_of(ws);
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
 #define WXA_GT(O, G)                                                                                        \
     do {                                                                                                    \
         hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE, PART>), grid, block, 0, st, pv, offsets, ex, \
-                           ey, ez, bx, by, bz, g, tg, q, m, dt, sq);                                        \
+                           ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
-                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt);                          \
+                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);                     \
     } while (0)
     if (galerkin) {
         if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else WXA_GT(3, 1);
@@ -192,8 +195,12 @@ wxa_status gather_push_tiled(const wxa_particle_view* p, const wxa_field_view E[
         if (move) return launch<WXA_PUSHER_BORIS, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
         return launch<WXA_PUSHER_BORIS, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
     }
-    if (move) return launch<WXA_PUSHER_VAY, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
-    return launch<WXA_PUSHER_VAY, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    if (pusher == WXA_PUSHER_VAY) {
+        if (move) return launch<WXA_PUSHER_VAY, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+        return launch<WXA_PUSHER_VAY, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    }
+    if (move) return launch<WXA_PUSHER_HC, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    return launch<WXA_PUSHER_HC, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
 }
 
 // PushPX on one part of the tiles (part = 1 interior, 2 faces), see the kernel
@@ -204,8 +211,12 @@ wxa_status gather_push_tiled_part(const wxa_particle_view* p, const wxa_field_vi
         if (part == 1) return launch<WXA_PUSHER_BORIS, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
         return launch<WXA_PUSHER_BORIS, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
     }
-    if (part == 1) return launch<WXA_PUSHER_VAY, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
-    return launch<WXA_PUSHER_VAY, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    if (pusher == WXA_PUSHER_VAY) {
+        if (part == 1) return launch<WXA_PUSHER_VAY, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+        return launch<WXA_PUSHER_VAY, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    }
+    if (part == 1) return launch<WXA_PUSHER_HC, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    return launch<WXA_PUSHER_HC, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
 }
 
 }  // namespace wxa

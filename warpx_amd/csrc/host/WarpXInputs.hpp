@@ -344,7 +344,8 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     if (pp.query_word("algo.particle_pusher", w)) {
         if (w == "boris") cfg.particle_pusher = WXA_PUSHER_BORIS;
         else if (w == "vay") cfg.particle_pusher = WXA_PUSHER_VAY;
-        else throw std::runtime_error("inputs: algo.particle_pusher = " + w + " is not on this path (boris, vay)");
+        else if (w == "higuera") cfg.particle_pusher = WXA_PUSHER_HC;
+        else throw std::runtime_error("inputs: algo.particle_pusher = " + w + " is not on this path (boris, vay, higuera)");
     }
     // same shape factors in all directions with direct deposition and an EM solver (WarpX.cpp:1208-1214)
     cfg.galerkin = cfg.current_deposition == WXA_DEPOSIT_DIRECT ? 0 : 1;
@@ -438,9 +439,25 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
             throw std::runtime_error("inputs: " + style_key + " = " + w + " is not on this path");
         }
     }
-    for (const char* key : {"particles.E_ext_particle_init_style", "particles.B_ext_particle_init_style"})
-        if (pp.query_word(key, w) && w != "none" && w != "default")
-            throw std::runtime_error(std::string("inputs: ") + key + " is not on this path");
+    // particles.E/B_ext_particle_init_style = constant + particles.E/B_external_particle
+    // (MultiParticleContainer::ReadParameters, MultiParticleContainer.cpp:120-160): the same for every species
+    double ext_E[3] = {0, 0, 0}, ext_B[3] = {0, 0, 0};
+    bool any_ext = false;
+    {
+        const char* style[2] = {"particles.E_ext_particle_init_style", "particles.B_ext_particle_init_style"};
+        const char* value[2] = {"particles.E_external_particle", "particles.B_external_particle"};
+        double* dst[2] = {ext_E, ext_B};
+        for (int f = 0; f < 2; ++f) {
+            if (!pp.query_word(style[f], w) || w == "none" || w == "default") continue;
+            if (w != "constant")
+                throw std::runtime_error(std::string("inputs: ") + style[f] + " = " + w + " is not on this path (constant)");
+            std::vector<double> v;
+            if (!pp.queryArrWithParser(value[f], v) || v.size() != 3)
+                throw std::runtime_error(std::string("inputs: ") + value[f] + " needs three values");
+            for (int d = 0; d < 3; ++d) dst[f][d] = v[d];
+            any_ext = true;
+        }
+    }
 
     // ---- species (PlasmaInjector.cpp, PhysicalParticleContainer::AddParticles) ----
     const double c = 299'792'458.;
@@ -470,6 +487,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         pp.ignore_prefix(name + ".attribute.");
 
         const int sid = wx.GetPartContainer().AddSpecies(charge, mass);
+        if (any_ext) wx.GetPartContainer().GetParticleContainer(sid).SetExternalParticleFields(ext_E, ext_B);
         auto* pc = dynamic_cast<PhysicalParticleContainer*>(&wx.GetPartContainer().GetParticleContainer(sid));
         if (!pp.query_word(name + ".injection_style", w)) throw std::runtime_error("inputs: " + name + ".injection_style must be set");
         std::vector<double> cols[7];

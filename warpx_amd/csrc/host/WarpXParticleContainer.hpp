@@ -156,6 +156,13 @@ public:
         check(ctx->be->workspace_create(&m_ws), "workspace_create");
     }
     virtual ~WarpXParticleContainer() { if (m_ws) m_ctx->be->workspace_destroy(m_ws); }
+    // particles.E_external_particle / B_external_particle, *_ext_particle_init_style = constant
+    // (m_E_external_particle / m_B_external_particle, PhysicalParticleContainer.cpp:2589-2596): they live with the
+    // container's workspace, where the gather kernels find them
+    void SetExternalParticleFields(const double E[3], const double B[3]) {
+        if (!m_ctx->be->ws_set_external_eb) throw std::runtime_error("external particle fields: not in this backend");
+        check(m_ctx->be->ws_set_external_eb(m_ws, E, B), "ws_set_external_eb");
+    }
 
     // Source/Particles/WarpXParticleContainer.H:150-154
     virtual void Evolve(ablastr::fields::MultiFabRegister& fields, int lev, const std::string& current_fp_string,

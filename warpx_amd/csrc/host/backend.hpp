@@ -31,6 +31,8 @@ struct Backend {
     double (*ckc_max_dt)(const double* cell_size);
     int (*evolve_b_ckc)(const wxa_field_view*, const wxa_field_view*, double, const double* cx, const double* cy,
                         const double* cz, void*);
+    // constant external fields of the container that owns workspace `ws` (wxa_workspace_set_external_particle_fields)
+    int (*ws_set_external_eb)(void* ws, const double* E, const double* B);
     // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace
     int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);

@@ -74,6 +74,18 @@ inline int sim_set_moving_window(SimHandle* h, const wxa_moving_window* mw) {
     }
 }
 
+// particles.E_external_particle / B_external_particle (constant) for one species
+inline int sim_set_external_particle_fields(SimHandle* h, int32_t id, const double* E, const double* B) {
+    if (!h || !E || !B || id < 0 || id >= h->warpx->GetPartContainer().nSpecies()) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->GetPartContainer().GetParticleContainer(id).SetExternalParticleFields(E, B);
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
 // <species>.injection_style = NUniformPerCell (...): add_initial fills the current domain now
 // (PhysicalParticleContainer::InitData -> AddParticles -> AddPlasma), continuous keeps injecting behind a moving window
 inline int sim_set_injection(SimHandle* h, int32_t id, const wxa_plasma_injector* inj, int add_initial, int continuous) {
@@ -215,6 +227,9 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
                                int continuous) {                                                       \
         return (RET)wxa::host::sim_set_injection(reinterpret_cast<wxa::host::SimHandle*>(s), id, inj,    \
                                                  add_initial, continuous);                             \
+    }                                                                                                  \
+    RET PFX##sim_set_external_particle_fields(SIMTYPE* s, int32_t id, const double E[3], const double B[3]) { \
+        return (RET)wxa::host::sim_set_external_particle_fields(reinterpret_cast<wxa::host::SimHandle*>(s), id, E, B); \
     }                                                                                                  \
     RET PFX##sim_add_laser(SIMTYPE* s, const wxa_laser_antenna* la) {                                  \
         return (RET)wxa::host::sim_add_laser(reinterpret_cast<wxa::host::SimHandle*>(s), la);            \

@@ -74,6 +74,8 @@ const Backend* hip_backend() {
             return wxa_evolve_b(E, B, dt, di, st); };
         b.evolve_e = [](const wxa_field_view* E, const wxa_field_view* B, const wxa_field_view* J, double dt,
                         const double* di, void* st) -> int { return wxa_evolve_e(E, B, J, dt, di, st); };
+        b.ws_set_external_eb = [](void* ws, const double* E, const double* B) -> int {
+            return wxa_workspace_set_external_particle_fields(static_cast<wxa_workspace*>(ws), E, B); };
         b.ckc_stencil_coefficients = wxa_ckc_stencil_coefficients;
         b.ckc_max_dt = wxa_ckc_max_dt;
         b.evolve_b_ckc = [](const wxa_field_view* E, const wxa_field_view* B, double dt, const double* cx, const double* cy,

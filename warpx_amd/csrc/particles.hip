@@ -14,7 +14,7 @@ namespace wxa {
 template <int O, int G, int PUSHER, bool MOVE>
 __global__ void __launch_bounds__(256)
 gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Geom g, double q,
-                   double m, double dt) {
+                   double m, double dt, ExtEB ext) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= p.np) return;
     double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
@@ -23,10 +23,9 @@ gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, G
     double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
     gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
 
+    Exp += ext.ex; Eyp += ext.ey; Ezp += ext.ez; Bxp += ext.bx; Byp += ext.by; Bzp += ext.bz;
     double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
-    // doParticleMomentumPush (Source/Particles/Pusher/PushSelector.H:38-102), ion_lev = 1
-    if constexpr (PUSHER == WXA_PUSHER_BORIS) push_boris(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
-    else push_vay(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
+    push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
     if constexpr (MOVE) {
         update_position(xp, yp, zp, ux, uy, uz, dt);
@@ -451,13 +450,13 @@ pack_leavers_kernel(PV p, const int* __restrict__ list, long n, double* __restri
 template <int PUSHER, bool MOVE>
 static wxa_status launch_gather_push(const PV& pv, const wxa_field_view E[3], const wxa_field_view B[3],
                                      const Geom& g, double q, double m, double dt, int order, int galerkin,
-                                     hipStream_t st) {
+                                     const ExtEB& ext, hipStream_t st) {
     const DevF ex = make_devf(E[0]), ey = make_devf(E[1]), ez = make_devf(E[2]);
     const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
     const dim3 grid(blocks_for(pv.np)), block(256);
 #define WXA_GP(O, G)                                                                              \
     hipLaunchKernelGGL((gather_push_kernel<O, G, PUSHER, MOVE>), grid, block, 0, st, pv, ex, ey, ez, bx, by, \
-                       bz, g, q, m, dt)
+                       bz, g, q, m, dt, ext)
     if (galerkin) {
         if (order == 1) WXA_GP(1, 1); else if (order == 2) WXA_GP(2, 1); else WXA_GP(3, 1);
     } else {
@@ -476,7 +475,8 @@ static wxa_status check_gather_args(const wxa_particle_view* p, const wxa_field_
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
     WXA_REQUIRE(order >= 1 && order <= 3, "particle shape order must be 1..3");
     WXA_REQUIRE(galerkin == 0 || galerkin == 1, "galerkin must be 0 or 1");
-    WXA_REQUIRE(pusher == WXA_PUSHER_BORIS || pusher == WXA_PUSHER_VAY, "pusher must be Boris or Vay");
+    WXA_REQUIRE(pusher == WXA_PUSHER_BORIS || pusher == WXA_PUSHER_VAY || pusher == WXA_PUSHER_HC,
+                "pusher must be Boris, Vay or Higuera-Cary");
     if (!yee_E(E) || !yee_B(B)) {
         set_last_error("gather: only the Yee staggering is supported");
         return WXA_ERR_UNSUPPORTED;
@@ -489,6 +489,24 @@ static wxa_status check_gather_args(const wxa_particle_view* p, const wxa_field_
 using namespace wxa;
 
 extern "C" {
+
+// the global-memory kernel on `rest` with the external fields `ext`
+static wxa_status gather_push_global(const wxa_particle_view& rest, const wxa_field_view E[3], const wxa_field_view B[3],
+                                     const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
+                                     int pusher, int move, const ExtEB& ext, hipStream_t st) {
+    const PV pv = make_pv(rest);
+    const Geom g = make_geom(*geom);
+    if (pusher == WXA_PUSHER_BORIS) {
+        if (move) return launch_gather_push<WXA_PUSHER_BORIS, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+        return launch_gather_push<WXA_PUSHER_BORIS, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+    }
+    if (pusher == WXA_PUSHER_VAY) {
+        if (move) return launch_gather_push<WXA_PUSHER_VAY, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+        return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+    }
+    if (move) return launch_gather_push<WXA_PUSHER_HC, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+    return launch_gather_push<WXA_PUSHER_HC, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+}
 
 wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
                               const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
@@ -509,15 +527,7 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E
         rest = tail_view(*p, ws->sorted_np);
         if (rest.np == 0) return WXA_OK;
     }
-    const PV pv = make_pv(rest);
-    const Geom g = make_geom(*geom);
-    hipStream_t st = (hipStream_t)stream;
-    if (pusher == WXA_PUSHER_BORIS) {
-        if (move) return launch_gather_push<WXA_PUSHER_BORIS, true>(pv, E, B, g, q, m, dt, order, galerkin, st);
-        return launch_gather_push<WXA_PUSHER_BORIS, false>(pv, E, B, g, q, m, dt, order, galerkin, st);
-    }
-    if (move) return launch_gather_push<WXA_PUSHER_VAY, true>(pv, E, B, g, q, m, dt, order, galerkin, st);
-    return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, st);
+    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, move, ext_of(ws), (hipStream_t)stream);
 }
 
 wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
@@ -529,7 +539,7 @@ wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view
     if (p->np == 0) return WXA_OK;
     if (!gather_tile_available(ws, p)) {   // no tiles: the interior part is empty, the rest is everything
         if (part == WXA_PART_INTERIOR) return WXA_OK;
-        return wxa_gather_push_ws(p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, nullptr, stream);
+        return gather_push_global(*p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws), (hipStream_t)stream);
     }
     wxa_particle_view head = *p;
     head.np = ws->sorted_np;
@@ -540,7 +550,7 @@ wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view
     if (part == WXA_PART_INTERIOR) return WXA_OK;
     const wxa_particle_view rest = tail_view(*p, ws->sorted_np);   // arrivals since the sort may sit anywhere
     if (rest.np == 0) return WXA_OK;
-    return wxa_gather_push_ws(&rest, E, B, geom, q, m, dt, order, galerkin, pusher, 1, nullptr, stream);
+    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws), (hipStream_t)stream);
 }
 
 wxa_status wxa_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],

@@ -35,6 +35,12 @@ void wxa_workspace_destroy(wxa_workspace* ws) {
     delete ws;
 }
 
+wxa_status wxa_workspace_set_external_particle_fields(wxa_workspace* ws, const double E[3], const double B[3]) {
+    WXA_REQUIRE(ws && E && B, "null argument");
+    for (int d = 0; d < 3; ++d) { ws->ext_eb[d] = E[d]; ws->ext_eb[3 + d] = B[d]; }
+    return WXA_OK;
+}
+
 wxa_status wxa_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes) {
     WXA_REQUIRE(bytes >= 0 && (bytes == 0 || (dst_host && src_dev)), "bad copy arguments");
     if (bytes == 0) return WXA_OK;

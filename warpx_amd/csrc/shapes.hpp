@@ -177,6 +177,49 @@ __device__ __forceinline__ void push_vay(double& ux, double& uy, double& uz, con
     uz = s * (uzpr + tz * tu + uxpr * ty - uypr * tx);
 }
 
+// Source/Particles/Pusher/UpdateMomentumHigueraCary.H:20-68
+__device__ __forceinline__ void push_hc(double& ux, double& uy, double& uz, const double Ex, const double Ey,
+                                        const double Ez, const double Bx, const double By, const double Bz,
+                                        const double q, const double m, const double dt) {
+    const double qmt = 0.5 * q * dt / m;
+    constexpr double invclight = 1. / PhysConst::c;
+    constexpr double invclightsq = 1. / (PhysConst::c * PhysConst::c);
+    const double umx = ux + qmt * Ex, umy = uy + qmt * Ey, umz = uz + qmt * Ez;
+    double gamma = 1. + (umx * umx + umy * umy + umz * umz) * invclightsq;
+    const double betax = qmt * Bx, betay = qmt * By, betaz = qmt * Bz;
+    const double betam = betax * betax + betay * betay + betaz * betaz;
+    const double sigma = gamma - betam;
+    const double ust = (umx * betax + umy * betay + umz * betaz) * invclight;
+    gamma = 1. / sqrt(0.5 * (sigma + sqrt(sigma * sigma + 4. * (betam + ust * ust))));
+    const double tx = gamma * betax, ty = gamma * betay, tz = gamma * betaz;
+    const double s = 1. / (1. + (tx * tx + ty * ty + tz * tz));
+    const double umt = umx * tx + umy * ty + umz * tz;
+    const double upx = s * (umx + umt * tx + umy * tz - umz * ty);
+    const double upy = s * (umy + umt * ty + umz * tx - umx * tz);
+    const double upz = s * (umz + umt * tz + umx * ty - umy * tx);
+    ux = upx + qmt * Ex + upy * tz - upz * ty;
+    uy = upy + qmt * Ey + upz * tx - upx * tz;
+    uz = upz + qmt * Ez + upx * ty - upy * tx;
+}
+
+// doParticleMomentumPush (Source/Particles/Pusher/PushSelector.H:38-102), ion_lev = 1; the selector is a
+// template parameter of the kernels (uniform per launch)
+template <int PUSHER>
+__device__ __forceinline__ void push_momentum(double& ux, double& uy, double& uz, const double Ex, const double Ey,
+                                              const double Ez, const double Bx, const double By, const double Bz,
+                                              const double q, const double m, const double dt) {
+    if constexpr (PUSHER == WXA_PUSHER_BORIS) push_boris(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
+    else if constexpr (PUSHER == WXA_PUSHER_VAY) push_vay(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
+    else push_hc(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
+}
+
+// particles.E_external_particle / B_external_particle (constant): members of the container in the reference
+// (m_E_external_particle, PhysicalParticleContainer.cpp:2589-2596,2705-2710).  The reference starts the gather sums
+// from these values; here they are added to the gathered sums (same value, last-bit differences in the rounding).
+struct ExtEB {
+    double ex, ey, ez, bx, by, bz;
+};
+
 // Source/Particles/Pusher/UpdatePosition.H:24-45
 __device__ __forceinline__ void update_position(double& x, double& y, double& z, const double ux,
                                                 const double uy, const double uz, const double dt) {

@@ -3,6 +3,7 @@
 #define WXA_WORKSPACE_HPP_
 
 #include "common.hpp"
+#include "shapes.hpp"
 
 #define WXA_TILE 8   // tile edge (cells) of the tile-major cell sort and of the LDS-tile kernels
 
@@ -39,9 +40,16 @@ struct wxa_workspace {
     int32_t sort_cell_lo[3] = {0, 0, 0};
     double sort_plo[3] = {0, 0, 0};
     double sort_dinv[3] = {0, 0, 0};
+    // particles.E_external_particle / B_external_particle of the container that owns this workspace
+    // (wxa_workspace_set_external_particle_fields); added to the gathered fields in PushPX / PushP
+    double ext_eb[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace wxa {
+inline ExtEB ext_of(const wxa_workspace* ws) {
+    if (!ws) return ExtEB{0, 0, 0, 0, 0, 0};
+    return ExtEB{ws->ext_eb[0], ws->ext_eb[1], ws->ext_eb[2], ws->ext_eb[3], ws->ext_eb[4], ws->ext_eb[5]};
+}
 // LDS-tile deposition (deposit_tile.hip)
 bool deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p);
 wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_view J[3],
