@@ -41,7 +41,8 @@ typedef enum wxa_status {
 
 /* ---- enums crossing the boundary; same enumerator order as the reference
  *      (Source/Utils/WarpXAlgorithmSelection.H:72-84, Source/Evolve/WarpXDtType.H:10-15) */
-enum { WXA_PUSHER_BORIS = 0, WXA_PUSHER_VAY = 1, WXA_PUSHER_HC = 2 };   /* algo.particle_pusher: boris, vay, higuera */
+enum { WXA_PUSHER_BORIS = 0, WXA_PUSHER_VAY = 1, WXA_PUSHER_HC = 2,   /* algo.particle_pusher: boris, vay, higuera */
+       WXA_PUSHER_BORIS_RR = 3 };   /* <species>.do_classical_radiation_reaction = 1: Boris + radiation reaction */
 enum { WXA_DEPOSIT_ESIRKEPOV = 0, WXA_DEPOSIT_DIRECT = 1 };
 enum { WXA_DT_FULL = 0, WXA_DT_FIRST_HALF = 1, WXA_DT_SECOND_HALF = 2 };
 
@@ -538,6 +539,9 @@ wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
 /* particles.E_external_particle / particles.B_external_particle (constant external fields on the particles of
  * species `id`; the reference keeps them per container and reads them from the `particles.` block) */
 wxa_status wxa_sim_set_external_particle_fields(wxa_sim* s, int32_t id, const double E[3], const double B[3]);
+/* <species>.do_classical_radiation_reaction (PhysicalParticleContainer.cpp:330-340; PushSelector.H:60-87: the species is
+ * pushed by UpdateMomentumBorisWithRadiationReaction whatever algo.particle_pusher says) */
+wxa_status wxa_sim_set_radiation_reaction(wxa_sim* s, int32_t id, int32_t on);
 /* ---- input-deck front end -------------------------------------------------
  * Builds the simulation a WarpX inputs file describes (amrex::ParmParse syntax, FILE includes,
  * my_constants, math expressions; WarpX::ReadParameters' defaults) for the parameters on this path:

@@ -41,6 +41,7 @@ constexpr double ep0 = 8.8541878128e-12;
 constexpr double mu0 = 1.25663706212e-06;
 constexpr double q_e = 1.602176634e-19;
 constexpr double m_e = 9.1093837015e-31;
+constexpr double r_e = 2.817940326204929e-15;   // classical electron radius (constant.H:63)
 constexpr double m_p = 1.67262192369e-27;
 }
 
@@ -364,7 +365,43 @@ inline void UpdateMomentumHigueraCary(double& ux, double& uy, double& uz,
     uz = upz + qmt * Ez + upx * ty - upy * tx;
 }
 
-// Source/Particles/Pusher/PushSelector.H:38-102 (Boris / Vay / Higuera-Cary branches; ion_lev = 1)
+// Source/Particles/Pusher/UpdateMomentumBorisWithRadiationReaction.H:20-93
+inline void UpdateMomentumBorisWithRadiationReaction(double& ux, double& uy, double& uz,
+                                                     const double Ex, const double Ey, const double Ez,
+                                                     const double Bx, const double By, const double Bz,
+                                                     const double q, const double m, const double dt) {
+    const double ux_old = ux, uy_old = uy, uz_old = uz;
+    constexpr double inv_c2 = 1. / (PhysConst::c * PhysConst::c);
+    UpdateMomentumBoris(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
+    const double ux_n = (ux + ux_old) * 0.5;
+    const double uy_n = (uy + uy_old) * 0.5;
+    const double uz_n = (uz + uz_old) * 0.5;
+    const double gamma_n = std::sqrt(1. + (ux_n * ux_n + uy_n * uy_n + uz_n * uz_n) * inv_c2);
+    const double inv_gamma_n = 1.0 / gamma_n;
+    const double vx_n = ux_n * inv_gamma_n;
+    const double vy_n = uy_n * inv_gamma_n;
+    const double vz_n = uz_n * inv_gamma_n;
+    const double bx_n = vx_n / PhysConst::c;
+    const double by_n = vy_n / PhysConst::c;
+    const double bz_n = vz_n / PhysConst::c;
+    const double flx_q = (Ex + vy_n * Bz - vz_n * By);
+    const double fly_q = (Ey + vz_n * Bx - vx_n * Bz);
+    const double flz_q = (Ez + vx_n * By - vy_n * Bx);
+    const double fl_q2 = flx_q * flx_q + fly_q * fly_q + flz_q * flz_q;
+    const double bdotE = (bx_n * Ex + by_n * Ey + bz_n * Ez);
+    const double bdotE2 = bdotE * bdotE;
+    const double coeff = gamma_n * gamma_n * (fl_q2 - bdotE2);
+    const double q_over_mc = q / (m * PhysConst::c);
+    const double RRcoeff = (2.0 / 3.0) * PhysConst::r_e * q_over_mc * q_over_mc;
+    const double frx = RRcoeff * (PhysConst::c * (fly_q * Bz - flz_q * By) + bdotE * Ex - coeff * bx_n);
+    const double fry = RRcoeff * (PhysConst::c * (flz_q * Bx - flx_q * Bz) + bdotE * Ey - coeff * by_n);
+    const double frz = RRcoeff * (PhysConst::c * (flx_q * By - fly_q * Bx) + bdotE * Ez - coeff * bz_n);
+    ux += frx * dt;
+    uy += fry * dt;
+    uz += frz * dt;
+}
+
+// Source/Particles/Pusher/PushSelector.H:38-102 (Boris / Vay / Higuera-Cary / radiation-reaction branches; ion_lev = 1)
 inline void doParticleMomentumPush(double& ux, double& uy, double& uz,
                                    const double Ex, const double Ey, const double Ez,
                                    const double Bx, const double By, const double Bz,
@@ -378,6 +415,8 @@ inline void doParticleMomentumPush(double& ux, double& uy, double& uz,
         UpdateMomentumVay(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, qp, m, dt);
     } else if (pusher_algo == WXA_PUSHER_HC) {
         UpdateMomentumHigueraCary(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, qp, m, dt);
+    } else if (pusher_algo == WXA_PUSHER_BORIS_RR) {   // do_crr
+        UpdateMomentumBorisWithRadiationReaction(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, qp, m, dt);
     }
 }
 

@@ -1198,6 +1198,7 @@ struct Species {
     wxa_plasma_injector inj{};
     double inj_pos = 0.0;   // WarpXParticleContainer::m_current_injection_position
     double ext_eb[6] = {0, 0, 0, 0, 0, 0};   // m_E_external_particle, m_B_external_particle
+    bool do_crr = false;                     // do_classical_radiation_reaction
     wxa_particle_view view() {
         wxa_particle_view p{};
         p.x = a[0].data(); p.y = a[1].data(); p.z = a[2].data(); p.w = a[3].data();
@@ -1450,7 +1451,7 @@ void push_p_all(orc_sim* s, double dt) {
     for (auto& sp : s->species) {
         wxa_particle_view p = sp->view();
         orc_gather_push_ext(&p, s->Ev, s->Bv, &g, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
-                            s->cfg.particle_pusher, /*move=*/0, sp->ext_eb);
+                            sp->do_crr ? WXA_PUSHER_BORIS_RR : s->cfg.particle_pusher, /*move=*/0, sp->ext_eb);
     }
 }
 
@@ -1466,7 +1467,7 @@ void one_step_nosub(orc_sim* s) {
         {   // PhysicalParticleContainer::Evolve :1961 PushPX
             Tic t(s, 0);
             orc_gather_push_ext(&p, s->Ev, s->Bv, &gEB, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
-                                s->cfg.particle_pusher, /*move=*/1, sp->ext_eb);
+                                sp->do_crr ? WXA_PUSHER_BORIS_RR : s->cfg.particle_pusher, /*move=*/1, sp->ext_eb);
         }
         {   // :2029-2038 DepositCurrent with relative_time = -0.5*dt
             Tic t(s, 1);
@@ -1705,6 +1706,12 @@ int orc_sim_set_injection(orc_sim* s, int32_t id, const wxa_plasma_injector* inj
 int orc_sim_set_external_particle_fields(orc_sim* s, int32_t id, const double E[3], const double B[3]) {
     if (!s || !E || !B || id < 0 || id >= (int32_t)s->species.size()) return -1;
     for (int d = 0; d < 3; ++d) { s->species[id]->ext_eb[d] = E[d]; s->species[id]->ext_eb[3 + d] = B[d]; }
+    return 0;
+}
+
+int orc_sim_set_radiation_reaction(orc_sim* s, int32_t id, int32_t on) {
+    if (!s || id < 0 || id >= (int32_t)s->species.size()) return -1;
+    s->species[id]->do_crr = on != 0;
     return 0;
 }
 

@@ -140,6 +140,8 @@ OUR_DECKS = [
     # Higuera-Cary pusher, constant external fields on the particle, 10^4 steps: every digit, including the
     # round-off residues in x and px (the CPU kernels keep the reference's operation order)
     ("particle_pusher_3d.inputs", "particle_pusher_3d_checksums.json", ()),
+    # <species>.do_classical_radiation_reaction: Boris + radiation reaction in a constant external B
+    ("radiation_reaction_3d.inputs", "radiation_reaction_3d_checksums.json", ()),
 ]
 
 
@@ -175,6 +177,7 @@ REFERENCE_DECKS = [
     ("Examples/Physics_applications/laser_acceleration/inputs_test_3d_laser_acceleration", "test_3d_laser_acceleration", ()),
     ("Examples/Tests/laser_injection/inputs_test_3d_laser_injection", "test_3d_laser_injection", ()),
     ("Examples/Tests/particle_pusher/inputs_test_3d_particle_pusher", "test_3d_particle_pusher", ()),
+    ("Examples/Tests/radiation_reaction/inputs_test_3d_radiation_reaction", "test_3d_radiation_reaction", ()),
 ]
 
 

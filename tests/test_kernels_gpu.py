@@ -846,9 +846,11 @@ def test_empty_inputs_are_no_ops(product):
 
 
 @UNVERIFIED
-@pytest.mark.parametrize("order,sort", [(1, False), (3, True)])
-def test_higuera_cary_push_with_external_fields(oracle, product, order, sort):
-    """algo.particle_pusher = higuera (UpdateMomentumHigueraCary) with the container's constant external fields
+@pytest.mark.parametrize("order,sort,pusher", [(1, False, _capi.PUSHER_HC), (3, True, _capi.PUSHER_HC),
+                                               (3, True, _capi.PUSHER_BORIS_RR), (2, False, _capi.PUSHER_BORIS_RR)])
+def test_higuera_cary_push_with_external_fields(oracle, product, order, sort, pusher):
+    """algo.particle_pusher = higuera (UpdateMomentumHigueraCary) and the radiation-reaction pusher of
+    <species>.do_classical_radiation_reaction (UpdateMomentumBorisWithRadiationReaction) with the container's constant external fields
     (particles.E/B_external_particle) on top of the gathered ones: PushPX and PushP against the CPU restatement,
     on the global-memory kernel and on the LDS tiles."""
     ng = 4
@@ -874,10 +876,10 @@ def test_higuera_cary_push_with_external_fields(oracle, product, order, sort):
         pc = ParticleArrays.from_numpy(list(pd.to_numpy()), "cpu")
         oracle._dll.orc_gather_push_ext.restype = C.c_int
         rc = oracle._dll.orc_gather_push_ext(C.byref(pc.view), field_triplet(E), field_triplet(B), C.byref(g), C.c_double(q),
-                                             C.c_double(m), C.c_double(dt), order, 1, _capi.PUSHER_HC, move, ext6)
+                                             C.c_double(m), C.c_double(dt), order, 1, pusher, move, ext6)
         assert rc == 0
         product.gather_push_ws(C.byref(pd.view), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt, order, 1,
-                               _capi.PUSHER_HC, move, ws, None)
+                               pusher, move, ws, None)
         _sync(product)
         a, b = pd.to_numpy(), pc.to_numpy()
         for row in range(7):
@@ -885,6 +887,6 @@ def test_higuera_cary_push_with_external_fields(oracle, product, order, sort):
     # without the workspace the external fields are zero: a different result
     pz = ParticleArrays.from_numpy(parts, DEV)
     product.gather_push(C.byref(pz.view), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt, order, 1,
-                        _capi.PUSHER_HC, None)
+                        pusher, None)
     _sync(product)
     product.workspace_destroy(ws)

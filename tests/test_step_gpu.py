@@ -328,6 +328,7 @@ def test_picmi_langmuir_golden_on_gpu(oracle, product):
     # Higuera-Cary, constant external fields, 10^4 steps: x and px are pure round-off residue (1e-14 of y and py),
     # reproduced digit for digit by the CPU kernels but not by contracted / rsqrt device arithmetic
     ("particle_pusher_3d.inputs", "particle_pusher_3d_checksums.json", ("particle_momentum_x", "particle_position_x")),
+    ("radiation_reaction_3d.inputs", "radiation_reaction_3d_checksums.json", ()),
 ])
 def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden, skip):
     """tests/decks/*.inputs through wxa_sim_create_from_inputs, wxa_sim_evolve and wxa_sim_checksum_json on the HIP

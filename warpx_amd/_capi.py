@@ -117,7 +117,7 @@ class Comm(C.Structure):
     ]
 
 
-PUSHER_BORIS, PUSHER_VAY, PUSHER_HC = 0, 1, 2
+PUSHER_BORIS, PUSHER_VAY, PUSHER_HC, PUSHER_BORIS_RR = 0, 1, 2, 3
 DEPOSIT_ESIRKEPOV, DEPOSIT_DIRECT = 0, 1
 BOUNDARY_PERIODIC, BOUNDARY_PEC = 0, 1
 PBOUNDARY_DEFAULT, PBOUNDARY_ABSORBING, PBOUNDARY_REFLECTING, PBOUNDARY_PERIODIC = 0, 1, 2, 3
@@ -192,6 +192,7 @@ _SIM_SIGS = {
     "sim_set_moving_window": (C.c_int, [C.c_void_p, C.POINTER(MovingWindow)]),
     "sim_set_injection": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PlasmaInjector), C.c_int, C.c_int]),
     "sim_set_external_particle_fields": (C.c_int, [C.c_void_p, C.c_int32, _D3, _D3]),
+    "sim_set_radiation_reaction": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
 }
 

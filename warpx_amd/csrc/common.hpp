@@ -17,6 +17,7 @@ constexpr double ep0 = 8.8541878128e-12;
 constexpr double mu0 = 1.25663706212e-06;
 constexpr double q_e = 1.602176634e-19;
 constexpr double m_e = 9.1093837015e-31;
+constexpr double r_e = 2.817940326204929e-15;   // classical electron radius (constant.H:63)
 }
 
 void set_last_error(const char* fmt, ...);

@@ -199,8 +199,12 @@ wxa_status gather_push_tiled(const wxa_particle_view* p, const wxa_field_view E[
         if (move) return launch<WXA_PUSHER_VAY, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
         return launch<WXA_PUSHER_VAY, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
     }
-    if (move) return launch<WXA_PUSHER_HC, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
-    return launch<WXA_PUSHER_HC, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    if (pusher == WXA_PUSHER_HC) {
+        if (move) return launch<WXA_PUSHER_HC, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+        return launch<WXA_PUSHER_HC, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    }
+    if (move) return launch<WXA_PUSHER_BORIS_RR, true>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    return launch<WXA_PUSHER_BORIS_RR, false>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
 }
 
 // PushPX on one part of the tiles (part = 1 interior, 2 faces), see the kernel
@@ -215,8 +219,12 @@ wxa_status gather_push_tiled_part(const wxa_particle_view* p, const wxa_field_vi
         if (part == 1) return launch<WXA_PUSHER_VAY, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
         return launch<WXA_PUSHER_VAY, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
     }
-    if (part == 1) return launch<WXA_PUSHER_HC, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
-    return launch<WXA_PUSHER_HC, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    if (pusher == WXA_PUSHER_HC) {
+        if (part == 1) return launch<WXA_PUSHER_HC, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+        return launch<WXA_PUSHER_HC, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    }
+    if (part == 1) return launch<WXA_PUSHER_BORIS_RR, true, 1>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
+    return launch<WXA_PUSHER_BORIS_RR, true, 2>(p, E, B, geom, q, m, dt, order, galerkin, ws, st);
 }
 
 }  // namespace wxa

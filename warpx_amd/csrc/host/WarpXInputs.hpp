@@ -478,7 +478,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         if (charge != 0.0 && wx.any_reflecting_wall())
             throw std::runtime_error("inputs: charged species with a reflecting particle boundary are not on this path");
         for (const char* off : {".do_not_push", ".do_not_deposit", ".do_not_gather", ".do_field_ionization", ".do_qed_quantum_sync",
-                                ".do_qed_breit_wheeler", ".do_classical_radiation_reaction", ".do_backward_propagation",
+                                ".do_qed_breit_wheeler", ".do_backward_propagation",
                                 ".rigid_advance", ".initialize_self_fields", ".do_resampling"})
             if (pp.queryWithParser(name + off, flag) && flag)
                 throw std::runtime_error("inputs: " + name + off + " is not on this path");
@@ -488,6 +488,9 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
 
         const int sid = wx.GetPartContainer().AddSpecies(charge, mass);
         if (any_ext) wx.GetPartContainer().GetParticleContainer(sid).SetExternalParticleFields(ext_E, ext_B);
+        double crr = 0;
+        if (pp.queryWithParser(name + ".do_classical_radiation_reaction", crr) && crr != 0)
+            wx.GetPartContainer().GetParticleContainer(sid).SetRadiationReaction(true);
         auto* pc = dynamic_cast<PhysicalParticleContainer*>(&wx.GetPartContainer().GetParticleContainer(sid));
         if (!pp.query_word(name + ".injection_style", w)) throw std::runtime_error("inputs: " + name + ".injection_style must be set");
         std::vector<double> cols[7];

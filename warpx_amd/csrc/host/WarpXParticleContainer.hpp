@@ -159,6 +159,10 @@ public:
     // particles.E_external_particle / B_external_particle, *_ext_particle_init_style = constant
     // (m_E_external_particle / m_B_external_particle, PhysicalParticleContainer.cpp:2589-2596): they live with the
     // container's workspace, where the gather kernels find them
+    // <species>.do_classical_radiation_reaction: doParticleMomentumPush takes the radiation-reaction branch first,
+    // whatever algo.particle_pusher says (PushSelector.H:60-87)
+    void SetRadiationReaction(bool on) { m_do_crr = on; }
+    int pusher_algo() const { return m_do_crr ? WXA_PUSHER_BORIS_RR : (int)m_ctx->particle_pusher_algo; }
     void SetExternalParticleFields(const double E[3], const double B[3]) {
         if (!m_ctx->be->ws_set_external_eb) throw std::runtime_error("external particle fields: not in this backend");
         check(m_ctx->be->ws_set_external_eb(m_ws, E, B), "ws_set_external_eb");
@@ -366,6 +370,7 @@ protected:
     DeviceBuffer m_sendbuf, m_recvbuf, m_lists, m_arrival_lists[3];
     int64_t m_nretired = 0;            // retired by Redistribute since the last sort (still in the tile)
     void* m_ws = nullptr;
+    bool m_do_crr = false;
 
 public:
     amrex::ParticleReal charge, mass;
@@ -538,13 +543,13 @@ public:
         if (m_interior_pushed) {   // PushInterior ran on these particles already: the rest
             m_interior_pushed = false;
             check(m_ctx->be->gather_push_part(&p, E, B, &g, charge, mass, dt, m_ctx->nox,
-                                              m_ctx->galerkin_interpolation ? 1 : 0, (int)m_ctx->particle_pusher_algo, m_ws,
+                                              m_ctx->galerkin_interpolation ? 1 : 0, pusher_algo(), m_ws,
                                               WXA_PART_REST, m_ctx->stream),
                   "gather_push_part");
             return;
         }
         check(m_ctx->be->gather_push(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
-                                     (int)m_ctx->particle_pusher_algo, /*move=*/1, m_ws, m_ctx->stream),
+                                     pusher_algo(), /*move=*/1, m_ws, m_ctx->stream),
               "gather_push");
     }
     // PushPX of the particles that read no guard point of E and B (the interior tiles of the last sort), issued
@@ -560,7 +565,7 @@ public:
         const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
         const wxa_particle_view p = m_tile.view();
         check(m_ctx->be->gather_push_part(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
-                                          (int)m_ctx->particle_pusher_algo, m_ws, WXA_PART_INTERIOR, m_ctx->stream),
+                                          pusher_algo(), m_ws, WXA_PART_INTERIOR, m_ctx->stream),
               "gather_push_part");
         m_interior_pushed = true;
     }
@@ -575,7 +580,7 @@ public:
         const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
         const wxa_particle_view p = m_tile.view();
         check(m_ctx->be->gather_push(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
-                                     (int)m_ctx->particle_pusher_algo, /*move=*/0, m_ws, m_ctx->stream),
+                                     pusher_algo(), /*move=*/0, m_ws, m_ctx->stream),
               "push_p");
     }
 };

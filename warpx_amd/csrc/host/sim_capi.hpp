@@ -86,6 +86,12 @@ inline int sim_set_external_particle_fields(SimHandle* h, int32_t id, const doub
     }
 }
 
+inline int sim_set_radiation_reaction(SimHandle* h, int32_t id, int32_t on) {
+    if (!h || id < 0 || id >= h->warpx->GetPartContainer().nSpecies()) return WXA_ERR_INVALID_ARG;
+    h->warpx->GetPartContainer().GetParticleContainer(id).SetRadiationReaction(on != 0);
+    return WXA_OK;
+}
+
 // <species>.injection_style = NUniformPerCell (...): add_initial fills the current domain now
 // (PhysicalParticleContainer::InitData -> AddParticles -> AddPlasma), continuous keeps injecting behind a moving window
 inline int sim_set_injection(SimHandle* h, int32_t id, const wxa_plasma_injector* inj, int add_initial, int continuous) {
@@ -230,6 +236,9 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     }                                                                                                  \
     RET PFX##sim_set_external_particle_fields(SIMTYPE* s, int32_t id, const double E[3], const double B[3]) { \
         return (RET)wxa::host::sim_set_external_particle_fields(reinterpret_cast<wxa::host::SimHandle*>(s), id, E, B); \
+    }                                                                                                  \
+    RET PFX##sim_set_radiation_reaction(SIMTYPE* s, int32_t id, int32_t on) {                          \
+        return (RET)wxa::host::sim_set_radiation_reaction(reinterpret_cast<wxa::host::SimHandle*>(s), id, on); \
     }                                                                                                  \
     RET PFX##sim_add_laser(SIMTYPE* s, const wxa_laser_antenna* la) {                                  \
         return (RET)wxa::host::sim_add_laser(reinterpret_cast<wxa::host::SimHandle*>(s), la);            \

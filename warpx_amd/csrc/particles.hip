@@ -475,8 +475,8 @@ static wxa_status check_gather_args(const wxa_particle_view* p, const wxa_field_
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
     WXA_REQUIRE(order >= 1 && order <= 3, "particle shape order must be 1..3");
     WXA_REQUIRE(galerkin == 0 || galerkin == 1, "galerkin must be 0 or 1");
-    WXA_REQUIRE(pusher == WXA_PUSHER_BORIS || pusher == WXA_PUSHER_VAY || pusher == WXA_PUSHER_HC,
-                "pusher must be Boris, Vay or Higuera-Cary");
+    WXA_REQUIRE(pusher >= WXA_PUSHER_BORIS && pusher <= WXA_PUSHER_BORIS_RR,
+                "pusher must be Boris, Vay, Higuera-Cary or Boris with radiation reaction");
     if (!yee_E(E) || !yee_B(B)) {
         set_last_error("gather: only the Yee staggering is supported");
         return WXA_ERR_UNSUPPORTED;
@@ -504,8 +504,12 @@ static wxa_status gather_push_global(const wxa_particle_view& rest, const wxa_fi
         if (move) return launch_gather_push<WXA_PUSHER_VAY, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
         return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
     }
-    if (move) return launch_gather_push<WXA_PUSHER_HC, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
-    return launch_gather_push<WXA_PUSHER_HC, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+    if (pusher == WXA_PUSHER_HC) {
+        if (move) return launch_gather_push<WXA_PUSHER_HC, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+        return launch_gather_push<WXA_PUSHER_HC, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+    }
+    if (move) return launch_gather_push<WXA_PUSHER_BORIS_RR, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+    return launch_gather_push<WXA_PUSHER_BORIS_RR, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
 }
 
 wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],

@@ -202,6 +202,41 @@ __device__ __forceinline__ void push_hc(double& ux, double& uy, double& uz, cons
     uz = upz + qmt * Ez + upx * ty - upy * tx;
 }
 
+// Source/Particles/Pusher/UpdateMomentumBorisWithRadiationReaction.H:20-93
+__device__ __forceinline__ void push_boris_rr(double& ux, double& uy, double& uz, const double Ex, const double Ey,
+                                              const double Ez, const double Bx, const double By, const double Bz,
+                                              const double q, const double m, const double dt) {
+    const double ux_old = ux, uy_old = uy, uz_old = uz;
+    constexpr double inv_c2 = 1. / (PhysConst::c * PhysConst::c);
+    push_boris(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
+    const double ux_n = (ux + ux_old) * 0.5;
+    const double uy_n = (uy + uy_old) * 0.5;
+    const double uz_n = (uz + uz_old) * 0.5;
+    const double gamma_n = sqrt(1. + (ux_n * ux_n + uy_n * uy_n + uz_n * uz_n) * inv_c2);
+    const double inv_gamma_n = 1.0 / gamma_n;
+    const double vx_n = ux_n * inv_gamma_n;
+    const double vy_n = uy_n * inv_gamma_n;
+    const double vz_n = uz_n * inv_gamma_n;
+    const double bx_n = vx_n / PhysConst::c;
+    const double by_n = vy_n / PhysConst::c;
+    const double bz_n = vz_n / PhysConst::c;
+    const double flx_q = (Ex + vy_n * Bz - vz_n * By);
+    const double fly_q = (Ey + vz_n * Bx - vx_n * Bz);
+    const double flz_q = (Ez + vx_n * By - vy_n * Bx);
+    const double fl_q2 = flx_q * flx_q + fly_q * fly_q + flz_q * flz_q;
+    const double bdotE = (bx_n * Ex + by_n * Ey + bz_n * Ez);
+    const double bdotE2 = bdotE * bdotE;
+    const double coeff = gamma_n * gamma_n * (fl_q2 - bdotE2);
+    const double q_over_mc = q / (m * PhysConst::c);
+    const double RRcoeff = (2.0 / 3.0) * PhysConst::r_e * q_over_mc * q_over_mc;
+    const double frx = RRcoeff * (PhysConst::c * (fly_q * Bz - flz_q * By) + bdotE * Ex - coeff * bx_n);
+    const double fry = RRcoeff * (PhysConst::c * (flz_q * Bx - flx_q * Bz) + bdotE * Ey - coeff * by_n);
+    const double frz = RRcoeff * (PhysConst::c * (flx_q * By - fly_q * Bx) + bdotE * Ez - coeff * bz_n);
+    ux += frx * dt;
+    uy += fry * dt;
+    uz += frz * dt;
+}
+
 // doParticleMomentumPush (Source/Particles/Pusher/PushSelector.H:38-102), ion_lev = 1; the selector is a
 // template parameter of the kernels (uniform per launch)
 template <int PUSHER>
@@ -210,7 +245,8 @@ __device__ __forceinline__ void push_momentum(double& ux, double& uy, double& uz
                                               const double q, const double m, const double dt) {
     if constexpr (PUSHER == WXA_PUSHER_BORIS) push_boris(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
     else if constexpr (PUSHER == WXA_PUSHER_VAY) push_vay(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
-    else push_hc(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
+    else if constexpr (PUSHER == WXA_PUSHER_HC) push_hc(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
+    else push_boris_rr(ux, uy, uz, Ex, Ey, Ez, Bx, By, Bz, q, m, dt);
 }
 
 // particles.E_external_particle / B_external_particle (constant): members of the container in the reference
