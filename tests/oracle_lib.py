@@ -51,6 +51,14 @@ HIPCPU_LIB = os.path.join(HIPCPU_DIR, "libwarpx_amd_hipcpu.so")
 _hip_on_cpu = None
 
 
+def build_hip_on_cpu():
+    """Both builds of tests/hipcpu (plain and FMA-contracting), where the host clang of the ROCm install exists."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        return
+    for extra in ([], ["FMA=1"]):
+        subprocess.check_call(["make", "-C", HIPCPU_DIR, "-j8"] + extra, stdout=subprocess.DEVNULL)
+
+
 def load_hip_on_cpu():
     """The product's .hip sources, unmodified, compiled against the HIP-on-CPU execution model of
     tests/hipcpu (tests only; a logic check of the kernels and launches where there is no GPU)."""
