@@ -114,6 +114,15 @@ class WarpXSim:
         self.species.append((float(charge), float(mass)))
         return sid.value
 
+    def set_external_particle_fields(self, sid: int, E, B):
+        """particles.E_external_particle / B_external_particle (constant) for species `sid`."""
+        self.lib.sim_set_external_particle_fields(self._h, int(sid), (C.c_double * 3)(*map(float, E)),
+                                                  (C.c_double * 3)(*map(float, B)))
+
+    def set_radiation_reaction(self, sid: int, on=True):
+        """<species>.do_classical_radiation_reaction: Boris + radiation reaction for species `sid`."""
+        self.lib.sim_set_radiation_reaction(self._h, int(sid), 1 if on else 0)
+
     # ---- stepping -----------------------------------------------------------
     def evolve(self, numsteps: int):
         self.lib.sim_evolve(self._h, int(numsteps))
