@@ -337,7 +337,12 @@ def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden
     gold = json.load(open(os.path.join(HERE, "golden", golden)))
     sim = WarpXSim.from_inputs(product, os.path.join(HERE, "decks", deck))
     sim.evolve(sim.max_step)
-    compare_with_golden(sim.checksum(), gold["checksums"], gold["rtol"], skip)
+    got = sim.checksum()
+    compare_with_golden(got, gold["checksums"], gold["rtol"], skip)
+    if deck.startswith("particle_pusher"):
+        # the gate of the reference's analysis script (Examples/Tests/particle_pusher/analysis.py): the force-free orbit
+        # stays straight with the Higuera-Cary pusher, |x| < 1e-3 m after 10^4 steps (Boris drifts by 2321 m)
+        assert got["positron"]["particle_position_x"] < 1e-3
     sim.close()
 
 
