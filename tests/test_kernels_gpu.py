@@ -267,6 +267,44 @@ def test_deposit_current_lds_tiles(oracle, product, order, algo, stale, u_scale)
     product.workspace_destroy(ws)
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("zero_dir", [0, 1, 2])
+@pytest.mark.parametrize("u_scale", [0.003, 1.0])
+def test_esirkepov_zero_displacement_deposits_exactly_zero(product, order, zero_dir, u_scale):
+    """A particle with u_d == 0 has x_old == x_new bit for bit in the reference (CurrentDeposition.H:700-716), so its
+    old and new weights are identical and sdxi = (sx_old - sx_new) * ... of :792-801 is exactly 0: J_d == 0.0 on every
+    point (the antenna particles of test_3d_laser_injection.json, jx golden value 0.0, comparator atol 0).  Checked on
+    the global-atomics kernel and on the LDS-tile kernel (fast pairs / singles at small u, general path at large u)."""
+    ncell = (24, 20, 16)
+    _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    parts = H.random_particles(30000, ncell, 900 + order, u_scale=u_scale)
+    parts[4 + zero_dir][:] = 0.0
+    # several particles per cell so that the tile kernel forms pairs
+    for d in range(3):
+        parts[d][10000:20000] = parts[d][:10000] + 1e-3 * (H.LX / ncell[d])
+    parts[4 + zero_dir][:] = 0.0
+    dx = H.LX / np.asarray(ncell)
+    g, _ = H.geom_for(ncell, ng_depos)
+    dt = H.yee_dt(dx)
+    q = -plasma.Q_E
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    srt = ParticleArrays(pd0.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    for use_ws, pa in ((None, pd0), (ws, srt)):
+        for rel_t in (-0.5 * dt, 0.0):
+            Jd = [FieldArray(ncell, STAG[n], (ng_j,) * 3, DEV, pad=True) for n in ("jx", "jy", "jz")]
+            product.deposit_current(C.byref(pa.view), field_triplet(Jd), C.byref(g), q, dt, rel_t, order,
+                                    _capi.DEPOSIT_ESIRKEPOV, use_ws, None)
+            _sync(product)
+            j = [f.to_numpy() for f in Jd]
+            assert np.count_nonzero(j[zero_dir]) == 0, (use_ws is not None, rel_t, float(np.max(np.abs(j[zero_dir]))))
+            assert all(np.max(np.abs(j[d])) > 0 for d in range(3) if d != zero_dir)
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.parametrize("order,galerkin", [(1, 1), (2, 1), (3, 1), (3, 0)])
 @pytest.mark.parametrize("stale", [False, True])
 def test_gather_push_lds_tiles(oracle, product, order, galerkin, stale):

@@ -23,29 +23,56 @@ struct EsirkepovShapes {
     double wq;
 };
 
-template <int O>
-__device__ __forceinline__ void esirkepov_shapes(const ParticleState& p, const Geom& g, double q, double dt,
-                                                 double relative_time, EsirkepovShapes<O>& s) {
+// Grid coordinates of the particle at the start and at the end of the step, CurrentDeposition.H:700-716.
+// The reference rounds x_new once and derives x_old from that rounded value, so a particle with u_d == 0 has
+// x_old == x_new bit for bit, its old and new weights are identical and J_d is exactly 0 (the laser antenna's
+// jx in test_3d_laser_injection.json).  With FMA contraction the device compiler would fuse the final "* dxi"
+// into each consumer separately (fma(sum, dxi, -j) in the weights, a rounded product for the cell index and as
+// the operand of x_old): old and new weights then differ by an ulp and deposit a spurious J of ~2e-16 of the
+// transverse current.  This block keeps one rounding per operation, like the CPU path.
+struct EsirkepovCoords {
+    double x_new, x_old, y_new, y_old, z_new, z_old;
+};
+__device__ __forceinline__ EsirkepovCoords esirkepov_coords(const ParticleState& p, const Geom& g, double dt,
+                                                            double relative_time) {
+#pragma clang fp contract(off)
     constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
     const double gaminv =
         inv_sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
+    EsirkepovCoords c;
+    c.x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
+    c.x_old = c.x_new - dt * g.dxi * p.ux * gaminv;
+    c.y_new = (p.y - g.ymin + (relative_time + 0.5 * dt) * p.uy * gaminv) * g.dyi;
+    c.y_old = c.y_new - dt * g.dyi * p.uy * gaminv;
+    c.z_new = (p.z - g.zmin + (relative_time + 0.5 * dt) * p.uz * gaminv) * g.dzi;
+    c.z_old = c.z_new - dt * g.dzi * p.uz * gaminv;
+    return c;
+}
+
+// old - new weight without contraction: the weights are products, and a fused fma(a, b, -s_new) would subtract the
+// rounded new weight from the unrounded old one -- a residue of one rounding error where the reference has exactly 0
+__device__ __forceinline__ double sub_rn(const double a, const double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
+template <int O>
+__device__ __forceinline__ void esirkepov_shapes(const ParticleState& p, const Geom& g, double q, double dt,
+                                                 double relative_time, EsirkepovShapes<O>& s) {
     s.wq = q * p.w;
-    const double x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
-    const double x_old = x_new - dt * g.dxi * p.ux * gaminv;
-    const double y_new = (p.y - g.ymin + (relative_time + 0.5 * dt) * p.uy * gaminv) * g.dyi;
-    const double y_old = y_new - dt * g.dyi * p.uy * gaminv;
-    const double z_new = (p.z - g.zmin + (relative_time + 0.5 * dt) * p.uz * gaminv) * g.dzi;
-    const double z_old = z_new - dt * g.dzi * p.uz * gaminv;
+    const EsirkepovCoords cc = esirkepov_coords(p, g, dt, relative_time);
+    const double x_new = cc.x_new, x_old = cc.x_old, y_new = cc.y_new, y_old = cc.y_old, z_new = cc.z_new,
+                 z_old = cc.z_old;
 #pragma unroll
     for (int a = 0; a < O + 3; ++a) {
         s.sx_new[a] = 0.; s.sx_old[a] = 0.; s.sy_new[a] = 0.; s.sy_old[a] = 0.; s.sz_new[a] = 0.; s.sz_old[a] = 0.;
     }
-    const int i_new = shape_factor<O>(s.sx_new + 1, x_new);
-    const int i_old = shifted_shape_factor<O>(s.sx_old, x_old, i_new);
-    const int j_new = shape_factor<O>(s.sy_new + 1, y_new);
-    const int j_old = shifted_shape_factor<O>(s.sy_old, y_old, j_new);
-    const int k_new = shape_factor<O>(s.sz_new + 1, z_new);
-    const int k_old = shifted_shape_factor<O>(s.sz_old, z_old, k_new);
+    const int i_new = shape_factor<O, true>(s.sx_new + 1, x_new);
+    const int i_old = shifted_shape_factor<O, true>(s.sx_old, x_old, i_new);
+    const int j_new = shape_factor<O, true>(s.sy_new + 1, y_new);
+    const int j_old = shifted_shape_factor<O, true>(s.sy_old, y_old, j_new);
+    const int k_new = shape_factor<O, true>(s.sz_new + 1, z_new);
+    const int k_old = shifted_shape_factor<O, true>(s.sz_old, z_old, k_new);
     s.dil = (i_old < i_new) ? 0 : 1; s.diu = (i_old > i_new) ? 0 : 1;
     s.djl = (j_old < j_new) ? 0 : 1; s.dju = (j_old > j_new) ? 0 : 1;
     s.dkl = (k_old < k_new) ? 0 : 1; s.dku = (k_old > k_new) ? 0 : 1;
@@ -108,7 +135,7 @@ __device__ __forceinline__ void esirkepov_accumulate_comp(const EsirkepovShapes<
     const int du = COMP == 0 ? s.diu : COMP == 1 ? s.dju : s.dku;
     double d[O + 2];
 #pragma unroll
-    for (int a = 0; a < O + 2; ++a) d[a] = s.wq * invdtd * (Lo[a] - Ln[a]);
+    for (int a = 0; a < O + 2; ++a) d[a] = s.wq * invdtd * sub_rn(Lo[a], Ln[a]);
     const bool lo = __builtin_amdgcn_ballot_w64(dl == 0) != 0, hi = __builtin_amdgcn_ballot_w64(du == 0) != 0;
     double an[O + 3], ao[O + 3], bnv[O + 3], bov[O + 3];   // by value: the run-time loop must not see the struct
 #pragma unroll
@@ -173,36 +200,24 @@ __device__ __forceinline__ int shape_cell(double x) {
 template <int O>
 __device__ __forceinline__ void esirkepov_nc_shapes(const ParticleState& p, const Geom& g, double q, double dt,
                                                     double relative_time, EsirkepovNC<O>& s) {
-    constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
-    const double gaminv =
-        inv_sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
     s.wq = q * p.w;
-    const double x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
-    const double x_old = x_new - dt * g.dxi * p.ux * gaminv;
-    const double y_new = (p.y - g.ymin + (relative_time + 0.5 * dt) * p.uy * gaminv) * g.dyi;
-    const double y_old = y_new - dt * g.dyi * p.uy * gaminv;
-    const double z_new = (p.z - g.zmin + (relative_time + 0.5 * dt) * p.uz * gaminv) * g.dzi;
-    const double z_old = z_new - dt * g.dzi * p.uz * gaminv;
+    const EsirkepovCoords cc = esirkepov_coords(p, g, dt, relative_time);
+    const double x_new = cc.x_new, x_old = cc.x_old, y_new = cc.y_new, y_old = cc.y_old, z_new = cc.z_new,
+                 z_old = cc.z_old;
     // old weights on the node of the NEW position: the caller guarantees i_old == i_new up to the
     // rounding of x_old on a cell boundary (see shape_weights_at)
-    shape_weights_at<O>(s.o[0], x_old, shape_node<O>(shape_factor<O>(s.n[0], x_new)));
-    shape_weights_at<O>(s.o[1], y_old, shape_node<O>(shape_factor<O>(s.n[1], y_new)));
-    shape_weights_at<O>(s.o[2], z_old, shape_node<O>(shape_factor<O>(s.n[2], z_new)));
+    shape_weights_at<O, true>(s.o[0], x_old, shape_node<O>(shape_factor<O, true>(s.n[0], x_new)));
+    shape_weights_at<O, true>(s.o[1], y_old, shape_node<O>(shape_factor<O, true>(s.n[1], y_new)));
+    shape_weights_at<O, true>(s.o[2], z_old, shape_node<O>(shape_factor<O, true>(s.n[2], z_new)));
 }
 
 // frame (slot-0 grid index) and crossing flag of one particle
 template <int O>
 __device__ __forceinline__ bool esirkepov_frame_cross(const ParticleState& p, const Geom& g, double dt,
                                                       double relative_time, int& bi, int& bj, int& bk) {
-    constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
-    const double gaminv =
-        inv_sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
-    const double x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
-    const double x_old = x_new - dt * g.dxi * p.ux * gaminv;
-    const double y_new = (p.y - g.ymin + (relative_time + 0.5 * dt) * p.uy * gaminv) * g.dyi;
-    const double y_old = y_new - dt * g.dyi * p.uy * gaminv;
-    const double z_new = (p.z - g.zmin + (relative_time + 0.5 * dt) * p.uz * gaminv) * g.dzi;
-    const double z_old = z_new - dt * g.dzi * p.uz * gaminv;
+    const EsirkepovCoords cc = esirkepov_coords(p, g, dt, relative_time);
+    const double x_new = cc.x_new, x_old = cc.x_old, y_new = cc.y_new, y_old = cc.y_old, z_new = cc.z_new,
+                 z_old = cc.z_old;
     double tmp[O + 1];
     bi = g.lo0 + shape_factor<O>(tmp, x_new) - 1;
     bj = g.lo1 + shape_factor<O>(tmp, y_new) - 1;
@@ -230,8 +245,8 @@ __device__ __forceinline__ void esirkepov_accumulate_pair_nc(const EsirkepovNC<O
             double r1 = 0.0, r2 = 0.0;
 #pragma unroll
             for (int l = 0; l < O; ++l) {
-                r1 += s1.wq * invdtd[c] * (s1.o[c][l] - s1.n[c][l]);
-                r2 += wq2 * invdtd[c] * (s2.o[c][l] - s2.n[c][l]);
+                r1 += s1.wq * invdtd[c] * sub_rn(s1.o[c][l], s1.n[c][l]);
+                r2 += wq2 * invdtd[c] * sub_rn(s2.o[c][l], s2.n[c][l]);
                 D1[l] = r1; D2[l] = r2;
             }
         }

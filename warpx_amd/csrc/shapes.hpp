@@ -9,38 +9,58 @@
 
 namespace wxa {
 
-// B-spline weights, Source/Particles/ShapeFactors.H:27-84. Returns the leftmost index.
+// B-spline weights of the offset xi from the reference node, Source/Particles/ShapeFactors.H:27-84.
+// RN = false: the device compiler may contract a*b+c into FMAs (gather: one more correct bit, fewer instructions).
+// RN = true: one rounding per operation, the CPU path's arithmetic.  The Esirkepov deposition needs it: it
+// subtracts the weights of the old and the new position, and the contraction choices of the compiler differ between
+// the two evaluations (they depend on how each weight is consumed), so that identical positions would give weights
+// that differ by an ulp -- a spurious current where the reference deposits exactly 0.
+#define WXA_BSPLINE_BODY                                                   \
+    if constexpr (ORDER == 0) {                                            \
+        s[0] = 1.0;                                                        \
+    } else if constexpr (ORDER == 1) {                                     \
+        s[0] = 1.0 - xi;                                                   \
+        s[1] = xi;                                                         \
+    } else if constexpr (ORDER == 2) {                                     \
+        s[0] = 0.5 * (0.5 - xi) * (0.5 - xi);                              \
+        s[1] = 0.75 - xi * xi;                                             \
+        s[2] = 0.5 * (0.5 + xi) * (0.5 + xi);                              \
+    } else {                                                               \
+        static_assert(ORDER == 3, "orders 0..3");                          \
+        const double om = 1.0 - xi;                                        \
+        s[0] = (1.0 / 6.0) * om * om * om;                                 \
+        s[1] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);                   \
+        s[2] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);                   \
+        s[3] = (1.0 / 6.0) * xi * xi * xi;                                 \
+    }
+
+template <int ORDER, bool RN>
+__device__ __forceinline__ void bspline_weights(double* __restrict__ s, const double x, const int j) {
+    if constexpr (RN) {
+#pragma clang fp contract(off)
+        const double xi = x - (double)j;
+        WXA_BSPLINE_BODY
+    } else {
+        const double xi = x - (double)j;
+        WXA_BSPLINE_BODY
+    }
+}
+#undef WXA_BSPLINE_BODY
+
+// reference node of a coordinate: nearest node for even orders, node below for odd ones.
 // x >= 0 is guaranteed by the guard-grown index origin, so truncation == floor.
 template <int ORDER>
+__device__ __forceinline__ int shape_node_of(const double x) {
+    if constexpr (ORDER == 0 || ORDER == 2) return (int)(x + 0.5);
+    else return (int)x;
+}
+
+// Compute_shape_factor, ShapeFactors.H:27-84.  Returns the leftmost index.
+template <int ORDER, bool RN = false>
 __device__ __forceinline__ int shape_factor(double* __restrict__ s, const double x) {
-    if constexpr (ORDER == 0) {
-        const int j = (int)(x + 0.5);
-        s[0] = 1.0;
-        return j;
-    } else if constexpr (ORDER == 1) {
-        const int j = (int)x;
-        const double xi = x - (double)j;
-        s[0] = 1.0 - xi;
-        s[1] = xi;
-        return j;
-    } else if constexpr (ORDER == 2) {
-        const int j = (int)(x + 0.5);
-        const double xi = x - (double)j;
-        s[0] = 0.5 * (0.5 - xi) * (0.5 - xi);
-        s[1] = 0.75 - xi * xi;
-        s[2] = 0.5 * (0.5 + xi) * (0.5 + xi);
-        return j - 1;
-    } else {
-        static_assert(ORDER == 3, "orders 0..3");
-        const int j = (int)x;
-        const double xi = x - (double)j;
-        const double om = 1.0 - xi;
-        s[0] = (1.0 / 6.0) * om * om * om;
-        s[1] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);
-        s[2] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);
-        s[3] = (1.0 / 6.0) * xi * xi * xi;
-        return j - 1;
-    }
+    const int j = shape_node_of<ORDER>(x);
+    bspline_weights<ORDER, RN>(s, x, j);
+    return ORDER >= 2 ? j - 1 : j;
 }
 
 // The same weights with the reference node j imposed by the caller (xint = x - j) instead of
@@ -48,24 +68,10 @@ __device__ __forceinline__ int shape_factor(double* __restrict__ s, const double
 // "same cell as the new position".  When x sits on a cell boundary to within an ulp the two
 // evaluations of (int)x can disagree; the spline pieces are continuous there, so imposing j
 // changes the weights by O(ulp) while keeping them on the slots the caller expects.
-template <int ORDER>
+template <int ORDER, bool RN = false>
 __device__ __forceinline__ void shape_weights_at(double* __restrict__ s, const double x, const int j) {
-    const double xi = x - (double)j;
-    if constexpr (ORDER == 1) {
-        s[0] = 1.0 - xi;
-        s[1] = xi;
-    } else if constexpr (ORDER == 2) {
-        s[0] = 0.5 * (0.5 - xi) * (0.5 - xi);
-        s[1] = 0.75 - xi * xi;
-        s[2] = 0.5 * (0.5 + xi) * (0.5 + xi);
-    } else {
-        static_assert(ORDER == 3, "orders 1..3");
-        const double om = 1.0 - xi;
-        s[0] = (1.0 / 6.0) * om * om * om;
-        s[1] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);
-        s[2] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);
-        s[3] = (1.0 / 6.0) * xi * xi * xi;
-    }
+    static_assert(ORDER >= 1 && ORDER <= 3, "orders 1..3");
+    bspline_weights<ORDER, RN>(s, x, j);
 }
 
 // reference node j of shape_factor<ORDER> from its return value (leftmost index)
@@ -77,38 +83,16 @@ __device__ __forceinline__ int shape_node(int leftmost) { return ORDER == 1 ? le
 // The reference stores the ORDER+1 weights at the run-time offset 1+i_shift; a run-time
 // register index would spill the array to scratch memory on gfx950, so every slot is
 // selected from the (at most three) candidate weights instead.
-template <int ORDER>
+template <int ORDER, bool RN = false>
 __device__ __forceinline__ int shifted_shape_factor(double* __restrict__ s, const double x_old,
                                                     const int i_new) {
+    static_assert(ORDER >= 1 && ORDER <= 3, "orders 1..3");
     double w[ORDER + 1];
-    int i, sh, ret;
-    if constexpr (ORDER == 1) {
-        i = (int)floor(x_old);
-        sh = i - i_new;
-        const double xi = x_old - (double)i;
-        w[0] = 1.0 - xi;
-        w[1] = xi;
-        ret = i;
-    } else if constexpr (ORDER == 2) {
-        i = (int)(x_old + 0.5);
-        sh = i - (i_new + 1);
-        const double xi = x_old - (double)i;
-        w[0] = 0.5 * (0.5 - xi) * (0.5 - xi);
-        w[1] = 0.75 - xi * xi;
-        w[2] = 0.5 * (0.5 + xi) * (0.5 + xi);
-        ret = i - 1;
-    } else {
-        static_assert(ORDER == 3, "orders 1..3");
-        i = (int)x_old;
-        sh = i - (i_new + 1);
-        const double xi = x_old - (double)i;
-        const double om = 1.0 - xi;
-        w[0] = (1.0 / 6.0) * om * om * om;
-        w[1] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);
-        w[2] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);
-        w[3] = (1.0 / 6.0) * xi * xi * xi;
-        ret = i - 1;
-    }
+    // ORDER 1 floors (ShapeFactors.H:112), the others truncate like Compute_shape_factor
+    const int i = ORDER == 1 ? (int)floor(x_old) : shape_node_of<ORDER>(x_old);
+    const int sh = ORDER == 1 ? i - i_new : i - (i_new + 1);
+    const int ret = ORDER == 1 ? i : i - 1;
+    bspline_weights<ORDER, RN>(w, x_old, i);
     // slot a holds w[a - 1 - sh] when that index exists (sh in {-1,0,+1} under the CFL limit)
 #pragma unroll
     for (int a = 0; a < ORDER + 3; ++a) {
