@@ -305,6 +305,29 @@ def test_esirkepov_zero_displacement_deposits_exactly_zero(product, order, zero_
     product.workspace_destroy(ws)
 
 
+@pytest.fixture
+def deposit_variant(request):
+    """WXA_DEPOSIT_VARIANT selects one of the LDS-tile configurations of deposit_tile.hip (read per launch)."""
+    old = os.environ.get("WXA_DEPOSIT_VARIANT")
+    os.environ["WXA_DEPOSIT_VARIANT"] = str(request.param)
+    yield request.param
+    if old is None:
+        del os.environ["WXA_DEPOSIT_VARIANT"]
+    else:
+        os.environ["WXA_DEPOSIT_VARIANT"] = old
+
+
+@pytest.mark.parametrize("deposit_variant", list(range(8)), indirect=True)
+@pytest.mark.parametrize("stale", [False, True])
+@pytest.mark.parametrize("u_scale", [1.0, 0.003])
+def test_deposit_tile_variants(oracle, product, deposit_variant, stale, u_scale):
+    """Every configuration of the order-3 Esirkepov LDS-tile deposition (bucketed / wave-independent, whole / half
+    tiles, staged or not) against the oracle, fresh and stale sort, fast and general path; and exact zeros."""
+    test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_ESIRKEPOV, stale, u_scale)
+    if not stale:
+        test_esirkepov_zero_displacement_deposits_exactly_zero(product, 3, 1, u_scale)
+
+
 @pytest.mark.parametrize("order,galerkin", [(1, 1), (2, 1), (3, 1), (3, 0)])
 @pytest.mark.parametrize("stale", [False, True])
 def test_gather_push_lds_tiles(oracle, product, order, galerkin, stale):

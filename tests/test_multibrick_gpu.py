@@ -83,10 +83,6 @@ class ThreadBrickTransport:
             return -1
 
 
-@pytest.mark.skipif(os.environ.get("WXA_UNVERIFIED_GPU_TESTS") != "1",
-                    reason="written after round 1's GPU budget was spent: never run on a GPU yet (the overlapped "
-                           "schedule is bit-identical to the plain one on the CPU build, tests/test_multibrick_cpu.py); "
-                           "WXA_UNVERIFIED_GPU_TESTS=1 runs it")
 @pytest.mark.parametrize("nb", [(1, 1, 2), (2, 2, 2)])
 def test_bricks_with_overlapped_halo_exchange(oracle, product, nb):
     """overlap_halo = 1 on the HIP path: J's guard sum on the exchange stream behind the first half update of B."""

@@ -8,6 +8,17 @@
 
 #include "../../include/warpx_amd.h"
 
+// Value barrier: the compiler has to treat the fp64 value as redefined at this point (used to keep it from merging a
+// deliberate second evaluation with the first one).  tests/hipcpu defines its own for the host compiler.
+#ifndef WXA_OPAQUE_F64
+#define WXA_OPAQUE_F64(v) asm volatile("" : "+v"(v))
+#endif
+
+// Register budget of a kernel as waves per SIMD (512 VGPRs per lane and SIMD: 4 -> 128, 3 -> 168 VGPRs)
+#ifndef WXA_WAVES_PER_SIMD
+#define WXA_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+
 namespace wxa {
 
 // Source/ablastr/constant.H:41-50 (CODATA 2018), digit for digit.

@@ -7,6 +7,8 @@
 
 #include "shapes.hpp"
 
+#include <type_traits>
+
 namespace wxa {
 
 struct ParticleState {
@@ -33,19 +35,37 @@ struct EsirkepovShapes {
 struct EsirkepovCoords {
     double x_new, x_old, y_new, y_old, z_new, z_old;
 };
-__device__ __forceinline__ EsirkepovCoords esirkepov_coords(const ParticleState& p, const Geom& g, double dt,
-                                                            double relative_time) {
+// What the Esirkepov arithmetic needs from (dt, relative_time, cell size), uniform per launch.  Evaluated once on the
+// host, with the reference's operation order, and handed to the kernels as arguments: a uniform double computed in a
+// kernel lives in a VGPR pair of every lane (there is no scalar fp64 unit), and the compiler hoists such values out
+// of the particle loop -- a dozen of them cost the LDS-tile kernel 24 VGPRs through its whole life.
+struct EsirkepovStep {
+    double t_half;      // relative_time + 0.5 dt                      (CurrentDeposition.H:700)
+    double dtdx[3];     // dt * dinv[d]                                 (:703)
+    double invdtd[3];   // 1/dt * dinv[t1] * dinv[t2] per component     (:669-671)
+};
+inline EsirkepovStep make_esirkepov_step(const Geom& g, double dt, double relative_time) {
+    EsirkepovStep es;
+    es.t_half = relative_time + 0.5 * dt;
+    es.dtdx[0] = dt * g.dxi; es.dtdx[1] = dt * g.dyi; es.dtdx[2] = dt * g.dzi;
+    es.invdtd[0] = (1.0 / dt) * g.dyi * g.dzi;
+    es.invdtd[1] = (1.0 / dt) * g.dxi * g.dzi;
+    es.invdtd[2] = (1.0 / dt) * g.dxi * g.dyi;
+    return es;
+}
+__device__ __forceinline__ EsirkepovCoords esirkepov_coords(const ParticleState& p, const Geom& g,
+                                                            const EsirkepovStep& es) {
 #pragma clang fp contract(off)
     constexpr double clightsq = 1.0 / (PhysConst::c * PhysConst::c);
     const double gaminv =
         inv_sqrt(1.0 + p.ux * p.ux * clightsq + p.uy * p.uy * clightsq + p.uz * p.uz * clightsq);
     EsirkepovCoords c;
-    c.x_new = (p.x - g.xmin + (relative_time + 0.5 * dt) * p.ux * gaminv) * g.dxi;
-    c.x_old = c.x_new - dt * g.dxi * p.ux * gaminv;
-    c.y_new = (p.y - g.ymin + (relative_time + 0.5 * dt) * p.uy * gaminv) * g.dyi;
-    c.y_old = c.y_new - dt * g.dyi * p.uy * gaminv;
-    c.z_new = (p.z - g.zmin + (relative_time + 0.5 * dt) * p.uz * gaminv) * g.dzi;
-    c.z_old = c.z_new - dt * g.dzi * p.uz * gaminv;
+    c.x_new = (p.x - g.xmin + es.t_half * p.ux * gaminv) * g.dxi;
+    c.x_old = c.x_new - es.dtdx[0] * p.ux * gaminv;
+    c.y_new = (p.y - g.ymin + es.t_half * p.uy * gaminv) * g.dyi;
+    c.y_old = c.y_new - es.dtdx[1] * p.uy * gaminv;
+    c.z_new = (p.z - g.zmin + es.t_half * p.uz * gaminv) * g.dzi;
+    c.z_old = c.z_new - es.dtdx[2] * p.uz * gaminv;
     return c;
 }
 
@@ -57,10 +77,10 @@ __device__ __forceinline__ double sub_rn(const double a, const double b) {
 }
 
 template <int O>
-__device__ __forceinline__ void esirkepov_shapes(const ParticleState& p, const Geom& g, double q, double dt,
-                                                 double relative_time, EsirkepovShapes<O>& s) {
+__device__ __forceinline__ void esirkepov_shapes(const ParticleState& p, const Geom& g, double q,
+                                                 const EsirkepovStep& es, EsirkepovShapes<O>& s) {
     s.wq = q * p.w;
-    const EsirkepovCoords cc = esirkepov_coords(p, g, dt, relative_time);
+    const EsirkepovCoords cc = esirkepov_coords(p, g, es);
     const double x_new = cc.x_new, x_old = cc.x_old, y_new = cc.y_new, y_old = cc.y_old, z_new = cc.z_new,
                  z_old = cc.z_old;
 #pragma unroll
@@ -119,7 +139,7 @@ __device__ __forceinline__ void esirkepov_row(Sink& sink, const double (&d)[O + 
 // a handful of particles, and as straight-line code (~15 KB per component) it was bound by
 // instruction fetch, not by arithmetic.  The rows inside one b are static as before.
 template <int O, int COMP, class Sink>
-__device__ __forceinline__ void esirkepov_accumulate_comp(const EsirkepovShapes<O>& s, const Geom& g, double dt,
+__device__ __forceinline__ void esirkepov_accumulate_comp(const EsirkepovShapes<O>& s, const EsirkepovStep& es,
                                                           Sink& sink) {
     constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
     // longitudinal direction L, transverse directions A (fast index of the row) and B
@@ -129,8 +149,7 @@ __device__ __forceinline__ void esirkepov_accumulate_comp(const EsirkepovShapes<
     const double* Ao = COMP == 0 ? s.sy_old : s.sx_old;
     const double* Bn = COMP == 2 ? s.sy_new : s.sz_new;
     const double* Bo = COMP == 2 ? s.sy_old : s.sz_old;
-    const double invdtd = COMP == 0 ? (1.0 / dt) * g.dyi * g.dzi
-                                    : COMP == 1 ? (1.0 / dt) * g.dxi * g.dzi : (1.0 / dt) * g.dxi * g.dyi;
+    const double invdtd = es.invdtd[COMP];
     const int dl = COMP == 0 ? s.dil : COMP == 1 ? s.djl : s.dkl;
     const int du = COMP == 0 ? s.diu : COMP == 1 ? s.dju : s.dku;
     double d[O + 2];
@@ -158,11 +177,10 @@ __device__ __forceinline__ void esirkepov_accumulate_comp(const EsirkepovShapes<
 }
 
 template <int O, class Sink>
-__device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s, const Geom& g, double dt,
-                                                     Sink& sink) {
-    esirkepov_accumulate_comp<O, 0>(s, g, dt, sink);
-    esirkepov_accumulate_comp<O, 1>(s, g, dt, sink);
-    esirkepov_accumulate_comp<O, 2>(s, g, dt, sink);
+__device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s, const EsirkepovStep& es, Sink& sink) {
+    esirkepov_accumulate_comp<O, 0>(s, es, sink);
+    esirkepov_accumulate_comp<O, 1>(s, es, sink);
+    esirkepov_accumulate_comp<O, 2>(s, es, sink);
 }
 
 // ---- fast path: particles that stay in their cell during the step ---------------------------
@@ -198,10 +216,10 @@ __device__ __forceinline__ int shape_cell(double x) {
 }
 
 template <int O>
-__device__ __forceinline__ void esirkepov_nc_shapes(const ParticleState& p, const Geom& g, double q, double dt,
-                                                    double relative_time, EsirkepovNC<O>& s) {
+__device__ __forceinline__ void esirkepov_nc_shapes(const ParticleState& p, const Geom& g, double q,
+                                                    const EsirkepovStep& es, EsirkepovNC<O>& s) {
     s.wq = q * p.w;
-    const EsirkepovCoords cc = esirkepov_coords(p, g, dt, relative_time);
+    const EsirkepovCoords cc = esirkepov_coords(p, g, es);
     const double x_new = cc.x_new, x_old = cc.x_old, y_new = cc.y_new, y_old = cc.y_old, z_new = cc.z_new,
                  z_old = cc.z_old;
     // old weights on the node of the NEW position: the caller guarantees i_old == i_new up to the
@@ -211,28 +229,30 @@ __device__ __forceinline__ void esirkepov_nc_shapes(const ParticleState& p, cons
     shape_weights_at<O, true>(s.o[2], z_old, shape_node<O>(shape_factor<O, true>(s.n[2], z_new)));
 }
 
-// frame (slot-0 grid index) and crossing flag of one particle
+// frame (slot-0 grid index) and crossing flag from the grid coordinates
 template <int O>
-__device__ __forceinline__ bool esirkepov_frame_cross(const ParticleState& p, const Geom& g, double dt,
-                                                      double relative_time, int& bi, int& bj, int& bk) {
-    const EsirkepovCoords cc = esirkepov_coords(p, g, dt, relative_time);
-    const double x_new = cc.x_new, x_old = cc.x_old, y_new = cc.y_new, y_old = cc.y_old, z_new = cc.z_new,
-                 z_old = cc.z_old;
-    double tmp[O + 1];
-    bi = g.lo0 + shape_factor<O>(tmp, x_new) - 1;
-    bj = g.lo1 + shape_factor<O>(tmp, y_new) - 1;
-    bk = g.lo2 + shape_factor<O>(tmp, z_new) - 1;
-    return shape_cell<O>(x_old) != shape_cell<O>(x_new) || shape_cell<O>(y_old) != shape_cell<O>(y_new) ||
-           shape_cell<O>(z_old) != shape_cell<O>(z_new);
+__device__ __forceinline__ bool esirkepov_frame_cross(const EsirkepovCoords& cc, const Geom& g, int& bi, int& bj,
+                                                      int& bk) {
+    bi = g.lo0 + shape_node_of<O>(cc.x_new) - (O == 1 ? 1 : 2);
+    bj = g.lo1 + shape_node_of<O>(cc.y_new) - (O == 1 ? 1 : 2);
+    bk = g.lo2 + shape_node_of<O>(cc.z_new) - (O == 1 ? 1 : 2);
+    return shape_cell<O>(cc.x_old) != shape_cell<O>(cc.x_new) || shape_cell<O>(cc.y_old) != shape_cell<O>(cc.y_new) ||
+           shape_cell<O>(cc.z_old) != shape_cell<O>(cc.z_new);
+}
+
+template <int O>
+__device__ __forceinline__ bool esirkepov_frame_cross(const ParticleState& p, const Geom& g, const EsirkepovStep& es,
+                                                      int& bi, int& bj, int& bk) {
+    return esirkepov_frame_cross<O>(esirkepov_coords(p, g, es), g, bi, bj, bk);
 }
 
 // sink slot 0 = the frame's slot 0 (grid index bi,bj,bk)
 template <int O, class Sink>
 __device__ __forceinline__ void esirkepov_accumulate_pair_nc(const EsirkepovNC<O>& s1, const EsirkepovNC<O>& s2,
-                                                             bool null2, const Geom& g, double dt, Sink& sink) {
+                                                             bool null2, const EsirkepovStep& es, Sink& sink) {
     constexpr int NW = O + 1;
     constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
-    const double invdtd[3] = {(1.0 / dt) * g.dyi * g.dzi, (1.0 / dt) * g.dxi * g.dzi, (1.0 / dt) * g.dxi * g.dyi};
+    const double (&invdtd)[3] = es.invdtd;
     const double wq2 = null2 ? 0.0 : s2.wq;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -270,6 +290,109 @@ __device__ __forceinline__ void esirkepov_accumulate_pair_nc(const EsirkepovNC<O
             }
         }
     }
+}
+
+// The same pair deposit as esirkepov_accumulate_pair_nc (same formulas, same order of the sums), organised for a small
+// register footprint: the three components run as three phases separated by scheduling barriers, each phase holds only
+// the weights it needs, and the weights of a direction that two phases need (x: Jz and Jy) are evaluated again from the
+// grid coordinate instead of being carried across the phase in between (RECOMPUTE_X; 4 spline evaluations per pair).
+// Live state per phase at order 3: Jz 16 + 16 + 6 doubles (x, y weights of both particles, Dz), Jx 16 + 16 + 6 (+ 6 for
+// Dy, + the x coordinates), Jy 16 + 16 + 6 -- against 2 x 24 weights + 2 x 9 running sums when everything is kept.
+// Both particles of a pair share the stencil frame, i.e. the reference node of every direction.
+template <int O, bool RECOMPUTE_X, class Sink>
+__device__ __forceinline__ void esirkepov_pair_phased(EsirkepovCoords c1, EsirkepovCoords c2, const double wq1,
+                                                      const double wq2, const EsirkepovStep& es, Sink& sink) {
+    constexpr int NW = O + 1;
+    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
+    const int jx = shape_node_of<O>(c1.x_new), jy = shape_node_of<O>(c1.y_new), jz = shape_node_of<O>(c1.z_new);
+    // running sums of wq invdtd (s_old - s_new) along one direction (CurrentDeposition.H:794-799, re-associated as in
+    // esirkepov_accumulate_pair_nc)
+    auto running = [&](double (&D)[O], const double wq, const double invdtd, const double xn, const double xo, const int j) {
+        double n[NW], o[NW];
+        bspline_weights<O, true>(n, xn, j);
+        bspline_weights<O, true>(o, xo, j);
+        double r = 0.0;
+#pragma unroll
+        for (int l = 0; l < O; ++l) {
+            r += wq * invdtd * sub_rn(o[l], n[l]);
+            D[l] = r;
+        }
+    };
+    // one component: D along the longitudinal direction, (an, ao) weights of the rows' inner index, (bn, bo) of the outer
+    auto phase = [&](auto comp, const double (&D1)[O], const double (&D2)[O], const double (&a1n)[NW],
+                     const double (&a1o)[NW], const double (&a2n)[NW], const double (&a2o)[NW], const double (&b1n)[NW],
+                     const double (&b1o)[NW], const double (&b2n)[NW], const double (&b2o)[NW]) {
+        constexpr int c = decltype(comp)::value;
+#pragma unroll
+        for (int b = 0; b < NW; ++b) {
+            const double P1 = one_third * b1n[b] + one_sixth * b1o[b];
+            const double Q1 = one_third * b1o[b] + one_sixth * b1n[b];
+            const double P2 = one_third * b2n[b] + one_sixth * b2o[b];
+            const double Q2 = one_third * b2o[b] + one_sixth * b2n[b];
+#pragma unroll
+            for (int a = 0; a < NW; ++a) {
+                const double T1 = a1n[a] * P1 + a1o[a] * Q1;
+                const double T2 = a2n[a] * P2 + a2o[a] * Q2;
+#pragma unroll
+                for (int l = 0; l < O; ++l) {
+                    const double v = D1[l] * T1 + D2[l] * T2;
+                    if constexpr (c == 0) sink.add(0, l + 1, a + 1, b + 1, v);
+                    else if constexpr (c == 1) sink.add(1, a + 1, l + 1, b + 1, v);
+                    else sink.add(2, a + 1, b + 1, l + 1, v);
+                }
+            }
+        }
+    };
+    double x1n[NW], x1o[NW], x2n[NW], x2o[NW];
+    bspline_weights<O, true>(x1n, c1.x_new, jx); bspline_weights<O, true>(x1o, c1.x_old, jx);
+    bspline_weights<O, true>(x2n, c2.x_new, jx); bspline_weights<O, true>(x2o, c2.x_old, jx);
+    double y1n[NW], y1o[NW], y2n[NW], y2o[NW];
+    bspline_weights<O, true>(y1n, c1.y_new, jy); bspline_weights<O, true>(y1o, c1.y_old, jy);
+    bspline_weights<O, true>(y2n, c2.y_new, jy); bspline_weights<O, true>(y2o, c2.y_old, jy);
+    {   // Jz: rows (i, j), running along k
+        double D1[O], D2[O];
+        running(D1, wq1, es.invdtd[2], c1.z_new, c1.z_old, jz);
+        running(D2, wq2, es.invdtd[2], c2.z_new, c2.z_old, jz);
+        phase(std::integral_constant<int, 2>{}, D1, D2, x1n, x1o, x2n, x2o, y1n, y1o, y2n, y2o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double z1n[NW], z1o[NW], z2n[NW], z2o[NW];
+    bspline_weights<O, true>(z1n, c1.z_new, jz); bspline_weights<O, true>(z1o, c1.z_old, jz);
+    bspline_weights<O, true>(z2n, c2.z_new, jz); bspline_weights<O, true>(z2o, c2.z_old, jz);
+    double Dy1[O], Dy2[O];
+    {   // Jx: rows (j, k), running along i; Dy is taken here, before the y weights die
+        double D1[O], D2[O];
+        double r1 = 0.0, r2 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int l = 0; l < O; ++l) {
+            r1 += wq1 * es.invdtd[0] * sub_rn(x1o[l], x1n[l]);
+            r2 += wq2 * es.invdtd[0] * sub_rn(x2o[l], x2n[l]);
+            s1 += wq1 * es.invdtd[1] * sub_rn(y1o[l], y1n[l]);
+            s2 += wq2 * es.invdtd[1] * sub_rn(y2o[l], y2n[l]);
+            D1[l] = r1; D2[l] = r2; Dy1[l] = s1; Dy2[l] = s2;
+        }
+        if constexpr (RECOMPUTE_X) {
+            // the x weights are not carried across this phase: make the coordinates opaque so that the second
+            // evaluation below is not merged with the first one
+            WXA_OPAQUE_F64(c1.x_new); WXA_OPAQUE_F64(c1.x_old); WXA_OPAQUE_F64(c2.x_new); WXA_OPAQUE_F64(c2.x_old);
+        }
+        phase(std::integral_constant<int, 0>{}, D1, D2, y1n, y1o, y2n, y2o, z1n, z1o, z2n, z2o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (RECOMPUTE_X) {
+        bspline_weights<O, true>(x1n, c1.x_new, jx); bspline_weights<O, true>(x1o, c1.x_old, jx);
+        bspline_weights<O, true>(x2n, c2.x_new, jx); bspline_weights<O, true>(x2o, c2.x_old, jx);
+    }
+    // Jy: rows (i, k), running along j
+    phase(std::integral_constant<int, 1>{}, Dy1, Dy2, x1n, x1o, x2n, x2o, z1n, z1o, z2n, z2o);
+}
+
+template <int O, bool RECOMPUTE_X, class Sink>
+__device__ __forceinline__ void esirkepov_pair_phased(const ParticleState& p1, const ParticleState& p2, const bool null2,
+                                                      const Geom& g, const double q, const EsirkepovStep& es,
+                                                      Sink& sink) {
+    esirkepov_pair_phased<O, RECOMPUTE_X>(esirkepov_coords(p1, g, es), esirkepov_coords(p2, g, es), q * p1.w,
+                                          null2 ? 0.0 : q * p2.w, es, sink);
 }
 
 // Direct deposition on the Yee grid: jx(c,n,n) jy(n,c,n) jz(n,n,c).

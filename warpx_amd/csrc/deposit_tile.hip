@@ -22,30 +22,40 @@
 #include "deposit_body.hpp"
 #include "workspace.hpp"
 
+#include <stdlib.h>
+
+#ifndef WXA_DEPOSIT_CFG
+#define WXA_DEPOSIT_CFG CfgWhole
+#endif
+
 namespace wxa {
 
 constexpr int TS = WXA_TILE;          // tile edge in cells (workspace.hpp)
 constexpr int TILE_CELLS = TS * TS * TS;
 
-template <int M>
+// A workgroup owns TS x TS x TSZ cells: a whole tile of the sort (TSZ = 8) or its lower / upper half in z
+// (TSZ = 4; the sort order inside a tile has k/2 as its slowest index, so a half tile is a contiguous range
+// of cells and of particles).  Half tiles need 61 KB instead of 83.5 KB of LDS: two workgroups per CU.
+template <int M, int TSZ>
 struct TileDims {
     static constexpr int LO = -2 - M;            // first LDS point relative to the tile's first cell
-    static constexpr int N = TS + 5 + 2 * M;     // points per direction
+    static constexpr int N = TS + 5 + 2 * M;     // points per direction (x, y)
+    static constexpr int NZ = TSZ + 5 + 2 * M;   // planes
     // Plane stride padded to 8 (mod 16): with the row stride N = 15 = -1 (mod 16) the LDS bank of
     // point (i,j,k) is (i - j + 8k) mod 16, so the 16 cells {8 i} x {k, k+1} of one row j sit on
     // 16 different banks (see the lane assignment in the kernel and cell_of in particles.hip).
     static constexpr int PS = N * N + ((8 - (N * N) % 16) + 16) % 16;
-    static constexpr int NPTS = N * PS;          // doubles per component (incl. padding)
+    static constexpr int NPTS = NZ * PS;         // doubles per component (incl. padding)
 };
 
-template <int M>
+template <int M, int TSZ>
 struct LdsSink {
+    using TD = TileDims<M, TSZ>;
     double* base;   // LDS address of slot 0 of component 0: every deposit is base + a compile-time offset
     __device__ __forceinline__ LdsSink(double* lds, int oi, int oj, int ok)
-        : base(lds + oi + TileDims<M>::N * oj + TileDims<M>::PS * ok) {}
+        : base(lds + oi + TD::N * oj + TD::PS * ok) {}
     __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
-        constexpr int N = TileDims<M>::N;
-        atomic_add_f64(base + (c * TileDims<M>::NPTS + i + N * j + TileDims<M>::PS * k), v);
+        atomic_add_f64(base + (c * TD::NPTS + i + TD::N * j + TD::PS * k), v);
     }
     __device__ __forceinline__ void add_abs(int c, int gi, int gj, int gk, double v) { add(c, gi, gj, gk, v); }
 };
@@ -86,11 +96,7 @@ struct TileGeom {
     int cell_lo[3];   // global index of the brick's first cell
 };
 
-constexpr int DT_THREADS = 512;   // 8 waves: one workgroup per CU (LDS-limited), 2 waves per SIMD
-constexpr int DT_BATCH = 1024;    // particles staged in LDS per round (7 x 1024 x 8 B = 56 KB)
 constexpr int NBANK = 16;         // LDS banks (8-byte wide) seen by one step of a ds_add_f64
-constexpr int ROWS = 512 / NBANK; // quarter-waves of a workgroup = rows of the lane-assignment table
-constexpr int DT_DEFER = 1024;    // capacity of the per-tile list of deferred (cell-crossing) particles
 
 // Particles whose stencil leaves the LDS tile (stale sort, particles outside the domain before
 // the periodic wrap) are queued and deposited by deposit_stragglers_kernel with global atomics:
@@ -101,55 +107,85 @@ struct StragglerQueue {
     __device__ __forceinline__ void push(int ip) const { idx[atomicAdd(count, 1u)] = ip; }
 };
 
-template <int O, int ALGO, int M>
-__global__ void __launch_bounds__(DT_THREADS)
+// Work-item word: particle slot in the batch, "merged with the next particle", stencil frame in the LDS tile
+constexpr int IT_AMASK = (1 << 11) - 1;   // batch slot (batches hold at most 2048 particles)
+constexpr int IT_PAIRED = 1 << 11;
+constexpr int IT_FRAME_SHIFT = 12;        // 4 bits each for the frame's first LDS point (i, j, k) < 16
+__device__ __forceinline__ int frame_key(int li, int lj, int lk) { return li | (lj << 4) | (lk << 8); }
+
+// Configuration of the tile kernel (compile time):
+//   NT     work-items per workgroup; a trip takes up to 2 NT particles and at most NT fast items (one per lane)
+//   TSZ    cells of the tile along z (8: whole sort tile; 4: half tile)
+//   STAGE  true: the batch is staged in LDS (coalesced loads, 56 B per particle) and the fast pass reads its
+//          particles from there; false: the fast pass reads them from global memory by index (they were touched
+//          by the keying pass a moment ago and come from L2), which frees 56 KB of LDS per 1024 particles
+//   WPE    waves per SIMD the register allocation is held to
+//   PHASED 0: all weights of the pair kept in registers; 1: component by component (esirkepov_pair_phased);
+//          2: as 1, and the x weights evaluated a second time instead of carried across the Jx phase
+template <int NT_, int TSZ_, bool STAGE_, int WPE_, int PHASED_>
+struct TileCfg {
+    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_;
+    static constexpr bool STAGE = STAGE_;
+};
+
+template <int O, int ALGO, int M, class CFG>
+__global__ void __launch_bounds__(CFG::NT) WXA_WAVES_PER_SIMD(CFG::WPE)
 deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py,
                     const double* __restrict__ pz, const double* __restrict__ pw,
                     const double* __restrict__ pux, const double* __restrict__ puy,
                     const double* __restrict__ puz, const int* __restrict__ offsets, DevF Jx, DevF Jy,
-                    DevF Jz, Geom g, TileGeom tg, double q, double dt, double relative_time,
+                    DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, double relative_time,
                     StragglerQueue sq) {
-    constexpr int N = TileDims<M>::N;
-    constexpr int NPTS = TileDims<M>::NPTS;
-    constexpr int PS = TileDims<M>::PS;
-    constexpr int PAIRED = 1 << 30;
+    constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
+    constexpr bool STAGE = CFG::STAGE;
+    using TD = TileDims<M, TSZ>;
+    constexpr int N = TD::N, NZ = TD::NZ, NPTS = TD::NPTS, PS = TD::PS;
+    constexpr int SUB = TS / TSZ;                  // workgroups per sort tile
+    constexpr int SUB_CELLS = TILE_CELLS / SUB;
+    constexpr int BATCH = 2 * NT;                  // particles per trip
+    constexpr int ROWS = NT / NBANK;               // quarter-waves of a workgroup = rows of the lane-assignment table
+    constexpr int DEFER = BATCH;                   // capacity of the per-tile list of deferred (cell-crossing) particles:
+                                                   // a flush empties it and one batch appends at most BATCH entries
+    static_assert(TS % TSZ == 0 && TSZ % 2 == 0, "a half tile is a contiguous cell range of the sort order");
+    static_assert(BATCH <= IT_AMASK + 1 && N <= 16 && NZ <= 16, "work-item word");
     __shared__ double lds[3 * NPTS];
-    __shared__ double stage[7][DT_BATCH];
-    __shared__ int keys[DT_BATCH + 1];
-    __shared__ int items[DT_BATCH];
+    __shared__ double stage[STAGE ? 7 : 1][STAGE ? BATCH : 1];
+    __shared__ int items[BATCH];
     __shared__ int nitems;
-    __shared__ int segcnt[2][DT_BATCH / 64];   // fast / slow items per 64-particle segment
+    __shared__ int segcnt[2][BATCH / 64];      // fast / slow items per 64-particle segment
     __shared__ int cut_a, cut_nslow;           // set by the thread holding the first fast item beyond the cap
     __shared__ int pf_scratch[64];             // landing zone of the L2 prefetch loads
-    __shared__ int slots[DT_THREADS];          // fast item of every lane (row = quarter-wave, column = LDS bank)
+    __shared__ int slots[NT];                  // fast item of every lane (row = quarter-wave, column = LDS bank)
     __shared__ int bcnt[NBANK], novf;
-    __shared__ unsigned deferred[DT_DEFER];   // particles with a cell crossing (global indices), kept for one dense pass
+    __shared__ unsigned deferred[DEFER];      // particles with a cell crossing (global indices), kept for one dense pass
     __shared__ int ndeferred;
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
-    const long tile = xcd_tile_id(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
-    const int start = offsets[tile * TILE_CELLS];
-    const int end = offsets[(tile + 1) * TILE_CELLS];
+    const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
+    if (unit >= ntiles * SUB) return;
+    const long tile = unit / SUB;
+    const int half = (int)(unit % SUB);
+    const int start = offsets[tile * TILE_CELLS + half * SUB_CELLS];
+    const int end = offsets[tile * TILE_CELLS + (half + 1) * SUB_CELLS];
     if (end <= start) return;
     const int tid = threadIdx.x;
     DPROF_INIT
-    for (int a = tid; a < 3 * NPTS; a += DT_THREADS) lds[a] = 0.0;
+    for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = 0.0;
     const int ti = (int)(tile % tg.nt[0]);
     const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
     const int tk = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
     // global grid index of LDS point 0
-    const int o0 = tg.cell_lo[0] + ti * TS + TileDims<M>::LO;
-    const int o1 = tg.cell_lo[1] + tj * TS + TileDims<M>::LO;
-    const int o2 = tg.cell_lo[2] + tk * TS + TileDims<M>::LO;
+    const int o0 = tg.cell_lo[0] + ti * TS + TD::LO;
+    const int o1 = tg.cell_lo[1] + tj * TS + TD::LO;
+    const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
     const int wave = tid >> 6, lane = tid & 63;
     if (tid == 0) ndeferred = 0;
     constexpr bool ESIRKEPOV = ALGO == WXA_DEPOSIT_ESIRKEPOV;
-    constexpr int ROUNDS = DT_BATCH / DT_THREADS;   // particles per thread and batch
-    constexpr int WAVES = DT_THREADS / 64;
-    constexpr int NSEG = DT_BATCH / 64;             // 64-particle segments of a batch (one ballot each)
-    constexpr int FAST_CAP = DT_THREADS;            // one fast item per lane: the fast pass is ONE pass
+    constexpr int ROUNDS = BATCH / NT;              // particles per thread and batch
+    constexpr int WAVES = NT / 64;
+    constexpr int NSEG = BATCH / 64;                // 64-particle segments of a batch (one ballot each)
+    constexpr int FAST_CAP = NT;                    // one fast item per lane: the fast pass is ONE pass
     const double* const parr[7] = {px, py, pz, pw, pux, puy, puz};
-    int nb_cap = DT_BATCH;   // particles staged per batch; shrinks when the item cap cuts batches short
+    int nb_cap = BATCH;   // particles taken per batch; shrinks when the item cap cuts batches short
     int b0 = start;
     // One extra trip after the last batch only flushes the deferred list, so that the (large)
     // general-path code exists once in the kernel.
@@ -160,7 +196,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
         }
         const int nb = last ? 0 : min(nb_cap, end - b0);
         __syncthreads();   // previous round's readers are done (and the zero fill on round 0)
-        // ---- stage the batch (coalesced, all loads in flight together) and key every particle
+        // ---- load the batch (coalesced, all loads in flight together) and key every particle
         //      by its stencil frame ----
         int key_r[ROUNDS];     // stencil frame of this thread's particles (< 0: none / straggler)
         bool cross_r[ROUNDS];  // the particle crosses a cell during the step
@@ -168,7 +204,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             double r[ROUNDS][7];
 #pragma unroll
             for (int rr = 0; rr < ROUNDS; ++rr) {
-                const int a = tid + rr * DT_THREADS;
+                const int a = tid + rr * NT;
                 key_r[rr] = -1; cross_r[rr] = false;
                 if (a < nb) {
 #pragma unroll
@@ -177,21 +213,23 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             }
 #pragma unroll
             for (int rr = 0; rr < ROUNDS; ++rr) {
-                const int a = tid + rr * DT_THREADS;
+                const int a = tid + rr * NT;
                 if (a < nb) {
                     const ParticleState p{r[rr][0], r[rr][1], r[rr][2], r[rr][3], r[rr][4], r[rr][5], r[rr][6]};
+                    if constexpr (STAGE) {
 #pragma unroll
-                    for (int c = 0; c < 7; ++c) stage[c][a] = r[rr][c];
+                        for (int c = 0; c < 7; ++c) stage[c][a] = r[rr][c];
+                    }
                     int key;
                     if constexpr (ESIRKEPOV) {
                         int bi, bj, bk;
-                        const bool cross = esirkepov_frame_cross<O>(p, g, dt, relative_time, bi, bj, bk);
+                        const bool cross = esirkepov_frame_cross<O>(p, g, es, bi, bj, bk);
                         const int li = bi - o0, lj = bj - o1, lk = bk - o2;
                         const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N &&
-                                        lk + O + 3 <= N;
+                                        lk + O + 3 <= NZ;
                         // outside the LDS tile: straggler (a key no neighbour shares); queued below,
                         // once it is known that this batch consumes the particle
-                        key = in ? (li | (lj << 8) | (lk << 16)) : -2 - a;
+                        key = in ? frame_key(li, lj, lk) : -2 - a;
                         cross_r[rr] = cross;
                     } else {
                         DirectShapes<O> sh;
@@ -200,10 +238,9 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                                   lo_k = min(sh.ln, sh.lc) - o2;
                         const int hi_i = max(sh.jn, sh.jc) - o0 + O, hi_j = max(sh.kn, sh.kc) - o1 + O,
                                   hi_k = max(sh.ln, sh.lc) - o2 + O;
-                        key = (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N) ? 0 : -1;
+                        key = (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < NZ) ? 0 : -1;
                         if (key < 0) sq.push(b0 + a);
                     }
-                    keys[a] = key;
                     key_r[rr] = key;
                 }
             }
@@ -219,10 +256,10 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             const int nd0 = ndeferred;
             // ---- work items.  A run of equal frames (the particles of one cell, cut at the
             // 64-particle segments) is split into pairs (+ one single if odd); an item is "slow" if
-            // one of its particles crosses a cell.  Ranks come from ballots and a 16-entry prefix,
-            // so both lists keep the cell order of the sort (neighbouring lanes -> neighbouring
+            // one of its particles crosses a cell.  Ranks come from ballots and a prefix over the
+            // segments, so both lists keep the cell order of the sort (neighbouring lanes -> neighbouring
             // LDS addresses).  At most FAST_CAP fast items are taken: the batch ends where the
-            // next one would start (a_cut) and the rest is staged again by the next trip.
+            // next one would start (a_cut) and the rest is taken again by the next trip.
             bool is_item[ROUNDS], is_slow[ROUNDS], is_pair[ROUNDS];
             int rank_f[ROUNDS], rank_s[ROUNDS];
             const unsigned long long le = ~0ull >> (63 - lane), lt = le >> 1;
@@ -251,7 +288,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                 is_item[rr] = it; is_slow[rr] = sl; is_pair[rr] = pr;
             }
             __syncthreads();
-            DPROF(0);   // zero fill (first trip) + stage + key + item flags
+            DPROF(0);   // zero fill (first trip) + load + key + item flags
             int tot_f = 0, tot_s = 0;
             {
                 int pre_f[ROUNDS], pre_s[ROUNDS];
@@ -274,12 +311,12 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                 // column, so two lanes of a quarter-wave never hit the same address either.
 #pragma unroll
                 for (int rr = 0; rr < ROUNDS; ++rr) {
-                    const int a = tid + rr * DT_THREADS;
-                    const int e = a | (is_pair[rr] ? PAIRED : 0);
+                    const int a = tid + rr * NT;
+                    const int kk = key_r[rr];
+                    const int e = a | (is_pair[rr] ? IT_PAIRED : 0) | (kk << IT_FRAME_SHIFT);
                     const int rank = pre_f[rr] + rank_f[rr];
                     const bool fast = is_item[rr] && !is_slow[rr] && rank < FAST_CAP;
-                    const int kk = key_r[rr];
-                    const int bank = fast ? ((kk & 255) + N * ((kk >> 8) & 255) + PS * (kk >> 16)) & (NBANK - 1) : -1;
+                    const int bank = fast ? ((kk & 15) + N * ((kk >> 4) & 15) + PS * (kk >> 8)) & (NBANK - 1) : -1;
                     // (a wave-aggregated rank -- 16 ballots, one atomic per wave and bank -- was slower)
                     const int row = fast ? atomicAdd(&bcnt[bank], 1) : 0;
                     if (fast) {
@@ -287,7 +324,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                         else items[atomicAdd(&novf, 1)] = e;   // bucket full: takes a free slot below
                     }
                     if (is_item[rr]) {
-                        if (is_slow[rr]) items[DT_BATCH - 1 - (pre_s[rr] + rank_s[rr])] = e;   // from the back
+                        if (is_slow[rr]) items[BATCH - 1 - (pre_s[rr] + rank_s[rr])] = a;   // from the back
                         else if (rank == FAST_CAP) { cut_a = a; cut_nslow = pre_s[rr] + rank_s[rr]; }
                     }
                 }
@@ -295,25 +332,26 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             __syncthreads();
             DPROF(1);   // work-item lists
             const int a_cut = cut_a;                              // particles consumed by this trip
-            const int nfast = min(tot_f, FAST_CAP);
             const int nsl = cut_nslow >= 0 ? cut_nslow : tot_s;   // slow items before a_cut
-            if (a_cut < nb) nb_cap = min(DT_BATCH, ((a_cut + 127) >> 6) << 6);
-            else if (nb == nb_cap && nb_cap < DT_BATCH && tot_f < FAST_CAP - 32) nb_cap += 64;
+            if (a_cut < nb) nb_cap = min(BATCH, ((a_cut + 127) >> 6) << 6);
+            else if (nb == nb_cap && nb_cap < BATCH && tot_f < FAST_CAP - 32) nb_cap += 64;
 #pragma unroll
             for (int rr = 0; rr < ROUNDS; ++rr) {
-                const int a = tid + rr * DT_THREADS;
+                const int a = tid + rr * NT;
                 if (a < a_cut && key_r[rr] <= -2) sq.push(b0 + a);
             }
             // Pull the next batch towards the L2 while this one is deposited: one 4-byte load per
             // 128-byte line, straight into an LDS scratch word (no register, no wait until the
-            // next barrier).  Wave w touches array w.
-            if (!last && wave < 7) {
+            // next barrier).  Wave w touches array w (, w + WAVES).
+            if (!last) {
                 const int nx0 = b0 + a_cut;
                 const int nxn = min(nb_cap, end - nx0);
-                if (lane * 16 < nxn)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(parr[wave] + nx0 + lane * 16),
-                        (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
+                for (int arr = wave; arr < 7; arr += WAVES) {
+                    for (int l0 = lane * 16; l0 < nxn; l0 += 64 * 16)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(parr[arr] + nx0 + l0),
+                            (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
+                }
             }
             DCOUNT(15, novf);
             // This lane's fast item: slot (row, column) = (quarter-wave, bank) of the table if its
@@ -334,19 +372,30 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                 }
             }
             if (e >= 0) {   // pairs (and singles) that stay in their cell
-                const int a = e & (PAIRED - 1);
-                const bool paired = (e & PAIRED) != 0;
+                const int a = e & IT_AMASK;
+                const bool paired = (e & IT_PAIRED) != 0;
                 const int a2 = paired ? a + 1 : a;
-                const ParticleState p1{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
+                ParticleState p1, p2;
+                if constexpr (STAGE) {
+                    p1 = ParticleState{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
                                        stage[4][a], stage[5][a], stage[6][a]};
-                const ParticleState p2{stage[0][a2], stage[1][a2], stage[2][a2], stage[3][a2],
+                    p2 = ParticleState{stage[0][a2], stage[1][a2], stage[2][a2], stage[3][a2],
                                        stage[4][a2], stage[5][a2], stage[6][a2]};
-                EsirkepovNC<O> s1, s2;
-                esirkepov_nc_shapes<O>(p1, g, q, dt, relative_time, s1);
-                esirkepov_nc_shapes<O>(p2, g, q, dt, relative_time, s2);
-                const int key = keys[a];
-                LdsSink<M> sink(lds, key & 255, (key >> 8) & 255, (key >> 16) & 255);
-                esirkepov_accumulate_pair_nc<O>(s1, s2, /*null2=*/!paired, g, dt, sink);
+                } else {
+                    const int g1 = b0 + a, g2 = b0 + a2;
+                    p1 = ParticleState{px[g1], py[g1], pz[g1], pw[g1], pux[g1], puy[g1], puz[g1]};
+                    p2 = ParticleState{px[g2], py[g2], pz[g2], pw[g2], pux[g2], puy[g2], puz[g2]};
+                }
+                const int fk = e >> IT_FRAME_SHIFT;
+                LdsSink<M, TSZ> sink(lds, fk & 15, (fk >> 4) & 15, fk >> 8);
+                if constexpr (CFG::PHASED == 0) {
+                    EsirkepovNC<O> s1, s2;
+                    esirkepov_nc_shapes<O>(p1, g, q, es, s1);
+                    esirkepov_nc_shapes<O>(p2, g, q, es, s2);
+                    esirkepov_accumulate_pair_nc<O>(s1, s2, /*null2=*/!paired, es, sink);
+                } else {
+                    esirkepov_pair_phased<O, CFG::PHASED == 2>(p1, p2, /*null2=*/!paired, g, q, es, sink);
+                }
             }
             DPROF(2);   // fast pass
             // Particles with a cell crossing take the general path (alone: merging two of them would
@@ -356,8 +405,8 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
             // 64 to a wave, the three J components on different waves: when the list would overflow
             // (hot / relativistic plasma: every batch) and once at the end of the tile.
             int nd_base = nd0;
-            DCOUNT(8, nfast); DCOUNT(9, nsl); DCOUNT(10, 1); DCOUNT(11, a_cut); DCOUNT(12, nb);
-            if (last || nd0 + nsl > DT_DEFER) {   // block-uniform
+            DCOUNT(8, min(tot_f, FAST_CAP)); DCOUNT(9, nsl); DCOUNT(10, 1); DCOUNT(11, a_cut); DCOUNT(12, nb);
+            if (last || nd0 + nsl > DEFER) {   // block-uniform
                 DCOUNT(13, 1); DCOUNT(14, nd0);
                 // work unit = (64 deferred particles, one J component); units go round the waves
                 const int nunits = 3 * ((nd0 + 63) >> 6);
@@ -367,28 +416,29 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                     const int ip = (int)deferred[it];
                     const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
                     EsirkepovShapes<O> s1;
-                    esirkepov_shapes<O>(p1, g, q, dt, relative_time, s1);
-                    LdsSink<M> sink(lds, s1.bi - o0, s1.bj - o1, s1.bk - o2);
+                    esirkepov_shapes<O>(p1, g, q, es, s1);
+                    LdsSink<M, TSZ> sink(lds, s1.bi - o0, s1.bj - o1, s1.bk - o2);
                     switch (u % 3) {
-                        case 0: esirkepov_accumulate_comp<O, 0>(s1, g, dt, sink); break;
-                        case 1: esirkepov_accumulate_comp<O, 1>(s1, g, dt, sink); break;
-                        default: esirkepov_accumulate_comp<O, 2>(s1, g, dt, sink); break;
+                        case 0: esirkepov_accumulate_comp<O, 0>(s1, es, sink); break;
+                        case 1: esirkepov_accumulate_comp<O, 1>(s1, es, sink); break;
+                        default: esirkepov_accumulate_comp<O, 2>(s1, es, sink); break;
                     }
                 }
                 nd_base = 0;
                 __syncthreads();   // the list is free again
             }
             DPROF(3);   // deferred general-path flush
-            for (int rk = tid; rk < nsl; rk += DT_THREADS) {
-                const int e = items[DT_BATCH - 1 - rk];
-                deferred[nd_base + rk] = (unsigned)(b0 + (e & (PAIRED - 1)));   // slow items are singles
-            }
+            for (int rk = tid; rk < nsl; rk += NT)
+                deferred[nd_base + rk] = (unsigned)(b0 + items[BATCH - 1 - rk]);   // slow items are singles
             if (tid == 0) ndeferred = nd_base + nsl;
             if (last) break;
             b0 += a_cut;
         } else {
-            for (int a = tid; a < nb; a += DT_THREADS)
-                if (keys[a] >= 0) items[atomicAdd(&nitems, 1)] = a;
+#pragma unroll
+            for (int rr = 0; rr < ROUNDS; ++rr) {
+                const int a = tid + rr * NT;
+                if (a < nb && key_r[rr] >= 0) items[atomicAdd(&nitems, 1)] = a;
+            }
             __syncthreads();
             DPROF(1);
             constexpr int IPC = 4;
@@ -398,11 +448,17 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                 const int it = (c / IPC) * (64 * IPC) + lane * IPC + (c % IPC);
                 if (it >= total) continue;
                 const int a = items[it];
-                const ParticleState p1{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
+                ParticleState p1;
+                if constexpr (STAGE) {
+                    p1 = ParticleState{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
                                        stage[4][a], stage[5][a], stage[6][a]};
+                } else {
+                    const int g1 = b0 + a;
+                    p1 = ParticleState{px[g1], py[g1], pz[g1], pw[g1], pux[g1], puy[g1], puz[g1]};
+                }
                 DirectShapes<O> sh;
                 direct_shapes<O>(p1, g, q, relative_time, sh);
-                LdsSink<M> sink(lds, -o0, -o1, -o2);
+                LdsSink<M, TSZ> sink(lds, -o0, -o1, -o2);
                 direct_accumulate<O>(sh, sink);
             }
             b0 += nb;
@@ -415,10 +471,185 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const DevF& J = *Jc[c];
-        for (int a = tid; a < NPTS; a += DT_THREADS) {
+        for (int a = tid; a < NPTS; a += NT) {
             const double v = lds[c * NPTS + a];
             if (v != 0.0) {
                 // a = i + N j + PS k; the padding words of a plane (a % PS >= N N) stay zero
+                const int i = o0 + (a % PS) % N, j = o1 + (a % PS) / N, k = o2 + a / PS;
+                if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
+                    k < J.lo2 + J.n2)
+                    atomic_add_f64(J.p + J.off(i, j, k), v);
+            }
+        }
+    }
+    DPROF(5);   // write-back
+    DPROF_FINISH
+}
+
+// ---- Esirkepov on LDS tiles, wave-independent variant -------------------------------------------------------------
+// No staging, no work-item lists, no barrier inside the particle loop: wave w of the workgroup takes the 128-particle
+// chunks w, w + WAVES, ... of the tile's (contiguous, cell-sorted) range, lane (r, c) = (lane / 16, lane % 16) of the wave
+// takes the particles (2P, 2P + 1), P = 4 c + r, of its chunk, and merges them in registers when both stay in their
+// cell and share the stencil frame (neighbours in the cell sort: ~85 % at 8 particles per cell).  The 16 lanes that one
+// step of a ds_add_f64 serves together (a quarter-wave r) then hold every 4th pair, i.e. particles 8 apart -- about one
+// cell apart, and 16 consecutive cells of the sort order start on 16 different LDS banks (TileDims, cell_of) -- so the
+// bank spread of the bucketed variant above is approximated by the mapping alone; the wave's loads still cover one
+// contiguous 1 KB range per array.  What does not fit the mapping goes to two small per-tile lists that are run densely
+// after the loop: second particles that could not be merged ("leftover", fast path with an empty partner) and particles
+// with a cell crossing ("deferred", general Esirkepov body, three components on different waves).
+// Waves never wait for each other inside the loop, so loads, weight arithmetic and LDS atomics of different waves overlap.
+template <int NT_, int TSZ_, int WPE_, int PHASED_>
+struct WaveCfg {
+    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_;
+};
+
+template <int O, int M, class CFG>
+__global__ void __launch_bounds__(CFG::NT) WXA_WAVES_PER_SIMD(CFG::WPE)
+deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                          const double* __restrict__ pz, const double* __restrict__ pw,
+                          const double* __restrict__ pux, const double* __restrict__ puy,
+                          const double* __restrict__ puz, const int* __restrict__ offsets, DevF Jx, DevF Jy,
+                          DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, StragglerQueue sq) {
+    constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
+    using TD = TileDims<M, TSZ>;
+    constexpr int N = TD::N, NZ = TD::NZ, NPTS = TD::NPTS, PS = TD::PS;
+    constexpr int SUB = TS / TSZ;
+    constexpr int SUB_CELLS = TILE_CELLS / SUB;
+    constexpr int WAVES = NT / 64;
+    constexpr int LEFT = TSZ == 8 ? 2048 : 1024;   // capacity of the leftover list
+    constexpr int DEFER = TSZ == 8 ? 1024 : 512;   // capacity of the deferred list
+    __shared__ double lds[3 * NPTS];
+    __shared__ unsigned leftover[LEFT];
+    __shared__ unsigned deferred[DEFER];
+    __shared__ int nleft, ndeferred;
+    const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
+    const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
+    if (unit >= ntiles * SUB) return;
+    const long tile = unit / SUB;
+    const int half = (int)(unit % SUB);
+    const int start = offsets[tile * TILE_CELLS + half * SUB_CELLS];
+    const int end = offsets[tile * TILE_CELLS + (half + 1) * SUB_CELLS];
+    if (end <= start) return;
+    const int tid = threadIdx.x;
+    DPROF_INIT
+    for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = 0.0;
+    if (tid == 0) { nleft = 0; ndeferred = 0; }
+    const int ti = (int)(tile % tg.nt[0]);
+    const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
+    const int tk = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
+    const int o0 = tg.cell_lo[0] + ti * TS + TD::LO;
+    const int o1 = tg.cell_lo[1] + tj * TS + TD::LO;
+    const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
+    const int wave = tid >> 6, lane = tid & 63;
+    __syncthreads();
+    DPROF(0);   // zero fill
+    const int first = start & ~1;                      // pairs start on an even particle index
+    const int npairs = (end - first + 1) >> 1;
+    const int pair_in_chunk = 4 * (lane & 15) + (lane >> 4);
+    // classification of one particle: coordinates, stencil frame relative to the tile, fast / deferred / straggler
+    auto classify = [&](const int ip, EsirkepovCoords& cc, double& wq, int& key) -> int {
+        const ParticleState p{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+        cc = esirkepov_coords(p, g, es);
+        wq = q * p.w;
+        int bi, bj, bk;
+        const bool cross = esirkepov_frame_cross<O>(cc, g, bi, bj, bk);
+        const int li = bi - o0, lj = bj - o1, lk = bk - o2;
+        const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N && lk + O + 3 <= NZ;
+        key = frame_key(li, lj, lk);
+        return !in ? 2 : cross ? 1 : 0;   // 0: fast, 1: deferred (general path on the tile), 2: straggler
+    };
+    int mode = 0;                 // 0: the tile's particles pair by pair; 1: the leftover list
+    int c0 = wave * 64;
+    int nl = 0;
+    for (;;) {
+        EsirkepovCoords c1, c2;
+        double wq1 = 0.0, wq2 = 0.0;
+        int key = -1;
+        if (mode == 0) {
+            if (c0 >= npairs) {   // every wave passes here exactly once
+                __syncthreads();
+                DPROF(2);
+                mode = 1;
+                c0 = wave * 64;
+                nl = min(nleft, LEFT);
+                continue;
+            }
+            const int P = c0 + pair_in_chunk;
+            const int ia = first + 2 * P, ib = ia + 1;
+            const bool va = P < npairs && ia >= start, vb = P < npairs && ib < end;
+            int ka = -1, kb = -1, sa = 3, sb = 3;   // 3: no particle
+            double wqb = 0.0;
+            if (va) sa = classify(ia, c1, wq1, ka);
+            if (vb) sb = classify(ib, c2, wqb, kb);
+            auto defer = [&](const int ip) {
+                const int n = atomicAdd(&ndeferred, 1);
+                if (n < DEFER) deferred[n] = (unsigned)ip;
+                else sq.push(ip);
+            };
+            if (sa == 1) defer(ia);
+            if (sb == 1) defer(ib);
+            if (sa == 2) sq.push(ia);
+            if (sb == 2) sq.push(ib);
+            if (sa == 0) {
+                key = ka;
+                if (sb == 0 && kb == ka) {
+                    wq2 = wqb;   // merged with its neighbour
+                } else {
+                    if (sb == 0) {
+                        const int n = atomicAdd(&nleft, 1);
+                        if (n < LEFT) leftover[n] = (unsigned)ib;
+                        else sq.push(ib);
+                    }
+                    c2 = c1;     // empty partner (weight 0)
+                }
+            } else if (sb == 0) {
+                key = kb; c1 = c2; wq1 = wqb;   // the second particle alone, its own coordinates as the empty partner's
+            }
+        } else {
+            if (c0 >= nl) break;
+            const int it = c0 + lane;
+            if (it < nl) {
+                const int st = classify((int)leftover[it], c1, wq1, key);
+                (void)st;   // classified as fast when it was listed
+                c2 = c1;
+            }
+        }
+        if (key >= 0) {
+            LdsSink<M, TSZ> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
+            esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
+        }
+        c0 += WAVES * 64;
+    }
+    __syncthreads();
+    DPROF(3);   // leftover pass
+    {
+        // particles with a cell crossing: general body, 64 to a wave, the three J components on different waves
+        const int nd = min(ndeferred, DEFER);
+        const int nunits = 3 * ((nd + 63) >> 6);
+        for (int u = wave; u < nunits; u += WAVES) {
+            const int it = (u / 3) * 64 + lane;
+            if (it >= nd) continue;
+            const int ip = (int)deferred[it];
+            const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+            EsirkepovShapes<O> s1;
+            esirkepov_shapes<O>(p1, g, q, es, s1);
+            LdsSink<M, TSZ> sink(lds, s1.bi - o0, s1.bj - o1, s1.bk - o2);
+            switch (u % 3) {
+                case 0: esirkepov_accumulate_comp<O, 0>(s1, es, sink); break;
+                case 1: esirkepov_accumulate_comp<O, 1>(s1, es, sink); break;
+                default: esirkepov_accumulate_comp<O, 2>(s1, es, sink); break;
+            }
+        }
+    }
+    __syncthreads();
+    DPROF(4);   // deferred general path
+    const DevF* Jc[3] = {&Jx, &Jy, &Jz};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const DevF& J = *Jc[c];
+        for (int a = tid; a < NPTS; a += NT) {
+            const double v = lds[c * NPTS + a];
+            if (v != 0.0) {
                 const int i = o0 + (a % PS) % N, j = o1 + (a % PS) / N, k = o2 + a / PS;
                 if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
                     k < J.lo2 + J.n2)
@@ -437,7 +668,7 @@ deposit_stragglers_kernel(const double* __restrict__ px, const double* __restric
                           const double* __restrict__ pux, const double* __restrict__ puy,
                           const double* __restrict__ puz, const int* __restrict__ idx,
                           const unsigned* __restrict__ count, DevF Jx, DevF Jy, DevF Jz, Geom g, double q,
-                          double dt, double relative_time) {
+                          EsirkepovStep es, double relative_time) {
     const unsigned n = *count;
     GlobalSink gs = make_global_sink(Jx, Jy, Jz);
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
@@ -445,9 +676,9 @@ deposit_stragglers_kernel(const double* __restrict__ px, const double* __restric
         const ParticleState p{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
         if constexpr (ALGO == WXA_DEPOSIT_ESIRKEPOV) {
             EsirkepovShapes<O> s;
-            esirkepov_shapes<O>(p, g, q, dt, relative_time, s);
+            esirkepov_shapes<O>(p, g, q, es, s);
             gs.bi = s.bi; gs.bj = s.bj; gs.bk = s.bk;
-            esirkepov_accumulate<O>(s, g, dt, gs);
+            esirkepov_accumulate<O>(s, es, gs);
         } else {
             DirectShapes<O> s;
             direct_shapes<O>(p, g, q, relative_time, s);
@@ -460,7 +691,12 @@ bool deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p)
     return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np <= p->np;
 }
 
-template <int O, int ALGO>
+// One extra LDS point per side beyond the exact stencil reach (M = 1): particles may have drifted up
+// to one cell since the last sort (sort_intervals > 1) before they have to take the
+// straggler path (global atomics, ~7 ns per particle).
+constexpr int MARGIN = 1;
+
+template <int O, int ALGO, class CFG>
 static wxa_status launch_tile(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
                               double q, double dt, double relative_time, wxa_workspace* ws, hipStream_t st) {
     TileGeom tg;
@@ -468,39 +704,90 @@ static wxa_status launch_tile(const wxa_particle_view* p, const wxa_field_view J
         tg.nt[d] = (ws->sort_nc[d] + TS - 1) / TS;
         tg.cell_lo[d] = ws->sort_cell_lo[d];
     }
-    const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
+    const long nunits = (long)tg.nt[0] * tg.nt[1] * tg.nt[2] * (TS / CFG::TSZ);
     const Geom g = make_geom(*geom);
     const int* offsets = (const int*)ws->offsets.p;
-    const dim3 grid((unsigned)xcd_grid_size(ntiles)), block(DT_THREADS);
+    const dim3 grid((unsigned)xcd_grid_size(nunits)), block(CFG::NT);
     wxa_status rc;
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
     if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
     StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
-    // One extra LDS point per side beyond the exact stencil reach: particles may have drifted up
-    // to one cell since the last sort (sort_intervals > 1) before they have to take the
-    // straggler path (global atomics, ~7 ns per particle).  3 x 15^3 x 8 B = 81 KB + 56 KB stage.
-    constexpr int M = 1;
-    hipLaunchKernelGGL((deposit_tile_kernel<O, ALGO, M>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, dt, relative_time, sq);
+    const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
+    hipLaunchKernelGGL((deposit_tile_kernel<O, ALGO, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
+                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, relative_time, sq);
     hipLaunchKernelGGL((deposit_stragglers_kernel<O, ALGO>), dim3(512), dim3(256), 0, st, p->x, p->y, p->z, p->w,
-                       p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, dt, relative_time);
+                       p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
+}
+
+template <int O, class CFG>
+static wxa_status launch_waves(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
+                               double q, double dt, double relative_time, wxa_workspace* ws, hipStream_t st) {
+    TileGeom tg;
+    for (int d = 0; d < 3; ++d) {
+        tg.nt[d] = (ws->sort_nc[d] + TS - 1) / TS;
+        tg.cell_lo[d] = ws->sort_cell_lo[d];
+    }
+    const long nunits = (long)tg.nt[0] * tg.nt[1] * tg.nt[2] * (TS / CFG::TSZ);
+    const Geom g = make_geom(*geom);
+    const int* offsets = (const int*)ws->offsets.p;
+    const dim3 grid((unsigned)xcd_grid_size(nunits)), block(CFG::NT);
+    wxa_status rc;
+    if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
+    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
+    WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
+    const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
+    const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
+    hipLaunchKernelGGL((deposit_tile_waves_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
+                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, sq);
+    hipLaunchKernelGGL((deposit_stragglers_kernel<O, WXA_DEPOSIT_ESIRKEPOV>), dim3(512), dim3(256), 0, st, p->x, p->y,
+                       p->z, p->w, p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+// Production configuration, and the alternatives kept for A/B timing (WXA_DEPOSIT_VARIANT=<n>, order 3 Esirkepov
+// only; scripts/deposit_variants.py)
+using CfgWhole = TileCfg<512, 8, true, 2, 0>;      // round 1: whole tile + LDS stage, 155 KB, 1 workgroup per CU
+using CfgHalf = TileCfg<512, 4, false, 4, 2>;      // half tile, no stage, 2 workgroups per CU, 128 VGPRs
+using CfgHalf3 = TileCfg<384, 4, false, 3, 1>;     // half tile, no stage, 2 workgroups of 6 waves, 168 VGPRs
+using CfgWhole3 = TileCfg<768, 8, false, 3, 1>;    // whole tile, no stage, 1 workgroup of 12 waves, 168 VGPRs
+using WavesHalf4 = WaveCfg<512, 4, 4, 2>;          // half tile, 2 workgroups of 8 waves per CU, 128 VGPRs
+using WavesHalf3 = WaveCfg<384, 4, 3, 1>;          // half tile, 2 workgroups of 6 waves per CU, 168 VGPRs
+using WavesWhole3 = WaveCfg<768, 8, 3, 1>;         // whole tile, 1 workgroup of 12 waves per CU
+using WavesWhole4 = WaveCfg<1024, 8, 4, 2>;        // whole tile, 1 workgroup of 16 waves per CU
+using CfgDefault = WXA_DEPOSIT_CFG;
+
+static int deposit_variant() {   // read per launch: the tests switch it between calls
+    const char* e = getenv("WXA_DEPOSIT_VARIANT");
+    return e ? atoi(e) : -1;
 }
 
 wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
                                  double q, double dt, double relative_time, int order, int algo,
                                  wxa_workspace* ws, hipStream_t st) {
     if (algo == WXA_DEPOSIT_ESIRKEPOV) {
-        if (order == 1) return launch_tile<1, WXA_DEPOSIT_ESIRKEPOV>(p, J, geom, q, dt, relative_time, ws, st);
-        if (order == 2) return launch_tile<2, WXA_DEPOSIT_ESIRKEPOV>(p, J, geom, q, dt, relative_time, ws, st);
-        return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV>(p, J, geom, q, dt, relative_time, ws, st);
+        if (order == 1) return launch_tile<1, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
+        if (order == 2) return launch_tile<2, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
+        switch (deposit_variant()) {
+            case 0: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgWhole>(p, J, geom, q, dt, relative_time, ws, st);
+            case 1: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgHalf>(p, J, geom, q, dt, relative_time, ws, st);
+            case 2: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgHalf3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 3: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgWhole3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 4: return launch_waves<3, WavesHalf4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 5: return launch_waves<3, WavesHalf3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 6: return launch_waves<3, WavesWhole3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 7: return launch_waves<3, WavesWhole4>(p, J, geom, q, dt, relative_time, ws, st);
+            default: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
+        }
     }
-    if (order == 1) return launch_tile<1, WXA_DEPOSIT_DIRECT>(p, J, geom, q, dt, relative_time, ws, st);
-    if (order == 2) return launch_tile<2, WXA_DEPOSIT_DIRECT>(p, J, geom, q, dt, relative_time, ws, st);
-    return launch_tile<3, WXA_DEPOSIT_DIRECT>(p, J, geom, q, dt, relative_time, ws, st);
+    if (order == 1) return launch_tile<1, WXA_DEPOSIT_DIRECT, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
+    if (order == 2) return launch_tile<2, WXA_DEPOSIT_DIRECT, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
+    return launch_tile<3, WXA_DEPOSIT_DIRECT, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
 }
 
 }  // namespace wxa

@@ -39,16 +39,15 @@ gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, G
 // is available.  Bodies in deposit_body.hpp.
 template <int O>
 __global__ void __launch_bounds__(256)
-deposit_esirkepov_global_kernel(PV p, DevF Jx, DevF Jy, DevF Jz, Geom g, double q, double dt,
-                                double relative_time) {
+deposit_esirkepov_global_kernel(PV p, DevF Jx, DevF Jy, DevF Jz, Geom g, double q, EsirkepovStep es) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= p.np) return;
     const ParticleState ps{p.x[ip], p.y[ip], p.z[ip], p.w[ip], p.ux[ip], p.uy[ip], p.uz[ip]};
     EsirkepovShapes<O> s;
-    esirkepov_shapes<O>(ps, g, q, dt, relative_time, s);
+    esirkepov_shapes<O>(ps, g, q, es, s);
     GlobalSink sink = make_global_sink(Jx, Jy, Jz);
     sink.bi = s.bi; sink.bj = s.bj; sink.bk = s.bk;
-    esirkepov_accumulate<O>(s, g, dt, sink);
+    esirkepov_accumulate<O>(s, es, sink);
 }
 
 template <int O>
@@ -600,9 +599,10 @@ wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view 
     const dim3 grid(blocks_for(pv.np)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (algo == WXA_DEPOSIT_ESIRKEPOV) {
-        if (order == 1) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<1>, grid, block, 0, st, pv, jx, jy, jz, g, q, dt, relative_time);
-        else if (order == 2) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<2>, grid, block, 0, st, pv, jx, jy, jz, g, q, dt, relative_time);
-        else hipLaunchKernelGGL(deposit_esirkepov_global_kernel<3>, grid, block, 0, st, pv, jx, jy, jz, g, q, dt, relative_time);
+        const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
+        if (order == 1) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<1>, grid, block, 0, st, pv, jx, jy, jz, g, q, es);
+        else if (order == 2) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<2>, grid, block, 0, st, pv, jx, jy, jz, g, q, es);
+        else hipLaunchKernelGGL(deposit_esirkepov_global_kernel<3>, grid, block, 0, st, pv, jx, jy, jz, g, q, es);
     } else {
         if (order == 1) hipLaunchKernelGGL(deposit_direct_global_kernel<1>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
         else if (order == 2) hipLaunchKernelGGL(deposit_direct_global_kernel<2>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
