@@ -8,7 +8,8 @@ from collections import defaultdict
 root = sys.argv[1]
 pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else ".")
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True):
+for f in (glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True) +
+          glob.glob(root + "pass*/**/*counter_collection.csv", recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name", "")

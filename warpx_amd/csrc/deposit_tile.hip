@@ -498,9 +498,12 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 // after the loop: second particles that could not be merged ("leftover", fast path with an empty partner) and particles
 // with a cell crossing ("deferred", general Esirkepov body, three components on different waves).
 // Waves never wait for each other inside the loop, so loads, weight arithmetic and LDS atomics of different waves overlap.
-template <int NT_, int TSZ_, int WPE_, int PHASED_>
+// SPACING = pairs between neighbouring lanes of a quarter-wave (a multiple of 4): 4 puts them about one cell apart at
+// 8 particles per cell, 8 about two cells apart (16 cells of every other one still cover the 16 banks, and two lanes
+// land in the same cell -- same LDS address -- only when a cell holds more than 16 particles).
+template <int NT_, int TSZ_, int WPE_, int PHASED_, int SPACING_ = 4>
 struct WaveCfg {
-    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_;
+    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, SPACING = SPACING_;
 };
 
 template <int O, int M, class CFG>
@@ -545,7 +548,11 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
     DPROF(0);   // zero fill
     const int first = start & ~1;                      // pairs start on an even particle index
     const int npairs = (end - first + 1) >> 1;
-    const int pair_in_chunk = 4 * (lane & 15) + (lane >> 4);
+    // a wave's group = 16 SPACING pairs, covered in SPACING / 4 iterations of 64 pairs: iteration h takes the pairs
+    // SPACING c + 4 h + r of the group
+    constexpr int SPACING = CFG::SPACING, SUBIT = SPACING / 4, GROUP = 16 * SPACING;
+    static_assert(SPACING % 4 == 0, "quarter-wave rows");
+    const int pair_in_group = SPACING * (lane & 15) + (lane >> 4);
     // classification of one particle: coordinates, stencil frame relative to the tile, fast / deferred / straggler
     auto classify = [&](const int ip, EsirkepovCoords& cc, double& wq, int& key) -> int {
         const ParticleState p{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
@@ -559,7 +566,8 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
         return !in ? 2 : cross ? 1 : 0;   // 0: fast, 1: deferred (general path on the tile), 2: straggler
     };
     int mode = 0;                 // 0: the tile's particles pair by pair; 1: the leftover list
-    int c0 = wave * 64;
+    int c0 = wave * GROUP;        // mode 0: first pair of the wave's group; mode 1: first list entry of the wave's chunk
+    int sub = 0;                  // iteration inside the group
     int nl = 0;
     for (;;) {
         EsirkepovCoords c1, c2;
@@ -574,7 +582,7 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
                 nl = min(nleft, LEFT);
                 continue;
             }
-            const int P = c0 + pair_in_chunk;
+            const int P = c0 + pair_in_group + 4 * sub;
             const int ia = first + 2 * P, ib = ia + 1;
             const bool va = P < npairs && ia >= start, vb = P < npairs && ib < end;
             int ka = -1, kb = -1, sa = 3, sb = 3;   // 3: no particle
@@ -618,7 +626,11 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
             LdsSink<M, TSZ> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
             esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
         }
-        c0 += WAVES * 64;
+        if (mode == 0) {
+            if (++sub == SUBIT) { sub = 0; c0 += WAVES * GROUP; }
+        } else {
+            c0 += WAVES * 64;
+        }
     }
     __syncthreads();
     DPROF(3);   // leftover pass
@@ -760,6 +772,8 @@ using WavesHalf4 = WaveCfg<512, 4, 4, 2>;          // half tile, 2 workgroups of
 using WavesHalf3 = WaveCfg<384, 4, 3, 1>;          // half tile, 2 workgroups of 6 waves per CU, 168 VGPRs
 using WavesWhole3 = WaveCfg<768, 8, 3, 1>;         // whole tile, 1 workgroup of 12 waves per CU
 using WavesWhole4 = WaveCfg<1024, 8, 4, 2>;        // whole tile, 1 workgroup of 16 waves per CU
+using WavesHalf4S8 = WaveCfg<512, 4, 4, 2, 8>;     // as WavesHalf4, quarter-wave lanes two cells apart
+using WavesWhole3S8 = WaveCfg<768, 8, 3, 1, 8>;    // as WavesWhole3, quarter-wave lanes two cells apart
 using CfgDefault = WXA_DEPOSIT_CFG;
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
@@ -782,6 +796,8 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
             case 5: return launch_waves<3, WavesHalf3>(p, J, geom, q, dt, relative_time, ws, st);
             case 6: return launch_waves<3, WavesWhole3>(p, J, geom, q, dt, relative_time, ws, st);
             case 7: return launch_waves<3, WavesWhole4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 8: return launch_waves<3, WavesHalf4S8>(p, J, geom, q, dt, relative_time, ws, st);
+            case 9: return launch_waves<3, WavesWhole3S8>(p, J, geom, q, dt, relative_time, ws, st);
             default: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
         }
     }
