@@ -487,23 +487,25 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 }
 
 // ---- Esirkepov on LDS tiles, wave-independent variant -------------------------------------------------------------
-// No staging, no work-item lists, no barrier inside the particle loop: wave w of the workgroup takes the 128-particle
-// chunks w, w + WAVES, ... of the tile's (contiguous, cell-sorted) range, lane (r, c) = (lane / 16, lane % 16) of the wave
-// takes the particles (2P, 2P + 1), P = 4 c + r, of its chunk, and merges them in registers when both stay in their
-// cell and share the stencil frame (neighbours in the cell sort: ~85 % at 8 particles per cell).  The 16 lanes that one
-// step of a ds_add_f64 serves together (a quarter-wave r) then hold every 4th pair, i.e. particles 8 apart -- about one
-// cell apart, and 16 consecutive cells of the sort order start on 16 different LDS banks (TileDims, cell_of) -- so the
-// bank spread of the bucketed variant above is approximated by the mapping alone; the wave's loads still cover one
-// contiguous 1 KB range per array.  What does not fit the mapping goes to two small per-tile lists that are run densely
-// after the loop: second particles that could not be merged ("leftover", fast path with an empty partner) and particles
-// with a cell crossing ("deferred", general Esirkepov body, three components on different waves).
+// No staging, no work-item lists, no barrier inside the particle loop.  Two lane mappings:
+//  * MAP_CELLS: a wave iteration takes 16 consecutive cells of the sort order; lane (r, c) = (lane / 16, lane % 16)
+//    takes the particles (2 r, 2 r + 1) of cell c's run (offsets[] of the cell sort).  The 16 lanes that one step of a
+//    ds_add_f64 serves together (quarter-wave r) then sit in 16 different cells whose stencil frames start on 16
+//    different LDS banks (TileDims, cell_of): conflict-free by construction while the particles are still in the
+//    cell they were sorted into, and no two lanes of a step share an address.  A cell's particles beyond the 8th
+//    go to the leftover list as pair entries.
+//  * MAP_SPACED: wave w takes 64-pair chunks of the tile's contiguous range, lane (r, c) the pair SPACING c + r (+ 4 h):
+//    neighbouring lanes of a quarter-wave are SPACING / 4 cells apart on average -- no offsets[] reads, but the bank
+//    spread is only statistical (measured: 45-70 % extra LDS cycles from bank / same-address conflicts).
+// A lane merges its two particles in registers when both stay in their cell and share the stencil frame.  What does not
+// fit goes to two small per-tile lists that are run densely after the loop: the "leftover" entries (second particles
+// that could not be merged, particles beyond a cell's 8th) through the same fast code, and particles with a cell
+// crossing ("deferred") through the general Esirkepov body, spread over (particle, component, plane) lanes.
 // Waves never wait for each other inside the loop, so loads, weight arithmetic and LDS atomics of different waves overlap.
-// SPACING = pairs between neighbouring lanes of a quarter-wave (a multiple of 4): 4 puts them about one cell apart at
-// 8 particles per cell, 8 about two cells apart (16 cells of every other one still cover the 16 banks, and two lanes
-// land in the same cell -- same LDS address -- only when a cell holds more than 16 particles).
-template <int NT_, int TSZ_, int WPE_, int PHASED_, int SPACING_ = 4>
+constexpr int MAP_SPACED = 0, MAP_CELLS = 1;
+template <int NT_, int TSZ_, int WPE_, int PHASED_, int SPACING_ = 4, int MAP_ = MAP_SPACED>
 struct WaveCfg {
-    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, SPACING = SPACING_;
+    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, SPACING = SPACING_, MAP = MAP_;
 };
 
 template <int O, int M, class CFG>
@@ -522,7 +524,7 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
     constexpr int LEFT = TSZ == 8 ? 2048 : 1024;   // capacity of the leftover list
     constexpr int DEFER = TSZ == 8 ? 1024 : 512;   // capacity of the deferred list
     __shared__ double lds[3 * NPTS];
-    __shared__ unsigned leftover[LEFT];
+    __shared__ unsigned leftover[LEFT];            // (particle index << 1) | "merge with the next particle if possible"
     __shared__ unsigned deferred[DEFER];
     __shared__ int nleft, ndeferred;
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
@@ -530,8 +532,9 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
     if (unit >= ntiles * SUB) return;
     const long tile = unit / SUB;
     const int half = (int)(unit % SUB);
-    const int start = offsets[tile * TILE_CELLS + half * SUB_CELLS];
-    const int end = offsets[tile * TILE_CELLS + (half + 1) * SUB_CELLS];
+    const long ucell0 = tile * TILE_CELLS + half * SUB_CELLS;
+    const int start = offsets[ucell0];
+    const int end = offsets[ucell0 + SUB_CELLS];
     if (end <= start) return;
     const int tid = threadIdx.x;
     DPROF_INIT
@@ -546,13 +549,16 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
     DPROF(0);   // zero fill
-    const int first = start & ~1;                      // pairs start on an even particle index
+    const int first = start & ~1;                      // MAP_SPACED: pairs start on an even particle index
     const int npairs = (end - first + 1) >> 1;
-    // a wave's group = 16 SPACING pairs, covered in SPACING / 4 iterations of 64 pairs: iteration h takes the pairs
-    // SPACING c + 4 h + r of the group
-    constexpr int SPACING = CFG::SPACING, SUBIT = SPACING / 4, GROUP = 16 * SPACING;
+    // MAP_SPACED: a wave's group = 16 SPACING pairs, covered in SPACING / 4 iterations of 64 pairs: iteration h takes
+    // the pairs SPACING c + 4 h + r of the group.  MAP_CELLS: a group = 16 cells, one iteration.
+    constexpr int SPACING = CFG::SPACING, SUBIT = CFG::MAP == MAP_CELLS ? 1 : SPACING / 4;
+    constexpr int GROUP = CFG::MAP == MAP_CELLS ? 16 : 16 * SPACING;
+    constexpr int NWORK_CELLS = SUB_CELLS;
     static_assert(SPACING % 4 == 0, "quarter-wave rows");
     const int pair_in_group = SPACING * (lane & 15) + (lane >> 4);
+    const int nwork = CFG::MAP == MAP_CELLS ? NWORK_CELLS : npairs;   // cells or pairs of this unit
     // classification of one particle: coordinates, stencil frame relative to the tile, fast / deferred / straggler
     auto classify = [&](const int ip, EsirkepovCoords& cc, double& wq, int& key) -> int {
         const ParticleState p{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
@@ -565,16 +571,20 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
         key = frame_key(li, lj, lk);
         return !in ? 2 : cross ? 1 : 0;   // 0: fast, 1: deferred (general path on the tile), 2: straggler
     };
-    int mode = 0;                 // 0: the tile's particles pair by pair; 1: the leftover list
-    int c0 = wave * GROUP;        // mode 0: first pair of the wave's group; mode 1: first list entry of the wave's chunk
+    auto defer = [&](const int ip) {
+        const int n = atomicAdd(&ndeferred, 1);
+        if (n < DEFER) deferred[n] = (unsigned)ip;
+        else sq.push(ip);
+    };
+    int mode = 0;                 // 0: the tile's particles through the lane mapping; 1: the leftover list
+    int c0 = wave * GROUP;        // mode 0: first pair / cell of the wave's group; mode 1: first list entry of its chunk
     int sub = 0;                  // iteration inside the group
     int nl = 0;
     for (;;) {
-        EsirkepovCoords c1, c2;
-        double wq1 = 0.0, wq2 = 0.0;
-        int key = -1;
+        int ia = start;
+        bool va = false, vb = false;
         if (mode == 0) {
-            if (c0 >= npairs) {   // every wave passes here exactly once
+            if (c0 >= nwork) {   // every wave passes here exactly once
                 __syncthreads();
                 DPROF(2);
                 mode = 1;
@@ -582,45 +592,65 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
                 nl = min(nleft, LEFT);
                 continue;
             }
-            const int P = c0 + pair_in_group + 4 * sub;
-            const int ia = first + 2 * P, ib = ia + 1;
-            const bool va = P < npairs && ia >= start, vb = P < npairs && ib < end;
-            int ka = -1, kb = -1, sa = 3, sb = 3;   // 3: no particle
-            double wqb = 0.0;
-            if (va) sa = classify(ia, c1, wq1, ka);
-            if (vb) sb = classify(ib, c2, wqb, kb);
-            auto defer = [&](const int ip) {
-                const int n = atomicAdd(&ndeferred, 1);
-                if (n < DEFER) deferred[n] = (unsigned)ip;
-                else sq.push(ip);
-            };
-            if (sa == 1) defer(ia);
-            if (sb == 1) defer(ib);
-            if (sa == 2) sq.push(ia);
-            if (sb == 2) sq.push(ib);
-            if (sa == 0) {
-                key = ka;
-                if (sb == 0 && kb == ka) {
-                    wq2 = wqb;   // merged with its neighbour
-                } else {
-                    if (sb == 0) {
+            if constexpr (CFG::MAP == MAP_CELLS) {
+                const long cell = ucell0 + c0 + (lane & 15);
+                const int s0 = offsets[cell], e0 = offsets[cell + 1];
+                const int r = lane >> 4;
+                ia = s0 + 2 * r;
+                va = ia < e0;
+                vb = ia + 1 < e0;
+                if (r == 3) {   // the cell's particles beyond the 8th
+                    for (int k = s0 + 8; k < e0; k += 2) {
                         const int n = atomicAdd(&nleft, 1);
-                        if (n < LEFT) leftover[n] = (unsigned)ib;
-                        else sq.push(ib);
+                        if (n < LEFT) leftover[n] = ((unsigned)k << 1) | (k + 1 < e0 ? 1u : 0u);
+                        else { sq.push(k); if (k + 1 < e0) sq.push(k + 1); }
                     }
-                    c2 = c1;     // empty partner (weight 0)
                 }
-            } else if (sb == 0) {
-                key = kb; c1 = c2; wq1 = wqb;   // the second particle alone, its own coordinates as the empty partner's
+            } else {
+                const int P = c0 + pair_in_group + 4 * sub;
+                ia = first + 2 * P;
+                va = P < npairs && ia >= start;
+                vb = P < npairs && ia + 1 < end;
             }
         } else {
             if (c0 >= nl) break;
             const int it = c0 + lane;
             if (it < nl) {
-                const int st = classify((int)leftover[it], c1, wq1, key);
-                (void)st;   // classified as fast when it was listed
-                c2 = c1;
+                const unsigned ent = leftover[it];
+                ia = (int)(ent >> 1);
+                va = true;
+                vb = (ent & 1u) != 0;
             }
+        }
+        const int ib = ia + 1;
+        EsirkepovCoords c1, c2;
+        double wq1 = 0.0, wq2 = 0.0, wqb = 0.0;
+        int key = -1, ka = -1, kb = -1, sa = 3, sb = 3;   // 3: no particle
+        if (va) sa = classify(ia, c1, wq1, ka);
+        if (vb) sb = classify(ib, c2, wqb, kb);
+        if (sa == 1) defer(ia);
+        if (sb == 1) defer(ib);
+        if (sa == 2) sq.push(ia);
+        if (sb == 2) sq.push(ib);
+        if (sa == 0) {
+            key = ka;
+            if (sb == 0 && kb == ka) {
+                wq2 = wqb;   // merged with its neighbour
+            } else {
+                if (sb == 0) {   // a fast particle with another frame: a leftover single; from the leftover pass
+                                 // itself it goes to the general path (rare: its partner is beyond a cell's 8th)
+                    if (mode == 0) {
+                        const int n = atomicAdd(&nleft, 1);
+                        if (n < LEFT) leftover[n] = (unsigned)ib << 1;
+                        else sq.push(ib);
+                    } else {
+                        defer(ib);
+                    }
+                }
+                c2 = c1;     // empty partner (weight 0)
+            }
+        } else if (sb == 0) {
+            key = kb; c1 = c2; wq1 = wqb;   // the second particle alone, its own coordinates as the empty partner's
         }
         if (key >= 0) {
             LdsSink<M, TSZ> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
@@ -635,22 +665,22 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
     __syncthreads();
     DPROF(3);   // leftover pass
     {
-        // particles with a cell crossing: general body, 64 to a wave, the three J components on different waves
+        // Particles with a cell crossing: general body.  One lane per (component, plane, particle), so that the few
+        // dozen crossing particles of a tile occupy all the waves for one short pass (a lane per particle and
+        // component kept three waves busy for ~3000 instructions while the others waited at the barrier).
+        constexpr int NP = O + 3;
         const int nd = min(ndeferred, DEFER);
-        const int nunits = 3 * ((nd + 63) >> 6);
-        for (int u = wave; u < nunits; u += WAVES) {
-            const int it = (u / 3) * 64 + lane;
-            if (it >= nd) continue;
-            const int ip = (int)deferred[it];
+        const int nunits = 3 * NP * nd;
+        for (int u = tid; u < nunits; u += NT) {
+            const int comp = u / (NP * nd), rem = u - comp * (NP * nd);
+            const int b = rem / nd, ip = (int)deferred[rem - b * nd];
             const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
             EsirkepovShapes<O> s1;
             esirkepov_shapes<O>(p1, g, q, es, s1);
             LdsSink<M, TSZ> sink(lds, s1.bi - o0, s1.bj - o1, s1.bk - o2);
-            switch (u % 3) {
-                case 0: esirkepov_accumulate_comp<O, 0>(s1, es, sink); break;
-                case 1: esirkepov_accumulate_comp<O, 1>(s1, es, sink); break;
-                default: esirkepov_accumulate_comp<O, 2>(s1, es, sink); break;
-            }
+            if (comp == 0) esirkepov_accumulate_comp_plane<O, 0>(s1, es, sink, b);
+            else if (comp == 1) esirkepov_accumulate_comp_plane<O, 1>(s1, es, sink, b);
+            else esirkepov_accumulate_comp_plane<O, 2>(s1, es, sink, b);
         }
     }
     __syncthreads();
@@ -774,6 +804,10 @@ using WavesWhole3 = WaveCfg<768, 8, 3, 1>;         // whole tile, 1 workgroup of
 using WavesWhole4 = WaveCfg<1024, 8, 4, 2>;        // whole tile, 1 workgroup of 16 waves per CU
 using WavesHalf4S8 = WaveCfg<512, 4, 4, 2, 8>;     // as WavesHalf4, quarter-wave lanes two cells apart
 using WavesWhole3S8 = WaveCfg<768, 8, 3, 1, 8>;    // as WavesWhole3, quarter-wave lanes two cells apart
+using CellsHalf4 = WaveCfg<512, 4, 4, 2, 4, MAP_CELLS>;    // cell-indexed lanes, half tile, 2 x 8 waves per CU
+using CellsHalf3 = WaveCfg<384, 4, 3, 1, 4, MAP_CELLS>;    // cell-indexed lanes, half tile, 2 x 6 waves per CU
+using CellsWhole3 = WaveCfg<768, 8, 3, 1, 4, MAP_CELLS>;   // cell-indexed lanes, whole tile, 12 waves per CU
+using CellsWhole4 = WaveCfg<1024, 8, 4, 2, 4, MAP_CELLS>;  // cell-indexed lanes, whole tile, 16 waves per CU
 using CfgDefault = WXA_DEPOSIT_CFG;
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
@@ -798,6 +832,10 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
             case 7: return launch_waves<3, WavesWhole4>(p, J, geom, q, dt, relative_time, ws, st);
             case 8: return launch_waves<3, WavesHalf4S8>(p, J, geom, q, dt, relative_time, ws, st);
             case 9: return launch_waves<3, WavesWhole3S8>(p, J, geom, q, dt, relative_time, ws, st);
+            case 10: return launch_waves<3, CellsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 11: return launch_waves<3, CellsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 12: return launch_waves<3, CellsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 13: return launch_waves<3, CellsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
             default: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
         }
     }
