@@ -703,6 +703,200 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
     DPROF_FINISH
 }
 
+// ---- Esirkepov on LDS tiles, work items from the cell counts ----------------------------------------------------------
+// The cell sort already says where every cell's particles are (offsets[]), so the work items -- (cell, r) = the cell's
+// particles (2 r, 2 r + 1) -- follow from the cell counts alone, without looking at a particle:
+//   A  one lane per cell reads its count, row r of the item table holds the cells with more than r pairs (one wave
+//      ballot per row); the tile is zeroed meanwhile;
+//   B  every wave scans the (row, cell-wave) counts (64 numbers) and each cell writes its items to their places: the
+//      table lists row 0 of all cells, then row 1, ... -- consecutive items are consecutive cells of the sort order,
+//      so the 16 lanes that a step of a ds_add_f64 serves sit in 16 different cells on (mostly) 16 different banks,
+//      and the table is dense: no idle lanes for short cells, no second pass for long ones;
+//   C  lane t takes items t, t + NT, ...: loads its two particles (14 loads in flight), merges them when both stay
+//      in their cell and share the frame, deposits through the phased pair body; what cannot be merged or crosses a
+//      cell goes to the deferred list;
+//   D  deferred particles through the general body, one lane per (component, plane, particle);
+//   E  write-back.
+// Cells with more than 2 RMAX particles hand the rest to the deferred list as well.
+template <int NT_, int TSZ_, int WPE_, int PHASED_>
+struct RowsCfg {
+    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_;
+};
+
+template <int O, int M, class CFG>
+__global__ void __launch_bounds__(CFG::NT) WXA_WAVES_PER_SIMD(CFG::WPE)
+deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                         const double* __restrict__ pz, const double* __restrict__ pw,
+                         const double* __restrict__ pux, const double* __restrict__ puy,
+                         const double* __restrict__ puz, const int* __restrict__ offsets, DevF Jx, DevF Jy,
+                         DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, StragglerQueue sq) {
+    constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
+    using TD = TileDims<M, TSZ>;
+    constexpr int N = TD::N, NZ = TD::NZ, NPTS = TD::NPTS, PS = TD::PS;
+    constexpr int SUB = TS / TSZ;
+    constexpr int CELLS = TILE_CELLS / SUB;        // cells of this unit
+    constexpr int CW = CELLS / 64;                 // cell-waves (waves that hold a cell per lane in phases A and B)
+    constexpr int RMAX = 64 / CW;                  // rows of the item table: RMAX CW = 64 counts = one wave scan
+    constexpr int TCAP = CELLS * 6;                // item table capacity (8 ppc: 4.25 items per cell on average)
+    constexpr int DEFER = TSZ == 8 ? 2048 : 1024;
+    static_assert(NT >= CELLS && RMAX >= 8, "one lane per cell; at least 16 particles per cell on the fast path");
+    __shared__ double lds[3 * NPTS];
+    __shared__ unsigned long long masks[RMAX][CW];
+    __shared__ int cstart[CELLS + 1];
+    __shared__ unsigned short table[TCAP];
+    __shared__ unsigned deferred[DEFER];
+    __shared__ int ndeferred, nitems;
+    const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
+    const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
+    if (unit >= ntiles * SUB) return;
+    const long tile = unit / SUB;
+    const int half = (int)(unit % SUB);
+    const long ucell0 = tile * TILE_CELLS + half * CELLS;
+    const int start = offsets[ucell0];
+    const int end = offsets[ucell0 + CELLS];
+    if (end <= start) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    DPROF_INIT
+    auto defer = [&](const int ip) {
+        const int n = atomicAdd(&ndeferred, 1);
+        if (n < DEFER) deferred[n] = (unsigned)ip;
+        else sq.push(ip);
+    };
+    // ---- A: cell counts, row masks; zero fill
+    if (tid == 0) { ndeferred = 0; nitems = 0; }
+    int my_s = 0, my_n = 0, my_pairs = 0;
+    unsigned long long my_mask[RMAX];   // wave-uniform: row r of this cell-wave
+    if (tid < CELLS) {
+        my_s = offsets[ucell0 + tid];
+        my_n = offsets[ucell0 + tid + 1] - my_s;
+        cstart[tid] = my_s;
+        if (tid == CELLS - 1) cstart[CELLS] = my_s + my_n;
+        my_pairs = min((my_n + 1) >> 1, RMAX);
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            my_mask[r] = __ballot(my_pairs > r);
+            if (lane == 0) masks[r][wave] = my_mask[r];
+        }
+    }
+    for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = 0.0;
+    __syncthreads();
+    DPROF(0);
+    // ---- B: scan of the 64 (row, cell-wave) counts, item table
+    if (tid < CELLS) {
+        const int cnt = __popcll(masks[lane / CW][lane % CW]);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        const int excl = incl - cnt;
+        const int total = __shfl(incl, 63);
+        if (tid == 0) nitems = min(total, TCAP);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int base = __shfl(excl, r * CW + wave);   // first item of (row r, this cell-wave)
+            if (my_pairs > r) {
+                const int at = base + __popcll(my_mask[r] & lt);
+                if (at < TCAP) table[at] = (unsigned short)(tid | (r << 9));
+                else { defer(my_s + 2 * r); if (2 * r + 1 < my_n) defer(my_s + 2 * r + 1); }
+            }
+        }
+        for (int k = 2 * RMAX; k < my_n; ++k) defer(my_s + k);   // beyond the table's rows (> 2 RMAX particles in a cell)
+    }
+    __syncthreads();
+    DPROF(1);
+    const int ti = (int)(tile % tg.nt[0]);
+    const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
+    const int tk = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
+    const int o0 = tg.cell_lo[0] + ti * TS + TD::LO;
+    const int o1 = tg.cell_lo[1] + tj * TS + TD::LO;
+    const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
+    // ---- C: the items
+    const int T = nitems;
+    for (int I0 = wave * 64; I0 < T; I0 += NT) {   // wave-uniform trip count
+        const int I = I0 + lane;
+        const bool va = I < T;
+        const unsigned ent = va ? table[I] : 0u;
+        const int c = (int)(ent & 511u), r = (int)(ent >> 9);
+        const int s0 = cstart[c], n0 = cstart[c + 1] - s0;
+        const int ia = va ? s0 + 2 * r : start;
+        const bool vb = va && 2 * r + 1 < n0;
+        const int ib = vb ? ia + 1 : ia;
+        // all fourteen loads in flight together (an empty lane reads the tile's first particle)
+        const ParticleState pa{px[ia], py[ia], pz[ia], pw[ia], pux[ia], puy[ia], puz[ia]};
+        const ParticleState pb{px[ib], py[ib], pz[ib], pw[ib], pux[ib], puy[ib], puz[ib]};
+        EsirkepovCoords c1 = esirkepov_coords(pa, g, es), c2 = esirkepov_coords(pb, g, es);
+        double wq1 = q * pa.w, wq2 = 0.0;
+        const double wqb = q * pb.w;
+        int ai, aj, ak, bi, bj, bk;
+        const bool crossa = esirkepov_frame_cross<O>(c1, g, ai, aj, ak);
+        const bool crossb = esirkepov_frame_cross<O>(c2, g, bi, bj, bk);
+        auto inside = [&](int li, int lj, int lk) {
+            return li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N && lk + O + 3 <= NZ;
+        };
+        const bool ina = inside(ai - o0, aj - o1, ak - o2), inb = inside(bi - o0, bj - o1, bk - o2);
+        const int ka = frame_key(ai - o0, aj - o1, ak - o2), kb = frame_key(bi - o0, bj - o1, bk - o2);
+        const int sa = !va ? 3 : !ina ? 2 : crossa ? 1 : 0;   // 0: fast, 1: general path on the tile, 2: straggler, 3: none
+        const int sb = !vb ? 3 : !inb ? 2 : crossb ? 1 : 0;
+        if (sa == 2) sq.push(ia);
+        if (sb == 2) sq.push(ib);
+        if (sa == 1) defer(ia);
+        if (sb == 1) defer(ib);
+        int key = -1;
+        if (sa == 0) {
+            key = ka;
+            if (sb == 0 && kb == ka) wq2 = wqb;          // merged with its neighbour
+            else { if (sb == 0) defer(ib); c2 = c1; }   // another frame: the general path takes it; empty partner
+        } else if (sb == 0) {
+            key = kb; c1 = c2; wq1 = wqb;               // the second particle alone
+        }
+        if (key >= 0) {
+            LdsSink<M, TSZ> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
+            esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
+        }
+    }
+    __syncthreads();
+    DPROF(2);
+    {   // ---- D: general body, one lane per (component, plane, particle)
+        constexpr int NP = O + 3;
+        const int nd = min(ndeferred, DEFER);
+        const int nunits = 3 * NP * nd;
+        for (int u = tid; u < nunits; u += NT) {
+            const int comp = u / (NP * nd), rem = u - comp * (NP * nd);
+            const int b = rem / nd, ip = (int)deferred[rem - b * nd];
+            const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+            EsirkepovShapes<O> s1;
+            esirkepov_shapes<O>(p1, g, q, es, s1);
+            const int li = s1.bi - o0, lj = s1.bj - o1, lk = s1.bk - o2;
+            LdsSink<M, TSZ> sink(lds, li, lj, lk);
+            if (comp == 0) esirkepov_accumulate_comp_plane<O, 0>(s1, es, sink, b);
+            else if (comp == 1) esirkepov_accumulate_comp_plane<O, 1>(s1, es, sink, b);
+            else esirkepov_accumulate_comp_plane<O, 2>(s1, es, sink, b);
+        }
+    }
+    __syncthreads();
+    DPROF(3);
+    const DevF* Jc[3] = {&Jx, &Jy, &Jz};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const DevF& J = *Jc[c];
+        for (int a = tid; a < NPTS; a += NT) {
+            const double v = lds[c * NPTS + a];
+            if (v != 0.0) {
+                const int i = o0 + (a % PS) % N, j = o1 + (a % PS) / N, k = o2 + a / PS;
+                if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
+                    k < J.lo2 + J.n2)
+                    atomic_add_f64(J.p + J.off(i, j, k), v);
+            }
+        }
+    }
+    DPROF(4);
+    DPROF_FINISH
+}
+
 template <int O, int ALGO>
 __global__ void __launch_bounds__(256)
 deposit_stragglers_kernel(const double* __restrict__ px, const double* __restrict__ py,
@@ -765,6 +959,9 @@ static wxa_status launch_tile(const wxa_particle_view* p, const wxa_field_view J
     return WXA_OK;
 }
 
+template <class CFG> struct is_rows_cfg { static constexpr bool value = false; };
+template <int A, int B, int C, int D> struct is_rows_cfg<RowsCfg<A, B, C, D>> { static constexpr bool value = true; };
+
 template <int O, class CFG>
 static wxa_status launch_waves(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
                                double q, double dt, double relative_time, wxa_workspace* ws, hipStream_t st) {
@@ -784,8 +981,12 @@ static wxa_status launch_waves(const wxa_particle_view* p, const wxa_field_view 
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
-    hipLaunchKernelGGL((deposit_tile_waves_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, sq);
+    if constexpr (is_rows_cfg<CFG>::value)
+        hipLaunchKernelGGL((deposit_tile_rows_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
+                           p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, sq);
+    else
+        hipLaunchKernelGGL((deposit_tile_waves_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
+                           p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, sq);
     hipLaunchKernelGGL((deposit_stragglers_kernel<O, WXA_DEPOSIT_ESIRKEPOV>), dim3(512), dim3(256), 0, st, p->x, p->y,
                        p->z, p->w, p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
     WXA_LAUNCH_CHECK();
@@ -808,6 +1009,10 @@ using CellsHalf4 = WaveCfg<512, 4, 4, 2, 4, MAP_CELLS>;    // cell-indexed lanes
 using CellsHalf3 = WaveCfg<384, 4, 3, 1, 4, MAP_CELLS>;    // cell-indexed lanes, half tile, 2 x 6 waves per CU
 using CellsWhole3 = WaveCfg<768, 8, 3, 1, 4, MAP_CELLS>;   // cell-indexed lanes, whole tile, 12 waves per CU
 using CellsWhole4 = WaveCfg<1024, 8, 4, 2, 4, MAP_CELLS>;  // cell-indexed lanes, whole tile, 16 waves per CU
+using RowsWhole3 = RowsCfg<768, 8, 3, 1>;                  // item table from the cell counts, whole tile, 12 waves
+using RowsHalf3 = RowsCfg<384, 4, 3, 1>;                   // half tile, 2 x 6 waves
+using RowsHalf4 = RowsCfg<512, 4, 4, 2>;                   // half tile, 2 x 8 waves, 128 VGPRs
+using RowsWhole4 = RowsCfg<1024, 8, 4, 2>;                 // whole tile, 16 waves, 128 VGPRs
 using CfgDefault = WXA_DEPOSIT_CFG;
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
@@ -836,6 +1041,10 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
             case 11: return launch_waves<3, CellsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
             case 12: return launch_waves<3, CellsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
             case 13: return launch_waves<3, CellsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 14: return launch_waves<3, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 15: return launch_waves<3, RowsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 16: return launch_waves<3, RowsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 17: return launch_waves<3, RowsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
             default: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
         }
     }
