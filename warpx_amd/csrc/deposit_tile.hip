@@ -41,10 +41,12 @@ struct TileDims {
     static constexpr int LO = -2 - M;            // first LDS point relative to the tile's first cell
     static constexpr int N = TS + 5 + 2 * M;     // points per direction (x, y)
     static constexpr int NZ = TSZ + 5 + 2 * M;   // planes
-    // Plane stride padded to 8 (mod 16): with the row stride N = 15 = -1 (mod 16) the LDS bank of
-    // point (i,j,k) is (i - j + 8k) mod 16, so the 16 cells {8 i} x {k, k+1} of one row j sit on
-    // 16 different banks (see the lane assignment in the kernel and cell_of in particles.hip).
-    static constexpr int PS = N * N + ((8 - (N * N) % 16) + 16) % 16;
+    // Row stride 16 and plane stride 8 (mod 16): the LDS bank (8-byte banks, 16 per ds_add_f64 step) of point (i,j,k)
+    // is (i + 8 k) mod 16 -- for the frame bases of the cells of the sort order (i fastest, then the parity of k, see
+    // cell_of in particles.hip) that is the cell's index in that order mod 16, so ANY 16 consecutive cells of the
+    // order, aligned or not, start on 16 different banks.
+    static constexpr int NS = 16;
+    static constexpr int PS = N * NS + 8;
     static constexpr int NPTS = NZ * PS;         // doubles per component (incl. padding)
 };
 
@@ -53,9 +55,9 @@ struct LdsSink {
     using TD = TileDims<M, TSZ>;
     double* base;   // LDS address of slot 0 of component 0: every deposit is base + a compile-time offset
     __device__ __forceinline__ LdsSink(double* lds, int oi, int oj, int ok)
-        : base(lds + oi + TD::N * oj + TD::PS * ok) {}
+        : base(lds + oi + TD::NS * oj + TD::PS * ok) {}
     __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
-        atomic_add_f64(base + (c * TD::NPTS + i + TD::N * j + TD::PS * k), v);
+        atomic_add_f64(base + (c * TD::NPTS + i + TD::NS * j + TD::PS * k), v);
     }
     __device__ __forceinline__ void add_abs(int c, int gi, int gj, int gk, double v) { add(c, gi, gj, gk, v); }
 };
@@ -316,7 +318,7 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
                     const int e = a | (is_pair[rr] ? IT_PAIRED : 0) | (kk << IT_FRAME_SHIFT);
                     const int rank = pre_f[rr] + rank_f[rr];
                     const bool fast = is_item[rr] && !is_slow[rr] && rank < FAST_CAP;
-                    const int bank = fast ? ((kk & 15) + N * ((kk >> 4) & 15) + PS * (kk >> 8)) & (NBANK - 1) : -1;
+                    const int bank = fast ? ((kk & 15) + TD::NS * ((kk >> 4) & 15) + PS * (kk >> 8)) & (NBANK - 1) : -1;
                     // (a wave-aggregated rank -- 16 ballots, one atomic per wave and bank -- was slower)
                     const int row = fast ? atomicAdd(&bcnt[bank], 1) : 0;
                     if (fast) {
@@ -474,8 +476,8 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
         for (int a = tid; a < NPTS; a += NT) {
             const double v = lds[c * NPTS + a];
             if (v != 0.0) {
-                // a = i + N j + PS k; the padding words of a plane (a % PS >= N N) stay zero
-                const int i = o0 + (a % PS) % N, j = o1 + (a % PS) / N, k = o2 + a / PS;
+                // a = i + NS j + PS k; the padding words (i >= N, a % PS >= N NS) stay zero
+                const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
                 if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
                     k < J.lo2 + J.n2)
                     atomic_add_f64(J.p + J.off(i, j, k), v);
@@ -692,7 +694,7 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
         for (int a = tid; a < NPTS; a += NT) {
             const double v = lds[c * NPTS + a];
             if (v != 0.0) {
-                const int i = o0 + (a % PS) % N, j = o1 + (a % PS) / N, k = o2 + a / PS;
+                const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
                 if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
                     k < J.lo2 + J.n2)
                     atomic_add_f64(J.p + J.off(i, j, k), v);
@@ -886,7 +888,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         for (int a = tid; a < NPTS; a += NT) {
             const double v = lds[c * NPTS + a];
             if (v != 0.0) {
-                const int i = o0 + (a % PS) % N, j = o1 + (a % PS) / N, k = o2 + a / PS;
+                const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
                 if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
                     k < J.lo2 + J.n2)
                     atomic_add_f64(J.p + J.off(i, j, k), v);
