@@ -746,8 +746,9 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     __shared__ unsigned long long masks[RMAX][CW];
     __shared__ int cstart[CELLS + 1];
     __shared__ unsigned short table[TCAP];
-    __shared__ unsigned deferred[DEFER];
-    __shared__ int ndeferred, nitems;
+    __shared__ unsigned deferred[DEFER];           // particles with a cell crossing (wide body)
+    __shared__ unsigned leftover[DEFER];           // fast particles without a partner on their frame
+    __shared__ int ndeferred, nleft, nitems;
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
     if (unit >= ntiles * SUB) return;
@@ -766,7 +767,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         else sq.push(ip);
     };
     // ---- A: cell counts, row masks; zero fill
-    if (tid == 0) { ndeferred = 0; nitems = 0; }
+    if (tid == 0) { ndeferred = 0; nleft = 0; nitems = 0; }
     int my_s = 0, my_n = 0, my_pairs = 0;
     unsigned long long my_mask[RMAX];   // wave-uniform: row r of this cell-wave
     if (tid < CELLS) {
@@ -850,8 +851,16 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         int key = -1;
         if (sa == 0) {
             key = ka;
-            if (sb == 0 && kb == ka) wq2 = wqb;          // merged with its neighbour
-            else { if (sb == 0) defer(ib); c2 = c1; }   // another frame: the general path takes it; empty partner
+            if (sb == 0 && kb == ka) {
+                wq2 = wqb;                               // merged with its neighbour
+            } else {
+                if (sb == 0) {                           // another frame: a single of the second pass
+                    const int n = atomicAdd(&nleft, 1);
+                    if (n < DEFER) leftover[n] = (unsigned)ib;
+                    else sq.push(ib);
+                }
+                c2 = c1;                                 // empty partner
+            }
         } else if (sb == 0) {
             key = kb; c1 = c2; wq1 = wqb;               // the second particle alone
         }
@@ -862,21 +871,37 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     }
     __syncthreads();
     DPROF(2);
-    {   // ---- D: general body, one lane per (component, plane, particle)
-        constexpr int NP = O + 3;
-        const int nd = min(ndeferred, DEFER);
-        const int nunits = 3 * NP * nd;
-        for (int u = tid; u < nunits; u += NT) {
-            const int comp = u / (NP * nd), rem = u - comp * (NP * nd);
-            const int b = rem / nd, ip = (int)deferred[rem - b * nd];
-            const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-            EsirkepovShapes<O> s1;
-            esirkepov_shapes<O>(p1, g, q, es, s1);
-            const int li = s1.bi - o0, lj = s1.bj - o1, lk = s1.bk - o2;
-            LdsSink<M, TSZ> sink(lds, li, lj, lk);
-            if (comp == 0) esirkepov_accumulate_comp_plane<O, 0>(s1, es, sink, b);
-            else if (comp == 1) esirkepov_accumulate_comp_plane<O, 1>(s1, es, sink, b);
-            else esirkepov_accumulate_comp_plane<O, 2>(s1, es, sink, b);
+    {   // ---- D: one pass of wave-sized chunks over the two lists: the singles through the fast body with an empty
+        //      partner, the crossing particles through the wide body, one lane per (component, particle)
+        const int nl = min(nleft, DEFER), nd = min(ndeferred, DEFER);
+        const int lchunks = (nl + 63) >> 6, dchunks = (3 * nd + 63) >> 6;
+        constexpr int WAVES = NT / 64;
+        for (int ch = wave; ch < lchunks + dchunks; ch += WAVES) {
+            if (ch < lchunks) {
+                const int it = ch * 64 + lane;
+                if (it < nl) {
+                    const int ip = (int)leftover[it];
+                    const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+                    const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
+                    int bi, bj, bk;
+                    (void)esirkepov_frame_cross<O>(c1, g, bi, bj, bk);
+                    LdsSink<M, TSZ> sink(lds, bi - o0, bj - o1, bk - o2);
+                    esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c1, q * p1.w, 0.0, es, sink);
+                }
+            } else {
+                const int u = (ch - lchunks) * 64 + lane;
+                if (u < 3 * nd) {
+                    const int comp = u / nd, ip = (int)deferred[u - comp * nd];
+                    const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+                    const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
+                    const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
+                    LdsSink<M, TSZ> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
+                    const double wq = q * p1.w;
+                    if (comp == 0) esirkepov_single_wide<O, 0>(c1, f, wq, es, sink);
+                    else if (comp == 1) esirkepov_single_wide<O, 1>(c1, f, wq, es, sink);
+                    else esirkepov_single_wide<O, 2>(c1, f, wq, es, sink);
+                }
+            }
         }
     }
     __syncthreads();
