@@ -708,21 +708,26 @@ deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restric
 // ---- Esirkepov on LDS tiles, work items from the cell counts ----------------------------------------------------------
 // The cell sort already says where every cell's particles are (offsets[]), so the work items -- (cell, r) = the cell's
 // particles (2 r, 2 r + 1) -- follow from the cell counts alone, without looking at a particle:
-//   A  one lane per cell reads its count, row r of the item table holds the cells with more than r pairs (one wave
-//      ballot per row); the tile is zeroed meanwhile;
-//   B  every wave scans the (row, cell-wave) counts (64 numbers) and each cell writes its items to their places: the
-//      table lists row 0 of all cells, then row 1, ... -- consecutive items are consecutive cells of the sort order,
-//      so the 16 lanes that a step of a ds_add_f64 serves sit in 16 different cells on (mostly) 16 different banks,
-//      and the table is dense: no idle lanes for short cells, no second pass for long ones;
-//   C  lane t takes items t, t + NT, ...: loads its two particles (14 loads in flight), merges them when both stay
-//      in their cell and share the frame, deposits through the phased pair body; what cannot be merged or crosses a
-//      cell goes to the deferred list;
-//   D  deferred particles through the general body, one lane per (component, plane, particle);
-//   E  write-back.
-// Cells with more than 2 RMAX particles hand the rest to the deferred list as well.
-template <int NT_, int TSZ_, int WPE_, int PHASED_>
+//   * the first four pairs of every cell need no table: chunk b of 64 items is the block of 16 consecutive cells
+//     16 b .. 16 b + 15, lane (r, c) = (lane / 16, lane % 16) takes pair r of cell 16 b + c.  The 16 lanes that a step of a
+//     ds_add_f64 serves sit in 16 consecutive cells of the sort order = 16 different LDS banks (TileDims), never on one
+//     address, and the wave's loads cover the block's particles contiguously (1 KB per array);
+//   * pairs beyond the fourth (cells with more than 8 particles: ~15 % of the pairs of a thermal plasma at 8 per cell)
+//     are listed in a tail table, row-major (all cells' pair 4, then pair 5, ...), built from one ballot per row and one
+//     wave scan of the 64 (row, cell-wave) counts -- dense chunks again, processed by the same loop.
+// Phases: A cell counts, row masks, zero fill | B scan + tail table | C the chunks: two particles per lane (14 loads in
+// flight), merged when both stay in their cell and share the frame, phased pair body; what cannot be merged or crosses
+// a cell goes to the deferred list | D deferred particles through the wide single body, one lane per (component,
+// particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
+// DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
+template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0>
 struct RowsCfg {
-    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_;
+    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_;
+};
+
+struct NullSink {   // DBG = 1: keeps every deposited value alive without touching the LDS
+    double acc = 0.0;
+    __device__ __forceinline__ void add(int, int, int, int, double v) { acc += v; }
 };
 
 template <int O, int M, class CFG>
@@ -738,12 +743,14 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     constexpr int SUB = TS / TSZ;
     constexpr int CELLS = TILE_CELLS / SUB;        // cells of this unit
     constexpr int CW = CELLS / 64;                 // cell-waves (waves that hold a cell per lane in phases A and B)
-    constexpr int RMAX = 64 / CW;                  // rows of the item table: RMAX CW = 64 counts = one wave scan
-    constexpr int TCAP = CELLS * 6;                // item table capacity (8 ppc: 4.25 items per cell on average)
+    constexpr int NB = CELLS / 16;                 // blocks of 16 cells = chunks of the direct part
+    constexpr int RT = 64 / CW;                    // rows of the tail table (pairs 4 .. 3 + RT): RT CW = 64 counts = one wave scan
+    constexpr int RMAX = 4 + RT;
+    constexpr int TCAP = CELLS * 2;                // tail capacity (8 ppc: 0.66 tail items per cell on average)
     constexpr int DEFER = TSZ == 8 ? 2048 : 1024;
-    static_assert(NT >= CELLS && RMAX >= 8, "one lane per cell; at least 16 particles per cell on the fast path");
+    static_assert(NT >= CELLS && RT >= 8, "one lane per cell");
     __shared__ double lds[3 * NPTS];
-    __shared__ unsigned long long masks[RMAX][CW];
+    __shared__ unsigned long long masks[RT][CW];
     __shared__ int cstart[CELLS + 1];
     __shared__ unsigned short table[TCAP];
     __shared__ unsigned deferred[DEFER];           // particles with a cell crossing (wide body)
@@ -769,7 +776,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     // ---- A: cell counts, row masks; zero fill
     if (tid == 0) { ndeferred = 0; nleft = 0; nitems = 0; }
     int my_s = 0, my_n = 0, my_pairs = 0;
-    unsigned long long my_mask[RMAX];   // wave-uniform: row r of this cell-wave
+    unsigned long long my_mask[RT];   // wave-uniform: tail row r of this cell-wave
     if (tid < CELLS) {
         my_s = offsets[ucell0 + tid];
         my_n = offsets[ucell0 + tid + 1] - my_s;
@@ -777,8 +784,8 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         if (tid == CELLS - 1) cstart[CELLS] = my_s + my_n;
         my_pairs = min((my_n + 1) >> 1, RMAX);
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            my_mask[r] = __ballot(my_pairs > r);
+        for (int r = 0; r < RT; ++r) {
+            my_mask[r] = __ballot(my_pairs > 4 + r);
             if (lane == 0) masks[r][wave] = my_mask[r];
         }
     }
@@ -799,12 +806,12 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         if (tid == 0) nitems = min(total, TCAP);
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int base = __shfl(excl, r * CW + wave);   // first item of (row r, this cell-wave)
-            if (my_pairs > r) {
+        for (int r = 0; r < RT; ++r) {
+            const int base = __shfl(excl, r * CW + wave);   // first item of (tail row r, this cell-wave)
+            if (my_pairs > 4 + r) {
                 const int at = base + __popcll(my_mask[r] & lt);
-                if (at < TCAP) table[at] = (unsigned short)(tid | (r << 9));
-                else { defer(my_s + 2 * r); if (2 * r + 1 < my_n) defer(my_s + 2 * r + 1); }
+                if (at < TCAP) table[at] = (unsigned short)(tid | ((4 + r) << 9));
+                else { defer(my_s + 2 * (4 + r)); if (2 * (4 + r) + 1 < my_n) defer(my_s + 2 * (4 + r) + 1); }
             }
         }
         for (int k = 2 * RMAX; k < my_n; ++k) defer(my_s + k);   // beyond the table's rows (> 2 RMAX particles in a cell)
@@ -817,14 +824,22 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     const int o0 = tg.cell_lo[0] + ti * TS + TD::LO;
     const int o1 = tg.cell_lo[1] + tj * TS + TD::LO;
     const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
-    // ---- C: the items
+    // ---- C: the chunks (NB blocks of 16 cells x 4 pairs, then the tail table)
     const int T = nitems;
-    for (int I0 = wave * 64; I0 < T; I0 += NT) {   // wave-uniform trip count
-        const int I = I0 + lane;
-        const bool va = I < T;
-        const unsigned ent = va ? table[I] : 0u;
-        const int c = (int)(ent & 511u), r = (int)(ent >> 9);
+    constexpr int WAVES = NT / 64;
+    for (int ch = wave; ch < NB + ((T + 63) >> 6); ch += WAVES) {   // wave-uniform
+        int c, r;
+        bool va;
+        if (ch < NB) {
+            c = 16 * ch + (lane & 15); r = lane >> 4; va = true;
+        } else {
+            const int I = (ch - NB) * 64 + lane;
+            va = I < T;
+            const unsigned ent = va ? table[I] : 0u;
+            c = (int)(ent & 511u); r = (int)(ent >> 9);
+        }
         const int s0 = cstart[c], n0 = cstart[c + 1] - s0;
+        va = va && 2 * r < n0;
         const int ia = va ? s0 + 2 * r : start;
         const bool vb = va && 2 * r + 1 < n0;
         const int ib = vb ? ia + 1 : ia;
@@ -854,11 +869,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             if (sb == 0 && kb == ka) {
                 wq2 = wqb;                               // merged with its neighbour
             } else {
-                if (sb == 0) {                           // another frame: a single of the second pass
-                    const int n = atomicAdd(&nleft, 1);
-                    if (n < DEFER) leftover[n] = (unsigned)ib;
-                    else sq.push(ib);
-                }
+                if (sb == 0) defer(ib);                  // another frame: the wide body takes it alone
                 c2 = c1;                                 // empty partner
             }
         } else if (sb == 0) {
@@ -866,7 +877,22 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         }
         if (key >= 0) {
             LdsSink<M, TSZ> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
-            esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
+            if constexpr (CFG::DBG == 1) {
+                NullSink ns;
+                esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, ns);
+                if (ns.acc == 1.2345e-300) lds[0] = ns.acc;
+            } else if constexpr (CFG::DBG == 2) {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                    for (int b = 1; b <= O + 1; ++b)
+#pragma unroll
+                        for (int a = 1; a <= O + 1; ++a)
+#pragma unroll
+                            for (int l = 1; l <= O; ++l) sink.add(cc, l, a, b, wq1 + wq2);
+            } else {
+                esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
+            }
         }
     }
     __syncthreads();
@@ -875,7 +901,6 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         //      partner, the crossing particles through the wide body, one lane per (component, particle)
         const int nl = min(nleft, DEFER), nd = min(ndeferred, DEFER);
         const int lchunks = (nl + 63) >> 6, dchunks = (3 * nd + 63) >> 6;
-        constexpr int WAVES = NT / 64;
         for (int ch = wave; ch < lchunks + dchunks; ch += WAVES) {
             if (ch < lchunks) {
                 const int it = ch * 64 + lane;
@@ -987,7 +1012,7 @@ static wxa_status launch_tile(const wxa_particle_view* p, const wxa_field_view J
 }
 
 template <class CFG> struct is_rows_cfg { static constexpr bool value = false; };
-template <int A, int B, int C, int D> struct is_rows_cfg<RowsCfg<A, B, C, D>> { static constexpr bool value = true; };
+template <int A, int B, int C, int D, int E> struct is_rows_cfg<RowsCfg<A, B, C, D, E>> { static constexpr bool value = true; };
 
 template <int O, class CFG>
 static wxa_status launch_waves(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
@@ -1040,6 +1065,8 @@ using RowsWhole3 = RowsCfg<768, 8, 3, 1>;                  // item table from th
 using RowsHalf3 = RowsCfg<384, 4, 3, 1>;                   // half tile, 2 x 6 waves
 using RowsHalf4 = RowsCfg<512, 4, 4, 2>;                   // half tile, 2 x 8 waves, 128 VGPRs
 using RowsWhole4 = RowsCfg<1024, 8, 4, 2>;                 // whole tile, 16 waves, 128 VGPRs
+using RowsWhole3NoLds = RowsCfg<768, 8, 3, 1, 1>;          // timing experiment: arithmetic only (wrong J)
+using RowsWhole3NoAlu = RowsCfg<768, 8, 3, 1, 2>;          // timing experiment: atomics only (wrong J)
 using CfgDefault = WXA_DEPOSIT_CFG;
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
@@ -1072,6 +1099,8 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
             case 15: return launch_waves<3, RowsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
             case 16: return launch_waves<3, RowsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
             case 17: return launch_waves<3, RowsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 101: return launch_waves<3, RowsWhole3NoLds>(p, J, geom, q, dt, relative_time, ws, st);
+            case 102: return launch_waves<3, RowsWhole3NoAlu>(p, J, geom, q, dt, relative_time, ws, st);
             default: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
         }
     }
