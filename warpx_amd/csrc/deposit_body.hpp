@@ -176,41 +176,6 @@ __device__ __forceinline__ void esirkepov_accumulate_comp(const EsirkepovShapes<
     }
 }
 
-// One plane b (run-time index of the slow transverse direction) of one component: the body of the loop above, for
-// callers that spread a particle over (component, plane) lanes.  The two weights of the plane are selected from the
-// register arrays with compares, so that no array is indexed at run time.
-template <int O, int COMP, class Sink>
-__device__ __forceinline__ void esirkepov_accumulate_comp_plane(const EsirkepovShapes<O>& s, const EsirkepovStep& es,
-                                                                Sink& sink, const int b) {
-    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
-    const double* Ln = COMP == 0 ? s.sx_new : COMP == 1 ? s.sy_new : s.sz_new;
-    const double* Lo = COMP == 0 ? s.sx_old : COMP == 1 ? s.sy_old : s.sz_old;
-    const double* An = COMP == 0 ? s.sy_new : s.sx_new;
-    const double* Ao = COMP == 0 ? s.sy_old : s.sx_old;
-    const double* Bn = COMP == 2 ? s.sy_new : s.sz_new;
-    const double* Bo = COMP == 2 ? s.sy_old : s.sz_old;
-    const double invdtd = es.invdtd[COMP];
-    const int dl = COMP == 0 ? s.dil : COMP == 1 ? s.djl : s.dkl;
-    const int du = COMP == 0 ? s.diu : COMP == 1 ? s.dju : s.dku;
-    double d[O + 2];
-#pragma unroll
-    for (int a = 0; a < O + 2; ++a) d[a] = s.wq * invdtd * sub_rn(Lo[a], Ln[a]);
-    const bool lo = __builtin_amdgcn_ballot_w64(dl == 0) != 0, hi = __builtin_amdgcn_ballot_w64(du == 0) != 0;
-    double bn = 0.0, bo = 0.0;
-#pragma unroll
-    for (int i = 0; i < O + 3; ++i) {
-        bn = (b == i) ? Bn[i] : bn;
-        bo = (b == i) ? Bo[i] : bo;
-    }
-    if (bn != 0.0 || bo != 0.0) {
-#pragma unroll
-        for (int a = 0; a <= O + 2; a++) {
-            const double T = one_third * (An[a] * bn + Ao[a] * bo) + one_sixth * (An[a] * bo + Ao[a] * bn);
-            if (T != 0.0) esirkepov_row<O, COMP>(sink, d, T, dl, du, lo, hi, a, b);
-        }
-    }
-}
-
 template <int O, class Sink>
 __device__ __forceinline__ void esirkepov_accumulate(const EsirkepovShapes<O>& s, const EsirkepovStep& es, Sink& sink) {
     esirkepov_accumulate_comp<O, 0>(s, es, sink);

@@ -5,28 +5,26 @@
 // one component per pass.  Here one workgroup owns one tile of 8x8x8 cells of the
 // tile-major cell sort (wxa_sort_particles_by_cell), keeps all three J components of the
 // tile plus its stencil halo (and one point of drift margin) in LDS as fp64
-// (3 x 15 x 232 x 8 B = 83.5 KB), accumulates with ds_add_f64, and writes each non-zero LDS
-// point back to HBM with one global fp64 atomic.
+// (3 x 15 x 248 x 8 B = 89 KB), accumulates with ds_add_f64, and writes each non-zero LDS
+// point back to HBM with one global fp64 atomic.  Two kernels:
 //
-// Per trip the workgroup stages up to 1024 particles through LDS (coalesced, 56 KB), keys them by
-// stencil frame, and builds work items: two neighbours of one cell that do not cross a cell form
-// a PAIR (merged in registers before the atomics), a particle that crosses a cell is a slow
-// single.  At most 512 fast items are taken per trip -- one per lane, so the pass over them is a
-// single pass for every wave -- and each goes to the lane (quarter-wave, LDS bank of its frame
-// base): the 16 lanes that a ds_add_f64 serves together then always hit 16 different banks.
-// Slow singles are deferred per tile and run once through the general Esirkepov body, 64 to a
-// wave, the three components on different waves.  Particles whose stencil leaves the LDS tile
-// (drift of more than a cell since the last sort, particles outside the domain before the
-// periodic wrap) are queued and deposited with global atomics by a second kernel, so correctness
+//  * deposit_tile_rows_kernel (Esirkepov, production): work items straight from the cell counts of the
+//    sort -- lane (r, c) of a chunk takes pair r of cell 16 b + c, pairs beyond a cell's fourth come from a
+//    small tail table -- two particles merged in registers per lane, the three components as three
+//    register-lean phases, crossing particles through a wide-frame single body.  No staging, no per-particle
+//    keying, no barrier in the particle loop.  See the comment at the kernel.
+//  * deposit_tile_kernel (direct deposition; Esirkepov of round 1, kept as variant 0 for A/B): stages up to
+//    1024 particles through LDS, keys them by stencil frame, builds work-item lists, buckets the fast items by
+//    the LDS bank of their frame.
+//
+// Particles whose stencil leaves the LDS tile (drift of more than a cell since the last sort, particles outside the
+// domain before the periodic wrap) are queued and deposited with global atomics by a second kernel, so correctness
 // never depends on the sort being fresh.  DESIGN.md section 3 has the measurements behind each step.
 #include "deposit_body.hpp"
 #include "workspace.hpp"
 
 #include <stdlib.h>
 
-#ifndef WXA_DEPOSIT_CFG
-#define WXA_DEPOSIT_CFG CfgWhole
-#endif
 
 namespace wxa {
 
@@ -488,223 +486,6 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
     DPROF_FINISH
 }
 
-// ---- Esirkepov on LDS tiles, wave-independent variant -------------------------------------------------------------
-// No staging, no work-item lists, no barrier inside the particle loop.  Two lane mappings:
-//  * MAP_CELLS: a wave iteration takes 16 consecutive cells of the sort order; lane (r, c) = (lane / 16, lane % 16)
-//    takes the particles (2 r, 2 r + 1) of cell c's run (offsets[] of the cell sort).  The 16 lanes that one step of a
-//    ds_add_f64 serves together (quarter-wave r) then sit in 16 different cells whose stencil frames start on 16
-//    different LDS banks (TileDims, cell_of): conflict-free by construction while the particles are still in the
-//    cell they were sorted into, and no two lanes of a step share an address.  A cell's particles beyond the 8th
-//    go to the leftover list as pair entries.
-//  * MAP_SPACED: wave w takes 64-pair chunks of the tile's contiguous range, lane (r, c) the pair SPACING c + r (+ 4 h):
-//    neighbouring lanes of a quarter-wave are SPACING / 4 cells apart on average -- no offsets[] reads, but the bank
-//    spread is only statistical (measured: 45-70 % extra LDS cycles from bank / same-address conflicts).
-// A lane merges its two particles in registers when both stay in their cell and share the stencil frame.  What does not
-// fit goes to two small per-tile lists that are run densely after the loop: the "leftover" entries (second particles
-// that could not be merged, particles beyond a cell's 8th) through the same fast code, and particles with a cell
-// crossing ("deferred") through the general Esirkepov body, spread over (particle, component, plane) lanes.
-// Waves never wait for each other inside the loop, so loads, weight arithmetic and LDS atomics of different waves overlap.
-constexpr int MAP_SPACED = 0, MAP_CELLS = 1;
-template <int NT_, int TSZ_, int WPE_, int PHASED_, int SPACING_ = 4, int MAP_ = MAP_SPACED>
-struct WaveCfg {
-    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, SPACING = SPACING_, MAP = MAP_;
-};
-
-template <int O, int M, class CFG>
-__global__ void __launch_bounds__(CFG::NT) WXA_WAVES_PER_SIMD(CFG::WPE)
-deposit_tile_waves_kernel(const double* __restrict__ px, const double* __restrict__ py,
-                          const double* __restrict__ pz, const double* __restrict__ pw,
-                          const double* __restrict__ pux, const double* __restrict__ puy,
-                          const double* __restrict__ puz, const int* __restrict__ offsets, DevF Jx, DevF Jy,
-                          DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, StragglerQueue sq) {
-    constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
-    using TD = TileDims<M, TSZ>;
-    constexpr int N = TD::N, NZ = TD::NZ, NPTS = TD::NPTS, PS = TD::PS;
-    constexpr int SUB = TS / TSZ;
-    constexpr int SUB_CELLS = TILE_CELLS / SUB;
-    constexpr int WAVES = NT / 64;
-    constexpr int LEFT = TSZ == 8 ? 2048 : 1024;   // capacity of the leftover list
-    constexpr int DEFER = TSZ == 8 ? 1024 : 512;   // capacity of the deferred list
-    __shared__ double lds[3 * NPTS];
-    __shared__ unsigned leftover[LEFT];            // (particle index << 1) | "merge with the next particle if possible"
-    __shared__ unsigned deferred[DEFER];
-    __shared__ int nleft, ndeferred;
-    const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
-    const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
-    if (unit >= ntiles * SUB) return;
-    const long tile = unit / SUB;
-    const int half = (int)(unit % SUB);
-    const long ucell0 = tile * TILE_CELLS + half * SUB_CELLS;
-    const int start = offsets[ucell0];
-    const int end = offsets[ucell0 + SUB_CELLS];
-    if (end <= start) return;
-    const int tid = threadIdx.x;
-    DPROF_INIT
-    for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = 0.0;
-    if (tid == 0) { nleft = 0; ndeferred = 0; }
-    const int ti = (int)(tile % tg.nt[0]);
-    const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
-    const int tk = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
-    const int o0 = tg.cell_lo[0] + ti * TS + TD::LO;
-    const int o1 = tg.cell_lo[1] + tj * TS + TD::LO;
-    const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
-    const int wave = tid >> 6, lane = tid & 63;
-    __syncthreads();
-    DPROF(0);   // zero fill
-    const int first = start & ~1;                      // MAP_SPACED: pairs start on an even particle index
-    const int npairs = (end - first + 1) >> 1;
-    // MAP_SPACED: a wave's group = 16 SPACING pairs, covered in SPACING / 4 iterations of 64 pairs: iteration h takes
-    // the pairs SPACING c + 4 h + r of the group.  MAP_CELLS: a group = 16 cells, one iteration.
-    constexpr int SPACING = CFG::SPACING, SUBIT = CFG::MAP == MAP_CELLS ? 1 : SPACING / 4;
-    constexpr int GROUP = CFG::MAP == MAP_CELLS ? 16 : 16 * SPACING;
-    constexpr int NWORK_CELLS = SUB_CELLS;
-    static_assert(SPACING % 4 == 0, "quarter-wave rows");
-    const int pair_in_group = SPACING * (lane & 15) + (lane >> 4);
-    const int nwork = CFG::MAP == MAP_CELLS ? NWORK_CELLS : npairs;   // cells or pairs of this unit
-    // classification of one particle: coordinates, stencil frame relative to the tile, fast / deferred / straggler
-    auto classify = [&](const int ip, EsirkepovCoords& cc, double& wq, int& key) -> int {
-        const ParticleState p{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-        cc = esirkepov_coords(p, g, es);
-        wq = q * p.w;
-        int bi, bj, bk;
-        const bool cross = esirkepov_frame_cross<O>(cc, g, bi, bj, bk);
-        const int li = bi - o0, lj = bj - o1, lk = bk - o2;
-        const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N && lk + O + 3 <= NZ;
-        key = frame_key(li, lj, lk);
-        return !in ? 2 : cross ? 1 : 0;   // 0: fast, 1: deferred (general path on the tile), 2: straggler
-    };
-    auto defer = [&](const int ip) {
-        const int n = atomicAdd(&ndeferred, 1);
-        if (n < DEFER) deferred[n] = (unsigned)ip;
-        else sq.push(ip);
-    };
-    int mode = 0;                 // 0: the tile's particles through the lane mapping; 1: the leftover list
-    int c0 = wave * GROUP;        // mode 0: first pair / cell of the wave's group; mode 1: first list entry of its chunk
-    int sub = 0;                  // iteration inside the group
-    int nl = 0;
-    for (;;) {
-        int ia = start;
-        bool va = false, vb = false;
-        if (mode == 0) {
-            if (c0 >= nwork) {   // every wave passes here exactly once
-                __syncthreads();
-                DPROF(2);
-                mode = 1;
-                c0 = wave * 64;
-                nl = min(nleft, LEFT);
-                continue;
-            }
-            if constexpr (CFG::MAP == MAP_CELLS) {
-                const long cell = ucell0 + c0 + (lane & 15);
-                const int s0 = offsets[cell], e0 = offsets[cell + 1];
-                const int r = lane >> 4;
-                ia = s0 + 2 * r;
-                va = ia < e0;
-                vb = ia + 1 < e0;
-                if (r == 3) {   // the cell's particles beyond the 8th
-                    for (int k = s0 + 8; k < e0; k += 2) {
-                        const int n = atomicAdd(&nleft, 1);
-                        if (n < LEFT) leftover[n] = ((unsigned)k << 1) | (k + 1 < e0 ? 1u : 0u);
-                        else { sq.push(k); if (k + 1 < e0) sq.push(k + 1); }
-                    }
-                }
-            } else {
-                const int P = c0 + pair_in_group + 4 * sub;
-                ia = first + 2 * P;
-                va = P < npairs && ia >= start;
-                vb = P < npairs && ia + 1 < end;
-            }
-        } else {
-            if (c0 >= nl) break;
-            const int it = c0 + lane;
-            if (it < nl) {
-                const unsigned ent = leftover[it];
-                ia = (int)(ent >> 1);
-                va = true;
-                vb = (ent & 1u) != 0;
-            }
-        }
-        const int ib = ia + 1;
-        EsirkepovCoords c1, c2;
-        double wq1 = 0.0, wq2 = 0.0, wqb = 0.0;
-        int key = -1, ka = -1, kb = -1, sa = 3, sb = 3;   // 3: no particle
-        if (va) sa = classify(ia, c1, wq1, ka);
-        if (vb) sb = classify(ib, c2, wqb, kb);
-        if (sa == 1) defer(ia);
-        if (sb == 1) defer(ib);
-        if (sa == 2) sq.push(ia);
-        if (sb == 2) sq.push(ib);
-        if (sa == 0) {
-            key = ka;
-            if (sb == 0 && kb == ka) {
-                wq2 = wqb;   // merged with its neighbour
-            } else {
-                if (sb == 0) {   // a fast particle with another frame: a leftover single; from the leftover pass
-                                 // itself it goes to the general path (rare: its partner is beyond a cell's 8th)
-                    if (mode == 0) {
-                        const int n = atomicAdd(&nleft, 1);
-                        if (n < LEFT) leftover[n] = (unsigned)ib << 1;
-                        else sq.push(ib);
-                    } else {
-                        defer(ib);
-                    }
-                }
-                c2 = c1;     // empty partner (weight 0)
-            }
-        } else if (sb == 0) {
-            key = kb; c1 = c2; wq1 = wqb;   // the second particle alone, its own coordinates as the empty partner's
-        }
-        if (key >= 0) {
-            LdsSink<M, TSZ> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
-            esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
-        }
-        if (mode == 0) {
-            if (++sub == SUBIT) { sub = 0; c0 += WAVES * GROUP; }
-        } else {
-            c0 += WAVES * 64;
-        }
-    }
-    __syncthreads();
-    DPROF(3);   // leftover pass
-    {
-        // Particles with a cell crossing: general body.  One lane per (component, plane, particle), so that the few
-        // dozen crossing particles of a tile occupy all the waves for one short pass (a lane per particle and
-        // component kept three waves busy for ~3000 instructions while the others waited at the barrier).
-        constexpr int NP = O + 3;
-        const int nd = min(ndeferred, DEFER);
-        const int nunits = 3 * NP * nd;
-        for (int u = tid; u < nunits; u += NT) {
-            const int comp = u / (NP * nd), rem = u - comp * (NP * nd);
-            const int b = rem / nd, ip = (int)deferred[rem - b * nd];
-            const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-            EsirkepovShapes<O> s1;
-            esirkepov_shapes<O>(p1, g, q, es, s1);
-            LdsSink<M, TSZ> sink(lds, s1.bi - o0, s1.bj - o1, s1.bk - o2);
-            if (comp == 0) esirkepov_accumulate_comp_plane<O, 0>(s1, es, sink, b);
-            else if (comp == 1) esirkepov_accumulate_comp_plane<O, 1>(s1, es, sink, b);
-            else esirkepov_accumulate_comp_plane<O, 2>(s1, es, sink, b);
-        }
-    }
-    __syncthreads();
-    DPROF(4);   // deferred general path
-    const DevF* Jc[3] = {&Jx, &Jy, &Jz};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const DevF& J = *Jc[c];
-        for (int a = tid; a < NPTS; a += NT) {
-            const double v = lds[c * NPTS + a];
-            if (v != 0.0) {
-                const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
-                if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
-                    k < J.lo2 + J.n2)
-                    atomic_add_f64(J.p + J.off(i, j, k), v);
-            }
-        }
-    }
-    DPROF(5);   // write-back
-    DPROF_FINISH
-}
-
 // ---- Esirkepov on LDS tiles, work items from the cell counts ----------------------------------------------------------
 // The cell sort already says where every cell's particles are (offsets[]), so the work items -- (cell, r) = the cell's
 // particles (2 r, 2 r + 1) -- follow from the cell counts alone, without looking at a particle:
@@ -756,6 +537,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     __shared__ unsigned deferred[DEFER];           // particles with a cell crossing (wide body)
     __shared__ unsigned leftover[DEFER];           // fast particles without a partner on their frame
     __shared__ int ndeferred, nleft, nitems;
+    __shared__ int pf_scratch[64];                 // landing zone of the prefetch loads
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
     if (unit >= ntiles * SUB) return;
@@ -773,6 +555,21 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         if (n < DEFER) deferred[n] = (unsigned)ip;
         else sq.push(ip);
     };
+    // Pulls the particles [p0, p1) of all seven arrays towards the L2: one 4-byte load per 128-byte line straight into an
+    // LDS scratch word (no register, nothing waits for it); lanes 8 a .. 8 a + 7 take the first 8 lines of array a, i.e.
+    // 128 particles -- a block of 16 cells at 8 per cell.  The deposition streams 56 B per particle from HBM
+    // (7.5 GB at 256^3 x 8 = ~1.5 ms at the achievable bandwidth); without the prefetch every chunk starts with
+    // that latency exposed: measured 3 of the kernel's 5 ms in the chunk loop with the arithmetic AND the atomics off.
+    const double* const parr[7] = {px, py, pz, pw, pux, puy, puz};
+    auto prefetch = [&](const int p0, const int p1) {
+        const int arr = lane >> 3, seg = lane & 7;
+        const int q0 = (p0 & ~15) + 16 * seg;
+        if (arr < 7 && q0 < p1)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(parr[arr] + q0),
+                                             (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
+    };
+    constexpr int WAVES = NT / 64;
+    if (wave < NB) prefetch(offsets[ucell0 + 16 * wave], offsets[ucell0 + 16 * wave + 16]);   // this wave's first chunk
     // ---- A: cell counts, row masks; zero fill
     if (tid == 0) { ndeferred = 0; nleft = 0; nitems = 0; }
     int my_s = 0, my_n = 0, my_pairs = 0;
@@ -826,10 +623,10 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
     // ---- C: the chunks (NB blocks of 16 cells x 4 pairs, then the tail table)
     const int T = nitems;
-    constexpr int WAVES = NT / 64;
     for (int ch = wave; ch < NB + ((T + 63) >> 6); ch += WAVES) {   // wave-uniform
         int c, r;
         bool va;
+        if (ch + WAVES < NB) prefetch(cstart[16 * (ch + WAVES)], cstart[16 * (ch + WAVES) + 16]);   // its next chunk
         if (ch < NB) {
             c = 16 * ch + (lane & 15); r = lane >> 4; va = true;
         } else {
@@ -1011,11 +808,8 @@ static wxa_status launch_tile(const wxa_particle_view* p, const wxa_field_view J
     return WXA_OK;
 }
 
-template <class CFG> struct is_rows_cfg { static constexpr bool value = false; };
-template <int A, int B, int C, int D, int E> struct is_rows_cfg<RowsCfg<A, B, C, D, E>> { static constexpr bool value = true; };
-
 template <int O, class CFG>
-static wxa_status launch_waves(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
+static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
                                double q, double dt, double relative_time, wxa_workspace* ws, hipStream_t st) {
     TileGeom tg;
     for (int d = 0; d < 3; ++d) {
@@ -1033,41 +827,26 @@ static wxa_status launch_waves(const wxa_particle_view* p, const wxa_field_view 
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
-    if constexpr (is_rows_cfg<CFG>::value)
-        hipLaunchKernelGGL((deposit_tile_rows_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                           p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, sq);
-    else
-        hipLaunchKernelGGL((deposit_tile_waves_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                           p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, sq);
+    hipLaunchKernelGGL((deposit_tile_rows_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
+                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, sq);
     hipLaunchKernelGGL((deposit_stragglers_kernel<O, WXA_DEPOSIT_ESIRKEPOV>), dim3(512), dim3(256), 0, st, p->x, p->y,
                        p->z, p->w, p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
 
-// Production configuration, and the alternatives kept for A/B timing (WXA_DEPOSIT_VARIANT=<n>, order 3 Esirkepov
-// only; scripts/deposit_variants.py)
-using CfgWhole = TileCfg<512, 8, true, 2, 0>;      // round 1: whole tile + LDS stage, 155 KB, 1 workgroup per CU
-using CfgHalf = TileCfg<512, 4, false, 4, 2>;      // half tile, no stage, 2 workgroups per CU, 128 VGPRs
-using CfgHalf3 = TileCfg<384, 4, false, 3, 1>;     // half tile, no stage, 2 workgroups of 6 waves, 168 VGPRs
-using CfgWhole3 = TileCfg<768, 8, false, 3, 1>;    // whole tile, no stage, 1 workgroup of 12 waves, 168 VGPRs
-using WavesHalf4 = WaveCfg<512, 4, 4, 2>;          // half tile, 2 workgroups of 8 waves per CU, 128 VGPRs
-using WavesHalf3 = WaveCfg<384, 4, 3, 1>;          // half tile, 2 workgroups of 6 waves per CU, 168 VGPRs
-using WavesWhole3 = WaveCfg<768, 8, 3, 1>;         // whole tile, 1 workgroup of 12 waves per CU
-using WavesWhole4 = WaveCfg<1024, 8, 4, 2>;        // whole tile, 1 workgroup of 16 waves per CU
-using WavesHalf4S8 = WaveCfg<512, 4, 4, 2, 8>;     // as WavesHalf4, quarter-wave lanes two cells apart
-using WavesWhole3S8 = WaveCfg<768, 8, 3, 1, 8>;    // as WavesWhole3, quarter-wave lanes two cells apart
-using CellsHalf4 = WaveCfg<512, 4, 4, 2, 4, MAP_CELLS>;    // cell-indexed lanes, half tile, 2 x 8 waves per CU
-using CellsHalf3 = WaveCfg<384, 4, 3, 1, 4, MAP_CELLS>;    // cell-indexed lanes, half tile, 2 x 6 waves per CU
-using CellsWhole3 = WaveCfg<768, 8, 3, 1, 4, MAP_CELLS>;   // cell-indexed lanes, whole tile, 12 waves per CU
-using CellsWhole4 = WaveCfg<1024, 8, 4, 2, 4, MAP_CELLS>;  // cell-indexed lanes, whole tile, 16 waves per CU
-using RowsWhole3 = RowsCfg<768, 8, 3, 1>;                  // item table from the cell counts, whole tile, 12 waves
-using RowsHalf3 = RowsCfg<384, 4, 3, 1>;                   // half tile, 2 x 6 waves
-using RowsHalf4 = RowsCfg<512, 4, 4, 2>;                   // half tile, 2 x 8 waves, 128 VGPRs
-using RowsWhole4 = RowsCfg<1024, 8, 4, 2>;                 // whole tile, 16 waves, 128 VGPRs
-using RowsWhole3NoLds = RowsCfg<768, 8, 3, 1, 1>;          // timing experiment: arithmetic only (wrong J)
-using RowsWhole3NoAlu = RowsCfg<768, 8, 3, 1, 2>;          // timing experiment: atomics only (wrong J)
-using CfgDefault = WXA_DEPOSIT_CFG;
+// Production configurations: Esirkepov -> the rows kernel on whole tiles (768 lanes, 3 waves per SIMD); direct deposition
+// -> the staged kernel of round 1.  WXA_DEPOSIT_VARIANT=<n> selects an alternative per launch (order-3 Esirkepov only)
+// for A/B timing and for the parity tests of every configuration (scripts/deposit_variants.py):
+//   0 staged / bucketed kernel of round 1 | 14 production | 15 half tiles, 2 x 6 waves | 16 half tiles, 2 x 8 waves,
+//   128 VGPRs | 17 whole tiles, 16 waves, 128 VGPRs | 101 / 102 timing experiments (arithmetic only / atomics only: wrong J)
+using CfgStaged = TileCfg<512, 8, true, 2, 0>;
+using RowsWhole3 = RowsCfg<768, 8, 3, 1>;
+using RowsHalf3 = RowsCfg<384, 4, 3, 1>;
+using RowsHalf4 = RowsCfg<512, 4, 4, 2>;
+using RowsWhole4 = RowsCfg<1024, 8, 4, 2>;
+using RowsWhole3NoLds = RowsCfg<768, 8, 3, 1, 1>;
+using RowsWhole3NoAlu = RowsCfg<768, 8, 3, 1, 2>;
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
     const char* e = getenv("WXA_DEPOSIT_VARIANT");
@@ -1078,35 +857,21 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                                  double q, double dt, double relative_time, int order, int algo,
                                  wxa_workspace* ws, hipStream_t st) {
     if (algo == WXA_DEPOSIT_ESIRKEPOV) {
-        if (order == 1) return launch_tile<1, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
-        if (order == 2) return launch_tile<2, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
+        if (order == 1) return launch_rows<1, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
+        if (order == 2) return launch_rows<2, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
         switch (deposit_variant()) {
-            case 0: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgWhole>(p, J, geom, q, dt, relative_time, ws, st);
-            case 1: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgHalf>(p, J, geom, q, dt, relative_time, ws, st);
-            case 2: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgHalf3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 3: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgWhole3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 4: return launch_waves<3, WavesHalf4>(p, J, geom, q, dt, relative_time, ws, st);
-            case 5: return launch_waves<3, WavesHalf3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 6: return launch_waves<3, WavesWhole3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 7: return launch_waves<3, WavesWhole4>(p, J, geom, q, dt, relative_time, ws, st);
-            case 8: return launch_waves<3, WavesHalf4S8>(p, J, geom, q, dt, relative_time, ws, st);
-            case 9: return launch_waves<3, WavesWhole3S8>(p, J, geom, q, dt, relative_time, ws, st);
-            case 10: return launch_waves<3, CellsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
-            case 11: return launch_waves<3, CellsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 12: return launch_waves<3, CellsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 13: return launch_waves<3, CellsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
-            case 14: return launch_waves<3, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 15: return launch_waves<3, RowsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 16: return launch_waves<3, RowsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
-            case 17: return launch_waves<3, RowsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
-            case 101: return launch_waves<3, RowsWhole3NoLds>(p, J, geom, q, dt, relative_time, ws, st);
-            case 102: return launch_waves<3, RowsWhole3NoAlu>(p, J, geom, q, dt, relative_time, ws, st);
-            default: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
+            case 0: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
+            case 15: return launch_rows<3, RowsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
+            case 16: return launch_rows<3, RowsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 17: return launch_rows<3, RowsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 101: return launch_rows<3, RowsWhole3NoLds>(p, J, geom, q, dt, relative_time, ws, st);
+            case 102: return launch_rows<3, RowsWhole3NoAlu>(p, J, geom, q, dt, relative_time, ws, st);
+            default: return launch_rows<3, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
         }
     }
-    if (order == 1) return launch_tile<1, WXA_DEPOSIT_DIRECT, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
-    if (order == 2) return launch_tile<2, WXA_DEPOSIT_DIRECT, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
-    return launch_tile<3, WXA_DEPOSIT_DIRECT, CfgDefault>(p, J, geom, q, dt, relative_time, ws, st);
+    if (order == 1) return launch_tile<1, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
+    if (order == 2) return launch_tile<2, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
+    return launch_tile<3, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
 }
 
 }  // namespace wxa
