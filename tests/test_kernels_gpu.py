@@ -390,16 +390,16 @@ def test_device_pointer_wrapping(product):
     assert np.all(f.storage[f.front + 16:f.front + 32].cpu().numpy() == 3.5)
 
 
-@pytest.mark.parametrize("ncell", [(24, 20, 16), (25, 9, 7), (130, 6, 5), (64, 8, 8)])
-def test_evolve_two_point_kernels_bit_exact(oracle, product, ncell):
-    """The 16-byte-per-lane stencil kernels (padded, 16-B aligned rows) on odd/even and multi-tile
-    row lengths, bit for bit against the oracle (opt-in variant, WXA_STENCIL_V2=1)."""
-    import os
-    os.environ["WXA_STENCIL_V2"] = "1"
+@pytest.mark.parametrize("ncell", [(24, 20, 16), (25, 9, 7), (130, 6, 5), (300, 8, 8)])
+@pytest.mark.parametrize("variant", list(range(14)))
+def test_evolve_stencil_configurations_bit_exact(oracle, product, ncell, variant):
+    """Every tile shape / non-temporal configuration of the EvolveB / EvolveE kernels (WXA_STENCIL_VARIANT, read per
+    launch) on odd, even and multi-tile row lengths, bit for bit against the oracle."""
+    os.environ["WXA_STENCIL_VARIANT"] = str(variant)
     try:
         _two_point_body(oracle, product, ncell)
     finally:
-        del os.environ["WXA_STENCIL_V2"]
+        del os.environ["WXA_STENCIL_VARIANT"]
 
 
 def _two_point_body(oracle, product, ncell):

@@ -18,51 +18,66 @@
 
 namespace wxa {
 
-// Tile shape, measured on MI355X at 256^3 (EvolveB / EvolveE, ms back to back, same box):
+// Tile shape: a workgroup is TW waves side by side along i (64 TW lanes: one contiguous segment of 512 TW bytes
+// per row and array) x TJ rows, and every lane marches KC planes in k.  Round 1 measured TW = 1 at 256^3
+// (EvolveB / EvolveE, ms back to back, same box):
 //   TJ x KC = 4 x 16: 0.247 / 0.323    4 x 4: 0.233 / 0.305    2 x 4: 0.228 / 0.311
 //   2 x 2: 0.233 / 0.308    1 x 4: 0.231 / 0.312    8 x 4: 0.247 / 0.310    4 x 32: 0.295 / 0.378
 // Short marches win: the k-halo re-read of a 4-plane tile is served by the XCD's L2 (the tile order
 // keeps k-neighbours on one XCD), and 4x more workgroups keep more loads in flight.
-// (-DWXA_TJ / -DWXA_KC override them for such sweeps.)
-constexpr int TI = 64;   // lanes along i (one wavefront per row)
-#ifndef WXA_TJ
-#define WXA_TJ 2
-#endif
-constexpr int TJ = WXA_TJ;    // rows per workgroup
-#ifndef WXA_KC
-#define WXA_KC 4
-#endif
-constexpr int KC = WXA_KC;   // planes marched per workgroup
+// NT: the arrays that are read once and written once per call (B in EvolveB; E and J in EvolveE) move with
+// non-temporal loads / stores, so that they do not evict the rows of the other operand that the j / k neighbours
+// re-read from L2.  WXA_STENCIL_VARIANT=<n> selects a configuration per launch (scripts/stencil_variants.py).
+template <int TW_, int TJ_, int KC_, int NT_>
+struct StencilCfg {
+    static constexpr int TW = TW_, TI = 64 * TW_, TJ = TJ_, KC = KC_, NT = NT_;
+};
+constexpr int TI = 64, TJ = 2, KC = 4;   // the thin-box launches (guard layer) use the plain configuration
 
 struct TileGrid {
     int nti, ntj, ntk;
     long ntiles;
 };
 
-static TileGrid make_tiles(const Box3& ub) {
+template <class CFG>
+static TileGrid make_tiles_cfg(const Box3& ub) {
     TileGrid t;
-    t.nti = (ub.hi[0] - ub.lo[0] + TI - 1) / TI;
-    t.ntj = (ub.hi[1] - ub.lo[1] + TJ - 1) / TJ;
-    t.ntk = (ub.hi[2] - ub.lo[2] + KC - 1) / KC;
+    t.nti = (ub.hi[0] - ub.lo[0] + CFG::TI - 1) / CFG::TI;
+    t.ntj = (ub.hi[1] - ub.lo[1] + CFG::TJ - 1) / CFG::TJ;
+    t.ntk = (ub.hi[2] - ub.lo[2] + CFG::KC - 1) / CFG::KC;
     t.ntiles = (long)t.nti * t.ntj * t.ntk;
     return t;
 }
+static TileGrid make_tiles(const Box3& ub) { return make_tiles_cfg<StencilCfg<1, TJ, KC, 0>>(ub); }
 
 __device__ inline bool in_ij(const Box3& b, int i, int j) {
     return i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1];
 }
 
+template <int NT>
+__device__ __forceinline__ double ld_once(const double* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int NT>
+__device__ __forceinline__ void st_once(double* p, double v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // Source/FieldSolver/FiniteDifferenceSolver/EvolveB.cpp:164-186 (three fused lambdas)
-__global__ void __launch_bounds__(TI* TJ)
+template <class CFG>
+__global__ void __launch_bounds__(CFG::TI* CFG::TJ)
 evolve_b_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, Box3 bbx, Box3 bby,
                 Box3 bbz, TileGrid tg, double dt, double idx, double idy, double idz) {
+    constexpr int KC = CFG::KC, NT = CFG::NT;
     const long tile = xcd_tile_id(blockIdx.x, tg.ntiles);
     if (tile >= tg.ntiles) return;
     const int ti = (int)(tile % tg.nti);
     const int tj = (int)((tile / tg.nti) % tg.ntj);
     const int tk = (int)(tile / ((long)tg.nti * tg.ntj));
-    const int i = ub.lo[0] + ti * TI + (int)threadIdx.x;
-    const int j = ub.lo[1] + tj * TJ + (int)threadIdx.y;
+    const int i = ub.lo[0] + ti * CFG::TI + (int)threadIdx.x;
+    const int j = ub.lo[1] + tj * CFG::TJ + (int)threadIdx.y;
     if (i >= ub.hi[0] || j >= ub.hi[1]) return;
     const int k0 = ub.lo[2] + tk * KC;
     const int k1 = min(k0 + KC, ub.hi[2]);
@@ -82,28 +97,30 @@ evolve_b_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, B
         const double ez_c = ez[0], ez_j1 = ez[Ez.js], ez_i1 = ez[1];
         const double ex_j1 = ex[Ex.js], ey_i1 = ey[1];
         if (px && k >= bbx.lo[2] && k < bbx.hi[2])
-            bx[0] += dt * (idz * (ey_k1 - ey_k)) - dt * (idy * (ez_j1 - ez_c));
+            st_once<NT>(bx, ld_once<NT>(bx) + (dt * (idz * (ey_k1 - ey_k)) - dt * (idy * (ez_j1 - ez_c))));
         if (py && k >= bby.lo[2] && k < bby.hi[2])
-            by[0] += dt * (idx * (ez_i1 - ez_c)) - dt * (idz * (ex_k1 - ex_k));
+            st_once<NT>(by, ld_once<NT>(by) + (dt * (idx * (ez_i1 - ez_c)) - dt * (idz * (ex_k1 - ex_k))));
         if (pz && k >= bbz.lo[2] && k < bbz.hi[2])
-            bz[0] += dt * (idy * (ex_j1 - ex_k)) - dt * (idx * (ey_i1 - ey_k));
+            st_once<NT>(bz, ld_once<NT>(bz) + (dt * (idy * (ex_j1 - ex_k)) - dt * (idx * (ey_i1 - ey_k))));
         ex_k = ex_k1; ey_k = ey_k1;
         ex += Ex.ks; ey += Ey.ks; ez += Ez.ks; bx += Bx.ks; by += By.ks; bz += Bz.ks;
     }
 }
 
 // Source/FieldSolver/FiniteDifferenceSolver/EvolveE.cpp:179-216
-__global__ void __launch_bounds__(TI* TJ)
+template <class CFG>
+__global__ void __launch_bounds__(CFG::TI* CFG::TJ)
 evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, DevF Jy, DevF Jz,
                 Box3 ub, Box3 bex, Box3 bey, Box3 bez, TileGrid tg, double dt, double idx, double idy,
                 double idz) {
+    constexpr int KC = CFG::KC, NT = CFG::NT;
     const long tile = xcd_tile_id(blockIdx.x, tg.ntiles);
     if (tile >= tg.ntiles) return;
     const int ti = (int)(tile % tg.nti);
     const int tj = (int)((tile / tg.nti) % tg.ntj);
     const int tk = (int)(tile / ((long)tg.nti * tg.ntj));
-    const int i = ub.lo[0] + ti * TI + (int)threadIdx.x;
-    const int j = ub.lo[1] + tj * TJ + (int)threadIdx.y;
+    const int i = ub.lo[0] + ti * CFG::TI + (int)threadIdx.x;
+    const int j = ub.lo[1] + tj * CFG::TJ + (int)threadIdx.y;
     if (i >= ub.hi[0] || j >= ub.hi[1]) return;
     const int k0 = ub.lo[2] + tk * KC;
     const int k1 = min(k0 + KC, ub.hi[2]);
@@ -128,180 +145,57 @@ evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, D
         const double bz_jm = bz[-Bz.js], bz_im = bz[-1];
         const double bx_jm = bx[-Bx.js], by_im = by[-1];
         if (px && k >= bex.lo[2] && k < bex.hi[2])
-            ex[0] += c2 * dt * (-(idz * (by_c - by_km)) + (idy * (bz_c - bz_jm)) - mu0 * jx[0]);
+            st_once<NT>(ex, ld_once<NT>(ex) + c2 * dt * (-(idz * (by_c - by_km)) + (idy * (bz_c - bz_jm)) - mu0 * ld_once<NT>(jx)));
         if (py && k >= bey.lo[2] && k < bey.hi[2])
-            ey[0] += c2 * dt * (-(idx * (bz_c - bz_im)) + (idz * (bx_c - bx_km)) - mu0 * jy[0]);
+            st_once<NT>(ey, ld_once<NT>(ey) + c2 * dt * (-(idx * (bz_c - bz_im)) + (idz * (bx_c - bx_km)) - mu0 * ld_once<NT>(jy)));
         if (pz && k >= bez.lo[2] && k < bez.hi[2])
-            ez[0] += c2 * dt * (-(idy * (bx_c - bx_jm)) + (idx * (by_c - by_im)) - mu0 * jz[0]);
+            st_once<NT>(ez, ld_once<NT>(ez) + c2 * dt * (-(idy * (bx_c - bx_jm)) + (idx * (by_c - by_im)) - mu0 * ld_once<NT>(jz)));
         bx_km = bx_c; by_km = by_c;
         ex += Ex.ks; ey += Ey.ks; ez += Ez.ks; bx += Bx.ks; by += By.ks; bz += Bz.ks;
         jx += Jx.ks; jy += Jy.ks; jz += Jz.ks;
     }
 }
 
-// ---- two points per lane (16-B loads) -------------------------------------------------------
-// Same arithmetic, but every lane owns points (i0, i0+1) of a row and moves them with 16-byte
-// loads/stores (1 KiB per wave instruction, the coalescing sweet spot of the memory pipe).  The
-// i+-1 neighbour that belongs to the next / previous lane comes through a wave shuffle; only the
-// edge lane issues an extra 8-byte load.  Needs every row 16-byte aligned (true for the host
-// layer's padded MultiFabs).  Measured on MI355X at 256^3 (round 1): EvolveB 0.246 ms vs 0.245 ms,
-// EvolveE 0.337 ms vs 0.322 ms for the one-point kernels -- the stencils are bound by the HBM
-// system under 9-12 concurrent streams (4.9 TB/s = 78 % of the measured copy rate), not by the
-// width of the wave's memory instructions.  Kept bit-exact and tested, but opt-in
-// (WXA_STENCIL_V2=1); the one-point kernels are the default.
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ dbl2 ld2(const double* p) { return *reinterpret_cast<const dbl2*>(p); }
-__device__ __forceinline__ void st2(double* p, dbl2 v) { *reinterpret_cast<dbl2*>(p) = v; }
-
-constexpr int TI2 = 128;  // points along i per wave
-
-__global__ void __launch_bounds__(64 * TJ)
-evolve_b_kernel_v2(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, Box3 bbx, Box3 bby,
-                   Box3 bbz, TileGrid tg, double dt, double idx, double idy, double idz) {
-    const long tile = xcd_tile_id(blockIdx.x, tg.ntiles);
-    if (tile >= tg.ntiles) return;
-    const int ti = (int)(tile % tg.nti);
-    const int tj = (int)((tile / tg.nti) % tg.ntj);
-    const int tk = (int)(tile / ((long)tg.nti * tg.ntj));
-    const int lane = (int)threadIdx.x;
-    const int j = ub.lo[1] + tj * TJ + (int)threadIdx.y;
-    if (j >= ub.hi[1]) return;                                    // whole wave
-    const int i_raw = ub.lo[0] + ti * TI2 + 2 * lane;
-    const int i_last = ub.hi[0] - 2 + ((ub.hi[0] - ub.lo[0]) & 1);   // last even offset inside the row
-    const int i0 = min(i_raw, i_last);                                // keep every lane alive (shuffles)
-    const bool mine = i_raw == i0;
-    const bool edge = lane == 63 || i_raw + 2 > i_last;               // the next lane does not hold i0+2
-    const int k0 = ub.lo[2] + tk * KC;
-    const int k1 = min(k0 + KC, ub.hi[2]);
-    auto ok = [&](const Box3& b, int i) { return mine && i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1]; };
-    const bool pxa = ok(bbx, i0), pxb = ok(bbx, i0 + 1), pya = ok(bby, i0), pyb = ok(bby, i0 + 1);
-    const bool pza = ok(bbz, i0), pzb = ok(bbz, i0 + 1);
-
-    const double* __restrict__ ex = Ex.p + Ex.off(i0, j, k0);
-    const double* __restrict__ ey = Ey.p + Ey.off(i0, j, k0);
-    const double* __restrict__ ez = Ez.p + Ez.off(i0, j, k0);
-    double* __restrict__ bx = Bx.p + Bx.off(i0, j, k0);
-    double* __restrict__ by = By.p + By.off(i0, j, k0);
-    double* __restrict__ bz = Bz.p + Bz.off(i0, j, k0);
-
-    dbl2 ex_k = ld2(ex), ey_k = ld2(ey);
-    double ey_kn = __shfl_down(ey_k.x, 1);
-    if (edge) ey_kn = ey[2];
-#pragma unroll 2
-    for (int k = k0; k < k1; ++k) {
-        const dbl2 ex_k1 = ld2(ex + Ex.ks), ey_k1 = ld2(ey + Ey.ks);
-        const dbl2 ez_c = ld2(ez), ez_j1 = ld2(ez + Ez.js), ex_j1 = ld2(ex + Ex.js);
-        double ez_n = __shfl_down(ez_c.x, 1);
-        double ey_k1n = __shfl_down(ey_k1.x, 1);
-        if (edge) { ez_n = ez[2]; ey_k1n = ey[Ey.ks + 2]; }
-        const bool kx = k >= bbx.lo[2] && k < bbx.hi[2], ky = k >= bby.lo[2] && k < bby.hi[2];
-        const bool kz = k >= bbz.lo[2] && k < bbz.hi[2];
-        if (kx && (pxa || pxb)) {
-            dbl2 b = ld2(bx);
-            b.x += dt * (idz * (ey_k1.x - ey_k.x)) - dt * (idy * (ez_j1.x - ez_c.x));
-            b.y += dt * (idz * (ey_k1.y - ey_k.y)) - dt * (idy * (ez_j1.y - ez_c.y));
-            if (pxa && pxb) st2(bx, b); else if (pxa) bx[0] = b.x; else bx[1] = b.y;
-        }
-        if (ky && (pya || pyb)) {
-            dbl2 b = ld2(by);
-            b.x += dt * (idx * (ez_c.y - ez_c.x)) - dt * (idz * (ex_k1.x - ex_k.x));
-            b.y += dt * (idx * (ez_n - ez_c.y)) - dt * (idz * (ex_k1.y - ex_k.y));
-            if (pya && pyb) st2(by, b); else if (pya) by[0] = b.x; else by[1] = b.y;
-        }
-        if (kz && (pza || pzb)) {
-            dbl2 b = ld2(bz);
-            b.x += dt * (idy * (ex_j1.x - ex_k.x)) - dt * (idx * (ey_k.y - ey_k.x));
-            b.y += dt * (idy * (ex_j1.y - ex_k.y)) - dt * (idx * (ey_kn - ey_k.y));
-            if (pza && pzb) st2(bz, b); else if (pza) bz[0] = b.x; else bz[1] = b.y;
-        }
-        ex_k = ex_k1; ey_k = ey_k1; ey_kn = ey_k1n;
-        ex += Ex.ks; ey += Ey.ks; ez += Ez.ks; bx += Bx.ks; by += By.ks; bz += Bz.ks;
-    }
+// configurations selectable per launch (timing sweeps; every one is bit-identical to the CPU path)
+using StPlain = StencilCfg<1, 2, 4, 0>;
+static int stencil_variant() {
+    const char* e = getenv("WXA_STENCIL_VARIANT");
+    return e ? atoi(e) : -1;
 }
-
-__global__ void __launch_bounds__(64 * TJ)
-evolve_e_kernel_v2(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, DevF Jy, DevF Jz,
-                   Box3 ub, Box3 bex, Box3 bey, Box3 bez, TileGrid tg, double dt, double idx, double idy,
-                   double idz) {
-    const long tile = xcd_tile_id(blockIdx.x, tg.ntiles);
-    if (tile >= tg.ntiles) return;
-    const int ti = (int)(tile % tg.nti);
-    const int tj = (int)((tile / tg.nti) % tg.ntj);
-    const int tk = (int)(tile / ((long)tg.nti * tg.ntj));
-    const int lane = (int)threadIdx.x;
-    const int j = ub.lo[1] + tj * TJ + (int)threadIdx.y;
-    if (j >= ub.hi[1]) return;
-    const int i_raw = ub.lo[0] + ti * TI2 + 2 * lane;
-    const int i0 = min(i_raw, ub.hi[0] - 2 + ((ub.hi[0] - ub.lo[0]) & 1));
-    const bool mine = i_raw == i0;
-    const int k0 = ub.lo[2] + tk * KC;
-    const int k1 = min(k0 + KC, ub.hi[2]);
-    auto ok = [&](const Box3& b, int i) { return mine && i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1]; };
-    const bool pxa = ok(bex, i0), pxb = ok(bex, i0 + 1), pya = ok(bey, i0), pyb = ok(bey, i0 + 1);
-    const bool pza = ok(bez, i0), pzb = ok(bez, i0 + 1);
-    constexpr double c2 = PhysConst::c * PhysConst::c;
-    constexpr double mu0 = PhysConst::mu0;
-
-    double* __restrict__ ex = Ex.p + Ex.off(i0, j, k0);
-    double* __restrict__ ey = Ey.p + Ey.off(i0, j, k0);
-    double* __restrict__ ez = Ez.p + Ez.off(i0, j, k0);
-    const double* __restrict__ bx = Bx.p + Bx.off(i0, j, k0);
-    const double* __restrict__ by = By.p + By.off(i0, j, k0);
-    const double* __restrict__ bz = Bz.p + Bz.off(i0, j, k0);
-    const double* __restrict__ jx = Jx.p + Jx.off(i0, j, k0);
-    const double* __restrict__ jy = Jy.p + Jy.off(i0, j, k0);
-    const double* __restrict__ jz = Jz.p + Jz.off(i0, j, k0);
-
-    dbl2 bx_km = ld2(bx - Bx.ks), by_km = ld2(by - By.ks);
-#pragma unroll 2
-    for (int k = k0; k < k1; ++k) {
-        const dbl2 bx_c = ld2(bx), by_c = ld2(by), bz_c = ld2(bz);
-        const dbl2 bz_jm = ld2(bz - Bz.js), bx_jm = ld2(bx - Bx.js);
-        double bz_p = __shfl_up(bz_c.y, 1), by_p = __shfl_up(by_c.y, 1);   // element i0-1
-        if (lane == 0) { bz_p = bz[-1]; by_p = by[-1]; }
-        const bool kx = k >= bex.lo[2] && k < bex.hi[2], ky = k >= bey.lo[2] && k < bey.hi[2];
-        const bool kz = k >= bez.lo[2] && k < bez.hi[2];
-        if (kx && (pxa || pxb)) {
-            dbl2 e = ld2(ex);
-            const dbl2 jj = ld2(jx);
-            e.x += c2 * dt * (-(idz * (by_c.x - by_km.x)) + (idy * (bz_c.x - bz_jm.x)) - mu0 * jj.x);
-            e.y += c2 * dt * (-(idz * (by_c.y - by_km.y)) + (idy * (bz_c.y - bz_jm.y)) - mu0 * jj.y);
-            if (pxa && pxb) st2(ex, e); else if (pxa) ex[0] = e.x; else ex[1] = e.y;
-        }
-        if (ky && (pya || pyb)) {
-            dbl2 e = ld2(ey);
-            const dbl2 jj = ld2(jy);
-            e.x += c2 * dt * (-(idx * (bz_c.x - bz_p)) + (idz * (bx_c.x - bx_km.x)) - mu0 * jj.x);
-            e.y += c2 * dt * (-(idx * (bz_c.y - bz_c.x)) + (idz * (bx_c.y - bx_km.y)) - mu0 * jj.y);
-            if (pya && pyb) st2(ey, e); else if (pya) ey[0] = e.x; else ey[1] = e.y;
-        }
-        if (kz && (pza || pzb)) {
-            dbl2 e = ld2(ez);
-            const dbl2 jj = ld2(jz);
-            e.x += c2 * dt * (-(idy * (bx_c.x - bx_jm.x)) + (idx * (by_c.x - by_p)) - mu0 * jj.x);
-            e.y += c2 * dt * (-(idy * (bx_c.y - bx_jm.y)) + (idx * (by_c.y - by_c.x)) - mu0 * jj.y);
-            if (pza && pzb) st2(ez, e); else if (pza) ez[0] = e.x; else ez[1] = e.y;
-        }
-        bx_km = bx_c; by_km = by_c;
-        ex += Ex.ks; ey += Ey.ks; ez += Ez.ks; bx += Bx.ks; by += By.ks; bz += Bz.ks;
-        jx += Jx.ks; jy += Jy.ks; jz += Jz.ks;
+using St1 = StencilCfg<1, 2, 4, 1>;
+using St2 = StencilCfg<1, 4, 4, 0>;
+using St3 = StencilCfg<1, 4, 4, 1>;
+using St4 = StencilCfg<1, 1, 8, 1>;
+using St5 = StencilCfg<1, 2, 8, 1>;
+using St6 = StencilCfg<1, 4, 2, 1>;
+using St7 = StencilCfg<4, 1, 4, 0>;
+using St8 = StencilCfg<4, 1, 4, 1>;
+using St9 = StencilCfg<4, 1, 8, 1>;
+using St10 = StencilCfg<4, 2, 4, 1>;
+using St11 = StencilCfg<2, 2, 4, 1>;
+using St12 = StencilCfg<4, 1, 2, 1>;
+using St13 = StencilCfg<1, 1, 4, 1>;
+#define WXA_STENCIL_DISPATCH(CALL)          \
+    switch (stencil_variant()) {            \
+        case 0: CALL(StPlain); break;       \
+        case 1: CALL(St1); break;           \
+        case 2: CALL(St2); break;           \
+        case 3: CALL(St3); break;           \
+        case 4: CALL(St4); break;           \
+        case 5: CALL(St5); break;           \
+        case 6: CALL(St6); break;           \
+        case 7: CALL(St7); break;           \
+        case 8: CALL(St8); break;           \
+        case 9: CALL(St9); break;           \
+        case 10: CALL(St10); break;         \
+        case 11: CALL(St11); break;         \
+        case 12: CALL(St12); break;         \
+        case 13: CALL(St13); break;         \
+        default: CALL(WXA_STENCIL_DEFAULT); break; \
     }
-}
-
-// every array 16-byte aligned at the first union point, even strides, >= 2 guard points in i
-static bool v2_ok(const wxa_field_view* const* views, int nviews, const Box3& ub) {
-    if (!getenv("WXA_STENCIL_V2")) return false;   // opt-in, see the note above
-    if (ub.hi[0] - ub.lo[0] < 2) return false;
-    for (int v = 0; v < nviews; ++v) {
-        const wxa_field_view& f = *views[v];
-        if (f.ng[0] < 2 || (f.jstride & 1) || (f.kstride & 1)) return false;
-        const uintptr_t a = reinterpret_cast<uintptr_t>(f.p + (ub.lo[0] - f.lo[0]));
-        if (a & 15) return false;
-        if (ub.lo[0] - f.lo[0] < 1 || f.lo[0] + f.n[0] - ub.hi[0] < 2) return false;
-    }
-    return true;
-}
+#ifndef WXA_STENCIL_DEFAULT
+#define WXA_STENCIL_DEFAULT StPlain
+#endif
 
 // Source/Filter/Filter.cpp:105-133 with the 1-pass stencil of BilinearFilter.cpp:26-60
 // ({0.25, 0.25} per direction); same tap order as the reference -> bit-identical.
@@ -685,26 +579,17 @@ wxa_status wxa_evolve_b(const wxa_field_view E[3], const wxa_field_view B[3], do
         ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
         ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
     }
-    {
-        const wxa_field_view* vs[6] = {&E[0], &E[1], &E[2], &B[0], &B[1], &B[2]};
-        if (v2_ok(vs, 6, ub)) {
-            TileGrid t2 = make_tiles(ub);
-            t2.nti = (ub.hi[0] - ub.lo[0] + TI2 - 1) / TI2;
-            t2.ntiles = (long)t2.nti * t2.ntj * t2.ntk;
-            hipLaunchKernelGGL(evolve_b_kernel_v2, dim3((unsigned)xcd_grid_size(t2.ntiles)), dim3(64, TJ), 0,
-                               (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
-                               make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, t2, dt,
-                               dinv[0], dinv[1], dinv[2]);
-            WXA_LAUNCH_CHECK();
-            return WXA_OK;
-        }
-    }
-    const TileGrid tg = make_tiles(ub);
-    if (tg.ntiles <= 0) return WXA_OK;
-    hipLaunchKernelGGL(evolve_b_kernel, dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(TI, TJ), 0,
-                       (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
-                       make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, tg, dt,
-                       dinv[0], dinv[1], dinv[2]);
+#define WXA_LAUNCH_B(CFG)                                                                                       \
+    do {                                                                                                        \
+        const TileGrid tg = make_tiles_cfg<CFG>(ub);                                                            \
+        if (tg.ntiles > 0)                                                                                      \
+            hipLaunchKernelGGL((evolve_b_kernel<CFG>), dim3((unsigned)xcd_grid_size(tg.ntiles)),                \
+                               dim3(CFG::TI, CFG::TJ), 0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), \
+                               make_devf(E[2]), make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bx, by,  \
+                               bz, tg, dt, dinv[0], dinv[1], dinv[2]);                                          \
+    } while (0)
+    WXA_STENCIL_DISPATCH(WXA_LAUNCH_B)
+#undef WXA_LAUNCH_B
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
@@ -746,7 +631,7 @@ wxa_status wxa_evolve_b_guard_layer(const wxa_field_view E[3], const wxa_field_v
                 if (bc[c].hi[d] == bc[c].lo[d]) bc[c].lo[d] = bc[c].hi[d] = ub.lo[d];
             const TileGrid tg = make_tiles(ub);
             if (tg.ntiles <= 0) continue;
-            hipLaunchKernelGGL(evolve_b_kernel, dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(TI, TJ), 0,
+            hipLaunchKernelGGL((evolve_b_kernel<StPlain>), dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(TI, TJ), 0,
                                (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
                                make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bc[0], bc[1], bc[2], tg, dt,
                                dinv[0], dinv[1], dinv[2]);
@@ -835,26 +720,18 @@ wxa_status wxa_evolve_e(const wxa_field_view E[3], const wxa_field_view B[3], co
         ub.lo[d] = std::min(bx.lo[d], std::min(by.lo[d], bz.lo[d]));
         ub.hi[d] = std::max(bx.hi[d], std::max(by.hi[d], bz.hi[d]));
     }
-    {
-        const wxa_field_view* vs[9] = {&E[0], &E[1], &E[2], &B[0], &B[1], &B[2], &J[0], &J[1], &J[2]};
-        if (v2_ok(vs, 9, ub)) {
-            TileGrid t2 = make_tiles(ub);
-            t2.nti = (ub.hi[0] - ub.lo[0] + TI2 - 1) / TI2;
-            t2.ntiles = (long)t2.nti * t2.ntj * t2.ntk;
-            hipLaunchKernelGGL(evolve_e_kernel_v2, dim3((unsigned)xcd_grid_size(t2.ntiles)), dim3(64, TJ), 0,
-                               (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
-                               make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), make_devf(J[0]),
-                               make_devf(J[1]), make_devf(J[2]), ub, bx, by, bz, t2, dt, dinv[0], dinv[1], dinv[2]);
-            WXA_LAUNCH_CHECK();
-            return WXA_OK;
-        }
-    }
-    const TileGrid tg = make_tiles(ub);
-    if (tg.ntiles <= 0) return WXA_OK;
-    hipLaunchKernelGGL(evolve_e_kernel, dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(TI, TJ), 0,
-                       (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
-                       make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), make_devf(J[0]),
-                       make_devf(J[1]), make_devf(J[2]), ub, bx, by, bz, tg, dt, dinv[0], dinv[1], dinv[2]);
+#define WXA_LAUNCH_E(CFG)                                                                                       \
+    do {                                                                                                        \
+        const TileGrid tg = make_tiles_cfg<CFG>(ub);                                                            \
+        if (tg.ntiles > 0)                                                                                      \
+            hipLaunchKernelGGL((evolve_e_kernel<CFG>), dim3((unsigned)xcd_grid_size(tg.ntiles)),                \
+                               dim3(CFG::TI, CFG::TJ), 0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), \
+                               make_devf(E[2]), make_devf(B[0]), make_devf(B[1]), make_devf(B[2]),              \
+                               make_devf(J[0]), make_devf(J[1]), make_devf(J[2]), ub, bx, by, bz, tg, dt,       \
+                               dinv[0], dinv[1], dinv[2]);                                                      \
+    } while (0)
+    WXA_STENCIL_DISPATCH(WXA_LAUNCH_E)
+#undef WXA_LAUNCH_E
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
