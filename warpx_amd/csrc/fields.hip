@@ -55,6 +55,11 @@ __device__ inline bool in_ij(const Box3& b, int i, int j) {
 }
 
 template <int NT>
+__device__ __forceinline__ double ld_shared(const double* p) {   // operands that neighbouring tiles read again
+    if constexpr (NT >= 2) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int NT>
 __device__ __forceinline__ double ld_once(const double* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
@@ -90,12 +95,12 @@ evolve_b_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, B
     double* __restrict__ by = By.p + By.off(i, j, k0);
     double* __restrict__ bz = Bz.p + Bz.off(i, j, k0);
 
-    double ex_k = ex[0], ey_k = ey[0];
+    double ex_k = ld_shared<NT>(ex), ey_k = ld_shared<NT>(ey);
 #pragma unroll 4
     for (int k = k0; k < k1; ++k) {
-        const double ex_k1 = ex[Ex.ks], ey_k1 = ey[Ey.ks];
-        const double ez_c = ez[0], ez_j1 = ez[Ez.js], ez_i1 = ez[1];
-        const double ex_j1 = ex[Ex.js], ey_i1 = ey[1];
+        const double ex_k1 = ld_shared<NT>(ex + Ex.ks), ey_k1 = ld_shared<NT>(ey + Ey.ks);
+        const double ez_c = ld_shared<NT>(ez), ez_j1 = ld_shared<NT>(ez + Ez.js), ez_i1 = ld_shared<NT>(ez + 1);
+        const double ex_j1 = ld_shared<NT>(ex + Ex.js), ey_i1 = ld_shared<NT>(ey + 1);
         if (px && k >= bbx.lo[2] && k < bbx.hi[2])
             st_once<NT>(bx, ld_once<NT>(bx) + (dt * (idz * (ey_k1 - ey_k)) - dt * (idy * (ez_j1 - ez_c))));
         if (py && k >= bby.lo[2] && k < bby.hi[2])
@@ -138,12 +143,12 @@ evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, D
     const double* __restrict__ jy = Jy.p + Jy.off(i, j, k0);
     const double* __restrict__ jz = Jz.p + Jz.off(i, j, k0);
 
-    double bx_km = bx[-Bx.ks], by_km = by[-By.ks];
+    double bx_km = ld_shared<NT>(bx - Bx.ks), by_km = ld_shared<NT>(by - By.ks);
 #pragma unroll 4
     for (int k = k0; k < k1; ++k) {
-        const double bx_c = bx[0], by_c = by[0], bz_c = bz[0];
-        const double bz_jm = bz[-Bz.js], bz_im = bz[-1];
-        const double bx_jm = bx[-Bx.js], by_im = by[-1];
+        const double bx_c = ld_shared<NT>(bx), by_c = ld_shared<NT>(by), bz_c = ld_shared<NT>(bz);
+        const double bz_jm = ld_shared<NT>(bz - Bz.js), bz_im = ld_shared<NT>(bz - 1);
+        const double bx_jm = ld_shared<NT>(bx - Bx.js), by_im = ld_shared<NT>(by - 1);
         if (px && k >= bex.lo[2] && k < bex.hi[2])
             st_once<NT>(ex, ld_once<NT>(ex) + c2 * dt * (-(idz * (by_c - by_km)) + (idy * (bz_c - bz_jm)) - mu0 * ld_once<NT>(jx)));
         if (py && k >= bey.lo[2] && k < bey.hi[2])
@@ -162,19 +167,17 @@ static int stencil_variant() {
     const char* e = getenv("WXA_STENCIL_VARIANT");
     return e ? atoi(e) : -1;
 }
+// MI355X, 256^3, back to back, same box (round 2; % of 8 TB/s for 72 / 96 B per cell):
+//   2 x 4 plain 0.2290 / 0.3060 ms (65.9 / 65.8 %)   2 x 4 NT 0.2204 / 0.2866 (68.5 / 70.2)   1 x 4 NT 0.2188 / 0.2865
+//   1 x 3 NT 0.2146 / 0.2803 (70.3 / 71.8)   1 x 2 NT 0.2214 / 0.2866   4 x 2 NT 0.2294 / 0.2897
+//   NT on the shared operand too: 0.2633 / 0.3088 (57 / 65)   256-lane rows (TW = 4): 0.325 / 0.372 (46 / 54)
 using St1 = StencilCfg<1, 2, 4, 1>;
-using St2 = StencilCfg<1, 4, 4, 0>;
-using St3 = StencilCfg<1, 4, 4, 1>;
-using St4 = StencilCfg<1, 1, 8, 1>;
-using St5 = StencilCfg<1, 2, 8, 1>;
-using St6 = StencilCfg<1, 4, 2, 1>;
-using St7 = StencilCfg<4, 1, 4, 0>;
-using St8 = StencilCfg<4, 1, 4, 1>;
-using St9 = StencilCfg<4, 1, 8, 1>;
-using St10 = StencilCfg<4, 2, 4, 1>;
-using St11 = StencilCfg<2, 2, 4, 1>;
-using St12 = StencilCfg<4, 1, 2, 1>;
-using St13 = StencilCfg<1, 1, 4, 1>;
+using St2 = StencilCfg<1, 1, 4, 1>;
+using St3 = StencilCfg<1, 1, 3, 1>;
+using St4 = StencilCfg<1, 1, 2, 1>;
+using St5 = StencilCfg<1, 4, 2, 1>;
+using St6 = StencilCfg<1, 1, 3, 2>;
+using St7 = StencilCfg<4, 1, 4, 1>;
 #define WXA_STENCIL_DISPATCH(CALL)          \
     switch (stencil_variant()) {            \
         case 0: CALL(StPlain); break;       \
@@ -185,16 +188,10 @@ using St13 = StencilCfg<1, 1, 4, 1>;
         case 5: CALL(St5); break;           \
         case 6: CALL(St6); break;           \
         case 7: CALL(St7); break;           \
-        case 8: CALL(St8); break;           \
-        case 9: CALL(St9); break;           \
-        case 10: CALL(St10); break;         \
-        case 11: CALL(St11); break;         \
-        case 12: CALL(St12); break;         \
-        case 13: CALL(St13); break;         \
         default: CALL(WXA_STENCIL_DEFAULT); break; \
     }
 #ifndef WXA_STENCIL_DEFAULT
-#define WXA_STENCIL_DEFAULT StPlain
+#define WXA_STENCIL_DEFAULT St3
 #endif
 
 // Source/Filter/Filter.cpp:105-133 with the 1-pass stencil of BilinearFilter.cpp:26-60
