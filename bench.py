@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: the guard exchanges of E+B and of J on a second stream, behind the push of the interior "
                          "tiles and B's half update (N > 1 only; off until it has been measured on the 8-GPU node)")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1: rccl = the library's own transport (ncclSend / ncclRecv groups on the library's streams, "
+                         "csrc/rccl_comm.hip); torch = torch.distributed P2P through Python callbacks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-pass", action="store_true")
     args = ap.parse_args()
@@ -180,12 +183,19 @@ def main():
     nbricks, coord = (1, 1, 1), (0, 0, 0)
     if world > 1:
         import torch.distributed as dist
-        from warpx_amd.distributed import TorchBrickTransport, brick_coord, brick_layout
+        from warpx_amd.distributed import RcclBrickTransport, TorchBrickTransport, brick_coord, brick_layout
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(device))
         nbricks = brick_layout(world)
         coord = brick_coord(rank, nbricks)
-        transport = TorchBrickTransport(on_device=True)
+        transport = None
+        if args.transport == "rccl":
+            try:
+                transport = RcclBrickTransport(lib, timing=True)
+            except Exception as e:   # keep the run alive on the Python transport, and say so
+                print(f"[bench] rank {rank}: in-library RCCL transport unavailable ({e}); using torch.distributed", flush=True)
+        if transport is None:
+            transport = TorchBrickTransport(on_device=True)
 
     nb = args.ncell
     n_cell = tuple(nb * nbricks[d] for d in range(3))
@@ -240,6 +250,19 @@ def main():
         phases = sim.timers(reset=True)
         sim.enable_timers(False)
 
+    comm_stats = None
+    if transport is not None and hasattr(transport, "stats"):
+        st = transport.stats()
+        comm_stats = {"transport": "rccl (in-library)", "exchanges_per_step": st["n_exchanges"] / max(sim.istep, 1),
+                      "messages_per_step": st["n_messages"] / max(sim.istep, 1),
+                      "MB_sent_per_step": st["bytes_sent"] / max(sim.istep, 1) / 1e6,
+                      "count_exchanges_per_step": st["n_count_exchanges"] / max(sim.istep, 1),
+                      "ms_per_exchange": st["timed_ms"] / max(st["timed_exchanges"], 1),
+                      "exchange_ms_per_step": st["timed_ms"] / max(sim.istep, 1)}
+    elif transport is not None:
+        comm_stats = {"transport": "torch.distributed (Python callbacks)",
+                      "exchanges_per_step": transport.n_exchanges / max(sim.istep, 1),
+                      "MB_sent_per_step": transport.bytes_sent / max(sim.istep, 1) / 1e6}
     if rank == 0:
         total_particles = np_local * world
         total_cells = ncells_local * world
@@ -299,6 +322,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if comm_stats:
+            out["exchange"] = comm_stats
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

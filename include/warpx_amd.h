@@ -525,6 +525,27 @@ typedef struct wxa_comm {
                            const int32_t* recv_peer, int64_t* recv_val);
 } wxa_comm;
 
+/* ---- the library's own transport: RCCL over xGMI ------------------------------------------------------
+ * Fills a wxa_comm whose callbacks enqueue ncclSend / ncclRecv groups on the stream they are handed (no host
+ * wait per exchange; the 8-byte particle counts travel on a stream of the transport's own).  What the reference
+ * gets from MPI under amrex FillBoundary / SumBoundary / Redistribute (Source/ablastr/utils/Communication.cpp:
+ * 71-175, Source/Parallelization/WarpXComm.cpp:699-827,1386-1424).  One process per GPU: rank 0 calls
+ * wxa_rccl_unique_id and hands the 128 bytes to the others (any channel: torch.distributed, MPI, a file), then
+ * every rank calls wxa_rccl_comm_create after selecting its device.  RCCL is loaded with dlopen at the first
+ * call: WXA_ERR_UNSUPPORTED where librccl.so is missing. */
+#define WXA_RCCL_ID_BYTES 128
+#define WXA_RCCL_LOOPBACK 1   /* messages to this rank itself go through ncclSend / ncclRecv as well (tests) */
+#define WXA_RCCL_TIMING   2   /* a pair of HIP events around every exchange (wxa_rccl_comm_stats.timed_ms)  */
+typedef struct wxa_rccl_stats {
+    int64_t n_exchanges, n_messages, bytes_sent, n_count_exchanges, timed_exchanges;
+    double timed_ms;
+} wxa_rccl_stats;
+wxa_status wxa_rccl_unique_id(char id[WXA_RCCL_ID_BYTES]);
+wxa_status wxa_rccl_comm_create(const char id[WXA_RCCL_ID_BYTES], int32_t rank, int32_t nranks, int32_t flags,
+                                wxa_comm* out);
+void       wxa_rccl_comm_destroy(wxa_comm* comm);
+wxa_status wxa_rccl_comm_stats(wxa_comm* comm, wxa_rccl_stats* out, int32_t reset);
+
 typedef struct wxa_sim wxa_sim;
 
 wxa_status wxa_sim_create(const wxa_sim_config* cfg, const wxa_comm* comm, wxa_sim** out);

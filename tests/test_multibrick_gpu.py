@@ -162,3 +162,42 @@ def test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, order, filt,
     assert abs(ek - rmom["ekin"]) / rmom["ekin"] < 1e-11
     ap = np.sum([r["abs_p"] for r in results], axis=0)
     assert np.max(np.abs(ap - np.array(rmom["abs_momentum"])) / np.array(rmom["abs_momentum"])) < 1e-11
+
+
+@pytest.mark.skipif(H.HIP_ON_CPU, reason="RCCL needs the GPU")
+def test_rccl_transport_loopback(product):
+    """The library's own transport (csrc/rccl_comm.hip) on one GPU: a one-rank RCCL communicator in loop-back mode, so
+    that the messages BrickComm would send to a neighbour really travel through an ncclSend / ncclRecv group on the
+    caller's stream -- two messages each way to the same peer (the 2 x 2 x 2 case: both faces of a direction lead to
+    one rank), matched by posting order; then the 8-byte count exchange on the transport's own stream."""
+    import ctypes as C
+
+    import torch
+
+    from warpx_amd import _capi
+    from warpx_amd.distributed import RcclBrickTransport
+    tr = RcclBrickTransport(product, rank=0, nranks=1, loopback=True, timing=True)
+    n0, n1 = 1 << 20, 3000
+    s0 = torch.arange(n0, dtype=torch.float64, device="cuda")
+    s1 = -torch.arange(n1, dtype=torch.float64, device="cuda")
+    r0 = torch.zeros(n0, dtype=torch.float64, device="cuda")
+    r1 = torch.zeros(n1, dtype=torch.float64, device="cuda")
+    peers = (C.c_int32 * 2)(0, 0)
+    sbuf = (C.c_void_p * 2)(s0.data_ptr(), s1.data_ptr())
+    rbuf = (C.c_void_p * 2)(r0.data_ptr(), r1.data_ptr())
+    sbytes = (C.c_int64 * 2)(8 * n0, 8 * n1)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        rc = tr.comm.exchange(tr.comm.ctx, 2, peers, sbuf, sbytes, peers, rbuf, sbytes, stream)
+        assert rc == 0, product.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(r0, s0) and torch.equal(r1, s1)
+    sv = (C.c_int64 * 2)(123456789012, 7)
+    rv = (C.c_int64 * 2)(0, 0)
+    assert tr.comm.exchange_counts(tr.comm.ctx, 2, peers, sv, peers, rv) == 0, product.last_error()
+    assert list(rv) == [123456789012, 7]
+    st = tr.stats()
+    assert st["n_exchanges"] == 3 and st["n_messages"] == 6 and st["bytes_sent"] == 3 * 8 * (n0 + n1)
+    assert st["timed_exchanges"] == 3 and st["timed_ms"] > 0.0
+    print("rccl loop-back:", st)
+    tr.close()

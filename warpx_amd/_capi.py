@@ -117,6 +117,12 @@ class Comm(C.Structure):
     ]
 
 
+class RcclStats(C.Structure):
+    _fields_ = [("n_exchanges", C.c_int64), ("n_messages", C.c_int64), ("bytes_sent", C.c_int64),
+                ("n_count_exchanges", C.c_int64), ("timed_exchanges", C.c_int64), ("timed_ms", C.c_double)]
+
+
+RCCL_LOOPBACK, RCCL_TIMING = 1, 2
 PUSHER_BORIS, PUSHER_VAY, PUSHER_HC, PUSHER_BORIS_RR = 0, 1, 2, 3
 DEPOSIT_ESIRKEPOV, DEPOSIT_DIRECT = 0, 1
 BOUNDARY_PERIODIC, BOUNDARY_PEC = 0, 1
@@ -223,6 +229,14 @@ _PRODUCT_SIGS = {
     "device_synchronize": (C.c_int, []),
 }
 
+# the library's own transport (rccl_comm.hip): product only
+_TRANSPORT_SIGS = {
+    "rccl_unique_id": (C.c_int, [C.c_char * 128]),
+    "rccl_comm_create": (C.c_int, [C.c_char * 128, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Comm)]),
+    "rccl_comm_destroy": (None, [C.POINTER(Comm)]),
+    "rccl_comm_stats": (C.c_int, [C.POINTER(Comm), C.POINTER(RcclStats), C.c_int32]),
+}
+
 # oracle-only entry points (diagnostic formulas that define the parity metric)
 _ORACLE_SIGS = {
     "sum_sq_unique": (C.c_double, [_PFV]),
@@ -304,7 +318,8 @@ def load_product() -> CLib:
     global _product
     if _product is None:
         # WXA_PRODUCT_LIB: another build of the same library (kernel experiments, scripts/)
-        _product = CLib(os.environ.get("WXA_PRODUCT_LIB", PRODUCT_LIB), "wxa_", {**_PRODUCT_SIGS, **_INPUTS_SIGS})
+        _product = CLib(os.environ.get("WXA_PRODUCT_LIB", PRODUCT_LIB), "wxa_",
+                       {**_PRODUCT_SIGS, **_INPUTS_SIGS, **_TRANSPORT_SIGS})
     return _product
 
 

@@ -32,6 +32,7 @@ SOURCES = [
     ("deposit_tile.hip", []),
     ("gather_tile.hip", []),
     ("host/warpx_host.hip", []),
+    ("rccl_comm.hip", []),
 ]
 
 
@@ -70,7 +71,7 @@ def build(force=False, verbose=True):
     objs = [o for o, _ in res]
     changed = any(c for _, c in res)
     if changed or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

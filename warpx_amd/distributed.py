@@ -178,3 +178,39 @@ class TorchBrickTransport:
             traceback.print_exc()
             print(f"[warpx_amd.distributed] exchange_counts failed: {e}", flush=True)
             return -1
+
+
+class RcclBrickTransport:
+    """The library's own transport (csrc/rccl_comm.hip): ncclSend / ncclRecv groups enqueued on the library's streams
+    by C++ callbacks -- no Python in the exchange path, no host wait per message.  torch.distributed is used once, to
+    hand rank 0's RCCL unique id to the other ranks."""
+
+    def __init__(self, lib, rank=None, nranks=None, group=None, loopback=False, timing=False):
+        import torch.distributed as dist
+        self.lib = lib
+        have_group = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank(group) if have_group else 0)
+        self.nranks = nranks if nranks is not None else (dist.get_world_size(group) if have_group else 1)
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            lib.rccl_unique_id(uid)
+        if self.nranks > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(box[0])
+        self.comm = _capi.Comm()
+        flags = (_capi.RCCL_LOOPBACK if loopback else 0) | (_capi.RCCL_TIMING if timing else 0)
+        lib.rccl_comm_create(uid, self.rank, self.nranks, flags, C.byref(self.comm))
+
+    def stats(self, reset=False):
+        st = _capi.RcclStats()
+        self.lib.rccl_comm_stats(C.byref(self.comm), C.byref(st), 1 if reset else 0)
+        return {k: getattr(st, k) for k, _ in _capi.RcclStats._fields_}
+
+    @property
+    def n_exchanges(self):
+        return self.stats()["n_exchanges"]
+
+    def close(self):
+        if self.comm.ctx:
+            self.lib.rccl_comm_destroy(C.byref(self.comm))
