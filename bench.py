@@ -60,55 +60,122 @@ def device_uniform_plasma(n_cell, prob_lo, prob_hi, ppc, density, u_th, seed, bo
     return out
 
 
+def kernel_sources_sha():
+    """Fingerprint of the kernel sources the PMC traffic numbers were collected on (warpx_amd/csrc/*.hip, *.hpp)."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "warpx_amd", "csrc")
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_TRAFFIC_FILE = os.path.join("profiles", "round2", "r2_pmc_traffic.json")
+
+
 def pmc_traffic(args):
-    """HBM bytes per launch of each phase's kernel from the committed rocprofv3 PMC passes
-    (profiles/round1/r1c_pmc_traffic.json), for the workload they were collected on; {} otherwise.
-    bench.py cannot collect PMC counters itself: they need their own rocprofv3 runs."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "r1c_pmc_traffic.json")
+    """HBM bytes per launch of each phase's kernel from the committed rocprofv3 PMC passes (scripts/pmc_traffic.py ->
+    profiles/round2/r2_pmc_traffic.json; bench.py cannot collect PMC counters itself: they need their own rocprofv3
+    runs).  Used only when the file was collected on this workload AND on these kernel sources (its `sources_sha16`
+    stamp equals kernel_sources_sha()): stale counters are dropped, not shown."""
     try:
-        rec = json.load(open(path))
+        rec = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
     except (OSError, ValueError):
-        return {}
+        return {}, "no committed PMC pass"
     w = rec["workload"]
     same = (w["ncell"] == args.ncell and w["ppc"] == args.ppc and w["order"] == args.order and
-            w["deposition"] == args.deposition and w["pusher"] == args.pusher and w["filter"] == (not args.no_filter))
+            w["deposition"] == args.deposition and w["pusher"] == args.pusher and w["filter"] == (not args.no_filter)
+            and w.get("sort_interval") == args.sort_interval)
     if not same:
-        return {}
-    return {k: (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1e9 for k, v in rec["KiB_per_dispatch"].items()}
+        return {}, "the committed PMC pass is of another workload"
+    if rec.get("sources_sha16") != kernel_sources_sha():
+        return {}, (f"the committed PMC pass ({PMC_TRAFFIC_FILE}) was taken on other kernel sources "
+                    f"({rec.get('sources_sha16')} vs {kernel_sources_sha()}): dropped")
+    return ({k: (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1e9 for k, v in rec["KiB_per_dispatch"].items()},
+            f"rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE per dispatch, {PMC_TRAFFIC_FILE} (same kernel sources)")
+
+
+def energies(sim, sid):
+    """(field energy, kinetic energy) in joules: fields through the host reduction of warpx_amd.sim, particles on the
+    device."""
+    import torch
+    from warpx_amd import plasma
+    from warpx_amd.distributed import _as_tensor
+    from warpx_amd.sim import field_energy
+    ee, eb = field_energy(sim)
+    v = sim.particle_view(sid)
+    n = int(v.np)
+    arr = {k: _as_tensor(int(getattr(v, k)), 8 * n, True).view(torch.float64) for k in ("w", "ux", "uy", "uz")}
+    u2 = arr["ux"] ** 2 + arr["uy"] ** 2 + arr["uz"] ** 2
+    gamma = torch.sqrt(1.0 + u2 / plasma.C_LIGHT ** 2)
+    ekin = float(torch.sum(arr["w"] * plasma.M_E * u2 / (1.0 + gamma)))
+    return ee + eb, ekin, n
 
 
 def cpu_baseline():
-    """The CPU oracle (our restatement of the reference's algorithms; the reference itself
-    cannot be built here: AMReX is not on disk) timed on a bounded sample of the same
-    workload: 128^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on, OpenMP over all host cores
-    (thread-private J scratch + accumulate, as the reference's CPU path)."""
+    """The CPU oracle (our restatement of the reference's algorithms; the reference itself cannot be built here: AMReX
+    is not on disk) timed on bounded samples, SURVEY.md 8(d) protocol -- median of 5 runs, thread count stated:
+      * all host cores (OpenMP; thread-private J scratch + accumulate, as the reference's CPU path) on a 128^3 sample of
+        the bench workload (8 ppc, order 3, Esirkepov, Boris, filter on), with the oracle's per-phase timers;
+      * one thread ("CPU serial") on BASELINE.json config 1 itself: 64^3, 1 ppc, order 1 (Examples/Tests/uniform_plasma)."""
+    import statistics
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
     from tests.oracle_lib import load_oracle
     from warpx_amd import _capi, plasma
     from warpx_amd.sim import WarpXSim
     orc = load_oracle()
-    n = 128
-    n_cell = (n, n, n)
     L = 40e-6
-    parts = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (2, 2, 2), 1e25, 0.01, seed=12345)
-    sim = WarpXSim(orc, n_cell, (-L / 2,) * 3, (L / 2,) * 3, nox=3, galerkin=1,
-                   particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
-                   use_filter=1)
-    sim.add_species(-plasma.Q_E, plasma.M_E, parts)
-    npart = len(parts[0])
-    del parts
-    sim.evolve(1)
-    steps = 4
+
+    def sample(n, ppc, order, steps, runs, threads):
+        orc._set_num_threads(threads)
+        n_cell = (n, n, n)
+        parts = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, ppc, 1e25, 0.01, seed=12345)
+        sim = WarpXSim(orc, n_cell, (-L / 2,) * 3, (L / 2,) * 3, nox=order, galerkin=1,
+                       particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV, use_filter=1)
+        sim.add_species(-plasma.Q_E, plasma.M_E, parts)
+        npart = len(parts[0])
+        del parts
+        sim.evolve(1)
+        rates, phases = [], None
+        try:
+            sim.enable_timers(True)
+            sim.timers(reset=True)
+        except Exception:
+            pass
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            sim.evolve(steps)
+            rates.append(npart * steps / (time.perf_counter() - t0))
+        try:
+            ph = sim.timers(reset=True)
+            phases = {k: v[0] / (runs * steps) for k, v in ph.items() if v[1] > 0}
+        except Exception:
+            phases = None
+        sim.close()
+        return statistics.median(rates), min(rates), max(rates), npart, phases
+
+    all_threads = int(orc._set_num_threads(0))
     t0 = time.perf_counter()
-    sim.evolve(steps)
-    dt = time.perf_counter() - t0
-    sim.close()
-    return {"value": npart * steps / dt, "unit": "particle-steps/s", "cores": int(orc._num_threads()),
-            "kind": "port",
-            "sample": f"{n}^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on, {steps} steps "
-                      f"({npart} particles); {dt:.1f} s wall on the host cores; cell-updates/s = "
-                      f"{n ** 3 * steps / dt:.3e}"}
+    med, lo, hi, npart, phases = sample(128, (2, 2, 2), 3, 2, 5, all_threads)
+    t_all = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    smed, slo, shi, snp, _ = sample(64, (1, 1, 1), 1, 2, 5, 1)
+    t_ser = time.perf_counter() - t0
+    orc._set_num_threads(all_threads)
+    out = {"value": med, "unit": "particle-steps/s", "cores": all_threads, "kind": "port",
+           "sample": f"128^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on ({npart} particles): median of 5 runs of "
+                     f"2 steps (min {lo:.3e}, max {hi:.3e}); {t_all:.1f} s wall incl. set-up; cell-updates/s = "
+                     f"{med / 8.0:.3e}",
+           "serial": {"value": smed, "unit": "particle-steps/s", "cores": 1,
+                      "sample": f"BASELINE.json config 1: 64^3 cells, 1 ppc, order 1, Esirkepov, Boris, filter on ({snp} "
+                                f"particles): median of 5 runs of 2 steps (min {slo:.3e}, max {shi:.3e}); {t_ser:.1f} s "
+                                f"wall incl. set-up; cell-updates/s = {smed:.3e}"}}
+    if phases:
+        out["ms_per_step_by_phase"] = phases
+    return out
 
 
 def stencil_microbench(sim, reps=20):
@@ -163,6 +230,7 @@ def main():
                          "csrc/rccl_comm.hip); torch = torch.distributed P2P through Python callbacks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-pass", action="store_true")
+    ap.add_argument("--no-sanity", action="store_true", help="skip the energy / particle-count figures around the timed steps")
     args = ap.parse_args()
 
     import torch
@@ -228,6 +296,7 @@ def main():
     if args.preroll > 0:
         sim.evolve(args.preroll)
     sim.evolve(args.warmup)
+    e_before = energies(sim, 0) if not args.no_sanity else None
     barrier()
     t0 = time.perf_counter()
     sim.evolve(args.steps)
@@ -239,6 +308,19 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    sanity = None
+    if e_before is not None:
+        e_after = energies(sim, 0)
+        counts = [float(e_after[2])]
+        if world > 1:
+            t = torch.tensor(counts, dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t)
+            counts = [float(t.item())]
+        tot0, tot1 = e_before[0] + e_before[1], e_after[0] + e_after[1]
+        sanity = {"particles_after": int(counts[0]), "particles_expected": int(np_local * world),
+                  "total_energy_drift_over_timed_steps": (tot1 - tot0) / tot0,
+                  "kinetic_energy_J_rank0": e_after[1], "field_energy_J_rank0": e_after[0],
+                  "note": "rank 0's share of the energy before / after the timed steps; the count is global"}
     # second, short pass with per-phase HIP-event timers (on the stream the kernels run on)
     phases = {}
     if not args.no_phase_pass:
@@ -270,7 +352,7 @@ def main():
         cps = total_cells * args.steps / elapsed
         kernels = {}
         dominant = None
-        traffic = pmc_traffic(args) if world == 1 else {}
+        traffic, traffic_note = pmc_traffic(args) if world == 1 else ({}, "N > 1")
         micro = {} if args.no_phase_pass else stencil_microbench(sim)
         for name, (ms, cnt) in phases.items():
             if cnt == 0 or ms <= 0:
@@ -303,8 +385,7 @@ def main():
             k = kernels[dominant]
             roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": k["hbm_frac"], "traffic": k.get("pmc_traffic_GB"),
-                        "traffic_unit": "GB per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, "
-                                        "profiles/round1/r1c_pmc_traffic.json)",
+                        "traffic_unit": "GB per launch; " + traffic_note,
                         "note": "particle kernels are VALU/LDS-atomic bound, not HBM bound (SURVEY.md 8(d)); "
                                 "the HBM-bound stencils are listed under kernels"}
         out = {
@@ -324,6 +405,8 @@ def main():
         }
         if comm_stats:
             out["exchange"] = comm_stats
+        if sanity:
+            out["sanity"] = sanity
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

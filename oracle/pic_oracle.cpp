@@ -88,6 +88,13 @@ extern "C" {
 
 const char* orc_version(void) { return "warpx_amd oracle (CPU restatement), fp64"; }
 int orc_num_threads(void) { return max_threads(); }
+// number of OpenMP threads of the following calls (bench.py's serial CPU figure: BASELINE.json config 1 is "CPU serial")
+int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#endif
+    return max_threads();
+}
 
 // Source/FieldSolver/FiniteDifferenceSolver/EvolveB.cpp:122-215 with
 // CartesianYeeAlgorithm::UpwardD{x,y,z} (CartesianYeeAlgorithm.H:69-101,125-167,191-225)
@@ -1006,7 +1013,14 @@ int orc_apply_particle_boundaries(const wxa_particle_view* p, const double prob_
     double* u[3] = {p->ux, p->uy, p->uz};
     int64_t lost_total = 0;
     for (int64_t ip = 0; ip < p->np; ++ip) {
-        if (p->idcpu[ip] == WXA_IDCPU_RETIRED) continue;   // :1617-1618 skip particles already flagged
+        if (p->idcpu[ip] == WXA_IDCPU_RETIRED) {   // :1617-1618 skip particles already flagged; this library keeps
+            // them in the tile until the next sort (still pushed, weight 0): parked inside the domain, momentum 0
+            for (int d = 0; d < 3; ++d) {
+                pos[d][ip] = std::min(std::max(pos[d][ip], prob_lo[d]), std::nextafter(prob_hi[d], prob_lo[d]));
+                u[d][ip] = 0.0;
+            }
+            continue;
+        }
         bool lost = false, flip[3] = {false, false, false};
         for (int d = 0; d < 3; ++d) {
             double& x = pos[d][ip];

@@ -247,6 +247,7 @@ _ORACLE_SIGS = {
     "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
 
     "num_threads": (C.c_int, []),
+    "set_num_threads": (C.c_int, [C.c_int]),
     "add_plasma": (C.c_int, [_PPV, C.POINTER(PlasmaInjector), _D3, _I32_3, _D3, _D3, _D3,
                              C.POINTER(InjectedMomentum), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     # CPU counterparts of the Redistribute entry points (host-layer tests, parity tests)
@@ -263,7 +264,7 @@ class WxaError(RuntimeError):
 
 
 # int-returning entry points whose result is a value, not a status
-_RETURNS_A_VALUE = {"sim_max_step", "sim_num_species", "num_threads", "sim_halo_overlap"}
+_RETURNS_A_VALUE = {"sim_max_step", "sim_num_species", "num_threads", "set_num_threads", "sim_halo_overlap"}
 
 
 class CLib:

@@ -333,6 +333,11 @@ public:
         m_overlap = false;
         bool any_split = false;
         for (int d = 0; d < 3; ++d) any_split = any_split || !m_comm->self_periodic(d);
+        // PushInterior relies on the particles of the interior tiles of the last sort reading no guard point while the
+        // fill is in flight: true while the drift since that sort stays below a tile minus the stencil reach, i.e. for
+        // short sort intervals only (a particle moves < 1 cell per step)
+        if (want && !(m_cfg.sort_interval > 0 && m_cfg.sort_interval <= 4))
+            throw std::runtime_error("overlap_halo needs 0 < warpx.sort_intervals <= 4 (interior tiles must stay clear of the guards)");
         if (!want || !m_grown_b || !any_split || !m_be->stream_create) return;
         m_comm_stream = m_be->stream_create();
         if (!m_comm_stream) return;

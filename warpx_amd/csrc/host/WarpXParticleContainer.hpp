@@ -232,6 +232,10 @@ public:
                                                    m_ctx->particle_bc_hi, &lost, m_ws, m_ctx->stream),
               "apply_particle_boundaries");
         m_nretired += lost;
+        // without a periodic sort (warpx.sort_intervals <= 0) nothing else would ever drop the retired particles:
+        // compact once they make up a quarter of the tile
+        if (!m_ctx->sort_intervals_on && m_nretired > 1024 && 4 * m_nretired > m_tile.numParticles())
+            SortParticlesByBin(amrex::IntVect(1));
     }
 
     // amrex ParticleContainer::Redistribute restricted to what the periodic brick decomposition

@@ -354,8 +354,22 @@ __global__ void __launch_bounds__(256)
 particle_walls_kernel(PV p, WallGeom wg, unsigned* __restrict__ n_lost) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= p.np) return;
-    if (p.id[ip] == WXA_IDCPU_RETIRED) return;
     double x[3] = {p.x[ip], p.y[ip], p.z[ip]};
+    if (p.id[ip] == WXA_IDCPU_RETIRED) {
+        // A retired particle stays in the tile until the next sort and is still pushed (weight 0: it deposits
+        // nothing): park it inside the domain again and take its momentum away, every step, so that it can never
+        // drift out of the range the field arrays cover -- however long the sort is away
+        bool out = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double c = fmin(fmax(x[d], wg.lo[d]), nextafter(wg.hi[d], wg.lo[d]));
+            out = out || c != x[d];
+            x[d] = c;
+        }
+        if (out) { p.x[ip] = x[0]; p.y[ip] = x[1]; p.z[ip] = x[2]; }
+        p.ux[ip] = 0.0; p.uy[ip] = 0.0; p.uz[ip] = 0.0;
+        return;
+    }
     bool lost = false, flip[3] = {false, false, false}, moved = false;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
