@@ -501,9 +501,9 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 // a cell goes to the deferred list | D deferred particles through the wide single body, one lane per (component,
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
-template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0>
+template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0>
 struct RowsCfg {
-    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_;
+    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_, PF = PF_;   // PF: L2 prefetch
 };
 
 struct NullSink {   // DBG = 1: keeps every deposited value alive without touching the LDS
@@ -555,16 +555,15 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         if (n < DEFER) deferred[n] = (unsigned)ip;
         else sq.push(ip);
     };
-    // Pulls the particles [p0, p1) of all seven arrays towards the L2: one 4-byte load per 128-byte line straight into an
-    // LDS scratch word (no register, nothing waits for it); lanes 8 a .. 8 a + 7 take the first 8 lines of array a, i.e.
-    // 128 particles -- a block of 16 cells at 8 per cell.  The deposition streams 56 B per particle from HBM
-    // (7.5 GB at 256^3 x 8 = ~1.5 ms at the achievable bandwidth); without the prefetch every chunk starts with
-    // that latency exposed: measured 3 of the kernel's 5 ms in the chunk loop with the arithmetic AND the atomics off.
+    // Optional (CFG::PF, off in production): pull the particles [p0, p1) of all seven arrays towards the L2 a chunk ahead
+    // -- one 4-byte load per 128-byte line straight into an LDS scratch word; lanes 8 a .. 8 a + 7 take the first 8
+    // lines of array a.  Measured at 256^3 x 8: 7.13 ms with, 6.76 ms without, and FETCH_SIZE + 29 % with it: the lines
+    // do not survive in the L2 until their chunk runs, so they are fetched twice.
     const double* const parr[7] = {px, py, pz, pw, pux, puy, puz};
     auto prefetch = [&](const int p0, const int p1) {
         const int arr = lane >> 3, seg = lane & 7;
         const int q0 = (p0 & ~15) + 16 * seg;
-        if (arr < 7 && q0 < p1)
+        if (CFG::PF && arr < 7 && q0 < p1)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(parr[arr] + q0),
                                              (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
     };
@@ -839,7 +838,8 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
 // -> the staged kernel of round 1.  WXA_DEPOSIT_VARIANT=<n> selects an alternative per launch (order-3 Esirkepov only)
 // for A/B timing and for the parity tests of every configuration (scripts/deposit_variants.py):
 //   0 staged / bucketed kernel of round 1 | 14 production | 15 half tiles, 2 x 6 waves | 16 half tiles, 2 x 8 waves,
-//   128 VGPRs | 17 whole tiles, 16 waves, 128 VGPRs | 101 / 102 timing experiments (arithmetic only / atomics only: wrong J)
+//   128 VGPRs | 17 whole tiles, 16 waves, 128 VGPRs | 18 production + L2 prefetch of the next chunk | 101 / 102 timing
+//   experiments (arithmetic only / atomics only: wrong J)
 using CfgStaged = TileCfg<512, 8, true, 2, 0>;
 using RowsWhole3 = RowsCfg<768, 8, 3, 1>;
 using RowsHalf3 = RowsCfg<384, 4, 3, 1>;
@@ -847,6 +847,7 @@ using RowsHalf4 = RowsCfg<512, 4, 4, 2>;
 using RowsWhole4 = RowsCfg<1024, 8, 4, 2>;
 using RowsWhole3NoLds = RowsCfg<768, 8, 3, 1, 1>;
 using RowsWhole3NoAlu = RowsCfg<768, 8, 3, 1, 2>;
+using RowsWhole3Pf = RowsCfg<768, 8, 3, 1, 0, 1>;
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
     const char* e = getenv("WXA_DEPOSIT_VARIANT");
@@ -864,6 +865,7 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
             case 15: return launch_rows<3, RowsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
             case 16: return launch_rows<3, RowsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
             case 17: return launch_rows<3, RowsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
+            case 18: return launch_rows<3, RowsWhole3Pf>(p, J, geom, q, dt, relative_time, ws, st);
             case 101: return launch_rows<3, RowsWhole3NoLds>(p, J, geom, q, dt, relative_time, ws, st);
             case 102: return launch_rows<3, RowsWhole3NoAlu>(p, J, geom, q, dt, relative_time, ws, st);
             default: return launch_rows<3, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
