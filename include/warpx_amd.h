@@ -221,6 +221,12 @@ wxa_status wxa_deposit_charge(const wxa_particle_view* p,
 wxa_status wxa_enforce_periodic(const wxa_particle_view* p,
                                 const double plo[3], const double phi[3],
                                 const int periodic[3], void* stream);
+/* The same wrap, restricted through the workspace's last cell sort to the tiles that touch a periodic face of the sorted
+ * box (+ the particles appended since): valid while `steps_since_sort` pushes (< 1 cell each) cannot have carried a
+ * particle of an interior tile out of the domain; otherwise, or without a usable sort, the plain pass. */
+wxa_status wxa_enforce_periodic_sorted(const wxa_particle_view* p, const double plo[3], const double phi[3],
+                                       const int periodic[3], wxa_workspace* ws, int32_t steps_since_sort,
+                                       void* stream);
 
 /* Replaces MultiParticleContainer::SortParticlesByBin (bin = 1 cell,
  * Source/Particles/MultiParticleContainer.cpp:615-621 -> amrex SortParticlesByBin):

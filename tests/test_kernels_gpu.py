@@ -226,6 +226,40 @@ def test_enforce_periodic_and_sort(oracle, product):
     product.workspace_destroy(ws)
 
 
+@pytest.mark.parametrize("steps", [0, 3, 6, 7])
+def test_enforce_periodic_through_the_sort(product, steps):
+    """wxa_enforce_periodic_sorted (face tiles of the last sort + appended tail) against the plain pass, bit for bit:
+    particles displaced by up to `steps` cells since the sort, an unsorted tail behind them."""
+    import torch
+    ncell = (24, 20, 16)
+    dx = H.LX / np.asarray(ncell)
+    parts = H.random_particles(50000, ncell, 77, u_scale=0.1)
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    big = ParticleArrays(pd0.np + 5000, DEV)       # room for a tail behind the sorted part
+    srt_view = big.view
+    srt_view.np = pd0.np
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt_view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    rng = np.random.default_rng(8)
+    for d in range(3):
+        big.data[d][:pd0.np] += torch.from_numpy(dx[d] * max(steps, 0.5) * (2 * rng.random(pd0.np) - 1)).to(DEV)
+        big.data[d][pd0.np:] = torch.from_numpy(H.LX * (1.5 * rng.random(5000) - 0.75)).to(DEV)   # tail: anywhere within one period
+    ref = ParticleArrays(big.np, DEV)
+    ref.data.copy_(big.data)
+    per = (C.c_int * 3)(1, 1, 0)
+    lo, hi = H.d3((-H.LX / 2,) * 3), H.d3((H.LX / 2,) * 3)
+    product.enforce_periodic(C.byref(ref.view), lo, hi, per, None)
+    product.enforce_periodic_sorted(C.byref(big.view), lo, hi, per, ws, steps, None)
+    _sync(product)
+    assert torch.equal(big.data, ref.data)
+    a = ref.to_numpy()
+    assert np.all(a[0] >= -H.LX / 2) and np.all(a[0] < H.LX / 2) and np.all(a[1] >= -H.LX / 2) and np.all(a[1] < H.LX / 2)
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
 @pytest.mark.parametrize("stale", [False, True])

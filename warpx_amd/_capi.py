@@ -227,6 +227,7 @@ _PRODUCT_SIGS = {
     "copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "device_synchronize": (C.c_int, []),
+    "enforce_periodic_sorted": (C.c_int, [_PPV, _D3, _D3, _I3, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 # the library's own transport (rccl_comm.hip): product only

@@ -212,6 +212,7 @@ public:
                                                 m_ws, m_ctx->stream),
               "sort_particles_by_cell");
         m_tile.swap(m_spare);
+        m_steps_since_sort = 0;
         if (m_nretired > 0) {
             int64_t live = np;
             check(m_ctx->be->sort_live_count(m_ws, &live, m_ctx->stream), "sort_live_count");
@@ -257,9 +258,15 @@ public:
         if (!any_split) {
             if (np0 > 0) {
                 const wxa_particle_view p = m_tile.view();
-                check(be->enforce_periodic(&p, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic, m_ctx->stream),
-                      "enforce_periodic");
+                if (be->enforce_periodic_sorted && m_steps_since_sort >= 0)
+                    check(be->enforce_periodic_sorted(&p, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic, m_ws,
+                                                      m_steps_since_sort, m_ctx->stream),
+                          "enforce_periodic_sorted");
+                else
+                    check(be->enforce_periodic(&p, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic, m_ctx->stream),
+                          "enforce_periodic");
             }
+            if (m_steps_since_sort >= 0) ++m_steps_since_sort;
             return;
         }
         // one scan of the whole tile: wrap + six leaver lists (by first split direction)
@@ -373,6 +380,7 @@ protected:
     ParticleTile m_tile, m_spare;
     DeviceBuffer m_sendbuf, m_recvbuf, m_lists, m_arrival_lists[3];
     int64_t m_nretired = 0;            // retired by Redistribute since the last sort (still in the tile)
+    int32_t m_steps_since_sort = -1;   // Redistribute calls since the last cell sort (-1: never sorted)
     void* m_ws = nullptr;
     bool m_do_crr = false;
 

@@ -69,6 +69,9 @@ struct Backend {
     int (*unpack_box)(const wxa_field_view*, const int32_t*, const int32_t*, const double*, int, void*);
     int (*field_set_zero)(const wxa_field_view*, void*);
     int (*enforce_periodic)(const wxa_particle_view*, const double*, const double*, const int*, void*);
+    // optional: the wrap restricted to the face tiles of the last sort (ws, steps since that sort)
+    int (*enforce_periodic_sorted)(const wxa_particle_view*, const double*, const double*, const int*, void* ws, int32_t,
+                                   void*) = nullptr;
     int (*sort_particles_by_cell)(const wxa_particle_view*, const wxa_particle_view*, const double*,
                                   const double*, const int32_t*, const int32_t*, void* ws, void*);
     // Stable 3-way partition of a tile along `dim` for Redistribute: dst = [stay | to-minus | to-plus]

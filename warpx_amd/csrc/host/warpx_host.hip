@@ -108,6 +108,9 @@ const Backend* hip_backend() {
         b.field_set_zero = [](const wxa_field_view* f, void* st) -> int { return wxa_field_set_zero(f, st); };
         b.enforce_periodic = [](const wxa_particle_view* p, const double* lo, const double* hi, const int* per,
                                 void* st) -> int { return wxa_enforce_periodic(p, lo, hi, per, st); };
+        b.enforce_periodic_sorted = [](const wxa_particle_view* p, const double* lo, const double* hi, const int* per,
+                                       void* ws, int32_t steps, void* st) -> int {
+            return wxa_enforce_periodic_sorted(p, lo, hi, per, static_cast<wxa_workspace*>(ws), steps, st); };
         b.sort_particles_by_cell = k_sort;
         b.partition_particles = k_partition;
         b.wrap_and_classify = [](const wxa_particle_view* p, int64_t first, int64_t count, const double* plo,
