@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
                     help="N > 1: rccl = the library's own transport (ncclSend / ncclRecv groups on the library's streams, "
                          "csrc/rccl_comm.hip); torch = torch.distributed P2P through Python callbacks")
+    ap.add_argument("--deposit-acc", choices=["f64", "f32"], default="f64",
+                    help="accumulators of the LDS deposition tiles: f64 = ds_add_f64 (the parity build, the headline line); "
+                         "f32 = ds_add_f32, the throughput variant of BASELINE.json's north_star (2e-6 gate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-pass", action="store_true")
     ap.add_argument("--no-sanity", action="store_true", help="skip the energy / particle-count figures around the timed steps")
@@ -282,7 +285,9 @@ def main():
     from warpx_amd.containers import ParticleArrays
     pa = ParticleArrays(parts.shape[1], device)
     pa.data = parts
-    sim.add_species(-plasma.Q_E, plasma.M_E, pa)
+    sid0 = sim.add_species(-plasma.Q_E, plasma.M_E, pa)
+    if args.deposit_acc == "f32":
+        sim.set_deposit_accumulator(sid0, _capi.ACC_FP32)
     np_local = parts.shape[1]
     del parts, pa
     torch.cuda.empty_cache()
@@ -393,7 +398,8 @@ def main():
             "cell_updates_per_s": cps,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if args.deposit_acc == "f64" else "f64 (fp32 deposition tiles)",
+            "data": "synthetic",
             "config": {"workload": f"3D uniform_plasma {n_cell[0]}x{n_cell[1]}x{n_cell[2]}, "
                                    f"{args.ppc ** 3} ppc, Yee FDTD, order-{args.order} shape, {args.deposition}, "
                                    f"{args.pusher}, filter {'off' if args.no_filter else 'on'}",

@@ -93,6 +93,15 @@ void       wxa_workspace_destroy(wxa_workspace* ws);
  * Source/Particles/PhysicalParticleContainer.cpp:2589-2596,2705-2710): added to the gathered fields by
  * wxa_gather_push_ws / wxa_gather_push_part when they are handed this workspace.  Zero by default. */
 wxa_status wxa_workspace_set_external_particle_fields(wxa_workspace* ws, const double E[3], const double B[3]);
+/* Accumulator of the LDS-tile Esirkepov deposition for the container that owns this workspace.  WXA_ACC_FP64 (default):
+ * ds_add_f64 tiles, the double/double build of the reference (1e-10 parity gate).  WXA_ACC_FP32: ds_add_f32 tiles --
+ * every deposit is still evaluated in fp64 and rounded once when it enters the tile; the tile's sums then carry fp32
+ * round-off, J stays an fp64 array.  Counterpart of the reference's WarpX_PRECISION=SINGLE switch (CMakeLists.txt:109-118)
+ * restricted to where BASELINE.json's north_star asks for it; gate: the reference's single-precision tolerance 2e-6
+ * (Examples/analysis_default_regression.py:18). */
+#define WXA_ACC_FP64 0
+#define WXA_ACC_FP32 1
+wxa_status wxa_workspace_set_deposit_accumulator(wxa_workspace* ws, int32_t accumulator);
 
 const char* wxa_version(void);
 const char* wxa_last_error(void);
@@ -566,6 +575,9 @@ wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
 /* particles.E_external_particle / particles.B_external_particle (constant external fields on the particles of
  * species `id`; the reference keeps them per container and reads them from the `particles.` block) */
 wxa_status wxa_sim_set_external_particle_fields(wxa_sim* s, int32_t id, const double E[3], const double B[3]);
+/* WXA_ACC_FP64 (default) / WXA_ACC_FP32 tiles for the Esirkepov deposition of species `id`
+ * (wxa_workspace_set_deposit_accumulator) */
+wxa_status wxa_sim_set_deposit_accumulator(wxa_sim* s, int32_t id, int32_t accumulator);
 /* <species>.do_classical_radiation_reaction (PhysicalParticleContainer.cpp:330-340; PushSelector.H:60-87: the species is
  * pushed by UpdateMomentumBorisWithRadiationReaction whatever algo.particle_pusher says) */
 wxa_status wxa_sim_set_radiation_reaction(wxa_sim* s, int32_t id, int32_t on);

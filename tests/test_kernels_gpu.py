@@ -363,6 +363,43 @@ def test_deposit_tile_variants(oracle, product, deposit_variant, stale, u_scale)
         test_esirkepov_zero_displacement_deposits_exactly_zero(product, 3, 1, u_scale)
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("u_scale", [1.0, 0.01])
+def test_deposit_current_fp32_tiles(oracle, product, order, u_scale):
+    """The ds_add_f32 variant of the LDS-tile Esirkepov deposition (wxa_workspace_set_deposit_accumulator, WXA_ACC_FP32)
+    against the fp64 oracle at the reference's single-precision tolerance, 2e-6 of max|J|
+    (Examples/analysis_default_regression.py:18), and charge conservation at the same level: the values are computed in
+    fp64 and rounded once on entering the tile, so only the tile's sums carry fp32 round-off."""
+    ncell = (24, 20, 16)
+    _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    parts = H.random_particles(60000, ncell, 300 + order, u_scale=u_scale)
+    dx = H.LX / np.asarray(ncell)
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    product.workspace_set_deposit_accumulator(ws, _capi.ACC_FP32)
+    srt = ParticleArrays(pd0.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    ph = ParticleArrays.from_numpy(list(srt.to_numpy()), "cpu")
+    J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    Jd = H.clone_fields(J, DEV, True)
+    g, _ = H.geom_for(ncell, ng_depos)
+    dt = H.yee_dt(dx)
+    q = -plasma.Q_E
+    oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order,
+                           _capi.DEPOSIT_ESIRKEPOV, None, None)
+    product.deposit_current(C.byref(srt.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order,
+                            _capi.DEPOSIT_ESIRKEPOV, ws, None)
+    _sync(product)
+    errs = [H.max_rel_err(a.to_numpy(), b.to_numpy()) for a, b in zip(Jd, J)]
+    print("fp32 tiles: max |dJ| / max|J| per component", errs)
+    assert max(errs) < 2e-6
+    assert max(errs) > 1e-12   # really the fp32 path
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.parametrize("order,galerkin", [(1, 1), (2, 1), (3, 1), (3, 0)])
 @pytest.mark.parametrize("stale", [False, True])
 def test_gather_push_lds_tiles(oracle, product, order, galerkin, stale):

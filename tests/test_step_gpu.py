@@ -102,6 +102,23 @@ def test_uniform_plasma_parity_in_the_benchmark_regime(oracle, product):
         assert err <= 1e-9, name
 
 
+def test_uniform_plasma_fp32_deposition_tiles(oracle, product):
+    """A thermal plasma stepped with the ds_add_f32 deposition tiles against the fp64 oracle stepper: energies and
+    particle moments at the reference's single-precision regression tolerance, 2e-6
+    (Examples/analysis_default_regression.py:18)."""
+    n_cell = (32, 32, 32)
+    L = 40e-6
+    parts = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (2, 2, 2), 1e25, 0.01, seed=4321)
+    kw = dict(nox=3, galerkin=1, particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
+              use_filter=1, sort_interval=3)
+    sg = WarpXSim(product, n_cell, (-L / 2,) * 3, (L / 2,) * 3, **kw)
+    ig = [sg.add_species(-plasma.Q_E, plasma.M_E, parts)]
+    sg.set_deposit_accumulator(ig[0], _capi.ACC_FP32)
+    sg.evolve(12)
+    so, io = _run(oracle, n_cell, [(-plasma.Q_E, plasma.M_E, parts)], 12, **kw)
+    _compare(_metrics(sg, ig), _metrics(so, io), rtol=2e-6)
+
+
 def test_langmuir_golden_on_gpu(oracle, product):
     """The reference's own golden checksums (64^3 Langmuir, 40 steps) reproduced by the HIP path."""
     import ctypes as C

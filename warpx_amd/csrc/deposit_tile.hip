@@ -48,14 +48,19 @@ struct TileDims {
     static constexpr int NPTS = NZ * PS;         // doubles per component (incl. padding)
 };
 
-template <int M, int TSZ>
+// ACC = double: ds_add_f64, the parity build (1e-10 gate).  ACC = float: ds_add_f32 -- the throughput variant
+// BASELINE.json's north_star sketches; every value is still computed in fp64 and rounded once when it enters the tile,
+// the tile's sums carry fp32 round-off (the reference's own single-precision tolerance is 2e-6,
+// Examples/analysis_default_regression.py:18).
+template <int M, int TSZ, class ACC = double>
 struct LdsSink {
     using TD = TileDims<M, TSZ>;
-    double* base;   // LDS address of slot 0 of component 0: every deposit is base + a compile-time offset
-    __device__ __forceinline__ LdsSink(double* lds, int oi, int oj, int ok)
+    ACC* base;   // LDS address of slot 0 of component 0: every deposit is base + a compile-time offset
+    __device__ __forceinline__ LdsSink(ACC* lds, int oi, int oj, int ok)
         : base(lds + oi + TD::NS * oj + TD::PS * ok) {}
     __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
-        atomic_add_f64(base + (c * TD::NPTS + i + TD::NS * j + TD::PS * k), v);
+        if constexpr (sizeof(ACC) == 8) atomic_add_f64(base + (c * TD::NPTS + i + TD::NS * j + TD::PS * k), v);
+        else unsafeAtomicAdd(base + (c * TD::NPTS + i + TD::NS * j + TD::PS * k), (float)v);
     }
     __device__ __forceinline__ void add_abs(int c, int gi, int gj, int gk, double v) { add(c, gi, gj, gk, v); }
 };
@@ -501,9 +506,14 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 // a cell goes to the deferred list | D deferred particles through the wide single body, one lane per (component,
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
-template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0>
+template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0, class ACC_ = double>
 struct RowsCfg {
     static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_, PF = PF_;   // PF: L2 prefetch
+    using ACC = ACC_;   // accumulator type of the LDS tile
+    // cells per block of the direct part = lanes that one step of the LDS atomic serves (16 for ds_add_f64, 32 for
+    // ds_add_f32): a chunk is BW consecutive cells x 64 / BW pairs, and the first four pairs of a block take
+    // 4 BW / 64 chunks.  32 consecutive cells of the sort order start on 32 different 4-byte banks (i + 16 j + 24 k).
+    static constexpr int BW = sizeof(ACC_) == 8 ? 16 : 32;
 };
 
 struct NullSink {   // DBG = 1: keeps every deposited value alive without touching the LDS
@@ -524,13 +534,15 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     constexpr int SUB = TS / TSZ;
     constexpr int CELLS = TILE_CELLS / SUB;        // cells of this unit
     constexpr int CW = CELLS / 64;                 // cell-waves (waves that hold a cell per lane in phases A and B)
-    constexpr int NB = CELLS / 16;                 // blocks of 16 cells = chunks of the direct part
+    using ACC = typename CFG::ACC;
+    constexpr int BW = CFG::BW, RPC = 64 / BW;     // cells per block, pairs (rows) of a cell per chunk
+    constexpr int NB = (CELLS / BW) * (4 / RPC);   // chunks of the direct part (the first four pairs of every cell)
     constexpr int RT = 64 / CW;                    // rows of the tail table (pairs 4 .. 3 + RT): RT CW = 64 counts = one wave scan
     constexpr int RMAX = 4 + RT;
     constexpr int TCAP = CELLS * 2;                // tail capacity (8 ppc: 0.66 tail items per cell on average)
     constexpr int DEFER = TSZ == 8 ? 2048 : 1024;
     static_assert(NT >= CELLS && RT >= 8, "one lane per cell");
-    __shared__ double lds[3 * NPTS];
+    __shared__ ACC lds[3 * NPTS];
     __shared__ unsigned long long masks[RT][CW];
     __shared__ int cstart[CELLS + 1];
     __shared__ unsigned short table[TCAP];
@@ -568,7 +580,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
                                              (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
     };
     constexpr int WAVES = NT / 64;
-    if (wave < NB) prefetch(offsets[ucell0 + 16 * wave], offsets[ucell0 + 16 * wave + 16]);   // this wave's first chunk
+    if (wave < CELLS / 16) prefetch(offsets[ucell0 + 16 * wave], offsets[ucell0 + 16 * wave + 16]);
     // ---- A: cell counts, row masks; zero fill
     if (tid == 0) { ndeferred = 0; nleft = 0; nitems = 0; }
     int my_s = 0, my_n = 0, my_pairs = 0;
@@ -585,7 +597,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             if (lane == 0) masks[r][wave] = my_mask[r];
         }
     }
-    for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = 0.0;
+    for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = (ACC)0;
     __syncthreads();
     DPROF(0);
     // ---- B: scan of the 64 (row, cell-wave) counts, item table
@@ -625,9 +637,9 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     for (int ch = wave; ch < NB + ((T + 63) >> 6); ch += WAVES) {   // wave-uniform
         int c, r;
         bool va;
-        if (ch + WAVES < NB) prefetch(cstart[16 * (ch + WAVES)], cstart[16 * (ch + WAVES) + 16]);   // its next chunk
+        if (BW == 16 && ch + WAVES < NB) prefetch(cstart[16 * (ch + WAVES)], cstart[16 * (ch + WAVES) + 16]);   // its next chunk
         if (ch < NB) {
-            c = 16 * ch + (lane & 15); r = lane >> 4; va = true;
+            c = BW * (ch / (4 / RPC)) + (lane % BW); r = RPC * (ch % (4 / RPC)) + lane / BW; va = true;
         } else {
             const int I = (ch - NB) * 64 + lane;
             va = I < T;
@@ -672,11 +684,11 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             key = kb; c1 = c2; wq1 = wqb;               // the second particle alone
         }
         if (key >= 0) {
-            LdsSink<M, TSZ> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
+            LdsSink<M, TSZ, ACC> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
             if constexpr (CFG::DBG == 1) {
                 NullSink ns;
                 esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, ns);
-                if (ns.acc == 1.2345e-300) lds[0] = ns.acc;
+                if (ns.acc == 1.2345e-300) lds[0] = (ACC)ns.acc;
             } else if constexpr (CFG::DBG == 2) {
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc)
@@ -706,7 +718,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
                     const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
                     int bi, bj, bk;
                     (void)esirkepov_frame_cross<O>(c1, g, bi, bj, bk);
-                    LdsSink<M, TSZ> sink(lds, bi - o0, bj - o1, bk - o2);
+                    LdsSink<M, TSZ, ACC> sink(lds, bi - o0, bj - o1, bk - o2);
                     esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c1, q * p1.w, 0.0, es, sink);
                 }
             } else {
@@ -716,7 +728,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
                     const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
                     const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
                     const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
-                    LdsSink<M, TSZ> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
+                    LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
                     const double wq = q * p1.w;
                     if (comp == 0) esirkepov_single_wide<O, 0>(c1, f, wq, es, sink);
                     else if (comp == 1) esirkepov_single_wide<O, 1>(c1, f, wq, es, sink);
@@ -732,7 +744,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     for (int c = 0; c < 3; ++c) {
         const DevF& J = *Jc[c];
         for (int a = tid; a < NPTS; a += NT) {
-            const double v = lds[c * NPTS + a];
+            const double v = (double)lds[c * NPTS + a];
             if (v != 0.0) {
                 const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
                 if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
@@ -848,6 +860,7 @@ using RowsWhole4 = RowsCfg<1024, 8, 4, 2>;
 using RowsWhole3NoLds = RowsCfg<768, 8, 3, 1, 1>;
 using RowsWhole3NoAlu = RowsCfg<768, 8, 3, 1, 2>;
 using RowsWhole3Pf = RowsCfg<768, 8, 3, 1, 0, 1>;
+using RowsWhole3F32 = RowsCfg<768, 8, 3, 1, 0, 0, float>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
     const char* e = getenv("WXA_DEPOSIT_VARIANT");
@@ -858,6 +871,11 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                                  double q, double dt, double relative_time, int order, int algo,
                                  wxa_workspace* ws, hipStream_t st) {
     if (algo == WXA_DEPOSIT_ESIRKEPOV) {
+        if (ws->deposit_accumulator == WXA_ACC_FP32) {
+            if (order == 1) return launch_rows<1, RowsWhole3F32>(p, J, geom, q, dt, relative_time, ws, st);
+            if (order == 2) return launch_rows<2, RowsWhole3F32>(p, J, geom, q, dt, relative_time, ws, st);
+            return launch_rows<3, RowsWhole3F32>(p, J, geom, q, dt, relative_time, ws, st);
+        }
         if (order == 1) return launch_rows<1, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
         if (order == 2) return launch_rows<2, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
         switch (deposit_variant()) {

@@ -163,6 +163,11 @@ public:
     // whatever algo.particle_pusher says (PushSelector.H:60-87)
     void SetRadiationReaction(bool on) { m_do_crr = on; }
     int pusher_algo() const { return m_do_crr ? WXA_PUSHER_BORIS_RR : (int)m_ctx->particle_pusher_algo; }
+    // fp32 / fp64 accumulators of the LDS-tile current deposition of this container (include/warpx_amd.h, WXA_ACC_*)
+    void SetDepositAccumulator(int32_t acc) {
+        if (!m_ctx->be->ws_set_deposit_accumulator) throw std::runtime_error("deposit accumulator: not in this backend");
+        check(m_ctx->be->ws_set_deposit_accumulator(m_ws, acc), "ws_set_deposit_accumulator");
+    }
     void SetExternalParticleFields(const double E[3], const double B[3]) {
         if (!m_ctx->be->ws_set_external_eb) throw std::runtime_error("external particle fields: not in this backend");
         check(m_ctx->be->ws_set_external_eb(m_ws, E, B), "ws_set_external_eb");

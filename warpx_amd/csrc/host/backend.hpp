@@ -33,6 +33,8 @@ struct Backend {
                         const double* cz, void*);
     // constant external fields of the container that owns workspace `ws` (wxa_workspace_set_external_particle_fields)
     int (*ws_set_external_eb)(void* ws, const double* E, const double* B);
+    // optional: accumulator type of the LDS-tile deposition of that container (wxa_workspace_set_deposit_accumulator)
+    int (*ws_set_deposit_accumulator)(void* ws, int32_t acc) = nullptr;
     // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace
     int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);

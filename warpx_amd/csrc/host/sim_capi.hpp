@@ -86,6 +86,17 @@ inline int sim_set_external_particle_fields(SimHandle* h, int32_t id, const doub
     }
 }
 
+inline int sim_set_deposit_accumulator(SimHandle* h, int32_t id, int32_t acc) {
+    if (!h || id < 0 || id >= h->warpx->GetPartContainer().nSpecies()) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->GetPartContainer().GetParticleContainer(id).SetDepositAccumulator(acc);
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
 inline int sim_set_radiation_reaction(SimHandle* h, int32_t id, int32_t on) {
     if (!h || id < 0 || id >= h->warpx->GetPartContainer().nSpecies()) return WXA_ERR_INVALID_ARG;
     h->warpx->GetPartContainer().GetParticleContainer(id).SetRadiationReaction(on != 0);
@@ -236,6 +247,9 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     }                                                                                                  \
     RET PFX##sim_set_external_particle_fields(SIMTYPE* s, int32_t id, const double E[3], const double B[3]) { \
         return (RET)wxa::host::sim_set_external_particle_fields(reinterpret_cast<wxa::host::SimHandle*>(s), id, E, B); \
+    }                                                                                                  \
+    RET PFX##sim_set_deposit_accumulator(SIMTYPE* s, int32_t id, int32_t acc) {                        \
+        return (RET)wxa::host::sim_set_deposit_accumulator(reinterpret_cast<wxa::host::SimHandle*>(s), id, acc); \
     }                                                                                                  \
     RET PFX##sim_set_radiation_reaction(SIMTYPE* s, int32_t id, int32_t on) {                          \
         return (RET)wxa::host::sim_set_radiation_reaction(reinterpret_cast<wxa::host::SimHandle*>(s), id, on); \

@@ -76,6 +76,8 @@ const Backend* hip_backend() {
                         const double* di, void* st) -> int { return wxa_evolve_e(E, B, J, dt, di, st); };
         b.ws_set_external_eb = [](void* ws, const double* E, const double* B) -> int {
             return wxa_workspace_set_external_particle_fields(static_cast<wxa_workspace*>(ws), E, B); };
+        b.ws_set_deposit_accumulator = [](void* ws, int32_t acc) -> int {
+            return wxa_workspace_set_deposit_accumulator(static_cast<wxa_workspace*>(ws), acc); };
         b.ckc_stencil_coefficients = wxa_ckc_stencil_coefficients;
         b.ckc_max_dt = wxa_ckc_max_dt;
         b.evolve_b_ckc = [](const wxa_field_view* E, const wxa_field_view* B, double dt, const double* cx, const double* cy,

@@ -41,6 +41,13 @@ wxa_status wxa_workspace_set_external_particle_fields(wxa_workspace* ws, const d
     return WXA_OK;
 }
 
+wxa_status wxa_workspace_set_deposit_accumulator(wxa_workspace* ws, int32_t acc) {
+    WXA_REQUIRE(ws, "null argument");
+    WXA_REQUIRE(acc == WXA_ACC_FP64 || acc == WXA_ACC_FP32, "accumulator must be WXA_ACC_FP64 or WXA_ACC_FP32");
+    ws->deposit_accumulator = acc;
+    return WXA_OK;
+}
+
 wxa_status wxa_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes) {
     WXA_REQUIRE(bytes >= 0 && (bytes == 0 || (dst_host && src_dev)), "bad copy arguments");
     if (bytes == 0) return WXA_OK;

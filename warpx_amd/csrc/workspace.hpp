@@ -43,6 +43,8 @@ struct wxa_workspace {
     // particles.E_external_particle / B_external_particle of the container that owns this workspace
     // (wxa_workspace_set_external_particle_fields); added to the gathered fields in PushPX / PushP
     double ext_eb[6] = {0, 0, 0, 0, 0, 0};
+    // accumulator type of the LDS-tile Esirkepov deposition (wxa_workspace_set_deposit_accumulator)
+    int32_t deposit_accumulator = WXA_ACC_FP64;
 };
 
 namespace wxa {

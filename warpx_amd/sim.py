@@ -119,6 +119,10 @@ class WarpXSim:
         self.lib.sim_set_external_particle_fields(self._h, int(sid), (C.c_double * 3)(*map(float, E)),
                                                   (C.c_double * 3)(*map(float, B)))
 
+    def set_deposit_accumulator(self, sid: int, acc: int):
+        """_capi.ACC_FP64 (default) / _capi.ACC_FP32: accumulator of the LDS-tile Esirkepov deposition of species `sid`."""
+        self.lib.sim_set_deposit_accumulator(self._h, int(sid), int(acc))
+
     def set_radiation_reaction(self, sid: int, on=True):
         """<species>.do_classical_radiation_reaction: Boris + radiation reaction for species `sid`."""
         self.lib.sim_set_radiation_reaction(self._h, int(sid), 1 if on else 0)
