@@ -194,6 +194,7 @@ inline unsigned atomicOr(unsigned* a, unsigned v) { unsigned o = *a; *a = o | v;
 // asynchronous global -> LDS copy, used by the product as an L2 prefetch whose LDS target is scratch
 template <class G, class L> inline void __builtin_amdgcn_global_load_lds(G, L, int, int, int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // used on wave-uniform values only
 #define WXA_OPAQUE_F64(v) asm volatile("" : "+x"(v))
 #define WXA_WAVES_PER_SIMD(n)
 

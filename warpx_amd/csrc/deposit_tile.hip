@@ -56,9 +56,22 @@ template <int M, int TSZ, class ACC = double>
 struct LdsSink {
     using TD = TileDims<M, TSZ>;
     ACC* base;   // LDS address of slot 0 of component 0: every deposit is base + a compile-time offset
+#ifdef WXA_LDS_CHECK
+    ACC* origin;
+    __device__ __forceinline__ LdsSink(ACC* lds, int oi, int oj, int ok)
+        : base(lds + oi + TD::NS * oj + TD::PS * ok), origin(lds) {}
+#else
     __device__ __forceinline__ LdsSink(ACC* lds, int oi, int oj, int ok)
         : base(lds + oi + TD::NS * oj + TD::PS * ok) {}
+#endif
     __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
+#ifdef WXA_LDS_CHECK
+        {
+            const long at = (base - origin) + (c * TD::NPTS + i + TD::NS * j + TD::PS * k);
+            if (at < 0 || at >= 3 * TD::NPTS)
+                printf("LDS deposit out of the tile: at %ld (c %d i %d j %d k %d, base %ld)\n", at, c, i, j, k, (long)(base - origin));
+        }
+#endif
         if constexpr (sizeof(ACC) == 8) atomic_add_f64(base + (c * TD::NPTS + i + TD::NS * j + TD::PS * k), v);
         else unsafeAtomicAdd(base + (c * TD::NPTS + i + TD::NS * j + TD::PS * k), (float)v);
     }
@@ -506,14 +519,14 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 // a cell goes to the deferred list | D deferred particles through the wide single body, one lane per (component,
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
-template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0, class ACC_ = double>
+template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0, class ACC_ = double, int BW_ = 0>
 struct RowsCfg {
     static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_, PF = PF_;   // PF: L2 prefetch
     using ACC = ACC_;   // accumulator type of the LDS tile
     // cells per block of the direct part = lanes that one step of the LDS atomic serves (16 for ds_add_f64, 32 for
     // ds_add_f32): a chunk is BW consecutive cells x 64 / BW pairs, and the first four pairs of a block take
     // 4 BW / 64 chunks.  32 consecutive cells of the sort order start on 32 different 4-byte banks (i + 16 j + 24 k).
-    static constexpr int BW = sizeof(ACC_) == 8 ? 16 : 32;
+    static constexpr int BW = BW_ ? BW_ : (sizeof(ACC_) == 8 ? 16 : 32);
 };
 
 struct NullSink {   // DBG = 1: keeps every deposited value alive without touching the LDS
@@ -546,9 +559,8 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     __shared__ unsigned long long masks[RT][CW];
     __shared__ int cstart[CELLS + 1];
     __shared__ unsigned short table[TCAP];
-    __shared__ unsigned deferred[DEFER];           // particles with a cell crossing (wide body)
-    __shared__ unsigned leftover[DEFER];           // fast particles without a partner on their frame
-    __shared__ int ndeferred, nleft, nitems;
+    __shared__ unsigned deferred[DEFER];           // particles with a cell crossing or without a partner (wide body)
+    __shared__ int ndeferred, nitems;
     __shared__ int pf_scratch[64];                 // landing zone of the prefetch loads
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
@@ -582,7 +594,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     constexpr int WAVES = NT / 64;
     if (wave < CELLS / 16) prefetch(offsets[ucell0 + 16 * wave], offsets[ucell0 + 16 * wave + 16]);
     // ---- A: cell counts, row masks; zero fill
-    if (tid == 0) { ndeferred = 0; nleft = 0; nitems = 0; }
+    if (tid == 0) { ndeferred = 0; nitems = 0; }
     int my_s = 0, my_n = 0, my_pairs = 0;
     unsigned long long my_mask[RT];   // wave-uniform: tail row r of this cell-wave
     if (tid < CELLS) {
@@ -705,35 +717,27 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     }
     __syncthreads();
     DPROF(2);
-    {   // ---- D: one pass of wave-sized chunks over the two lists: the singles through the fast body with an empty
-        //      partner, the crossing particles through the wide body, one lane per (component, particle)
-        const int nl = min(nleft, DEFER), nd = min(ndeferred, DEFER);
-        const int lchunks = (nl + 63) >> 6, dchunks = (3 * nd + 63) >> 6;
-        for (int ch = wave; ch < lchunks + dchunks; ch += WAVES) {
-            if (ch < lchunks) {
-                const int it = ch * 64 + lane;
-                if (it < nl) {
-                    const int ip = (int)leftover[it];
-                    const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-                    const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
-                    int bi, bj, bk;
-                    (void)esirkepov_frame_cross<O>(c1, g, bi, bj, bk);
-                    LdsSink<M, TSZ, ACC> sink(lds, bi - o0, bj - o1, bk - o2);
-                    esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c1, q * p1.w, 0.0, es, sink);
-                }
-            } else {
-                const int u = (ch - lchunks) * 64 + lane;
-                if (u < 3 * nd) {
-                    const int comp = u / nd, ip = (int)deferred[u - comp * nd];
-                    const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-                    const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
-                    const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
-                    LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
-                    const double wq = q * p1.w;
-                    if (comp == 0) esirkepov_single_wide<O, 0>(c1, f, wq, es, sink);
-                    else if (comp == 1) esirkepov_single_wide<O, 1>(c1, f, wq, es, sink);
-                    else esirkepov_single_wide<O, 2>(c1, f, wq, es, sink);
-                }
+    {   // ---- D: the deferred particles through the wide body, one lane per (component, particle).  A chunk of 64
+        //      lanes belongs to ONE component, and the component is made a scalar: with lanes of one wave in different
+        //      component branches the compiler merged the branches' last ds_add_f32 into a shared tail under a
+        //      hand-built exec mask, and the fp32 build deposited that one value (the stencil's far corner) wrongly
+        //      for some lanes -- seen as 1e-5 errors on a few points and once as a memory fault on gfx950; the fp64
+        //      build was not transformed that way.  Uniform branches leave nothing to merge across lanes.
+        const int nd = min(ndeferred, DEFER);
+        const int dch = (nd + 63) >> 6;
+        for (int ch = wave; ch < 3 * dch; ch += WAVES) {
+            const int comp = __builtin_amdgcn_readfirstlane(ch / dch);
+            const int it = (ch - comp * dch) * 64 + lane;
+            if (it < nd) {
+                const int ip = (int)deferred[it];
+                const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+                const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
+                const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
+                LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
+                const double wq = q * p1.w;
+                if (comp == 0) esirkepov_single_wide<O, 0>(c1, f, wq, es, sink);
+                else if (comp == 1) esirkepov_single_wide<O, 1>(c1, f, wq, es, sink);
+                else esirkepov_single_wide<O, 2>(c1, f, wq, es, sink);
             }
         }
     }
