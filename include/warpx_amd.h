@@ -604,6 +604,13 @@ const char* wxa_sim_species_name(const wxa_sim* s, int32_t id); /* particles.spe
  * text: "lev=0" sums of |cell-centred field| for E, B, j, rho and per species sums of |x|, |m u|, w
  * (this brick's share).  Returns the text length (buf may be NULL to ask for it) or < 0. */
 int64_t     wxa_sim_checksum_json(wxa_sim* s, char* buf, int64_t capacity);
+/* FlushFormatPlotfile::WriteToFile (Source/Diagnostics/FlushFormats/FlushFormatPlotfile.cpp:61-113) for this brick: an
+ * AMReX plotfile directory `dir` -- Header, Level_0/Cell_H + Cell_D_00000 with Ex..Bz, jx..jz, rho averaged to the cell
+ * centres, <species>/Header + Level_0/Particle_H + DATA_00000 with x y z weight momentum_x/y/z (SI), WarpXHeader,
+ * warpx_job_info -- in the text / binary layouts of AMReX as the reference restates them in
+ * Source/Diagnostics/BTD_Plotfile_Header_Impl.cpp; what Regression/Checksum/checksum.py (yt) and
+ * Tools/PostProcessing/read_raw_data.py read. */
+wxa_status  wxa_sim_write_plotfile(wxa_sim* s, const char* dir);
 /* The decks' expression evaluator (what the reference gets from amrex::Parser): value of `expr` with
  * the named variables bound to `values`; q_e, m_e, m_p, m_u, epsilon0, mu0, clight, kb, pi predefined. */
 wxa_status  wxa_parser_eval(const char* expr, int32_t nvars, const char* const* names,

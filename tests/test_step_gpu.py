@@ -412,3 +412,19 @@ def test_ckc_uniform_plasma_parity(oracle, product, order, filt):
     for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz"):
         a, b = sg.field_valid(name), so.field_valid(name)
         assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), name
+
+
+def test_plotfile_from_the_hip_path(product, tmp_path):
+    """wxa_sim_write_plotfile on the HIP path: the AMReX plotfile (FlushFormatPlotfile's output) of the Langmuir deck after
+    40 steps, parsed back from the files, carries the reference's golden checksums at the reference's tolerance."""
+    from tests.test_inputs_cpu import compare_with_golden
+    from tests.test_plotfile_cpu import checksum_of, read_plotfile
+    gold = json.load(open(os.path.join(HERE, "golden", "langmuir_multi_3d_checksums.json")))
+    sim = WarpXSim.from_inputs(product, os.path.join(HERE, "decks", "langmuir_multi_3d.inputs"))
+    sim.evolve(sim.max_step)
+    plt = str(tmp_path / "plt")
+    sim.write_plotfile(plt)
+    sim.close()
+    got = checksum_of(read_plotfile(plt))
+    gold_cs = {g: {k: v for k, v in vals.items() if k != "part_per_cell"} for g, vals in gold["checksums"].items()}
+    compare_with_golden(got, gold_cs, gold["rtol"])

@@ -1,0 +1,190 @@
+// AMReX plotfile of the state held by a simulation: what FlushFormatPlotfile::WriteToFile
+// (Source/Diagnostics/FlushFormats/FlushFormatPlotfile.cpp:61-113) produces for a single level and the default
+// fields_to_plot, so that the reference's own readers (yt via Regression/Checksum/checksum.py:78-140,
+// Tools/PostProcessing/read_raw_data.py) open this library's output:
+//   <dir>/Header                     amrex::WriteGenericPlotfileHeader, text layout as restated by
+//                                    BTDPlotfileHeaderImpl::WriteHeader (BTD_Plotfile_Header_Impl.cpp:108-176)
+//   <dir>/Level_0/Cell_H             VisMF header, version 1 (BTDMultiFabHeaderImpl::WriteMultiFabHeader, :254-301)
+//   <dir>/Level_0/Cell_D_00000       one FAB per brick: "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))<box> <ncomp>\n"
+//                                    + the components as native doubles, Fortran order, component slowest
+//   <dir>/<species>/Header           BTDSpeciesHeaderImpl::WriteHeader (:440-476): Version_Two_Dot_One_double, 4 real
+//                                    components weight momentum_x/y/z (FlushFormatPlotfile.cpp:363-366), no int ones
+//   <dir>/<species>/Level_0/Particle_H   the particle BoxArray (BTDParticleDataHeaderImpl::WriteHeader, :524-540)
+//   <dir>/<species>/Level_0/DATA_00000   per particle x y z w px py pz as doubles (momenta in SI: m u,
+//                                    particlesConvertUnits, FlushFormatPlotfile.cpp:412-424)
+//   <dir>/WarpXHeader, <dir>/warpx_job_info   (:116-236, :238-343; text, informative)
+// Fields are averaged to the cell centres like CellCenterFunctor (ablastr/coarsen/sample.H:47-99, ratio 1).
+// Output stage, not on the step path: everything is copied to the host first.  One brick writes one plotfile
+// (its own box as the only grid); multi-brick runs write one directory per rank.
+#ifndef WXA_HOST_PLOTFILE_HPP_
+#define WXA_HOST_PLOTFILE_HPP_
+
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+#include "sim_capi.hpp"
+
+namespace wxa::host {
+
+inline void make_dir(const std::string& path) {
+    if (::mkdir(path.c_str(), 0755) != 0 && errno != EEXIST) throw std::runtime_error("plotfile: cannot create " + path);
+}
+
+// staggered component -> cell centres of the valid box, dense Fortran-order array
+inline std::vector<double> cell_centered(const Backend* be, const amrex::MultiFab& mf, int ncell[3]) {
+    const wxa_field_view& v = mf.view();
+    std::vector<double> a((size_t)v.kstride * (size_t)v.n[2]);
+    if (be->memcpy_d2h(a.data(), v.p, sizeof(double) * a.size()) != 0) throw std::runtime_error("plotfile: device copy failed");
+    int np[3];
+    for (int d = 0; d < 3; ++d) {
+        np[d] = 1 + v.stag[d];
+        ncell[d] = v.n[d] - 2 * v.ng[d] - v.stag[d];
+    }
+    const double wx = 1.0 / np[0], wy = 1.0 / np[1], wz = 1.0 / np[2];
+    std::vector<double> out((size_t)ncell[0] * ncell[1] * ncell[2]);
+    size_t o = 0;
+    for (int k = 0; k < ncell[2]; ++k)
+        for (int j = 0; j < ncell[1]; ++j)
+            for (int i = 0; i < ncell[0]; ++i) {
+                double c = 0.0;
+                for (int kr = 0; kr < np[2]; ++kr)
+                    for (int jr = 0; jr < np[1]; ++jr)
+                        for (int ir = 0; ir < np[0]; ++ir)
+                            c += wx * wy * wz * a[(size_t)(i + ir + v.ng[0]) + (size_t)(j + jr + v.ng[1]) * v.jstride +
+                                                 (size_t)(k + kr + v.ng[2]) * v.kstride];
+                out[o++] = c;
+            }
+    return out;
+}
+
+inline std::string box_string(const int lo[3], const int hi[3]) {
+    std::ostringstream s;
+    s << "((" << lo[0] << ',' << lo[1] << ',' << lo[2] << ") (" << hi[0] << ',' << hi[1] << ',' << hi[2] << ") (0,0,0))";
+    return s.str();
+}
+
+inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vector<std::string>& species_names) {
+    using warpx::fields::FieldType;
+    using ablastr::fields::Direction;
+    WarpX& wx = *h.warpx;
+    const WarpXContext& ctx = wx.context();
+    const Backend* be = ctx.be;
+    be->stream_sync(ctx.stream);
+    make_dir(dir);
+    make_dir(dir + "/Level_0");
+
+    // ---- fields: the reference's default fields_to_plot, cell-centred
+    const struct { const char* name; FieldType ft; int d; } comps[9] = {
+        {"Ex", FieldType::Efield_fp, 0}, {"Ey", FieldType::Efield_fp, 1}, {"Ez", FieldType::Efield_fp, 2},
+        {"Bx", FieldType::Bfield_fp, 0}, {"By", FieldType::Bfield_fp, 1}, {"Bz", FieldType::Bfield_fp, 2},
+        {"jx", FieldType::current_fp, 0}, {"jy", FieldType::current_fp, 1}, {"jz", FieldType::current_fp, 2}};
+    constexpr int NCOMP = 10;   // + rho
+    int ncell[3] = {0, 0, 0};
+    std::vector<std::vector<double>> data;
+    std::vector<std::string> names;
+    for (const auto& c : comps) {
+        data.push_back(cell_centered(be, *wx.fields().get(c.ft, Direction{c.d}, 0), ncell));
+        names.emplace_back(c.name);
+    }
+    data.push_back(cell_centered(be, wx.ComputeRho(), ncell));
+    names.emplace_back("rho");
+    int lo[3], hi[3];
+    double rlo[3], rhi[3], dx[3];
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = ctx.brick_box.lo[d];
+        hi[d] = lo[d] + ncell[d] - 1;
+        dx[d] = 1.0 / ctx.dinv[d];
+        rlo[d] = ctx.brick_plo[d];
+        rhi[d] = ctx.brick_plo[d] + ncell[d] * dx[d];
+    }
+    const std::string box = box_string(lo, hi);
+    const std::string fab_header = "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" + box + " " +
+                                   std::to_string(NCOMP) + "\n";
+    {
+        std::ofstream f(dir + "/Level_0/Cell_D_00000", std::ios::binary | std::ios::trunc);
+        if (!f.good()) throw std::runtime_error("plotfile: cannot open Cell_D_00000");
+        f << fab_header;
+        for (const auto& c : data) f.write(reinterpret_cast<const char*>(c.data()), (std::streamsize)(sizeof(double) * c.size()));
+    }
+    {
+        std::ofstream f(dir + "/Level_0/Cell_H", std::ios::binary | std::ios::trunc);
+        f.precision(17);
+        f << 1 << '\n' << 1 << '\n' << NCOMP << '\n' << 0 << '\n';      // version, how (one fab per file), ncomp, ngrow
+        f << "(1 0\n" << box << "\n)\n";                                // BoxArray::writeOn
+        f << 1 << '\n' << "FabOnDisk: Cell_D_00000 0\n" << '\n';
+        f << 1 << ',' << NCOMP << '\n';
+        for (const auto& c : data) { double m = c.empty() ? 0.0 : c[0]; for (double v : c) m = std::min(m, v); f << m << ','; }
+        f << "\n\n" << 1 << ',' << NCOMP << '\n';
+        for (const auto& c : data) { double m = c.empty() ? 0.0 : c[0]; for (double v : c) m = std::max(m, v); f << m << ','; }
+        f << '\n';
+    }
+    {
+        std::ofstream f(dir + "/Header", std::ios::binary | std::ios::trunc);
+        f.precision(17);
+        f << "HyperCLaw-V1.1\n" << NCOMP << '\n';
+        for (const auto& n : names) f << n << '\n';
+        f << 3 << '\n' << wx.gett_new() << '\n' << 0 << '\n';
+        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ';
+        f << '\n';
+        for (int d = 0; d < 3; ++d) f << rhi[d] << ' ';
+        f << '\n' << '\n';                                              // no refinement ratios on a single level
+        f << box << '\n' << wx.getistep() << '\n';
+        for (int d = 0; d < 3; ++d) f << dx[d] << ' ';
+        f << '\n' << 0 << '\n' << 0 << '\n';                            // Cartesian, bwidth
+        f << 0 << ' ' << 1 << ' ' << wx.gett_new() << '\n' << wx.getistep() << '\n';
+        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ' << rhi[d] << '\n';
+        f << "Level_0/Cell\n";
+    }
+    // ---- particles
+    for (int s = 0; s < wx.GetPartContainer().nSpecies(); ++s) {
+        WarpXParticleContainer& pc = wx.GetPartContainer().GetParticleContainer(s);
+        ParticleTile& t = pc.tile();
+        const size_t n = (size_t)t.numParticles();
+        const std::string name = s < (int)species_names.size() ? species_names[s] : "species" + std::to_string(s);
+        make_dir(dir + "/" + name);
+        make_dir(dir + "/" + name + "/Level_0");
+        std::vector<double> soa(7 * n), rec(7 * n);
+        for (int c = 0; c < 7; ++c)
+            if (n && be->memcpy_d2h(soa.data() + (size_t)c * n, t.comp(c), sizeof(double) * n) != 0)
+                throw std::runtime_error("plotfile: device copy failed");
+        for (size_t i = 0; i < n; ++i)
+            for (int c = 0; c < 7; ++c) rec[7 * i + c] = c >= 4 ? soa[(size_t)c * n + i] * pc.mass : soa[(size_t)c * n + i];
+        {
+            std::ofstream f(dir + "/" + name + "/Level_0/DATA_00000", std::ios::binary | std::ios::trunc);
+            f.write(reinterpret_cast<const char*>(rec.data()), (std::streamsize)(sizeof(double) * rec.size()));
+        }
+        {
+            std::ofstream f(dir + "/" + name + "/Level_0/Particle_H", std::ios::binary | std::ios::trunc);
+            f << "(1 0\n" << box << "\n)\n";
+        }
+        {
+            std::ofstream f(dir + "/" + name + "/Header", std::ios::binary | std::ios::trunc);
+            f.precision(17);
+            f << "Version_Two_Dot_One_double\n" << 3 << '\n' << 4 << '\n'
+              << "weight\nmomentum_x\nmomentum_y\nmomentum_z\n" << 0 << '\n'      // no int components
+              << 0 << '\n' << n << '\n' << (n + 1) << '\n' << 0 << '\n'           // is_checkpoint, count, next id, finest level
+              << 1 << '\n' << 0 << ' ' << n << ' ' << 0 << '\n';                  // one grid: file 0, count, offset
+        }
+    }
+    {   // WarpXHeader (FlushFormatPlotfile.cpp:238-343), the part readers look at
+        std::ofstream f(dir + "/WarpXHeader", std::ios::binary | std::ios::trunc);
+        f.precision(17);
+        f << "Checkpoint version: 1\n" << 1 << "\n" << wx.getistep() << " \n" << 1 << " \n" << wx.gett_new() << " \n"
+          << wx.gett_new() - wx.getdt(0) << " \n" << wx.getdt(0) << " \n" << 0.0 << "\n" << 1 << "\n";
+        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ';
+        f << '\n';
+        for (int d = 0; d < 3; ++d) f << rhi[d] << ' ';
+        f << '\n';
+    }
+    {
+        std::ofstream f(dir + "/warpx_job_info", std::ios::trunc);
+        f << std::string(78, '=') << "\n WarpX Job Information\n" << std::string(78, '=') << "\n"
+          << "written by warpx_amd (MI355X-native hot path behind the WarpX operator surface), not by WarpX\n";
+    }
+}
+
+}  // namespace wxa::host
+#endif

@@ -543,6 +543,7 @@ public:
     WarpXContext& context() { return m_ctx; }
     amrex::Real getdt(int lev) const { return dt[lev]; }
     int64_t getistep() const { return istep; }
+    amrex::Real gett_new() const { return cur_time; }
     BrickComm& comm() { return *m_comm; }
     bool any_reflecting_wall() const { return m_any_reflecting_wall; }
 

@@ -637,6 +637,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
 }  // namespace wxa::host
 
 #include "Checksum.hpp"
+#include "Plotfile.hpp"
 
 // C entry points of the deck front end (include/warpx_amd.h), instantiated next to WXA_SIM_CAPI
 #define WXA_INPUTS_CAPI(PFX, RET, SIMTYPE, BACKEND_GETTER, SET_ERROR)                                   \
@@ -687,6 +688,18 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         } catch (const std::exception& e) {                                                            \
             SET_ERROR(e.what());                                                                       \
             return -2;                                                                                 \
+        }                                                                                              \
+    }                                                                                                  \
+    /* FlushFormatPlotfile::WriteToFile for this brick (host/Plotfile.hpp) */                          \
+    RET PFX##sim_write_plotfile(SIMTYPE* s, const char* dir) {                                         \
+        if (!s || !dir) return (RET)WXA_ERR_INVALID_ARG;                                               \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        try {                                                                                          \
+            wxa::host::write_plotfile(*h, dir, h->species_names);                                      \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
         }                                                                                              \
     }                                                                                                  \
     /* the expression evaluator of the decks, for tests and tools */                                   \

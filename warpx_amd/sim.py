@@ -81,6 +81,10 @@ class WarpXSim:
         self.dx = None
         return self
 
+    def write_plotfile(self, path: str):
+        """AMReX plotfile of the current state (wxa_sim_write_plotfile): the reference's FlushFormatPlotfile output."""
+        self.lib.sim_write_plotfile(self._h, str(path).encode())
+
     def checksum(self) -> dict:
         """The reference's regression checksum of the current state (wxa_sim_checksum_json), this brick's share."""
         import json
