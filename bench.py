@@ -107,7 +107,8 @@ def energies(sim, sid):
     ee, eb = field_energy(sim)
     v = sim.particle_view(sid)
     n = int(v.np)
-    arr = {k: _as_tensor(int(getattr(v, k)), 8 * n, True).view(torch.float64) for k in ("w", "ux", "uy", "uz")}
+    on_device = str(sim.lib.memory).startswith("cuda")   # host memory on the CPU execution model of the tests
+    arr = {k: _as_tensor(int(getattr(v, k)), 8 * n, on_device).view(torch.float64) for k in ("w", "ux", "uy", "uz")}
     u2 = arr["ux"] ** 2 + arr["uy"] ** 2 + arr["uz"] ** 2
     gamma = torch.sqrt(1.0 + u2 / plasma.C_LIGHT ** 2)
     ekin = float(torch.sum(arr["w"] * plasma.M_E * u2 / (1.0 + gamma)))

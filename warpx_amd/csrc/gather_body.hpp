@@ -56,7 +56,7 @@ __device__ __forceinline__ double gather_rows(const double* __restrict__ base, l
             double r = 0.0;
 #pragma unroll
             for (int ix = 0; ix < NX; ++ix) r += sx[ix] * row[ix];
-            acc += (sy[iy] * sz[iz]) * r;
+            acc += sy[iy] * (sz[iz] * r);   // same association as gather_rows2 (gather_pairs.hip): the kernels agree bit for bit
         }
     }
     return acc;
