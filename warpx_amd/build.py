@@ -31,7 +31,6 @@ SOURCES = [
     ("particles.hip", []),
     ("deposit_tile.hip", []),
     ("gather_tile.hip", []),
-    ("gather_pairs.hip", []),
     ("host/warpx_host.hip", []),
     ("rccl_comm.hip", []),
 ]

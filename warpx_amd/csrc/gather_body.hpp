@@ -56,7 +56,9 @@ __device__ __forceinline__ double gather_rows(const double* __restrict__ base, l
             double r = 0.0;
 #pragma unroll
             for (int ix = 0; ix < NX; ++ix) r += sx[ix] * row[ix];
-            acc += sy[iy] * (sz[iz] * r);   // same association as gather_rows2 (gather_pairs.hip): the kernels agree bit for bit
+            // sy (sz r), not (sy sz) r: the products sy sz are common to several components, and the compiler kept all 49
+            // of them alive across the six gathers when they could be shared (125 VGPRs; 93 this way)
+            acc += sy[iy] * (sz[iz] * r);
         }
     }
     return acc;

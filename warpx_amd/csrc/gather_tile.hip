@@ -178,16 +178,7 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);                     \
     } while (0)
-    if (PART == 0 && gather_pairs_applicable(order, galerkin, PUSHER)) {
-        // two particles per lane (gather_pairs.hip), then the same straggler pass
-        if ((rc = gather_push_pairs(p, E, B, geom, q, m, dt, order, PUSHER, MOVE, ws, st)) != WXA_OK) return rc;
-        if (order == 1)
-            hipLaunchKernelGGL((gather_push_stragglers_kernel<1, 1, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, sq.idx,
-                               sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);
-        else
-            hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, sq.idx,
-                               sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);
-    } else if (galerkin) {
+    if (galerkin) {
         if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else WXA_GT(3, 1);
     } else {
         if (order == 1) WXA_GT(1, 0); else if (order == 2) WXA_GT(2, 0); else WXA_GT(3, 0);

@@ -65,11 +65,5 @@ wxa_status gather_push_tiled(const wxa_particle_view* p, const wxa_field_view E[
 wxa_status gather_push_tiled_part(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
                                   const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
                                   int pusher, int part, wxa_workspace* ws, hipStream_t stream);
-// two particles per lane where all particles of a cell share their stencil frames (gather_pairs.hip); the caller
-// owns the straggler queue and runs the straggler pass
-bool gather_pairs_applicable(int order, int galerkin, int pusher);
-wxa_status gather_push_pairs(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
-                             const wxa_grid_geom* geom, double q, double m, double dt, int order, int pusher, bool move,
-                             wxa_workspace* ws, hipStream_t stream);
 }  // namespace wxa
 #endif
