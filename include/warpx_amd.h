@@ -93,6 +93,29 @@ void       wxa_workspace_destroy(wxa_workspace* ws);
  * Source/Particles/PhysicalParticleContainer.cpp:2589-2596,2705-2710): added to the gathered fields by
  * wxa_gather_push_ws / wxa_gather_push_part when they are handed this workspace.  Zero by default. */
 wxa_status wxa_workspace_set_external_particle_fields(wxa_workspace* ws, const double E[3], const double B[3]);
+/* particles.E_ext_particle_init_style / B_ext_particle_init_style = repeated_plasma_lens
+ * (GetExternalEBField::operator(), Source/Particles/Gather/GetExternalFields.H:137-189; parameters read in
+ * MultiParticleContainer::ReadParameters, MultiParticleContainer.cpp:210-260): lens i occupies
+ * [i period + starts[i], ... + lengths[i]) of the lab-frame z axis and acts on a particle with
+ * E = strengths_E[i] frac (x, y, 0), B = strengths_B[i] frac (y, -x, 0), frac = the share of the particle's
+ * slice [z, z + vz dt) of this step that lies inside the lens.  With gamma_boost > 1 the slice is taken to the
+ * lab frame first (z -> gamma z + uz_boost t) and the fields are transformed back (:176-187).  The four arrays
+ * (host memory, n_lenses entries each) are copied; n_lenses = 0 switches the lens off.  `dt` is the step of the
+ * level (warpx.getdt), not the dt of the push that applies the fields (PushP at initialisation uses -dt/2). */
+typedef struct wxa_repeated_plasma_lens {
+    int32_t n_lenses;
+    double  period;
+    const double* starts;
+    const double* lengths;
+    const double* strengths_E;
+    const double* strengths_B;
+    double  gamma_boost;     /* 1 = lab frame */
+    double  dt;
+} wxa_repeated_plasma_lens;
+wxa_status wxa_workspace_set_repeated_plasma_lens(wxa_workspace* ws, const wxa_repeated_plasma_lens* lens);
+/* warpx.gett_new(lev) as the external-field functor sees it (m_time, GetExternalFields.cpp:43): set before the
+ * pushes of a step when a time-dependent external field (the boosted lens) is active */
+wxa_status wxa_workspace_set_time(wxa_workspace* ws, double t);
 /* Accumulator of the LDS-tile Esirkepov deposition for the container that owns this workspace.  WXA_ACC_FP64 (default):
  * ds_add_f64 tiles, the double/double build of the reference (1e-10 parity gate).  WXA_ACC_FP32: ds_add_f32 tiles --
  * every deposit is still evaluated in fp64 and rounded once when it enters the tile; the tile's sums then carry fp32
@@ -443,6 +466,11 @@ typedef struct wxa_sim_config {
     int32_t maxwell_solver;      /* algo.maxwell_solver: WXA_SOLVER_YEE (0, the default) or WXA_SOLVER_CKC; with CKC
                                     dt = cfl min(dx)/c and every field exchange of the reference's schedule is issued
                                     (the B update reads guard points of E)                                        */
+    double  gamma_boost;         /* warpx.gamma_boost with warpx.boost_direction = z (WarpXUtil.cpp:114-141); 0 or 1 = lab
+                                    frame.  prob_lo / prob_hi above are boosted-frame values already (the inputs reader
+                                    applies ConvertLabParamsToBoost, WarpXUtil.cpp:180-262); the value reaches the
+                                    injection (MapParticletoBoostedFrame, the boosted branch of AddPlasma), the
+                                    injection position of the moving window and the repeated plasma lens          */
 } wxa_sim_config;
 
 /* ---- second "next" row: moving window, continuous plasma injection, laser antenna -----------------

@@ -309,9 +309,51 @@ int orc_evolve_e_box(const wxa_field_view E[3], const wxa_field_view B[3], const
 
 namespace {
 
+// GetExternalEBField::operator(), the RepeatedPlasmaLens branch and the transformation to the boosted frame
+// (Source/Particles/Gather/GetExternalFields.H:137-189); m_uz_boost from GetExternalFields.cpp:28
+inline void getExternalEB_lens(const wxa_repeated_plasma_lens& L, double time, double x, double y, double z, double uxp,
+                               double uyp, double uzp, double& field_Ex, double& field_Ey, double& field_Bx,
+                               double& field_By) {
+    constexpr double c = 299792458.0;
+    constexpr double inv_c2 = 1.0 / (c * c);
+    const double uz_boost = std::sqrt(L.gamma_boost * L.gamma_boost - 1.0) * c;
+    double Ex = 0.0, Ey = 0.0, Bx = 0.0, By = 0.0;
+    const double gamma = std::sqrt(1.0 + (uxp * uxp + uyp * uyp + uzp * uzp) * inv_c2);
+    const double vzp = uzp / gamma;
+    double zl = z;
+    double zr = z + vzp * L.dt;
+    if (L.gamma_boost > 1.0) {
+        zl = L.gamma_boost * zl + uz_boost * time;
+        zr = L.gamma_boost * zr + uz_boost * (time + L.dt);
+    }
+    if (zl > 0) {
+        const int i_lens = static_cast<int>(std::floor(zl / L.period));
+        if (i_lens < L.n_lenses) {
+            const double lens_start = L.starts[i_lens] + i_lens * L.period;
+            const double lens_end = lens_start + L.lengths[i_lens];
+            const double zl_bounded = std::min(std::max(zl, lens_start), lens_end);
+            const double zr_bounded = std::min(std::max(zr, lens_start), lens_end);
+            const double frac = ((zr - zl) == 0.0 ? 1.0 : (zr_bounded - zl_bounded) / (zr - zl));
+            Ex += x * frac * L.strengths_E[i_lens];
+            Ey += y * frac * L.strengths_E[i_lens];
+            Bx += +y * frac * L.strengths_B[i_lens];
+            By += -x * frac * L.strengths_B[i_lens];
+        }
+    }
+    if (L.gamma_boost > 1.0) {
+        const double Ex_boost = L.gamma_boost * Ex - uz_boost * By;
+        const double Ey_boost = L.gamma_boost * Ey + uz_boost * Bx;
+        const double Bx_boost = L.gamma_boost * Bx + uz_boost * Ey * inv_c2;
+        const double By_boost = L.gamma_boost * By - uz_boost * Ex * inv_c2;
+        Ex = Ex_boost; Ey = Ey_boost; Bx = Bx_boost; By = By_boost;
+    }
+    field_Ex += Ex; field_Ey += Ey; field_Bx += Bx; field_By += By;
+}
+
 template <int O, int G, bool MOVE>
 void gather_push_impl(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
-                      const wxa_grid_geom* g, double q, double m, double dt, int pusher, const double* ext) {
+                      const wxa_grid_geom* g, double q, double m, double dt, int pusher, const double* ext,
+                      const wxa_repeated_plasma_lens* lens, double time) {
     const Arr ex(E[0]), ey(E[1]), ez(E[2]), bx(B[0]), by(B[1]), bz(B[2]);
     // particles.E/B_external_particle (constant): the sums of the gather start from them
     // (PhysicalParticleContainer.cpp:2589-2596,2705-2710)
@@ -324,6 +366,8 @@ void gather_push_impl(const wxa_particle_view* p, const wxa_field_view E[3], con
         doGatherShapeN<O, G>(xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, ex, ey, ez, bx, by, bz,
                              E[0].stag, E[1].stag, E[2].stag, B[0].stag, B[1].stag, B[2].stag,
                              g->dinv, g->xyzmin, g->lo);
+        if (lens && lens->n_lenses > 0)
+            getExternalEB_lens(*lens, time, xp, yp, zp, p->ux[ip], p->uy[ip], p->uz[ip], Exp, Eyp, Bxp, Byp);
         doParticleMomentumPush(p->ux[ip], p->uy[ip], p->uz[ip], Exp, Eyp, Ezp, Bxp, Byp, Bzp, m, q,
                                pusher, dt);
         if (MOVE) {
@@ -336,17 +380,18 @@ void gather_push_impl(const wxa_particle_view* p, const wxa_field_view E[3], con
 template <bool MOVE>
 int gather_push_dispatch(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
                          const wxa_grid_geom* g, double q, double m, double dt, int order, int galerkin,
-                         int pusher, const double* ext = nullptr) {
+                         int pusher, const double* ext = nullptr, const wxa_repeated_plasma_lens* lens = nullptr,
+                         double time = 0.0) {
     // Source/Particles/Gather/FieldGather.H:1590-1664 (runtime dispatch on nox, galerkin)
     if (galerkin) {
-        if (order == 1) gather_push_impl<1, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
-        else if (order == 2) gather_push_impl<2, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
-        else if (order == 3) gather_push_impl<3, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
+        if (order == 1) gather_push_impl<1, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
+        else if (order == 2) gather_push_impl<2, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
+        else if (order == 3) gather_push_impl<3, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
         else return -1;
     } else {
-        if (order == 1) gather_push_impl<1, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
-        else if (order == 2) gather_push_impl<2, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
-        else if (order == 3) gather_push_impl<3, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext);
+        if (order == 1) gather_push_impl<1, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
+        else if (order == 2) gather_push_impl<2, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
+        else if (order == 3) gather_push_impl<3, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
         else return -1;
     }
     return 0;
@@ -441,6 +486,14 @@ int orc_gather_push_ext(const wxa_particle_view* p, const wxa_field_view E[3], c
                         int move, const double* ext) {
     return move ? gather_push_dispatch<true>(p, E, B, g, q, m, dt, order, galerkin, pusher, ext)
                 : gather_push_dispatch<false>(p, E, B, g, q, m, dt, order, galerkin, pusher, ext);
+}
+
+// the same with a repeated plasma lens evaluated at `time` (wxa_repeated_plasma_lens of include/warpx_amd.h, host arrays)
+int orc_gather_push_lens(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                         const wxa_grid_geom* g, double q, double m, double dt, int order, int galerkin, int pusher,
+                         int move, const double* ext, const wxa_repeated_plasma_lens* lens, double time) {
+    return move ? gather_push_dispatch<true>(p, E, B, g, q, m, dt, order, galerkin, pusher, ext, lens, time)
+                : gather_push_dispatch<false>(p, E, B, g, q, m, dt, order, galerkin, pusher, ext, lens, time);
 }
 
 // Source/Particles/PhysicalParticleContainer.cpp:2368-2516 (PushP), kernel :2454-2511
@@ -1542,6 +1595,7 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
     if (!cfg || !out) return -1;
     if (cfg->nox < 1 || cfg->nox > 3) return -1;
     if (cfg->nbricks[0] * cfg->nbricks[1] * cfg->nbricks[2] != 1) return -3;
+    if (cfg->gamma_boost > 1.0) return -3;   // boosted frames run through the host layer (tests/host_cpu), not this driver
     auto* s = new orc_sim();
     s->cfg = *cfg;
     for (int d = 0; d < 3; ++d) {

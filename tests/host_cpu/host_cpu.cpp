@@ -5,6 +5,7 @@
 // machine without a GPU.  Exports `hst_sim_*`.  Never linked into libwarpx_amd.so.
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../warpx_amd/csrc/host/WarpXInputs.hpp"
 
@@ -19,8 +20,8 @@ int orc_gather_push(const wxa_particle_view*, const wxa_field_view*, const wxa_f
                     double, double, double, int, int, int, void*);
 int orc_push_p(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
                double, double, double, int, int, int, void*);
-int orc_gather_push_ext(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
-                        double, double, double, int, int, int, int, const double*);
+int orc_gather_push_lens(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*, const wxa_grid_geom*,
+                         double, double, double, int, int, int, int, const double*, const wxa_repeated_plasma_lens*, double);
 int orc_deposit_current(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, double,
                         double, int, int, void*, void*);
 int orc_filter_bilinear(const wxa_field_view*, const wxa_field_view*, void*);
@@ -62,15 +63,45 @@ using wxa::host::Backend;
 
 // the container's workspace on this backend: the live count of the last sort (orc_sort_particles_by_cell writes it
 // to the first 8 bytes) followed by the constant external fields
-struct CpuWorkspace { int64_t live; double ext[6]; };
-int ws_create(void** ws) { *ws = std::calloc(1, sizeof(CpuWorkspace)); return 0; }
-const double* ws_ext(void* ws) { return static_cast<CpuWorkspace*>(ws)->ext; }
+struct CpuWorkspace {
+    int64_t live;
+    double ext[6];
+    wxa_repeated_plasma_lens lens;       // arrays point into lens_tab
+    std::vector<double>* lens_tab;
+    double time;
+};
+int ws_create(void** ws) {
+    auto* w = static_cast<CpuWorkspace*>(std::calloc(1, sizeof(CpuWorkspace)));
+    w->lens_tab = new std::vector<double>();
+    w->lens.gamma_boost = 1.0;
+    *ws = w;
+    return 0;
+}
 int ws_set_ext(void* ws, const double* E, const double* B) {
     double* e = static_cast<CpuWorkspace*>(ws)->ext;
     for (int d = 0; d < 3; ++d) { e[d] = E[d]; e[3 + d] = B[d]; }
     return 0;
 }
-void ws_destroy(void* ws) { std::free(ws); }
+int ws_set_lens(void* ws, const wxa_repeated_plasma_lens* lens) {
+    auto* w = static_cast<CpuWorkspace*>(ws);
+    const int n = lens->n_lenses;
+    w->lens_tab->assign((size_t)4 * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        (*w->lens_tab)[i] = lens->starts[i]; (*w->lens_tab)[n + i] = lens->lengths[i];
+        (*w->lens_tab)[2 * n + i] = lens->strengths_E[i]; (*w->lens_tab)[3 * n + i] = lens->strengths_B[i];
+    }
+    w->lens = *lens;
+    const double* t = w->lens_tab->data();
+    w->lens.starts = t; w->lens.lengths = t + n; w->lens.strengths_E = t + 2 * n; w->lens.strengths_B = t + 3 * n;
+    return 0;
+}
+int ws_set_time(void* ws, double t) { static_cast<CpuWorkspace*>(ws)->time = t; return 0; }
+int ws_gather_push(const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B, const wxa_grid_geom* g,
+                   double q, double m, double dt, int o, int ga, int pu, int move, void* ws) {
+    auto* w = static_cast<CpuWorkspace*>(ws);
+    return orc_gather_push_lens(p, E, B, g, q, m, dt, o, ga, pu, move, w->ext, &w->lens, w->time);
+}
+void ws_destroy(void* ws) { delete static_cast<CpuWorkspace*>(ws)->lens_tab; std::free(ws); }
 void* h_malloc(size_t n) { return std::malloc(n ? n : 8); }
 void h_free(void* p) { std::free(p); }
 int h_memset(void* p, int v, size_t n, void*) { std::memset(p, v, n); return 0; }
@@ -88,13 +119,15 @@ const Backend* cpu_backend() {
         b.gather_push = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
                            const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, int move,
                            void* ws, void*) -> int {
-            return orc_gather_push_ext(p, E, B, g, q, m, dt, o, ga, pu, move, ws_ext(ws)); };
+            return ws_gather_push(p, E, B, g, q, m, dt, o, ga, pu, move, ws); };
         b.ws_set_external_eb = ws_set_ext;
+        b.ws_set_repeated_plasma_lens = ws_set_lens;
+        b.ws_set_time = ws_set_time;
         // no tiles on this backend: the interior part is empty, the rest is everything (a valid split)
         b.gather_push_part = [](const wxa_particle_view* p, const wxa_field_view* E, const wxa_field_view* B,
                                 const wxa_grid_geom* g, double q, double m, double dt, int o, int ga, int pu, void* ws,
                                 int part, void*) -> int {
-            return part == WXA_PART_INTERIOR ? 0 : orc_gather_push_ext(p, E, B, g, q, m, dt, o, ga, pu, 1, ws_ext(ws)); };
+            return part == WXA_PART_INTERIOR ? 0 : ws_gather_push(p, E, B, g, q, m, dt, o, ga, pu, 1, ws); };
         b.add_plasma = orc_add_plasma;
         b.deposit_current = orc_deposit_current;
         b.filter_bilinear = orc_filter_bilinear;

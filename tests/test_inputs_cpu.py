@@ -8,6 +8,7 @@ import json
 import math
 import os
 
+import numpy as np
 import pytest
 
 from tests.oracle_lib import load_host_cpu
@@ -142,6 +143,12 @@ OUR_DECKS = [
     ("particle_pusher_3d.inputs", "particle_pusher_3d_checksums.json", ()),
     # <species>.do_classical_radiation_reaction: Boris + radiation reaction in a constant external B
     ("radiation_reaction_3d.inputs", "radiation_reaction_3d_checksums.json", ()),
+    # particles.*_ext_particle_init_style = repeated_plasma_lens: lab frame, lenses shorter than a step (residence
+    # correction), and a frame boosted by gamma = 2 (ConvertLabParamsToBoost, MapParticletoBoostedFrame, the lens
+    # evaluated in the lab frame and its fields transformed back)
+    ("plasma_lens_3d.inputs", "plasma_lens_3d_checksums.json", ()),
+    ("plasma_lens_short_3d.inputs", "plasma_lens_short_3d_checksums.json", ()),
+    ("plasma_lens_boosted_3d.inputs", "plasma_lens_boosted_3d_checksums.json", ()),
 ]
 
 
@@ -178,6 +185,9 @@ REFERENCE_DECKS = [
     ("Examples/Tests/laser_injection/inputs_test_3d_laser_injection", "test_3d_laser_injection", ()),
     ("Examples/Tests/particle_pusher/inputs_test_3d_particle_pusher", "test_3d_particle_pusher", ()),
     ("Examples/Tests/radiation_reaction/inputs_test_3d_radiation_reaction", "test_3d_radiation_reaction", ()),
+    ("Examples/Tests/plasma_lens/inputs_test_3d_plasma_lens", "test_3d_plasma_lens", ()),
+    ("Examples/Tests/plasma_lens/inputs_test_3d_plasma_lens_short", "test_3d_plasma_lens_short", ()),
+    ("Examples/Tests/plasma_lens/inputs_test_3d_plasma_lens_boosted", "test_3d_plasma_lens_boosted", ()),
 ]
 
 
@@ -189,6 +199,57 @@ def test_the_reference_decks_run_unmodified(lib, deck, name, skip):
     sim = WarpXSim.from_inputs(lib, os.path.join(REFERENCE, deck))
     sim.evolve(sim.max_step)
     compare_with_golden(sim.checksum(), gold, 1e-9, skip)
+    sim.close()
+
+
+def lens_orbit_errors(sim, sid=0, gamma_boost=1.0, short=False):
+    """The gate of the reference's analysis script for the plasma lens decks (Examples/Tests/plasma_lens/analysis.py):
+    the thick-lens solution x'' = -k^2 x, k^2 = e E' / (m gamma vz^2), through the four lenses and the drifts
+    between them, against the simulated transverse position and momentum of the two particles.  Returns the
+    relative errors (x, y, ux, uy) and the tolerances (position, velocity)."""
+    from scipy.constants import c, e, m_e
+    p = sim.particles(sid)
+    i0 = int(np.argmax(np.abs(p[0]))), int(np.argmax(np.abs(p[1])))
+    zz_sim = [p[2][i0[0]], p[2][i0[1]]]
+    if gamma_boost > 1.0:
+        uz_boost = math.sqrt(gamma_boost * gamma_boost - 1.0) * c
+        t = sim.istep * sim.dt
+        zz_sim = [gamma_boost * z + uz_boost * t for z in zz_sim]
+    period = 0.5
+    starts = [0.1, 0.11, 0.12, 0.13]
+    lengths = [0.001, 0.0011, 0.0012, 0.0013] if short else [0.1, 0.11, 0.12, 0.13]
+    strengths = [6.e7, 8.e7, 6.e7, 2.e7] if short else [6.e5, 8.e5, 6.e5, 2.e5]
+    pos, u, zz = [0.05, 0.04], [0.0, 0.0], 0.05
+    uz = 0.5 * c
+    gamma = math.sqrt(uz ** 2 / c ** 2 + 1.0)
+    vz = uz / gamma
+    for i in range(4):
+        z_lens = i * period + starts[i]
+        kb0 = math.sqrt(e / (m_e * gamma * vz ** 2) * strengths[i])
+        for a in range(2):
+            v = u[a] / gamma
+            x = pos[a] + (z_lens - zz) / vz * v
+            x1 = x * math.cos(kb0 * lengths[i]) + (v / vz) / kb0 * math.sin(kb0 * lengths[i])
+            v1 = vz * (-kb0 * x * math.sin(kb0 * lengths[i]) + (v / vz) * math.cos(kb0 * lengths[i]))
+            pos[a], u[a] = x1, gamma * v1
+        zz = z_lens + lengths[i]
+    errs = []
+    for a in range(2):
+        x = pos[a] + (zz_sim[a] - zz) / vz * (u[a] / gamma)
+        errs.append(abs((x - p[a][i0[a]]) / x))
+    for a in range(2):
+        errs.append(abs((u[a] - p[4 + a][i0[a]]) / u[a]))
+    return errs, ((0.023, 0.003) if short else (0.02, 0.002))
+
+
+@pytest.mark.parametrize("deck,boost,short", [("plasma_lens_3d.inputs", 1.0, False), ("plasma_lens_short_3d.inputs", 1.0, True),
+                                              ("plasma_lens_boosted_3d.inputs", 2.0, False)])
+def test_plasma_lens_orbits_follow_the_thick_lens_solution(lib, deck, boost, short):
+    sim = WarpXSim.from_inputs(lib, os.path.join(DECKS, deck))
+    sim.evolve(sim.max_step)
+    errs, (ptol, vtol) = lens_orbit_errors(sim, gamma_boost=boost, short=short)
+    print(deck, errs)
+    assert errs[0] < ptol and errs[1] < ptol and errs[2] < vtol and errs[3] < vtol, errs
     sim.close()
 
 

@@ -4,6 +4,7 @@ operation order and must be bit-identical; per-particle kernels may differ by FM
 contraction (tolerance 1e-12 of the field scale); deposition sums in a different order
 (atomics) and is compared per cell at 1e-12 of max|J|."""
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -975,6 +976,80 @@ def test_empty_inputs_are_no_ops(product):
     _sync(product)
     for f, a in zip(J + [rho], before):
         assert np.array_equal(f.to_numpy(), a)
+    product.workspace_destroy(ws)
+
+
+@pytest.mark.parametrize("order,sort,gamma_boost", [(1, False, 1.0), (3, True, 1.0), (3, True, 2.0), (2, False, 5.0)])
+def test_push_through_a_repeated_plasma_lens(oracle, product, order, sort, gamma_boost):
+    """particles.*_ext_particle_init_style = repeated_plasma_lens (GetExternalEBField, GetExternalFields.H:137-189) on top
+    of the gathered and the constant external fields: lab frame and boosted frames, electric and magnetic lenses,
+    particles before the first lens, inside lenses, stepping over a lens shorter than their step, and beyond the last
+    one; PushPX and PushP against the CPU restatement, on the global-memory kernel and on the LDS tiles."""
+    ng = 4
+    E = H.random_fields(("Ex", "Ey", "Ez"), NCELL, ng, 81, scale=1e6)
+    B = H.random_fields(("Bx", "By", "Bz"), NCELL, ng, 82, scale=3e-3)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    g, dx = H.geom_for(NCELL, ng)
+    dt = H.yee_dt(dx)
+    n = 20000
+    parts = H.random_particles(n, NCELL, 83, u_scale=2.0, margin=0.5)
+    rng = np.random.default_rng(84)
+    parts[6] = np.abs(parts[6]) + 0.05 * plasma.C_LIGHT            # the lens assumes vz > 0 in the lab frame
+    q, m = plasma.Q_E, plasma.M_E
+    # the lattice in units of the box (z spans [-LX/2, LX/2]): five periods cover the box's lab-frame image, lens 1 is
+    # shorter than a step of the fast particles, the last period has no lens (i_lens >= n_lenses)
+    uz_boost = math.sqrt(gamma_boost ** 2 - 1.0) * plasma.C_LIGHT
+    if gamma_boost == 1.0:
+        time = 3.7 * dt
+        parts[2] = rng.uniform(0.02 * H.LX, 0.45 * H.LX, n)        # lab frame: lenses only act at z > 0
+        z_lab_lo, z_lab_hi = 0.0, 0.45 * H.LX
+    else:
+        time = gamma_boost * H.LX / uz_boost                       # late enough that the whole box is at z_lab > 0
+        z_lab_lo = gamma_boost * (-H.LX / 2) + uz_boost * time
+        z_lab_hi = gamma_boost * (H.LX / 2) + uz_boost * time
+    period = (z_lab_hi - z_lab_lo) / 5.0
+    first = math.floor(z_lab_lo / period)
+    nl = first + 4
+    starts = [0.1 * period] * nl
+    lengths = [0.8 * period] * nl
+    lengths[first + 1] = 1e-3 * period
+    sE = list(rng.uniform(-1, 1, nl) * 1e13)
+    sB = list(rng.uniform(-1, 1, nl) * 3e4)
+    lens = _capi.RepeatedPlasmaLens.make(period, starts, lengths, sE, sB, gamma_boost, dt)
+    ext_e, ext_b = (3e5, -1e6, 5e5), (1e-3, -4e-4, 7e-4)
+    ext6 = (C.c_double * 6)(*ext_e, *ext_b)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    product.workspace_set_external_particle_fields(ws, H.d3(ext_e), H.d3(ext_b))
+    product.workspace_set_repeated_plasma_lens(ws, C.byref(lens))
+    product.workspace_set_time(ws, time)
+    pd = ParticleArrays.from_numpy(parts, DEV, np.arange(1, n + 1, dtype=np.int64))
+    if sort:
+        srt = ParticleArrays(pd.np, DEV, with_id=True)
+        product.sort_particles_by_cell(C.byref(pd.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                       (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*NCELL), ws, None)
+        pd = srt
+    fn = oracle._dll.orc_gather_push_lens
+    fn.restype = C.c_int
+    for move in (1, 0):
+        before = pd.to_numpy()
+        pc = ParticleArrays.from_numpy(list(before), "cpu")
+        rc = fn(C.byref(pc.view), field_triplet(E), field_triplet(B), C.byref(g), C.c_double(q), C.c_double(m), C.c_double(dt),
+                order, 1, _capi.PUSHER_BORIS, move, ext6, C.byref(lens), C.c_double(time))
+        assert rc == 0
+        # the same push without the lens: the lens must matter for most particles, or the comparison proves nothing
+        pn = ParticleArrays.from_numpy(list(before), "cpu")
+        oracle._dll.orc_gather_push_ext.restype = C.c_int
+        oracle._dll.orc_gather_push_ext(C.byref(pn.view), field_triplet(E), field_triplet(B), C.byref(g), C.c_double(q),
+                                        C.c_double(m), C.c_double(dt), order, 1, _capi.PUSHER_BORIS, move, ext6)
+        product.gather_push_ws(C.byref(pd.view), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt, order, 1,
+                               _capi.PUSHER_BORIS, move, ws, None)
+        _sync(product)
+        a, b, c0 = pd.to_numpy(), pc.to_numpy(), pn.to_numpy()
+        touched = np.mean(np.abs(b[4] - c0[4]) > 1e-6 * np.abs(c0[4]))
+        assert 0.25 < touched < 0.95, touched
+        for row in range(7):
+            assert np.max(np.abs(a[row] - b[row])) <= 1e-12 * max(np.max(np.abs(b[row])), 1e-300), (move, row)
     product.workspace_destroy(ws)
 
 

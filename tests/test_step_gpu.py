@@ -378,6 +378,9 @@ def test_picmi_langmuir_golden_on_gpu(oracle, product):
     # reproduced digit for digit by the CPU kernels but not by contracted / rsqrt device arithmetic
     ("particle_pusher_3d.inputs", "particle_pusher_3d_checksums.json", ("particle_momentum_x", "particle_position_x")),
     ("radiation_reaction_3d.inputs", "radiation_reaction_3d_checksums.json", ()),
+    ("plasma_lens_3d.inputs", "plasma_lens_3d_checksums.json", ()),
+    ("plasma_lens_short_3d.inputs", "plasma_lens_short_3d_checksums.json", ()),
+    ("plasma_lens_boosted_3d.inputs", "plasma_lens_boosted_3d_checksums.json", ()),
 ])
 def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden, skip):
     """tests/decks/*.inputs through wxa_sim_create_from_inputs, wxa_sim_evolve and wxa_sim_checksum_json on the HIP
@@ -392,6 +395,12 @@ def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden
         # the gate of the reference's analysis script (Examples/Tests/particle_pusher/analysis.py): the force-free orbit
         # stays straight with the Higuera-Cary pusher, |x| < 1e-3 m after 10^4 steps (Boris drifts by 2321 m)
         assert got["positron"]["particle_position_x"] < 1e-3
+    if deck.startswith("plasma_lens"):
+        # the gate of Examples/Tests/plasma_lens/analysis.py: the thick-lens orbit
+        from tests.test_inputs_cpu import lens_orbit_errors
+        short = "short" in deck
+        errs, (ptol, vtol) = lens_orbit_errors(sim, gamma_boost=2.0 if "boosted" in deck else 1.0, short=short)
+        assert errs[0] < ptol and errs[1] < ptol and errs[2] < vtol and errs[3] < vtol, errs
     sim.close()
 
 

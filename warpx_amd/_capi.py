@@ -69,6 +69,7 @@ class SimConfig(C.Structure):
         ("overlap_halo", C.c_int32),
         ("grid_type", C.c_int32),
         ("maxwell_solver", C.c_int32),
+        ("gamma_boost", C.c_double),
     ]
 
 
@@ -78,6 +79,20 @@ class MovingWindow(C.Structure):
 
 class PlasmaInjector(C.Structure):
     _fields_ = [("density", C.c_double), ("ppc", C.c_int32 * 3), ("lo", C.c_double * 3), ("hi", C.c_double * 3)]
+
+
+class RepeatedPlasmaLens(C.Structure):
+    _fields_ = [("n_lenses", C.c_int32), ("period", C.c_double), ("starts", C.POINTER(C.c_double)),
+                ("lengths", C.POINTER(C.c_double)), ("strengths_E", C.POINTER(C.c_double)),
+                ("strengths_B", C.POINTER(C.c_double)), ("gamma_boost", C.c_double), ("dt", C.c_double)]
+
+    @classmethod
+    def make(cls, period, starts, lengths, strengths_E, strengths_B, gamma_boost, dt):
+        n = len(starts)
+        arrays = [(C.c_double * n)(*map(float, a)) for a in (starts, lengths, strengths_E, strengths_B)]
+        lens = cls(n, float(period), *[C.cast(a, C.POINTER(C.c_double)) for a in arrays], float(gamma_boost), float(dt))
+        lens._keep = arrays
+        return lens
 
 
 class InjectedMomentum(C.Structure):
@@ -206,6 +221,8 @@ _SIM_SIGS = {
 # product-only entry points
 _PRODUCT_SIGS = {
     "workspace_set_external_particle_fields": (C.c_int, [C.c_void_p, _D3, _D3]),
+    "workspace_set_repeated_plasma_lens": (C.c_int, [C.c_void_p, C.POINTER(RepeatedPlasmaLens)]),
+    "workspace_set_time": (C.c_int, [C.c_void_p, C.c_double]),
     "workspace_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "workspace_destroy": (None, [C.c_void_p]),
     "last_error": (C.c_char_p, []),

@@ -108,6 +108,10 @@ public:
         m_ctx.galerkin_interpolation = cfg.galerkin != 0;
         m_ctx.particle_pusher_algo = (ParticlePusherAlgo)cfg.particle_pusher;
         m_ctx.current_deposition_algo = (CurrentDepositionAlgo)cfg.current_deposition;
+        if (cfg.gamma_boost > 1.0) {   // ReadBoostedFrameParameters (WarpXUtil.cpp:114-141), boost along z
+            m_ctx.gamma_boost = cfg.gamma_boost;
+            m_ctx.beta_boost = std::sqrt(1.0 - 1.0 / std::pow(cfg.gamma_boost, 2.0));
+        }
         amrex::IntVect blo, bhi;
         for (int d = 0; d < 3; ++d) {
             if (cfg.nbricks[d] < 1 || cfg.coord[d] < 0 || cfg.coord[d] >= cfg.nbricks[d])
@@ -223,6 +227,7 @@ public:
             if (step == numsteps_max - 1) Synchronize();
             ++istep;
             cur_time += dt[0];
+            m_ctx.t_new = cur_time;
             const bool move_j = is_synchronized;
             const int num_moved = MoveWindow(istep, move_j);     // :246 MoveWindow(step+1, move_j)
             HandleParticlesAtBoundaries(step, cur_time, num_moved);  // :256

@@ -286,6 +286,27 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     pp.getArrWithParser("geometry.prob_hi", v, 3);
     for (int d = 0; d < 3; ++d) cfg.prob_hi[d] = v[d];
     std::string w;
+    // ---- boosted frame (ReadBoostedFrameParameters + ConvertLabParamsToBoost, WarpXUtil.cpp:114-141,180-262) ----
+    double gamma_boost = 1.0, beta_boost = 0.0;
+    if (pp.queryWithParser("warpx.gamma_boost", gamma_boost) && gamma_boost > 1.0) {
+        beta_boost = std::sqrt(1.0 - 1.0 / std::pow(gamma_boost, 2.0));
+        if (!pp.query_word("warpx.boost_direction", w)) throw std::runtime_error("inputs: warpx.boost_direction must be set");
+        if (w != "z") throw std::runtime_error("inputs: The boost must be in the z direction.");
+        int window = 0;
+        pp.queryWithParser("warpx.do_moving_window", window);
+        double beta_window = beta_boost;
+        if (window) {
+            std::string wd;
+            if (pp.query_word("warpx.moving_window_dir", wd) && wd == "z") beta_window = pp.getWithParser("warpx.moving_window_v");
+        }
+        const double convert_factor = 1.0 / (gamma_boost * (1 - beta_boost * beta_window));
+        cfg.prob_lo[2] *= convert_factor;
+        cfg.prob_hi[2] *= convert_factor;
+        cfg.gamma_boost = gamma_boost;
+    } else {
+        gamma_boost = 1.0;
+        pp.ignore("warpx.boost_direction");
+    }
     if (pp.query_word("geometry.coord_sys", w) && w != "0" && w != "cartesian")
         throw std::runtime_error("inputs: only cartesian geometry is on this path");
 
@@ -370,9 +391,6 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                             "particles.use_fdtd_nci_corr", "warpx.do_electrostatic", "warpx.do_multi_J"})
         if (pp.queryWithParser(key, flag) && flag)
             throw std::runtime_error(std::string("inputs: ") + key + " = 1 is not on this path");
-    double gamma_boost = 1.0;
-    if (pp.queryWithParser("warpx.gamma_boost", gamma_boost) && gamma_boost > 1.0)
-        throw std::runtime_error("inputs: a boosted frame (warpx.gamma_boost) is not on this path");
 
     info.max_step = -1;
     pp.queryWithParser("max_step", info.max_step);
@@ -443,14 +461,17 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     // (MultiParticleContainer::ReadParameters, MultiParticleContainer.cpp:120-160): the same for every species
     double ext_E[3] = {0, 0, 0}, ext_B[3] = {0, 0, 0};
     bool any_ext = false;
+    bool lens_style[2] = {false, false};
     {
         const char* style[2] = {"particles.E_ext_particle_init_style", "particles.B_ext_particle_init_style"};
         const char* value[2] = {"particles.E_external_particle", "particles.B_external_particle"};
         double* dst[2] = {ext_E, ext_B};
         for (int f = 0; f < 2; ++f) {
             if (!pp.query_word(style[f], w) || w == "none" || w == "default") continue;
+            if (w == "repeatedplasmalens") { lens_style[f] = true; continue; }
             if (w != "constant")
-                throw std::runtime_error(std::string("inputs: ") + style[f] + " = " + w + " is not on this path (constant)");
+                throw std::runtime_error(std::string("inputs: ") + style[f] + " = " + w +
+                                         " is not on this path (constant, repeated_plasma_lens)");
             std::vector<double> v;
             if (!pp.queryArrWithParser(value[f], v) || v.size() != 3)
                 throw std::runtime_error(std::string("inputs: ") + value[f] + " needs three values");
@@ -459,8 +480,46 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         }
     }
 
-    // ---- species (PlasmaInjector.cpp, PhysicalParticleContainer::AddParticles) ----
+    // particles.repeated_plasma_lens_* (MultiParticleContainer.cpp:210-260): the strengths are read only for the field
+    // whose style asks for the lens, the other one stays zero
+    wxa_repeated_plasma_lens lens{};
+    std::vector<double> lens_starts, lens_lengths, lens_sE, lens_sB;
+    if (lens_style[0] || lens_style[1]) {
+        lens.period = pp.getWithParser("particles.repeated_plasma_lens_period");
+        if (!(lens.period > 0.0)) throw std::runtime_error("inputs: particles.repeated_plasma_lens_period must be > 0");
+        if (!pp.queryArrWithParser("particles.repeated_plasma_lens_starts", lens_starts) ||
+            !pp.queryArrWithParser("particles.repeated_plasma_lens_lengths", lens_lengths))
+            throw std::runtime_error("inputs: particles.repeated_plasma_lens_starts and _lengths must be set");
+        const size_t n = lens_starts.size();
+        if (lens_lengths.size() != n) throw std::runtime_error("inputs: particles.repeated_plasma_lens_* lengths differ");
+        lens_sE.assign(n, 0.0);
+        lens_sB.assign(n, 0.0);
+        const char* keys[2] = {"particles.repeated_plasma_lens_strengths_E", "particles.repeated_plasma_lens_strengths_B"};
+        std::vector<double>* dst[2] = {&lens_sE, &lens_sB};
+        for (int f = 0; f < 2; ++f) {
+            if (!lens_style[f]) { pp.ignore(keys[f]); continue; }
+            if (!pp.queryArrWithParser(keys[f], *dst[f]) || dst[f]->size() != n)
+                throw std::runtime_error(std::string("inputs: ") + keys[f] + " needs one value per lens");
+        }
+        lens.n_lenses = (int32_t)n;
+        lens.starts = lens_starts.data(); lens.lengths = lens_lengths.data();
+        lens.strengths_E = lens_sE.data(); lens.strengths_B = lens_sB.data();
+    }
     const double c = 299'792'458.;
+    // MapParticletoBoostedFrame (PhysicalParticleContainer.cpp:456-500) with t_lab = 0, at simulation time t0 = 0,
+    // boost_adjust_transverse_positions off, forward propagation: single / multiple particles are given in the lab frame
+    auto map_to_boosted_frame = [&](double pos[3], double u[3]) {
+        const double uz_boost = gamma_boost * beta_boost * c;
+        const double t_lab = 0.0, t0 = wx.gett_new();
+        const double tpr = gamma_boost * t_lab - uz_boost * pos[2] / (c * c);
+        const double zpr = gamma_boost * pos[2] - uz_boost * t_lab;
+        const double gamma_lab = std::sqrt(1.0 + (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) / (c * c));
+        u[2] = gamma_boost * u[2] - uz_boost * gamma_lab;
+        const double gammapr = std::sqrt(1.0 + (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) / (c * c));
+        const double vzpr = u[2] / gammapr;
+        pos[2] = zpr - (tpr - t0) * vzpr;
+    };
+    // ---- species (PlasmaInjector.cpp, PhysicalParticleContainer::AddParticles) ----
     for (const std::string& name : species_names) {
         double charge = 0.0, mass = 0.0;
         bool have_q = false, have_m = false;
@@ -488,21 +547,27 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
 
         const int sid = wx.GetPartContainer().AddSpecies(charge, mass);
         if (any_ext) wx.GetPartContainer().GetParticleContainer(sid).SetExternalParticleFields(ext_E, ext_B);
+        if (lens.n_lenses > 0) wx.GetPartContainer().GetParticleContainer(sid).SetRepeatedPlasmaLens(lens, wx.getdt(0));
         double crr = 0;
         if (pp.queryWithParser(name + ".do_classical_radiation_reaction", crr) && crr != 0)
             wx.GetPartContainer().GetParticleContainer(sid).SetRadiationReaction(true);
         auto* pc = dynamic_cast<PhysicalParticleContainer*>(&wx.GetPartContainer().GetParticleContainer(sid));
         if (!pp.query_word(name + ".injection_style", w)) throw std::runtime_error("inputs: " + name + ".injection_style must be set");
         std::vector<double> cols[7];
-        auto add_if_mine = [&](const double pos[3], const double u[3], double weight) {
+        auto add_if_mine = [&](const double pos_in[3], const double u_in[3], double weight) {
+            double pos[3] = {pos_in[0], pos_in[1], pos_in[2]};
+            double u[3] = {u_in[0] * c, u_in[1] * c, u_in[2] * c};          // setupSingleParticle: u *= c
+            if (gamma_boost > 1.0) map_to_boosted_frame(pos, u);           // AddParticles, :862-893
             // AddNParticles keeps the particles of this rank's boxes: here [brick_plo, brick_phi)
             for (int d = 0; d < 3; ++d)
                 if (!(pos[d] >= ctx.brick_plo[d] && pos[d] < ctx.brick_phi[d])) return;
             for (int d = 0; d < 3; ++d) cols[d].push_back(pos[d]);
             cols[3].push_back(weight);
-            for (int d = 0; d < 3; ++d) cols[4 + d].push_back(u[d] * c);   // setupSingleParticle: u *= c
+            for (int d = 0; d < 3; ++d) cols[4 + d].push_back(u[d]);
         };
         if (w == "nuniformpercell") {
+            if (gamma_boost > 1.0)
+                throw std::runtime_error("inputs: " + name + ": NUniformPerCell injection in a boosted frame is not on this path");
             wxa_plasma_injector inj{};
             pp.getArrWithParser(name + ".num_particles_per_cell_each_dim", v, 3);
             for (int d = 0; d < 3; ++d) inj.ppc[d] = ParmParse::safe_int(v[d], name + ".num_particles_per_cell_each_dim");
@@ -590,6 +655,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
 
     // ---- laser antennas (LaserParticleContainer.cpp:70-250) ----
     for (const std::string& name : laser_names) {
+        if (gamma_boost > 1.0) throw std::runtime_error("inputs: " + name + ": a laser antenna in a boosted frame is not on this path");
         if (!pp.query_word(name + ".profile", w) || w != "gaussian")
             throw std::runtime_error("inputs: " + name + ".profile must be Gaussian on this path");
         wxa_laser_antenna la{};

@@ -38,6 +38,9 @@ struct WarpXContext {
     int32_t particle_bc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     int32_t particle_bc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     bool any_particle_wall = false;
+    // warpx.gamma_boost / beta_boost (boost along z, WarpXUtil.cpp:114-141) and warpx.gett_new(0)
+    double gamma_boost = 1.0, beta_boost = 0.0;
+    double t_new = 0.0;
     // per-phase device timers, named after the reference's profiler regions
     bool timers_on = false;
     double ms[8] = {0};
@@ -167,6 +170,20 @@ public:
     void SetDepositAccumulator(int32_t acc) {
         if (!m_ctx->be->ws_set_deposit_accumulator) throw std::runtime_error("deposit accumulator: not in this backend");
         check(m_ctx->be->ws_set_deposit_accumulator(m_ws, acc), "ws_set_deposit_accumulator");
+    }
+    // particles.*_ext_particle_init_style = repeated_plasma_lens (MultiParticleContainer.cpp:210-260): lens.gamma_boost
+    // and lens.dt are filled in here from the run's own values
+    void SetRepeatedPlasmaLens(wxa_repeated_plasma_lens lens, double level_dt) {
+        if (!m_ctx->be->ws_set_repeated_plasma_lens || !m_ctx->be->ws_set_time)
+            throw std::runtime_error("repeated plasma lens: not in this backend");
+        lens.gamma_boost = m_ctx->gamma_boost;
+        lens.dt = level_dt;
+        check(m_ctx->be->ws_set_repeated_plasma_lens(m_ws, &lens), "ws_set_repeated_plasma_lens");
+        m_time_dependent_ext = lens.n_lenses > 0;
+    }
+    // m_time of GetExternalEBField (GetExternalFields.cpp:43), before a push
+    void stamp_external_time() {
+        if (m_time_dependent_ext) check(m_ctx->be->ws_set_time(m_ws, m_ctx->t_new), "ws_set_time");
     }
     void SetExternalParticleFields(const double E[3], const double B[3]) {
         if (!m_ctx->be->ws_set_external_eb) throw std::runtime_error("external particle fields: not in this backend");
@@ -388,6 +405,7 @@ protected:
     int32_t m_steps_since_sort = -1;   // Redistribute calls since the last cell sort (-1: never sorted)
     void* m_ws = nullptr;
     bool m_do_crr = false;
+    bool m_time_dependent_ext = false;   // an external field on the particles that depends on the time (boosted lens)
 
 public:
     amrex::ParticleReal charge, mass;
@@ -557,6 +575,7 @@ public:
         const wxa_field_view B[3] = {Bx.view(), By.view(), Bz.view()};
         const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
         const wxa_particle_view p = m_tile.view();
+        stamp_external_time();
         if (m_interior_pushed) {   // PushInterior ran on these particles already: the rest
             m_interior_pushed = false;
             check(m_ctx->be->gather_push_part(&p, E, B, &g, charge, mass, dt, m_ctx->nox,
@@ -581,6 +600,7 @@ public:
         const wxa_field_view B[3] = {Bf[0]->view(), Bf[1]->view(), Bf[2]->view()};
         const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
         const wxa_particle_view p = m_tile.view();
+        stamp_external_time();
         check(m_ctx->be->gather_push_part(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
                                           pusher_algo(), m_ws, WXA_PART_INTERIOR, m_ctx->stream),
               "gather_push_part");
@@ -596,6 +616,7 @@ public:
         const wxa_field_view B[3] = {Bx.view(), By.view(), Bz.view()};
         const wxa_grid_geom g = m_ctx->geom(m_ctx->ng_alloc_EB);
         const wxa_particle_view p = m_tile.view();
+        stamp_external_time();
         check(m_ctx->be->gather_push(&p, E, B, &g, charge, mass, dt, m_ctx->nox, m_ctx->galerkin_interpolation ? 1 : 0,
                                      pusher_algo(), /*move=*/0, m_ws, m_ctx->stream),
               "push_p");

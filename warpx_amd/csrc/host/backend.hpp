@@ -33,6 +33,10 @@ struct Backend {
                         const double* cz, void*);
     // constant external fields of the container that owns workspace `ws` (wxa_workspace_set_external_particle_fields)
     int (*ws_set_external_eb)(void* ws, const double* E, const double* B);
+    // optional: repeated plasma lens of that container and the time its fields are evaluated at
+    // (wxa_workspace_set_repeated_plasma_lens, wxa_workspace_set_time)
+    int (*ws_set_repeated_plasma_lens)(void* ws, const wxa_repeated_plasma_lens*) = nullptr;
+    int (*ws_set_time)(void* ws, double t) = nullptr;
     // optional: accumulator type of the LDS-tile deposition of that container (wxa_workspace_set_deposit_accumulator)
     int (*ws_set_deposit_accumulator)(void* ws, int32_t acc) = nullptr;
     // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace

@@ -76,6 +76,9 @@ const Backend* hip_backend() {
                         const double* di, void* st) -> int { return wxa_evolve_e(E, B, J, dt, di, st); };
         b.ws_set_external_eb = [](void* ws, const double* E, const double* B) -> int {
             return wxa_workspace_set_external_particle_fields(static_cast<wxa_workspace*>(ws), E, B); };
+        b.ws_set_repeated_plasma_lens = [](void* ws, const wxa_repeated_plasma_lens* lens) -> int {
+            return wxa_workspace_set_repeated_plasma_lens(static_cast<wxa_workspace*>(ws), lens); };
+        b.ws_set_time = [](void* ws, double t) -> int { return wxa_workspace_set_time(static_cast<wxa_workspace*>(ws), t); };
         b.ws_set_deposit_accumulator = [](void* ws, int32_t acc) -> int {
             return wxa_workspace_set_deposit_accumulator(static_cast<wxa_workspace*>(ws), acc); };
         b.ckc_stencil_coefficients = wxa_ckc_stencil_coefficients;

@@ -23,7 +23,7 @@ gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, G
     double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
     gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
 
-    Exp += ext.ex; Eyp += ext.ey; Ezp += ext.ez; Bxp += ext.bx; Byp += ext.by; Bzp += ext.bz;
+    add_external_fields(ext, ip, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
     double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
     push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
@@ -31,6 +31,16 @@ gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, G
         update_position(xp, yp, zp, ux, uy, uz, dt);
         p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp;
     }
+}
+
+// The repeated plasma lens seen by every particle before the push (add_lens_fields, shapes.hpp):
+// out[c * stride + ip], c = Ex Ey Bx By
+__global__ void __launch_bounds__(256) lens_fields_kernel(PV p, ExtLens L, double* __restrict__ out, long stride) {
+    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.np) return;
+    double Ex = 0., Ey = 0., Bx = 0., By = 0.;
+    add_lens_fields(L, p.x[ip], p.y[ip], p.z[ip], p.ux[ip], p.uy[ip], p.uz[ip], Ex, Ey, Bx, By);
+    out[ip] = Ex; out[stride + ip] = Ey; out[2 * stride + ip] = Bx; out[3 * stride + ip] = By;
 }
 
 // ---------------------------------------------------------------------------
@@ -480,6 +490,21 @@ static wxa_status launch_gather_push(const PV& pv, const wxa_field_view E[3], co
     return WXA_OK;
 }
 
+// per-particle external fields of the push that follows (none unless the workspace carries a lens)
+static wxa_status evaluate_particle_fields(const wxa_particle_view* p, wxa_workspace* ws, hipStream_t st) {
+    if (!ws) return WXA_OK;
+    ws->ext_pp_stride = 0;
+    if (ws->lens_n <= 0 || p->np == 0) return WXA_OK;
+    wxa_status rc;
+    if ((rc = ws->ext_pp.reserve(sizeof(double) * 4 * (size_t)p->np)) != WXA_OK) return rc;
+    const PV pv = make_pv(*p);
+    hipLaunchKernelGGL(lens_fields_kernel, dim3(blocks_for(pv.np)), dim3(256), 0, st, pv, lens_of(ws), (double*)ws->ext_pp.p,
+                       (long)p->np);
+    WXA_LAUNCH_CHECK();
+    ws->ext_pp_stride = p->np;
+    return WXA_OK;
+}
+
 static wxa_status check_gather_args(const wxa_particle_view* p, const wxa_field_view E[3],
                                     const wxa_field_view B[3], const wxa_grid_geom* geom, int order,
                                     int galerkin, int pusher) {
@@ -531,7 +556,9 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E
     wxa_status rc = check_gather_args(p, E, B, geom, order, galerkin, pusher);
     if (rc != WXA_OK) return rc;
     if (p->np == 0) return WXA_OK;
+    if ((rc = evaluate_particle_fields(p, ws, (hipStream_t)stream)) != WXA_OK) return rc;
     wxa_particle_view rest = *p;
+    int64_t first = 0;
     if (gather_tile_available(ws, p)) {
         // sorted part on the LDS tiles; particles appended since the sort (arrivals from the
         // neighbouring bricks) take the global-memory kernel below
@@ -542,9 +569,10 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E
                                     (hipStream_t)stream)) != WXA_OK)
             return rc;
         rest = tail_view(*p, ws->sorted_np);
+        first = ws->sorted_np;
         if (rest.np == 0) return WXA_OK;
     }
-    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, move, ext_of(ws), (hipStream_t)stream);
+    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, move, ext_of(ws, first), (hipStream_t)stream);
 }
 
 wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
@@ -554,6 +582,7 @@ wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view
     if (rc != WXA_OK) return rc;
     WXA_REQUIRE(part == WXA_PART_INTERIOR || part == WXA_PART_REST, "part must be WXA_PART_INTERIOR or WXA_PART_REST");
     if (p->np == 0) return WXA_OK;
+    if ((rc = evaluate_particle_fields(p, ws, (hipStream_t)stream)) != WXA_OK) return rc;
     if (!gather_tile_available(ws, p)) {   // no tiles: the interior part is empty, the rest is everything
         if (part == WXA_PART_INTERIOR) return WXA_OK;
         return gather_push_global(*p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws), (hipStream_t)stream);
@@ -567,7 +596,7 @@ wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view
     if (part == WXA_PART_INTERIOR) return WXA_OK;
     const wxa_particle_view rest = tail_view(*p, ws->sorted_np);   // arrivals since the sort may sit anywhere
     if (rest.np == 0) return WXA_OK;
-    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws), (hipStream_t)stream);
+    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws, ws->sorted_np), (hipStream_t)stream);
 }
 
 wxa_status wxa_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],

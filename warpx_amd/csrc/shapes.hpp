@@ -236,9 +236,76 @@ __device__ __forceinline__ void push_momentum(double& ux, double& uy, double& uz
 // particles.E_external_particle / B_external_particle (constant): members of the container in the reference
 // (m_E_external_particle, PhysicalParticleContainer.cpp:2589-2596,2705-2710).  The reference starts the gather sums
 // from these values; here they are added to the gathered sums (same value, last-bit differences in the rounding).
+// particles.*_ext_particle_init_style = repeated_plasma_lens (include/warpx_amd.h, wxa_repeated_plasma_lens);
+// tab = starts | lengths | strengths_E | strengths_B, n entries each, device memory
+struct ExtLens {
+    int n;
+    double period, time, dt, gamma_boost, uz_boost;
+    const double* tab;
+};
+// fields[c * stride + ip], c = Ex Ey Bx By: per-particle external fields evaluated by a kernel of their own before the push
+// (lens_fields_kernel, particles.hip); null = none.  Kept out of the gather kernels: with the lens arithmetic inlined
+// the tile kernel went from 93 to 255 VGPRs and the global-memory one from 102 to 256.
+struct ExtPerParticle {
+    const double* fields;
+    long stride;
+};
 struct ExtEB {
     double ex, ey, ez, bx, by, bz;
+    ExtPerParticle pp;
 };
+__device__ __forceinline__ void add_external_fields(const ExtEB& ext, long ip, double& Ex, double& Ey, double& Ez, double& Bx,
+                                                    double& By, double& Bz) {
+    Ex += ext.ex; Ey += ext.ey; Ez += ext.ez; Bx += ext.bx; By += ext.by; Bz += ext.bz;
+    // the gathered sums are complete here: without the pins the compiler sinks their tails past the branch below and the
+    // register allocation of the 252-point gather falls apart (93 -> 247 VGPRs in the tile kernel)
+    WXA_OPAQUE_F64(Ex); WXA_OPAQUE_F64(Ey); WXA_OPAQUE_F64(Ez); WXA_OPAQUE_F64(Bx); WXA_OPAQUE_F64(By); WXA_OPAQUE_F64(Bz);
+    if (ext.pp.fields) {   // uniform
+        Ex += ext.pp.fields[ip];
+        Ey += ext.pp.fields[ext.pp.stride + ip];
+        Bx += ext.pp.fields[2 * ext.pp.stride + ip];
+        By += ext.pp.fields[3 * ext.pp.stride + ip];
+    }
+}
+
+// GetExternalEBField::operator() (Source/Particles/Gather/GetExternalFields.H:137-189): the lens fields seen by a
+// particle at (x, y, z) with momentum u before the push, added to the gathered fields
+__device__ __forceinline__ void add_lens_fields(const ExtLens& L, const double x, const double y, const double z,
+                                                const double ux, const double uy, const double uz, double& fEx,
+                                                double& fEy, double& fBx, double& fBy) {
+    constexpr double inv_c2 = 1. / (PhysConst::c * PhysConst::c);
+    const double gamma = sqrt(1. + (ux * ux + uy * uy + uz * uz) * inv_c2);
+    const double vzp = uz / gamma;
+    double zl = z, zr = z + vzp * L.dt;
+    if (L.gamma_boost > 1.) {
+        zl = L.gamma_boost * zl + L.uz_boost * L.time;
+        zr = L.gamma_boost * zr + L.uz_boost * (L.time + L.dt);
+    }
+    double Ex = 0., Ey = 0., Bx = 0., By = 0.;
+    if (zl > 0) {
+        const int i_lens = (int)floor(zl / L.period);
+        if (i_lens < L.n) {
+            const double lens_start = L.tab[i_lens] + i_lens * L.period;
+            const double lens_end = lens_start + L.tab[L.n + i_lens];
+            const double zl_bounded = fmin(fmax(zl, lens_start), lens_end);
+            const double zr_bounded = fmin(fmax(zr, lens_start), lens_end);
+            const double frac = (zr - zl) == 0. ? 1. : (zr_bounded - zl_bounded) / (zr - zl);
+            const double sE = L.tab[2 * L.n + i_lens], sB = L.tab[3 * L.n + i_lens];
+            Ex = x * frac * sE;
+            Ey = y * frac * sE;
+            Bx = +y * frac * sB;
+            By = -x * frac * sB;
+        }
+    }
+    if (L.gamma_boost > 1.) {
+        const double Ex_boost = L.gamma_boost * Ex - L.uz_boost * By;
+        const double Ey_boost = L.gamma_boost * Ey + L.uz_boost * Bx;
+        const double Bx_boost = L.gamma_boost * Bx + L.uz_boost * Ey * inv_c2;
+        const double By_boost = L.gamma_boost * By - L.uz_boost * Ex * inv_c2;
+        Ex = Ex_boost; Ey = Ey_boost; Bx = Bx_boost; By = By_boost;
+    }
+    fEx += Ex; fEy += Ey; fBx += Bx; fBy += By;
+}
 
 // Source/Particles/Pusher/UpdatePosition.H:24-45
 __device__ __forceinline__ void update_position(double& x, double& y, double& z, const double ux,

@@ -43,14 +43,43 @@ struct wxa_workspace {
     // particles.E_external_particle / B_external_particle of the container that owns this workspace
     // (wxa_workspace_set_external_particle_fields); added to the gathered fields in PushPX / PushP
     double ext_eb[6] = {0, 0, 0, 0, 0, 0};
+    // repeated plasma lens of that container (wxa_workspace_set_repeated_plasma_lens) and the time its fields are
+    // evaluated at (wxa_workspace_set_time)
+    wxa::DevBuf lens_tab, ext_pp;   // ext_pp: per-particle external fields of the current push (4 x np)
+    int32_t lens_n = 0;
+    double lens_period = 0, lens_dt = 0, lens_gamma_boost = 1, ext_time = 0;
+    int64_t ext_pp_stride = 0;
     // accumulator type of the LDS-tile Esirkepov deposition (wxa_workspace_set_deposit_accumulator)
     int32_t deposit_accumulator = WXA_ACC_FP64;
 };
 
 namespace wxa {
+// external fields of a push: the constants, and the per-particle ones once evaluate_particle_fields (particles.hip) has run
 inline ExtEB ext_of(const wxa_workspace* ws) {
-    if (!ws) return ExtEB{0, 0, 0, 0, 0, 0};
-    return ExtEB{ws->ext_eb[0], ws->ext_eb[1], ws->ext_eb[2], ws->ext_eb[3], ws->ext_eb[4], ws->ext_eb[5]};
+    ExtEB e{};
+    if (!ws) return e;
+    e.ex = ws->ext_eb[0]; e.ey = ws->ext_eb[1]; e.ez = ws->ext_eb[2];
+    e.bx = ws->ext_eb[3]; e.by = ws->ext_eb[4]; e.bz = ws->ext_eb[5];
+    if (ws->lens_n > 0 && ws->ext_pp_stride > 0) e.pp = ExtPerParticle{(const double*)ws->ext_pp.p, ws->ext_pp_stride};
+    return e;
+}
+// the same for a view that starts `first` particles into the array the per-particle fields were evaluated on
+inline ExtEB ext_of(const wxa_workspace* ws, int64_t first) {
+    ExtEB e = ext_of(ws);
+    if (e.pp.fields) e.pp.fields += first;
+    return e;
+}
+inline ExtLens lens_of(const wxa_workspace* ws) {
+    ExtLens L{};
+    L.n = ws->lens_n;
+    L.period = ws->lens_period;
+    L.time = ws->ext_time;
+    L.dt = ws->lens_dt;
+    L.gamma_boost = ws->lens_gamma_boost;
+    // m_uz_boost (GetExternalFields.cpp:28)
+    L.uz_boost = std::sqrt(ws->lens_gamma_boost * ws->lens_gamma_boost - 1.0) * PhysConst::c;
+    L.tab = (const double*)ws->lens_tab.p;
+    return L;
 }
 // LDS-tile deposition (deposit_tile.hip)
 bool deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p);
