@@ -50,16 +50,18 @@ __device__ __forceinline__ double gather_rows(const double* __restrict__ base, l
     double acc = 0.0;
 #pragma unroll
     for (int iz = 0; iz < NZ; ++iz) {
+        double plane = 0.0;
 #pragma unroll
         for (int iy = 0; iy < NY; ++iy) {
             const double* __restrict__ row = base + iy * js + iz * ks;
             double r = 0.0;
 #pragma unroll
             for (int ix = 0; ix < NX; ++ix) r += sx[ix] * row[ix];
-            // sy (sz r), not (sy sz) r: the products sy sz are common to several components, and the compiler kept all 49
-            // of them alive across the six gathers when they could be shared (125 VGPRs; 93 this way)
-            acc += sy[iy] * (sz[iz] * r);
+            // sz (sum_y sy r): one fma per row and one per plane.  (sy sz) r is what the reference writes; its products
+            // sy sz are common to several components and the compiler kept all 49 of them alive (125 VGPRs)
+            plane += sy[iy] * r;
         }
+        acc += sz[iz] * plane;
     }
     return acc;
 }

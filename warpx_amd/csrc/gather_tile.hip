@@ -9,9 +9,11 @@
 // gathers from LDS (same-cell lanes broadcast).  Particles whose stencil leaves the staged range
 // (stale sort, particles wrapped across the periodic boundary) are queued and handled by a second
 // kernel with global loads, so correctness never depends on the sort being fresh.
-// (Tried and rejected: reading the rows with inline-asm single ds_read_b64 to avoid the
-// half-rate ds_read2_b64 the compiler emits -- the coarse s_waitcnt it needs cost more than the
-// LDS cycles it saved: 6.3 ms vs 5.6 ms per launch at 256^3 x 8 ppc.)
+// (Tried and rejected, ms per launch at 256^3 x 8 ppc against 5.9: rows read with inline-asm single ds_read_b64 instead of
+// the ds_read2_b64 the compiler emits, 6.3 (the coarse s_waitcnt it needs); 640 lanes per tile = 5 waves per SIMD, 5.9;
+// the next particle's position and momentum loaded while the current one gathers (127 VGPRs), 6.2; two particles of a
+// cell per lane sharing the LDS reads, 9.95.  Counters, profiles/round2/r2g_pmc_128cube_gather_tile_kernel.txt: 8 LDS
+// cycles per ds instruction and 0.2 % bank conflicts, the LDS busy 60 % and the VALU 50 % of the kernel's time.)
 #include "gather_body.hpp"
 #include "workspace.hpp"
 
@@ -46,11 +48,10 @@ struct GatherStragglers {
 };
 
 template <int PUSHER, bool MOVE>
-__device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, double yp, double zp, double Exp,
-                                               double Eyp, double Ezp, double Bxp, double Byp, double Bzp, double q,
-                                               double m, double dt, const ExtEB& ext) {
+__device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, double yp, double zp, double ux, double uy,
+                                               double uz, double Exp, double Eyp, double Ezp, double Bxp, double Byp,
+                                               double Bzp, double q, double m, double dt, const ExtEB& ext) {
     add_external_fields(ext, ip, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
-    double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
     push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
     if constexpr (MOVE) {
@@ -65,8 +66,8 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // point, even as stragglers: a particle is at most a few cells from the tile it was sorted into); 2 = only
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
-template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int NT = GT_THREADS>
-__global__ void __launch_bounds__(NT)
+template <int O, int G, int PUSHER, bool MOVE, int PART = 0>
+__global__ void __launch_bounds__(GT_THREADS)
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext) {
     constexpr int N = GatherTileDims<G>::N;
@@ -94,7 +95,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const DevF& f = *fld[c];
-        for (int a = tid; a < NPTS; a += NT) {
+        for (int a = tid; a < NPTS; a += GT_THREADS) {
             const int i = o0 + a % N, j = o1 + (a / N) % N, k = o2 + a / (N * N);
             const bool in = i >= f.lo0 && i < f.lo0 + f.n0 && j >= f.lo1 && j < f.lo1 + f.n1 && k >= f.lo2 &&
                             k < f.lo2 + f.n2;
@@ -103,7 +104,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     }
     __syncthreads();
 
-    for (int ip = start + tid; ip < end; ip += NT) {
+    for (int ip = start + tid; ip < end; ip += GT_THREADS) {
         const double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
         GatherShapes<O, G> s;
         gather_shapes<O, G>(xp, yp, zp, g, s);
@@ -123,7 +124,8 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const double Bzp = gather_rows<NC, NC, NN>(F + 5 * NPTS + jc + N * (kc + N * ln), N, N * N, s.sxc, s.syc, s.szn);
         const double Byp = gather_rows<NC, NN, NC>(F + 4 * NPTS + jc + N * (kn + N * lc), N, N * N, s.sxc, s.syn, s.szc);
         const double Bxp = gather_rows<NN, NC, NC>(F + 3 * NPTS + jn + N * (kc + N * lc), N, N * N, s.sxn, s.syc, s.szc);
-        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext);
+        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, p.ux[ip], p.uy[ip], p.uz[ip], Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt,
+                                     ext);
     }
 }
 
@@ -140,7 +142,8 @@ gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned*
         gather_shapes<O, G>(xp, yp, zp, g, s);
         double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
         gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
-        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext);
+        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, p.ux[ip], p.uy[ip], p.uz[ip], Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt,
+                                     ext);
     }
 }
 
@@ -177,14 +180,6 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);                     \
     } while (0)
-    // experiment: 640 lanes per tile (2 x 10 waves per CU = 5 per SIMD; the kernel needs 89 VGPRs)
-    static const int wide = std::getenv("WXA_GATHER_THREADS") ? std::atoi(std::getenv("WXA_GATHER_THREADS")) : 0;
-    if (wide == 640 && galerkin && order == 3 && PUSHER == WXA_PUSHER_BORIS && MOVE && PART == 0) {
-        hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, 640>), grid, dim3(640), 0, st, pv, offsets, ex,
-                           ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);
-        hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv,
-                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);
-    } else
     if (galerkin) {
         if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else WXA_GT(3, 1);
     } else {
