@@ -493,7 +493,14 @@ typedef struct wxa_moving_window {
 typedef struct wxa_plasma_injector {
     double  density;        /* <species>.density, m^-3              */
     int32_t ppc[3];         /* num_particles_per_cell_each_dim      */
-    double  lo[3], hi[3];   /* xmin,ymin,zmin / xmax,ymax,zmax (+-1e300 = unbounded) */
+    double  lo[3], hi[3];   /* xmin,ymin,zmin / xmax,ymax,zmax (+-1e300 = unbounded), lab frame */
+    double  gamma_boost;    /* warpx.gamma_boost (boost along z); 0 or 1 = lab frame.  Boosted frame (the branch at
+                               PhysicalParticleContainer.cpp:1210-1247): bounds and density are the lab-frame ones, looked
+                               up at z0_lab = gamma (z (1 - beta beta_bulk) - c t (beta_bulk - beta)); the density becomes
+                               gamma n (1 - beta beta_z) and u_z -> gamma (u_z - beta gamma_lab) per particle          */
+    double  t;              /* warpx.gett_new(lev) when the plasma is added: the ballistic correction
+                               (applyBallisticCorrection, :138-148) also moves the bounds of a lab-frame plasma with a
+                               bulk velocity along z                                                               */
 } wxa_plasma_injector;
 
 /* PhysicalParticleContainer::AddPlasma on the device for that injector: the particles of the `ncells` cells

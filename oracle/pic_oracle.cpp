@@ -828,7 +828,15 @@ int orc_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj,
     *n_added = 0;
     if (!(inj->density > 0)) return 0;
     const int nppc = inj->ppc[0] * inj->ppc[1] * inj->ppc[2];
-    const double weight = inj->density * (dx[0] * dx[1] * dx[2] / nppc);
+    const double scale_fac = dx[0] * dx[1] * dx[2] / nppc;
+    // applyBallisticCorrection (PhysicalParticleContainer.cpp:138-148) with the bulk momentum of the injector
+    const double gamma_boost = inj->gamma_boost > 1.0 ? inj->gamma_boost : 1.0;
+    const double beta_boost = gamma_boost > 1.0 ? std::sqrt(1.0 - 1.0 / std::pow(gamma_boost, 2.0)) : 0.0;
+    const double ub[3] = {mom ? mom->u_mean[0] : 0.0, mom ? mom->u_mean[1] : 0.0, mom ? mom->u_mean[2] : 0.0};
+    const double gamma_bulk = std::sqrt(1.0 + (ub[0] * ub[0] + ub[1] * ub[1] + ub[2] * ub[2]));
+    const double betaz_bulk = ub[2] / gamma_bulk;
+    const double za = 1.0 - beta_boost * betaz_bulk, zb = PhysConst::c * inj->t * (betaz_bulk - beta_boost);
+    auto ballistic = [&](double z) { return gamma_boost * (z * za - zb); };
     int64_t n = 0;
     for (int k = 0; k < ncells[2]; ++k)
         for (int j = 0; j < ncells[1]; ++j)
@@ -836,7 +844,8 @@ int orc_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj,
                 const int iv[3] = {i, j, k};
                 bool cell_ok = true;
                 for (int d = 0; d < 3; ++d) {
-                    const double clo = corner[d] + (iv[d] + 0.0) * dx[d], chi = corner[d] + (iv[d] + 1.0) * dx[d];
+                    double clo = corner[d] + (iv[d] + 0.0) * dx[d], chi = corner[d] + (iv[d] + 1.0) * dx[d];
+                    if (d == 2) { clo = ballistic(clo); chi = ballistic(chi); }   // :1021-1022
                     const double mid = (clo + chi) / 2.;
                     const bool sample = (clo < inj->hi[d] && clo >= inj->lo[d]) || (mid < inj->hi[d] && mid >= inj->lo[d]) ||
                                         (chi < inj->hi[d] && chi >= inj->lo[d]);
@@ -853,12 +862,13 @@ int orc_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj,
                     bool ok = true;
                     for (int d = 0; d < 3; ++d) {
                         pos[d] = corner[d] + (iv[d] + r[d]) * dx[d];
-                        ok = ok && pos[d] > brick_lo[d] && pos[d] < brick_hi[d] && pos[d] < inj->hi[d] && pos[d] >= inj->lo[d];
+                        const double lab = d == 2 ? ballistic(pos[d]) : pos[d];   // z0 / z0_lab of :1181, :1212
+                        ok = ok && pos[d] > brick_lo[d] && pos[d] < brick_hi[d] && lab < inj->hi[d] && lab >= inj->lo[d];
                     }
                     if (!ok) continue;
                     if (n >= dst->np) return -4;
-                    dst->x[n] = pos[0]; dst->y[n] = pos[1]; dst->z[n] = pos[2]; dst->w[n] = weight;
-                    double u[3] = {mom ? mom->u_mean[0] : 0.0, mom ? mom->u_mean[1] : 0.0, mom ? mom->u_mean[2] : 0.0};
+                    dst->x[n] = pos[0]; dst->y[n] = pos[1]; dst->z[n] = pos[2];
+                    double u[3] = {ub[0], ub[1], ub[2]};
                     if (thermal) {
                         double nrm[3];
                         normal3(mom->seed, (int)std::floor((pos[0] - mom->origin[0]) / dx[0] * inj->ppc[0]),
@@ -866,6 +876,14 @@ int orc_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj,
                                 (int)std::floor((pos[2] - mom->origin[2]) / dx[2] * inj->ppc[2]), nrm);
                         for (int d = 0; d < 3; ++d) u[d] += mom->u_th[d] * nrm[d];
                     }
+                    double dens = inj->density;
+                    if (gamma_boost > 1.0) {   // :1232-1246 Lorentz transform of the lab-frame density and momentum
+                        const double gamma_lab = std::sqrt(1.0 + (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]));
+                        const double betaz_lab = u[2] / gamma_lab;
+                        dens = gamma_boost * dens * (1.0 - beta_boost * betaz_lab);
+                        u[2] = gamma_boost * (u[2] - beta_boost * gamma_lab);
+                    }
+                    dst->w[n] = dens * scale_fac;
                     dst->ux[n] = u[0] * PhysConst::c; dst->uy[n] = u[1] * PhysConst::c; dst->uz[n] = u[2] * PhysConst::c;
                     if (dst->idcpu) dst->idcpu[n] = 0;
                     ++n;

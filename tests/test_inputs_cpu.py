@@ -253,6 +253,42 @@ def test_plasma_lens_orbits_follow_the_thick_lens_solution(lib, deck, boost, sho
     sim.close()
 
 
+def check_boosted_injection(sim):
+    """tests/decks/boosted_injection_3d.inputs after its 30 steps: every electron carries u_z = -gamma beta c and the
+    weight gamma n dV / ppc (the boosted branch of AddPlasma), the plasma entered through the right edge of a window
+    that moved with c while the plasma streamed against it (their closing speed fixes how many layers entered), and
+    the layers injected step by step join into one regular lattice: the injection front drifts with the plasma
+    (UpdateInjectionPosition), so there is neither a gap nor a doubly filled layer between two injections."""
+    c = 299792458.0
+    gamma = 3.0
+    beta = math.sqrt(1.0 - 1.0 / gamma ** 2)
+    p = sim.particles(0)
+    n = p.shape[1]
+    assert n > 0 and n % 64 == 0                          # whole layers of 8 x 8 cells x 1 x 1 points
+    assert np.allclose(p[6], -gamma * beta * c, rtol=1e-12) and np.max(np.abs(p[4:6])) < 1e-12 * c   # self-fields of 1e6 m^-3
+    convert = 1.0 / (gamma * (1.0 - beta * 1.0))          # ConvertLabParamsToBoost with the window moving at c
+    dz = 16e-6 * convert / 32
+    dv = 2e-6 * 2e-6 * dz
+    assert np.allclose(p[3], gamma * 1e6 * dv / 2, rtol=1e-12)
+    layers = np.unique(np.round(p[2] / (dz / 2), 6))
+    assert len(layers) * 64 == n
+    assert np.allclose(np.diff(layers), 1.0, atol=1e-5)   # one lattice of spacing dz / 2 across all injections
+    # the plasma edge: z0_lab = gamma (z + beta c t) >= 1 um; the left-most layer sits within one lattice spacing of it
+    t = sim.istep * sim.dt
+    edge = 1e-6 / gamma - beta * c * t
+    assert 0.0 <= layers.min() * (dz / 2) - edge < dz / 2 * 1.001
+    # ... and the right-most one within a cell of the window's right edge, which moved by c t in whole cells
+    right = math.floor(c * t / dz) * dz
+    assert 0.0 < right - layers.max() * (dz / 2) <= dz * 1.001
+
+
+def test_boosted_frame_injection_through_a_moving_window(lib):
+    sim = WarpXSim.from_inputs(lib, os.path.join(DECKS, "boosted_injection_3d.inputs"))
+    sim.evolve(sim.max_step)
+    check_boosted_injection(sim)
+    sim.close()
+
+
 def test_a_reference_deck_outside_the_path_is_refused(lib):
     if not os.path.isdir(REFERENCE):
         pytest.skip("the reference checkout is not on this machine")

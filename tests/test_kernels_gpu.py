@@ -849,15 +849,24 @@ def test_gather_push_in_two_parts(product, order, pusher):
 
 
 @UNVERIFIED
-@pytest.mark.parametrize("ppc,u,uth", [((1, 1, 1), None, None), ((2, 1, 3), (0.1, -0.2, 0.0), None),
-                                       ((2, 2, 2), (0.0, 0.0, 0.3), (0.01, 0.02, 0.03))])
-def test_add_plasma(oracle, product, ppc, u, uth):
+@pytest.mark.parametrize("ppc,u,uth,gamma_boost,t", [
+    ((1, 1, 1), None, None, 1.0, 0.0), ((2, 1, 3), (0.1, -0.2, 0.0), None, 1.0, 0.0),
+    ((2, 2, 2), (0.0, 0.0, 0.3), (0.01, 0.02, 0.03), 1.0, 0.0),
+    # a lab-frame plasma drifting along z, added at t > 0: the bounds are looked up at the ballistically corrected z
+    ((2, 1, 3), (0.1, -0.2, 0.5), None, 1.0, 3e-15),
+    # boosted frames: at rest in the lab, and drifting + thermal at t > 0
+    ((1, 1, 2), None, None, 2.0, 0.0), ((2, 2, 2), (0.0, 0.0, 0.3), (0.01, 0.02, 0.03), 3.0, 2e-15)])
+def test_add_plasma(oracle, product, ppc, u, uth, gamma_boost, t):
     """wxa_add_plasma (PhysicalParticleContainer::AddPlasma on the device): injector bounds cutting through cells,
     a brick smaller than the cell box; at rest and with a constant momentum the same particles as the CPU
     restatement bit for bit (as a set: the device does not promise an order), with gaussian momenta the same
-    draws to 1e-13 of the spread (device log / sin / cos differ from libm by ulps) and unit variance."""
+    draws to 1e-13 of the spread (device log / sin / cos differ from libm by ulps) and unit variance.  In a boosted
+    frame (the branch at PhysicalParticleContainer.cpp:1210-1247) the same lattice points are kept -- the lab-frame
+    bounds are tested at z0_lab -- and weight and u_z carry the Lorentz transform."""
     inj = _capi.PlasmaInjector()
     inj.density = 2e23
+    inj.gamma_boost = gamma_boost
+    inj.t = t
     for d in range(3):
         inj.ppc[d] = ppc[d]
     lo, hi = (-3.3e-6, -1e300, 0.4e-6), (2.1e-6, 1e300, 1e300)
@@ -888,14 +897,43 @@ def test_add_plasma(oracle, product, ppc, u, uth):
     assert nc.value == nd.value and 0 < nc.value < room
     a, b = pd.to_numpy()[:, :nd.value], pc.to_numpy()[:, :nc.value]
     a, b = a[:, np.lexsort(a[:3])], b[:, np.lexsort(b[:3])]
-    assert np.array_equal(a[:4], b[:4])
-    if uth is None:
+    assert np.array_equal(a[:3], b[:3])
+    if gamma_boost == 1.0:
+        assert np.array_equal(a[3], b[3])
+        assert np.all(b[3] == inj.density * dx[0] * dx[1] * dx[2] / (ppc[0] * ppc[1] * ppc[2]))
+    else:
+        assert np.max(np.abs(a[3] - b[3])) <= 1e-13 * np.max(b[3])
+    if t > 0.0 or gamma_boost > 1.0:   # the z bounds act on the lab-frame image of the lattice
+        beta = math.sqrt(1.0 - 1.0 / gamma_boost ** 2)
+        ub = u if u is not None else (0.0, 0.0, 0.0)
+        bz = ub[2] / math.sqrt(1.0 + ub[0] ** 2 + ub[1] ** 2 + ub[2] ** 2)
+        z0 = gamma_boost * (b[2] * (1.0 - beta * bz) - plasma.C_LIGHT * t * (bz - beta))
+        assert z0.min() >= lo[2] and (b[2].min() < corner[2] + dx[2] or (z0.min() - lo[2]) < gamma_boost * dx[2] * 1.01)
+    if uth is None and gamma_boost == 1.0:
         assert np.array_equal(a, b)
+    elif uth is None:
+        beta = math.sqrt(1.0 - 1.0 / gamma_boost ** 2)
+        for d in range(3):
+            assert np.max(np.abs(a[4 + d] - b[4 + d])) <= 1e-14 * plasma.C_LIGHT
+        if u is None:   # at rest in the lab: u_z = -gamma beta c, density gamma n
+            assert np.allclose(b[6], -gamma_boost * beta * plasma.C_LIGHT, rtol=1e-15)
+            assert np.allclose(b[3], gamma_boost * inj.density * dx[0] * dx[1] * dx[2] / (ppc[0] * ppc[1] * ppc[2]), rtol=1e-15)
     else:
         for d in range(3):
-            assert np.max(np.abs(a[4 + d] - b[4 + d])) <= 1e-13 * uth[d] * plasma.C_LIGHT * 8
-            z = (b[4 + d] / plasma.C_LIGHT - u[d]) / uth[d]
-            assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05
+            assert np.max(np.abs(a[4 + d] - b[4 + d])) <= 1e-13 * uth[d] * plasma.C_LIGHT * 8 * gamma_boost
+        if gamma_boost == 1.0:
+            for d in range(3):
+                z = (b[4 + d] / plasma.C_LIGHT - u[d]) / uth[d]
+                assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05
+        else:   # invariants of the transform: n / gamma_particle is a Lorentz scalar per particle
+            beta = math.sqrt(1.0 - 1.0 / gamma_boost ** 2)
+            g_boosted = np.sqrt(1.0 + (b[4] ** 2 + b[5] ** 2 + b[6] ** 2) / plasma.C_LIGHT ** 2)
+            uz_lab = gamma_boost * (b[6] / plasma.C_LIGHT + beta * g_boosted)
+            g_lab = np.sqrt(1.0 + (b[4] ** 2 + b[5] ** 2) / plasma.C_LIGHT ** 2 + uz_lab ** 2)
+            w0 = inj.density * dx[0] * dx[1] * dx[2] / (ppc[0] * ppc[1] * ppc[2])
+            assert np.allclose(b[3] / g_boosted, w0 / g_lab, rtol=1e-12)
+            zz = (uz_lab - u[2]) / uth[2]
+            assert abs(zz.mean()) < 0.05 and abs(zz.std() - 1.0) < 0.05
     small = ParticleArrays(nc.value - 1, DEV, with_id=True)        # too little room is an error, not an overrun
     with pytest.raises(_capi.WxaError):
         product.add_plasma(C.byref(small.view), *args, C.byref(nd), ws, None)

@@ -404,6 +404,16 @@ def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden
     sim.close()
 
 
+def test_boosted_frame_injection_through_a_moving_window_on_gpu(product):
+    """tests/decks/boosted_injection_3d.inputs on the HIP path: the boosted branch of wxa_add_plasma behind the moving
+    window, checked by the lattice it must leave (tests/test_inputs_cpu.py::check_boosted_injection)."""
+    from tests.test_inputs_cpu import check_boosted_injection
+    sim = WarpXSim.from_inputs(product, os.path.join(HERE, "decks", "boosted_injection_3d.inputs"))
+    sim.evolve(sim.max_step)
+    check_boosted_injection(sim)
+    sim.close()
+
+
 @H.FIRST_GPU_RUN
 @pytest.mark.parametrize("order,filt", [(3, 1), (1, 0)])
 def test_ckc_uniform_plasma_parity(oracle, product, order, filt):

@@ -78,7 +78,8 @@ class MovingWindow(C.Structure):
 
 
 class PlasmaInjector(C.Structure):
-    _fields_ = [("density", C.c_double), ("ppc", C.c_int32 * 3), ("lo", C.c_double * 3), ("hi", C.c_double * 3)]
+    _fields_ = [("density", C.c_double), ("ppc", C.c_int32 * 3), ("lo", C.c_double * 3), ("hi", C.c_double * 3),
+                ("gamma_boost", C.c_double), ("t", C.c_double)]
 
 
 class RepeatedPlasmaLens(C.Structure):

@@ -258,8 +258,10 @@ public:
             WarpXParticleContainer& pc = mypc->GetParticleContainer(i);
             if (std::isnan(pc.m_current_injection_position)) pc.m_current_injection_position = m_ctx.prob_hi[moving_window_dir];
         }
-        moving_window_x += moving_window_v * dt[0];                                 // :158
+        const amrex::Real c = 299'792'458.;
+        moving_window_x += (moving_window_v - m_ctx.beta_boost * c) / (1 - moving_window_v * m_ctx.beta_boost / c) * dt[0];   // :157
         const int dir = moving_window_dir;
+        UpdateInjectionPosition(dt[0]);                                             // :161
         const amrex::Real cdx = m_ctx.dx[dir];
         const int num_shift_base = static_cast<int>((moving_window_x - m_ctx.prob_lo[dir]) / cdx);   // :171
         if (num_shift_base == 0) return 0;
@@ -290,6 +292,24 @@ public:
         // last sort no longer lines up with the tiles, so sort now instead of at the next interval
         if (sort_intervals > 0) mypc->SortParticlesByBin(amrex::IntVect(1));
         return num_shift_base;
+    }
+
+    // WarpX::UpdateInjectionPosition (Source/Utils/WarpXMovingWindow.cpp:60-136): the plasma drifts with its bulk
+    // velocity -- in a boosted frame even a plasma at rest in the lab does -- and the injection front follows it
+    void UpdateInjectionPosition(amrex::Real a_dt) {
+        const amrex::Real c = 299'792'458.;
+        const int dir = moving_window_dir;
+        for (int i = 0; i < mypc->nContainers(); ++i) {
+            WarpXParticleContainer& pc = mypc->GetParticleContainer(i);
+            if (!pc.doContinuousInjection()) continue;
+            const amrex::Real u_bulk = pc.BulkMomentum(dir);                         // getBulkMomentum, in units of c
+            amrex::Real v_shift = c * u_bulk / std::sqrt(1.0 + u_bulk * u_bulk);
+            if (m_ctx.gamma_boost > 1.0) {
+                v_shift = (v_shift - c * m_ctx.beta_boost) / (1.0 - v_shift * m_ctx.beta_boost / c);
+                v_shift *= (dir == 2) ? 1.0 : 0.0;                                   // boost_direction[dir]
+            }
+            pc.m_current_injection_position += v_shift * a_dt;
+        }
     }
 
     // WarpX::shiftMF (:478-648), zero external field

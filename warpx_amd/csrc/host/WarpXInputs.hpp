@@ -566,8 +566,6 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
             for (int d = 0; d < 3; ++d) cols[4 + d].push_back(u[d]);
         };
         if (w == "nuniformpercell") {
-            if (gamma_boost > 1.0)
-                throw std::runtime_error("inputs: " + name + ": NUniformPerCell injection in a boosted frame is not on this path");
             wxa_plasma_injector inj{};
             pp.getArrWithParser(name + ".num_particles_per_cell_each_dim", v, 3);
             for (int d = 0; d < 3; ++d) inj.ppc[d] = ParmParse::safe_int(v[d], name + ".num_particles_per_cell_each_dim");

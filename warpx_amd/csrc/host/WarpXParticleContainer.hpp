@@ -387,6 +387,8 @@ public:
     // WarpXParticleContainer::doContinuousInjection / ContinuousInjection / m_current_injection_position
     virtual bool doContinuousInjection() const { return false; }
     virtual void ContinuousInjection(const double* /*box_lo*/, const double* /*box_hi*/) {}
+    // InjectorMomentum::getBulkMomentum of the base injector along `dir`, in units of c
+    virtual amrex::Real BulkMomentum(int /*dir*/) const { return 0.0; }
     amrex::Real m_current_injection_position = std::numeric_limits<amrex::Real>::quiet_NaN();   // unset
 
     // The tile without retired particles (compacts by sorting if Redistribute retired some since
@@ -426,6 +428,7 @@ public:
     bool doContinuousInjection() const override { return m_has_injector && m_do_continuous_injection; }
     // PhysicalParticleContainer::ContinuousInjection (PhysicalParticleContainer.cpp:2518-2528)
     void ContinuousInjection(const double* box_lo, const double* box_hi) override { AddPlasma(box_lo, box_hi); }
+    amrex::Real BulkMomentum(int dir) const override { return m_momentum_on_device ? m_device_momentum.u_mean[dir] : 0.0; }
 
     // PhysicalParticleContainer::AddPlasma (:924-1333) for one box per brick, lab frame, plasma at rest: the
     // cells of part_box that overlap this brick (find_overlap, Source/Particles/AddPlasmaUtilities.cpp:12-43),
@@ -433,6 +436,8 @@ public:
     // Generated on the host (a slab of one or two cell layers per step in a moving window) and appended.
     void AddPlasma(const double* part_lo, const double* part_hi) {
         if (!m_has_injector) return;
+        m_inj.gamma_boost = m_ctx->gamma_boost;
+        m_inj.t = m_ctx->t_new;
         const wxa_plasma_injector& in = m_inj;
         double olo[3], ohi[3];
         int nov[3];
@@ -460,6 +465,9 @@ public:
             m_tile.resize(n0 + added);
             return;
         }
+        if (m_ctx->gamma_boost > 1.0)
+            throw std::runtime_error("AddPlasma: a momentum function evaluated on the host is lab-frame only; use at_rest, "
+                                     "constant or gaussian momenta in a boosted frame");
         const double scale_fac = m_ctx->dx[0] * m_ctx->dx[1] * m_ctx->dx[2] / nppc;   // compute_scale_fac_volume
         auto inside = [&](double x, double y, double z) {   // InjectorPosition::insideBounds
             return x < in.hi[0] && x >= in.lo[0] && y < in.hi[1] && y >= in.lo[1] && z < in.hi[2] && z >= in.lo[2];

@@ -265,9 +265,12 @@ laser_push_kernel(PV p, LaserPushGeom lg, double dt) {
 struct InjectGeom {
     double corner[3], dx[3], blo[3], bhi[3], lo[3], hi[3], u[3], uth[3], origin[3];
     int nc[3], ppc[3];
-    double weight;
+    double density, scale_fac;
     unsigned long long seed;
     int thermal;
+    // boosted frame / ballistic correction: z0 = gamma_boost (z za - zb) (applyBallisticCorrection, :138-148),
+    // za = 1 - beta_boost betaz_bulk, zb = c t (betaz_bulk - beta_boost)
+    double gamma_boost, beta_boost, za, zb;
 };
 
 // Philox4x32-10 (Salmon et al., SC'11): counter-based, so a particle's draws depend on its position only
@@ -315,7 +318,8 @@ add_plasma_kernel(PV dst, InjectGeom ig, long npoints, unsigned long long* __res
         const double r[3] = {(0.5 + ix_part) / ig.ppc[0], (0.5 + iy_part) / ig.ppc[1], (0.5 + iz_part) / ig.ppc[2]};
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const double clo = ig.corner[d] + (iv[d] + 0.0) * ig.dx[d], chi = ig.corner[d] + (iv[d] + 1.0) * ig.dx[d];
+            double clo = ig.corner[d] + (iv[d] + 0.0) * ig.dx[d], chi = ig.corner[d] + (iv[d] + 1.0) * ig.dx[d];
+            if (d == 2) { clo = ig.gamma_boost * (clo * ig.za - ig.zb); chi = ig.gamma_boost * (chi * ig.za - ig.zb); }   // :1021-1022
             // overlapsWith, and :1030-1048: a corner, an edge midpoint or the centre of the cell has density
             const double mid = (clo + chi) / 2.;
             const bool sample = (clo < ig.hi[d] && clo >= ig.lo[d]) || (mid < ig.hi[d] && mid >= ig.lo[d]) ||
@@ -323,7 +327,8 @@ add_plasma_kernel(PV dst, InjectGeom ig, long npoints, unsigned long long* __res
             ok = ok && !(clo > ig.hi[d] || chi < ig.lo[d]) && sample;
             pos[d] = ig.corner[d] + (iv[d] + r[d]) * ig.dx[d];                        // getCellCoords
             ok = ok && pos[d] > ig.blo[d] && pos[d] < ig.bhi[d];                      // tile_realbox.contains
-            ok = ok && pos[d] < ig.hi[d] && pos[d] >= ig.lo[d];                       // insideBounds
+            const double lab = d == 2 ? ig.gamma_boost * (pos[d] * ig.za - ig.zb) : pos[d];   // z0 / z0_lab (:1181, :1212)
+            ok = ok && lab < ig.hi[d] && lab >= ig.lo[d];                             // insideBounds
         }
     }
     const unsigned long long mask = __ballot(ok);
@@ -337,7 +342,6 @@ add_plasma_kernel(PV dst, InjectGeom ig, long npoints, unsigned long long* __res
     const long slot = (long)(base + __popcll(mask & ((1ULL << lane) - 1ULL)));
     if (slot >= dst.np) return;   // the host sees count > room and reports it
     dst.x[slot] = pos[0]; dst.y[slot] = pos[1]; dst.z[slot] = pos[2];
-    dst.w[slot] = ig.weight;
     double u[3] = {ig.u[0], ig.u[1], ig.u[2]};
     if (ig.thermal) {
         double n[3];
@@ -347,6 +351,14 @@ add_plasma_kernel(PV dst, InjectGeom ig, long npoints, unsigned long long* __res
                 (int)floor((pos[2] - ig.origin[2]) / ig.dx[2] * ig.ppc[2]), n);
         u[0] += ig.uth[0] * n[0]; u[1] += ig.uth[1] * n[1]; u[2] += ig.uth[2] * n[2];
     }
+    double dens = ig.density;
+    if (ig.gamma_boost > 1.0) {   // :1232-1246 Lorentz transform of the lab-frame density and momentum
+        const double gamma_lab = sqrt(1.0 + (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]));
+        const double betaz_lab = u[2] / gamma_lab;
+        dens = ig.gamma_boost * dens * (1.0 - ig.beta_boost * betaz_lab);
+        u[2] = ig.gamma_boost * (u[2] - ig.beta_boost * gamma_lab);
+    }
+    dst.w[slot] = dens * ig.scale_fac;
     dst.ux[slot] = u[0] * PhysConst::c; dst.uy[slot] = u[1] * PhysConst::c; dst.uz[slot] = u[2] * PhysConst::c;
     if (dst.id) dst.id[slot] = 0;
 }
@@ -905,7 +917,16 @@ wxa_status wxa_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injecto
     ig.seed = mom ? mom->seed : 0;
     ig.thermal = mom && (mom->u_th[0] != 0.0 || mom->u_th[1] != 0.0 || mom->u_th[2] != 0.0);
     if (npoints == 0 || !(inj->density > 0)) return WXA_OK;
-    ig.weight = inj->density * (dx[0] * dx[1] * dx[2] / (inj->ppc[0] * inj->ppc[1] * inj->ppc[2]));   // compute_scale_fac_volume
+    ig.density = inj->density;
+    ig.scale_fac = dx[0] * dx[1] * dx[2] / (inj->ppc[0] * inj->ppc[1] * inj->ppc[2]);   // compute_scale_fac_volume
+    ig.gamma_boost = inj->gamma_boost > 1.0 ? inj->gamma_boost : 1.0;
+    ig.beta_boost = ig.gamma_boost > 1.0 ? std::sqrt(1.0 - 1.0 / std::pow(ig.gamma_boost, 2.0)) : 0.0;
+    {
+        const double gamma_bulk = std::sqrt(1.0 + (ig.u[0] * ig.u[0] + ig.u[1] * ig.u[1] + ig.u[2] * ig.u[2]));
+        const double betaz_bulk = ig.u[2] / gamma_bulk;
+        ig.za = 1.0 - ig.beta_boost * betaz_bulk;
+        ig.zb = PhysConst::c * inj->t * (betaz_bulk - ig.beta_boost);
+    }
     hipStream_t st = (hipStream_t)stream;
     wxa_status rc;
     if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
