@@ -940,12 +940,23 @@ def test_add_plasma(oracle, product, ppc, u, uth, gamma_boost, t):
     product.workspace_destroy(ws)
 
 
-@UNVERIFIED
-@pytest.mark.parametrize("cells", [(1.0, 1.0, 1.0), (1.0, 1.5, 0.8)])
-def test_evolve_b_ckc_bit_exact(oracle, product, cells):
+@pytest.mark.parametrize("cells,ncell,ng,plain", [((1.0, 1.0, 1.0), NCELL, 2, 0), ((1.0, 1.5, 0.8), NCELL, 2, 0),
+                                                  ((1.0, 1.5, 0.8), NCELL, 2, 1),
+                                                  # several tiles along every direction, partial ones at the high ends,
+                                                  # and the minimum guard depth: the staged halo reaches past the arrays
+                                                  ((1.0, 1.0, 1.0), (70, 13, 21), 1, 0), ((1.1, 0.9, 1.0), (130, 9, 35), 3, 0),
+                                                  # the other tile shapes of the timing sweep (WXA_CKC_VARIANT)
+                                                  ((1.0, 1.0, 1.0), (70, 13, 37), 1, -1), ((1.0, 1.0, 1.0), (70, 13, 37), 1, -3),
+                                                  ((1.0, 1.0, 1.0), (70, 13, 37), 1, -4), ((1.0, 1.0, 1.0), (70, 21, 37), 1, -5),
+                                                  ((1.0, 1.0, 1.0), (70, 13, 37), 1, -6)])
+def test_evolve_b_ckc_bit_exact(oracle, product, cells, ncell, ng, plain, monkeypatch):
     """wxa_evolve_b_ckc (EvolveBCartesian<CartesianCKCAlgorithm>) and its coefficients against the CPU restatement:
-    same operation order, no contraction -> bit-identical, on cubic and on anisotropic cells."""
-    ng = 2
+    same operation order, no contraction -> bit-identical, on cubic and on anisotropic cells; the LDS-tiled kernel
+    and the plain one (WXA_CKC_PLAIN=1)."""
+    monkeypatch.setenv("WXA_CKC_PLAIN", str(max(plain, 0)))
+    if plain < 0:
+        monkeypatch.setenv("WXA_CKC_VARIANT", str(-plain - 1))
+    NCELL = ncell
     E = H.random_fields(("Ex", "Ey", "Ez"), NCELL, ng, 61)
     B = H.random_fields(("Bx", "By", "Bz"), NCELL, ng, 62, scale=1e-8)
     Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)

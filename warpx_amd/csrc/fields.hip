@@ -485,7 +485,8 @@ unpack_kernel(DevF f, BoxN box, const double* __restrict__ buf, int mode) {
 // term in the reference's order (this file is compiled without FMA contraction: bit-identical to the CPU path).
 struct CkcCoefs { double x[5], y[5], z[5]; };
 
-__device__ __forceinline__ double ckc_up_x(const DevF& F, const double* c, int i, int j, int k) {
+template <class Acc>
+__device__ __forceinline__ double ckc_up_x(const Acc& F, const double* c, int i, int j, int k) {
     const double alphax = c[1], betaxy = c[2], betaxz = c[3], gammax = c[4];
     return alphax * (F(i + 1, j, k) - F(i, j, k))
          + betaxy * (F(i + 1, j + 1, k) - F(i, j + 1, k)
@@ -497,7 +498,8 @@ __device__ __forceinline__ double ckc_up_x(const DevF& F, const double* c, int i
                   +  F(i + 1, j + 1, k - 1) - F(i, j + 1, k - 1)
                   +  F(i + 1, j - 1, k - 1) - F(i, j - 1, k - 1));
 }
-__device__ __forceinline__ double ckc_up_y(const DevF& F, const double* c, int i, int j, int k) {
+template <class Acc>
+__device__ __forceinline__ double ckc_up_y(const Acc& F, const double* c, int i, int j, int k) {
     const double alphay = c[1], betayz = c[2], betayx = c[3], gammay = c[4];
     return alphay * (F(i, j + 1, k) - F(i, j, k))
          + betayx * (F(i + 1, j + 1, k) - F(i + 1, j, k)
@@ -509,7 +511,8 @@ __device__ __forceinline__ double ckc_up_y(const DevF& F, const double* c, int i
                   +  F(i + 1, j + 1, k - 1) - F(i + 1, j, k - 1)
                   +  F(i - 1, j + 1, k - 1) - F(i - 1, j, k - 1));
 }
-__device__ __forceinline__ double ckc_up_z(const DevF& F, const double* c, int i, int j, int k) {
+template <class Acc>
+__device__ __forceinline__ double ckc_up_z(const Acc& F, const double* c, int i, int j, int k) {
     const double alphaz = c[1], betazx = c[2], betazy = c[3], gammaz = c[4];
     return alphaz * (F(i, j, k + 1) - F(i, j, k))
          + betazx * (F(i + 1, j, k + 1) - F(i + 1, j, k)
@@ -526,9 +529,9 @@ __device__ inline bool in_box(const Box3& b, int i, int j, int k) {
     return i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1] && k >= b.lo[2] && k < b.hi[2];
 }
 
-// EvolveBCartesian<CartesianCKCAlgorithm> (EvolveB.cpp:164-186).  First correct version: one lane per point of the
-// union of the three valid boxes, i fastest (coalesced rows; the 3 x 18 neighbour reads of a point are served by
-// L1/L2: each E value is read by up to 16 points of three components).  Not tuned: no MI355X has timed it yet.
+// EvolveBCartesian<CartesianCKCAlgorithm> (EvolveB.cpp:164-186).  Plain version (WXA_CKC_PLAIN=1): one lane per point
+// of the union of the three valid boxes, i fastest (coalesced rows; the 3 x 18 neighbour reads of a point are served
+// by L1/L2: each E value is read by up to 16 points of three components).
 __global__ void __launch_bounds__(256)
 evolve_b_ckc_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, Box3 bbx, Box3 bby, Box3 bbz,
                     double dt, CkcCoefs c) {
@@ -540,6 +543,127 @@ evolve_b_ckc_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 u
     if (in_box(bby, i, j, k)) By(i, j, k) += dt * ckc_up_x(Ez, c.x, i, j, k) - dt * ckc_up_z(Ex, c.z, i, j, k);
     if (in_box(bbz, i, j, k)) Bz(i, j, k) += dt * ckc_up_y(Ex, c.y, i, j, k) - dt * ckc_up_x(Ey, c.x, i, j, k);
 }
+
+// The same update with the E planes staged in LDS (production).  A workgroup owns 64 x TJ points of KC consecutive
+// planes; it keeps four planes of each E component, with one halo point on every side in i and j, in a ring: while
+// plane k is computed from k-1, k, k+1, plane k+2 replaces plane k-2 (one barrier per plane).  PIPE: the values of
+// plane k+2 are loaded into registers before plane k is computed and written to LDS after it, so the loads' latency
+// hides behind the arithmetic.  Every E value then comes from HBM / L2 once per tile (+ halo) instead of up to 16 times
+// from L1; B is read and written once with non-temporal accesses.  The sums are the ones of ckc_up_x/y/z on an
+// accessor into the ring: bit-identical to the plain kernel and to the CPU path.
+// MI355X, 256^3, back to back (72 B/cell; Yee's EvolveB 0.216 ms = 69.8 % of 8 TB/s on the same box):
+//   plain 1.038 ms (14.5 %)   TJ x KC = 8 x 16 0.363 (41.6 %)   8 x 16 PIPE 0.337 (44.8 %)   8 x 32 PIPE 0.370
+//   4 x 32 PIPE 0.343   16 x 16 PIPE 0.373   8 x 8 PIPE 0.335 (45.1 %)
+// Tried and rejected: the staging loop as `for (a = tid; a < PLANE; a += NT) slot[a] = load` (one load in flight per lane:
+// 0.553); a 3 x 3 x 3 register window per component shifted along k, fed from global memory (0.689) or from a two-slot
+// LDS copy of the plane (0.749: the shifts); all six derivatives evaluated before the three stores so that the LDS
+// reads common to two of them are issued once (0.648: registers).  What is left is LDS read rate: 108 ds_read_b64 per point.
+template <int TJ_, int KC_, int PIPE_>
+struct CkcCfg {
+    static constexpr int TI = 64, TJ = TJ_, KC = KC_, PIPE = PIPE_;
+    static constexpr int NI = TI + 2, NJ = TJ + 2, PLANE = NI * NJ, NT = TI * TJ;
+    static constexpr int PER = (PLANE + NT - 1) / NT;   // staged points per lane and plane
+};
+
+template <class CFG>
+struct CkcRing {
+    const double* s;   // 4 slots of CFG::PLANE
+    int i0, j0;        // global index of the local point (1, 1)
+    __device__ __forceinline__ double operator()(int i, int j, int k) const {
+        return s[(k & 3) * CFG::PLANE + (j - j0 + 1) * CFG::NI + (i - i0 + 1)];
+    }
+};
+
+// plane kk of F around the tile, halo included, into registers / from registers into a slot; points outside the
+// array read 0 (they feed no valid output: a valid point's neighbours lie within the guard point the entry requires)
+template <class CFG>
+__device__ __forceinline__ void ckc_fetch_plane(double (&r)[CFG::PER], const DevF& F, int i0, int j0, int kk, int tid) {
+    const bool kin = kk >= F.lo2 && kk < F.lo2 + F.n2;
+#pragma unroll
+    for (int n = 0; n < CFG::PER; ++n) {
+        const int a = tid + n * CFG::NT;
+        const int i = i0 - 1 + a % CFG::NI, j = j0 - 1 + a / CFG::NI;
+        const bool in = a < CFG::PLANE && kin && i >= F.lo0 && i < F.lo0 + F.n0 && j >= F.lo1 && j < F.lo1 + F.n1;
+        r[n] = in ? F.p[F.off(i, j, kk)] : 0.0;
+    }
+}
+template <class CFG>
+__device__ __forceinline__ void ckc_put_plane(double* slot, const double (&r)[CFG::PER], int tid) {
+#pragma unroll
+    for (int n = 0; n < CFG::PER; ++n) {
+        const int a = tid + n * CFG::NT;
+        if (a < CFG::PLANE) slot[a] = r[n];
+    }
+}
+
+template <class CFG>
+__global__ void __launch_bounds__(CFG::NT)
+evolve_b_ckc_tiled_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, Box3 bbx, Box3 bby, Box3 bbz,
+                          TileGrid tg, double dt, CkcCoefs c) {
+    constexpr int PLANE = CFG::PLANE;
+    __shared__ double ring[3][4 * PLANE];
+    const long tile = xcd_tile_id(blockIdx.x, tg.ntiles);
+    if (tile >= tg.ntiles) return;
+    const int ti = (int)(tile % tg.nti);
+    const int tj = (int)((tile / tg.nti) % tg.ntj);
+    const int tk = (int)(tile / ((long)tg.nti * tg.ntj));
+    const int i0 = ub.lo[0] + ti * CFG::TI, j0 = ub.lo[1] + tj * CFG::TJ;
+    const int k0 = ub.lo[2] + tk * CFG::KC;
+    const int k1 = min(k0 + CFG::KC, ub.hi[2]);
+    const int tid = (int)(threadIdx.y * CFG::TI + threadIdx.x);
+    const int i = i0 + (int)threadIdx.x, j = j0 + (int)threadIdx.y;
+    double rx[CFG::PER], ry[CFG::PER], rz[CFG::PER];
+    for (int k = k0 - 1; k <= k0 + 1; ++k) {
+        ckc_fetch_plane<CFG>(rx, Ex, i0, j0, k, tid);
+        ckc_fetch_plane<CFG>(ry, Ey, i0, j0, k, tid);
+        ckc_fetch_plane<CFG>(rz, Ez, i0, j0, k, tid);
+        ckc_put_plane<CFG>(ring[0] + (k & 3) * PLANE, rx, tid);
+        ckc_put_plane<CFG>(ring[1] + (k & 3) * PLANE, ry, tid);
+        ckc_put_plane<CFG>(ring[2] + (k & 3) * PLANE, rz, tid);
+    }
+    const CkcRing<CFG> ex{ring[0], i0, j0}, ey{ring[1], i0, j0}, ez{ring[2], i0, j0};
+    const bool px = in_ij(bbx, i, j), py = in_ij(bby, i, j), pz = in_ij(bbz, i, j);
+    for (int k = k0; k < k1; ++k) {
+        __syncthreads();   // planes k-1, k, k+1 are in the ring; everyone is done with plane k-2
+        const bool more = k + 2 <= k1;   // plane k+2 for the next step, into the slot of k-2
+        if (more) {
+            ckc_fetch_plane<CFG>(rx, Ex, i0, j0, k + 2, tid);
+            ckc_fetch_plane<CFG>(ry, Ey, i0, j0, k + 2, tid);
+            ckc_fetch_plane<CFG>(rz, Ez, i0, j0, k + 2, tid);
+            if constexpr (!CFG::PIPE) {
+                ckc_put_plane<CFG>(ring[0] + ((k + 2) & 3) * PLANE, rx, tid);
+                ckc_put_plane<CFG>(ring[1] + ((k + 2) & 3) * PLANE, ry, tid);
+                ckc_put_plane<CFG>(ring[2] + ((k + 2) & 3) * PLANE, rz, tid);
+            }
+        }
+        if (px && k >= bbx.lo[2] && k < bbx.hi[2]) {
+            double* b = &Bx(i, j, k);
+            __builtin_nontemporal_store(__builtin_nontemporal_load(b) + (dt * ckc_up_z(ey, c.z, i, j, k) - dt * ckc_up_y(ez, c.y, i, j, k)), b);
+        }
+        if (py && k >= bby.lo[2] && k < bby.hi[2]) {
+            double* b = &By(i, j, k);
+            __builtin_nontemporal_store(__builtin_nontemporal_load(b) + (dt * ckc_up_x(ez, c.x, i, j, k) - dt * ckc_up_z(ex, c.z, i, j, k)), b);
+        }
+        if (pz && k >= bbz.lo[2] && k < bbz.hi[2]) {
+            double* b = &Bz(i, j, k);
+            __builtin_nontemporal_store(__builtin_nontemporal_load(b) + (dt * ckc_up_y(ex, c.y, i, j, k) - dt * ckc_up_x(ey, c.x, i, j, k)), b);
+        }
+        if constexpr (CFG::PIPE) {
+            if (more) {
+                ckc_put_plane<CFG>(ring[0] + ((k + 2) & 3) * PLANE, rx, tid);
+                ckc_put_plane<CFG>(ring[1] + ((k + 2) & 3) * PLANE, ry, tid);
+                ckc_put_plane<CFG>(ring[2] + ((k + 2) & 3) * PLANE, rz, tid);
+            }
+        }
+    }
+}
+
+using Ckc0 = CkcCfg<8, 16, 0>;
+using Ckc1 = CkcCfg<8, 16, 1>;
+using Ckc2 = CkcCfg<8, 32, 1>;
+using Ckc3 = CkcCfg<4, 32, 1>;
+using Ckc4 = CkcCfg<16, 16, 1>;
+using Ckc5 = CkcCfg<8, 8, 1>;
 
 static inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
     long g = (total + block - 1) / block;
@@ -685,12 +809,34 @@ wxa_status wxa_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3]
     }
     CkcCoefs cc;
     for (int n = 0; n < 5; ++n) { cc.x[n] = cx[n]; cc.y[n] = cy[n]; cc.z[n] = cz[n]; }
-    const dim3 block(64, 4);
-    const dim3 grid((unsigned)((ub.hi[0] - ub.lo[0] + 63) / 64), (unsigned)((ub.hi[1] - ub.lo[1] + 3) / 4),
-                    (unsigned)(ub.hi[2] - ub.lo[2]));
-    WXA_REQUIRE(grid.z <= 65535u, "more than 65535 planes");
-    hipLaunchKernelGGL(evolve_b_ckc_kernel, grid, block, 0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]),
-                       make_devf(E[2]), make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, dt, cc);
+    const char* plain = getenv("WXA_CKC_PLAIN");   // the one-lane-per-point kernel (reference for the tiled one, timing)
+    if (plain && atoi(plain) != 0) {
+        const dim3 block(64, 4);
+        const dim3 grid((unsigned)((ub.hi[0] - ub.lo[0] + 63) / 64), (unsigned)((ub.hi[1] - ub.lo[1] + 3) / 4),
+                        (unsigned)(ub.hi[2] - ub.lo[2]));
+        WXA_REQUIRE(grid.z <= 65535u, "more than 65535 planes");
+        hipLaunchKernelGGL(evolve_b_ckc_kernel, grid, block, 0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]),
+                           make_devf(E[2]), make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, dt, cc);
+    } else {
+#define WXA_CKC_LAUNCH(CFG)                                                                                            \
+    do {                                                                                                               \
+        const TileGrid tg = make_tiles_cfg<StencilCfg<1, CFG::TJ, CFG::KC, 1>>(ub);                                    \
+        hipLaunchKernelGGL(evolve_b_ckc_tiled_kernel<CFG>, dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(CFG::TI, CFG::TJ), \
+                           0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]), make_devf(B[0]),    \
+                           make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, tg, dt, cc);                              \
+    } while (0)
+        const char* var = getenv("WXA_CKC_VARIANT");   // timing sweeps (scripts/ckc_timing.py)
+        switch (var ? atoi(var) : -1) {
+            case 0: WXA_CKC_LAUNCH(Ckc0); break;
+            case 1: WXA_CKC_LAUNCH(Ckc1); break;
+            case 2: WXA_CKC_LAUNCH(Ckc2); break;
+            case 3: WXA_CKC_LAUNCH(Ckc3); break;
+            case 4: WXA_CKC_LAUNCH(Ckc4); break;
+            case 5: WXA_CKC_LAUNCH(Ckc5); break;
+            default: WXA_CKC_LAUNCH(Ckc1); break;
+        }
+#undef WXA_CKC_LAUNCH
+    }
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
