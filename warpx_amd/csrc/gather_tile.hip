@@ -11,7 +11,8 @@
 // kernel with global loads, so correctness never depends on the sort being fresh.
 // (Tried and rejected, ms per launch at 256^3 x 8 ppc against 5.9: rows read with inline-asm single ds_read_b64 instead of
 // the ds_read2_b64 the compiler emits, 6.3 (the coarse s_waitcnt it needs); 640 lanes per tile = 5 waves per SIMD, 5.9;
-// the next particle's position and momentum loaded while the current one gathers (127 VGPRs), 6.2; two particles of a
+// the next particle's position and momentum loaded while the current one gathers (127 VGPRs), 6.2; this particle's
+// momentum loaded together with its position instead of after the gather (hand-issued loads), no change; two particles of a
 // cell per lane sharing the LDS reads, 9.95.  Counters, profiles/round2/r2g_pmc_128cube_gather_tile_kernel.txt: 8 LDS
 // cycles per ds instruction and 0.2 % bank conflicts, the LDS busy 60 % and the VALU 50 % of the kernel's time.)
 #include "gather_body.hpp"
@@ -91,16 +92,30 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     const int o0 = tg.cell_lo[0] + ti * GT_TS + GatherTileDims<G>::LO;
     const int o1 = tg.cell_lo[1] + tj * GT_TS + GatherTileDims<G>::LO;
     const int o2 = tg.cell_lo[2] + tk * GT_TS + GatherTileDims<G>::LO;
-    const DevF* fld[6] = {&Ex, &Ey, &Ez, &Bx, &By, &Bz};
+    // staging: all loads of a component pair are in flight before the first LDS write (as a plain
+    // `for (a = tid; ...) F[a] = load` loop every lane had one load in flight at a time)
+    constexpr int PER = (NPTS + GT_THREADS - 1) / GT_THREADS;
+    auto fetch = [&](const DevF& f, double (&r)[PER]) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const DevF& f = *fld[c];
-        for (int a = tid; a < NPTS; a += GT_THREADS) {
+        for (int n = 0; n < PER; ++n) {
+            const int a = tid + n * GT_THREADS;
             const int i = o0 + a % N, j = o1 + (a / N) % N, k = o2 + a / (N * N);
-            const bool in = i >= f.lo0 && i < f.lo0 + f.n0 && j >= f.lo1 && j < f.lo1 + f.n1 && k >= f.lo2 &&
+            const bool in = a < NPTS && i >= f.lo0 && i < f.lo0 + f.n0 && j >= f.lo1 && j < f.lo1 + f.n1 && k >= f.lo2 &&
                             k < f.lo2 + f.n2;
-            F[c * NPTS + a] = in ? f.p[f.off(i, j, k)] : 0.0;
+            r[n] = in ? f.p[f.off(i, j, k)] : 0.0;
         }
+    };
+    auto put = [&](int c, const double (&r)[PER]) {
+#pragma unroll
+        for (int n = 0; n < PER; ++n) {
+            const int a = tid + n * GT_THREADS;
+            if (a < NPTS) F[c * NPTS + a] = r[n];
+        }
+    };
+    {
+        double r0[PER], r1[PER], r2[PER], r3[PER], r4[PER], r5[PER];
+        fetch(Ex, r0); fetch(Ey, r1); fetch(Ez, r2); fetch(Bx, r3); fetch(By, r4); fetch(Bz, r5);
+        put(0, r0); put(1, r1); put(2, r2); put(3, r3); put(4, r4); put(5, r5);
     }
     __syncthreads();
 
