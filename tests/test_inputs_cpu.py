@@ -289,6 +289,24 @@ def test_boosted_frame_injection_through_a_moving_window(lib):
     sim.close()
 
 
+def test_constant_external_grid_fields(lib, tmp_path):
+    """warpx.B_ext_grid_init_style = constant with non-zero values (WarpXInitData.cpp:940-960): the value at every
+    point, guards included; a uniform B stays what it is under the Yee update."""
+    deck = tmp_path / "inputs"
+    deck.write_text("max_step = 3\namr.n_cell = 8 8 8\namr.max_level = 0\ngeometry.dims = 3\n"
+                    "geometry.prob_lo = -1 -1 -1\ngeometry.prob_hi = 1 1 1\n"
+                    "boundary.field_lo = periodic periodic periodic\nboundary.field_hi = periodic periodic periodic\n"
+                    "algo.particle_shape = 1\nwarpx.B_ext_grid_init_style = constant\n"
+                    "warpx.B_external_grid = 0. 0.5 2*0.125\nwarpx.E_ext_grid_init_style = constant\n"
+                    "warpx.E_external_grid = 3.e3 0. 0.\n")
+    sim = WarpXSim.from_inputs(lib, str(deck))
+    assert np.all(sim.field("Bx") == 0.0) and np.all(sim.field("By") == 0.5) and np.all(sim.field("Bz") == 0.25)
+    assert np.all(sim.field("Ex") == 3.e3)
+    sim.evolve(sim.max_step)
+    assert np.all(sim.field_valid("By") == 0.5) and np.all(sim.field_valid("Ex") == 3.e3)
+    sim.close()
+
+
 def test_a_reference_deck_outside_the_path_is_refused(lib):
     if not os.path.isdir(REFERENCE):
         pytest.skip("the reference checkout is not on this machine")

@@ -445,7 +445,13 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         if (!pp.query_word(style_key, w) || w == "default") continue;
         if (w == "constant") {
             pp.getArrWithParser(std::string("warpx.") + eb + "_external_grid", v, 3);
-            for (int d = 0; d < 3; ++d) wx.fields().get(ft, Direction{d}, 0)->setVal(v[d], ctx.stream);
+            std::vector<std::string> exprs;
+            pp.queryarr(std::string("warpx.") + eb + "_external_grid", exprs);
+            for (int d = 0; d < 3; ++d) {
+                amrex::MultiFab& mf = *wx.fields().get(ft, Direction{d}, 0);
+                if (v[d] == 0.0) mf.setVal(0.0, ctx.stream);
+                else fill_from_parser(be, mf, pp.makeParser(exprs[d], {"x", "y", "z", "t"}), ctx);   // the value at every point
+            }
         } else if (w == std::string("parse") + (char)std::tolower(eb[0]) + "extgridfunction") {
             for (int d = 0; d < 3; ++d) {
                 const std::string key = std::string("warpx.") + eb + "xyz"[d] + "_external_grid_function(x,y,z)";
