@@ -98,6 +98,47 @@ def test_bricks_with_overlapped_halo_exchange(oracle, product, nb):
 def test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, order, filt, overlap=0):
     n_cell = (32, 32, 32)
     steps = 7
+    results, parts, bn = run_bricks(product, nb, order, filt, overlap, n_cell, steps)
+    prob_lo, prob_hi = (-L / 2,) * 3, (L / 2,) * 3
+    ref = WarpXSim(oracle, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt)
+    rid = ref.add_species(-plasma.Q_E, plasma.M_E, list(parts))
+    ref.evolve(steps)
+    rmom = particle_moments(ref, rid)
+    assert sum(r["np"] for r in results) == parts.shape[1]      # nobody lost, duplicated or left retired
+    assert all(r["inside"] and r["live"] for r in results)
+    assert results[0]["exchanges"] > 0
+    for n in FIELDS:
+        full = ref.field_valid(n)
+        scale = max(np.max(np.abs(full)), 1e-300)
+        for r in results:
+            c, a = r["coord"], r["fields"][n]
+            sl = tuple(slice(c[d] * bn[d], c[d] * bn[d] + a.shape[d]) for d in range(3))
+            assert float(np.max(np.abs(a - full[sl])) / scale) < 1e-10, n
+    ek = sum(r["ekin"] for r in results)
+    assert abs(ek - rmom["ekin"]) / rmom["ekin"] < 1e-11
+    ap = np.sum([r["abs_p"] for r in results], axis=0)
+    assert np.max(np.abs(ap - np.array(rmom["abs_momentum"])) / np.array(rmom["abs_momentum"])) < 1e-11
+
+
+@pytest.mark.parametrize("nb", [(1, 1, 2), (2, 2, 2)])
+def test_guard_layer_update_equals_the_guard_exchange(product, nb, monkeypatch):
+    """The all-periodic step updates the first guard layer of B itself (wxa_evolve_b_guard_layer) instead of exchanging
+    it after EvolveB, and drops FillBoundaryE after EvolveE: the redundant guard values must be the neighbour's bit
+    for bit.  WXA_NO_GUARD_LAYER=1 brings the reference's exchanges back; both schedules leave identical fields and
+    particles on every brick."""
+    n_cell, steps = (32, 32, 32), 7
+    monkeypatch.delenv("WXA_NO_GUARD_LAYER", raising=False)
+    fast, _, _ = run_bricks(product, nb, 3, 1, 0, n_cell, steps)
+    monkeypatch.setenv("WXA_NO_GUARD_LAYER", "1")
+    plain, _, _ = run_bricks(product, nb, 3, 1, 0, n_cell, steps)
+    assert plain[0]["exchanges"] > fast[0]["exchanges"]          # the exchanges really came back
+    for a, b in zip(fast, plain):
+        assert a["np"] == b["np"] and a["ekin"] == b["ekin"]
+        for n in FIELDS:
+            assert np.array_equal(a["fields"][n], b["fields"][n]), n
+
+
+def run_bricks(product, nb, order, filt, overlap, n_cell, steps):
     nranks = nb[0] * nb[1] * nb[2]
     prob_lo, prob_hi = (-L / 2,) * 3, (L / 2,) * 3
     # hot plasma: particles cross brick faces (and tile boundaries) within a few steps
@@ -144,27 +185,10 @@ def test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, order, filt,
     assert not errors, errors
     assert all(r is not None for r in results)
 
-    ref = WarpXSim(oracle, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt)
-    rid = ref.add_species(-plasma.Q_E, plasma.M_E, list(parts))
-    ref.evolve(steps)
-    rmom = particle_moments(ref, rid)
-    assert sum(r["np"] for r in results) == parts.shape[1]      # nobody lost, duplicated or left retired
-    assert all(r["inside"] and r["live"] for r in results)
-    assert results[0]["exchanges"] > 0
-    for n in FIELDS:
-        full = ref.field_valid(n)
-        scale = max(np.max(np.abs(full)), 1e-300)
-        for r in results:
-            c, a = r["coord"], r["fields"][n]
-            sl = tuple(slice(c[d] * bn[d], c[d] * bn[d] + a.shape[d]) for d in range(3))
-            assert float(np.max(np.abs(a - full[sl])) / scale) < 1e-10, n
-    ek = sum(r["ekin"] for r in results)
-    assert abs(ek - rmom["ekin"]) / rmom["ekin"] < 1e-11
-    ap = np.sum([r["abs_p"] for r in results], axis=0)
-    assert np.max(np.abs(ap - np.array(rmom["abs_momentum"])) / np.array(rmom["abs_momentum"])) < 1e-11
+    return results, parts, bn
 
 
-@pytest.mark.skipif(H.HIP_ON_CPU, reason="RCCL needs the GPU")
+@pytest.mark.skipif(not H.ON_GPU, reason="RCCL needs a GPU (the CPU execution model has no transport of its own)")
 def test_rccl_transport_loopback(product):
     """The library's own transport (csrc/rccl_comm.hip) on one GPU: a one-rank RCCL communicator in loop-back mode, so
     that the messages BrickComm would send to a neighbour really travel through an ncclSend / ncclRecv group on the
