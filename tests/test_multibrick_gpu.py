@@ -124,7 +124,7 @@ def test_bricks_on_one_gpu_match_single_domain(oracle, product, nb, order, filt,
 def test_guard_layer_update_equals_the_guard_exchange(product, nb, monkeypatch):
     """The all-periodic step updates the first guard layer of B itself (wxa_evolve_b_guard_layer) instead of exchanging
     it after EvolveB, and drops FillBoundaryE after EvolveE: the redundant guard values must be the neighbour's bit
-    for bit.  WXA_NO_GUARD_LAYER=1 brings the reference's exchanges back; both schedules leave identical fields and
+    for bit.  WXA_NO_GUARD_LAYER=1 brings the reference's exchanges back; both schedules leave the same fields and
     particles on every brick."""
     n_cell, steps = (32, 32, 32), 7
     monkeypatch.delenv("WXA_NO_GUARD_LAYER", raising=False)
@@ -132,10 +132,18 @@ def test_guard_layer_update_equals_the_guard_exchange(product, nb, monkeypatch):
     monkeypatch.setenv("WXA_NO_GUARD_LAYER", "1")
     plain, _, _ = run_bricks(product, nb, 3, 1, 0, n_cell, steps)
     assert plain[0]["exchanges"] > fast[0]["exchanges"]          # the exchanges really came back
+    # bit for bit where a run is reproducible (the CPU execution model); on the GPU the order of the deposition's
+    # atomics differs from run to run, so two runs of one schedule already differ at round-off: a stale or wrong guard
+    # value would show at the scale of the fields themselves
     for a, b in zip(fast, plain):
-        assert a["np"] == b["np"] and a["ekin"] == b["ekin"]
+        assert a["np"] == b["np"]
         for n in FIELDS:
-            assert np.array_equal(a["fields"][n], b["fields"][n]), n
+            if H.ON_GPU:
+                scale = max(np.max(np.abs(b["fields"][n])), 1e-300)
+                assert float(np.max(np.abs(a["fields"][n] - b["fields"][n])) / scale) < 1e-11, n
+            else:
+                assert np.array_equal(a["fields"][n], b["fields"][n]), n
+        assert abs(a["ekin"] - b["ekin"]) <= (1e-12 if H.ON_GPU else 0.0) * b["ekin"]
 
 
 def run_bricks(product, nb, order, filt, overlap, n_cell, steps):
