@@ -544,13 +544,19 @@ wxa_status wxa_shift_field_window(const wxa_field_view* f, double* tmp, int32_t 
 /* The laser antenna push: LaserParticleContainer::calculate_laser_plane_coordinates,
  * GaussianLaserProfile::fill_amplitude (no space-time couplings) and update_laser_particle
  * (Source/Particles/LaserParticleContainer.cpp:795-951, Source/Laser/LaserProfilesImpl/
- * LaserProfileGaussian.cpp:104-161), lab frame: the antenna particles get the velocity
+ * LaserProfileGaussian.cpp:104-161): the antenna particles get the velocity
  * -/+ mobility * E(X, Y, t) c along the polarization (sign opposite to the sign of their weight), their
  * momentum gamma v, and move by v dt.  p_X, p_Y: unit polarization vectors (p_Y = n x p_X). */
 typedef struct wxa_laser_push_params {
     double position[3], p_X[3], p_Y[3];
-    double mobility;                                  /* ComputeWeightMobility: 0.05 / e_max */
+    double mobility;                                  /* ComputeWeightMobility: 0.05 / e_max (/ gamma_boost) */
     double e_max, wavelength, waist, duration, t_peak, focal_distance;
+    /* boosted frame (update_laser_particle, LaserParticleContainer.cpp:892-916): the antenna drifts with
+     * -beta_boost c along nvec on top of the emitting velocity, and gamma = gamma_boost / sqrt(1 - (v/c)^2);
+     * `t` of wxa_laser_push is then the lab-frame time t / gamma_boost + beta_boost Z0_lab / c (:574-579).
+     * gamma_boost = 0 or 1: lab frame, nvec unused. */
+    double nvec[3];
+    double gamma_boost;
 } wxa_laser_push_params;
 wxa_status wxa_laser_push(const wxa_particle_view* p, const wxa_laser_push_params* par, double t,
                           double dt, void* stream);

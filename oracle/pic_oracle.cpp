@@ -895,7 +895,7 @@ int orc_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injector* inj,
 
 // calculate_laser_plane_coordinates (LaserParticleContainer.cpp:795-847), GaussianLaserProfile::fill_amplitude
 // (LaserProfileGaussian.cpp:104-161 with zeta = beta = phi2 = phi0 = 0, theta_stc = 0), update_laser_particle
-// (:850-951), lab frame
+// (:850-951); t is the lab-frame time also in a boosted frame (the caller converts, :574-579)
 int orc_laser_push(const wxa_particle_view* p, const wxa_laser_push_params* c, double t, double dt, void*) {
     using cplx = std::complex<double>;
     const cplx I(0, 1);
@@ -907,6 +907,8 @@ int orc_laser_push(const wxa_particle_view* p, const wxa_laser_push_params* c, d
     const cplx stretch_factor = 1.;   // 1 + 4 (zeta + beta f / tau^2)(...) + 2 i (phi2 - ...) / tau^2 with zeta = beta = phi2 = 0
     const cplx t_prefactor = c->e_max * std::exp(I * oscillation_phase);
     const cplx prefactor = t_prefactor / diffract_factor;
+    const double gamma_boost = c->gamma_boost > 1. ? c->gamma_boost : 1.;
+    const double beta_boost = gamma_boost > 1. ? std::sqrt(1. - 1. / std::pow(gamma_boost, 2.)) : 0.;
     for (int64_t i = 0; i < p->np; ++i) {
         double x = p->x[i], y = p->y[i], z = p->z[i];
         const double Xp = c->p_X[0] * (x - c->position[0]) + c->p_X[1] * (y - c->position[1]) + c->p_X[2] * (z - c->position[2]);
@@ -918,10 +920,16 @@ int orc_laser_push(const wxa_particle_view* p, const wxa_laser_push_params* c, d
         const double amplitude = (stcfactor * std::exp(exp_argument)).real();
         const double sign_charge = (p->w[i] > 0) ? -1 : 1;
         const double v_over_c = sign_charge * c->mobility * amplitude;
-        const double vx = PhysConst::c * v_over_c * c->p_X[0];
-        const double vy = PhysConst::c * v_over_c * c->p_X[1];
-        const double vz = PhysConst::c * v_over_c * c->p_X[2];
-        const double gamma = 1. / std::sqrt(1. - v_over_c * v_over_c);
+        double vx = PhysConst::c * v_over_c * c->p_X[0];
+        double vy = PhysConst::c * v_over_c * c->p_X[1];
+        double vz = PhysConst::c * v_over_c * c->p_X[2];
+        // When running in the boosted-frame, their is additional velocity along nvec (:907-912)
+        if (gamma_boost > 1.) {
+            vx -= PhysConst::c * beta_boost * c->nvec[0];
+            vy -= PhysConst::c * beta_boost * c->nvec[1];
+            vz -= PhysConst::c * beta_boost * c->nvec[2];
+        }
+        const double gamma = gamma_boost / std::sqrt(1. - v_over_c * v_over_c);
         p->ux[i] = gamma * vx; p->uy[i] = gamma * vy; p->uz[i] = gamma * vz;
         p->x[i] = x + vx * dt; p->y[i] = y + vy * dt; p->z[i] = z + vz * dt;
     }

@@ -104,7 +104,9 @@ def test_ckc_solver_from_the_inputs_file(lib, tmp_path):
 
 @pytest.mark.parametrize("extra,needle", [
     ("algo.maxwell_solver = psatd", "maxwell_solver"),
-    ("warpx.gamma_boost = 10.", "gamma_boost"),
+    ("warpx.gamma_boost = 10.", "boost_direction"),                      # the frame is on the path, its direction is mandatory
+    ("warpx.gamma_boost = 10.\nwarpx.boost_direction = x", "boost must be in the z direction"),
+    ("particles.use_fdtd_nci_corr = 1", "use_fdtd_nci_corr"),
     ("boundary.field_lo = pml pml pml", "pml"),
     ("warpx.do_pml = 1", "do_pml"),
     ("amr.max_level = 1", "max_level"),
@@ -280,6 +282,58 @@ def check_boosted_injection(sim):
     # ... and the right-most one within a cell of the window's right edge, which moved by c t in whole cells
     right = math.floor(c * t / dz) * dz
     assert 0.0 < right - layers.max() * (dz / 2) <= dz * 1.001
+
+
+def check_boosted_laser(sim):
+    """tests/decks/boosted_laser_3d.inputs after its 130 steps: the plane pulse the boosted antenna emitted travels
+    along +z with the Lorentz-transformed amplitude E gamma (1 - beta) and wavelength lambda gamma (1 + beta) of the
+    lab-frame laser the deck describes, polarised along y, the same on every transverse line."""
+    g = 2.0
+    b = math.sqrt(1.0 - 1.0 / g ** 2)
+    ey = sim.field_valid("Ey")
+    peak = np.abs(ey).max()
+    assert abs(peak / (1e12 * g * (1.0 - b)) - 1.0) < 0.02, peak
+    assert np.abs(sim.field_valid("Ex")).max() < 1e-6 * peak and np.abs(sim.field_valid("Ez")).max() < 1e-6 * peak
+    assert np.abs(ey - ey[3:4, 3:4, :]).max() < 1e-6 * peak
+    line = ey[3, 3, :]
+    dz = 30e-6 / (g * (1.0 - b)) / 512
+    k = np.fft.rfftfreq(len(line), d=dz)
+    kp = k[np.argmax(np.abs(np.fft.rfft(line)))]
+    assert abs(1.0 / kp / (0.8e-6 * g * (1.0 + b)) - 1.0) < 0.03, 1.0 / kp          # one FFT bin is 2.7 %
+    # B of a wave along +z polarised along y: Bx = -Ey / c
+    bx = sim.field_valid("Bx")
+    assert abs(np.abs(bx).max() * 299792458.0 / peak - 1.0) < 0.05     # sampled half a cell and half a step apart
+
+
+def test_boosted_frame_laser_antenna(lib):
+    sim = WarpXSim.from_inputs(lib, os.path.join(DECKS, "boosted_laser_3d.inputs"))
+    sim.evolve(sim.max_step)
+    check_boosted_laser(sim)
+    sim.close()
+
+
+def test_boosted_frame_laser_wakefield_deck(lib):
+    """tests/decks/laser_wakefield_boosted_3d.inputs (BASELINE config 5 in small: gamma = 5, window at c, CKC, Vay,
+    order 3, antenna + continuously injected plasma): every piece of the boosted-frame row in one run.  Every electron
+    carries gamma n dV, those the pulse has not reached still stream with u_z = -gamma beta c; the pulse has the transformed
+    amplitude; the wake drives a longitudinal field and accelerates electrons forward."""
+    c = 299792458.0
+    g = 5.0
+    b = math.sqrt(1.0 - 1.0 / g ** 2)
+    sim = WarpXSim.from_inputs(lib, os.path.join(DECKS, "laser_wakefield_boosted_3d.inputs"))
+    sim.evolve(sim.max_step)
+    p = sim.particles(0)
+    convert = 1.0 / (g * (1.0 - b))
+    dv = (60e-6 / 16) ** 2 * (16e-6 * convert / 256)
+    assert np.allclose(p[3], g * 2e23 * dv, rtol=1e-12)
+    fresh = np.abs(p[6] / c + g * b) < 1e-9                  # untouched since their injection
+    assert fresh.sum() > 100 and p.shape[1] > 20000          # the layers injected last; the pulse fills most of the window
+    assert np.all(np.abs(p[4][fresh]) < 1e-9 * c) and np.all(np.abs(p[5][fresh]) < 1e-9 * c)
+    ey, ez = sim.field_valid("Ey"), sim.field_valid("Ez")
+    assert 0.5 < np.abs(ey).max() / (16e12 * g * (1.0 - b)) < 1.3     # focusing + coarse transverse grid
+    assert np.abs(ez).max() > 0.02 * np.abs(ey).max()                 # the wake
+    assert p[6].max() > 0                                             # electrons moving with the pulse
+    sim.close()
 
 
 def test_boosted_frame_injection_through_a_moving_window(lib):

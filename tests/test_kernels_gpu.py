@@ -722,11 +722,12 @@ def test_shift_field_window(oracle, product, direction, num_shift):
         assert np.array_equal(fd.to_numpy(), f.to_numpy())
 
 
-@UNVERIFIED
-def test_laser_push(oracle, product):
+@pytest.mark.parametrize("gamma_boost", [1.0, 5.0])
+def test_laser_push(oracle, product, gamma_boost):
     """wxa_laser_push (LaserParticleContainer::Evolve: plane coordinates, Gaussian profile with a focal distance,
     update_laser_particle) on an antenna plane of +/- weighted macro-particles at three times around the peak:
-    positions and momenta within 1e-13 of the CPU restatement (device exp/sin/cos differ from libm by ulps)."""
+    positions and momenta within 1e-13 of the CPU restatement (device exp/sin/cos differ from libm by ulps).
+    gamma_boost > 1: the antenna of a boosted frame drifts with -beta c along its normal on top of that."""
     n = 30000
     rng = np.random.default_rng(11)
     par = _capi.LaserPushParams()
@@ -739,6 +740,9 @@ def test_laser_push(oracle, product):
     par.e_max, par.wavelength, par.waist = 16e12, 0.8e-6, 5e-6
     par.duration, par.t_peak, par.focal_distance = 15e-15, 30e-15, 100e-6
     par.mobility = 4e-14                       # |v/c| <= 0.64
+    par.gamma_boost = gamma_boost
+    for d, v in enumerate((0.0, 0.0, 1.0)):
+        par.nvec[d] = v
     x, y = (rng.random(n) - 0.5) * 30e-6, (rng.random(n) - 0.5) * 30e-6
     w = np.where(rng.random(n) < 0.5, 1.0, -1.0) * 1e5
     parts = [x, y, np.full(n, 9e-6), w, np.zeros(n), np.zeros(n), np.zeros(n)]
@@ -751,6 +755,12 @@ def test_laser_push(oracle, product):
         _sync(product)
         a, b = pd.to_numpy(), pc.to_numpy()
         assert np.max(np.abs(b[5])) > 0            # the antenna moves along the polarisation
+        if gamma_boost > 1.0:                      # ... and backwards along its normal, all of it alike
+            beta = math.sqrt(1.0 - 1.0 / gamma_boost ** 2)
+            assert np.allclose(b[2] - 9e-6, -beta * plasma.C_LIGHT * dt, rtol=1e-9)
+            assert np.all(b[6] < 0)
+        else:
+            assert np.all(b[2] == 9e-6) and np.all(b[6] == 0)
         for row in range(7):
             scale = max(np.max(np.abs(b[row])), 1e-300)
             assert np.max(np.abs(a[row] - b[row])) <= 1e-13 * scale, (t, row)

@@ -109,7 +109,8 @@ class LaserAntenna(C.Structure):
 class LaserPushParams(C.Structure):
     _fields_ = [("position", C.c_double * 3), ("p_X", C.c_double * 3), ("p_Y", C.c_double * 3),
                 ("mobility", C.c_double), ("e_max", C.c_double), ("wavelength", C.c_double), ("waist", C.c_double),
-                ("duration", C.c_double), ("t_peak", C.c_double), ("focal_distance", C.c_double)]
+                ("duration", C.c_double), ("t_peak", C.c_double), ("focal_distance", C.c_double),
+                ("nvec", C.c_double * 3), ("gamma_boost", C.c_double)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(

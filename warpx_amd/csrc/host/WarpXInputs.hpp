@@ -659,7 +659,6 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
 
     // ---- laser antennas (LaserParticleContainer.cpp:70-250) ----
     for (const std::string& name : laser_names) {
-        if (gamma_boost > 1.0) throw std::runtime_error("inputs: " + name + ": a laser antenna in a boosted frame is not on this path");
         if (!pp.query_word(name + ".profile", w) || w != "gaussian")
             throw std::runtime_error("inputs: " + name + ".profile must be Gaussian on this path");
         wxa_laser_antenna la{};

@@ -646,6 +646,14 @@ public:
         double dp = 0;
         for (int d = 0; d < 3; ++d) dp += m_nvec[d] * m_p_X[d];
         if (std::abs(dp) >= 1.0e-14) throw std::runtime_error("Laser plane vector is not perpendicular to the main polarization vector");
+        if (ctx->gamma_boost > 1.0) {                                                            // :183-197
+            if (m_nvec[0] * m_nvec[0] + m_nvec[1] * m_nvec[1] + (m_nvec[2] - 1.0) * (m_nvec[2] - 1.0) >= 1.e-12)
+                throw std::runtime_error("The Lorentz boost should be in the same direction as the laser propagation");
+            // the plane's position along the boost direction in the lab frame, and the antenna in the boosted frame
+            m_Z0_lab = m_nvec[0] * m_position[0] + m_nvec[1] * m_position[1] + m_nvec[2] * m_position[2];
+            const double Z0_boost = m_Z0_lab / ctx->gamma_boost;
+            for (int d = 0; d < 3; ++d) m_position[d] += (Z0_boost - m_Z0_lab) * m_nvec[d];
+        }
         m_p_Y[0] = m_nvec[1] * m_p_X[2] - m_nvec[2] * m_p_X[1];                                  // :222 CrossProduct
         m_p_Y[1] = m_nvec[2] * m_p_X[0] - m_nvec[0] * m_p_X[2];
         m_p_Y[2] = m_nvec[0] * m_p_X[1] - m_nvec[1] * m_p_X[0];
@@ -664,6 +672,7 @@ public:
         m_mobility = 0.05 / m_cfg.e_max;                                                         // ComputeWeightMobility :764-781
         m_weight = 8.8541878128e-12 / m_mobility;
         m_weight *= m_S_X * m_S_Y;
+        m_mobility = m_mobility / m_ctx->gamma_boost;   // e_max is a lab-frame amplitude (:772-775)
         int plo[2] = {INT_MAX, INT_MAX}, phi[2] = {INT_MIN, INT_MIN};
         for (int c = 0; c < 8; ++c) {                                                           // :418-457
             const double pos[3] = {(c & 1) ? m_ctx->prob_hi[0] : m_ctx->prob_lo[0], (c & 2) ? m_ctx->prob_hi[1] : m_ctx->prob_lo[1],
@@ -708,10 +717,15 @@ public:
         par.mobility = m_mobility;
         par.e_max = m_cfg.e_max; par.wavelength = m_cfg.wavelength; par.waist = m_cfg.waist;
         par.duration = m_cfg.duration; par.t_peak = m_cfg.t_peak; par.focal_distance = m_cfg.focal_distance;
+        for (int d = 0; d < 3; ++d) par.nvec[d] = m_nvec[d];
+        par.gamma_boost = m_ctx->gamma_boost;
+        amrex::Real t_lab = t;
+        if (m_ctx->gamma_boost > 1.0)   // the field to emit is the lab-frame one at the antenna's lab-frame time (:574-579)
+            t_lab = 1.0 / m_ctx->gamma_boost * t + m_ctx->beta_boost * m_Z0_lab / 299'792'458.;
         {
             PhaseTimer tm(m_ctx, kGatherAndPush);   // "LaserParticleContainer::Evolve::ParticlePush"
             const wxa_particle_view p = m_tile.view();
-            check(m_ctx->be->laser_push(&p, &par, t, dt, m_ctx->stream), "laser_push");
+            check(m_ctx->be->laser_push(&p, &par, t_lab, dt, m_ctx->stream), "laser_push");
         }
         if (m_ctx->sort_now) SortParticlesByBin(amrex::IntVect(1));
         if (!skip_deposition) {
@@ -729,6 +743,7 @@ private:
     wxa_laser_antenna m_cfg;
     double m_nvec[3], m_p_X[3], m_p_Y[3], m_position[3];
     double m_S_X = 0, m_S_Y = 0, m_mobility = 0, m_weight = 0;
+    double m_Z0_lab = 0;
 };
 
 // Source/Particles/MultiParticleContainer.{H,cpp}

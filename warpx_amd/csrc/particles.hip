@@ -237,6 +237,8 @@ struct LaserPushGeom {
     double mobility;
     double pre_re, pre_im;     // P
     double iw2_re, iw2_im;     // 1 / (w^2 D)
+    double drift[3];           // c beta_boost nvec (0 in the lab frame)
+    double gamma_boost;        // >= 1
 };
 
 __global__ void __launch_bounds__(256)
@@ -253,10 +255,11 @@ laser_push_kernel(PV p, LaserPushGeom lg, double dt) {
     const double amplitude = lg.pre_re * er - lg.pre_im * ei;
     const double sign_charge = (p.w[i] > 0) ? -1.0 : 1.0;
     const double v_over_c = sign_charge * lg.mobility * amplitude;
-    const double vx = PhysConst::c * v_over_c * lg.p_X[0];
-    const double vy = PhysConst::c * v_over_c * lg.p_X[1];
-    const double vz = PhysConst::c * v_over_c * lg.p_X[2];
-    const double gamma = 1.0 / sqrt(1.0 - v_over_c * v_over_c);
+    // in a boosted frame the antenna also drifts with -beta_boost c along nvec (:907-915)
+    const double vx = PhysConst::c * v_over_c * lg.p_X[0] - lg.drift[0];
+    const double vy = PhysConst::c * v_over_c * lg.p_X[1] - lg.drift[1];
+    const double vz = PhysConst::c * v_over_c * lg.p_X[2] - lg.drift[2];
+    const double gamma = lg.gamma_boost / sqrt(1.0 - v_over_c * v_over_c);
     p.ux[i] = gamma * vx; p.uy[i] = gamma * vy; p.uz[i] = gamma * vz;
     p.x[i] = x + vx * dt; p.y[i] = y + vy * dt; p.z[i] = z + vz * dt;
 }
@@ -965,6 +968,9 @@ wxa_status wxa_laser_push(const wxa_particle_view* p, const wxa_laser_push_param
     lg.mobility = c->mobility;
     lg.pre_re = stcfactor.real(); lg.pre_im = stcfactor.imag();
     lg.iw2_re = inv_complex_waist_2.real(); lg.iw2_im = inv_complex_waist_2.imag();
+    lg.gamma_boost = c->gamma_boost > 1.0 ? c->gamma_boost : 1.0;
+    const double beta_boost = lg.gamma_boost > 1.0 ? std::sqrt(1.0 - 1.0 / std::pow(lg.gamma_boost, 2.0)) : 0.0;
+    for (int d = 0; d < 3; ++d) lg.drift[d] = lg.gamma_boost > 1.0 ? PhysConst::c * beta_boost * c->nvec[d] : 0.0;
     hipLaunchKernelGGL(laser_push_kernel, dim3(blocks_for(p->np)), dim3(256), 0, (hipStream_t)stream, make_pv(*p), lg, dt);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
