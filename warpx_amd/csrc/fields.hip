@@ -494,6 +494,8 @@ evolve_b_ckc_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 u
 // MI355X, 256^3, back to back (72 B/cell; Yee's EvolveB 0.216 ms = 69.8 % of 8 TB/s on the same box):
 //   plain 1.038 ms (14.5 %)   TJ x KC = 8 x 16 0.363 (41.6 %)   8 x 16 PIPE 0.337 (44.8 %)   8 x 32 PIPE 0.370
 //   4 x 32 PIPE 0.343   16 x 16 PIPE 0.373   8 x 8 PIPE 0.335 (45.1 %)
+// (Also tried, on the Yee kernels too: the three old values of B -- E and J in evolve_e_kernel -- loaded before the first
+// store instead of load - add - store per component: EvolveE 0.316 -> 0.351 ms, this kernel 0.337 -> 0.415.)
 // Tried and rejected: the staging loop as `for (a = tid; a < PLANE; a += NT) slot[a] = load` (one load in flight per lane:
 // 0.553); a 3 x 3 x 3 register window per component shifted along k, fed from global memory (0.689) or from a two-slot
 // LDS copy of the plane (0.749: the shifts); all six derivatives evaluated before the three stores so that the LDS
