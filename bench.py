@@ -234,6 +234,9 @@ def main():
                          "f32 = ds_add_f32, the throughput variant of BASELINE.json's north_star (2e-6 gate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-pass", action="store_true")
+    ap.add_argument("--sync-each-call", action="store_true",
+                    help="synchronise the momenta at the end of every evolve call like WarpX::Evolve(n) does (the timed "
+                         "region then contains one PushP(-dt/2) / PushP(+dt/2) pair); default: one run advanced in pieces")
     ap.add_argument("--no-sanity", action="store_true", help="skip the energy / particle-count figures around the timed steps")
     args = ap.parse_args()
 
@@ -299,6 +302,12 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # The K timed steps are steps in the middle of a run: WarpX::Evolve(n) pushes the momenta back by dt/2 in its first
+    # step and forward again in its last one (WarpXEvolve.cpp:142-145, 222-226), once per run, not per step; called once
+    # per timing interval that pair (two extra field gathers over all particles) would be charged to the K steps.
+    # --sync-each-call times Evolve(K) with the pair inside.
+    if not args.sync_each_call:
+        sim.set_synchronize_at_end(False)
     if args.preroll > 0:
         sim.evolve(args.preroll)
     sim.evolve(args.warmup)
@@ -326,7 +335,9 @@ def main():
         sanity = {"particles_after": int(counts[0]), "particles_expected": int(np_local * world),
                   "total_energy_drift_over_timed_steps": (tot1 - tot0) / tot0,
                   "kinetic_energy_J_rank0": e_after[1], "field_energy_J_rank0": e_after[0],
-                  "note": "rank 0's share of the energy before / after the timed steps; the count is global"}
+                  "note": "rank 0's share of the energy before / after the timed steps; the count is global"
+                          + ("" if args.sync_each_call else "; kinetic energy from the leap-frog momenta (half a step "
+                             "behind the fields) at both ends")}
     # second, short pass with per-phase HIP-event timers (on the stream the kernels run on)
     phases = {}
     if not args.no_phase_pass:
@@ -406,7 +417,9 @@ def main():
                                    f"{args.pusher}, filter {'off' if args.no_filter else 'on'}",
                        "cells_per_gpu": ncells_local, "particles_per_gpu": np_local,
                        "bricks": list(nbricks), "sort_interval": args.sort_interval,
-                       "preroll_steps": args.preroll, "overlap_halo": bool(sim.halo_overlap)},
+                       "preroll_steps": args.preroll, "overlap_halo": bool(sim.halo_overlap),
+                       "momentum_synchronisation": "inside the timed region (Evolve(K) as one run)" if args.sync_each_call
+                       else "outside the timed region (the K steps are consecutive steps of one longer run)"},
             "roofline": roofline,
             "kernels": kernels,
         }

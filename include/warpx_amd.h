@@ -613,6 +613,12 @@ wxa_status wxa_sim_add_species(wxa_sim* s, double charge, double mass,
 /* WarpX::Evolve(numsteps): first step de-synchronises u by PushP(-dt/2),
  * the last one re-synchronises (WarpXEvolve.cpp:142-145,222-226). */
 wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
+/* on = 0: wxa_sim_evolve leaves the momenta at the half step when it returns and the next call continues from there,
+ * so that several calls are exactly the steps of one long WarpX::Evolve (what a run of many steps looks like between
+ * its first and last step); wxa_sim_synchronize does the push of WarpX::Synchronize (WarpXEvolve.cpp:65-93) when the
+ * momenta are wanted at the time of the positions (diagnostics, checksums).  Default: on = 1, the reference's behaviour. */
+wxa_status wxa_sim_set_synchronize_at_end(wxa_sim* s, int32_t on);
+wxa_status wxa_sim_synchronize(wxa_sim* s);
 /* particles.E_external_particle / particles.B_external_particle (constant external fields on the particles of
  * species `id`; the reference keeps them per container and reads them from the `particles.` block) */
 wxa_status wxa_sim_set_external_particle_fields(wxa_sim* s, int32_t id, const double E[3], const double B[3]);

@@ -343,6 +343,40 @@ def test_boosted_frame_injection_through_a_moving_window(lib):
     sim.close()
 
 
+def test_evolve_in_pieces_without_the_synchronisation_in_between(lib):
+    """wxa_sim_set_synchronize_at_end(0): three calls of wxa_sim_evolve + wxa_sim_synchronize are the steps of one long
+    call (no PushP(+dt/2) / PushP(-dt/2) pair at the seams, which would round differently)."""
+    deck = os.path.join(DECKS, "langmuir_multi_3d.inputs")
+    ov = ["max_step = 9", "amr.n_cell = 16 16 16"]
+    whole = WarpXSim.from_inputs(lib, deck, overrides=ov)
+    whole.evolve(9)
+    pieces = WarpXSim.from_inputs(lib, deck, overrides=ov)
+    pieces.set_synchronize_at_end(False)
+    for n in (2, 4, 3):
+        pieces.evolve(n)
+    half = pieces.particles(0)[4].copy()                  # momenta still at the half step
+    pieces.synchronize()
+    pieces.synchronize()                                  # a second call is a no-op
+    assert not np.array_equal(half, pieces.particles(0)[4])
+    # to round-off, not bit for bit: the CPU kernels' threaded deposition adds in no fixed order, and the final half
+    # push gathers before the last periodic wrap in the one case and after it in the other
+    for sid in range(len(whole.species_names)):
+        a, b = whole.particles(sid), pieces.particles(sid)
+        assert np.allclose(a[:3], b[:3], rtol=0, atol=1e-13 * 40e-6) and np.array_equal(a[3], b[3])
+        assert np.allclose(a[4:], b[4:], rtol=0, atol=1e-12 * np.abs(a[4:]).max())
+    for name in ("Ex", "Ey", "Ez", "jx", "jy", "jz"):          # (B of a Langmuir oscillation is round-off residue)
+        fa, fb = whole.field_valid(name), pieces.field_valid(name)
+        assert np.abs(fa - fb).max() <= 1e-12 * np.abs(fa).max(), name
+    # with the default every call synchronises: same physics, different rounding at the seams
+    seams = WarpXSim.from_inputs(lib, deck, overrides=ov)
+    for n in (2, 4, 3):
+        seams.evolve(n)
+    a, b = whole.particles(0)[4], seams.particles(0)[4]
+    assert np.allclose(a, b, rtol=0, atol=1e-11 * np.abs(a).max())
+    for sim in (whole, pieces, seams):
+        sim.close()
+
+
 def test_constant_external_grid_fields(lib, tmp_path):
     """warpx.B_ext_grid_init_style = constant with non-zero values (WarpXInitData.cpp:940-960): the value at every
     point, guards included; a uniform B stays what it is under the Yee update."""

@@ -771,6 +771,23 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
             return (RET)WXA_ERR_INVALID_ARG;                                                           \
         }                                                                                              \
     }                                                                                                  \
+    /* Evolve without / with the velocity synchronisation at the end of the call, and the synchronisation alone */ \
+    RET PFX##sim_set_synchronize_at_end(SIMTYPE* s, int32_t on) {                                      \
+        if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \
+        reinterpret_cast<wxa::host::SimHandle*>(s)->warpx->synchronize_at_end = on != 0;               \
+        return (RET)WXA_OK;                                                                            \
+    }                                                                                                  \
+    RET PFX##sim_synchronize(SIMTYPE* s) {                                                             \
+        if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        try {                                                                                          \
+            h->warpx->SynchronizeNow();                                                                \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_HIP;                                                                   \
+        }                                                                                              \
+    }                                                                                                  \
     /* the expression evaluator of the decks, for tests and tools */                                   \
     RET PFX##parser_eval(const char* expr, int32_t nvars, const char* const* names, const double* values, \
                          double* out) {                                                                \

@@ -132,6 +132,14 @@ class WarpXSim:
         self.lib.sim_set_radiation_reaction(self._h, int(sid), 1 if on else 0)
 
     # ---- stepping -----------------------------------------------------------
+    def set_synchronize_at_end(self, on: bool):
+        """evolve() leaves the momenta at the half step (on = False): consecutive calls are the steps of one long run."""
+        self.lib.sim_set_synchronize_at_end(self._h, 1 if on else 0)
+
+    def synchronize(self):
+        """WarpX::Synchronize: the momenta to the time of the positions, if they are not there already."""
+        self.lib.sim_synchronize(self._h)
+
     def evolve(self, numsteps: int):
         self.lib.sim_evolve(self._h, int(numsteps))
 
