@@ -227,6 +227,61 @@ def test_enforce_periodic_and_sort(oracle, product):
     product.workspace_destroy(ws)
 
 
+@pytest.mark.parametrize("drift,retire", [(0.0, False), (0.3, False), (0.3, True), (3.0, False)])
+def test_sort_of_a_nearly_sorted_tile(product, drift, retire, monkeypatch):
+    """The windowed scatter (a workgroup stages the particles that stay near their place in LDS and writes whole
+    lines) on what it is built for -- a second sort after the particles drifted by a fraction of a cell -- and on what it
+    must survive: no drift at all, a drift of several cells (most particles beyond the window margin), retired particles
+    (sorted behind the live ones).  Same permutation of the same particles, ids included, as the plain scatter
+    (WXA_SORT_SCATTER=0); keys non-decreasing."""
+    ncell = (24, 16, 40)
+    n = 150000
+    parts = H.random_particles(n, ncell, 95)
+    rng = np.random.default_rng(96)
+    dx = H.LX / np.asarray(ncell)
+    plo = H.d3((-H.LX / 2,) * 3)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    first = ParticleArrays.from_numpy(parts, DEV, ids)
+    srt = ParticleArrays(n, DEV, with_id=True)
+    args = (plo, H.d3(1.0 / dx), (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    product.sort_particles_by_cell(C.byref(first.view), C.byref(srt.view), *args)
+    _sync(product)
+    a = srt.to_numpy()
+    aid = srt.ids_to_numpy()
+    for d in range(3):   # drift, kept inside the box
+        a[d] = np.clip(a[d] + drift * dx[d] * rng.standard_normal(n), -H.LX / 2 * 0.999, H.LX / 2 * 0.999)
+    if retire:
+        gone = rng.random(n) < 0.01
+        aid = np.where(gone, np.int64(-1), aid)       # WXA_IDCPU_RETIRED = all ones
+        a[3] = np.where(gone, 0.0, a[3])
+    results = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WXA_SORT_SCATTER", mode)
+        src = ParticleArrays.from_numpy(list(a), DEV, aid)
+        out = ParticleArrays(n, DEV, with_id=True)
+        product.sort_particles_by_cell(C.byref(src.view), C.byref(out.view), *args)
+        _sync(product)
+        s, sid = out.to_numpy(), out.ids_to_numpy()
+        live = sid != -1
+        assert live.sum() == (aid != -1).sum() and np.all(live[:live.sum()])      # retired ones at the end
+        sl = s[:, live]
+        cell = [np.clip(np.floor((sl[d] + H.LX / 2) / dx[d]).astype(np.int64), 0, ncell[d] - 1) for d in range(3)]
+        T = 8
+        nt = [(m + T - 1) // T for m in ncell]
+        tile = cell[0] // T + nt[0] * (cell[1] // T + nt[1] * (cell[2] // T))
+        kt = cell[2] % T
+        key = tile * T ** 3 + cell[0] % T + T * ((kt & 1) + 2 * (cell[1] % T + T * (kt >> 1)))
+        assert np.all(np.diff(key) >= 0)
+        order = np.argsort(sid[live], kind="stable")
+        results.append((sid[live][order], sl[:, order]))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    ref_order = np.argsort(aid[aid != -1], kind="stable")
+    assert np.array_equal(results[1][1], a[:, aid != -1][:, ref_order])           # every particle arrived with its own data
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.parametrize("steps", [0, 3, 6, 7])
 def test_enforce_periodic_through_the_sort(product, steps):
     """wxa_enforce_periodic_sorted (face tiles of the last sort + appended tail) against the plain pass, bit for bit:

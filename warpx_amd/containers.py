@@ -165,6 +165,14 @@ class ParticleArrays:
             return self.data.copy()
         return np.array(self.data.cpu().numpy())   # an owned copy wherever the tensor lives
 
+    def ids_to_numpy(self) -> np.ndarray:
+        """idcpu as int64 (WXA_IDCPU_RETIRED, all ones, reads -1)."""
+        if self.idcpu is None:
+            raise ValueError("this tile carries no idcpu")
+        if self.device == "cpu":
+            return self.idcpu.astype(np.int64)
+        return np.array(self.idcpu.cpu().numpy()).astype(np.int64)
+
     def copy_to(self, device):
         ids = None
         if self.idcpu is not None:

@@ -200,6 +200,71 @@ sort_scatter_kernel(PV src, PV dst, const int* __restrict__ cell, const int* __r
     if (has_id) dst.id[d] = id;
 }
 
+// The same scatter for an input that is nearly sorted already (every sort after the first: a particle moves less than
+// a cell between sorts, so its destination index is within a few hundred of its source index).  A workgroup takes
+// SW_CHUNK consecutive source particles and a window of destination indices around them; a component at a time, the
+// particles whose destination lies inside the window are placed at their destination offset in LDS and the window is
+// written out in index order -- whole lines instead of 8-byte writes scattered over them -- and the others (movers
+// beyond the margin; everything, on an unsorted input) are written directly as before.  A destination slot belongs to
+// exactly one particle, so the masked window writes of neighbouring workgroups never touch the same element.
+constexpr int SW_THREADS = 512, SW_U = 8, SW_CHUNK = SW_THREADS * SW_U, SW_MARGIN = 512, SW_WIN = SW_CHUNK + 2 * SW_MARGIN;
+
+__global__ void __launch_bounds__(SW_THREADS)
+sort_scatter_window_kernel(PV src, PV dst, const int* __restrict__ cell, const int* __restrict__ rank,
+                           const int* __restrict__ offsets) {
+    __shared__ double win[SW_WIN];
+    __shared__ unsigned char mine[SW_WIN];
+    const int tid = threadIdx.x;
+    const long c0 = (long)blockIdx.x * SW_CHUNK;
+    const long w0 = c0 > SW_MARGIN ? c0 - SW_MARGIN : 0;
+    for (int a = tid; a < SW_WIN; a += SW_THREADS) mine[a] = 0;
+    long d[SW_U];
+    int slot[SW_U];   // offset in the window, or -1: written directly
+    int ce[SW_U], ra[SW_U];
+#pragma unroll
+    for (int u = 0; u < SW_U; ++u) {
+        const long ip = c0 + u * SW_THREADS + tid;
+        const bool in = ip < src.np;
+        ce[u] = in ? cell[ip] : 0;
+        ra[u] = in ? rank[ip] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < SW_U; ++u) {
+        const long ip = c0 + u * SW_THREADS + tid;
+        d[u] = ip < src.np ? (long)offsets[ce[u]] + ra[u] : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SW_U; ++u) {
+        const long o = d[u] - w0;
+        slot[u] = (d[u] >= 0 && o >= 0 && o < SW_WIN) ? (int)o : -1;
+        if (slot[u] >= 0) mine[slot[u]] = 1;
+    }
+    __syncthreads();
+    const bool has_id = src.id && dst.id;
+    const double* sp[8] = {src.x, src.y, src.z, src.w, src.ux, src.uy, src.uz, reinterpret_cast<const double*>(src.id)};
+    double* dp[8] = {dst.x, dst.y, dst.z, dst.w, dst.ux, dst.uy, dst.uz, reinterpret_cast<double*>(dst.id)};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c == 7 && !has_id) break;
+        double v[SW_U];
+#pragma unroll
+        for (int u = 0; u < SW_U; ++u) {
+            const long ip = c0 + u * SW_THREADS + tid;
+            v[u] = ip < src.np ? sp[c][ip] : 0.0;   // ids travel as bit patterns
+        }
+#pragma unroll
+        for (int u = 0; u < SW_U; ++u) {
+            if (slot[u] >= 0) win[slot[u]] = v[u];
+            else if (d[u] >= 0) dp[c][d[u]] = v[u];
+        }
+        __syncthreads();
+        for (int a = tid; a < SW_WIN; a += SW_THREADS)
+            if (mine[a]) dp[c][w0 + a] = win[a];
+        __syncthreads();
+    }
+}
+
 // ---- 3-way partition for Redistribute ---------------------------------------------
 __global__ void __launch_bounds__(256)
 partition_flag_kernel(const double* __restrict__ pos, long np, double lo, double hi, int* __restrict__ stay,
@@ -829,7 +894,14 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
     if ((rc = ws->scan_tmp.reserve(tmp_bytes)) != WXA_OK) return rc;
     WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s, d, cell, rank, offsets);
+    // WXA_SORT_SCATTER=0: the plain scatter (one lane per particle, 8-byte writes wherever they fall)
+    const char* scatter_env = std::getenv("WXA_SORT_SCATTER");
+    const bool plain_scatter = scatter_env && std::atoi(scatter_env) == 0;
+    if (plain_scatter)
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s, d, cell, rank, offsets);
+    else
+        hipLaunchKernelGGL(sort_scatter_window_kernel, dim3(blocks_for(s.np, SW_CHUNK)), dim3(SW_THREADS), 0, st, s, d, cell,
+                           rank, offsets);
     WXA_LAUNCH_CHECK();
     ws->sorted_valid = true;
     ws->sorted_np = src->np;   // wxa_sort_live_count lowers it to the live count
