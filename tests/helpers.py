@@ -17,11 +17,9 @@ ON_GPU = not HIP_ON_CPU
 DEVICE = "cuda" if ON_GPU else "cpu:0"   # "cpu:0": torch tensors in host memory (the containers keep "cpu" for numpy)
 
 
-# Tests of kernels that no MI355X has executed yet (written after round 1's GPU budget was spent).  They have
-# passed on the HIP-on-CPU execution model (plain, FMA-contracting and guard-page builds, tests/hipcpu), and the CPU
-# restatement they compare with is pinned to the reference's golden vectors.  conftest.py runs them after every other
-# test, so that with `-x` a first-run failure cannot hide the tests that have a GPU history;
-# WXA_SKIP_FIRST_GPU_RUN=1 skips them.
+# Tests that were written after round 1's GPU budget was spent (first run on an MI355X in round 2, all green since).
+# The marker only orders them: conftest.py runs them after every other test, so that with `-x` a failure among the
+# younger tests cannot hide the ones with a longer GPU history; WXA_SKIP_FIRST_GPU_RUN=1 skips them.
 import pytest  # noqa: E402
 
 FIRST_GPU_RUN = pytest.mark.first_gpu_run
