@@ -415,6 +415,8 @@ def test_deposit_tile_variants(oracle, product, deposit_variant, stale, u_scale)
     on whole / half tiles at 3 / 4 waves per SIMD) against the oracle: fresh and stale sort, fast and crossing path;
     and exact zeros."""
     test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_ESIRKEPOV, stale, u_scale)
+    if deposit_variant in (0, 14):   # direct deposition: the staged kernel of round 1 (0) and the rows kernel (default)
+        test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_DIRECT, stale, u_scale)
     if not stale:
         test_esirkepov_zero_displacement_deposits_exactly_zero(product, 3, 1, u_scale)
 

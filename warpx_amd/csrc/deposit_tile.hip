@@ -519,9 +519,11 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 // a cell goes to the deferred list | D deferred particles through the wide single body, one lane per (component,
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
-template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0, class ACC_ = double, int BW_ = 0>
+template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0, class ACC_ = double, int BW_ = 0,
+          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV>
 struct RowsCfg {
     static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_, PF = PF_;   // PF: L2 prefetch
+    static constexpr int ALGO = ALGO_;   // WXA_DEPOSIT_DIRECT: the same work items, every particle on its own (no pairs)
     using ACC = ACC_;   // accumulator type of the LDS tile
     // cells per block of the direct part = lanes that one step of the LDS atomic serves (16 for ds_add_f64, 32 for
     // ds_add_f32): a chunk is BW consecutive cells x 64 / BW pairs, and the first four pairs of a block take
@@ -540,7 +542,8 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
                          const double* __restrict__ pz, const double* __restrict__ pw,
                          const double* __restrict__ pux, const double* __restrict__ puy,
                          const double* __restrict__ puz, const int* __restrict__ offsets, DevF Jx, DevF Jy,
-                         DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, StragglerQueue sq) {
+                         DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, double relative_time,
+                         StragglerQueue sq) {
     constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
     using TD = TileDims<M, TSZ>;
     constexpr int N = TD::N, NZ = TD::NZ, NPTS = TD::NPTS, PS = TD::PS;
@@ -666,6 +669,39 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         // all fourteen loads in flight together (an empty lane reads the tile's first particle)
         const ParticleState pa{px[ia], py[ia], pz[ia], pw[ia], pux[ia], puy[ia], puz[ia]};
         const ParticleState pb{px[ib], py[ib], pz[ib], pw[ib], pux[ib], puy[ib], puz[ib]};
+        if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT) {
+            // doDepositionShapeN (CurrentDeposition.H:48-249) on the tile: the lane's two particles one after the other,
+            // each component on its own frame (jx: cell-centred in x, nodal in y and z; ...), products in the
+            // reference's order; a stencil that leaves the tile goes to the global-atomics pass
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                if (!(h ? vb : va)) continue;
+                const ParticleState pp = h ? pb : pa;
+                DirectShapes<O> ds;
+                direct_shapes<O>(pp, g, q, relative_time, ds);
+                const int li = min(ds.jn, ds.jc) - o0, hi = max(ds.jn, ds.jc) + O - o0;
+                const int lj = min(ds.kn, ds.kc) - o1, hj = max(ds.kn, ds.kc) + O - o1;
+                const int lk = min(ds.ln, ds.lc) - o2, hk = max(ds.ln, ds.lc) + O - o2;
+                if (!(li >= 0 && lj >= 0 && lk >= 0 && hi < N && hj < N && hk < NZ)) {
+                    sq.push(h ? ib : ia);
+                    continue;
+                }
+                LdsSink<M, TSZ, ACC> sjx(lds, ds.jc - o0, ds.kn - o1, ds.ln - o2);
+                LdsSink<M, TSZ, ACC> sjy(lds, ds.jn - o0, ds.kc - o1, ds.ln - o2);
+                LdsSink<M, TSZ, ACC> sjz(lds, ds.jn - o0, ds.kn - o1, ds.lc - o2);
+#pragma unroll
+                for (int iz = 0; iz <= O; iz++)
+#pragma unroll
+                    for (int iy = 0; iy <= O; iy++)
+#pragma unroll
+                        for (int ix = 0; ix <= O; ix++) {
+                            sjx.add(0, ix, iy, iz, ds.sxc[ix] * ds.syn[iy] * ds.szn[iz] * ds.wqx);
+                            sjy.add(1, ix, iy, iz, ds.sxn[ix] * ds.syc[iy] * ds.szn[iz] * ds.wqy);
+                            sjz.add(2, ix, iy, iz, ds.sxn[ix] * ds.syn[iy] * ds.szc[iz] * ds.wqz);
+                        }
+            }
+            continue;
+        }
         EsirkepovCoords c1 = esirkepov_coords(pa, g, es), c2 = esirkepov_coords(pb, g, es);
         double wq1 = q * pa.w, wq2 = 0.0;
         const double wqb = q * pb.w;
@@ -843,8 +879,8 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
     hipLaunchKernelGGL((deposit_tile_rows_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, sq);
-    hipLaunchKernelGGL((deposit_stragglers_kernel<O, WXA_DEPOSIT_ESIRKEPOV>), dim3(512), dim3(256), 0, st, p->x, p->y,
+                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, relative_time, sq);
+    hipLaunchKernelGGL((deposit_stragglers_kernel<O, CFG::ALGO>), dim3(512), dim3(256), 0, st, p->x, p->y,
                        p->z, p->w, p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
@@ -865,6 +901,7 @@ using RowsWhole3NoLds = RowsCfg<768, 8, 3, 1, 1>;
 using RowsWhole3NoAlu = RowsCfg<768, 8, 3, 1, 2>;
 using RowsWhole3Pf = RowsCfg<768, 8, 3, 1, 0, 1>;
 using RowsWhole3F32 = RowsCfg<768, 8, 3, 1, 0, 0, float>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
+using RowsDirect = RowsCfg<768, 8, 3, 1, 0, 0, double, 0, WXA_DEPOSIT_DIRECT>;   // direct deposition on the same work items
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
     const char* e = getenv("WXA_DEPOSIT_VARIANT");
@@ -893,9 +930,15 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
             default: return launch_rows<3, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
         }
     }
-    if (order == 1) return launch_tile<1, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
-    if (order == 2) return launch_tile<2, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
-    return launch_tile<3, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
+    // direct deposition: the rows kernel too (round 2, last session); WXA_DEPOSIT_VARIANT=0 = the staged kernel of round 1
+    if (deposit_variant() == 0) {
+        if (order == 1) return launch_tile<1, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
+        if (order == 2) return launch_tile<2, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
+        return launch_tile<3, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
+    }
+    if (order == 1) return launch_rows<1, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
+    if (order == 2) return launch_rows<2, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
+    return launch_rows<3, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
 }
 
 }  // namespace wxa
