@@ -265,8 +265,8 @@ def test_pec_field_golden_on_gpu(oracle, product):
     gold = json.load(open(os.path.join(HERE, "golden", "pec_field_3d_checksums.json")))
     ref = pec_case.make_sim(oracle)
     ref.evolve(pec_case.MAX_STEP)
-    for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz"):
-        assert np.array_equal(sim.field(name), ref.field(name)), name
+    for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz"):     # valid points (the corner guards differ by design, see
+        assert np.array_equal(sim.field_valid(name), ref.field_valid(name)), name   # tests/test_pec_golden.py)
     for name, want in gold["checksums"]["lev=0"].items():
         got = oracle.cell_centered_abs_sum(C.byref(ref.field_view(name)))   # == the GPU field, checked above
         assert abs(got - want) / want < gold["rtol"]
