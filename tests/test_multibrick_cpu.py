@@ -62,6 +62,9 @@ def test_ckc_bricks_match_single_domain(nb, order, filt, port, tmp_path):
     ((0, 0, 0), 8, "langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", 29625),
     # reflecting walls in x, absorbing ones in y, bricks along the periodic z
     ((1, 1, 2), 2, "particle_walls_3d.inputs", "particle_boundaries_3d_checksums.json", 29626),
+    # direct deposition, 8 ppc, filter, the gather without Galerkin shapes
+    ((1, 2, 2), 4, "langmuir_beam_direct_3d.inputs", "langmuir_multi_picmi_3d_checksums.json", 29627),
+    ((0, 0, 0), 2, "laser_injection_3d.inputs", "laser_injection_3d_checksums.json", 29628),
 ])
 def test_deck_on_bricks_reaches_the_golden_checksums(nb, nranks, deck, golden, port, tmp_path):
     """A whole inputs file on several bricks (gloo): the per-brick checksums add up to the reference's golden
