@@ -61,6 +61,17 @@ from tests.oracle_lib import load_hip_on_cpu  # noqa: E402
 
 warpx_amd.load_product = load_hip_on_cpu
 
+# N > 1 (python -m torch.distributed.run --nproc-per-node N scripts/bench_on_cpu.py --gpus N ...): gloo instead of RCCL,
+# host buffers in the torch transport; the in-library RCCL transport is not in the CPU build, so bench.py takes its
+# documented fall-back to the torch.distributed callbacks.
+import torch.distributed as _dist  # noqa: E402
+import warpx_amd.distributed as _wd  # noqa: E402
+
+_init = _dist.init_process_group
+_dist.init_process_group = lambda backend=None, **kw: _init("gloo", **{k: v for k, v in kw.items() if k != "device_id"})
+_Torch = _wd.TorchBrickTransport
+_wd.TorchBrickTransport = lambda on_device=True: _Torch(on_device=False)
+
 import bench  # noqa: E402
 
 if __name__ == "__main__":

@@ -14,6 +14,8 @@ Kept to the kernel-level tests (seconds); the step-level and multi-brick tests r
 """
 import os
 import subprocess
+
+import pytest
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -82,6 +84,26 @@ def test_bricks_over_gloo_with_the_hip_kernels(tmp_path):
     assert rep["np_total"] == rep["np_ref"] and rep["inside"] and rep["exchanges"] > 0
     assert all(err < 1e-10 for err in rep["errors"].values()), rep["errors"]
     assert rep["ekin_rel"] < 1e-11 and rep["abs_p_rel"] < 1e-11
+
+
+@pytest.mark.parametrize("n,port", [(2, 29661), (4, 29662), (8, 29663)])
+def test_bench_control_flow_on_several_ranks(n, port):
+    """bench.py --gpus N as the driver launches it (torch.distributed.run, one rank per GPU), on the CPU execution
+    model over gloo: brick layout, per-rank particles, the barrier / max-over-ranks timing, the exchange statistics
+    and the JSON line of rank 0.  Control flow only."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "bench_on_cpu.py"), "--gpus", str(n),
+           "--ncell", "16", "--steps", "3", "--warmup", "1", "--preroll", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == n and line["scaling"] == "weak" and line["steps"] == 3
+    assert line["config"]["bricks"] == {2: [1, 1, 2], 4: [1, 2, 2], 8: [2, 2, 2]}[n]
+    assert line["config"]["particles_per_gpu"] == 16 ** 3 * 8 and line["exchange"]["exchanges_per_step"] > 0
+    assert line["sanity"]["particles_after"] == n * 16 ** 3 * 8
 
 
 def test_bench_control_flow_on_the_cpu_execution_model():

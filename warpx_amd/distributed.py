@@ -191,16 +191,47 @@ class RcclBrickTransport:
         have_group = dist.is_available() and dist.is_initialized()
         self.rank = rank if rank is not None else (dist.get_rank(group) if have_group else 0)
         self.nranks = nranks if nranks is not None else (dist.get_world_size(group) if have_group else 1)
+        # Every step of the set-up is agreed on by all ranks before the next one starts: a rank that failed alone (no
+        # RCCL symbols, no unique id, communicator not created) would otherwise leave the others waiting in a
+        # broadcast or inside ncclCommInitRank while it has already fallen back to another transport.
+        def all_ok(ok, what):
+            if self.nranks > 1:
+                flags_ = [None] * self.nranks
+                dist.all_gather_object(flags_, bool(ok), group=group)
+                ok = all(flags_)
+            if not ok:
+                raise _capi.WxaError(f"RCCL transport: {what} failed on at least one rank")
+
         uid = (C.c_char * 128)()
+        err = None
         if self.rank == 0:
-            lib.rccl_unique_id(uid)
+            try:
+                lib.rccl_unique_id(uid)
+            except Exception as e:   # noqa: BLE001 -- reported to every rank below
+                err = repr(e)
         if self.nranks > 1:
-            box = [bytes(uid.raw)]
+            box = [None if err else bytes(uid.raw)]
             dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:
+                raise _capi.WxaError("RCCL transport: rank 0 could not create the unique id" + (f" ({err})" if err else ""))
             uid = (C.c_char * 128).from_buffer_copy(box[0])
+        elif err:
+            raise _capi.WxaError(f"RCCL transport: could not create the unique id ({err})")
+        all_ok(hasattr(lib, "_rccl_comm_create"), "loading the library's RCCL entry points")
         self.comm = _capi.Comm()
         flags = (_capi.RCCL_LOOPBACK if loopback else 0) | (_capi.RCCL_TIMING if timing else 0)
-        lib.rccl_comm_create(uid, self.rank, self.nranks, flags, C.byref(self.comm))
+        created = True
+        try:
+            lib.rccl_comm_create(uid, self.rank, self.nranks, flags, C.byref(self.comm))
+        except Exception as e:   # noqa: BLE001
+            created = False
+            err = repr(e)
+        try:
+            all_ok(created, "creating the communicator" + (f" ({err})" if err else ""))
+        except _capi.WxaError:
+            if created:
+                self.close()
+            raise
 
     def stats(self, reset=False):
         st = _capi.RcclStats()
