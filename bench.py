@@ -217,8 +217,8 @@ def main():
     ap.add_argument("--pusher", choices=["boris", "vay"], default="boris")
     ap.add_argument("--no-filter", action="store_true")
     ap.add_argument("--sort-interval", type=int, default=3,
-                    help="cell sort every N steps (warpx.sort_intervals); 3 measured best on MI355X: 1: 22.9, 2: 20.9, "
-                         "3: 20.6, 4: 21.8, 6: 22.5, 8: 25.1 ms/step")
+                    help="cell sort every N steps (warpx.sort_intervals); 3 measured best on MI355X (round 2 kernels): "
+                         "2: 15.9, 3: 15.75, 4: 16.4 ms/step")
     ap.add_argument("--preroll", type=int, default=40,
                     help="untimed steps before the warmup: the regular-lattice start is atypically cheap "
                          "(no particle crosses a cell for ~20 steps), the timed region must see the "
