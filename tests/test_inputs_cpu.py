@@ -284,6 +284,39 @@ def check_boosted_injection(sim):
     assert 0.0 < right - layers.max() * (dz / 2) <= dz * 1.001
 
 
+def check_particle_walls(sim, pos_tol=1e-15):
+    """The gate of Examples/Tests/boundaries/analysis.py on tests/decks/particle_walls_3d.inputs after its 8 steps: one of
+    the three particles heading for the absorbing walls is left; the two heading for the reflecting walls sit at the
+    mirror image of their free flight with the velocity reversed, the two crossing the periodic faces at the wrapped
+    position with the velocity unchanged (positions to 1e-15 on the CPU kernels, which keep the reference's operation
+    order; the device's reciprocal square root may differ in the last bit per step)."""
+    c = 299792458.0
+    t = sim.istep * sim.dt
+    names = sim.species_names
+    refl, absb, peri = (sim.particles(names.index(n)) for n in
+                        ("reflecting_particles", "absorbing_particles", "periodic_particles"))
+    assert absb.shape[1] == 1 and refl.shape[1] == 2 and peri.shape[1] == 2
+    for x0, u0 in ((-0.9, -0.9), (0.91, 0.91)):
+        v0 = u0 / math.sqrt(1.0 + u0 * u0) * c
+        xa = x0 + v0 * t
+        xa = 2.0 * -1.0 - xa if xa < -1.0 else (2.0 * 1.0 - xa if xa > 1.0 else xa)
+        i = int(np.argmin(np.abs(refl[0] - xa)))
+        assert abs((refl[0][i] - xa) / xa) < pos_tol and refl[4][i] == -u0 * c
+    for z0, u0 in ((-0.94, -0.94), (0.95, 0.95)):
+        v0 = u0 / math.sqrt(1.0 + u0 * u0) * c
+        za = z0 + v0 * t
+        za = za + 2.0 if za < -1.0 else (za - 2.0 if za > 1.0 else za)
+        i = int(np.argmin(np.abs(peri[2] - za)))
+        assert abs((peri[2][i] - za) / za) < pos_tol and peri[6][i] == u0 * c
+
+
+def test_particle_walls_analysis(lib):
+    sim = WarpXSim.from_inputs(lib, os.path.join(DECKS, "particle_walls_3d.inputs"))
+    sim.evolve(sim.max_step)
+    check_particle_walls(sim)
+    sim.close()
+
+
 def check_boosted_laser(sim):
     """tests/decks/boosted_laser_3d.inputs after its 130 steps: the plane pulse the boosted antenna emitted travels
     along +z with the Lorentz-transformed amplitude E gamma (1 - beta) and wavelength lambda gamma (1 + beta) of the
