@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402,F401
 import torch.distributed as dist  # noqa: E402
 
-from tests.oracle_lib import load_host_cpu  # noqa: E402
+from tests.oracle_lib import load_hip_on_cpu, load_host_cpu  # noqa: E402
 from warpx_amd.distributed import TorchBrickTransport, brick_coord  # noqa: E402
 from warpx_amd.sim import WarpXSim  # noqa: E402
 
@@ -25,11 +25,13 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     transport = TorchBrickTransport(on_device=False)
+    # WXA_WORKER_LIB=hipcpu: the product's .hip sources on the CPU execution model instead of the CPU kernels
+    load = load_hip_on_cpu if os.environ.get("WXA_WORKER_LIB") == "hipcpu" else load_host_cpu
     if nb == (0, 0, 0):     # let the library choose the bricks for comm.nranks
-        sim = WarpXSim.from_inputs(load_host_cpu(), deck, comm=transport.comm)
+        sim = WarpXSim.from_inputs(load(), deck, comm=transport.comm)
     else:
         assert world == nb[0] * nb[1] * nb[2]
-        sim = WarpXSim.from_inputs(load_host_cpu(), deck, nbricks=nb, coord=brick_coord(rank, nb), comm=transport.comm)
+        sim = WarpXSim.from_inputs(load(), deck, nbricks=nb, coord=brick_coord(rank, nb), comm=transport.comm)
     sim.evolve(sim.max_step)
     gathered = [None] * world
     dist.gather_object(sim.checksum(), gathered if rank == 0 else None, dst=0)

@@ -86,6 +86,34 @@ def test_bricks_over_gloo_with_the_hip_kernels(tmp_path):
     assert rep["ekin_rel"] < 1e-11 and rep["abs_p_rel"] < 1e-11
 
 
+def test_boosted_wakefield_deck_on_bricks_with_the_hip_kernels(tmp_path):
+    """BASELINE config 5 in small (tests/decks/laser_wakefield_boosted_3d.inputs, first 40 steps) on two bricks over gloo,
+    every brick running the product's .hip sources on the execution model: device-side boosted injection per brick, the
+    antenna split over the bricks, CKC next to the PEC walls, the windowed sort, the moving window -- against one brick on
+    the CPU kernels at the reference's 1e-9."""
+    import json
+    from tests.oracle_lib import load_host_cpu
+    from tests.test_inputs_cpu import compare_with_golden
+    from warpx_amd.sim import WarpXSim
+    deck = str(tmp_path / "inputs")
+    text = open(os.path.join(ROOT, "tests", "decks", "laser_wakefield_boosted_3d.inputs")).read()
+    open(deck, "w").write(text.replace("max_step = 120", "max_step = 40"))
+    one = WarpXSim.from_inputs(load_host_cpu(), deck)
+    one.evolve(one.max_step)
+    want = one.checksum()
+    one.close()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hipcpu"), "-j8"], stdout=subprocess.DEVNULL)
+    out = str(tmp_path / "sum.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29664", os.path.join(ROOT, "tests", "deck_worker.py"), "2", "1", "1", deck, out]
+    env = dict(os.environ, OMP_NUM_THREADS="1", WXA_WORKER_LIB="hipcpu", WXA_HIP_ON_CPU="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = json.load(open(out))
+    assert got["lev=0"]["part_per_cell"] == want["lev=0"]["part_per_cell"]
+    compare_with_golden(got, want, 1e-9)
+
+
 @pytest.mark.parametrize("n,port", [(2, 29661), (4, 29662), (8, 29663)])
 def test_bench_control_flow_on_several_ranks(n, port):
     """bench.py --gpus N as the driver launches it (torch.distributed.run, one rank per GPU), on the CPU execution
