@@ -67,16 +67,18 @@ def test_smoke_body_on_the_cpu_execution_model():
     assert r.returncode == 0 and "[smoke] HIP vs oracle" in r.stdout, (r.stdout + r.stderr)[-2000:]
 
 
-def test_bricks_over_gloo_with_the_hip_kernels(tmp_path):
-    """The 2-GPU layout of bench.py as two processes over gloo, every brick running the HIP kernels on the
+@pytest.mark.parametrize("nb,port", [((1, 1, 2), 29641), ((1, 2, 2), 29645), ((2, 2, 2), 29646)])
+def test_bricks_over_gloo_with_the_hip_kernels(tmp_path, nb, port):
+    """The 2-, 4- and 8-GPU layouts of bench.py as separate processes over gloo, every brick running the HIP kernels on the
     execution model with guard-page allocations (a stencil, gather or deposit that leaves a brick's arrays faults):
     separate processes, the real torch.distributed transport, leaver lists, retirement, tile tails."""
     import json
     out = str(tmp_path / "report.json")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hipcpu"), "-j8"], stdout=subprocess.DEVNULL)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "tests", "multibrick_worker.py"), "1", "1", "2",
-           "3", "1", out, "0"]
+    n = nb[0] * nb[1] * nb[2]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "multibrick_worker.py"),
+           *[str(v) for v in nb], "3", "1", out, "0"]
     env = dict(os.environ, OMP_NUM_THREADS="1", WXA_WORKER_LIB="hipcpu", HIPCPU_GUARD_PAGES="1", WXA_TEST_STEPS="8")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
