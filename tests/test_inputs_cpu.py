@@ -284,6 +284,35 @@ def check_boosted_injection(sim):
     assert 0.0 < right - layers.max() * (dz / 2) <= dz * 1.001
 
 
+def check_radiation_reaction(sim):
+    """The gate of Examples/Tests/radiation_reaction/analysis.py on tests/decks/radiation_reaction_3d.inputs after its 64
+    steps: an electron moving along B keeps its Lorentz factor; one gyrating perpendicular to B loses energy as
+    gamma(t) = coth(t / tau_c - C), tau_c = 1 / (omega_c^2 t0), t0 = 2 r_e / (3 c), C = -1/2 ln((gamma0 + 1) / (gamma0 - 1))
+    (the Landau-Lifshitz solution in a constant field), for 50, 200 and 1000 m_e c, electrons and a positron: 5 %."""
+    c, m_e, q_e, r_e = 299792458.0, 9.1093837015e-31, 1.602176634e-19, 2.81794e-15
+    b_val = 300 * m_e * 2.0 * math.pi * c / q_e / 1.0e-6
+    omega_c = q_e * b_val / m_e
+    tau_c = 1.0 / omega_c / omega_c / ((2.0 / 3.0) * r_e / c)
+    t = sim.istep * sim.dt
+    start = {"ele_para0": (1000.0, True), "ele_perp0": (50.0, False), "ele_perp1": (200.0, False),
+             "ele_perp2": (1000.0, False), "pos_perp2": (1000.0, False)}
+    for name, (p0, parallel) in start.items():
+        u = sim.particles(sim.species_names.index(name))[4:7, 0] / c
+        g_end = math.sqrt(1.0 + float(np.dot(u, u)))
+        g0 = math.sqrt(1.0 + p0 * p0)
+        want = g0 if parallel else 1.0 / math.tanh(t / tau_c + 0.5 * math.log((g0 + 1.0) / (g0 - 1.0)))
+        assert abs(g_end - want) / want < 0.05, (name, g_end, want)
+        if not parallel:
+            assert g_end < 0.999 * g0            # it did radiate
+
+
+def test_radiation_reaction_analysis(lib):
+    sim = WarpXSim.from_inputs(lib, os.path.join(DECKS, "radiation_reaction_3d.inputs"))
+    sim.evolve(sim.max_step)
+    check_radiation_reaction(sim)
+    sim.close()
+
+
 def check_particle_walls(sim, pos_tol=1e-15):
     """The gate of Examples/Tests/boundaries/analysis.py on tests/decks/particle_walls_3d.inputs after its 8 steps: one of
     the three particles heading for the absorbing walls is left; the two heading for the reflecting walls sit at the

@@ -395,6 +395,9 @@ def test_decks_reach_the_reference_golden_checksums_on_gpu(product, deck, golden
         # the gate of the reference's analysis script (Examples/Tests/particle_pusher/analysis.py): the force-free orbit
         # stays straight with the Higuera-Cary pusher, |x| < 1e-3 m after 10^4 steps (Boris drifts by 2321 m)
         assert got["positron"]["particle_position_x"] < 1e-3
+    if deck.startswith("radiation_reaction"):
+        from tests.test_inputs_cpu import check_radiation_reaction   # Examples/Tests/radiation_reaction/analysis.py
+        check_radiation_reaction(sim)
     if deck.startswith("particle_walls"):
         from tests.test_inputs_cpu import check_particle_walls   # the gate of Examples/Tests/boundaries/analysis.py
         check_particle_walls(sim, pos_tol=1e-13)
