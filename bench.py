@@ -20,6 +20,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the host driver of these boxes only supports dmabuf IPC: without this RCCL's buffer sharing between the ranks of a node
+# fails with "hipIpcGetMemHandle: invalid argument" (already exported on the boxes; kept here for a bare environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
