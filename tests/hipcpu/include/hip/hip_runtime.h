@@ -197,6 +197,14 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // used on wave-uniform values only
 #define WXA_OPAQUE_F64(v) asm volatile("" : "+x"(v))
 #define WXA_WAVES_PER_SIMD(n)
+// the inline-asm LDS reads of gather_body.hpp: plain loads here, nothing to wait for
+typedef const char* wxa_lds_addr;
+#define WXA_LDS_ADDR(p) ((const char*)(p))
+#define WXA_LDS_READ_B64(dst, addr, off) ((dst) = *(const double*)((addr) + (off)))
+#define WXA_LDS_WAIT1(n, a) ((void)0)
+#define WXA_LDS_WAIT2(n, a, b) ((void)0)
+#define WXA_LDS_WAIT3(n, a, b, c) ((void)0)
+#define WXA_LDS_WAIT4(n, a, b, c, d) ((void)0)
 
 // HIP's unqualified min / max over mixed integer types
 #define HIPCPU_MINMAX(A, B, R)                                   \

@@ -562,8 +562,13 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     __shared__ unsigned long long masks[RT][CW];
     __shared__ int cstart[CELLS + 1];
     __shared__ unsigned short table[TCAP];
-    __shared__ unsigned deferred[DEFER];           // particles with a cell crossing or without a partner (wide body)
-    __shared__ int ndeferred, nitems;
+    // particles with a cell crossing or without a partner (wide body), bucketed by the LDS bank of their wide frame:
+    // phase D takes lane l's particle from bucket l % 16, so the 16 lanes of a ds_add_f64 step sit on 16 different banks
+    // like the lanes of phase C (the single list it replaces cost 2-3 LDS cycles per step in conflicts: the list
+    // pass was 16 % of the kernel for 3 % of the particles)
+    __shared__ unsigned deferred[DEFER];
+    __shared__ int ndef[NBANK];
+    __shared__ int nitems;
     __shared__ int pf_scratch[64];                 // landing zone of the prefetch loads
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
@@ -577,9 +582,10 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     DPROF_INIT
-    auto defer = [&](const int ip) {
-        const int n = atomicAdd(&ndeferred, 1);
-        if (n < DEFER) deferred[n] = (unsigned)ip;
+    constexpr int DCAP = DEFER / NBANK;
+    auto defer = [&](const int ip, const int bank) {
+        const int n = atomicAdd(&ndef[bank], 1);
+        if (n < DCAP) deferred[bank * DCAP + n] = (unsigned)ip;
         else sq.push(ip);
     };
     // Optional (CFG::PF, off in production): pull the particles [p0, p1) of all seven arrays towards the L2 a chunk ahead
@@ -597,7 +603,8 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     constexpr int WAVES = NT / 64;
     if (wave < CELLS / 16) prefetch(offsets[ucell0 + 16 * wave], offsets[ucell0 + 16 * wave + 16]);
     // ---- A: cell counts, row masks; zero fill
-    if (tid == 0) { ndeferred = 0; nitems = 0; }
+    if (tid == 0) nitems = 0;
+    if (tid < NBANK) ndef[tid] = 0;
     int my_s = 0, my_n = 0, my_pairs = 0;
     unsigned long long my_mask[RT];   // wave-uniform: tail row r of this cell-wave
     if (tid < CELLS) {
@@ -634,10 +641,13 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             if (my_pairs > 4 + r) {
                 const int at = base + __popcll(my_mask[r] & lt);
                 if (at < TCAP) table[at] = (unsigned short)(tid | ((4 + r) << 9));
-                else { defer(my_s + 2 * (4 + r)); if (2 * (4 + r) + 1 < my_n) defer(my_s + 2 * (4 + r) + 1); }
+                else {   // any bucket is correct; the cell's place in the sort order is the bank of a particle that stayed
+                    defer(my_s + 2 * (4 + r), tid & (NBANK - 1));
+                    if (2 * (4 + r) + 1 < my_n) defer(my_s + 2 * (4 + r) + 1, tid & (NBANK - 1));
+                }
             }
         }
-        for (int k = 2 * RMAX; k < my_n; ++k) defer(my_s + k);   // beyond the table's rows (> 2 RMAX particles in a cell)
+        for (int k = 2 * RMAX; k < my_n; ++k) defer(my_s + k, tid & (NBANK - 1));   // beyond the table's rows (> 2 RMAX particles in a cell)
     }
     __syncthreads();
     DPROF(1);
@@ -715,17 +725,22 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         const int ka = frame_key(ai - o0, aj - o1, ak - o2), kb = frame_key(bi - o0, bj - o1, bk - o2);
         const int sa = !va ? 3 : !ina ? 2 : crossa ? 1 : 0;   // 0: fast, 1: general path on the tile, 2: straggler, 3: none
         const int sb = !vb ? 3 : !inb ? 2 : crossb ? 1 : 0;
+        // LDS bank (8-byte banks, 16 per step) of the first point of the particle's wide frame: i + 8 k (TileDims)
+        auto wide_bank = [&](const EsirkepovCoords& cc) {
+            const WideFrame<O> f = esirkepov_wide_frame<O>(cc, g);
+            return ((f.b[0] - o0) + 8 * (f.b[2] - o2)) & (NBANK - 1);
+        };
         if (sa == 2) sq.push(ia);
         if (sb == 2) sq.push(ib);
-        if (sa == 1) defer(ia);
-        if (sb == 1) defer(ib);
+        if (sa == 1) defer(ia, wide_bank(c1));
+        if (sb == 1) defer(ib, wide_bank(c2));
         int key = -1;
         if (sa == 0) {
             key = ka;
             if (sb == 0 && kb == ka) {
                 wq2 = wqb;                               // merged with its neighbour
             } else {
-                if (sb == 0) defer(ib);                  // another frame: the wide body takes it alone
+                if (sb == 0) defer(ib, wide_bank(c2));   // another frame: the wide body takes it alone
                 c2 = c1;                                 // empty partner
             }
         } else if (sb == 0) {
@@ -759,13 +774,17 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         //      hand-built exec mask, and the fp32 build deposited that one value (the stencil's far corner) wrongly
         //      for some lanes -- seen as 1e-5 errors on a few points and once as a memory fault on gfx950; the fp64
         //      build was not transformed that way.  Uniform branches leave nothing to merge across lanes.
-        const int nd = min(ndeferred, DEFER);
-        const int dch = (nd + 63) >> 6;
+        // a chunk = 4 rows of the 16 buckets: lane l takes entry 4 (chunk) + l / 16 of bucket l % 16
+        const int my_nd = min(ndef[lane & (NBANK - 1)], DCAP);
+        int nrows = my_nd;
+#pragma unroll
+        for (int d = 1; d < NBANK; d <<= 1) nrows = max(nrows, __shfl_xor(nrows, d));
+        const int dch = (nrows + 3) >> 2;
         for (int ch = wave; ch < 3 * dch; ch += WAVES) {
             const int comp = __builtin_amdgcn_readfirstlane(ch / dch);
-            const int it = (ch - comp * dch) * 64 + lane;
-            if (it < nd) {
-                const int ip = (int)deferred[it];
+            const int row = (ch - comp * dch) * 4 + (lane >> 4);
+            if (row < my_nd) {
+                const int ip = (int)deferred[(lane & (NBANK - 1)) * DCAP + row];
                 const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
                 const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
                 const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);

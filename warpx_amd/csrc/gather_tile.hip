@@ -9,14 +9,21 @@
 // gathers from LDS (same-cell lanes broadcast).  Particles whose stencil leaves the staged range
 // (stale sort, particles wrapped across the periodic boundary) are queued and handled by a second
 // kernel with global loads, so correctness never depends on the sort being fresh.
-// (Tried and rejected, ms per launch at 256^3 x 8 ppc against 5.9: rows read with inline-asm single ds_read_b64 instead of
-// the ds_read2_b64 the compiler emits, 6.3 (the coarse s_waitcnt it needs); 640 lanes per tile = 5 waves per SIMD, 5.9;
+// The rows are read with single ds_read_b64 on a fixed software pipeline (gather_rows_lds, gather_body.hpp; round 3).
+// (Tried and rejected, ms per launch at 256^3 x 8 ppc against 5.9: round 2's first attempt at single reads -- inline asm
+// with one s_waitcnt lgkmcnt(0) per row and nothing in flight behind it -- 6.3; 640 lanes per tile = 5 waves per SIMD, 5.9;
 // the next particle's position and momentum loaded while the current one gathers (127 VGPRs), 6.2; this particle's
 // momentum loaded together with its position instead of after the gather (hand-issued loads), no change; two particles of a
 // cell per lane sharing the LDS reads, 9.95.  Counters, profiles/round2/r2g_pmc_128cube_gather_tile_kernel.txt: 8 LDS
 // cycles per ds instruction and 0.2 % bank conflicts, the LDS busy 60 % and the VALU 50 % of the kernel's time.)
 #include "gather_body.hpp"
 #include "workspace.hpp"
+
+#include <stdlib.h>
+
+#ifndef WXA_GATHER_RB
+#define WXA_GATHER_RB 2   // rows per batch of single LDS reads (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
+#endif
 
 namespace wxa {
 
@@ -67,8 +74,8 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // point, even as stragglers: a particle is at most a few cells from the tile it was sorted into); 2 = only
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
-template <int O, int G, int PUSHER, bool MOVE, int PART = 0>
-__global__ void __launch_bounds__(GT_THREADS)
+template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB>
+__global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(G ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext) {
     constexpr int N = GatherTileDims<G>::N;
@@ -133,12 +140,18 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
             continue;
         }
         const int jn = s.jn - o0, jc = s.jc - o0, kn = s.kn - o1, kc = s.kc - o1, ln = s.ln - o2, lc = s.lc - o2;
-        const double Exp = gather_rows<NC, NN, NN>(F + 0 * NPTS + jc + N * (kn + N * ln), N, N * N, s.sxc, s.syn, s.szn);
-        const double Eyp = gather_rows<NN, NC, NN>(F + 1 * NPTS + jn + N * (kc + N * ln), N, N * N, s.sxn, s.syc, s.szn);
-        const double Ezp = gather_rows<NN, NN, NC>(F + 2 * NPTS + jn + N * (kn + N * lc), N, N * N, s.sxn, s.syn, s.szc);
-        const double Bzp = gather_rows<NC, NC, NN>(F + 5 * NPTS + jc + N * (kc + N * ln), N, N * N, s.sxc, s.syc, s.szn);
-        const double Byp = gather_rows<NC, NN, NC>(F + 4 * NPTS + jc + N * (kn + N * lc), N, N * N, s.sxc, s.syn, s.szc);
-        const double Bxp = gather_rows<NN, NC, NC>(F + 3 * NPTS + jn + N * (kc + N * lc), N, N * N, s.sxn, s.syc, s.szc);
+#define GROWS(...)                                                                                         \
+    [&](const double* b_, const double* sx_, const double* sy_, const double* sz_) {                       \
+        if constexpr (RB > 0) return gather_rows_lds<__VA_ARGS__, N, N * N, RB>(b_, sx_, sy_, sz_);        \
+        else return gather_rows<__VA_ARGS__>(b_, N, N * N, sx_, sy_, sz_);                                 \
+    }
+        const double Exp = GROWS(NC, NN, NN)(F + 0 * NPTS + jc + N * (kn + N * ln), s.sxc, s.syn, s.szn);
+        const double Eyp = GROWS(NN, NC, NN)(F + 1 * NPTS + jn + N * (kc + N * ln), s.sxn, s.syc, s.szn);
+        const double Ezp = GROWS(NN, NN, NC)(F + 2 * NPTS + jn + N * (kn + N * lc), s.sxn, s.syn, s.szc);
+        const double Bzp = GROWS(NC, NC, NN)(F + 5 * NPTS + jc + N * (kc + N * ln), s.sxc, s.syc, s.szn);
+        const double Byp = GROWS(NC, NN, NC)(F + 4 * NPTS + jc + N * (kn + N * lc), s.sxc, s.syn, s.szc);
+        const double Bxp = GROWS(NN, NC, NC)(F + 3 * NPTS + jn + N * (kc + N * lc), s.sxn, s.syc, s.szc);
+#undef GROWS
         push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, p.ux[ip], p.uy[ip], p.uz[ip], Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt,
                                      ext);
     }
@@ -195,6 +208,29 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);                     \
     } while (0)
+#ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/gather_variants.py): rows in flight per env, 0 = ds_read2_b64 rows
+    if constexpr (PUSHER == WXA_PUSHER_BORIS && MOVE && PART == 0) {
+        const char* e = getenv("WXA_GATHER_RB");
+        if (e && galerkin && order == 3) {
+#define WXA_GT_RB(RBV)                                                                                          \
+    do {                                                                                                        \
+        hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
+                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);                         \
+    } while (0)
+            switch (atoi(e)) {
+                case 0: WXA_GT_RB(0); break;
+                case 1: WXA_GT_RB(1); break;
+                case 3: WXA_GT_RB(3); break;
+                default: WXA_GT_RB(2); break;
+            }
+#undef WXA_GT_RB
+            WXA_LAUNCH_CHECK();
+            return WXA_OK;
+        }
+    }
+#endif
     if (galerkin) {
         if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else WXA_GT(3, 1);
     } else {
