@@ -21,7 +21,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
 if os.environ.get("WXA_DEPOSIT_PROFILE") == "1":   # phase clocks in the deposition tile kernel
     COMMON.append("-DWXA_DEPOSIT_PROFILE")
 COMMON += os.environ.get("WXA_EXTRA_DEFS", "").split()   # experiment switches (scripts/microbench)
-LIB = os.environ.get("WXA_LIB_OUT", LIB)
+if os.environ.get("WXA_LIB_OUT"):   # an experiment build next to the product: its own objects
+    LIB = os.path.abspath(os.environ["WXA_LIB_OUT"])
+    OBJ = os.path.join(CSRC, "_obj_" + os.path.basename(LIB).replace(".so", ""))
 
 # (source, extra flags).  The field kernels keep the reference's operation order and
 # are compiled without FMA contraction so that they are bit-identical to the CPU path.
