@@ -597,6 +597,9 @@ int orc_fill_boundary_periodic(const wxa_field_view* f, const int ng[3], const i
                 const int dsti = side == 0 ? v0 - gi : v1 - 1 + gi;
                 const int srci = side == 0 ? dsti + nc : dsti - nc;
                 rl[d] = dsti; rh[d] = dsti + 1;
+                // every point of the slab is independent (its source lies outside the slab): all cores, as in the
+                // reference's OpenMP build of FillBoundary
+#pragma omp parallel for collapse(2)
                 for (int k = rl[2]; k < rh[2]; ++k)
                     for (int j = rl[1]; j < rh[1]; ++j)
                         for (int i = rl[0]; i < rh[0]; ++i) {
@@ -956,6 +959,7 @@ int orc_sync_nodal_periodic(const wxa_field_view* f, const int periodic[3], void
         int rl[3], rh[3];
         for (int e = 0; e < 3; ++e) { rl[e] = vlo(*f, e); rh[e] = vhi(*f, e); }
         rl[d] = vlo(*f, d) + nc; rh[d] = rl[d] + 1;
+#pragma omp parallel for collapse(2)
         for (int k = rl[2]; k < rh[2]; ++k)
             for (int j = rl[1]; j < rh[1]; ++j)
                 for (int i = rl[0]; i < rh[0]; ++i) {
@@ -972,16 +976,18 @@ int orc_sync_nodal_periodic(const wxa_field_view* f, const int periodic[3], void
 // (Source/Parallelization/WarpXSumGuardCells.cpp:17-37).
 int orc_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3], const int periodic[3], void*) {
     const Arr a(*f);
-    std::vector<double> line;
     for (int d = 0; d < 3; ++d) {
         if (!periodic[d]) continue;
         const int nc = ncell_of(*f, d);
         const int a0 = f->lo[d], a1 = f->lo[d] + f->n[d];
         const int s0 = vlo(*f, d) - src_ng[d], s1 = vhi(*f, d) + src_ng[d];
         const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
-        line.resize(f->n[d]);
+        // the lines along d are independent of each other: all cores (each line is summed in the same order as before)
+#pragma omp parallel for collapse(2)
         for (int u = f->lo[d2]; u < f->lo[d2] + f->n[d2]; ++u)
             for (int v = f->lo[d1]; v < f->lo[d1] + f->n[d1]; ++v) {
+                static thread_local std::vector<double> line;
+                line.resize(f->n[d]);
                 int idx[3];
                 idx[d1] = v; idx[d2] = u;
                 for (int t = a0; t < a1; ++t) { idx[d] = t; line[t - a0] = a(idx[0], idx[1], idx[2]); }

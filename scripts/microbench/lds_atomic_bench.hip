@@ -7,13 +7,15 @@
 constexpr int NPTS = 3 * 15 * 15 * 15;
 
 template <int MODE>
-__global__ void __launch_bounds__(512) bench(double* out, long long* cyc, int iters, int stride, int group) {
+__global__ void __launch_bounds__(1024) bench(double* out, long long* cyc, int iters, int stride, int group) {
     __shared__ double lds[NPTS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int a = tid; a < NPTS; a += blockDim.x) lds[a] = 0.0;
     __syncthreads();
     // lane -> base address: (lane / group) * stride doubles, waves offset from each other
-    const int base = (lane / group) * stride + wave * 97;
+    // group > 0: lanes / group share an address; group < 0: lane % (-group) (lanes -group apart share an address: the
+    // deposition's chunk layout, lane = 16 r + c, has the four pairs of a cell on lanes c, c + 16, c + 32, c + 48)
+    const int base = (group > 0 ? lane / group : lane % (-group)) * stride + wave * 97;
     double v = 1.0 + lane;
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
@@ -38,7 +40,7 @@ template <int MODE>
 static void run(const char* name, int threads, int stride, int group) {
     const int blocks = 256, iters = 2000;
     double* out; long long* cyc;
-    hipMalloc(&out, sizeof(double) * blocks * 512);
+    hipMalloc(&out, sizeof(double) * blocks * 1024);
     hipMalloc(&cyc, sizeof(long long) * blocks);
     hipLaunchKernelGGL(bench<MODE>, dim3(blocks), dim3(threads), 0, 0, out, cyc, 10, stride, group);
     hipDeviceSynchronize();
@@ -72,5 +74,10 @@ int main() {
     run<0>("add_f64", 512, 15, 1);   // one tile row apart
     run<0>("add_f64", 512, 16, 1);
     run<0>("add_f64", 512, 32, 1);
+    run<0>("add_f64", 512, 1, -32);  // lanes l and l + 32 on one address
+    run<0>("add_f64", 512, 1, -16);  // lanes l, l + 16, l + 32, l + 48 on one address (the deposition's layout)
+    run<0>("add_f64", 512, 1, -8);
+    run<0>("add_f64", 768, 1, 1);
+    run<0>("add_f64", 768, 1, -16);
     return 0;
 }

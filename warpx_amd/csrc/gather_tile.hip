@@ -22,7 +22,10 @@
 #include <stdlib.h>
 
 #ifndef WXA_GATHER_RB
-#define WXA_GATHER_RB 2   // rows per batch of single LDS reads (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
+#define WXA_GATHER_RB 1   // rows in flight ahead of the fma chain (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
+#endif
+#ifndef WXA_GATHER_PF
+#define WXA_GATHER_PF 1   // 1: the next particle's position and momentum are loaded while this one gathers
 #endif
 
 namespace wxa {
@@ -74,7 +77,7 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // point, even as stragglers: a particle is at most a few cells from the tile it was sorted into); 2 = only
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
-template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB>
+template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF>
 __global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(G ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext) {
@@ -101,6 +104,22 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     const int o2 = tg.cell_lo[2] + tk * GT_TS + GatherTileDims<G>::LO;
     // staging: all loads of a component pair are in flight before the first LDS write (as a plain
     // `for (a = tid; ...) F[a] = load` loop every lane had one load in flight at a time)
+    // The lane's particle of the NEXT trip: loaded (volatile: the loads keep their place in front of the inline-asm LDS
+    // reads) while the current one gathers, the first one before the staging, so that no trip starts by waiting for
+    // HBM (counters of the kernel without it: waves parked in s_waitcnt 46 % of their cycles, VALU and LDS each < 50 %)
+    int ip = start + tid;
+    double nxt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    auto load_particle = [&](const int i) {
+        nxt[0] = *(const volatile double*)(p.x + i); nxt[1] = *(const volatile double*)(p.y + i);
+        nxt[2] = *(const volatile double*)(p.z + i);
+        if constexpr (PF == 1) {
+            nxt[3] = *(const volatile double*)(p.ux + i); nxt[4] = *(const volatile double*)(p.uy + i);
+            nxt[5] = *(const volatile double*)(p.uz + i);
+        }
+    };
+    if constexpr (PF) {
+        if (ip < end) load_particle(ip);
+    }
     constexpr int PER = (NPTS + GT_THREADS - 1) / GT_THREADS;
     auto fetch = [&](const DevF& f, double (&r)[PER]) {
 #pragma unroll
@@ -126,8 +145,19 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     }
     __syncthreads();
 
-    for (int ip = start + tid; ip < end; ip += GT_THREADS) {
-        const double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
+    for (; ip < end; ip += GT_THREADS) {
+        double xp, yp, zp, ux0, uy0, uz0;
+        if constexpr (PF) {
+            xp = nxt[0]; yp = nxt[1]; zp = nxt[2];
+            if constexpr (PF == 1) { ux0 = nxt[3]; uy0 = nxt[4]; uz0 = nxt[5]; }
+            else {   // PF == 2: this particle's momentum is requested now and used after the gather
+                ux0 = *(const volatile double*)(p.ux + ip); uy0 = *(const volatile double*)(p.uy + ip);
+                uz0 = *(const volatile double*)(p.uz + ip);
+            }
+            if (ip + GT_THREADS < end) load_particle(ip + GT_THREADS);
+        } else {
+            xp = p.x[ip]; yp = p.y[ip]; zp = p.z[ip];
+        }
         GatherShapes<O, G> s;
         gather_shapes<O, G>(xp, yp, zp, g, s);
         // staged range check on the extreme points of the node / cell stencils
@@ -152,8 +182,8 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const double Byp = GROWS(NC, NN, NC)(F + 4 * NPTS + jc + N * (kn + N * lc), s.sxc, s.syn, s.szc);
         const double Bxp = GROWS(NN, NC, NC)(F + 3 * NPTS + jn + N * (kc + N * lc), s.sxn, s.syc, s.szc);
 #undef GROWS
-        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, p.ux[ip], p.uy[ip], p.uz[ip], Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt,
-                                     ext);
+        if constexpr (!PF) { ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip]; }
+        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext);
     }
 }
 
@@ -211,10 +241,16 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/gather_variants.py): rows in flight per env, 0 = ds_read2_b64 rows
     if constexpr (PUSHER == WXA_PUSHER_BORIS && MOVE && PART == 0) {
         const char* e = getenv("WXA_GATHER_RB");
+        const char* epf = getenv("WXA_GATHER_PF");
+        const int pf = epf ? atoi(epf) : WXA_GATHER_PF;
         if (e && galerkin && order == 3) {
 #define WXA_GT_RB(RBV)                                                                                          \
     do {                                                                                                        \
-        hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV>), grid, block, 0, st, pv, offsets, \
+        if (pf == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 1>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        else if (pf == 2) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 2>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        else hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 0>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);                         \
