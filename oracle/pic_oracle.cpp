@@ -591,23 +591,22 @@ int orc_fill_boundary_periodic(const wxa_field_view* f, const int ng[3], const i
         if (!periodic[d] || ng[d] <= 0) continue;
         const int nc = ncell_of(*f, d);
         const int v0 = vlo(*f, d), v1 = vhi(*f, d);
-        int rl[3] = {lo[0], lo[1], lo[2]}, rh[3] = {hi[0], hi[1], hi[2]};
+        // the lines along d are independent of each other: all cores, one parallel region per direction and side (the
+        // reference's OpenMP build runs FillBoundary on all threads too).  Threads split the SLOWEST of the other two
+        // dimensions and keep whole rows: splitting i between threads would have them write into one another's cache lines
+        const int dp = d == 2 ? 1 : 2, dq = d == 0 ? 1 : 0;
         for (int side = 0; side < 2; ++side) {
-            for (int gi = 1; gi <= ng[d]; ++gi) {
-                const int dsti = side == 0 ? v0 - gi : v1 - 1 + gi;
-                const int srci = side == 0 ? dsti + nc : dsti - nc;
-                rl[d] = dsti; rh[d] = dsti + 1;
-                // every point of the slab is independent (its source lies outside the slab): all cores, as in the
-                // reference's OpenMP build of FillBoundary
-#pragma omp parallel for collapse(2)
-                for (int k = rl[2]; k < rh[2]; ++k)
-                    for (int j = rl[1]; j < rh[1]; ++j)
-                        for (int i = rl[0]; i < rh[0]; ++i) {
-                            int s[3] = {i, j, k};
-                            s[d] = srci;
-                            a(i, j, k) = a(s[0], s[1], s[2]);
-                        }
-            }
+#pragma omp parallel for
+            for (int u = lo[dp]; u < hi[dp]; ++u)
+                for (int v = lo[dq]; v < hi[dq]; ++v)
+                    for (int gi = 1; gi <= ng[d]; ++gi) {
+                        const int dsti = side == 0 ? v0 - gi : v1 - 1 + gi;
+                        const int srci = side == 0 ? dsti + nc : dsti - nc;
+                        int t[3], s[3];
+                        t[dq] = v; t[dp] = u; t[d] = dsti;
+                        s[dq] = v; s[dp] = u; s[d] = srci;
+                        a(t[0], t[1], t[2]) = a(s[0], s[1], s[2]);
+                    }
         }
         lo[d] = v0 - ng[d]; hi[d] = v1 + ng[d];
     }
@@ -959,7 +958,7 @@ int orc_sync_nodal_periodic(const wxa_field_view* f, const int periodic[3], void
         int rl[3], rh[3];
         for (int e = 0; e < 3; ++e) { rl[e] = vlo(*f, e); rh[e] = vhi(*f, e); }
         rl[d] = vlo(*f, d) + nc; rh[d] = rl[d] + 1;
-#pragma omp parallel for collapse(2)
+#pragma omp parallel for   // over k (one plane when d is z: a small copy then)
         for (int k = rl[2]; k < rh[2]; ++k)
             for (int j = rl[1]; j < rh[1]; ++j)
                 for (int i = rl[0]; i < rh[0]; ++i) {
@@ -981,9 +980,10 @@ int orc_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3], cons
         const int nc = ncell_of(*f, d);
         const int a0 = f->lo[d], a1 = f->lo[d] + f->n[d];
         const int s0 = vlo(*f, d) - src_ng[d], s1 = vhi(*f, d) + src_ng[d];
-        const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
-        // the lines along d are independent of each other: all cores (each line is summed in the same order as before)
-#pragma omp parallel for collapse(2)
+        // the lines along d are independent of each other: all cores (each line is summed in the same order as before);
+        // threads split the slowest of the other two dimensions and keep whole rows (no shared cache lines)
+        const int d2 = d == 2 ? 1 : 2, d1 = d == 0 ? 1 : 0;
+#pragma omp parallel for
         for (int u = f->lo[d2]; u < f->lo[d2] + f->n[d2]; ++u)
             for (int v = f->lo[d1]; v < f->lo[d1] + f->n[d1]; ++v) {
                 static thread_local std::vector<double> line;

@@ -30,8 +30,11 @@ steps = 6
 sim.evolve(steps)
 torch.cuda.synchronize()
 raw.wxa_debug_deposit_profile(out, 1)
-tot = sum(out[:6])
+tot = sum(out[:6])   # the workgroup clocks of the phases (6, 7, 8: wave 0's chunk clocks)
 print(f"variant {variant}: total workgroup-clock {tot:.3e} per {steps} launches")
 for i in range(6):
     print(f"   phase {i}: {100.0 * out[i] / tot:5.1f} %")
 print("   counters:", [int(out[i]) for i in range(8, 16)])
+if out[8]:   # wave 0's chunks: load wait and the rest, cycles per chunk
+    print(f"   wave 0, per chunk: loads issued -> arrived {out[6] / out[8]:.0f} cycles, coordinates .. last atomic retired "
+          f"{out[7] / out[8]:.0f} cycles, {out[8] / steps:.0f} chunks per launch")

@@ -206,6 +206,16 @@ typedef const char* wxa_lds_addr;
 #define WXA_LDS_WAIT3(n, a, b, c) ((void)0)
 #define WXA_LDS_WAIT4(n, a, b, c, d) ((void)0)
 
+// v_permlane32_swap based helpers of deposit_body.hpp: lanes l and l ^ 32 exchange through the wave shuffle
+#define WXA_HAVE_SWAP_ADD_HALVES 1
+namespace wxa {
+inline double swap_add_halves(const double v_lo_planes, const double v_hi_planes) {
+    const double plo = __shfl_xor(v_lo_planes, 32), phi = __shfl_xor(v_hi_planes, 32);
+    return (threadIdx.x & 32) ? phi + v_hi_planes : v_lo_planes + plo;
+}
+inline int partner32(const int v) { return __shfl_xor(v, 32); }
+}
+
 // HIP's unqualified min / max over mixed integer types
 #define HIPCPU_MINMAX(A, B, R)                                   \
     inline R min(A a, B b) { return (R)a < (R)b ? (R)a : (R)b; } \

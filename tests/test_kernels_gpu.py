@@ -407,7 +407,7 @@ def deposit_variant(request):
         os.environ["WXA_DEPOSIT_VARIANT"] = old
 
 
-@pytest.mark.parametrize("deposit_variant", [0, 14, 15, 16, 17], indirect=True)
+@pytest.mark.parametrize("deposit_variant", [0, 14, 15, 16, 17, 20, 21, 22], indirect=True)
 @pytest.mark.parametrize("stale", [False, True])
 @pytest.mark.parametrize("u_scale", [1.0, 0.003])
 def test_deposit_tile_variants(oracle, product, deposit_variant, stale, u_scale):

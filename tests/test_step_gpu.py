@@ -151,6 +151,98 @@ def test_langmuir_golden_on_gpu(oracle, product):
     assert np.max(np.abs(exc - Eth[0])) / np.max(np.abs(Eth[0])) < 5e-2
 
 
+def _metrics_f64(sim, ids):
+    """The reductions of _metrics in float64, species by species and array by array (numpy sums pairwise: ~1e-15 at
+    1e8 terms, five orders below the gate) -- the extended-precision copies of particle_moments would take 40 GB at
+    the headline sizes."""
+    ee, eb = field_energy(sim)
+    out = {"E_energy": ee, "B_energy": eb}
+    c2 = plasma.C_LIGHT ** 2
+    for i in ids:
+        _, m = sim.species[i]
+        p = sim.particles(i)
+        u2 = p[4] * p[4] + p[5] * p[5] + p[6] * p[6]
+        out[f"ekin{i}"] = float(np.sum(p[3] * (m * u2 / (1.0 + np.sqrt(1.0 + u2 / c2)))))
+        del u2
+        out[f"abs_p{i}"] = np.array([float(np.sum(np.abs(m * p[c]))) for c in (4, 5, 6)])
+        out[f"abs_x{i}"] = np.array([float(np.sum(np.abs(p[c]))) for c in (0, 1, 2)])
+        out[f"np{i}"] = float(p.shape[1])
+        del p
+    return out
+
+
+def _full_size_parity(oracle, product, n, species, steps, kw):
+    """HIP path, then the oracle stepper, on the same host arrays: energies / moments at 1e-10, E, B, J point-wise at
+    1e-9 of each field's scale (the gates of every step test in this file, at the headline size)."""
+    import time
+    n_cell = (n, n, n)
+    names = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz")
+    t0 = time.perf_counter()
+    sg, ig = _run(product, n_cell, species, steps, **kw)
+    mg = _metrics_f64(sg, ig)
+    fields_g = {name: sg.field_valid(name) for name in names}
+    dt_g = sg.dt
+    sg.close()
+    t1 = time.perf_counter()
+    so, io = _run(oracle, n_cell, species, steps, **kw)
+    t2 = time.perf_counter()
+    print(f"HIP path {t1 - t0:.1f} s (incl. upload, download), oracle stepper {t2 - t1:.1f} s for {steps} steps")
+    assert abs(so.dt - dt_g) == 0.0
+    _compare(mg, _metrics_f64(so, io))
+    e_scale = max(np.max(np.abs(so.field_valid(c))) for c in ("Ex", "Ey", "Ez"))
+    for name, a in fields_g.items():
+        b = so.field_valid(name)
+        # B of an electrostatic wave is round-off residue: its scale is that of E / c, not its own maximum
+        scale = max(np.max(np.abs(b)), e_scale / plasma.C_LIGHT) if name.startswith("B") else np.max(np.abs(b))
+        err = np.max(np.abs(a - b)) / scale
+        print(f"{name} max point-wise diff / field scale {err:.2e}")
+        assert err <= 1e-9, name
+    so.close()
+
+
+FULL_SIZE = pytest.mark.skipif(os.environ.get("WXA_HIP_ON_CPU") == "1" and "WXA_FULL_SIZE_N" not in os.environ,
+                               reason="full size: needs the GPU (WXA_FULL_SIZE_N=<n> runs it in small on the CPU model)")
+
+
+@FULL_SIZE
+def test_uniform_plasma_256_against_the_oracle(oracle, product):
+    """BASELINE.json config 2 ITSELF -- 256^3 cells, 8 particles per cell, order 3, Esirkepov, Boris, bilinear filter,
+    cell sort every 3rd step, thermal start (u_th = 0.01 c, Poisson cell occupancy) -- HIP path against the independent
+    oracle stepper: 6 steps = 2 sorts (schedule: WarpXEvolve.cpp:354-455).  What only this size exercises: 32 768
+    tiles, 1.3e8-entry index arithmetic, the windowed sort scatter at scale.  1.34e8 particles: ~1 min of oracle time
+    on the GPU box's host cores, ~25 GB of host memory."""
+    n = int(os.environ.get("WXA_FULL_SIZE_N", "256"))
+    L = 40e-6
+    rng = np.random.default_rng(256)
+    counts = rng.poisson(8.0, n ** 3)
+    cell = np.repeat(np.arange(n ** 3, dtype=np.int64), counts)   # cell-ordered: the oracle streams through its fields
+    npart = cell.size
+    dx = L / n
+    parts = []
+    for idx in (cell % n, (cell // n) % n, cell // (n * n)):
+        parts.append(-L / 2 + (idx + rng.random(npart)) * dx)
+    del cell, idx
+    parts.append(np.full(npart, 1e25 * dx ** 3 / 8.0))
+    parts += [0.01 * plasma.C_LIGHT * rng.standard_normal(npart) for _ in range(3)]
+    kw = dict(nox=3, galerkin=1, particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
+              use_filter=1, sort_interval=3)
+    _full_size_parity(oracle, product, n, [(-plasma.Q_E, plasma.M_E, parts)], 6, kw)
+
+
+@FULL_SIZE
+def test_langmuir_256_against_the_oracle(oracle, product):
+    """BASELINE.json config 3 at full size against the oracle stepper: Langmuir wave, 256^3 cells, e- / e+, 8 particles
+    per cell on the regular lattice, order 3, Esirkepov, no filter (Examples/Tests/langmuir/inputs_base_3d scaled up),
+    6 steps with a sort every 4th.  2.7e8 particles."""
+    n = int(os.environ.get("WXA_FULL_SIZE_N", "256"))
+    n_cell = (n, n, n)
+    el, lo, hi = plasma.langmuir_3d(n_cell, ppc=(2, 2, 2), sign=+1.0)
+    po, _, _ = plasma.langmuir_3d(n_cell, ppc=(2, 2, 2), sign=-1.0)
+    kw = dict(nox=3, galerkin=1, particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
+              use_filter=0, sort_interval=4)
+    _full_size_parity(oracle, product, n, [(-plasma.Q_E, plasma.M_E, el), (+plasma.Q_E, plasma.M_E, po)], 6, kw)
+
+
 @pytest.mark.skipif(os.environ.get("WXA_HIP_ON_CPU") == "1", reason="full size: needs the GPU")
 def test_langmuir_256_two_species_full_size(product):
     """BASELINE.json config 3 at full size (256^3, e-/e+, 8 ppc, Esirkepov, order 3, 40 steps) through

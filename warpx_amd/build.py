@@ -19,7 +19,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
           "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 if os.environ.get("WXA_DEPOSIT_PROFILE") == "1":   # phase clocks in the deposition tile kernel
-    COMMON.append("-DWXA_DEPOSIT_PROFILE")
+    COMMON += ["-DWXA_DEPOSIT_PROFILE", "-DWXA_GATHER_PROFILE"]   # ... and in the gather tile kernel
 COMMON += os.environ.get("WXA_EXTRA_DEFS", "").split()   # experiment switches (scripts/microbench)
 if os.environ.get("WXA_LIB_OUT"):   # an experiment build next to the product: its own objects
     LIB = os.path.abspath(os.environ["WXA_LIB_OUT"])

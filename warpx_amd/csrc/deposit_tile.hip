@@ -76,6 +76,11 @@ struct LdsSink {
         else unsafeAtomicAdd(base + (c * TD::NPTS + i + TD::NS * j + TD::PS * k), (float)v);
     }
     __device__ __forceinline__ void add_abs(int c, int gi, int gj, int gk, double v) { add(c, gi, gj, gk, v); }
+    __device__ __forceinline__ LdsSink shifted(int dj, int dk) const {
+        LdsSink s2 = *this;
+        s2.base += TD::NS * dj + TD::PS * dk;
+        return s2;
+    }
 };
 
 // Phase clocks of the tile kernel (opt-in: WXA_DEPOSIT_PROFILE=1 python -m warpx_amd.build --force;
@@ -520,8 +525,11 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
 template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0, class ACC_ = double, int BW_ = 0,
-          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV>
+          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0>
 struct RowsCfg {
+    // COOP: lanes l and l + 32 of a chunk (pairs r and r + 2 of one cell) share their deposits, each lane issues half the
+    // LDS atomics (esirkepov_pair_phased_coop; odd orders, fp64 tiles)
+    static constexpr int COOP = COOP_;
     static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_, PF = PF_;   // PF: L2 prefetch
     static constexpr int ALGO = ALGO_;   // WXA_DEPOSIT_DIRECT: the same work items, every particle on its own (no pairs)
     using ACC = ACC_;   // accumulator type of the LDS tile
@@ -659,15 +667,17 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
     // ---- C: the chunks (NB blocks of 16 cells x 4 pairs, then the tail table)
     const int T = nitems;
-    for (int ch = wave; ch < NB + ((T + 63) >> 6); ch += WAVES) {   // wave-uniform
+    constexpr bool COOP = CFG::COOP != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && (O % 2) == 1 && sizeof(ACC) == 8;
+    constexpr int TPC = COOP ? 32 : 64;   // tail items per chunk: with COOP the upper half of the wave only assists
+    for (int ch = wave; ch < NB + ((T + TPC - 1) / TPC); ch += WAVES) {   // wave-uniform
         int c, r;
         bool va;
         if (BW == 16 && ch + WAVES < NB) prefetch(cstart[16 * (ch + WAVES)], cstart[16 * (ch + WAVES) + 16]);   // its next chunk
         if (ch < NB) {
             c = BW * (ch / (4 / RPC)) + (lane % BW); r = RPC * (ch % (4 / RPC)) + lane / BW; va = true;
         } else {
-            const int I = (ch - NB) * 64 + lane;
-            va = I < T;
+            const int I = (ch - NB) * TPC + (lane & (TPC - 1));
+            va = I < T && lane < TPC;
             const unsigned ent = va ? table[I] : 0u;
             c = (int)(ent & 511u); r = (int)(ent >> 9);
         }
@@ -677,8 +687,18 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         const bool vb = va && 2 * r + 1 < n0;
         const int ib = vb ? ia + 1 : ia;
         // all fourteen loads in flight together (an empty lane reads the tile's first particle)
+#ifdef WXA_DEPOSIT_PROFILE
+        const long long prof_c0 = clock64();
+#endif
         const ParticleState pa{px[ia], py[ia], pz[ia], pw[ia], pux[ia], puy[ia], puz[ia]};
         const ParticleState pb{px[ib], py[ib], pz[ib], pw[ib], pux[ib], puy[ib], puz[ib]};
+#ifdef WXA_DEPOSIT_PROFILE   // wave 0 of every workgroup: cycles from the loads' issue to their arrival, and of the whole chunk
+        long long prof_c1 = 0;
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prof_c1 = clock64();
+        }
+#endif
         if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT) {
             // doDepositionShapeN (CurrentDeposition.H:48-249) on the tile: the lane's two particles one after the other,
             // each component on its own frame (jx: cell-centred in x, nodal in y and z; ...), products in the
@@ -735,18 +755,39 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         if (sa == 1) defer(ia, wide_bank(c1));
         if (sb == 1) defer(ib, wide_bank(c2));
         int key = -1;
+        bool fast_a = false, fast_b = false;   // which of the lane's particles its fast item holds
         if (sa == 0) {
-            key = ka;
+            key = ka; fast_a = true;
             if (sb == 0 && kb == ka) {
-                wq2 = wqb;                               // merged with its neighbour
+                wq2 = wqb; fast_b = true;                // merged with its neighbour
             } else {
                 if (sb == 0) defer(ib, wide_bank(c2));   // another frame: the wide body takes it alone
                 c2 = c1;                                 // empty partner
             }
         } else if (sb == 0) {
-            key = kb; c1 = c2; wq1 = wqb;               // the second particle alone
+            key = kb; c1 = c2; wq1 = wqb; fast_b = true;   // the second particle alone
         }
-        if (key >= 0) {
+        if constexpr (COOP) {
+            // lanes l and l + 32 work on one frame: a lane without a fast item assists with zero weights; two different
+            // frames (a stale sort: one of the pairs has left the cell) -- the upper lane hands its particles to phase D
+            const int pkey = partner32(key);
+            if (pkey >= 0 && pkey != key) {
+                if (key < 0 || lane >= 32) {
+                    if (key >= 0) {
+                        if (fast_a) defer(ia, wide_bank(esirkepov_coords(pa, g, es)));
+                        if (fast_b) defer(ib, wide_bank(esirkepov_coords(pb, g, es)));
+                    }
+                    key = pkey; wq1 = 0.0; wq2 = 0.0; c2 = c1;
+                }
+            }
+            if (key >= 0) {
+                LdsSink<M, TSZ, ACC> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
+                constexpr int H = (O + 1) / 2;
+                LdsSink<M, TSZ, ACC> sink_jxy = lane >= 32 ? sink.shifted(0, H) : sink;
+                LdsSink<M, TSZ, ACC> sink_jz = lane >= 32 ? sink.shifted(H, 0) : sink;
+                esirkepov_pair_phased_coop<O>(c1, c2, wq1, wq2, es, sink_jxy, sink_jz);
+            }
+        } else if (key >= 0) {
             LdsSink<M, TSZ, ACC> sink(lds, key & 15, (key >> 4) & 15, key >> 8);
             if constexpr (CFG::DBG == 1) {
                 NullSink ns;
@@ -765,6 +806,13 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
                 esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
             }
         }
+#ifdef WXA_DEPOSIT_PROFILE
+        if (wave == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the chunk's atomics have left the queue
+            const long long prof_c2 = clock64();
+            if (tid == 0) { DCOUNT(6, prof_c1 - prof_c0); DCOUNT(7, prof_c2 - prof_c1); DCOUNT(8, 1); }
+        }
+#endif
     }
     __syncthreads();
     DPROF(2);
@@ -920,6 +968,13 @@ using RowsWhole3NoLds = RowsCfg<768, 8, 3, 1, 1>;
 using RowsWhole3NoAlu = RowsCfg<768, 8, 3, 1, 2>;
 using RowsWhole3Pf = RowsCfg<768, 8, 3, 1, 0, 1>;
 using RowsWhole3F32 = RowsCfg<768, 8, 3, 1, 0, 0, float>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
+using RowsWhole3Coop = RowsCfg<768, 8, 3, 1, 0, 0, double, 0, WXA_DEPOSIT_ESIRKEPOV, 1>;   // lane pairs share their deposits
+// blocks of 32 cells x 2 pairs: the four 16-lane steps of a ds_add_f64 are (pair 0, cells 0-15), (pair 0, cells 16-31),
+// (pair 1, cells 0-15), (pair 1, cells 16-31) -- consecutive steps never touch the same addresses (measured,
+// scripts/microbench/lds_atomic_bench: the same addresses in consecutive steps cost 11 cycles per wave instruction, in
+// steps two apart 8)
+using RowsWhole3B32 = RowsCfg<768, 8, 3, 1, 0, 0, double, 32>;
+using RowsWhole3B32Coop = RowsCfg<768, 8, 3, 1, 0, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 1>;
 using RowsDirect = RowsCfg<768, 8, 3, 1, 0, 0, double, 0, WXA_DEPOSIT_DIRECT>;   // direct deposition on the same work items
 
 static int deposit_variant() {   // read per launch: the tests switch it between calls
@@ -944,6 +999,9 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
             case 16: return launch_rows<3, RowsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
             case 17: return launch_rows<3, RowsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
             case 18: return launch_rows<3, RowsWhole3Pf>(p, J, geom, q, dt, relative_time, ws, st);
+            case 20: return launch_rows<3, RowsWhole3Coop>(p, J, geom, q, dt, relative_time, ws, st);
+            case 21: return launch_rows<3, RowsWhole3B32>(p, J, geom, q, dt, relative_time, ws, st);
+            case 22: return launch_rows<3, RowsWhole3B32Coop>(p, J, geom, q, dt, relative_time, ws, st);
             case 101: return launch_rows<3, RowsWhole3NoLds>(p, J, geom, q, dt, relative_time, ws, st);
             case 102: return launch_rows<3, RowsWhole3NoAlu>(p, J, geom, q, dt, relative_time, ws, st);
             default: return launch_rows<3, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);

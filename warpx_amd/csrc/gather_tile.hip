@@ -25,10 +25,22 @@
 #define WXA_GATHER_RB 1   // rows in flight ahead of the fma chain (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
 #endif
 #ifndef WXA_GATHER_PF
-#define WXA_GATHER_PF 1   // 1: the next particle's position and momentum are loaded while this one gathers
+#define WXA_GATHER_PF 0   // 1: the next particle's position and momentum are loaded while this one gathers
 #endif
 
 namespace wxa {
+
+// Clocks of the tile kernel (opt-in build, -DWXA_GATHER_PROFILE; read with scripts/gather_profile.py): thread 0 of every
+// workgroup adds [0] start -> field tile staged, [1] staged -> wave 0 out of its particle loop, [2] workgroups; per trip of
+// wave 0: [3] its particle's loads, [4] shapes + LDS gather, [5] momentum loads + push + stores, [6] trips
+#ifdef WXA_GATHER_PROFILE
+__device__ unsigned long long wxa_gather_prof[8];
+#define GPROF_CLOCK(v) const long long v = clock64()
+#define GPROF_ADD(n, v) do { if (threadIdx.x == 0) atomicAdd(&wxa_gather_prof[n], (unsigned long long)(v)); } while (0)
+#else
+#define GPROF_CLOCK(v)
+#define GPROF_ADD(n, v)
+#endif
 
 constexpr int GT_TS = WXA_TILE;
 constexpr int GT_THREADS = 512;
@@ -92,6 +104,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     const int end = offsets[(tile + 1) * TC];
     if (end <= start) return;
     const int tid = threadIdx.x;
+    GPROF_CLOCK(prof_t0);
     const int ti = (int)(tile % tg.nt[0]);
     const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
     const int tk = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
@@ -144,8 +157,12 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         put(0, r0); put(1, r1); put(2, r2); put(3, r3); put(4, r4); put(5, r5);
     }
     __syncthreads();
+    GPROF_CLOCK(prof_t1);
+    GPROF_ADD(0, prof_t1 - prof_t0);
+    GPROF_ADD(2, 1);
 
     for (; ip < end; ip += GT_THREADS) {
+        GPROF_CLOCK(prof_a);
         double xp, yp, zp, ux0, uy0, uz0;
         if constexpr (PF) {
             xp = nxt[0]; yp = nxt[1]; zp = nxt[2];
@@ -158,6 +175,10 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         } else {
             xp = p.x[ip]; yp = p.y[ip]; zp = p.z[ip];
         }
+#ifdef WXA_GATHER_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xp), "+v"(yp), "+v"(zp));
+#endif
+        GPROF_CLOCK(prof_b);
         GatherShapes<O, G> s;
         gather_shapes<O, G>(xp, yp, zp, g, s);
         // staged range check on the extreme points of the node / cell stencils
@@ -182,9 +203,23 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const double Byp = GROWS(NC, NN, NC)(F + 4 * NPTS + jc + N * (kn + N * lc), s.sxc, s.syn, s.szc);
         const double Bxp = GROWS(NN, NC, NC)(F + 3 * NPTS + jn + N * (kc + N * lc), s.sxn, s.syc, s.szc);
 #undef GROWS
+#ifdef WXA_GATHER_PROFILE
+        double prof_e = Exp + Bxp;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(prof_e));
+#endif
+        GPROF_CLOCK(prof_c);
         if constexpr (!PF) { ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip]; }
         push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext);
+#ifdef WXA_GATHER_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GPROF_CLOCK(prof_d);
+        GPROF_ADD(3, prof_b - prof_a); GPROF_ADD(4, prof_c - prof_b); GPROF_ADD(5, prof_d - prof_c); GPROF_ADD(6, 1);
+        if (prof_e == 1.2345e-300) p.x[ip] = prof_e;
+#endif
     }
+#ifdef WXA_GATHER_PROFILE
+    { GPROF_CLOCK(prof_t2); GPROF_ADD(1, prof_t2 - prof_t1); }
+#endif
 }
 
 template <int O, int G, int PUSHER, bool MOVE>
@@ -317,3 +352,15 @@ wxa_status gather_push_tiled_part(const wxa_particle_view* p, const wxa_field_vi
 }
 
 }  // namespace wxa
+
+#ifdef WXA_GATHER_PROFILE
+extern "C" int wxa_debug_gather_profile(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(wxa::wxa_gather_prof), sizeof(wxa::wxa_gather_prof)) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wxa::wxa_gather_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

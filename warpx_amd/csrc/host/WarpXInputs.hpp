@@ -443,8 +443,18 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         const std::string style_key = std::string("warpx.") + eb + "_ext_grid_init_style";
         const FieldType ft = eb[0] == 'E' ? FieldType::Efield_fp : FieldType::Bfield_fp;
         if (!pp.query_word(style_key, w) || w == "default") continue;
+        // WarpX::shiftMF fills the cells that enter a moving window with the external field
+        // (WarpXMovingWindow.cpp:225-246); the window of this library fills them with zero, so the combination is
+        // refused rather than run differently from the reference
+        auto refuse_with_window = [&]() {
+            if (do_moving_window)
+                throw std::runtime_error("inputs: " + style_key + " = " + w +
+                                         " with warpx.do_moving_window = 1 is not on this path (cells entering the "
+                                         "window are filled with zero, not with the external field)");
+        };
         if (w == "constant") {
             pp.getArrWithParser(std::string("warpx.") + eb + "_external_grid", v, 3);
+            if (v[0] != 0.0 || v[1] != 0.0 || v[2] != 0.0) refuse_with_window();
             std::vector<std::string> exprs;
             pp.queryarr(std::string("warpx.") + eb + "_external_grid", exprs);
             for (int d = 0; d < 3; ++d) {
@@ -453,6 +463,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                 else fill_from_parser(be, mf, pp.makeParser(exprs[d], {"x", "y", "z", "t"}), ctx);   // the value at every point
             }
         } else if (w == std::string("parse") + (char)std::tolower(eb[0]) + "extgridfunction") {
+            refuse_with_window();
             for (int d = 0; d < 3; ++d) {
                 const std::string key = std::string("warpx.") + eb + "xyz"[d] + "_external_grid_function(x,y,z)";
                 std::string expr;

@@ -388,6 +388,7 @@ public:
     virtual bool doContinuousInjection() const { return false; }
     virtual void ContinuousInjection(const double* /*box_lo*/, const double* /*box_hi*/) {}
     // InjectorMomentum::getBulkMomentum of the base injector along `dir`, in units of c
+    // (evaluated at the current injection position along `dir`, 0 in the other directions: WarpXMovingWindow.cpp:78-97)
     virtual amrex::Real BulkMomentum(int /*dir*/) const { return 0.0; }
     amrex::Real m_current_injection_position = std::numeric_limits<amrex::Real>::quiet_NaN();   // unset
 
@@ -428,7 +429,15 @@ public:
     bool doContinuousInjection() const override { return m_has_injector && m_do_continuous_injection; }
     // PhysicalParticleContainer::ContinuousInjection (PhysicalParticleContainer.cpp:2518-2528)
     void ContinuousInjection(const double* box_lo, const double* box_hi) override { AddPlasma(box_lo, box_hi); }
-    amrex::Real BulkMomentum(int dir) const override { return m_momentum_on_device ? m_device_momentum.u_mean[dir] : 0.0; }
+    amrex::Real BulkMomentum(int dir) const override {
+        if (m_momentum_on_device) return m_device_momentum.u_mean[dir];
+        if (!m_momentum) return 0.0;   // at rest
+        // InjectorMomentumParser::getBulkMomentum(x, y, z): the parsed functions at the injection position
+        double pos[3] = {0.0, 0.0, 0.0}, u[3] = {0.0, 0.0, 0.0};
+        pos[dir] = m_current_injection_position;
+        m_momentum(pos[0], pos[1], pos[2], u);
+        return u[dir];
+    }
 
     // PhysicalParticleContainer::AddPlasma (:924-1333) for one box per brick, lab frame, plasma at rest: the
     // cells of part_box that overlap this brick (find_overlap, Source/Particles/AddPlasmaUtilities.cpp:12-43),
