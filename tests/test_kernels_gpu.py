@@ -397,7 +397,8 @@ def test_esirkepov_zero_displacement_deposits_exactly_zero(product, order, zero_
 
 @pytest.fixture
 def deposit_variant(request):
-    """WXA_DEPOSIT_VARIANT selects one of the LDS-tile configurations of deposit_tile.hip (read per launch)."""
+    """WXA_DEPOSIT_VARIANT selects one of the LDS-tile configurations of a -DWXA_DEV_VARIANTS build of deposit_tile.hip
+    (read per launch; the production library has no such switch)."""
     old = os.environ.get("WXA_DEPOSIT_VARIANT")
     os.environ["WXA_DEPOSIT_VARIANT"] = str(request.param)
     yield request.param
@@ -407,16 +408,26 @@ def deposit_variant(request):
         os.environ["WXA_DEPOSIT_VARIANT"] = old
 
 
-@pytest.mark.parametrize("deposit_variant", [0, 14, 15, 16, 17, 20, 21, 22], indirect=True)
+@pytest.mark.parametrize("stale", [False, True])
+@pytest.mark.parametrize("u_scale", [1.0, 0.003])
+def test_deposit_tiles_fast_and_crossing_paths(oracle, product, stale, u_scale):
+    """The order-3 LDS-tile depositions (Esirkepov and direct) against the oracle: fresh and stale sort, a plasma where
+    nearly every particle stays in its cell (pair body) and one where most cross (wide-frame body); and exact zeros."""
+    test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_ESIRKEPOV, stale, u_scale)
+    test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_DIRECT, stale, u_scale)
+    if not stale:
+        test_esirkepov_zero_displacement_deposits_exactly_zero(product, 3, 1, u_scale)
+
+
+@pytest.mark.skipif("dev" not in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", "")),
+                    reason="timing variants exist in -DWXA_DEV_VARIANTS builds only (WXA_PRODUCT_LIB=.../libwarpx_amd_dev.so)")
+@pytest.mark.parametrize("deposit_variant", [14, 20, 22], indirect=True)
 @pytest.mark.parametrize("stale", [False, True])
 @pytest.mark.parametrize("u_scale", [1.0, 0.003])
 def test_deposit_tile_variants(oracle, product, deposit_variant, stale, u_scale):
-    """Every configuration of the order-3 Esirkepov LDS-tile deposition (the staged kernel of round 1, the rows kernel
-    on whole / half tiles at 3 / 4 waves per SIMD) against the oracle: fresh and stale sort, fast and crossing path;
-    and exact zeros."""
+    """The A/B configurations of the order-3 Esirkepov tile deposition in a dev build (16-cell blocks, lane pairs that
+    share their deposits) against the oracle."""
     test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_ESIRKEPOV, stale, u_scale)
-    if deposit_variant in (0, 14):   # direct deposition: the staged kernel of round 1 (0) and the rows kernel (default)
-        test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_DIRECT, stale, u_scale)
     if not stale:
         test_esirkepov_zero_displacement_deposits_exactly_zero(product, 3, 1, u_scale)
 
@@ -519,11 +530,15 @@ def test_device_pointer_wrapping(product):
     assert np.all(f.storage[f.front + 16:f.front + 32].cpu().numpy() == 3.5)
 
 
+DEV_BUILD = "dev" in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", ""))   # a -DWXA_DEV_VARIANTS build of the library
+
+
 @pytest.mark.parametrize("ncell", [(24, 20, 16), (25, 9, 7), (130, 6, 5), (300, 8, 8)])
-@pytest.mark.parametrize("variant", list(range(8)))
+@pytest.mark.parametrize("variant", [-1] + (list(range(8)) if DEV_BUILD else []))
 def test_evolve_stencil_configurations_bit_exact(oracle, product, ncell, variant):
-    """Every tile shape / non-temporal configuration of the EvolveB / EvolveE kernels (WXA_STENCIL_VARIANT, read per
-    launch) on odd, even and multi-tile row lengths, bit for bit against the oracle."""
+    """The EvolveB / EvolveE kernels on odd, even and multi-tile row lengths, bit for bit against the oracle: the
+    production configuration, and in a dev build every tile shape / non-temporal configuration of the timing sweep
+    (WXA_STENCIL_VARIANT, read per launch there; the production library has no such switch)."""
     os.environ["WXA_STENCIL_VARIANT"] = str(variant)
     try:
         _two_point_body(oracle, product, ncell)
@@ -1019,7 +1034,8 @@ def test_add_plasma(oracle, product, ppc, u, uth, gamma_boost, t):
 def test_evolve_b_ckc_bit_exact(oracle, product, cells, ncell, ng, plain, monkeypatch):
     """wxa_evolve_b_ckc (EvolveBCartesian<CartesianCKCAlgorithm>) and its coefficients against the CPU restatement:
     same operation order, no contraction -> bit-identical, on cubic and on anisotropic cells; the LDS-tiled kernel
-    and the plain one (WXA_CKC_PLAIN=1)."""
+    and, in a dev build, the plain one (WXA_CKC_PLAIN=1) and the tile shapes of the timing sweep (the production library
+    ignores both switches: those cases then exercise the production configuration on further box shapes)."""
     monkeypatch.setenv("WXA_CKC_PLAIN", str(max(plain, 0)))
     if plain < 0:
         monkeypatch.setenv("WXA_CKC_VARIANT", str(-plain - 1))

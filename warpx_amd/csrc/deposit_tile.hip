@@ -8,14 +8,12 @@
 // (3 x 15 x 248 x 8 B = 89 KB), accumulates with ds_add_f64, and writes each non-zero LDS
 // point back to HBM with one global fp64 atomic.  Two kernels:
 //
-//  * deposit_tile_rows_kernel (Esirkepov, production): work items straight from the cell counts of the
-//    sort -- lane (r, c) of a chunk takes pair r of cell 16 b + c, pairs beyond a cell's fourth come from a
-//    small tail table -- two particles merged in registers per lane, the three components as three
-//    register-lean phases, crossing particles through a wide-frame single body.  No staging, no per-particle
-//    keying, no barrier in the particle loop.  See the comment at the kernel.
-//  * deposit_tile_kernel (direct deposition; Esirkepov of round 1, kept as variant 0 for A/B): stages up to
-//    1024 particles through LDS, keys them by stencil frame, builds work-item lists, buckets the fast items by
-//    the LDS bank of their frame.
+//  * deposit_tile_rows_kernel (both algorithms): work items straight from the cell counts of the sort -- lane (r, c) of
+//    a chunk takes pair r of cell 32 b + c, pairs beyond a cell's fourth come from a small tail table -- two particles
+//    merged in registers per lane, the three components as three register-lean phases, crossing particles through a
+//    wide-frame single body.  No staging, no per-particle keying, no barrier in the particle loop.  See the comment at the
+//    kernel.
+//  * deposit_stragglers_kernel: global atomics for what cannot go through the tile.
 //
 // Particles whose stencil leaves the LDS tile (drift of more than a cell since the last sort, particles outside the
 // domain before the periodic wrap) are queued and deposited with global atomics by a second kernel, so correctness
@@ -130,384 +128,7 @@ struct StragglerQueue {
     __device__ __forceinline__ void push(int ip) const { idx[atomicAdd(count, 1u)] = ip; }
 };
 
-// Work-item word: particle slot in the batch, "merged with the next particle", stencil frame in the LDS tile
-constexpr int IT_AMASK = (1 << 11) - 1;   // batch slot (batches hold at most 2048 particles)
-constexpr int IT_PAIRED = 1 << 11;
-constexpr int IT_FRAME_SHIFT = 12;        // 4 bits each for the frame's first LDS point (i, j, k) < 16
 __device__ __forceinline__ int frame_key(int li, int lj, int lk) { return li | (lj << 4) | (lk << 8); }
-
-// Configuration of the tile kernel (compile time):
-//   NT     work-items per workgroup; a trip takes up to 2 NT particles and at most NT fast items (one per lane)
-//   TSZ    cells of the tile along z (8: whole sort tile; 4: half tile)
-//   STAGE  true: the batch is staged in LDS (coalesced loads, 56 B per particle) and the fast pass reads its
-//          particles from there; false: the fast pass reads them from global memory by index (they were touched
-//          by the keying pass a moment ago and come from L2), which frees 56 KB of LDS per 1024 particles
-//   WPE    waves per SIMD the register allocation is held to
-//   PHASED 0: all weights of the pair kept in registers; 1: component by component (esirkepov_pair_phased);
-//          2: as 1, and the x weights evaluated a second time instead of carried across the Jx phase
-template <int NT_, int TSZ_, bool STAGE_, int WPE_, int PHASED_>
-struct TileCfg {
-    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_;
-    static constexpr bool STAGE = STAGE_;
-};
-
-template <int O, int ALGO, int M, class CFG>
-__global__ void __launch_bounds__(CFG::NT) WXA_WAVES_PER_SIMD(CFG::WPE)
-deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py,
-                    const double* __restrict__ pz, const double* __restrict__ pw,
-                    const double* __restrict__ pux, const double* __restrict__ puy,
-                    const double* __restrict__ puz, const int* __restrict__ offsets, DevF Jx, DevF Jy,
-                    DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, double relative_time,
-                    StragglerQueue sq) {
-    constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
-    constexpr bool STAGE = CFG::STAGE;
-    using TD = TileDims<M, TSZ>;
-    constexpr int N = TD::N, NZ = TD::NZ, NPTS = TD::NPTS, PS = TD::PS;
-    constexpr int SUB = TS / TSZ;                  // workgroups per sort tile
-    constexpr int SUB_CELLS = TILE_CELLS / SUB;
-    constexpr int BATCH = 2 * NT;                  // particles per trip
-    constexpr int ROWS = NT / NBANK;               // quarter-waves of a workgroup = rows of the lane-assignment table
-    constexpr int DEFER = BATCH;                   // capacity of the per-tile list of deferred (cell-crossing) particles:
-                                                   // a flush empties it and one batch appends at most BATCH entries
-    static_assert(TS % TSZ == 0 && TSZ % 2 == 0, "a half tile is a contiguous cell range of the sort order");
-    static_assert(BATCH <= IT_AMASK + 1 && N <= 16 && NZ <= 16, "work-item word");
-    __shared__ double lds[3 * NPTS];
-    __shared__ double stage[STAGE ? 7 : 1][STAGE ? BATCH : 1];
-    __shared__ int items[BATCH];
-    __shared__ int nitems;
-    __shared__ int segcnt[2][BATCH / 64];      // fast / slow items per 64-particle segment
-    __shared__ int cut_a, cut_nslow;           // set by the thread holding the first fast item beyond the cap
-    __shared__ int pf_scratch[64];             // landing zone of the L2 prefetch loads
-    __shared__ int slots[NT];                  // fast item of every lane (row = quarter-wave, column = LDS bank)
-    __shared__ int bcnt[NBANK], novf;
-    __shared__ unsigned deferred[DEFER];      // particles with a cell crossing (global indices), kept for one dense pass
-    __shared__ int ndeferred;
-    const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
-    const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
-    if (unit >= ntiles * SUB) return;
-    const long tile = unit / SUB;
-    const int half = (int)(unit % SUB);
-    const int start = offsets[tile * TILE_CELLS + half * SUB_CELLS];
-    const int end = offsets[tile * TILE_CELLS + (half + 1) * SUB_CELLS];
-    if (end <= start) return;
-    const int tid = threadIdx.x;
-    DPROF_INIT
-    for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = 0.0;
-    const int ti = (int)(tile % tg.nt[0]);
-    const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
-    const int tk = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
-    // global grid index of LDS point 0
-    const int o0 = tg.cell_lo[0] + ti * TS + TD::LO;
-    const int o1 = tg.cell_lo[1] + tj * TS + TD::LO;
-    const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
-    const int wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) ndeferred = 0;
-    constexpr bool ESIRKEPOV = ALGO == WXA_DEPOSIT_ESIRKEPOV;
-    constexpr int ROUNDS = BATCH / NT;              // particles per thread and batch
-    constexpr int WAVES = NT / 64;
-    constexpr int NSEG = BATCH / 64;                // 64-particle segments of a batch (one ballot each)
-    constexpr int FAST_CAP = NT;                    // one fast item per lane: the fast pass is ONE pass
-    const double* const parr[7] = {px, py, pz, pw, pux, puy, puz};
-    int nb_cap = BATCH;   // particles taken per batch; shrinks when the item cap cuts batches short
-    int b0 = start;
-    // One extra trip after the last batch only flushes the deferred list, so that the (large)
-    // general-path code exists once in the kernel.
-    for (;;) {
-        const bool last = b0 >= end;
-        if constexpr (!ESIRKEPOV) {
-            if (last) break;
-        }
-        const int nb = last ? 0 : min(nb_cap, end - b0);
-        __syncthreads();   // previous round's readers are done (and the zero fill on round 0)
-        // ---- load the batch (coalesced, all loads in flight together) and key every particle
-        //      by its stencil frame ----
-        int key_r[ROUNDS];     // stencil frame of this thread's particles (< 0: none / straggler)
-        bool cross_r[ROUNDS];  // the particle crosses a cell during the step
-        {
-            double r[ROUNDS][7];
-#pragma unroll
-            for (int rr = 0; rr < ROUNDS; ++rr) {
-                const int a = tid + rr * NT;
-                key_r[rr] = -1; cross_r[rr] = false;
-                if (a < nb) {
-#pragma unroll
-                    for (int c = 0; c < 7; ++c) r[rr][c] = parr[c][b0 + a];
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < ROUNDS; ++rr) {
-                const int a = tid + rr * NT;
-                if (a < nb) {
-                    const ParticleState p{r[rr][0], r[rr][1], r[rr][2], r[rr][3], r[rr][4], r[rr][5], r[rr][6]};
-                    if constexpr (STAGE) {
-#pragma unroll
-                        for (int c = 0; c < 7; ++c) stage[c][a] = r[rr][c];
-                    }
-                    int key;
-                    if constexpr (ESIRKEPOV) {
-                        int bi, bj, bk;
-                        const bool cross = esirkepov_frame_cross<O>(p, g, es, bi, bj, bk);
-                        const int li = bi - o0, lj = bj - o1, lk = bk - o2;
-                        const bool in = li >= 0 && lj >= 0 && lk >= 0 && li + O + 3 <= N && lj + O + 3 <= N &&
-                                        lk + O + 3 <= NZ;
-                        // outside the LDS tile: straggler (a key no neighbour shares); queued below,
-                        // once it is known that this batch consumes the particle
-                        key = in ? frame_key(li, lj, lk) : -2 - a;
-                        cross_r[rr] = cross;
-                    } else {
-                        DirectShapes<O> sh;
-                        direct_shapes<O>(p, g, q, relative_time, sh);
-                        const int lo_i = min(sh.jn, sh.jc) - o0, lo_j = min(sh.kn, sh.kc) - o1,
-                                  lo_k = min(sh.ln, sh.lc) - o2;
-                        const int hi_i = max(sh.jn, sh.jc) - o0 + O, hi_j = max(sh.kn, sh.kc) - o1 + O,
-                                  hi_k = max(sh.ln, sh.lc) - o2 + O;
-                        key = (lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < NZ) ? 0 : -1;
-                        if (key < 0) sq.push(b0 + a);
-                    }
-                    key_r[rr] = key;
-                }
-            }
-        }
-        if (tid == 0) { nitems = 0; cut_a = nb; cut_nslow = -1; novf = 0; }
-        if (tid < NBANK) bcnt[tid] = 0;
-        if constexpr (!ESIRKEPOV) {
-            __syncthreads();
-            DPROF(0);
-        }
-        if constexpr (ESIRKEPOV) {
-            // Nobody appends to the deferred list before the flush decision below.
-            const int nd0 = ndeferred;
-            // ---- work items.  A run of equal frames (the particles of one cell, cut at the
-            // 64-particle segments) is split into pairs (+ one single if odd); an item is "slow" if
-            // one of its particles crosses a cell.  Ranks come from ballots and a prefix over the
-            // segments, so both lists keep the cell order of the sort (neighbouring lanes -> neighbouring
-            // LDS addresses).  At most FAST_CAP fast items are taken: the batch ends where the
-            // next one would start (a_cut) and the rest is taken again by the next trip.
-            bool is_item[ROUNDS], is_slow[ROUNDS], is_pair[ROUNDS];
-            int rank_f[ROUNDS], rank_s[ROUNDS];
-            const unsigned long long le = ~0ull >> (63 - lane), lt = le >> 1;
-#pragma unroll
-            for (int rr = 0; rr < ROUNDS; ++rr) {
-                // the neighbours' keys come from the neighbouring lanes (runs are cut at the wave's
-                // 64 particles anyway), so this needs no barrier after the staging
-                const int key = key_r[rr];
-                const bool cr = cross_r[rr];
-                const int kprev = __shfl_up(key, 1), knext = __shfl_down(key, 1);
-                const bool cprev = __shfl_up((int)cr, 1) != 0, cnext = __shfl_down((int)cr, 1) != 0;
-                // a crossing particle is a run of its own (slow single); pairs form among the others
-                const bool head = lane == 0 || kprev != key || cr || cprev;
-                const unsigned long long H = __ballot(head);
-                const int run_start = 63 - __clzll((long long)(H & le));   // lane 0 is always a head
-                const bool it = key >= 0 && ((lane - run_start) & 1) == 0;
-                const bool pr = it && !cr && lane < 63 && knext == key && !cnext;
-                const bool sl = it && cr;
-                const unsigned long long F = __ballot(it && !sl), S = __ballot(sl);
-                rank_f[rr] = __popcll(F & lt);
-                rank_s[rr] = __popcll(S & lt);
-                if (lane == 0) {
-                    segcnt[0][wave + rr * WAVES] = __popcll(F);
-                    segcnt[1][wave + rr * WAVES] = __popcll(S);
-                }
-                is_item[rr] = it; is_slow[rr] = sl; is_pair[rr] = pr;
-            }
-            __syncthreads();
-            DPROF(0);   // zero fill (first trip) + load + key + item flags
-            int tot_f = 0, tot_s = 0;
-            {
-                int pre_f[ROUNDS], pre_s[ROUNDS];
-#pragma unroll
-                for (int rr = 0; rr < ROUNDS; ++rr) pre_f[rr] = pre_s[rr] = 0;
-#pragma unroll
-                for (int sg = 0; sg < NSEG; ++sg) {
-                    const int cf = segcnt[0][sg], cs = segcnt[1][sg];
-#pragma unroll
-                    for (int rr = 0; rr < ROUNDS; ++rr)
-                        if (sg < wave + rr * WAVES) { pre_f[rr] += cf; pre_s[rr] += cs; }
-                    tot_f += cf; tot_s += cs;
-                }
-                // Lane assignment of the fast items.  ds_add_f64 serves 16 lanes (a quarter-wave) per
-                // step from 16 banks of 8 bytes (scripts/microbench/lds_*_bench.hip), and ANY two
-                // lanes on one bank double the cost of the step; every deposit of a lane is (frame
-                // base + compile-time offset), so lanes conflict exactly when their frame bases share
-                // a bank.  Items are therefore bucketed by the bank of their frame base: column =
-                // bank, row (= quarter-wave) = rank in the bucket.  All items of a cell land in one
-                // column, so two lanes of a quarter-wave never hit the same address either.
-#pragma unroll
-                for (int rr = 0; rr < ROUNDS; ++rr) {
-                    const int a = tid + rr * NT;
-                    const int kk = key_r[rr];
-                    const int e = a | (is_pair[rr] ? IT_PAIRED : 0) | (kk << IT_FRAME_SHIFT);
-                    const int rank = pre_f[rr] + rank_f[rr];
-                    const bool fast = is_item[rr] && !is_slow[rr] && rank < FAST_CAP;
-                    const int bank = fast ? ((kk & 15) + TD::NS * ((kk >> 4) & 15) + PS * (kk >> 8)) & (NBANK - 1) : -1;
-                    // (a wave-aggregated rank -- 16 ballots, one atomic per wave and bank -- was slower)
-                    const int row = fast ? atomicAdd(&bcnt[bank], 1) : 0;
-                    if (fast) {
-                        if (row < ROWS) slots[row * NBANK + bank] = e;
-                        else items[atomicAdd(&novf, 1)] = e;   // bucket full: takes a free slot below
-                    }
-                    if (is_item[rr]) {
-                        if (is_slow[rr]) items[BATCH - 1 - (pre_s[rr] + rank_s[rr])] = a;   // from the back
-                        else if (rank == FAST_CAP) { cut_a = a; cut_nslow = pre_s[rr] + rank_s[rr]; }
-                    }
-                }
-            }
-            __syncthreads();
-            DPROF(1);   // work-item lists
-            const int a_cut = cut_a;                              // particles consumed by this trip
-            const int nsl = cut_nslow >= 0 ? cut_nslow : tot_s;   // slow items before a_cut
-            if (a_cut < nb) nb_cap = min(BATCH, ((a_cut + 127) >> 6) << 6);
-            else if (nb == nb_cap && nb_cap < BATCH && tot_f < FAST_CAP - 32) nb_cap += 64;
-#pragma unroll
-            for (int rr = 0; rr < ROUNDS; ++rr) {
-                const int a = tid + rr * NT;
-                if (a < a_cut && key_r[rr] <= -2) sq.push(b0 + a);
-            }
-            // Pull the next batch towards the L2 while this one is deposited: one 4-byte load per
-            // 128-byte line, straight into an LDS scratch word (no register, no wait until the
-            // next barrier).  Wave w touches array w (, w + WAVES).
-            if (!last) {
-                const int nx0 = b0 + a_cut;
-                const int nxn = min(nb_cap, end - nx0);
-                for (int arr = wave; arr < 7; arr += WAVES) {
-                    for (int l0 = lane * 16; l0 < nxn; l0 += 64 * 16)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(parr[arr] + nx0 + l0),
-                            (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
-                }
-            }
-            DCOUNT(15, novf);
-            // This lane's fast item: slot (row, column) = (quarter-wave, bank) of the table if its
-            // bucket reaches this row, else one of the items of overfull buckets.  Free slots are
-            // numbered column by column, so that consecutive overflow items (same bucket, often the
-            // same cell) land in different quarter-waves: each one then conflicts with a single lane.
-            int e;
-            {
-                const int col = tid & (NBANK - 1), row = tid / NBANK;
-                if (row < bcnt[col]) {
-                    e = slots[tid];
-                } else {
-                    int m = row - bcnt[col];
-#pragma unroll
-                    for (int c2 = 0; c2 < NBANK; ++c2)
-                        if (c2 < col) m += ROWS - min(bcnt[c2], ROWS);
-                    e = m < novf ? items[m] : -1;
-                }
-            }
-            if (e >= 0) {   // pairs (and singles) that stay in their cell
-                const int a = e & IT_AMASK;
-                const bool paired = (e & IT_PAIRED) != 0;
-                const int a2 = paired ? a + 1 : a;
-                ParticleState p1, p2;
-                if constexpr (STAGE) {
-                    p1 = ParticleState{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
-                                       stage[4][a], stage[5][a], stage[6][a]};
-                    p2 = ParticleState{stage[0][a2], stage[1][a2], stage[2][a2], stage[3][a2],
-                                       stage[4][a2], stage[5][a2], stage[6][a2]};
-                } else {
-                    const int g1 = b0 + a, g2 = b0 + a2;
-                    p1 = ParticleState{px[g1], py[g1], pz[g1], pw[g1], pux[g1], puy[g1], puz[g1]};
-                    p2 = ParticleState{px[g2], py[g2], pz[g2], pw[g2], pux[g2], puy[g2], puz[g2]};
-                }
-                const int fk = e >> IT_FRAME_SHIFT;
-                LdsSink<M, TSZ> sink(lds, fk & 15, (fk >> 4) & 15, fk >> 8);
-                if constexpr (CFG::PHASED == 0) {
-                    EsirkepovNC<O> s1, s2;
-                    esirkepov_nc_shapes<O>(p1, g, q, es, s1);
-                    esirkepov_nc_shapes<O>(p2, g, q, es, s2);
-                    esirkepov_accumulate_pair_nc<O>(s1, s2, /*null2=*/!paired, es, sink);
-                } else {
-                    esirkepov_pair_phased<O, CFG::PHASED == 2>(p1, p2, /*null2=*/!paired, g, q, es, sink);
-                }
-            }
-            DPROF(2);   // fast pass
-            // Particles with a cell crossing take the general path (alone: merging two of them would
-            // double its already long instruction stream), whose cost per wave does not depend on how
-            // many lanes are active.  A handful per batch (thermal plasma: ~1.5 %) would cost every
-            // batch a full pass, so they are deferred (as global particle indices) and run packed
-            // 64 to a wave, the three J components on different waves: when the list would overflow
-            // (hot / relativistic plasma: every batch) and once at the end of the tile.
-            int nd_base = nd0;
-            DCOUNT(8, min(tot_f, FAST_CAP)); DCOUNT(9, nsl); DCOUNT(10, 1); DCOUNT(11, a_cut); DCOUNT(12, nb);
-            if (last || nd0 + nsl > DEFER) {   // block-uniform
-                DCOUNT(13, 1); DCOUNT(14, nd0);
-                // work unit = (64 deferred particles, one J component); units go round the waves
-                const int nunits = 3 * ((nd0 + 63) >> 6);
-                for (int u = wave; u < nunits; u += WAVES) {
-                    const int it = (u / 3) * 64 + lane;
-                    if (it >= nd0) continue;
-                    const int ip = (int)deferred[it];
-                    const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-                    EsirkepovShapes<O> s1;
-                    esirkepov_shapes<O>(p1, g, q, es, s1);
-                    LdsSink<M, TSZ> sink(lds, s1.bi - o0, s1.bj - o1, s1.bk - o2);
-                    switch (u % 3) {
-                        case 0: esirkepov_accumulate_comp<O, 0>(s1, es, sink); break;
-                        case 1: esirkepov_accumulate_comp<O, 1>(s1, es, sink); break;
-                        default: esirkepov_accumulate_comp<O, 2>(s1, es, sink); break;
-                    }
-                }
-                nd_base = 0;
-                __syncthreads();   // the list is free again
-            }
-            DPROF(3);   // deferred general-path flush
-            for (int rk = tid; rk < nsl; rk += NT)
-                deferred[nd_base + rk] = (unsigned)(b0 + items[BATCH - 1 - rk]);   // slow items are singles
-            if (tid == 0) ndeferred = nd_base + nsl;
-            if (last) break;
-            b0 += a_cut;
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < ROUNDS; ++rr) {
-                const int a = tid + rr * NT;
-                if (a < nb && key_r[rr] >= 0) items[atomicAdd(&nitems, 1)] = a;
-            }
-            __syncthreads();
-            DPROF(1);
-            constexpr int IPC = 4;
-            const int total = nitems;
-            const int nchunks = ((total + 64 * IPC - 1) / (64 * IPC)) * IPC;
-            for (int c = wave; c < nchunks; c += WAVES) {
-                const int it = (c / IPC) * (64 * IPC) + lane * IPC + (c % IPC);
-                if (it >= total) continue;
-                const int a = items[it];
-                ParticleState p1;
-                if constexpr (STAGE) {
-                    p1 = ParticleState{stage[0][a], stage[1][a], stage[2][a], stage[3][a],
-                                       stage[4][a], stage[5][a], stage[6][a]};
-                } else {
-                    const int g1 = b0 + a;
-                    p1 = ParticleState{px[g1], py[g1], pz[g1], pw[g1], pux[g1], puy[g1], puz[g1]};
-                }
-                DirectShapes<O> sh;
-                direct_shapes<O>(p1, g, q, relative_time, sh);
-                LdsSink<M, TSZ> sink(lds, -o0, -o1, -o2);
-                direct_accumulate<O>(sh, sink);
-            }
-            b0 += nb;
-        }
-    }
-    __syncthreads();
-    DPROF(4);   // append to the deferred list / direct pass
-    // write-back: one global atomic per non-zero LDS point (tiles overlap on their halos)
-    const DevF* Jc[3] = {&Jx, &Jy, &Jz};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const DevF& J = *Jc[c];
-        for (int a = tid; a < NPTS; a += NT) {
-            const double v = lds[c * NPTS + a];
-            if (v != 0.0) {
-                // a = i + NS j + PS k; the padding words (i >= N, a % PS >= N NS) stay zero
-                const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
-                if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
-                    k < J.lo2 + J.n2)
-                    atomic_add_f64(J.p + J.off(i, j, k), v);
-            }
-        }
-    }
-    DPROF(5);   // write-back
-    DPROF_FINISH
-}
 
 // ---- Esirkepov on LDS tiles, work items from the cell counts ----------------------------------------------------------
 // The cell sort already says where every cell's particles are (offsets[]), so the work items -- (cell, r) = the cell's
@@ -524,13 +145,13 @@ deposit_tile_kernel(const double* __restrict__ px, const double* __restrict__ py
 // a cell goes to the deferred list | D deferred particles through the wide single body, one lane per (component,
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
-template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, int PF_ = 0, class ACC_ = double, int BW_ = 0,
+template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, class ACC_ = double, int BW_ = 0,
           int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0>
 struct RowsCfg {
     // COOP: lanes l and l + 32 of a chunk (pairs r and r + 2 of one cell) share their deposits, each lane issues half the
     // LDS atomics (esirkepov_pair_phased_coop; odd orders, fp64 tiles)
     static constexpr int COOP = COOP_;
-    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_, PF = PF_;   // PF: L2 prefetch
+    static constexpr int NT = NT_, TSZ = TSZ_, WPE = WPE_, PHASED = PHASED_, DBG = DBG_;
     static constexpr int ALGO = ALGO_;   // WXA_DEPOSIT_DIRECT: the same work items, every particle on its own (no pairs)
     using ACC = ACC_;   // accumulator type of the LDS tile
     // cells per block of the direct part = lanes that one step of the LDS atomic serves (16 for ds_add_f64, 32 for
@@ -577,7 +198,6 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     __shared__ unsigned deferred[DEFER];
     __shared__ int ndef[NBANK];
     __shared__ int nitems;
-    __shared__ int pf_scratch[64];                 // landing zone of the prefetch loads
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
     if (unit >= ntiles * SUB) return;
@@ -596,20 +216,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         if (n < DCAP) deferred[bank * DCAP + n] = (unsigned)ip;
         else sq.push(ip);
     };
-    // Optional (CFG::PF, off in production): pull the particles [p0, p1) of all seven arrays towards the L2 a chunk ahead
-    // -- one 4-byte load per 128-byte line straight into an LDS scratch word; lanes 8 a .. 8 a + 7 take the first 8
-    // lines of array a.  Measured at 256^3 x 8: 7.13 ms with, 6.76 ms without, and FETCH_SIZE + 29 % with it: the lines
-    // do not survive in the L2 until their chunk runs, so they are fetched twice.
-    const double* const parr[7] = {px, py, pz, pw, pux, puy, puz};
-    auto prefetch = [&](const int p0, const int p1) {
-        const int arr = lane >> 3, seg = lane & 7;
-        const int q0 = (p0 & ~15) + 16 * seg;
-        if (CFG::PF && arr < 7 && q0 < p1)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(parr[arr] + q0),
-                                             (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
-    };
     constexpr int WAVES = NT / 64;
-    if (wave < CELLS / 16) prefetch(offsets[ucell0 + 16 * wave], offsets[ucell0 + 16 * wave + 16]);
     // ---- A: cell counts, row masks; zero fill
     if (tid == 0) nitems = 0;
     if (tid < NBANK) ndef[tid] = 0;
@@ -672,7 +279,6 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     for (int ch = wave; ch < NB + ((T + TPC - 1) / TPC); ch += WAVES) {   // wave-uniform
         int c, r;
         bool va;
-        if (BW == 16 && ch + WAVES < NB) prefetch(cstart[16 * (ch + WAVES)], cstart[16 * (ch + WAVES) + 16]);   // its next chunk
         if (ch < NB) {
             c = BW * (ch / (4 / RPC)) + (lane % BW); r = RPC * (ch % (4 / RPC)) + lane / BW; va = true;
         } else {
@@ -899,33 +505,6 @@ bool deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p)
 // straggler path (global atomics, ~7 ns per particle).
 constexpr int MARGIN = 1;
 
-template <int O, int ALGO, class CFG>
-static wxa_status launch_tile(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
-                              double q, double dt, double relative_time, wxa_workspace* ws, hipStream_t st) {
-    TileGeom tg;
-    for (int d = 0; d < 3; ++d) {
-        tg.nt[d] = (ws->sort_nc[d] + TS - 1) / TS;
-        tg.cell_lo[d] = ws->sort_cell_lo[d];
-    }
-    const long nunits = (long)tg.nt[0] * tg.nt[1] * tg.nt[2] * (TS / CFG::TSZ);
-    const Geom g = make_geom(*geom);
-    const int* offsets = (const int*)ws->offsets.p;
-    const dim3 grid((unsigned)xcd_grid_size(nunits)), block(CFG::NT);
-    wxa_status rc;
-    if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
-    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
-    StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
-    WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
-    const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
-    const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
-    hipLaunchKernelGGL((deposit_tile_kernel<O, ALGO, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, relative_time, sq);
-    hipLaunchKernelGGL((deposit_stragglers_kernel<O, ALGO>), dim3(512), dim3(256), 0, st, p->x, p->y, p->z, p->w,
-                       p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
-    WXA_LAUNCH_CHECK();
-    return WXA_OK;
-}
-
 template <int O, class CFG>
 static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
                                double q, double dt, double relative_time, wxa_workspace* ws, hipStream_t st) {
@@ -953,65 +532,48 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
     return WXA_OK;
 }
 
-// Production configurations: Esirkepov -> the rows kernel on whole tiles (768 lanes, 3 waves per SIMD); direct deposition
-// -> the staged kernel of round 1.  WXA_DEPOSIT_VARIANT=<n> selects an alternative per launch (order-3 Esirkepov only)
-// for A/B timing and for the parity tests of every configuration (scripts/deposit_variants.py):
-//   0 staged / bucketed kernel of round 1 | 14 production | 15 half tiles, 2 x 6 waves | 16 half tiles, 2 x 8 waves,
-//   128 VGPRs | 17 whole tiles, 16 waves, 128 VGPRs | 18 production + L2 prefetch of the next chunk | 101 / 102 timing
-//   experiments (arithmetic only / atomics only: wrong J)
-using CfgStaged = TileCfg<512, 8, true, 2, 0>;
-using RowsWhole3 = RowsCfg<768, 8, 3, 1>;
-using RowsHalf3 = RowsCfg<384, 4, 3, 1>;
-using RowsHalf4 = RowsCfg<512, 4, 4, 2>;
-using RowsWhole4 = RowsCfg<1024, 8, 4, 2>;
-using RowsWhole3NoLds = RowsCfg<768, 8, 3, 1, 1>;
-using RowsWhole3NoAlu = RowsCfg<768, 8, 3, 1, 2>;
-using RowsWhole3Pf = RowsCfg<768, 8, 3, 1, 0, 1>;
-using RowsWhole3F32 = RowsCfg<768, 8, 3, 1, 0, 0, float>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
-using RowsWhole3Coop = RowsCfg<768, 8, 3, 1, 0, 0, double, 0, WXA_DEPOSIT_ESIRKEPOV, 1>;   // lane pairs share their deposits
-// blocks of 32 cells x 2 pairs: the four 16-lane steps of a ds_add_f64 are (pair 0, cells 0-15), (pair 0, cells 16-31),
-// (pair 1, cells 0-15), (pair 1, cells 16-31) -- consecutive steps never touch the same addresses (measured,
-// scripts/microbench/lds_atomic_bench: the same addresses in consecutive steps cost 11 cycles per wave instruction, in
-// steps two apart 8)
-using RowsWhole3B32 = RowsCfg<768, 8, 3, 1, 0, 0, double, 32>;
-using RowsWhole3B32Coop = RowsCfg<768, 8, 3, 1, 0, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 1>;
-using RowsDirect = RowsCfg<768, 8, 3, 1, 0, 0, double, 0, WXA_DEPOSIT_DIRECT>;   // direct deposition on the same work items
-
-static int deposit_variant() {   // read per launch: the tests switch it between calls
-    const char* e = getenv("WXA_DEPOSIT_VARIANT");
-    return e ? atoi(e) : -1;
-}
+// Production configurations (whole tiles, 768 lanes = 3 waves per SIMD, blocks of 32 cells x 2 pairs): Esirkepov, Esirkepov
+// on fp32 tiles (opt-in per workspace), direct deposition.  Measured and removed again, ms per launch at 256^3 x 8 ppc
+// against 6.3 (profiles/round2/README.md, profiles/round3/README.md): the staged / bucketed kernel of round 1 9.4; half
+// tiles with 2 x 6 waves 9.1 and 2 x 8 waves at 128 VGPRs 7.0; whole tiles with 16 waves at 128 VGPRs 7.7; an L2 prefetch
+// of the next chunk +0.35; blocks of 16 cells x 4 pairs 6.6 (the same addresses in consecutive 16-lane steps of a
+// ds_add_f64 cost 11 cycles per wave instruction instead of 8, scripts/microbench/lds_atomic_bench.hip); lanes l and l + 32
+// sharing their deposits through v_permlane32_swap (half the LDS atomics, + 17 % VALU) 6.6 -- kept as dev variant 22.
+using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32>;
+using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
+using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 0, WXA_DEPOSIT_DIRECT>;   // direct deposition on the same work items
+#ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/variants.py): WXA_DEPOSIT_VARIANT=<n>, order-3 Esirkepov
+using RowsB16 = RowsCfg<768, 8, 3, 1, 0, double, 16>;
+using RowsB16Coop = RowsCfg<768, 8, 3, 1, 0, double, 16, WXA_DEPOSIT_ESIRKEPOV, 1>;
+using RowsB32Coop = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 1>;
+using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
+using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
+#endif
 
 wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
                                  double q, double dt, double relative_time, int order, int algo,
                                  wxa_workspace* ws, hipStream_t st) {
     if (algo == WXA_DEPOSIT_ESIRKEPOV) {
         if (ws->deposit_accumulator == WXA_ACC_FP32) {
-            if (order == 1) return launch_rows<1, RowsWhole3F32>(p, J, geom, q, dt, relative_time, ws, st);
-            if (order == 2) return launch_rows<2, RowsWhole3F32>(p, J, geom, q, dt, relative_time, ws, st);
-            return launch_rows<3, RowsWhole3F32>(p, J, geom, q, dt, relative_time, ws, st);
+            if (order == 1) return launch_rows<1, RowsEsirkepovF32>(p, J, geom, q, dt, relative_time, ws, st);
+            if (order == 2) return launch_rows<2, RowsEsirkepovF32>(p, J, geom, q, dt, relative_time, ws, st);
+            return launch_rows<3, RowsEsirkepovF32>(p, J, geom, q, dt, relative_time, ws, st);
         }
-        if (order == 1) return launch_rows<1, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
-        if (order == 2) return launch_rows<2, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
-        switch (deposit_variant()) {
-            case 0: return launch_tile<3, WXA_DEPOSIT_ESIRKEPOV, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
-            case 15: return launch_rows<3, RowsHalf3>(p, J, geom, q, dt, relative_time, ws, st);
-            case 16: return launch_rows<3, RowsHalf4>(p, J, geom, q, dt, relative_time, ws, st);
-            case 17: return launch_rows<3, RowsWhole4>(p, J, geom, q, dt, relative_time, ws, st);
-            case 18: return launch_rows<3, RowsWhole3Pf>(p, J, geom, q, dt, relative_time, ws, st);
-            case 20: return launch_rows<3, RowsWhole3Coop>(p, J, geom, q, dt, relative_time, ws, st);
-            case 21: return launch_rows<3, RowsWhole3B32>(p, J, geom, q, dt, relative_time, ws, st);
-            case 22: return launch_rows<3, RowsWhole3B32Coop>(p, J, geom, q, dt, relative_time, ws, st);
-            case 101: return launch_rows<3, RowsWhole3NoLds>(p, J, geom, q, dt, relative_time, ws, st);
-            case 102: return launch_rows<3, RowsWhole3NoAlu>(p, J, geom, q, dt, relative_time, ws, st);
-            default: return launch_rows<3, RowsWhole3>(p, J, geom, q, dt, relative_time, ws, st);
+        if (order == 1) return launch_rows<1, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
+        if (order == 2) return launch_rows<2, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
+#ifdef WXA_DEV_VARIANTS
+        if (const char* e = getenv("WXA_DEPOSIT_VARIANT")) {
+            switch (atoi(e)) {
+                case 14: return launch_rows<3, RowsB16>(p, J, geom, q, dt, relative_time, ws, st);
+                case 20: return launch_rows<3, RowsB16Coop>(p, J, geom, q, dt, relative_time, ws, st);
+                case 22: return launch_rows<3, RowsB32Coop>(p, J, geom, q, dt, relative_time, ws, st);
+                case 101: return launch_rows<3, RowsNoLds>(p, J, geom, q, dt, relative_time, ws, st);
+                case 102: return launch_rows<3, RowsNoAlu>(p, J, geom, q, dt, relative_time, ws, st);
+                default: break;
+            }
         }
-    }
-    // direct deposition: the rows kernel too (round 2, last session); WXA_DEPOSIT_VARIANT=0 = the staged kernel of round 1
-    if (deposit_variant() == 0) {
-        if (order == 1) return launch_tile<1, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
-        if (order == 2) return launch_tile<2, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
-        return launch_tile<3, WXA_DEPOSIT_DIRECT, CfgStaged>(p, J, geom, q, dt, relative_time, ws, st);
+#endif
+        return launch_rows<3, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
     }
     if (order == 1) return launch_rows<1, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
     if (order == 2) return launch_rows<2, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);

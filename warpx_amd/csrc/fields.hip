@@ -161,37 +161,37 @@ evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, D
     }
 }
 
-// configurations selectable per launch (timing sweeps; every one is bit-identical to the CPU path)
-using StPlain = StencilCfg<1, 2, 4, 0>;
-static int stencil_variant() {
-    const char* e = getenv("WXA_STENCIL_VARIANT");
-    return e ? atoi(e) : -1;
-}
-// MI355X, 256^3, back to back, same box (round 2; % of 8 TB/s for 72 / 96 B per cell):
+// Production configuration: one row per workgroup, 3 planes per lane, non-temporal moves of the arrays touched once.
+// MI355X, 256^3, back to back, same box (round 2; % of 8 TB/s for 72 / 96 B per cell; every one bit-identical to the CPU path):
 //   2 x 4 plain 0.2290 / 0.3060 ms (65.9 / 65.8 %)   2 x 4 NT 0.2204 / 0.2866 (68.5 / 70.2)   1 x 4 NT 0.2188 / 0.2865
 //   1 x 3 NT 0.2146 / 0.2803 (70.3 / 71.8)   1 x 2 NT 0.2214 / 0.2866   4 x 2 NT 0.2294 / 0.2897
 //   NT on the shared operand too: 0.2633 / 0.3088 (57 / 65)   256-lane rows (TW = 4): 0.325 / 0.372 (46 / 54)
+using StProduction = StencilCfg<1, 1, 3, 1>;
+using StPlain = StencilCfg<1, 2, 4, 0>;   // the thin guard-layer launches (wxa_evolve_b_guard_layer): plain moves
+#ifdef WXA_DEV_VARIANTS   // the sweep above: WXA_STENCIL_VARIANT=<n> per launch (scripts/stencil_variants.py, dev builds only)
 using St1 = StencilCfg<1, 2, 4, 1>;
 using St2 = StencilCfg<1, 1, 4, 1>;
-using St3 = StencilCfg<1, 1, 3, 1>;
 using St4 = StencilCfg<1, 1, 2, 1>;
 using St5 = StencilCfg<1, 4, 2, 1>;
 using St6 = StencilCfg<1, 1, 3, 2>;
 using St7 = StencilCfg<4, 1, 4, 1>;
+static int stencil_variant() {
+    const char* e = getenv("WXA_STENCIL_VARIANT");
+    return e ? atoi(e) : -1;
+}
 #define WXA_STENCIL_DISPATCH(CALL)          \
     switch (stencil_variant()) {            \
         case 0: CALL(StPlain); break;       \
         case 1: CALL(St1); break;           \
         case 2: CALL(St2); break;           \
-        case 3: CALL(St3); break;           \
         case 4: CALL(St4); break;           \
         case 5: CALL(St5); break;           \
         case 6: CALL(St6); break;           \
         case 7: CALL(St7); break;           \
-        default: CALL(WXA_STENCIL_DEFAULT); break; \
+        default: CALL(StProduction); break; \
     }
-#ifndef WXA_STENCIL_DEFAULT
-#define WXA_STENCIL_DEFAULT St3
+#else
+#define WXA_STENCIL_DISPATCH(CALL) CALL(StProduction);
 #endif
 
 // generic box copy kernels -----------------------------------------------------
@@ -600,12 +600,14 @@ evolve_b_ckc_tiled_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, 
     }
 }
 
+using CkcProduction = CkcCfg<8, 16, 1>;
+#ifdef WXA_DEV_VARIANTS   // tile shapes of the timing sweep (WXA_CKC_VARIANT, scripts/ckc_timing.py; dev builds only)
 using Ckc0 = CkcCfg<8, 16, 0>;
-using Ckc1 = CkcCfg<8, 16, 1>;
 using Ckc2 = CkcCfg<8, 32, 1>;
 using Ckc3 = CkcCfg<4, 32, 1>;
 using Ckc4 = CkcCfg<16, 16, 1>;
 using Ckc5 = CkcCfg<8, 8, 1>;
+#endif
 
 // Source/Filter/Filter.cpp:105-133 with the 1-pass stencil of BilinearFilter.cpp:26-60 ({0.25, 0.25} per direction);
 // same tap order as the reference -> bit-identical.  The staging of the CKC kernel above: a workgroup filters
@@ -804,7 +806,11 @@ wxa_status wxa_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3]
     }
     CkcCoefs cc;
     for (int n = 0; n < 5; ++n) { cc.x[n] = cx[n]; cc.y[n] = cy[n]; cc.z[n] = cz[n]; }
+#ifdef WXA_DEV_VARIANTS
     const char* plain = getenv("WXA_CKC_PLAIN");   // the one-lane-per-point kernel (reference for the tiled one, timing)
+#else
+    const char* plain = nullptr;
+#endif
     if (plain && atoi(plain) != 0) {
         const dim3 block(64, 4);
         const dim3 grid((unsigned)((ub.hi[0] - ub.lo[0] + 63) / 64), (unsigned)((ub.hi[1] - ub.lo[1] + 3) / 4),
@@ -820,16 +826,19 @@ wxa_status wxa_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3]
                            0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]), make_devf(B[0]),    \
                            make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, tg, dt, cc);                              \
     } while (0)
-        const char* var = getenv("WXA_CKC_VARIANT");   // timing sweeps (scripts/ckc_timing.py)
+#ifdef WXA_DEV_VARIANTS
+        const char* var = getenv("WXA_CKC_VARIANT");
         switch (var ? atoi(var) : -1) {
             case 0: WXA_CKC_LAUNCH(Ckc0); break;
-            case 1: WXA_CKC_LAUNCH(Ckc1); break;
             case 2: WXA_CKC_LAUNCH(Ckc2); break;
             case 3: WXA_CKC_LAUNCH(Ckc3); break;
             case 4: WXA_CKC_LAUNCH(Ckc4); break;
             case 5: WXA_CKC_LAUNCH(Ckc5); break;
-            default: WXA_CKC_LAUNCH(Ckc1); break;
+            default: WXA_CKC_LAUNCH(CkcProduction); break;
         }
+#else
+        WXA_CKC_LAUNCH(CkcProduction);
+#endif
 #undef WXA_CKC_LAUNCH
     }
     WXA_LAUNCH_CHECK();

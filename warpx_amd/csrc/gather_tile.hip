@@ -22,10 +22,10 @@
 #include <stdlib.h>
 
 #ifndef WXA_GATHER_RB
-#define WXA_GATHER_RB 1   // rows in flight ahead of the fma chain (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
+#define WXA_GATHER_RB 2   // rows in flight ahead of the fma chain (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
 #endif
 #ifndef WXA_GATHER_PF
-#define WXA_GATHER_PF 0   // 1: the next particle's position and momentum are loaded while this one gathers
+#define WXA_GATHER_PF 2   // 2: the next particle's position is requested a trip ahead, this particle's momentum at the top of its trip
 #endif
 
 namespace wxa {
@@ -122,15 +122,15 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     // HBM (counters of the kernel without it: waves parked in s_waitcnt 46 % of their cycles, VALU and LDS each < 50 %)
     int ip = start + tid;
     double nxt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    // plain loads between two compiler fences: they stay where they are written (in front of the inline-asm LDS reads) and
+    // keep the L1/L2 path of ordinary loads (volatile loads become flat_load ... sc0 sc1: system-coherent, slower)
     auto load_particle = [&](const int i) {
-        nxt[0] = *(const volatile double*)(p.x + i); nxt[1] = *(const volatile double*)(p.y + i);
-        nxt[2] = *(const volatile double*)(p.z + i);
-        if constexpr (PF == 1) {
-            nxt[3] = *(const volatile double*)(p.ux + i); nxt[4] = *(const volatile double*)(p.uy + i);
-            nxt[5] = *(const volatile double*)(p.uz + i);
-        }
+        asm volatile("" ::: "memory");
+        nxt[0] = p.x[i]; nxt[1] = p.y[i]; nxt[2] = p.z[i];
+        if constexpr (PF == 1) { nxt[3] = p.ux[i]; nxt[4] = p.uy[i]; nxt[5] = p.uz[i]; }
+        asm volatile("" ::: "memory");
     };
-    if constexpr (PF) {
+    if constexpr (PF == 1 || PF == 2) {
         if (ip < end) load_particle(ip);
     }
     constexpr int PER = (NPTS + GT_THREADS - 1) / GT_THREADS;
@@ -151,12 +151,18 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
             if (a < NPTS) F[c * NPTS + a] = r[n];
         }
     };
-    {
+    if constexpr (PF == 9) {   // timing experiment (dev builds): no staging, the tile holds a constant
+        for (int a = tid; a < 6 * NPTS; a += GT_THREADS) F[a] = 1.0;
+    } else {
         double r0[PER], r1[PER], r2[PER], r3[PER], r4[PER], r5[PER];
         fetch(Ex, r0); fetch(Ey, r1); fetch(Ez, r2); fetch(Bx, r3); fetch(By, r4); fetch(Bz, r5);
         put(0, r0); put(1, r1); put(2, r2); put(3, r3); put(4, r4); put(5, r5);
     }
     __syncthreads();
+    if constexpr (PF == 8) {   // timing experiment (dev builds): the staging alone
+        if (F[tid] == 1.2345e-300) p.x[start] = F[tid + 1];
+        return;
+    }
     GPROF_CLOCK(prof_t1);
     GPROF_ADD(0, prof_t1 - prof_t0);
     GPROF_ADD(2, 1);
@@ -164,12 +170,13 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     for (; ip < end; ip += GT_THREADS) {
         GPROF_CLOCK(prof_a);
         double xp, yp, zp, ux0, uy0, uz0;
-        if constexpr (PF) {
+        if constexpr (PF == 1 || PF == 2) {
             xp = nxt[0]; yp = nxt[1]; zp = nxt[2];
             if constexpr (PF == 1) { ux0 = nxt[3]; uy0 = nxt[4]; uz0 = nxt[5]; }
             else {   // PF == 2: this particle's momentum is requested now and used after the gather
-                ux0 = *(const volatile double*)(p.ux + ip); uy0 = *(const volatile double*)(p.uy + ip);
-                uz0 = *(const volatile double*)(p.uz + ip);
+                asm volatile("" ::: "memory");
+                ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip];
+                asm volatile("" ::: "memory");
             }
             if (ip + GT_THREADS < end) load_particle(ip + GT_THREADS);
         } else {
@@ -208,7 +215,14 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(prof_e));
 #endif
         GPROF_CLOCK(prof_c);
-        if constexpr (!PF) { ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip]; }
+        if constexpr (PF != 1 && PF != 2) { ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip]; }
+        if constexpr (PF == 7) {   // timing experiment (dev builds): everything but the stores
+            double ex_ = Exp, ey_ = Eyp, ez_ = Ezp, bx_ = Bxp, by_ = Byp, bz_ = Bzp;
+            add_external_fields(ext, ip, ex_, ey_, ez_, bx_, by_, bz_);
+            push_momentum<PUSHER>(ux0, uy0, uz0, ex_, ey_, ez_, bx_, by_, bz_, q, m, dt);
+            update_position(xp, yp, zp, ux0, uy0, uz0, dt);
+            if (xp + ux0 == 1.2345e-300) p.x[ip] = yp + zp + uy0 + uz0;
+        } else
         push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext);
 #ifdef WXA_GATHER_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -284,6 +298,12 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         if (pf == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 1>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 2) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 2>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        else if (pf == 7) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 7>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        else if (pf == 8) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 8>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        else if (pf == 9) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 9>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 0>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \

@@ -896,9 +896,12 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
     if ((rc = ws->scan_tmp.reserve(tmp_bytes)) != WXA_OK) return rc;
     WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
-    // WXA_SORT_SCATTER=0: the plain scatter (one lane per particle, 8-byte writes wherever they fall)
+#ifdef WXA_DEV_VARIANTS   // WXA_SORT_SCATTER=0: the plain scatter (one lane per particle, 8-byte writes wherever they fall)
     const char* scatter_env = std::getenv("WXA_SORT_SCATTER");
     const bool plain_scatter = scatter_env && std::atoi(scatter_env) == 0;
+#else
+    const bool plain_scatter = false;
+#endif
     if (plain_scatter)
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s, d, cell, rank, offsets);
     else {
