@@ -226,9 +226,10 @@ def main():
                     help="untimed steps before the warmup: the regular-lattice start is atypically cheap "
                          "(no particle crosses a cell for ~20 steps), the timed region must see the "
                          "thermalised steady state")
-    ap.add_argument("--overlap", type=int, default=0,
+    ap.add_argument("--overlap", type=int, default=-1,
                     help="1: the guard exchanges of E+B and of J on a second stream, behind the push of the interior "
-                         "tiles and B's half update (N > 1 only; off until it has been measured on the 8-GPU node)")
+                         "tiles and B's half update; 0: everything on one stream (the fallback); default: 1 for N > 1 "
+                         "(what north_star asks for; both schedules give the same fields, tests/test_multibrick_*)")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
                     help="N > 1: rccl = the library's own transport (ncclSend / ncclRecv groups on the library's streams, "
                          "csrc/rccl_comm.hip); torch = torch.distributed P2P through Python callbacks")
@@ -269,7 +270,7 @@ def main():
         transport = None
         if args.transport == "rccl":
             try:
-                transport = RcclBrickTransport(lib, timing=True)
+                transport = RcclBrickTransport(lib, timing=False)   # timed in the phase pass below, not in the headline
             except Exception as e:   # keep the run alive on the Python transport, and say so
                 print(f"[bench] rank {rank}: in-library RCCL transport unavailable ({e}); using torch.distributed", flush=True)
         if transport is None:
@@ -285,7 +286,8 @@ def main():
     sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=args.order, galerkin=None, particle_pusher=pusher,
                    current_deposition=depos, use_filter=0 if args.no_filter else 1, cfl=1.0,
                    sort_interval=args.sort_interval, nbricks=nbricks, coord=coord,
-                   comm=transport.comm if transport else None, overlap_halo=args.overlap)
+                   comm=transport.comm if transport else None,
+                   overlap_halo=(1 if world > 1 else 0) if args.overlap < 0 else args.overlap)
     box_lo = tuple(coord[d] * nb for d in range(3))
     parts = device_uniform_plasma(n_cell, prob_lo, prob_hi, (args.ppc,) * 3, 1e25, 0.01, 12345 + rank,
                                   box_lo, (nb,) * 3, device)
@@ -329,21 +331,33 @@ def main():
     sanity = None
     if e_before is not None:
         e_after = energies(sim, 0)
-        counts = [float(e_after[2])]
-        if world > 1:
-            t = torch.tensor(counts, dtype=torch.float64, device=device)
+        tot = [e_before[0], e_before[1], float(e_before[2]), e_after[0], e_after[1], float(e_after[2])]
+        if world > 1:   # the job's totals, not rank 0's share
+            t = torch.tensor(tot, dtype=torch.float64, device=device)
             torch.distributed.all_reduce(t)
-            counts = [float(t.item())]
-        tot0, tot1 = e_before[0] + e_before[1], e_after[0] + e_after[1]
-        sanity = {"particles_after": int(counts[0]), "particles_expected": int(np_local * world),
-                  "total_energy_drift_over_timed_steps": (tot1 - tot0) / tot0,
-                  "kinetic_energy_J_rank0": e_after[1], "field_energy_J_rank0": e_after[0],
-                  "note": "rank 0's share of the energy before / after the timed steps; the count is global"
+            tot = [float(v) for v in t.tolist()]
+        tot0, tot1 = tot[0] + tot[1], tot[3] + tot[4]
+        drift = (tot1 - tot0) / tot0
+        expected = int(np_local * world)
+        ok = int(tot[5]) == expected and int(tot[2]) == expected and abs(drift) < 1e-2
+        sanity = {"ok": ok, "particles_after": int(tot[5]), "particles_before": int(tot[2]), "particles_expected": expected,
+                  "total_energy_drift_over_timed_steps": drift,
+                  "kinetic_energy_J": tot[4], "field_energy_J": tot[3],
+                  "note": "sums over all ranks, before / after the timed steps"
                           + ("" if args.sync_each_call else "; kinetic energy from the leap-frog momenta (half a step "
                              "behind the fields) at both ends")}
-    # second, short pass with per-phase HIP-event timers (on the stream the kernels run on)
+        if not ok and rank == 0:
+            print(f"[bench] SANITY FAILED: particles {int(tot[2])} -> {int(tot[5])} (expected {expected}), "
+                  f"energy drift {drift:.3e}", file=sys.stderr, flush=True)
+    # second, short pass with per-phase HIP-event timers (on the stream the kernels run on); the transport's event pairs
+    # around every exchange are on in this pass only
     phases = {}
+    nph = 0
+    rccl = transport is not None and hasattr(transport, "stats")
+    st_head = transport.stats(reset=True) if rccl else None
     if not args.no_phase_pass:
+        if rccl:
+            transport.set_timing(True)
         sim.enable_timers(True)
         sim.timers(reset=True)
         nph = min(args.steps, 4)
@@ -351,16 +365,21 @@ def main():
         torch.cuda.synchronize()
         phases = sim.timers(reset=True)
         sim.enable_timers(False)
+        if rccl:
+            transport.set_timing(False)
 
     comm_stats = None
-    if transport is not None and hasattr(transport, "stats"):
+    if rccl:
         st = transport.stats()
-        comm_stats = {"transport": "rccl (in-library)", "exchanges_per_step": st["n_exchanges"] / max(sim.istep, 1),
-                      "messages_per_step": st["n_messages"] / max(sim.istep, 1),
-                      "MB_sent_per_step": st["bytes_sent"] / max(sim.istep, 1) / 1e6,
-                      "count_exchanges_per_step": st["n_count_exchanges"] / max(sim.istep, 1),
+        nsteps_head = max(sim.istep - nph, 1)
+        comm_stats = {"transport": "rccl (in-library)", "exchanges_per_step": st_head["n_exchanges"] / nsteps_head,
+                      "messages_per_step": st_head["n_messages"] / nsteps_head,
+                      "MB_sent_per_step": st_head["bytes_sent"] / nsteps_head / 1e6,
+                      "count_exchanges_per_step": st_head["n_count_exchanges"] / nsteps_head,
                       "ms_per_exchange": st["timed_ms"] / max(st["timed_exchanges"], 1),
-                      "exchange_ms_per_step": st["timed_ms"] / max(sim.istep, 1)}
+                      "exchange_ms_per_step": st["timed_ms"] / max(nph, 1),
+                      "note": "counts over the whole run up to the end of the timed steps; milliseconds from HIP events "
+                              "around every exchange in the separate phase pass (rank 0)"}
     elif transport is not None:
         comm_stats = {"transport": "torch.distributed (Python callbacks)",
                       "exchanges_per_step": transport.n_exchanges / max(sim.istep, 1),

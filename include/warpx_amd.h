@@ -310,6 +310,20 @@ wxa_status wxa_wrap_and_classify(const wxa_particle_view* p, int64_t first, int6
                                  int64_t capacity, int64_t counts[6], wxa_workspace* ws,
                                  void* stream);
 
+/* The same scan with the leavers listed by their DESTINATION brick instead of by the first split direction: 27 lists,
+ * list (ox + 1) + 3 (oy + 1) + 9 (oz + 1) for the brick at offset (ox, oy, oz) in {-1, 0, 1}^3 from this one (decided
+ * on the unwrapped position, along split directions only; list 13 -- no offset -- stays empty).  A particle moves less
+ * than a cell per step, so its destination is one of the 26 neighbours and it can be handed over in ONE message: one
+ * count round per step for all neighbours instead of one per split direction, and no second classification of the
+ * arrivals (edges and corners took up to three hops before).  What amrex ParticleContainer::Redistribute does with its
+ * neighbour lists (MultiParticleContainer.cpp:651-654: Redistribute(..., local = 1)).  counts[27] (host) valid on return. */
+wxa_status wxa_wrap_and_classify_dest(const wxa_particle_view* p, int64_t first, int64_t count,
+                                      const double prob_lo[3], const double prob_hi[3],
+                                      const int periodic[3], const double brick_lo[3],
+                                      const double brick_hi[3], const int split[3], int32_t* lists,
+                                      int64_t capacity, int64_t counts[27], wxa_workspace* ws,
+                                      void* stream);
+
 /* Writes the n listed particles into entries [offset, offset+n) of a message of 8 rows of
  * row_len doubles/uint64 each (row r at msg + 8*r*row_len bytes), so that several lists can
  * share one message.  retire != 0: see above. */
@@ -597,6 +611,9 @@ typedef struct wxa_rccl_stats {
     double timed_ms;
 } wxa_rccl_stats;
 wxa_status wxa_rccl_unique_id(char id[WXA_RCCL_ID_BYTES]);
+/* Event pairs around every exchange on / off at run time (diagnostic passes: the events are pooled, reading them
+ * waits on the host, so the headline timing of bench.py runs with timing off). */
+wxa_status wxa_rccl_comm_set_timing(wxa_comm* comm, int32_t on);
 wxa_status wxa_rccl_comm_create(const char id[WXA_RCCL_ID_BYTES], int32_t rank, int32_t nranks, int32_t flags,
                                 wxa_comm* out);
 void       wxa_rccl_comm_destroy(wxa_comm* comm);

@@ -1166,6 +1166,36 @@ int orc_wrap_and_classify(const wxa_particle_view* p, int64_t first, int64_t cou
     return orc_enforce_periodic(&r, prob_lo, prob_hi, periodic, nullptr);
 }
 
+// The same scan with the leavers listed by destination brick: list (ox + 1) + 3 (oy + 1) + 9 (oz + 1)
+// (include/warpx_amd.h, wxa_wrap_and_classify_dest)
+int orc_wrap_and_classify_dest(const wxa_particle_view* p, int64_t first, int64_t count, const double prob_lo[3],
+                               const double prob_hi[3], const int periodic[3], const double brick_lo[3],
+                               const double brick_hi[3], const int split[3], int32_t* lists, int64_t capacity,
+                               int64_t counts[27], void*, void*) {
+    for (int c = 0; c < 27; ++c) counts[c] = 0;
+    double* pos[3] = {p->x, p->y, p->z};
+    for (int64_t ip = first; ip < first + count; ++ip) {
+        int o[3] = {0, 0, 0};
+        for (int d = 0; d < 3; ++d)
+            if (split[d]) o[d] = pos[d][ip] < brick_lo[d] ? -1 : (pos[d][ip] >= brick_hi[d] ? 1 : 0);
+        int code = (o[0] + 1) + 3 * (o[1] + 1) + 9 * (o[2] + 1);
+        if (code != 13 && p->idcpu[ip] == WXA_IDCPU_RETIRED) {
+            code = 13;   // parked again on the brick's side of the faces (mirror of wrap_classify_kernel)
+            for (int d = 0; d < 3; ++d)
+                if (split[d])
+                    pos[d][ip] = std::min(std::max(pos[d][ip], brick_lo[d]), std::nextafter(brick_hi[d], brick_lo[d]));
+        }
+        if (code != 13) {
+            if (counts[code] < capacity) lists[code * capacity + counts[code]] = (int32_t)ip;
+            counts[code]++;
+        }
+    }
+    wxa_particle_view r = *p;
+    r.x += first; r.y += first; r.z += first;
+    r.np = count;
+    return orc_enforce_periodic(&r, prob_lo, prob_hi, periodic, nullptr);
+}
+
 int orc_pack_leavers(const wxa_particle_view* p, const int32_t* list, int64_t n, void* msg, int64_t row_len,
                      int64_t offset, int retire, const double brick_lo[3], const double brick_hi[3], void*) {
     double* m = static_cast<double*>(msg) + offset;

@@ -38,6 +38,8 @@ int orc_partition_particles(const wxa_particle_view*, const wxa_particle_view*, 
                             void*, void*);
 int orc_wrap_and_classify(const wxa_particle_view*, int64_t, int64_t, const double*, const double*, const int*,
                           const double*, const double*, const int*, int32_t*, int64_t, int64_t*, void*, void*);
+int orc_wrap_and_classify_dest(const wxa_particle_view*, int64_t, int64_t, const double*, const double*, const int*,
+                               const double*, const double*, const int*, int32_t*, int64_t, int64_t*, void*, void*);
 int orc_pack_leavers(const wxa_particle_view*, const int32_t*, int64_t, void*, int64_t, int64_t, int, const double*,
                      const double*, void*);
 int orc_sort_live_count(void*, int64_t*, void*);
@@ -140,6 +142,7 @@ const Backend* cpu_backend() {
         b.sort_particles_by_cell = orc_sort_particles_by_cell;
         b.partition_particles = orc_partition_particles;
         b.wrap_and_classify = orc_wrap_and_classify;
+        b.wrap_and_classify_dest = orc_wrap_and_classify_dest;
         b.pack_leavers = orc_pack_leavers;
         b.sort_live_count = orc_sort_live_count;
         b.apply_pec_e = orc_apply_pec_e;

@@ -606,6 +606,21 @@ def test_redistribute_ops(oracle, product):
                              lists_c.ctypes.data, cap, cnt_c, None, None)
     assert list(cnt_d) == list(cnt_c)
     assert cnt_d[2] == 0 and cnt_d[3] == 0 and sum(cnt_d) > 1000       # y is not split
+    # the same scan with the leavers listed by destination brick (27 lists), on fresh copies
+    pc27 = ParticleArrays.from_numpy(parts, "cpu", ids.copy())
+    pd27 = ParticleArrays.from_numpy(parts, DEV, ids.view(np.int64))
+    l27_d = torch.zeros(27 * cap, dtype=torch.int32, device=DEV)
+    l27_c = np.zeros(27 * cap, dtype=np.int32)
+    c27_d, c27_c = (C.c_int64 * 27)(), (C.c_int64 * 27)()
+    product.wrap_and_classify_dest(C.byref(pd27.view), 0, n, H.d3(plo), H.d3(phi), periodic, H.d3(blo), H.d3(bhi), split,
+                                   l27_d.data_ptr(), cap, c27_d, ws, None)
+    oracle.wrap_and_classify_dest(C.byref(pc27.view), 0, n, H.d3(plo), H.d3(phi), periodic, H.d3(blo), H.d3(bhi), split,
+                                  l27_c.ctypes.data, cap, c27_c, None, None)
+    assert list(c27_d) == list(c27_c) and sum(c27_d) == sum(cnt_d) and c27_d[13] == 0
+    l27 = l27_d.cpu().numpy()
+    for c in range(27):
+        assert np.array_equal(np.sort(l27[c * cap:c * cap + c27_d[c]]), np.sort(l27_c[c * cap:c * cap + c27_c[c]]))
+    assert np.array_equal(pd27.to_numpy(), pc27.to_numpy())
     ld = lists_d.cpu().numpy()
     for c in range(6):
         assert np.array_equal(np.sort(ld[c * cap:c * cap + cnt_d[c]]), np.sort(lists_c[c * cap:c * cap + cnt_c[c]]))

@@ -60,6 +60,49 @@ def test_wrap_and_classify_against_numpy(oracle):
     assert np.array_equal(got[3:], np.array(parts[3:]))
 
 
+def test_wrap_and_classify_dest_against_numpy(oracle):
+    """wxa_wrap_and_classify_dest's CPU restatement: the leavers listed by the offset of their destination brick (27
+    lists, decided on the unwrapped position along the split directions), retired particles parked, positions wrapped."""
+    ncell = (24, 20, 16)
+    dx = H.LX / np.asarray(ncell)
+    plo, phi = np.full(3, -H.LX / 2), np.full(3, H.LX / 2)
+    blo, bhi = plo.copy(), np.array([0.0, phi[1], 0.0])
+    n = 20000
+    parts, ids = _particles(n, 15, blo, bhi, dx)
+    pc = ParticleArrays.from_numpy(parts, "cpu", ids.copy())
+    split = (1, 0, 1)
+    lists = np.full(27 * n, -1, dtype=np.int32)
+    cnt = (C.c_int64 * 27)()
+    oracle.wrap_and_classify_dest(C.byref(pc.view), 0, n, H.d3(plo), H.d3(phi), H.i3((1, 1, 1)), H.d3(blo), H.d3(bhi),
+                                  H.i3(split), lists.ctypes.data, n, cnt, None, None)
+    x = np.array(parts[:3])
+    off = [np.where(x[d] < blo[d], -1, np.where(x[d] >= bhi[d], 1, 0)) if split[d] else np.zeros(n, dtype=int)
+           for d in range(3)]
+    code = (off[0] + 1) + 3 * (off[1] + 1) + 9 * (off[2] + 1)
+    code[ids == RETIRED] = 13
+    assert cnt[13] == 0
+    seen = 0
+    for c in range(27):
+        if c == 13:
+            continue
+        want = np.nonzero(code == c)[0]
+        assert cnt[c] == want.size, c
+        assert np.array_equal(lists[c * n:c * n + cnt[c]], want)
+        seen += want.size
+    # faces, and the edges where both split directions are left at once; nothing along the unsplit direction
+    assert cnt[12] > 100 and cnt[14] > 100 and cnt[4] > 100 and cnt[22] > 100
+    assert cnt[3] + cnt[5] + cnt[21] + cnt[23] > 10
+    assert all(cnt[c] == 0 for c in range(27) if (c // 3) % 3 != 1)
+    assert seen == int((code != 13).sum())
+    # the positions: the same as after wxa_wrap_and_classify
+    pc2 = ParticleArrays.from_numpy(parts, "cpu", ids.copy())
+    l6, c6 = np.zeros(6 * n, dtype=np.int32), (C.c_int64 * 6)()
+    oracle.wrap_and_classify(C.byref(pc2.view), 0, n, H.d3(plo), H.d3(phi), H.i3((1, 1, 1)), H.d3(blo), H.d3(bhi),
+                             H.i3(split), l6.ctypes.data, n, c6, None, None)
+    assert np.array_equal(pc.to_numpy(), pc2.to_numpy())
+    assert sum(c6) == seen
+
+
 def test_pack_retire_and_sort(oracle):
     ncell = (12, 20, 8)
     dx = H.LX / np.asarray((24, 20, 16))

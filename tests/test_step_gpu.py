@@ -248,7 +248,7 @@ def test_langmuir_256_two_species_full_size(product):
     """BASELINE.json config 3 at full size (256^3, e-/e+, 8 ppc, Esirkepov, order 3, 40 steps) through
     size-independent properties -- the CPU oracle cannot run 2.7e8 particles in test time:
     (i) the reference's analytic gate (Examples/Tests/langmuir/analysis_3d.py: max-norm error < 5 %),
-    (ii) Gauss' law div E = rho/eps0 kept to round-off by the charge-conserving deposition,
+    (ii) Gauss' law div E = rho/eps0 kept to round-off (1e-10 of max rho/eps0) by the charge-conserving deposition,
     (iii) total energy conserved to 1e-3 over the run, (iv) particle count and weights unchanged."""
     import ctypes as C
     import torch
@@ -342,7 +342,7 @@ def test_langmuir_256_two_species_full_size(product):
            + (ez[:n, :n, :n] - np.roll(ez[:n, :n, :n], 1, axis=2))) / dx
     resid = np.max(np.abs(div - r / plasma.EP0)) / np.max(np.abs(r / plasma.EP0))
     print("gauss residual", resid)
-    assert resid < 1e-7
+    assert resid < 1e-10   # 6.0e-12 on the MI355X (profiles/round3): atomic summation order of rho and J, nothing else
 
 
 def test_pec_field_golden_on_gpu(oracle, product):

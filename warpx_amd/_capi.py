@@ -241,6 +241,8 @@ _PRODUCT_SIGS = {
                                       C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "wrap_and_classify": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,
                                     C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "wrap_and_classify_dest": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,
+                                         C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "pack_leavers": (C.c_int, [_PPV, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _D3, _D3,
                                C.c_void_p]),
     "sort_live_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
@@ -261,6 +263,7 @@ _TRANSPORT_SIGS = {
     "rccl_comm_create": (C.c_int, [C.c_char * 128, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Comm)]),
     "rccl_comm_destroy": (None, [C.POINTER(Comm)]),
     "rccl_comm_stats": (C.c_int, [C.POINTER(Comm), C.POINTER(RcclStats), C.c_int32]),
+    "rccl_comm_set_timing": (C.c_int, [C.POINTER(Comm), C.c_int32]),
 }
 
 # oracle-only entry points (diagnostic formulas that define the parity metric)
@@ -280,6 +283,8 @@ _ORACLE_SIGS = {
     "sort_particles_by_cell": (C.c_int, [_PPV, _PPV, _D3, _D3, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "wrap_and_classify": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,
                                     C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "wrap_and_classify_dest": (C.c_int, [_PPV, C.c_int64, C.c_int64, _D3, _D3, _I3, _D3, _D3, _I3, C.c_void_p,
+                                         C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "pack_leavers": (C.c_int, [_PPV, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _D3, _D3,
                                C.c_void_p]),
 }

@@ -198,6 +198,11 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     __shared__ unsigned deferred[DEFER];
     __shared__ int ndef[NBANK];
     __shared__ int nitems;
+    // ... and their data, for the first DKEEP entries of every bucket: phase C has the particle in registers when it
+    // defers it; fetched again by index in phase D each one costs seven cache lines from HBM (the tile's lines have left
+    // the L2 by then: FETCH_SIZE 1.57 x the particle data, phase D 12 % of the kernel for 3 % of the particles)
+    constexpr int DKEEP = sizeof(ACC) == 8 ? 48 : 16;   // 16 x 48 x 56 B = 42 KB next to the 89 KB tile
+    __shared__ double dkeep[7][NBANK * DKEEP];
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
     if (unit >= ntiles * SUB) return;
@@ -211,10 +216,24 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     const int wave = tid >> 6, lane = tid & 63;
     DPROF_INIT
     constexpr int DCAP = DEFER / NBANK;
-    auto defer = [&](const int ip, const int bank) {
+    auto defer = [&](const int ip, const int bank) {   // phase B: by index only (the particle has not been loaded)
         const int n = atomicAdd(&ndef[bank], 1);
-        if (n < DCAP) deferred[bank * DCAP + n] = (unsigned)ip;
+        if (n < DCAP) deferred[bank * DCAP + n] = (unsigned)ip | 0x80000000u;
         else sq.push(ip);
+    };
+    auto defer_particle = [&](const int ip, const int bank, const ParticleState& pp) {
+        const int n = atomicAdd(&ndef[bank], 1);
+        if (n < DCAP) {
+            const bool keep = n < DKEEP;
+            deferred[bank * DCAP + n] = (unsigned)ip | (keep ? 0u : 0x80000000u);
+            if (keep) {
+                const int at = bank * DKEEP + n;
+                dkeep[0][at] = pp.x; dkeep[1][at] = pp.y; dkeep[2][at] = pp.z; dkeep[3][at] = pp.w;
+                dkeep[4][at] = pp.ux; dkeep[5][at] = pp.uy; dkeep[6][at] = pp.uz;
+            }
+        } else {
+            sq.push(ip);
+        }
     };
     constexpr int WAVES = NT / 64;
     // ---- A: cell counts, row masks; zero fill
@@ -358,8 +377,8 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         };
         if (sa == 2) sq.push(ia);
         if (sb == 2) sq.push(ib);
-        if (sa == 1) defer(ia, wide_bank(c1));
-        if (sb == 1) defer(ib, wide_bank(c2));
+        if (sa == 1) defer_particle(ia, wide_bank(c1), pa);
+        if (sb == 1) defer_particle(ib, wide_bank(c2), pb);
         int key = -1;
         bool fast_a = false, fast_b = false;   // which of the lane's particles its fast item holds
         if (sa == 0) {
@@ -367,7 +386,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             if (sb == 0 && kb == ka) {
                 wq2 = wqb; fast_b = true;                // merged with its neighbour
             } else {
-                if (sb == 0) defer(ib, wide_bank(c2));   // another frame: the wide body takes it alone
+                if (sb == 0) defer_particle(ib, wide_bank(c2), pb);   // another frame: the wide body takes it alone
                 c2 = c1;                                 // empty partner
             }
         } else if (sb == 0) {
@@ -380,8 +399,8 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             if (pkey >= 0 && pkey != key) {
                 if (key < 0 || lane >= 32) {
                     if (key >= 0) {
-                        if (fast_a) defer(ia, wide_bank(esirkepov_coords(pa, g, es)));
-                        if (fast_b) defer(ib, wide_bank(esirkepov_coords(pb, g, es)));
+                        if (fast_a) defer_particle(ia, wide_bank(esirkepov_coords(pa, g, es)), pa);
+                        if (fast_b) defer_particle(ib, wide_bank(esirkepov_coords(pb, g, es)), pb);
                     }
                     key = pkey; wq1 = 0.0; wq2 = 0.0; c2 = c1;
                 }
@@ -438,8 +457,16 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             const int comp = __builtin_amdgcn_readfirstlane(ch / dch);
             const int row = (ch - comp * dch) * 4 + (lane >> 4);
             if (row < my_nd) {
-                const int ip = (int)deferred[(lane & (NBANK - 1)) * DCAP + row];
-                const ParticleState p1{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+                const unsigned ent = deferred[(lane & (NBANK - 1)) * DCAP + row];
+                ParticleState p1;
+                if (ent & 0x80000000u) {
+                    const int ip = (int)(ent & 0x7fffffffu);
+                    p1 = ParticleState{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+                } else {
+                    const int at = (lane & (NBANK - 1)) * DKEEP + row;
+                    p1 = ParticleState{dkeep[0][at], dkeep[1][at], dkeep[2][at], dkeep[3][at], dkeep[4][at],
+                                       dkeep[5][at], dkeep[6][at]};
+                }
                 const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
                 const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
                 LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
@@ -519,7 +546,7 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
     const dim3 grid((unsigned)xcd_grid_size(nunits)), block(CFG::NT);
     wxa_status rc;
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
-    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
     StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);

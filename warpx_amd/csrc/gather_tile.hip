@@ -276,7 +276,7 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
     const dim3 grid((unsigned)xcd_grid_size(ntiles)), block(GT_THREADS);
     wxa_status rc;
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
-    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
     GatherStragglers sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p + 16};
     const ExtEB ext = ext_of(ws);
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));

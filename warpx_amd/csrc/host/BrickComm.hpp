@@ -175,6 +175,25 @@ public:
         SumBoundary(std::vector<amrex::MultiFab*>{&mf}, src_ng, refresh_guards, stream);
     }
 
+    // The slab staging of the largest exchange these fields can ask for (`layers` guard layers + the shared node, over
+    // the whole allocation transversally): allocated once at set-up, so that no exchange of the time loop frees and
+    // reallocates device memory (DeviceBuffer::reserve would, the first time a deeper exchange comes by).
+    void presize(const std::vector<amrex::MultiFab*>& mfs, const amrex::IntVect& layers) {
+        for (int d = 0; d < 3; ++d) {
+            if (self_periodic(d) || !m_periodic[d]) continue;
+            size_t pts = 0;
+            for (const amrex::MultiFab* mf : mfs) {
+                const wxa_field_view& f = mf->view();
+                size_t t = (size_t)std::min(layers[d], f.ng[d]) + 1;
+                for (int e = 0; e < 3; ++e)
+                    if (e != d) t *= (size_t)f.n[e];
+                pts += t;
+            }
+            for (auto& b : m_send) b.reserve(8 * pts);
+            for (auto& b : m_recv) b.reserve(8 * pts);
+        }
+    }
+
     // post `n` (<= 2) sends/recvs of raw device buffers with the +/- neighbours in direction d
     void exchange_raw(int d, void* send_minus, int64_t sm_bytes, void* send_plus, int64_t sp_bytes,
                       void* recv_plus, int64_t rp_bytes, void* recv_minus, int64_t rm_bytes, void* stream) {
@@ -196,6 +215,26 @@ public:
             throw std::runtime_error("BrickComm: exchange_counts callback failed");
         from_plus = rv[0];
         from_minus = rv[1];
+    }
+
+    // the brick at offset o (each component in {-1, 0, 1}) from this one, periodic images included
+    int rank_at_offset(const int o[3]) const {
+        int c[3];
+        for (int d = 0; d < 3; ++d) c[d] = (m_coord[d] + o[d] + m_nb[d]) % m_nb[d];
+        return rank_of(c);
+    }
+    // one message each way with every listed peer (the particle hand-off: every rank lists its peers in ascending rank
+    // order, so the one send / one receive of a pair match on both sides)
+    void exchange_with(int n, const int32_t* peer, void* const* send_buf, const int64_t* send_bytes, void* const* recv_buf,
+                       const int64_t* recv_bytes, void* stream) {
+        if (n == 0) return;
+        if (m_comm.exchange(m_comm.ctx, n, peer, send_buf, send_bytes, peer, recv_buf, recv_bytes, stream) != 0)
+            throw std::runtime_error("BrickComm: exchange callback failed");
+    }
+    void exchange_counts_with(int n, const int32_t* peer, const int64_t* send_val, int64_t* recv_val) {
+        if (n == 0) return;
+        if (m_comm.exchange_counts(m_comm.ctx, n, peer, send_val, peer, recv_val) != 0)
+            throw std::runtime_error("BrickComm: exchange_counts callback failed");
     }
 
     static void check(int rc) {

@@ -192,6 +192,16 @@ public:
             if (cfg.nbricks[d] == 1 && m_comm->periodic(d) &&
                 m_ctx.brick_box.length(d) < 2 * guard_cells.ng_alloc_J[d] + 1)
                 throw std::runtime_error("periodic direction shorter than twice the guard depth");
+        {   // the exchanges of the time loop: E + B together at any guard depth, J at its guard sum
+            std::vector<amrex::MultiFab*> eb, jj;
+            for (int d = 0; d < 3; ++d) {
+                eb.push_back(m_fields.get(FieldType::Efield_fp, Direction{d}, 0));
+                eb.push_back(m_fields.get(FieldType::Bfield_fp, Direction{d}, 0));
+                jj.push_back(m_fields.get(FieldType::current_fp, Direction{d}, 0));
+            }
+            m_comm->presize(eb, guard_cells.ng_alloc_EB);
+            m_comm->presize(jj, guard_cells.ng_alloc_J);
+        }
         m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, cfg.maxwell_solver, m_ctx.dx);
         sort_intervals = cfg.sort_interval;
         m_ctx.sort_intervals_on = sort_intervals > 0;

@@ -272,7 +272,6 @@ public:
         const Backend* be = m_ctx->be;
         // particles wrap only along the periodic directions (walls: ApplyBoundaryConditions)
         const int periodic[3] = {comm.periodic(0) ? 1 : 0, comm.periodic(1) ? 1 : 0, comm.periodic(2) ? 1 : 0};
-        const int none[3] = {0, 0, 0};
         int split[3];
         bool any_split = false;
         for (int d = 0; d < 3; ++d) { split[d] = comm.self_periodic(d) ? 0 : 1; any_split = any_split || split[d]; }
@@ -291,80 +290,94 @@ public:
             if (m_steps_since_sort >= 0) ++m_steps_since_sort;
             return;
         }
-        // one scan of the whole tile: wrap + six leaver lists (by first split direction)
-        struct Segment { const int32_t* list; int64_t n; };
-        std::vector<Segment> seg[6];
-        const int64_t cap = np0 / 4 + 4096;
-        m_lists.reserve(sizeof(int32_t) * 6 * (size_t)cap);
+        // One scan of the whole tile: periodic wrap + the leavers listed by DESTINATION brick (26 neighbours): a
+        // particle moves less than a cell per step, so it is handed to its final brick in one message.  Per step: one
+        // host read of the 27 counts, ONE count round with all neighbours, one grouped data exchange -- no second
+        // classification of arrivals (edges and corners took up to three hops, each with its own blocking count
+        // exchange, before).
+        const int64_t cap = np0 / 64 + 4096;   // per list; the faces of a 256^3 brick at |v| -> c send ~np / 150
+        m_lists.reserve(sizeof(int32_t) * 27 * (size_t)cap);
         int32_t* lists = static_cast<int32_t*>(m_lists.p);
-        int64_t cnt[6] = {0, 0, 0, 0, 0, 0};
+        int64_t cnt[27];
+        for (int64_t& c : cnt) c = 0;
         if (np0 > 0) {
             const wxa_particle_view p = m_tile.view();
-            check(be->wrap_and_classify(&p, 0, np0, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic,
-                                        m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), split, lists, cap, cnt, m_ws,
-                                        m_ctx->stream),
-                  "wrap_and_classify");
-            for (int c = 0; c < 6; ++c) {
+            check(be->wrap_and_classify_dest(&p, 0, np0, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic,
+                                             m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), split, lists, cap, cnt,
+                                             m_ws, m_ctx->stream),
+                  "wrap_and_classify_dest");
+            for (int c = 0; c < 27; ++c)
                 if (cnt[c] > cap) throw std::runtime_error("Redistribute: leaver list overflow");
-                if (cnt[c] > 0) seg[c].push_back({lists + c * cap, cnt[c]});
-            }
         }
-        for (int d = 0; d < 3; ++d) {
-            if (!split[d]) continue;
-            int64_t nsend[2] = {0, 0};
-            for (int s = 0; s < 2; ++s)
-                for (const Segment& g : seg[2 * d + s]) nsend[s] += g.n;
-            int64_t from_plus = 0, from_minus = 0;
-            comm.exchange_counts(d, nsend[0], nsend[1], from_plus, from_minus);
-            const int64_t nrecv = from_plus + from_minus;
-            // staging: one message per peer = 8 SoA rows (7 reals + idcpu) of n entries
-            m_sendbuf.reserve(64 * (size_t)std::max<int64_t>(nsend[0] + nsend[1], 1));
-            m_recvbuf.reserve(64 * (size_t)std::max<int64_t>(nrecv, 1));
-            char* msg[2] = {static_cast<char*>(m_sendbuf.p), static_cast<char*>(m_sendbuf.p) + 64 * nsend[0]};
+        // the distinct peers, in the same canonical order on both sides of every pair: ascending offset code on the
+        // sender is descending code (the mirrored offset) on the receiver, so peers are ordered by rank instead
+        struct Peer { int rank; int64_t nsend = 0, nrecv = 0; std::vector<int> codes; };
+        std::vector<Peer> peers;
+        for (int code = 0; code < 27; ++code) {
+            if (code == 13) continue;
+            const int o[3] = {code % 3 - 1, (code / 3) % 3 - 1, code / 9 - 1};
+            bool reachable = true;
+            for (int d = 0; d < 3; ++d) reachable = reachable && (o[d] == 0 || split[d]);
+            if (!reachable) continue;
+            const int r = comm.rank_at_offset(o);
+            auto it = std::find_if(peers.begin(), peers.end(), [&](const Peer& q) { return q.rank == r; });
+            if (it == peers.end()) { peers.push_back(Peer{r}); it = peers.end() - 1; }
+            it->codes.push_back(code);
+            it->nsend += cnt[code];
+        }
+        std::sort(peers.begin(), peers.end(), [](const Peer& a, const Peer& b) { return a.rank < b.rank; });
+        const int npeers = (int)peers.size();
+        {
+            std::vector<int32_t> pr(npeers);
+            std::vector<int64_t> sv(npeers), rv(npeers, 0);
+            for (int i = 0; i < npeers; ++i) { pr[i] = peers[i].rank; sv[i] = peers[i].nsend; }
+            comm.exchange_counts_with(npeers, pr.data(), sv.data(), rv.data());
+            for (int i = 0; i < npeers; ++i) peers[i].nrecv = rv[i];
+        }
+        int64_t nsend_tot = 0, nrecv_tot = 0;
+        for (const Peer& q : peers) { nsend_tot += q.nsend; nrecv_tot += q.nrecv; }
+        // staging: one message per peer = 8 SoA rows (7 reals + idcpu) of n entries
+        m_sendbuf.reserve(64 * (size_t)std::max<int64_t>(nsend_tot, 1));
+        m_recvbuf.reserve(64 * (size_t)std::max<int64_t>(nrecv_tot, 1));
+        std::vector<void*> sb(npeers), rb(npeers);
+        std::vector<int64_t> sbytes(npeers), rbytes(npeers);
+        std::vector<int32_t> prank(npeers);
+        {
             const wxa_particle_view p = m_tile.view();
-            for (int s = 0; s < 2; ++s) {
+            char* sp = static_cast<char*>(m_sendbuf.p);
+            char* rp = static_cast<char*>(m_recvbuf.p);
+            for (int i = 0; i < npeers; ++i) {
+                const Peer& q = peers[i];
                 int64_t off = 0;
-                for (const Segment& g : seg[2 * d + s]) {
-                    check(be->pack_leavers(&p, g.list, g.n, msg[s], nsend[s], off, /*retire=*/1,
+                for (int code : q.codes) {
+                    if (cnt[code] == 0) continue;
+                    check(be->pack_leavers(&p, lists + (int64_t)code * cap, cnt[code], sp, q.nsend, off, /*retire=*/1,
                                            m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), m_ctx->stream),
                           "pack_leavers");
-                    off += g.n;
+                    off += cnt[code];
                 }
-            }
-            m_nretired += nsend[0] + nsend[1];
-            char* rb = static_cast<char*>(m_recvbuf.p);
-            char* rmsg_plus = rb;
-            char* rmsg_minus = rb + 64 * from_plus;
-            comm.exchange_raw(d, msg[0], 64 * nsend[0], msg[1], 64 * nsend[1], rmsg_plus, 64 * from_plus, rmsg_minus,
-                              64 * from_minus, m_ctx->stream);
-            if (nrecv == 0) continue;
-            const int64_t n0 = m_tile.numParticles();
-            m_tile.resize(n0 + nrecv);   // appends behind the sorted part (reallocation keeps the contents)
-            auto unpack_msg = [&](const char* srcb, int64_t off, int64_t n) {
-                for (int c = 0; c < 7; ++c)
-                    be->memcpy_async(m_tile.comp(c) + off, srcb + 8 * (int64_t)c * n, 8 * (size_t)n, m_ctx->stream);
-                be->memcpy_async(m_tile.idcpu() + off, srcb + 8 * 7 * n, 8 * (size_t)n, m_ctx->stream);
-            };
-            if (from_plus > 0) unpack_msg(rmsg_plus, n0, from_plus);
-            if (from_minus > 0) unpack_msg(rmsg_minus, n0 + from_plus, from_minus);
-            // arrivals may have to travel on along the remaining directions (edges and corners)
-            int later[3] = {0, 0, 0};
-            bool any_later = false;
-            for (int e = d + 1; e < 3; ++e) { later[e] = split[e]; any_later = any_later || split[e]; }
-            if (any_later) {
-                DeviceBuffer& al = m_arrival_lists[d];
-                al.reserve(sizeof(int32_t) * 6 * (size_t)nrecv);
-                int32_t* alist = static_cast<int32_t*>(al.p);
-                int64_t acnt[6];
-                const wxa_particle_view pa = m_tile.view();
-                check(be->wrap_and_classify(&pa, n0, nrecv, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), none,
-                                            m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), later, alist, nrecv, acnt,
-                                            m_ws, m_ctx->stream),
-                      "wrap_and_classify(arrivals)");
-                for (int c = 0; c < 6; ++c)
-                    if (acnt[c] > 0) seg[c].push_back({alist + c * nrecv, acnt[c]});
+                prank[i] = q.rank;
+                sb[i] = sp; sbytes[i] = 64 * q.nsend; sp += 64 * q.nsend;
+                rb[i] = rp; rbytes[i] = 64 * q.nrecv; rp += 64 * q.nrecv;
             }
         }
+        m_nretired += nsend_tot;
+        if (nsend_tot > 0 || nrecv_tot > 0)
+            comm.exchange_with(npeers, prank.data(), sb.data(), sbytes.data(), rb.data(), rbytes.data(), m_ctx->stream);
+        if (nrecv_tot > 0) {
+            int64_t n0 = m_tile.numParticles();
+            m_tile.resize(n0 + nrecv_tot);   // appends behind the sorted part (reallocation keeps the contents)
+            for (int i = 0; i < npeers; ++i) {
+                const int64_t n = peers[i].nrecv;
+                if (n == 0) continue;
+                const char* srcb = static_cast<const char*>(rb[i]);
+                for (int c = 0; c < 7; ++c)
+                    be->memcpy_async(m_tile.comp(c) + n0, srcb + 8 * (int64_t)c * n, 8 * (size_t)n, m_ctx->stream);
+                be->memcpy_async(m_tile.idcpu() + n0, srcb + 8 * 7 * n, 8 * (size_t)n, m_ctx->stream);
+                n0 += n;
+            }
+        }
+        if (m_steps_since_sort >= 0) ++m_steps_since_sort;
         be->stream_sync(m_ctx->stream);
     }
 

@@ -90,6 +90,10 @@ struct Backend {
                              const double* prob_hi, const int* periodic, const double* brick_lo,
                              const double* brick_hi, const int* split, int32_t* lists, int64_t capacity,
                              int64_t* counts, void* ws, void*);
+    int (*wrap_and_classify_dest)(const wxa_particle_view*, int64_t first, int64_t count, const double* prob_lo,
+                                  const double* prob_hi, const int* periodic, const double* brick_lo,
+                                  const double* brick_hi, const int* split, int32_t* lists, int64_t capacity,
+                                  int64_t* counts27, void* ws, void*);
     int (*pack_leavers)(const wxa_particle_view*, const int32_t* list, int64_t n, void* msg, int64_t row_len,
                         int64_t offset, int retire, const double* brick_lo, const double* brick_hi, void*);
     int (*sort_live_count)(void* ws, int64_t* n, void*);

@@ -124,6 +124,12 @@ const Backend* hip_backend() {
                                  void* st) -> int {
             return wxa_wrap_and_classify(p, first, count, plo, phi, per, blo, bhi, split, lists, cap, counts,
                                          static_cast<wxa_workspace*>(ws), st); };
+        b.wrap_and_classify_dest = [](const wxa_particle_view* p, int64_t first, int64_t count, const double* plo,
+                                      const double* phi, const int* per, const double* blo, const double* bhi,
+                                      const int* split, int32_t* lists, int64_t cap, int64_t* counts, void* ws,
+                                      void* st) -> int {
+            return wxa_wrap_and_classify_dest(p, first, count, plo, phi, per, blo, bhi, split, lists, cap, counts,
+                                              static_cast<wxa_workspace*>(ws), st); };
         b.pack_leavers = [](const wxa_particle_view* p, const int32_t* list, int64_t n, void* msg, int64_t row_len,
                             int64_t offset, int retire, const double* blo, const double* bhi, void* st) -> int {
             return wxa_pack_leavers(p, list, n, msg, row_len, offset, retire, blo, bhi, st); };

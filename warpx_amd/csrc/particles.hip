@@ -507,6 +507,9 @@ struct ClassifyGeom {
     int periodic[3], split[3];
 };
 
+// DEST = false: 6 lists, by the first split direction in which the particle is outside (before the wrap);
+// DEST = true: 27 lists, by the offset of the destination brick (wxa_wrap_and_classify_dest)
+template <bool DEST>
 __global__ void __launch_bounds__(256)
 wrap_classify_kernel(double* __restrict__ x, double* __restrict__ y, double* __restrict__ z,
                      const uint64_t* __restrict__ id, long first, long count, ClassifyGeom cg,
@@ -515,10 +518,19 @@ wrap_classify_kernel(double* __restrict__ x, double* __restrict__ y, double* __r
     if (t >= count) return;
     const long ip = first + t;
     double v[3] = {x[ip], y[ip], z[ip]};
-    int code = -1;   // first split direction in which the particle is outside, before the wrap
+    int code = -1;
+    if constexpr (DEST) {
+        int o[3] = {0, 0, 0};
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-        if (cg.split[d] && code < 0) code = v[d] < cg.blo[d] ? 2 * d : (v[d] >= cg.bhi[d] ? 2 * d + 1 : -1);
+        for (int d = 0; d < 3; ++d)
+            if (cg.split[d]) o[d] = v[d] < cg.blo[d] ? -1 : (v[d] >= cg.bhi[d] ? 1 : 0);
+        code = (o[0] + 1) + 3 * (o[1] + 1) + 9 * (o[2] + 1);
+        if (code == 13) code = -1;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (cg.split[d] && code < 0) code = v[d] < cg.blo[d] ? 2 * d : (v[d] >= cg.bhi[d] ? 2 * d + 1 : -1);
+    }
     if (code >= 0 && id[ip] == WXA_IDCPU_RETIRED) {
         // A retired particle is still pushed until the next sort drops it (weight 0: it deposits zeros).  It was
         // parked on the brick's side of the face it left through, so the push can carry it across again; if
@@ -959,17 +971,21 @@ wxa_status wxa_partition_particles(const wxa_particle_view* src, const wxa_parti
     return WXA_OK;
 }
 
-wxa_status wxa_wrap_and_classify(const wxa_particle_view* p, int64_t first, int64_t count, const double prob_lo[3],
-                                 const double prob_hi[3], const int periodic[3], const double brick_lo[3],
-                                 const double brick_hi[3], const int split[3], int32_t* lists, int64_t capacity,
-                                 int64_t counts[6], wxa_workspace* ws, void* stream) {
+}  // extern "C"
+
+template <bool DEST>
+static wxa_status wrap_and_classify_impl(const wxa_particle_view* p, int64_t first, int64_t count, const double prob_lo[3],
+                                         const double prob_hi[3], const int periodic[3], const double brick_lo[3],
+                                         const double brick_hi[3], const int split[3], int32_t* lists, int64_t capacity,
+                                         int64_t* counts, wxa_workspace* ws, void* stream) {
+    constexpr int NL = DEST ? 27 : 6;
     WXA_REQUIRE(pv_ok(p) && prob_lo && prob_hi && periodic && brick_lo && brick_hi && split && counts && ws,
                 "bad argument");
     WXA_REQUIRE(first >= 0 && count >= 0 && first + count <= p->np, "range outside the tile");
     WXA_REQUIRE(capacity >= 0 && (capacity == 0 || lists), "null list storage");
     const bool any_split = split[0] || split[1] || split[2];
     WXA_REQUIRE(!any_split || p->idcpu, "idcpu is needed to recognise retired particles");
-    for (int c = 0; c < 6; ++c) counts[c] = 0;
+    for (int c = 0; c < NL; ++c) counts[c] = 0;
     if (count == 0) return WXA_OK;
     ClassifyGeom cg;
     for (int d = 0; d < 3; ++d) {
@@ -979,18 +995,36 @@ wxa_status wxa_wrap_and_classify(const wxa_particle_view* p, int64_t first, int6
     }
     hipStream_t st = (hipStream_t)stream;
     wxa_status rc;
-    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
-    unsigned* dcount = (unsigned*)ws->counters.p + 32;
-    WXA_HIP_CHECK(hipMemsetAsync(dcount, 0, 6 * sizeof(unsigned), st));
-    hipLaunchKernelGGL(wrap_classify_kernel, dim3(blocks_for(count)), dim3(256), 0, st, p->x, p->y, p->z, p->idcpu,
+    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
+    unsigned* dcount = (unsigned*)ws->counters.p + (DEST ? 64 : 32);   // words: 0 deposit, 16 gather, 32 classify, 48 walls, 56 injection, 64..90 destinations
+    WXA_HIP_CHECK(hipMemsetAsync(dcount, 0, NL * sizeof(unsigned), st));
+    hipLaunchKernelGGL(wrap_classify_kernel<DEST>, dim3(blocks_for(count)), dim3(256), 0, st, p->x, p->y, p->z, p->idcpu,
                        (long)first, (long)count, cg, lists, (long)capacity, dcount);
     WXA_LAUNCH_CHECK();
     if (!any_split) return WXA_OK;   // nothing can be listed: no need to wait
-    unsigned h[6];
+    unsigned h[NL];
     WXA_HIP_CHECK(hipMemcpyAsync(h, dcount, sizeof(h), hipMemcpyDeviceToHost, st));
     WXA_HIP_CHECK(hipStreamSynchronize(st));
-    for (int c = 0; c < 6; ++c) counts[c] = h[c];
+    for (int c = 0; c < NL; ++c) counts[c] = h[c];
     return WXA_OK;
+}
+
+extern "C" {
+
+wxa_status wxa_wrap_and_classify(const wxa_particle_view* p, int64_t first, int64_t count, const double prob_lo[3],
+                                 const double prob_hi[3], const int periodic[3], const double brick_lo[3],
+                                 const double brick_hi[3], const int split[3], int32_t* lists, int64_t capacity,
+                                 int64_t counts[6], wxa_workspace* ws, void* stream) {
+    return wrap_and_classify_impl<false>(p, first, count, prob_lo, prob_hi, periodic, brick_lo, brick_hi, split, lists,
+                                         capacity, counts, ws, stream);
+}
+
+wxa_status wxa_wrap_and_classify_dest(const wxa_particle_view* p, int64_t first, int64_t count, const double prob_lo[3],
+                                      const double prob_hi[3], const int periodic[3], const double brick_lo[3],
+                                      const double brick_hi[3], const int split[3], int32_t* lists, int64_t capacity,
+                                      int64_t counts[27], wxa_workspace* ws, void* stream) {
+    return wrap_and_classify_impl<true>(p, first, count, prob_lo, prob_hi, periodic, brick_lo, brick_hi, split, lists,
+                                        capacity, counts, ws, stream);
 }
 
 wxa_status wxa_pack_leavers(const wxa_particle_view* p, const int32_t* list, int64_t n, void* msg, int64_t row_len,
@@ -1043,7 +1077,7 @@ wxa_status wxa_add_plasma(const wxa_particle_view* dst, const wxa_plasma_injecto
     }
     hipStream_t st = (hipStream_t)stream;
     wxa_status rc;
-    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
     unsigned long long* dcount = (unsigned long long*)((unsigned*)ws->counters.p + 56);   // 0: deposit, 16: gather, 32: classify, 48: walls
     WXA_HIP_CHECK(hipMemsetAsync(dcount, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(add_plasma_kernel, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, st, make_pv(*dst), ig, npoints,
@@ -1105,7 +1139,7 @@ wxa_status wxa_apply_particle_boundaries(const wxa_particle_view* p, const doubl
     WXA_REQUIRE(p->idcpu, "idcpu is needed to retire absorbed particles");
     hipStream_t st = (hipStream_t)stream;
     wxa_status rc;
-    if ((rc = ws->counters.reserve(256)) != WXA_OK) return rc;
+    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
     unsigned* dcount = (unsigned*)ws->counters.p + 48;
     WXA_HIP_CHECK(hipMemsetAsync(dcount, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(particle_walls_kernel, dim3(blocks_for(p->np)), dim3(256), 0, st, make_pv(*p), wg, dcount);

@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 namespace wxa {
@@ -40,9 +41,8 @@ struct RcclApi {
 
 static RcclApi* rccl_api() {
     static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         // a copy that the process already holds (PyTorch ships its own librccl.so) is reused by the loader
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names)
@@ -62,7 +62,7 @@ static RcclApi* rccl_api() {
                 api.dl = nullptr;
             }
         }
-    }
+    });
     return api.dl ? &api : nullptr;
 }
 
@@ -71,13 +71,16 @@ struct RcclCtx {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool loopback = false;        // test mode: messages to this rank go through ncclSend / ncclRecv too
-    hipStream_t cstream = nullptr;   // count exchanges: their own stream, they never queue behind the kernels
+    hipStream_t cstream = nullptr;   // count exchanges: their own stream -- the host waits for these 8-byte messages only,
+                                     // not for the kernels of the main stream (RCCL still runs the operations of one
+                                     // communicator in posting order: they follow the data exchanges posted before them)
     int64_t* dcounts = nullptr;      // device staging, 2 x kMaxMsg
     int64_t* hcounts = nullptr;      // pinned host staging, 2 x kMaxMsg
     // statistics (wxa_rccl_comm_stats)
     int64_t n_exchanges = 0, n_messages = 0, bytes_sent = 0, n_count_exchanges = 0;
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per exchange while timing is on
+    bool timing = false;       // wxa_rccl_comm_set_timing: a pair of events around every exchange (diagnostic runs only)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded pairs, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;     // read pairs, ready for reuse (no event creation per exchange)
     double timed_ms = 0.0;
     int64_t timed_exchanges = 0;
 };
@@ -89,6 +92,18 @@ constexpr int kMaxMsg = 32;
         if (_r != 0) {                                                                             \
             set_last_error("%s failed: %s", #expr,                                                 \
                            (ctx)->api->GetErrorString ? (ctx)->api->GetErrorString(_r) : "RCCL error"); \
+            return -1;                                                                             \
+        }                                                                                          \
+    } while (0)
+// inside ncclGroupStart .. ncclGroupEnd: leave the group before returning, or every later call of this thread would
+// be queued into it
+#define WXA_NCCL_IN_GROUP(ctx, expr)                                                               \
+    do {                                                                                           \
+        const ncclResult_t _r = (expr);                                                            \
+        if (_r != 0) {                                                                             \
+            set_last_error("%s failed: %s", #expr,                                                 \
+                           (ctx)->api->GetErrorString ? (ctx)->api->GetErrorString(_r) : "RCCL error"); \
+            (void)(ctx)->api->GroupEnd();                                                          \
             return -1;                                                                             \
         }                                                                                          \
     } while (0)
@@ -108,10 +123,14 @@ static void drain_events(RcclCtx* c) {
             c->timed_ms += ms;
             c->timed_exchanges += 1;
         }
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+        c->pool.push_back(ev);
     }
     c->events.clear();
+}
+static void destroy_events(RcclCtx* c) {
+    drain_events(c);
+    for (auto& ev : c->pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    c->pool.clear();
 }
 
 // nmsg sends + nmsg receives of device buffers, enqueued on `stream`; returns as soon as they are enqueued
@@ -121,9 +140,14 @@ static int rccl_exchange(void* vctx, int nmsg, const int32_t* send_peer, void* c
     hipStream_t st = (hipStream_t)vstream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
-        if (c->events.size() >= 4096) drain_events(c);
-        WXA_HIP_RC(hipEventCreate(&e0));
-        WXA_HIP_RC(hipEventCreate(&e1));
+        if (c->pool.empty() && c->events.size() >= 4096) drain_events(c);   // (a host wait: timing runs only)
+        if (!c->pool.empty()) {
+            e0 = c->pool.back().first; e1 = c->pool.back().second;
+            c->pool.pop_back();
+        } else {
+            WXA_HIP_RC(hipEventCreate(&e0));
+            WXA_HIP_RC(hipEventCreate(&e1));
+        }
         WXA_HIP_RC(hipEventRecord(e0, st));
     }
     // messages to this rank itself (a direction of one brick handled by the caller never gets here; this is the
@@ -149,14 +173,14 @@ static int rccl_exchange(void* vctx, int nmsg, const int32_t* send_peer, void* c
         WXA_NCCL(c, c->api->GroupStart());
         for (int i = 0; i < nmsg; ++i) {
             if ((c->loopback || send_peer[i] != c->rank) && send_bytes[i] > 0) {
-                WXA_NCCL(c, c->api->Send(send_buf[i], (size_t)send_bytes[i], kNcclChar, send_peer[i], c->comm, st));
+                WXA_NCCL_IN_GROUP(c, c->api->Send(send_buf[i], (size_t)send_bytes[i], kNcclChar, send_peer[i], c->comm, st));
                 c->bytes_sent += send_bytes[i];
                 c->n_messages += 1;
             }
         }
         for (int i = 0; i < nmsg; ++i) {
             if ((c->loopback || recv_peer[i] != c->rank) && recv_bytes[i] > 0)
-                WXA_NCCL(c, c->api->Recv(recv_buf[i], (size_t)recv_bytes[i], kNcclChar, recv_peer[i], c->comm, st));
+                WXA_NCCL_IN_GROUP(c, c->api->Recv(recv_buf[i], (size_t)recv_bytes[i], kNcclChar, recv_peer[i], c->comm, st));
         }
         WXA_NCCL(c, c->api->GroupEnd());
     }
@@ -189,10 +213,10 @@ static int rccl_exchange_counts(void* vctx, int nmsg, const int32_t* send_peer, 
     WXA_NCCL(c, c->api->GroupStart());
     for (int i = 0; i < nmsg; ++i)
         if (c->loopback || send_peer[i] != c->rank)
-            WXA_NCCL(c, c->api->Send(c->dcounts + i, sizeof(int64_t), kNcclChar, send_peer[i], c->comm, c->cstream));
+            WXA_NCCL_IN_GROUP(c, c->api->Send(c->dcounts + i, sizeof(int64_t), kNcclChar, send_peer[i], c->comm, c->cstream));
     for (int i = 0; i < nmsg; ++i)
         if (c->loopback || recv_peer[i] != c->rank)
-            WXA_NCCL(c, c->api->Recv(c->dcounts + kMaxMsg + i, sizeof(int64_t), kNcclChar, recv_peer[i], c->comm, c->cstream));
+            WXA_NCCL_IN_GROUP(c, c->api->Recv(c->dcounts + kMaxMsg + i, sizeof(int64_t), kNcclChar, recv_peer[i], c->comm, c->cstream));
     WXA_NCCL(c, c->api->GroupEnd());
     WXA_HIP_RC(hipMemcpyAsync(c->hcounts + kMaxMsg, c->dcounts + kMaxMsg, sizeof(int64_t) * nmsg, hipMemcpyDeviceToHost,
                               c->cstream));
@@ -252,6 +276,11 @@ wxa_status wxa_rccl_comm_create(const char id[WXA_RCCL_ID_BYTES], int32_t rank, 
         hipMalloc((void**)&c->dcounts, sizeof(int64_t) * 2 * kMaxMsg) != hipSuccess ||
         hipHostMalloc((void**)&c->hcounts, sizeof(int64_t) * 2 * kMaxMsg) != hipSuccess) {
         set_last_error("wxa_rccl_comm_create: staging allocation failed");
+        if (c->cstream) (void)hipStreamDestroy(c->cstream);
+        if (c->dcounts) (void)hipFree(c->dcounts);
+        if (c->hcounts) (void)hipHostFree(c->hcounts);
+        (void)api->CommDestroy(c->comm);
+        delete c;
         return WXA_ERR_NOMEM;
     }
     out->ctx = c;
@@ -265,13 +294,21 @@ wxa_status wxa_rccl_comm_create(const char id[WXA_RCCL_ID_BYTES], int32_t rank, 
 void wxa_rccl_comm_destroy(wxa_comm* comm) {
     if (!comm || !comm->ctx || comm->exchange != rccl_exchange) return;
     RcclCtx* c = static_cast<RcclCtx*>(comm->ctx);
-    drain_events(c);
+    destroy_events(c);
     if (c->cstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream); }
     if (c->dcounts) (void)hipFree(c->dcounts);
     if (c->hcounts) (void)hipHostFree(c->hcounts);
     if (c->comm) c->api->CommDestroy(c->comm);
     delete c;
     comm->ctx = nullptr;
+}
+
+wxa_status wxa_rccl_comm_set_timing(wxa_comm* comm, int32_t on) {
+    WXA_REQUIRE(comm && comm->ctx && comm->exchange == rccl_exchange, "not an RCCL transport");
+    RcclCtx* c = static_cast<RcclCtx*>(comm->ctx);
+    if (!on) drain_events(c);
+    c->timing = on != 0;
+    return WXA_OK;
 }
 
 wxa_status wxa_rccl_comm_stats(wxa_comm* comm, wxa_rccl_stats* out, int32_t reset) {

@@ -121,17 +121,25 @@ class TorchBrickTransport:
                     assert rp == self.rank and rn == sn
                     if sn:
                         _as_tensor(rb, rn, self.on_device).copy_(_as_tensor(sb, sn, self.on_device))
+            # tag = ordinal of the message among those of the same peer: the k-th send to a peer pairs with that peer's
+            # k-th receive from here -- RCCL's own matching rule (posting order per peer pair), which is what the callers
+            # rely on; gloo matches by tag.  (Zero-length messages are skipped on both sides but still counted.)
+            nth = {}
             for (sp, sb, sn, i) in sends:
+                k = nth.get(("s", sp), 0)
+                nth[("s", sp)] = k + 1
                 if sp != self.rank and sn > 0:
                     t = _as_tensor(sb, sn, self.on_device)
                     keep.append(t)
-                    ops.append(dist.P2POp(dist.isend, t, sp, self.group, tag=i))
+                    ops.append(dist.P2POp(dist.isend, t, sp, self.group, tag=k))
                     self.bytes_sent += sn
             for (rp, rb, rn, i) in recvs:
+                k = nth.get(("r", rp), 0)
+                nth[("r", rp)] = k + 1
                 if rp != self.rank and rn > 0:
                     t = _as_tensor(rb, rn, self.on_device)
                     keep.append(t)
-                    ops.append(dist.P2POp(dist.irecv, t, rp, self.group, tag=i))
+                    ops.append(dist.P2POp(dist.irecv, t, rp, self.group, tag=k))
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
@@ -156,15 +164,20 @@ class TorchBrickTransport:
             # (the only synchronisation) after the batch
             sbuf = torch.tensor([int(send_val[i]) for i in range(nmsg)], dtype=torch.int64).to(dev)
             rbuf = torch.zeros(nmsg, dtype=torch.int64, device=dev)
+            nth = {}   # tags: ordinal per peer, as in _exchange
             for i in range(nmsg):
                 sp = int(send_peer[i])
+                k = nth.get(("s", sp), 0)
+                nth[("s", sp)] = k + 1
                 if sp != self.rank:
-                    ops.append(dist.P2POp(dist.isend, sbuf[i:i + 1], sp, self.group, tag=100 + i))
+                    ops.append(dist.P2POp(dist.isend, sbuf[i:i + 1], sp, self.group, tag=100 + k))
             for i in range(nmsg):
                 rp = int(recv_peer[i])
+                k = nth.get(("r", rp), 0)
+                nth[("r", rp)] = k + 1
                 if rp != self.rank:
                     outs.append(i)
-                    ops.append(dist.P2POp(dist.irecv, rbuf[i:i + 1], rp, self.group, tag=100 + i))
+                    ops.append(dist.P2POp(dist.irecv, rbuf[i:i + 1], rp, self.group, tag=100 + k))
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
@@ -237,6 +250,11 @@ class RcclBrickTransport:
         st = _capi.RcclStats()
         self.lib.rccl_comm_stats(C.byref(self.comm), C.byref(st), 1 if reset else 0)
         return {k: getattr(st, k) for k, _ in _capi.RcclStats._fields_}
+
+    def set_timing(self, on: bool):
+        """A pair of HIP events around every exchange (stats()["timed_ms"]): diagnostic passes only -- reading the
+        events waits on the host."""
+        self.lib.rccl_comm_set_timing(C.byref(self.comm), 1 if on else 0)
 
     @property
     def n_exchanges(self):
