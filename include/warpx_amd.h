@@ -408,6 +408,22 @@ wxa_status wxa_apply_pec_rho(const wxa_field_view* rho, const int32_t dom_lo[3],
 wxa_status wxa_filter_bilinear(const wxa_field_view* src, const wxa_field_view* dst,
                                void* stream);
 
+/* Filter::ApplyStencil -> Filter::DoFilter for any symmetric stencil (Source/Filter/Filter.cpp:92-133): s0, s1, s2 are
+ * the half stencils per direction as the reference stores them (entry 0 pre-halved), n0, n1, n2 <= 8 their lengths.
+ * dst = filtered src over the whole allocated box, zero padding beyond it; src and dst must not alias.  Used for the
+ * NCI corrector (NCIGodfreyFilter, lengths 1, 1, 5): PhysicalParticleContainer::applyNCIFilter filters E and B into
+ * temporaries before the gather (Source/Particles/PhysicalParticleContainer.cpp:1900-1911, 2097-2172). */
+wxa_status wxa_filter_stencil(const wxa_field_view* src, const wxa_field_view* dst, const double* s0, int32_t n0,
+                              const double* s1, int32_t n1, const double* s2, int32_t n2, void* stream);
+
+/* NCIGodfreyFilter::ComputeStencils (Source/Filter/NCIGodfreyFilter.cpp:45-154): the five z coefficients of the
+ * Godfrey filter for c dt / dz = cdtodz, interpolated from the fitted tables of Source/Utils/NCIGodfreyTables.H
+ * (coeff_set 0: Ex, Ey, Bz; 1: Bx, By, Ez; nodal_gather != 0: the momentum-conserving tables), entry 0 pre-halved as
+ * Filter::DoFilter expects; the x and y stencils are {0.5}.  Host function. */
+#define WXA_NCI_EX_EY_BZ 0
+#define WXA_NCI_BX_BY_EZ 1
+wxa_status wxa_nci_godfrey_stencil(double cdtodz, int32_t nodal_gather, int32_t coeff_set, double stencil_z[5]);
+
 /* Single-brick periodic FillBoundary: guard points within ng of the valid box
  * take the value of their periodic image (amrex FabArray::FillBoundary with
  * geom.periodicity(); Source/ablastr/utils/Communication.cpp:71-115 called
@@ -485,6 +501,9 @@ typedef struct wxa_sim_config {
                                     applies ConvertLabParamsToBoost, WarpXUtil.cpp:180-262); the value reaches the
                                     injection (MapParticletoBoostedFrame, the boosted branch of AddPlasma), the
                                     injection position of the moving window and the repeated plasma lens          */
+    int32_t use_fdtd_nci_corr;   /* particles.use_fdtd_nci_corr (WarpX::use_fdtd_nci_corr, MultiParticleContainer.cpp:327): the
+                                    NCI corrector of the boosted-frame runs -- E and B are filtered along z with the Godfrey
+                                    stencil before every species' gather (applyNCIFilter), E/B carry 4 more guard cells in z */
 } wxa_sim_config;
 
 /* ---- second "next" row: moving window, continuous plasma injection, laser antenna -----------------

@@ -8,6 +8,7 @@
 // (3) the diagnostics formulas that define the parity metric and the golden
 // checksums (FieldEnergy, ParticleEnergy, ParticleMomentum, cell-centred sum|Q|).
 #include "pic_kernels.hpp"
+#include "nci_godfrey_tables.hpp"
 
 #include <climits>
 #include <complex>
@@ -577,6 +578,57 @@ int orc_filter_bilinear(const wxa_field_view* src, const wxa_field_view* dst, vo
                         }
                 d(i, j, k) = acc;
             }
+    return 0;
+}
+
+// Filter::DoFilter (Source/Filter/Filter.cpp:92-133) for any stencil lengths (the NCI corrector's filter has 1, 1, 5)
+int orc_filter_stencil(const wxa_field_view* src, const wxa_field_view* dst, const double* s0, int32_t n0,
+                       const double* s1, int32_t n1, const double* s2, int32_t n2, void*) {
+    const Arr s(*src), d(*dst);
+    const int lo0 = src->lo[0], lo1 = src->lo[1], lo2 = src->lo[2];
+    const int hi0 = lo0 + src->n[0], hi1 = lo1 + src->n[1], hi2 = lo2 + src->n[2];
+    auto zp = [&](int i, int j, int k) -> double {   // src_zeropad (:111-114)
+        return (i >= lo0 && i < hi0 && j >= lo1 && j < hi1 && k >= lo2 && k < hi2) ? s(i, j, k) : 0.0;
+    };
+#pragma omp parallel for collapse(2)
+    for (int k = lo2; k < hi2; ++k)
+        for (int j = lo1; j < hi1; ++j)
+            for (int i = lo0; i < hi0; ++i) {
+                double acc = 0.0;
+                for (int i2 = 0; i2 < n2; ++i2)
+                    for (int i1 = 0; i1 < n1; ++i1)
+                        for (int i0 = 0; i0 < n0; ++i0) {
+                            const double sss = s0[i0] * s1[i1] * s2[i2];
+                            acc += sss * (zp(i - i0, j - i1, k - i2) + zp(i + i0, j - i1, k - i2) +
+                                          zp(i - i0, j + i1, k - i2) + zp(i + i0, j + i1, k - i2) +
+                                          zp(i - i0, j - i1, k + i2) + zp(i + i0, j - i1, k + i2) +
+                                          zp(i - i0, j + i1, k + i2) + zp(i + i0, j + i1, k + i2));
+                        }
+                d(i, j, k) = acc;
+            }
+    return 0;
+}
+
+// NCIGodfreyFilter::ComputeStencils (Source/Filter/NCIGodfreyFilter.cpp:45-154); the coefficient tables are the data
+// file the product ships too (generated from Source/Utils/NCIGodfreyTables.H, pinned against it by
+// tests/test_nci_cpu.py where the reference is on disk)
+int orc_nci_godfrey_stencil(double cdtodz, int32_t nodal_gather, int32_t coeff_set, double stencil_z[5]) {
+    using namespace orc_nci_godfrey;
+    if (coeff_set != 0 && coeff_set != 1) return -1;
+    int index = static_cast<int>(tab_length * cdtodz);                     // :57
+    index = std::min(index, tab_length - 2);                               // :58
+    index = std::max(index, 0);                                            // :59
+    const double weight_right = cdtodz - double(index) / double(tab_length);   // :60
+    const double* tab = tables + (size_t)((nodal_gather ? 2 : 0) + coeff_set) * tab_length * tab_width;
+    double pre[4];
+    for (int i = 0; i < tab_width; i++)                                    // :66-98
+        pre[i] = (1. - weight_right) * tab[index * tab_width + i] + weight_right * tab[(index + 1) * tab_width + i];
+    stencil_z[0] = (256 + 128 * pre[0] + 96 * pre[1] + 80 * pre[2] + 70 * pre[3]) / 256;   // :101-105
+    stencil_z[1] = -(64 * pre[0] + 64 * pre[1] + 60 * pre[2] + 56 * pre[3]) / 256;
+    stencil_z[2] = (16 * pre[1] + 24 * pre[2] + 28 * pre[3]) / 256;
+    stencil_z[3] = -(4 * pre[2] + 8 * pre[3]) / 256;
+    stencil_z[4] = (1 * pre[3]) / 256;
+    stencil_z[0] /= 2.;                                                    // :126
     return 0;
 }
 
@@ -1357,6 +1409,9 @@ struct orc_sim {
     double ckc_x[5] = {0}, ckc_y[5] = {0}, ckc_z[5] = {0};   // algo.maxwell_solver = ckc
     int ng_EB[3], ng_J[3], ng_depos_J[3], ng_gather[3], ng_solver[3], ng_rho[3];
     Field E[3], B[3], J[3], Jtmp, rho;
+    // particles.use_fdtd_nci_corr (WarpX::InitNCICorrector, WarpXInitData.cpp:858-890): filtered copies of E and B
+    Field nciE[3], nciB[3];
+    double nci_exeybz[5] = {0.5, 0, 0, 0, 0}, nci_bxbyez[5] = {0.5, 0, 0, 0, 0};
     std::vector<std::unique_ptr<Species>> species;
     bool is_synchronized = true;
     int64_t istep = 0;
@@ -1595,7 +1650,22 @@ void one_step_nosub(orc_sim* s) {
         wxa_particle_view p = sp->view();
         {   // PhysicalParticleContainer::Evolve :1961 PushPX
             Tic t(s, 0);
-            orc_gather_push_ext(&p, s->Ev, s->Bv, &gEB, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
+            const wxa_field_view* Eg = s->Ev;
+            const wxa_field_view* Bg = s->Bv;
+            wxa_field_view Ef[3], Bf[3];
+            if (s->cfg.use_fdtd_nci_corr) {
+                // :1900-1911 applyNCIFilter (:2097-2172): Ex, Ey, Bz with one stencil, Bx, By, Ez with the other, along z
+                const double half[1] = {0.5};
+                for (int c = 0; c < 3; ++c) { Ef[c] = s->nciE[c].v; Bf[c] = s->nciB[c].v; }
+                orc_filter_stencil(&s->Ev[0], &Ef[0], half, 1, half, 1, s->nci_exeybz, 5, nullptr);
+                orc_filter_stencil(&s->Ev[2], &Ef[2], half, 1, half, 1, s->nci_bxbyez, 5, nullptr);
+                orc_filter_stencil(&s->Bv[1], &Bf[1], half, 1, half, 1, s->nci_bxbyez, 5, nullptr);
+                orc_filter_stencil(&s->Ev[1], &Ef[1], half, 1, half, 1, s->nci_exeybz, 5, nullptr);
+                orc_filter_stencil(&s->Bv[0], &Bf[0], half, 1, half, 1, s->nci_bxbyez, 5, nullptr);
+                orc_filter_stencil(&s->Bv[2], &Bf[2], half, 1, half, 1, s->nci_exeybz, 5, nullptr);
+                Eg = Ef; Bg = Bf;
+            }
+            orc_gather_push_ext(&p, Eg, Bg, &gEB, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
                                 sp->do_crr ? WXA_PUSHER_BORIS_RR : s->cfg.particle_pusher, /*move=*/1, sp->ext_eb);
         }
         {   // :2029-2038 DepositCurrent with relative_time = -0.5*dt
@@ -1686,7 +1756,13 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
         s->ng_depos_J[d] = ngJ;
         s->ng_J[d] = ngJ + (cfg->use_filter ? 1 : 0);
         s->ng_rho[d] = ngt + 1 + (int)std::ceil(PhysConst::c * s->dt / dx[d]);
-        s->ng_gather[d] = (nox + 1) / 2;
+        s->ng_gather[d] = std::min((nox + 1) / 2, s->ng_EB[d]);   // ng_FieldGather_noNCI (:314-316)
+        if (d == 2 && cfg->use_fdtd_nci_corr) {
+            // GuardCellManager.cpp:87-89: E and B carry the NCI stencil's cells in z; :319-325 the gather-depth exchange too
+            const int ng = ngt + 4;   // NCIGodfreyFilter::m_stencil_width
+            s->ng_EB[d] = (ng % 2) ? ng + 1 : ng;
+            s->ng_gather[d] = std::min(s->ng_gather[d] + 4, s->ng_EB[d]);
+        }
         s->ng_solver[d] = 1;
         // GuardCellManager.cpp:338: ng_FieldGather = max(ng_FieldGather, ng_FieldSolver)
         s->ng_gather[d] = std::max(s->ng_gather[d], s->ng_solver[d]);
@@ -1732,6 +1808,16 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
         s->B[c].alloc(cfg->n_cell, Bs[c], s->ng_EB);
         s->J[c].alloc(cfg->n_cell, Es[c], s->ng_J);
         s->Ev[c] = s->E[c].v; s->Bv[c] = s->B[c].v; s->Jv[c] = s->J[c].v;
+    }
+    if (cfg->use_fdtd_nci_corr) {
+        // WarpX::InitNCICorrector: cdtodz = c dt / dz, Galerkin tables unless the gather is nodal (:872-886)
+        const double cdtodz = PhysConst::c * s->dt / s->dx[2];
+        orc_nci_godfrey_stencil(cdtodz, s->cfg.galerkin ? 0 : 1, 0, s->nci_exeybz);
+        orc_nci_godfrey_stencil(cdtodz, s->cfg.galerkin ? 0 : 1, 1, s->nci_bxbyez);
+        for (int c = 0; c < 3; ++c) {
+            s->nciE[c].alloc(cfg->n_cell, Es[c], s->ng_EB);
+            s->nciB[c].alloc(cfg->n_cell, Bs[c], s->ng_EB);
+        }
     }
     const int nodal[3] = {1, 1, 1};
     s->rho.alloc(cfg->n_cell, nodal, s->ng_rho);

@@ -144,6 +144,36 @@ def test_filter_bit_exact(oracle, product):
         product.filter_bilinear(C.byref(srcd.view), C.byref(srcd.view), None)
 
 
+@pytest.mark.parametrize("name,lens", [("Ex", (1, 1, 5)), ("Bz", (1, 1, 5)), ("Ey", (2, 2, 2)), ("Bx", (3, 1, 4))])
+def test_filter_stencil_bit_exact(oracle, product, name, lens):
+    """wxa_filter_stencil (Filter::DoFilter with any half stencils): the NCI corrector's 1 x 1 x 5 Godfrey stencil from
+    wxa_nci_godfrey_stencil, the bilinear filter's 2 x 2 x 2 through the generic kernel, and an odd mix -- bit for bit
+    against the CPU restatement (same loop and term order, no contraction)."""
+    (src,) = H.random_fields((name,), (20, 12, 28), 4, 51)
+    dst = src.like()
+    srcd, dstd = src.copy_to(DEV, True), src.like(DEV, True)
+    rng = np.random.default_rng(3)
+    st = []
+    for d in range(3):
+        if lens == (1, 1, 5) and d == 2:
+            z = (C.c_double * 5)()
+            product.nci_godfrey_stencil(0.577, 0, 0 if name == "Ex" else 1, z)
+            zo = (C.c_double * 5)()
+            oracle.nci_godfrey_stencil(0.577, 0, 0 if name == "Ex" else 1, zo)
+            assert list(z) == list(zo)
+            st.append(z)
+        elif lens[d] == 1:
+            st.append((C.c_double * 1)(0.5))
+        else:
+            st.append((C.c_double * lens[d])(*rng.random(lens[d])))
+    oracle.filter_stencil(C.byref(src.view), C.byref(dst.view), st[0], lens[0], st[1], lens[1], st[2], lens[2], None)
+    product.filter_stencil(C.byref(srcd.view), C.byref(dstd.view), st[0], lens[0], st[1], lens[1], st[2], lens[2], None)
+    _sync(product)
+    assert np.array_equal(dstd.to_numpy(), dst.to_numpy())
+    with pytest.raises(_capi.WxaError):
+        product.filter_stencil(C.byref(srcd.view), C.byref(srcd.view), st[0], lens[0], st[1], lens[1], st[2], lens[2], None)
+
+
 @pytest.mark.parametrize("name", ["Ex", "By", "rho"])
 @pytest.mark.parametrize("ng_fill", [1, 2, 4])
 def test_fill_boundary_bit_exact(oracle, product, name, ng_fill):

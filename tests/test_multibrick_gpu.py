@@ -48,13 +48,20 @@ class ThreadBrickTransport:
             import torch
             H.device_sync()
             box = self.shared["box"]
+            # the k-th message to a peer pairs with that peer's k-th receive from here (RCCL's matching rule, which the
+            # host layer relies on: posting order per peer pair)
+            nth = {}
             for i in range(nmsg):
                 n = int(send_bytes[i])
-                box[(self.rank, int(send_peer[i]), i)] = _as_tensor(send_buf[i], n, H.ON_GPU).clone() if n else None
+                k = nth.get(("s", int(send_peer[i])), 0)
+                nth[("s", int(send_peer[i]))] = k + 1
+                box[(self.rank, int(send_peer[i]), k)] = _as_tensor(send_buf[i], n, H.ON_GPU).clone() if n else None
             self._wait()
             for i in range(nmsg):
                 n = int(recv_bytes[i])
-                t = box[(int(recv_peer[i]), self.rank, i)]
+                k = nth.get(("r", int(recv_peer[i])), 0)
+                nth[("r", int(recv_peer[i]))] = k + 1
+                t = box[(int(recv_peer[i]), self.rank, k)]
                 assert (t.numel() if t is not None else 0) == n
                 if n:
                     _as_tensor(recv_buf[i], n, H.ON_GPU).copy_(t)
@@ -70,11 +77,16 @@ class ThreadBrickTransport:
     def _exchange_counts(self, ctx, nmsg, send_peer, send_val, recv_peer, recv_val):
         try:
             box = self.shared["cbox"]
+            nth = {}
             for i in range(nmsg):
-                box[(self.rank, int(send_peer[i]), i)] = int(send_val[i])
+                k = nth.get(("s", int(send_peer[i])), 0)
+                nth[("s", int(send_peer[i]))] = k + 1
+                box[(self.rank, int(send_peer[i]), k)] = int(send_val[i])
             self._wait()
             for i in range(nmsg):
-                recv_val[i] = box[(int(recv_peer[i]), self.rank, i)]
+                k = nth.get(("r", int(recv_peer[i])), 0)
+                nth[("r", int(recv_peer[i]))] = k + 1
+                recv_val[i] = box[(int(recv_peer[i]), self.rank, k)]
             self._wait()
             return 0
         except Exception as e:

@@ -560,6 +560,32 @@ def test_ckc_uniform_plasma_parity(oracle, product, order, filt):
         assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), name
 
 
+def test_nci_corrector_step_parity(oracle, product):
+    """particles.use_fdtd_nci_corr = 1 on the HIP path (E and B filtered along z with the Godfrey stencil before the
+    gather, four more guard cells in z: applyNCIFilter, PhysicalParticleContainer.cpp:2097-2172) against the oracle
+    stepper: a plasma drifting relativistically along z, CKC + Vay as in the reference's boosted example, order 3,
+    bilinear filter, 10 steps with two sorts -- the 1e-10 gate of the other step tests, fields point-wise at 1e-9."""
+    n_cell = (16, 16, 32)
+    L3 = (8e-6, 8e-6, 16e-6)
+    lo, hi = tuple(-v for v in L3), L3
+    parts = plasma.uniform_plasma(n_cell, lo, hi, (1, 1, 2), 1e25, 0.02, seed=78)
+    parts[6] = parts[6] + 2.0 * plasma.C_LIGHT
+    kw = dict(nox=3, galerkin=1, particle_pusher=_capi.PUSHER_VAY, use_filter=1, sort_interval=4,
+              maxwell_solver=_capi.SOLVER_CKC, cfl=0.98, use_fdtd_nci_corr=1)
+    out = []
+    for lib in (oracle, product):
+        sim = WarpXSim(lib, n_cell, lo, hi, **kw)
+        ids = [sim.add_species(-plasma.Q_E, plasma.M_E, [p.copy() for p in parts])]
+        sim.evolve(10)
+        out.append((sim, ids))
+    (so, io), (sg, ig) = out
+    assert tuple(sg.field_view("Ex").ng) == (4, 4, 8)
+    _compare(_metrics(sg, ig), _metrics(so, io))
+    for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz"):
+        a, b = sg.field_valid(name), so.field_valid(name)
+        assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), name
+
+
 def test_plotfile_from_the_hip_path(product, tmp_path):
     """wxa_sim_write_plotfile on the HIP path: the AMReX plotfile (FlushFormatPlotfile's output) of the Langmuir deck after
     40 steps, parsed back from the files, carries the reference's golden checksums at the reference's tolerance."""

@@ -70,6 +70,7 @@ class SimConfig(C.Structure):
         ("grid_type", C.c_int32),
         ("maxwell_solver", C.c_int32),
         ("gamma_boost", C.c_double),
+        ("use_fdtd_nci_corr", C.c_int32),
     ]
 
 
@@ -178,6 +179,9 @@ _KERNEL_SIGS = {
     "shift_field_window": (C.c_int, [_PFV, C.c_void_p, C.c_int32, C.c_int32, _I3, C.c_void_p]),
     "laser_push": (C.c_int, [_PPV, C.POINTER(LaserPushParams), C.c_double, C.c_double, C.c_void_p]),
     "filter_bilinear": (C.c_int, [_PFV, _PFV, C.c_void_p]),
+    "filter_stencil": (C.c_int, [_PFV, _PFV, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32,
+                                 C.POINTER(C.c_double), C.c_int32, C.c_void_p]),
+    "nci_godfrey_stencil": (C.c_int, [C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "fill_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
     "sum_boundary_periodic": (C.c_int, [_PFV, _I3, _I3, C.c_void_p]),
     "sync_nodal_periodic": (C.c_int, [_PFV, _I3, C.c_void_p]),

@@ -618,6 +618,40 @@ using Ckc5 = CkcCfg<8, 8, 1>;
 // component at 256^3 + guards.)
 using FilterCfg = CkcCfg<8, 16, 1>;
 
+// Filter::DoFilter (Source/Filter/Filter.cpp:92-133) for any stencil lengths: the filter that the NCI corrector applies to
+// E and B before the gather (NCIGodfreyFilter: lengths 1, 1, 5, along z only; PhysicalParticleContainer::applyNCIFilter,
+// PhysicalParticleContainer.cpp:2097-2172).  One lane per point over the whole allocation, zero padding beyond it, the
+// reference's loop and term order (sss = s0 s1 s2; eight mirrored taps summed left to right) -> bit-identical to the
+// CPU path.  Six fields per species and step in the boosted-frame runs only: not tiled.
+struct FilterStencils {
+    static constexpr int MAXLEN = 8;
+    double s[3][MAXLEN];
+    int n[3];
+};
+__global__ void __launch_bounds__(256)
+filter_stencil_kernel(DevF src, DevF dst, FilterStencils fs) {
+    const long total = (long)src.n0 * src.n1 * src.n2;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int i = src.lo0 + (int)(t % src.n0);
+        const int j = src.lo1 + (int)((t / src.n0) % src.n1);
+        const int k = src.lo2 + (int)(t / ((long)src.n0 * src.n1));
+        auto zp = [&](int ii, int jj, int kk) -> double {
+            return (ii >= src.lo0 && ii < src.lo0 + src.n0 && jj >= src.lo1 && jj < src.lo1 + src.n1 && kk >= src.lo2 &&
+                    kk < src.lo2 + src.n2) ? src.p[src.off(ii, jj, kk)] : 0.0;
+        };
+        double d = 0.0;
+        for (int i2 = 0; i2 < fs.n[2]; ++i2)
+            for (int i1 = 0; i1 < fs.n[1]; ++i1)
+                for (int i0 = 0; i0 < fs.n[0]; ++i0) {
+                    const double sss = fs.s[0][i0] * fs.s[1][i1] * fs.s[2][i2];
+                    d += sss * (zp(i - i0, j - i1, k - i2) + zp(i + i0, j - i1, k - i2) + zp(i - i0, j + i1, k - i2) +
+                                zp(i + i0, j + i1, k - i2) + zp(i - i0, j - i1, k + i2) + zp(i + i0, j - i1, k + i2) +
+                                zp(i - i0, j + i1, k + i2) + zp(i + i0, j + i1, k + i2));
+                }
+        dst.p[dst.off(i, j, k)] = d;
+    }
+}
+
 template <class CFG>
 __global__ void __launch_bounds__(CFG::NT)
 filter_bilinear_kernel(DevF src, DevF dst, TileGrid tg) {
@@ -895,6 +929,27 @@ wxa_status wxa_filter_bilinear(const wxa_field_view* src, const wxa_field_view* 
     tg.ntiles = (long)tg.nti * tg.ntj * tg.ntk;
     hipLaunchKernelGGL(filter_bilinear_kernel<FilterCfg>, dim3((unsigned)xcd_grid_size(tg.ntiles)),
                        dim3(FilterCfg::TI, FilterCfg::TJ), 0, (hipStream_t)stream, make_devf(*src), make_devf(*dst), tg);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_filter_stencil(const wxa_field_view* src, const wxa_field_view* dst, const double* s0, int32_t n0,
+                              const double* s1, int32_t n1, const double* s2, int32_t n2, void* stream) {
+    WXA_REQUIRE(src && dst && view_ok(*src) && view_ok(*dst) && s0 && s1 && s2, "bad argument");
+    WXA_REQUIRE(src->p != dst->p, "src and dst must not alias");
+    WXA_REQUIRE(n0 >= 1 && n0 <= FilterStencils::MAXLEN && n1 >= 1 && n1 <= FilterStencils::MAXLEN && n2 >= 1 &&
+                n2 <= FilterStencils::MAXLEN, "stencil length");
+    for (int d = 0; d < 3; ++d)
+        WXA_REQUIRE(src->lo[d] == dst->lo[d] && src->n[d] == dst->n[d], "src/dst boxes differ");
+    FilterStencils fs;
+    fs.n[0] = n0; fs.n[1] = n1; fs.n[2] = n2;
+    for (int a = 0; a < FilterStencils::MAXLEN; ++a) {
+        fs.s[0][a] = a < n0 ? s0[a] : 0.0; fs.s[1][a] = a < n1 ? s1[a] : 0.0; fs.s[2][a] = a < n2 ? s2[a] : 0.0;
+    }
+    const long total = (long)src->n[0] * src->n[1] * src->n[2];
+    if (total == 0) return WXA_OK;
+    hipLaunchKernelGGL(filter_stencil_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(*src),
+                       make_devf(*dst), fs);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }

@@ -7,6 +7,7 @@
 #ifndef WXA_HOST_WARPX_HPP_
 #define WXA_HOST_WARPX_HPP_
 
+#include "NCIGodfreyFilter.hpp"
 #include "WarpXParticleContainer.hpp"
 
 namespace wxa::host {
@@ -16,11 +17,16 @@ struct guardCellManager {
     amrex::IntVect ng_alloc_EB, ng_alloc_J, ng_depos_J, ng_FieldSolver, ng_FieldGather, ng_UpdateAux;
 
     void Init(const amrex::Real dt, const std::array<amrex::Real, 3>& dx, const int nox, const bool use_filter,
-              const amrex::IntVect& bilinear_filter_stencil_length) {
+              const amrex::IntVect& bilinear_filter_stencil_length, const bool do_fdtd_nci_corr = false,
+              const int nci_corr_stencil = 0) {
         constexpr double c = 299'792'458.;
         for (int d = 0; d < 3; ++d) {
             const int ng_tmp = nox;                                   // :62-64 (no subcycling / MR)
             ng_alloc_EB[d] = (ng_tmp % 2) ? ng_tmp + 1 : ng_tmp;      // :83-85 always even
+            if (d == 2 && do_fdtd_nci_corr) {                         // :87-89 more guard cells in z for the NCI filter
+                const int ng = ng_tmp + nci_corr_stencil;
+                ng_alloc_EB[d] = (ng % 2) ? ng + 1 : ng;
+            }
             int ngJ = ng_tmp;                                         // :96-98
             ngJ += static_cast<int>(std::ceil(c * 0.5 * dt / dx[d])); // :161 half a step of motion
             ng_depos_J[d] = ngJ;                                      // :166
@@ -28,6 +34,13 @@ struct guardCellManager {
             ng_FieldSolver[d] = 1;                                    // :276-278 Yee: GetMaxGuardCell
             ng_FieldGather[d] = (nox + 1) / 2;                        // :314-316 (staggered, galerkin: +0)
             ng_UpdateAux[d] = 0;
+        }
+        {   // :315-325 ng_FieldGather_noNCI capped by the allocation, then the NCI filter's cells along z
+            const amrex::IntVect no_nci(std::min(ng_FieldGather[0], nox % 2 ? nox + 1 : nox),
+                                        std::min(ng_FieldGather[1], nox % 2 ? nox + 1 : nox),
+                                        std::min(ng_FieldGather[2], nox % 2 ? nox + 1 : nox));
+            ng_FieldGather = no_nci;
+            if (do_fdtd_nci_corr) ng_FieldGather[2] += nci_corr_stencil;   // NCIGodfreyFilter::m_stencil_width
         }
         ng_FieldGather = amrex::min(ng_FieldGather, ng_alloc_EB);     // :333
         for (int d = 0; d < 3; ++d) ng_FieldGather[d] = std::max(ng_FieldGather[d], ng_FieldSolver[d]);   // :338
@@ -134,7 +147,8 @@ public:
         ComputeDt();
         // warpx.use_filter: 1-pass bilinear, stencil length npass+1 = 2 (BilinearFilter.cpp:63-68)
         use_filter = cfg.use_filter != 0;
-        guard_cells.Init(dt[0], m_ctx.dx, cfg.nox, use_filter, amrex::IntVect(2));
+        guard_cells.Init(dt[0], m_ctx.dx, cfg.nox, use_filter, amrex::IntVect(2), cfg.use_fdtd_nci_corr != 0,
+                         NCIGodfreyFilter::m_stencil_width);   // Source/WarpX.cpp:2019-2025
         m_ctx.ng_alloc_EB = guard_cells.ng_alloc_EB;
         m_ctx.ng_depos_J = guard_cells.ng_depos_J;
         for (int d = 0; d < 3; ++d)
@@ -192,6 +206,7 @@ public:
             if (cfg.nbricks[d] == 1 && m_comm->periodic(d) &&
                 m_ctx.brick_box.length(d) < 2 * guard_cells.ng_alloc_J[d] + 1)
                 throw std::runtime_error("periodic direction shorter than twice the guard depth");
+        if (cfg.use_fdtd_nci_corr) InitNCICorrector(Etype, Btype);
         {   // the exchanges of the time loop: E + B together at any guard depth, J at its guard sum
             std::vector<amrex::MultiFab*> eb, jj;
             for (int d = 0; d < 3; ++d) {
@@ -205,6 +220,30 @@ public:
         m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, cfg.maxwell_solver, m_ctx.dx);
         sort_intervals = cfg.sort_interval;
         m_ctx.sort_intervals_on = sort_intervals > 0;
+    }
+
+    // WarpX::InitNCICorrector (Source/Initialization/WarpXInitData.cpp:858-890): the two Godfrey filters for
+    // c dt / dz, Galerkin tables unless the gather uses the same shape in every direction; plus the six arrays that
+    // receive the filtered fields (the reference's per-tile filtered_Ex ... filtered_Bz)
+    void InitNCICorrector(const amrex::IntVect (&Etype)[3], const amrex::IntVect (&Btype)[3]) {
+        constexpr double c = 299'792'458.;
+        const double cdtodz = c * dt[0] / m_ctx.dx[2];
+        const bool nodal_gather = !m_ctx.galerkin_interpolation;
+        nci_godfrey_filter_exeybz = std::make_unique<NCIGodfreyFilter>(godfrey_coeff_set::Ex_Ey_Bz, cdtodz, nodal_gather);
+        nci_godfrey_filter_bxbyez = std::make_unique<NCIGodfreyFilter>(godfrey_coeff_set::Bx_By_Ez, cdtodz, nodal_gather);
+        nci_godfrey_filter_exeybz->ComputeStencils();
+        nci_godfrey_filter_bxbyez->ComputeStencils();
+        for (int i = 0; i < 5; ++i) {
+            m_ctx.nci_stencil_exeybz[i] = nci_godfrey_filter_exeybz->stencil_z[i];
+            m_ctx.nci_stencil_bxbyez[i] = nci_godfrey_filter_bxbyez->stencil_z[i];
+        }
+        for (int d = 0; d < 3; ++d) {
+            m_nci_E[d] = std::make_unique<amrex::MultiFab>(m_be, m_ctx.brick_box, Etype[d], guard_cells.ng_alloc_EB);
+            m_nci_B[d] = std::make_unique<amrex::MultiFab>(m_be, m_ctx.brick_box, Btype[d], guard_cells.ng_alloc_EB);
+            m_ctx.nci_E[d] = m_nci_E[d].get();
+            m_ctx.nci_B[d] = m_nci_B[d].get();
+        }
+        m_ctx.use_fdtd_nci_corr = true;
     }
 
     // Source/Evolve/WarpXComputeDt.cpp:41-102 with CartesianYeeAlgorithm::ComputeMaxDt (:48-56) or
@@ -373,7 +412,8 @@ public:
         // short sort intervals only (a particle moves < 1 cell per step)
         if (want && !(m_cfg.sort_interval > 0 && m_cfg.sort_interval <= 4))
             throw std::runtime_error("overlap_halo needs 0 < warpx.sort_intervals <= 4 (interior tiles must stay clear of the guards)");
-        if (!want || !m_grown_b || !any_split || !m_be->stream_create) return;
+        // with the NCI corrector the gather reads filtered copies that need the guards along z filled first
+        if (!want || !m_grown_b || !any_split || !m_be->stream_create || m_cfg.use_fdtd_nci_corr) return;
         m_comm_stream = m_be->stream_create();
         if (!m_comm_stream) return;
         if (m_be->event_create)
@@ -641,6 +681,8 @@ private:
     std::unique_ptr<MultiParticleContainer> mypc;
     std::unique_ptr<FiniteDifferenceSolver> m_fdtd_solver_fp;
     std::unique_ptr<BrickComm> m_comm;
+    std::unique_ptr<NCIGodfreyFilter> nci_godfrey_filter_exeybz, nci_godfrey_filter_bxbyez;   // Source/WarpX.H:468-469
+    std::unique_ptr<amrex::MultiFab> m_nci_E[3], m_nci_B[3];
     std::unique_ptr<amrex::MultiFab> m_filter_tmp[3];
     std::unique_ptr<amrex::MultiFab> m_rho, m_rho_tmp;   // ComputeRho (diagnostics)
     // field-solve exchanges: guard layer of B computed redundantly; J's guard sum on a second stream

@@ -379,6 +379,9 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     int use_filter = 1;                                         // WarpX.cpp:158
     pp.queryWithParser("warpx.use_filter", use_filter);
     cfg.use_filter = use_filter != 0;
+    int use_fdtd_nci_corr = 0;                                  // MultiParticleContainer.cpp:327 (WarpX.cpp:153)
+    pp.queryWithParser("particles.use_fdtd_nci_corr", use_fdtd_nci_corr);
+    cfg.use_fdtd_nci_corr = use_fdtd_nci_corr != 0;
     if (pp.queryArrWithParser("warpx.filter_npass_each_dir", v))
         for (double np : v)
             if (np != 1.0) throw std::runtime_error("inputs: only one bilinear filter pass per direction is on this path");
@@ -388,7 +391,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     cfg.sort_interval = 4;                                      // WarpX.cpp:168 (GPU default)
     if (pp.query("warpx.sort_intervals", w)) cfg.sort_interval = ParmParse::safe_int(pp.evaluate(w), "warpx.sort_intervals");
     for (const char* key : {"warpx.do_dive_cleaning", "warpx.do_divb_cleaning", "warpx.do_subcycling", "warpx.do_pml",
-                            "particles.use_fdtd_nci_corr", "warpx.do_electrostatic", "warpx.do_multi_J"})
+                            "warpx.do_electrostatic", "warpx.do_multi_J"})
         if (pp.queryWithParser(key, flag) && flag)
             throw std::runtime_error(std::string("inputs: ") + key + " = 1 is not on this path");
 

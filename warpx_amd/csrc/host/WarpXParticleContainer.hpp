@@ -38,6 +38,12 @@ struct WarpXContext {
     int32_t particle_bc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     int32_t particle_bc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     bool any_particle_wall = false;
+    // particles.use_fdtd_nci_corr: E and B filtered along z (Godfrey stencil) into these before every species' gather
+    // (PhysicalParticleContainer::applyNCIFilter, PhysicalParticleContainer.cpp:2097-2172); owned by WarpX
+    bool use_fdtd_nci_corr = false;
+    amrex::MultiFab* nci_E[3] = {nullptr, nullptr, nullptr};
+    amrex::MultiFab* nci_B[3] = {nullptr, nullptr, nullptr};
+    double nci_stencil_exeybz[5] = {0.5, 0, 0, 0, 0}, nci_stencil_bxbyez[5] = {0.5, 0, 0, 0, 0};
     // warpx.gamma_boost / beta_boost (boost along z, WarpXUtil.cpp:114-141) and warpx.gett_new(0)
     double gamma_boost = 1.0, beta_boost = 0.0;
     double t_new = 0.0;
@@ -579,7 +585,13 @@ public:
         auto J = fields.get_alldirs(FieldType::current_fp, lev);
         {
             PhaseTimer t(m_ctx, kGatherAndPush);  // "PhysicalParticleContainer::Evolve::GatherAndPush"
-            PushPX(*E[0], *E[1], *E[2], *B[0], *B[1], *B[2], dt);
+            if (m_ctx->use_fdtd_nci_corr) {   // :1900-1911: filter E and B, gather from the filtered copies
+                applyNCIFilter(E, B);
+                PushPX(*m_ctx->nci_E[0], *m_ctx->nci_E[1], *m_ctx->nci_E[2], *m_ctx->nci_B[0], *m_ctx->nci_B[1],
+                       *m_ctx->nci_B[2], dt);
+            } else {
+                PushPX(*E[0], *E[1], *E[2], *B[0], *B[1], *B[2], dt);
+            }
         }
         // Cell sort (amrex SortParticlesByBin, called by the reference from
         // HandleParticlesAtBoundaries, WarpXEvolve.cpp:575-580).  Sorting only permutes the
@@ -595,6 +607,25 @@ public:
             // :2029 relative_time = -0.5*dt: deposit at the half step
             DepositCurrent(J[0], J[1], J[2], dt, -0.5 * dt);
         }
+    }
+
+    // PhysicalParticleContainer::applyNCIFilter (:2097-2172): Ex, Ey, Bz with one Godfrey stencil, Bx, By, Ez with the
+    // other, along z (NCIGodfreyFilter: stencil lengths 1, 1, 5).  The reference filters the tile box grown by the shape
+    // order; here the whole allocation is filtered (zero padding beyond it, as Filter::DoFilter pads): the same values
+    // wherever the gather reads.  Like the reference, once per species and step.
+    void applyNCIFilter(const ablastr::fields::VectorField& E, const ablastr::fields::VectorField& B) {
+        const Backend* be = m_ctx->be;
+        if (!be->filter_stencil) throw std::runtime_error("particles.use_fdtd_nci_corr: not in this backend");
+        const double half[1] = {0.5};
+        auto run = [&](const amrex::MultiFab& src, amrex::MultiFab& dst, const double* sz) {
+            check(be->filter_stencil(&src.view(), &dst.view(), half, 1, half, 1, sz, 5, m_ctx->stream), "filter_stencil");
+        };
+        run(*E[0], *m_ctx->nci_E[0], m_ctx->nci_stencil_exeybz);
+        run(*E[2], *m_ctx->nci_E[2], m_ctx->nci_stencil_bxbyez);
+        run(*B[1], *m_ctx->nci_B[1], m_ctx->nci_stencil_bxbyez);
+        run(*E[1], *m_ctx->nci_E[1], m_ctx->nci_stencil_exeybz);
+        run(*B[0], *m_ctx->nci_B[0], m_ctx->nci_stencil_bxbyez);
+        run(*B[2], *m_ctx->nci_B[2], m_ctx->nci_stencil_exeybz);
     }
 
     // :2549-2786

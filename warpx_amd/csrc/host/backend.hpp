@@ -68,6 +68,9 @@ struct Backend {
                               void*);
     int (*laser_push)(const wxa_particle_view*, const wxa_laser_push_params*, double t, double dt, void*);
     int (*filter_bilinear)(const wxa_field_view*, const wxa_field_view*, void*);
+    // Filter::DoFilter with any half stencils (the NCI corrector: lengths 1, 1, 5); optional
+    int (*filter_stencil)(const wxa_field_view*, const wxa_field_view*, const double* s0, int32_t n0, const double* s1,
+                          int32_t n1, const double* s2, int32_t n2, void*) = nullptr;
     int (*fill_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);
     int (*sync_nodal_periodic)(const wxa_field_view*, const int*, void*);
     int (*sum_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);

@@ -100,6 +100,9 @@ const Backend* hip_backend() {
         b.deposit_current = k_deposit;
         b.filter_bilinear = [](const wxa_field_view* s, const wxa_field_view* d, void* st) -> int {
             return wxa_filter_bilinear(s, d, st); };
+        b.filter_stencil = [](const wxa_field_view* s, const wxa_field_view* d, const double* s0, int32_t n0,
+                              const double* s1, int32_t n1, const double* s2, int32_t n2, void* st) -> int {
+            return wxa_filter_stencil(s, d, s0, n0, s1, n1, s2, n2, st); };
         b.fill_boundary_periodic = [](const wxa_field_view* f, const int* ng, const int* per, void* st) -> int {
             return wxa_fill_boundary_periodic(f, ng, per, st); };
         b.sync_nodal_periodic = [](const wxa_field_view* f, const int* per, void* st) -> int {
@@ -182,6 +185,20 @@ const Backend* hip_backend() {
 void set_err(const char* msg) { wxa::set_last_error("%s", msg); }
 
 }  // namespace
+
+// NCIGodfreyFilter::ComputeStencils through the host layer's class (host function)
+extern "C" wxa_status wxa_nci_godfrey_stencil(double cdtodz, int32_t nodal_gather, int32_t coeff_set, double stencil_z[5]) {
+    if (!stencil_z || (coeff_set != WXA_NCI_EX_EY_BZ && coeff_set != WXA_NCI_BX_BY_EZ)) {
+        wxa::set_last_error("wxa_nci_godfrey_stencil: bad argument");
+        return WXA_ERR_INVALID_ARG;
+    }
+    wxa::host::NCIGodfreyFilter f(coeff_set == WXA_NCI_EX_EY_BZ ? wxa::host::godfrey_coeff_set::Ex_Ey_Bz
+                                                                  : wxa::host::godfrey_coeff_set::Bx_By_Ez,
+                                  cdtodz, nodal_gather != 0);
+    f.ComputeStencils();
+    for (int i = 0; i < 5; ++i) stencil_z[i] = f.stencil_z[i];
+    return WXA_OK;
+}
 
 struct wxa_sim {};
 WXA_SIM_CAPI(wxa_, wxa_status, wxa_sim, hip_backend, set_err)
