@@ -120,7 +120,8 @@ def energies(sim, sid):
 
 def cpu_baseline():
     """The CPU oracle (our restatement of the reference's algorithms; the reference itself cannot be built here: AMReX
-    is not on disk) timed on bounded samples, SURVEY.md 8(d) protocol -- median of 5 runs, thread count stated:
+    is not on disk) timed on bounded samples, SURVEY.md 8(d) protocol -- median of 5 runs of 10 steps, thread count
+    stated, every phase of the step on all threads (the guard exchanges too since round 3):
       * all host cores (OpenMP; thread-private J scratch + accumulate, as the reference's CPU path) on a 128^3 sample of
         the bench workload (8 ppc, order 3, Esirkepov, Boris, filter on), with the oracle's per-phase timers;
       * one thread ("CPU serial") on BASELINE.json config 1 itself: 64^3, 1 ppc, order 1 (Examples/Tests/uniform_plasma)."""
@@ -163,19 +164,19 @@ def cpu_baseline():
 
     all_threads = int(orc._set_num_threads(0))
     t0 = time.perf_counter()
-    med, lo, hi, npart, phases = sample(128, (2, 2, 2), 3, 2, 5, all_threads)
+    med, lo, hi, npart, phases = sample(128, (2, 2, 2), 3, 10, 5, all_threads)
     t_all = time.perf_counter() - t0
     t0 = time.perf_counter()
-    smed, slo, shi, snp, _ = sample(64, (1, 1, 1), 1, 2, 5, 1)
+    smed, slo, shi, snp, _ = sample(64, (1, 1, 1), 1, 10, 5, 1)
     t_ser = time.perf_counter() - t0
     orc._set_num_threads(all_threads)
     out = {"value": med, "unit": "particle-steps/s", "cores": all_threads, "kind": "port",
            "sample": f"128^3 cells, 8 ppc, order 3, Esirkepov, Boris, filter on ({npart} particles): median of 5 runs of "
-                     f"2 steps (min {lo:.3e}, max {hi:.3e}); {t_all:.1f} s wall incl. set-up; cell-updates/s = "
+                     f"10 steps (min {lo:.3e}, max {hi:.3e}); {t_all:.1f} s wall incl. set-up; cell-updates/s = "
                      f"{med / 8.0:.3e}",
            "serial": {"value": smed, "unit": "particle-steps/s", "cores": 1,
                       "sample": f"BASELINE.json config 1: 64^3 cells, 1 ppc, order 1, Esirkepov, Boris, filter on ({snp} "
-                                f"particles): median of 5 runs of 2 steps (min {slo:.3e}, max {shi:.3e}); {t_ser:.1f} s "
+                                f"particles): median of 5 runs of 10 steps (min {slo:.3e}, max {shi:.3e}); {t_ser:.1f} s "
                                 f"wall incl. set-up; cell-updates/s = {smed:.3e}"}}
     if phases:
         out["ms_per_step_by_phase"] = phases

@@ -571,6 +571,9 @@ typedef struct wxa_laser_antenna {
  * top num_shift layers, after (1) refreshing one guard cell of the periodic directions and (2) zeroing
  * everything beyond the domain on the high side, both on a scratch copy `tmp` (a second array of the same
  * shape, contents irrelevant).  num_shift <= the guard depth along dir. */
+#define WXA_WINDOW_KEEP_GUARDS 2   /* periodic[dir] of wxa_shift_field_window: the guards beyond the high face of the
+                                      window direction hold the next brick's cells (filled by the caller): they enter
+                                      this brick instead of the zero external field (bricks along the window)        */
 wxa_status wxa_shift_field_window(const wxa_field_view* f, double* tmp, int32_t dir, int32_t num_shift,
                                   const int periodic[3], void* stream);
 

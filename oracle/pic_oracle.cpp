@@ -828,7 +828,10 @@ int orc_shift_field_window(const wxa_field_view* f, double* tmp, int32_t dir, in
     int ng_mw[3] = {1, 1, 1};
     ng_mw[dir] = num_shift;
     for (int d = 0; d < 3; ++d) ng_mw[d] = std::min(ng_mw[d], (int)v.ng[d]);
-    orc_fill_boundary_periodic(&tv, ng_mw, periodic, nullptr);
+    // WXA_WINDOW_KEEP_GUARDS: bricks along the window -- the guards beyond the high face hold the next brick's cells
+    const bool keep_guards = periodic[dir] == WXA_WINDOW_KEEP_GUARDS;
+    const int per[3] = {dir == 0 ? 0 : periodic[0], dir == 1 ? 0 : periodic[1], dir == 2 ? 0 : periodic[2]};
+    orc_fill_boundary_periodic(&tv, ng_mw, per, nullptr);
     const Arr src(tv), dst(v);
     // the region the window moved into takes the external field (0): adjCellHi(domain, dir, ng) in the
     // field's index type, without the boundary node of a nodal direction, grown by ng transversally
@@ -837,9 +840,10 @@ int orc_shift_field_window(const wxa_field_view* f, double* tmp, int32_t dir, in
     for (int d = 0; d < 3; ++d) { zlo[d] = v.lo[d]; zhi[d] = v.lo[d] + v.n[d]; }
     zlo[dir] = vhi_d;                // first point beyond the domain (cell dom_hi+1 / node dom_hi+2)
     zhi[dir] = vhi_d + v.ng[dir];
-    for (int k = zlo[2]; k < zhi[2]; ++k)
-        for (int j = zlo[1]; j < zhi[1]; ++j)
-            for (int i = zlo[0]; i < zhi[0]; ++i) src(i, j, k) = 0.0;
+    if (!keep_guards)
+        for (int k = zlo[2]; k < zhi[2]; ++k)
+            for (int j = zlo[1]; j < zhi[1]; ++j)
+                for (int i = zlo[0]; i < zhi[0]; ++i) src(i, j, k) = 0.0;
     // dst(i) = src(i + shift) on the fab box shrunk by num_shift on the high side
     int dlo[3], dhi[3];
     for (int d = 0; d < 3; ++d) { dlo[d] = v.lo[d]; dhi[d] = v.lo[d] + v.n[d]; }

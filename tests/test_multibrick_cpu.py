@@ -65,6 +65,12 @@ def test_ckc_bricks_match_single_domain(nb, order, filt, port, tmp_path):
     # direct deposition, 8 ppc, filter, the gather without Galerkin shapes
     ((1, 2, 2), 4, "langmuir_beam_direct_3d.inputs", "langmuir_multi_picmi_3d_checksums.json", 29627),
     ((0, 0, 0), 2, "laser_injection_3d.inputs", "laser_injection_3d_checksums.json", 29628),
+    # round 3: bricks ALONG the moving window and between the PEC walls -- the fields that enter a brick come from its
+    # upper neighbour, the walls belong to the end bricks, the plasma is injected into the top brick and handed down
+    ((1, 1, 2), 2, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29651),
+    ((1, 1, 4), 4, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29652),
+    ((1, 2, 2), 4, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29653),
+    ((1, 1, 2), 2, "laser_injection_3d.inputs", "laser_injection_3d_checksums.json", 29654),
 ])
 def test_deck_on_bricks_reaches_the_golden_checksums(nb, nranks, deck, golden, port, tmp_path):
     """A whole inputs file on several bricks (gloo): the per-brick checksums add up to the reference's golden
@@ -87,6 +93,9 @@ def test_deck_on_bricks_reaches_the_golden_checksums(nb, nranks, deck, golden, p
     ((0, 0, 0), 4, "laser_wakefield_boosted_3d.inputs", 29642),     # ... and on the 2 x 2 bricks the library chooses
     ((1, 2, 1), 2, "boosted_injection_3d.inputs", 29643),
     ((2, 1, 1), 2, "boosted_laser_3d.inputs", 29644),               # the drifting antenna split over two bricks
+    ((1, 1, 2), 2, "laser_wakefield_boosted_3d.inputs", 29645),     # round 3: config 5 in small cut along z (the window)
+    ((1, 1, 4), 4, "laser_wakefield_boosted_3d.inputs", 29646),
+    ((1, 1, 2), 2, "boosted_injection_3d.inputs", 29647),
 ])
 def test_boosted_frame_decks_on_bricks_match_one_brick(nb, nranks, deck, port, tmp_path):
     """The boosted-frame decks (no golden file of the reference pins them) on several bricks against the same deck on

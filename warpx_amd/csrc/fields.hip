@@ -1119,7 +1119,9 @@ wxa_status wxa_shift_field_window(const wxa_field_view* f, double* tmp, int32_t 
     int ng_mw[3] = {1, 1, 1};
     ng_mw[dir] = num_shift;
     for (int d = 0; d < 3; ++d) ng_mw[d] = std::min(ng_mw[d], (int)f->ng[d]);
-    wxa_status rc = wxa_fill_boundary_periodic(&tv, ng_mw, periodic, stream);
+    const bool keep_guards = periodic[dir] == WXA_WINDOW_KEEP_GUARDS;   // the next brick's cells are in the guards already
+    const int per[3] = {dir == 0 ? 0 : periodic[0], dir == 1 ? 0 : periodic[1], dir == 2 ? 0 : periodic[2]};
+    wxa_status rc = wxa_fill_boundary_periodic(&tv, ng_mw, per, stream);
     if (rc != WXA_OK) return rc;
     const DevF dsrc = make_devf(tv), ddst = make_devf(*f);
     // everything beyond the domain on the high side takes the external field (0)
@@ -1128,7 +1130,8 @@ wxa_status wxa_shift_field_window(const wxa_field_view* f, double* tmp, int32_t 
     z.lo[dir] = f->lo[dir] + f->n[dir] - f->ng[dir];
     z.n[dir] = f->ng[dir];
     long total = (long)z.n[0] * z.n[1] * z.n[2];
-    if (total > 0) hipLaunchKernelGGL(set_box_kernel, dim3(grid_for(total)), dim3(256), 0, st, dsrc, z, 0.0);
+    if (total > 0 && !keep_guards)
+        hipLaunchKernelGGL(set_box_kernel, dim3(grid_for(total)), dim3(256), 0, st, dsrc, z, 0.0);
     // dst(i) = src(i + shift) on the array box shrunk by num_shift on the high side
     BoxN b;
     for (int d = 0; d < 3; ++d) { b.lo[d] = f->lo[d]; b.n[d] = f->n[d]; }

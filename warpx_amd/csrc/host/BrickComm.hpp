@@ -51,17 +51,21 @@ public:
     }
 
     bool self_periodic(int d) const { return m_nb[d] == 1; }
-    // boundary.field_lo/hi: a non-periodic direction (PEC) must be unsplit; nothing is exchanged
-    // or wrapped along it (amrex FillBoundary/SumBoundary only act across periodic or interior faces)
+    // boundary.field_lo/hi: along a non-periodic direction (PEC) nothing is exchanged or wrapped across the domain
+    // boundary; the faces between bricks are exchanged like any others (amrex FillBoundary / SumBoundary act across
+    // periodic or interior faces only: round 3 -- before, a non-periodic direction had to be unsplit)
     void set_periodic(const int periodic[3]) {
-        for (int d = 0; d < 3; ++d) {
-            if (!periodic[d] && m_nb[d] != 1) throw std::runtime_error("BrickComm: a non-periodic direction must be unsplit");
-            m_periodic[d] = periodic[d] != 0;
-        }
+        for (int d = 0; d < 3; ++d) m_periodic[d] = periodic[d] != 0;
     }
     bool periodic(int d) const { return m_periodic[d]; }
+    // a brick (or this brick's periodic image) beyond face `side` (0 = minus, 1 = plus) of direction d
+    bool has_neighbor(int d, int side) const {
+        return m_periodic[d] || (side == 0 ? m_coord[d] > 0 : m_coord[d] < m_nb[d] - 1);
+    }
+    bool exchanges(int d) const { return m_nb[d] > 1; }   // faces between bricks exist along d
     int rank_of(const int c[3]) const { return c[0] + m_nb[0] * (c[1] + m_nb[1] * c[2]); }
-    int neighbor(int d, int side) const {  // side 0 = minus, 1 = plus
+    int neighbor(int d, int side) const {  // side 0 = minus, 1 = plus; -1: the domain boundary
+        if (!has_neighbor(d, side)) return -1;
         int c[3] = {m_coord[0], m_coord[1], m_coord[2]};
         c[d] = (c[d] + (side ? 1 : -1) + m_nb[d]) % m_nb[d];
         return rank_of(c);
@@ -95,7 +99,9 @@ public:
             }
         }
         for (int d = 0; d < 3; ++d) {
-            if (!m_periodic[d]) continue;   // guards behind a physical boundary belong to the boundary condition
+            // guards behind a physical boundary belong to the boundary condition; between the bricks of a non-periodic
+            // direction the exchange runs as usual (exchange_slabs skips the side without a neighbour)
+            if (!m_periodic[d] && !exchanges(d)) continue;
             if (self_periodic(d)) {
                 for (size_t c = 0; c < nf; ++c) {
                     const wxa_field_view& f = mfs[c]->view();
@@ -121,6 +127,7 @@ public:
                 }
                 exchange_slabs(mfs, sl, d, /*mode=*/0, stream);
             }
+            if (!m_periodic[d]) continue;   // the later directions' slabs already span the whole allocation along d
             for (size_t c = 0; c < nf; ++c) {
                 const wxa_field_view& f = mfs[c]->view();
                 lo[c][d] = f.lo[d] + f.ng[d] - ng[d];
@@ -139,7 +146,7 @@ public:
                      void* stream) {
         const size_t nf = mfs.size();
         for (int d = 0; d < 3; ++d) {
-            if (!m_periodic[d]) continue;
+            if (!m_periodic[d] && !exchanges(d)) continue;
             if (self_periodic(d)) {
                 for (size_t c = 0; c < nf; ++c) {
                     int per[3] = {0, 0, 0}, g[3] = {0, 0, 0};
@@ -180,7 +187,7 @@ public:
     // reallocates device memory (DeviceBuffer::reserve would, the first time a deeper exchange comes by).
     void presize(const std::vector<amrex::MultiFab*>& mfs, const amrex::IntVect& layers) {
         for (int d = 0; d < 3; ++d) {
-            if (self_periodic(d) || !m_periodic[d]) continue;
+            if (self_periodic(d)) continue;
             size_t pts = 0;
             for (const amrex::MultiFab* mf : mfs) {
                 const wxa_field_view& f = mf->view();
@@ -197,30 +204,29 @@ public:
     // post `n` (<= 2) sends/recvs of raw device buffers with the +/- neighbours in direction d
     void exchange_raw(int d, void* send_minus, int64_t sm_bytes, void* send_plus, int64_t sp_bytes,
                       void* recv_plus, int64_t rp_bytes, void* recv_minus, int64_t rm_bytes, void* stream) {
-        int32_t speer[2] = {neighbor(d, 0), neighbor(d, 1)};
-        int32_t rpeer[2] = {neighbor(d, 1), neighbor(d, 0)};
-        void* sb[2] = {send_minus, send_plus};
-        void* rb[2] = {recv_plus, recv_minus};
-        int64_t sbytes[2] = {sm_bytes, sp_bytes};
-        int64_t rbytes[2] = {rp_bytes, rm_bytes};
-        if (m_comm.exchange(m_comm.ctx, 2, speer, sb, sbytes, rpeer, rb, rbytes, stream) != 0)
+        // canonical order: "to minus, to plus" on the sender is "from plus, from minus" on the receiver; a side without
+        // a neighbour (the domain boundary of a non-periodic direction) posts nothing
+        int32_t speer[2], rpeer[2];
+        void *sb[2], *rb[2];
+        int64_t sbytes[2], rbytes[2];
+        int n = 0;
+        if (has_neighbor(d, 0)) { speer[n] = neighbor(d, 0); sb[n] = send_minus; sbytes[n] = sm_bytes; ++n; }
+        if (has_neighbor(d, 1)) { speer[n] = neighbor(d, 1); sb[n] = send_plus; sbytes[n] = sp_bytes; ++n; }
+        int m = 0;
+        if (has_neighbor(d, 1)) { rpeer[m] = neighbor(d, 1); rb[m] = recv_plus; rbytes[m] = rp_bytes; ++m; }
+        if (has_neighbor(d, 0)) { rpeer[m] = neighbor(d, 0); rb[m] = recv_minus; rbytes[m] = rm_bytes; ++m; }
+        if (n == 0) return;
+        if (m_comm.exchange(m_comm.ctx, n, speer, sb, sbytes, rpeer, rb, rbytes, stream) != 0)
             throw std::runtime_error("BrickComm: exchange callback failed");
     }
-    void exchange_counts(int d, int64_t to_minus, int64_t to_plus, int64_t& from_plus, int64_t& from_minus) {
-        int32_t speer[2] = {neighbor(d, 0), neighbor(d, 1)};
-        int32_t rpeer[2] = {neighbor(d, 1), neighbor(d, 0)};
-        int64_t sv[2] = {to_minus, to_plus};
-        int64_t rv[2] = {0, 0};
-        if (m_comm.exchange_counts(m_comm.ctx, 2, speer, sv, rpeer, rv) != 0)
-            throw std::runtime_error("BrickComm: exchange_counts callback failed");
-        from_plus = rv[0];
-        from_minus = rv[1];
-    }
-
     // the brick at offset o (each component in {-1, 0, 1}) from this one, periodic images included
-    int rank_at_offset(const int o[3]) const {
+    int rank_at_offset(const int o[3]) const {   // -1: beyond the domain boundary of a non-periodic direction
         int c[3];
-        for (int d = 0; d < 3; ++d) c[d] = (m_coord[d] + o[d] + m_nb[d]) % m_nb[d];
+        for (int d = 0; d < 3; ++d) {
+            c[d] = m_coord[d] + o[d];
+            if (m_periodic[d]) c[d] = (c[d] + m_nb[d]) % m_nb[d];
+            else if (c[d] < 0 || c[d] >= m_nb[d]) return -1;
+        }
         return rank_of(c);
     }
     // one message each way with every listed peer (the particle hand-off: every rank lists its peers in ascending rank
@@ -284,10 +290,11 @@ private:
         m_send[0].reserve(8 * nsm); m_send[1].reserve(8 * nsp);
         m_recv[0].reserve(8 * nrp); m_recv[1].reserve(8 * nrm);
         int64_t om = 0, op = 0;
+        const bool minus = has_neighbor(d, 0), plus = has_neighbor(d, 1);
         for (size_t c = 0; c < mfs.size(); ++c) {
             const wxa_field_view& f = mfs[c]->view();
-            check(m_be->pack_box(&f, sl[c].smlo, sl[c].smhi, (double*)m_send[0].p + om, stream));
-            check(m_be->pack_box(&f, sl[c].splo, sl[c].sphi, (double*)m_send[1].p + op, stream));
+            if (minus) check(m_be->pack_box(&f, sl[c].smlo, sl[c].smhi, (double*)m_send[0].p + om, stream));
+            if (plus) check(m_be->pack_box(&f, sl[c].splo, sl[c].sphi, (double*)m_send[1].p + op, stream));
             om += box_pts(sl[c].smlo, sl[c].smhi);
             op += box_pts(sl[c].splo, sl[c].sphi);
         }
@@ -296,8 +303,8 @@ private:
         om = 0; op = 0;
         for (size_t c = 0; c < mfs.size(); ++c) {
             const wxa_field_view& f = mfs[c]->view();
-            check(m_be->unpack_box(&f, sl[c].rplo, sl[c].rphi, (const double*)m_recv[0].p + op, mode, stream));
-            check(m_be->unpack_box(&f, sl[c].rmlo, sl[c].rmhi, (const double*)m_recv[1].p + om, mode, stream));
+            if (plus) check(m_be->unpack_box(&f, sl[c].rplo, sl[c].rphi, (const double*)m_recv[0].p + op, mode, stream));
+            if (minus) check(m_be->unpack_box(&f, sl[c].rmlo, sl[c].rmhi, (const double*)m_recv[1].p + om, mode, stream));
             op += box_pts(sl[c].rplo, sl[c].rphi);
             om += box_pts(sl[c].rmlo, sl[c].rmhi);
         }

@@ -164,13 +164,16 @@ public:
                             ((lo == WXA_BOUNDARY_PERIODIC) == (hi == WXA_BOUNDARY_PERIODIC));
             if (!ok) throw std::runtime_error("field boundary: a direction is periodic on both sides or on neither");
             periodic[d] = lo == WXA_BOUNDARY_PERIODIC;
-            m_pec_lo[d] = lo == WXA_BOUNDARY_PEC;
-            m_pec_hi[d] = hi == WXA_BOUNDARY_PEC;
-            m_any_pec = m_any_pec || m_pec_lo[d] || m_pec_hi[d];
+            // a wall belongs to the bricks that touch it; the schedule (which exchanges are issued) follows the
+            // domain's walls, the same on every brick
+            m_pec_lo[d] = lo == WXA_BOUNDARY_PEC && cfg.coord[d] == 0;
+            m_pec_hi[d] = hi == WXA_BOUNDARY_PEC && cfg.coord[d] == cfg.nbricks[d] - 1;
+            m_any_pec = m_any_pec || lo == WXA_BOUNDARY_PEC || hi == WXA_BOUNDARY_PEC;
+            m_pec_here = m_pec_here || m_pec_lo[d] || m_pec_hi[d];
             m_dom_lo[d] = 0;
             m_dom_hi[d] = cfg.n_cell[d] - 1;
         }
-        m_comm->set_periodic(periodic);   // throws if a PEC direction is split into bricks
+        m_comm->set_periodic(periodic);
         SetUpHaloOverlap(cfg.overlap_halo != 0);
         // boundary.particle_lo / particle_hi: default = periodic with a periodic field boundary, absorbing
         // otherwise; periodic particles need a periodic field boundary and vice versa
@@ -288,7 +291,6 @@ public:
     void SetMovingWindow(int dir, amrex::Real v_over_c) {
         if (dir < 0 || dir > 2 || !(v_over_c > 0.0)) throw std::runtime_error("moving window: direction 0..2, v > 0");
         if (m_comm->periodic(dir)) throw std::runtime_error("the moving window direction cannot be periodic");
-        if (m_comm->nbricks()[dir] != 1) throw std::runtime_error("the moving window direction must be unsplit");
         do_moving_window = true;
         moving_window_dir = dir;
         moving_window_v = v_over_c * 299'792'458.;
@@ -316,8 +318,9 @@ public:
         if (num_shift_base == 0) return 0;
         m_ctx.prob_lo[dir] += num_shift_base * cdx;                                 // :181-186 ResetProbDomain
         m_ctx.prob_hi[dir] += num_shift_base * cdx;
-        m_ctx.brick_plo[dir] = m_ctx.prob_lo[dir];                                  // the window direction is unsplit
-        m_ctx.brick_phi[dir] = m_ctx.prob_hi[dir];
+        // the bricks move with the domain: brick c of the window direction covers its cells of the shifted index space
+        m_ctx.brick_plo[dir] = m_ctx.prob_lo[dir] + (m_ctx.brick_box.lo[dir] - m_dom_lo[dir]) * cdx;
+        m_ctx.brick_phi[dir] = m_ctx.prob_lo[dir] + (m_ctx.brick_box.lo[dir] - m_dom_lo[dir] + m_ctx.brick_box.length(dir)) * cdx;
         for (int dim = 0; dim < 3; ++dim) {                                         // :222-246
             shiftMF(*m_fields.get(FieldType::Bfield_fp, Direction{dim}, 0), num_shift_base, dir);
             shiftMF(*m_fields.get(FieldType::Efield_fp, Direction{dim}, 0), num_shift_base, dir);
@@ -361,13 +364,23 @@ public:
         }
     }
 
-    // WarpX::shiftMF (:478-648), zero external field
+    // WarpX::shiftMF (:478-648), zero external field.  Across the bricks of the window direction the cells that enter a
+    // brick come from its upper neighbour: the reference fills the guards of its temporary along the window
+    // (FillBoundary(tmpmf, ng_mw, periodicity), :503-513) and shifts over them; here the field's own guards are filled
+    // to the shift's depth first and the device routine is told to keep them (WXA_WINDOW_KEEP_GUARDS) -- only the
+    // topmost brick, where the domain ends, lets zeros in.
     void shiftMF(amrex::MultiFab& mf, int num_shift, int dir) {
         const wxa_field_view& v = mf.view();
         if (num_shift > v.ng[dir]) throw std::runtime_error("shiftMF: shift exceeds the guard depth");   // :491
         m_shift_tmp.be = m_be;
         m_shift_tmp.reserve(sizeof(double) * (size_t)v.kstride * (size_t)v.n[2]);
-        const int periodic[3] = {m_comm->periodic(0) ? 1 : 0, m_comm->periodic(1) ? 1 : 0, m_comm->periodic(2) ? 1 : 0};
+        int periodic[3] = {m_comm->periodic(0) ? 1 : 0, m_comm->periodic(1) ? 1 : 0, m_comm->periodic(2) ? 1 : 0};
+        if (m_comm->exchanges(dir)) {
+            amrex::IntVect ng(0);
+            ng[dir] = num_shift;
+            m_comm->FillBoundary(mf, ng, false, m_ctx.stream);
+            if (m_comm->has_neighbor(dir, 1)) periodic[dir] = WXA_WINDOW_KEEP_GUARDS;
+        }
         if (m_be->shift_field_window(&v, static_cast<double*>(m_shift_tmp.p), dir, num_shift, periodic, m_ctx.stream) != 0)
             throw std::runtime_error("shift_field_window failed");
     }
@@ -462,7 +475,7 @@ public:
     // (WarpX_PEC.cpp:713-900) with absorbing particle boundaries next to the PEC walls
     void ApplyJfieldBoundary(int /*lev*/, amrex::MultiFab* Jx, amrex::MultiFab* Jy, amrex::MultiFab* Jz,
                              PatchType /*patch_type*/) {
-        if (!m_any_pec) return;
+        if (!m_pec_here) return;
         const wxa_field_view Jv[3] = {Jx->view(), Jy->view(), Jz->view()};
         if (m_be->apply_pec_j(Jv, m_dom_lo, m_dom_hi, m_pec_lo, m_pec_hi, m_ctx.stream) != 0)
             throw std::runtime_error("apply_pec_j failed");
@@ -484,7 +497,7 @@ public:
         amrex::MultiFab& rho = *m_rho;
         rho.setVal(0.0, m_ctx.stream);
         for (int i = 0; i < mypc->nContainers(); ++i) mypc->GetParticleContainer(i).DepositCharge(&rho);
-        if (m_any_pec &&
+        if (m_pec_here &&
             m_be->apply_pec_rho(&rho.view(), m_dom_lo, m_dom_hi, m_pec_lo, m_pec_hi, m_ctx.stream) != 0)
             throw std::runtime_error("apply_pec_rho failed");
         if (use_filter) {
@@ -540,7 +553,7 @@ public:
     // Source/BoundaryConditions/WarpXFieldBoundaries.cpp:51-106 -> PEC::ApplyPECtoEfield
     // (WarpX_PEC.cpp:457-538) with get_ng_fieldgather(); periodic faces: nothing to do
     void ApplyEfieldBoundary(int /*lev*/, PatchType /*patch_type*/) {
-        if (!m_any_pec) return;
+        if (!m_pec_here) return;
         auto E = m_fields.get_alldirs(warpx::fields::FieldType::Efield_fp, 0);
         const wxa_field_view Ev[3] = {E[0]->view(), E[1]->view(), E[2]->view()};
         const int32_t ng[3] = {guard_cells.ng_FieldGather[0], guard_cells.ng_FieldGather[1], guard_cells.ng_FieldGather[2]};
@@ -549,7 +562,7 @@ public:
     }
     // :108-135 -> PEC::ApplyPECtoBfield (WarpX_PEC.cpp:540-626)
     void ApplyBfieldBoundary(int /*lev*/, PatchType /*patch_type*/) {
-        if (!m_any_pec) return;
+        if (!m_pec_here) return;
         auto B = m_fields.get_alldirs(warpx::fields::FieldType::Bfield_fp, 0);
         const wxa_field_view Bv[3] = {B[0]->view(), B[1]->view(), B[2]->view()};
         const int32_t ng[3] = {guard_cells.ng_FieldGather[0], guard_cells.ng_FieldGather[1], guard_cells.ng_FieldGather[2]};
@@ -638,7 +651,8 @@ public:
     int sort_intervals = -1;         // Source/WarpX.cpp:1335 (GPU default 4; set by the config)
     // WarpX::field_boundary_lo / field_boundary_hi restricted to periodic | PEC
     int32_t m_pec_lo[3] = {0, 0, 0}, m_pec_hi[3] = {0, 0, 0}, m_dom_lo[3] = {0, 0, 0}, m_dom_hi[3] = {0, 0, 0};
-    bool m_any_pec = false;
+    bool m_any_pec = false;    // the domain has a PEC wall (schedule decisions: identical on every brick)
+    bool m_pec_here = false;   // ... and this brick touches one
     bool m_any_reflecting_wall = false;
     // WarpX::do_moving_window, moving_window_dir, moving_window_v (m/s), moving_window_x
     bool do_moving_window = false;

@@ -326,6 +326,19 @@ public:
             for (int d = 0; d < 3; ++d) reachable = reachable && (o[d] == 0 || split[d]);
             if (!reachable) continue;
             const int r = comm.rank_at_offset(o);
+            if (r < 0) {
+                // beyond the domain boundary of a non-periodic direction: the particle walls have dealt with every such
+                // particle before this point (ApplyBoundaryConditions); what is left is retired here, sent nowhere
+                if (cnt[code] > 0) {
+                    const wxa_particle_view p = m_tile.view();
+                    m_sendbuf.reserve(64 * (size_t)cnt[code]);
+                    check(be->pack_leavers(&p, lists + (int64_t)code * cap, cnt[code], m_sendbuf.p, cnt[code], 0,
+                                           /*retire=*/1, m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), m_ctx->stream),
+                          "pack_leavers");
+                    m_nretired += cnt[code];
+                }
+                continue;
+            }
             auto it = std::find_if(peers.begin(), peers.end(), [&](const Peer& q) { return q.rank == r; });
             if (it == peers.end()) { peers.push_back(Peer{r}); it = peers.end() - 1; }
             it->codes.push_back(code);
