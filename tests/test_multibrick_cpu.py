@@ -56,8 +56,8 @@ def test_ckc_bricks_match_single_domain(nb, order, filt, port, tmp_path):
     # window along z (unsplit), bricks along x: continuous injection, the antenna and the PEC walls per brick
     ((2, 1, 1), 2, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29621),
     ((1, 1, 2), 2, "langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", 29623),
-    # (0, 0, 0): the library chooses the bricks -- x and y for the wakefield deck (PEC walls and the window along z),
-    # 2 x 2 x 2 for the all-periodic Langmuir deck on 8 ranks
+    # (0, 0, 0): the library chooses the bricks, the longest direction first -- four bricks along z for the wakefield
+    # deck (across the PEC walls and along the window, since round 3), 2 x 2 x 2 for the all-periodic Langmuir deck
     ((0, 0, 0), 4, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29624),
     ((0, 0, 0), 8, "langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", 29625),
     # reflecting walls in x, absorbing ones in y, bricks along the periodic z
