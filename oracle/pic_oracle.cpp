@@ -647,18 +647,30 @@ int orc_fill_boundary_periodic(const wxa_field_view* f, const int ng[3], const i
         // reference's OpenMP build runs FillBoundary on all threads too).  Threads split the SLOWEST of the other two
         // dimensions and keep whole rows: splitting i between threads would have them write into one another's cache lines
         const int dp = d == 2 ? 1 : 2, dq = d == 0 ? 1 : 0;
+        // (a parallel region costs tens of microseconds on a 128-core host: small arrays -- the 16^3 .. 32^3 grids of the
+        // parity tests, thousands of steps -- stay serial, with no OpenMP construct on their path at all)
+        const bool big = (long)(hi[dp] - lo[dp]) * (hi[dq] - lo[dq]) * ng[d] >= 65536;
         for (int side = 0; side < 2; ++side) {
-#pragma omp parallel for
-            for (int u = lo[dp]; u < hi[dp]; ++u)
-                for (int v = lo[dq]; v < hi[dq]; ++v)
-                    for (int gi = 1; gi <= ng[d]; ++gi) {
-                        const int dsti = side == 0 ? v0 - gi : v1 - 1 + gi;
-                        const int srci = side == 0 ? dsti + nc : dsti - nc;
+            auto plane = [&](const int u) {
+                // guard layers in ascending depth (a layer deeper than the period reads a layer filled just before);
+                // the contiguous index innermost where it is not the exchanged direction itself
+                for (int gi = 1; gi <= ng[d]; ++gi) {
+                    const int dsti = side == 0 ? v0 - gi : v1 - 1 + gi;
+                    const int srci = side == 0 ? dsti + nc : dsti - nc;
+                    for (int v = lo[dq]; v < hi[dq]; ++v) {
                         int t[3], s[3];
                         t[dq] = v; t[dp] = u; t[d] = dsti;
                         s[dq] = v; s[dp] = u; s[d] = srci;
                         a(t[0], t[1], t[2]) = a(s[0], s[1], s[2]);
                     }
+                }
+            };
+            if (big) {
+#pragma omp parallel for
+                for (int u = lo[dp]; u < hi[dp]; ++u) plane(u);
+            } else {
+                for (int u = lo[dp]; u < hi[dp]; ++u) plane(u);
+            }
         }
         lo[d] = v0 - ng[d]; hi[d] = v1 + ng[d];
     }
@@ -1014,7 +1026,6 @@ int orc_sync_nodal_periodic(const wxa_field_view* f, const int periodic[3], void
         int rl[3], rh[3];
         for (int e = 0; e < 3; ++e) { rl[e] = vlo(*f, e); rh[e] = vhi(*f, e); }
         rl[d] = vlo(*f, d) + nc; rh[d] = rl[d] + 1;
-#pragma omp parallel for   // over k (one plane when d is z: a small copy then)
         for (int k = rl[2]; k < rh[2]; ++k)
             for (int j = rl[1]; j < rh[1]; ++j)
                 for (int i = rl[0]; i < rh[0]; ++i) {
@@ -1039,11 +1050,9 @@ int orc_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3], cons
         // the lines along d are independent of each other: all cores (each line is summed in the same order as before);
         // threads split the slowest of the other two dimensions and keep whole rows (no shared cache lines)
         const int d2 = d == 2 ? 1 : 2, d1 = d == 0 ? 1 : 0;
-#pragma omp parallel for
-        for (int u = f->lo[d2]; u < f->lo[d2] + f->n[d2]; ++u)
+        auto plane = [&](const int u, std::vector<double>& line) {
+            line.resize(f->n[d]);
             for (int v = f->lo[d1]; v < f->lo[d1] + f->n[d1]; ++v) {
-                static thread_local std::vector<double> line;
-                line.resize(f->n[d]);
                 int idx[3];
                 idx[d1] = v; idx[d2] = u;
                 for (int t = a0; t < a1; ++t) { idx[d] = t; line[t - a0] = a(idx[0], idx[1], idx[2]); }
@@ -1056,6 +1065,18 @@ int orc_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3], cons
                     a(idx[0], idx[1], idx[2]) = sum;
                 }
             }
+        };
+        if ((long)f->n[0] * f->n[1] * f->n[2] >= 262144) {   // small arrays stay serial, see orc_fill_boundary_periodic
+#pragma omp parallel
+            {
+                std::vector<double> line;
+#pragma omp for
+                for (int u = f->lo[d2]; u < f->lo[d2] + f->n[d2]; ++u) plane(u, line);
+            }
+        } else {
+            std::vector<double> line;
+            for (int u = f->lo[d2]; u < f->lo[d2] + f->n[d2]; ++u) plane(u, line);
+        }
     }
     return 0;
 }
@@ -1403,6 +1424,7 @@ struct LaserAntenna {
     wxa_laser_antenna cfg{};
     double nvec[3], p_X[3], p_Y[3];   // plane normal, polarization, second polarization vector
     double position[3];
+    double Z0_lab = 0.0;              // boosted frame: the antenna plane's lab-frame position along the boost (:190)
     double S_X = 0, S_Y = 0, mobility = 0, weight = 0;
     Species parts;                    // q = 1 (:86), m irrelevant (never pushed by the fields)
 };
@@ -1437,6 +1459,8 @@ struct orc_sim {
     // current physical domain (moves with the moving window)
     double plo[3] = {0, 0, 0}, phi[3] = {0, 0, 0};
     // warpx.do_moving_window
+    // warpx.gamma_boost, boost along z (WarpXUtil.cpp:114-141)
+    double gamma_boost = 1.0, beta_boost = 0.0;
     bool mw_on = false;
     int mw_dir = 2;
     double mw_v = 0.0;   // m/s
@@ -1487,6 +1511,26 @@ void add_plasma(orc_sim* s, Species& sp, const double part_lo[3], const double p
         nov[d] = (int)std::round((ohi[d] - olo[d]) / dx);   // cells 0 .. nov-1
     }
     const int nppc = in.ppc[0] * in.ppc[1] * in.ppc[2];
+    if (s->gamma_boost > 1.0) {
+        // the boosted branch of AddPlasma (:1021-1022 ballistic correction of the cell test, :1181-1247 lab-frame
+        // bounds, transformed density and momentum) lives in the exported routine below; plasma at rest in the lab
+        wxa_plasma_injector inj = in;
+        inj.gamma_boost = s->gamma_boost;
+        inj.t = s->cur_time;                       // warpx.gett_new(lev)
+        const int64_t room = (int64_t)nov[0] * nov[1] * nov[2] * nppc;
+        if (room <= 0) return;
+        std::vector<double> col[7];
+        for (auto& c : col) c.assign((size_t)room, 0.0);
+        wxa_particle_view dst{};
+        dst.x = col[0].data(); dst.y = col[1].data(); dst.z = col[2].data(); dst.w = col[3].data();
+        dst.ux = col[4].data(); dst.uy = col[5].data(); dst.uz = col[6].data(); dst.idcpu = nullptr; dst.np = room;
+        const int32_t nc[3] = {nov[0], nov[1], nov[2]};
+        int64_t added = 0;
+        orc_add_plasma(&dst, &inj, olo, nc, s->dx, s->plo, s->phi, nullptr, &added, nullptr, nullptr);
+        for (int c = 0; c < 7; ++c) sp.a[c].insert(sp.a[c].end(), col[c].begin(), col[c].begin() + added);
+        if (!sp.id.empty() || s->any_particle_wall) sp.id.resize(sp.a[0].size(), 0);
+        return;
+    }
     const double scale_fac = s->dx[0] * s->dx[1] * s->dx[2] / nppc;   // compute_scale_fac_volume
     auto inside = [&](double x, double y, double z) {   // InjectorPosition::insideBounds
         return x < in.hi[0] && x >= in.lo[0] && y < in.hi[1] && y >= in.lo[1] && z < in.hi[2] && z >= in.lo[2];
@@ -1542,8 +1586,14 @@ void shift_field(orc_sim* s, Field& f, int num_shift, int dir) {
 // WarpX::MoveWindow (:138-476): forward window, lab frame, plasma at rest
 int move_window(orc_sim* s, bool move_j) {
     if (!s->mw_on) return 0;
-    s->mw_x += s->mw_v * s->dt;                                   // :158
+    const double c = PhysConst::c;
+    s->mw_x += (s->mw_v - s->beta_boost * c) / (1 - s->mw_v * s->beta_boost / c) * s->dt;   // :157
     const int dir = s->mw_dir;
+    // UpdateInjectionPosition (:60-136): the plasma (at rest in the lab: u_bulk = 0) drifts in a boosted frame and the
+    // injection front with it, v' = (v - c beta) / (1 - v beta / c) along the boost direction (z)
+    if (s->gamma_boost > 1.0 && dir == 2)
+        for (auto& sp : s->species)
+            if (sp->inject) sp->inj_pos += ((0.0 - c * s->beta_boost) / (1.0 - 0.0 * s->beta_boost / c)) * s->dt;
     const double cdx = s->dx[dir];
     const int num_shift = (int)((s->mw_x - s->plo[dir]) / cdx);   // :171
     if (num_shift == 0) return 0;
@@ -1584,6 +1634,7 @@ void laser_init(orc_sim* s, LaserAntenna& L) {
     L.mobility = 0.05 / L.cfg.e_max;
     L.weight = PhysConst::ep0 / L.mobility;
     L.weight *= L.S_X * L.S_Y;
+    L.mobility = L.mobility / s->gamma_boost;   // :772-775 e_max is a lab-frame amplitude
     // plane index range from the corners of the injection box (:418-457), truncation towards zero
     int plo[2] = {INT_MAX, INT_MAX}, phi[2] = {INT_MIN, INT_MIN};
     for (int c = 0; c < 8; ++c) {
@@ -1614,12 +1665,16 @@ void laser_init(orc_sim* s, LaserAntenna& L) {
 }
 
 // LaserParticleContainer::Evolve (:563-713) through the exported kernel (orc_laser_push below)
-void laser_push(orc_sim* /*s*/, LaserAntenna& L, double t, double dt) {
+void laser_push(orc_sim* s, LaserAntenna& L, double t, double dt) {
     wxa_laser_push_params par{};
     for (int d = 0; d < 3; ++d) { par.position[d] = L.position[d]; par.p_X[d] = L.p_X[d]; par.p_Y[d] = L.p_Y[d]; }
     par.mobility = L.mobility;
     par.e_max = L.cfg.e_max; par.wavelength = L.cfg.wavelength; par.waist = L.cfg.waist;
     par.duration = L.cfg.duration; par.t_peak = L.cfg.t_peak; par.focal_distance = L.cfg.focal_distance;
+    for (int d = 0; d < 3; ++d) par.nvec[d] = L.nvec[d];
+    par.gamma_boost = s->gamma_boost;
+    // :574-579 the field to emit is the lab-frame one at the antenna's lab-frame time
+    if (s->gamma_boost > 1.0) t = 1.0 / s->gamma_boost * t + s->beta_boost * L.Z0_lab / PhysConst::c;
     wxa_particle_view p = L.parts.view();
     orc_laser_push(&p, &par, t, dt, nullptr);
 }
@@ -1731,9 +1786,12 @@ int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** ou
     if (!cfg || !out) return -1;
     if (cfg->nox < 1 || cfg->nox > 3) return -1;
     if (cfg->nbricks[0] * cfg->nbricks[1] * cfg->nbricks[2] != 1) return -3;
-    if (cfg->gamma_boost > 1.0) return -3;   // boosted frames run through the host layer (tests/host_cpu), not this driver
     auto* s = new orc_sim();
     s->cfg = *cfg;
+    if (cfg->gamma_boost > 1.0) {   // ReadBoostedFrameParameters (WarpXUtil.cpp:114-141)
+        s->gamma_boost = cfg->gamma_boost;
+        s->beta_boost = std::sqrt(1.0 - 1.0 / std::pow(cfg->gamma_boost, 2.0));
+    }
     for (int d = 0; d < 3; ++d) {
         s->dx[d] = (cfg->prob_hi[d] - cfg->prob_lo[d]) / cfg->n_cell[d];
         s->plo[d] = cfg->prob_lo[d];
@@ -1866,8 +1924,29 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
         s->istep++;
         s->cur_time += s->dt;
         move_window(s, /*move_j=*/s->is_synchronized);   // :246 MoveWindow(step+1, move_j)
-        for (auto& L : s->lasers) {   // lasers are particle containers too: periodic wrap (they never reach a wall)
-            wxa_particle_view p = L->parts.view();
+        for (auto& L : s->lasers) {
+            // lasers are particle containers too (MultiParticleContainer::ApplyBoundaryConditions loops over all of them,
+            // MultiParticleContainer.cpp:629-635): in a boosted frame the antenna drifts with -beta c and leaves through
+            // the lower wall, where its particles are absorbed and dropped like any others; then the periodic wrap
+            Species& sp = L->parts;
+            if (s->any_particle_wall && !sp.a[0].empty()) {
+                if (sp.id.empty()) sp.id.assign(sp.a[0].size(), 0);
+                wxa_particle_view p = sp.view();
+                int64_t lost = 0;
+                orc_apply_particle_boundaries(&p, s->plo, s->phi, s->pbc_lo, s->pbc_hi, &lost, nullptr, nullptr);
+                if (lost > 0) {
+                    size_t keep = 0;
+                    for (size_t ip = 0; ip < sp.id.size(); ++ip) {
+                        if (sp.id[ip] == WXA_IDCPU_RETIRED) continue;
+                        for (int c = 0; c < 7; ++c) sp.a[c][keep] = sp.a[c][ip];
+                        sp.id[keep] = sp.id[ip];
+                        ++keep;
+                    }
+                    for (int c = 0; c < 7; ++c) sp.a[c].resize(keep);
+                    sp.id.resize(keep);
+                }
+            }
+            wxa_particle_view p = sp.view();
             orc_enforce_periodic(&p, s->plo, s->phi, s->periodic, nullptr);
         }
         {   // HandleParticlesAtBoundaries (:533-581): ApplyBoundaryConditions, then the periodic wrap of Redistribute
@@ -1947,6 +2026,12 @@ int orc_sim_add_laser(orc_sim* s, const wxa_laser_antenna* la) {
     double dp = 0;
     for (int d = 0; d < 3; ++d) dp += L->nvec[d] * L->p_X[d];
     if (std::abs(dp) >= 1e-14) return -2;   // polarization must lie in the antenna plane
+    if (s->gamma_boost > 1.0) {   // :182-197 the antenna sits at Z0_lab / gamma_boost; the boost must be along the laser
+        if (L->nvec[0] * L->nvec[0] + L->nvec[1] * L->nvec[1] + (L->nvec[2] - 1.0) * (L->nvec[2] - 1.0) >= 1.e-12) return -2;
+        L->Z0_lab = L->nvec[0] * L->position[0] + L->nvec[1] * L->position[1] + L->nvec[2] * L->position[2];
+        const double Z0_boost = L->Z0_lab / s->gamma_boost;
+        for (int d = 0; d < 3; ++d) L->position[d] += (Z0_boost - L->Z0_lab) * L->nvec[d];
+    }
     // p_Y = nvec x p_X (:222)
     L->p_Y[0] = L->nvec[1] * L->p_X[2] - L->nvec[2] * L->p_X[1];
     L->p_Y[1] = L->nvec[2] * L->p_X[0] - L->nvec[0] * L->p_X[2];

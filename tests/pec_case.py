@@ -127,3 +127,47 @@ def make_lwfa_sim(lib):
     la.waist, la.duration, la.t_peak, la.focal_distance = 5e-6, 15e-15, 30e-15, 100e-6
     lib.sim_add_laser(sim._h, C.byref(la))
     return sim, electrons
+
+
+# ---- BASELINE config 5 in small, by hand: tests/decks/laser_wakefield_boosted_3d.inputs for the oracle stepper ----------
+BOOST_GAMMA = 5.0
+BOOST_MAX_STEP = 120
+
+
+def make_boosted_lwfa_sim(lib):
+    """The boosted laser-wakefield deck (gamma = 5, window at c, PEC z, CKC, Vay, order 3, bilinear filter, NCI
+    corrector, Gaussian antenna, electrons injected continuously) set up call by call -- for the oracle stepper, which
+    has no inputs reader.  The z bounds go through ConvertLabParamsToBoost (Source/Utils/WarpXUtil.cpp:180-262):
+    divided by gamma (1 - beta beta_window), beta_window = moving_window_v."""
+    import ctypes as C
+    beta = np.sqrt(1.0 - 1.0 / BOOST_GAMMA ** 2)
+    convert_factor = 1.0 / (BOOST_GAMMA * (1.0 - beta * 1.0))
+    lo = (-30e-6, -30e-6, -14e-6 * convert_factor)
+    hi = (30e-6, 30e-6, 2e-6 * convert_factor)
+    sim = WarpXSim(lib, (16, 16, 256), lo, hi, nox=3, galerkin=1, particle_pusher=_capi.PUSHER_VAY, use_filter=1, cfl=1.0,
+                   sort_interval=4, maxwell_solver=_capi.SOLVER_CKC, use_fdtd_nci_corr=1,
+                   field_boundary_lo=(_capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PEC),
+                   field_boundary_hi=(_capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PERIODIC, _capi.BOUNDARY_PEC),
+                   gamma_boost=BOOST_GAMMA)
+    mw = _capi.MovingWindow(dir=2, v=1.0)
+    lib.sim_set_moving_window(sim._h, C.byref(mw))
+    electrons = sim.add_species(-Q_E, M_E_, [np.zeros(0) for _ in range(7)])
+    inj = _capi.PlasmaInjector()
+    inj.density = 2e23
+    for d in range(3):
+        inj.ppc[d] = 1
+    inj.lo[0], inj.hi[0] = -20e-6, 20e-6
+    inj.lo[1], inj.hi[1] = -20e-6, 20e-6
+    inj.lo[2], inj.hi[2] = 0.0, 1e300
+    lib.sim_set_injection(sim._h, electrons, C.byref(inj), 1, 1)
+    la = _capi.LaserAntenna()
+    for d, v in enumerate((0.0, 0.0, -1e-6)):
+        la.position[d] = v
+    for d, v in enumerate((0.0, 0.0, 1.0)):
+        la.direction[d] = v
+    for d, v in enumerate((0.0, 1.0, 0.0)):
+        la.polarization[d] = v
+    la.e_max, la.wavelength = 16e12, 0.8e-6
+    la.waist, la.duration, la.t_peak, la.focal_distance = 12e-6, 15e-15, 30e-15, 100e-6
+    lib.sim_add_laser(sim._h, C.byref(la))
+    return sim, electrons

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from tests import pec_case
+from warpx_amd.sim import WarpXSim
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -189,3 +190,28 @@ def test_laser_acceleration_golden(oracle, which):
     sim.evolve(pec_case.L_MAX_STEP)
     check_lwfa_against_golden(_lwfa_report(oracle, sim, e))
     assert sim.particles(e).shape[1] == 69212           # 98 planes injected while the window advanced
+
+
+def test_boosted_laser_wakefield_host_layer_against_the_independent_oracle_stepper(oracle):
+    """BASELINE config 5 in small (tests/decks/laser_wakefield_boosted_3d.inputs: gamma = 5, window at c, CKC, Vay, order 3,
+    filter, NCI corrector, drifting antenna, boosted continuous injection) -- the product's host layer reading the deck
+    (on the CPU kernels) against the INDEPENDENT oracle stepper set up call by call (tests/pec_case.make_boosted_lwfa_sim:
+    its own moving window, injection front, antenna, PEC walls, NCI filter and schedule): every regression checksum at
+    the reference's 1e-9.  No golden file of the reference pins a 3-D boosted run (its boosted decks draw random beams)."""
+    from tests.oracle_lib import load_host_cpu
+    from tests.test_inputs_cpu import compare_with_golden
+    deck = os.path.join(HERE, "decks", "laser_wakefield_boosted_3d.inputs")
+    host = WarpXSim.from_inputs(load_host_cpu(), deck)
+    assert host.max_step == pec_case.BOOST_MAX_STEP
+    host.evolve(host.max_step)
+    got = host.checksum()
+    host.close()
+    sim, e = pec_case.make_boosted_lwfa_sim(oracle)
+    sim.evolve(pec_case.BOOST_MAX_STEP)
+    want = _lwfa_report(oracle, sim, e)
+    npart = sim.particles(e).shape[1]
+    sim.close()
+    got["lev=0"].pop("part_per_cell", None)
+    worst = compare_with_golden(got, want, 1e-9)
+    print("boosted wakefield deck, host layer vs oracle stepper: worst relative deviation", worst, "particles", npart)
+    assert npart > 10000

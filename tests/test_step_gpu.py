@@ -407,7 +407,7 @@ def test_particle_boundaries_golden_on_gpu(product):
     from tests import pec_case
     from tests.test_pec_golden import _boundaries_report, _check_boundaries
     sim, r, a, p = pec_case.make_boundaries_sim(product)
-    sim.evolve(pec_case.B_MAX_STEP)
+    sim.evolve(pec_case.BOOST_MAX_STEP)
     _check_boundaries(_boundaries_report(sim, (r, a, p)))
     assert sim.particles(a).shape[1] == 1
 
@@ -512,22 +512,27 @@ def test_boosted_frame_injection_through_a_moving_window_on_gpu(product):
     sim.close()
 
 
-def test_boosted_frame_laser_wakefield_deck_on_gpu(product):
-    """tests/decks/laser_wakefield_boosted_3d.inputs (BASELINE config 5 in small) on the HIP path against the same host
-    layer on the CPU kernels: every regression checksum (fields, J, rho, particle sums) at the reference's 1e-9."""
-    from tests.oracle_lib import load_host_cpu
+def test_boosted_frame_laser_wakefield_deck_on_gpu(oracle, product):
+    """tests/decks/laser_wakefield_boosted_3d.inputs (BASELINE config 5 in small, with the NCI corrector) on the HIP path
+    against the INDEPENDENT oracle stepper set up call by call (tests/pec_case.make_boosted_lwfa_sim: its own window,
+    injection front, antenna, walls, NCI filter, schedule): every regression checksum (fields, J, rho, particle sums)
+    at the reference's 1e-9.  (Round 2 compared with the same host layer on the CPU kernels only.)"""
+    from tests import pec_case
     from tests.test_inputs_cpu import compare_with_golden
+    from tests.test_pec_golden import _lwfa_report
     deck = os.path.join(HERE, "decks", "laser_wakefield_boosted_3d.inputs")
-    ref = WarpXSim.from_inputs(load_host_cpu(), deck)
-    ref.evolve(ref.max_step)
-    want = ref.checksum()
+    ref, e = pec_case.make_boosted_lwfa_sim(oracle)
+    ref.evolve(pec_case.BOOST_MAX_STEP)
+    want = _lwfa_report(oracle, ref, e)
+    npart = ref.particles(e).shape[1]
     ref.close()
     sim = WarpXSim.from_inputs(product, deck)
+    assert sim.max_step == pec_case.BOOST_MAX_STEP
     sim.evolve(sim.max_step)
     got = sim.checksum()
-    assert got["lev=0"]["part_per_cell"] == want["lev=0"]["part_per_cell"] if "part_per_cell" in want["lev=0"] else True
-    want["lev=0"].pop("part_per_cell", None)
-    compare_with_golden(got, want, 1e-9)
+    assert got["lev=0"].pop("part_per_cell") == npart
+    worst = compare_with_golden(got, want, 1e-9)
+    print("boosted wakefield deck, HIP path vs oracle stepper: worst relative deviation", worst)
     sim.close()
 
 

@@ -23,7 +23,7 @@ class WarpXSim:
                  comm: _capi.Comm | None = None, field_boundary_lo=(0, 0, 0), field_boundary_hi=(0, 0, 0),
                  particle_boundary_lo=(0, 0, 0), particle_boundary_hi=(0, 0, 0),
                  grid_type=_capi.GRID_STAGGERED, overlap_halo=0, maxwell_solver=_capi.SOLVER_YEE,
-                 use_fdtd_nci_corr=0):
+                 use_fdtd_nci_corr=0, gamma_boost=0.0):
         self.lib = lib
         self.on_device = lib.prefix == "wxa_"
         cfg = _capi.SimConfig()
@@ -52,6 +52,7 @@ class WarpXSim:
         cfg.grid_type = int(grid_type)   # collocated: CPU restatement only
         cfg.maxwell_solver = int(maxwell_solver)   # algo.maxwell_solver: SOLVER_YEE or SOLVER_CKC
         cfg.overlap_halo = int(overlap_halo)
+        cfg.gamma_boost = float(gamma_boost)   # warpx.gamma_boost (boost along z); prob_lo / prob_hi are boosted-frame values
         cfg.use_fdtd_nci_corr = int(use_fdtd_nci_corr)   # particles.use_fdtd_nci_corr: Godfrey filter on E, B before the gather
         self.cfg = cfg
         self._comm = comm  # keep the callbacks alive
