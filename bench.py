@@ -25,6 +25,8 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_CU = 256          # MI355X_MICROARCH.md: 8 XCDs x 32 CUs
+CLOCK_GHZ = 2.4     # MI355X_MICROARCH.md: peak engine clock
 
 # algorithmic bytes per unit, fp64 (SURVEY.md 8(d) / BASELINE.md section 3)
 BYTES = {
@@ -75,12 +77,12 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_FILE = os.path.join("profiles", "round2", "r2_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "round3", "r3_pmc_traffic.json")
 
 
 def pmc_traffic(args):
     """HBM bytes per launch of each phase's kernel from the committed rocprofv3 PMC passes (scripts/pmc_traffic.py ->
-    profiles/round2/r2_pmc_traffic.json; bench.py cannot collect PMC counters itself: they need their own rocprofv3
+    profiles/round3/r3_pmc_traffic.json; bench.py cannot collect PMC counters itself: they need their own rocprofv3
     runs).  Used only when the file was collected on this workload AND on these kernel sources (its `sources_sha16`
     stamp equals kernel_sources_sha()): stale counters are dropped, not shown."""
     try:
@@ -122,7 +124,10 @@ def cpu_baseline():
     """The CPU oracle (our restatement of the reference's algorithms; the reference itself cannot be built here: AMReX
     is not on disk) timed on bounded samples, SURVEY.md 8(d) protocol -- median of 5 runs of 10 steps, thread count
     stated, every phase of the step on all threads (the guard exchanges too since round 3):
-      * all host cores (OpenMP; thread-private J scratch + accumulate, as the reference's CPU path) on a 128^3 sample of
+      * all the CPUs the box grants this process (OpenMP team = affinity mask capped by the cgroup quota,
+        tests/oracle_lib.py::available_cpus -- 16 on the pool's GPU boxes, which show 256 logical CPUs; rounds 1 and 2
+        ran a team of 128-256 on those 16 and reported "cores": 128; thread-private J scratch + accumulate, as the
+        reference's CPU path) on a 128^3 sample of
         the bench workload (8 ppc, order 3, Esirkepov, Boris, filter on), with the oracle's per-phase timers;
       * one thread ("CPU serial") on BASELINE.json config 1 itself: 64^3, 1 ppc, order 1 (Examples/Tests/uniform_plasma)."""
     import statistics
@@ -426,8 +431,21 @@ def main():
             roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": k["hbm_frac"], "traffic": k.get("pmc_traffic_GB"),
                         "traffic_unit": "GB per launch; " + traffic_note,
-                        "note": "particle kernels are VALU/LDS-atomic bound, not HBM bound (SURVEY.md 8(d)); "
-                                "the HBM-bound stencils are listed under kernels"}
+                        "note": "the bench contract's roofline is the HBM one; the particle kernels sit far below it "
+                                "because they are limited by the fp64 VALU and LDS pipes (SURVEY.md 8(d), "
+                                "profiles/round3/README.md) -- see `limiter` and the floors beside it; the HBM-bound "
+                                "stencils are listed under kernels"}
+            if dominant == "CurrentDeposition" and args.deposition == "esirkepov" and args.order == 3:
+                # order 3 Esirkepov: 2 particles share one set of 4x4x4(+1) rows; 144 ds_add_f64 per pair and lane
+                # (deposit_body.hpp).  One ds_add_f64 wave-instruction occupies a CU's LDS pipe for 8 cycles when
+                # conflict-free (scripts/microbench/lds_atomic_bench.hip, profiles/round3/lds_atomic_microbench.txt).
+                wave_instr = np_local / 2 * 144 / 64
+                floor_ms = wave_instr / N_CU * 8 / (CLOCK_GHZ * 1e9) * 1e3
+                roofline["limiter"] = "fp64 VALU (shape factors, ~42 % busy) + LDS pipe (ds_add_f64, ~41 % busy)"
+                roofline["lds_atomic_floor_ms"] = floor_ms
+                roofline["lds_atomic_floor_frac"] = floor_ms / k["avg_ms"]
+            elif dominant in ("GatherAndPush", "CurrentDeposition"):
+                roofline["limiter"] = "fp64 VALU + LDS pipe"
         out = {
             "metric": "particle_steps_per_s", "value": pps, "unit": "particle-steps/s",
             "cell_updates_per_s": cps,

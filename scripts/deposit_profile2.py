@@ -35,6 +35,8 @@ print(f"variant {variant}: total workgroup-clock {tot:.3e} per {steps} launches"
 for i in range(6):
     print(f"   phase {i}: {100.0 * out[i] / tot:5.1f} %")
 print("   counters:", [int(out[i]) for i in range(8, 16)])
+if out[9]:
+    print(f"   wave 0 spends {100.0 * out[9] / out[2]:.1f} % of phase 2 in its chunk loop (the rest: waiting for the slowest wave)")
 if out[8]:   # wave 0's chunks: load wait and the rest, cycles per chunk
     print(f"   wave 0, per chunk: loads issued -> arrived {out[6] / out[8]:.0f} cycles, coordinates .. last atomic retired "
           f"{out[7] / out[8]:.0f} cycles, {out[8] / steps:.0f} chunks per launch")

@@ -1,5 +1,5 @@
 """HBM traffic per launch of the step's main kernels from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
-runs, counters only -- no tracing), written to profiles/round2/r2_pmc_traffic.json with a fingerprint of the kernel
+runs, counters only -- no tracing), written to profiles/round3/r3_pmc_traffic.json with a fingerprint of the kernel
 sources; bench.py shows the numbers only while the fingerprint matches.  Run on the GPU box from the repo root:
     python scripts/pmc_traffic.py [outdir]"""
 import csv
@@ -54,5 +54,5 @@ rec = {
                   "bytes (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as reported",
     "KiB_per_dispatch": {k: {"kernel": names.get(k, "?"), **v} for k, v in res.items() if len(v) == 2},
 }
-json.dump(rec, open(os.path.join(out, "r2_pmc_traffic.json"), "w"), indent=1)
+json.dump(rec, open(os.path.join(out, os.path.basename(PMC_TRAFFIC_FILE)), "w"), indent=1)
 print(json.dumps(rec, indent=1))

@@ -13,6 +13,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "first_gpu_run: no MI355X has executed this test yet (runs last)")
 
 
+def pytest_sessionstart(session):
+    """Thread teams sized to what the cgroup grants (tests/oracle_lib.py::available_cpus): the GPU boxes show 256 logical
+    CPUs under a quota of 16, and a team of 256 then costs 50-100x."""
+    from tests.oracle_lib import available_cpus
+    n = available_cpus()
+    for var in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(var, str(n))
+    if "OMP_NUM_THREADS" not in os.environ:
+        try:
+            import torch
+            torch.set_num_threads(n)
+        except Exception:   # noqa: BLE001 -- torch is only plumbing here
+            pass
+
+
 def pytest_collection_modifyitems(config, items):
     first = [it for it in items if it.get_closest_marker("first_gpu_run")]
     if not first:

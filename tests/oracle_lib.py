@@ -23,11 +23,41 @@ def build_oracle(force=False):
     return ORACLE_LIB
 
 
+def available_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota.  The GPU boxes show 256
+    logical CPUs under a quota of 16 (cpu.max = "1600000 100000"): an OpenMP team of 256 spinning threads on 16 CPUs'
+    worth of time made every parallel region of the oracle 50-100x slower than a team of 16 (profiles/round3/README.md)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:   # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 def load_oracle():
+    """The OpenMP team is sized to available_cpus() unless OMP_NUM_THREADS says otherwise (one libgomp per process: the
+    setting also covers tests/host_cpu, which links the same kernels)."""
     global _oracle
     if _oracle is None:
         build_oracle()
         _oracle = _capi.CLib(ORACLE_LIB, "orc_", _capi._ORACLE_SIGS)
+        if "OMP_NUM_THREADS" not in os.environ:
+            _oracle._set_num_threads(available_cpus())
     return _oracle
 
 
@@ -43,6 +73,7 @@ def load_host_cpu():
     if _host_cpu is None:
         subprocess.check_call(["make", "-C", HOST_CPU_DIR, "libhost_cpu.so"], stdout=subprocess.DEVNULL)
         _host_cpu = _capi.CLib(HOST_CPU_LIB, "hst_", _capi._INPUTS_SIGS, kernels=False)
+        load_oracle()   # sizes the OpenMP team, see available_cpus()
     return _host_cpu
 
 
@@ -67,6 +98,9 @@ def load_hip_on_cpu():
         # WXA_HIP_ON_CPU_FMA=1: the build that contracts a*b+c in the kernels like the gfx950 compiler does
         fma = os.environ.get("WXA_HIP_ON_CPU_FMA") == "1"
         lib = HIPCPU_LIB.replace(".so", "_fma.so") if fma else HIPCPU_LIB
-        subprocess.check_call(["make", "-C", HIPCPU_DIR, "-j8"] + (["FMA=1"] if fma else []), stdout=subprocess.DEVNULL)
+        if os.environ.get("WXA_HIPCPU_LIB"):   # a hand-made build, e.g. with -DWXA_DEV_VARIANTS (see tests/hipcpu/Makefile)
+            lib = os.environ["WXA_HIPCPU_LIB"]
+        else:
+            subprocess.check_call(["make", "-C", HIPCPU_DIR, "-j8"] + (["FMA=1"] if fma else []), stdout=subprocess.DEVNULL)
         _hip_on_cpu = _capi.CLib(lib, "wxa_", {**_capi._PRODUCT_SIGS, **_capi._INPUTS_SIGS}, memory="cpu:0")
     return _hip_on_cpu

@@ -106,7 +106,6 @@ def test_ckc_solver_from_the_inputs_file(lib, tmp_path):
     ("algo.maxwell_solver = psatd", "maxwell_solver"),
     ("warpx.gamma_boost = 10.", "boost_direction"),                      # the frame is on the path, its direction is mandatory
     ("warpx.gamma_boost = 10.\nwarpx.boost_direction = x", "boost must be in the z direction"),
-    ("particles.use_fdtd_nci_corr = 1", "use_fdtd_nci_corr"),
     ("boundary.field_lo = pml pml pml", "pml"),
     ("warpx.do_pml = 1", "do_pml"),
     ("amr.max_level = 1", "max_level"),

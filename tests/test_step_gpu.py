@@ -407,7 +407,7 @@ def test_particle_boundaries_golden_on_gpu(product):
     from tests import pec_case
     from tests.test_pec_golden import _boundaries_report, _check_boundaries
     sim, r, a, p = pec_case.make_boundaries_sim(product)
-    sim.evolve(pec_case.BOOST_MAX_STEP)
+    sim.evolve(pec_case.B_MAX_STEP)
     _check_boundaries(_boundaries_report(sim, (r, a, p)))
     assert sim.particles(a).shape[1] == 1
 

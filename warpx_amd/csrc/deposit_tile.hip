@@ -146,8 +146,12 @@ __device__ __forceinline__ int frame_key(int li, int lj, int lk) { return li | (
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
 template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, class ACC_ = double, int BW_ = 0,
-          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0>
+          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0>
 struct RowsCfg {
+    // DYN: the chunks of phase C are handed out through an LDS counter instead of chunk = wave + k WAVES: the SIMD's
+    // issue arbiter favours its oldest waves, so with equal static shares the youngest waves of every SIMD finish last and
+    // the others wait at the barrier (profile build: wave 0 idles 22 % of the phase, profiles/round3/README.md)
+    static constexpr int DYN = DYN_;
     // COOP: lanes l and l + 32 of a chunk (pairs r and r + 2 of one cell) share their deposits, each lane issues half the
     // LDS atomics (esirkepov_pair_phased_coop; odd orders, fp64 tiles)
     static constexpr int COOP = COOP_;
@@ -198,6 +202,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     __shared__ unsigned deferred[DEFER];
     __shared__ int ndef[NBANK];
     __shared__ int nitems;
+    __shared__ int next_chunk;
     // ... and their data, for the first DKEEP entries of every bucket: phase C has the particle in registers when it
     // defers it; fetched again by index in phase D each one costs seven cache lines from HBM (the tile's lines have left
     // the L2 by then: FETCH_SIZE 1.57 x the particle data, phase D 12 % of the kernel for 3 % of the particles)
@@ -237,7 +242,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     };
     constexpr int WAVES = NT / 64;
     // ---- A: cell counts, row masks; zero fill
-    if (tid == 0) nitems = 0;
+    if (tid == 0) { nitems = 0; next_chunk = 0; }
     if (tid < NBANK) ndef[tid] = 0;
     int my_s = 0, my_n = 0, my_pairs = 0;
     unsigned long long my_mask[RT];   // wave-uniform: tail row r of this cell-wave
@@ -295,7 +300,21 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     const int T = nitems;
     constexpr bool COOP = CFG::COOP != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && (O % 2) == 1 && sizeof(ACC) == 8;
     constexpr int TPC = COOP ? 32 : 64;   // tail items per chunk: with COOP the upper half of the wave only assists
-    for (int ch = wave; ch < NB + ((T + TPC - 1) / TPC); ch += WAVES) {   // wave-uniform
+#ifdef WXA_DEPOSIT_PROFILE
+    const long long prof_l0 = clock64();
+#endif
+    const int nchunks = NB + ((T + TPC - 1) / TPC);
+    // DYN: a wave holds the chunk it works on and has already claimed the next one (the counter's round trip through the
+    // LDS queue -- behind the other waves' atomics -- hides behind the chunk)
+    auto claim = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&next_chunk, 1);
+        return v;
+    };
+    int claimed = 0;
+    if constexpr (CFG::DYN != 0) claimed = claim();
+    for (int ch = CFG::DYN ? __builtin_amdgcn_readfirstlane(__shfl(claimed, 0)) : wave; ch < nchunks;) {   // wave-uniform
+        if constexpr (CFG::DYN != 0) claimed = claim();
         int c, r;
         bool va;
         if (ch < NB) {
@@ -355,6 +374,8 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
                             sjz.add(2, ix, iy, iz, ds.sxn[ix] * ds.syn[iy] * ds.szc[iz] * ds.wqz);
                         }
             }
+            if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
+            else ch += WAVES;
             continue;
         }
         EsirkepovCoords c1 = esirkepov_coords(pa, g, es), c2 = esirkepov_coords(pb, g, es);
@@ -438,7 +459,12 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             if (tid == 0) { DCOUNT(6, prof_c1 - prof_c0); DCOUNT(7, prof_c2 - prof_c1); DCOUNT(8, 1); }
         }
 #endif
+        if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
+        else ch += WAVES;
     }
+#ifdef WXA_DEPOSIT_PROFILE
+    if (tid == 0) DCOUNT(9, clock64() - prof_l0);   // wave 0's own time in the loop; the rest of phase 2 is its wait at the barrier
+#endif
     __syncthreads();
     DPROF(2);
     {   // ---- D: the deferred particles through the wide body, one lane per (component, particle).  A chunk of 64
@@ -573,6 +599,9 @@ using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 0, WXA_DEPOSIT_DIRECT>;   //
 using RowsB16 = RowsCfg<768, 8, 3, 1, 0, double, 16>;
 using RowsB16Coop = RowsCfg<768, 8, 3, 1, 0, double, 16, WXA_DEPOSIT_ESIRKEPOV, 1>;
 using RowsB32Coop = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 1>;
+using RowsW10 = RowsCfg<640, 8, 3, 1, 0, double, 32>;   // 30: 10 waves -- 38 chunks of a tile in 4 rounds of 10 instead of 12
+using RowsW11 = RowsCfg<704, 8, 3, 1, 0, double, 32>;   // 31: 11 waves
+using RowsDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1>;   // 40: chunks through an LDS counter
 using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
 using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
 #endif
@@ -594,6 +623,9 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                 case 14: return launch_rows<3, RowsB16>(p, J, geom, q, dt, relative_time, ws, st);
                 case 20: return launch_rows<3, RowsB16Coop>(p, J, geom, q, dt, relative_time, ws, st);
                 case 22: return launch_rows<3, RowsB32Coop>(p, J, geom, q, dt, relative_time, ws, st);
+                case 30: return launch_rows<3, RowsW10>(p, J, geom, q, dt, relative_time, ws, st);
+                case 31: return launch_rows<3, RowsW11>(p, J, geom, q, dt, relative_time, ws, st);
+                case 40: return launch_rows<3, RowsDyn>(p, J, geom, q, dt, relative_time, ws, st);
                 case 101: return launch_rows<3, RowsNoLds>(p, J, geom, q, dt, relative_time, ws, st);
                 case 102: return launch_rows<3, RowsNoAlu>(p, J, geom, q, dt, relative_time, ws, st);
                 default: break;

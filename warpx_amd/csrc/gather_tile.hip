@@ -25,7 +25,7 @@
 #define WXA_GATHER_RB 2   // rows in flight ahead of the fma chain (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
 #endif
 #ifndef WXA_GATHER_PF
-#define WXA_GATHER_PF 2   // 2: the next particle's position is requested a trip ahead, this particle's momentum at the top of its trip
+#define WXA_GATHER_PF 3   // 2: the next particle's position is requested a trip ahead, this particle's momentum at the top of its trip; 3: the same, chunks through an LDS counter
 #endif
 
 namespace wxa {
@@ -120,6 +120,20 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     // The lane's particle of the NEXT trip: loaded (volatile: the loads keep their place in front of the inline-asm LDS
     // reads) while the current one gathers, the first one before the staging, so that no trip starts by waiting for
     // HBM (counters of the kernel without it: waves parked in s_waitcnt 46 % of their cycles, VALU and LDS each < 50 %)
+    // PF == 3: PF == 2 with the 64-particle chunks of the tile handed out through an LDS counter instead of
+    // chunk = wave + k * 8 (the SIMD's arbiter favours its oldest waves; a workgroup's LDS is held until its slowest
+    // wave is done).  A wave works on one chunk, has the positions of the next one in flight and has claimed the one
+    // after that: the counter's round trip through the LDS queue hides behind a whole trip.  The first two chunks of
+    // every wave are the static ones, so no trip starts by waiting for the counter.
+    constexpr bool DYN = PF == 3;
+    constexpr bool PREFETCH = PF == 1 || PF == 2 || PF == 3;
+    constexpr int WAVES = GT_THREADS / 64;
+    __shared__ int next_chunk;
+    const int lane = tid & 63;
+    int cb_next = start + 64 * __builtin_amdgcn_readfirstlane(tid >> 6) + GT_THREADS;   // wave-uniform: first particle of the next chunk
+    if constexpr (DYN) {
+        if (tid == 0) next_chunk = 2 * WAVES;   // visible after the staging barrier below
+    }
     int ip = start + tid;
     double nxt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     // plain loads between two compiler fences: they stay where they are written (in front of the inline-asm LDS reads) and
@@ -130,7 +144,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         if constexpr (PF == 1) { nxt[3] = p.ux[i]; nxt[4] = p.uy[i]; nxt[5] = p.uz[i]; }
         asm volatile("" ::: "memory");
     };
-    if constexpr (PF == 1 || PF == 2) {
+    if constexpr (PREFETCH) {
         if (ip < end) load_particle(ip);
     }
     constexpr int PER = (NPTS + GT_THREADS - 1) / GT_THREADS;
@@ -167,18 +181,29 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     GPROF_ADD(0, prof_t1 - prof_t0);
     GPROF_ADD(2, 1);
 
-    for (; ip < end; ip += GT_THREADS) {
+    int claimed = 0;
+    // next trip: static shares, or the chunk claimed a trip ago (lane 0 is in the loop whenever any lane of the wave is:
+    // it holds the chunk's first particle)
+    auto advance = [&]() {
+        ip = cb_next + lane;
+        if constexpr (DYN) cb_next = start + 64 * __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
+        else cb_next += GT_THREADS;
+    };
+    for (; ip < end; advance()) {
         GPROF_CLOCK(prof_a);
         double xp, yp, zp, ux0, uy0, uz0;
-        if constexpr (PF == 1 || PF == 2) {
+        if constexpr (PREFETCH) {
             xp = nxt[0]; yp = nxt[1]; zp = nxt[2];
             if constexpr (PF == 1) { ux0 = nxt[3]; uy0 = nxt[4]; uz0 = nxt[5]; }
-            else {   // PF == 2: this particle's momentum is requested now and used after the gather
+            else {   // PF == 2, 3: this particle's momentum is requested now and used after the gather
                 asm volatile("" ::: "memory");
                 ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip];
                 asm volatile("" ::: "memory");
             }
-            if (ip + GT_THREADS < end) load_particle(ip + GT_THREADS);
+            if constexpr (DYN) {
+                if (lane == 0) claimed = atomicAdd(&next_chunk, 1);
+            }
+            if (cb_next + lane < end) load_particle(cb_next + lane);
         } else {
             xp = p.x[ip]; yp = p.y[ip]; zp = p.z[ip];
         }
@@ -215,7 +240,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(prof_e));
 #endif
         GPROF_CLOCK(prof_c);
-        if constexpr (PF != 1 && PF != 2) { ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip]; }
+        if constexpr (!PREFETCH) { ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip]; }
         if constexpr (PF == 7) {   // timing experiment (dev builds): everything but the stores
             double ex_ = Exp, ey_ = Eyp, ez_ = Ezp, bx_ = Bxp, by_ = Byp, bz_ = Bzp;
             add_external_fields(ext, ip, ex_, ey_, ez_, bx_, by_, bz_);
@@ -298,6 +323,8 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         if (pf == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 1>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 2) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 2>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        else if (pf == 3) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 7) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 7>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
