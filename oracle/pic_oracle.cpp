@@ -431,7 +431,11 @@ void deposit_impl(const wxa_particle_view* p, const wxa_field_view J[3], const w
     // Thread-private J scratch + accumulate (WarpXParticleContainer.cpp:455-470,819-826).  Each
     // thread takes a contiguous particle range; its scratch only spans the k-planes that range can
     // touch (the range's z extent + the stencil reach), so memory stays bounded on many-core hosts.
+    // The scratch arrays are added to J plane by plane in thread order (not with atomics in arrival
+    // order): for a given number of threads the result is reproducible bit for bit, which the tests
+    // that compare two schedules by checksum rely on.
     const int reach = O + 3;
+    std::vector<PrivJ> priv((size_t)nt);
 #pragma omp parallel
     {
 #ifdef _OPENMP
@@ -440,30 +444,33 @@ void deposit_impl(const wxa_particle_view* p, const wxa_field_view J[3], const w
         const int t = 0, T = 1;
 #endif
         const int64_t b = p->np * t / T, e = p->np * (t + 1) / T;
+        PrivJ& pj = priv[(size_t)t];
+        for (int c = 0; c < 3; ++c) { pj.v[c] = J[c]; pj.v[c].n[2] = 0; }
         if (e > b) {
             double zmin = p->z[b], zmax = p->z[b];
             for (int64_t i = b; i < e; ++i) { zmin = std::min(zmin, p->z[i]); zmax = std::max(zmax, p->z[i]); }
             int k0 = g->lo[2] + (int)std::floor((zmin - g->xyzmin[2]) * g->dinv[2]) - reach;
             int k1 = g->lo[2] + (int)std::floor((zmax - g->xyzmin[2]) * g->dinv[2]) + reach + 1;
-            PrivJ pj;
             for (int c = 0; c < 3; ++c) {
                 const int lo = std::max(k0, J[c].lo[2]), hi = std::min(k1, J[c].lo[2] + J[c].n[2]);
-                pj.v[c] = J[c];
                 pj.v[c].lo[2] = lo;
                 pj.v[c].n[2] = std::max(hi - lo, 0);
                 pj.buf[c].assign((size_t)J[c].kstride * pj.v[c].n[2], 0.0);
                 pj.v[c].p = pj.buf[c].data();
             }
             deposit_range<O>(p, b, e, pj.v, g, q, dt, rel, algo);
-            for (int c = 0; c < 3; ++c) {
-                const size_t n = pj.buf[c].size();
-                double* dst = J[c].p + (size_t)(pj.v[c].lo[2] - J[c].lo[2]) * J[c].kstride;
-                const double* src = pj.buf[c].data();
-                for (size_t i = 0; i < n; ++i) {
-                    if (src[i] != 0.0) {
-#pragma omp atomic
-                        dst[i] += src[i];
-                    }
+        }
+#pragma omp barrier
+        for (int c = 0; c < 3; ++c) {
+            const size_t plane = (size_t)J[c].kstride;
+#pragma omp for schedule(static)
+            for (int k = J[c].lo[2]; k < J[c].lo[2] + J[c].n[2]; ++k) {
+                double* dst = J[c].p + (size_t)(k - J[c].lo[2]) * plane;
+                for (int tt = 0; tt < T; ++tt) {
+                    const PrivJ& src_j = priv[(size_t)tt];
+                    if (k < src_j.v[c].lo[2] || k >= src_j.v[c].lo[2] + src_j.v[c].n[2]) continue;
+                    const double* src = src_j.buf[c].data() + (size_t)(k - src_j.v[c].lo[2]) * plane;
+                    for (size_t i = 0; i < plane; ++i) dst[i] += src[i];
                 }
             }
         }
