@@ -541,6 +541,89 @@ def test_gather_push_lds_tiles(oracle, product, order, galerkin, stale):
     product.workspace_destroy(ws)
 
 
+@pytest.mark.skipif("dev" not in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", "") + os.environ.get("WXA_HIPCPU_LIB", "")),
+                    reason="the fused kernel was measured and not adopted: -DWXA_DEV_VARIANTS builds only")
+@pytest.mark.parametrize("pusher", [_capi.PUSHER_BORIS, _capi.PUSHER_VAY])
+@pytest.mark.parametrize("stale,u_scale,tail", [(False, 1.0, 0), (True, 1.0, 0), (False, 0.003, 500), (True, 30.0, 500)])
+def test_push_and_deposit_in_one_kernel(oracle, product, pusher, stale, u_scale, tail):
+    """wxa_debug_push_and_deposit (dev builds: PhysicalParticleContainer::Evolve's PushPX + DepositCurrent,
+    PhysicalParticleContainer.cpp:1812-2095, on the LDS tiles as ONE kernel -- order 3, energy-conserving gather, Esirkepov;
+    30 % slower than the two kernels on the MI355X, profiles/round3/README.md) against the oracle's two
+    calls and against the product's own two kernels: pushed particles at 1e-12, J at 1e-12 of max|J| per component.
+    `stale` moves the particles after the sort (gather and deposit stencils leave the staged tiles: both straggler lists);
+    u_scale = 30 makes most particles cross a cell (deferred list, read back after the push); `tail` particles are
+    appended behind the sorted part (global-memory kernels)."""
+    import torch
+    order, galerkin = 3, 1
+    ncell = (24, 20, 16)
+    ng, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, ng, 10, scale=1e9)
+    B = H.random_fields(("Bx", "By", "Bz"), ncell, ng, 11, scale=10.0)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    nsorted = 60000
+    parts = H.random_particles(nsorted + tail, ncell, 911, u_scale=u_scale)
+    dx = H.LX / np.asarray(ncell)
+    pd0 = ParticleArrays.from_numpy([a[:nsorted] for a in parts], DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    srt = ParticleArrays(nsorted + tail, DEV)
+    head = srt.view
+    head.np = nsorted   # the sort fills the first nsorted slots; the rest of the arrays is the appended tail
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(head), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    if stale:
+        rng = np.random.default_rng(6)
+        for d in range(3):
+            srt.data[d][:nsorted] += torch.from_numpy(dx[d] * 0.9 * (2 * rng.random(nsorted) - 1)).to(DEV)
+            srt.data[d][:nsorted].clamp_(-H.LX / 2, H.LX / 2 - 1e-12)
+    if tail:
+        for row in range(7):
+            srt.data[row][nsorted:] = torch.from_numpy(parts[row][nsorted:]).to(DEV)
+    start = [a.copy() for a in srt.to_numpy()]
+    ph = ParticleArrays.from_numpy(start, "cpu")
+    ge, _ = H.geom_for(ncell, ng)
+    gj, _ = H.geom_for(ncell, ng_depos)
+    dt = H.yee_dt(dx)
+    q, m = -plasma.Q_E, plasma.M_E
+    Jo = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    oracle.gather_push(C.byref(ph.view), field_triplet(E), field_triplet(B), C.byref(ge), q, m, dt, order, galerkin,
+                       pusher, None)
+    oracle.deposit_current(C.byref(ph.view), field_triplet(Jo), C.byref(gj), q, dt, -0.5 * dt, order,
+                           _capi.DEPOSIT_ESIRKEPOV, None, None)
+    # the product's two kernels on a copy of the same start
+    two = ParticleArrays.from_numpy(start, DEV)
+    J2 = H.clone_fields(Jo, DEV, True)
+    for f in J2:
+        f.storage.zero_()
+    # (the workspace describes `srt`; the two-kernel reference path runs on the global-memory kernels)
+    product.gather_push_ws(C.byref(two.view), field_triplet(Ed), field_triplet(Bd), C.byref(ge), q, m, dt, order, galerkin,
+                           pusher, 1, None, None)
+    product.deposit_current(C.byref(two.view), field_triplet(J2), C.byref(gj), q, dt, -0.5 * dt, order,
+                            _capi.DEPOSIT_ESIRKEPOV, None, None)
+    J1 = H.clone_fields(Jo, DEV, True)
+    for f in J1:
+        f.storage.zero_()
+    fused = product._dll.wxa_debug_push_and_deposit
+    fused.restype = C.c_int
+    fused.argtypes = [_capi._PPV, _capi._FV3, _capi._FV3, _capi._FV3, _capi._PGG, _capi._PGG, C.c_double, C.c_double,
+                      C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert fused(C.byref(srt.view), field_triplet(Ed), field_triplet(Bd), field_triplet(J1), C.byref(ge), C.byref(gj), q, m,
+                 dt, -0.5 * dt, order, galerkin, pusher, _capi.DEPOSIT_ESIRKEPOV, ws, None) == 0
+    _sync(product)
+    a, b, c = srt.to_numpy(), ph.to_numpy(), two.to_numpy()
+    for row in range(7):
+        assert H.max_rel_err(a[row], b[row]) < 1e-12, ("oracle", row)
+        assert H.max_rel_err(a[row], c[row]) < 1e-13, ("two kernels", row)
+    for f1, f2, fo in zip(J1, J2, Jo):
+        v1, v2, vo = f1.to_numpy(), f2.to_numpy(), fo.to_numpy()
+        scale = np.max(np.abs(vo))
+        assert scale > 0
+        assert np.max(np.abs(v1 - vo)) <= 1e-12 * scale
+        assert np.max(np.abs(v1 - v2)) <= 1e-12 * scale
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.skipif(H.HIP_ON_CPU, reason="wraps a device pointer in a torch CUDA tensor")
 def test_device_pointer_wrapping(product):
     """The torch.distributed transport wraps raw device pointers handed out by the C++ host layer

@@ -19,6 +19,7 @@
 // domain before the periodic wrap) are queued and deposited with global atomics by a second kernel, so correctness
 // never depends on the sort being fresh.  DESIGN.md section 3 has the measurements behind each step.
 #include "deposit_body.hpp"
+#include "gather_body.hpp"
 #include "workspace.hpp"
 
 #include <stdlib.h>
@@ -130,6 +131,23 @@ struct StragglerQueue {
 
 __device__ __forceinline__ int frame_key(int li, int lj, int lk) { return li | (lj << 4) | (lk << 8); }
 
+// CFG::FUSED: PhysicalParticleContainer::Evolve (PhysicalParticleContainer.cpp:1812-2095) on a tile in one kernel -- the
+// chunk loop gathers E and B for its two particles from a staged tile of the six field components (the gather tile
+// kernel's 6 x 11^3 doubles), pushes them, stores position and momentum, and deposits the pair from registers: the
+// deposition's re-read of the particles (56 B of the 164 B per particle and step) and its exposed load latency are gone.
+// LDS: 89 KB J tile + 64 KB field tile + tables = 158 KB, so the deferred particles are not kept in LDS (they are read
+// back after the chunk loop's barrier) and their list is half as long.  Order 3 with the energy-conserving gather only.
+struct FusedArgs {
+    PV p;                                // the same arrays as px .. puz, writable
+    DevF Ex, Ey, Ez, Bx, By, Bz;
+    Geom gg;                             // geometry of the E / B arrays (the gather's index origin)
+    double m, dt;
+    StragglerQueue gq;                   // particles whose gather stencil leaves the staged tile: pushed AND deposited later
+};
+constexpr int FUSED_GN = TS + 3;         // staged field points per direction (gather_tile.hip, GatherTileDims<1>)
+constexpr int FUSED_GLO = -1;
+constexpr int FUSED_GNPTS = FUSED_GN * FUSED_GN * FUSED_GN;
+
 // ---- Esirkepov on LDS tiles, work items from the cell counts ----------------------------------------------------------
 // The cell sort already says where every cell's particles are (offsets[]), so the work items -- (cell, r) = the cell's
 // particles (2 r, 2 r + 1) -- follow from the cell counts alone, without looking at a particle:
@@ -146,8 +164,9 @@ __device__ __forceinline__ int frame_key(int li, int lj, int lk) { return li | (
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
 template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, class ACC_ = double, int BW_ = 0,
-          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0>
+          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0, int FUSED_ = 0, int PUSHER_ = WXA_PUSHER_BORIS>
 struct RowsCfg {
+    static constexpr int FUSED = FUSED_, PUSHER = PUSHER_;   // gather + push inside the chunk loop (FusedArgs)
     // DYN: the chunks of phase C are handed out through an LDS counter instead of chunk = wave + k WAVES: the SIMD's
     // issue arbiter favours its oldest waves, so with equal static shares the youngest waves of every SIMD finish last and
     // the others wait at the barrier (profile build: wave 0 idles 22 % of the phase, profiles/round3/README.md)
@@ -171,13 +190,22 @@ struct NullSink {   // DBG = 1: keeps every deposited value alive without touchi
 
 template <int O, int M, class CFG>
 __global__ void __launch_bounds__(CFG::NT) WXA_WAVES_PER_SIMD(CFG::WPE)
-deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict__ py,
-                         const double* __restrict__ pz, const double* __restrict__ pw,
-                         const double* __restrict__ pux, const double* __restrict__ puy,
-                         const double* __restrict__ puz, const int* __restrict__ offsets, DevF Jx, DevF Jy,
+deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restrict__ py_,
+                         const double* __restrict__ pz_, const double* __restrict__ pw_,
+                         const double* __restrict__ pux_, const double* __restrict__ puy_,
+                         const double* __restrict__ puz_, const int* __restrict__ offsets, DevF Jx, DevF Jy,
                          DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, double relative_time,
-                         StragglerQueue sq) {
+                         StragglerQueue sq, FusedArgs fa) {
     constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
+    constexpr bool FUSED = CFG::FUSED != 0;
+    static_assert(!FUSED || (O == 3 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && CFG::TSZ == TS && sizeof(typename CFG::ACC) == 8),
+                  "the fused kernel: order 3, Esirkepov, whole tiles, fp64 tiles");
+    const double *px, *py, *pz, *pw, *pux, *puy, *puz;
+    if constexpr (FUSED) {   // every access goes through the writable views (the const restrict parameters stay unused)
+        px = fa.p.x; py = fa.p.y; pz = fa.p.z; pw = fa.p.w; pux = fa.p.ux; puy = fa.p.uy; puz = fa.p.uz;
+    } else {
+        px = px_; py = py_; pz = pz_; pw = pw_; pux = pux_; puy = puy_; puz = puz_;
+    }
     using TD = TileDims<M, TSZ>;
     constexpr int N = TD::N, NZ = TD::NZ, NPTS = TD::NPTS, PS = TD::PS;
     constexpr int SUB = TS / TSZ;
@@ -189,7 +217,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     constexpr int RT = 64 / CW;                    // rows of the tail table (pairs 4 .. 3 + RT): RT CW = 64 counts = one wave scan
     constexpr int RMAX = 4 + RT;
     constexpr int TCAP = CELLS * 2;                // tail capacity (8 ppc: 0.66 tail items per cell on average)
-    constexpr int DEFER = TSZ == 8 ? 2048 : 1024;
+    constexpr int DEFER = TSZ == 8 && !FUSED ? 2048 : 1024;
     static_assert(NT >= CELLS && RT >= 8, "one lane per cell");
     __shared__ ACC lds[3 * NPTS];
     __shared__ unsigned long long masks[RT][CW];
@@ -206,8 +234,9 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
     // ... and their data, for the first DKEEP entries of every bucket: phase C has the particle in registers when it
     // defers it; fetched again by index in phase D each one costs seven cache lines from HBM (the tile's lines have left
     // the L2 by then: FETCH_SIZE 1.57 x the particle data, phase D 12 % of the kernel for 3 % of the particles)
-    constexpr int DKEEP = sizeof(ACC) == 8 ? 48 : 16;   // 16 x 48 x 56 B = 42 KB next to the 89 KB tile
-    __shared__ double dkeep[7][NBANK * DKEEP];
+    constexpr int DKEEP = FUSED ? 0 : sizeof(ACC) == 8 ? 48 : 16;   // 16 x 48 x 56 B = 42 KB next to the 89 KB tile
+    __shared__ double dkeep[7][FUSED ? 1 : NBANK * DKEEP];
+    __shared__ double F[FUSED ? 6 * FUSED_GNPTS : 1];   // FUSED: Ex Ey Ez Bx By Bz of the tile + halo
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
     if (unit >= ntiles * SUB) return;
@@ -225,6 +254,12 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         const int n = atomicAdd(&ndef[bank], 1);
         if (n < DCAP) deferred[bank * DCAP + n] = (unsigned)ip | 0x80000000u;
         else sq.push(ip);
+    };
+    // phase B's overflow cases never pass through the chunk loop: the fused kernel, which pushes there, hands them to the
+    // straggler kernels (push + deposit) instead
+    auto defer_unloaded = [&](const int ip, const int bank) {
+        if constexpr (FUSED) fa.gq.push(ip);
+        else defer(ip, bank);
     };
     auto defer_particle = [&](const int ip, const int bank, const ParticleState& pp) {
         const int n = atomicAdd(&ndef[bank], 1);
@@ -259,6 +294,34 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         }
     }
     for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = (ACC)0;
+    if constexpr (FUSED) {
+        // the six staggered components of the tile + halo, all of a lane's loads in flight before its first LDS write
+        const int ti_ = (int)(tile % tg.nt[0]), tj_ = (int)((tile / tg.nt[0]) % tg.nt[1]);
+        const int tk_ = (int)(tile / ((long)tg.nt[0] * tg.nt[1]));
+        const int q0 = tg.cell_lo[0] + ti_ * TS + FUSED_GLO, q1 = tg.cell_lo[1] + tj_ * TS + FUSED_GLO;
+        const int q2 = tg.cell_lo[2] + tk_ * TS + FUSED_GLO;
+        constexpr int GN = FUSED_GN, PER = (FUSED_GNPTS + NT - 1) / NT;
+        auto fetch = [&](const DevF& f, double (&r)[PER]) {
+#pragma unroll
+            for (int n = 0; n < PER; ++n) {
+                const int a = tid + n * NT;
+                const int i = q0 + a % GN, j = q1 + (a / GN) % GN, k = q2 + a / (GN * GN);
+                const bool in = a < FUSED_GNPTS && i >= f.lo0 && i < f.lo0 + f.n0 && j >= f.lo1 && j < f.lo1 + f.n1 &&
+                                k >= f.lo2 && k < f.lo2 + f.n2;
+                r[n] = in ? f.p[f.off(i, j, k)] : 0.0;
+            }
+        };
+        auto put = [&](int c, const double (&r)[PER]) {
+#pragma unroll
+            for (int n = 0; n < PER; ++n) {
+                const int a = tid + n * NT;
+                if (a < FUSED_GNPTS) F[c * FUSED_GNPTS + a] = r[n];
+            }
+        };
+        double r0[PER], r1[PER], r2[PER], r3[PER], r4[PER], r5[PER];
+        fetch(fa.Ex, r0); fetch(fa.Ey, r1); fetch(fa.Ez, r2); fetch(fa.Bx, r3); fetch(fa.By, r4); fetch(fa.Bz, r5);
+        put(0, r0); put(1, r1); put(2, r2); put(3, r3); put(4, r4); put(5, r5);
+    }
     __syncthreads();
     DPROF(0);
     // ---- B: scan of the 64 (row, cell-wave) counts, item table
@@ -281,12 +344,12 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
                 const int at = base + __popcll(my_mask[r] & lt);
                 if (at < TCAP) table[at] = (unsigned short)(tid | ((4 + r) << 9));
                 else {   // any bucket is correct; the cell's place in the sort order is the bank of a particle that stayed
-                    defer(my_s + 2 * (4 + r), tid & (NBANK - 1));
-                    if (2 * (4 + r) + 1 < my_n) defer(my_s + 2 * (4 + r) + 1, tid & (NBANK - 1));
+                    defer_unloaded(my_s + 2 * (4 + r), tid & (NBANK - 1));
+                    if (2 * (4 + r) + 1 < my_n) defer_unloaded(my_s + 2 * (4 + r) + 1, tid & (NBANK - 1));
                 }
             }
         }
-        for (int k = 2 * RMAX; k < my_n; ++k) defer(my_s + k, tid & (NBANK - 1));   // beyond the table's rows (> 2 RMAX particles in a cell)
+        for (int k = 2 * RMAX; k < my_n; ++k) defer_unloaded(my_s + k, tid & (NBANK - 1));   // beyond the table's rows (> 2 RMAX particles in a cell)
     }
     __syncthreads();
     DPROF(1);
@@ -328,14 +391,14 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
         const int s0 = cstart[c], n0 = cstart[c + 1] - s0;
         va = va && 2 * r < n0;
         const int ia = va ? s0 + 2 * r : start;
-        const bool vb = va && 2 * r + 1 < n0;
+        bool vb = va && 2 * r + 1 < n0;
         const int ib = vb ? ia + 1 : ia;
         // all fourteen loads in flight together (an empty lane reads the tile's first particle)
 #ifdef WXA_DEPOSIT_PROFILE
         const long long prof_c0 = clock64();
 #endif
-        const ParticleState pa{px[ia], py[ia], pz[ia], pw[ia], pux[ia], puy[ia], puz[ia]};
-        const ParticleState pb{px[ib], py[ib], pz[ib], pw[ib], pux[ib], puy[ib], puz[ib]};
+        ParticleState pa{px[ia], py[ia], pz[ia], pw[ia], pux[ia], puy[ia], puz[ia]};
+        ParticleState pb{px[ib], py[ib], pz[ib], pw[ib], pux[ib], puy[ib], puz[ib]};
 #ifdef WXA_DEPOSIT_PROFILE   // wave 0 of every workgroup: cycles from the loads' issue to their arrival, and of the whole chunk
         long long prof_c1 = 0;
         if (wave == 0) {
@@ -343,6 +406,38 @@ deposit_tile_rows_kernel(const double* __restrict__ px, const double* __restrict
             prof_c1 = clock64();
         }
 #endif
+        if constexpr (FUSED) {
+            // PushPX (PhysicalParticleContainer.cpp:2687-2785) of the lane's two particles from the staged field tile;
+            // a particle whose gather stencil leaves the tile is pushed and deposited by the straggler kernels
+            constexpr int GN = FUSED_GN, G1 = FUSED_GNPTS;
+            const int q0 = o0 - TD::LO + FUSED_GLO, q1 = o1 - TD::LO + FUSED_GLO, q2 = o2 - TD::LO + FUSED_GLO;
+            auto push_one = [&](ParticleState& pp, const int ip) -> bool {
+                GatherShapes<O, 1> sh;
+                gather_shapes<O, 1>(pp.x, pp.y, pp.z, fa.gg, sh);
+                constexpr int NN = O + 1, NC = O;
+                const int lo_i = min(sh.jn, sh.jc) - q0, hi_i = max(sh.jn + NN, sh.jc + NC) - 1 - q0;
+                const int lo_j = min(sh.kn, sh.kc) - q1, hi_j = max(sh.kn + NN, sh.kc + NC) - 1 - q1;
+                const int lo_k = min(sh.ln, sh.lc) - q2, hi_k = max(sh.ln + NN, sh.lc + NC) - 1 - q2;
+                if (!(lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < GN && hi_j < GN && hi_k < GN)) return false;
+                const int jn = sh.jn - q0, jc = sh.jc - q0, kn = sh.kn - q1, kc = sh.kc - q1, ln = sh.ln - q2, lc = sh.lc - q2;
+#define WXA_FROWS(...) gather_rows_lds<__VA_ARGS__, GN, GN * GN, 2>
+                double Exp = WXA_FROWS(NC, NN, NN)(F + 0 * G1 + jc + GN * (kn + GN * ln), sh.sxc, sh.syn, sh.szn);
+                double Eyp = WXA_FROWS(NN, NC, NN)(F + 1 * G1 + jn + GN * (kc + GN * ln), sh.sxn, sh.syc, sh.szn);
+                double Ezp = WXA_FROWS(NN, NN, NC)(F + 2 * G1 + jn + GN * (kn + GN * lc), sh.sxn, sh.syn, sh.szc);
+                double Bzp = WXA_FROWS(NC, NC, NN)(F + 5 * G1 + jc + GN * (kc + GN * ln), sh.sxc, sh.syc, sh.szn);
+                double Byp = WXA_FROWS(NC, NN, NC)(F + 4 * G1 + jc + GN * (kn + GN * lc), sh.sxc, sh.syn, sh.szc);
+                double Bxp = WXA_FROWS(NN, NC, NC)(F + 3 * G1 + jn + GN * (kc + GN * lc), sh.sxn, sh.syc, sh.szc);
+#undef WXA_FROWS
+                WXA_OPAQUE_F64(Exp); WXA_OPAQUE_F64(Eyp); WXA_OPAQUE_F64(Ezp); WXA_OPAQUE_F64(Bxp); WXA_OPAQUE_F64(Byp); WXA_OPAQUE_F64(Bzp);
+                push_momentum<CFG::PUSHER>(pp.ux, pp.uy, pp.uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, fa.m, fa.dt);
+                update_position(pp.x, pp.y, pp.z, pp.ux, pp.uy, pp.uz, fa.dt);
+                fa.p.ux[ip] = pp.ux; fa.p.uy[ip] = pp.uy; fa.p.uz[ip] = pp.uz;
+                fa.p.x[ip] = pp.x; fa.p.y[ip] = pp.y; fa.p.z[ip] = pp.z;
+                return true;
+            };
+            if (va && !push_one(pa, ia)) { fa.gq.push(ia); va = false; }
+            if (vb && !push_one(pb, ib)) { fa.gq.push(ib); vb = false; }
+        }
         if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT) {
             // doDepositionShapeN (CurrentDeposition.H:48-249) on the tile: the lane's two particles one after the other,
             // each component on its own frame (jx: cell-centred in x, nodal in y and z; ...), products in the
@@ -578,7 +673,7 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
     hipLaunchKernelGGL((deposit_tile_rows_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, relative_time, sq);
+                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, relative_time, sq, FusedArgs{});
     hipLaunchKernelGGL((deposit_stragglers_kernel<O, CFG::ALGO>), dim3(512), dim3(256), 0, st, p->x, p->y,
                        p->z, p->w, p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
     WXA_LAUNCH_CHECK();
@@ -604,6 +699,70 @@ using RowsW11 = RowsCfg<704, 8, 3, 1, 0, double, 32>;   // 31: 11 waves
 using RowsDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1>;   // 40: chunks through an LDS counter
 using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
 using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
+#endif
+
+#ifdef WXA_DEV_VARIANTS   // measured and not adopted (wxa_debug_push_and_deposit, particles.hip): 14.8 ms against 4.7 + 6.8
+// PushPX + DepositCurrent of the sorted part of a tile in one kernel (CFG::FUSED), then the two straggler lists: particles
+// whose gather stencil left the staged field tile (pushed, then deposited) and pushed particles whose deposit left the J tile.
+using RowsFusedBoris = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 1, WXA_PUSHER_BORIS>;
+using RowsFusedVay = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 1, WXA_PUSHER_VAY>;
+
+bool push_deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p, int order, int galerkin, int pusher,
+                                 int algo) {
+    if (!deposit_tile_available(ws, p) || order != 3 || !galerkin || algo != WXA_DEPOSIT_ESIRKEPOV) return false;
+    if (pusher != WXA_PUSHER_BORIS && pusher != WXA_PUSHER_VAY) return false;
+    if (ws->deposit_accumulator != WXA_ACC_FP64 || ws->lens_n > 0) return false;
+    for (int c = 0; c < 6; ++c)
+        if (ws->ext_eb[c] != 0.0) return false;
+    return true;
+}
+
+template <class CFG>
+static wxa_status launch_fused(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                               const wxa_field_view J[3], const wxa_grid_geom* geom_eb, const wxa_grid_geom* geom_j, double q,
+                               double m, double dt, double relative_time, wxa_workspace* ws, hipStream_t st) {
+    TileGeom tg;
+    for (int d = 0; d < 3; ++d) {
+        tg.nt[d] = (ws->sort_nc[d] + TS - 1) / TS;
+        tg.cell_lo[d] = ws->sort_cell_lo[d];
+    }
+    const long nunits = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
+    const Geom g = make_geom(*geom_j);
+    const int* offsets = (const int*)ws->offsets.p;
+    const dim3 grid((unsigned)xcd_grid_size(nunits)), block(CFG::NT);
+    wxa_status rc;
+    if ((rc = ws->stragglers.reserve(2 * (sizeof(int) * (size_t)p->np + 64))) != WXA_OK) return rc;
+    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
+    StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
+    FusedArgs fa;
+    fa.p = make_pv(*p);
+    fa.Ex = make_devf(E[0]); fa.Ey = make_devf(E[1]); fa.Ez = make_devf(E[2]);
+    fa.Bx = make_devf(B[0]); fa.By = make_devf(B[1]); fa.Bz = make_devf(B[2]);
+    fa.gg = make_geom(*geom_eb);
+    fa.m = m; fa.dt = dt;
+    fa.gq = StragglerQueue{(int*)ws->stragglers.p + p->np + 16, (unsigned*)ws->counters.p + 16};
+    WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
+    WXA_HIP_CHECK(hipMemsetAsync(fa.gq.count, 0, sizeof(unsigned), st));
+    const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
+    const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
+    hipLaunchKernelGGL((deposit_tile_rows_kernel<3, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
+                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, relative_time, sq, fa);
+    // the particles the tile kernel could not push: global-memory gather + push, then their deposit
+    if ((rc = gather_push_listed(p, fa.gq.idx, fa.gq.count, E, B, geom_eb, q, m, dt, CFG::PUSHER, st)) != WXA_OK) return rc;
+    hipLaunchKernelGGL((deposit_stragglers_kernel<3, WXA_DEPOSIT_ESIRKEPOV>), dim3(512), dim3(256), 0, st, p->x, p->y,
+                       p->z, p->w, p->ux, p->uy, p->uz, fa.gq.idx, fa.gq.count, jx, jy, jz, g, q, es, relative_time);
+    hipLaunchKernelGGL((deposit_stragglers_kernel<3, WXA_DEPOSIT_ESIRKEPOV>), dim3(512), dim3(256), 0, st, p->x, p->y,
+                       p->z, p->w, p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status push_deposit_tiled(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                              const wxa_field_view J[3], const wxa_grid_geom* geom_eb, const wxa_grid_geom* geom_j, double q,
+                              double m, double dt, double relative_time, int pusher, wxa_workspace* ws, hipStream_t st) {
+    if (pusher == WXA_PUSHER_VAY) return launch_fused<RowsFusedVay>(p, E, B, J, geom_eb, geom_j, q, m, dt, relative_time, ws, st);
+    return launch_fused<RowsFusedBoris>(p, E, B, J, geom_eb, geom_j, q, m, dt, relative_time, ws, st);
+}
 #endif
 
 wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,

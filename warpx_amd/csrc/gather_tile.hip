@@ -279,6 +279,26 @@ gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned*
     }
 }
 
+#ifdef WXA_DEV_VARIANTS   // for the fused kernel's stragglers (deposit_tile.hip, dev builds)
+wxa_status gather_push_listed(const wxa_particle_view* p, const int* idx, const unsigned* count, const wxa_field_view E[3],
+                              const wxa_field_view B[3], const wxa_grid_geom* geom, double q, double m, double dt, int pusher,
+                              hipStream_t st) {
+    const PV pv = make_pv(*p);
+    const Geom g = make_geom(*geom);
+    const DevF ex = make_devf(E[0]), ey = make_devf(E[1]), ez = make_devf(E[2]);
+    const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
+    const ExtEB ext{};
+    if (pusher == WXA_PUSHER_VAY)
+        hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, WXA_PUSHER_VAY, true>), dim3(512), dim3(256), 0, st, pv, idx,
+                           count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);
+    else
+        hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, WXA_PUSHER_BORIS, true>), dim3(512), dim3(256), 0, st, pv, idx,
+                           count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+#endif
+
 bool gather_tile_available(const wxa_workspace* ws, const wxa_particle_view* p) {
     return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np <= p->np;
 }

@@ -719,6 +719,39 @@ wxa_status wxa_push_p(const wxa_particle_view* p, const wxa_field_view E[3], con
     return wxa_gather_push_ws(p, E, B, geom, q, m, dt, order, galerkin, pusher, 0, nullptr, stream);
 }
 
+#ifdef WXA_DEV_VARIANTS
+// Measurement only (dev builds; scripts/fused_timing.py, tests/test_kernels_gpu.py::test_push_and_deposit_in_one_kernel):
+// PhysicalParticleContainer::Evolve's PushPX + DepositCurrent (PhysicalParticleContainer.cpp:1812-2095) of the sorted part
+// of a tile as ONE kernel over the LDS tiles (deposit_tile.hip, CFG::FUSED) -- order 3, energy-conserving gather,
+// Esirkepov, Boris or Vay, fp64 tiles, no external particle fields; the two calls one after the other otherwise.
+// Correct, and 30 % slower than the two kernels (profiles/round3/README.md): not in the C-ABI, not used by the host layer.
+wxa_status wxa_debug_push_and_deposit(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
+                                const wxa_field_view J[3], const wxa_grid_geom* geom_eb, const wxa_grid_geom* geom_j,
+                                double q, double m, double dt, double relative_time, int order, int galerkin, int pusher,
+                                int algo, wxa_workspace* ws, void* stream) {
+    wxa_status rc = check_gather_args(p, E, B, geom_eb, order, galerkin, pusher);
+    if (rc != WXA_OK) return rc;
+    WXA_REQUIRE(J && geom_j, "null argument");
+    if (p->np == 0) return WXA_OK;
+    if (ws && dt > 0.0 && yee_E(J) && push_deposit_tile_available(ws, p, order, galerkin, pusher, algo)) {
+        for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(J[c]), "bad field view");
+        // the sorted part on the LDS tiles in one kernel; particles appended since the sort through the global-memory kernels
+        wxa_particle_view head = *p;
+        head.np = ws->sorted_np;
+        if (head.np > 0 && (rc = push_deposit_tiled(&head, E, B, J, geom_eb, geom_j, q, m, dt, relative_time, pusher, ws,
+                                                    (hipStream_t)stream)) != WXA_OK)
+            return rc;
+        const wxa_particle_view rest = tail_view(*p, ws->sorted_np);
+        if (rest.np == 0) return WXA_OK;
+        if ((rc = wxa_gather_push_ws(&rest, E, B, geom_eb, q, m, dt, order, galerkin, pusher, 1, nullptr, stream)) != WXA_OK)
+            return rc;
+        return wxa_deposit_current(&rest, J, geom_j, q, dt, relative_time, order, algo, nullptr, stream);
+    }
+    if ((rc = wxa_gather_push_ws(p, E, B, geom_eb, q, m, dt, order, galerkin, pusher, 1, ws, stream)) != WXA_OK) return rc;
+    return wxa_deposit_current(p, J, geom_j, q, dt, relative_time, order, algo, ws, stream);
+}
+#endif
+
 wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
                                double q, double dt, double relative_time, int order, int algo,
                                wxa_workspace* ws, void* stream) {
