@@ -79,7 +79,7 @@ def test_ckc_bricks_match_single_domain(nb, order, filt, port, tmp_path):
     # round 3: bricks ALONG the moving window and between the PEC walls -- the fields that enter a brick come from its
     # upper neighbour, the walls belong to the end bricks, the plasma is injected into the top brick and handed down
     pytest.param((1, 1, 2), 2, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29651, marks=EXTRA),
-    ((1, 1, 4), 4, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29652),
+    pytest.param((1, 1, 4), 4, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29652, marks=EXTRA),   # = what (0, 0, 0) chooses
     ((1, 2, 2), 4, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29653),
     ((1, 1, 2), 2, "laser_injection_3d.inputs", "laser_injection_3d_checksums.json", 29654),
 ])
@@ -100,12 +100,12 @@ def test_deck_on_bricks_reaches_the_golden_checksums(nb, nranks, deck, golden, p
 
 
 @pytest.mark.parametrize("nb,nranks,deck,port", [
-    ((2, 1, 1), 2, "laser_wakefield_boosted_3d.inputs", 29641),     # BASELINE config 5 in small on bricks along x
-    ((0, 0, 0), 4, "laser_wakefield_boosted_3d.inputs", 29642),     # ... and on the 2 x 2 bricks the library chooses
+    pytest.param((2, 1, 1), 2, "laser_wakefield_boosted_3d.inputs", 29641, marks=EXTRA),   # BASELINE config 5 in small on bricks along x
+    ((2, 2, 1), 4, "laser_wakefield_boosted_3d.inputs", 29642),     # ... on 2 x 2 bricks across the window direction
     ((1, 2, 1), 2, "boosted_injection_3d.inputs", 29643),
     ((2, 1, 1), 2, "boosted_laser_3d.inputs", 29644),               # the drifting antenna split over two bricks
     pytest.param((1, 1, 2), 2, "laser_wakefield_boosted_3d.inputs", 29645, marks=EXTRA),   # round 3: config 5 in small cut along z (the window)
-    ((1, 1, 4), 4, "laser_wakefield_boosted_3d.inputs", 29646),
+    ((0, 0, 0), 4, "laser_wakefield_boosted_3d.inputs", 29646),     # ... and on the bricks the library chooses: four along z, the window
     ((1, 1, 2), 2, "boosted_injection_3d.inputs", 29647),
 ])
 def test_boosted_frame_decks_on_bricks_match_one_brick(nb, nranks, deck, port, tmp_path):
@@ -116,9 +116,12 @@ def test_boosted_frame_decks_on_bricks_match_one_brick(nb, nranks, deck, port, t
     from tests.test_inputs_cpu import compare_with_golden
     from warpx_amd.sim import WarpXSim
     path = os.path.join(ROOT, "tests", "decks", deck)
+    # config 5 in small: 70 of its 120 steps (antenna on, window moving, plasma entering, particles crossing brick faces)
+    # are what a layout can get wrong; the full run against the oracle stepper is tests/test_pec_golden.py
+    nsteps = 70 if deck.startswith("laser_wakefield_boosted") else 10 ** 9
     if deck not in _ONE_BRICK:   # the single-brick run of a deck is the same for every brick layout: once per session
         one = WarpXSim.from_inputs(load_host_cpu(), path)
-        one.evolve(one.max_step)
+        one.evolve(min(one.max_step, nsteps))
         _ONE_BRICK[deck] = one.checksum()
         one.close()
     want = _ONE_BRICK[deck]
@@ -126,7 +129,8 @@ def test_boosted_frame_decks_on_bricks_match_one_brick(nb, nranks, deck, port, t
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
            *[str(v) for v in nb], path, out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks)))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks), WXA_TEST_MAX_STEP=str(nsteps)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     got = json.load(open(out))
     assert got["lev=0"]["part_per_cell"] == want["lev=0"]["part_per_cell"]
