@@ -387,6 +387,44 @@ def test_deposit_current_lds_tiles(oracle, product, order, algo, stale, u_scale)
     product.workspace_destroy(ws)
 
 
+@pytest.mark.parametrize("order", [2, 3])
+@pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
+def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo):
+    """Cells with more particles than the tile kernel's work items cover (more than 24 in a cell: at 8 per cell on
+    average about one cell in a million, i.e. only at the headline size -- found there, round 3, by
+    test_direct_vay_ckc_256_against_the_oracle: the overflow list was deposited with the Esirkepov body whatever the
+    algorithm).  A few cells with 30 to 90 particles among ordinary ones, both algorithms, against the oracle."""
+    ncell = (16, 16, 16)
+    _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    parts = H.random_particles(20000, ncell, 77 + order, u_scale=1.0)
+    dx = H.LX / np.asarray(ncell)
+    rng = np.random.default_rng(12)
+    crowd = []
+    for cell, count in (((3, 4, 5), 30), ((8, 8, 8), 57), ((15, 0, 7), 90), ((9, 8, 8), 26)):
+        pos = [-H.LX / 2 + (cell[d] + rng.random(count)) * dx[d] for d in range(3)]
+        crowd.append(pos + [1e9 * (0.5 + rng.random(count))] + [plasma.C_LIGHT * rng.standard_normal(count) for _ in range(3)])
+    parts = [np.concatenate([parts[r]] + [c[r] for c in crowd]) for r in range(7)]
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    srt = ParticleArrays(pd0.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    ph = ParticleArrays.from_numpy(list(srt.to_numpy()), "cpu")
+    J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    Jd = H.clone_fields(J, DEV, True)
+    g, _ = H.geom_for(ncell, ng_depos)
+    dt = H.yee_dt(dx)
+    q = -plasma.Q_E
+    oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order, algo, None, None)
+    product.deposit_current(C.byref(srt.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, algo, ws, None)
+    _sync(product)
+    for a, b in zip(Jd, J):
+        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("zero_dir", [0, 1, 2])
 @pytest.mark.parametrize("u_scale", [0.003, 1.0])

@@ -230,6 +230,31 @@ def test_uniform_plasma_256_against_the_oracle(oracle, product):
 
 
 @FULL_SIZE
+def test_direct_vay_ckc_256_against_the_oracle(oracle, product):
+    """The other branches of the hot path at the headline size, in one run: 256^3 cells, 8 particles per cell (Poisson
+    occupancy, thermal), order 2, direct deposition with the gather the reference pairs it with (no Galerkin shapes,
+    Source/WarpX.cpp:1208-1214), Vay pusher, CKC solver (its two extra guard exchanges per step), filter on, sort every 2nd
+    step, 4 steps = 2 sorts -- HIP path against the oracle stepper.  (CartesianCKCAlgorithm.H:129-272, CurrentDeposition.H:
+    48-335, UpdateMomentumVay.H.)"""
+    n = int(os.environ.get("WXA_FULL_SIZE_N", "256"))
+    L = 40e-6
+    rng = np.random.default_rng(257)
+    counts = rng.poisson(8.0, n ** 3)
+    cell = np.repeat(np.arange(n ** 3, dtype=np.int64), counts)
+    npart = cell.size
+    dx = L / n
+    parts = []
+    for idx in (cell % n, (cell // n) % n, cell // (n * n)):
+        parts.append(-L / 2 + (idx + rng.random(npart)) * dx)
+    del cell, idx
+    parts.append(np.full(npart, 1e25 * dx ** 3 / 8.0))
+    parts += [0.01 * plasma.C_LIGHT * rng.standard_normal(npart) for _ in range(3)]
+    kw = dict(nox=2, galerkin=0, particle_pusher=_capi.PUSHER_VAY, current_deposition=_capi.DEPOSIT_DIRECT,
+              use_filter=1, sort_interval=2, maxwell_solver=_capi.SOLVER_CKC)
+    _full_size_parity(oracle, product, n, [(-plasma.Q_E, plasma.M_E, parts)], 4, kw)
+
+
+@FULL_SIZE
 def test_langmuir_256_against_the_oracle(oracle, product):
     """BASELINE.json config 3 at full size against the oracle stepper: Langmuir wave, 256^3 cells, e- / e+, 8 particles
     per cell on the regular lattice, order 3, Esirkepov, no filter (Examples/Tests/langmuir/inputs_base_3d scaled up),

@@ -255,10 +255,13 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
         if (n < DCAP) deferred[bank * DCAP + n] = (unsigned)ip | 0x80000000u;
         else sq.push(ip);
     };
-    // phase B's overflow cases never pass through the chunk loop: the fused kernel, which pushes there, hands them to the
-    // straggler kernels (push + deposit) instead
+    // phase B's overflow cases (a cell with more than 2 RMAX particles, a full tail table) never pass through the chunk
+    // loop.  Esirkepov: the deferred list (phase D's wide body).  Direct deposition: the straggler kernel -- phase D is
+    // Esirkepov's body (until round 3 these particles went there whatever the algorithm: one cell in a million at 8 per
+    // cell, seen first at 256^3).  The fused kernel, which pushes in the chunk loop: its own push + deposit list.
     auto defer_unloaded = [&](const int ip, const int bank) {
         if constexpr (FUSED) fa.gq.push(ip);
+        else if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT) sq.push(ip);
         else defer(ip, bank);
     };
     auto defer_particle = [&](const int ip, const int bank, const ParticleState& pp) {
