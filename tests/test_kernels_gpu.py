@@ -387,7 +387,7 @@ def test_deposit_current_lds_tiles(oracle, product, order, algo, stale, u_scale)
     product.workspace_destroy(ws)
 
 
-@pytest.mark.parametrize("order", [2, 3])
+@pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
 def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo):
     """Cells with more particles than the tile kernel's work items cover (more than 24 in a cell: at 8 per cell on
