@@ -425,6 +425,38 @@ def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo):
     product.workspace_destroy(ws)
 
 
+@pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
+@pytest.mark.parametrize("ppc", [20, 40])
+def test_deposit_current_lds_tiles_many_particles_per_cell(oracle, product, algo, ppc):
+    """20 and 40 particles per cell on average (the tile kernel's tables are sized for 8: the tail table of a tile holds
+    1024 pairs beyond the fourth of a cell, the deferred list 2048 particles; what does not fit goes on to the next list
+    and finally to the global-atomics kernel) -- every overflow path at once, order 3, against the oracle."""
+    order = 3
+    ncell = (16, 16, 8)
+    _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    parts = H.random_particles(ppc * ncell[0] * ncell[1] * ncell[2], ncell, 31 + ppc, u_scale=1.0)
+    dx = H.LX / np.asarray(ncell)
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    srt = ParticleArrays(pd0.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    ph = ParticleArrays.from_numpy(list(srt.to_numpy()), "cpu")
+    J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    Jd = H.clone_fields(J, DEV, True)
+    g, _ = H.geom_for(ncell, ng_depos)
+    dt = H.yee_dt(dx)
+    q = -plasma.Q_E
+    oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order, algo, None, None)
+    product.deposit_current(C.byref(srt.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, algo, ws, None)
+    _sync(product)
+    for a, b in zip(Jd, J):
+        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("zero_dir", [0, 1, 2])
 @pytest.mark.parametrize("u_scale", [0.003, 1.0])
