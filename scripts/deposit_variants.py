@@ -1,4 +1,7 @@
-"""A/B timing of the LDS-tile deposition configurations (WXA_DEPOSIT_VARIANT, deposit_tile.hip) inside the bench
+"""HISTORICAL (round 2): the variant numbers it drives no longer exist in deposit_tile.hip; kept as the record of how
+profiles/round2/* was produced.  Use scripts/variants.py (any WXA_* switch of a -DWXA_DEV_VARIANTS build).
+
+A/B timing of the LDS-tile deposition configurations (WXA_DEPOSIT_VARIANT, deposit_tile.hip) inside the bench
 workload: 256^3, 8 ppc, order 3, Esirkepov, thermalised by the pre-roll.  Prints the CurrentDeposition phase time
 per launch (HIP events on the kernels' stream) and the whole step for every variant.
 
