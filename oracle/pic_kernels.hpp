@@ -87,8 +87,17 @@ inline int compute_shape_factor(double* sx, double xmid) {
         sx[2] = (2.0) / (3.0) - (1.0 - xint) * (1.0 - xint) * (1.0 - 0.5 * (1.0 - xint));
         sx[3] = (1.0) / (6.0) * xint * xint * xint;
         return j - 1;
+    } else if constexpr (depos_order == 4) {   // :67-77
+        const auto j = static_cast<int>(xmid + 0.5);
+        const double xint = xmid - double(j);
+        sx[0] = (1.0) / (24.0) * (0.5 - xint) * (0.5 - xint) * (0.5 - xint) * (0.5 - xint);
+        sx[1] = (1.0) / (24.0) * (4.75 - 11.0 * xint + 4.0 * xint * xint * (1.5 + xint - xint * xint));
+        sx[2] = (1.0) / (24.0) * (14.375 + 6.0 * xint * xint * (xint * xint - 2.5));
+        sx[3] = (1.0) / (24.0) * (4.75 + 11.0 * xint + 4.0 * xint * xint * (1.5 - xint - xint * xint));
+        sx[4] = (1.0) / (24.0) * (0.5 + xint) * (0.5 + xint) * (0.5 + xint) * (0.5 + xint);
+        return j - 2;
     } else {
-        static_assert(depos_order <= 3, "orders 0..3");
+        static_assert(depos_order <= 4, "orders 0..4");
         return 0;
     }
 }
@@ -120,8 +129,18 @@ inline int compute_shifted_shape_factor(double* sx, const double x_old, const in
         sx[3 + i_shift] = (2.0) / (3.0) - (1.0 - xint) * (1.0 - xint) * (1.0 - 0.5 * (1.0 - xint));
         sx[4 + i_shift] = (1.0) / (6.0) * xint * xint * xint;
         return i - 1;
+    } else if constexpr (depos_order == 4) {   // :138-149
+        const auto i = static_cast<int>(x_old + 0.5);
+        const int i_shift = i - (i_new + 2);
+        const double xint = x_old - double(i);
+        sx[1 + i_shift] = (1.0) / (24.0) * (0.5 - xint) * (0.5 - xint) * (0.5 - xint) * (0.5 - xint);
+        sx[2 + i_shift] = (1.0) / (24.0) * (4.75 - 11.0 * xint + 4.0 * xint * xint * (1.5 + xint - xint * xint));
+        sx[3 + i_shift] = (1.0) / (24.0) * (14.375 + 6.0 * xint * xint * (xint * xint - 2.5));
+        sx[4 + i_shift] = (1.0) / (24.0) * (4.75 + 11.0 * xint + 4.0 * xint * xint * (1.5 - xint - xint * xint));
+        sx[5 + i_shift] = (1.0) / (24.0) * (0.5 + xint) * (0.5 + xint) * (0.5 + xint) * (0.5 + xint);
+        return i - 2;
     } else {
-        static_assert(depos_order >= 1 && depos_order <= 3, "orders 1..3");
+        static_assert(depos_order >= 1 && depos_order <= 4, "orders 1..4");
         return 0;
     }
 }

@@ -388,11 +388,13 @@ int gather_push_dispatch(const wxa_particle_view* p, const wxa_field_view E[3], 
         if (order == 1) gather_push_impl<1, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
         else if (order == 2) gather_push_impl<2, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
         else if (order == 3) gather_push_impl<3, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
+        else if (order == 4) gather_push_impl<4, 1, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
         else return -1;
     } else {
         if (order == 1) gather_push_impl<1, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
         else if (order == 2) gather_push_impl<2, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
         else if (order == 3) gather_push_impl<3, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
+        else if (order == 4) gather_push_impl<4, 0, MOVE>(p, E, B, g, q, m, dt, pusher, ext, lens, time);
         else return -1;
     }
     return 0;
@@ -517,6 +519,7 @@ int orc_deposit_current(const wxa_particle_view* p, const wxa_field_view J[3], c
     if (order == 1) deposit_impl<1>(p, J, g, q, dt, relative_time, algo);
     else if (order == 2) deposit_impl<2>(p, J, g, q, dt, relative_time, algo);
     else if (order == 3) deposit_impl<3>(p, J, g, q, dt, relative_time, algo);
+    else if (order == 4) deposit_impl<4>(p, J, g, q, dt, relative_time, algo);
     else return -1;
     return 0;
 }
@@ -528,6 +531,7 @@ int orc_deposit_charge(const wxa_particle_view* p, const wxa_field_view* rho, co
         if (order == 1) doChargeDepositionShapeN_one<1>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], r, rho->stag, g->dinv, g->xyzmin, g->lo, q);
         else if (order == 2) doChargeDepositionShapeN_one<2>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], r, rho->stag, g->dinv, g->xyzmin, g->lo, q);
         else if (order == 3) doChargeDepositionShapeN_one<3>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], r, rho->stag, g->dinv, g->xyzmin, g->lo, q);
+        else if (order == 4) doChargeDepositionShapeN_one<4>(p->x[ip], p->y[ip], p->z[ip], p->w[ip], r, rho->stag, g->dinv, g->xyzmin, g->lo, q);
         else return -1;
     }
     return 0;
@@ -1791,7 +1795,7 @@ extern "C" {
 
 int orc_sim_create(const wxa_sim_config* cfg, const void* /*comm*/, orc_sim** out) {
     if (!cfg || !out) return -1;
-    if (cfg->nox < 1 || cfg->nox > 3) return -1;
+    if (cfg->nox < 1 || cfg->nox > 4) return -1;
     if (cfg->nbricks[0] * cfg->nbricks[1] * cfg->nbricks[2] != 1) return -3;
     auto* s = new orc_sim();
     s->cfg = *cfg;

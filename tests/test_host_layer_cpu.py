@@ -23,11 +23,12 @@ def _species(n_cell, ppc=(1, 1, 2), seed=3):
 @pytest.mark.parametrize("order,filt,sort,pusher,depos", [
     (1, 1, -1, _capi.PUSHER_BORIS, _capi.DEPOSIT_ESIRKEPOV), (3, 1, 2, _capi.PUSHER_BORIS, _capi.DEPOSIT_ESIRKEPOV),
     (2, 0, 1, _capi.PUSHER_BORIS, _capi.DEPOSIT_ESIRKEPOV), (3, 1, 3, _capi.PUSHER_VAY, _capi.DEPOSIT_DIRECT),
-    (1, 0, 4, _capi.PUSHER_VAY, _capi.DEPOSIT_ESIRKEPOV), (2, 1, -1, _capi.PUSHER_BORIS, _capi.DEPOSIT_DIRECT)])
+    (1, 0, 4, _capi.PUSHER_VAY, _capi.DEPOSIT_ESIRKEPOV), (2, 1, -1, _capi.PUSHER_BORIS, _capi.DEPOSIT_DIRECT),
+    (4, 1, 3, _capi.PUSHER_BORIS, _capi.DEPOSIT_ESIRKEPOV)])
 def test_single_brick_schedule_matches_oracle(oracle, host_cpu, order, filt, sort, pusher, depos):
     """The product's schedule (no exchange inside the field solve: guard layer of B computed, solver-depth fill of E
     dropped) against the oracle stepper, which keeps the reference's five fills."""
-    n_cell = (16, 12, 12)
+    n_cell = (16, 12, 12) if order < 4 else (16, 16, 16)   # a periodic direction must hold twice the guard depth
     parts = _species(n_cell)
     res = []
     for lib in (host_cpu, oracle):

@@ -63,7 +63,7 @@ def test_evolve_unsupported_staggering(product):
         product.evolve_b(field_triplet(f[:3]), field_triplet(f[3:]), 1e-16, H.d3((1, 1, 1)), None)
 
 
-@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
 @pytest.mark.parametrize("galerkin", [1, 0])
 @pytest.mark.parametrize("pusher", [_capi.PUSHER_BORIS, _capi.PUSHER_VAY])
 def test_gather_push(oracle, product, order, galerkin, pusher):
@@ -88,7 +88,7 @@ def test_gather_push(oracle, product, order, galerkin, pusher):
             assert H.max_rel_err(a[row], b[row]) < 1e-12, (fn, row)
 
 
-@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
 @pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
 def test_deposit_current(oracle, product, order, algo):
     _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
@@ -110,7 +110,7 @@ def test_deposit_current(oracle, product, order, algo):
     product.deposit_current(C.byref(empty.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, algo, None, None)
 
 
-@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
 def test_esirkepov_continuity(product, order):
     """Discrete continuity (rho_new - rho_old)/dt + div J = 0 to round-off (Esirkepov 2001):
     an analytic property of the path that no reference test pins."""
@@ -118,7 +118,7 @@ def test_esirkepov_continuity(product, order):
     assert resid < 1e-11
 
 
-@pytest.mark.parametrize("order", [1, 3])
+@pytest.mark.parametrize("order", [1, 3, 4])
 def test_deposit_charge(oracle, product, order):
     ng = order + 2
     rho = FieldArray(NCELL, STAG["rho"], (ng,) * 3, "cpu")

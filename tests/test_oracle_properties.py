@@ -12,7 +12,7 @@ from warpx_amd.containers import STAG, FieldArray, ParticleArrays, field_triplet
 NCELL = (12, 10, 8)
 
 
-@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
 def test_esirkepov_continuity(oracle, order):
     assert H.continuity_residual(oracle, "cpu", order, NCELL) < 1e-11
 
@@ -36,7 +36,7 @@ def test_div_b_preserved(oracle):
     assert np.max(np.abs(div)) < 1e-12 * scale
 
 
-@pytest.mark.parametrize("order", [1, 3])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
 def test_gather_of_linear_field_is_exact(oracle, order):
     """B-spline interpolation reproduces a linear field; galerkin off so every component
     uses the full order along every direction."""

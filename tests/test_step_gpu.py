@@ -52,6 +52,8 @@ def _compare(a, b, rtol=RTOL):
     (3, _capi.DEPOSIT_ESIRKEPOV, _capi.PUSHER_BORIS, 1),   # config 2 shape
     (3, _capi.DEPOSIT_DIRECT, _capi.PUSHER_VAY, 0),
     (2, _capi.DEPOSIT_ESIRKEPOV, _capi.PUSHER_VAY, 0),
+    (4, _capi.DEPOSIT_ESIRKEPOV, _capi.PUSHER_BORIS, 1),   # order 4 (ShapeFactors.H:67-77, 138-149): the global-memory kernels
+    (4, _capi.DEPOSIT_DIRECT, _capi.PUSHER_BORIS, 0),
 ])
 def test_uniform_plasma_parity(oracle, product, order, depos, pusher, filt):
     n_cell = (32, 32, 32)

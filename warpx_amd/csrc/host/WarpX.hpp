@@ -115,7 +115,7 @@ public:
         : m_be(be), m_cfg(cfg), m_fields(be), mypc(std::make_unique<MultiParticleContainer>(&m_ctx)) {
         using warpx::fields::FieldType;
         using ablastr::fields::Direction;
-        if (cfg.nox < 1 || cfg.nox > 3) throw std::runtime_error("algo.particle_shape must be 1..3");
+        if (cfg.nox < 1 || cfg.nox > 4) throw std::runtime_error("algo.particle_shape must be 1..4");
         m_ctx.be = be;
         m_ctx.nox = cfg.nox;
         m_ctx.galerkin_interpolation = cfg.galerkin != 0;

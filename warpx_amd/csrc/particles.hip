@@ -589,9 +589,9 @@ static wxa_status launch_gather_push(const PV& pv, const wxa_field_view E[3], co
     hipLaunchKernelGGL((gather_push_kernel<O, G, PUSHER, MOVE>), grid, block, 0, st, pv, ex, ey, ez, bx, by, \
                        bz, g, q, m, dt, ext)
     if (galerkin) {
-        if (order == 1) WXA_GP(1, 1); else if (order == 2) WXA_GP(2, 1); else WXA_GP(3, 1);
+        if (order == 1) WXA_GP(1, 1); else if (order == 2) WXA_GP(2, 1); else if (order == 3) WXA_GP(3, 1); else WXA_GP(4, 1);
     } else {
-        if (order == 1) WXA_GP(1, 0); else if (order == 2) WXA_GP(2, 0); else WXA_GP(3, 0);
+        if (order == 1) WXA_GP(1, 0); else if (order == 2) WXA_GP(2, 0); else if (order == 3) WXA_GP(3, 0); else WXA_GP(4, 0);
     }
 #undef WXA_GP
     WXA_LAUNCH_CHECK();
@@ -619,7 +619,7 @@ static wxa_status check_gather_args(const wxa_particle_view* p, const wxa_field_
     WXA_REQUIRE(pv_ok(p), "bad particle view");
     WXA_REQUIRE(E && B && geom, "null argument");
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(E[c]) && view_ok(B[c]), "bad field view");
-    WXA_REQUIRE(order >= 1 && order <= 3, "particle shape order must be 1..3");
+    WXA_REQUIRE(order >= 1 && order <= 4, "particle shape order must be 1..4");
     WXA_REQUIRE(galerkin == 0 || galerkin == 1, "galerkin must be 0 or 1");
     WXA_REQUIRE(pusher >= WXA_PUSHER_BORIS && pusher <= WXA_PUSHER_BORIS_RR,
                 "pusher must be Boris, Vay, Higuera-Cary or Boris with radiation reaction");
@@ -667,7 +667,7 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E
     if ((rc = evaluate_particle_fields(p, ws, (hipStream_t)stream)) != WXA_OK) return rc;
     wxa_particle_view rest = *p;
     int64_t first = 0;
-    if (gather_tile_available(ws, p)) {
+    if (order <= 3 && gather_tile_available(ws, p)) {   // order 4: the global-memory kernels (the LDS tiles are sized for orders <= 3)
         // sorted part on the LDS tiles; particles appended since the sort (arrivals from the
         // neighbouring bricks) take the global-memory kernel below
         wxa_particle_view head = *p;
@@ -691,7 +691,7 @@ wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view
     WXA_REQUIRE(part == WXA_PART_INTERIOR || part == WXA_PART_REST, "part must be WXA_PART_INTERIOR or WXA_PART_REST");
     if (p->np == 0) return WXA_OK;
     if ((rc = evaluate_particle_fields(p, ws, (hipStream_t)stream)) != WXA_OK) return rc;
-    if (!gather_tile_available(ws, p)) {   // no tiles: the interior part is empty, the rest is everything
+    if (order > 3 || !gather_tile_available(ws, p)) {   // no tiles: the interior part is empty, the rest is everything
         if (part == WXA_PART_INTERIOR) return WXA_OK;
         return gather_push_global(*p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws), (hipStream_t)stream);
     }
@@ -758,7 +758,7 @@ wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view 
     WXA_REQUIRE(pv_ok(p), "bad particle view");
     WXA_REQUIRE(J && geom, "null argument");
     for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(J[c]), "bad field view");
-    WXA_REQUIRE(order >= 1 && order <= 3, "particle shape order must be 1..3");
+    WXA_REQUIRE(order >= 1 && order <= 4, "particle shape order must be 1..4");
     WXA_REQUIRE(algo == WXA_DEPOSIT_ESIRKEPOV || algo == WXA_DEPOSIT_DIRECT, "unknown deposition algorithm");
     WXA_REQUIRE(dt > 0.0 || algo == WXA_DEPOSIT_DIRECT, "dt must be positive");
     if (!yee_E(J)) {
@@ -767,7 +767,7 @@ wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view 
     }
     if (p->np == 0) return WXA_OK;
     wxa_particle_view rest = *p;
-    if (ws && deposit_tile_available(ws, p)) {
+    if (ws && order <= 3 && deposit_tile_available(ws, p)) {
         wxa_particle_view head = *p;
         head.np = ws->sorted_np;
         wxa_status rc;
@@ -786,11 +786,13 @@ wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view 
         const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
         if (order == 1) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<1>, grid, block, 0, st, pv, jx, jy, jz, g, q, es);
         else if (order == 2) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<2>, grid, block, 0, st, pv, jx, jy, jz, g, q, es);
-        else hipLaunchKernelGGL(deposit_esirkepov_global_kernel<3>, grid, block, 0, st, pv, jx, jy, jz, g, q, es);
+        else if (order == 3) hipLaunchKernelGGL(deposit_esirkepov_global_kernel<3>, grid, block, 0, st, pv, jx, jy, jz, g, q, es);
+        else hipLaunchKernelGGL(deposit_esirkepov_global_kernel<4>, grid, block, 0, st, pv, jx, jy, jz, g, q, es);
     } else {
         if (order == 1) hipLaunchKernelGGL(deposit_direct_global_kernel<1>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
         else if (order == 2) hipLaunchKernelGGL(deposit_direct_global_kernel<2>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
-        else hipLaunchKernelGGL(deposit_direct_global_kernel<3>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
+        else if (order == 3) hipLaunchKernelGGL(deposit_direct_global_kernel<3>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
+        else hipLaunchKernelGGL(deposit_direct_global_kernel<4>, grid, block, 0, st, pv, jx, jy, jz, g, q, relative_time);
     }
     WXA_LAUNCH_CHECK();
     return WXA_OK;
@@ -800,7 +802,7 @@ wxa_status wxa_deposit_charge(const wxa_particle_view* p, const wxa_field_view* 
                               double q, int order, void* stream) {
     WXA_REQUIRE(pv_ok(p), "bad particle view");
     WXA_REQUIRE(rho && geom && view_ok(*rho), "bad argument");
-    WXA_REQUIRE(order >= 1 && order <= 3, "particle shape order must be 1..3");
+    WXA_REQUIRE(order >= 1 && order <= 4, "particle shape order must be 1..4");
     if (p->np == 0) return WXA_OK;
     const PV pv = make_pv(*p);
     const Geom g = make_geom(*geom);
@@ -809,7 +811,8 @@ wxa_status wxa_deposit_charge(const wxa_particle_view* p, const wxa_field_view* 
     hipStream_t st = (hipStream_t)stream;
     if (order == 1) hipLaunchKernelGGL(deposit_charge_kernel<1>, grid, block, 0, st, pv, r, rho->stag[0], rho->stag[1], rho->stag[2], g, q);
     else if (order == 2) hipLaunchKernelGGL(deposit_charge_kernel<2>, grid, block, 0, st, pv, r, rho->stag[0], rho->stag[1], rho->stag[2], g, q);
-    else hipLaunchKernelGGL(deposit_charge_kernel<3>, grid, block, 0, st, pv, r, rho->stag[0], rho->stag[1], rho->stag[2], g, q);
+    else if (order == 3) hipLaunchKernelGGL(deposit_charge_kernel<3>, grid, block, 0, st, pv, r, rho->stag[0], rho->stag[1], rho->stag[2], g, q);
+    else hipLaunchKernelGGL(deposit_charge_kernel<4>, grid, block, 0, st, pv, r, rho->stag[0], rho->stag[1], rho->stag[2], g, q);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }

@@ -25,13 +25,20 @@ namespace wxa {
         s[0] = 0.5 * (0.5 - xi) * (0.5 - xi);                              \
         s[1] = 0.75 - xi * xi;                                             \
         s[2] = 0.5 * (0.5 + xi) * (0.5 + xi);                              \
-    } else {                                                               \
-        static_assert(ORDER == 3, "orders 0..3");                          \
+    } else if constexpr (ORDER == 3) {                                     \
         const double om = 1.0 - xi;                                        \
         s[0] = (1.0 / 6.0) * om * om * om;                                 \
         s[1] = (2.0 / 3.0) - xi * xi * (1.0 - xi / 2.0);                   \
         s[2] = (2.0 / 3.0) - om * om * (1.0 - 0.5 * om);                   \
         s[3] = (1.0 / 6.0) * xi * xi * xi;                                 \
+    } else {   /* quartic spline, ShapeFactors.H:67-77 */                  \
+        static_assert(ORDER == 4, "orders 0..4");                          \
+        const double lo = 0.5 - xi, hi = 0.5 + xi;                         \
+        s[0] = (1.0 / 24.0) * lo * lo * lo * lo;                           \
+        s[1] = (1.0 / 24.0) * (4.75 - 11.0 * xi + 4.0 * xi * xi * (1.5 + xi - xi * xi)); \
+        s[2] = (1.0 / 24.0) * (14.375 + 6.0 * xi * xi * (xi * xi - 2.5));  \
+        s[3] = (1.0 / 24.0) * (4.75 + 11.0 * xi + 4.0 * xi * xi * (1.5 - xi - xi * xi)); \
+        s[4] = (1.0 / 24.0) * hi * hi * hi * hi;                           \
     }
 
 template <int ORDER, bool RN>
@@ -51,7 +58,7 @@ __device__ __forceinline__ void bspline_weights(double* __restrict__ s, const do
 // x >= 0 is guaranteed by the guard-grown index origin, so truncation == floor.
 template <int ORDER>
 __device__ __forceinline__ int shape_node_of(const double x) {
-    if constexpr (ORDER == 0 || ORDER == 2) return (int)(x + 0.5);
+    if constexpr (ORDER % 2 == 0) return (int)(x + 0.5);
     else return (int)x;
 }
 
@@ -60,7 +67,7 @@ template <int ORDER, bool RN = false>
 __device__ __forceinline__ int shape_factor(double* __restrict__ s, const double x) {
     const int j = shape_node_of<ORDER>(x);
     bspline_weights<ORDER, RN>(s, x, j);
-    return ORDER >= 2 ? j - 1 : j;
+    return j - ORDER / 2;   // j, j - 1, j - 1, j - 2 for orders 1 .. 4
 }
 
 // The same weights with the reference node j imposed by the caller (xint = x - j) instead of
@@ -70,13 +77,13 @@ __device__ __forceinline__ int shape_factor(double* __restrict__ s, const double
 // changes the weights by O(ulp) while keeping them on the slots the caller expects.
 template <int ORDER, bool RN = false>
 __device__ __forceinline__ void shape_weights_at(double* __restrict__ s, const double x, const int j) {
-    static_assert(ORDER >= 1 && ORDER <= 3, "orders 1..3");
+    static_assert(ORDER >= 1 && ORDER <= 4, "orders 1..4");
     bspline_weights<ORDER, RN>(s, x, j);
 }
 
 // reference node j of shape_factor<ORDER> from its return value (leftmost index)
 template <int ORDER>
-__device__ __forceinline__ int shape_node(int leftmost) { return ORDER == 1 ? leftmost : leftmost + 1; }
+__device__ __forceinline__ int shape_node(int leftmost) { return leftmost + ORDER / 2; }
 
 // Old-position weights on the slots of the new position (Esirkepov),
 // Source/Particles/ShapeFactors.H:93-156.  s has ORDER+3 entries, all written here.
@@ -86,12 +93,12 @@ __device__ __forceinline__ int shape_node(int leftmost) { return ORDER == 1 ? le
 template <int ORDER, bool RN = false>
 __device__ __forceinline__ int shifted_shape_factor(double* __restrict__ s, const double x_old,
                                                     const int i_new) {
-    static_assert(ORDER >= 1 && ORDER <= 3, "orders 1..3");
+    static_assert(ORDER >= 1 && ORDER <= 4, "orders 1..4");
     double w[ORDER + 1];
     // ORDER 1 floors (ShapeFactors.H:112), the others truncate like Compute_shape_factor
     const int i = ORDER == 1 ? (int)floor(x_old) : shape_node_of<ORDER>(x_old);
-    const int sh = ORDER == 1 ? i - i_new : i - (i_new + 1);
-    const int ret = ORDER == 1 ? i : i - 1;
+    const int sh = i - (i_new + ORDER / 2);   // :113, :122, :134, :147
+    const int ret = i - ORDER / 2;
     bspline_weights<ORDER, RN>(w, x_old, i);
     // slot a holds w[a - 1 - sh] when that index exists (sh in {-1,0,+1} under the CFL limit)
 #pragma unroll
