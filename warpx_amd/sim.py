@@ -91,12 +91,17 @@ class WarpXSim:
     def checksum(self) -> dict:
         """The reference's regression checksum of the current state (wxa_sim_checksum_json), this brick's share."""
         import json
-        n = self.lib.sim_checksum_json(self._h, None, 0)
-        if n < 0:
-            raise _capi.WxaError("sim_checksum_json failed")
-        buf = C.create_string_buffer(n + 1)
-        self.lib.sim_checksum_json(self._h, buf, n + 1)
-        return json.loads(buf.value.decode())
+        # every call recomputes the sums (rho is deposited with atomics: its last digits, and with them the length of the
+        # text, can differ from call to call), so the buffer is taken with a margin and the call repeated if it was short
+        cap = 4096
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = self.lib.sim_checksum_json(self._h, buf, cap)
+            if n < 0:
+                raise _capi.WxaError("sim_checksum_json failed")
+            if n < cap:
+                return json.loads(buf.value.decode())
+            cap = n + 256
 
     def close(self):
         if self._h:
