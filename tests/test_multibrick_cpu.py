@@ -39,6 +39,7 @@ def _run(nb, order, filt, tmp_path, port, overlap=0, extra_env=None):
     ((2, 1, 1), 1, 0, 29612),   # split along the contiguous direction
     ((1, 2, 2), 2, 1, 29613),   # the 4-GPU layout: edges/corners through two exchanged directions
     ((2, 2, 2), 3, 1, 29614),   # the 8-GPU layout: corners travel through all three directions
+    ((1, 1, 2), 4, 1, 29615),   # order 4 (round 3): the deepest guards of the path
 ])
 def test_bricks_match_single_domain(nb, order, filt, port, tmp_path):
     rep = _run(nb, order, filt, tmp_path, port)
