@@ -720,6 +720,19 @@ wxa_status wxa_sim_get_particles(wxa_sim* s, int32_t species_id, wxa_particle_vi
  * reference's profiler regions: 0 GatherAndPush,
  * 1 CurrentDeposition, 2 SyncCurrent(filter+SumBoundary), 3 EvolveB, 4 EvolveE,
  * 5 FillBoundary, 6 Redistribute+Sort.  counts[i] = number of launches. */
+/* <diag>.diag_type = BackTransformed with do_back_transformed_fields = 1 (Source/Diagnostics/BTDiagnostics.cpp,
+ * ComputeDiagFunctors/BackTransformFunctor.cpp), fields only, one brick, boost and moving window along z:
+ * num_snapshots lab-frame snapshots at t_lab = i dt_snapshots_lab (+ the offset of :346-347), each assembled from one
+ * z slice per step -- the cell-centred Ex Ey Ez Bx By Bz jx jy jz rho interpolated at the snapshot's current plane in the
+ * boosted frame (amrex::get_slice_data), Lorentz-transformed (LorentzTransformZ, :246-317), stored at lab index k_lab
+ * (k_index_zlab, :892-905).  buffer_size only rounds the snapshot's length as :464-469 do; the snapshot is kept whole in
+ * host memory.  wxa_sim_btd_info: cells n (x, y, z), lab-frame extent along z, t_lab, slices received, closed flag;
+ * wxa_sim_btd_data: component comp (order above) into out[k][j][i] (host pointer).  Diagnostic stage: host arithmetic. */
+wxa_status wxa_sim_add_btd(wxa_sim* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size);
+wxa_status wxa_sim_btd_info(wxa_sim* s, int32_t i, int32_t n[3], double z_lab[2], double* t_lab, int32_t* slices,
+                            int32_t* full);
+wxa_status wxa_sim_btd_data(wxa_sim* s, int32_t i, int32_t comp, double* out);
+
 wxa_status wxa_sim_get_timers(wxa_sim* s, double ms[8], int64_t counts[8], int reset);
 wxa_status wxa_sim_enable_timers(wxa_sim* s, int enable);
 

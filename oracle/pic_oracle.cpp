@@ -1477,6 +1477,16 @@ struct orc_sim {
     double mw_v = 0.0;   // m/s
     double mw_x = 0.0;   // WarpX::moving_window_x
     std::vector<std::unique_ptr<struct LaserAntenna>> lasers;
+    // <diag>.diag_type = BackTransformed, fields (BTDiagnostics.cpp; see btd_compute_and_pack below)
+    struct BtdSnapshot {
+        double t_lab = 0, zlo_lab = 0, zhi_lab = 0, z_boost = 0, z_lab = 0;
+        int ksmall = 0, kbig = 0, counter = 0, last_valid = 0, full = 0;
+        int n[3] = {0, 0, 0};
+        std::vector<double> data;   // [comp][k][j][i]
+    };
+    std::vector<BtdSnapshot> btd;
+    int btd_buffer_size = 0;
+    double btd_dt_snap = 0.0;
 
     wxa_grid_geom geom_for(const int ng[3]) const {
         // WarpX::LowerCorner(box.grow(ng)) = prob_lo + box.lo * dx (Source/WarpX.cpp:2851-2875)
@@ -1912,6 +1922,147 @@ int orc_sim_add_species(orc_sim* s, double charge, double mass, const wxa_partic
 }
 
 // WarpX::Evolve (Source/Evolve/WarpXEvolve.cpp:94-347)
+int orc_sim_compute_rho(orc_sim* s);
+
+// ---- back-transformed diagnostics, fields (Source/Diagnostics/BTDiagnostics.cpp, ComputeDiagFunctors/BackTransformFunctor.cpp)
+// Lab-frame snapshot i is the set of events t_lab = t_i; at boosted time t it is the plane
+//   z_boost = (t_i / gamma - t) c / beta     (BTDiagnostics.H:276-280),  lab position z_lab = (t_i - t / gamma) c / beta (:285-289)
+// which sweeps down through the boosted domain; each step contributes one lab-frame slice, dz_lab = c dt / (beta gamma)
+// apart (:885-890).  amrex::get_slice_data(interpolate = true) is restated as a linear interpolation between the two cell
+// centres around z_boost (AMReX is not on disk: unpinned).
+static double btd_dz_lab(const orc_sim* s) { return PhysConst::c * s->dt * 1.0 / s->beta_boost * 1.0 / s->gamma_boost; }
+static int btd_k_index(const orc_sim::BtdSnapshot& b, double dzl) {   // k_index_zlab (:892-905)
+    return (int)std::floor((b.z_lab - b.zlo_lab) / dzl) + b.ksmall;
+}
+static bool btd_slice_in_domain(const orc_sim* s, const orc_sim::BtdSnapshot& b) {   // GetZSliceInDomainFlag (:999-1018)
+    const double cs = s->dx[2];
+    return !((b.z_boost <= s->plo[2] + 0.5 * cs) || (b.z_boost >= s->phi[2] - 0.5 * cs) || (b.z_lab <= b.zlo_lab) ||
+             (b.z_lab >= b.zhi_lab));
+}
+// cell-centred value of a staggered component at cell (i, j, k): CellCenterFunctor -> ablastr::coarsen::Interp (sample.H:47-99)
+static double btd_cell_value(const wxa_field_view& f, int i, int j, int k) {
+    const Arr a(f);
+    const int np[3] = {1 + f.stag[0], 1 + f.stag[1], 1 + f.stag[2]};
+    const double wx = 1.0 / np[0], wy = 1.0 / np[1], wz = 1.0 / np[2];
+    double c = 0.0;
+    for (int kr = 0; kr < np[2]; ++kr)
+        for (int jr = 0; jr < np[1]; ++jr)
+            for (int ir = 0; ir < np[0]; ++ir) c += wx * wy * wz * a(i + ir, j + jr, k + kr);
+    return c;
+}
+static void btd_compute_and_pack(orc_sim* s) {
+    const double dzl = btd_dz_lab(s);
+    const double g = s->gamma_boost, b = s->beta_boost, clight = PhysConst::c, inv_clight = 1.0 / PhysConst::c;
+    bool any = false;
+    for (auto& sn : s->btd) {   // PrepareBufferData (:755-776)
+        sn.z_boost = (sn.t_lab / g - s->cur_time) * clight / b;
+        sn.z_lab = (sn.t_lab - s->cur_time / g) * clight / b;
+        any = any || (btd_slice_in_domain(s, sn) && !sn.full);
+    }
+    if (any) orc_sim_compute_rho(s);
+    for (auto& sn : s->btd) {
+        const bool in_domain = btd_slice_in_domain(s, sn);
+        const int k_lab = btd_k_index(sn, dzl);
+        if (in_domain && !sn.full && k_lab >= sn.ksmall && k_lab <= sn.kbig) {
+            // BackTransformFunctor::operator() (:49-149): slice, Lorentz transform, copy to k_lab
+            const double cs = s->dx[2];
+            const int kc = (int)std::floor((sn.z_boost - s->plo[2]) / cs);
+            const double zc = s->plo[2] + (kc + 0.5) * cs;
+            int klo, khi;
+            double w;
+            if (sn.z_boost >= zc) { klo = kc; khi = kc + 1; w = (sn.z_boost - zc) / cs; }
+            else { klo = kc - 1; khi = kc; w = (sn.z_boost - (zc - cs)) / cs; }
+            if (klo >= 0 && khi < s->cfg.n_cell[2]) {
+                const wxa_field_view* comp[10] = {&s->Ev[0], &s->Ev[1], &s->Ev[2], &s->Bv[0], &s->Bv[1], &s->Bv[2],
+                                                  &s->Jv[0], &s->Jv[1], &s->Jv[2], &s->rho.v};
+                const size_t plane = (size_t)sn.n[0] * sn.n[1], vol = plane * (size_t)sn.n[2];
+                const size_t kk = (size_t)(k_lab - sn.ksmall);
+                for (int j = 0; j < sn.n[1]; ++j)
+                    for (int i = 0; i < sn.n[0]; ++i) {
+                        double v[10];
+                        for (int c = 0; c < 10; ++c)
+                            v[c] = (1.0 - w) * btd_cell_value(*comp[c], i, j, klo) + w * btd_cell_value(*comp[c], i, j, khi);
+                        // LorentzTransformZ (:246-317)
+                        const double ex_lab = g * (v[0] + b * clight * v[4]);
+                        const double by_lab = g * (v[4] + b * inv_clight * v[0]);
+                        v[0] = ex_lab; v[4] = by_lab;
+                        const double ey_lab = g * (v[1] - b * clight * v[3]);
+                        const double bx_lab = g * (v[3] - b * inv_clight * v[1]);
+                        v[1] = ey_lab; v[3] = bx_lab;
+                        const double j_lab = g * (v[8] + b * clight * v[9]);
+                        const double rho_lab = g * (v[9] + b * inv_clight * v[8]);
+                        v[8] = j_lab; v[9] = rho_lab;
+                        for (int c = 0; c < 10; ++c) sn.data[(size_t)c * vol + kk * plane + (size_t)j * sn.n[0] + i] = v[c];
+                    }
+            }
+        }
+        // UpdateBufferData (:778-798), and the flags DoDump / Flush leave behind (:294-320, :907-914)
+        if (in_domain) ++sn.counter;
+        if (k_lab == sn.ksmall) sn.last_valid = 1;
+        if (sn.last_valid == 1) sn.full = 1;
+    }
+}
+
+// BTDiagnostics::ReadParameters (:206-292) + DerivedInitData (:66-205) + InitializeBufferData (:333-506), one level, one box,
+// diag domain = the whole boosted-frame domain
+int orc_sim_add_btd(orc_sim* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size) {
+    if (!s || num_snapshots < 1 || !(dt_snapshots_lab > 0.0) || buffer_size < 1) return -1;
+    if (!(s->gamma_boost > 1.0) || s->mw_dir != 2) return -1;
+    s->btd_buffer_size = buffer_size;
+    s->btd_dt_snap = dt_snapshots_lab;
+    const double g = s->gamma_boost, b = s->beta_boost;
+    const double mw_beta = s->mw_on ? s->mw_v / PhysConst::c : 0.0;
+    const double boosted_mw_v = (mw_beta - b) / (1.0 - b * mw_beta);
+    const double dzl = btd_dz_lab(s);
+    s->btd.assign((size_t)num_snapshots, orc_sim::BtdSnapshot{});
+    for (int i = 0; i < num_snapshots; ++i) {
+        auto& sn = s->btd[(size_t)i];
+        sn.t_lab = i * dt_snapshots_lab + g * b * s->phi[2] / PhysConst::c;
+        double dlo[3], dhi[3];
+        for (int d = 0; d < 3; ++d) {
+            int lo = std::max(0, (int)std::floor((s->plo[d] - s->plo[d]) / s->dx[d]));
+            int hi = std::max(0, (int)std::ceil((s->phi[d] - s->plo[d]) / s->dx[d])) - 1;
+            if (hi <= lo) hi = lo + 1;
+            dlo[d] = s->plo[d] + lo * s->dx[d];
+            dhi[d] = s->plo[d] + (hi + 1) * s->dx[d];
+        }
+        const double zmin_lab = (dlo[2] - boosted_mw_v * s->cur_time) * (1.0 - b * mw_beta) * g;
+        const double zmax_lab = (dhi[2] - boosted_mw_v * s->cur_time) * (1.0 - b * mw_beta) * g;
+        sn.z_boost = (sn.t_lab / g - s->cur_time) * PhysConst::c / b;
+        sn.z_lab = (sn.t_lab - s->cur_time / g) * PhysConst::c / b;
+        const int nz_lab = std::max(0, (int)std::floor((zmax_lab - zmin_lab) / dzl));
+        sn.n[0] = std::max(0, (int)std::floor((dhi[0] - dlo[0]) / s->dx[0]));
+        sn.n[1] = std::max(0, (int)std::floor((dhi[1] - dlo[1]) / s->dx[1]));
+        const int nzs = (int)std::ceil((double)nz_lab / (double)buffer_size) * buffer_size;
+        sn.n[2] = nzs;
+        sn.zlo_lab = zmin_lab + s->mw_v * sn.t_lab;
+        sn.zhi_lab = zmax_lab + s->mw_v * sn.t_lab;
+        sn.zhi_lab = sn.zhi_lab + 0.5 * dzl;
+        sn.zlo_lab = sn.zhi_lab - nzs * dzl;
+        sn.kbig = (int)std::floor((sn.zhi_lab - (sn.zlo_lab + 0.5 * dzl)) / dzl);
+        sn.ksmall = sn.kbig - (nzs - 1);
+        sn.data.assign((size_t)10 * (size_t)nzs * (size_t)sn.n[1] * (size_t)sn.n[0], 0.0);
+    }
+    return 0;
+}
+int orc_sim_btd_info(orc_sim* s, int32_t i, int32_t n[3], double z_lab[2], double* t_lab, int32_t* filled, int32_t* full) {
+    if (!s || i < 0 || i >= (int32_t)s->btd.size()) return -1;
+    const auto& sn = s->btd[(size_t)i];
+    if (n) for (int d = 0; d < 3; ++d) n[d] = sn.n[d];
+    if (z_lab) { z_lab[0] = sn.zlo_lab; z_lab[1] = sn.zhi_lab; }
+    if (t_lab) *t_lab = sn.t_lab;
+    if (filled) *filled = sn.counter;
+    if (full) *full = sn.full;
+    return 0;
+}
+int orc_sim_btd_data(orc_sim* s, int32_t i, int32_t comp, double* out) {
+    if (!s || !out || i < 0 || i >= (int32_t)s->btd.size() || comp < 0 || comp >= 10) return -1;
+    const auto& sn = s->btd[(size_t)i];
+    const size_t n = (size_t)sn.n[0] * sn.n[1] * sn.n[2];
+    std::memcpy(out, sn.data.data() + (size_t)comp * n, sizeof(double) * n);
+    return 0;
+}
+
 int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
     for (int32_t step = 0; step < numsteps; ++step) {
         // ExplicitFillBoundaryEBUpdateAux (:473-531)
@@ -1985,6 +2136,7 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
                 orc_enforce_periodic(&p, s->plo, s->phi, s->periodic, nullptr);
             }
         }
+        if (!s->btd.empty()) btd_compute_and_pack(s);   // WarpXEvolve.cpp:300-304 multi_diags->FilterComputePackFlush(step)
     }
     return 0;
 }

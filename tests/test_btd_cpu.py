@@ -1,0 +1,116 @@
+"""Back-transformed diagnostics, fields (host/BTDiagnostics.hpp against Source/Diagnostics/BTDiagnostics.cpp and
+ComputeDiagFunctors/BackTransformFunctor.cpp).  No golden file of the reference pins it (its only 3-D BTD deck draws a
+random beam) and AMReX's slice interpolation is not on disk, so the pins are: the independent restatement in the oracle
+stepper, and the physics a back-transformation must deliver -- a laser emitted in a gamma = 2 frame is found in the lab
+frame at the lab position, with the lab wavelength and the lab amplitude."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import pec_case
+from warpx_amd import plasma
+from warpx_amd.sim import WarpXSim
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def host_cpu():
+    from tests.oracle_lib import load_host_cpu
+    return load_host_cpu()
+
+
+def test_btd_host_layer_against_the_oracle_stepper(oracle, host_cpu):
+    """Config 5 in small (gamma = 5, window at c, CKC, Vay, NCI, antenna, injected plasma) with three lab-frame snapshots:
+    the host layer's BTDiagnostics and the oracle stepper's own give the same slices, component by component."""
+    steps = 50
+    out = []
+    for lib in (host_cpu, oracle):
+        sim, _ = pec_case.make_boosted_lwfa_sim(lib)
+        dt_snap = 12 * sim.dt * pec_case.BOOST_GAMMA   # a new snapshot plane enters the boosted domain every ~12 steps
+        sim.add_btd(3, dt_snap, buffer_size=32)
+        sim.evolve(steps)
+        info = [sim.btd_info(i) for i in range(3)]
+        data = [{c: sim.btd_snapshot(i, c) for c in WarpXSim.BTD_COMPONENTS} for i in range(3)]
+        sim.close()
+        out.append((info, data))
+    (ih, dh), (io, do) = out
+    for i in range(3):
+        assert ih[i]["n"] == io[i]["n"] and ih[i]["n"][2] % 32 == 0
+        assert ih[i]["slices"] == io[i]["slices"] and ih[i]["full"] == io[i]["full"]
+        assert abs(ih[i]["t_lab"] - io[i]["t_lab"]) <= 1e-15 * abs(io[i]["t_lab"]) + 1e-30
+        for a, b in zip(ih[i]["z_lab"], io[i]["z_lab"]):
+            assert abs(a - b) <= 1e-12 * max(abs(b), 1e-6)
+        for c in WarpXSim.BTD_COMPONENTS:
+            a, b = dh[i][c], do[i][c]
+            scale = np.max(np.abs(b))
+            assert np.max(np.abs(a - b)) <= 1e-9 * scale, (i, c)
+    # the first snapshot has received one slice per step, the later ones fewer; untouched planes are zero
+    assert ih[0]["slices"] == steps and 0 < ih[2]["slices"] < ih[1]["slices"] < steps
+    rho = dh[0]["rho"]   # slices are written from the top of the lab-frame box downwards: nothing below the last one
+    assert np.all(rho[:, :, : rho.shape[2] - steps - 1] == 0.0) and np.any(rho != 0.0)
+
+
+def test_btd_laser_pulse_in_the_lab_frame(host_cpu):
+    """tests/decks/boosted_laser_3d.inputs (gamma = 2, window at c, a plane pulse of 0.8 um and 1e12 V/m emitted at
+    z = -1 um around t = 20 fs, all lab-frame numbers) with a lab-frame snapshot at 60 fs: the pulse sits at
+    -1 um + c (60 - 20) fs with the lab wavelength and amplitude, Bx = -Ey / c -- the Lorentz transform, the slice times
+    and the lab-frame indexing at once.  In the boosted frame the same pulse has 3.7 x the wavelength and 0.27 x the
+    amplitude (test_boosted_frame_laser_antenna)."""
+    deck = os.path.join(HERE, "decks", "boosted_laser_3d.inputs")
+    sim = WarpXSim.from_inputs(host_cpu, deck, overrides=("max_step=700",))
+    sim.add_btd(2, 60e-15, buffer_size=64)
+    sim.evolve(700)
+    info = sim.btd_info(1)
+    ey = sim.btd_snapshot(1, "Ey")
+    bx = sim.btd_snapshot(1, "Bx")
+    ex = sim.btd_snapshot(1, "Ex")
+    sim.close()
+    assert info["full"] or info["slices"] > 400
+    nz = info["n"][2]
+    zlo, zhi = info["z_lab"]
+    dz = (zhi - zlo) / nz
+    z = zlo + (np.arange(nz) + 0.5) * dz
+    line = ey[ey.shape[0] // 2, ey.shape[1] // 2, :]
+    k = int(np.argmax(np.abs(line)))
+    amp = np.max(np.abs(line))
+    c = plasma.C_LIGHT
+    assert abs(z[k] - (-1e-6 + c * 40e-15)) < 1.5e-6                     # where a lab-frame observer sees it at 60 fs
+    # e_max, less what the diagnostic's own averaging takes: cell-centring (two z nodes, 13.7 cells per boosted-frame
+    # wavelength: x 0.974), the linear slice interpolation, and 6.5 lab-frame samples per wavelength around the crest
+    assert 0.88e12 < amp < 1.02e12
+    # wavelength from the zero crossings around the peak
+    w = (np.abs(z - z[k]) < 2.0e-6)
+    seg, zs = line[w], z[w]
+    cross = np.flatnonzero(seg[:-1] * seg[1:] < 0)
+    zc = zs[cross] + (zs[cross + 1] - zs[cross]) * seg[cross] / (seg[cross] - seg[cross + 1])
+    lam = 2.0 * np.mean(np.diff(zc))
+    assert abs(lam - 0.8e-6) < 0.04e-6
+    # a plane wave along +z polarised along y: Bx = -Ey / c, nothing in Ex
+    assert np.max(np.abs(bx + ey / c)) < 0.03 * amp / c
+    assert np.max(np.abs(ex)) < 1e-6 * amp
+
+
+def test_btd_from_an_inputs_file(host_cpu):
+    """<diag>.diag_type = BackTransformed in a deck (BTDiagnostics::ReadParameters, BTDiagnostics.cpp:206-292): snapshots every
+    dz_snapshots_lab / c, the lab-frame box of the reference's InitializeBufferData (:333-506) -- the lab-frame domain
+    [-30 um, 0] plus half a lab cell, its length rounded up to whole buffers."""
+    deck = os.path.join(HERE, "decks", "boosted_laser_3d.inputs")
+    over = ("max_step=20", "diagnostics.diags_names=d1", "d1.diag_type=BackTransformed", "d1.do_back_transformed_fields=1",
+            "d1.num_snapshots_lab=2", "d1.dz_snapshots_lab=18.e-6", "d1.buffer_size=64", "d1.format=plotfile",
+            "d1.fields_to_plot=Ex Ey Ez Bx By Bz jx jy jz rho")
+    sim = WarpXSim.from_inputs(host_cpu, deck, overrides=over)
+    sim.evolve(20)
+    a, b = sim.btd_info(0), sim.btd_info(1)
+    sim.close()
+    c = plasma.C_LIGHT
+    assert a["t_lab"] == 0.0 and abs(b["t_lab"] - 18e-6 / c) < 1e-25      # prob_hi = 0: no offset (:346-347)
+    assert a["n"][:2] == (8, 8) and a["n"][2] % 64 == 0
+    dz_lab = (a["z_lab"][1] - a["z_lab"][0]) / a["n"][2]
+    assert abs(a["z_lab"][1] - 0.5 * dz_lab) < 1e-12                      # the lab-frame domain ends at z = 0
+    assert a["z_lab"][0] < -30e-6 < a["z_lab"][0] + 64 * dz_lab           # ... and starts at -30 um, rounded up by < 1 buffer
+    assert abs((b["z_lab"][1] - a["z_lab"][1]) - c * b["t_lab"]) < 1e-12  # the snapshots ride with the window (:472-475)
+    assert a["slices"] == 20 and not a["full"]
+    with pytest.raises(Exception):
+        WarpXSim.from_inputs(host_cpu, deck, overrides=over[:4] + ("d1.intervals=0:3",))

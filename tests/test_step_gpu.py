@@ -563,6 +563,27 @@ def test_boosted_frame_laser_wakefield_deck_on_gpu(oracle, product):
     sim.close()
 
 
+def test_back_transformed_fields_on_gpu(oracle, product):
+    """Lab-frame snapshots (wxa_sim_add_btd: BTDiagnostics.cpp, BackTransformFunctor.cpp) of config 5 in small from the HIP
+    path against the oracle stepper's own back-transformation: three snapshots, 50 steps, every component at 1e-9 of its
+    scale (tests/test_btd_cpu.py has the host layer on the CPU kernels and the lab-frame physics)."""
+    from tests import pec_case
+    out = []
+    for lib in (product, oracle):
+        sim, _ = pec_case.make_boosted_lwfa_sim(lib)
+        sim.add_btd(3, 12 * sim.dt * pec_case.BOOST_GAMMA, buffer_size=32)
+        sim.evolve(50)
+        out.append(([sim.btd_info(i) for i in range(3)],
+                    [{c: sim.btd_snapshot(i, c) for c in WarpXSim.BTD_COMPONENTS} for i in range(3)]))
+        sim.close()
+    (ig, dg), (io, do) = out
+    for i in range(3):
+        assert ig[i]["n"] == io[i]["n"] and ig[i]["slices"] == io[i]["slices"] > 0
+        for c in WarpXSim.BTD_COMPONENTS:
+            scale = np.max(np.abs(do[i][c]))
+            assert scale > 0 and np.max(np.abs(dg[i][c] - do[i][c])) <= 1e-9 * scale, (i, c)
+
+
 def test_boosted_frame_laser_antenna_on_gpu(product):
     """tests/decks/boosted_laser_3d.inputs on the HIP path: the pulse arrives with the Lorentz-transformed amplitude and
     wavelength (tests/test_inputs_cpu.py::check_boosted_laser)."""

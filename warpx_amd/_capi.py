@@ -224,6 +224,10 @@ _SIM_SIGS = {
     "sim_set_external_particle_fields": (C.c_int, [C.c_void_p, C.c_int32, _D3, _D3]),
     "sim_set_radiation_reaction": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
+    "sim_add_btd": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32]),
+    "sim_btd_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sim_btd_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
 }
 
 # product-only entry points

@@ -1,0 +1,242 @@
+// Back-transformed diagnostics, fields only: lab-frame snapshots assembled slice by slice from a boosted-frame run.
+// Restates the field part of Source/Diagnostics/BTDiagnostics.cpp and
+// Source/Diagnostics/ComputeDiagFunctors/BackTransformFunctor.cpp for one level, one box, boost and window along z:
+//   DerivedInitData (:66-205), InitializeBufferData (:333-506): lab time, lab-frame extent and index box of snapshot i;
+//   PrepareBufferData / UpdateBufferData (:755-798), GetZSliceInDomainFlag (:999-1018), k_index_zlab (:892-905):
+//     where the snapshot's plane z_lab(t) sits in the boosted frame at this step and which lab-frame index it fills;
+//   BackTransformFunctor::operator() (:49-149): the cell-centred fields (CellCenterFunctor: Ex .. Bz, jx .. jz, rho)
+//     sliced at z_boost with linear interpolation between the two nearest cell centres (amrex::get_slice_data with
+//     interpolate = true -- AMReX is not on disk: the rule is restated from its documented behaviour and from the
+//     half-cell exclusion of GetZSliceInDomainFlag, parity unpinned), LorentzTransformZ (:246-317), copy to index k_lab.
+// What is not here: the buffer multifabs and their flushes (a snapshot is kept whole in host memory: the merged plotfile
+// of the reference holds the same numbers), particles (BackTransformParticleFunctor), mesh refinement, RZ, openPMD.
+// Output stage, not on the step path: the fields are copied to the host (Plotfile.hpp does the same).
+#ifndef WXA_HOST_BTDIAGNOSTICS_HPP_
+#define WXA_HOST_BTDIAGNOSTICS_HPP_
+
+#include <cmath>
+#include <stdexcept>
+#include <vector>
+
+#include "amrex_shim.hpp"
+#include "backend.hpp"
+
+namespace wxa::host {
+
+class BTDiagnostics {
+public:
+    static constexpr int NCOMP = 10;   // Ex Ey Ez Bx By Bz jx jy jz rho (BackTransformFunctor.cpp:190-201)
+
+    struct Snapshot {
+        double t_lab = 0;                       // m_t_lab
+        double zlo_lab = 0, zhi_lab = 0;        // m_snapshot_domain_lab along z
+        int ksmall = 0, kbig = 0;               // m_snapshot_box along z
+        double z_boost = 0, z_lab = 0;          // m_current_z_boost / m_current_z_lab
+        int counter = 0, last_valid = 0, full = 0;
+        int n[3] = {0, 0, 0};                   // cells of the snapshot array (x, y, z)
+        std::vector<double> data;               // [comp][k][j][i], zero until a slice arrives
+    };
+
+    BTDiagnostics(int num_snapshots, double dt_snapshots_lab, int buffer_size)
+        : m_num(num_snapshots), m_dt_snap(dt_snapshots_lab), m_buffer_size(buffer_size) {
+        if (num_snapshots < 1 || !(dt_snapshots_lab > 0.0) || buffer_size < 1)
+            throw std::runtime_error("BackTransformed diagnostic: num_snapshots_lab >= 1, dt_snapshots_lab > 0, buffer_size >= 1");
+    }
+
+    int num_snapshots() const { return m_num; }
+    const Snapshot& snapshot(int i) const { return m_snap.at((size_t)i); }
+
+    // c dt / (beta gamma): lab-frame distance between the slices of consecutive steps (:885-890)
+    double dz_lab(double dt) const { return kC * dt * 1.0 / m_beta * 1.0 / m_gamma; }
+
+    // InitializeBufferData for every snapshot; called once, when the diagnostic is added
+    template <class WX>
+    void Init(WX& wx) {
+        const auto& ctx = wx.context();
+        if (!(ctx.gamma_boost > 1.0)) throw std::runtime_error("BackTransformed diagnostic: needs warpx.gamma_boost > 1");
+        if (wx.moving_window_dir != 2) throw std::runtime_error("BackTransformed diagnostic: boost and window along z");
+        m_gamma = ctx.gamma_boost;
+        m_beta = std::sqrt(1.0 - 1.0 / (m_gamma * m_gamma));
+        m_mw_beta = wx.do_moving_window ? wx.moving_window_v / kC : 0.0;
+        const double t_new = wx.gett_new();
+        const double dt = wx.getdt();
+        const double dzl = dz_lab(dt);
+        const double bmw_v = (m_mw_beta - m_beta) / (1.0 - m_beta * m_mw_beta);   // :341-342
+        m_snap.assign((size_t)m_num, Snapshot{});
+        for (int i = 0; i < m_num; ++i) {
+            Snapshot& s = m_snap[(size_t)i];
+            const double zmax_boost = ctx.prob_hi[2];
+            s.t_lab = i * m_dt_snap + m_gamma * m_beta * zmax_boost / kC;              // :346-347
+            // diag domain = the whole boosted-frame domain (m_lo / m_hi default), re-derived from the index box (:391-397)
+            int lo[3], hi[3];
+            double dlo[3], dhi[3];
+            for (int d = 0; d < 3; ++d) {
+                const double cs = ctx.dx[d];
+                const int lo_index = (int)std::floor((ctx.prob_lo[d] - ctx.prob_lo[d]) / cs);
+                lo[d] = std::max(0, lo_index);
+                const int hi_index = (int)std::ceil((ctx.prob_hi[d] - ctx.prob_lo[d]) / cs);
+                hi[d] = std::max(0, hi_index) - 1;
+                if (hi[d] <= lo[d]) hi[d] = lo[d] + 1;
+                dlo[d] = ctx.prob_lo[d] + lo[d] * cs;
+                dhi[d] = ctx.prob_lo[d] + (hi[d] + 1) * cs;
+            }
+            // lab-frame extent along z (:401-404), literally: the reference multiplies this ratio of betas by the time
+            // (a restart term; t_new is 0 when a diagnostic is set up at the start of a run)
+            const double zmin_lab = (dlo[2] - bmw_v * t_new) * (1.0 - m_beta * m_mw_beta) * m_gamma;
+            const double zmax_lab = (dhi[2] - bmw_v * t_new) * (1.0 - m_beta * m_mw_beta) * m_gamma;
+            s.z_boost = z_boost_of(s.t_lab, t_new);
+            s.z_lab = z_lab_of(s.t_lab, t_new);
+            const int nz_lab = std::max(0, (int)std::floor((zmax_lab - zmin_lab) / dzl));          // :430-434
+            const int nx_lab = std::max(0, (int)std::floor((dhi[0] - dlo[0]) / ctx.dx[0]));
+            const int ny_lab = std::max(0, (int)std::floor((dhi[1] - dlo[1]) / ctx.dx[1]));
+            const int max_buffers = (int)std::ceil((double)nz_lab / (double)m_buffer_size);        // :464-466
+            const int nzs = max_buffers * m_buffer_size;                                            // :469
+            s.zlo_lab = zmin_lab + wx.moving_window_v * s.t_lab;                                    // :472-475
+            s.zhi_lab = zmax_lab + wx.moving_window_v * s.t_lab;
+            s.zhi_lab = s.zhi_lab + 0.5 * dzl;                                                      // :478-480
+            s.zlo_lab = s.zhi_lab - nzs * dzl;                                                      // :481-484
+            const int kindex_hi = (int)std::floor((s.zhi_lab - (s.zlo_lab + 0.5 * dzl)) / dzl);     // :489-494
+            s.kbig = kindex_hi;
+            s.ksmall = kindex_hi - (nzs - 1);
+            s.n[0] = nx_lab; s.n[1] = ny_lab; s.n[2] = nzs;
+            s.data.assign((size_t)NCOMP * (size_t)nzs * (size_t)ny_lab * (size_t)nx_lab, 0.0);
+        }
+    }
+
+    // Diagnostics::ComputeAndPack (Diagnostics.cpp:558-608) for this diagnostic, once per step after the step
+    template <class WX>
+    void ComputeAndPack(WX& wx) {
+        const auto& ctx = wx.context();
+        const double t_new = wx.gett_new();
+        const double dzl = dz_lab(wx.getdt());
+        // PrepareBufferData
+        for (Snapshot& s : m_snap) {
+            s.z_boost = z_boost_of(s.t_lab, t_new);
+            s.z_lab = z_lab_of(s.t_lab, t_new);
+        }
+        bool any = false;
+        std::vector<char> in_domain(m_snap.size(), 0);
+        for (size_t i = 0; i < m_snap.size(); ++i) {
+            in_domain[i] = slice_in_domain(m_snap[i], ctx) ? 1 : 0;
+            any = any || (in_domain[i] && !m_snap[i].full);
+        }
+        if (any) {
+            // PrepareFieldDataForOutput: the ten cell-centred components of the whole (single) box, on the host
+            using warpx::fields::FieldType;
+            using ablastr::fields::Direction;
+            int nc[3] = {0, 0, 0};
+            std::vector<std::vector<double>> cc;
+            const FieldType fts[3] = {FieldType::Efield_fp, FieldType::Bfield_fp, FieldType::current_fp};
+            wx.sync_stream();
+            for (const FieldType ft : fts)
+                for (int d = 0; d < 3; ++d) cc.push_back(cell_centered(ctx.be, *wx.fields().get(ft, Direction{d}, 0), nc));
+            cc.push_back(cell_centered(ctx.be, wx.ComputeRho(), nc));
+            for (size_t i = 0; i < m_snap.size(); ++i) {
+                Snapshot& s = m_snap[i];
+                if (!in_domain[i] || s.full) continue;                     // m_perform_backtransform (:152-164)
+                const int k_lab = k_index_zlab(s, dzl);
+                if (k_lab < s.ksmall || k_lab > s.kbig) continue;          // outside the snapshot's box: no buffer there
+                back_transform_slice(s, k_lab, cc, nc, ctx);
+            }
+        }
+        // UpdateBufferData, then what DoDump / Flush do to the flags (:294-320, :907-914)
+        for (size_t i = 0; i < m_snap.size(); ++i) {
+            Snapshot& s = m_snap[i];
+            if (in_domain[i]) ++s.counter;
+            if (k_index_zlab(s, dzl) == s.ksmall) s.last_valid = 1;
+            if (s.last_valid == 1) s.full = 1;
+        }
+    }
+
+private:
+    static constexpr double kC = 299792458.0;
+
+    double z_boost_of(double t_lab, double t_boost) const { return (t_lab / m_gamma - t_boost) * kC / m_beta; }   // BTDiagnostics.H:276-280
+    double z_lab_of(double t_lab, double t_boost) const { return (t_lab - t_boost / m_gamma) * kC / m_beta; }     // :285-289
+
+    template <class CTX>
+    bool slice_in_domain(const Snapshot& s, const CTX& ctx) const {   // GetZSliceInDomainFlag
+        const double cs = ctx.dx[2];
+        const bool out = (s.z_boost <= ctx.prob_lo[2] + 0.5 * cs) || (s.z_boost >= ctx.prob_hi[2] - 0.5 * cs) ||
+                         (s.z_lab <= s.zlo_lab) || (s.z_lab >= s.zhi_lab);
+        return !out;
+    }
+    int k_index_zlab(const Snapshot& s, double dzl) const {
+        return (int)std::floor((s.z_lab - s.zlo_lab) / dzl) + s.ksmall;
+    }
+
+    // staggered component -> cell centres of the valid box (CellCenterFunctor.cpp:20-29 -> ablastr/coarsen/sample.H:47-99)
+    static std::vector<double> cell_centered(const Backend* be, const amrex::MultiFab& mf, int ncell[3]) {
+        const wxa_field_view& v = mf.view();
+        std::vector<double> a((size_t)v.kstride * (size_t)v.n[2]);
+        if (be->memcpy_d2h(a.data(), v.p, sizeof(double) * a.size()) != 0)
+            throw std::runtime_error("BackTransformed diagnostic: device copy failed");
+        int np[3];
+        for (int d = 0; d < 3; ++d) {
+            np[d] = 1 + v.stag[d];
+            ncell[d] = v.n[d] - 2 * v.ng[d] - v.stag[d];
+        }
+        const double wx = 1.0 / np[0], wy = 1.0 / np[1], wz = 1.0 / np[2];
+        std::vector<double> out((size_t)ncell[0] * ncell[1] * ncell[2]);
+        size_t o = 0;
+        for (int k = 0; k < ncell[2]; ++k)
+            for (int j = 0; j < ncell[1]; ++j)
+                for (int i = 0; i < ncell[0]; ++i) {
+                    double c = 0.0;
+                    for (int kr = 0; kr < np[2]; ++kr)
+                        for (int jr = 0; jr < np[1]; ++jr)
+                            for (int ir = 0; ir < np[0]; ++ir)
+                                c += wx * wy * wz * a[(size_t)(i + ir + v.ng[0]) + (size_t)(j + jr + v.ng[1]) * v.jstride +
+                                                     (size_t)(k + kr + v.ng[2]) * v.kstride];
+                    out[o++] = c;
+                }
+        return out;
+    }
+
+    template <class CTX>
+    void back_transform_slice(Snapshot& s, int k_lab, const std::vector<std::vector<double>>& cc, const int nc[3],
+                              const CTX& ctx) const {
+        // get_slice_data(dir = z, coord = z_boost, interpolate): the cell that holds the coordinate and its neighbour on
+        // the side of the coordinate, weighted linearly between the two cell centres
+        const double cs = ctx.dx[2];
+        const int kc = (int)std::floor((s.z_boost - ctx.prob_lo[2]) / cs);
+        const double zc = ctx.prob_lo[2] + (kc + 0.5) * cs;
+        int klo, khi;
+        double w;
+        if (s.z_boost >= zc) { klo = kc; khi = kc + 1; w = (s.z_boost - zc) / cs; }
+        else { klo = kc - 1; khi = kc; w = (s.z_boost - (zc - cs)) / cs; }
+        if (klo < 0 || khi >= nc[2]) return;   // excluded by GetZSliceInDomainFlag's half cell; kept as a guard
+        const size_t plane = (size_t)nc[0] * nc[1];
+        const size_t snap_plane = (size_t)s.n[0] * s.n[1];
+        const size_t kk = (size_t)(k_lab - s.ksmall);
+        const double clight = kC, inv_clight = 1.0 / kC;
+        for (int j = 0; j < s.n[1] && j < nc[1]; ++j)
+            for (int i = 0; i < s.n[0] && i < nc[0]; ++i) {
+                double v[NCOMP];
+                const size_t at = (size_t)i + (size_t)j * nc[0];
+                for (int c = 0; c < NCOMP; ++c)
+                    v[c] = (1.0 - w) * cc[(size_t)c][at + (size_t)klo * plane] + w * cc[(size_t)c][at + (size_t)khi * plane];
+                // LorentzTransformZ (BackTransformFunctor.cpp:289-313)
+                const double ex_lab = m_gamma * (v[0] + m_beta * clight * v[4]);
+                const double by_lab = m_gamma * (v[4] + m_beta * inv_clight * v[0]);
+                v[0] = ex_lab; v[4] = by_lab;
+                const double ey_lab = m_gamma * (v[1] - m_beta * clight * v[3]);
+                const double bx_lab = m_gamma * (v[3] - m_beta * inv_clight * v[1]);
+                v[1] = ey_lab; v[3] = bx_lab;
+                const double j_lab = m_gamma * (v[8] + m_beta * clight * v[9]);
+                const double rho_lab = m_gamma * (v[9] + m_beta * inv_clight * v[8]);
+                v[8] = j_lab; v[9] = rho_lab;
+                const size_t dst = (size_t)i + (size_t)j * s.n[0] + kk * snap_plane;
+                for (int c = 0; c < NCOMP; ++c) s.data[(size_t)c * snap_plane * (size_t)s.n[2] + dst] = v[c];
+            }
+    }
+
+    int m_num;
+    double m_dt_snap;
+    int m_buffer_size;
+    double m_gamma = 1.0, m_beta = 0.0, m_mw_beta = 0.0;
+    std::vector<Snapshot> m_snap;
+};
+
+}  // namespace wxa::host
+#endif

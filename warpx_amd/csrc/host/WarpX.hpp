@@ -7,6 +7,7 @@
 #ifndef WXA_HOST_WARPX_HPP_
 #define WXA_HOST_WARPX_HPP_
 
+#include "BTDiagnostics.hpp"
 #include "NCIGodfreyFilter.hpp"
 #include "WarpXParticleContainer.hpp"
 
@@ -283,9 +284,22 @@ public:
             const bool move_j = is_synchronized;
             const int num_moved = MoveWindow(istep, move_j);     // :246 MoveWindow(step+1, move_j)
             HandleParticlesAtBoundaries(step, cur_time, num_moved);  // :256
+            if (m_btd) m_btd->ComputeAndPack(*this);             // :300-304 multi_diags->FilterComputePackFlush(step)
         }
         m_be->stream_sync(m_ctx.stream);
     }
+
+    // <diag>.diag_type = BackTransformed with do_back_transformed_fields = 1 (BTDiagnostics.hpp): lab-frame snapshots
+    // num_snapshots_lab, dt_snapshots_lab (= dz_snapshots_lab / c), buffer_size as in BTDiagnostics::ReadParameters (:206-292)
+    void AddBTDiagnostics(int num_snapshots, amrex::Real dt_snapshots_lab, int buffer_size) {
+        for (int d = 0; d < 3; ++d)
+            if (m_cfg.nbricks[d] != 1) throw std::runtime_error("BackTransformed diagnostic: one brick only");
+        m_btd = std::make_unique<BTDiagnostics>(num_snapshots, dt_snapshots_lab, buffer_size);
+        m_btd->Init(*this);
+    }
+    const BTDiagnostics* btd() const { return m_btd.get(); }
+    amrex::Real getdt() const { return dt[0]; }
+    void sync_stream() { m_be->stream_sync(m_ctx.stream); }
 
     // warpx.do_moving_window / moving_window_dir / moving_window_v (Source/WarpX.cpp:620-660): forward window, lab frame
     void SetMovingWindow(int dir, amrex::Real v_over_c) {
@@ -699,6 +713,7 @@ private:
     std::unique_ptr<amrex::MultiFab> m_nci_E[3], m_nci_B[3];
     std::unique_ptr<amrex::MultiFab> m_filter_tmp[3];
     std::unique_ptr<amrex::MultiFab> m_rho, m_rho_tmp;   // ComputeRho (diagnostics)
+    std::unique_ptr<BTDiagnostics> m_btd;
     // field-solve exchanges: guard layer of B computed redundantly; J's guard sum on a second stream
     bool m_grown_b = false, m_overlap = false;
     void* m_comm_stream = nullptr;

@@ -697,6 +697,24 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     std::vector<std::string> diag_names, rdiag_names;
     pp.queryarr("diagnostics.diags_names", diag_names);
     pp.queryarr("warpx.reduced_diags_names", rdiag_names);
+    // <diag>.diag_type = BackTransformed (BTDiagnostics::ReadParameters, BTDiagnostics.cpp:206-292): the field snapshots are
+    // assembled in memory (wxa_sim_btd_info / _data); formats, species output and the other diagnostics are not produced
+    for (const std::string& d : diag_names) {
+        std::string type;
+        if (!pp.query_word(d + ".diag_type", type) || type != "backtransformed") continue;
+        int fields_on = 1, nsnap = 0, buffer = 256;
+        pp.queryWithParser(d + ".do_back_transformed_fields", fields_on);
+        if (!fields_on) continue;
+        if (pp.contains(d + ".intervals")) throw std::runtime_error("inputs: " + d + ".intervals is not on this path (num_snapshots_lab)");
+        if (!pp.queryWithParser(d + ".num_snapshots_lab", nsnap)) throw std::runtime_error("inputs: " + d + ".num_snapshots_lab must be set");
+        double dt_snap = 0.0, dz_snap = 0.0;
+        const bool have_dt = pp.queryWithParser(d + ".dt_snapshots_lab", dt_snap);
+        if (pp.queryWithParser(d + ".dz_snapshots_lab", dz_snap)) dt_snap = dz_snap / 299792458.0;   // :258-261
+        else if (!have_dt) throw std::runtime_error("inputs: " + d + ".dt_snapshots_lab or dz_snapshots_lab must be set");
+        pp.queryWithParser(d + ".buffer_size", buffer);
+        if (wx.btd()) throw std::runtime_error("inputs: one BackTransformed diagnostic only");
+        wx.AddBTDiagnostics(nsnap, dt_snap, buffer);
+    }
     for (const std::string& d : diag_names) pp.ignore_prefix(d + ".");
     for (const std::string& d : rdiag_names) pp.ignore_prefix(d + ".");
     pp.ignore_prefix("diagnostics.");

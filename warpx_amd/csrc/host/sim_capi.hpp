@@ -179,6 +179,41 @@ inline int sim_compute_rho(SimHandle* h) {
     }
 }
 
+inline int sim_add_btd(SimHandle* h, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size) {
+    if (!h) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->AddBTDiagnostics(num_snapshots, dt_snapshots_lab, buffer_size);
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
+// n: cells of snapshot i (x, y, z); z_lab: its lab-frame extent along z; t_lab; filled: slices received; full: closed
+inline int sim_btd_info(SimHandle* h, int32_t i, int32_t n[3], double z_lab[2], double* t_lab, int32_t* filled,
+                        int32_t* full) {
+    if (!h || !h->warpx->btd() || i < 0 || i >= h->warpx->btd()->num_snapshots()) return WXA_ERR_INVALID_ARG;
+    const auto& s = h->warpx->btd()->snapshot(i);
+    if (n) for (int d = 0; d < 3; ++d) n[d] = s.n[d];
+    if (z_lab) { z_lab[0] = s.zlo_lab; z_lab[1] = s.zhi_lab; }
+    if (t_lab) *t_lab = s.t_lab;
+    if (filled) *filled = s.counter;
+    if (full) *full = s.full;
+    return WXA_OK;
+}
+
+// component comp (Ex Ey Ez Bx By Bz jx jy jz rho) of snapshot i into out[k][j][i] (host memory, n[0] n[1] n[2] doubles)
+inline int sim_btd_data(SimHandle* h, int32_t i, int32_t comp, double* out) {
+    if (!h || !out || !h->warpx->btd() || i < 0 || i >= h->warpx->btd()->num_snapshots() || comp < 0 ||
+        comp >= BTDiagnostics::NCOMP)
+        return WXA_ERR_INVALID_ARG;
+    const auto& s = h->warpx->btd()->snapshot(i);
+    const size_t n = (size_t)s.n[0] * s.n[1] * s.n[2];
+    std::memcpy(out, s.data.data() + (size_t)comp * n, sizeof(double) * n);
+    return WXA_OK;
+}
+
 inline int sim_get_particles(SimHandle* h, int32_t id, wxa_particle_view* out) {
     if (!h || !out || id < 0 || id >= h->warpx->GetPartContainer().nSpecies()) return WXA_ERR_INVALID_ARG;
     *out = h->warpx->GetPartContainer().GetParticleContainer(id).tile().view();
@@ -256,6 +291,19 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     }                                                                                                  \
     RET PFX##sim_add_laser(SIMTYPE* s, const wxa_laser_antenna* la) {                                  \
         return (RET)wxa::host::sim_add_laser(reinterpret_cast<wxa::host::SimHandle*>(s), la);            \
+    }                                                                                                  \
+    RET PFX##sim_add_btd(SIMTYPE* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size) { \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        int rc = wxa::host::sim_add_btd(h, num_snapshots, dt_snapshots_lab, buffer_size);              \
+        if (rc != 0 && h) SET_ERROR(h->error.c_str());                                                 \
+        return (RET)rc;                                                                                \
+    }                                                                                                  \
+    RET PFX##sim_btd_info(SIMTYPE* s, int32_t i, int32_t n[3], double z_lab[2], double* t_lab, int32_t* filled, \
+                          int32_t* full) {                                                             \
+        return (RET)wxa::host::sim_btd_info(reinterpret_cast<wxa::host::SimHandle*>(s), i, n, z_lab, t_lab, filled, full); \
+    }                                                                                                  \
+    RET PFX##sim_btd_data(SIMTYPE* s, int32_t i, int32_t comp, double* out) {                          \
+        return (RET)wxa::host::sim_btd_data(reinterpret_cast<wxa::host::SimHandle*>(s), i, comp, out); \
     }                                                                                                  \
     RET PFX##sim_get_particles(SIMTYPE* s, int32_t id, wxa_particle_view* out) {                       \
         return (RET)wxa::host::sim_get_particles(reinterpret_cast<wxa::host::SimHandle*>(s), id, out);      \

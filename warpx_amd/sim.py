@@ -88,6 +88,27 @@ class WarpXSim:
         """AMReX plotfile of the current state (wxa_sim_write_plotfile): the reference's FlushFormatPlotfile output."""
         self.lib.sim_write_plotfile(self._h, str(path).encode())
 
+    BTD_COMPONENTS = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho")
+
+    def add_btd(self, num_snapshots: int, dt_snapshots_lab: float, buffer_size: int = 256):
+        """<diag>.diag_type = BackTransformed, fields (wxa_sim_add_btd): lab-frame snapshots every dt_snapshots_lab."""
+        self.lib.sim_add_btd(self._h, int(num_snapshots), float(dt_snapshots_lab), int(buffer_size))
+
+    def btd_info(self, i: int) -> dict:
+        n = (C.c_int32 * 3)()
+        z = (C.c_double * 2)()
+        t = C.c_double()
+        filled, full = C.c_int32(), C.c_int32()
+        self.lib.sim_btd_info(self._h, int(i), n, z, C.byref(t), C.byref(filled), C.byref(full))
+        return {"n": tuple(n), "z_lab": tuple(z), "t_lab": t.value, "slices": filled.value, "full": bool(full.value)}
+
+    def btd_snapshot(self, i: int, name: str) -> np.ndarray:
+        """Component `name` of lab-frame snapshot i, indexed [i, j, k] (zeros where no slice has arrived yet)."""
+        n = self.btd_info(i)["n"]
+        out = np.zeros(n[0] * n[1] * n[2], dtype=np.float64)
+        self.lib.sim_btd_data(self._h, int(i), self.BTD_COMPONENTS.index(name), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return np.ascontiguousarray(out.reshape(n[2], n[1], n[0]).transpose(2, 1, 0))
+
     def checksum(self) -> dict:
         """The reference's regression checksum of the current state (wxa_sim_checksum_json), this brick's share."""
         import json
