@@ -52,7 +52,7 @@ def test_btd_host_layer_against_the_oracle_stepper(oracle, host_cpu):
     assert np.all(rho[:, :, : rho.shape[2] - steps - 1] == 0.0) and np.any(rho != 0.0)
 
 
-def test_btd_laser_pulse_in_the_lab_frame(host_cpu):
+def test_btd_laser_pulse_in_the_lab_frame(host_cpu, tmp_path):
     """tests/decks/boosted_laser_3d.inputs (gamma = 2, window at c, a plane pulse of 0.8 um and 1e12 V/m emitted at
     z = -1 um around t = 20 fs, all lab-frame numbers) with a lab-frame snapshot at 60 fs: the pulse sits at
     -1 um + c (60 - 20) fs with the lab wavelength and amplitude, Bx = -Ey / c -- the Lorentz transform, the slice times
@@ -66,6 +66,13 @@ def test_btd_laser_pulse_in_the_lab_frame(host_cpu):
     ey = sim.btd_snapshot(1, "Ey")
     bx = sim.btd_snapshot(1, "Bx")
     ex = sim.btd_snapshot(1, "Ex")
+    # the snapshot as a plotfile (wxa_sim_btd_write_plotfile), read back with the strict reader of test_plotfile_cpu.py:
+    # the same numbers, lab-frame geometry and time
+    from tests.test_plotfile_cpu import read_plotfile
+    sim.btd_write_plotfile(1, str(tmp_path / "lab_snapshot_1"))
+    pf = read_plotfile(str(tmp_path / "lab_snapshot_1"))
+    assert pf["names"] == list(WarpXSim.BTD_COMPONENTS) and pf["time"] == info["t_lab"] and pf["step"] == 1
+    assert np.array_equal(pf["fields"]["Ey"], ey) and np.array_equal(pf["fields"]["Bx"], bx)
     sim.close()
     assert info["full"] or info["slices"] > 400
     nz = info["n"][2]

@@ -66,6 +66,77 @@ inline std::string box_string(const int lo[3], const int hi[3]) {
     return s.str();
 }
 
+// Header + Level_0/Cell_H + Level_0/Cell_D_00000 of a single-level plotfile with one grid: `data[c]` is component c of
+// the box lo..hi in Fortran order (layouts cited at the top of this file)
+inline void write_cell_data(const std::string& dir, const std::vector<std::string>& names,
+                            const std::vector<std::vector<double>>& data, const int lo[3], const int hi[3],
+                            const double rlo[3], const double rhi[3], const double dx[3], double time, int64_t step) {
+    const int ncomp = (int)names.size();
+    make_dir(dir);
+    make_dir(dir + "/Level_0");
+    const std::string box = box_string(lo, hi);
+    const std::string fab_header = "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" + box + " " +
+                                   std::to_string(ncomp) + "\n";
+    {
+        std::ofstream f(dir + "/Level_0/Cell_D_00000", std::ios::binary | std::ios::trunc);
+        if (!f.good()) throw std::runtime_error("plotfile: cannot open Cell_D_00000");
+        f << fab_header;
+        for (const auto& c : data) f.write(reinterpret_cast<const char*>(c.data()), (std::streamsize)(sizeof(double) * c.size()));
+    }
+    {
+        std::ofstream f(dir + "/Level_0/Cell_H", std::ios::binary | std::ios::trunc);
+        f.precision(17);
+        f << 1 << '\n' << 1 << '\n' << ncomp << '\n' << 0 << '\n';      // version, how (one fab per file), ncomp, ngrow
+        f << "(1 0\n" << box << "\n)\n";                                // BoxArray::writeOn
+        f << 1 << '\n' << "FabOnDisk: Cell_D_00000 0\n" << '\n';
+        f << 1 << ',' << ncomp << '\n';
+        for (const auto& c : data) { double m = c.empty() ? 0.0 : c[0]; for (double v : c) m = std::min(m, v); f << m << ','; }
+        f << "\n\n" << 1 << ',' << ncomp << '\n';
+        for (const auto& c : data) { double m = c.empty() ? 0.0 : c[0]; for (double v : c) m = std::max(m, v); f << m << ','; }
+        f << '\n';
+    }
+    {
+        std::ofstream f(dir + "/Header", std::ios::binary | std::ios::trunc);
+        f.precision(17);
+        f << "HyperCLaw-V1.1\n" << ncomp << '\n';
+        for (const auto& n : names) f << n << '\n';
+        f << 3 << '\n' << time << '\n' << 0 << '\n';
+        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ';
+        f << '\n';
+        for (int d = 0; d < 3; ++d) f << rhi[d] << ' ';
+        f << '\n' << '\n';                                              // no refinement ratios on a single level
+        f << box << '\n' << step << '\n';
+        for (int d = 0; d < 3; ++d) f << dx[d] << ' ';
+        f << '\n' << 0 << '\n' << 0 << '\n';                            // Cartesian, bwidth
+        f << 0 << ' ' << 1 << ' ' << time << '\n' << step << '\n';
+        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ' << rhi[d] << '\n';
+        f << "Level_0/Cell\n";
+    }
+}
+
+// Lab-frame snapshot i of the back-transformed diagnostics as a plotfile (fields only): what the reference's BTD flushes
+// add up to once BTDiagnostics::MergeBuffersForPlotfile (BTDiagnostics.cpp:1146-1314) has interleaved their headers -- one
+// grid here instead of one per flushed buffer.  Geometry: x, y of the boosted-frame domain, z = the snapshot's lab-frame
+// extent, time = t_lab (BTD_Plotfile_Header_Impl.cpp:108-176).
+inline void write_btd_plotfile(SimHandle& h, int i, const std::string& dir) {
+    WarpX& wx = *h.warpx;
+    if (!wx.btd() || i < 0 || i >= wx.btd()->num_snapshots()) throw std::runtime_error("plotfile: no such lab-frame snapshot");
+    const auto& s = wx.btd()->snapshot(i);
+    const WarpXContext& ctx = wx.context();
+    static const char* comp_names[BTDiagnostics::NCOMP] = {"Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho"};
+    std::vector<std::string> names(comp_names, comp_names + BTDiagnostics::NCOMP);
+    const size_t n = (size_t)s.n[0] * s.n[1] * s.n[2];
+    std::vector<std::vector<double>> data;
+    for (int c = 0; c < BTDiagnostics::NCOMP; ++c)
+        data.emplace_back(s.data.begin() + (std::ptrdiff_t)((size_t)c * n), s.data.begin() + (std::ptrdiff_t)((size_t)(c + 1) * n));
+    const int lo[3] = {0, 0, s.ksmall}, hi[3] = {s.n[0] - 1, s.n[1] - 1, s.kbig};
+    const double dzl = (s.zhi_lab - s.zlo_lab) / s.n[2];
+    const double rlo[3] = {ctx.prob_lo[0], ctx.prob_lo[1], s.zlo_lab};
+    const double rhi[3] = {ctx.prob_lo[0] + s.n[0] * ctx.dx[0], ctx.prob_lo[1] + s.n[1] * ctx.dx[1], s.zhi_lab};
+    const double dx[3] = {ctx.dx[0], ctx.dx[1], dzl};
+    write_cell_data(dir, names, data, lo, hi, rlo, rhi, dx, s.t_lab, i);
+}
+
 inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vector<std::string>& species_names) {
     using warpx::fields::FieldType;
     using ablastr::fields::Direction;
@@ -74,15 +145,13 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
     const Backend* be = ctx.be;
     be->stream_sync(ctx.stream);
     make_dir(dir);
-    make_dir(dir + "/Level_0");
 
     // ---- fields: the reference's default fields_to_plot, cell-centred
     const struct { const char* name; FieldType ft; int d; } comps[9] = {
         {"Ex", FieldType::Efield_fp, 0}, {"Ey", FieldType::Efield_fp, 1}, {"Ez", FieldType::Efield_fp, 2},
         {"Bx", FieldType::Bfield_fp, 0}, {"By", FieldType::Bfield_fp, 1}, {"Bz", FieldType::Bfield_fp, 2},
         {"jx", FieldType::current_fp, 0}, {"jy", FieldType::current_fp, 1}, {"jz", FieldType::current_fp, 2}};
-    constexpr int NCOMP = 10;   // + rho
-    int ncell[3] = {0, 0, 0};
+    int ncell[3] = {0, 0, 0};   // ten components: + rho
     std::vector<std::vector<double>> data;
     std::vector<std::string> names;
     for (const auto& c : comps) {
@@ -101,43 +170,7 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
         rhi[d] = ctx.brick_plo[d] + ncell[d] * dx[d];
     }
     const std::string box = box_string(lo, hi);
-    const std::string fab_header = "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" + box + " " +
-                                   std::to_string(NCOMP) + "\n";
-    {
-        std::ofstream f(dir + "/Level_0/Cell_D_00000", std::ios::binary | std::ios::trunc);
-        if (!f.good()) throw std::runtime_error("plotfile: cannot open Cell_D_00000");
-        f << fab_header;
-        for (const auto& c : data) f.write(reinterpret_cast<const char*>(c.data()), (std::streamsize)(sizeof(double) * c.size()));
-    }
-    {
-        std::ofstream f(dir + "/Level_0/Cell_H", std::ios::binary | std::ios::trunc);
-        f.precision(17);
-        f << 1 << '\n' << 1 << '\n' << NCOMP << '\n' << 0 << '\n';      // version, how (one fab per file), ncomp, ngrow
-        f << "(1 0\n" << box << "\n)\n";                                // BoxArray::writeOn
-        f << 1 << '\n' << "FabOnDisk: Cell_D_00000 0\n" << '\n';
-        f << 1 << ',' << NCOMP << '\n';
-        for (const auto& c : data) { double m = c.empty() ? 0.0 : c[0]; for (double v : c) m = std::min(m, v); f << m << ','; }
-        f << "\n\n" << 1 << ',' << NCOMP << '\n';
-        for (const auto& c : data) { double m = c.empty() ? 0.0 : c[0]; for (double v : c) m = std::max(m, v); f << m << ','; }
-        f << '\n';
-    }
-    {
-        std::ofstream f(dir + "/Header", std::ios::binary | std::ios::trunc);
-        f.precision(17);
-        f << "HyperCLaw-V1.1\n" << NCOMP << '\n';
-        for (const auto& n : names) f << n << '\n';
-        f << 3 << '\n' << wx.gett_new() << '\n' << 0 << '\n';
-        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ';
-        f << '\n';
-        for (int d = 0; d < 3; ++d) f << rhi[d] << ' ';
-        f << '\n' << '\n';                                              // no refinement ratios on a single level
-        f << box << '\n' << wx.getistep() << '\n';
-        for (int d = 0; d < 3; ++d) f << dx[d] << ' ';
-        f << '\n' << 0 << '\n' << 0 << '\n';                            // Cartesian, bwidth
-        f << 0 << ' ' << 1 << ' ' << wx.gett_new() << '\n' << wx.getistep() << '\n';
-        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ' << rhi[d] << '\n';
-        f << "Level_0/Cell\n";
-    }
+    write_cell_data(dir, names, data, lo, hi, rlo, rhi, dx, wx.gett_new(), wx.getistep());
     // ---- particles
     for (int s = 0; s < wx.GetPartContainer().nSpecies(); ++s) {
         WarpXParticleContainer& pc = wx.GetPartContainer().GetParticleContainer(s);

@@ -803,6 +803,18 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
             return (RET)WXA_ERR_INVALID_ARG;                                                           \
         }                                                                                              \
     }                                                                                                  \
+    /* lab-frame snapshot i of the back-transformed diagnostics as a plotfile (host/Plotfile.hpp, write_btd_plotfile) */ \
+    RET PFX##sim_btd_write_plotfile(SIMTYPE* s, int32_t i, const char* dir) {                          \
+        if (!s || !dir) return (RET)WXA_ERR_INVALID_ARG;                                               \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        try {                                                                                          \
+            wxa::host::write_btd_plotfile(*h, i, dir);                                                 \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
+    }                                                                                                  \
     /* Evolve without / with the velocity synchronisation at the end of the call, and the synchronisation alone */ \
     RET PFX##sim_set_synchronize_at_end(SIMTYPE* s, int32_t on) {                                      \
         if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \

@@ -109,6 +109,10 @@ class WarpXSim:
         self.lib.sim_btd_data(self._h, int(i), self.BTD_COMPONENTS.index(name), out.ctypes.data_as(C.POINTER(C.c_double)))
         return np.ascontiguousarray(out.reshape(n[2], n[1], n[0]).transpose(2, 1, 0))
 
+    def btd_write_plotfile(self, i: int, path: str):
+        """Lab-frame snapshot i as an AMReX plotfile (wxa_sim_btd_write_plotfile)."""
+        self.lib.sim_btd_write_plotfile(self._h, int(i), str(path).encode())
+
     def checksum(self) -> dict:
         """The reference's regression checksum of the current state (wxa_sim_checksum_json), this brick's share."""
         import json
