@@ -729,9 +729,23 @@ wxa_status wxa_sim_get_particles(wxa_sim* s, int32_t species_id, wxa_particle_vi
  * z slice per step -- the cell-centred Ex Ey Ez Bx By Bz jx jy jz rho interpolated at the snapshot's current plane in the
  * boosted frame (amrex::get_slice_data), Lorentz-transformed (LorentzTransformZ, :246-317), stored at lab index k_lab
  * (k_index_zlab, :892-905).  buffer_size only rounds the snapshot's length as :464-469 do; the snapshot is kept whole in
- * host memory.  wxa_sim_btd_info: cells n (x, y, z), lab-frame extent along z, t_lab, slices received, closed flag;
+ * host memory; write_species != 0 adds the particles (wxa_btd_select_particles).  wxa_sim_btd_info: cells n (x, y, z), lab-frame extent along z, t_lab, slices received, closed flag;
  * wxa_sim_btd_data: component comp (order above) into out[k][j][i] (host pointer).  Diagnostic stage: host arithmetic. */
-wxa_status wxa_sim_add_btd(wxa_sim* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size);
+/* The particle half: BackTransformParticleFunctor (ComputeDiagFunctors/BackTransformParticleFunctor.cpp:76-152) -- the
+ * particles of p that crossed the snapshot's plane during the step (SelectParticles, .H:49-62: plane at z_boost now,
+ * z_boost_old one step ago; old6 = x y z ux uy uz before the push, CopyParticleAttribs, PhysicalParticleContainer.cpp:
+ * 2626-2629), interpolated in time to t_lab and Lorentz-transformed to the lab frame (LorentzTransformParticles, .H:106-168),
+ * appended to out[7][capacity] (rows x y z w ux uy uz, device memory) in no particular order.  *n_selected is the number
+ * that crossed; if it exceeds capacity the surplus was not stored.  Blocks on the stream (it reads the count). */
+wxa_status wxa_btd_select_particles(const wxa_particle_view* p, const double* const old6[6], double z_boost,
+                                    double z_boost_old, double t_boost, double dt, double t_lab, double gamma_boost,
+                                    double* out, int64_t capacity, int64_t* n_selected, void* stream);
+wxa_status wxa_sim_add_btd(wxa_sim* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size,
+                           int32_t write_species);
+/* particles of species id that snapshot i has met so far (write_species != 0): their number, and the rows
+ * x y z w ux uy uz, lab frame, into out[7][n] (host pointer) */
+wxa_status wxa_sim_btd_num_particles(wxa_sim* s, int32_t i, int32_t id, int64_t* n);
+wxa_status wxa_sim_btd_particles(wxa_sim* s, int32_t i, int32_t id, double* out);
 wxa_status wxa_sim_btd_info(wxa_sim* s, int32_t i, int32_t n[3], double z_lab[2], double* t_lab, int32_t* slices,
                             int32_t* full);
 wxa_status wxa_sim_btd_data(wxa_sim* s, int32_t i, int32_t comp, double* out);

@@ -11,6 +11,7 @@
 #include "nci_godfrey_tables.hpp"
 
 #include <climits>
+#include <array>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
@@ -1483,8 +1484,10 @@ struct orc_sim {
         int ksmall = 0, kbig = 0, counter = 0, last_valid = 0, full = 0;
         int n[3] = {0, 0, 0};
         std::vector<double> data;   // [comp][k][j][i]
+        std::vector<std::array<std::vector<double>, 7>> particles;   // per species: x y z w ux uy uz in the lab frame
     };
     std::vector<BtdSnapshot> btd;
+    bool btd_write_species = false;
     int btd_buffer_size = 0;
     double btd_dt_snap = 0.0;
 
@@ -1720,14 +1723,52 @@ void push_p_all(orc_sim* s, double dt) {
 }
 
 // WarpX::OneStep_nosub (Source/Evolve/WarpXEvolve.cpp:354-455), FDTD branch
+// BackTransformParticleFunctor::operator() (BackTransformParticleFunctor.cpp:76-152) right after the push of species
+// `species` (the oracle keeps its arrays in order, so this could run at the end of the step like the reference's; it runs
+// here to see the same domain as the product's host layer, see host/BTDiagnostics.hpp)
+extern "C" int orc_btd_select_particles(const wxa_particle_view* p, const double* const old6[6], double z_boost,
+                                        double z_boost_old, double t_boost, double dt, double t_lab, double gamma_boost,
+                                        double* out, int64_t capacity, int64_t* n_selected, void*);
+static void btd_pack_particles(orc_sim* s, int species, const wxa_particle_view& p, const std::vector<double> (&old_attr)[6],
+                               double t_new, double dt) {
+    const double g = s->gamma_boost, b = s->beta_boost, c = PhysConst::c;
+    const double* old6[6];
+    for (int k = 0; k < 6; ++k) old6[k] = old_attr[k].data();
+    for (auto& sn : s->btd) {
+        if ((int)sn.particles.size() <= species) sn.particles.resize((size_t)species + 1);
+        const double zb = (sn.t_lab / g - t_new) * c / b, zl = (sn.t_lab - t_new / g) * c / b;
+        const double cs = s->dx[2];
+        const bool in_domain = !((zb <= s->plo[2] + 0.5 * cs) || (zb >= s->phi[2] - 0.5 * cs) || (zl <= sn.zlo_lab) ||
+                                 (zl >= sn.zhi_lab));
+        if (!in_domain || sn.full) continue;
+        const double zb_old = (sn.t_lab / g - (t_new - dt)) * c / b;
+        std::vector<double> out((size_t)7 * (size_t)p.np);
+        int64_t n = 0;
+        orc_btd_select_particles(&p, old6, zb, zb_old, t_new, dt, sn.t_lab, g, out.data(), p.np, &n, nullptr);
+        for (int k = 0; k < 7; ++k)
+            sn.particles[(size_t)species][(size_t)k].insert(sn.particles[(size_t)species][(size_t)k].end(),
+                                                            out.begin() + (std::ptrdiff_t)((size_t)k * (size_t)p.np),
+                                                            out.begin() + (std::ptrdiff_t)((size_t)k * (size_t)p.np + (size_t)n));
+    }
+}
+
 void one_step_nosub(orc_sim* s) {
     const double dt = s->dt;
     // PushParticlesandDeposit (:1101-1180) -> MultiParticleContainer::Evolve (:460-482)
     for (int c = 0; c < 3; ++c) orc_field_set_zero(&s->Jv[c], nullptr);
     const wxa_grid_geom gEB = s->geom_for(s->ng_EB);
     const wxa_grid_geom gJ = s->geom_for(s->ng_depos_J);
+    int species_index = -1;
     for (auto& sp : s->species) {
+        ++species_index;
         wxa_particle_view p = sp->view();
+        // CopyParticleAttribs (:2626-2629): the attributes before the push, for the back-transformed diagnostics
+        std::vector<double> old_attr[6];
+        const bool btd_particles = s->btd_write_species && !s->btd.empty() && p.np > 0;
+        if (btd_particles) {
+            const double* src[6] = {p.x, p.y, p.z, p.ux, p.uy, p.uz};
+            for (int c = 0; c < 6; ++c) old_attr[c].assign(src[c], src[c] + p.np);
+        }
         {   // PhysicalParticleContainer::Evolve :1961 PushPX
             Tic t(s, 0);
             const wxa_field_view* Eg = s->Ev;
@@ -1748,6 +1789,7 @@ void one_step_nosub(orc_sim* s) {
             orc_gather_push_ext(&p, Eg, Bg, &gEB, sp->q, sp->m, dt, s->cfg.nox, s->cfg.galerkin,
                                 sp->do_crr ? WXA_PUSHER_BORIS_RR : s->cfg.particle_pusher, /*move=*/1, sp->ext_eb);
         }
+        if (btd_particles) btd_pack_particles(s, species_index, p, old_attr, s->cur_time + dt, dt);
         {   // :2029-2038 DepositCurrent with relative_time = -0.5*dt
             Tic t(s, 1);
             orc_deposit_current(&p, s->Jv, &gJ, sp->q, dt, -0.5 * dt, s->cfg.nox, s->cfg.current_deposition,
@@ -1922,6 +1964,45 @@ int orc_sim_add_species(orc_sim* s, double charge, double mass, const wxa_partic
 }
 
 // WarpX::Evolve (Source/Evolve/WarpXEvolve.cpp:94-347)
+// BackTransformParticleFunctor (ComputeDiagFunctors/BackTransformParticleFunctor.cpp:76-152): SelectParticles (.H:49-62) and
+// LorentzTransformParticles (.H:106-168) on host arrays; out[7][capacity], rows x y z w ux uy uz, in particle order
+int orc_btd_select_particles(const wxa_particle_view* p, const double* const old6[6], double z_boost, double z_boost_old,
+                             double t_boost, double dt, double t_lab, double gamma_boost, double* out, int64_t capacity,
+                             int64_t* n_selected, void*) {
+    if (!p || !old6 || !out || !n_selected || capacity <= 0 || !(gamma_boost > 1.0)) return -1;
+    const double m_gammaboost = gamma_boost, m_betaboost = std::sqrt(1.0 - 1.0 / (gamma_boost * gamma_boost));
+    const double m_Phys_c = PhysConst::c, m_inv_c2 = 1.0 / (m_Phys_c * m_Phys_c);
+    const double m_uzfrm = -m_gammaboost * m_betaboost * m_Phys_c;
+    int64_t n = 0;
+    for (int64_t i = 0; i < p->np; ++i) {
+        if (p->idcpu && p->idcpu[i] == WXA_IDCPU_RETIRED) continue;
+        const double zp = p->z[i], zpold = old6[2][i];
+        if (!(((zp >= z_boost) && (zpold <= z_boost_old)) || ((zp <= z_boost) && (zpold >= z_boost_old)))) continue;
+        const double gamma_new_p = std::sqrt(1.0 + m_inv_c2 * (p->ux[i] * p->ux[i] + p->uy[i] * p->uy[i] + p->uz[i] * p->uz[i]));
+        const double gamma_old_p = std::sqrt(1.0 + m_inv_c2 * (old6[3][i] * old6[3][i] + old6[4][i] * old6[4][i] + old6[5][i] * old6[5][i]));
+        const double t_new_p = m_gammaboost * t_boost - m_uzfrm * zp * m_inv_c2;
+        const double z_new_p = m_gammaboost * (zp + m_betaboost * m_Phys_c * t_boost);
+        const double uz_new_p = m_gammaboost * p->uz[i] - gamma_new_p * m_uzfrm;
+        const double t_old_p = m_gammaboost * (t_boost - dt) - m_uzfrm * zpold * m_inv_c2;
+        const double z_old_p = m_gammaboost * (zpold + m_betaboost * m_Phys_c * (t_boost - dt));
+        const double uz_old_p = m_gammaboost * old6[5][i] - gamma_old_p * m_uzfrm;
+        const double weight_old = (t_new_p - t_lab) / (t_new_p - t_old_p);
+        const double weight_new = (t_lab - t_old_p) / (t_new_p - t_old_p);
+        if (n < capacity) {
+            out[0 * capacity + n] = old6[0][i] * weight_old + p->x[i] * weight_new;
+            out[1 * capacity + n] = old6[1][i] * weight_old + p->y[i] * weight_new;
+            out[2 * capacity + n] = z_old_p * weight_old + z_new_p * weight_new;
+            out[3 * capacity + n] = p->w[i];
+            out[4 * capacity + n] = old6[3][i] * weight_old + p->ux[i] * weight_new;
+            out[5 * capacity + n] = old6[4][i] * weight_old + p->uy[i] * weight_new;
+            out[6 * capacity + n] = uz_old_p * weight_old + uz_new_p * weight_new;
+        }
+        ++n;
+    }
+    *n_selected = n;
+    return 0;
+}
+
 int orc_sim_compute_rho(orc_sim* s);
 
 // ---- back-transformed diagnostics, fields (Source/Diagnostics/BTDiagnostics.cpp, ComputeDiagFunctors/BackTransformFunctor.cpp)
@@ -2005,9 +2086,10 @@ static void btd_compute_and_pack(orc_sim* s) {
 
 // BTDiagnostics::ReadParameters (:206-292) + DerivedInitData (:66-205) + InitializeBufferData (:333-506), one level, one box,
 // diag domain = the whole boosted-frame domain
-int orc_sim_add_btd(orc_sim* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size) {
+int orc_sim_add_btd(orc_sim* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size, int32_t write_species) {
     if (!s || num_snapshots < 1 || !(dt_snapshots_lab > 0.0) || buffer_size < 1) return -1;
     if (!(s->gamma_boost > 1.0) || s->mw_dir != 2) return -1;
+    s->btd_write_species = write_species != 0;
     s->btd_buffer_size = buffer_size;
     s->btd_dt_snap = dt_snapshots_lab;
     const double g = s->gamma_boost, b = s->beta_boost;
@@ -2053,6 +2135,20 @@ int orc_sim_btd_info(orc_sim* s, int32_t i, int32_t n[3], double z_lab[2], doubl
     if (t_lab) *t_lab = sn.t_lab;
     if (filled) *filled = sn.counter;
     if (full) *full = sn.full;
+    return 0;
+}
+int orc_sim_btd_num_particles(orc_sim* s, int32_t i, int32_t id, int64_t* n) {
+    if (!s || !n || i < 0 || i >= (int32_t)s->btd.size() || id < 0) return -1;
+    const auto& sn = s->btd[(size_t)i];
+    *n = id < (int32_t)sn.particles.size() ? (int64_t)sn.particles[(size_t)id][0].size() : 0;
+    return 0;
+}
+int orc_sim_btd_particles(orc_sim* s, int32_t i, int32_t id, double* out) {
+    int64_t n = 0;
+    if (orc_sim_btd_num_particles(s, i, id, &n) != 0 || !out) return -1;
+    if (n == 0) return 0;
+    const auto& rows = s->btd[(size_t)i].particles[(size_t)id];
+    for (int c = 0; c < 7; ++c) std::memcpy(out + (size_t)c * (size_t)n, rows[(size_t)c].data(), sizeof(double) * (size_t)n);
     return 0;
 }
 int orc_sim_btd_data(orc_sim* s, int32_t i, int32_t comp, double* out) {

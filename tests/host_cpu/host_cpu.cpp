@@ -25,6 +25,8 @@ int orc_gather_push_lens(const wxa_particle_view*, const wxa_field_view*, const 
 int orc_deposit_current(const wxa_particle_view*, const wxa_field_view*, const wxa_grid_geom*, double, double,
                         double, int, int, void*, void*);
 int orc_filter_bilinear(const wxa_field_view*, const wxa_field_view*, void*);
+int orc_btd_select_particles(const wxa_particle_view*, const double* const[6], double, double, double, double, double, double,
+                             double*, int64_t, int64_t*, void*);
 int orc_filter_stencil(const wxa_field_view*, const wxa_field_view*, const double*, int32_t, const double*, int32_t,
                        const double*, int32_t, void*);
 int orc_fill_boundary_periodic(const wxa_field_view*, const int*, const int*, void*);
@@ -136,6 +138,7 @@ const Backend* cpu_backend() {
         b.deposit_current = orc_deposit_current;
         b.filter_bilinear = orc_filter_bilinear;
         b.filter_stencil = orc_filter_stencil;
+        b.btd_select_particles = orc_btd_select_particles;
         b.fill_boundary_periodic = orc_fill_boundary_periodic;
         b.sync_nodal_periodic = orc_sync_nodal_periodic;
         b.sum_boundary_periodic = orc_sum_boundary_periodic;

@@ -25,17 +25,26 @@ def test_btd_host_layer_against_the_oracle_stepper(oracle, host_cpu):
     """Config 5 in small (gamma = 5, window at c, CKC, Vay, NCI, antenna, injected plasma) with three lab-frame snapshots:
     the host layer's BTDiagnostics and the oracle stepper's own give the same slices, component by component."""
     steps = 50
-    out = []
+    out, parts = [], []
     for lib in (host_cpu, oracle):
-        sim, _ = pec_case.make_boosted_lwfa_sim(lib)
+        sim, e = pec_case.make_boosted_lwfa_sim(lib)
         dt_snap = 12 * sim.dt * pec_case.BOOST_GAMMA   # a new snapshot plane enters the boosted domain every ~12 steps
         sim.add_btd(3, dt_snap, buffer_size=32)
         sim.evolve(steps)
         info = [sim.btd_info(i) for i in range(3)]
         data = [{c: sim.btd_snapshot(i, c) for c in WarpXSim.BTD_COMPONENTS} for i in range(3)]
+        parts.append([sim.btd_particles(i, e) for i in range(3)])
         sim.close()
         out.append((info, data))
     (ih, dh), (io, do) = out
+    # the electrons each snapshot's plane has met (BackTransformParticleFunctor): the same particles, the same lab-frame values
+    for i in range(3):
+        a, b = parts[0][i], parts[1][i]
+        assert a.shape == b.shape and (i > 0 or a.shape[1] > 100)
+        # the host layer re-sorts its tile by cell, the oracle keeps injection order: same set, different sequence
+        a, b = (q[:, np.lexsort((q[2], np.round(q[1] / 1e-10), np.round(q[0] / 1e-10)))] for q in (a, b))
+        for row in range(7):
+            assert np.max(np.abs(a[row] - b[row])) <= 1e-9 * max(np.max(np.abs(b[row])), 1e-300), (i, row)
     for i in range(3):
         assert ih[i]["n"] == io[i]["n"] and ih[i]["n"][2] % 32 == 0
         assert ih[i]["slices"] == io[i]["slices"] and ih[i]["full"] == io[i]["full"]
@@ -121,3 +130,28 @@ def test_btd_from_an_inputs_file(host_cpu):
     assert a["slices"] == 20 and not a["full"]
     with pytest.raises(Exception):
         WarpXSim.from_inputs(host_cpu, deck, overrides=over[:4] + ("d1.intervals=0:3",))
+
+
+def test_btd_particles_of_a_plasma_at_rest_in_the_lab(host_cpu):
+    """tests/decks/boosted_injection_3d.inputs: a tenuous plasma at rest in the lab frame seen from a gamma = 3 frame, where
+    every electron streams backwards with u_z = -gamma beta c.  Back-transformed (BackTransformParticleFunctor.H:106-168) the
+    particles a snapshot's plane has met are at rest again, sit inside the snapshot's lab-frame extent, and carry the
+    weights they were injected with."""
+    deck = os.path.join(HERE, "decks", "boosted_injection_3d.inputs")
+    sim = WarpXSim.from_inputs(host_cpu, deck)
+    dt_snap = 5 * sim.lib.sim_dt(sim._h) * 3.0
+    sim.add_btd(2, dt_snap, buffer_size=16, write_species=True)
+    sim.evolve(sim.max_step)
+    info = sim.btd_info(1)
+    p = sim.btd_particles(1, 0)
+    empty = sim.btd_particles(0, 0)
+    live = sim.particles(0)
+    sim.close()
+    assert empty.shape[1] == 0        # at t_lab = 0 the lab window [-16 um, 0] lies below the plasma (z > 1 um)
+    assert p.shape[1] > 50 and np.all(p[2] > 1e-6 - 1e-9)   # ... a few femtoseconds later its head has entered it
+    c = plasma.C_LIGHT
+    assert np.max(np.abs(p[6])) < 1e-9 * 3.0 * c           # u_z back to 0 (it is -gamma beta c = -2.8 c in the boosted frame)
+    assert np.max(np.abs(p[4])) < 1e-9 * c and np.max(np.abs(p[5])) < 1e-9 * c
+    assert np.all(p[2] > info["z_lab"][0]) and np.all(p[2] < info["z_lab"][1])
+    assert np.all(np.abs(live[6] + np.sqrt(8.0) * c) < 1e-6 * c)   # the boosted-frame drift the transform removes
+    assert np.allclose(p[3], live[3][0], rtol=1e-12)        # one weight for all: the lab density x the lab cell volume / ppc

@@ -696,6 +696,50 @@ def test_push_and_deposit_in_one_kernel(oracle, product, pusher, stale, u_scale,
     product.workspace_destroy(ws)
 
 
+def test_btd_select_particles(oracle, product):
+    """wxa_btd_select_particles (BackTransformParticleFunctor.cpp:76-152, .H:49-62 and :106-168) against the oracle: the
+    particles that crossed the snapshot's plane during a step, interpolated to t_lab and transformed to the lab frame.
+    The device appends in no particular order: compared after sorting by the (unique) transformed x."""
+    import torch
+    rng = np.random.default_rng(99)
+    n = 20000
+    gamma = 4.0
+    c = plasma.C_LIGHT
+    dt = 2e-16
+    new = [rng.uniform(-1e-5, 1e-5, n), rng.uniform(-1e-5, 1e-5, n), rng.uniform(-1.03e-5, -0.97e-5, n), rng.uniform(1.0, 2.0, n),
+           c * rng.normal(0, 1, n), c * rng.normal(0, 1, n), c * rng.normal(-1.0, 2.0, n)]   # a slab around the plane
+    u_old = [new[4 + d] * (1.0 + 0.01 * rng.normal(0, 1, n)) for d in range(3)]
+    g_new = np.sqrt(1.0 + (new[4] ** 2 + new[5] ** 2 + new[6] ** 2) / c ** 2)
+    old_pos = [new[d] - dt * new[4 + d] / g_new for d in range(3)]
+    ph = ParticleArrays.from_numpy(new, "cpu")
+    pd = ParticleArrays.from_numpy(new, DEV)
+    old_h = [np.ascontiguousarray(a) for a in old_pos + u_old]
+    old_d = [torch.from_numpy(a).to(DEV) for a in old_h]
+    z_plane, z_plane_old = -1.0e-5, -1.0e-5 + 1.03 * c * dt
+    t_boost, t_lab = 40 * dt, 40 * dt * gamma * 0.9
+    cap = n
+    out_h = np.zeros((7, cap))
+    out_d = torch.zeros((7, cap), dtype=torch.float64, device=DEV)
+    nh, nd = C.c_int64(), C.c_int64()
+    ptr_h = (C.c_void_p * 6)(*[a.ctypes.data for a in old_h])
+    ptr_d = (C.c_void_p * 6)(*[a.data_ptr() for a in old_d])
+    oracle.btd_select_particles(C.byref(ph.view), ptr_h, z_plane, z_plane_old, t_boost, dt, t_lab, gamma,
+                                out_h.ctypes.data, cap, C.byref(nh), None)
+    product.btd_select_particles(C.byref(pd.view), ptr_d, z_plane, z_plane_old, t_boost, dt, t_lab, gamma,
+                                 out_d.data_ptr(), cap, C.byref(nd), None)
+    _sync(product)
+    assert nh.value == nd.value and 50 < nh.value < n // 4
+    a = out_d.cpu().numpy()[:, :nd.value]
+    b = out_h[:, :nh.value]
+    a, b = a[:, np.argsort(a[0])], b[:, np.argsort(b[0])]
+    for row in range(7):
+        assert H.max_rel_err(a[row], b[row]) < 1e-12, row
+    # a buffer that is too small: the count still says how many crossed
+    product.btd_select_particles(C.byref(pd.view), ptr_d, z_plane, z_plane_old, t_boost, dt, t_lab, gamma,
+                                 out_d.data_ptr(), 10, C.byref(nd), None)
+    assert nd.value == nh.value
+
+
 @pytest.mark.skipif(H.HIP_ON_CPU, reason="wraps a device pointer in a torch CUDA tensor")
 def test_device_pointer_wrapping(product):
     """The torch.distributed transport wraps raw device pointers handed out by the C++ host layer

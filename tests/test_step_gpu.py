@@ -564,19 +564,25 @@ def test_boosted_frame_laser_wakefield_deck_on_gpu(oracle, product):
 
 
 def test_back_transformed_fields_on_gpu(oracle, product):
-    """Lab-frame snapshots (wxa_sim_add_btd: BTDiagnostics.cpp, BackTransformFunctor.cpp) of config 5 in small from the HIP
-    path against the oracle stepper's own back-transformation: three snapshots, 50 steps, every component at 1e-9 of its
-    scale (tests/test_btd_cpu.py has the host layer on the CPU kernels and the lab-frame physics)."""
+    """Lab-frame snapshots (wxa_sim_add_btd: BTDiagnostics.cpp, BackTransformFunctor.cpp, BackTransformParticleFunctor.cpp) of
+    config 5 in small from the HIP path against the oracle stepper's own back-transformation: three snapshots, 50 steps, every
+    field component and every particle row at 1e-9 of its scale (tests/test_btd_cpu.py has the host layer on the CPU kernels and the lab-frame physics)."""
     from tests import pec_case
-    out = []
+    out, parts = [], []
     for lib in (product, oracle):
-        sim, _ = pec_case.make_boosted_lwfa_sim(lib)
-        sim.add_btd(3, 12 * sim.dt * pec_case.BOOST_GAMMA, buffer_size=32)
+        sim, e = pec_case.make_boosted_lwfa_sim(lib)
+        sim.add_btd(3, 12 * sim.dt * pec_case.BOOST_GAMMA, buffer_size=32, write_species=True)
         sim.evolve(50)
         out.append(([sim.btd_info(i) for i in range(3)],
                     [{c: sim.btd_snapshot(i, c) for c in WarpXSim.BTD_COMPONENTS} for i in range(3)]))
+        parts.append([sim.btd_particles(i, e) for i in range(3)])
         sim.close()
     (ig, dg), (io, do) = out
+    for i in range(3):   # the back-transformed electrons (wxa_btd_select_particles): same set, any order
+        a, b = (q[:, np.lexsort((q[2], np.round(q[1] / 1e-10), np.round(q[0] / 1e-10)))] for q in (parts[0][i], parts[1][i]))
+        assert a.shape == b.shape and (i > 0 or a.shape[1] > 100)
+        for row in range(7):
+            assert np.max(np.abs(a[row] - b[row])) <= 1e-9 * max(np.max(np.abs(b[row])), 1e-300), (i, row)
     for i in range(3):
         assert ig[i]["n"] == io[i]["n"] and ig[i]["slices"] == io[i]["slices"] > 0
         for c in WarpXSim.BTD_COMPONENTS:

@@ -165,6 +165,8 @@ _KERNEL_SIGS = {
     "deposit_current": (C.c_int, [_PPV, _FV3, _PGG, C.c_double, C.c_double, C.c_double,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "deposit_charge": (C.c_int, [_PPV, _PFV, _PGG, C.c_double, C.c_int, C.c_void_p]),
+    "btd_select_particles": (C.c_int, [_PPV, C.POINTER(C.c_void_p), C.c_double, C.c_double, C.c_double, C.c_double,
+                                       C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
     "enforce_periodic": (C.c_int, [_PPV, _D3, _D3, _I3, C.c_void_p]),
     "apply_pec_e": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_pec_b": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
@@ -225,7 +227,9 @@ _SIM_SIGS = {
     "sim_set_external_particle_fields": (C.c_int, [C.c_void_p, C.c_int32, _D3, _D3]),
     "sim_set_radiation_reaction": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "sim_add_laser": (C.c_int, [C.c_void_p, C.POINTER(LaserAntenna)]),
-    "sim_add_btd": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32]),
+    "sim_add_btd": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32]),
+    "sim_btd_num_particles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "sim_btd_particles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "sim_btd_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sim_btd_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),

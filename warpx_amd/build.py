@@ -34,6 +34,7 @@ SOURCES = [
     ("deposit_tile.hip", []),
     ("gather_tile.hip", []),
     ("host/warpx_host.hip", []),
+    ("host/btd_kernels.hip", []),
     ("rccl_comm.hip", []),
 ]
 

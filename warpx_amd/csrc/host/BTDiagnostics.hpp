@@ -14,12 +14,14 @@
 #ifndef WXA_HOST_BTDIAGNOSTICS_HPP_
 #define WXA_HOST_BTDIAGNOSTICS_HPP_
 
+#include <array>
 #include <cmath>
 #include <stdexcept>
 #include <vector>
 
 #include "amrex_shim.hpp"
 #include "backend.hpp"
+#include "BrickComm.hpp"
 
 namespace wxa::host {
 
@@ -35,6 +37,8 @@ public:
         int counter = 0, last_valid = 0, full = 0;
         int n[3] = {0, 0, 0};                   // cells of the snapshot array (x, y, z)
         std::vector<double> data;               // [comp][k][j][i], zero until a slice arrives
+        // back-transformed particles per species: rows x y z w ux uy uz (lab frame), in arrival order
+        std::vector<std::array<std::vector<double>, 7>> particles;
     };
 
     BTDiagnostics(int num_snapshots, double dt_snapshots_lab, int buffer_size)
@@ -100,6 +104,43 @@ public:
             s.ksmall = kindex_hi - (nzs - 1);
             s.n[0] = nx_lab; s.n[1] = ny_lab; s.n[2] = nzs;
             s.data.assign((size_t)NCOMP * (size_t)nzs * (size_t)ny_lab * (size_t)nx_lab, 0.0);
+        }
+    }
+
+    // The particle half (BackTransformParticleFunctor::operator(), BackTransformParticleFunctor.cpp:76-152) for one species,
+    // called by its container right after PushPX with the attributes saved before it (CopyParticleAttribs,
+    // PhysicalParticleContainer.cpp:2626-2629): the particles that the snapshot's plane met during this step, in the lab
+    // frame.  The reference does this at the end of the step; here the tile is re-sorted between the push and the
+    // deposition, which would separate the particles from their saved attributes -- same positions, momenta and plane,
+    // but the in-domain test sees the domain before this step's window shift (one cell, at a snapshot's first / last slice).
+    template <class CTX>
+    void PackParticles(const CTX& ctx, int species, const wxa_particle_view& p, const double* const old6[6], double t_new,
+                       double dt, DeviceBuffer& scratch) {
+        if (!ctx.be->btd_select_particles) throw std::runtime_error("BackTransformed diagnostic: particles not in this backend");
+        for (Snapshot& s : m_snap) {
+            if ((int)s.particles.size() <= species) s.particles.resize((size_t)species + 1);
+            Snapshot now = s;
+            now.z_boost = z_boost_of(s.t_lab, t_new);
+            now.z_lab = z_lab_of(s.t_lab, t_new);
+            if (!slice_in_domain(now, ctx) || s.full) continue;           // m_perform_backtransform (:166-176)
+            const double zb_old = z_boost_of(s.t_lab, t_new - dt);        // m_old_z_boost: the plane at the previous step
+            int64_t cap = p.np / 16 + 1024, n = 0;
+            for (;;) {
+                scratch.reserve(sizeof(double) * 7 * (size_t)cap);
+                if (ctx.be->btd_select_particles(&p, old6, now.z_boost, zb_old, t_new, dt, s.t_lab, m_gamma,
+                                                 static_cast<double*>(scratch.p), cap, &n, ctx.stream) != 0)
+                    throw std::runtime_error("BackTransformed diagnostic: particle selection failed");
+                if (n <= cap) break;
+                cap = n;
+            }
+            if (n == 0) continue;
+            std::vector<double> host((size_t)7 * (size_t)cap);
+            if (ctx.be->memcpy_d2h(host.data(), scratch.p, sizeof(double) * host.size()) != 0)
+                throw std::runtime_error("BackTransformed diagnostic: device copy failed");
+            for (int c = 0; c < 7; ++c)
+                s.particles[(size_t)species][(size_t)c].insert(s.particles[(size_t)species][(size_t)c].end(),
+                                                               host.begin() + (std::ptrdiff_t)((size_t)c * cap),
+                                                               host.begin() + (std::ptrdiff_t)((size_t)c * cap + (size_t)n));
         }
     }
 

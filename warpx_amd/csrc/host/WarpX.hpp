@@ -291,11 +291,20 @@ public:
 
     // <diag>.diag_type = BackTransformed with do_back_transformed_fields = 1 (BTDiagnostics.hpp): lab-frame snapshots
     // num_snapshots_lab, dt_snapshots_lab (= dz_snapshots_lab / c), buffer_size as in BTDiagnostics::ReadParameters (:206-292)
-    void AddBTDiagnostics(int num_snapshots, amrex::Real dt_snapshots_lab, int buffer_size) {
+    // write_species (<diag>.write_species, default 1 in the reference): the species' particles too
+    void AddBTDiagnostics(int num_snapshots, amrex::Real dt_snapshots_lab, int buffer_size, bool write_species) {
         for (int d = 0; d < 3; ++d)
             if (m_cfg.nbricks[d] != 1) throw std::runtime_error("BackTransformed diagnostic: one brick only");
         m_btd = std::make_unique<BTDiagnostics>(num_snapshots, dt_snapshots_lab, buffer_size);
         m_btd->Init(*this);
+        m_btd_write_species = write_species;
+        HookBTDSpecies();
+    }
+    // species added after the diagnostic are picked up too (SetDoBackTransformedParticles, BTDiagnostics.cpp:124-130)
+    void HookBTDSpecies() {
+        if (!m_btd || !m_btd_write_species) return;
+        m_ctx.btd = m_btd.get();
+        for (int i = 0; i < mypc->nSpecies(); ++i) mypc->GetParticleContainer(i).btd_species_id = i;
     }
     const BTDiagnostics* btd() const { return m_btd.get(); }
     amrex::Real getdt() const { return dt[0]; }
@@ -714,6 +723,7 @@ private:
     std::unique_ptr<amrex::MultiFab> m_filter_tmp[3];
     std::unique_ptr<amrex::MultiFab> m_rho, m_rho_tmp;   // ComputeRho (diagnostics)
     std::unique_ptr<BTDiagnostics> m_btd;
+    bool m_btd_write_species = false;
     // field-solve exchanges: guard layer of B computed redundantly; J's guard sum on a second stream
     bool m_grown_b = false, m_overlap = false;
     void* m_comm_stream = nullptr;

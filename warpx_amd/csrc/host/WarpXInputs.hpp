@@ -713,7 +713,9 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         else if (!have_dt) throw std::runtime_error("inputs: " + d + ".dt_snapshots_lab or dz_snapshots_lab must be set");
         pp.queryWithParser(d + ".buffer_size", buffer);
         if (wx.btd()) throw std::runtime_error("inputs: one BackTransformed diagnostic only");
-        wx.AddBTDiagnostics(nsnap, dt_snap, buffer);
+        int write_species = 1;                                     // BTDiagnostics.cpp:113-114
+        pp.queryWithParser(d + ".write_species", write_species);
+        wx.AddBTDiagnostics(nsnap, dt_snap, buffer, write_species != 0);
     }
     for (const std::string& d : diag_names) pp.ignore_prefix(d + ".");
     for (const std::string& d : rdiag_names) pp.ignore_prefix(d + ".");

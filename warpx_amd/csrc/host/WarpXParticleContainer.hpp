@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "BrickComm.hpp"
+#include "BTDiagnostics.hpp"
 
 namespace wxa::host {
 
@@ -47,6 +48,8 @@ struct WarpXContext {
     // warpx.gamma_boost / beta_boost (boost along z, WarpXUtil.cpp:114-141) and warpx.gett_new(0)
     double gamma_boost = 1.0, beta_boost = 0.0;
     double t_new = 0.0;
+    // <diag>.diag_type = BackTransformed with species output: owned by WarpX (BTDiagnostics.hpp)
+    BTDiagnostics* btd = nullptr;
     // per-phase device timers, named after the reference's profiler regions
     bool timers_on = false;
     double ms[8] = {0};
@@ -436,6 +439,10 @@ protected:
     WarpXContext* m_ctx;
     ParticleTile m_tile, m_spare;
     DeviceBuffer m_sendbuf, m_recvbuf, m_lists, m_arrival_lists[3];
+    DeviceBuffer m_btd_old[6], m_btd_scratch;   // back-transformed diagnostics: attributes before the push, selection output
+public:
+    int btd_species_id = -1;                    // >= 0: this species is written by the BackTransformed diagnostic
+protected:
     int64_t m_nretired = 0;            // retired by Redistribute since the last sort (still in the tile)
     int32_t m_steps_since_sort = -1;   // Redistribute calls since the last cell sort (-1: never sorted)
     void* m_ws = nullptr;
@@ -588,7 +595,7 @@ public:
 
     // Source/Particles/PhysicalParticleContainer.cpp:1812-2095: PushPX then DepositCurrent
     void Evolve(ablastr::fields::MultiFabRegister& fields, int lev, const std::string& current_fp_string,
-                amrex::Real /*t*/, amrex::Real dt, DtType /*a_dt_type*/ = DtType::Full, bool skip_deposition = false,
+                amrex::Real t_now, amrex::Real dt, DtType /*a_dt_type*/ = DtType::Full, bool skip_deposition = false,
                 PushType push_type = PushType::Explicit) override {
         using warpx::fields::FieldType;
         if (push_type != PushType::Explicit) throw std::runtime_error("only the explicit push is supported");
@@ -596,6 +603,16 @@ public:
         auto E = fields.get_alldirs(FieldType::Efield_aux, lev);
         auto B = fields.get_alldirs(FieldType::Bfield_aux, lev);
         auto J = fields.get_alldirs(FieldType::current_fp, lev);
+        const bool btd_particles = m_ctx->btd != nullptr && btd_species_id >= 0 && m_tile.numParticles() > 0;
+        if (btd_particles) {   // CopyParticleAttribs (:2626-2629): x y z ux uy uz before the push
+            const int64_t np = m_tile.numParticles();
+            const int comp[6] = {0, 1, 2, 4, 5, 6};
+            for (int c = 0; c < 6; ++c) {
+                m_btd_old[c].be = m_ctx->be;
+                m_btd_old[c].reserve(sizeof(double) * (size_t)np);
+                m_ctx->be->memcpy_async(m_btd_old[c].p, m_tile.comp(comp[c]), sizeof(double) * (size_t)np, m_ctx->stream);
+            }
+        }
         {
             PhaseTimer t(m_ctx, kGatherAndPush);  // "PhysicalParticleContainer::Evolve::GatherAndPush"
             if (m_ctx->use_fdtd_nci_corr) {   // :1900-1911: filter E and B, gather from the filtered copies
@@ -605,6 +622,13 @@ public:
             } else {
                 PushPX(*E[0], *E[1], *E[2], *B[0], *B[1], *B[2], dt);
             }
+        }
+        if (btd_particles) {   // the particles that a lab-frame snapshot's plane met during this push (BTDiagnostics.hpp)
+            const wxa_particle_view p = m_tile.view();
+            const double* old6[6];
+            for (int c = 0; c < 6; ++c) old6[c] = static_cast<const double*>(m_btd_old[c].p);
+            m_btd_scratch.be = m_ctx->be;
+            m_ctx->btd->PackParticles(*m_ctx, btd_species_id, p, old6, t_now + dt, dt, m_btd_scratch);
         }
         // Cell sort (amrex SortParticlesByBin, called by the reference from
         // HandleParticlesAtBoundaries, WarpXEvolve.cpp:575-580).  Sorting only permutes the

@@ -69,6 +69,10 @@ struct Backend {
     int (*laser_push)(const wxa_particle_view*, const wxa_laser_push_params*, double t, double dt, void*);
     int (*filter_bilinear)(const wxa_field_view*, const wxa_field_view*, void*);
     // Filter::DoFilter with any half stencils (the NCI corrector: lengths 1, 1, 5); optional
+    // BackTransformParticleFunctor's selection + transform (wxa_btd_select_particles); optional
+    int (*btd_select_particles)(const wxa_particle_view*, const double* const old6[6], double z_boost, double z_boost_old,
+                                double t_boost, double dt, double t_lab, double gamma_boost, double* out, int64_t capacity,
+                                int64_t* n_selected, void* stream) = nullptr;
     int (*filter_stencil)(const wxa_field_view*, const wxa_field_view*, const double* s0, int32_t n0, const double* s1,
                           int32_t n1, const double* s2, int32_t n2, void*) = nullptr;
     int (*fill_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);

@@ -40,6 +40,7 @@ inline int sim_add_species(SimHandle* h, double charge, double mass, const wxa_p
             throw std::runtime_error("charged species with a reflecting particle boundary: the current fold at the "
                                      "walls has the image-charge sign of absorbing walls only");
         const int sid = w.GetPartContainer().AddSpecies(charge, mass);
+        w.HookBTDSpecies();
         ParticleTile& t = w.GetPartContainer().GetParticleContainer(sid).tile();
         t.resize(init->np);
         const Backend* be = w.context().be;
@@ -179,10 +180,11 @@ inline int sim_compute_rho(SimHandle* h) {
     }
 }
 
-inline int sim_add_btd(SimHandle* h, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size) {
+inline int sim_add_btd(SimHandle* h, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size,
+                       int32_t write_species) {
     if (!h) return WXA_ERR_INVALID_ARG;
     try {
-        h->warpx->AddBTDiagnostics(num_snapshots, dt_snapshots_lab, buffer_size);
+        h->warpx->AddBTDiagnostics(num_snapshots, dt_snapshots_lab, buffer_size, write_species != 0);
         return WXA_OK;
     } catch (const std::exception& e) {
         h->error = e.what();
@@ -211,6 +213,24 @@ inline int sim_btd_data(SimHandle* h, int32_t i, int32_t comp, double* out) {
     const auto& s = h->warpx->btd()->snapshot(i);
     const size_t n = (size_t)s.n[0] * s.n[1] * s.n[2];
     std::memcpy(out, s.data.data() + (size_t)comp * n, sizeof(double) * n);
+    return WXA_OK;
+}
+
+// back-transformed particles of species `id` in snapshot i: their number, and the rows x y z w ux uy uz (lab frame) into
+// out[7][n] (host memory)
+inline int sim_btd_num_particles(SimHandle* h, int32_t i, int32_t id, int64_t* n) {
+    if (!h || !n || !h->warpx->btd() || i < 0 || i >= h->warpx->btd()->num_snapshots() || id < 0) return WXA_ERR_INVALID_ARG;
+    const auto& s = h->warpx->btd()->snapshot(i);
+    *n = id < (int32_t)s.particles.size() ? (int64_t)s.particles[(size_t)id][0].size() : 0;
+    return WXA_OK;
+}
+inline int sim_btd_particles(SimHandle* h, int32_t i, int32_t id, double* out) {
+    int64_t n = 0;
+    const int rc = sim_btd_num_particles(h, i, id, &n);
+    if (rc != WXA_OK || !out) return rc != WXA_OK ? rc : WXA_ERR_INVALID_ARG;
+    if (n == 0) return WXA_OK;
+    const auto& rows = h->warpx->btd()->snapshot(i).particles[(size_t)id];
+    for (int c = 0; c < 7; ++c) std::memcpy(out + (size_t)c * (size_t)n, rows[(size_t)c].data(), sizeof(double) * (size_t)n);
     return WXA_OK;
 }
 
@@ -292,9 +312,10 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     RET PFX##sim_add_laser(SIMTYPE* s, const wxa_laser_antenna* la) {                                  \
         return (RET)wxa::host::sim_add_laser(reinterpret_cast<wxa::host::SimHandle*>(s), la);            \
     }                                                                                                  \
-    RET PFX##sim_add_btd(SIMTYPE* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size) { \
+    RET PFX##sim_add_btd(SIMTYPE* s, int32_t num_snapshots, double dt_snapshots_lab, int32_t buffer_size, \
+                         int32_t write_species) {                                                      \
         auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
-        int rc = wxa::host::sim_add_btd(h, num_snapshots, dt_snapshots_lab, buffer_size);              \
+        int rc = wxa::host::sim_add_btd(h, num_snapshots, dt_snapshots_lab, buffer_size, write_species); \
         if (rc != 0 && h) SET_ERROR(h->error.c_str());                                                 \
         return (RET)rc;                                                                                \
     }                                                                                                  \
@@ -304,6 +325,12 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     }                                                                                                  \
     RET PFX##sim_btd_data(SIMTYPE* s, int32_t i, int32_t comp, double* out) {                          \
         return (RET)wxa::host::sim_btd_data(reinterpret_cast<wxa::host::SimHandle*>(s), i, comp, out); \
+    }                                                                                                  \
+    RET PFX##sim_btd_num_particles(SIMTYPE* s, int32_t i, int32_t id, int64_t* n) {                    \
+        return (RET)wxa::host::sim_btd_num_particles(reinterpret_cast<wxa::host::SimHandle*>(s), i, id, n); \
+    }                                                                                                  \
+    RET PFX##sim_btd_particles(SIMTYPE* s, int32_t i, int32_t id, double* out) {                       \
+        return (RET)wxa::host::sim_btd_particles(reinterpret_cast<wxa::host::SimHandle*>(s), i, id, out); \
     }                                                                                                  \
     RET PFX##sim_get_particles(SIMTYPE* s, int32_t id, wxa_particle_view* out) {                       \
         return (RET)wxa::host::sim_get_particles(reinterpret_cast<wxa::host::SimHandle*>(s), id, out);      \

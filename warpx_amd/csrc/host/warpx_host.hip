@@ -100,6 +100,9 @@ const Backend* hip_backend() {
         b.deposit_current = k_deposit;
         b.filter_bilinear = [](const wxa_field_view* s, const wxa_field_view* d, void* st) -> int {
             return wxa_filter_bilinear(s, d, st); };
+        b.btd_select_particles = [](const wxa_particle_view* p, const double* const o[6], double zb, double zbo, double tb,
+                                    double dt, double tl, double g, double* out, int64_t cap, int64_t* n, void* st) -> int {
+            return wxa_btd_select_particles(p, o, zb, zbo, tb, dt, tl, g, out, cap, n, st); };
         b.filter_stencil = [](const wxa_field_view* s, const wxa_field_view* d, const double* s0, int32_t n0,
                               const double* s1, int32_t n1, const double* s2, int32_t n2, void* st) -> int {
             return wxa_filter_stencil(s, d, s0, n0, s1, n1, s2, n2, st); };

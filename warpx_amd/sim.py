@@ -90,9 +90,19 @@ class WarpXSim:
 
     BTD_COMPONENTS = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho")
 
-    def add_btd(self, num_snapshots: int, dt_snapshots_lab: float, buffer_size: int = 256):
-        """<diag>.diag_type = BackTransformed, fields (wxa_sim_add_btd): lab-frame snapshots every dt_snapshots_lab."""
-        self.lib.sim_add_btd(self._h, int(num_snapshots), float(dt_snapshots_lab), int(buffer_size))
+    def add_btd(self, num_snapshots: int, dt_snapshots_lab: float, buffer_size: int = 256, write_species: bool = True):
+        """<diag>.diag_type = BackTransformed (wxa_sim_add_btd): lab-frame snapshots every dt_snapshots_lab -- the fields,
+        and with write_species the particles of every species."""
+        self.lib.sim_add_btd(self._h, int(num_snapshots), float(dt_snapshots_lab), int(buffer_size), 1 if write_species else 0)
+
+    def btd_particles(self, i: int, sid: int) -> np.ndarray:
+        """(7, n) lab-frame x, y, z, w, ux, uy, uz of the particles of species `sid` that snapshot i has met so far."""
+        n = C.c_int64()
+        self.lib.sim_btd_num_particles(self._h, int(i), int(sid), C.byref(n))
+        out = np.zeros((7, n.value), dtype=np.float64)
+        if n.value:
+            self.lib.sim_btd_particles(self._h, int(i), int(sid), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     def btd_info(self, i: int) -> dict:
         n = (C.c_int32 * 3)()
