@@ -697,9 +697,14 @@ int64_t     wxa_sim_checksum_json(wxa_sim* s, char* buf, int64_t capacity);
  * Source/Diagnostics/BTD_Plotfile_Header_Impl.cpp; what Regression/Checksum/checksum.py (yt) and
  * Tools/PostProcessing/read_raw_data.py read. */
 wxa_status  wxa_sim_write_plotfile(wxa_sim* s, const char* dir);
-/* Lab-frame snapshot i of wxa_sim_add_btd as a plotfile (fields; geometry and time of the lab frame): what the reference's
- * BTD flushes hold once merged (BTDiagnostics::MergeBuffersForPlotfile, BTDiagnostics.cpp:1146-1314), as one grid. */
+/* Lab-frame snapshot i of wxa_sim_add_btd as a plotfile (fields and the back-transformed particles of every species;
+ * geometry and time of the lab frame): what the reference's BTD flushes hold once merged
+ * (BTDiagnostics::MergeBuffersForPlotfile, BTDiagnostics.cpp:1146-1314), as one grid -- this brick's share. */
 wxa_status  wxa_sim_btd_write_plotfile(wxa_sim* s, int32_t i, const char* dir);
+/* Index box (inclusive) of this brick's share of snapshot i in the snapshot's (x, y, k_lab) index space: m_snapshot_box
+ * (BTDiagnostics.cpp:489-506) cut to the brick's cells in x and y.  A brick keeps all of z and fills the slices whose
+ * plane lies in its cells; the shares of the bricks of a run add up to the snapshot. */
+wxa_status  wxa_sim_btd_box(wxa_sim* s, int32_t i, int32_t lo[3], int32_t hi[3]);
 /* The decks' expression evaluator (what the reference gets from amrex::Parser): value of `expr` with
  * the named variables bound to `values`; q_e, m_e, m_p, m_u, epsilon0, mu0, clight, kb, pi predefined. */
 wxa_status  wxa_parser_eval(const char* expr, int32_t nvars, const char* const* names,

@@ -27,11 +27,14 @@ def main():
     transport = TorchBrickTransport(on_device=False)
     # WXA_WORKER_LIB=hipcpu: the product's .hip sources on the CPU execution model instead of the CPU kernels
     load = load_hip_on_cpu if os.environ.get("WXA_WORKER_LIB") == "hipcpu" else load_host_cpu
+    # WXA_TEST_OVERRIDES: "a=b;c=d" appended to the deck, as on the reference's command line
+    over = tuple(v for v in os.environ.get("WXA_TEST_OVERRIDES", "").split(";") if v)
     if nb == (0, 0, 0):     # let the library choose the bricks for comm.nranks
-        sim = WarpXSim.from_inputs(load(), deck, comm=transport.comm)
+        sim = WarpXSim.from_inputs(load(), deck, overrides=over, comm=transport.comm)
     else:
         assert world == nb[0] * nb[1] * nb[2]
-        sim = WarpXSim.from_inputs(load(), deck, nbricks=nb, coord=brick_coord(rank, nb), comm=transport.comm)
+        sim = WarpXSim.from_inputs(load(), deck, overrides=over, nbricks=nb, coord=brick_coord(rank, nb),
+                                   comm=transport.comm)
     # WXA_TEST_MAX_STEP: a shorter run for brick-against-one-brick comparisons (both sides stop at the same step)
     sim.evolve(min(sim.max_step, int(os.environ.get("WXA_TEST_MAX_STEP", sim.max_step))))
     gathered = [None] * world
@@ -44,6 +47,34 @@ def main():
                     total.setdefault(group, {}).setdefault(key, 0.0)
                     total[group][key] += val
         json.dump(total, open(out, "w"))
+    # WXA_TEST_BTD_OUT: the lab-frame snapshots of the deck's BackTransformed diagnostic, the bricks' shares put together
+    btd_out = os.environ.get("WXA_TEST_BTD_OUT")
+    if btd_out:
+        import numpy as np
+        nsnap = int(os.environ.get("WXA_TEST_BTD_NUM", "1"))
+        mine = []
+        for i in range(nsnap):
+            mine.append({"box": sim.btd_box(i), "info": sim.btd_info(i),
+                         "data": {c: sim.btd_snapshot(i, c) for c in WarpXSim.BTD_COMPONENTS},
+                         "particles": [sim.btd_particles(i, s) for s in range(len(sim.species_names))]})
+        shares = [None] * world
+        dist.gather_object(mine, shares if rank == 0 else None, dst=0)
+        if rank == 0:
+            out = {}
+            for i in range(nsnap):
+                hi = np.max([sh[i]["box"][1] for sh in shares], axis=0)
+                lo = np.min([sh[i]["box"][0] for sh in shares], axis=0)
+                for c in WarpXSim.BTD_COMPONENTS:
+                    whole = np.zeros(tuple(int(v) for v in hi - lo + 1))
+                    for sh in shares:
+                        (i0, j0, _), (i1, j1, _) = sh[i]["box"]
+                        whole[i0 - lo[0]:i1 - lo[0] + 1, j0 - lo[1]:j1 - lo[1] + 1, :] += sh[i]["data"][c]
+                    out[f"s{i}_{c}"] = whole
+                for s in range(len(sim.species_names)):
+                    out[f"s{i}_particles{s}"] = np.concatenate([sh[i]["particles"][s] for sh in shares], axis=1)
+                out[f"s{i}_slices"] = np.array([sh[i]["info"]["slices"] for sh in shares])
+                out[f"s{i}_zlab"] = np.array([sh[i]["info"]["z_lab"] for sh in shares])
+            np.savez(btd_out, **out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,5 +1,5 @@
-"""Back-transformed diagnostics, fields (host/BTDiagnostics.hpp against Source/Diagnostics/BTDiagnostics.cpp and
-ComputeDiagFunctors/BackTransformFunctor.cpp).  No golden file of the reference pins it (its only 3-D BTD deck draws a
+"""Back-transformed diagnostics, fields and particles (host/BTDiagnostics.hpp against Source/Diagnostics/BTDiagnostics.cpp,
+ComputeDiagFunctors/BackTransformFunctor.cpp and BackTransformParticleFunctor.cpp).  No golden file of the reference pins it (its only 3-D BTD deck draws a
 random beam) and AMReX's slice interpolation is not on disk, so the pins are: the independent restatement in the oracle
 stepper, and the physics a back-transformation must deliver -- a laser emitted in a gamma = 2 frame is found in the lab
 frame at the lab position, with the lab wavelength and the lab amplitude."""
@@ -132,7 +132,7 @@ def test_btd_from_an_inputs_file(host_cpu):
         WarpXSim.from_inputs(host_cpu, deck, overrides=over[:4] + ("d1.intervals=0:3",))
 
 
-def test_btd_particles_of_a_plasma_at_rest_in_the_lab(host_cpu):
+def test_btd_particles_of_a_plasma_at_rest_in_the_lab(host_cpu, tmp_path):
     """tests/decks/boosted_injection_3d.inputs: a tenuous plasma at rest in the lab frame seen from a gamma = 3 frame, where
     every electron streams backwards with u_z = -gamma beta c.  Back-transformed (BackTransformParticleFunctor.H:106-168) the
     particles a snapshot's plane has met are at rest again, sit inside the snapshot's lab-frame extent, and carry the
@@ -146,7 +146,13 @@ def test_btd_particles_of_a_plasma_at_rest_in_the_lab(host_cpu):
     p = sim.btd_particles(1, 0)
     empty = sim.btd_particles(0, 0)
     live = sim.particles(0)
+    # the snapshot's plotfile carries them as species "electrons": positions, weight, momenta m u (lab frame)
+    from tests.test_plotfile_cpu import read_plotfile
+    sim.btd_write_plotfile(1, str(tmp_path / "lab_snapshot_1"))
+    sp = read_plotfile(str(tmp_path / "lab_snapshot_1"))["species"]["electrons"]
     sim.close()
+    assert np.array_equal(sp["particle_position_z"], p[2]) and np.array_equal(sp["particle_weight"], p[3])
+    assert np.array_equal(sp["particle_momentum_x"], p[4] * plasma.M_E) and np.array_equal(sp["particle_position_x"], p[0])
     assert empty.shape[1] == 0        # at t_lab = 0 the lab window [-16 um, 0] lies below the plasma (z > 1 um)
     assert p.shape[1] > 50 and np.all(p[2] > 1e-6 - 1e-9)   # ... a few femtoseconds later its head has entered it
     c = plasma.C_LIGHT

@@ -177,3 +177,51 @@ def test_random_momenta_do_not_depend_on_the_brick_layout(tmp_path):
     got = json.load(open(out))["electrons"]
     for key, val in want.items():
         assert abs(got[key] - val) <= 1e-13 * abs(val), key
+
+
+@pytest.mark.parametrize("nb,nranks,port", [
+    ((2, 1, 2), 4, 29651),      # split across the window and along it
+    ((1, 1, 4), 4, 29652),      # three faces along z: two slices of this run take a plane from the neighbour brick
+])
+def test_back_transformed_diagnostics_on_bricks_match_one_brick(nb, nranks, port, tmp_path):
+    """<diag>.diag_type = BackTransformed on config 5 in small, several bricks against one: every brick keeps its x-y share
+    of a lab-frame snapshot and fills the slices whose plane lies in its cells (the plane next to a z face comes from the
+    neighbour, BTDiagnostics.cpp:824-828); the shares add up to the single-brick snapshot, fields at 1e-9 of their scale,
+    and the bricks' back-transformed electrons are the single brick's."""
+    import numpy as np
+    from tests.oracle_lib import load_host_cpu
+    from warpx_amd.sim import WarpXSim
+    path = os.path.join(ROOT, "tests", "decks", "laser_wakefield_boosted_3d.inputs")
+    nsteps, nsnap = 50, 3
+    probe = WarpXSim.from_inputs(load_host_cpu(), path)
+    dt_snap = 12 * probe.dt * 5.0          # warpx.gamma_boost = 5: a new plane enters the domain every ~12 steps
+    probe.close()
+    over = ("diagnostics.diags_names=d1", "d1.diag_type=BackTransformed", "d1.do_back_transformed_fields=1",
+            f"d1.num_snapshots_lab={nsnap}", f"d1.dt_snapshots_lab={dt_snap!r}", "d1.buffer_size=32", "d1.format=plotfile",
+            "d1.fields_to_plot=Ex Ey Ez Bx By Bz jx jy jz rho")
+    one = WarpXSim.from_inputs(load_host_cpu(), path, overrides=over)
+    one.evolve(nsteps)
+    want = [({c: one.btd_snapshot(i, c) for c in WarpXSim.BTD_COMPONENTS}, one.btd_particles(i, 0), one.btd_info(i))
+            for i in range(nsnap)]
+    one.close()
+    out = str(tmp_path / "btd.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
+           *[str(v) for v in nb], path, str(tmp_path / "sum.json")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks), WXA_TEST_MAX_STEP=str(nsteps),
+                                WXA_TEST_OVERRIDES=";".join(over), WXA_TEST_BTD_OUT=out, WXA_TEST_BTD_NUM=str(nsnap)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = np.load(out)
+    for i in range(nsnap):
+        fields, parts, info = want[i]
+        assert np.all(got[f"s{i}_slices"] == info["slices"])          # every brick counts the same slices
+        for c in WarpXSim.BTD_COMPONENTS:
+            a, b = got[f"s{i}_{c}"], fields[c]
+            assert a.shape == b.shape
+            assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), (i, c)
+        a, b = got[f"s{i}_particles0"], parts
+        assert a.shape == b.shape and (i > 0 or a.shape[1] > 100)
+        a, b = (q[:, np.lexsort((q[2], np.round(q[1] / 1e-10), np.round(q[0] / 1e-10)))] for q in (a, b))
+        for row in range(7):
+            assert np.max(np.abs(a[row] - b[row])) <= 1e-9 * max(np.max(np.abs(b[row])), 1e-300), (i, row)

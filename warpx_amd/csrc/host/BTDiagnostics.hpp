@@ -1,15 +1,18 @@
-// Back-transformed diagnostics, fields only: lab-frame snapshots assembled slice by slice from a boosted-frame run.
-// Restates the field part of Source/Diagnostics/BTDiagnostics.cpp and
-// Source/Diagnostics/ComputeDiagFunctors/BackTransformFunctor.cpp for one level, one box, boost and window along z:
+// Back-transformed diagnostics: lab-frame snapshots (fields and particles) assembled slice by slice from a boosted-frame run.
+// Restates Source/Diagnostics/BTDiagnostics.cpp, Source/Diagnostics/ComputeDiagFunctors/BackTransformFunctor.cpp and
+// BackTransformParticleFunctor.cpp for one level, boost and window along z (one box per rank: a brick
+// keeps its own x-y part of every snapshot, see ComputeAndPack):
 //   DerivedInitData (:66-205), InitializeBufferData (:333-506): lab time, lab-frame extent and index box of snapshot i;
 //   PrepareBufferData / UpdateBufferData (:755-798), GetZSliceInDomainFlag (:999-1018), k_index_zlab (:892-905):
 //     where the snapshot's plane z_lab(t) sits in the boosted frame at this step and which lab-frame index it fills;
 //   BackTransformFunctor::operator() (:49-149): the cell-centred fields (CellCenterFunctor: Ex .. Bz, jx .. jz, rho)
 //     sliced at z_boost with linear interpolation between the two nearest cell centres (amrex::get_slice_data with
 //     interpolate = true -- AMReX is not on disk: the rule is restated from its documented behaviour and from the
-//     half-cell exclusion of GetZSliceInDomainFlag, parity unpinned), LorentzTransformZ (:246-317), copy to index k_lab.
+//     half-cell exclusion of GetZSliceInDomainFlag, parity unpinned), LorentzTransformZ (:246-317), copy to index k_lab;
+//   BackTransformParticleFunctor::operator() (BackTransformParticleFunctor.cpp:76-152): PackParticles below, the selection
+//     and the transform on the device (host/btd_kernels.hip).
 // What is not here: the buffer multifabs and their flushes (a snapshot is kept whole in host memory: the merged plotfile
-// of the reference holds the same numbers), particles (BackTransformParticleFunctor), mesh refinement, RZ, openPMD.
+// of the reference holds the same numbers), mesh refinement, RZ, openPMD.
 // Output stage, not on the step path: the fields are copied to the host (Plotfile.hpp does the same).
 #ifndef WXA_HOST_BTDIAGNOSTICS_HPP_
 #define WXA_HOST_BTDIAGNOSTICS_HPP_
@@ -35,7 +38,8 @@ public:
         int ksmall = 0, kbig = 0;               // m_snapshot_box along z
         double z_boost = 0, z_lab = 0;          // m_current_z_boost / m_current_z_lab
         int counter = 0, last_valid = 0, full = 0;
-        int n[3] = {0, 0, 0};                   // cells of the snapshot array (x, y, z)
+        int n[3] = {0, 0, 0};                   // cells of the snapshot array (x, y, z): this brick's x-y cells, all of z
+        int ilo[2] = {0, 0};                    // ... and where its first cell sits in the snapshot's index box
         std::vector<double> data;               // [comp][k][j][i], zero until a slice arrives
         // back-transformed particles per species: rows x y z w ux uy uz (lab frame), in arrival order
         std::vector<std::array<std::vector<double>, 7>> particles;
@@ -67,6 +71,7 @@ public:
         const double dzl = dz_lab(dt);
         const double bmw_v = (m_mw_beta - m_beta) / (1.0 - m_beta * m_mw_beta);   // :341-342
         m_snap.assign((size_t)m_num, Snapshot{});
+        m_xbuf.be = ctx.be;
         for (int i = 0; i < m_num; ++i) {
             Snapshot& s = m_snap[(size_t)i];
             const double zmax_boost = ctx.prob_hi[2];
@@ -102,8 +107,14 @@ public:
             const int kindex_hi = (int)std::floor((s.zhi_lab - (s.zlo_lab + 0.5 * dzl)) / dzl);     // :489-494
             s.kbig = kindex_hi;
             s.ksmall = kindex_hi - (nzs - 1);
-            s.n[0] = nx_lab; s.n[1] = ny_lab; s.n[2] = nzs;
-            s.data.assign((size_t)NCOMP * (size_t)nzs * (size_t)ny_lab * (size_t)nx_lab, 0.0);
+            // this brick's share: its own cells in x and y (the reference keeps one buffer box per boosted-frame box)
+            const int nxy_lab[2] = {nx_lab, ny_lab};
+            for (int d = 0; d < 2; ++d) {
+                s.ilo[d] = ctx.brick_box.lo[d];
+                s.n[d] = std::max(0, std::min(ctx.brick_box.hi[d] + 1, lo[d] + nxy_lab[d]) - ctx.brick_box.lo[d]);
+            }
+            s.n[2] = nzs;
+            s.data.assign((size_t)NCOMP * (size_t)nzs * (size_t)s.n[1] * (size_t)s.n[0], 0.0);
         }
     }
 
@@ -172,6 +183,10 @@ public:
             for (const FieldType ft : fts)
                 for (int d = 0; d < 3; ++d) cc.push_back(cell_centered(ctx.be, *wx.fields().get(ft, Direction{d}, 0), nc));
             cc.push_back(cell_centered(ctx.be, wx.ComputeRho(), nc));
+            // bricks stacked along z: the interpolation across a brick face needs the neighbour's first / last plane of
+            // cell-centred values (m_cell_centered_data has one guard cell, BTDiagnostics.cpp:516-527, filled by the
+            // FillBoundary of PrepareFieldDataForOutput, :824-828)
+            if (wx.comm().exchanges(2)) exchange_guard_planes(wx, cc, nc);
             for (size_t i = 0; i < m_snap.size(); ++i) {
                 Snapshot& s = m_snap[i];
                 if (!in_domain[i] || s.full) continue;                     // m_perform_backtransform (:152-164)
@@ -234,6 +249,31 @@ private:
         return out;
     }
 
+    // the plane next to each z face of this brick, from the brick behind that face (zeros at a domain boundary)
+    template <class WX>
+    void exchange_guard_planes(WX& wx, const std::vector<std::vector<double>>& cc, const int nc[3]) {
+        const auto& ctx = wx.context();
+        const size_t plane = (size_t)nc[0] * nc[1], bytes = sizeof(double) * NCOMP * plane;
+        std::vector<double> host(2 * NCOMP * plane);
+        for (int c = 0; c < NCOMP; ++c) {
+            std::copy(cc[(size_t)c].begin(), cc[(size_t)c].begin() + (std::ptrdiff_t)plane, host.begin() + (std::ptrdiff_t)(c * plane));
+            std::copy(cc[(size_t)c].end() - (std::ptrdiff_t)plane, cc[(size_t)c].end(),
+                      host.begin() + (std::ptrdiff_t)((NCOMP + c) * plane));
+        }
+        m_xbuf.reserve(4 * bytes);   // to minus | to plus | from plus | from minus
+        char* base = static_cast<char*>(m_xbuf.p);
+        if (ctx.be->memcpy_h2d(base, host.data(), 2 * bytes) != 0 ||
+            ctx.be->memset_async(base + 2 * bytes, 0, 2 * bytes, ctx.stream) != 0)
+            throw std::runtime_error("BackTransformed diagnostic: device copy failed");
+        wx.comm().exchange_raw(2, base, (int64_t)bytes, base + bytes, (int64_t)bytes, base + 2 * bytes, (int64_t)bytes,
+                               base + 3 * bytes, (int64_t)bytes, ctx.stream);
+        wx.sync_stream();
+        if (ctx.be->memcpy_d2h(host.data(), base + 2 * bytes, 2 * bytes) != 0)
+            throw std::runtime_error("BackTransformed diagnostic: device copy failed");
+        m_guard_hi.assign(host.begin(), host.begin() + (std::ptrdiff_t)(NCOMP * plane));
+        m_guard_lo.assign(host.begin() + (std::ptrdiff_t)(NCOMP * plane), host.end());
+    }
+
     template <class CTX>
     void back_transform_slice(Snapshot& s, int k_lab, const std::vector<std::vector<double>>& cc, const int nc[3],
                               const CTX& ctx) const {
@@ -246,8 +286,23 @@ private:
         double w;
         if (s.z_boost >= zc) { klo = kc; khi = kc + 1; w = (s.z_boost - zc) / cs; }
         else { klo = kc - 1; khi = kc; w = (s.z_boost - (zc - cs)) / cs; }
-        if (klo < 0 || khi >= nc[2]) return;   // excluded by GetZSliceInDomainFlag's half cell; kept as a guard
+        const int nz_domain = (int)std::lround((ctx.prob_hi[2] - ctx.prob_lo[2]) / cs);
+        if (klo < 0 || khi >= nz_domain) return;   // excluded by GetZSliceInDomainFlag's half cell; kept as a guard
+        // the brick that holds the plane's cell fills the slice (get_slice_data: the box that contains the coordinate)
+        const int k0 = ctx.brick_box.lo[2];
+        if (kc < k0 || kc >= k0 + nc[2]) return;
         const size_t plane = (size_t)nc[0] * nc[1];
+        const bool guards = m_guard_lo.size() == (size_t)NCOMP * plane;
+        if ((klo < k0 || khi >= k0 + nc[2]) && !guards) return;
+        // component c on the global cell plane kg: this brick's, or the neighbour's plane behind a z face
+        auto plane_of = [&](int c, int kg) -> const double* {
+            if (kg < k0) return m_guard_lo.data() + (size_t)c * plane;
+            if (kg >= k0 + nc[2]) return m_guard_hi.data() + (size_t)c * plane;
+            return cc[(size_t)c].data() + (size_t)(kg - k0) * plane;
+        };
+        const double* plo[NCOMP];
+        const double* phi[NCOMP];
+        for (int c = 0; c < NCOMP; ++c) { plo[c] = plane_of(c, klo); phi[c] = plane_of(c, khi); }
         const size_t snap_plane = (size_t)s.n[0] * s.n[1];
         const size_t kk = (size_t)(k_lab - s.ksmall);
         const double clight = kC, inv_clight = 1.0 / kC;
@@ -256,7 +311,7 @@ private:
                 double v[NCOMP];
                 const size_t at = (size_t)i + (size_t)j * nc[0];
                 for (int c = 0; c < NCOMP; ++c)
-                    v[c] = (1.0 - w) * cc[(size_t)c][at + (size_t)klo * plane] + w * cc[(size_t)c][at + (size_t)khi * plane];
+                    v[c] = (1.0 - w) * plo[c][at] + w * phi[c][at];
                 // LorentzTransformZ (BackTransformFunctor.cpp:289-313)
                 const double ex_lab = m_gamma * (v[0] + m_beta * clight * v[4]);
                 const double by_lab = m_gamma * (v[4] + m_beta * inv_clight * v[0]);
@@ -277,6 +332,8 @@ private:
     int m_buffer_size;
     double m_gamma = 1.0, m_beta = 0.0, m_mw_beta = 0.0;
     std::vector<Snapshot> m_snap;
+    DeviceBuffer m_xbuf;                         // exchange_guard_planes
+    std::vector<double> m_guard_lo, m_guard_hi;  // [comp][j][i] behind the low / high z face
 };
 
 }  // namespace wxa::host

@@ -114,11 +114,35 @@ inline void write_cell_data(const std::string& dir, const std::vector<std::strin
     }
 }
 
-// Lab-frame snapshot i of the back-transformed diagnostics as a plotfile (fields only): what the reference's BTD flushes
+// <dir>/<name>/{Header, Level_0/Particle_H, Level_0/DATA_00000} of one species on one grid: `rec` holds x y z w px py pz
+// per particle (layouts cited at the top of this file)
+inline void write_particle_data(const std::string& dir, const std::string& name, const std::vector<double>& rec, size_t n,
+                                const std::string& box) {
+    make_dir(dir + "/" + name);
+    make_dir(dir + "/" + name + "/Level_0");
+    {
+        std::ofstream f(dir + "/" + name + "/Level_0/DATA_00000", std::ios::binary | std::ios::trunc);
+        f.write(reinterpret_cast<const char*>(rec.data()), (std::streamsize)(sizeof(double) * 7 * n));
+    }
+    {
+        std::ofstream f(dir + "/" + name + "/Level_0/Particle_H", std::ios::binary | std::ios::trunc);
+        f << "(1 0\n" << box << "\n)\n";
+    }
+    {
+        std::ofstream f(dir + "/" + name + "/Header", std::ios::binary | std::ios::trunc);
+        f.precision(17);
+        f << "Version_Two_Dot_One_double\n" << 3 << '\n' << 4 << '\n'
+          << "weight\nmomentum_x\nmomentum_y\nmomentum_z\n" << 0 << '\n'      // no int components
+          << 0 << '\n' << n << '\n' << (n + 1) << '\n' << 0 << '\n'           // is_checkpoint, count, next id, finest level
+          << 1 << '\n' << 0 << ' ' << n << ' ' << 0 << '\n';                  // one grid: file 0, count, offset
+    }
+}
+
+// Lab-frame snapshot i of the back-transformed diagnostics as a plotfile (fields and back-transformed particles): what the reference's BTD flushes
 // add up to once BTDiagnostics::MergeBuffersForPlotfile (BTDiagnostics.cpp:1146-1314) has interleaved their headers -- one
 // grid here instead of one per flushed buffer.  Geometry: x, y of the boosted-frame domain, z = the snapshot's lab-frame
 // extent, time = t_lab (BTD_Plotfile_Header_Impl.cpp:108-176).
-inline void write_btd_plotfile(SimHandle& h, int i, const std::string& dir) {
+inline void write_btd_plotfile(SimHandle& h, int i, const std::string& dir, const std::vector<std::string>& species_names) {
     WarpX& wx = *h.warpx;
     if (!wx.btd() || i < 0 || i >= wx.btd()->num_snapshots()) throw std::runtime_error("plotfile: no such lab-frame snapshot");
     const auto& s = wx.btd()->snapshot(i);
@@ -129,12 +153,26 @@ inline void write_btd_plotfile(SimHandle& h, int i, const std::string& dir) {
     std::vector<std::vector<double>> data;
     for (int c = 0; c < BTDiagnostics::NCOMP; ++c)
         data.emplace_back(s.data.begin() + (std::ptrdiff_t)((size_t)c * n), s.data.begin() + (std::ptrdiff_t)((size_t)(c + 1) * n));
-    const int lo[3] = {0, 0, s.ksmall}, hi[3] = {s.n[0] - 1, s.n[1] - 1, s.kbig};
+    // this brick's share (wxa_sim_btd_box): its x-y cells, all of z -- bricks stacked along z each hold the slices whose
+    // plane lay in their cells and zeros elsewhere, their plotfiles add up
+    const int lo[3] = {s.ilo[0], s.ilo[1], s.ksmall}, hi[3] = {s.ilo[0] + s.n[0] - 1, s.ilo[1] + s.n[1] - 1, s.kbig};
     const double dzl = (s.zhi_lab - s.zlo_lab) / s.n[2];
-    const double rlo[3] = {ctx.prob_lo[0], ctx.prob_lo[1], s.zlo_lab};
-    const double rhi[3] = {ctx.prob_lo[0] + s.n[0] * ctx.dx[0], ctx.prob_lo[1] + s.n[1] * ctx.dx[1], s.zhi_lab};
+    const double rlo[3] = {ctx.prob_lo[0] + s.ilo[0] * ctx.dx[0], ctx.prob_lo[1] + s.ilo[1] * ctx.dx[1], s.zlo_lab};
+    const double rhi[3] = {rlo[0] + s.n[0] * ctx.dx[0], rlo[1] + s.n[1] * ctx.dx[1], s.zhi_lab};
     const double dx[3] = {ctx.dx[0], ctx.dx[1], dzl};
     write_cell_data(dir, names, data, lo, hi, rlo, rhi, dx, s.t_lab, i);
+    // the particles the snapshot's plane has met so far, momenta as m u like every plotfile of the reference
+    // (BTD goes through the same WriteParticles, FlushFormatPlotfile.cpp:345-441)
+    for (size_t sp = 0; sp < s.particles.size(); ++sp) {
+        const auto& rows = s.particles[sp];
+        const size_t np = rows[0].size();
+        const double mass = wx.GetPartContainer().GetParticleContainer((int)sp).mass;
+        std::vector<double> rec(7 * np);
+        for (size_t q = 0; q < np; ++q)
+            for (int c = 0; c < 7; ++c) rec[7 * q + (size_t)c] = c >= 4 ? rows[(size_t)c][q] * mass : rows[(size_t)c][q];
+        const std::string name = sp < species_names.size() ? species_names[sp] : "species" + std::to_string(sp);
+        write_particle_data(dir, name, rec, np, box_string(lo, hi));
+    }
 }
 
 inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vector<std::string>& species_names) {
@@ -177,30 +215,13 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
         ParticleTile& t = pc.tile();
         const size_t n = (size_t)t.numParticles();
         const std::string name = s < (int)species_names.size() ? species_names[s] : "species" + std::to_string(s);
-        make_dir(dir + "/" + name);
-        make_dir(dir + "/" + name + "/Level_0");
         std::vector<double> soa(7 * n), rec(7 * n);
         for (int c = 0; c < 7; ++c)
             if (n && be->memcpy_d2h(soa.data() + (size_t)c * n, t.comp(c), sizeof(double) * n) != 0)
                 throw std::runtime_error("plotfile: device copy failed");
         for (size_t i = 0; i < n; ++i)
             for (int c = 0; c < 7; ++c) rec[7 * i + c] = c >= 4 ? soa[(size_t)c * n + i] * pc.mass : soa[(size_t)c * n + i];
-        {
-            std::ofstream f(dir + "/" + name + "/Level_0/DATA_00000", std::ios::binary | std::ios::trunc);
-            f.write(reinterpret_cast<const char*>(rec.data()), (std::streamsize)(sizeof(double) * rec.size()));
-        }
-        {
-            std::ofstream f(dir + "/" + name + "/Level_0/Particle_H", std::ios::binary | std::ios::trunc);
-            f << "(1 0\n" << box << "\n)\n";
-        }
-        {
-            std::ofstream f(dir + "/" + name + "/Header", std::ios::binary | std::ios::trunc);
-            f.precision(17);
-            f << "Version_Two_Dot_One_double\n" << 3 << '\n' << 4 << '\n'
-              << "weight\nmomentum_x\nmomentum_y\nmomentum_z\n" << 0 << '\n'      // no int components
-              << 0 << '\n' << n << '\n' << (n + 1) << '\n' << 0 << '\n'           // is_checkpoint, count, next id, finest level
-              << 1 << '\n' << 0 << ' ' << n << ' ' << 0 << '\n';                  // one grid: file 0, count, offset
-        }
+        write_particle_data(dir, name, rec, n, box);
     }
     {   // WarpXHeader (FlushFormatPlotfile.cpp:238-343), the part readers look at
         std::ofstream f(dir + "/WarpXHeader", std::ios::binary | std::ios::trunc);

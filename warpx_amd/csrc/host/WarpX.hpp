@@ -293,8 +293,6 @@ public:
     // num_snapshots_lab, dt_snapshots_lab (= dz_snapshots_lab / c), buffer_size as in BTDiagnostics::ReadParameters (:206-292)
     // write_species (<diag>.write_species, default 1 in the reference): the species' particles too
     void AddBTDiagnostics(int num_snapshots, amrex::Real dt_snapshots_lab, int buffer_size, bool write_species) {
-        for (int d = 0; d < 3; ++d)
-            if (m_cfg.nbricks[d] != 1) throw std::runtime_error("BackTransformed diagnostic: one brick only");
         m_btd = std::make_unique<BTDiagnostics>(num_snapshots, dt_snapshots_lab, buffer_size);
         m_btd->Init(*this);
         m_btd_write_species = write_species;

@@ -810,12 +810,23 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         if (!s || !dir) return (RET)WXA_ERR_INVALID_ARG;                                               \
         auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
         try {                                                                                          \
-            wxa::host::write_btd_plotfile(*h, i, dir);                                                 \
+            wxa::host::write_btd_plotfile(*h, i, dir, h->species_names);                                      \
             return (RET)WXA_OK;                                                                        \
         } catch (const std::exception& e) {                                                            \
             SET_ERROR(e.what());                                                                       \
             return (RET)WXA_ERR_INVALID_ARG;                                                           \
         }                                                                                              \
+    }                                                                                                  \
+    /* index box of this brick's share of snapshot i in the snapshot's (x, y, k_lab) index space (m_snapshot_box, */ \
+    /* BTDiagnostics.cpp:489-506, cut to the brick in x and y), inclusive bounds */                  \
+    RET PFX##sim_btd_box(SIMTYPE* s, int32_t i, int32_t lo[3], int32_t hi[3]) {                       \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        if (!s || !lo || !hi || !h->warpx->btd() || i < 0 || i >= h->warpx->btd()->num_snapshots())   \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        const auto& sn = h->warpx->btd()->snapshot(i);                                                 \
+        lo[0] = sn.ilo[0]; lo[1] = sn.ilo[1]; lo[2] = sn.ksmall;                                       \
+        hi[0] = sn.ilo[0] + sn.n[0] - 1; hi[1] = sn.ilo[1] + sn.n[1] - 1; hi[2] = sn.kbig;             \
+        return (RET)WXA_OK;                                                                            \
     }                                                                                                  \
     /* Evolve without / with the velocity synchronisation at the end of the call, and the synchronisation alone */ \
     RET PFX##sim_set_synchronize_at_end(SIMTYPE* s, int32_t on) {                                      \

@@ -112,6 +112,12 @@ class WarpXSim:
         self.lib.sim_btd_info(self._h, int(i), n, z, C.byref(t), C.byref(filled), C.byref(full))
         return {"n": tuple(n), "z_lab": tuple(z), "t_lab": t.value, "slices": filled.value, "full": bool(full.value)}
 
+    def btd_box(self, i: int):
+        """(lo, hi), inclusive: this brick's share of snapshot i in the snapshot's (x, y, k_lab) index space."""
+        lo, hi = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+        self.lib.sim_btd_box(self._h, int(i), lo, hi)
+        return tuple(lo), tuple(hi)
+
     def btd_snapshot(self, i: int, name: str) -> np.ndarray:
         """Component `name` of lab-frame snapshot i, indexed [i, j, k] (zeros where no slice has arrived yet)."""
         n = self.btd_info(i)["n"]
