@@ -161,3 +161,73 @@ def test_btd_particles_of_a_plasma_at_rest_in_the_lab(host_cpu, tmp_path):
     assert np.all(p[2] > info["z_lab"][0]) and np.all(p[2] < info["z_lab"][1])
     assert np.all(np.abs(live[6] + np.sqrt(8.0) * c) < 1e-6 * c)   # the boosted-frame drift the transform removes
     assert np.allclose(p[3], live[3][0], rtol=1e-12)        # one weight for all: the lab density x the lab cell volume / ppc
+
+
+def test_btd_snapshots_flushed_to_disk_buffer_by_buffer(host_cpu, tmp_path):
+    """wxa_sim_btd_set_flush (BTDiagnostics::Flush + MergeBuffersForPlotfile, BTDiagnostics.cpp:1027-1314): with a file prefix
+    every full buffer of 16 slices becomes one more grid of the snapshot's plotfile and only the buffer being filled stays
+    in memory; the forced flush after the last step writes the partly filled ones.  Read back with the strict reader of
+    test_plotfile_cpu.py the grids hold, bit for bit, what the in-memory diagnostic of a second run holds."""
+    from tests.test_plotfile_cpu import read_plotfile
+    steps, nsnap, bs = 50, 3, 16
+    runs = []
+    for flush in (False, True):
+        sim, e = pec_case.make_boosted_lwfa_sim(host_cpu)
+        sim.add_btd(nsnap, 12 * sim.dt * pec_case.BOOST_GAMMA, buffer_size=bs)
+        if flush:
+            sim.btd_set_flush(str(tmp_path / "lab"), 5)
+        sim.evolve(steps)
+        if flush:
+            sim.btd_flush()
+            with pytest.raises(Exception):
+                sim.btd_write_plotfile(0, str(tmp_path / "no"))     # the diagnostic writes its snapshots itself
+        info = [sim.btd_info(i) for i in range(nsnap)]
+        box = [sim.btd_box(i) for i in range(nsnap)]
+        mem = None if flush else [({c: sim.btd_snapshot(i, c) for c in WarpXSim.BTD_COMPONENTS}, sim.btd_particles(i, e))
+                                  for i in range(nsnap)]
+        runs.append((info, box, mem))
+        sim.close()
+    (info, box, mem), (info_f, box_f, _) = runs
+    assert [a["slices"] for a in info] == [a["slices"] for a in info_f] and box == box_f
+    for i in range(nsnap):
+        path = str(tmp_path / ("lab%05d" % i))
+        pf = read_plotfile(path)
+        fabs = sorted(f for f in os.listdir(os.path.join(path, "Level_0")) if f.startswith("Cell_D_"))
+        # one grid per started buffer: the planes arrive one per step from the top of the snapshot's box downwards
+        assert len(fabs) == -(-info[i]["slices"] // bs) and fabs[0] == "Cell_D_00000"
+        assert pf["time"] == info[i]["t_lab"] and pf["step"] == steps and pf["names"] == list(WarpXSim.BTD_COMPONENTS)
+        (lo, hi), nz = box[i], info[i]["n"][2]
+        k1 = nz - len(fabs) * bs                     # the grids cover the top len(fabs) buffers of the snapshot's box
+        for c in WarpXSim.BTD_COMPONENTS:
+            assert pf["fields"][c].shape == (info[i]["n"][0], info[i]["n"][1], len(fabs) * bs)
+            assert np.array_equal(pf["fields"][c], mem[i][0][c][:, :, k1:]), (i, c)
+            assert not np.any(mem[i][0][c][:, :, :k1])                  # nothing below them yet
+        sp = pf["species"]["species0"]
+        want = mem[i][1]
+        got = np.array([sp["particle_position_x"], sp["particle_position_y"], sp["particle_position_z"], sp["particle_weight"],
+                        sp["particle_momentum_x"] / plasma.M_E, sp["particle_momentum_y"] / plasma.M_E,
+                        sp["particle_momentum_z"] / plasma.M_E])
+        assert got.shape == want.shape and (i > 0 or got.shape[1] > 100)
+        assert np.array_equal(got[:4], want[:4])                        # arrival order is flush order
+        assert np.allclose(got[4:], want[4:], rtol=1e-15, atol=0.0)
+
+
+def test_btd_file_prefix_in_an_inputs_file(host_cpu, tmp_path):
+    """<diag>.file_prefix in a deck turns the flushes on (the reference always writes; here the snapshots otherwise stay in
+    memory): 20 steps of the gamma = 2 antenna deck with buffers of 8 slices leave two complete grids and, after the forced
+    flush, a third."""
+    from tests.test_plotfile_cpu import read_plotfile
+    deck = os.path.join(HERE, "decks", "boosted_laser_3d.inputs")
+    prefix = str(tmp_path / "diags" / "lab")
+    over = ("max_step=20", "diagnostics.diags_names=d1", "d1.diag_type=BackTransformed", "d1.do_back_transformed_fields=1",
+            "d1.num_snapshots_lab=1", "d1.dz_snapshots_lab=18.e-6", "d1.buffer_size=8", "d1.format=plotfile",
+            f"d1.file_prefix={prefix}", "d1.file_min_digits=3")
+    sim = WarpXSim.from_inputs(host_cpu, deck, overrides=over)
+    sim.evolve(20)
+    assert len(read_plotfile(prefix + "000")["fields"]["Ey"][0, 0, :]) == 16
+    with pytest.raises(Exception):
+        sim.btd_snapshot(0, "Ey")            # flushed, not kept
+    sim.btd_flush()
+    sim.close()
+    pf = read_plotfile(prefix + "000")
+    assert pf["fields"]["Ey"].shape[2] == 24 and pf["step"] == 20

@@ -66,7 +66,7 @@ def test_ckc_bricks_match_single_domain(nb, order, filt, port, tmp_path):
 
 @pytest.mark.parametrize("nb,nranks,deck,golden,port", [
     # window along z (unsplit), bricks along x: continuous injection, the antenna and the PEC walls per brick
-    ((2, 1, 1), 2, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29621),
+    pytest.param((2, 1, 1), 2, "laser_wakefield_3d.inputs", "laser_acceleration_3d_checksums.json", 29621, marks=EXTRA),   # x split: (1, 2, 2) below
     ((1, 1, 2), 2, "langmuir_multi_3d.inputs", "langmuir_multi_3d_checksums.json", 29623),
     # (0, 0, 0): the library chooses the bricks, the longest direction first -- four bricks along z for the wakefield
     # deck (across the PEC walls and along the window, since round 3), 2 x 2 x 2 for the all-periodic Langmuir deck
@@ -102,7 +102,8 @@ def test_deck_on_bricks_reaches_the_golden_checksums(nb, nranks, deck, golden, p
 
 @pytest.mark.parametrize("nb,nranks,deck,port", [
     pytest.param((2, 1, 1), 2, "laser_wakefield_boosted_3d.inputs", 29641, marks=EXTRA),   # BASELINE config 5 in small on bricks along x
-    ((2, 2, 1), 4, "laser_wakefield_boosted_3d.inputs", 29642),     # ... on 2 x 2 bricks across the window direction
+    pytest.param((2, 2, 1), 4, "laser_wakefield_boosted_3d.inputs", 29642, marks=EXTRA),   # ... on 2 x 2 bricks across the window direction
+    # (the back-transformed test below runs the same deck on 2 x 1 x 2 and compares every lab-frame slice)
     ((1, 2, 1), 2, "boosted_injection_3d.inputs", 29643),
     ((2, 1, 1), 2, "boosted_laser_3d.inputs", 29644),               # the drifting antenna split over two bricks
     pytest.param((1, 1, 2), 2, "laser_wakefield_boosted_3d.inputs", 29645, marks=EXTRA),   # round 3: config 5 in small cut along z (the window)

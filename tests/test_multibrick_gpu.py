@@ -20,12 +20,26 @@ L = 40e-6
 FIELDS = ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz")
 
 
+def thread_transport_state():
+    """What the bricks (threads) of one test share: the mailboxes, a condition for arrivals, the turn lock."""
+    return {"box": {}, "cbox": {}, "arrival": threading.Condition(), "turn": threading.Lock(), "failed": []}
+
+
+def thread_transport_abort(shared):
+    with shared["arrival"]:
+        shared["failed"].append(True)
+        shared["arrival"].notify_all()
+
+
 class ThreadBrickTransport:
-    """Mailbox + barrier exchange between the bricks (threads) of one process."""
+    """Mailbox exchange between the bricks (threads) of one process.  Matching is per pair of bricks, like RCCL's and
+    gloo's: the k-th message a brick sends to a peer is the k-th that peer receives from it, whatever the other bricks do
+    meanwhile (bricks along a moving window do not all take part in every exchange)."""
 
     def __init__(self, rank, nranks, shared):
         self.rank, self.nranks, self.shared = rank, nranks, shared
         self.n_exchanges = 0
+        self._sent, self._received = {}, {}       # (mailbox, peer) -> messages so far
         self._exchange_cb = _capi.EXCHANGE_FN(self._exchange)
         self._counts_cb = _capi.EXCHANGE_COUNTS_FN(self._exchange_counts)
         self.comm = _capi.Comm()
@@ -33,65 +47,62 @@ class ThreadBrickTransport:
         self.comm.rank, self.comm.nranks = rank, nranks
         self.comm.exchange, self.comm.exchange_counts = self._exchange_cb, self._counts_cb
 
-    def _wait(self):
-        # One brick at a time runs native code (the lock is handed over only at the exchange points):
-        # the bricks of a real run are separate processes, concurrency inside one process is not
-        # what this test is about.
+    def _post(self, mailbox, peer, item):
+        k = self._sent.get((mailbox, peer), 0)
+        self._sent[(mailbox, peer)] = k + 1
+        with self.shared["arrival"]:
+            self.shared[mailbox][(self.rank, peer, k)] = item
+            self.shared["arrival"].notify_all()
+
+    def _take(self, mailbox, peer):
+        k = self._received.get((mailbox, peer), 0)
+        self._received[(mailbox, peer)] = k + 1
+        key = (peer, self.rank, k)
+        # One brick at a time runs native code (the lock is handed over only while a brick waits for a message): the
+        # bricks of a real run are separate processes, concurrency inside one process is not what these tests are about.
         self.shared["turn"].release()
         try:
-            self.shared["barrier"].wait(timeout=120)
+            with self.shared["arrival"]:
+                ok = self.shared["arrival"].wait_for(lambda: key in self.shared[mailbox] or self.shared["failed"], timeout=120)
+                if not ok or key not in self.shared[mailbox]:
+                    raise RuntimeError("no message from brick %d" % peer)
+                return self.shared[mailbox].pop(key)
         finally:
             self.shared["turn"].acquire()
 
     def _exchange(self, ctx, nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf, recv_bytes, stream):
         try:
-            import torch
             H.device_sync()
-            box = self.shared["box"]
-            # the k-th message to a peer pairs with that peer's k-th receive from here (RCCL's matching rule, which the
-            # host layer relies on: posting order per peer pair)
-            nth = {}
+            # an empty message is no message, on either side (the RCCL and the torch.distributed transports skip them too:
+            # a brick with nothing to hand to a peer and nothing to expect from it may not make the call at all)
             for i in range(nmsg):
                 n = int(send_bytes[i])
-                k = nth.get(("s", int(send_peer[i])), 0)
-                nth[("s", int(send_peer[i]))] = k + 1
-                box[(self.rank, int(send_peer[i]), k)] = _as_tensor(send_buf[i], n, H.ON_GPU).clone() if n else None
-            self._wait()
+                if n:
+                    self._post("box", int(send_peer[i]), _as_tensor(send_buf[i], n, H.ON_GPU).clone())
             for i in range(nmsg):
                 n = int(recv_bytes[i])
-                k = nth.get(("r", int(recv_peer[i])), 0)
-                nth[("r", int(recv_peer[i]))] = k + 1
-                t = box[(int(recv_peer[i]), self.rank, k)]
-                assert (t.numel() if t is not None else 0) == n
                 if n:
+                    t = self._take("box", int(recv_peer[i]))
+                    assert t.numel() == n, (self.rank, int(recv_peer[i]), n, t.numel())
                     _as_tensor(recv_buf[i], n, H.ON_GPU).copy_(t)
             H.device_sync()
-            self._wait()
             self.n_exchanges += 1
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             print(f"[ThreadBrickTransport] exchange failed on rank {self.rank}: {e!r}", flush=True)
-            self.shared["barrier"].abort()
+            thread_transport_abort(self.shared)
             return -1
 
     def _exchange_counts(self, ctx, nmsg, send_peer, send_val, recv_peer, recv_val):
         try:
-            box = self.shared["cbox"]
-            nth = {}
             for i in range(nmsg):
-                k = nth.get(("s", int(send_peer[i])), 0)
-                nth[("s", int(send_peer[i]))] = k + 1
-                box[(self.rank, int(send_peer[i]), k)] = int(send_val[i])
-            self._wait()
+                self._post("cbox", int(send_peer[i]), int(send_val[i]))
             for i in range(nmsg):
-                k = nth.get(("r", int(recv_peer[i])), 0)
-                nth[("r", int(recv_peer[i]))] = k + 1
-                recv_val[i] = box[(int(recv_peer[i]), self.rank, k)]
-            self._wait()
+                recv_val[i] = self._take("cbox", int(recv_peer[i]))
             return 0
         except Exception as e:
             print(f"[ThreadBrickTransport] exchange_counts failed on rank {self.rank}: {e!r}", flush=True)
-            self.shared["barrier"].abort()
+            thread_transport_abort(self.shared)
             return -1
 
 
@@ -165,7 +176,7 @@ def run_bricks(product, nb, order, filt, overlap, n_cell, steps):
     parts = np.array(plasma.uniform_plasma(n_cell, prob_lo, prob_hi, (1, 2, 1), 1e25, 0.3, seed=11))
     bn = [n_cell[d] // nb[d] for d in range(3)]
     dx = [L / n_cell[d] for d in range(3)]
-    shared = {"box": {}, "cbox": {}, "barrier": threading.Barrier(nranks), "turn": threading.Lock()}
+    shared = thread_transport_state()
     results, errors = [None] * nranks, []
 
     def brick(rank):
@@ -193,7 +204,7 @@ def run_bricks(product, nb, order, filt, overlap, n_cell, steps):
             sim.close()
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
-            shared["barrier"].abort()
+            thread_transport_abort(shared)
         finally:
             shared["turn"].release()
 
@@ -245,3 +256,65 @@ def test_rccl_transport_loopback(product):
     assert st["timed_exchanges"] == 3 and st["timed_ms"] > 0.0
     print("rccl loop-back:", st)
     tr.close()
+
+
+def test_back_transformed_diagnostics_on_bricks(product):
+    """<diag>.diag_type = BackTransformed on the HIP path with four bricks stacked along z, the boost and window direction
+    (config 5 in small, 50 steps, three lab-frame snapshots): every brick fills the slices whose plane lies in its cells,
+    the plane behind a z face travels through the transport from device memory (BTDiagnostics::exchange_guard_planes),
+    particles are selected on the brick they live on.  The shares add up to the one-brick run of the same library: fields
+    at 1e-9 of their scale, the same back-transformed electrons."""
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decks", "laser_wakefield_boosted_3d.inputs")
+    nb, nsteps, nsnap = (1, 1, 4), 50, 3
+    probe = WarpXSim.from_inputs(product, deck)
+    dt_snap = 12 * probe.dt * 5.0
+    probe.close()
+    over = ("diagnostics.diags_names=d1", "d1.diag_type=BackTransformed", "d1.do_back_transformed_fields=1",
+            f"d1.num_snapshots_lab={nsnap}", f"d1.dt_snapshots_lab={dt_snap!r}", "d1.buffer_size=32", "d1.format=plotfile",
+            "d1.fields_to_plot=Ex Ey Ez Bx By Bz jx jy jz rho")
+
+    def snapshots(sim):
+        return [{"box": sim.btd_box(i), "slices": sim.btd_info(i)["slices"],
+                 "data": {c: sim.btd_snapshot(i, c) for c in WarpXSim.BTD_COMPONENTS},
+                 "particles": sim.btd_particles(i, 0)} for i in range(nsnap)]
+
+    one = WarpXSim.from_inputs(product, deck, overrides=over)
+    one.evolve(nsteps)
+    want = snapshots(one)
+    one.close()
+
+    nranks = nb[0] * nb[1] * nb[2]
+    shared = thread_transport_state()
+    shares, errors = [None] * nranks, []
+
+    def brick(rank):
+        shared["turn"].acquire()
+        try:
+            tr = ThreadBrickTransport(rank, nranks, shared)
+            sim = WarpXSim.from_inputs(product, deck, overrides=over, nbricks=nb, coord=brick_coord(rank, nb), comm=tr.comm)
+            sim.evolve(nsteps)
+            shares[rank] = snapshots(sim)
+            sim.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            thread_transport_abort(shared)
+        finally:
+            shared["turn"].release()
+
+    threads = [threading.Thread(target=brick, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    for i in range(nsnap):
+        assert all(sh[i]["slices"] == want[i]["slices"] and sh[i]["box"] == want[i]["box"] for sh in shares)
+        for c in WarpXSim.BTD_COMPONENTS:
+            whole = sum(sh[i]["data"][c] for sh in shares)       # same x-y box on every brick: the shares differ in z only
+            b = want[i]["data"][c]
+            assert np.max(np.abs(whole - b)) <= 1e-9 * np.max(np.abs(b)), (i, c)
+        a, b = np.concatenate([sh[i]["particles"] for sh in shares], axis=1), want[i]["particles"]
+        assert a.shape == b.shape and (i > 0 or a.shape[1] > 100)
+        a, b = (q[:, np.lexsort((q[2], np.round(q[1] / 1e-10), np.round(q[0] / 1e-10)))] for q in (a, b))
+        for row in range(7):
+            assert np.max(np.abs(a[row] - b[row])) <= 1e-9 * max(np.max(np.abs(b[row])), 1e-300), (i, row)

@@ -99,6 +99,8 @@ def read_plotfile(path):
         data = np.zeros((0, len(cols)))
         for g in range(ngr):
             which, count, where = (int(x) for x in h[q + 5 + g].split())
+            if count == 0:      # a grid without particles has no DATA file (BTDiagnostics.cpp:1274, 1290)
+                continue
             with open(os.path.join(path, entry, "Level_0", "DATA_%05d" % which), "rb") as f:
                 f.seek(where)
                 rec = np.fromfile(f, "<f8", count * len(cols)).reshape(count, len(cols))

@@ -201,6 +201,8 @@ _INPUTS_SIGS = {
     "sim_checksum_json": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "sim_write_plotfile": (C.c_int, [C.c_void_p, C.c_char_p]),
     "sim_btd_write_plotfile": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p]),
+    "sim_btd_set_flush": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "sim_btd_flush": (C.c_int, [C.c_void_p]),
     "sim_btd_box": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sim_set_synchronize_at_end": (C.c_int, [C.c_void_p, C.c_int32]),
     "sim_synchronize": (C.c_int, [C.c_void_p]),

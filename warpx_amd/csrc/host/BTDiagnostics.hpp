@@ -11,8 +11,10 @@
 //     half-cell exclusion of GetZSliceInDomainFlag, parity unpinned), LorentzTransformZ (:246-317), copy to index k_lab;
 //   BackTransformParticleFunctor::operator() (BackTransformParticleFunctor.cpp:76-152): PackParticles below, the selection
 //     and the transform on the device (host/btd_kernels.hip).
-// What is not here: the buffer multifabs and their flushes (a snapshot is kept whole in host memory: the merged plotfile
-// of the reference holds the same numbers), mesh refinement, RZ, openPMD.
+//   DefineFieldBufferMultiFab (:916-974), DoDump (:294-320), Flush (:1027-1137), MergeBuffersForPlotfile (:1146-1314):
+//     with SetFlush a snapshot is assembled buffer_size slices at a time and every full buffer goes to disk as one more
+//     grid of the snapshot's plotfile (flush below); without it a snapshot is kept whole in host memory.
+// What is not here: mesh refinement, RZ, openPMD.
 // Output stage, not on the step path: the fields are copied to the host (Plotfile.hpp does the same).
 #ifndef WXA_HOST_BTDIAGNOSTICS_HPP_
 #define WXA_HOST_BTDIAGNOSTICS_HPP_
@@ -25,6 +27,7 @@
 #include "amrex_shim.hpp"
 #include "backend.hpp"
 #include "BrickComm.hpp"
+#include "PlotfileFormat.hpp"
 
 namespace wxa::host {
 
@@ -43,6 +46,12 @@ public:
         std::vector<double> data;               // [comp][k][j][i], zero until a slice arrives
         // back-transformed particles per species: rows x y z w ux uy uz (lab frame), in arrival order
         std::vector<std::array<std::vector<double>, 7>> particles;
+        // the planes `data` holds: all of the snapshot, or (SetFlush) the buffer being filled
+        int data_k0 = 0, data_nz = 0;
+        // m_buffer_box along z, m_buffer_counter, m_buffer_k_index_hi; one PlotGrid per flushed buffer (m_buffer_flush_counter)
+        int buffer_klo = 0, buffer_khi = -1, buffer_counter = 0, buffer_k_index_hi = 0;
+        std::vector<PlotGrid> flushed;
+        std::vector<std::vector<ParticleGrid>> flushed_particles;   // per species
     };
 
     BTDiagnostics(int num_snapshots, double dt_snapshots_lab, int buffer_size)
@@ -50,6 +59,20 @@ public:
         if (num_snapshots < 1 || !(dt_snapshots_lab > 0.0) || buffer_size < 1)
             throw std::runtime_error("BackTransformed diagnostic: num_snapshots_lab >= 1, dt_snapshots_lab > 0, buffer_size >= 1");
     }
+
+    // <diag>.file_prefix / file_min_digits: snapshot i is written to <prefix><i, min_digits>/ buffer by buffer, and only the
+    // buffer being filled is kept in memory.  Before the first slice arrives.
+    void SetFlush(const std::string& file_prefix, int file_min_digits) {
+        for (const Snapshot& s : m_snap)
+            if (s.counter > 0) throw std::runtime_error("BackTransformed diagnostic: SetFlush comes before the first slice");
+        if (file_prefix.empty() || file_min_digits < 1) throw std::runtime_error("BackTransformed diagnostic: file_prefix / file_min_digits");
+        m_flush_prefix = file_prefix;
+        m_file_min_digits = file_min_digits;
+        for (Snapshot& s : m_snap) { s.data.clear(); s.data.shrink_to_fit(); s.data_k0 = 0; s.data_nz = 0; }
+    }
+    bool flushing() const { return !m_flush_prefix.empty(); }
+    std::string snapshot_path(int i) const { return numbered(m_flush_prefix, i, m_file_min_digits); }
+    void SetSpeciesNames(const std::vector<std::string>& names) { m_species_names = names; }
 
     int num_snapshots() const { return m_num; }
     const Snapshot& snapshot(int i) const { return m_snap.at((size_t)i); }
@@ -114,7 +137,12 @@ public:
                 s.n[d] = std::max(0, std::min(ctx.brick_box.hi[d] + 1, lo[d] + nxy_lab[d]) - ctx.brick_box.lo[d]);
             }
             s.n[2] = nzs;
-            s.data.assign((size_t)NCOMP * (size_t)nzs * (size_t)s.n[1] * (size_t)s.n[0], 0.0);
+            s.buffer_k_index_hi = s.kbig;                                                            // :502-504
+            if (!flushing()) {
+                s.data_k0 = s.ksmall;
+                s.data_nz = nzs;
+                s.data.assign((size_t)NCOMP * (size_t)nzs * (size_t)s.n[1] * (size_t)s.n[0], 0.0);
+            }
         }
     }
 
@@ -172,6 +200,18 @@ public:
             in_domain[i] = slice_in_domain(m_snap[i], ctx) ? 1 : 0;
             any = any || (in_domain[i] && !m_snap[i].full);
         }
+        // DefineFieldBufferMultiFab: an empty buffer starts below the last one as soon as the plane's index is in the snapshot
+        for (Snapshot& s : m_snap) {
+            const int k_lab = k_index_zlab(s, dzl);
+            if (k_lab < s.ksmall || k_lab > s.kbig || s.buffer_counter != 0 || s.full) continue;
+            s.buffer_khi = s.buffer_k_index_hi;
+            s.buffer_klo = s.buffer_khi - m_buffer_size + 1;
+            if (flushing()) {
+                s.data_k0 = s.buffer_klo;
+                s.data_nz = m_buffer_size;
+                s.data.assign((size_t)NCOMP * (size_t)m_buffer_size * (size_t)s.n[1] * (size_t)s.n[0], 0.0);
+            }
+        }
         if (any) {
             // PrepareFieldDataForOutput: the ten cell-centred components of the whole (single) box, on the host
             using warpx::fields::FieldType;
@@ -198,14 +238,88 @@ public:
         // UpdateBufferData, then what DoDump / Flush do to the flags (:294-320, :907-914)
         for (size_t i = 0; i < m_snap.size(); ++i) {
             Snapshot& s = m_snap[i];
-            if (in_domain[i]) ++s.counter;
-            if (k_index_zlab(s, dzl) == s.ksmall) s.last_valid = 1;
+            if (in_domain[i]) { ++s.counter; ++s.buffer_counter; }
+            const int k_lab = k_index_zlab(s, dzl);
+            if (k_lab == s.ksmall) s.last_valid = 1;
+            // DoDump: the plane has reached the bottom of the buffer, or of the snapshot
+            if (flushing() && !s.full && s.buffer_khi >= s.buffer_klo && s.buffer_counter > 0 &&
+                (k_lab == s.buffer_klo || s.last_valid == 1))
+                flush(wx, (int)i);
             if (s.last_valid == 1) s.full = 1;
         }
     }
 
+    // The forced flush after the last step (Diagnostics::FilterComputePackFlushLastTimestep, DoDump's force_flush): the
+    // buffers that have received slices since their last flush go to disk as they are
+    template <class WX>
+    void FlushLast(WX& wx) {
+        if (!flushing()) return;
+        for (size_t i = 0; i < m_snap.size(); ++i)
+            if (!m_snap[i].full && m_snap[i].buffer_counter > 0 && m_snap[i].buffer_khi >= m_snap[i].buffer_klo) flush(wx, (int)i);
+    }
+
 private:
     static constexpr double kC = 299792458.0;
+
+    // Flush + MergeBuffersForPlotfile for snapshot i: the buffer becomes grid number m_buffer_flush_counter of the
+    // snapshot's plotfile (Level_0/Cell_D_<n>, <species>/Level_0/DATA_<n>), the headers are rewritten for the grids so
+    // far (the reference interleaves the buffer's headers into the snapshot's, :1316-1434), the buffer is emptied and the
+    // next one starts below it (:1127-1137).  This brick's share, like wxa_sim_btd_write_plotfile.
+    template <class WX>
+    void flush(WX& wx, int i) {
+        Snapshot& s = m_snap[(size_t)i];
+        const auto& ctx = wx.context();
+        const std::string dir = snapshot_path(i);
+        const int id = (int)s.flushed.size();
+        if (id == 0) { make_dirs(dir); make_dir(dir + "/Level_0"); }
+        PlotGrid g;
+        g.lo[0] = s.ilo[0]; g.lo[1] = s.ilo[1]; g.lo[2] = s.buffer_klo;
+        g.hi[0] = s.ilo[0] + s.n[0] - 1; g.hi[1] = s.ilo[1] + s.n[1] - 1; g.hi[2] = s.buffer_khi;
+        g.fab_file = numbered("Cell_D_", id, 5);
+        const size_t npts = (size_t)s.n[0] * s.n[1] * (size_t)s.data_nz;
+        std::vector<const double*> comps;
+        for (int c = 0; c < NCOMP; ++c) comps.push_back(s.data.data() + (size_t)c * npts);
+        write_fab(dir, g, comps);
+        s.flushed.push_back(g);
+        // the particles the plane has met while this buffer was filled, momenta as m u (FlushFormatPlotfile.cpp:412-424)
+        const int nspecies = (int)s.particles.size();   // empty without <diag>.write_species
+        if ((int)s.flushed_particles.size() < nspecies) s.flushed_particles.resize((size_t)nspecies);
+        for (int sp = 0; sp < nspecies; ++sp) {
+            const std::string name = sp < (int)m_species_names.size() ? m_species_names[(size_t)sp] : "species" + std::to_string(sp);
+            if (id == 0) { make_dir(dir + "/" + name); make_dir(dir + "/" + name + "/Level_0"); }
+            auto& rows = s.particles[(size_t)sp];
+            const size_t np = rows[0].size();
+            const double mass = wx.GetPartContainer().GetParticleContainer(sp).mass;
+            std::vector<double> rec(7 * np);
+            for (size_t q = 0; q < np; ++q)
+                for (int c = 0; c < 7; ++c) rec[7 * q + (size_t)c] = c >= 4 ? rows[(size_t)c][q] * mass : rows[(size_t)c][q];
+            if (np) write_particle_records(dir, name, id, rec, np);   // no file for an empty grid (:1274, :1290)
+            for (auto& r : rows) { r.clear(); r.shrink_to_fit(); }
+            ParticleGrid pg;
+            for (int d = 0; d < 3; ++d) { pg.lo[d] = g.lo[d]; pg.hi[d] = g.hi[d]; }
+            pg.which = id;
+            pg.count = (int64_t)np;
+            s.flushed_particles[(size_t)sp].push_back(pg);
+            write_species_headers(dir, name, s.flushed_particles[(size_t)sp]);
+        }
+        // the snapshot's Header covers the grids written so far (InterleaveBufferAndSnapshotHeader, :1316-1359)
+        int dom_lo[3] = {g.lo[0], g.lo[1], g.lo[2]}, dom_hi[3] = {g.hi[0], g.hi[1], g.hi[2]};
+        for (const PlotGrid& q : s.flushed) { dom_lo[2] = std::min(dom_lo[2], q.lo[2]); dom_hi[2] = std::max(dom_hi[2], q.hi[2]); }
+        const double dzl = (s.zhi_lab - s.zlo_lab) / s.n[2];
+        const double dx[3] = {ctx.dx[0], ctx.dx[1], dzl};
+        const double rlo[3] = {ctx.prob_lo[0] + dom_lo[0] * dx[0], ctx.prob_lo[1] + dom_lo[1] * dx[1],
+                               s.zlo_lab + (dom_lo[2] - s.ksmall) * dzl};
+        const double rhi[3] = {ctx.prob_lo[0] + (dom_hi[0] + 1) * dx[0], ctx.prob_lo[1] + (dom_hi[1] + 1) * dx[1],
+                               s.zlo_lab + (dom_hi[2] + 1 - s.ksmall) * dzl};
+        static const char* comp_names[NCOMP] = {"Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho"};
+        write_cell_headers(dir, std::vector<std::string>(comp_names, comp_names + NCOMP), s.flushed, dom_lo, dom_hi, rlo, rhi,
+                           dx, s.t_lab, wx.getistep());
+        s.buffer_counter = 0;
+        s.buffer_k_index_hi = s.buffer_klo - 1;
+        s.buffer_khi = s.buffer_klo - 1;   // no buffer until the next one is defined
+        s.data.clear();
+        s.data_nz = 0;
+    }
 
     double z_boost_of(double t_lab, double t_boost) const { return (t_lab / m_gamma - t_boost) * kC / m_beta; }   // BTDiagnostics.H:276-280
     double z_lab_of(double t_lab, double t_boost) const { return (t_lab - t_boost / m_gamma) * kC / m_beta; }     // :285-289
@@ -304,7 +418,8 @@ private:
         const double* phi[NCOMP];
         for (int c = 0; c < NCOMP; ++c) { plo[c] = plane_of(c, klo); phi[c] = plane_of(c, khi); }
         const size_t snap_plane = (size_t)s.n[0] * s.n[1];
-        const size_t kk = (size_t)(k_lab - s.ksmall);
+        if (k_lab < s.data_k0 || k_lab >= s.data_k0 + s.data_nz) return;   // not in the planes held (a buffer not yet defined)
+        const size_t kk = (size_t)(k_lab - s.data_k0);
         const double clight = kC, inv_clight = 1.0 / kC;
         for (int j = 0; j < s.n[1] && j < nc[1]; ++j)
             for (int i = 0; i < s.n[0] && i < nc[0]; ++i) {
@@ -323,7 +438,7 @@ private:
                 const double rho_lab = m_gamma * (v[9] + m_beta * inv_clight * v[8]);
                 v[8] = j_lab; v[9] = rho_lab;
                 const size_t dst = (size_t)i + (size_t)j * s.n[0] + kk * snap_plane;
-                for (int c = 0; c < NCOMP; ++c) s.data[(size_t)c * snap_plane * (size_t)s.n[2] + dst] = v[c];
+                for (int c = 0; c < NCOMP; ++c) s.data[(size_t)c * snap_plane * (size_t)s.data_nz + dst] = v[c];
             }
     }
 
@@ -332,6 +447,9 @@ private:
     int m_buffer_size;
     double m_gamma = 1.0, m_beta = 0.0, m_mw_beta = 0.0;
     std::vector<Snapshot> m_snap;
+    std::string m_flush_prefix;                  // SetFlush
+    int m_file_min_digits = 6;
+    std::vector<std::string> m_species_names;
     DeviceBuffer m_xbuf;                         // exchange_guard_planes
     std::vector<double> m_guard_lo, m_guard_hi;  // [comp][j][i] behind the low / high z face
 };

@@ -25,13 +25,10 @@
 #include <fstream>
 #include <sstream>
 
+#include "PlotfileFormat.hpp"
 #include "sim_capi.hpp"
 
 namespace wxa::host {
-
-inline void make_dir(const std::string& path) {
-    if (::mkdir(path.c_str(), 0755) != 0 && errno != EEXIST) throw std::runtime_error("plotfile: cannot create " + path);
-}
 
 // staggered component -> cell centres of the valid box, dense Fortran-order array
 inline std::vector<double> cell_centered(const Backend* be, const amrex::MultiFab& mf, int ncell[3]) {
@@ -60,82 +57,33 @@ inline std::vector<double> cell_centered(const Backend* be, const amrex::MultiFa
     return out;
 }
 
-inline std::string box_string(const int lo[3], const int hi[3]) {
-    std::ostringstream s;
-    s << "((" << lo[0] << ',' << lo[1] << ',' << lo[2] << ") (" << hi[0] << ',' << hi[1] << ',' << hi[2] << ") (0,0,0))";
-    return s.str();
-}
-
 // Header + Level_0/Cell_H + Level_0/Cell_D_00000 of a single-level plotfile with one grid: `data[c]` is component c of
-// the box lo..hi in Fortran order (layouts cited at the top of this file)
+// the box lo..hi in Fortran order (layouts: PlotfileFormat.hpp)
 inline void write_cell_data(const std::string& dir, const std::vector<std::string>& names,
                             const std::vector<std::vector<double>>& data, const int lo[3], const int hi[3],
                             const double rlo[3], const double rhi[3], const double dx[3], double time, int64_t step) {
-    const int ncomp = (int)names.size();
     make_dir(dir);
     make_dir(dir + "/Level_0");
-    const std::string box = box_string(lo, hi);
-    const std::string fab_header = "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" + box + " " +
-                                   std::to_string(ncomp) + "\n";
-    {
-        std::ofstream f(dir + "/Level_0/Cell_D_00000", std::ios::binary | std::ios::trunc);
-        if (!f.good()) throw std::runtime_error("plotfile: cannot open Cell_D_00000");
-        f << fab_header;
-        for (const auto& c : data) f.write(reinterpret_cast<const char*>(c.data()), (std::streamsize)(sizeof(double) * c.size()));
-    }
-    {
-        std::ofstream f(dir + "/Level_0/Cell_H", std::ios::binary | std::ios::trunc);
-        f.precision(17);
-        f << 1 << '\n' << 1 << '\n' << ncomp << '\n' << 0 << '\n';      // version, how (one fab per file), ncomp, ngrow
-        f << "(1 0\n" << box << "\n)\n";                                // BoxArray::writeOn
-        f << 1 << '\n' << "FabOnDisk: Cell_D_00000 0\n" << '\n';
-        f << 1 << ',' << ncomp << '\n';
-        for (const auto& c : data) { double m = c.empty() ? 0.0 : c[0]; for (double v : c) m = std::min(m, v); f << m << ','; }
-        f << "\n\n" << 1 << ',' << ncomp << '\n';
-        for (const auto& c : data) { double m = c.empty() ? 0.0 : c[0]; for (double v : c) m = std::max(m, v); f << m << ','; }
-        f << '\n';
-    }
-    {
-        std::ofstream f(dir + "/Header", std::ios::binary | std::ios::trunc);
-        f.precision(17);
-        f << "HyperCLaw-V1.1\n" << ncomp << '\n';
-        for (const auto& n : names) f << n << '\n';
-        f << 3 << '\n' << time << '\n' << 0 << '\n';
-        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ';
-        f << '\n';
-        for (int d = 0; d < 3; ++d) f << rhi[d] << ' ';
-        f << '\n' << '\n';                                              // no refinement ratios on a single level
-        f << box << '\n' << step << '\n';
-        for (int d = 0; d < 3; ++d) f << dx[d] << ' ';
-        f << '\n' << 0 << '\n' << 0 << '\n';                            // Cartesian, bwidth
-        f << 0 << ' ' << 1 << ' ' << time << '\n' << step << '\n';
-        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ' << rhi[d] << '\n';
-        f << "Level_0/Cell\n";
-    }
+    PlotGrid g;
+    for (int d = 0; d < 3; ++d) { g.lo[d] = lo[d]; g.hi[d] = hi[d]; }
+    g.fab_file = "Cell_D_00000";
+    std::vector<const double*> comps;
+    for (const auto& c : data) comps.push_back(c.data());
+    write_fab(dir, g, comps);
+    write_cell_headers(dir, names, {g}, lo, hi, rlo, rhi, dx, time, step);
 }
 
 // <dir>/<name>/{Header, Level_0/Particle_H, Level_0/DATA_00000} of one species on one grid: `rec` holds x y z w px py pz
-// per particle (layouts cited at the top of this file)
+// per particle
 inline void write_particle_data(const std::string& dir, const std::string& name, const std::vector<double>& rec, size_t n,
-                                const std::string& box) {
+                                const int lo[3], const int hi[3]) {
     make_dir(dir + "/" + name);
     make_dir(dir + "/" + name + "/Level_0");
-    {
-        std::ofstream f(dir + "/" + name + "/Level_0/DATA_00000", std::ios::binary | std::ios::trunc);
-        f.write(reinterpret_cast<const char*>(rec.data()), (std::streamsize)(sizeof(double) * 7 * n));
-    }
-    {
-        std::ofstream f(dir + "/" + name + "/Level_0/Particle_H", std::ios::binary | std::ios::trunc);
-        f << "(1 0\n" << box << "\n)\n";
-    }
-    {
-        std::ofstream f(dir + "/" + name + "/Header", std::ios::binary | std::ios::trunc);
-        f.precision(17);
-        f << "Version_Two_Dot_One_double\n" << 3 << '\n' << 4 << '\n'
-          << "weight\nmomentum_x\nmomentum_y\nmomentum_z\n" << 0 << '\n'      // no int components
-          << 0 << '\n' << n << '\n' << (n + 1) << '\n' << 0 << '\n'           // is_checkpoint, count, next id, finest level
-          << 1 << '\n' << 0 << ' ' << n << ' ' << 0 << '\n';                  // one grid: file 0, count, offset
-    }
+    write_particle_records(dir, name, 0, rec, n);
+    ParticleGrid g;
+    for (int d = 0; d < 3; ++d) { g.lo[d] = lo[d]; g.hi[d] = hi[d]; }
+    g.count = (int64_t)n;
+    write_species_headers(dir, name, {g});
 }
 
 // Lab-frame snapshot i of the back-transformed diagnostics as a plotfile (fields and back-transformed particles): what the reference's BTD flushes
@@ -145,6 +93,7 @@ inline void write_particle_data(const std::string& dir, const std::string& name,
 inline void write_btd_plotfile(SimHandle& h, int i, const std::string& dir, const std::vector<std::string>& species_names) {
     WarpX& wx = *h.warpx;
     if (!wx.btd() || i < 0 || i >= wx.btd()->num_snapshots()) throw std::runtime_error("plotfile: no such lab-frame snapshot");
+    if (wx.btd()->flushing()) throw std::runtime_error("plotfile: this diagnostic writes its snapshots itself (wxa_sim_btd_set_flush)");
     const auto& s = wx.btd()->snapshot(i);
     const WarpXContext& ctx = wx.context();
     static const char* comp_names[BTDiagnostics::NCOMP] = {"Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho"};
@@ -171,7 +120,7 @@ inline void write_btd_plotfile(SimHandle& h, int i, const std::string& dir, cons
         for (size_t q = 0; q < np; ++q)
             for (int c = 0; c < 7; ++c) rec[7 * q + (size_t)c] = c >= 4 ? rows[(size_t)c][q] * mass : rows[(size_t)c][q];
         const std::string name = sp < species_names.size() ? species_names[sp] : "species" + std::to_string(sp);
-        write_particle_data(dir, name, rec, np, box_string(lo, hi));
+        write_particle_data(dir, name, rec, np, lo, hi);
     }
 }
 
@@ -207,7 +156,6 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
         rlo[d] = ctx.brick_plo[d];
         rhi[d] = ctx.brick_plo[d] + ncell[d] * dx[d];
     }
-    const std::string box = box_string(lo, hi);
     write_cell_data(dir, names, data, lo, hi, rlo, rhi, dx, wx.gett_new(), wx.getistep());
     // ---- particles
     for (int s = 0; s < wx.GetPartContainer().nSpecies(); ++s) {
@@ -221,7 +169,7 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
                 throw std::runtime_error("plotfile: device copy failed");
         for (size_t i = 0; i < n; ++i)
             for (int c = 0; c < 7; ++c) rec[7 * i + c] = c >= 4 ? soa[(size_t)c * n + i] * pc.mass : soa[(size_t)c * n + i];
-        write_particle_data(dir, name, rec, n, box);
+        write_particle_data(dir, name, rec, n, lo, hi);
     }
     {   // WarpXHeader (FlushFormatPlotfile.cpp:238-343), the part readers look at
         std::ofstream f(dir + "/WarpXHeader", std::ios::binary | std::ios::trunc);

@@ -304,7 +304,7 @@ public:
         m_ctx.btd = m_btd.get();
         for (int i = 0; i < mypc->nSpecies(); ++i) mypc->GetParticleContainer(i).btd_species_id = i;
     }
-    const BTDiagnostics* btd() const { return m_btd.get(); }
+    BTDiagnostics* btd() const { return m_btd.get(); }
     amrex::Real getdt() const { return dt[0]; }
     void sync_stream() { m_be->stream_sync(m_ctx.stream); }
 

@@ -716,6 +716,20 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         int write_species = 1;                                     // BTDiagnostics.cpp:113-114
         pp.queryWithParser(d + ".write_species", write_species);
         wx.AddBTDiagnostics(nsnap, dt_snap, buffer, write_species != 0);
+        wx.btd()->SetSpeciesNames(info.species_names);
+        // <diag>.file_prefix (BTDiagnostics.cpp:98-99 reads it through Diagnostics::BaseReadParameters): given, the snapshots
+        // are flushed to <file_prefix><i>/ buffer by buffer as plotfiles; absent, they stay in memory.  One directory per
+        // brick: the bricks of a run do not share a file.
+        std::string prefix;
+        if (pp.query(d + ".file_prefix", prefix)) {
+            int digits = 6;                                        // Diagnostics.H: m_file_min_digits
+            pp.queryWithParser(d + ".file_min_digits", digits);
+            std::string format = "plotfile";
+            pp.query_word(d + ".format", format);
+            if (format != "plotfile") throw std::runtime_error("inputs: " + d + ".format = " + format + " is not on this path (plotfile)");
+            if (comm && comm->nranks > 1) prefix += "brick" + std::to_string(comm->rank) + "_";
+            wx.btd()->SetFlush(prefix, digits);
+        }
     }
     for (const std::string& d : diag_names) pp.ignore_prefix(d + ".");
     for (const std::string& d : rdiag_names) pp.ignore_prefix(d + ".");
@@ -811,6 +825,33 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
         try {                                                                                          \
             wxa::host::write_btd_plotfile(*h, i, dir, h->species_names);                                      \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
+    }                                                                                                  \
+    /* snapshots to disk: <file_prefix><i, file_min_digits>/ receives every full buffer as one more grid of a plotfile */ \
+    /* (BTDiagnostics::Flush + MergeBuffersForPlotfile, BTDiagnostics.cpp:1027-1314); after wxa_sim_add_btd, before stepping */ \
+    RET PFX##sim_btd_set_flush(SIMTYPE* s, const char* file_prefix, int32_t file_min_digits) {        \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        if (!s || !file_prefix || !h->warpx->btd()) return (RET)WXA_ERR_INVALID_ARG;                   \
+        try {                                                                                          \
+            h->warpx->btd()->SetSpeciesNames(h->species_names);                                        \
+            h->warpx->btd()->SetFlush(file_prefix, file_min_digits);                                   \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
+    }                                                                                                  \
+    /* the forced flush after the last step (FilterComputePackFlushLastTimestep): partly filled buffers go to disk */ \
+    RET PFX##sim_btd_flush(SIMTYPE* s) {                                                               \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        if (!s || !h->warpx->btd()) return (RET)WXA_ERR_INVALID_ARG;                                   \
+        try {                                                                                          \
+            h->warpx->btd()->SetSpeciesNames(h->species_names);                                        \
+            h->warpx->btd()->FlushLast(*h->warpx);                                                     \
             return (RET)WXA_OK;                                                                        \
         } catch (const std::exception& e) {                                                            \
             SET_ERROR(e.what());                                                                       \

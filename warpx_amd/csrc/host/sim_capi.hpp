@@ -212,6 +212,7 @@ inline int sim_btd_data(SimHandle* h, int32_t i, int32_t comp, double* out) {
         return WXA_ERR_INVALID_ARG;
     const auto& s = h->warpx->btd()->snapshot(i);
     const size_t n = (size_t)s.n[0] * s.n[1] * s.n[2];
+    if (s.data.size() != (size_t)BTDiagnostics::NCOMP * n) return WXA_ERR_INVALID_ARG;   // flushed to disk, not kept (wxa_sim_btd_set_flush)
     std::memcpy(out, s.data.data() + (size_t)comp * n, sizeof(double) * n);
     return WXA_OK;
 }

@@ -112,6 +112,14 @@ class WarpXSim:
         self.lib.sim_btd_info(self._h, int(i), n, z, C.byref(t), C.byref(filled), C.byref(full))
         return {"n": tuple(n), "z_lab": tuple(z), "t_lab": t.value, "slices": filled.value, "full": bool(full.value)}
 
+    def btd_set_flush(self, file_prefix: str, file_min_digits: int = 6):
+        """Write the lab-frame snapshots to <file_prefix><i>/ buffer by buffer instead of keeping them (wxa_sim_btd_set_flush)."""
+        self.lib.sim_btd_set_flush(self._h, str(file_prefix).encode(), int(file_min_digits))
+
+    def btd_flush(self):
+        """The forced flush after the last step (wxa_sim_btd_flush)."""
+        self.lib.sim_btd_flush(self._h)
+
     def btd_box(self, i: int):
         """(lo, hi), inclusive: this brick's share of snapshot i in the snapshot's (x, y, k_lab) index space."""
         lo, hi = (C.c_int32 * 3)(), (C.c_int32 * 3)()
