@@ -732,10 +732,6 @@ int64_t    wxa_sim_istep(const wxa_sim* s);
  * Source/ablastr/fields/MultiFabRegister.H:389-470). */
 wxa_status wxa_sim_get_field(wxa_sim* s, const char* name, wxa_field_view* out);
 wxa_status wxa_sim_get_particles(wxa_sim* s, int32_t species_id, wxa_particle_view* out);
-/* Per-phase accumulated device time in ms since the last reset, named after the
- * reference's profiler regions (SURVEY.md section 5): 0 GatherAndPush,
- * 1 CurrentDeposition, 2 SyncCurrent(filter+SumBoundary), 3 EvolveB, 4 EvolveE,
- * 5 FillBoundary, 6 Redistribute+Sort.  counts[i] = number of launches. */
 /* <diag>.diag_type = BackTransformed with do_back_transformed_fields = 1 (Source/Diagnostics/BTDiagnostics.cpp,
  * ComputeDiagFunctors/BackTransformFunctor.cpp), fields only, one brick, boost and moving window along z:
  * num_snapshots lab-frame snapshots at t_lab = i dt_snapshots_lab (+ the offset of :346-347), each assembled from one
@@ -763,8 +759,41 @@ wxa_status wxa_sim_btd_info(wxa_sim* s, int32_t i, int32_t n[3], double z_lab[2]
                             int32_t* full);
 wxa_status wxa_sim_btd_data(wxa_sim* s, int32_t i, int32_t comp, double* out);
 
+/* Per-phase accumulated device time in ms since the last reset, named after the
+ * reference's profiler regions (SURVEY.md section 5): 0 GatherAndPush,
+ * 1 CurrentDeposition, 2 SyncCurrent(filter+SumBoundary), 3 EvolveB, 4 EvolveE,
+ * 5 FillBoundary, 6 Redistribute+Sort.  counts[i] = number of launches. */
 wxa_status wxa_sim_get_timers(wxa_sim* s, double ms[8], int64_t counts[8], int reset);
 wxa_status wxa_sim_enable_timers(wxa_sim* s, int enable);
+
+/* ---- Reduced diagnostics: the parity metric on the device (Source/Diagnostics/ReducedDiags/) ----------------------
+ * The two reductions behind FieldEnergy, ParticleEnergy, ParticleMomentum and ParticleNumber.
+ * wxa_reduce_field: over the points [lo, hi) (global indices) of one component, sum of squares and largest magnitude
+ *   -- what MultiFab::norm2(0, periodicity) and norminf give FieldEnergy::ComputeDiags (FieldEnergy.cpp:81-157); the caller
+ *   chooses the box so that a point shared by two bricks or by the two ends of a periodic direction is counted once
+ *   (amrex's owner mask).  sum_sq / max_abs: host pointers, either may be null.
+ * wxa_reduce_particles: over the live particles of p (retired slots skipped), out[0] = sum w Ekin with
+ *   Ekin = m u^2 / (1 + gamma) (Algorithms::KineticEnergy, Source/Particles/Algorithms/KineticEnergy.H:33-47) or
+ *   m_e c |u| for photon != 0 (:59-67), out[1] = sum w, out[2..4] = sum w m u_{x,y,z} (ParticleMomentum.cpp:143-156;
+ *   m = m_e for photons), out[5] = number of live particles (ParticleNumber.cpp:97-139).  Host pointer.
+ * Both are two-pass block reductions in a fixed order: the same input gives the same bits.  They block on the stream. */
+wxa_status wxa_reduce_field(const wxa_field_view* f, const int32_t lo[3], const int32_t hi[3], double* sum_sq,
+                            double* max_abs, void* stream);
+wxa_status wxa_reduce_particles(const wxa_particle_view* p, double mass, int32_t photon, double out[6], void* stream);
+/* warpx.reduced_diags_names / <name>.type / <name>.intervals / <name>.path (MultiReducedDiags.cpp:36-83,
+ * ReducedDiags.cpp:26-72): type in {"FieldEnergy", "ParticleEnergy", "ParticleMomentum", "ParticleNumber"}; intervals in
+ * the reference's slice syntax ("5", "0:100:10", "3:7, 20:"; utils::parser::IntervalsParser); path = output directory
+ * with a trailing '/' (the reference's default is "./diags/reducedfiles/"), null or "" = nothing is written.  From then
+ * on every step whose number is in the intervals computes the row (all bricks; sums over the bricks of a run) and
+ * brick 0 appends it to <path><name>.txt in the reference's format (header line "#[0]step() [1]time(s) ...", 14
+ * digits, ReducedDiags.cpp:97-125); step 0 is written at the first wxa_sim_evolve.  Add after the species. */
+wxa_status wxa_sim_add_reduced_diag(wxa_sim* s, const char* name, const char* type, const char* intervals,
+                                    const char* path);
+/* the data columns of diagnostic `name` (everything after step and time): their number in *n, the values of the last
+ * row computed into out[capacity]; compute_now != 0 evaluates the diagnostic at the current state first (no row is
+ * written) */
+wxa_status wxa_sim_reduced_diag_data(wxa_sim* s, const char* name, int32_t compute_now, double* out, int32_t capacity,
+                                     int32_t* n);
 
 #ifdef __cplusplus
 }

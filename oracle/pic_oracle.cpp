@@ -1356,6 +1356,55 @@ void orc_particle_momentum(const wxa_particle_view* p, double mass, double out[3
     out[0] = (double)s[0]; out[1] = (double)s[1]; out[2] = (double)s[2];
 }
 
+// The reductions of the reduced diagnostics with the product's signatures (include/warpx_amd.h: wxa_reduce_field,
+// wxa_reduce_particles), so that the host layer's ReducedDiags can run on this backend and the HIP kernels can be
+// checked against it.  Plain loops in long double: FieldEnergy.cpp:81-157 (norm2 / norminf over the box the caller
+// passes), ParticleEnergy.cpp:95-200 + KineticEnergy.H:33-67, ParticleMomentum.cpp:122-253, ParticleNumber.cpp:97-139.
+int orc_reduce_field(const wxa_field_view* f, const int32_t lo[3], const int32_t hi[3], double* sum_sq, double* max_abs,
+                     void*) {
+    if (!f || !f->p || !lo || !hi) return -1;
+    const Arr a(*f);
+    long double s = 0.0L;
+    double m = 0.0;
+    for (int k = lo[2]; k < hi[2]; ++k)
+        for (int j = lo[1]; j < hi[1]; ++j)
+            for (int i = lo[0]; i < hi[0]; ++i) {
+                const double x = a(i, j, k);
+                s += (long double)x * x;
+                m = std::max(m, std::fabs(x));
+            }
+    if (sum_sq) *sum_sq = (double)s;
+    if (max_abs) *max_abs = m;
+    return 0;
+}
+
+int orc_reduce_particles(const wxa_particle_view* p, double mass, int32_t photon, double out[6], void*) {
+    if (!p || !out) return -1;
+    constexpr double inv_c2 = 1.0 / (PhysConst::c * PhysConst::c);
+    constexpr double me_c = PhysConst::m_e * PhysConst::c;
+    long double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < p->np; ++i) {
+        if (p->idcpu && p->idcpu[i] == WXA_IDCPU_RETIRED) continue;
+        const double w = p->w[i], ux = p->ux[i], uy = p->uy[i], uz = p->uz[i];
+        const double u2 = ux * ux + uy * uy + uz * uz;
+        double ekin;
+        if (photon) {
+            ekin = me_c * std::sqrt(u2);
+        } else {
+            const double gamma = std::sqrt(1.0 + u2 * inv_c2);
+            ekin = 1.0 / (1.0 + gamma) * mass * u2;
+        }
+        s[0] += (long double)w * ekin;
+        s[1] += w;
+        s[2] += (long double)w * mass * ux;
+        s[3] += (long double)w * mass * uy;
+        s[4] += (long double)w * mass * uz;
+        s[5] += 1;
+    }
+    for (int c = 0; c < 6; ++c) out[c] = (double)s[c];
+    return 0;
+}
+
 // Plotfile/checksum view: each field interpolated to cell centres
 // (Source/Diagnostics/ComputeDiagFunctors/CellCenterFunctor.cpp:20-29 ->
 // Source/ablastr/coarsen/sample.H:30-95 with cr = 1, sc = cell), then sum |Q| over the
@@ -1490,6 +1539,14 @@ struct orc_sim {
     bool btd_write_species = false;
     int btd_buffer_size = 0;
     double btd_dt_snap = 0.0;
+    // warpx.reduced_diags_names: FieldEnergy / ParticleEnergy / ParticleMomentum / ParticleNumber (rd_compute below)
+    struct ReducedDiag {
+        std::string name, type, file;
+        int start = 0, stop = 2147483647, period = 1;   // one slice "start:stop:period" (or "period")
+        std::vector<double> data;
+    };
+    std::vector<ReducedDiag> rdiags;
+    bool rdiags_started = false;
 
     wxa_grid_geom geom_for(const int ng[3]) const {
         // WarpX::LowerCorner(box.grow(ng)) = prob_lo + box.lo * dx (Source/WarpX.cpp:2851-2875)
@@ -2159,7 +2216,124 @@ int orc_sim_btd_data(orc_sim* s, int32_t i, int32_t comp, double* out) {
     return 0;
 }
 
+// Reduced diagnostics of the oracle stepper (Source/Diagnostics/ReducedDiags/): the row of one diagnostic from the
+// formulas above (orc_field_energy, orc_particle_energy, orc_particle_momentum), laid out as FieldEnergy.cpp:146-150,
+// ParticleEnergy.cpp:160-210, ParticleMomentum.cpp:175-240 and ParticleNumber.cpp:97-127 lay out m_data.
+static void rd_compute(orc_sim* s, orc_sim::ReducedDiag& rd) {
+    const int ns = (int)s->species.size();
+    constexpr double tiny = std::numeric_limits<double>::min();
+    if (rd.type == "FieldEnergy") {
+        double out[3];
+        orc_field_energy(s->Ev, s->Bv, s->dx, out);
+        rd.data.assign(out, out + 3);
+    } else if (rd.type == "ParticleEnergy") {
+        rd.data.assign((size_t)(2 * ns + 2), 0.0);
+        double Wtot = 0.0;
+        for (int i = 0; i < ns; ++i) {
+            wxa_particle_view p = s->species[i]->view();
+            const double E = orc_particle_energy(&p, s->species[i]->m);
+            long double W = 0.0L;
+            for (int64_t k = 0; k < p.np; ++k) W += p.w[k];
+            rd.data[1 + i] = E;
+            rd.data[1 + ns + 1 + i] = (double)W > tiny ? E / (double)W : 0.0;
+            rd.data[0] += E;
+            Wtot += (double)W;
+        }
+        rd.data[1 + ns] = Wtot > tiny ? rd.data[0] / Wtot : 0.0;
+    } else if (rd.type == "ParticleMomentum") {
+        rd.data.assign((size_t)(6 * ns + 6), 0.0);
+        double Wtot = 0.0;
+        for (int i = 0; i < ns; ++i) {
+            wxa_particle_view p = s->species[i]->view();
+            double P[3];
+            orc_particle_momentum(&p, s->species[i]->m, P);
+            long double W = 0.0L;
+            for (int64_t k = 0; k < p.np; ++k) W += p.w[k];
+            for (int d = 0; d < 3; ++d) {
+                rd.data[3 + 3 * i + d] = P[d];
+                rd.data[3 + 3 * ns + 3 + 3 * i + d] = (double)W > tiny ? P[d] / (double)W : 0.0;
+                rd.data[d] += P[d];
+            }
+            Wtot += (double)W;
+        }
+        for (int d = 0; d < 3; ++d) rd.data[3 + 3 * ns + d] = Wtot > tiny ? rd.data[d] / Wtot : 0.0;
+    } else {   // ParticleNumber
+        rd.data.assign((size_t)(2 * ns + 2), 0.0);
+        for (int i = 0; i < ns; ++i) {
+            wxa_particle_view p = s->species[i]->view();
+            long double W = 0.0L;
+            int64_t live = 0;
+            for (int64_t k = 0; k < p.np; ++k) {
+                if (p.idcpu && p.idcpu[k] == WXA_IDCPU_RETIRED) continue;
+                W += p.w[k];
+                ++live;
+            }
+            rd.data[1 + i] = (double)live;
+            rd.data[1 + ns + 1 + i] = (double)W;
+            rd.data[0] += (double)live;
+            rd.data[1 + ns] += (double)W;
+        }
+    }
+}
+
+// ComputeDiags(step) + WriteToFile(step) (WarpXEvolve.cpp:299-305; ReducedDiags.cpp:97-125); step = -1 before the first step
+static void rd_compute_and_write(orc_sim* s, int step) {
+    for (auto& rd : s->rdiags) {
+        const int n = step + 1;
+        if (!(rd.period > 0 && (n - rd.start) % rd.period == 0 && n >= rd.start && n <= rd.stop)) continue;
+        rd_compute(s, rd);
+        if (rd.file.empty()) continue;
+        FILE* f = std::fopen(rd.file.c_str(), "a");
+        if (!f) continue;
+        std::fprintf(f, "%d %.14e", n, s->cur_time);
+        for (double v : rd.data) std::fprintf(f, " %.14e", v);
+        std::fprintf(f, "\n");
+        std::fclose(f);
+    }
+}
+
+// one slice only ("period" or "start:stop:period"): what the oracle's own tests use
+int orc_sim_add_reduced_diag(orc_sim* s, const char* name, const char* type, const char* intervals, const char* path) {
+    if (!s || !name || !type) return -1;
+    const std::string t = type;
+    if (t != "FieldEnergy" && t != "ParticleEnergy" && t != "ParticleMomentum" && t != "ParticleNumber") return -2;
+    orc_sim::ReducedDiag rd;
+    rd.name = name;
+    rd.type = t;
+    if (intervals && *intervals) {
+        int a = 0, b = 0, c = 0;
+        if (std::strchr(intervals, ',')) return -3;
+        if (std::sscanf(intervals, "%d:%d:%d", &a, &b, &c) == 3) { rd.start = a; rd.stop = b; rd.period = c; }
+        else if (!std::strchr(intervals, ':') && std::sscanf(intervals, "%d", &a) == 1) rd.period = a;
+        else return -3;
+    }
+    if (path && *path) {   // the directory must exist (the host layer creates it; the oracle is a checker)
+        rd.file = std::string(path) + rd.name + ".txt";
+        FILE* f = std::fopen(rd.file.c_str(), "w");
+        if (!f) return -4;
+        std::fclose(f);   // rows only: the header row is the host layer's business
+    }
+    s->rdiags.push_back(std::move(rd));
+    return 0;
+}
+
+int orc_sim_reduced_diag_data(orc_sim* s, const char* name, int32_t compute_now, double* out, int32_t capacity, int32_t* n) {
+    if (!s || !name || !n) return -1;
+    for (auto& rd : s->rdiags)
+        if (rd.name == name) {
+            if (compute_now) rd_compute(s, rd);
+            *n = (int32_t)rd.data.size();
+            for (int32_t i = 0; i < std::min(*n, capacity); ++i) out[i] = rd.data[(size_t)i];
+            return 0;
+        }
+    return -2;
+}
+
 int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
+    if (!s->rdiags_started) {   // WarpXInitData.cpp:612-619
+        s->rdiags_started = true;
+        rd_compute_and_write(s, (int)s->istep - 1);
+    }
     for (int32_t step = 0; step < numsteps; ++step) {
         // ExplicitFillBoundaryEBUpdateAux (:473-531)
         if (s->is_synchronized) {
@@ -2232,7 +2406,8 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
                 orc_enforce_periodic(&p, s->plo, s->phi, s->periodic, nullptr);
             }
         }
-        if (!s->btd.empty()) btd_compute_and_pack(s);   // WarpXEvolve.cpp:300-304 multi_diags->FilterComputePackFlush(step)
+        rd_compute_and_write(s, (int)s->istep - 1);     // WarpXEvolve.cpp:299-305
+        if (!s->btd.empty()) btd_compute_and_pack(s);   // WarpXEvolve.cpp:306 multi_diags->FilterComputePackFlush(step)
     }
     return 0;
 }

@@ -27,6 +27,8 @@ int orc_deposit_current(const wxa_particle_view*, const wxa_field_view*, const w
 int orc_filter_bilinear(const wxa_field_view*, const wxa_field_view*, void*);
 int orc_btd_select_particles(const wxa_particle_view*, const double* const[6], double, double, double, double, double, double,
                              double*, int64_t, int64_t*, void*);
+int orc_reduce_field(const wxa_field_view*, const int32_t*, const int32_t*, double*, double*, void*);
+int orc_reduce_particles(const wxa_particle_view*, double, int32_t, double*, void*);
 int orc_filter_stencil(const wxa_field_view*, const wxa_field_view*, const double*, int32_t, const double*, int32_t,
                        const double*, int32_t, void*);
 int orc_fill_boundary_periodic(const wxa_field_view*, const int*, const int*, void*);
@@ -139,6 +141,8 @@ const Backend* cpu_backend() {
         b.filter_bilinear = orc_filter_bilinear;
         b.filter_stencil = orc_filter_stencil;
         b.btd_select_particles = orc_btd_select_particles;
+        b.reduce_field = orc_reduce_field;
+        b.reduce_particles = orc_reduce_particles;
         b.fill_boundary_periodic = orc_fill_boundary_periodic;
         b.sync_nodal_periodic = orc_sync_nodal_periodic;
         b.sum_boundary_periodic = orc_sum_boundary_periodic;

@@ -48,7 +48,7 @@ def test_kernel_tests_with_guard_pages_and_fma_contraction():
 
 def test_short_step_parity_on_the_cpu_execution_model():
     """The whole product schedule (host layer + HIP kernels) against the oracle stepper: order 1 and 3."""
-    _run(["tests/test_step_gpu.py", "-k", "test_uniform_plasma_parity"])
+    _run(["tests/test_step_gpu.py", "-k", "test_uniform_plasma_parity or test_reduced_diags_on_the_device"])
 
 
 def test_gpu_only_modules_bind_every_global_they_read():

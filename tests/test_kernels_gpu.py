@@ -1474,3 +1474,82 @@ def test_higuera_cary_push_with_external_fields(oracle, product, order, sort, pu
                         pusher, None)
     _sync(product)
     product.workspace_destroy(ws)
+
+
+@pytest.mark.parametrize("name,box", [("Ex", "owned"), ("Bz", "owned"), ("rho", "valid"), ("jy", "all")])
+def test_reduce_field(oracle, product, name, box):
+    """wxa_reduce_field (FieldEnergy.cpp:81-157: MultiFab::norm2 / norminf of one component) against the oracle's
+    long-double loop and numpy on the same box: the points a brick owns (valid minus the duplicated high node), the
+    valid points, the whole allocation.  More points than one pass of 1024 workgroups x 256 lanes covers at once."""
+    ncell = (72, 64, 60)
+    ng = 3
+    f = H.random_fields((name,), ncell, ng, 41, scale=3.0e9)[0]
+    fd = f.copy_to(DEV, pad=True)
+    v = f.view
+    if box == "all":
+        lo = [v.lo[d] for d in range(3)]
+        hi = [v.lo[d] + v.n[d] for d in range(3)]
+    else:
+        lo = [v.lo[d] + v.ng[d] for d in range(3)]
+        hi = [v.lo[d] + v.n[d] - v.ng[d] - (v.stag[d] if box == "owned" else 0) for d in range(3)]
+    assert (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]) > 1024 * 256
+    a = f.to_numpy()   # [i][j][k], guards included
+    sl = tuple(slice(lo[d] - v.lo[d], hi[d] - v.lo[d]) for d in range(3))
+    x = a[sl].astype(np.longdouble)
+    ref_s, ref_m = float(np.sum(x * x)), float(np.max(np.abs(a[sl])))
+    lo32, hi32 = (C.c_int32 * 3)(*lo), (C.c_int32 * 3)(*hi)
+    res = {}
+    for lib, arr in ((oracle, f), (product, fd)):
+        s, m = C.c_double(), C.c_double()
+        lib.reduce_field(C.byref(arr.view), lo32, hi32, C.byref(s), C.byref(m), None)
+        res[lib.prefix] = (s.value, m.value)
+        assert abs(s.value - ref_s) <= 1e-13 * ref_s, (lib.prefix, s.value, ref_s)
+        assert m.value == ref_m, lib.prefix
+    # the same input gives the same bits (two passes in a fixed order, no atomics)
+    s2 = C.c_double()
+    product.reduce_field(C.byref(fd.view), lo32, hi32, C.byref(s2), None, None)
+    assert s2.value == res[product.prefix][0]
+    # an empty box, and a box that leaves the array
+    hi0 = (C.c_int32 * 3)(lo[0], hi[1], hi[2])
+    product.reduce_field(C.byref(fd.view), lo32, hi0, C.byref(s2), None, None)
+    assert s2.value == 0.0
+    bad = (C.c_int32 * 3)(hi[0] + 100, hi[1], hi[2])
+    with pytest.raises(_capi.WxaError):
+        product.reduce_field(C.byref(fd.view), lo32, bad, C.byref(s2), None, None)
+
+
+@pytest.mark.parametrize("n,photon", [(300_000, 0), (777, 0), (50_000, 1), (0, 0)])
+def test_reduce_particles(oracle, product, n, photon):
+    """wxa_reduce_particles (ParticleEnergy.cpp:95-200 with KineticEnergy.H:33-67, ParticleMomentum.cpp:122-253,
+    ParticleNumber.cpp:97-139) against the oracle and numpy: sum w Ekin, sum w, sum w m u, number of live particles; a
+    tenth of the slots retired (weight and momentum zeroed, idcpu = WXA_IDCPU_RETIRED) as Redistribute leaves them."""
+    rng = np.random.default_rng(5)
+    parts = H.random_particles(n, NCELL, 77, u_scale=1.5)
+    ids = np.zeros(n, dtype=np.uint64)
+    retired = rng.random(n) < 0.1
+    ids[retired] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for c in (3, 4, 5, 6):
+        parts[c] = np.where(retired, 0.0, parts[c])
+    m = plasma.M_E * 3.0
+    ph = ParticleArrays.from_numpy(parts, "cpu", idcpu=ids)
+    pd = ParticleArrays.from_numpy(parts, DEV, idcpu=ids.view(np.int64))
+    w, ux, uy, uz = (np.asarray(parts[c], dtype=np.longdouble) for c in (3, 4, 5, 6))
+    u2 = ux * ux + uy * uy + uz * uz
+    if photon:
+        ekin = np.longdouble(plasma.M_E * plasma.C_LIGHT) * np.sqrt(u2)
+    else:
+        ekin = m * u2 / (1.0 + np.sqrt(1.0 + u2 / np.longdouble(plasma.C_LIGHT) ** 2))
+    ref = [float(np.sum(w * ekin)), float(np.sum(w)), float(np.sum(w * m * ux)), float(np.sum(w * m * uy)),
+           float(np.sum(w * m * uz)), float(n - np.count_nonzero(retired))]
+    scale = [ref[0], ref[1]] + [float(np.sum(w * m * np.abs(c))) for c in (ux, uy, uz)] + [1.0]
+    got = {}
+    for lib, arr in ((oracle, ph), (product, pd)):
+        out = (C.c_double * 6)()
+        lib.reduce_particles(C.byref(arr.view), m, photon, out, None)
+        got[lib.prefix] = list(out)
+        for c in range(6):
+            assert abs(out[c] - ref[c]) <= 1e-13 * max(scale[c], 1e-300), (lib.prefix, c, out[c], ref[c])
+        assert out[5] == ref[5]
+    out2 = (C.c_double * 6)()
+    product.reduce_particles(C.byref(pd.view), m, photon, out2, None)
+    assert list(out2) == got[product.prefix]

@@ -659,3 +659,45 @@ def test_plotfile_from_the_hip_path(product, tmp_path):
     got = checksum_of(read_plotfile(plt))
     gold_cs = {g: {k: v for k, v in vals.items() if k != "part_per_cell"} for g, vals in gold["checksums"].items()}
     compare_with_golden(got, gold_cs, gold["rtol"])
+
+
+def test_reduced_diags_on_the_device(oracle, product, tmp_path):
+    """The parity gate's own quantities from the device: FieldEnergy / ParticleEnergy / ParticleMomentum / ParticleNumber
+    of the host layer (wxa_reduce_field, wxa_reduce_particles; ReducedDiags.hpp) over a two-species run on the HIP path --
+    every row of the files against the rows the oracle stepper writes with its own formulas, and the last row against
+    numpy on the arrays copied back (what every other test of this module compares)."""
+    n_cell = (32, 24, 24)
+    L = 40e-6
+    a = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (1, 1, 2), 1e25, 0.02, seed=21)
+    b = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (2, 1, 1), 1e25, 0.001, seed=22)
+    b[6] = b[6] + 0.02 * plasma.C_LIGHT
+    species = [(-plasma.Q_E, plasma.M_E, a), (plasma.Q_E, 1836.0 * plasma.M_E, b)]
+    rows = {}
+    for lib, sub in ((product, "hip"), (oracle, "oracle")):
+        path = str(tmp_path / sub) + "/"
+        os.makedirs(path, exist_ok=True)
+        sim = WarpXSim(lib, n_cell, (-L / 2,) * 3, (L / 2,) * 3, nox=3, use_filter=1, sort_interval=3)
+        ids = [sim.add_species(q, m, parts) for q, m, parts in species]
+        for name, kind in (("EF", "FieldEnergy"), ("EP", "ParticleEnergy"), ("PP", "ParticleMomentum"), ("NP", "ParticleNumber")):
+            sim.add_reduced_diag(name, kind, "2", path)
+        sim.evolve(8)
+        rows[sub] = {n: np.atleast_2d(np.genfromtxt(path + n + ".txt")) for n in ("EF", "EP", "PP", "NP")}
+        if lib is product:
+            ee, eb = field_energy(sim)
+            mom = [particle_moments(sim, i) for i in ids]
+            assert np.allclose(rows[sub]["EF"][-1, 2:], [ee + eb, ee, eb], rtol=1e-12)
+            assert np.allclose(rows[sub]["EP"][-1, 3:5], [m["ekin"] for m in mom], rtol=1e-12)
+            assert np.isclose(rows[sub]["PP"][-1, 10], mom[1]["momentum"][2], rtol=1e-12)
+            assert list(rows[sub]["NP"][-1, 3:5]) == [a[0].size, b[0].size]
+        sim.close()
+    for n in ("EF", "EP", "PP", "NP"):
+        x, y = rows["hip"][n], rows["oracle"][n]
+        assert x.shape == y.shape and np.array_equal(x[:, :2], y[:, :2]), n
+        assert list(x[:, 0]) == [0, 2, 4, 6, 8]
+        scale = np.max(np.abs(y[:, 2:]), axis=0)
+        if n == "PP":   # thermal sums of +- terms: against the largest component of their group (sums | means)
+            for g in (slice(0, 9), slice(9, 18)):
+                scale[g] = np.maximum(scale[g], 1e-4 * np.max(scale[g]))
+        worst = np.max(np.abs(x[:, 2:] - y[:, 2:]) / np.maximum(scale, 1e-300))
+        print(f"{n}: worst relative deviation {worst:.2e}")
+        assert worst <= RTOL, n

@@ -167,6 +167,8 @@ _KERNEL_SIGS = {
     "deposit_charge": (C.c_int, [_PPV, _PFV, _PGG, C.c_double, C.c_int, C.c_void_p]),
     "btd_select_particles": (C.c_int, [_PPV, C.POINTER(C.c_void_p), C.c_double, C.c_double, C.c_double, C.c_double,
                                        C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "reduce_field": (C.c_int, [_PFV, _I32_3, _I32_3, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
+    "reduce_particles": (C.c_int, [_PPV, C.c_double, C.c_int32, C.c_double * 6, C.c_void_p]),
     "enforce_periodic": (C.c_int, [_PPV, _D3, _D3, _I3, C.c_void_p]),
     "apply_pec_e": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
     "apply_pec_b": (C.c_int, [_FV3, _I32_3, _I32_3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
@@ -236,6 +238,9 @@ _SIM_SIGS = {
     "sim_btd_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sim_btd_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "sim_add_reduced_diag": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "sim_reduced_diag_data": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_int32,
+                                       C.POINTER(C.c_int32)]),
 }
 
 # product-only entry points

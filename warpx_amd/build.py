@@ -35,6 +35,7 @@ SOURCES = [
     ("gather_tile.hip", []),
     ("host/warpx_host.hip", []),
     ("host/btd_kernels.hip", []),
+    ("host/reduced_kernels.hip", []),
     ("rccl_comm.hip", []),
 ]
 

@@ -9,6 +9,7 @@
 
 #include "BTDiagnostics.hpp"
 #include "NCIGodfreyFilter.hpp"
+#include "ReducedDiags.hpp"
 #include "WarpXParticleContainer.hpp"
 
 namespace wxa::host {
@@ -268,6 +269,10 @@ public:
     // Source/Evolve/WarpXEvolve.cpp:94-347
     void Evolve(int numsteps) {
         const int numsteps_max = numsteps;
+        if (!m_reduced_diags_started) {   // WarpX::InitData (WarpXInitData.cpp:612-619): the row before the first iteration
+            m_reduced_diags_started = true;
+            reduced_diags.ComputeAndWrite(*this, (int)istep - 1);
+        }
         for (int step = 0; step < numsteps_max; ++step) {
             // :142-145 if synchronized, push velocity backward one half step
             ExplicitFillBoundaryEBUpdateAux();
@@ -284,7 +289,8 @@ public:
             const bool move_j = is_synchronized;
             const int num_moved = MoveWindow(istep, move_j);     // :246 MoveWindow(step+1, move_j)
             HandleParticlesAtBoundaries(step, cur_time, num_moved);  // :256
-            if (m_btd) m_btd->ComputeAndPack(*this);             // :300-304 multi_diags->FilterComputePackFlush(step)
+            reduced_diags.ComputeAndWrite(*this, (int)istep - 1);   // :299-305 reduced_diags->ComputeDiags(step), WriteToFile(step)
+            if (m_btd) m_btd->ComputeAndPack(*this);             // :306 multi_diags->FilterComputePackFlush(step)
         }
         m_be->stream_sync(m_ctx.stream);
     }
@@ -305,6 +311,21 @@ public:
         for (int i = 0; i < mypc->nSpecies(); ++i) mypc->GetParticleContainer(i).btd_species_id = i;
     }
     BTDiagnostics* btd() const { return m_btd.get(); }
+
+    // warpx.reduced_diags_names (ReducedDiags.hpp): FieldEnergy, ParticleEnergy, ParticleMomentum, ParticleNumber
+    MultiReducedDiags reduced_diags;
+    // The points of component f that this brick owns in a sum over the domain -- amrex's owner mask, as
+    // MultiFab::norm2(0, periodicity) applies it (FieldEnergy.cpp:127-135): a nodal point on the face between two bricks,
+    // or on the two ends of a periodic direction, is counted by the brick below it; the last node of a direction with
+    // walls belongs to the topmost brick.  Index box [lo, hi).
+    void owned_points(const wxa_field_view& f, int32_t lo[3], int32_t hi[3]) const {
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = f.lo[d] + f.ng[d];
+            hi[d] = f.lo[d] + f.n[d] - f.ng[d];
+            const bool top_wall = !m_comm->periodic(d) && m_comm->coord()[d] == m_comm->nbricks()[d] - 1;
+            if (f.stag[d] && !top_wall) hi[d] -= 1;
+        }
+    }
     amrex::Real getdt() const { return dt[0]; }
     void sync_stream() { m_be->stream_sync(m_ctx.stream); }
 
@@ -722,6 +743,7 @@ private:
     std::unique_ptr<amrex::MultiFab> m_rho, m_rho_tmp;   // ComputeRho (diagnostics)
     std::unique_ptr<BTDiagnostics> m_btd;
     bool m_btd_write_species = false;
+    bool m_reduced_diags_started = false;
     // field-solve exchanges: guard layer of B computed redundantly; J's guard sum on a second stream
     bool m_grown_b = false, m_overlap = false;
     void* m_comm_stream = nullptr;

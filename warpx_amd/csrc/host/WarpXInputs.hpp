@@ -731,6 +731,26 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
             wx.btd()->SetFlush(prefix, digits);
         }
     }
+    // warpx.reduced_diags_names (MultiReducedDiags.cpp:36-83, ReducedDiags.cpp:26-72): the four types of ReducedDiags.hpp
+    // are produced; the others (probes, histograms, load-balance costs ...) are output this library does not write
+    for (const std::string& d : rdiag_names) {
+        std::string type;
+        if (!pp.query(d + ".type", type)) throw std::runtime_error("inputs: " + d + ".type must be set");
+        if (!MultiReducedDiags::known_type(type)) continue;
+        if (pp.contains(d + ".frequency"))   // ReducedDiags::BackwardCompatibility
+            throw std::runtime_error("inputs: " + d + ".frequency is no longer a valid option. Please use the renamed option " +
+                                     d + ".intervals instead.");
+        std::vector<std::string> iv{"1"};
+        pp.queryarr(d + ".intervals", iv);   // getarr in the reference: the default is never used there
+        std::string intervals;
+        for (const std::string& e : iv) intervals += e;   // IntervalsParser concatenates the words (.cpp:86-87)
+        std::string path = "./diags/reducedfiles/";
+        pp.query(d + ".path", path);
+        for (const char* fixed : {".extension", ".separator", ".precision"})
+            if (pp.contains(d + fixed)) throw std::runtime_error("inputs: " + d + fixed + " is not on this path (txt, ' ', 14)");
+        wx.reduced_diags.Add(d, type, intervals, path.c_str());
+    }
+    wx.reduced_diags.SetSpeciesNames(info.species_names);
     for (const std::string& d : diag_names) pp.ignore_prefix(d + ".");
     for (const std::string& d : rdiag_names) pp.ignore_prefix(d + ".");
     pp.ignore_prefix("diagnostics.");

@@ -73,6 +73,10 @@ struct Backend {
     int (*btd_select_particles)(const wxa_particle_view*, const double* const old6[6], double z_boost, double z_boost_old,
                                 double t_boost, double dt, double t_lab, double gamma_boost, double* out, int64_t capacity,
                                 int64_t* n_selected, void* stream) = nullptr;
+    // the reductions of the reduced diagnostics (wxa_reduce_field, wxa_reduce_particles); optional
+    int (*reduce_field)(const wxa_field_view*, const int32_t* lo, const int32_t* hi, double* sum_sq, double* max_abs,
+                        void* stream) = nullptr;
+    int (*reduce_particles)(const wxa_particle_view*, double mass, int32_t photon, double* out6, void* stream) = nullptr;
     int (*filter_stencil)(const wxa_field_view*, const wxa_field_view*, const double* s0, int32_t n0, const double* s1,
                           int32_t n1, const double* s2, int32_t n2, void*) = nullptr;
     int (*fill_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);

@@ -235,6 +235,32 @@ inline int sim_btd_particles(SimHandle* h, int32_t i, int32_t id, double* out) {
     return WXA_OK;
 }
 
+// warpx.reduced_diags_names (ReducedDiags.hpp)
+inline int sim_add_reduced_diag(SimHandle* h, const char* name, const char* type, const char* intervals, const char* path) {
+    if (!h || !name || !*name || !type) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->reduced_diags.Add(name, type, intervals ? intervals : "", path);
+        h->warpx->reduced_diags.SetSpeciesNames(h->species_names);
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+inline int sim_reduced_diag_data(SimHandle* h, const char* name, int32_t compute_now, double* out, int32_t capacity,
+                                 int32_t* n) {
+    if (!h || !name || !n || capacity < 0 || (capacity > 0 && !out)) return WXA_ERR_INVALID_ARG;
+    try {
+        const std::vector<double>& d = h->warpx->reduced_diags.Data(*h->warpx, name, compute_now != 0);
+        *n = (int32_t)d.size();
+        for (int32_t i = 0; i < std::min(*n, capacity); ++i) out[i] = d[(size_t)i];
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_INVALID_ARG;
+    }
+}
+
 inline int sim_get_particles(SimHandle* h, int32_t id, wxa_particle_view* out) {
     if (!h || !out || id < 0 || id >= h->warpx->GetPartContainer().nSpecies()) return WXA_ERR_INVALID_ARG;
     *out = h->warpx->GetPartContainer().GetParticleContainer(id).tile().view();
@@ -332,6 +358,20 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     }                                                                                                  \
     RET PFX##sim_btd_particles(SIMTYPE* s, int32_t i, int32_t id, double* out) {                       \
         return (RET)wxa::host::sim_btd_particles(reinterpret_cast<wxa::host::SimHandle*>(s), i, id, out); \
+    }                                                                                                  \
+    RET PFX##sim_add_reduced_diag(SIMTYPE* s, const char* name, const char* type, const char* intervals, \
+                                  const char* path) {                                                  \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        int rc = wxa::host::sim_add_reduced_diag(h, name, type, intervals, path);                      \
+        if (rc != 0 && h) SET_ERROR(h->error.c_str());                                                 \
+        return (RET)rc;                                                                                \
+    }                                                                                                  \
+    RET PFX##sim_reduced_diag_data(SIMTYPE* s, const char* name, int32_t compute_now, double* out,     \
+                                   int32_t capacity, int32_t* n) {                                     \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        int rc = wxa::host::sim_reduced_diag_data(h, name, compute_now, out, capacity, n);             \
+        if (rc != 0 && h) SET_ERROR(h->error.c_str());                                                 \
+        return (RET)rc;                                                                                \
     }                                                                                                  \
     RET PFX##sim_get_particles(SIMTYPE* s, int32_t id, wxa_particle_view* out) {                       \
         return (RET)wxa::host::sim_get_particles(reinterpret_cast<wxa::host::SimHandle*>(s), id, out);      \

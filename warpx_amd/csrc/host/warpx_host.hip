@@ -103,6 +103,10 @@ const Backend* hip_backend() {
         b.btd_select_particles = [](const wxa_particle_view* p, const double* const o[6], double zb, double zbo, double tb,
                                     double dt, double tl, double g, double* out, int64_t cap, int64_t* n, void* st) -> int {
             return wxa_btd_select_particles(p, o, zb, zbo, tb, dt, tl, g, out, cap, n, st); };
+        b.reduce_field = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, double* ss, double* mx,
+                            void* st) -> int { return wxa_reduce_field(f, lo, hi, ss, mx, st); };
+        b.reduce_particles = [](const wxa_particle_view* p, double m, int32_t photon, double* out, void* st) -> int {
+            return wxa_reduce_particles(p, m, photon, out, st); };
         b.filter_stencil = [](const wxa_field_view* s, const wxa_field_view* d, const double* s0, int32_t n0,
                               const double* s1, int32_t n1, const double* s2, int32_t n2, void* st) -> int {
             return wxa_filter_stencil(s, d, s0, n0, s1, n1, s2, n2, st); };

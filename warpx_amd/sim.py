@@ -137,6 +137,22 @@ class WarpXSim:
         """Lab-frame snapshot i as an AMReX plotfile (wxa_sim_btd_write_plotfile)."""
         self.lib.sim_btd_write_plotfile(self._h, int(i), str(path).encode())
 
+    def add_reduced_diag(self, name: str, rd_type: str, intervals: str = "1", path: str | None = None):
+        """warpx.reduced_diags_names += name (wxa_sim_add_reduced_diag): rd_type in FieldEnergy, ParticleEnergy,
+        ParticleMomentum, ParticleNumber; rows go to <path><name>.txt (path ends with '/'; None: kept in memory only)."""
+        self.lib.sim_add_reduced_diag(self._h, name.encode(), rd_type.encode(), str(intervals).encode(),
+                                      None if path is None else str(path).encode())
+
+    def reduced_diag(self, name: str, compute_now: bool = False) -> np.ndarray:
+        """The data columns (after step and time) of the last row of diagnostic `name`; compute_now: of the current state."""
+        n = C.c_int32()
+        self.lib.sim_reduced_diag_data(self._h, name.encode(), 1 if compute_now else 0, None, 0, C.byref(n))
+        out = np.zeros(n.value, dtype=np.float64)
+        if n.value:
+            self.lib.sim_reduced_diag_data(self._h, name.encode(), 0, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                           n.value, C.byref(n))
+        return out
+
     def checksum(self) -> dict:
         """The reference's regression checksum of the current state (wxa_sim_checksum_json), this brick's share."""
         import json
