@@ -690,12 +690,14 @@ const char* wxa_sim_species_name(const wxa_sim* s, int32_t id); /* particles.spe
  * text: "lev=0" sums of |cell-centred field| for E, B, j, rho and per species sums of |x|, |m u|, w
  * (this brick's share).  Returns the text length (buf may be NULL to ask for it) or < 0. */
 int64_t     wxa_sim_checksum_json(wxa_sim* s, char* buf, int64_t capacity);
-/* FlushFormatPlotfile::WriteToFile (Source/Diagnostics/FlushFormats/FlushFormatPlotfile.cpp:61-113) for this brick: an
- * AMReX plotfile directory `dir` -- Header, Level_0/Cell_H + Cell_D_00000 with Ex..Bz, jx..jz, rho averaged to the cell
- * centres, <species>/Header + Level_0/Particle_H + DATA_00000 with x y z weight momentum_x/y/z (SI), WarpXHeader,
- * warpx_job_info -- in the text / binary layouts of AMReX as the reference restates them in
+/* FlushFormatPlotfile::WriteToFile (Source/Diagnostics/FlushFormats/FlushFormatPlotfile.cpp:61-113): an AMReX plotfile
+ * directory `dir` -- Header, Level_0/Cell_H + Cell_D_<brick> with Ex..Bz, jx..jz, rho averaged to the cell centres,
+ * <species>/Header + Level_0/Particle_H + DATA_<brick> with x y z weight momentum_x/y/z (SI) of the live particles,
+ * WarpXHeader, warpx_job_info -- in the text / binary layouts of AMReX as the reference restates them in
  * Source/Diagnostics/BTD_Plotfile_Header_Impl.cpp; what Regression/Checksum/checksum.py (yt) and
- * Tools/PostProcessing/read_raw_data.py read. */
+ * Tools/PostProcessing/read_raw_data.py read.  Collective over the bricks of a run, like a parallel
+ * amrex::WriteMultiLevelPlotfile: every brick calls it with the same `dir` (one file system) and writes its own grid,
+ * brick 0 writes the headers that list all of them; nobody returns before the plotfile is complete. */
 wxa_status  wxa_sim_write_plotfile(wxa_sim* s, const char* dir);
 /* Lab-frame snapshot i of wxa_sim_add_btd as a plotfile (fields and the back-transformed particles of every species;
  * geometry and time of the lab frame): what the reference's BTD flushes hold once merged

@@ -37,6 +37,9 @@ def main():
                                    comm=transport.comm)
     # WXA_TEST_MAX_STEP: a shorter run for brick-against-one-brick comparisons (both sides stop at the same step)
     sim.evolve(min(sim.max_step, int(os.environ.get("WXA_TEST_MAX_STEP", sim.max_step))))
+    # WXA_TEST_PLOTFILE: one plotfile for all bricks (a collective call: every brick writes its grid, brick 0 the headers)
+    if os.environ.get("WXA_TEST_PLOTFILE"):
+        sim.write_plotfile(os.environ["WXA_TEST_PLOTFILE"])
     gathered = [None] * world
     dist.gather_object(sim.checksum(), gathered if rank == 0 else None, dst=0)
     if rank == 0:

@@ -169,7 +169,9 @@ def test_guard_layer_update_equals_the_guard_exchange(product, nb, monkeypatch):
         assert abs(a["ekin"] - b["ekin"]) <= (1e-12 if H.ON_GPU else 0.0) * b["ekin"]
 
 
-def run_bricks(product, nb, order, filt, overlap, n_cell, steps):
+def run_bricks(product, nb, order, filt, overlap, n_cell, steps, before=None, after=None):
+    """before(sim, rank) / after(sim, rank): called on every brick before the first step and after the last one (collective
+    output calls such as the plotfile go here: all bricks make them, in the same order)."""
     nranks = nb[0] * nb[1] * nb[2]
     prob_lo, prob_hi = (-L / 2,) * 3, (L / 2,) * 3
     # hot plasma: particles cross brick faces (and tile boundaries) within a few steps
@@ -193,7 +195,11 @@ def run_bricks(product, nb, order, filt, overlap, n_cell, steps):
                            nbricks=nb, coord=coord, comm=tr.comm, overlap_halo=overlap)
             assert sim.halo_overlap == bool(overlap)
             sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
+            if before:
+                before(sim, rank)
             sim.evolve(steps)
+            if after:
+                after(sim, rank)
             p = sim.particles(sid)
             mom = particle_moments(sim, sid)
             results[rank] = {
@@ -217,6 +223,61 @@ def run_bricks(product, nb, order, filt, overlap, n_cell, steps):
     assert all(r is not None for r in results)
 
     return results, parts, bn
+
+
+@pytest.mark.parametrize("nb", [(1, 1, 2), (2, 2, 1)])
+def test_one_plotfile_and_reduced_diags_for_all_bricks(oracle, product, nb, tmp_path):
+    """The output side of a multi-brick run on the HIP path: every brick writes its FAB and its particles into ONE plotfile
+    (brick 0 the headers: wxa_sim_write_plotfile), and brick 0 writes the reduced-diagnostics rows summed over the bricks
+    (device reductions + ReduceRealSum).  The plotfile, read back with the strict reader of tests/test_plotfile_cpu.py,
+    holds the single-domain oracle's cell-centred fields and every particle once; the rows equal the oracle stepper's."""
+    from tests.test_plotfile_cpu import read_plotfile
+    n_cell, steps, order, filt = (32, 32, 32), 5, 3, 1
+    plt = str(tmp_path / "plt")
+    rd_path = str(tmp_path / "reduced") + "/"
+
+    def before(sim, rank):
+        for name, kind in (("EF", "FieldEnergy"), ("EP", "ParticleEnergy"), ("NP", "ParticleNumber")):
+            sim.add_reduced_diag(name, kind, "1", rd_path)
+
+    def after(sim, rank):
+        sim.write_plotfile(plt)
+
+    results, parts, bn = run_bricks(product, nb, order, filt, 0, n_cell, steps, before=before, after=after)
+    pf = read_plotfile(plt)
+    prob_lo, prob_hi = (-L / 2,) * 3, (L / 2,) * 3
+    ref = WarpXSim(oracle, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt)
+    rid = ref.add_species(-plasma.Q_E, plasma.M_E, list(parts))
+    os.makedirs(str(tmp_path / "oracle"), exist_ok=True)
+    for name, kind in (("EF", "FieldEnergy"), ("EP", "ParticleEnergy"), ("NP", "ParticleNumber")):
+        ref.add_reduced_diag(name, kind, "1", str(tmp_path / "oracle") + "/")
+    ref.evolve(steps)
+    ref.compute_rho()
+    assert pf["step"] == steps and len(open(os.path.join(plt, "Level_0", "Cell_H")).read().split("FabOnDisk:")) == 1 + nb[0] * nb[1] * nb[2]
+    for n in FIELDS + ("rho",):
+        full = ref.field(n)                       # with guards, staggered: average to the cell centres like the writer
+        v = ref.field_view(n)
+        g, st = tuple(v.ng), tuple(v.stag)
+        a = full[g[0]:full.shape[0] - g[0], g[1]:full.shape[1] - g[1], g[2]:full.shape[2] - g[2]]
+        for d in range(3):
+            if st[d]:
+                lo = [slice(None)] * 3
+                hi = [slice(None)] * 3
+                lo[d], hi[d] = slice(0, -1), slice(1, None)
+                a = 0.5 * (a[tuple(lo)] + a[tuple(hi)])
+        assert a.shape == pf["fields"][n].shape == n_cell, n
+        assert float(np.max(np.abs(pf["fields"][n] - a)) / max(np.max(np.abs(a)), 1e-300)) < 1e-10, n
+    sp = pf["species"]["species0"]
+    assert sp["particle_weight"].size == parts.shape[1] and np.all(sp["particle_weight"] > 0.0)
+    rp = ref.particles(rid)
+    for k, row, fac in (("particle_position_x", 0, 1.0), ("particle_position_z", 2, 1.0), ("particle_momentum_y", 5, plasma.M_E)):
+        assert abs(np.sum(np.abs(sp[k])) - fac * np.sum(np.abs(rp[row]))) <= 1e-11 * fac * np.sum(np.abs(rp[row])), k
+    for name in ("EF", "EP", "NP"):
+        a = np.atleast_2d(np.genfromtxt(rd_path + name + ".txt"))
+        b = np.atleast_2d(np.genfromtxt(str(tmp_path / "oracle") + "/" + name + ".txt"))
+        assert a.shape == b.shape and a.shape[0] == steps + 1, name
+        scale = np.maximum(np.max(np.abs(b[:, 2:]), axis=0), 1e-300)
+        assert np.max(np.abs(a[:, 2:] - b[:, 2:]) / scale) < 1e-10, name
 
 
 @pytest.mark.skipif(not H.ON_GPU, reason="RCCL needs a GPU (the CPU execution model has no transport of its own)")

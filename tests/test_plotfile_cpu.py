@@ -9,6 +9,8 @@ import importlib.util
 import json
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -162,3 +164,30 @@ def test_the_reference_reader_opens_the_field_data(lib, tmp_path):  # noqa: F811
     for n in mine["names"]:
         assert np.array_equal(theirs[n], mine["fields"][n]), n
     assert np.max(np.abs(mine["fields"]["Ex"])) > 0
+
+
+@pytest.mark.parametrize("nb,port", [((1, 2, 2), 29681)])
+def test_bricks_write_one_plotfile(tmp_path, nb, port):
+    """A run on four bricks (gloo) writes ONE plotfile, as a parallel run of the reference does: a FAB and a particle file
+    per brick, the headers by brick 0 listing every grid.  Read back, it carries the golden checksums of the deck -- the
+    loop "multi-brick output -> the reference's regression checksum" closed through files."""
+    gold = json.load(open(os.path.join(HERE, "golden", "langmuir_multi_3d_checksums.json")))
+    deck = os.path.join(DECKS, "langmuir_multi_3d.inputs")
+    plt = str(tmp_path / "plt")
+    n = nb[0] * nb[1] * nb[2]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "deck_worker.py"),
+           *[str(v) for v in nb], deck, str(tmp_path / "sum.json")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, OMP_NUM_THREADS="2", WXA_TEST_PLOTFILE=plt))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert sorted(os.listdir(os.path.join(plt, "Level_0"))) == ["Cell_D_%05d" % i for i in range(n)] + ["Cell_H"]
+    pf = read_plotfile(plt)
+    got = checksum_of(pf)
+    gold_cs = {g: {k: v for k, v in vals.items() if k != "part_per_cell"} for g, vals in gold["checksums"].items()}
+    worst = compare_with_golden(got, gold_cs, gold["rtol"])
+    print("four bricks, one plotfile -> checksum: worst relative deviation from the reference's golden file", worst)
+    direct = json.load(open(str(tmp_path / "sum.json")))   # the bricks' own checksums, added up
+    for group, vals in got.items():
+        for k, v in vals.items():
+            assert abs(v - direct[group][k]) <= 1e-12 * max(abs(direct[group][k]), 1e-300), (group, k)

@@ -14,8 +14,8 @@
 //                                    particlesConvertUnits, FlushFormatPlotfile.cpp:412-424)
 //   <dir>/WarpXHeader, <dir>/warpx_job_info   (:116-236, :238-343; text, informative)
 // Fields are averaged to the cell centres like CellCenterFunctor (ablastr/coarsen/sample.H:47-99, ratio 1).
-// Output stage, not on the step path: everything is copied to the host first.  One brick writes one plotfile
-// (its own box as the only grid); multi-brick runs write one directory per rank.
+// Output stage, not on the step path: everything is copied to the host first.  The bricks of a run write ONE plotfile
+// (one grid per brick, see write_plotfile).
 #ifndef WXA_HOST_PLOTFILE_HPP_
 #define WXA_HOST_PLOTFILE_HPP_
 
@@ -26,6 +26,7 @@
 #include <sstream>
 
 #include "PlotfileFormat.hpp"
+#include "ReducedDiags.hpp"
 #include "sim_capi.hpp"
 
 namespace wxa::host {
@@ -124,6 +125,10 @@ inline void write_btd_plotfile(SimHandle& h, int i, const std::string& dir, cons
     }
 }
 
+// One plotfile for the whole run.  Like a parallel amrex::WriteMultiLevelPlotfile every brick writes the FAB of its own
+// box (Level_0/Cell_D_<rank>) and its own particles (<species>/Level_0/DATA_<rank>) into the same directory, and brick 0
+// writes the headers that list every brick's grid (VisMF "how" = one fab per file; the per-grid extrema and particle counts
+// travel through ReduceRealSum, each brick filling its own slots).  The bricks of a run see one file system (one node).
 inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vector<std::string>& species_names) {
     using warpx::fields::FieldType;
     using ablastr::fields::Direction;
@@ -131,7 +136,11 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
     const WarpXContext& ctx = wx.context();
     const Backend* be = ctx.be;
     be->stream_sync(ctx.stream);
+    BrickComm& comm = wx.comm();
+    const int* nb = comm.nbricks();
+    const int nranks = nb[0] * nb[1] * nb[2], me = comm.rank_of(comm.coord());
     make_dir(dir);
+    make_dir(dir + "/Level_0");
 
     // ---- fields: the reference's default fields_to_plot, cell-centred
     const struct { const char* name; FieldType ft; int d; } comps[9] = {
@@ -147,45 +156,106 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
     }
     data.push_back(cell_centered(be, wx.ComputeRho(), ncell));
     names.emplace_back("rho");
-    int lo[3], hi[3];
+    const size_t ncomp = names.size();
+    // the grid of brick r: its cells in the global index space (BrickComm::rank_of's numbering)
+    auto grid_of = [&](int r, int lo[3], int hi[3]) {
+        const int c[3] = {r % nb[0], (r / nb[0]) % nb[1], r / (nb[0] * nb[1])};
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = wx.m_dom_lo[d] + c[d] * ncell[d];
+            hi[d] = lo[d] + ncell[d] - 1;
+        }
+    };
+    PlotGrid mine;
+    grid_of(me, mine.lo, mine.hi);
+    for (int d = 0; d < 3; ++d)
+        if (mine.lo[d] != ctx.brick_box.lo[d]) throw std::runtime_error("plotfile: brick numbering mismatch");
+    mine.fab_file = numbered("Cell_D_", me, 5);
+    {
+        std::vector<const double*> ptrs;
+        for (const auto& c : data) ptrs.push_back(c.data());
+        write_fab(dir, mine, ptrs);
+    }
+    std::vector<double> ext((size_t)nranks * ncomp * 2, 0.0);   // [rank][min | max][comp]
+    for (size_t c = 0; c < ncomp; ++c) {
+        ext[((size_t)me * 2 + 0) * ncomp + c] = mine.vmin[c];
+        ext[((size_t)me * 2 + 1) * ncomp + c] = mine.vmax[c];
+    }
+    ReduceRealSum(comm, be, ext, ctx.stream);   // every brick's FAB is on disk once this has returned on brick 0
     double rlo[3], rhi[3], dx[3];
     for (int d = 0; d < 3; ++d) {
-        lo[d] = ctx.brick_box.lo[d];
-        hi[d] = lo[d] + ncell[d] - 1;
         dx[d] = 1.0 / ctx.dinv[d];
-        rlo[d] = ctx.brick_plo[d];
-        rhi[d] = ctx.brick_plo[d] + ncell[d] * dx[d];
+        rlo[d] = ctx.prob_lo[d];
+        rhi[d] = ctx.prob_lo[d] + (wx.m_dom_hi[d] - wx.m_dom_lo[d] + 1) * dx[d];
     }
-    write_cell_data(dir, names, data, lo, hi, rlo, rhi, dx, wx.gett_new(), wx.getistep());
-    // ---- particles
-    for (int s = 0; s < wx.GetPartContainer().nSpecies(); ++s) {
+    if (me == 0) {
+        std::vector<PlotGrid> grids((size_t)nranks);
+        for (int r = 0; r < nranks; ++r) {
+            PlotGrid& g = grids[(size_t)r];
+            grid_of(r, g.lo, g.hi);
+            g.fab_file = numbered("Cell_D_", r, 5);
+            g.vmin.assign(ext.begin() + (std::ptrdiff_t)(((size_t)r * 2 + 0) * ncomp), ext.begin() + (std::ptrdiff_t)(((size_t)r * 2 + 1) * ncomp));
+            g.vmax.assign(ext.begin() + (std::ptrdiff_t)(((size_t)r * 2 + 1) * ncomp), ext.begin() + (std::ptrdiff_t)(((size_t)r * 2 + 2) * ncomp));
+        }
+        write_cell_headers(dir, names, grids, wx.m_dom_lo, wx.m_dom_hi, rlo, rhi, dx, wx.gett_new(), wx.getistep());
+    }
+    // ---- particles: the live ones (slots retired by Redistribute or by an absorbing wall wait for the next sort)
+    const int ns = wx.GetPartContainer().nSpecies();
+    std::vector<double> counts((size_t)nranks * (size_t)std::max(ns, 1), 0.0);
+    for (int s = 0; s < ns; ++s) {
         WarpXParticleContainer& pc = wx.GetPartContainer().GetParticleContainer(s);
         ParticleTile& t = pc.tile();
         const size_t n = (size_t)t.numParticles();
         const std::string name = s < (int)species_names.size() ? species_names[s] : "species" + std::to_string(s);
-        std::vector<double> soa(7 * n), rec(7 * n);
+        std::vector<double> soa(7 * n), rec;
+        std::vector<uint64_t> id(n);
         for (int c = 0; c < 7; ++c)
             if (n && be->memcpy_d2h(soa.data() + (size_t)c * n, t.comp(c), sizeof(double) * n) != 0)
                 throw std::runtime_error("plotfile: device copy failed");
-        for (size_t i = 0; i < n; ++i)
-            for (int c = 0; c < 7; ++c) rec[7 * i + c] = c >= 4 ? soa[(size_t)c * n + i] * pc.mass : soa[(size_t)c * n + i];
-        write_particle_data(dir, name, rec, n, lo, hi);
+        if (n && be->memcpy_d2h(id.data(), t.idcpu(), sizeof(uint64_t) * n) != 0) throw std::runtime_error("plotfile: device copy failed");
+        rec.reserve(7 * n);
+        size_t live = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (id[i] == WXA_IDCPU_RETIRED) continue;
+            for (int c = 0; c < 7; ++c) rec.push_back(c >= 4 ? soa[(size_t)c * n + i] * pc.mass : soa[(size_t)c * n + i]);
+            ++live;
+        }
+        make_dir(dir + "/" + name);
+        make_dir(dir + "/" + name + "/Level_0");
+        if (live > 0 || nranks == 1) write_particle_records(dir, name, me, rec, live);   // a grid without particles has no DATA file
+        counts[(size_t)me * (size_t)ns + (size_t)s] = (double)live;
     }
-    {   // WarpXHeader (FlushFormatPlotfile.cpp:238-343), the part readers look at
-        std::ofstream f(dir + "/WarpXHeader", std::ios::binary | std::ios::trunc);
-        f.precision(17);
-        f << "Checkpoint version: 1\n" << 1 << "\n" << wx.getistep() << " \n" << 1 << " \n" << wx.gett_new() << " \n"
-          << wx.gett_new() - wx.getdt(0) << " \n" << wx.getdt(0) << " \n" << 0.0 << "\n" << 1 << "\n";
-        for (int d = 0; d < 3; ++d) f << rlo[d] << ' ';
-        f << '\n';
-        for (int d = 0; d < 3; ++d) f << rhi[d] << ' ';
-        f << '\n';
+    ReduceRealSum(comm, be, counts, ctx.stream);
+    if (me == 0) {
+        for (int s = 0; s < ns; ++s) {
+            const std::string name = s < (int)species_names.size() ? species_names[s] : "species" + std::to_string(s);
+            std::vector<ParticleGrid> grids((size_t)nranks);
+            for (int r = 0; r < nranks; ++r) {
+                ParticleGrid& g = grids[(size_t)r];
+                grid_of(r, g.lo, g.hi);
+                g.which = r;
+                g.count = (int64_t)counts[(size_t)r * (size_t)ns + (size_t)s];
+            }
+            write_species_headers(dir, name, grids);
+        }
+        {   // WarpXHeader (FlushFormatPlotfile.cpp:238-343), the part readers look at
+            std::ofstream f(dir + "/WarpXHeader", std::ios::binary | std::ios::trunc);
+            f.precision(17);
+            f << "Checkpoint version: 1\n" << 1 << "\n" << wx.getistep() << " \n" << 1 << " \n" << wx.gett_new() << " \n"
+              << wx.gett_new() - wx.getdt(0) << " \n" << wx.getdt(0) << " \n" << 0.0 << "\n" << 1 << "\n";
+            for (int d = 0; d < 3; ++d) f << rlo[d] << ' ';
+            f << '\n';
+            for (int d = 0; d < 3; ++d) f << rhi[d] << ' ';
+            f << '\n';
+        }
+        {
+            std::ofstream f(dir + "/warpx_job_info", std::ios::trunc);
+            f << std::string(78, '=') << "\n WarpX Job Information\n" << std::string(78, '=') << "\n"
+              << "written by warpx_amd (MI355X-native hot path behind the WarpX operator surface), not by WarpX\n"
+              << "bricks: " << nb[0] << " x " << nb[1] << " x " << nb[2] << "\n";
+        }
     }
-    {
-        std::ofstream f(dir + "/warpx_job_info", std::ios::trunc);
-        f << std::string(78, '=') << "\n WarpX Job Information\n" << std::string(78, '=') << "\n"
-          << "written by warpx_amd (MI355X-native hot path behind the WarpX operator surface), not by WarpX\n";
-    }
+    std::vector<double> done(1, 1.0);   // nobody returns before brick 0 has written the headers
+    ReduceRealSum(comm, be, done, ctx.stream);
 }
 
 }  // namespace wxa::host
