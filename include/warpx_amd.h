@@ -699,6 +699,18 @@ int64_t     wxa_sim_checksum_json(wxa_sim* s, char* buf, int64_t capacity);
  * amrex::WriteMultiLevelPlotfile: every brick calls it with the same `dir` (one file system) and writes its own grid,
  * brick 0 writes the headers that list all of them; nobody returns before the plotfile is complete. */
 wxa_status  wxa_sim_write_plotfile(wxa_sim* s, const char* dir);
+/* <diag>.diag_type = Full with format = plotfile (Source/Diagnostics/FullDiagnostics.cpp:109-125, 295-303;
+ * Diagnostics.cpp:47-60, 611-625; MultiDiagnostics.cpp:83-115): from now on the step loop writes the plotfile
+ * <file_prefix><istep, file_min_digits> (wxa_sim_write_plotfile; the reference's "diags/diag1000040") after every step
+ * whose number is in `intervals` (the reference's slice syntax), before the first step if 0 is, and -- dump_last_timestep --
+ * once more when a deck-built run reaches its max_step (a run built through wxa_sim_create ends when its caller says so:
+ * wxa_sim_flush_diags_last_timestep).  file_prefix NULL or "" = "diags/<name>", file_min_digits <= 0 = 6, fields =
+ * space-separated names out of Ex Ey Ez Bx By Bz jx jy jz rho (NULL = the reference's default, Ex .. jz; names outside
+ * the list are left out with a warning), write_species = 0: fields only.  In a deck: diagnostics.diags_names. */
+wxa_status  wxa_sim_add_full_diag(wxa_sim* s, const char* name, const char* intervals, const char* file_prefix,
+                                  int32_t file_min_digits, const char* fields, int32_t write_species,
+                                  int32_t dump_last_timestep);
+wxa_status  wxa_sim_flush_diags_last_timestep(wxa_sim* s);
 /* Lab-frame snapshot i of wxa_sim_add_btd as a plotfile (fields and the back-transformed particles of every species;
  * geometry and time of the lab frame): what the reference's BTD flushes hold once merged
  * (BTDiagnostics::MergeBuffersForPlotfile, BTDiagnostics.cpp:1146-1314), as one grid -- this brick's share. */

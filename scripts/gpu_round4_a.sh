@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
 timeout 300 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py tests/test_multibrick_gpu.py -m gpu -q -rf \
-    -k "reduce_ or reduced_diags or one_plotfile" 2>&1 | tail -15 | tee $OUT/pytest_new_since_r3z.txt
+    -k "reduce_ or reduced_diags or one_plotfile or full_diagnostics" 2>&1 | tail -15 | tee $OUT/pytest_new_since_r3z.txt
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python -c "import json;d=json.load(open('$OUT/bench.json'));print(d['ms_per_step'],d['value'],d['roofline']['traffic'],{k:round(v['avg_ms'],3) for k,v in d['kernels'].items()})"; tail -3 $OUT/bench.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- \

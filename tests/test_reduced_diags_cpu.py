@@ -149,7 +149,7 @@ def test_refusals(host_cpu, tmp_path):
     sim.close()
 
 
-RD_LINES = ["warpx.reduced_diags_names=EF EP PP NP FP", "EF.type=FieldEnergy", "EF.intervals=2", "EP.type=ParticleEnergy",
+RD_LINES = ["warpx_amd.write_diagnostics=1", "diag1.intervals=100000:", "diag1.dump_last_timestep=0", "warpx.reduced_diags_names=EF EP PP NP FP", "EF.type=FieldEnergy", "EF.intervals=2", "EP.type=ParticleEnergy",
             "PP.type=ParticleMomentum", "PP.intervals=3", "NP.type=ParticleNumber", "FP.type=FieldProbe", "FP.intervals=1"]
 
 
@@ -190,7 +190,8 @@ def test_particle_number_counts_live_particles(host_cpu, tmp_path):
     (TotalNumberOfParticles, ParticleNumber.cpp:113-117)."""
     deck = os.path.join(ROOT, "tests", "decks", "particle_walls_3d.inputs")
     path = str(tmp_path) + "/"
-    sim = WarpXSim.from_inputs(host_cpu, deck, overrides=["warpx.reduced_diags_names=NP", "NP.type=ParticleNumber",
+    sim = WarpXSim.from_inputs(host_cpu, deck, overrides=["warpx_amd.write_diagnostics=1",
+                                                          "warpx.reduced_diags_names=NP", "NP.type=ParticleNumber",
                                                           f"NP.path={path}"])
     sim.evolve(sim.max_step)
     sim.close()

@@ -202,6 +202,9 @@ _INPUTS_SIGS = {
     "sim_species_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "sim_checksum_json": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "sim_write_plotfile": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "sim_add_full_diag": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
+                                   C.c_int32]),
+    "sim_flush_diags_last_timestep": (C.c_int, [C.c_void_p]),
     "sim_btd_write_plotfile": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p]),
     "sim_btd_set_flush": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "sim_btd_flush": (C.c_int, [C.c_void_p]),

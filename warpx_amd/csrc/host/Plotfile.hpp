@@ -129,7 +129,11 @@ inline void write_btd_plotfile(SimHandle& h, int i, const std::string& dir, cons
 // box (Level_0/Cell_D_<rank>) and its own particles (<species>/Level_0/DATA_<rank>) into the same directory, and brick 0
 // writes the headers that list every brick's grid (VisMF "how" = one fab per file; the per-grid extrema and particle counts
 // travel through ReduceRealSum, each brick filling its own slots).  The bricks of a run see one file system (one node).
-inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vector<std::string>& species_names) {
+// fields: which of Ex Ey Ez Bx By Bz jx jy jz rho, in which order (null: all ten); species: which species by name (null or
+// empty: all); write_species = false: none
+inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vector<std::string>& species_names,
+                           const std::vector<std::string>* fields = nullptr, const std::vector<std::string>* species = nullptr,
+                           bool write_species = true) {
     using warpx::fields::FieldType;
     using ablastr::fields::Direction;
     WarpX& wx = *h.warpx;
@@ -150,12 +154,18 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
     int ncell[3] = {0, 0, 0};   // ten components: + rho
     std::vector<std::vector<double>> data;
     std::vector<std::string> names;
-    for (const auto& c : comps) {
-        data.push_back(cell_centered(be, *wx.fields().get(c.ft, Direction{c.d}, 0), ncell));
-        names.emplace_back(c.name);
+    static const std::vector<std::string> all_fields{"Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho"};
+    for (const std::string& want : (fields ? *fields : all_fields)) {
+        if (want == "rho") {
+            data.push_back(cell_centered(be, wx.ComputeRho(), ncell));
+        } else {
+            const auto* c = std::find_if(comps, comps + 9, [&](const auto& e) { return want == e.name; });
+            if (c == comps + 9) throw std::runtime_error("plotfile: no field named " + want);
+            data.push_back(cell_centered(be, *wx.fields().get(c->ft, Direction{c->d}, 0), ncell));
+        }
+        names.push_back(want);
     }
-    data.push_back(cell_centered(be, wx.ComputeRho(), ncell));
-    names.emplace_back("rho");
+    if (names.empty()) throw std::runtime_error("plotfile: no field to write");
     const size_t ncomp = names.size();
     // the grid of brick r: its cells in the global index space (BrickComm::rank_of's numbering)
     auto grid_of = [&](int r, int lo[3], int hi[3]) {
@@ -200,8 +210,15 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
     }
     // ---- particles: the live ones (slots retired by Redistribute or by an absorbing wall wait for the next sort)
     const int ns = wx.GetPartContainer().nSpecies();
+    auto species_name = [&](int s) { return s < (int)species_names.size() ? species_names[(size_t)s] : "species" + std::to_string(s); };
+    auto selected = [&](int s) {
+        if (!write_species) return false;
+        if (!species || species->empty()) return true;
+        return std::find(species->begin(), species->end(), species_name(s)) != species->end();
+    };
     std::vector<double> counts((size_t)nranks * (size_t)std::max(ns, 1), 0.0);
     for (int s = 0; s < ns; ++s) {
+        if (!selected(s)) continue;
         WarpXParticleContainer& pc = wx.GetPartContainer().GetParticleContainer(s);
         ParticleTile& t = pc.tile();
         const size_t n = (size_t)t.numParticles();
@@ -227,7 +244,8 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
     ReduceRealSum(comm, be, counts, ctx.stream);
     if (me == 0) {
         for (int s = 0; s < ns; ++s) {
-            const std::string name = s < (int)species_names.size() ? species_names[s] : "species" + std::to_string(s);
+            if (!selected(s)) continue;
+            const std::string name = species_name(s);
             std::vector<ParticleGrid> grids((size_t)nranks);
             for (int r = 0; r < nranks; ++r) {
                 ParticleGrid& g = grids[(size_t)r];

@@ -7,6 +7,8 @@
 #ifndef WXA_HOST_WARPX_HPP_
 #define WXA_HOST_WARPX_HPP_
 
+#include <functional>
+
 #include "BTDiagnostics.hpp"
 #include "NCIGodfreyFilter.hpp"
 #include "ReducedDiags.hpp"
@@ -269,11 +271,13 @@ public:
     // Source/Evolve/WarpXEvolve.cpp:94-347
     void Evolve(int numsteps) {
         const int numsteps_max = numsteps;
-        if (!m_reduced_diags_started) {   // WarpX::InitData (WarpXInitData.cpp:612-619): the row before the first iteration
+        if (!m_reduced_diags_started) {   // WarpX::InitData (WarpXInitData.cpp:612-619): full and reduced diagnostics before the first iteration
             m_reduced_diags_started = true;
+            if (diag_hook) diag_hook((int)istep - 1, kDiagFlush);
             reduced_diags.ComputeAndWrite(*this, (int)istep - 1);
         }
         for (int step = 0; step < numsteps_max; ++step) {
+            if (diag_hook) diag_hook((int)istep, kDiagNewIteration);   // :118 multi_diags->NewIteration()
             // :142-145 if synchronized, push velocity backward one half step
             ExplicitFillBoundaryEBUpdateAux();
             // warpx.sort_intervals (Source/WarpX.cpp:1335): the sort itself runs inside
@@ -291,9 +295,16 @@ public:
             HandleParticlesAtBoundaries(step, cur_time, num_moved);  // :256
             reduced_diags.ComputeAndWrite(*this, (int)istep - 1);   // :299-305 reduced_diags->ComputeDiags(step), WriteToFile(step)
             if (m_btd) m_btd->ComputeAndPack(*this);             // :306 multi_diags->FilterComputePackFlush(step)
+            if (diag_hook) diag_hook((int)istep - 1, kDiagFlush);   // ... of the Full diagnostics (FullDiagnostics.hpp)
         }
         m_be->stream_sync(m_ctx.stream);
+        // :341-343 the forced flush of the last time step, once the run has reached the deck's max_step
+        if (diag_hook && max_step >= 0 && istep == max_step) diag_hook((int)istep, kDiagLastTimestep);
     }
+    // <diag>.diag_type = Full: the plotfile writer sits above this class (FullDiagnostics.hpp installs the hook)
+    static constexpr int kDiagNewIteration = 0, kDiagFlush = 1, kDiagLastTimestep = 2;
+    std::function<void(int step, int what)> diag_hook;
+    int64_t max_step = -1;   // the deck's max_step (-1: not known; the caller flushes the last time step itself)
 
     // <diag>.diag_type = BackTransformed with do_back_transformed_fields = 1 (BTDiagnostics.hpp): lab-frame snapshots
     // num_snapshots_lab, dt_snapshots_lab (= dz_snapshots_lab / c), buffer_size as in BTDiagnostics::ReadParameters (:206-292)

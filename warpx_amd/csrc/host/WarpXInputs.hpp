@@ -262,6 +262,11 @@ struct DeckInfo {
     std::vector<std::string> species_names;
 };
 
+// <diag>.diag_type = Full (FullDiagnostics.hpp, which sits above the plotfile writer and is included below)
+inline void add_full_diagnostic(SimHandle& h, const std::string& name, const std::string& intervals, const std::string& file_prefix,
+                                int file_min_digits, const std::vector<std::string>& fields, bool write_species,
+                                const std::vector<std::string>& species, bool dump_last_timestep);
+
 // nbricks / coord: this library's decomposition (one brick per GPU), not the deck's amr.max_grid_size
 inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::string& path,
                                                   const std::vector<std::string>& overrides, const wxa_comm* comm,
@@ -731,12 +736,51 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
             wx.btd()->SetFlush(prefix, digits);
         }
     }
+    // <diag>.diag_type = Full with format = plotfile (Diagnostics::BaseReadParameters, Diagnostics.cpp:47-60;
+    // FullDiagnostics::ReadParameters, FullDiagnostics.cpp:109-125): plotfiles <file_prefix><step> at the steps of
+    // <diag>.intervals and after the last step.  Other formats (openpmd, checkpoint ...) and the other diagnostic types
+    // (TimeAveraged, BoundaryScraping) are output this library does not write.
+    h->species_names = info.species_names;
+    wx.max_step = info.max_step;
+    // warpx_amd.write_diagnostics = 0 (this library's own key; default 1 = what the reference does): the deck's Full
+    // and reduced diagnostics are not written -- for callers that only want the final state (the test-suite)
+    int write_diagnostics = 1;
+    pp.queryWithParser("warpx_amd.write_diagnostics", write_diagnostics);
+    for (const std::string& d : diag_names) {
+        if (!write_diagnostics) break;
+        std::string type, format = "plotfile";
+        if (!pp.query_word(d + ".diag_type", type)) throw std::runtime_error("inputs: " + d + ".diag_type must be set");
+        pp.query_word(d + ".format", format);
+        if (type != "full" || format != "plotfile") continue;
+        std::vector<std::string> iv;
+        if (!pp.queryarr(d + ".intervals", iv)) throw std::runtime_error("inputs: " + d + ".intervals must be set");
+        std::string intervals;
+        for (const std::string& e : iv) intervals += e;
+        std::string prefix = "diags/" + d;
+        pp.query(d + ".file_prefix", prefix);
+        int digits = 6, write_species = 1, dump_last = 1;
+        pp.queryWithParser(d + ".file_min_digits", digits);
+        pp.queryWithParser(d + ".write_species", write_species);
+        pp.queryWithParser(d + ".dump_last_timestep", dump_last);
+        std::vector<std::string> fields, species;
+        pp.queryarr(d + ".fields_to_plot", fields);
+        if (fields.size() == 1 && fields[0] == "none") fields = {"none"};
+        pp.queryarr(d + ".species", species);
+        for (const std::string& sp : species)
+            if (std::find(info.species_names.begin(), info.species_names.end(), sp) == info.species_names.end())
+                throw std::runtime_error("inputs: " + d + ".species names the unknown species " + sp);
+        if (comm && comm->nranks > 1 && !prefix.empty() && prefix[0] != '/') {
+            // the bricks of a run write into one directory: a relative prefix is relative to every process's own
+            // working directory, which a launcher normally makes the same
+        }
+        add_full_diagnostic(*h, d, intervals, prefix, digits, fields, write_species != 0, species, dump_last != 0);
+    }
     // warpx.reduced_diags_names (MultiReducedDiags.cpp:36-83, ReducedDiags.cpp:26-72): the four types of ReducedDiags.hpp
     // are produced; the others (probes, histograms, load-balance costs ...) are output this library does not write
     for (const std::string& d : rdiag_names) {
         std::string type;
         if (!pp.query(d + ".type", type)) throw std::runtime_error("inputs: " + d + ".type must be set");
-        if (!MultiReducedDiags::known_type(type)) continue;
+        if (!MultiReducedDiags::known_type(type) || !write_diagnostics) continue;
         if (pp.contains(d + ".frequency"))   // ReducedDiags::BackwardCompatibility
             throw std::runtime_error("inputs: " + d + ".frequency is no longer a valid option. Please use the renamed option " +
                                      d + ".intervals instead.");
@@ -774,7 +818,15 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
 }  // namespace wxa::host
 
 #include "Checksum.hpp"
-#include "Plotfile.hpp"
+#include "FullDiagnostics.hpp"
+
+namespace wxa::host {
+inline void add_full_diagnostic(SimHandle& h, const std::string& name, const std::string& intervals, const std::string& file_prefix,
+                                int file_min_digits, const std::vector<std::string>& fields, bool write_species,
+                                const std::vector<std::string>& species, bool dump_last_timestep) {
+    full_diagnostics(h).Add(name, intervals, file_prefix, file_min_digits, fields, write_species, species, dump_last_timestep);
+}
+}  // namespace wxa::host
 
 // C entry points of the deck front end (include/warpx_amd.h), instantiated next to WXA_SIM_CAPI
 #define WXA_INPUTS_CAPI(PFX, RET, SIMTYPE, BACKEND_GETTER, SET_ERROR)                                   \
@@ -837,6 +889,37 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         } catch (const std::exception& e) {                                                            \
             SET_ERROR(e.what());                                                                       \
             return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
+    }                                                                                                  \
+    /* <diag>.diag_type = Full, format = plotfile (host/FullDiagnostics.hpp); fields: space-separated names or NULL */ \
+    RET PFX##sim_add_full_diag(SIMTYPE* s, const char* name, const char* intervals, const char* file_prefix, \
+                               int32_t file_min_digits, const char* fields, int32_t write_species,    \
+                               int32_t dump_last_timestep) {                                           \
+        if (!s || !name || !*name) return (RET)WXA_ERR_INVALID_ARG;                                    \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        try {                                                                                          \
+            std::vector<std::string> f;                                                                \
+            std::istringstream words(fields ? fields : "");                                            \
+            for (std::string w; words >> w;) f.push_back(w);                                           \
+            wxa::host::add_full_diagnostic(*h, name, intervals ? intervals : "", file_prefix ? file_prefix : "", \
+                                           file_min_digits > 0 ? file_min_digits : 6, f, write_species != 0, {}, \
+                                           dump_last_timestep != 0);                                   \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
+    }                                                                                                  \
+    /* MultiDiagnostics::FilterComputePackFlushLastTimestep for a run the caller ends itself (no max_step known) */ \
+    RET PFX##sim_flush_diags_last_timestep(SIMTYPE* s) {                                               \
+        if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        try {                                                                                          \
+            if (h->warpx->diag_hook) h->warpx->diag_hook((int)h->warpx->getistep(), wxa::host::WarpX::kDiagLastTimestep); \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_HIP;                                                                   \
         }                                                                                              \
     }                                                                                                  \
     /* lab-frame snapshot i of the back-transformed diagnostics as a plotfile (host/Plotfile.hpp, write_btd_plotfile) */ \

@@ -16,6 +16,7 @@ struct SimHandle {
     // set when the simulation was built from an inputs file (WarpXInputs.hpp)
     int max_step = -1;
     std::vector<std::string> species_names;
+    std::shared_ptr<void> multi_diags;   // MultiDiagnostics of FullDiagnostics.hpp (declared after the plotfile writer)
 };
 
 inline int sim_create(const Backend* be, const wxa_sim_config* cfg, const wxa_comm* comm, SimHandle** out,

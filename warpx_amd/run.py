@@ -2,7 +2,9 @@
 
     python -m warpx_amd.run <inputs_file> [name=value ...] [--checksum out.json]
 
-Evolves for the deck's max_step and writes the reference-format regression checksum of the final
+Evolves for the deck's max_step, writes the deck's diagnostics as the reference does (diag_type = Full with
+format = plotfile -> <file_prefix><step>/, the reduced diagnostics FieldEnergy / ParticleEnergy / ParticleMomentum /
+ParticleNumber -> diags/reducedfiles/<name>.txt) and the reference-format regression checksum of the final
 state (Regression/Checksum/checksum.py) as JSON.  The deck reader, the step loop and the checksum are
 the library's (include/warpx_amd.h: wxa_sim_create_from_inputs, wxa_sim_evolve,
 wxa_sim_checksum_json); this file only parses the command line.
@@ -20,6 +22,8 @@ def main(argv=None):
     ap.add_argument("overrides", nargs="*", help="name=value, applied after the file")
     ap.add_argument("--checksum", default=None, help="write the checksum JSON here (default: stdout)")
     ap.add_argument("--max-step", type=int, default=None, help="instead of the deck's max_step")
+    ap.add_argument("--no-diagnostics", action="store_true",
+                    help="do not write the deck's diagnostics (plotfiles under <diag>.file_prefix, diags/reducedfiles/*.txt)")
     args = ap.parse_args(argv)
 
     import os
@@ -41,7 +45,8 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         transport = TorchBrickTransport(on_device=True)
         comm = transport.comm
-    sim = WarpXSim.from_inputs(lib, args.inputs, args.overrides, comm=comm)   # the library chooses the bricks
+    # the library chooses the bricks; the deck's Full (plotfile) and reduced diagnostics are written under diags/
+    sim = WarpXSim.from_inputs(lib, args.inputs, args.overrides, comm=comm, diagnostics=not args.no_diagnostics)
     steps = args.max_step if args.max_step is not None else sim.max_step
     if steps is None or steps < 0:
         raise SystemExit("max_step is not set in the inputs file: pass --max-step")

@@ -63,10 +63,13 @@ class WarpXSim:
 
     @classmethod
     def from_inputs(cls, lib: _capi.CLib, inputs_path, overrides=(), nbricks=None, coord=None,
-                    comm: _capi.Comm | None = None):
+                    comm: _capi.Comm | None = None, diagnostics: bool = False):
         """The simulation a WarpX inputs file describes (wxa_sim_create_from_inputs): `overrides` are
         "name=value" strings like the reference's command line; raises WxaError naming any parameter that is
-        outside this library's path."""
+        outside this library's path.  diagnostics=False (or an override warpx_amd.write_diagnostics=0): the plotfiles
+        and reduced-diagnostics files the deck asks for are not written (the C entry point's default is to write them,
+        as the reference does: python -m warpx_amd.run)."""
+        overrides = ([] if diagnostics else ["warpx_amd.write_diagnostics=0"]) + list(overrides)
         self = cls.__new__(cls)
         self.lib = lib
         self.on_device = lib.prefix == "wxa_"
@@ -136,6 +139,19 @@ class WarpXSim:
     def btd_write_plotfile(self, i: int, path: str):
         """Lab-frame snapshot i as an AMReX plotfile (wxa_sim_btd_write_plotfile)."""
         self.lib.sim_btd_write_plotfile(self._h, int(i), str(path).encode())
+
+    def add_full_diag(self, name: str, intervals: str, file_prefix: str | None = None, file_min_digits: int = 6,
+                      fields=None, write_species: bool = True, dump_last_timestep: bool = True):
+        """diagnostics.diags_names += name with diag_type = Full, format = plotfile (wxa_sim_add_full_diag): plotfiles
+        <file_prefix><step> at the steps of `intervals`; fields: names out of Ex .. jz, rho (None: Ex .. jz)."""
+        self.lib.sim_add_full_diag(self._h, name.encode(), str(intervals).encode(),
+                                   None if file_prefix is None else str(file_prefix).encode(), int(file_min_digits),
+                                   None if fields is None else " ".join(fields).encode(), 1 if write_species else 0,
+                                   1 if dump_last_timestep else 0)
+
+    def flush_diags_last_timestep(self):
+        """The forced flush after the last step of a run without a deck's max_step (wxa_sim_flush_diags_last_timestep)."""
+        self.lib.sim_flush_diags_last_timestep(self._h)
 
     def add_reduced_diag(self, name: str, rd_type: str, intervals: str = "1", path: str | None = None):
         """warpx.reduced_diags_names += name (wxa_sim_add_reduced_diag): rd_type in FieldEnergy, ParticleEnergy,
