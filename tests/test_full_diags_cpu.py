@@ -58,7 +58,7 @@ def test_a_deck_writes_the_reference_s_output_tree(host_cpu, tmp_path):
     """diagnostics.diags_names of a deck: plotfiles at the intervals and at max_step, reduced diagnostics next to them
     -- what `python -m warpx_amd.run deck` leaves behind, as the reference's executable does."""
     prefix = str(tmp_path / "diags" / "diag1")
-    over = ["warpx_amd.write_diagnostics=1", "my_constants.nx=16", "max_step=6", "diag1.intervals=4", f"diag1.file_prefix={prefix}",
+    over = ["warpx_amd.write_diagnostics=1", "my_constants.nx=16", "max_step=6", "my_constants.every=4", "diag1.intervals=0:nx*10:every", f"diag1.file_prefix={prefix}",
             "diag1.fields_to_plot=Ex Ey Ez jx rho", "diag1.species=positrons",
             "warpx.reduced_diags_names=EF", "EF.type=FieldEnergy", "EF.intervals=3", f"EF.path={tmp_path}/diags/reducedfiles/"]
     sim = WarpXSim.from_inputs(host_cpu, DECK, overrides=over)
@@ -84,6 +84,8 @@ def test_a_deck_writes_the_reference_s_output_tree(host_cpu, tmp_path):
         sim.evolve(sim.max_step)
         sim.close()
         assert not os.path.exists(out), extra
+    with pytest.raises(_capi.WxaError, match="names no field"):
+        WarpXSim.from_inputs(host_cpu, DECK, overrides=over + ["diag1.fields_to_plot=none"])
     with pytest.raises(_capi.WxaError, match="unknown species"):
         WarpXSim.from_inputs(host_cpu, DECK, overrides=over + ["diag1.species=muons"])
     with pytest.raises(_capi.WxaError, match="intervals must be set"):

@@ -51,6 +51,13 @@ def test_short_step_parity_on_the_cpu_execution_model():
     _run(["tests/test_step_gpu.py", "-k", "test_uniform_plasma_parity or test_reduced_diags_on_the_device"])
 
 
+def test_output_side_on_the_cpu_execution_model():
+    """The tests of the output side that no MI355X has run yet: one plotfile and the reduced-diagnostics rows for all
+    bricks of a run (bricks as threads, HIP kernels), and a deck's Full + reduced diagnostics on the HIP path."""
+    _run(["tests/test_multibrick_gpu.py", "tests/test_step_gpu.py", "-k",
+          "test_one_plotfile_and_reduced_diags_for_all_bricks or test_full_diagnostics_of_a_deck_on_the_hip_path"])
+
+
 def test_gpu_only_modules_bind_every_global_they_read():
     """The modules only a GPU box executes (tests marked gpu, bench.py, smoke) are otherwise first run at the end
     of a round; a scope-aware pass over their symbol tables catches the NameError class of failure here."""

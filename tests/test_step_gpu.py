@@ -701,3 +701,37 @@ def test_reduced_diags_on_the_device(oracle, product, tmp_path):
         worst = np.max(np.abs(x[:, 2:] - y[:, 2:]) / np.maximum(scale, 1e-300))
         print(f"{n}: worst relative deviation {worst:.2e}")
         assert worst <= RTOL, n
+
+
+def test_full_diagnostics_of_a_deck_on_the_hip_path(product, tmp_path):
+    """diagnostics.diags_names + warpx.reduced_diags_names of a deck on the HIP path: the step loop leaves the reference's
+    output tree (plotfiles at the intervals and at max_step, diags/reducedfiles/*.txt); the last plotfile, read back,
+    carries the library's own checksum of the final state and the last FieldEnergy row its field energy."""
+    from tests.test_plotfile_cpu import checksum_of, read_plotfile
+    deck = os.path.join(HERE, "decks", "langmuir_multi_3d.inputs")
+    prefix = str(tmp_path / "diags" / "diag1")
+    over = ["warpx_amd.write_diagnostics=1", "my_constants.nx=32", "max_step=9", "algo.particle_shape=3", "diag1.intervals=4",
+            f"diag1.file_prefix={prefix}", "diag1.fields_to_plot=Ex Ey Ez Bx By Bz jx jy jz rho",
+            "warpx.reduced_diags_names=EF EP", "EF.type=FieldEnergy", "EF.intervals=3", f"EF.path={tmp_path}/diags/reducedfiles/",
+            "EP.type=ParticleEnergy", "EP.intervals=9", f"EP.path={tmp_path}/diags/reducedfiles/"]
+    sim = WarpXSim.from_inputs(product, deck, overrides=over)
+    sim.evolve(sim.max_step)
+    direct = sim.checksum()
+    sim.close()
+    assert sorted(os.listdir(tmp_path / "diags")) == ["diag1000000", "diag1000004", "diag1000008", "diag1000009", "reducedfiles"]
+    pf = read_plotfile(prefix + "000009")
+    assert pf["step"] == 9 and sorted(pf["species"]) == ["electrons", "positrons"]
+    got = checksum_of(pf)
+    for group, vals in got.items():
+        for k, v in vals.items():
+            # rho is deposited with atomics on the GPU: two evaluations differ in the last digits
+            assert abs(v - direct[group][k]) <= (1e-10 if k == "rho" else 1e-12) * max(abs(direct[group][k]), 1e-300), (group, k)
+    ef = np.atleast_2d(np.genfromtxt(str(tmp_path / "diags" / "reducedfiles" / "EF.txt")))
+    ep = np.atleast_2d(np.genfromtxt(str(tmp_path / "diags" / "reducedfiles" / "EP.txt")))
+    assert list(ef[:, 0]) == [0, 3, 6, 9] and list(ep[:, 0]) == [0, 9]
+    # energy of the cell-centred fields of the plotfile against the row of the staggered ones: the same to the accuracy of
+    # the averaging (the reference's own analysis_reduced_diags_impl.py compares the two at 1e-3 .. 1e-2)
+    dV = (40e-6 / 32) ** 3
+    e2 = sum(np.sum(pf["fields"][n] ** 2) for n in ("Ex", "Ey", "Ez"))
+    assert abs(0.5 * plasma.EP0 * e2 * dV - ef[-1, 3]) < 0.1 * ef[-1, 3]
+    assert ep[-1, 2] > 0 and ep[0, 2] > ep[-1, 2]      # the oscillation has handed energy to the field

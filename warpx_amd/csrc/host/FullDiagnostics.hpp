@@ -68,6 +68,8 @@ public:
             if (std::find(known_fields().begin(), known_fields().end(), f) != known_fields().end()) d.m_varnames_fields.push_back(f);
             else std::fprintf(stderr, "[warpx_amd] %s.fields_to_plot: %s is not written by this library (left out)\n", name.c_str(), f.c_str());
         }
+        if (d.m_varnames_fields.empty())   // (the reference writes particle-only plotfiles for fields_to_plot = none)
+            throw std::runtime_error("diagnostics: " + name + ".fields_to_plot names no field this library writes");
         alldiags.push_back(std::move(d));
     }
     int size() const { return (int)alldiags.size(); }

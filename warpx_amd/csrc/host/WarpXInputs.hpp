@@ -262,6 +262,23 @@ struct DeckInfo {
     std::vector<std::string> species_names;
 };
 
+// "<diag>.intervals = 0:nsteps:nsteps/4, 5" -> "0:40:10,5": the words of an intervals entry concatenated (IntervalsParser.cpp:
+// 86-87), every number of every slice evaluated with the deck's constants (parseStringtoInt, IntervalsParser.cpp:27-47)
+inline std::string deck_intervals(ParmParse& pp, const std::vector<std::string>& words, const std::string& key) {
+    std::string all, out, part;
+    for (const std::string& w : words) all += w;
+    auto flush = [&]() {
+        if (!part.empty()) out += std::to_string(ParmParse::safe_int(pp.evaluate(part), key));
+        part.clear();
+    };
+    for (char c : all) {
+        if (c == ':' || c == ',') { flush(); out.push_back(c); }
+        else if (!std::isspace((unsigned char)c)) part.push_back(c);
+    }
+    flush();
+    return out;
+}
+
 // <diag>.diag_type = Full (FullDiagnostics.hpp, which sits above the plotfile writer and is included below)
 inline void add_full_diagnostic(SimHandle& h, const std::string& name, const std::string& intervals, const std::string& file_prefix,
                                 int file_min_digits, const std::vector<std::string>& fields, bool write_species,
@@ -754,8 +771,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         if (type != "full" || format != "plotfile") continue;
         std::vector<std::string> iv;
         if (!pp.queryarr(d + ".intervals", iv)) throw std::runtime_error("inputs: " + d + ".intervals must be set");
-        std::string intervals;
-        for (const std::string& e : iv) intervals += e;
+        const std::string intervals = deck_intervals(pp, iv, d + ".intervals");
         std::string prefix = "diags/" + d;
         pp.query(d + ".file_prefix", prefix);
         int digits = 6, write_species = 1, dump_last = 1;
@@ -786,8 +802,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                                      d + ".intervals instead.");
         std::vector<std::string> iv{"1"};
         pp.queryarr(d + ".intervals", iv);   // getarr in the reference: the default is never used there
-        std::string intervals;
-        for (const std::string& e : iv) intervals += e;   // IntervalsParser concatenates the words (.cpp:86-87)
+        const std::string intervals = deck_intervals(pp, iv, d + ".intervals");
         std::string path = "./diags/reducedfiles/";
         pp.query(d + ".path", path);
         for (const char* fixed : {".extension", ".separator", ".precision"})
