@@ -763,7 +763,7 @@ DEV_BUILD = "dev" in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", ""))   #
 
 
 @pytest.mark.parametrize("ncell", [(24, 20, 16), (25, 9, 7), (130, 6, 5), (300, 8, 8)])
-@pytest.mark.parametrize("variant", [-1] + (list(range(8)) if DEV_BUILD else []))
+@pytest.mark.parametrize("variant", [-1] + (list(range(10)) if DEV_BUILD else []))
 def test_evolve_stencil_configurations_bit_exact(oracle, product, ncell, variant):
     """The EvolveB / EvolveE kernels on odd, even and multi-tile row lengths, bit for bit against the oracle: the
     production configuration, and in a dev build every tile shape / non-temporal configuration of the timing sweep

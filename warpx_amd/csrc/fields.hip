@@ -28,9 +28,13 @@ namespace wxa {
 // NT: the arrays that are read once and written once per call (B in EvolveB; E and J in EvolveE) move with
 // non-temporal loads / stores, so that they do not evict the rows of the other operand that the j / k neighbours
 // re-read from L2.  WXA_STENCIL_VARIANT=<n> selects a configuration per launch (scripts/stencil_variants.py).
-template <int TW_, int TJ_, int KC_, int NT_>
+// BATCH: every load of the lane's KC planes is issued before the first store.  gfx950 counts loads and stores in one
+// vmcnt, and the three read-modify-writes of a plane sit in three conditional blocks: as written plane by plane the ISA is
+// load B -> s_waitcnt vmcnt(0) -> store B, three times per plane, each wait also draining the store before it -- one
+// round trip to memory at a time per wave, latency hidden by occupancy alone.  Same arithmetic per point: bit-identical.
+template <int TW_, int TJ_, int KC_, int NT_, int BATCH_ = 0>
 struct StencilCfg {
-    static constexpr int TW = TW_, TI = 64 * TW_, TJ = TJ_, KC = KC_, NT = NT_;
+    static constexpr int TW = TW_, TI = 64 * TW_, TJ = TJ_, KC = KC_, NT = NT_, BATCH = BATCH_;
 };
 constexpr int TI = 64, TJ = 2, KC = 4;   // the thin-box launches (guard layer) use the plain configuration
 
@@ -95,6 +99,43 @@ evolve_b_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, B
     double* __restrict__ by = By.p + By.off(i, j, k0);
     double* __restrict__ bz = Bz.p + Bz.off(i, j, k0);
 
+    if constexpr (CFG::BATCH != 0) {
+        double exv[KC + 1], eyv[KC + 1], ezc[KC], ezj[KC], ezi[KC], exj[KC], eyi[KC], b0[KC], b1[KC], b2[KC];
+        bool d0[KC], d1[KC], d2[KC];
+        exv[0] = ld_shared<NT>(ex); eyv[0] = ld_shared<NT>(ey);
+#pragma unroll
+        for (int n = 0; n < KC; ++n) {
+            const int k = k0 + n;
+            const bool in = k < k1;
+            d0[n] = in && px && k >= bbx.lo[2] && k < bbx.hi[2];
+            d1[n] = in && py && k >= bby.lo[2] && k < bby.hi[2];
+            d2[n] = in && pz && k >= bbz.lo[2] && k < bbz.hi[2];
+            exv[n + 1] = eyv[n + 1] = ezc[n] = ezj[n] = ezi[n] = exj[n] = eyi[n] = b0[n] = b1[n] = b2[n] = 0.0;
+            if (in) {
+                exv[n + 1] = ld_shared<NT>(ex + (n + 1) * Ex.ks); eyv[n + 1] = ld_shared<NT>(ey + (n + 1) * Ey.ks);
+                ezc[n] = ld_shared<NT>(ez + n * Ez.ks); ezj[n] = ld_shared<NT>(ez + n * Ez.ks + Ez.js);
+                ezi[n] = ld_shared<NT>(ez + n * Ez.ks + 1);
+                exj[n] = ld_shared<NT>(ex + n * Ex.ks + Ex.js); eyi[n] = ld_shared<NT>(ey + n * Ey.ks + 1);
+            }
+            if (d0[n]) b0[n] = ld_once<NT>(bx + n * Bx.ks);
+            if (d1[n]) b1[n] = ld_once<NT>(by + n * By.ks);
+            if (d2[n]) b2[n] = ld_once<NT>(bz + n * Bz.ks);
+        }
+        // every loaded value is "used" here, in straight-line code: the compiler's wait for the loads lands in front of
+        // the stores once, not inside each conditional store block (where, with stores pending, it would be vmcnt(0))
+        asm volatile("" : "+v"(exv[0]), "+v"(eyv[0]));
+#pragma unroll
+        for (int n = 0; n < KC; ++n)
+            asm volatile("" : "+v"(exv[n + 1]), "+v"(eyv[n + 1]), "+v"(ezc[n]), "+v"(ezj[n]), "+v"(ezi[n]), "+v"(exj[n]),
+                              "+v"(eyi[n]), "+v"(b0[n]), "+v"(b1[n]), "+v"(b2[n]));
+#pragma unroll
+        for (int n = 0; n < KC; ++n) {
+            if (d0[n]) st_once<NT>(bx + n * Bx.ks, b0[n] + (dt * (idz * (eyv[n + 1] - eyv[n])) - dt * (idy * (ezj[n] - ezc[n]))));
+            if (d1[n]) st_once<NT>(by + n * By.ks, b1[n] + (dt * (idx * (ezi[n] - ezc[n])) - dt * (idz * (exv[n + 1] - exv[n]))));
+            if (d2[n]) st_once<NT>(bz + n * Bz.ks, b2[n] + (dt * (idy * (exj[n] - exv[n])) - dt * (idx * (eyi[n] - eyv[n]))));
+        }
+        return;
+    }
     double ex_k = ld_shared<NT>(ex), ey_k = ld_shared<NT>(ey);
 #pragma unroll 4
     for (int k = k0; k < k1; ++k) {
@@ -143,6 +184,42 @@ evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, D
     const double* __restrict__ jy = Jy.p + Jy.off(i, j, k0);
     const double* __restrict__ jz = Jz.p + Jz.off(i, j, k0);
 
+    if constexpr (CFG::BATCH != 0) {
+        double bxv[KC + 1], byv[KC + 1], bzc[KC], bzj[KC], bzi[KC], bxj[KC], byi[KC], e0[KC], e1[KC], e2[KC], j0[KC], j1[KC], j2[KC];
+        bool d0[KC], d1[KC], d2[KC];
+        bxv[0] = ld_shared<NT>(bx - Bx.ks); byv[0] = ld_shared<NT>(by - By.ks);   // the plane below the first one
+#pragma unroll
+        for (int n = 0; n < KC; ++n) {
+            const int k = k0 + n;
+            const bool in = k < k1;
+            d0[n] = in && px && k >= bex.lo[2] && k < bex.hi[2];
+            d1[n] = in && py && k >= bey.lo[2] && k < bey.hi[2];
+            d2[n] = in && pz && k >= bez.lo[2] && k < bez.hi[2];
+            bxv[n + 1] = byv[n + 1] = bzc[n] = bzj[n] = bzi[n] = bxj[n] = byi[n] = 0.0;
+            e0[n] = e1[n] = e2[n] = j0[n] = j1[n] = j2[n] = 0.0;
+            if (in) {
+                bxv[n + 1] = ld_shared<NT>(bx + n * Bx.ks); byv[n + 1] = ld_shared<NT>(by + n * By.ks);
+                bzc[n] = ld_shared<NT>(bz + n * Bz.ks);
+                bzj[n] = ld_shared<NT>(bz + n * Bz.ks - Bz.js); bzi[n] = ld_shared<NT>(bz + n * Bz.ks - 1);
+                bxj[n] = ld_shared<NT>(bx + n * Bx.ks - Bx.js); byi[n] = ld_shared<NT>(by + n * By.ks - 1);
+            }
+            if (d0[n]) { e0[n] = ld_once<NT>(ex + n * Ex.ks); j0[n] = ld_once<NT>(jx + n * Jx.ks); }
+            if (d1[n]) { e1[n] = ld_once<NT>(ey + n * Ey.ks); j1[n] = ld_once<NT>(jy + n * Jy.ks); }
+            if (d2[n]) { e2[n] = ld_once<NT>(ez + n * Ez.ks); j2[n] = ld_once<NT>(jz + n * Jz.ks); }
+        }
+        asm volatile("" : "+v"(bxv[0]), "+v"(byv[0]));   // as in evolve_b_kernel: one wait for the loads, in front of the stores
+#pragma unroll
+        for (int n = 0; n < KC; ++n)
+            asm volatile("" : "+v"(bxv[n + 1]), "+v"(byv[n + 1]), "+v"(bzc[n]), "+v"(bzj[n]), "+v"(bzi[n]), "+v"(bxj[n]),
+                              "+v"(byi[n]), "+v"(e0[n]), "+v"(e1[n]), "+v"(e2[n]), "+v"(j0[n]), "+v"(j1[n]), "+v"(j2[n]));
+#pragma unroll
+        for (int n = 0; n < KC; ++n) {
+            if (d0[n]) st_once<NT>(ex + n * Ex.ks, e0[n] + c2 * dt * (-(idz * (byv[n + 1] - byv[n])) + (idy * (bzc[n] - bzj[n])) - mu0 * j0[n]));
+            if (d1[n]) st_once<NT>(ey + n * Ey.ks, e1[n] + c2 * dt * (-(idx * (bzc[n] - bzi[n])) + (idz * (bxv[n + 1] - bxv[n])) - mu0 * j1[n]));
+            if (d2[n]) st_once<NT>(ez + n * Ez.ks, e2[n] + c2 * dt * (-(idy * (bxv[n + 1] - bxj[n])) + (idx * (byv[n + 1] - byi[n])) - mu0 * j2[n]));
+        }
+        return;
+    }
     double bx_km = ld_shared<NT>(bx - Bx.ks), by_km = ld_shared<NT>(by - By.ks);
 #pragma unroll 4
     for (int k = k0; k < k1; ++k) {
@@ -166,7 +243,9 @@ evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, D
 //   2 x 4 plain 0.2290 / 0.3060 ms (65.9 / 65.8 %)   2 x 4 NT 0.2204 / 0.2866 (68.5 / 70.2)   1 x 4 NT 0.2188 / 0.2865
 //   1 x 3 NT 0.2146 / 0.2803 (70.3 / 71.8)   1 x 2 NT 0.2214 / 0.2866   4 x 2 NT 0.2294 / 0.2897
 //   NT on the shared operand too: 0.2633 / 0.3088 (57 / 65)   256-lane rows (TW = 4): 0.325 / 0.372 (46 / 54)
-using StProduction = StencilCfg<1, 1, 3, 1>;
+//   Round 4 (profiles/round4/r4b_stencil_loads_before_stores.txt, same box, two rounds): every load ahead of the first store
+//   (BATCH) 0.2414 -> 0.2326 / 0.3081 -> 0.3031 ms (62.5 -> 64.9 / 65.3 -> 66.4 %); two planes per lane the same.
+using StProduction = StencilCfg<1, 1, 3, 1, 1>;
 using StPlain = StencilCfg<1, 2, 4, 0>;   // the thin guard-layer launches (wxa_evolve_b_guard_layer): plain moves
 #ifdef WXA_DEV_VARIANTS   // the sweep above: WXA_STENCIL_VARIANT=<n> per launch (scripts/stencil_variants.py, dev builds only)
 using St1 = StencilCfg<1, 2, 4, 1>;
@@ -175,6 +254,8 @@ using St4 = StencilCfg<1, 1, 2, 1>;
 using St5 = StencilCfg<1, 4, 2, 1>;
 using St6 = StencilCfg<1, 1, 3, 2>;
 using St7 = StencilCfg<4, 1, 4, 1>;
+using St8 = StencilCfg<1, 1, 3, 1, 0>;   // production until round 3: load -> wait -> store, plane by plane
+using St9 = StencilCfg<1, 1, 2, 1, 1>;   // ... two planes per lane (fewer registers, more waves)
 static int stencil_variant() {
     const char* e = getenv("WXA_STENCIL_VARIANT");
     return e ? atoi(e) : -1;
@@ -188,6 +269,8 @@ static int stencil_variant() {
         case 5: CALL(St5); break;           \
         case 6: CALL(St6); break;           \
         case 7: CALL(St7); break;           \
+        case 8: CALL(St8); break;           \
+        case 9: CALL(St9); break;           \
         default: CALL(StProduction); break; \
     }
 #else
