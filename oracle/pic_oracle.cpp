@@ -2355,6 +2355,9 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
         }
         s->istep++;
         s->cur_time += s->dt;
+        // WarpXEvolve.cpp:241 multi_diags->FilterComputePackFlush(step, false, true): the BackTransformed diagnostics run
+        // before the window moves and before the particles meet the boundaries (MultiDiagnostics.cpp:81-96)
+        if (!s->btd.empty()) btd_compute_and_pack(s);
         move_window(s, /*move_j=*/s->is_synchronized);   // :246 MoveWindow(step+1, move_j)
         for (auto& L : s->lasers) {
             // lasers are particle containers too (MultiParticleContainer::ApplyBoundaryConditions loops over all of them,
@@ -2407,7 +2410,6 @@ int orc_sim_evolve(orc_sim* s, int32_t numsteps) {
             }
         }
         rd_compute_and_write(s, (int)s->istep - 1);     // WarpXEvolve.cpp:299-305
-        if (!s->btd.empty()) btd_compute_and_pack(s);   // WarpXEvolve.cpp:306 multi_diags->FilterComputePackFlush(step)
     }
     return 0;
 }

@@ -120,3 +120,31 @@ def continuity_residual(lib, device, order, ncell, nparts=3000, seed=33):
     div = dxJ[:, 1:B, 1:Cc] + dyJ[1:A, :, 1:Cc] + dzJ[1:A, 1:B, :]
     drho = (rn - ro)[1:A, 1:B, 1:Cc] / dt
     return float(np.max(np.abs(drho + div)) / np.max(np.abs(drho)))
+
+
+def btd_snapshot_checksum(sim, i, species_names, masses):
+    """The reference's checksum (Regression/Checksum/checksum.py: sum of |values| per field over level 0, per particle
+    quantity over a species; momenta as m u like the plotfile holds them) of lab-frame snapshot i of a BackTransformed
+    diagnostic, from the snapshot as the library keeps it in memory."""
+    out = {"lev=0": {name: float(np.abs(sim.btd_snapshot(i, name)).sum()) for name in sim.BTD_COMPONENTS}}
+    for sid, (name, m) in enumerate(zip(species_names, masses)):
+        p = sim.btd_particles(i, sid)
+        if p.shape[1] == 0:
+            continue   # a species without particles in the snapshot has no entry in the reference's file
+        out[name] = {"particle_position_x": float(np.abs(p[0]).sum()), "particle_position_y": float(np.abs(p[1]).sum()),
+                     "particle_position_z": float(np.abs(p[2]).sum()), "particle_weight": float(np.abs(p[3]).sum()),
+                     "particle_momentum_x": float(np.abs(p[4]).sum() * m), "particle_momentum_y": float(np.abs(p[5]).sum() * m),
+                     "particle_momentum_z": float(np.abs(p[6]).sum() * m)}
+    return out
+
+
+def compare_btd_with_golden(got, gold):
+    """Every value of the golden file within its tolerance (gold["rtol"][group][key]); the groups must be the same."""
+    assert sorted(got) == sorted(gold["checksums"]), (sorted(got), sorted(gold["checksums"]))
+    worst = {}
+    for group, vals in gold["checksums"].items():
+        for key, want in vals.items():
+            rel = abs(got[group][key] - want) / abs(want)
+            assert rel <= gold["rtol"][group][key], (group, key, got[group][key], want, rel)
+            worst[group] = max(worst.get(group, 0.0), rel)
+    return worst

@@ -197,6 +197,8 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // used on wave-uniform values only
 #define WXA_OPAQUE_F64(v) asm volatile("" : "+x"(v))
 #define WXA_WAVES_PER_SIMD(n)
+#define WXA_LATE_KERNARG(T, first_param) (&(first_param))
+#define WXA_OPAQUE_UNIFORM_F64(v)
 // the inline-asm LDS reads of gather_body.hpp: plain loads here, nothing to wait for
 typedef const char* wxa_lds_addr;
 #define WXA_LDS_ADDR(p) ((const char*)(p))
@@ -214,6 +216,8 @@ inline double swap_add_halves(const double v_lo_planes, const double v_hi_planes
     return (threadIdx.x & 32) ? phi + v_hi_planes : v_lo_planes + plo;
 }
 inline int partner32(const int v) { return __shfl_xor(v, 32); }
+#define WXA_HAVE_LANE_XOR1
+inline double lane_xor1(const double v) { return __shfl_xor(v, 1); }
 }
 
 // HIP's unqualified min / max over mixed integer types

@@ -118,6 +118,7 @@ __device__ inline long xcd_tile_id(long bid, long ntiles) {
     return (bid & 7) * per + (bid >> 3);
 }
 inline long xcd_grid_size(long ntiles) { return ((ntiles + 7) / 8) * 8; }
+constexpr long WXA_NUM_CU = 256;   // MI355X: 8 XCDs x 32 CUs (persistent kernels launch one workgroup per CU)
 
 // hardware fp64 atomic add (global_atomic_add_f64 / ds_add_f64), no CAS loop
 __device__ inline void atomic_add_f64(double* addr, double v) { unsafeAtomicAdd(addr, v); }

@@ -23,6 +23,7 @@
 #include "workspace.hpp"
 
 #include <stdlib.h>
+#include <algorithm>
 
 
 namespace wxa {
@@ -113,6 +114,22 @@ __device__ unsigned long long wxa_dep_prof[16];
 #define DPROF_FINISH
 #endif
 
+// The J arrays as the kernel's FIRST parameter: offset 0 of the kernel-argument segment (WXA_LATE_KERNARG)
+struct JTriple {
+    DevF x, y, z;
+};
+#ifndef WXA_OPAQUE_UNIFORM_F64   // a wave-uniform double in an SGPR pair, opaque to the optimiser (tests/hipcpu: nothing)
+#define WXA_OPAQUE_UNIFORM_F64(v) asm volatile("" : "+s"(v))
+#endif
+#ifndef WXA_LATE_KERNARG   // tests/hipcpu: the parameter itself
+#define WXA_LATE_KERNARG(T, first_param)                                                                         \
+    ([]() {                                                                                                      \
+        auto p_ = (const T __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();           \
+        asm volatile("" : "+s"(p_));                                                                             \
+        return (const T*)p_;                                                                                     \
+    }())
+#endif
+
 struct TileGeom {
     int nt[3];        // tiles per direction
     int cell_lo[3];   // global index of the brick's first cell
@@ -164,8 +181,28 @@ constexpr int FUSED_GNPTS = FUSED_GN * FUSED_GN * FUSED_GN;
 // particle) | E write-back.  Cells with more than 8 + 2 RT particles hand the rest to the deferred list as well.
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
 template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, class ACC_ = double, int BW_ = 0,
-          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0, int FUSED_ = 0, int PUSHER_ = WXA_PUSHER_BORIS>
+          int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0, int FUSED_ = 0, int PUSHER_ = WXA_PUSHER_BORIS,
+          int HF_ = 0, int PT_ = 0, int GIDX_ = 0>
 struct RowsCfg {
+    // GIDX: the direct chunks read their cell's first particle and count from the sort's offsets[] in global memory
+    // (vmcnt) instead of from the LDS copy: an LDS read at the top of a chunk returns behind whatever the CU's waves
+    // have queued on the LDS-atomic pipe (lgkmcnt counts the wave's own atomics too), and the fourteen particle loads
+    // cannot be issued before it is back
+    static constexpr int GIDX = GIDX_;
+    // PT (persistent tiles): one workgroup per CU works through the tiles of its XCD's range (claimed through a counter per
+    // XCD; other XCDs' ranges once its own is done) instead of one workgroup per tile.  With 145 KB of LDS a CU holds one
+    // workgroup, so every tile paid a workgroup launch after the previous one had retired, i.e. after its last global
+    // atomic had come back; here the flush's atomics drain behind the next tile's phases A-C, and the flush leaves the
+    // tile zeroed (read + clear by the same lane), so only a workgroup's first tile needs the zero fill of phase A.
+    static constexpr int PT = PT_;
+    // HF (hole filling): an empty slot of the direct part -- lane (r, c) of a cell with fewer than r + 1 pairs -- takes a
+    // pair beyond the fourth of another cell of the SAME bank class (cell index mod BW: the same lane position, the same
+    // LDS banks), matched by rank inside the class; only what the class's holes cannot take goes to the tail table.  At
+    // 8 per cell (Poisson) the direct part has 10.7 % of its slots empty and the tail holds 0.69 pairs per cell: 38 chunks
+    // per tile become ~35, i.e. three rounds of the workgroup's 12 waves instead of three and a fourth with two waves
+    // working (wave 0 idles 22 % of phase C, profiles/round3/README.md), and a cell's late pairs are read while their
+    // cache lines are still near (the tail table re-read them ~40 chunks later: 1.5 x the algorithmic HBM traffic).
+    static constexpr int HF = HF_;
     static constexpr int FUSED = FUSED_, PUSHER = PUSHER_;   // gather + push inside the chunk loop (FusedArgs)
     // DYN: the chunks of phase C are handed out through an LDS counter instead of chunk = wave + k WAVES: the SIMD's
     // issue arbiter favours its oldest waves, so with equal static shares the youngest waves of every SIMD finish last and
@@ -190,12 +227,12 @@ struct NullSink {   // DBG = 1: keeps every deposited value alive without touchi
 
 template <int O, int M, class CFG>
 __global__ void __launch_bounds__(CFG::NT) WXA_WAVES_PER_SIMD(CFG::WPE)
-deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restrict__ py_,
+deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const double* __restrict__ py_,
                          const double* __restrict__ pz_, const double* __restrict__ pw_,
                          const double* __restrict__ pux_, const double* __restrict__ puy_,
-                         const double* __restrict__ puz_, const int* __restrict__ offsets, DevF Jx, DevF Jy,
-                         DevF Jz, Geom g, TileGeom tg, double q, EsirkepovStep es, double relative_time,
-                         StragglerQueue sq, FusedArgs fa) {
+                         const double* __restrict__ puz_, const int* __restrict__ offsets, Geom g_, TileGeom tg, double q_,
+                         EsirkepovStep es_, double relative_time_, StragglerQueue sq, FusedArgs fa,
+                         unsigned* __restrict__ tile_ctr) {
     constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
     constexpr bool FUSED = CFG::FUSED != 0;
     static_assert(!FUSED || (O == 3 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && CFG::TSZ == TS && sizeof(typename CFG::ACC) == 8),
@@ -223,6 +260,12 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
     __shared__ unsigned long long masks[RT][CW];
     __shared__ int cstart[CELLS + 1];
     __shared__ unsigned short table[TCAP];
+    constexpr bool HF = CFG::HF != 0;
+    constexpr int NCLS = BW, MEM = CELLS / BW;          // bank classes of the cells (cell mod BW) and cells per class
+    static_assert(!HF || (MEM >= 2 && MEM <= 64 && (MEM & (MEM - 1)) == 0 && !FUSED), "hole filling: a class is a power-of-two lane segment");
+    constexpr unsigned short NOFILL = 0xFFFFu;
+    __shared__ unsigned short slot[HF ? 4 : 1][HF ? CELLS : 1];   // hole (r, c) of the direct part -> (cell | row << 9) that fills it
+    __shared__ unsigned short fill[HF ? 4 * CELLS : 1];           // per class: its pairs beyond the fourth, by rank
     // particles with a cell crossing or without a partner (wide body), bucketed by the LDS bank of their wide frame:
     // phase D takes lane l's particle from bucket l % 16, so the 16 lanes of a ds_add_f64 step sit on 16 different banks
     // like the lanes of phase C (the single list it replaces cost 2-3 LDS cycles per step in conflicts: the list
@@ -237,18 +280,60 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
     constexpr int DKEEP = FUSED ? 0 : sizeof(ACC) == 8 ? 48 : 16;   // 16 x 48 x 56 B = 42 KB next to the 89 KB tile
     __shared__ double dkeep[7][FUSED ? 1 : NBANK * DKEEP];
     __shared__ double F[FUSED ? 6 * FUSED_GNPTS : 1];   // FUSED: Ex Ey Ez Bx By Bz of the tile + halo
+    constexpr bool PT = CFG::PT != 0;
+    static_assert(!PT || !FUSED, "persistent tiles: the deposition kernels");
+    __shared__ long unit_s;
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
-    const long unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
-    if (unit >= ntiles * SUB) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    DPROF_INIT
+    bool first_tile = true;        // PT: the tile has to be zeroed by phase A (later ones are left zeroed by the flush)
+    unsigned xcd_done = 0;         // PT, thread 0: XCD ranges found exhausted
+  for (;;) {
+    long unit;
+    if constexpr (PT) {
+        if (tid == 0) {
+            const long nunits = ntiles * SUB, per = (nunits + 7) / 8;
+            long u = -1;
+            for (int t = 0; t < 8 && u < 0; ++t) {
+                const int x = (int)((blockIdx.x + t) & 7);
+                if (xcd_done & (1u << x)) continue;
+                const long v = (long)atomicAdd(&tile_ctr[x], 1u);
+                if (v < per && x * per + v < nunits) u = x * per + v;
+                else xcd_done |= 1u << x;
+            }
+            unit_s = u;
+        }
+        __syncthreads();   // the claim; and the previous tile's flush (which reads and clears the tile) before this tile's phase A
+        unit = unit_s;
+        if (unit < 0) break;
+    } else {
+        unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
+        if (unit >= ntiles * SUB) return;
+    }
+    // PT: the launch's uniform doubles are made opaque per tile.  Anything derived from them would otherwise be hoisted
+    // out of the tile loop into VGPR pairs (there is no scalar fp64 unit) that stay live through every phase of every
+    // tile: 168 VGPRs + 108 B of scratch against 151 without the loop.
+    Geom g = g_;
+    EsirkepovStep es = es_;
+    double q = q_, relative_time = relative_time_;
+    if constexpr (PT) {
+        WXA_OPAQUE_UNIFORM_F64(g.xmin); WXA_OPAQUE_UNIFORM_F64(g.ymin); WXA_OPAQUE_UNIFORM_F64(g.zmin);
+        WXA_OPAQUE_UNIFORM_F64(g.dxi); WXA_OPAQUE_UNIFORM_F64(g.dyi); WXA_OPAQUE_UNIFORM_F64(g.dzi);
+        WXA_OPAQUE_UNIFORM_F64(es.t_half);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { WXA_OPAQUE_UNIFORM_F64(es.dtdx[d]); WXA_OPAQUE_UNIFORM_F64(es.invdtd[d]); }
+        WXA_OPAQUE_UNIFORM_F64(q); WXA_OPAQUE_UNIFORM_F64(relative_time);
+    }
     const long tile = unit / SUB;
     const int half = (int)(unit % SUB);
     const long ucell0 = tile * TILE_CELLS + half * CELLS;
     const int start = offsets[ucell0];
     const int end = offsets[ucell0 + CELLS];
-    if (end <= start) return;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    DPROF_INIT
+    if (end <= start) {
+        if constexpr (PT) { __syncthreads(); continue; }   // unit_s is read by everyone before thread 0 claims again
+        else return;
+    }
     constexpr int DCAP = DEFER / NBANK;
     auto defer = [&](const int ip, const int bank) {   // phase B: by index only (the particle has not been loaded)
         const int n = atomicAdd(&ndef[bank], 1);
@@ -290,13 +375,17 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
         cstart[tid] = my_s;
         if (tid == CELLS - 1) cstart[CELLS] = my_s + my_n;
         my_pairs = min((my_n + 1) >> 1, RMAX);
+        if constexpr (!HF) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            my_mask[r] = __ballot(my_pairs > 4 + r);
-            if (lane == 0) masks[r][wave] = my_mask[r];
+            for (int r = 0; r < RT; ++r) {
+                my_mask[r] = __ballot(my_pairs > 4 + r);
+                if (lane == 0) masks[r][wave] = my_mask[r];
+            }
         }
     }
-    for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = (ACC)0;
+    if (!PT || first_tile)
+        for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = (ACC)0;
+    first_tile = false;
     if constexpr (FUSED) {
         // the six staggered components of the tile + halo, all of a lane's loads in flight before its first LDS write
         const int ti_ = (int)(tile % tg.nt[0]), tj_ = (int)((tile / tg.nt[0]) % tg.nt[1]);
@@ -328,7 +417,52 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
     __syncthreads();
     DPROF(0);
     // ---- B: scan of the 64 (row, cell-wave) counts, item table
-    if (tid < CELLS) {
+    if constexpr (HF) {
+        // lane p = (class b, member m) holds cell c = m BW + b: the MEM cells of a class are MEM consecutive lanes, the
+        // ranks of their holes and of their pairs beyond the fourth are two segmented wave scans
+        int c = 0, pairs = 4, holes = 0, over = 0, hpre = 0, opre = 0, htot = 0, otot = 0, cs = 0, cn = 0;
+        const int b = tid / MEM, m = tid % MEM;
+        if (tid < CELLS) {
+            c = m * BW + b;
+            cs = cstart[c];
+            cn = cstart[c + 1] - cs;
+            pairs = (cn + 1) >> 1;
+            holes = max(0, 4 - pairs);
+            over = min(max(0, pairs - 4), RT);
+            int hi = holes, oi = over;
+#pragma unroll
+            for (int d = 1; d < MEM; d <<= 1) {
+                const int vh = __shfl_up(hi, d, MEM), vo = __shfl_up(oi, d, MEM);
+                if (m >= d) { hi += vh; oi += vo; }
+            }
+            htot = __shfl(hi, MEM - 1, MEM); otot = __shfl(oi, MEM - 1, MEM);
+            hpre = hi - holes; opre = oi - over;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                if (t < over) {
+                    const unsigned short ent = (unsigned short)(c | ((4 + t) << 9));
+                    const int qq = opre + t;
+                    if (qq < htot) {
+                        fill[b * (4 * MEM) + qq] = ent;
+                    } else {
+                        const int at = atomicAdd(&nitems, 1);
+                        if (at < TCAP) table[at] = ent;
+                        else {   // any bucket is correct; the cell's place in the sort order is the bank of a particle that stayed
+                            defer_unloaded(cs + 2 * (4 + t), c & (NBANK - 1));
+                            if (2 * (4 + t) + 1 < cn) defer_unloaded(cs + 2 * (4 + t) + 1, c & (NBANK - 1));
+                        }
+                    }
+                }
+            }
+            for (int k = 2 * RMAX; k < cn; ++k) defer_unloaded(cs + k, c & (NBANK - 1));   // beyond the table's rows (> 2 RMAX particles in a cell)
+        }
+        __syncthreads();
+        if (tid < CELLS) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < holes) slot[pairs + t][c] = (hpre + t < otot) ? fill[b * (4 * MEM) + hpre + t] : NOFILL;
+        }
+    } else if (tid < CELLS) {
         const int cnt = __popcll(masks[lane / CW][lane % CW]);
         int incl = cnt;
 #pragma unroll
@@ -363,7 +497,7 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
     const int o1 = tg.cell_lo[1] + tj * TS + TD::LO;
     const int o2 = tg.cell_lo[2] + tk * TS + half * TSZ + TD::LO;
     // ---- C: the chunks (NB blocks of 16 cells x 4 pairs, then the tail table)
-    const int T = nitems;
+    const int T = min(nitems, TCAP);
     constexpr bool COOP = CFG::COOP != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && (O % 2) == 1 && sizeof(ACC) == 8;
     constexpr int TPC = COOP ? 32 : 64;   // tail items per chunk: with COOP the upper half of the wave only assists
 #ifdef WXA_DEPOSIT_PROFILE
@@ -385,13 +519,22 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
         bool va;
         if (ch < NB) {
             c = BW * (ch / (4 / RPC)) + (lane % BW); r = RPC * (ch % (4 / RPC)) + lane / BW; va = true;
+            if constexpr (HF) {
+                if (2 * r >= cstart[c + 1] - cstart[c]) {   // a hole: the pair of its class that fills it, if any
+                    const unsigned ent = slot[r][c];
+                    va = ent != NOFILL;
+                    c = va ? (int)(ent & 511u) : c; r = va ? (int)(ent >> 9) : r;
+                }
+            }
         } else {
             const int I = (ch - NB) * TPC + (lane & (TPC - 1));
             va = I < T && lane < TPC;
             const unsigned ent = va ? table[I] : 0u;
             c = (int)(ent & 511u); r = (int)(ent >> 9);
         }
-        const int s0 = cstart[c], n0 = cstart[c + 1] - s0;
+        int s0, n0;
+        if (CFG::GIDX != 0 && ch < NB) { s0 = offsets[ucell0 + c]; n0 = offsets[ucell0 + c + 1] - s0; }
+        else { s0 = cstart[c]; n0 = cstart[c + 1] - s0; }
         va = va && 2 * r < n0;
         const int ia = va ? s0 + 2 * r : start;
         bool vb = va && 2 * r + 1 < n0;
@@ -603,13 +746,17 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
     }
     __syncthreads();
     DPROF(3);
-    const DevF* Jc[3] = {&Jx, &Jy, &Jz};
+    // PT: the three array descriptors (36 SGPRs) are read from the kernel-argument segment here, per tile: as loop
+    // invariants they stayed in SGPRs through the whole tile loop, the kernel ran out of them (106) and spilled into VGPRs
+    const JTriple* jt = &J3;
+    if constexpr (PT) jt = WXA_LATE_KERNARG(JTriple, J3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const DevF& J = *Jc[c];
+        const DevF J = c == 0 ? jt->x : c == 1 ? jt->y : jt->z;
         for (int a = tid; a < NPTS; a += NT) {
             const double v = (double)lds[c * NPTS + a];
             if (v != 0.0) {
+                if constexpr (PT) lds[c * NPTS + a] = (ACC)0;
                 const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
                 if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
                     k < J.lo2 + J.n2)
@@ -618,6 +765,8 @@ deposit_tile_rows_kernel(const double* __restrict__ px_, const double* __restric
         }
     }
     DPROF(4);
+    if constexpr (!PT) break;
+  }
     DPROF_FINISH
 }
 
@@ -667,16 +816,19 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
     const long nunits = (long)tg.nt[0] * tg.nt[1] * tg.nt[2] * (TS / CFG::TSZ);
     const Geom g = make_geom(*geom);
     const int* offsets = (const int*)ws->offsets.p;
-    const dim3 grid((unsigned)xcd_grid_size(nunits)), block(CFG::NT);
+    // persistent tiles: one workgroup per CU (WXA_NUM_CU; more would only queue behind the LDS), tiles through tile_ctr
+    const dim3 grid((unsigned)(CFG::PT ? std::min<long>(xcd_grid_size(nunits), WXA_NUM_CU) : xcd_grid_size(nunits))), block(CFG::NT);
     wxa_status rc;
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
     if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
     StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
+    unsigned* tile_ctr = (unsigned*)ws->counters.p + 96;   // words of ws->counters: see particles.hip (0 deposit, 16 gather, 32 classify, 48 walls, 56 injection, 64..90 destinations); 96..103: tile claims per XCD
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
+    if (CFG::PT) WXA_HIP_CHECK(hipMemsetAsync(tile_ctr, 0, 8 * sizeof(unsigned), st));
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
-    hipLaunchKernelGGL((deposit_tile_rows_kernel<O, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, relative_time, sq, FusedArgs{});
+    hipLaunchKernelGGL((deposit_tile_rows_kernel<O, MARGIN, CFG>), grid, block, 0, st, JTriple{jx, jy, jz}, p->x, p->y, p->z, p->w,
+                       p->ux, p->uy, p->uz, offsets, g, tg, q, es, relative_time, sq, FusedArgs{}, tile_ctr);
     hipLaunchKernelGGL((deposit_stragglers_kernel<O, CFG::ALGO>), dim3(512), dim3(256), 0, st, p->x, p->y,
                        p->z, p->w, p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
     WXA_LAUNCH_CHECK();
@@ -700,6 +852,12 @@ using RowsB32Coop = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 
 using RowsW10 = RowsCfg<640, 8, 3, 1, 0, double, 32>;   // 30: 10 waves -- 38 chunks of a tile in 4 rounds of 10 instead of 12
 using RowsW11 = RowsCfg<704, 8, 3, 1, 0, double, 32>;   // 31: 11 waves
 using RowsDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1>;   // 40: chunks through an LDS counter
+using RowsHFPT = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 1, 1>;   // 62: hole filling + persistent tiles
+using RowsPT = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 1>;   // 63: persistent tiles alone
+using RowsHF = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 1, 0>;   // 64: hole filling alone
+using RowsGIdx = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 1>;   // 65: chunk indices from global memory
+using RowsGIdxDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 0, 0, 1>;   // 66: ... + dynamic chunks
+using RowsHFDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 1>;   // 61: ... + dynamic chunks
 using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
 using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
 #endif
@@ -748,8 +906,8 @@ static wxa_status launch_fused(const wxa_particle_view* p, const wxa_field_view 
     WXA_HIP_CHECK(hipMemsetAsync(fa.gq.count, 0, sizeof(unsigned), st));
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
-    hipLaunchKernelGGL((deposit_tile_rows_kernel<3, MARGIN, CFG>), grid, block, 0, st, p->x, p->y, p->z, p->w, p->ux,
-                       p->uy, p->uz, offsets, jx, jy, jz, g, tg, q, es, relative_time, sq, fa);
+    hipLaunchKernelGGL((deposit_tile_rows_kernel<3, MARGIN, CFG>), grid, block, 0, st, JTriple{jx, jy, jz}, p->x, p->y, p->z, p->w,
+                       p->ux, p->uy, p->uz, offsets, g, tg, q, es, relative_time, sq, fa, (unsigned*)nullptr);
     // the particles the tile kernel could not push: global-memory gather + push, then their deposit
     if ((rc = gather_push_listed(p, fa.gq.idx, fa.gq.count, E, B, geom_eb, q, m, dt, CFG::PUSHER, st)) != WXA_OK) return rc;
     hipLaunchKernelGGL((deposit_stragglers_kernel<3, WXA_DEPOSIT_ESIRKEPOV>), dim3(512), dim3(256), 0, st, p->x, p->y,
@@ -788,6 +946,12 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                 case 30: return launch_rows<3, RowsW10>(p, J, geom, q, dt, relative_time, ws, st);
                 case 31: return launch_rows<3, RowsW11>(p, J, geom, q, dt, relative_time, ws, st);
                 case 40: return launch_rows<3, RowsDyn>(p, J, geom, q, dt, relative_time, ws, st);
+                case 62: return launch_rows<3, RowsHFPT>(p, J, geom, q, dt, relative_time, ws, st);
+                case 63: return launch_rows<3, RowsPT>(p, J, geom, q, dt, relative_time, ws, st);
+                case 64: return launch_rows<3, RowsHF>(p, J, geom, q, dt, relative_time, ws, st);
+                case 65: return launch_rows<3, RowsGIdx>(p, J, geom, q, dt, relative_time, ws, st);
+                case 66: return launch_rows<3, RowsGIdxDyn>(p, J, geom, q, dt, relative_time, ws, st);
+                case 61: return launch_rows<3, RowsHFDyn>(p, J, geom, q, dt, relative_time, ws, st);
                 case 101: return launch_rows<3, RowsNoLds>(p, J, geom, q, dt, relative_time, ws, st);
                 case 102: return launch_rows<3, RowsNoAlu>(p, J, geom, q, dt, relative_time, ws, st);
                 default: break;

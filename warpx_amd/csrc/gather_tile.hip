@@ -70,17 +70,52 @@ struct GatherStragglers {
     __device__ __forceinline__ void push(int ip) const { idx[atomicAdd(count, 1u)] = ip; }
 };
 
-template <int PUSHER, bool MOVE>
+// ST = 1 (dev variant): lanes l and l ^ 1 hold consecutive particles; they exchange one value per pair of arrays through DPP
+// and each writes 16 bytes -- the even lane both particles' value of the first array, the odd lane both of the second:
+// three global_store_dwordx4 per lane instead of six global_store_dwordx2 (the kernel without its stores runs 1.1 ms
+// faster, profiles/round4/r4d_timing_experiments.txt; a store instruction of 8 bytes per lane costs the same issue slot
+// as one of 16).  A lane whose partner does not store (a straggler, the end of the tile) writes its own values as before.
+#ifndef WXA_HAVE_LANE_XOR1   // tests/hipcpu: a wave shuffle
+__device__ __forceinline__ double lane_xor1(const double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+#endif
+struct __attribute__((packed, aligned(8))) Pair8 { double a, b; };
+// recv = lane_xor1(odd ? a : b): the odd lane sends its a to the even one, the even lane its b
+__device__ __forceinline__ void store_pair(double* __restrict__ A, double* __restrict__ B, const int ip, const bool odd,
+                                           const double a, const double b, const double recv) {
+    Pair8 v;
+    v.a = odd ? recv : a;
+    v.b = odd ? b : recv;
+    *reinterpret_cast<Pair8*>(odd ? B + (ip - 1) : A + ip) = v;
+}
+
+template <int PUSHER, bool MOVE, int ST = 0>
 __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, double yp, double zp, double ux, double uy,
                                                double uz, double Exp, double Eyp, double Ezp, double Bxp, double Byp,
-                                               double Bzp, double q, double m, double dt, const ExtEB& ext) {
+                                               double Bzp, double q, double m, double dt, const ExtEB& ext,
+                                               const unsigned long long here = 0ull,   // ST: the lanes that store in this trip
+                                               const bool mine = true) {               // ST: ... this one among them
     add_external_fields(ext, ip, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
     push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
-    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
-    if constexpr (MOVE) {
-        update_position(xp, yp, zp, ux, uy, uz, dt);
-        p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp;
+    if constexpr (MOVE) update_position(xp, yp, zp, ux, uy, uz, dt);
+    if constexpr (ST != 0 && MOVE) {
+        // every lane of the trip takes part in the exchanges (a lane that does not store sends values nobody uses)
+        const int lane = threadIdx.x & 63;
+        const bool odd = lane & 1;
+        const double r0 = lane_xor1(odd ? ux : uy), r1 = lane_xor1(odd ? uz : xp), r2 = lane_xor1(odd ? yp : zp);
+        if (!mine) return;
+        if ((here >> (lane ^ 1)) & 1ull) {   // lane ^ 1 holds particle ip ^ 1 of the same 64-particle chunk, and stores
+            store_pair(p.ux, p.uy, ip, odd, ux, uy, r0);
+            store_pair(p.uz, p.x, ip, odd, uz, xp, r1);
+            store_pair(p.y, p.z, ip, odd, yp, zp, r2);
+            return;
+        }
     }
+    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
+    if constexpr (MOVE) { p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp; }
 }
 
 // 512 threads per tile and no global-load fallback inside (127 VGPRs at order 3): two workgroups
@@ -89,7 +124,7 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // point, even as stragglers: a particle is at most a few cells from the tile it was sorted into); 2 = only
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
-template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF>
+template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF, int ST = 0>
 __global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(G ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext) {
@@ -218,9 +253,15 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const int lo_i = min(s.jn, s.jc) - o0, hi_i = max(s.jn + NN, s.jc + NC) - 1 - o0;
         const int lo_j = min(s.kn, s.kc) - o1, hi_j = max(s.kn + NN, s.kc + NC) - 1 - o1;
         const int lo_k = min(s.ln, s.lc) - o2, hi_k = max(s.ln + NN, s.lc + NC) - 1 - o2;
-        if (!(lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N)) {
+        const bool staged = lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N;
+        unsigned long long storing = 0ull;
+        if constexpr (ST != 0) storing = __ballot(staged);   // taken while the trip's lanes are still together
+        if (!staged) {
             sq.push(ip);   // stencil leaves the staged tile: handled by gather_push_stragglers_kernel
-            continue;
+            if constexpr (ST == 0) continue;
+        }
+        if constexpr (ST != 0) {   // a lane that does not gather reads the tile's first points (its results are not stored)
+            if (!staged) { s.jn = s.jc = o0; s.kn = s.kc = o1; s.ln = s.lc = o2; }
         }
         const int jn = s.jn - o0, jc = s.jc - o0, kn = s.kn - o1, kc = s.kc - o1, ln = s.ln - o2, lc = s.lc - o2;
 #define GROWS(...)                                                                                         \
@@ -248,7 +289,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
             update_position(xp, yp, zp, ux0, uy0, uz0, dt);
             if (xp + ux0 == 1.2345e-300) p.x[ip] = yp + zp + uy0 + uz0;
         } else
-        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext);
+        push_and_store<PUSHER, MOVE, ST>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext, storing, staged);
 #ifdef WXA_GATHER_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GPROF_CLOCK(prof_d);
@@ -337,12 +378,16 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         const char* e = getenv("WXA_GATHER_RB");
         const char* epf = getenv("WXA_GATHER_PF");
         const int pf = epf ? atoi(epf) : WXA_GATHER_PF;
+        const char* est = getenv("WXA_GATHER_ST");
+        const int stv = est ? atoi(est) : 0;
         if (e && galerkin && order == 3) {
 #define WXA_GT_RB(RBV)                                                                                          \
     do {                                                                                                        \
         if (pf == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 1>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 2) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 2>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        else if (pf == 3 && stv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 1>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 3) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \

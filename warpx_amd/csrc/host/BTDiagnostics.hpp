@@ -8,7 +8,9 @@
 //   BackTransformFunctor::operator() (:49-149): the cell-centred fields (CellCenterFunctor: Ex .. Bz, jx .. jz, rho)
 //     sliced at z_boost with linear interpolation between the two nearest cell centres (amrex::get_slice_data with
 //     interpolate = true -- AMReX is not on disk: the rule is restated from its documented behaviour and from the
-//     half-cell exclusion of GetZSliceInDomainFlag, parity unpinned), LorentzTransformZ (:246-317), copy to index k_lab;
+//     half-cell exclusion of GetZSliceInDomainFlag; pinned since round 4 by the reference's golden file
+//     test_3d_laser_acceleration_btd.json, tests/golden/laser_acceleration_btd_3d_checksums.json), LorentzTransformZ
+//     (:246-317), copy to index k_lab;
 //   BackTransformParticleFunctor::operator() (BackTransformParticleFunctor.cpp:76-152): PackParticles below, the selection
 //     and the transform on the device (host/btd_kernels.hip).
 //   DefineFieldBufferMultiFab (:916-974), DoDump (:294-320), Flush (:1027-1137), MergeBuffersForPlotfile (:1146-1314):
@@ -149,9 +151,9 @@ public:
     // The particle half (BackTransformParticleFunctor::operator(), BackTransformParticleFunctor.cpp:76-152) for one species,
     // called by its container right after PushPX with the attributes saved before it (CopyParticleAttribs,
     // PhysicalParticleContainer.cpp:2626-2629): the particles that the snapshot's plane met during this step, in the lab
-    // frame.  The reference does this at the end of the step; here the tile is re-sorted between the push and the
-    // deposition, which would separate the particles from their saved attributes -- same positions, momenta and plane,
-    // but the in-domain test sees the domain before this step's window shift (one cell, at a snapshot's first / last slice).
+    // frame.  The reference does this in the BackTransformed pass of the diagnostics, after the step's field solve and
+    // before the window moves (WarpXEvolve.cpp:241); here the tile is re-sorted between the push and the deposition, which
+    // would separate the particles from their saved attributes -- same positions, momenta, plane and domain.
     template <class CTX>
     void PackParticles(const CTX& ctx, int species, const wxa_particle_view& p, const double* const old6[6], double t_new,
                        double dt, DeviceBuffer& scratch) {
@@ -183,7 +185,8 @@ public:
         }
     }
 
-    // Diagnostics::ComputeAndPack (Diagnostics.cpp:558-608) for this diagnostic, once per step after the step
+    // Diagnostics::ComputeAndPack (Diagnostics.cpp:558-608) for this diagnostic, once per step: after the field solve and
+    // the time update, BEFORE MoveWindow and the particle boundaries (WarpXEvolve.cpp:241, MultiDiagnostics.cpp:81-96)
     template <class WX>
     void ComputeAndPack(WX& wx) {
         const auto& ctx = wx.context();

@@ -290,12 +290,17 @@ public:
             ++istep;
             cur_time += dt[0];
             m_ctx.t_new = cur_time;
+            // :241 multi_diags->FilterComputePackFlush(step, false, true): the BackTransformed diagnostics, and only they,
+            // run BEFORE the window moves and before the particles meet the boundaries (MultiDiagnostics.cpp:81-96) --
+            // they see this step's domain, J where it was deposited, and rho without the plasma injected behind the shift.
+            // (Until round 4 this call sat with the other diagnostics below: found against the reference's own golden file
+            // test_3d_laser_acceleration_btd.json, whose field sums were 17 ... 97 % away.)
+            if (m_btd) m_btd->ComputeAndPack(*this);
             const bool move_j = is_synchronized;
             const int num_moved = MoveWindow(istep, move_j);     // :246 MoveWindow(step+1, move_j)
             HandleParticlesAtBoundaries(step, cur_time, num_moved);  // :256
             reduced_diags.ComputeAndWrite(*this, (int)istep - 1);   // :299-305 reduced_diags->ComputeDiags(step), WriteToFile(step)
-            if (m_btd) m_btd->ComputeAndPack(*this);             // :306 multi_diags->FilterComputePackFlush(step)
-            if (diag_hook) diag_hook((int)istep - 1, kDiagFlush);   // ... of the Full diagnostics (FullDiagnostics.hpp)
+            if (diag_hook) diag_hook((int)istep - 1, kDiagFlush);   // :306 multi_diags->FilterComputePackFlush(step): the Full diagnostics (FullDiagnostics.hpp)
         }
         m_be->stream_sync(m_ctx.stream);
         // :341-343 the forced flush of the last time step, once the run has reached the deck's max_step

@@ -202,6 +202,24 @@ private:
 // ---- the deck -> simulation builder ----------------------------------------------------------------------
 namespace inputs_detail {
 
+// Six standard normal draws for particle `index` of a gaussian_beam: a counter-based stream (splitmix64 of stream + 8 index
+// + draw), Box-Muller on pairs of 53-bit uniforms in (0, 1].  Host arithmetic only, the same for every backend.
+inline void beam_normals(uint64_t stream, uint64_t index, double n[6]) {
+    auto mix = [](uint64_t z) {
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto uniform = [&](uint64_t k) { return ((double)(mix(stream + 0xD1B54A32D192ED03ull * (8 * index + k)) >> 11) + 1.0) * (1.0 / 9007199254740992.0); };
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int k = 0; k < 3; ++k) {
+        const double r = std::sqrt(-2.0 * std::log(uniform(2 * k))), t = two_pi * uniform(2 * k + 1);
+        n[2 * k] = r * std::cos(t);
+        n[2 * k + 1] = r * std::sin(t);
+    }
+}
+
 inline int axis_of(const std::string& w, const std::string& key) {
     if (w == "x") return 0;
     if (w == "y") return 1;
@@ -460,6 +478,24 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         pp.ignore("warpx.moving_window_dir");
         pp.ignore("warpx.moving_window_v");
     }
+    // warpx.zmax_plasma_to_compute_max_step (WarpX.cpp:636-640; WarpX::computeMaxStepBoostAccelerator,
+    // WarpXInitData.cpp:820-855): max_step = the step at which the lower end of the (boosted-frame) domain passes the end
+    // of the plasma, given in the lab frame; replaces the deck's max_step
+    {
+        double zmax_plasma = 0.0;
+        if (pp.queryWithParser("warpx.zmax_plasma_to_compute_max_step", zmax_plasma)) {
+            if (!do_moving_window || window_dir != 2)
+                throw std::runtime_error("inputs: Can use zmax_plasma_to_compute_max_step only if moving window along z.");
+            const double len_plasma_boost = zmax_plasma / gamma_boost;
+            const double v_plasma_boost = -beta_boost * 299'792'458.;
+            const double zmin_domain_boost_step_0 = cfg.prob_lo[2];                       // WarpXInitData.cpp:529-531
+            const double interaction_time_boost = (len_plasma_boost - zmin_domain_boost_step_0) / (wx.moving_window_v - v_plasma_boost);
+            info.max_step = static_cast<int>(interaction_time_boost / wx.getdt(0));
+        }
+        int from_btd = 0;
+        if (pp.queryWithParser("warpx.compute_max_step_from_btd", from_btd) && from_btd)
+            throw std::runtime_error("inputs: warpx.compute_max_step_from_btd is not on this path");
+    }
 
     // ---- external fields on the grid (WarpXInitData.cpp:940-1060) ----
     using warpx::fields::FieldType;
@@ -685,9 +721,79 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                 add_if_mine(pos, u, q[3][i]);
             }
             pc->AppendFromHost(cols);
+        } else if (w == "gaussianbeam") {   // query_word: lower case, quotes and underscores dropped
+            // PlasmaInjector::setupGaussianBeam (PlasmaInjector.cpp:221-262) + PhysicalParticleContainer::AddGaussianBeam
+            // (PhysicalParticleContainer.cpp:503-677), 3-D: npart draws of N(x_m, x_rms) x N(y_m, y_rms) x N(z_m, z_rms),
+            // kept inside the species' bounds and the cuts, weight q_tot / (npart charge), momentum from the species'
+            // momentum distribution, optional 4- or 8-fold symmetrisation; CheckAndAddParticle maps to the boosted frame.
+            // The reference draws from AMReX's generator on the I/O rank; here every particle has its own counter-based
+            // stream (warpx.random_seed, species index, particle index), so the beam is the same on any brick layout and
+            // for the CPU and the HIP backend -- and statistically, not bit for bit, the reference's.
+            const double x_m = pp.getWithParser(name + ".x_m"), y_m = pp.getWithParser(name + ".y_m"), z_m = pp.getWithParser(name + ".z_m");
+            const double x_rms = pp.getWithParser(name + ".x_rms"), y_rms = pp.getWithParser(name + ".y_rms"), z_rms = pp.getWithParser(name + ".z_rms");
+            double cut[3] = {std::numeric_limits<double>::max(), std::numeric_limits<double>::max(), std::numeric_limits<double>::max()};
+            pp.queryWithParser(name + ".x_cut", cut[0]); pp.queryWithParser(name + ".y_cut", cut[1]); pp.queryWithParser(name + ".z_cut", cut[2]);
+            const double q_tot = pp.getWithParser(name + ".q_tot");
+            long npart = (long)pp.getWithParser(name + ".npart");
+            int do_symmetrize = 0, symmetrization_order = 4;
+            pp.queryWithParser(name + ".do_symmetrize", do_symmetrize);
+            pp.queryWithParser(name + ".symmetrization_order", symmetrization_order);
+            if (symmetrization_order != 4 && symmetrization_order != 8)
+                throw std::runtime_error("inputs: Symmetrization only supported to orders 4 or 8");
+            if (pp.contains(name + ".focal_distance")) throw std::runtime_error("inputs: " + name + ".focal_distance is not on this path");
+            if (charge == 0.0) throw std::runtime_error("inputs: " + name + ": a gaussian_beam needs a charge");
+            double blo[3], bhi[3];
+            const char* lo_keys[3] = {".xmin", ".ymin", ".zmin"};
+            const char* hi_keys[3] = {".xmax", ".ymax", ".zmax"};
+            for (int d = 0; d < 3; ++d) {
+                blo[d] = -std::numeric_limits<double>::max(); bhi[d] = std::numeric_limits<double>::max();   // PlasmaInjector.cpp:70-80
+                pp.queryWithParser(name + lo_keys[d], blo[d]); pp.queryWithParser(name + hi_keys[d], bhi[d]);
+            }
+            std::string mom = "atrest";
+            pp.query_word(name + ".momentum_distribution_type", mom);
+            double um[3] = {0.0, 0.0, 0.0}, uth[3] = {0.0, 0.0, 0.0};
+            if (mom == "gaussian" || mom == "constant") {
+                const char* mk[3] = {".ux_m", ".uy_m", ".uz_m"};
+                const char* ck[3] = {".ux", ".uy", ".uz"};
+                const char* tk[3] = {".ux_th", ".uy_th", ".uz_th"};
+                for (int d = 0; d < 3; ++d) {
+                    pp.queryWithParser(name + (mom == "gaussian" ? mk[d] : ck[d]), um[d]);
+                    if (mom == "gaussian") pp.queryWithParser(name + tk[d], uth[d]);
+                }
+            } else if (mom != "atrest") {
+                throw std::runtime_error("inputs: " + name + ".momentum_distribution_type = " + mom + " is not on this path for a gaussian_beam (at_rest, constant, gaussian)");
+            }
+            std::string seed_word = "default";
+            pp.query("warpx.random_seed", seed_word);
+            const uint64_t seed = seed_word == "default" ? 1u : (seed_word == "random" ? (uint64_t)std::random_device{}() : (uint64_t)pp.evaluate(seed_word));
+            const uint64_t stream = seed * 0x9E3779B97F4A7C15ull + 1000003ull * (uint64_t)sid + 0x6A09E667F3BCC909ull;
+            if (do_symmetrize) npart /= symmetrization_order;
+            const double weight = q_tot / ((double)npart * charge);
+            for (long i = 0; i < npart; ++i) {
+                double n6[6];
+                beam_normals(stream, (uint64_t)i, n6);
+                const double x = x_m + x_rms * n6[0], y = y_m + y_rms * n6[1], z = z_m + z_rms * n6[2];
+                if (!(x < bhi[0] && x >= blo[0] && y < bhi[1] && y >= blo[1] && z < bhi[2] && z >= blo[2])) continue;
+                if (!(std::abs(x - x_m) <= cut[0] * x_rms && std::abs(y - y_m) <= cut[1] * y_rms && std::abs(z - z_m) <= cut[2] * z_rms)) continue;
+                const double u[3] = {um[0] + uth[0] * n6[3], um[1] + uth[1] * n6[4], um[2] + uth[2] * n6[5]};   // gamma beta
+                auto add = [&](double px, double py, double ux, double uy, double wgt) {
+                    const double pos[3] = {px, py, z}, uu[3] = {ux, uy, u[2]};
+                    add_if_mine(pos, uu, wgt);
+                };
+                if (do_symmetrize) {
+                    const double wn = weight / symmetrization_order;
+                    add(x, y, u[0], u[1], wn); add(x, -y, u[0], -u[1], wn); add(-x, y, -u[0], u[1], wn); add(-x, -y, -u[0], -u[1], wn);
+                    if (symmetrization_order == 8) {
+                        add(y, x, u[1], u[0], wn); add(-y, x, -u[1], u[0], wn); add(y, -x, u[1], -u[0], wn); add(-y, -x, -u[1], -u[0], wn);
+                    }
+                } else {
+                    add(x, y, u[0], u[1], weight);
+                }
+            }
+            pc->AppendFromHost(cols);
         } else {
             throw std::runtime_error("inputs: " + name + ".injection_style = " + w +
-                                     " is not on this path (NUniformPerCell, SingleParticle, MultipleParticles)");
+                                     " is not on this path (NUniformPerCell, SingleParticle, MultipleParticles, gaussian_beam)");
         }
         if (wx.sort_intervals > 0 && pc->TotalNumberOfParticles() > 0) pc->SortParticlesByBin(amrex::IntVect(1));
         info.species_names.push_back(name);
@@ -727,6 +833,11 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         int fields_on = 1, nsnap = 0, buffer = 256;
         pp.queryWithParser(d + ".do_back_transformed_fields", fields_on);
         if (!fields_on) continue;
+        {   // formats this library does not write (openpmd ...): the diagnostic is left out, like a Full one of that format
+            std::string format = "plotfile";
+            pp.query_word(d + ".format", format);
+            if (format != "plotfile") { pp.ignore_prefix(d + "."); continue; }
+        }
         if (pp.contains(d + ".intervals")) throw std::runtime_error("inputs: " + d + ".intervals is not on this path (num_snapshots_lab)");
         if (!pp.queryWithParser(d + ".num_snapshots_lab", nsnap)) throw std::runtime_error("inputs: " + d + ".num_snapshots_lab must be set");
         double dt_snap = 0.0, dz_snap = 0.0;
