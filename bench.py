@@ -77,12 +77,12 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_FILE = os.path.join("profiles", "round3", "r3_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "round4", "r4_pmc_counters.json")
 
 
 def pmc_traffic(args):
     """HBM bytes per launch of each phase's kernel from the committed rocprofv3 PMC passes (scripts/pmc_traffic.py ->
-    profiles/round3/r3_pmc_traffic.json; bench.py cannot collect PMC counters itself: they need their own rocprofv3
+    bench.PMC_TRAFFIC_FILE; bench.py cannot collect PMC counters itself: they need their own rocprofv3
     runs).  Used only when the file was collected on this workload AND on these kernel sources (its `sources_sha16`
     stamp equals kernel_sources_sha()): stale counters are dropped, not shown."""
     try:
@@ -98,8 +98,9 @@ def pmc_traffic(args):
     if rec.get("sources_sha16") != kernel_sources_sha():
         return {}, (f"the committed PMC pass ({PMC_TRAFFIC_FILE}) was taken on other kernel sources "
                     f"({rec.get('sources_sha16')} vs {kernel_sources_sha()}): dropped")
-    return ({k: (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1e9 for k, v in rec["KiB_per_dispatch"].items()},
-            f"rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE per dispatch, {PMC_TRAFFIC_FILE} (same kernel sources)")
+    traffic = {k: (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1e9 for k, v in rec["KiB_per_dispatch"].items()}
+    traffic["_sq"] = {k: v.get("derived") for k, v in rec.get("sq", {}).items() if v.get("derived")}   # read by main()
+    return traffic, f"rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE per dispatch, {PMC_TRAFFIC_FILE} (same kernel sources)"
 
 
 def energies(sim, sid):
@@ -398,6 +399,7 @@ def main():
         kernels = {}
         dominant = None
         traffic, traffic_note = pmc_traffic(args) if world == 1 else ({}, "N > 1")
+        sq_counters = traffic.pop("_sq", {})   # SQ passes of the shipped particle kernels, same file, same stamp
         micro = {} if args.no_phase_pass else stencil_microbench(sim)
         for name, (ms, cnt) in phases.items():
             if cnt == 0 or ms <= 0:
@@ -441,11 +443,22 @@ def main():
                 # conflict-free (scripts/microbench/lds_atomic_bench.hip, profiles/round3/lds_atomic_microbench.txt).
                 wave_instr = np_local / 2 * 144 / 64
                 floor_ms = wave_instr / N_CU * 8 / (CLOCK_GHZ * 1e9) * 1e3
-                roofline["limiter"] = "fp64 VALU (shape factors, ~42 % busy) + LDS pipe (ds_add_f64, ~41 % busy)"
                 roofline["lds_atomic_floor_ms"] = floor_ms
                 roofline["lds_atomic_floor_frac"] = floor_ms / k["avg_ms"]
-            elif dominant in ("GatherAndPush", "CurrentDeposition"):
-                roofline["limiter"] = "fp64 VALU + LDS pipe"
+            if dominant in ("GatherAndPush", "CurrentDeposition"):
+                d = sq_counters.get(dominant)
+                if d:   # the committed SQ passes of the kernel that ships, taken on these kernel sources
+                    roofline["limiter"] = (f"fp64 VALU {100 * d['valu_busy_frac']:.0f} % busy + LDS array "
+                                           f"{100 * d['lds_array_busy_frac']:.0f} % busy over the launch (rocprofv3 SQ passes, "
+                                           f"{PMC_TRAFFIC_FILE})")
+                    roofline["sq_counters"] = {key: d[key] for key in ("valu_busy_frac", "lds_array_busy_frac", "lds_conflict_frac",
+                                                                       "lds_array_cycles_per_lds_instruction", "wave_waiting_frac",
+                                                                       "wave_issue_stall_frac") if key in d}
+                else:
+                    roofline["limiter"] = "fp64 VALU + LDS pipe (no SQ pass on these kernel sources: " + traffic_note + ")"
+            for name, d in sq_counters.items():
+                if name in kernels:
+                    kernels[name]["sq_counters"] = d
         out = {
             "metric": "particle_steps_per_s", "value": pps, "unit": "particle-steps/s",
             "cell_updates_per_s": cps,

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 4, evidence session at HEAD (production library, no variant switch): the default bench line, the kernel trace of the
+# same command, the PMC passes (FETCH / WRITE traffic and the SQ counters of the two particle kernels, stamped with the
+# kernel sources' fingerprint), the whole -m gpu suite, smoke.
+#   gpurun --timeout 2400 -- 'bash scripts/gpu_round4_f.sh'
+set -u
+OUT=$(pwd)/gpurun_out/r4f
+mkdir -p $OUT
+export TMPDIR=/tmp
+ROOTDIR=$(pwd)
+timeout 600 python scripts/pmc_traffic.py $OUT/pmc > $OUT/pmc_counters.log 2>&1
+tail -5 $OUT/pmc_counters.log; cp $OUT/pmc/r4_pmc_counters.json profiles/round4/r4_pmc_counters.json 2>/dev/null
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python -c "import json;d=json.load(open('$OUT/bench.json'));print(d['ms_per_step'],d['value'],d['roofline'],{k:round(v['avg_ms'],3) for k,v in d['kernels'].items()})"; tail -3 $OUT/bench.err
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- \
+    python $ROOTDIR/bench.py --no-cpu-baseline --no-phase-pass --no-sanity ) > $OUT/rocprof.log 2>&1
+tail -2 $OUT/rocprof.log
+for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -8 $f | cut -c1-160; cp $f $OUT/kernel_stats.csv; done
+rm -rf $OUT/prof/*/*.db $OUT/pmc/*/*/*.db $OUT/prof/*.db $OUT/pmc/*/*.db $OUT/prof/*kernel_trace.csv $OUT/pmc/*/*kernel_trace.csv 2>/dev/null
+timeout ${PYTEST_LIMIT:-1300} python -m pytest tests -m gpu -q -rf --durations=8 2>&1 | tail -30 > $OUT/pytest_gpu.txt
+tail -22 $OUT/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+du -sh $OUT

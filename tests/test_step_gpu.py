@@ -202,6 +202,7 @@ def _full_size_parity(oracle, product, n, species, steps, kw):
     so.close()
 
 
+M_PROTON = 1.67262192369e-27   # CODATA 2018, the reference's m_p
 FULL_SIZE = pytest.mark.skipif(os.environ.get("WXA_HIP_ON_CPU") == "1" and "WXA_FULL_SIZE_N" not in os.environ,
                                reason="full size: needs the GPU (WXA_FULL_SIZE_N=<n> runs it in small on the CPU model)")
 
@@ -268,6 +269,41 @@ def test_langmuir_256_against_the_oracle(oracle, product):
     kw = dict(nox=3, galerkin=1, particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
               use_filter=0, sort_interval=4)
     _full_size_parity(oracle, product, n, [(-plasma.Q_E, plasma.M_E, el), (+plasma.Q_E, plasma.M_E, po)], 6, kw)
+
+
+@FULL_SIZE
+def test_langmuir_256_electrons_and_protons_against_the_oracle(oracle, product):
+    """BASELINE.json config 3 as it is worded -- "2 species e+i": the same Langmuir wave with protons (at rest, m_p) as the
+    second species instead of positrons, 256^3 cells, 8 particles per cell and species, order 3, Esirkepov, 6 steps with a
+    sort every 4th, HIP path against the oracle stepper (same gates as the e- / e+ case above)."""
+    n = int(os.environ.get("WXA_FULL_SIZE_N", "256"))
+    n_cell = (n, n, n)
+    el, lo, hi = plasma.langmuir_3d(n_cell, ppc=(2, 2, 2), sign=+1.0)
+    io, _, _ = plasma.langmuir_3d(n_cell, ppc=(2, 2, 2), sign=-1.0)
+    for c in (4, 5, 6):
+        io[c][:] = 0.0
+    kw = dict(nox=3, galerkin=1, particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
+              use_filter=0, sort_interval=4)
+    _full_size_parity(oracle, product, n, [(-plasma.Q_E, plasma.M_E, el), (+plasma.Q_E, M_PROTON, io)], 6, kw)
+
+
+def test_back_transformed_snapshot_against_the_reference_golden_file_on_the_hip_path(product):
+    """tests/decks/laser_wakefield_btd_3d.inputs (the reference's 3-D boosted wakefield deck with back-transformed
+    diagnostics: gamma = 10, CKC, Vay, order 3, NCI corrector, moving window, PEC along z, Gaussian antenna, continuous
+    injection, Gaussian beam, max_step from warpx.zmax_plasma_to_compute_max_step) on the HIP path: lab-frame snapshot 3
+    against the reference's golden file, with the tolerances the file states (E and B 3e-5)."""
+    import json
+    from tests.helpers import btd_snapshot_checksum, compare_btd_with_golden
+    from warpx_amd.sim import WarpXSim
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = json.load(open(os.path.join(here, "golden", "laser_acceleration_btd_3d_checksums.json")))
+    sim = WarpXSim.from_inputs(product, os.path.join(here, "decks", "laser_wakefield_btd_3d.inputs"))
+    assert sim.max_step == 84
+    sim.evolve(sim.max_step)
+    got = btd_snapshot_checksum(sim, 3, ("electrons", "ions", "beam"), (plasma.M_E, M_PROTON, plasma.M_E))
+    worst = compare_btd_with_golden(got, gold)
+    print("worst relative deviation per group", worst)
+    sim.close()
 
 
 @pytest.mark.skipif(os.environ.get("WXA_HIP_ON_CPU") == "1", reason="full size: needs the GPU")
