@@ -304,20 +304,30 @@ public:
         // host read of the 27 counts, ONE count round with all neighbours, one grouped data exchange -- no second
         // classification of arrivals (edges and corners took up to three hops, each with its own blocking count
         // exchange, before).
-        const int64_t cap = np0 / 64 + 4096;   // per list; the faces of a 256^3 brick at |v| -> c send ~np / 150
-        m_lists.reserve(sizeof(int32_t) * 27 * (size_t)cap);
-        int32_t* lists = static_cast<int32_t*>(m_lists.p);
+        // per list; the faces of a 256^3 brick at |v| -> c send ~np / 150.  A thin brick of a boosted-frame run sends far
+        // more through its low z face (the plasma streams at ~ -c and the window shift moves the brick by a cell: c dt / dz
+        // of its thickness per step): a list that overflows is not fatal -- the counts are exact whatever the capacity,
+        // so the lists grow to what was counted and the scan runs again (the wrap is idempotent, nothing has been packed
+        // or retired yet); the capacity reached is kept for the following steps.
+        int64_t cap = std::max<int64_t>(m_list_cap, np0 / 64 + 4096);
+        int32_t* lists = nullptr;
         int64_t cnt[27];
         for (int64_t& c : cnt) c = 0;
-        if (np0 > 0) {
+        for (int attempt = 0; np0 > 0; ++attempt) {
+            m_lists.reserve(sizeof(int32_t) * 27 * (size_t)cap);
+            lists = static_cast<int32_t*>(m_lists.p);
             const wxa_particle_view p = m_tile.view();
             check(be->wrap_and_classify_dest(&p, 0, np0, m_ctx->prob_lo.data(), m_ctx->prob_hi.data(), periodic,
                                              m_ctx->brick_plo.data(), m_ctx->brick_phi.data(), split, lists, cap, cnt,
                                              m_ws, m_ctx->stream),
                   "wrap_and_classify_dest");
-            for (int c = 0; c < 27; ++c)
-                if (cnt[c] > cap) throw std::runtime_error("Redistribute: leaver list overflow");
+            const int64_t most = *std::max_element(cnt, cnt + 27);
+            if (most <= cap) break;
+            if (attempt > 0) throw std::runtime_error("Redistribute: leaver list overflow after the lists were grown");
+            cap = most + most / 8 + 64;
         }
+        if (np0 == 0) { m_lists.reserve(sizeof(int32_t) * 27 * (size_t)cap); lists = static_cast<int32_t*>(m_lists.p); }
+        m_list_cap = cap;
         // the distinct peers, in the same canonical order on both sides of every pair: ascending offset code on the
         // sender is descending code (the mirrored offset) on the receiver, so peers are ordered by rank instead
         struct Peer { int rank; int64_t nsend = 0, nrecv = 0; std::vector<int> codes; };
@@ -400,7 +410,10 @@ public:
             }
         }
         if (m_steps_since_sort >= 0) ++m_steps_since_sort;
-        be->stream_sync(m_ctx->stream);
+        // No stream_sync here (until round 4 every step ended with one): everything above is ordered on the compute
+        // stream -- the packs, the data exchange, the appends -- and the staging buffers belong to this container; the
+        // host runs ahead and queues the next step's kernels.  The one host wait of Redistribute is the read of the 27
+        // counts inside wrap_and_classify_dest, plus the count round on the transport's own stream.
     }
 
     // AddNParticles restricted to what injection needs: host columns x,y,z,w,ux,uy,uz appended behind the
@@ -439,6 +452,7 @@ protected:
     WarpXContext* m_ctx;
     ParticleTile m_tile, m_spare;
     DeviceBuffer m_sendbuf, m_recvbuf, m_lists, m_arrival_lists[3];
+    int64_t m_list_cap = 0;   // entries per destination list that Redistribute has grown to (0: the default sizing)
     DeviceBuffer m_btd_old[6], m_btd_scratch;   // back-transformed diagnostics: attributes before the push, selection output
 public:
     int btd_species_id = -1;                    // >= 0: this species is written by the BackTransformed diagnostic

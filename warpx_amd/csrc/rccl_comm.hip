@@ -14,6 +14,7 @@
 #include "common.hpp"
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -32,6 +33,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;   // optional (NCCL >= 2.18 API)
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -51,6 +53,7 @@ static RcclApi* rccl_api() {
             *(void**)&api.GetUniqueId = dlsym(api.dl, "ncclGetUniqueId");
             *(void**)&api.CommInitRank = dlsym(api.dl, "ncclCommInitRank");
             *(void**)&api.CommDestroy = dlsym(api.dl, "ncclCommDestroy");
+            *(void**)&api.CommSplit = dlsym(api.dl, "ncclCommSplit");
             *(void**)&api.GroupStart = dlsym(api.dl, "ncclGroupStart");
             *(void**)&api.GroupEnd = dlsym(api.dl, "ncclGroupEnd");
             *(void**)&api.Send = dlsym(api.dl, "ncclSend");
@@ -69,11 +72,16 @@ static RcclApi* rccl_api() {
 struct RcclCtx {
     RcclApi* api = nullptr;
     ncclComm_t comm = nullptr;
+    // The count round has a communicator of its own (ncclCommSplit of `comm`, all ranks, same order): RCCL runs the
+    // operations of ONE communicator in posting order whatever their streams, so on the shared communicator the 8-byte
+    // count messages of step n + 1 queued behind the data exchanges of step n that the compute stream had not reached
+    // yet -- the host, which blocks on the counts, then waited for the whole step.  Where ncclCommSplit is missing, or
+    // with WXA_RCCL_SHARED_COMM=1, ccomm == comm as before.
+    ncclComm_t ccomm = nullptr;
     int rank = 0, nranks = 1;
     bool loopback = false;        // test mode: messages to this rank go through ncclSend / ncclRecv too
     hipStream_t cstream = nullptr;   // count exchanges: their own stream -- the host waits for these 8-byte messages only,
-                                     // not for the kernels of the main stream (RCCL still runs the operations of one
-                                     // communicator in posting order: they follow the data exchanges posted before them)
+                                     // not for the kernels of the main stream
     int64_t* dcounts = nullptr;      // device staging, 2 x kMaxMsg
     int64_t* hcounts = nullptr;      // pinned host staging, 2 x kMaxMsg
     // statistics (wxa_rccl_comm_stats)
@@ -213,10 +221,10 @@ static int rccl_exchange_counts(void* vctx, int nmsg, const int32_t* send_peer, 
     WXA_NCCL(c, c->api->GroupStart());
     for (int i = 0; i < nmsg; ++i)
         if (c->loopback || send_peer[i] != c->rank)
-            WXA_NCCL_IN_GROUP(c, c->api->Send(c->dcounts + i, sizeof(int64_t), kNcclChar, send_peer[i], c->comm, c->cstream));
+            WXA_NCCL_IN_GROUP(c, c->api->Send(c->dcounts + i, sizeof(int64_t), kNcclChar, send_peer[i], c->ccomm, c->cstream));
     for (int i = 0; i < nmsg; ++i)
         if (c->loopback || recv_peer[i] != c->rank)
-            WXA_NCCL_IN_GROUP(c, c->api->Recv(c->dcounts + kMaxMsg + i, sizeof(int64_t), kNcclChar, recv_peer[i], c->comm, c->cstream));
+            WXA_NCCL_IN_GROUP(c, c->api->Recv(c->dcounts + kMaxMsg + i, sizeof(int64_t), kNcclChar, recv_peer[i], c->ccomm, c->cstream));
     WXA_NCCL(c, c->api->GroupEnd());
     WXA_HIP_RC(hipMemcpyAsync(c->hcounts + kMaxMsg, c->dcounts + kMaxMsg, sizeof(int64_t) * nmsg, hipMemcpyDeviceToHost,
                               c->cstream));
@@ -272,6 +280,15 @@ wxa_status wxa_rccl_comm_create(const char id[WXA_RCCL_ID_BYTES], int32_t rank, 
         delete c;
         return WXA_ERR_HIP;
     }
+    c->ccomm = c->comm;
+    {
+        const char* shared = getenv("WXA_RCCL_SHARED_COMM");
+        if (api->CommSplit && !(shared && shared[0] == '1')) {
+            ncclComm_t cc = nullptr;
+            // collective over the parent communicator: every rank creates its transport at the same point
+            if (api->CommSplit(c->comm, /*color=*/0, /*key=*/rank, &cc, nullptr) == 0 && cc) c->ccomm = cc;
+        }
+    }
     if (hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->dcounts, sizeof(int64_t) * 2 * kMaxMsg) != hipSuccess ||
         hipHostMalloc((void**)&c->hcounts, sizeof(int64_t) * 2 * kMaxMsg) != hipSuccess) {
@@ -279,6 +296,7 @@ wxa_status wxa_rccl_comm_create(const char id[WXA_RCCL_ID_BYTES], int32_t rank, 
         if (c->cstream) (void)hipStreamDestroy(c->cstream);
         if (c->dcounts) (void)hipFree(c->dcounts);
         if (c->hcounts) (void)hipHostFree(c->hcounts);
+        if (c->ccomm && c->ccomm != c->comm) (void)api->CommDestroy(c->ccomm);
         (void)api->CommDestroy(c->comm);
         delete c;
         return WXA_ERR_NOMEM;
@@ -298,6 +316,7 @@ void wxa_rccl_comm_destroy(wxa_comm* comm) {
     if (c->cstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream); }
     if (c->dcounts) (void)hipFree(c->dcounts);
     if (c->hcounts) (void)hipHostFree(c->hcounts);
+    if (c->ccomm && c->ccomm != c->comm) c->api->CommDestroy(c->ccomm);
     if (c->comm) c->api->CommDestroy(c->comm);
     delete c;
     comm->ctx = nullptr;
