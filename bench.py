@@ -251,6 +251,11 @@ def main():
                     help="synchronise the momenta at the end of every evolve call like WarpX::Evolve(n) does (the timed "
                          "region then contains one PushP(-dt/2) / PushP(+dt/2) pair); default: one run advanced in pieces")
     ap.add_argument("--no-sanity", action="store_true", help="skip the energy / particle-count figures around the timed steps")
+    ap.add_argument("--dry-comm", action="store_true",
+                    help="after the pre-roll, run ONLY the step's neighbour exchanges (FillBoundary E+B, SumBoundary J, "
+                         "Redistribute) on the run's own arrays and print their milliseconds next to the message counts "
+                         "and bytes, instead of the bench line: separates 'RCCL is slow' from 'the step is slow' on a "
+                         "first multi-GPU run")
     args = ap.parse_args()
 
     import torch
@@ -325,6 +330,35 @@ def main():
     if args.preroll > 0:
         sim.evolve(args.preroll)
     sim.evolve(args.warmup)
+    if args.dry_comm:
+        rccl = transport is not None and hasattr(transport, "stats")
+        if rccl:
+            transport.stats(reset=True)
+        reps = 20
+        barrier()
+        ms = sim.dry_comm(reps)
+        st = transport.stats() if rccl else None
+        vals = [ms[k] for k in ("FillBoundaryEB", "SumBoundaryJ", "Redistribute", "all_three")]
+        if world > 1:
+            t = torch.tensor(vals, dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            vals = [float(v) for v in t.tolist()]
+        if rank == 0:
+            calls = 4 * reps   # each of the three exchanges ran `reps` times alone and `reps` times in a row
+            line = {"dry_comm": True, "n_gpus": world, "bricks": list(nbricks), "cells_per_gpu": ncells_local, "particles_per_gpu": np_local,
+                    "ms_per_call_max_over_ranks": dict(zip(("FillBoundaryEB", "SumBoundaryJ", "Redistribute", "all_three"), vals)),
+                    "reps": reps, "transport": "rccl (in-library)" if rccl else ("none (one brick)" if transport is None else "torch.distributed"),
+                    "note": "host clock around a stream sync, nothing computed between the exchanges; a step issues each of the "
+                            "three once (E+B before the push, J after the deposition, particles at the end)"}
+            if st:
+                line["rank0_messages_per_exchange"] = st["n_messages"] / max(st["n_exchanges"], 1)
+                line["rank0_MB_sent_per_round_of_three"] = st["bytes_sent"] / (2 * reps) / 1e6
+                line["rank0_count_rounds"] = st["n_count_exchanges"]
+            print(json.dumps(line), flush=True)
+        sim.close()
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     e_before = energies(sim, 0) if not args.no_sanity else None
     barrier()
     t0 = time.perf_counter()

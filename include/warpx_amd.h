@@ -778,6 +778,13 @@ wxa_status wxa_sim_btd_data(wxa_sim* s, int32_t i, int32_t comp, double* out);
  * 1 CurrentDeposition, 2 SyncCurrent(filter+SumBoundary), 3 EvolveB, 4 EvolveE,
  * 5 FillBoundary, 6 Redistribute+Sort.  counts[i] = number of launches. */
 wxa_status wxa_sim_get_timers(wxa_sim* s, double ms[8], int64_t counts[8], int reset);
+/* Only the step's neighbour exchanges, on the run's own arrays and with its real message sizes, nothing computed in
+ * between: ms[0] FillBoundary of E and B at the gather's guard depth (Source/Evolve/WarpXEvolve.cpp:515-516 ->
+ * Source/Parallelization/WarpXComm.cpp:699-827), ms[1] SumBoundary of J (WarpXComm.cpp:1386-1424), ms[2] Redistribute of
+ * every species (count round + data exchange; Source/Particles/MultiParticleContainer.cpp:627-632), ms[3] the three in
+ * a row -- milliseconds per call over `reps` calls, host clock around a stream sync.  Collective: every rank of the
+ * run calls it at the same point.  E and B are unchanged; J's guard sums land in cells the next deposition zeroes. */
+wxa_status wxa_sim_dry_comm(wxa_sim* s, int32_t reps, double ms[4]);
 wxa_status wxa_sim_enable_timers(wxa_sim* s, int enable);
 
 /* ---- Reduced diagnostics: the parity metric on the device (Source/Diagnostics/ReducedDiags/) ----------------------

@@ -53,7 +53,18 @@ def main():
                    nbricks=nb, coord=coord, comm=transport.comm, overlap_halo=overlap, maxwell_solver=solver)
     assert sim.halo_overlap == bool(overlap)
     sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
-    sim.evolve(steps)
+    dry = None
+    if os.environ.get("WXA_TEST_DRY_COMM") == "1":   # bench.py --dry-comm in the middle of a run: it must not disturb it
+        sim.evolve(steps // 2)
+        before = {n: sim.field_valid(n).copy() for n in ("Ex", "Ey", "Ez", "Bx", "By", "Bz")}
+        np_before = sim.particle_view(sid).np
+        dry = sim.dry_comm(2)
+        assert all(np.array_equal(before[n], sim.field_valid(n)) for n in before), "dry_comm changed E or B"
+        assert sim.particle_view(sid).np == np_before
+        assert all(np.isfinite(v) and v >= 0.0 for v in dry.values()), dry
+        sim.evolve(steps - steps // 2)
+    else:
+        sim.evolve(steps)
     sim.compute_rho()           # charge deposition + filter + guard sum across bricks
     # ---- collect on rank 0 ----
     local = {n: sim.field_valid(n) for n in FIELDS}

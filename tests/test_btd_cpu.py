@@ -222,12 +222,19 @@ def test_btd_file_prefix_in_an_inputs_file(host_cpu, tmp_path):
     over = ("max_step=20", "diagnostics.diags_names=d1", "d1.diag_type=BackTransformed", "d1.do_back_transformed_fields=1",
             "d1.num_snapshots_lab=1", "d1.dz_snapshots_lab=18.e-6", "d1.buffer_size=8", "d1.format=plotfile",
             f"d1.file_prefix={prefix}", "d1.file_min_digits=3")
-    sim = WarpXSim.from_inputs(host_cpu, deck, overrides=over)
-    sim.evolve(20)
+    sim = WarpXSim.from_inputs(host_cpu, deck, overrides=over, diagnostics=True)
+    sim.evolve(19)
     assert len(read_plotfile(prefix + "000")["fields"]["Ey"][0, 0, :]) == 16
     with pytest.raises(Exception):
         sim.btd_snapshot(0, "Ey")            # flushed, not kept
-    sim.btd_flush()
-    sim.close()
+    sim.evolve(1)                            # the deck's max_step: the forced flush of the last time step, BTD included
+    sim.close()                              # (MultiDiagnostics::FilterComputePackFlushLastTimestep; round 4)
     pf = read_plotfile(prefix + "000")
     assert pf["fields"]["Ey"].shape[2] == 24 and pf["step"] == 20
+    # diagnostics=False (warpx_amd.write_diagnostics = 0): nothing on disk, the snapshot stays in memory
+    prefix2 = str(tmp_path / "diags2" / "lab")
+    quiet = WarpXSim.from_inputs(host_cpu, deck, overrides=over[:-2] + (f"d1.file_prefix={prefix2}", "d1.file_min_digits=3"),
+                                 diagnostics=False)
+    quiet.evolve(20)
+    assert not os.path.exists(str(tmp_path / "diags2")) and quiet.btd_snapshot(0, "Ey").shape[2] >= 24
+    quiet.close()

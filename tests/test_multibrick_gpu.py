@@ -319,6 +319,50 @@ def test_rccl_transport_loopback(product):
     tr.close()
 
 
+@pytest.mark.skipif(not H.ON_GPU, reason="RCCL needs a GPU (the CPU execution model has no transport of its own)")
+def test_rccl_count_round_does_not_wait_for_a_queued_data_exchange(product):
+    """The 2 x 2 x 2 posting pattern on the loop-back transport -- six messages each way to ONE peer (both faces of every
+    direction lead to the same rank), six distinct sizes, matched by posting order -- enqueued on a stream that is still
+    busy with a long kernel; the count round is then called on the host.  It has a communicator and a stream of its own
+    (ncclCommSplit, round 4): it returns the right counts while the data exchange has not even started, where on the
+    shared communicator it queued behind it (the host then waited for the whole step on every rank)."""
+    import ctypes as C
+    import time
+
+    import torch
+
+    from warpx_amd.distributed import RcclBrickTransport
+    tr = RcclBrickTransport(product, rank=0, nranks=1, loopback=True, timing=False)
+    sizes = [1 << 20, 3000, 77, 1 << 18, 12345, 9]
+    send = [torch.arange(n, dtype=torch.float64, device="cuda") * (i + 1) for i, n in enumerate(sizes)]
+    recv = [torch.zeros(n, dtype=torch.float64, device="cuda") for n in sizes]
+    peers = (C.c_int32 * 6)(*([0] * 6))
+    sbuf = (C.c_void_p * 6)(*[t.data_ptr() for t in send])
+    rbuf = (C.c_void_p * 6)(*[t.data_ptr() for t in recv])
+    sbytes = (C.c_int64 * 6)(*[8 * n for n in sizes])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(int(3e9))          # ~1.5 s of the stream's time in front of the exchange
+        rc = tr.comm.exchange(tr.comm.ctx, 6, peers, sbuf, sbytes, peers, rbuf, sbytes, side.cuda_stream)
+        assert rc == 0, product.last_error()
+        done = torch.cuda.Event()
+        done.record(side)
+    sv = (C.c_int64 * 6)(*[10 ** 10 + i for i in range(6)])
+    rv = (C.c_int64 * 6)(*([0] * 6))
+    t0 = time.perf_counter()
+    assert tr.comm.exchange_counts(tr.comm.ctx, 6, peers, sv, peers, rv) == 0, product.last_error()
+    waited = time.perf_counter() - t0
+    still_queued = not done.query()
+    assert list(rv) == list(sv)
+    side.synchronize()
+    for s, r in zip(send, recv):
+        assert torch.equal(s, r)
+    print(f"count round returned after {1e3 * waited:.1f} ms; data exchange still queued: {still_queued}")
+    if os.environ.get("WXA_RCCL_SHARED_COMM") != "1":
+        assert still_queued and waited < 0.5, (waited, still_queued)
+    tr.close()
+
+
 def test_back_transformed_diagnostics_on_bricks(product):
     """<diag>.diag_type = BackTransformed on the HIP path with four bricks stacked along z, the boost and window direction
     (config 5 in small, 50 steps, three lab-frame snapshots): every brick fills the slices whose plane lies in its cells,

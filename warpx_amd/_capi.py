@@ -195,6 +195,8 @@ _KERNEL_SIGS = {
 
 # the input-deck front end of the host layer (product and its CPU test build; not in the oracle)
 _INPUTS_SIGS = {
+    # the host layer's own entry points (not in the oracle stepper): the product, the CPU build of the host layer
+    "sim_dry_comm": (C.c_int, [C.c_void_p, C.c_int32, C.c_double * 4]),
     "sim_create_from_inputs": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(Comm),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "sim_max_step": (C.c_int32, [C.c_void_p]),

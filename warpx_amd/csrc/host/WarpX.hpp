@@ -7,6 +7,7 @@
 #ifndef WXA_HOST_WARPX_HPP_
 #define WXA_HOST_WARPX_HPP_
 
+#include <chrono>
 #include <functional>
 
 #include "BTDiagnostics.hpp"
@@ -304,7 +305,14 @@ public:
         }
         m_be->stream_sync(m_ctx.stream);
         // :341-343 the forced flush of the last time step, once the run has reached the deck's max_step
-        if (diag_hook && max_step >= 0 && istep == max_step) diag_hook((int)istep, kDiagLastTimestep);
+        if (max_step >= 0 && istep == max_step) FlushDiagsLastTimestep();
+    }
+    // MultiDiagnostics::FilterComputePackFlushLastTimestep (MultiDiagnostics.cpp:98-107): every diagnostic that dumps its
+    // last time step -- the Full ones through the hook, and the BackTransformed one's partly filled buffers (until round 4
+    // only the former: a deck run lost the slices since the last full buffer)
+    void FlushDiagsLastTimestep() {
+        if (diag_hook) diag_hook((int)istep, kDiagLastTimestep);
+        if (m_btd) m_btd->FlushLast(*this);
     }
     // <diag>.diag_type = Full: the plotfile writer sits above this class (FullDiagnostics.hpp installs the hook)
     static constexpr int kDiagNewIteration = 0, kDiagFlush = 1, kDiagLastTimestep = 2;
@@ -585,6 +593,33 @@ public:
         ng_depos_J = amrex::min(ng_depos_J, current[0]->nGrowVect());                     // :1417-1420
         m_comm->SumBoundary({current[0], current[1], current[2]}, ng_depos_J, /*refresh_guards=*/safe_guard_cells,
                             stream);
+    }
+
+    // Only the step's neighbour exchanges, with the run's real arrays and message sizes and nothing computed in between
+    // (bench.py --dry-comm): [0] FillBoundary of E and B with the gather's guard depth (WarpXEvolve.cpp:515-516),
+    // [1] SumBoundary of J (WarpXComm.cpp:1386-1424), [2] Redistribute of every species (one count round + the data
+    // exchange of the particles that have left since the last call: none on a repeated call), [3] the three together.
+    // Milliseconds per call, host clock around a stream sync: what a step pays for communication if nothing overlaps.
+    // E and B are unchanged by it (FillBoundary is idempotent); J's guard values are added into its valid cells, which
+    // the next step's deposition starts from zero anyway.
+    void DryComm(int reps, double ms[4]) {
+        using warpx::fields::FieldType;
+        reps = std::max(reps, 1);
+        auto timed = [&](auto&& f) {
+            sync_stream();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < reps; ++r) f();
+            sync_stream();
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+        };
+        auto J = m_fields.get_alldirs(FieldType::current_fp, 0);
+        auto fill = [&]() { FillBoundaryEB(guard_cells.ng_FieldGather); };
+        auto sum = [&]() { SumBoundaryJ(J, 0); };
+        auto redist = [&]() { for (int i = 0; i < mypc->nContainers(); ++i) mypc->GetParticleContainer(i).Redistribute(*m_comm); };
+        ms[0] = timed(fill);
+        ms[1] = timed(sum);
+        ms[2] = timed(redist);
+        ms[3] = timed([&]() { fill(); sum(); redist(); });
     }
 
     // Source/FieldSolver/WarpXPushFieldsEM.cpp:877-927

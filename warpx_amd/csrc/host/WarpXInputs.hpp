@@ -827,6 +827,10 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     pp.queryarr("warpx.reduced_diags_names", rdiag_names);
     // <diag>.diag_type = BackTransformed (BTDiagnostics::ReadParameters, BTDiagnostics.cpp:206-292): the field snapshots are
     // assembled in memory (wxa_sim_btd_info / _data); formats, species output and the other diagnostics are not produced
+    // warpx_amd.write_diagnostics = 0 (this library's own key; default 1 = what the reference does): nothing is written
+    // to disk -- no Full or reduced diagnostics, and a BackTransformed diagnostic keeps its snapshots in memory
+    int write_diagnostics = 1;
+    pp.queryWithParser("warpx_amd.write_diagnostics", write_diagnostics);
     for (const std::string& d : diag_names) {
         std::string type;
         if (!pp.query_word(d + ".diag_type", type) || type != "backtransformed") continue;
@@ -854,7 +858,7 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         // are flushed to <file_prefix><i>/ buffer by buffer as plotfiles; absent, they stay in memory.  One directory per
         // brick: the bricks of a run do not share a file.
         std::string prefix;
-        if (pp.query(d + ".file_prefix", prefix)) {
+        if (pp.query(d + ".file_prefix", prefix) && write_diagnostics) {
             int digits = 6;                                        // Diagnostics.H: m_file_min_digits
             pp.queryWithParser(d + ".file_min_digits", digits);
             std::string format = "plotfile";
@@ -870,10 +874,6 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
     // (TimeAveraged, BoundaryScraping) are output this library does not write.
     h->species_names = info.species_names;
     wx.max_step = info.max_step;
-    // warpx_amd.write_diagnostics = 0 (this library's own key; default 1 = what the reference does): the deck's Full
-    // and reduced diagnostics are not written -- for callers that only want the final state (the test-suite)
-    int write_diagnostics = 1;
-    pp.queryWithParser("warpx_amd.write_diagnostics", write_diagnostics);
     for (const std::string& d : diag_names) {
         if (!write_diagnostics) break;
         std::string type, format = "plotfile";
@@ -1041,7 +1041,8 @@ inline void add_full_diagnostic(SimHandle& h, const std::string& name, const std
         if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \
         auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
         try {                                                                                          \
-            if (h->warpx->diag_hook) h->warpx->diag_hook((int)h->warpx->getistep(), wxa::host::WarpX::kDiagLastTimestep); \
+            if (h->warpx->btd()) h->warpx->btd()->SetSpeciesNames(h->species_names);                       \
+            h->warpx->FlushDiagsLastTimestep();                                                            \
             return (RET)WXA_OK;                                                                        \
         } catch (const std::exception& e) {                                                            \
             SET_ERROR(e.what());                                                                       \

@@ -268,6 +268,17 @@ inline int sim_get_particles(SimHandle* h, int32_t id, wxa_particle_view* out) {
     return WXA_OK;
 }
 
+inline int sim_dry_comm(SimHandle* h, int32_t reps, double ms[4]) {
+    if (!h || !ms) return WXA_ERR_INVALID_ARG;
+    try {
+        h->warpx->DryComm(reps, ms);
+        return WXA_OK;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return WXA_ERR_HIP;
+    }
+}
+
 inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int reset) {
     if (!h) return WXA_ERR_INVALID_ARG;
     WarpXContext& c = h->warpx->context();
@@ -379,6 +390,12 @@ inline int sim_get_timers(SimHandle* h, double ms[8], int64_t counts[8], int res
     }                                                                                                  \
     RET PFX##sim_get_timers(SIMTYPE* s, double ms[8], int64_t counts[8], int reset) {                  \
         return (RET)wxa::host::sim_get_timers(reinterpret_cast<wxa::host::SimHandle*>(s), ms, counts, reset); \
+    }                                                                                                  \
+    RET PFX##sim_dry_comm(SIMTYPE* s, int32_t reps, double ms[4]) {                                    \
+        auto* h = reinterpret_cast<wxa::host::SimHandle*>(s);                                          \
+        int rc = wxa::host::sim_dry_comm(h, reps, ms);                                                 \
+        if (rc != 0 && h) SET_ERROR(h->error.c_str());                                                 \
+        return (RET)rc;                                                                                \
     }                                                                                                  \
     RET PFX##sim_enable_timers(SIMTYPE* s, int enable) {                                               \
         if (!s) return (RET)-1;                                                                            \

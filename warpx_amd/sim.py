@@ -294,6 +294,13 @@ class WarpXSim:
     def enable_timers(self, on=True):
         self.lib.sim_enable_timers(self._h, 1 if on else 0)
 
+    def dry_comm(self, reps=10):
+        """Only the step's neighbour exchanges on the run's own arrays (wxa_sim_dry_comm): ms per call of FillBoundary E+B,
+        SumBoundary J, Redistribute, and the three in a row.  Collective over the run's ranks."""
+        ms = (C.c_double * 4)()
+        self.lib.sim_dry_comm(self._h, int(reps), ms)
+        return {"FillBoundaryEB": ms[0], "SumBoundaryJ": ms[1], "Redistribute": ms[2], "all_three": ms[3]}
+
     def timers(self, reset=False):
         ms = (C.c_double * 8)()
         cnt = (C.c_int64 * 8)()
