@@ -26,7 +26,7 @@ def host_cpu():
 def test_which_steps_are_written(host_cpu, tmp_path):
     sim, ids = two_species_sim(host_cpu)
     sim.add_full_diag("diag1", "2", str(tmp_path / "diags" / "diag1"))
-    sim.add_full_diag("slim", "3:", str(tmp_path / "x" / "y" / "slim"), file_min_digits=4, fields=["Ez", "rho", "divE"],
+    sim.add_full_diag("slim", "3:", str(tmp_path / "x" / "y" / "slim"), file_min_digits=4, fields=["Ez", "rho", "F"],
                       write_species=False, dump_last_timestep=False)
     with pytest.raises(_capi.WxaError, match="defined twice"):
         sim.add_full_diag("slim", "1")
@@ -48,7 +48,7 @@ def test_which_steps_are_written(host_cpu, tmp_path):
     first = read_plotfile(str(tmp_path / "diags" / "diag1000000"))
     assert first["step"] == 0 and first["time"] == 0.0 and np.all(first["fields"]["Ex"] == 0.0)
     slim = read_plotfile(str(tmp_path / "x" / "y" / "slim0005"))
-    assert slim["names"] == ["Ez", "rho"] and slim["species"] == {}      # divE: left out with a warning
+    assert slim["names"] == ["Ez", "rho"] and slim["species"] == {}      # F (div E cleaning): left out with a warning
     assert np.array_equal(slim["fields"]["Ez"], last["fields"]["Ez"])
     assert abs(np.sum(np.abs(slim["fields"]["rho"])) - direct["lev=0"]["rho"]) <= 1e-12 * direct["lev=0"]["rho"]
     sim.close()
@@ -90,3 +90,29 @@ def test_a_deck_writes_the_reference_s_output_tree(host_cpu, tmp_path):
         WarpXSim.from_inputs(host_cpu, DECK, overrides=over + ["diag1.species=muons"])
     with pytest.raises(_capi.WxaError, match="intervals must be set"):
         WarpXSim.from_inputs(host_cpu, DECK, overrides=["warpx_amd.write_diagnostics=1", "diagnostics.diags_names=d2", "d2.diag_type=Full"])
+
+
+def test_div_e_and_part_per_cell_in_the_plotfile(host_cpu, tmp_path):
+    """fields_to_plot = ... divE part_per_cell (DivEFunctor.cpp, PartPerCellFunctor.cpp; round 4): part_per_cell counts
+    every macro-particle once in the cell that holds it; div E on the nodes, averaged to the cell centres, obeys the
+    discrete Gauss law of the charge-conserving deposition -- eps0 div E - rho is a constant of the run (the two species
+    start displaced from each other with E = 0, so the constant is not zero), to round-off, cell by cell."""
+    from scipy.constants import epsilon_0
+    sim, ids = two_species_sim(host_cpu)
+    fields = ["Ex", "rho", "divE", "part_per_cell"]
+    sim.add_full_diag("g", "0,6", str(tmp_path / "g"), fields=fields, write_species=False, dump_last_timestep=False)
+    sim.evolve(6)
+    a = read_plotfile(str(tmp_path / "g000000"))
+    b = read_plotfile(str(tmp_path / "g000006"))
+    assert a["names"] == fields and b["names"] == fields
+    n = sum(sim.particle_view(i).np for i in ids)
+    for pf in (a, b):
+        ppc = pf["fields"]["part_per_cell"]
+        assert np.all(ppc == np.round(ppc)) and ppc.min() >= 0 and ppc.sum() == n
+    ra = epsilon_0 * a["fields"]["divE"] - a["fields"]["rho"]
+    rb = epsilon_0 * b["fields"]["divE"] - b["fields"]["rho"]
+    scale = np.max(np.abs(b["fields"]["rho"]))
+    assert np.max(np.abs(b["fields"]["divE"])) * epsilon_0 > 1e-3 * scale          # the wave has built up a field
+    assert np.max(np.abs(ra - rb)) < 1e-9 * scale, (np.max(np.abs(ra - rb)), scale)
+    assert np.all(a["fields"]["divE"] == 0.0)                                       # E = 0 at the start
+    sim.close()

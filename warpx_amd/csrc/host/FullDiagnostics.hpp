@@ -8,8 +8,8 @@
 //   Source/Diagnostics/MultiDiagnostics.cpp:83-115  the loop over diagnostics, the forced flush of the last time step
 //   call sites: WarpXInitData.cpp:612-613 (before the first step), WarpXEvolve.cpp:306 (every step), :341-343 (istep ==
 //   max_step); file name amrex::Concatenate(file_prefix, istep, file_min_digits) (FlushFormatPlotfile.cpp:69)
-// The fields are those the plotfile writer knows (Ex Ey Ez Bx By Bz jx jy jz rho, cell-centred); other names of the
-// reference's list (divE, part_per_cell, rho_<species>, ...) are left out with a warning.  openPMD output is not produced.
+// The fields are those the plotfile writer knows (Ex Ey Ez Bx By Bz jx jy jz rho divE part_per_cell, cell-centred); other
+// names of the reference's list (rho_<species>, F, G, ...) are left out with a warning.  openPMD output is not produced.
 #ifndef WXA_HOST_FULL_DIAGNOSTICS_HPP_
 #define WXA_HOST_FULL_DIAGNOSTICS_HPP_
 
@@ -45,7 +45,7 @@ public:
 class MultiDiagnostics {
 public:
     static const std::vector<std::string>& known_fields() {
-        static const std::vector<std::string> k{"Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho"};
+        static const std::vector<std::string> k{"Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho", "divE", "part_per_cell"};
         return k;
     }
     // fields: empty = the reference's default (Ex .. jz); names this writer does not know are dropped with a warning

@@ -58,6 +58,92 @@ inline std::vector<double> cell_centered(const Backend* be, const amrex::MultiFa
     return out;
 }
 
+// DivEFunctor (Source/Diagnostics/ComputeDiagFunctors/DivEFunctor.cpp:29-76): div E on the nodes --
+// FiniteDifferenceSolver::ComputeDivECartesian (ComputeDivE.cpp:82-122): DownwardDx(Ex) + DownwardDy(Ey) + DownwardDz(Ez),
+// the Yee / CKC backward differences (CartesianYeeAlgorithm.H:125-167, CartesianCKCAlgorithm.H) on the staggered grid,
+// the centred ones of CartesianNodalAlgorithm.H on a collocated grid -- then sample::Coarsen to the cell centres (the
+// mean of a cell's eight nodes).  The nodes on a brick's faces read one guard point of E: filled first (the reference
+// reads what EvolveE's FillBoundaryE left there; the same values).  Output stage: on the host.
+inline std::vector<double> div_e_cell_centered(WarpX& wx, int ncell[3]) {
+    using warpx::fields::FieldType;
+    using ablastr::fields::Direction;
+    const WarpXContext& ctx = wx.context();
+    const Backend* be = ctx.be;
+    wx.FillBoundaryE(amrex::IntVect(1));
+    wx.sync_stream();
+    std::vector<double> e[3];
+    wxa_field_view v[3];
+    for (int d = 0; d < 3; ++d) {
+        v[d] = wx.fields().get(FieldType::Efield_fp, Direction{d}, 0)->view();
+        e[d].resize((size_t)v[d].kstride * (size_t)v[d].n[2]);
+        if (be->memcpy_d2h(e[d].data(), v[d].p, sizeof(double) * e[d].size()) != 0) throw std::runtime_error("plotfile: device copy failed");
+    }
+    for (int d = 0; d < 3; ++d) ncell[d] = v[0].n[d] - 2 * v[0].ng[d] - v[0].stag[d];
+    auto at = [&](int c, int i, int j, int k) {   // component c at its own index (i, j, k), 0 = first valid point
+        return e[c][(size_t)(i + v[c].ng[0]) + (size_t)(j + v[c].ng[1]) * v[c].jstride + (size_t)(k + v[c].ng[2]) * v[c].kstride];
+    };
+    const int nn[3] = {ncell[0] + 1, ncell[1] + 1, ncell[2] + 1};
+    std::vector<double> node((size_t)nn[0] * nn[1] * nn[2]);
+    for (int k = 0; k < nn[2]; ++k)
+        for (int j = 0; j < nn[1]; ++j)
+            for (int i = 0; i < nn[0]; ++i) {
+                double dsum = 0.0;
+                for (int c = 0; c < 3; ++c) {
+                    int lo[3] = {i, j, k}, hi[3] = {i, j, k};
+                    double coef = ctx.dinv[c];
+                    if (v[c].stag[c] == 0) lo[c] -= 1;                       // staggered: (F(i) - F(i-1)) / dx, F between the nodes
+                    else { lo[c] -= 1; hi[c] += 1; coef *= 0.5; }            // collocated: (F(i+1) - F(i-1)) / (2 dx)
+                    dsum += coef * (at(c, hi[0], hi[1], hi[2]) - at(c, lo[0], lo[1], lo[2]));
+                }
+                node[(size_t)i + (size_t)nn[0] * ((size_t)j + (size_t)nn[1] * k)] = dsum;
+            }
+    std::vector<double> out((size_t)ncell[0] * ncell[1] * ncell[2]);
+    size_t o = 0;
+    for (int k = 0; k < ncell[2]; ++k)
+        for (int j = 0; j < ncell[1]; ++j)
+            for (int i = 0; i < ncell[0]; ++i) {
+                double c = 0.0;
+                for (int kr = 0; kr < 2; ++kr)
+                    for (int jr = 0; jr < 2; ++jr)
+                        for (int ir = 0; ir < 2; ++ir)
+                            c += 0.125 * node[(size_t)(i + ir) + (size_t)nn[0] * ((size_t)(j + jr) + (size_t)nn[1] * (k + kr))];
+                out[o++] = c;
+            }
+    return out;
+}
+
+// PartPerCellFunctor (PartPerCellFunctor.cpp:26-41): the number of macro-particles of all species in every cell
+// (MultiParticleContainer::Increment -> amrex ParticleContainer::Increment: +1 in the cell that holds the particle)
+inline std::vector<double> part_per_cell(WarpX& wx, const int ncell[3]) {
+    const WarpXContext& ctx = wx.context();
+    const Backend* be = ctx.be;
+    std::vector<double> out((size_t)ncell[0] * ncell[1] * ncell[2], 0.0);
+    std::vector<double> pos[3];
+    for (int s = 0; s < wx.GetPartContainer().nSpecies(); ++s) {
+        WarpXParticleContainer& pc = wx.GetPartContainer().GetParticleContainer(s);
+        ParticleTile& t = pc.tile();
+        const size_t n = (size_t)t.numParticles();
+        if (n == 0) continue;
+        std::vector<uint64_t> id(n);
+        for (int d = 0; d < 3; ++d) {
+            pos[d].resize(n);
+            if (be->memcpy_d2h(pos[d].data(), t.comp(d), sizeof(double) * n) != 0) throw std::runtime_error("plotfile: device copy failed");
+        }
+        if (be->memcpy_d2h(id.data(), t.idcpu(), sizeof(uint64_t) * n) != 0) throw std::runtime_error("plotfile: device copy failed");
+        for (size_t q = 0; q < n; ++q) {
+            if (id[q] == WXA_IDCPU_RETIRED) continue;   // handed to a neighbour or absorbed: dropped by the next sort
+            int c[3];
+            bool in = true;
+            for (int d = 0; d < 3; ++d) {
+                c[d] = (int)std::floor((pos[d][q] - ctx.prob_lo[d]) * ctx.dinv[d]) - ctx.brick_box.lo[d];
+                in = in && c[d] >= 0 && c[d] < ncell[d];
+            }
+            if (in) out[(size_t)c[0] + (size_t)ncell[0] * ((size_t)c[1] + (size_t)ncell[1] * c[2])] += 1.0;
+        }
+    }
+    return out;
+}
+
 // Header + Level_0/Cell_H + Level_0/Cell_D_00000 of a single-level plotfile with one grid: `data[c]` is component c of
 // the box lo..hi in Fortran order (layouts: PlotfileFormat.hpp)
 inline void write_cell_data(const std::string& dir, const std::vector<std::string>& names,
@@ -158,6 +244,13 @@ inline void write_plotfile(SimHandle& h, const std::string& dir, const std::vect
     for (const std::string& want : (fields ? *fields : all_fields)) {
         if (want == "rho") {
             data.push_back(cell_centered(be, wx.ComputeRho(), ncell));
+        } else if (want == "divE") {
+            data.push_back(div_e_cell_centered(wx, ncell));
+        } else if (want == "part_per_cell") {
+            int nc[3];
+            for (int d = 0; d < 3; ++d) nc[d] = ctx.brick_box.hi[d] - ctx.brick_box.lo[d] + 1;
+            data.push_back(part_per_cell(wx, nc));
+            for (int d = 0; d < 3; ++d) ncell[d] = nc[d];
         } else {
             const auto* c = std::find_if(comps, comps + 9, [&](const auto& e) { return want == e.name; });
             if (c == comps + 9) throw std::runtime_error("plotfile: no field named " + want);

@@ -12,11 +12,14 @@
 
 #include <sys/stat.h>
 
+#include <cctype>
+#include <cerrno>
 #include <climits>
 #include <fstream>
 #include <iomanip>
 #include <limits>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -138,6 +141,7 @@ public:
     void WriteToFile(int step, double t_new) const {
         if (!m_write_file) return;
         std::ofstream ofs{file_name(), std::ofstream::out | std::ofstream::app};
+        if (!ofs) throw std::runtime_error("reduced diagnostics: cannot append to " + file_name());   // a row is never dropped silently
         ofs << step + 1;
         ofs << m_sep;
         ofs << std::fixed << std::setprecision(m_precision) << std::scientific;

@@ -128,6 +128,25 @@ __global__ void __launch_bounds__(RED_NT) reduce_particles_kernel(PV p, double m
     }
 }
 
+// Scratch of the two reductions: RED_MAX_BLOCKS partial rows + the result, allocated once per host thread and kept
+// (with <rd>.intervals = 1 these entry points run inside the time loop every step, several times per row: a hipMalloc /
+// hipFree pair per call is an allocator round trip and an implicit device-wide sync each -- ADVICE round 3)
+static double* red_scratch(size_t doubles) {
+    struct Holder {
+        double* p = nullptr;
+        size_t n = 0;
+        ~Holder() { if (p) (void)hipFree(p); }
+    };
+    static thread_local Holder h;
+    if (doubles > h.n) {
+        if (h.p) (void)hipFree(h.p);
+        h.p = nullptr; h.n = 0;
+        if (hipMalloc(&h.p, sizeof(double) * doubles) != hipSuccess) return nullptr;
+        h.n = doubles;
+    }
+    return h.p;
+}
+
 static int red_blocks(long n) {
     const long nb = (n + RED_NT - 1) / RED_NT;
     return (int)(nb < 1 ? 1 : nb > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : nb);
@@ -147,15 +166,14 @@ extern "C" wxa_status wxa_reduce_field(const wxa_field_view* f, const int32_t lo
     if (npts == 0) return WXA_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nb = red_blocks(npts);
-    double* scratch = nullptr;   // nb partials + the result
-    WXA_HIP_CHECK(hipMalloc(&scratch, sizeof(double) * 2 * ((size_t)nb + 1)));
+    double* scratch = red_scratch(2 * ((size_t)nb + 1));   // nb partials + the result
+    WXA_REQUIRE(scratch, "scratch allocation failed");
     hipLaunchKernelGGL(reduce_field_kernel, dim3((unsigned)nb), dim3(RED_NT), 0, st, make_devf(*f), lo[0], lo[1], lo[2],
                        hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], scratch);
     hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3(1), dim3(RED_NT), 0, st, scratch, nb, scratch + 2 * (size_t)nb);
     double h[2] = {0.0, 0.0};
     const hipError_t e1 = hipMemcpyAsync(h, scratch + 2 * (size_t)nb, sizeof(h), hipMemcpyDeviceToHost, st);
     const hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(scratch);
     WXA_HIP_CHECK(e1);
     WXA_HIP_CHECK(e2);
     WXA_LAUNCH_CHECK();
@@ -172,15 +190,14 @@ extern "C" wxa_status wxa_reduce_particles(const wxa_particle_view* p, double ma
     if (p->np == 0) return WXA_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nb = red_blocks((long)p->np);
-    double* scratch = nullptr;
-    WXA_HIP_CHECK(hipMalloc(&scratch, sizeof(double) * 7 * ((size_t)nb + 1)));
+    double* scratch = red_scratch(7 * ((size_t)nb + 1));
+    WXA_REQUIRE(scratch, "scratch allocation failed");
     hipLaunchKernelGGL(reduce_particles_kernel, dim3((unsigned)nb), dim3(RED_NT), 0, st, make_pv(*p), mass, (int)photon,
                        scratch);
     hipLaunchKernelGGL(reduce_partials_kernel<6>, dim3(1), dim3(RED_NT), 0, st, scratch, nb, scratch + 7 * (size_t)nb);
     double h[7] = {};
     const hipError_t e1 = hipMemcpyAsync(h, scratch + 7 * (size_t)nb, sizeof(h), hipMemcpyDeviceToHost, st);
     const hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(scratch);
     WXA_HIP_CHECK(e1);
     WXA_HIP_CHECK(e2);
     WXA_LAUNCH_CHECK();
