@@ -277,7 +277,8 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     // ... and their data, for the first DKEEP entries of every bucket: phase C has the particle in registers when it
     // defers it; fetched again by index in phase D each one costs seven cache lines from HBM (the tile's lines have left
     // the L2 by then: FETCH_SIZE 1.57 x the particle data, phase D 12 % of the kernel for 3 % of the particles)
-    constexpr int DKEEP = FUSED ? 0 : sizeof(ACC) == 8 ? 48 : 16;   // 16 x 48 x 56 B = 42 KB next to the 89 KB tile
+    // (half tiles: 8 per bucket = 7 KB, so that two workgroups of 79 KB fit a CU's 160 KB)
+    constexpr int DKEEP = FUSED ? 0 : TSZ != TS ? 8 : sizeof(ACC) == 8 ? 48 : 16;   // 16 x 48 x 56 B = 42 KB next to the 89 KB tile
     __shared__ double dkeep[7][FUSED ? 1 : NBANK * DKEEP];
     __shared__ double F[FUSED ? 6 * FUSED_GNPTS : 1];   // FUSED: Ex Ey Ez Bx By Bz of the tile + halo
     constexpr bool PT = CFG::PT != 0;
@@ -857,6 +858,8 @@ using RowsPT = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0,
 using RowsHF = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 1, 0>;   // 64: hole filling alone
 using RowsGIdx = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 1>;   // 65: chunk indices from global memory
 using RowsGIdxDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 0, 0, 1>;   // 66: ... + dynamic chunks
+using RowsHalf6 = RowsCfg<384, 4, 3, 1, 0, double, 32>;   // 70: half tiles (8 x 8 x 4 cells, 79 KB of LDS), two workgroups of 6 waves per CU
+using RowsHalf8 = RowsCfg<512, 4, 4, 1, 0, double, 32>;   // 71: ... of 8 waves at 128 VGPRs
 using RowsHFDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 1>;   // 61: ... + dynamic chunks
 using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
 using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
@@ -951,6 +954,8 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                 case 64: return launch_rows<3, RowsHF>(p, J, geom, q, dt, relative_time, ws, st);
                 case 65: return launch_rows<3, RowsGIdx>(p, J, geom, q, dt, relative_time, ws, st);
                 case 66: return launch_rows<3, RowsGIdxDyn>(p, J, geom, q, dt, relative_time, ws, st);
+                case 70: return launch_rows<3, RowsHalf6>(p, J, geom, q, dt, relative_time, ws, st);
+                case 71: return launch_rows<3, RowsHalf8>(p, J, geom, q, dt, relative_time, ws, st);
                 case 61: return launch_rows<3, RowsHFDyn>(p, J, geom, q, dt, relative_time, ws, st);
                 case 101: return launch_rows<3, RowsNoLds>(p, J, geom, q, dt, relative_time, ws, st);
                 case 102: return launch_rows<3, RowsNoAlu>(p, J, geom, q, dt, relative_time, ws, st);
