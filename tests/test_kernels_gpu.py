@@ -523,7 +523,7 @@ def test_deposit_tiles_fast_and_crossing_paths(oracle, product, stale, u_scale):
 
 @pytest.mark.skipif("dev" not in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", "")),
                     reason="timing variants exist in -DWXA_DEV_VARIANTS builds only (WXA_PRODUCT_LIB=.../libwarpx_amd_dev.so)")
-@pytest.mark.parametrize("deposit_variant", [14, 20, 22, 30, 31, 40, 61, 62, 63, 64, 65, 66, 70, 71], indirect=True)
+@pytest.mark.parametrize("deposit_variant", [14, 20, 22, 30, 31, 40, 61, 62, 63, 64, 65, 66, 70, 71, 80], indirect=True)
 @pytest.mark.parametrize("stale", [False, True])
 @pytest.mark.parametrize("u_scale", [1.0, 0.003])
 def test_deposit_tile_variants(oracle, product, deposit_variant, stale, u_scale):
@@ -1274,7 +1274,11 @@ def test_add_plasma(oracle, product, ppc, u, uth, gamma_boost, t):
                                                   # the other tile shapes of the timing sweep (WXA_CKC_VARIANT)
                                                   ((1.0, 1.0, 1.0), (70, 13, 37), 1, -1), ((1.0, 1.0, 1.0), (70, 13, 37), 1, -3),
                                                   ((1.0, 1.0, 1.0), (70, 13, 37), 1, -4), ((1.0, 1.0, 1.0), (70, 21, 37), 1, -5),
-                                                  ((1.0, 1.0, 1.0), (70, 13, 37), 1, -6)])
+                                                  ((1.0, 1.0, 1.0), (70, 13, 37), 1, -6),
+                                                  # planes requested two steps ahead (round 4): short, exact and long marches
+                                                  ((1.0, 1.0, 1.0), (70, 13, 37), 1, -7), ((1.1, 0.9, 1.0), (70, 13, 16), 2, -7),
+                                                  ((1.0, 1.0, 1.0), (70, 13, 2), 1, -7), ((1.0, 1.0, 1.0), (70, 13, 37), 1, -8),
+                                                  ((1.0, 1.0, 1.0), (70, 13, 37), 1, -9), ((1.0, 1.0, 1.0), (70, 13, 67), 1, -10)])
 def test_evolve_b_ckc_bit_exact(oracle, product, cells, ncell, ng, plain, monkeypatch):
     """wxa_evolve_b_ckc (EvolveBCartesian<CartesianCKCAlgorithm>) and its coefficients against the CPU restatement:
     same operation order, no contraction -> bit-identical, on cubic and on anisotropic cells; the LDS-tiled kernel

@@ -182,8 +182,9 @@ constexpr int FUSED_GNPTS = FUSED_GN * FUSED_GN * FUSED_GN;
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
 template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, class ACC_ = double, int BW_ = 0,
           int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0, int FUSED_ = 0, int PUSHER_ = WXA_PUSHER_BORIS,
-          int HF_ = 0, int PT_ = 0, int GIDX_ = 0>
+          int HF_ = 0, int PT_ = 0, int GIDX_ = 0, int FLUSH_ = 0>
 struct RowsCfg {
+    static constexpr int FLUSH = FLUSH_;   // 1: the write-back by columns (see phase E)
     // GIDX: the direct chunks read their cell's first particle and count from the sort's offsets[] in global memory
     // (vmcnt) instead of from the LDS copy: an LDS read at the top of a chunk returns behind whatever the CU's waves
     // have queued on the LDS-atomic pipe (lgkmcnt counts the wave's own atomics too), and the fourteen particle loads
@@ -751,17 +752,46 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     // invariants they stayed in SGPRs through the whole tile loop, the kernel ran out of them (106) and spilled into VGPRs
     const JTriple* jt = &J3;
     if constexpr (PT) jt = WXA_LATE_KERNARG(JTriple, J3);
+    if constexpr (CFG::FLUSH == 0) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const DevF J = c == 0 ? jt->x : c == 1 ? jt->y : jt->z;
-        for (int a = tid; a < NPTS; a += NT) {
-            const double v = (double)lds[c * NPTS + a];
-            if (v != 0.0) {
-                if constexpr (PT) lds[c * NPTS + a] = (ACC)0;
-                const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
-                if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
-                    k < J.lo2 + J.n2)
-                    atomic_add_f64(J.p + J.off(i, j, k), v);
+        for (int c = 0; c < 3; ++c) {
+            const DevF J = c == 0 ? jt->x : c == 1 ? jt->y : jt->z;
+            for (int a = tid; a < NPTS; a += NT) {
+                const double v = (double)lds[c * NPTS + a];
+                if (v != 0.0) {
+                    if constexpr (PT) lds[c * NPTS + a] = (ACC)0;
+                    const int i = o0 + (a % PS) % TD::NS, j = o1 + (a % PS) / TD::NS, k = o2 + a / PS;
+                    if (i >= J.lo0 && i < J.lo0 + J.n0 && j >= J.lo1 && j < J.lo1 + J.n1 && k >= J.lo2 &&
+                        k < J.lo2 + J.n2)
+                        atomic_add_f64(J.p + J.off(i, j, k), v);
+                }
+            }
+        }
+    } else {
+        // FLUSH = 1: a lane owns one (i, j) column of one component and walks it along k -- all NZ LDS reads of the
+        // column in flight at once, one address computation per column instead of one 64-bit index decomposition per
+        // point.  (As written above, per point: ds_read, s_waitcnt lgkmcnt(0), compare, ~20 integer instructions of
+        // address arithmetic, atomic -- fifteen times in a row per lane, 7 % of the kernel.)
+        constexpr int NSC = TD::NS, COLS = N * NSC;   // columns of a component, the padding points of a row included
+        for (int col = tid; col < 3 * COLS; col += NT) {
+            const int c = col / COLS, ij = col - c * COLS;
+            const int li = ij % NSC, lj = ij / NSC;
+            ACC* src = lds + c * NPTS + ij;
+            double v[NZ];
+#pragma unroll
+            for (int k = 0; k < NZ; ++k) v[k] = (double)src[k * PS];
+            if constexpr (PT) {
+#pragma unroll
+                for (int k = 0; k < NZ; ++k) src[k * PS] = (ACC)0;
+            }
+            const DevF J = c == 0 ? jt->x : c == 1 ? jt->y : jt->z;
+            const int i = o0 + li, j = o1 + lj;
+            if (li >= N || i < J.lo0 || i >= J.lo0 + J.n0 || j < J.lo1 || j >= J.lo1 + J.n1) continue;
+            double* dst = J.p + ((long)(i - J.lo0) + (long)(j - J.lo1) * J.js);
+#pragma unroll
+            for (int k = 0; k < NZ; ++k) {
+                const int kk = o2 + k - J.lo2;
+                if (v[k] != 0.0 && kk >= 0 && kk < J.n2) atomic_add_f64(dst + (long)kk * J.ks, v[k]);
             }
         }
     }
@@ -843,9 +873,12 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
 // of the next chunk +0.35; blocks of 16 cells x 4 pairs 6.6 (the same addresses in consecutive 16-lane steps of a
 // ds_add_f64 cost 11 cycles per wave instruction instead of 8, scripts/microbench/lds_atomic_bench.hip); lanes l and l + 32
 // sharing their deposits through v_permlane32_swap (half the LDS atomics, + 17 % VALU) 6.6 -- kept as dev variant 22.
-using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32>;
-using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
-using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT>;   // direct deposition on the same work items (32-cell chunks: 16.1 -> 14.9 ms)
+// Round 4: the write-back by columns (FLUSH = 1) 6.06-6.13 ms against 6.11-6.20 in four interleaved repeats
+// (profiles/round4/r4j_deposit_flush_by_columns.txt); everything else measured in round 4 (hole filling, persistent tiles,
+// chunk offsets from global memory, half tiles, the work item read ahead) did not beat this configuration and stays a dev variant.
+using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;
+using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
+using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;   // direct deposition on the same work items (32-cell chunks: 16.1 -> 14.9 ms)
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/variants.py): WXA_DEPOSIT_VARIANT=<n>, order-3 Esirkepov
 using RowsB16 = RowsCfg<768, 8, 3, 1, 0, double, 16>;
 using RowsB16Coop = RowsCfg<768, 8, 3, 1, 0, double, 16, WXA_DEPOSIT_ESIRKEPOV, 1>;
@@ -860,6 +893,7 @@ using RowsGIdx = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 
 using RowsGIdxDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 0, 0, 1>;   // 66: ... + dynamic chunks
 using RowsHalf6 = RowsCfg<384, 4, 3, 1, 0, double, 32>;   // 70: half tiles (8 x 8 x 4 cells, 79 KB of LDS), two workgroups of 6 waves per CU
 using RowsHalf8 = RowsCfg<512, 4, 4, 1, 0, double, 32>;   // 71: ... of 8 waves at 128 VGPRs
+using RowsFlushPoints = RowsCfg<768, 8, 3, 1, 0, double, 32>;   // 80: production until round 3 (the write-back point by point)
 using RowsHFDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 1>;   // 61: ... + dynamic chunks
 using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
 using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
@@ -956,6 +990,7 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                 case 66: return launch_rows<3, RowsGIdxDyn>(p, J, geom, q, dt, relative_time, ws, st);
                 case 70: return launch_rows<3, RowsHalf6>(p, J, geom, q, dt, relative_time, ws, st);
                 case 71: return launch_rows<3, RowsHalf8>(p, J, geom, q, dt, relative_time, ws, st);
+                case 80: return launch_rows<3, RowsFlushPoints>(p, J, geom, q, dt, relative_time, ws, st);
                 case 61: return launch_rows<3, RowsHFDyn>(p, J, geom, q, dt, relative_time, ws, st);
                 case 101: return launch_rows<3, RowsNoLds>(p, J, geom, q, dt, relative_time, ws, st);
                 case 102: return launch_rows<3, RowsNoAlu>(p, J, geom, q, dt, relative_time, ws, st);

@@ -648,10 +648,27 @@ evolve_b_ckc_tiled_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, 
     }
     const CkcRing<CFG> ex{ring[0], i0, j0}, ey{ring[1], i0, j0}, ez{ring[2], i0, j0};
     const bool px = in_ij(bbx, i, j), py = in_ij(bby, i, j), pz = in_ij(bbz, i, j);
+    // PIPE == 2: plane k+3 is requested while plane k is computed and plane k+2 (requested one step earlier, held in a
+    // second set of registers) goes to LDS after it: two plane steps for a load to arrive instead of one -- with one
+    // barrier per plane and ~1000 cycles of arithmetic per plane a single step is shorter than the HBM latency under load
+    double qx[CFG::PER], qy[CFG::PER], qz[CFG::PER];
+    if constexpr (CFG::PIPE == 2) {
+        if (k0 + 2 <= k1) {
+            ckc_fetch_plane<CFG>(rx, Ex, i0, j0, k0 + 2, tid);
+            ckc_fetch_plane<CFG>(ry, Ey, i0, j0, k0 + 2, tid);
+            ckc_fetch_plane<CFG>(rz, Ez, i0, j0, k0 + 2, tid);
+        }
+    }
     for (int k = k0; k < k1; ++k) {
         __syncthreads();   // planes k-1, k, k+1 are in the ring; everyone is done with plane k-2
         const bool more = k + 2 <= k1;   // plane k+2 for the next step, into the slot of k-2
-        if (more) {
+        if constexpr (CFG::PIPE == 2) {
+            if (k + 3 <= k1) {
+                ckc_fetch_plane<CFG>(qx, Ex, i0, j0, k + 3, tid);
+                ckc_fetch_plane<CFG>(qy, Ey, i0, j0, k + 3, tid);
+                ckc_fetch_plane<CFG>(qz, Ez, i0, j0, k + 3, tid);
+            }
+        } else if (more) {
             ckc_fetch_plane<CFG>(rx, Ex, i0, j0, k + 2, tid);
             ckc_fetch_plane<CFG>(ry, Ey, i0, j0, k + 2, tid);
             ckc_fetch_plane<CFG>(rz, Ez, i0, j0, k + 2, tid);
@@ -680,16 +697,27 @@ evolve_b_ckc_tiled_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, 
                 ckc_put_plane<CFG>(ring[2] + ((k + 2) & 3) * PLANE, rz, tid);
             }
         }
+        if constexpr (CFG::PIPE == 2) {
+#pragma unroll
+            for (int n = 0; n < CFG::PER; ++n) { rx[n] = qx[n]; ry[n] = qy[n]; rz[n] = qz[n]; }
+        }
     }
 }
 
-using CkcProduction = CkcCfg<8, 16, 1>;
+// Round 4 (profiles/round4/r4i_ckc_planes_two_steps_ahead.txt, 256^3, two rounds): 8 x 16 PIPE 1 (production until then)
+// 0.3379 ms (44.7 %); the same tile with the planes requested two steps ahead 0.3378 -- the loads' latency is not what
+// limits it; 4 rows x 16 planes, two steps ahead (38 KB of LDS: four workgroups per CU) 0.3172 ms (47.6 %), 4 x 32 0.341.
+using CkcProduction = CkcCfg<4, 16, 2>;
 #ifdef WXA_DEV_VARIANTS   // tile shapes of the timing sweep (WXA_CKC_VARIANT, scripts/ckc_timing.py; dev builds only)
 using Ckc0 = CkcCfg<8, 16, 0>;
 using Ckc2 = CkcCfg<8, 32, 1>;
 using Ckc3 = CkcCfg<4, 32, 1>;
 using Ckc4 = CkcCfg<16, 16, 1>;
 using Ckc5 = CkcCfg<8, 8, 1>;
+using Ckc6 = CkcCfg<8, 16, 2>;   // planes requested two steps ahead
+using Ckc7 = CkcCfg<8, 32, 2>;
+using Ckc8 = CkcCfg<8, 16, 1>;   // production until round 3
+using Ckc9 = CkcCfg<4, 32, 2>;
 #endif
 
 // Source/Filter/Filter.cpp:105-133 with the 1-pass stencil of BilinearFilter.cpp:26-60 ({0.25, 0.25} per direction);
@@ -951,6 +979,10 @@ wxa_status wxa_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3]
             case 3: WXA_CKC_LAUNCH(Ckc3); break;
             case 4: WXA_CKC_LAUNCH(Ckc4); break;
             case 5: WXA_CKC_LAUNCH(Ckc5); break;
+            case 6: WXA_CKC_LAUNCH(Ckc6); break;
+            case 7: WXA_CKC_LAUNCH(Ckc7); break;
+            case 8: WXA_CKC_LAUNCH(Ckc8); break;
+            case 9: WXA_CKC_LAUNCH(Ckc9); break;
             default: WXA_CKC_LAUNCH(CkcProduction); break;
         }
 #else
