@@ -4,7 +4,7 @@
 # kernel sources' fingerprint), the whole -m gpu suite, smoke.
 #   gpurun --timeout 2400 -- 'bash scripts/gpu_round4_f.sh'
 set -u
-OUT=$(pwd)/gpurun_out/r4f
+OUT=$(pwd)/gpurun_out/${SESSION:-r4f}
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
