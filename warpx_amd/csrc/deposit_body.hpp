@@ -572,6 +572,50 @@ __device__ __forceinline__ void esirkepov_single_wide(const EsirkepovCoords& cc,
     }
 }
 
+// One component of one particle that stays in its cell, on its own fast frame (slot 0 = the frame's first point, weights on
+// slots 1 .. O+1, like the pair body above with an empty partner): (O+1)^2 rows of O deposits.  Phase D of the tile kernel
+// for particles that could not be merged with their lane partner.
+template <int O, int COMP, class Sink>
+__device__ __forceinline__ void esirkepov_single_fast(const EsirkepovCoords& cc, const double wq, const EsirkepovStep& es,
+                                                      Sink& sink) {
+    constexpr int NW = O + 1;
+    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
+    const double xn[3] = {cc.x_new, cc.y_new, cc.z_new}, xo[3] = {cc.x_old, cc.y_old, cc.z_old};
+    constexpr int dl = COMP, da = COMP == 0 ? 1 : 0, db = COMP == 2 ? 1 : 2;   // longitudinal, inner and outer transverse
+    const int jl = shape_node_of<O>(xn[dl]), ja = shape_node_of<O>(xn[da]), jb = shape_node_of<O>(xn[db]);
+    double D[O];
+    {
+        double n[NW], o[NW];
+        bspline_weights<O, true>(n, xn[dl], jl);
+        bspline_weights<O, true>(o, xo[dl], jl);
+        double r = 0.0;
+#pragma unroll
+        for (int l = 0; l < O; ++l) {
+            r += wq * es.invdtd[COMP] * sub_rn(o[l], n[l]);
+            D[l] = r;
+        }
+    }
+    double an[NW], ao[NW], bn[NW], bo[NW];
+    bspline_weights<O, true>(an, xn[da], ja); bspline_weights<O, true>(ao, xo[da], ja);
+    bspline_weights<O, true>(bn, xn[db], jb); bspline_weights<O, true>(bo, xo[db], jb);
+#pragma unroll
+    for (int b = 0; b < NW; ++b) {
+        const double P = one_third * bn[b] + one_sixth * bo[b];
+        const double Q = one_third * bo[b] + one_sixth * bn[b];
+#pragma unroll
+        for (int a = 0; a < NW; ++a) {
+            const double T = an[a] * P + ao[a] * Q;
+#pragma unroll
+            for (int l = 0; l < O; ++l) {
+                const double v = D[l] * T;
+                if constexpr (COMP == 0) sink.add(0, l + 1, a + 1, b + 1, v);
+                else if constexpr (COMP == 1) sink.add(1, a + 1, l + 1, b + 1, v);
+                else sink.add(2, a + 1, b + 1, l + 1, v);
+            }
+        }
+    }
+}
+
 // Direct deposition on the Yee grid: jx(c,n,n) jy(n,c,n) jz(n,n,c).
 template <int O>
 struct DirectShapes {

@@ -182,8 +182,14 @@ constexpr int FUSED_GNPTS = FUSED_GN * FUSED_GN * FUSED_GN;
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
 template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, class ACC_ = double, int BW_ = 0,
           int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0, int FUSED_ = 0, int PUSHER_ = WXA_PUSHER_BORIS,
-          int HF_ = 0, int PT_ = 0, int GIDX_ = 0, int FLUSH_ = 0>
+          int HF_ = 0, int PT_ = 0, int GIDX_ = 0, int FLUSH_ = 0, int ZF_ = 0, int SNG_ = 0>
 struct RowsCfg {
+    // SNG: a second deferred list for the particles that stay in their cell but cannot be merged with their lane partner
+    // (another stencil frame: one of the two has left the sort cell since the last sort).  Phase D runs them through a
+    // one-component body on their own fast frame, (O+1)^2 O = 48 atomics per component, instead of the crossing
+    // particles' wide body with (O+2)^2 (O+1) = 100.  Half of phase D's entries are of this kind at a sort interval of 3.
+    static constexpr int SNG = SNG_;
+    static constexpr int ZF = ZF_;         // 1: zero fill behind the loads of the cell offsets (see phase A)
     static constexpr int FLUSH = FLUSH_;   // 1: the write-back by columns (see phase E)
     // GIDX: the direct chunks read their cell's first particle and count from the sort's offsets[] in global memory
     // (vmcnt) instead of from the LDS copy: an LDS read at the top of a chunk returns behind whatever the CU's waves
@@ -271,16 +277,18 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     // phase D takes lane l's particle from bucket l % 16, so the 16 lanes of a ds_add_f64 step sit on 16 different banks
     // like the lanes of phase C (the single list it replaces cost 2-3 LDS cycles per step in conflicts: the list
     // pass was 16 % of the kernel for 3 % of the particles)
+    constexpr bool SNG = CFG::SNG != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && !FUSED;
+    constexpr int NBKT = SNG ? 2 * NBANK : NBANK;   // buckets: by bank for the crossing particles, then by bank for the lone ones
     __shared__ unsigned deferred[DEFER];
-    __shared__ int ndef[NBANK];
+    __shared__ int ndef[NBKT];
     __shared__ int nitems;
     __shared__ int next_chunk;
     // ... and their data, for the first DKEEP entries of every bucket: phase C has the particle in registers when it
     // defers it; fetched again by index in phase D each one costs seven cache lines from HBM (the tile's lines have left
     // the L2 by then: FETCH_SIZE 1.57 x the particle data, phase D 12 % of the kernel for 3 % of the particles)
     // (half tiles: 8 per bucket = 7 KB, so that two workgroups of 79 KB fit a CU's 160 KB)
-    constexpr int DKEEP = FUSED ? 0 : TSZ != TS ? 8 : sizeof(ACC) == 8 ? 48 : 16;   // 16 x 48 x 56 B = 42 KB next to the 89 KB tile
-    __shared__ double dkeep[7][FUSED ? 1 : NBANK * DKEEP];
+    constexpr int DKEEP = (FUSED ? 0 : TSZ != TS ? 8 : sizeof(ACC) == 8 ? 48 : 16) / (SNG ? 2 : 1);   // 16 x 48 x 56 B = 42 KB next to the 89 KB tile
+    __shared__ double dkeep[7][FUSED ? 1 : NBKT * DKEEP];
     __shared__ double F[FUSED ? 6 * FUSED_GNPTS : 1];   // FUSED: Ex Ey Ez Bx By Bz of the tile + halo
     constexpr bool PT = CFG::PT != 0;
     static_assert(!PT || !FUSED, "persistent tiles: the deposition kernels");
@@ -336,7 +344,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         if constexpr (PT) { __syncthreads(); continue; }   // unit_s is read by everyone before thread 0 claims again
         else return;
     }
-    constexpr int DCAP = DEFER / NBANK;
+    constexpr int DCAP = DEFER / NBKT;
     auto defer = [&](const int ip, const int bank) {   // phase B: by index only (the particle has not been loaded)
         const int n = atomicAdd(&ndef[bank], 1);
         if (n < DCAP) deferred[bank * DCAP + n] = (unsigned)ip | 0x80000000u;
@@ -368,12 +376,20 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     constexpr int WAVES = NT / 64;
     // ---- A: cell counts, row masks; zero fill
     if (tid == 0) { nitems = 0; next_chunk = 0; }
-    if (tid < NBANK) ndef[tid] = 0;
+    if (tid < NBKT) ndef[tid] = 0;
     int my_s = 0, my_n = 0, my_pairs = 0;
     unsigned long long my_mask[RT];   // wave-uniform: tail row r of this cell-wave
+    int off_lo = 0, off_hi = 0;
+    if constexpr (CFG::ZF != 0) {
+        // ZF: the two offsets of the lane's cell are requested first and the tile is zeroed while they travel (as written
+        // below, the wait for them stands in front of the zero fill: in-order issue)
+        if (tid < CELLS) { off_lo = offsets[ucell0 + tid]; off_hi = offsets[ucell0 + tid + 1]; }
+        if (!PT || first_tile)
+            for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = (ACC)0;
+    }
     if (tid < CELLS) {
-        my_s = offsets[ucell0 + tid];
-        my_n = offsets[ucell0 + tid + 1] - my_s;
+        my_s = CFG::ZF != 0 ? off_lo : offsets[ucell0 + tid];
+        my_n = (CFG::ZF != 0 ? off_hi : offsets[ucell0 + tid + 1]) - my_s;
         cstart[tid] = my_s;
         if (tid == CELLS - 1) cstart[CELLS] = my_s + my_n;
         my_pairs = min((my_n + 1) >> 1, RMAX);
@@ -385,8 +401,10 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             }
         }
     }
-    if (!PT || first_tile)
-        for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = (ACC)0;
+    if constexpr (CFG::ZF == 0) {
+        if (!PT || first_tile)
+            for (int a = tid; a < 3 * NPTS; a += NT) lds[a] = (ACC)0;
+    }
     first_tile = false;
     if constexpr (FUSED) {
         // the six staggered components of the tile + halo, all of a lane's loads in flight before its first LDS write
@@ -650,7 +668,10 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             if (sb == 0 && kb == ka) {
                 wq2 = wqb; fast_b = true;                // merged with its neighbour
             } else {
-                if (sb == 0) defer_particle(ib, wide_bank(c2), pb);   // another frame: the wide body takes it alone
+                if (sb == 0) {   // another frame than its lane partner: deferred, alone
+                    if constexpr (SNG) defer_particle(ib, NBANK + (((kb & 15) + 8 * (kb >> 8)) & (NBANK - 1)), pb);   // its fast frame's bank
+                    else defer_particle(ib, wide_bank(c2), pb);   // the wide body takes it
+                }
                 c2 = c1;                                 // empty partner
             }
         } else if (sb == 0) {
@@ -717,32 +738,50 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         //      for some lanes -- seen as 1e-5 errors on a few points and once as a memory fault on gfx950; the fp64
         //      build was not transformed that way.  Uniform branches leave nothing to merge across lanes.
         // a chunk = 4 rows of the 16 buckets: lane l takes entry 4 (chunk) + l / 16 of bucket l % 16
-        const int my_nd = min(ndef[lane & (NBANK - 1)], DCAP);
-        int nrows = my_nd;
+        // chunks of the crossing particles (buckets 0 .. 15), then -- SNG -- of the lone ones (16 .. 31), numbered through
+        auto rows_of = [&](const int first_bucket) {
+            int n = min(ndef[first_bucket + (lane & (NBANK - 1))], DCAP);
 #pragma unroll
-        for (int d = 1; d < NBANK; d <<= 1) nrows = max(nrows, __shfl_xor(nrows, d));
-        const int dch = (nrows + 3) >> 2;
-        for (int ch = wave; ch < 3 * dch; ch += WAVES) {
-            const int comp = __builtin_amdgcn_readfirstlane(ch / dch);
-            const int row = (ch - comp * dch) * 4 + (lane >> 4);
-            if (row < my_nd) {
-                const unsigned ent = deferred[(lane & (NBANK - 1)) * DCAP + row];
+            for (int d = 1; d < NBANK; d <<= 1) n = max(n, __shfl_xor(n, d));
+            return (n + 3) >> 2;
+        };
+        const int dch0 = rows_of(0), dch1 = SNG ? rows_of(NBANK) : 0;
+        const int tot0 = 3 * dch0, tot = tot0 + 3 * dch1;
+        for (int ch = wave; ch < tot; ch += WAVES) {
+            const bool lone = __builtin_amdgcn_readfirstlane(ch >= tot0 ? 1 : 0) != 0;
+            const int cc = lone ? ch - tot0 : ch, dch = lone ? dch1 : dch0;
+            const int comp = __builtin_amdgcn_readfirstlane(cc / dch);
+            const int row = (cc - comp * dch) * 4 + (lane >> 4);
+            const int bkt = (lone ? NBANK : 0) + (lane & (NBANK - 1));
+            if (row < min(ndef[bkt], DCAP)) {
+                const unsigned ent = deferred[bkt * DCAP + row];
                 ParticleState p1;
                 if (ent & 0x80000000u) {
                     const int ip = (int)(ent & 0x7fffffffu);
                     p1 = ParticleState{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
                 } else {
-                    const int at = (lane & (NBANK - 1)) * DKEEP + row;
+                    const int at = bkt * DKEEP + row;
                     p1 = ParticleState{dkeep[0][at], dkeep[1][at], dkeep[2][at], dkeep[3][at], dkeep[4][at],
                                        dkeep[5][at], dkeep[6][at]};
                 }
                 const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
-                const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
-                LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
                 const double wq = q * p1.w;
-                if (comp == 0) esirkepov_single_wide<O, 0>(c1, f, wq, es, sink);
-                else if (comp == 1) esirkepov_single_wide<O, 1>(c1, f, wq, es, sink);
-                else esirkepov_single_wide<O, 2>(c1, f, wq, es, sink);
+                if (lone) {
+                    if constexpr (SNG) {
+                        int fi, fj, fk;
+                        esirkepov_frame_cross<O>(c1, g, fi, fj, fk);
+                        LdsSink<M, TSZ, ACC> sink(lds, fi - o0, fj - o1, fk - o2);
+                        if (comp == 0) esirkepov_single_fast<O, 0>(c1, wq, es, sink);
+                        else if (comp == 1) esirkepov_single_fast<O, 1>(c1, wq, es, sink);
+                        else esirkepov_single_fast<O, 2>(c1, wq, es, sink);
+                    }
+                } else {
+                    const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
+                    LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
+                    if (comp == 0) esirkepov_single_wide<O, 0>(c1, f, wq, es, sink);
+                    else if (comp == 1) esirkepov_single_wide<O, 1>(c1, f, wq, es, sink);
+                    else esirkepov_single_wide<O, 2>(c1, f, wq, es, sink);
+                }
             }
         }
     }
@@ -876,9 +915,11 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
 // Round 4: the write-back by columns (FLUSH = 1) 6.06-6.13 ms against 6.11-6.20 in four interleaved repeats
 // (profiles/round4/r4j_deposit_flush_by_columns.txt); everything else measured in round 4 (hole filling, persistent tiles,
 // chunk offsets from global memory, half tiles, the work item read ahead) did not beat this configuration and stays a dev variant.
-using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;
-using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
-using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;   // direct deposition on the same work items (32-cell chunks: 16.1 -> 14.9 ms)
+// ... then, same round (r4m, r4n: four interleaved repeats each): the zero fill behind the loads of the cell offsets (ZF)
+// 5.98 against 6.04, the lone partners of phase D on their own fast frame (SNG) 5.94, both 5.88-5.96 against 6.01-6.05.
+using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;
+using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
+using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // direct deposition on the same work items (32-cell chunks: 16.1 -> 14.9 ms)
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/variants.py): WXA_DEPOSIT_VARIANT=<n>, order-3 Esirkepov
 using RowsB16 = RowsCfg<768, 8, 3, 1, 0, double, 16>;
 using RowsB16Coop = RowsCfg<768, 8, 3, 1, 0, double, 16, WXA_DEPOSIT_ESIRKEPOV, 1>;
@@ -894,6 +935,9 @@ using RowsGIdxDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 
 using RowsHalf6 = RowsCfg<384, 4, 3, 1, 0, double, 32>;   // 70: half tiles (8 x 8 x 4 cells, 79 KB of LDS), two workgroups of 6 waves per CU
 using RowsHalf8 = RowsCfg<512, 4, 4, 1, 0, double, 32>;   // 71: ... of 8 waves at 128 VGPRs
 using RowsFlushPoints = RowsCfg<768, 8, 3, 1, 0, double, 32>;   // 80: production until round 3 (the write-back point by point)
+using RowsZeroFirst = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // 81
+using RowsSingles = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 0, 1>;   // 82: lone partners on their fast frame in phase D
+using RowsRound4J = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;   // 83: production of session j (write-back by columns only)
 using RowsHFDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 1>;   // 61: ... + dynamic chunks
 using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
 using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
@@ -991,6 +1035,9 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                 case 70: return launch_rows<3, RowsHalf6>(p, J, geom, q, dt, relative_time, ws, st);
                 case 71: return launch_rows<3, RowsHalf8>(p, J, geom, q, dt, relative_time, ws, st);
                 case 80: return launch_rows<3, RowsFlushPoints>(p, J, geom, q, dt, relative_time, ws, st);
+                case 81: return launch_rows<3, RowsZeroFirst>(p, J, geom, q, dt, relative_time, ws, st);
+                case 82: return launch_rows<3, RowsSingles>(p, J, geom, q, dt, relative_time, ws, st);
+                case 83: return launch_rows<3, RowsRound4J>(p, J, geom, q, dt, relative_time, ws, st);
                 case 61: return launch_rows<3, RowsHFDyn>(p, J, geom, q, dt, relative_time, ws, st);
                 case 101: return launch_rows<3, RowsNoLds>(p, J, geom, q, dt, relative_time, ws, st);
                 case 102: return launch_rows<3, RowsNoAlu>(p, J, geom, q, dt, relative_time, ws, st);

@@ -124,7 +124,7 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // point, even as stragglers: a particle is at most a few cells from the tile it was sorted into); 2 = only
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
-template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF, int ST = 0>
+template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF, int ST = 0, int SL = 0>
 __global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(G ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext) {
@@ -160,6 +160,24 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     // wave is done).  A wave works on one chunk, has the positions of the next one in flight and has claimed the one
     // after that: the counter's round trip through the LDS queue hides behind a whole trip.  The first two chunks of
     // every wave are the static ones, so no trip starts by waiting for the counter.
+    // SL: a tile's stragglers are collected in LDS and written to the global list as ONE contiguous block at the end of the
+    // workgroup (one global atomic per tile instead of one per straggler): the straggler kernel's waves then hold
+    // particles of one or two neighbouring tiles, whose 252 scattered loads share cache lines
+    constexpr int SCAP = 512;
+    __shared__ int slist[SL ? SCAP : 1];
+    __shared__ int sn, sbase;
+    if constexpr (SL != 0) {
+        if (tid == 0) sn = 0;   // visible after the staging barrier below
+    }
+    auto push_straggler = [&](const int i) {
+        if constexpr (SL != 0) {
+            const int n = atomicAdd(&sn, 1);
+            if (n < SCAP) slist[n] = i;
+            else sq.push(i);
+        } else {
+            sq.push(i);
+        }
+    };
     constexpr bool DYN = PF == 3;
     constexpr bool PREFETCH = PF == 1 || PF == 2 || PF == 3;
     constexpr int WAVES = GT_THREADS / 64;
@@ -257,7 +275,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         unsigned long long storing = 0ull;
         if constexpr (ST != 0) storing = __ballot(staged);   // taken while the trip's lanes are still together
         if (!staged) {
-            sq.push(ip);   // stencil leaves the staged tile: handled by gather_push_stragglers_kernel
+            push_straggler(ip);   // stencil leaves the staged tile: handled by gather_push_stragglers_kernel
             if constexpr (ST == 0) continue;
         }
         if constexpr (ST != 0) {   // a lane that does not gather reads the tile's first points (its results are not stored)
@@ -300,6 +318,13 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
 #ifdef WXA_GATHER_PROFILE
     { GPROF_CLOCK(prof_t2); GPROF_ADD(1, prof_t2 - prof_t1); }
 #endif
+    if constexpr (SL != 0) {
+        __syncthreads();
+        const int n = min(sn, SCAP);
+        if (tid == 0 && n > 0) sbase = (int)atomicAdd(sq.count, (unsigned)n);
+        __syncthreads();
+        for (int i = tid; i < n; i += GT_THREADS) sq.idx[sbase + i] = slist[i];
+    }
 }
 
 template <int O, int G, int PUSHER, bool MOVE>
@@ -380,12 +405,16 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         const int pf = epf ? atoi(epf) : WXA_GATHER_PF;
         const char* est = getenv("WXA_GATHER_ST");
         const int stv = est ? atoi(est) : 0;
+        const char* esl = getenv("WXA_GATHER_SL");
+        const int slv = esl ? atoi(esl) : 0;
         if (e && galerkin && order == 3) {
 #define WXA_GT_RB(RBV)                                                                                          \
     do {                                                                                                        \
         if (pf == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 1>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 2) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 2>), grid, block, 0, st, pv, offsets, \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+        else if (pf == 3 && slv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 1>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 3 && stv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 1>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
