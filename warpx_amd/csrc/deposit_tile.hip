@@ -24,6 +24,7 @@
 
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 
 namespace wxa {
@@ -732,11 +733,8 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     __syncthreads();
     DPROF(2);
     {   // ---- D: the deferred particles through the wide body, one lane per (component, particle).  A chunk of 64
-        //      lanes belongs to ONE component, and the component is made a scalar: with lanes of one wave in different
-        //      component branches the compiler merged the branches' last ds_add_f32 into a shared tail under a
-        //      hand-built exec mask, and the fp32 build deposited that one value (the stencil's far corner) wrongly
-        //      for some lanes -- seen as 1e-5 errors on a few points and once as a memory fault on gfx950; the fp64
-        //      build was not transformed that way.  Uniform branches leave nothing to merge across lanes.
+        //      lanes belongs to ONE component (until round 3 the lanes of a wave sat in different component branches; the
+        //      fp32 build then deposited the stencil's far corner wrongly for some lanes -- see below for what that was).
         // a chunk = 4 rows of the 16 buckets: lane l takes entry 4 (chunk) + l / 16 of bucket l % 16
         // chunks of the crossing particles (buckets 0 .. 15), then -- SNG -- of the lone ones (16 .. 31), numbered through
         auto rows_of = [&](const int first_bucket) {
@@ -746,43 +744,55 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             return (n + 3) >> 2;
         };
         const int dch0 = rows_of(0), dch1 = SNG ? rows_of(NBANK) : 0;
-        const int tot0 = 3 * dch0, tot = tot0 + 3 * dch1;
-        for (int ch = wave; ch < tot; ch += WAVES) {
-            const bool lone = __builtin_amdgcn_readfirstlane(ch >= tot0 ? 1 : 0) != 0;
-            const int cc = lone ? ch - tot0 : ch, dch = lone ? dch1 : dch0;
-            const int comp = __builtin_amdgcn_readfirstlane(cc / dch);
-            const int row = (cc - comp * dch) * 4 + (lane >> 4);
-            const int bkt = (lone ? NBANK : 0) + (lane & (NBANK - 1));
-            if (row < min(ndef[bkt], DCAP)) {
-                const unsigned ent = deferred[bkt * DCAP + row];
-                ParticleState p1;
-                if (ent & 0x80000000u) {
-                    const int ip = (int)(ent & 0x7fffffffu);
-                    p1 = ParticleState{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
-                } else {
-                    const int at = bkt * DKEEP + row;
-                    p1 = ParticleState{dkeep[0][at], dkeep[1][at], dkeep[2][at], dkeep[3][at], dkeep[4][at],
-                                       dkeep[5][at], dkeep[6][at]};
-                }
-                const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
-                const double wq = q * p1.w;
-                if (lone) {
-                    if constexpr (SNG) {
+        // One loop per (kind, component), both compile-time constants inside it.  As one loop with the component a
+        // wave-uniform scalar -- `if (comp == 0) ... else if (comp == 1) ... else ...` -- the gfx950 build merges the last
+        // ds_add of the three bodies into one shared block whose address register is an implicit-def on the edge from
+        // comp >= 2 (seen in the ISA of the fp32 order-2 build, round 4: the last deposit of every jz body went to a
+        // stale address; a far corner of 1e-5 for the wide body, a 4 % error and a memory fault for the lone
+        // particles' frame).  With nothing to choose between there is nothing to merge.  The chunks stay numbered
+        // through all six loops -- chunk n belongs to wave n % WAVES -- so the waves' shares are what they were.
+        auto pass = [&](auto comp_c, auto lone_c, const int base, const int dch) {
+            constexpr int COMP = decltype(comp_c)::value;
+            constexpr bool LONE = decltype(lone_c)::value;
+            int first = (wave - base) % WAVES;
+            if (first < 0) first += WAVES;
+            for (int cc = first; cc < dch; cc += WAVES) {
+                const int row = cc * 4 + (lane >> 4);
+                const int bkt = (LONE ? NBANK : 0) + (lane & (NBANK - 1));
+                if (row < min(ndef[bkt], DCAP)) {
+                    const unsigned ent = deferred[bkt * DCAP + row];
+                    ParticleState p1;
+                    if (ent & 0x80000000u) {
+                        const int ip = (int)(ent & 0x7fffffffu);
+                        p1 = ParticleState{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
+                    } else {
+                        const int at = bkt * DKEEP + row;
+                        p1 = ParticleState{dkeep[0][at], dkeep[1][at], dkeep[2][at], dkeep[3][at], dkeep[4][at],
+                                           dkeep[5][at], dkeep[6][at]};
+                    }
+                    const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
+                    const double wq = q * p1.w;
+                    if constexpr (LONE) {
                         int fi, fj, fk;
                         esirkepov_frame_cross<O>(c1, g, fi, fj, fk);
                         LdsSink<M, TSZ, ACC> sink(lds, fi - o0, fj - o1, fk - o2);
-                        if (comp == 0) esirkepov_single_fast<O, 0>(c1, wq, es, sink);
-                        else if (comp == 1) esirkepov_single_fast<O, 1>(c1, wq, es, sink);
-                        else esirkepov_single_fast<O, 2>(c1, wq, es, sink);
+                        esirkepov_single_fast<O, COMP>(c1, wq, es, sink);
+                    } else {
+                        const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
+                        LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
+                        esirkepov_single_wide<O, COMP>(c1, f, wq, es, sink);
                     }
-                } else {
-                    const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
-                    LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
-                    if (comp == 0) esirkepov_single_wide<O, 0>(c1, f, wq, es, sink);
-                    else if (comp == 1) esirkepov_single_wide<O, 1>(c1, f, wq, es, sink);
-                    else esirkepov_single_wide<O, 2>(c1, f, wq, es, sink);
                 }
             }
+        };
+        using std::integral_constant;
+        pass(integral_constant<int, 0>{}, integral_constant<bool, false>{}, 0, dch0);
+        pass(integral_constant<int, 1>{}, integral_constant<bool, false>{}, dch0, dch0);
+        pass(integral_constant<int, 2>{}, integral_constant<bool, false>{}, 2 * dch0, dch0);
+        if constexpr (SNG) {
+            pass(integral_constant<int, 0>{}, integral_constant<bool, true>{}, 3 * dch0, dch1);
+            pass(integral_constant<int, 1>{}, integral_constant<bool, true>{}, 3 * dch0 + dch1, dch1);
+            pass(integral_constant<int, 2>{}, integral_constant<bool, true>{}, 3 * dch0 + 2 * dch1, dch1);
         }
     }
     __syncthreads();
@@ -918,7 +928,13 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
 // ... then, same round (r4m, r4n: four interleaved repeats each): the zero fill behind the loads of the cell offsets (ZF)
 // 5.98 against 6.04, the lone partners of phase D on their own fast frame (SNG) 5.94, both 5.88-5.96 against 6.01-6.05.
 using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;
-using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
+#ifndef WXA_F32_ZF
+#define WXA_F32_ZF 1
+#endif
+#ifndef WXA_F32_SNG
+#define WXA_F32_SNG 1
+#endif
+using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, WXA_F32_ZF, WXA_F32_SNG>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
 using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // direct deposition on the same work items (32-cell chunks: 16.1 -> 14.9 ms)
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/variants.py): WXA_DEPOSIT_VARIANT=<n>, order-3 Esirkepov
 using RowsB16 = RowsCfg<768, 8, 3, 1, 0, double, 16>;

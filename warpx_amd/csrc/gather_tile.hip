@@ -24,6 +24,9 @@
 #ifndef WXA_GATHER_RB
 #define WXA_GATHER_RB 2   // rows in flight ahead of the fma chain (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
 #endif
+#ifndef WXA_GATHER_SL
+#define WXA_GATHER_SL 1   // 1: a tile's stragglers leave as one block of the global list (see the kernel); 0: one global atomic each
+#endif
 #ifndef WXA_GATHER_PF
 #define WXA_GATHER_PF 3   // 2: the next particle's position is requested a trip ahead, this particle's momentum at the top of its trip; 3: the same, chunks through an LDS counter
 #endif
@@ -124,7 +127,7 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // point, even as stragglers: a particle is at most a few cells from the tile it was sorted into); 2 = only
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
-template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF, int ST = 0, int SL = 0>
+template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF, int ST = 0, int SL = WXA_GATHER_SL>
 __global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(G ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext) {
@@ -406,7 +409,7 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         const char* est = getenv("WXA_GATHER_ST");
         const int stv = est ? atoi(est) : 0;
         const char* esl = getenv("WXA_GATHER_SL");
-        const int slv = esl ? atoi(esl) : 0;
+        const int slv = esl ? atoi(esl) : WXA_GATHER_SL;
         if (e && galerkin && order == 3) {
 #define WXA_GT_RB(RBV)                                                                                          \
     do {                                                                                                        \
@@ -416,9 +419,9 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 3 && slv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 1>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
-        else if (pf == 3 && stv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 1>), grid, block, 0, st, pv, offsets, \
+        else if (pf == 3 && stv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 1, 0>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
-        else if (pf == 3) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3>), grid, block, 0, st, pv, offsets, \
+        else if (pf == 3) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 0>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
         else if (pf == 7) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 7>), grid, block, 0, st, pv, offsets, \
                            ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
