@@ -954,6 +954,7 @@ using RowsFlushPoints = RowsCfg<768, 8, 3, 1, 0, double, 32>;   // 80: productio
 using RowsZeroFirst = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // 81
 using RowsSingles = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 0, 1>;   // 82: lone partners on their fast frame in phase D
 using RowsRound4J = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;   // 83: production of session j (write-back by columns only)
+using RowsW16 = RowsCfg<1024, 8, 4, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 90: production with 16 waves at 128 VGPRs
 using RowsHFDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 1>;   // 61: ... + dynamic chunks
 using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
 using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
@@ -1054,6 +1055,7 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                 case 81: return launch_rows<3, RowsZeroFirst>(p, J, geom, q, dt, relative_time, ws, st);
                 case 82: return launch_rows<3, RowsSingles>(p, J, geom, q, dt, relative_time, ws, st);
                 case 83: return launch_rows<3, RowsRound4J>(p, J, geom, q, dt, relative_time, ws, st);
+                case 90: return launch_rows<3, RowsW16>(p, J, geom, q, dt, relative_time, ws, st);
                 case 61: return launch_rows<3, RowsHFDyn>(p, J, geom, q, dt, relative_time, ws, st);
                 case 101: return launch_rows<3, RowsNoLds>(p, J, geom, q, dt, relative_time, ws, st);
                 case 102: return launch_rows<3, RowsNoAlu>(p, J, geom, q, dt, relative_time, ws, st);
