@@ -642,6 +642,65 @@ __device__ __forceinline__ void direct_shapes(const ParticleState& p, const Geom
     s.ln = g.lo2 + shape_factor<O>(s.szn, zmid); s.lc = g.lo2 + shape_factor<O>(s.szc, zmid - 0.5);
 }
 
+// doDepositionShapeN (CurrentDeposition.H:48-249) for the two particles of a lane at once (tile kernels), one component.
+// Two particles of one sort cell have the same nodal stencils; their cell-centred stencil starts at jn - 1 or at jn (the
+// half of the cell the particle sits in), so a frame of O + 2 slots along the component's own direction and O + 1 along the
+// others holds both: (O + 2) (O + 1)^2 sums of two products per component instead of 2 (O + 1)^3 products, 240 LDS atomics
+// per pair instead of 384 at order 3.  The sink's origin is the frame's first point: (jn - 1, kn, ln) for jx, (jn, kn - 1,
+// ln) for jy, (jn, kn, ln - 1) for jz, of whichever particle carries weight (a particle without weight contributes exact
+// zeros whatever its stencil).
+template <int O, int COMP, class Sink>
+__device__ __forceinline__ void direct_pair_component(const DirectShapes<O>& a, const DirectShapes<O>& b, Sink& sink) {
+    constexpr int NW = O + 1;
+    const double* wa = COMP == 0 ? a.sxc : COMP == 1 ? a.syc : a.szc;
+    const double* wb = COMP == 0 ? b.sxc : COMP == 1 ? b.syc : b.szc;
+    const double* ta1 = COMP == 0 ? a.syn : a.sxn;
+    const double* tb1 = COMP == 0 ? b.syn : b.sxn;
+    const double* ta2 = COMP == 2 ? a.syn : a.szn;
+    const double* tb2 = COMP == 2 ? b.syn : b.szn;
+    const double wqa = COMP == 0 ? a.wqx : COMP == 1 ? a.wqy : a.wqz;
+    const double wqb = COMP == 0 ? b.wqx : COMP == 1 ? b.wqy : b.wqz;
+    // first slot of the particle's own cell-centred stencil in the frame: 0 or 1
+    const bool offa = (COMP == 0 ? a.jc - a.jn : COMP == 1 ? a.kc - a.kn : a.lc - a.ln) != -1;
+    const bool offb = (COMP == 0 ? b.jc - b.jn : COMP == 1 ? b.kc - b.kn : b.lc - b.ln) != -1;
+    double fa[NW + 1], fb[NW + 1];
+#pragma unroll
+    for (int m = 0; m <= NW; ++m) {
+        fa[m] = offa ? (m >= 1 ? wa[m >= 1 ? m - 1 : 0] : 0.0) : (m < NW ? wa[m < NW ? m : 0] : 0.0);
+        fb[m] = offb ? (m >= 1 ? wb[m >= 1 ? m - 1 : 0] : 0.0) : (m < NW ? wb[m < NW ? m : 0] : 0.0);
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < NW; ++i2)
+#pragma unroll
+        for (int i1 = 0; i1 < NW; ++i1) {
+            // COMP 0: (i1, i2) = (y, z); COMP 1: (x, z); COMP 2: (x, y)
+            const double Ta = ta1[i1] * ta2[i2] * wqa;
+            const double Tb = tb1[i1] * tb2[i2] * wqb;
+#pragma unroll
+            for (int m = 0; m <= NW; ++m) {
+                const double v = fa[m] * Ta + fb[m] * Tb;
+                if constexpr (COMP == 0) sink.add(0, m, i1, i2, v);
+                else if constexpr (COMP == 1) sink.add(1, i1, m, i2, v);
+                else sink.add(2, i1, i2, m, v);
+            }
+        }
+}
+
+// ... and one component of one particle on its own stencil (the tile kernels' deferred particles), the reference's products
+template <int O, int COMP, class Sink>
+__device__ __forceinline__ void direct_single_component(const DirectShapes<O>& s, Sink& sink) {
+#pragma unroll
+    for (int iz = 0; iz <= O; iz++)
+#pragma unroll
+        for (int iy = 0; iy <= O; iy++)
+#pragma unroll
+            for (int ix = 0; ix <= O; ix++) {
+                if constexpr (COMP == 0) sink.add(0, ix, iy, iz, s.sxc[ix] * s.syn[iy] * s.szn[iz] * s.wqx);
+                else if constexpr (COMP == 1) sink.add(1, ix, iy, iz, s.sxn[ix] * s.syc[iy] * s.szn[iz] * s.wqy);
+                else sink.add(2, ix, iy, iz, s.sxn[ix] * s.syn[iy] * s.szc[iz] * s.wqz);
+            }
+}
+
 // Sink concept for direct: void add_abs(int comp, int gi, int gj, int gk, double v) with
 // absolute grid indices.
 template <int O, class Sink>

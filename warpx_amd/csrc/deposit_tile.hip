@@ -279,6 +279,8 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     // like the lanes of phase C (the single list it replaces cost 2-3 LDS cycles per step in conflicts: the list
     // pass was 16 % of the kernel for 3 % of the particles)
     constexpr bool SNG = CFG::SNG != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && !FUSED;
+    // the same switch on the direct deposition: the lane's two particles on one frame, the ones without a partner deferred
+    constexpr bool DPM = CFG::SNG != 0 && CFG::ALGO == WXA_DEPOSIT_DIRECT && !FUSED;
     constexpr int NBKT = SNG ? 2 * NBANK : NBANK;   // buckets: by bank for the crossing particles, then by bank for the lone ones
     __shared__ unsigned deferred[DEFER];
     __shared__ int ndef[NBKT];
@@ -605,7 +607,40 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             if (va && !push_one(pa, ia)) { fa.gq.push(ia); va = false; }
             if (vb && !push_one(pb, ib)) { fa.gq.push(ib); vb = false; }
         }
-        if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT) {
+        if constexpr (DPM) {
+            // doDepositionShapeN (CurrentDeposition.H:48-249) on the tile, the lane's two particles on one frame per
+            // component (direct_pair_component): they share it when their nodal stencils coincide (two particles of a
+            // sort cell).  A second particle on another frame goes to the deferred list (phase D: one lane per
+            // component and particle on the particle's own stencils); a stencil that leaves the tile to the
+            // global-atomics pass.  The range check is the frame's, one point wider than the particle's own.
+            DirectShapes<O> da, db;
+            direct_shapes<O>(pa, g, q, relative_time, da);
+            direct_shapes<O>(pb, g, q, relative_time, db);
+            auto inside = [&](const DirectShapes<O>& d) {
+                const int li = d.jn - 1 - o0, lj = d.kn - 1 - o1, lk = d.ln - 1 - o2;
+                return li >= 0 && lj >= 0 && lk >= 0 && li + O + 1 < N && lj + O + 1 < N && lk + O + 1 < NZ;
+            };
+            bool a_on = va && inside(da), b_on = vb && inside(db);
+            if (va && !a_on) sq.push(ia);
+            if (vb && !b_on) sq.push(ib);
+            if (a_on && b_on && (da.jn != db.jn || da.kn != db.kn || da.ln != db.ln)) {
+                defer_particle(ib, ((db.jn - o0) + 8 * (db.ln - o2)) & (NBANK - 1), pb);
+                b_on = false;
+            }
+            if (a_on || b_on) {
+                if (!a_on) da.wqx = da.wqy = da.wqz = 0.0;
+                if (!b_on) db.wqx = db.wqy = db.wqz = 0.0;
+                const int fi = (a_on ? da.jn : db.jn) - o0, fj = (a_on ? da.kn : db.kn) - o1, fk = (a_on ? da.ln : db.ln) - o2;
+                LdsSink<M, TSZ, ACC> sjx(lds, fi - 1, fj, fk), sjy(lds, fi, fj - 1, fk), sjz(lds, fi, fj, fk - 1);
+                direct_pair_component<O, 0>(da, db, sjx);
+                direct_pair_component<O, 1>(da, db, sjy);
+                direct_pair_component<O, 2>(da, db, sjz);
+            }
+            if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
+            else ch += WAVES;
+            continue;
+        }
+        if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT && !DPM) {
             // doDepositionShapeN (CurrentDeposition.H:48-249) on the tile: the lane's two particles one after the other,
             // each component on its own frame (jx: cell-centred in x, nodal in y and z; ...), products in the
             // reference's order; a stencil that leaves the tile goes to the global-atomics pass
@@ -769,6 +804,14 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                         const int at = bkt * DKEEP + row;
                         p1 = ParticleState{dkeep[0][at], dkeep[1][at], dkeep[2][at], dkeep[3][at], dkeep[4][at],
                                            dkeep[5][at], dkeep[6][at]};
+                    }
+                    if constexpr (DPM) {
+                        DirectShapes<O> ds;
+                        direct_shapes<O>(p1, g, q, relative_time, ds);
+                        LdsSink<M, TSZ, ACC> sink(lds, (COMP == 0 ? ds.jc : ds.jn) - o0, (COMP == 1 ? ds.kc : ds.kn) - o1,
+                                                  (COMP == 2 ? ds.lc : ds.ln) - o2);
+                        direct_single_component<O, COMP>(ds, sink);
+                        continue;
                     }
                     const EsirkepovCoords c1 = esirkepov_coords(p1, g, es);
                     const double wq = q * p1.w;
@@ -935,7 +978,8 @@ using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV
 #define WXA_F32_SNG 1
 #endif
 using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, WXA_F32_ZF, WXA_F32_SNG>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
-using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // direct deposition on the same work items (32-cell chunks: 16.1 -> 14.9 ms)
+using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;
+using RowsDirectSeq = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // 85 (dev builds): the lane's two particles one after the other, as until round 4   // direct deposition on the same work items (32-cell chunks: 16.1 -> 14.9 ms)
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/variants.py): WXA_DEPOSIT_VARIANT=<n>, order-3 Esirkepov
 using RowsB16 = RowsCfg<768, 8, 3, 1, 0, double, 16>;
 using RowsB16Coop = RowsCfg<768, 8, 3, 1, 0, double, 16, WXA_DEPOSIT_ESIRKEPOV, 1>;
@@ -1065,6 +1109,10 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
 #endif
         return launch_rows<3, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
     }
+#ifdef WXA_DEV_VARIANTS
+    if (const char* e = getenv("WXA_DEPOSIT_VARIANT"); e && atoi(e) == 85 && order == 3)
+        return launch_rows<3, RowsDirectSeq>(p, J, geom, q, dt, relative_time, ws, st);
+#endif
     if (order == 1) return launch_rows<1, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
     if (order == 2) return launch_rows<2, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
     return launch_rows<3, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
