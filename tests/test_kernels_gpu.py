@@ -523,7 +523,7 @@ def test_deposit_tiles_fast_and_crossing_paths(oracle, product, stale, u_scale):
 
 @pytest.mark.skipif("dev" not in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", "")),
                     reason="timing variants exist in -DWXA_DEV_VARIANTS builds only (WXA_PRODUCT_LIB=.../libwarpx_amd_dev.so)")
-@pytest.mark.parametrize("deposit_variant", [14, 20, 22, 30, 31, 40, 61, 62, 63, 64, 65, 66, 70, 71, 80, 81, 82, 83, 90], indirect=True)
+@pytest.mark.parametrize("deposit_variant", [14, 20, 22, 30, 31, 40, 61, 62, 63, 64, 65, 66, 70, 71, 80, 81, 82, 83, 90, 91, 92, 93, 94, 95], indirect=True)
 @pytest.mark.parametrize("stale", [False, True])
 @pytest.mark.parametrize("u_scale", [1.0, 0.003])
 def test_deposit_tile_variants(oracle, product, deposit_variant, stale, u_scale):

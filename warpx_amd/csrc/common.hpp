@@ -118,6 +118,16 @@ __device__ inline long xcd_tile_id(long bid, long ntiles) {
     return (bid & 7) * per + (bid >> 3);
 }
 inline long xcd_grid_size(long ntiles) { return ((ntiles + 7) / 8) * 8; }
+// The t-th tile of a traversal in blocks of 4 x 4 x 2 tiles (x fastest inside a block, blocks x fastest) instead of rows
+// of nt0 tiles: the ~32 workgroups an XCD runs at a time are then one block, whose tiles share their halos' J lines
+// while those are in the L2 (as a row, a tile met 2 of its 26 neighbours).  Grids that the blocks do not tile keep the rows.
+__device__ inline long blocked_tile(long t, int nt0, int nt1, int nt2) {
+    if ((nt0 & 3) || (nt1 & 3) || (nt2 & 1)) return t;
+    const long b = t >> 5;
+    const int w = (int)(t & 31), bx = nt0 >> 2, by = nt1 >> 2;
+    const long i = 4 * (b % bx) + (w & 3), j = 4 * ((b / bx) % by) + ((w >> 2) & 3), k = 2 * (b / ((long)bx * by)) + (w >> 4);
+    return i + nt0 * (j + (long)nt1 * k);
+}
 constexpr long WXA_NUM_CU = 256;   // MI355X: 8 XCDs x 32 CUs (persistent kernels launch one workgroup per CU)
 
 // hardware fp64 atomic add (global_atomic_add_f64 / ds_add_f64), no CAS loop

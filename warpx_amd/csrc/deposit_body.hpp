@@ -299,9 +299,15 @@ __device__ __forceinline__ void esirkepov_accumulate_pair_nc(const EsirkepovNC<O
 // Live state per phase at order 3: Jz 16 + 16 + 6 doubles (x, y weights of both particles, Dz), Jx 16 + 16 + 6 (+ 6 for
 // Dy, + the x coordinates), Jy 16 + 16 + 6 -- against 2 x 24 weights + 2 x 9 running sums when everything is kept.
 // Both particles of a pair share the stencil frame, i.e. the reference node of every direction.
-template <int O, bool RECOMPUTE_X, class Sink>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// before_jx / before_jy: called between the phases (the tile kernel requests its next chunk's particles there: the
+// phases that follow hide the loads' latency, and the registers of the phases that are over are free for them)
+template <int O, bool RECOMPUTE_X, class Sink, class HookX = NoHook, class HookY = NoHook>
 __device__ __forceinline__ void esirkepov_pair_phased(EsirkepovCoords c1, EsirkepovCoords c2, const double wq1,
-                                                      const double wq2, const EsirkepovStep& es, Sink& sink) {
+                                                      const double wq2, const EsirkepovStep& es, Sink& sink,
+                                                      HookX&& before_jx = NoHook{}, HookY&& before_jy = NoHook{}) {
     constexpr int NW = O + 1;
     constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
     const int jx = shape_node_of<O>(c1.x_new), jy = shape_node_of<O>(c1.y_new), jz = shape_node_of<O>(c1.z_new);
@@ -356,6 +362,7 @@ __device__ __forceinline__ void esirkepov_pair_phased(EsirkepovCoords c1, Esirke
         phase(std::integral_constant<int, 2>{}, D1, D2, x1n, x1o, x2n, x2o, y1n, y1o, y2n, y2o);
     }
     __builtin_amdgcn_sched_barrier(0);
+    before_jx();
     double z1n[NW], z1o[NW], z2n[NW], z2o[NW];
     bspline_weights<O, true>(z1n, c1.z_new, jz); bspline_weights<O, true>(z1o, c1.z_old, jz);
     bspline_weights<O, true>(z2n, c2.z_new, jz); bspline_weights<O, true>(z2o, c2.z_old, jz);
@@ -379,6 +386,7 @@ __device__ __forceinline__ void esirkepov_pair_phased(EsirkepovCoords c1, Esirke
         phase(std::integral_constant<int, 0>{}, D1, D2, y1n, y1o, y2n, y2o, z1n, z1o, z2n, z2o);
     }
     __builtin_amdgcn_sched_barrier(0);
+    before_jy();
     if constexpr (RECOMPUTE_X) {
         bspline_weights<O, true>(x1n, c1.x_new, jx); bspline_weights<O, true>(x1o, c1.x_old, jx);
         bspline_weights<O, true>(x2n, c2.x_new, jx); bspline_weights<O, true>(x2o, c2.x_old, jx);

@@ -183,8 +183,21 @@ constexpr int FUSED_GNPTS = FUSED_GN * FUSED_GN * FUSED_GN;
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
 template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, class ACC_ = double, int BW_ = 0,
           int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0, int FUSED_ = 0, int PUSHER_ = WXA_PUSHER_BORIS,
-          int HF_ = 0, int PT_ = 0, int GIDX_ = 0, int FLUSH_ = 0, int ZF_ = 0, int SNG_ = 0>
+          int HF_ = 0, int PT_ = 0, int GIDX_ = 0, int FLUSH_ = 0, int ZF_ = 0, int SNG_ = 0, int PFD_ = 0, int TI_ = 0, int TB_ = 0, int LD16_ = 0>
 struct RowsCfg {
+    // LD16: the lane's two particles -- neighbours in every array -- come as one 16-byte load per array (7 load instructions
+    // per chunk instead of 14, each lane's bytes in one place)
+    static constexpr int LD16 = LD16_;
+    static constexpr int TB = TB_;   // 1: the tiles in blocks of 4 x 4 x 2 (blocked_tile, common.hpp)
+    // TI: the tail table is ordered by cell (cell-wave, then row) instead of by row, and its chunks are interleaved with
+    // the direct chunks in proportion, so that a cell's pairs beyond the fourth are read a few chunks after its first
+    // four instead of ~35 chunks later, when their cache lines have left the L2 (a tile's particles are 230 KB, the L2
+    // holds 128 KB per CU): the loop's loads alone take 2.1 ms, what 12.5 GB of traffic cost -- 8.3 GB are algorithmic
+    static constexpr int TI = TI_;
+    // PFD: the particles of a wave's NEXT chunk are requested in the middle of the current chunk's pair body (1: before its
+    // last component, 2: before its second) instead of at the top of their own chunk: without it a wave has loads in
+    // flight only while it waits for them -- the kernel without arithmetic and without atomics still takes 3.8 of its 5.9 ms
+    static constexpr int PFD = PFD_;
     // SNG: a second deferred list for the particles that stay in their cell but cannot be merged with their lane partner
     // (another stencil frame: one of the two has left the sort cell since the last sort).  Phase D runs them through a
     // one-component body on their own fast frame, (O+1)^2 O = 48 atomics per component, instead of the crossing
@@ -338,7 +351,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         for (int d = 0; d < 3; ++d) { WXA_OPAQUE_UNIFORM_F64(es.dtdx[d]); WXA_OPAQUE_UNIFORM_F64(es.invdtd[d]); }
         WXA_OPAQUE_UNIFORM_F64(q); WXA_OPAQUE_UNIFORM_F64(relative_time);
     }
-    const long tile = unit / SUB;
+    const long tile = CFG::TB ? blocked_tile(unit / SUB, tg.nt[0], tg.nt[1], tg.nt[2]) : unit / SUB;
     const int half = (int)(unit % SUB);
     const long ucell0 = tile * TILE_CELLS + half * CELLS;
     const int start = offsets[ucell0];
@@ -486,7 +499,8 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 if (t < holes) slot[pairs + t][c] = (hpre + t < otot) ? fill[b * (4 * MEM) + hpre + t] : NOFILL;
         }
     } else if (tid < CELLS) {
-        const int cnt = __popcll(masks[lane / CW][lane % CW]);
+        // scan order of the 64 (row, cell-wave) counts: row-major, or -- TI -- cell-wave-major
+        const int cnt = CFG::TI ? __popcll(masks[lane % RT][lane / RT]) : __popcll(masks[lane / CW][lane % CW]);
         int incl = cnt;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -499,7 +513,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            const int base = __shfl(excl, r * CW + wave);   // first item of (tail row r, this cell-wave)
+            const int base = __shfl(excl, CFG::TI ? wave * RT + r : r * CW + wave);   // first item of (tail row r, this cell-wave)
             if (my_pairs > 4 + r) {
                 const int at = base + __popcll(my_mask[r] & lt);
                 if (at < TCAP) table[at] = (unsigned short)(tid | ((4 + r) << 9));
@@ -526,7 +540,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
 #ifdef WXA_DEPOSIT_PROFILE
     const long long prof_l0 = clock64();
 #endif
-    const int nchunks = NB + ((T + TPC - 1) / TPC);
+    const int nchunks = CFG::DBG == 5 ? 0 : NB + ((T + TPC - 1) / TPC);   // DBG 5 (timing): the phases around the loop alone
     // DYN: a wave holds the chunk it works on and has already claimed the next one (the counter's round trip through the
     // LDS queue -- behind the other waves' atomics -- hides behind the chunk)
     auto claim = [&]() {
@@ -536,10 +550,15 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     };
     int claimed = 0;
     if constexpr (CFG::DYN != 0) claimed = claim();
-    for (int ch = CFG::DYN ? __builtin_amdgcn_readfirstlane(__shfl(claimed, 0)) : wave; ch < nchunks;) {   // wave-uniform
-        if constexpr (CFG::DYN != 0) claimed = claim();
+    // the lane's work item of chunk ch: its two particles (an empty lane reads the tile's first particle)
+    auto item_of = [&](const int q, int& ia, int& ib, bool& va, bool& vb) {
+        int ch = q;
+        if constexpr (CFG::TI != 0 && !HF) {   // the q-th chunk of the interleaved sequence
+            const int ntail = nchunks - NB;
+            const int tb = q * ntail / nchunks, ti = (q + 1) * ntail / nchunks;
+            ch = ti > tb ? NB + tb : q - tb;
+        }
         int c, r;
-        bool va;
         if (ch < NB) {
             c = BW * (ch / (4 / RPC)) + (lane % BW); r = RPC * (ch % (4 / RPC)) + lane / BW; va = true;
             if constexpr (HF) {
@@ -559,15 +578,60 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         if (CFG::GIDX != 0 && ch < NB) { s0 = offsets[ucell0 + c]; n0 = offsets[ucell0 + c + 1] - s0; }
         else { s0 = cstart[c]; n0 = cstart[c + 1] - s0; }
         va = va && 2 * r < n0;
-        const int ia = va ? s0 + 2 * r : start;
-        bool vb = va && 2 * r + 1 < n0;
-        const int ib = vb ? ia + 1 : ia;
+        ia = va ? s0 + 2 * r : start;
+        vb = va && 2 * r + 1 < n0;
+        ib = vb ? ia + 1 : ia;
+    };
+    constexpr int PFD = (CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && !FUSED && !COOP && CFG::DYN == 0 && CFG::DBG == 0) ? CFG::PFD : 0;
+    int nia = start, nib = start;
+    bool nva = false, nvb = false, has_next = false;
+    ParticleState na{}, nb{};
+    auto request_next = [&]() {   // between two compiler fences: the loads stay where they are written
+        if (has_next) {
+            asm volatile("" ::: "memory");
+            na = ParticleState{px[nia], py[nia], pz[nia], pw[nia], pux[nia], puy[nia], puz[nia]};
+            nb = ParticleState{px[nib], py[nib], pz[nib], pw[nib], pux[nib], puy[nib], puz[nib]};
+            asm volatile("" ::: "memory");
+        }
+    };
+    if constexpr (PFD != 0) {
+        has_next = wave < nchunks;
+        if (has_next) item_of(wave, nia, nib, nva, nvb);
+        request_next();
+    }
+    for (int ch = CFG::DYN ? __builtin_amdgcn_readfirstlane(__shfl(claimed, 0)) : wave; ch < nchunks;) {   // wave-uniform
+        if constexpr (CFG::DYN != 0) claimed = claim();
+        int ia, ib;
+        bool va, vb;
+        if constexpr (PFD != 0) {
+            ia = nia; ib = nib; va = nva; vb = nvb;
+            has_next = ch + WAVES < nchunks;
+            if (has_next) item_of(ch + WAVES, nia, nib, nva, nvb);
+        } else {
+            item_of(ch, ia, ib, va, vb);
+        }
         // all fourteen loads in flight together (an empty lane reads the tile's first particle)
 #ifdef WXA_DEPOSIT_PROFILE
         const long long prof_c0 = clock64();
 #endif
-        ParticleState pa{px[ia], py[ia], pz[ia], pw[ia], pux[ia], puy[ia], puz[ia]};
-        ParticleState pb{px[ib], py[ib], pz[ib], pw[ib], pux[ib], puy[ib], puz[ib]};
+        ParticleState pa, pb;
+        if constexpr (PFD != 0) {
+            pa = na; pb = nb;
+        } else if (CFG::LD16 != 0 && end - start >= 2) {   // (a tile with one particle: below)
+            typedef double D2U __attribute__((ext_vector_type(2), aligned(8)));
+            const int b2 = ia + 1 < end ? ia : ia - 1;   // the pair's first index; a last particle without a partner comes second
+            const D2U vx = *reinterpret_cast<const D2U*>(px + b2), vy = *reinterpret_cast<const D2U*>(py + b2);
+            const D2U vz = *reinterpret_cast<const D2U*>(pz + b2), vw = *reinterpret_cast<const D2U*>(pw + b2);
+            const D2U vux = *reinterpret_cast<const D2U*>(pux + b2), vuy = *reinterpret_cast<const D2U*>(puy + b2);
+            const D2U vuz = *reinterpret_cast<const D2U*>(puz + b2);
+            const bool first = ia == b2;
+            pa = ParticleState{first ? vx.x : vx.y, first ? vy.x : vy.y, first ? vz.x : vz.y, first ? vw.x : vw.y,
+                               first ? vux.x : vux.y, first ? vuy.x : vuy.y, first ? vuz.x : vuz.y};
+            pb = vb ? ParticleState{vx.y, vy.y, vz.y, vw.y, vux.y, vuy.y, vuz.y} : pa;
+        } else {
+            pa = ParticleState{px[ia], py[ia], pz[ia], pw[ia], pux[ia], puy[ia], puz[ia]};
+            pb = ParticleState{px[ib], py[ib], pz[ib], pw[ib], pux[ib], puy[ib], puz[ib]};
+        }
 #ifdef WXA_DEPOSIT_PROFILE   // wave 0 of every workgroup: cycles from the loads' issue to their arrival, and of the whole chunk
         long long prof_c1 = 0;
         if (wave == 0) {
@@ -675,6 +739,11 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             else ch += WAVES;
             continue;
         }
+        if constexpr (CFG::DBG == 4) {   // timing: the loop's items and loads alone
+            if (pa.x + pa.y + pa.z + pa.w + pa.ux + pa.uy + pa.uz + pb.x + pb.y + pb.z + pb.w + pb.ux + pb.uy + pb.uz == 1.2345e-300) lds[0] = (ACC)pa.x;
+            ch += WAVES;
+            continue;
+        }
         EsirkepovCoords c1 = esirkepov_coords(pa, g, es), c2 = esirkepov_coords(pb, g, es);
         double wq1 = q * pa.w, wq2 = 0.0;
         const double wqb = q * pb.w;
@@ -739,6 +808,8 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 NullSink ns;
                 esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, ns);
                 if (ns.acc == 1.2345e-300) lds[0] = (ACC)ns.acc;
+            } else if constexpr (CFG::DBG == 3) {
+                if (c1.x_new + c2.x_new + wq1 + wq2 == 1.2345e-300) lds[0] = (ACC)wq1;   // neither: the loop's skeleton (loads, coordinates, frames, deferrals)
             } else if constexpr (CFG::DBG == 2) {
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc)
@@ -748,9 +819,15 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                         for (int a = 1; a <= O + 1; ++a)
 #pragma unroll
                             for (int l = 1; l <= O; ++l) sink.add(cc, l, a, b, wq1 + wq2);
+            } else if constexpr (PFD == 2) {
+                esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink, request_next, NoHook{});
+            } else if constexpr (PFD == 1) {
+                esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink, NoHook{}, request_next);
             } else {
                 esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
             }
+        } else if constexpr (PFD != 0) {
+            request_next();   // a lane without a fast item
         }
 #ifdef WXA_DEPOSIT_PROFILE
         if (wave == 0) {
@@ -999,9 +1076,20 @@ using RowsZeroFirst = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV
 using RowsSingles = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 0, 1>;   // 82: lone partners on their fast frame in phase D
 using RowsRound4J = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1>;   // 83: production of session j (write-back by columns only)
 using RowsW16 = RowsCfg<1024, 8, 4, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 90: production with 16 waves at 128 VGPRs
+using RowsPfd1 = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 1>;   // 91: next chunk's particles requested before the last component
+using RowsPfd2 = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 2>;   // 92: ... before the second
+using RowsTailInterleaved = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 0, 1>;   // 93: the tail's chunks among the direct ones
+using RowsTileBlocks = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 0, 0, 1>;   // 94: tiles in blocks of 4 x 4 x 2
+using RowsLd16 = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1>;   // 95: 16-byte particle loads
+using RowsLd16LoadsOnly = RowsCfg<768, 8, 3, 1, 4, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1>;   // 116: 114 with them
 using RowsHFDyn = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 1, 0, WXA_PUSHER_BORIS, 1>;   // 61: ... + dynamic chunks
 using RowsNoLds = RowsCfg<768, 8, 3, 1, 1, double, 32>;   // 101: the arithmetic without the LDS atomics (wrong J)
 using RowsNoAlu = RowsCfg<768, 8, 3, 1, 2, double, 32>;   // 102: the LDS atomics without the arithmetic (wrong J)
+using RowsNoLdsNew = RowsCfg<768, 8, 3, 1, 1, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 111: 101 on the production configuration
+using RowsNoAluNew = RowsCfg<768, 8, 3, 1, 2, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 112: 102 on it
+using RowsLoadsOnly = RowsCfg<768, 8, 3, 1, 4, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 114
+using RowsPhasesOnly = RowsCfg<768, 8, 3, 1, 5, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 115
+using RowsSkeleton = RowsCfg<768, 8, 3, 1, 3, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 113: neither (wrong J)
 #endif
 
 #ifdef WXA_DEV_VARIANTS   // measured and not adopted (wxa_debug_push_and_deposit, particles.hip): 14.8 ms against 4.7 + 6.8
@@ -1100,9 +1188,20 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                 case 82: return launch_rows<3, RowsSingles>(p, J, geom, q, dt, relative_time, ws, st);
                 case 83: return launch_rows<3, RowsRound4J>(p, J, geom, q, dt, relative_time, ws, st);
                 case 90: return launch_rows<3, RowsW16>(p, J, geom, q, dt, relative_time, ws, st);
+                case 91: return launch_rows<3, RowsPfd1>(p, J, geom, q, dt, relative_time, ws, st);
+                case 92: return launch_rows<3, RowsPfd2>(p, J, geom, q, dt, relative_time, ws, st);
+                case 93: return launch_rows<3, RowsTailInterleaved>(p, J, geom, q, dt, relative_time, ws, st);
+                case 94: return launch_rows<3, RowsTileBlocks>(p, J, geom, q, dt, relative_time, ws, st);
+                case 95: return launch_rows<3, RowsLd16>(p, J, geom, q, dt, relative_time, ws, st);
+                case 116: return launch_rows<3, RowsLd16LoadsOnly>(p, J, geom, q, dt, relative_time, ws, st);
                 case 61: return launch_rows<3, RowsHFDyn>(p, J, geom, q, dt, relative_time, ws, st);
                 case 101: return launch_rows<3, RowsNoLds>(p, J, geom, q, dt, relative_time, ws, st);
                 case 102: return launch_rows<3, RowsNoAlu>(p, J, geom, q, dt, relative_time, ws, st);
+                case 111: return launch_rows<3, RowsNoLdsNew>(p, J, geom, q, dt, relative_time, ws, st);
+                case 112: return launch_rows<3, RowsNoAluNew>(p, J, geom, q, dt, relative_time, ws, st);
+                case 114: return launch_rows<3, RowsLoadsOnly>(p, J, geom, q, dt, relative_time, ws, st);
+                case 115: return launch_rows<3, RowsPhasesOnly>(p, J, geom, q, dt, relative_time, ws, st);
+                case 113: return launch_rows<3, RowsSkeleton>(p, J, geom, q, dt, relative_time, ws, st);
                 default: break;
             }
         }

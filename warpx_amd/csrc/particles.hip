@@ -839,7 +839,8 @@ wxa_status wxa_enforce_periodic(const wxa_particle_view* p, const double plo[3],
 // moves less than one cell per step, so while fewer steps than a tile is wide have passed since the sort, a particle
 // of an interior tile cannot have left the domain.  Same arithmetic as wxa_enforce_periodic on 18 % of the particles
 // (256^3 in tiles of 8^3).
-__global__ void __launch_bounds__(256)
+constexpr int EPT_THREADS = 1024;   // x 4 particles per lane = a tile of 8 per cell in one pass, all its loads in flight
+__global__ void __launch_bounds__(EPT_THREADS)
 enforce_periodic_tiles_kernel(double* __restrict__ x, double* __restrict__ y, double* __restrict__ z,
                               const int* __restrict__ offsets, int nt0, int nt1, int nt2, int nc0, int nc1, int nc2,
                               PeriodicBox pb) {
@@ -855,11 +856,11 @@ enforce_periodic_tiles_kernel(double* __restrict__ x, double* __restrict__ y, do
     // four particles per lane and pass, all their loads in flight before the first (conditional) store: written as one
     // load - test - store after the other, the kernel had one load in flight per lane (0.49 ms for 18 % of the particles)
     constexpr int U = 4;
-    for (int base = start + (int)threadIdx.x; base < end; base += 256 * U) {
+    for (int base = start + (int)threadIdx.x; base < end; base += EPT_THREADS * U) {
         double v[U][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ip = base + u * 256;
+            const int ip = base + u * EPT_THREADS;
             const bool in = ip < end;
             v[u][0] = in && pb.on[0] ? x[ip] : 0.0;
             v[u][1] = in && pb.on[1] ? y[ip] : 0.0;
@@ -867,7 +868,7 @@ enforce_periodic_tiles_kernel(double* __restrict__ x, double* __restrict__ y, do
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ip = base + u * 256;
+            const int ip = base + u * EPT_THREADS;
             if (ip >= end) continue;
             if (pb.on[0]) { const double w = wrap_periodic(v[u][0], pb.plo[0], pb.phi[0]); if (w != v[u][0]) x[ip] = w; }
             if (pb.on[1]) { const double w = wrap_periodic(v[u][1], pb.plo[1], pb.phi[1]); if (w != v[u][1]) y[ip] = w; }
@@ -894,7 +895,7 @@ wxa_status wxa_enforce_periodic_sorted(const wxa_particle_view* p, const double 
     if (!any) return WXA_OK;
     const int nt0 = (ws->sort_nc[0] + WXA_TILE - 1) / WXA_TILE, nt1 = (ws->sort_nc[1] + WXA_TILE - 1) / WXA_TILE,
               nt2 = (ws->sort_nc[2] + WXA_TILE - 1) / WXA_TILE;
-    hipLaunchKernelGGL(enforce_periodic_tiles_kernel, dim3((unsigned)(nt0 * nt1 * nt2)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(enforce_periodic_tiles_kernel, dim3((unsigned)(nt0 * nt1 * nt2)), dim3(EPT_THREADS), 0, (hipStream_t)stream,
                        p->x, p->y, p->z, (const int*)ws->offsets.p, nt0, nt1, nt2, ws->sort_nc[0], ws->sort_nc[1],
                        ws->sort_nc[2], pb);
     if (p->np > ws->sorted_np) {   // appended since the sort
