@@ -4,7 +4,7 @@
 # run on the CPU execution model.  This session: (1) those tests first (seconds), (2) the default bench line + kernel
 # trace, (3) the whole -m gpu suite, (4) smoke.  PMC=1 re-takes the FETCH / WRITE passes (only needed when a kernel source
 # under warpx_amd/csrc/*.hip,*.hpp has changed: bench.py prints whether the committed stamp still matches).
-#   gpurun --timeout 1500 -- 'bash scripts/gpu_round4_a.sh'
+#   gpurun --timeout 1500 -- 'bash scripts/sessions/gpu_round4_a.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4a
 mkdir -p $OUT

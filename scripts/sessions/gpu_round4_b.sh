@@ -2,7 +2,7 @@
 # Round 4, second GPU session: the three kernel candidates of scripts/round4/ (prepared from the gfx950 ISA in round 3's
 # GPU-less session) in ONE dev build, each against the production configuration, then their parity tests on the MI355X.
 # Applies the patches to the working tree of the GPU box's snapshot only (nothing is committed by this script).
-#   gpurun --timeout 1200 -- 'bash scripts/gpu_round4_b.sh'
+#   gpurun --timeout 1200 -- 'bash scripts/sessions/gpu_round4_b.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4b
 mkdir -p $OUT

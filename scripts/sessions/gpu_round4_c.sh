@@ -2,7 +2,7 @@
 # Round 4, third GPU session: the deposition with hole filling (an empty slot of the direct part takes a late pair of a
 # cell of the same bank class) and persistent tiles (one workgroup per CU loops over tiles), each alone and together,
 # against round 3's kernel (variant 60), in one dev build; then their parity tests on the MI355X.
-#   gpurun --timeout 900 -- 'bash scripts/gpu_round4_c.sh'
+#   gpurun --timeout 900 -- 'bash scripts/sessions/gpu_round4_c.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4c
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, fourth GPU session: where the time of the two particle kernels goes at HEAD -- SQ counters of the SHIPPED
 # kernels (production library, no variant switch), and the timing experiments "no LDS atomics" / "no arithmetic".
-#   gpurun --timeout 1200 -- 'bash scripts/gpu_round4_d.sh'
+#   gpurun --timeout 1200 -- 'bash scripts/sessions/gpu_round4_d.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4d
 mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Round 4, fifth GPU session: two more candidates, each against production in one dev build --
 #  * deposition: the direct chunks' cell offsets from global memory instead of LDS (variants 65, 66: + dynamic chunks);
 #  * gather: lanes l and l ^ 1 exchange through DPP and store 16 bytes each (WXA_GATHER_ST=1): 3 dwordx4 stores instead of 6 dwordx2.
-#   gpurun --timeout 900 -- 'bash scripts/gpu_round4_e.sh'
+#   gpurun --timeout 900 -- 'bash scripts/sessions/gpu_round4_e.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4e
 mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Round 4, evidence session at HEAD (production library, no variant switch): the default bench line, the kernel trace of the
 # same command, the PMC passes (FETCH / WRITE traffic and the SQ counters of the two particle kernels, stamped with the
 # kernel sources' fingerprint), the whole -m gpu suite, smoke.
-#   gpurun --timeout 2400 -- 'bash scripts/gpu_round4_f.sh'
+#   gpurun --timeout 2400 -- 'bash scripts/sessions/gpu_round4_f.sh'
 set -u
 OUT=$(pwd)/gpurun_out/${SESSION:-r4f}
 mkdir -p $OUT

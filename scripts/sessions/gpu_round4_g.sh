@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4: the transport changes on the hardware (count round on its own communicator, no stream sync at the end of
 # Redistribute), the brick tests, the dry-comm line on one GPU, and the bench line again (Redistribute no longer syncs).
-#   gpurun --timeout 900 -- 'bash scripts/gpu_round4_g.sh'
+#   gpurun --timeout 900 -- 'bash scripts/sessions/gpu_round4_g.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4g
 mkdir -p $OUT

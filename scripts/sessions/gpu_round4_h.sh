@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4: half tiles again on round 3's kernel (two workgroups of 79 KB per CU: variants 70 = 2 x 6 waves, 71 = 2 x 8 waves at
 # 128 VGPRs) against production; parity of the two variants; the sort interval swept again on the production library.
-#   gpurun --timeout 900 -- 'bash scripts/gpu_round4_h.sh'
+#   gpurun --timeout 900 -- 'bash scripts/sessions/gpu_round4_h.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4h
 mkdir -p $OUT

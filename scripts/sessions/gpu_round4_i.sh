@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: CKC EvolveB with the E planes requested two steps ahead (variants 6-9) against production and the older tile shapes.
-#   gpurun --timeout 600 -- 'bash scripts/gpu_round4_i.sh'
+#   gpurun --timeout 600 -- 'bash scripts/sessions/gpu_round4_i.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4i
 mkdir -p $OUT

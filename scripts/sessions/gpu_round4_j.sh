@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: the deposition's write-back by columns (variant 80) against production; the new CKC production tile in the suite.
-#   gpurun --timeout 600 -- 'bash scripts/gpu_round4_j.sh'
+#   gpurun --timeout 600 -- 'bash scripts/sessions/gpu_round4_j.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4j
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: the secondary configurations at HEAD -- direct deposition (order 3 and 2), Vay pusher -- as bench lines.
-#   gpurun --timeout 600 -- 'bash scripts/gpu_round4_l.sh'
+#   gpurun --timeout 600 -- 'bash scripts/sessions/gpu_round4_l.sh'
 set -u
 OUT=$(pwd)/gpurun_out/r4l
 mkdir -p $OUT
