@@ -433,6 +433,11 @@ wxa_status wxa_nci_godfrey_stencil(double cdtodz, int32_t nodal_gather, int32_t 
 wxa_status wxa_fill_boundary_periodic(const wxa_field_view* f, const int ng[3],
                                       const int periodic[3], void* stream);
 
+/* The same fill for nf <= 6 fields at once (the components of E and B before the gather: WarpX::FillBoundaryE + FillBoundaryB,
+ * Source/Evolve/WarpXEvolve.cpp:515-516): one launch per direction instead of one per field and direction.  f[0 .. nf). */
+wxa_status wxa_fill_boundary_periodic_multi(const wxa_field_view* f, int32_t nf, const int ng[3],
+                                            const int periodic[3], void* stream);
+
 /* The extra step of FillBoundaryAndSync (Source/ablastr/utils/Communication.cpp:99-101,
  * 109-110; WarpX::sync_nodal_points, Source/WarpX.H:1523) on a self-periodic direction:
  * the high-edge nodal point takes the value of the low-edge one (its owner). */
@@ -443,6 +448,10 @@ wxa_status wxa_sync_nodal_periodic(const wxa_field_view* f, const int periodic[3
  * guards are refreshed (Source/Parallelization/WarpXSumGuardCells.cpp:17-37). */
 wxa_status wxa_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3],
                                      const int periodic[3], void* stream);
+
+/* ... for nf <= 6 fields at once (the three components of J: WarpX::SyncCurrent, Source/Parallelization/WarpXComm.cpp:1386-1424). */
+wxa_status wxa_sum_boundary_periodic_multi(const wxa_field_view* f, int32_t nf, const int src_ng[3],
+                                           const int periodic[3], void* stream);
 
 /* Multi-brick exchange helpers: copy a sub-box of a field to/from a dense
  * staging buffer (i fastest).  box = [blo, bhi) in the field's index space.

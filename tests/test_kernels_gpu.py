@@ -200,6 +200,39 @@ def test_sum_boundary(oracle, product, name, src_ng):
     assert np.array_equal(fd.to_numpy(), f.to_numpy())
 
 
+@pytest.mark.parametrize("names,ng_fill", [(("Ex", "Ey", "Ez", "Bx", "By", "Bz"), 2), (("Ex", "By"), 4), (("jx", "jy", "jz"), 1)])
+def test_fill_boundary_of_several_fields_in_one_launch(oracle, product, names, ng_fill):
+    """wxa_fill_boundary_periodic_multi (one launch per direction for all fields: E and B before the gather) against the
+    oracle's fill of every field on its own: bit-identical, each staggering with its own boxes."""
+    fs = H.random_fields(names, NCELL, 4, 61)
+    fds = [f.copy_to(DEV, True) for f in fs]
+    per = H.i3((1, 1, 1))
+    for f in fs:
+        oracle.fill_boundary_periodic(C.byref(f.view), H.i3((ng_fill,) * 3), per, None)
+    views = (_capi.FieldView * len(fds))(*[f.view for f in fds])
+    product.fill_boundary_periodic_multi(views, len(fds), H.i3((ng_fill,) * 3), per, None)
+    _sync(product)
+    for a, b in zip(fds, fs):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+    with pytest.raises(_capi.WxaError):
+        product.fill_boundary_periodic_multi(views, 7, H.i3((ng_fill,) * 3), per, None)
+
+
+@pytest.mark.parametrize("src_ng", [2, 4])
+def test_sum_boundary_of_several_fields_in_one_launch(oracle, product, src_ng):
+    """wxa_sum_boundary_periodic_multi (the three components of J in SyncCurrent) against the oracle's sum per field."""
+    fs = H.random_fields(("jx", "jy", "jz"), NCELL, 4, 71)
+    fds = [f.copy_to(DEV, True) for f in fs]
+    per = H.i3((1, 1, 0))
+    for f in fs:
+        oracle.sum_boundary_periodic(C.byref(f.view), H.i3((src_ng,) * 3), per, None)
+    views = (_capi.FieldView * 3)(*[f.view for f in fds])
+    product.sum_boundary_periodic_multi(views, 3, H.i3((src_ng,) * 3), per, None)
+    _sync(product)
+    for a, b in zip(fds, fs):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+
+
 def test_pack_unpack_roundtrip(product):
     import torch
     (f,) = H.random_fields(("Ey",), NCELL, 3, 80)

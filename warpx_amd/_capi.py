@@ -250,6 +250,8 @@ _SIM_SIGS = {
 
 # product-only entry points
 _PRODUCT_SIGS = {
+    "fill_boundary_periodic_multi": (C.c_int, [_PFV, C.c_int32, _I3, _I3, C.c_void_p]),
+    "sum_boundary_periodic_multi": (C.c_int, [_PFV, C.c_int32, _I3, _I3, C.c_void_p]),
     "workspace_set_external_particle_fields": (C.c_int, [C.c_void_p, _D3, _D3]),
     "workspace_set_repeated_plasma_lens": (C.c_int, [C.c_void_p, C.POINTER(RepeatedPlasmaLens)]),
     "workspace_set_time": (C.c_int, [C.c_void_p, C.c_double]),

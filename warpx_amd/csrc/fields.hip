@@ -480,6 +480,67 @@ sum_periodic_kernel(DevF f, int d, int nc, int s0, int s1) {
     }
 }
 
+// The two kernels above for several fields at once (blockIdx.y = field): the periodic fill of E and B before the gather is
+// 18 launches of a few microseconds as one launch per field and direction, and every launch costs about as much again in
+// the gap behind it; with the six components of a direction in one launch it is 3.  Same arithmetic, same order per field.
+constexpr int WXA_MULTI_MAX = 6;
+struct SideCopySet {
+    DevF f[WXA_MULTI_MAX];
+    BoxN lo[WXA_MULTI_MAX], hi[WXA_MULTI_MAX];
+    int shift[WXA_MULTI_MAX];   // the period along d in points
+};
+__global__ void __launch_bounds__(256)
+shift_copy_sides_multi_kernel(SideCopySet a, int d) {
+    const int c = blockIdx.y;
+    const DevF f = a.f[c];
+    const BoxN box_lo = a.lo[c], box_hi = a.hi[c];
+    const int s0 = d == 0 ? a.shift[c] : 0, s1 = d == 1 ? a.shift[c] : 0, s2 = d == 2 ? a.shift[c] : 0;
+    const long half = (long)box_lo.n[0] * box_lo.n[1] * box_lo.n[2];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < 2 * half; t += (long)gridDim.x * blockDim.x) {
+        const bool hi = t >= half;
+        const long u = hi ? t - half : t;
+        const BoxN& box = hi ? box_hi : box_lo;
+        const int sg = hi ? -1 : 1;
+        const int aa = (int)(u % box.n[0]);
+        const int bb = (int)((u / box.n[0]) % box.n[1]);
+        const int cc = (int)(u / ((long)box.n[0] * box.n[1]));
+        const int i = box.lo[0] + aa, j = box.lo[1] + bb, k = box.lo[2] + cc;
+        f.p[f.off(i, j, k)] = f.p[f.off(i + sg * s0, j + sg * s1, k + sg * s2)];
+    }
+}
+struct PeriodicSumSet {
+    DevF f[WXA_MULTI_MAX];
+    int nc[WXA_MULTI_MAX], s0[WXA_MULTI_MAX], s1[WXA_MULTI_MAX];
+};
+__global__ void __launch_bounds__(256)
+sum_periodic_multi_kernel(PeriodicSumSet a, int d) {
+    const int c = blockIdx.y;
+    const DevF f = a.f[c];
+    const int nc = a.nc[c], s0 = a.s0[c], s1 = a.s1[c];
+    const int lo[3] = {f.lo0, f.lo1, f.lo2};
+    const int n[3] = {f.n0, f.n1, f.n2};
+    const long st[3] = {1, f.js, f.ks};
+    const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+    const int nr = n[d] - nc;
+    if (nr <= 0) return;
+    const long total = (long)n[da] * nr * n[db];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        int aa, r, b;
+        if (d == 0) {
+            r = (int)(t % nr); aa = (int)((t / nr) % n[da]); b = (int)(t / ((long)nr * n[da]));
+        } else {
+            aa = (int)(t % n[da]); r = (int)((t / n[da]) % nr); b = (int)(t / ((long)n[da] * nr));
+        }
+        double* base = f.p + aa * st[da] + b * st[db];
+        const int a0 = lo[d], a1 = lo[d] + n[d];
+        const int first = a0 + r;
+        double sum = 0.0;
+        for (int m = first; m < a1; m += nc)
+            if (m >= s0 && m < s1) sum += base[(long)(m - a0) * st[d]];
+        for (int m = first; m < a1; m += nc) base[(long)(m - a0) * st[d]] = sum;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 pack_kernel(DevF f, BoxN box, double* __restrict__ buf) {
     const long total = (long)box.n[0] * box.n[1] * box.n[2];
@@ -1096,6 +1157,71 @@ wxa_status wxa_fill_boundary_periodic(const wxa_field_view* f, const int ng[3], 
                                blo, bhi, sh[0], sh[1], sh[2]);
         lo[d] = v0 - ng[d];
         hi[d] = v1 + ng[d];
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_fill_boundary_periodic_multi(const wxa_field_view* f, int32_t nf, const int ng[3], const int periodic[3],
+                                            void* stream) {
+    WXA_REQUIRE(f && ng && periodic && nf >= 1 && nf <= WXA_MULTI_MAX, "bad argument");
+    int lo[WXA_MULTI_MAX][3], hi[WXA_MULTI_MAX][3];
+    for (int c = 0; c < nf; ++c) {
+        WXA_REQUIRE(view_ok(f[c]), "bad field view");
+        for (int d = 0; d < 3; ++d) {
+            WXA_REQUIRE(ng[d] <= f[c].ng[d], "ng exceeds allocated guards");
+            lo[c][d] = f[c].lo[d] + f[c].ng[d];
+            hi[c][d] = f[c].lo[d] + f[c].n[d] - f[c].ng[d];
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d] || ng[d] <= 0) continue;
+        SideCopySet a;
+        long most = 0;
+        for (int c = 0; c < nf; ++c) {
+            const int nc = f[c].n[d] - 2 * f[c].ng[d] - f[c].stag[d];
+            WXA_REQUIRE(ng[d] <= nc, "guard depth exceeds the period");
+            const int v0 = f[c].lo[d] + f[c].ng[d], v1 = f[c].lo[d] + f[c].n[d] - f[c].ng[d];
+            a.f[c] = make_devf(f[c]);
+            for (int e = 0; e < 3; ++e) { a.lo[c].lo[e] = a.hi[c].lo[e] = lo[c][e]; a.lo[c].n[e] = a.hi[c].n[e] = hi[c][e] - lo[c][e]; }
+            a.lo[c].lo[d] = v0 - ng[d]; a.hi[c].lo[d] = v1;
+            a.lo[c].n[d] = a.hi[c].n[d] = ng[d];
+            a.shift[c] = nc;
+            most = std::max(most, 2 * (long)a.lo[c].n[0] * a.lo[c].n[1] * a.lo[c].n[2]);
+            lo[c][d] = v0 - ng[d];
+            hi[c][d] = v1 + ng[d];
+        }
+        for (int c = nf; c < WXA_MULTI_MAX; ++c) { a.f[c] = a.f[0]; a.lo[c] = a.lo[0]; a.hi[c] = a.hi[0]; a.shift[c] = 0; }
+        if (most > 0)
+            hipLaunchKernelGGL(shift_copy_sides_multi_kernel, dim3(grid_for(most), (unsigned)nf), dim3(256), 0,
+                               (hipStream_t)stream, a, d);
+    }
+    WXA_LAUNCH_CHECK();
+    return WXA_OK;
+}
+
+wxa_status wxa_sum_boundary_periodic_multi(const wxa_field_view* f, int32_t nf, const int src_ng[3], const int periodic[3],
+                                           void* stream) {
+    WXA_REQUIRE(f && src_ng && periodic && nf >= 1 && nf <= WXA_MULTI_MAX, "bad argument");
+    for (int c = 0; c < nf; ++c) WXA_REQUIRE(view_ok(f[c]), "bad field view");
+    for (int d = 0; d < 3; ++d) {
+        if (!periodic[d]) continue;
+        PeriodicSumSet a;
+        long most = 0;
+        const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+        for (int c = 0; c < nf; ++c) {
+            WXA_REQUIRE(src_ng[d] <= f[c].ng[d], "src_ng exceeds allocated guards");
+            const int nc = f[c].n[d] - 2 * f[c].ng[d] - f[c].stag[d];
+            WXA_REQUIRE(nc >= f[c].stag[d] + 2 * f[c].ng[d], "brick thinner than its guard cells");
+            a.f[c] = make_devf(f[c]);
+            a.nc[c] = nc;
+            a.s0[c] = f[c].lo[d] + f[c].ng[d] - src_ng[d];
+            a.s1[c] = f[c].lo[d] + f[c].n[d] - f[c].ng[d] + src_ng[d];
+            most = std::max(most, (long)f[c].n[da] * (f[c].n[d] - nc) * f[c].n[db]);
+        }
+        for (int c = nf; c < WXA_MULTI_MAX; ++c) { a.f[c] = a.f[0]; a.nc[c] = a.nc[0]; a.s0[c] = a.s0[0]; a.s1[c] = a.s1[0]; }
+        hipLaunchKernelGGL(sum_periodic_multi_kernel, dim3(grid_for(most), (unsigned)nf), dim3(256), 0, (hipStream_t)stream,
+                           a, d);
     }
     WXA_LAUNCH_CHECK();
     return WXA_OK;

@@ -103,10 +103,19 @@ public:
             // direction the exchange runs as usual (exchange_slabs skips the side without a neighbour)
             if (!m_periodic[d] && !exchanges(d)) continue;
             if (self_periodic(d)) {
-                for (size_t c = 0; c < nf; ++c) {
-                    const wxa_field_view& f = mfs[c]->view();
-                    if (nodal_sync && f.stag[d]) self_op(f, d, 0, lo[c].data(), hi[c].data(), /*sync=*/true, stream);
-                    self_op(f, d, ng[d], lo[c].data(), hi[c].data(), /*sync=*/false, stream);
+                if (!nodal_sync && ng[d] > 0 && m_be->fill_boundary_periodic_multi && nf >= 2 && nf <= 6) {
+                    // all fields of the direction in one launch (the device routine is the same copy per field)
+                    wxa_field_view v[6];
+                    for (size_t c = 0; c < nf; ++c) v[c] = transverse_view(mfs[c]->view(), d, lo[c].data(), hi[c].data());
+                    int per[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+                    per[d] = 1; g[d] = ng[d];
+                    check(m_be->fill_boundary_periodic_multi(v, (int32_t)nf, g, per, stream));
+                } else {
+                    for (size_t c = 0; c < nf; ++c) {
+                        const wxa_field_view& f = mfs[c]->view();
+                        if (nodal_sync && f.stag[d]) self_op(f, d, 0, lo[c].data(), hi[c].data(), /*sync=*/true, stream);
+                        self_op(f, d, ng[d], lo[c].data(), hi[c].data(), /*sync=*/false, stream);
+                    }
                 }
             } else {
                 std::vector<Slabs> sl(nf);
@@ -148,10 +157,14 @@ public:
         for (int d = 0; d < 3; ++d) {
             if (!m_periodic[d] && !exchanges(d)) continue;
             if (self_periodic(d)) {
-                for (size_t c = 0; c < nf; ++c) {
-                    int per[3] = {0, 0, 0}, g[3] = {0, 0, 0};
-                    per[d] = 1; g[d] = src_ng[d];
-                    check(m_be->sum_boundary_periodic(&mfs[c]->view(), g, per, stream));
+                int per[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+                per[d] = 1; g[d] = src_ng[d];
+                if (m_be->sum_boundary_periodic_multi && nf >= 2 && nf <= 6) {
+                    wxa_field_view v[6];
+                    for (size_t c = 0; c < nf; ++c) v[c] = mfs[c]->view();
+                    check(m_be->sum_boundary_periodic_multi(v, (int32_t)nf, g, per, stream));
+                } else {
+                    for (size_t c = 0; c < nf; ++c) check(m_be->sum_boundary_periodic(&mfs[c]->view(), g, per, stream));
                 }
             } else {
                 std::vector<Slabs> sl(nf);
@@ -250,9 +263,7 @@ public:
 private:
     // self-periodic fill (or nodal sync) along d over the transverse box [lo,hi) of the other
     // directions: restrict the view transversally so the device routine touches exactly that box
-    void self_op(const wxa_field_view& f, int d, int ng, const int lo[3], const int hi[3], bool sync,
-                 void* stream) {
-        if (!sync && ng <= 0) return;
+    static wxa_field_view transverse_view(const wxa_field_view& f, int d, const int lo[3], const int hi[3]) {
         wxa_field_view v = f;
         for (int e = 0; e < 3; ++e) {
             if (e == d) continue;
@@ -263,6 +274,12 @@ private:
             v.ng[e] = 0;
             v.stag[e] = 0;
         }
+        return v;
+    }
+    void self_op(const wxa_field_view& f, int d, int ng, const int lo[3], const int hi[3], bool sync,
+                 void* stream) {
+        if (!sync && ng <= 0) return;
+        wxa_field_view v = transverse_view(f, d, lo, hi);
         int per[3] = {0, 0, 0}, g[3] = {0, 0, 0};
         per[d] = 1; g[d] = ng;
         if (sync) {

@@ -82,6 +82,9 @@ struct Backend {
     int (*fill_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);
     int (*sync_nodal_periodic)(const wxa_field_view*, const int*, void*);
     int (*sum_boundary_periodic)(const wxa_field_view*, const int*, const int*, void*);
+    // optional (may be null: the callers loop over the fields): several fields per launch
+    int (*fill_boundary_periodic_multi)(const wxa_field_view*, int32_t, const int*, const int*, void*) = nullptr;
+    int (*sum_boundary_periodic_multi)(const wxa_field_view*, int32_t, const int*, const int*, void*) = nullptr;
     int (*pack_box)(const wxa_field_view*, const int32_t*, const int32_t*, double*, void*);
     int (*unpack_box)(const wxa_field_view*, const int32_t*, const int32_t*, const double*, int, void*);
     int (*field_set_zero)(const wxa_field_view*, void*);

@@ -116,6 +116,10 @@ const Backend* hip_backend() {
             return wxa_sync_nodal_periodic(f, per, st); };
         b.sum_boundary_periodic = [](const wxa_field_view* f, const int* ng, const int* per, void* st) -> int {
             return wxa_sum_boundary_periodic(f, ng, per, st); };
+        b.fill_boundary_periodic_multi = [](const wxa_field_view* f, int32_t nf, const int* ng, const int* per, void* st) -> int {
+            return wxa_fill_boundary_periodic_multi(f, nf, ng, per, st); };
+        b.sum_boundary_periodic_multi = [](const wxa_field_view* f, int32_t nf, const int* ng, const int* per, void* st) -> int {
+            return wxa_sum_boundary_periodic_multi(f, nf, ng, per, st); };
         b.pack_box = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, double* buf, void* st) -> int {
             return wxa_pack_box(f, lo, hi, buf, st); };
         b.unpack_box = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, const double* buf, int mode,
