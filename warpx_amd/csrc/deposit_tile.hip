@@ -1047,16 +1047,15 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
 // chunk offsets from global memory, half tiles, the work item read ahead) did not beat this configuration and stays a dev variant.
 // ... then, same round (r4m, r4n: four interleaved repeats each): the zero fill behind the loads of the cell offsets (ZF)
 // 5.98 against 6.04, the lone partners of phase D on their own fast frame (SNG) 5.94, both 5.88-5.96 against 6.01-6.05.
+// ... and the last sessions of the round (u - y, profiles/round4/README.md): timing builds took the kernel apart (complete 5.9,
+// without the pair body 3.8, items and loads alone 2.8, the phases around the loop 0.74 ms) and five more candidates did not
+// beat it: the next chunk's particles requested mid-body (PFD), the tail's chunks interleaved by cell (TI), tiles in blocks
+// (TB), 16-byte particle loads (LD16), 16 waves at 128 VGPRs.  Direct deposition (SNG = 1 there: the lane's two particles on
+// one frame per component, the second one deferred when it sits on another frame): 14.8 -> 7.5 ms.
 using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;
-#ifndef WXA_F32_ZF
-#define WXA_F32_ZF 1
-#endif
-#ifndef WXA_F32_SNG
-#define WXA_F32_SNG 1
-#endif
-using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, WXA_F32_ZF, WXA_F32_SNG>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
+using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
 using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;
-using RowsDirectSeq = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // 85 (dev builds): the lane's two particles one after the other, as until round 4   // direct deposition on the same work items (32-cell chunks: 16.1 -> 14.9 ms)
+using RowsDirectSeq = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // 85 (dev builds): the lane's two particles one after the other, as until round 4 (32-cell chunks: 16.1 -> 14.9 ms in round 3)
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/variants.py): WXA_DEPOSIT_VARIANT=<n>, order-3 Esirkepov
 using RowsB16 = RowsCfg<768, 8, 3, 1, 0, double, 16>;
 using RowsB16Coop = RowsCfg<768, 8, 3, 1, 0, double, 16, WXA_DEPOSIT_ESIRKEPOV, 1>;
