@@ -2,7 +2,7 @@
 # Round 4: the secondary configurations at HEAD -- direct deposition (order 3 and 2), Vay pusher -- as bench lines.
 #   gpurun --timeout 600 -- 'bash scripts/sessions/gpu_round4_l.sh'
 set -u
-OUT=$(pwd)/gpurun_out/r4l
+OUT=$(pwd)/gpurun_out/${SESSION:-r4l}
 mkdir -p $OUT
 export TMPDIR=/tmp
 for ARGS in "--deposition direct" "--deposition direct --order 2" "--pusher vay" "--order 2" "--order 1"; do

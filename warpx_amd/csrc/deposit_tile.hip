@@ -291,9 +291,13 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     // phase D takes lane l's particle from bucket l % 16, so the 16 lanes of a ds_add_f64 step sit on 16 different banks
     // like the lanes of phase C (the single list it replaces cost 2-3 LDS cycles per step in conflicts: the list
     // pass was 16 % of the kernel for 3 % of the particles)
-    constexpr bool SNG = CFG::SNG != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && !FUSED;
+    // Odd orders only: at an even order the stencil frame follows the NEAREST node, the particles of a sort cell fall into
+    // eight frames and most of them have no partner -- the lone list (half the deferred entries) overflowed into the
+    // global-atomics pass (order 2, 256^3 x 8 ppc: 37 ms per launch against 8.4 with one list), and two particles of a
+    // lane rarely share the direct deposition's frame (9.5 ms against 8.4 one after the other).
+    constexpr bool SNG = CFG::SNG != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && !FUSED && (O & 1) != 0;
     // the same switch on the direct deposition: the lane's two particles on one frame, the ones without a partner deferred
-    constexpr bool DPM = CFG::SNG != 0 && CFG::ALGO == WXA_DEPOSIT_DIRECT && !FUSED;
+    constexpr bool DPM = CFG::SNG != 0 && CFG::ALGO == WXA_DEPOSIT_DIRECT && !FUSED && (O & 1) != 0;
     constexpr int NBKT = SNG ? 2 * NBANK : NBANK;   // buckets: by bank for the crossing particles, then by bank for the lone ones
     __shared__ unsigned deferred[DEFER];
     __shared__ int ndef[NBKT];
@@ -766,6 +770,27 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         if (sb == 2) sq.push(ib);
         if (sa == 1) defer_particle(ia, wide_bank(c1), pa);
         if (sb == 1) defer_particle(ib, wide_bank(c2), pb);
+        if constexpr ((O & 1) == 0 && CFG::SNG != 0 && !FUSED && !COOP && CFG::DBG == 0) {
+            // Even orders: the frame follows the nearest node, so the particles of a sort cell sit on eight frames and a
+            // lane's two particles share one only by chance -- and a pair on the union frame would cost more atomics
+            // ((O + 2)^2 (O + 1) per component) than two particles on their own ((O + 1)^2 O each).  So the lane deposits its
+            // two particles one after the other, each on its own frame: 2 x 54 LDS atomics at order 2, nothing deferred
+            // but the crossing particles.  (Through the pair body with the partner deferred: 8.4 ms per launch at
+            // 256^3 x 8 ppc, more than order 3's 5.9.)
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                if ((h ? sb : sa) != 0) continue;
+                const EsirkepovCoords cc = h ? c2 : c1;
+                LdsSink<M, TSZ, ACC> sink(lds, (h ? bi : ai) - o0, (h ? bj : aj) - o1, (h ? bk : ak) - o2);
+                const double wq = h ? wqb : wq1;
+                esirkepov_single_fast<O, 0>(cc, wq, es, sink);
+                esirkepov_single_fast<O, 1>(cc, wq, es, sink);
+                esirkepov_single_fast<O, 2>(cc, wq, es, sink);
+            }
+            if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
+            else ch += WAVES;
+            continue;
+        }
         int key = -1;
         bool fast_a = false, fast_b = false;   // which of the lane's particles its fast item holds
         if (sa == 0) {
