@@ -177,7 +177,7 @@ sort_count_kernel(const double* __restrict__ x, const double* __restrict__ y,
     if (head && c >= 0) base = atomicAdd(&hist[c], nh - lane);
     base = __shfl(base, hl);
     if (valid) {
-        cell[ip] = c;
+        if (cell) cell[ip] = c;   // null: the scatter works the key out again from the position it loads anyway
         rank[ip] = base + (lane - hl);
     }
 }
@@ -209,10 +209,13 @@ sort_scatter_kernel(PV src, PV dst, const int* __restrict__ cell, const int* __r
 // exactly one particle, so the masked window writes of neighbouring workgroups never touch the same element.
 constexpr int SW_THREADS = 512;
 
-template <int SW_U, int SW_MARGIN>
+// RECELL: the keys are not read from the array the count pass wrote (4 bytes per particle written there and read here, of
+// the 152 the sort moves per particle) but worked out again from the position, which this kernel loads anyway: x, y, z and
+// the id of the lane's SW_U particles are loaded first and kept for their own component passes.
+template <int SW_U, int SW_MARGIN, bool RECELL = false>
 __global__ void __launch_bounds__(SW_THREADS)
 sort_scatter_window_kernel(PV src, PV dst, const int* __restrict__ cell, const int* __restrict__ rank,
-                           const int* __restrict__ offsets) {
+                           const int* __restrict__ offsets, SortGeom sg = SortGeom{}) {
     constexpr int SW_CHUNK = SW_THREADS * SW_U, SW_WIN = SW_CHUNK + 2 * SW_MARGIN;
     __shared__ double win[SW_WIN];
     __shared__ unsigned char mine[SW_WIN];
@@ -223,12 +226,25 @@ sort_scatter_window_kernel(PV src, PV dst, const int* __restrict__ cell, const i
     long d[SW_U];
     int slot[SW_U];   // offset in the window, or -1: written directly
     int ce[SW_U], ra[SW_U];
+    double keep[RECELL ? 4 : 1][SW_U];   // RECELL: x, y, z, id (as a bit pattern) of the lane's particles
 #pragma unroll
     for (int u = 0; u < SW_U; ++u) {
         const long ip = c0 + u * SW_THREADS + tid;
         const bool in = ip < src.np;
-        ce[u] = in ? cell[ip] : 0;
+        if constexpr (RECELL) {
+            keep[0][u] = in ? src.x[ip] : 0.0; keep[1][u] = in ? src.y[ip] : 0.0; keep[2][u] = in ? src.z[ip] : 0.0;
+            keep[3][u] = in && src.id ? reinterpret_cast<const double*>(src.id)[ip] : 0.0;
+        } else {
+            ce[u] = in ? cell[ip] : 0;
+        }
         ra[u] = in ? rank[ip] : 0;
+    }
+    if constexpr (RECELL) {
+#pragma unroll
+        for (int u = 0; u < SW_U; ++u) {
+            ce[u] = cell_of(sg, keep[0][u], keep[1][u], keep[2][u]);
+            if (src.id && __builtin_bit_cast(unsigned long long, keep[3][u]) == WXA_IDCPU_RETIRED) ce[u] = sg.retired_bin;
+        }
     }
 #pragma unroll
     for (int u = 0; u < SW_U; ++u) {
@@ -253,7 +269,8 @@ sort_scatter_window_kernel(PV src, PV dst, const int* __restrict__ cell, const i
 #pragma unroll
         for (int u = 0; u < SW_U; ++u) {
             const long ip = c0 + u * SW_THREADS + tid;
-            v[u] = ip < src.np ? sp[c][ip] : 0.0;   // ids travel as bit patterns
+            if (RECELL && (c < 3 || c == 7)) v[u] = keep[c < 3 ? c : 3][u];
+            else v[u] = ip < src.np ? sp[c][ip] : 0.0;   // ids travel as bit patterns
         }
 #pragma unroll
         for (int u = 0; u < SW_U; ++u) {
@@ -941,25 +958,30 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     sg.retired_bin = (int)ncells;
     (void)cell_lo;
     const PV s = make_pv(*src), d = make_pv(*dst);
+#ifdef WXA_DEV_VARIANTS   // WXA_SORT_SCATTER=0: the plain scatter (one lane per particle, 8-byte writes wherever they fall); 1: keys from the array
+    const char* scatter_env = std::getenv("WXA_SORT_SCATTER");
+    const bool plain_scatter = scatter_env && std::atoi(scatter_env) == 0;
+    const bool keys_from_array = plain_scatter || (scatter_env && std::atoi(scatter_env) == 1);
+#else
+    const bool plain_scatter = false, keys_from_array = false;
+#endif
     hipLaunchKernelGGL(sort_count_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s.x, s.y, s.z, s.id, s.np, sg,
-                       cell, rank, hist);
+                       keys_from_array ? cell : (int*)nullptr, rank, hist);
     size_t tmp_bytes = 0;
     WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
     if ((rc = ws->scan_tmp.reserve(tmp_bytes)) != WXA_OK) return rc;
     WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
-#ifdef WXA_DEV_VARIANTS   // WXA_SORT_SCATTER=0: the plain scatter (one lane per particle, 8-byte writes wherever they fall)
-    const char* scatter_env = std::getenv("WXA_SORT_SCATTER");
-    const bool plain_scatter = scatter_env && std::atoi(scatter_env) == 0;
-#else
-    const bool plain_scatter = false;
-#endif
     if (plain_scatter)
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s, d, cell, rank, offsets);
     else {
         // window shapes timed at 256^3 x 8 ppc (Redistribute per step, plain scatter 1.47): 8 x 512 lanes + 512 margin
         // 1.24, 4 x 512 + 512 1.29, 8 x 512 + 1024 1.25, 16 x 512 + 512 1.38
-        hipLaunchKernelGGL((sort_scatter_window_kernel<8, 512>), dim3(blocks_for(s.np, SW_THREADS * 8)), dim3(SW_THREADS), 0,
-                           st, s, d, cell, rank, offsets);
+        if (keys_from_array)
+            hipLaunchKernelGGL((sort_scatter_window_kernel<8, 512, false>), dim3(blocks_for(s.np, SW_THREADS * 8)), dim3(SW_THREADS), 0,
+                               st, s, d, cell, rank, offsets, sg);
+        else
+            hipLaunchKernelGGL((sort_scatter_window_kernel<8, 512, true>), dim3(blocks_for(s.np, SW_THREADS * 8)), dim3(SW_THREADS), 0,
+                               st, s, d, cell, rank, offsets, sg);
     }
     WXA_LAUNCH_CHECK();
     ws->sorted_valid = true;
