@@ -272,6 +272,37 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src,
                                       const int32_t cell_lo[3], const int32_t ncell[3],
                                       wxa_workspace* ws, void* stream);
 
+/* The same sort folded into PushPX: SortParticlesByBin only permutes the tile (Source/Particles/
+ * MultiParticleContainer.cpp:615-621), and PhysicalParticleContainer::PushPX (PhysicalParticleContainer.cpp:2549-2786) has
+ * every particle in registers, so the sort needs no passes of its own over the eight arrays.  Between wxa_push_sort_begin
+ * and wxa_push_sort_end every moving push on `ws` (wxa_gather_push_ws with move = 1, wxa_gather_push_part; PushP is
+ * untouched) additionally
+ *   WXA_PUSH_SORT_COUNT:   keys each particle's NEW position with the tile-major cell key of wxa_sort_particles_by_cell
+ *       (wrap[d] != 0: a cell index one period outside along d is brought back -- the key of the position that
+ *       wxa_enforce_periodic will produce; otherwise clamped) and takes its rank among equal keys; _end scans the
+ *       histogram.  Retired particles get the bin behind the cells.  The record stays in ws until a SCATTER uses it, a
+ *       new COUNT replaces it or wxa_sort_particles_by_cell / wxa_partition_particles invalidates it;
+ *   WXA_PUSH_SORT_SCATTER: writes the pushed particle (x y z ux uy uz, and w and idcpu carried over) to `dst` at the index
+ *       the record of the last COUNT on the same arrays gives it, instead of in place: `dst` then holds the particles
+ *       in the cell order of their positions BEFORE this push -- the order wxa_sort_particles_by_cell would have
+ *       produced one push earlier; the LDS-tile kernels take it like any sort that is one step old.  Particles
+ *       retired since the COUNT stay where they were counted (until the next cycle); particles appended since
+ *       (p->np grew) keep their order behind the cell-sorted ones; the retired ones of the record end up behind those.
+ *   Both at once (a sort every step): the new keys are recorded at the destination indices.
+ * _end: *live = cell-sorted particles now at the front of the tile (dst after a SCATTER), *appended = particles that
+ * follow them; the caller keeps live + appended particles of dst.  read_live != 0: the record contained retired particles
+ * and *live is read from the device (synchronises); read_live = 0: *live = the record's particle count.  After a SCATTER
+ * ws describes dst (tile offsets of the LDS-tile kernels), exactly as after wxa_sort_particles_by_cell(p, dst). */
+enum { WXA_PUSH_SORT_COUNT = 1, WXA_PUSH_SORT_SCATTER = 2 };
+wxa_status wxa_push_sort_begin(wxa_workspace* ws, int32_t mode, const wxa_particle_view* p,
+                               const wxa_particle_view* dst, const double plo[3], const double dinv[3],
+                               const int32_t cell_lo[3], const int32_t ncell[3], const int32_t wrap[3],
+                               void* stream);
+wxa_status wxa_push_sort_end(wxa_workspace* ws, int32_t read_live, int64_t* live, int64_t* appended,
+                             void* stream);
+/* 1 when ws holds a COUNT record that a SCATTER of exactly these arrays can use */
+int32_t wxa_push_sort_pending(const wxa_workspace* ws, const wxa_particle_view* p);
+
 /* 3-way partition of a tile along `dim` for the brick-to-brick part of
  * amrex ParticleContainer::Redistribute: dst = [stay | to-minus | to-plus] for positions
  * in [lo,hi) / < lo / >= hi.  counts[3] (host) is valid on return (synchronises). */

@@ -646,6 +646,167 @@ def test_gather_push_lds_tiles(oracle, product, order, galerkin, stale):
     product.workspace_destroy(ws)
 
 
+def _tile_major_key(pos, ncell, dx, wrap):
+    """cell_of (csrc/push_sort.hpp) in numpy: the tile-major cell key, indices one period outside brought back where
+    `wrap` says so, clamped otherwise."""
+    cell = []
+    for d in range(3):
+        c = np.floor((pos[d] + H.LX / 2) / dx[d]).astype(np.int64)
+        if wrap[d]:
+            c = np.where(c < 0, c + ncell[d], np.where(c >= ncell[d], c - ncell[d], c))
+        cell.append(np.clip(c, 0, ncell[d] - 1))
+    T = 8
+    nt = [(m + T - 1) // T for m in ncell]
+    tile = cell[0] // T + nt[0] * (cell[1] // T + nt[1] * (cell[2] // T))
+    kt = cell[2] % T
+    return tile * T ** 3 + cell[0] % T + T * ((kt & 1) + 2 * (cell[1] % T + T * (kt >> 1)))
+
+
+@pytest.mark.parametrize("order,sort_first,tail,retire,every_step", [
+    (3, True, 0, False, False),     # the LDS-tile kernels (tile + stragglers)
+    (3, True, 700, True, False),    # ... with an appended tail (global-memory kernel), retired particles, arrivals after the count
+    (1, True, 0, True, True),       # COUNT and SCATTER in the same push (a sort every step)
+    (4, False, 0, False, False),    # no tiles at all: the global-memory kernel does everything
+    (2, True, 300, False, True),
+])
+def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, retire, every_step):
+    """wxa_push_sort_begin / _end (SortParticlesByBin folded into PushPX, csrc/push_sort.hpp): three pushes, the first
+    records keys and ranks (COUNT), the second writes the particles into the sorted tile (SCATTER), the third runs on
+    that tile through the workspace the SCATTER left.  Against the oracle's plain pushes of the same particles: every
+    particle arrives with its own data (ids), pushed to 1e-12; the new order is the tile-major cell order of the
+    positions BEFORE the scattering push, wrapped along the periodic directions; retired particles of the record end up
+    behind everything and are dropped; particles appended after the COUNT follow the cell-sorted ones in their order."""
+    import torch
+    ncell = (24, 20, 16)
+    ng, _, _ = H.guard_depths(order)
+    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, ng, 10, scale=1e11)
+    B = H.random_fields(("Bx", "By", "Bz"), ncell, ng, 11, scale=1e3)
+    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
+    n0, n_arrive = 30000, 400
+    parts = H.random_particles(n0 + tail, ncell, 500 + order, u_scale=30.0)   # up to ~0.5 cell per push
+    dx = H.LX / np.asarray(ncell)
+    plo, dinv = H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx)
+    lo, nc = (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell)
+    wrap_flags = (1, 0, 1)
+    wrap = (C.c_int32 * 3)(*wrap_flags)
+    g, _ = H.geom_for(ncell, ng)
+    dt = H.yee_dt(dx)
+    q, m = -plasma.Q_E, plasma.M_E
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    cap = n0 + tail + n_arrive
+    ids0 = np.arange(1, n0 + tail + 1, dtype=np.int64)
+    cur = ParticleArrays(cap, DEV, with_id=True)          # the tile, with room for arrivals
+    head = [np.asarray(r[:n0]) for r in parts]
+    if sort_first:   # a classic sort of the first n0 particles; `tail` more are appended behind it
+        src = ParticleArrays.from_numpy(head, DEV, ids0[:n0])
+        v = cur.view
+        v.np = n0
+        product.sort_particles_by_cell(C.byref(src.view), C.byref(v), plo, dinv, lo, nc, ws, None)
+        _sync(product)
+        for r in range(7):
+            cur.data[r][n0:n0 + tail] = torch.from_numpy(np.asarray(parts[r][n0:])).to(DEV)
+        cur.idcpu[n0:n0 + tail] = torch.from_numpy(ids0[n0:]).to(DEV)
+    else:
+        for r in range(7):
+            cur.data[r][:n0 + tail] = torch.from_numpy(np.asarray(parts[r])).to(DEV)
+        cur.idcpu[:n0 + tail] = torch.from_numpy(ids0).to(DEV)
+    npart = n0 + tail
+    rng = np.random.default_rng(17)
+
+    def view_of(pa, n):
+        v = pa.view
+        v.np = n
+        return v
+
+    def host_copy(pa, n):
+        return pa.to_numpy()[:, :n], pa.ids_to_numpy()[:n]
+
+    def oracle_push(rows):
+        ph = ParticleArrays.from_numpy(list(rows), "cpu")
+        oracle.gather_push(C.byref(ph.view), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt, order, 1,
+                           _capi.PUSHER_BORIS, None)
+        return ph.to_numpy()
+
+    def keep_inside(pa, n):   # what Redistribute does between two pushes: periodic wrap, or a wall that keeps them in
+        for d in range(3):
+            x = pa.data[d][:n]
+            if wrap_flags[d]:
+                x.copy_(torch.where(x >= H.LX / 2, x - H.LX, torch.where(x < -H.LX / 2, x + H.LX, x)))
+            else:
+                x.clamp_(-H.LX / 2, H.LX / 2 - 1e-12)
+
+    live_i64 = C.c_int64()
+    app_i64 = C.c_int64()
+    spare = ParticleArrays(cap, DEV, with_id=True)
+    modes = [_capi.PUSH_SORT_COUNT, _capi.PUSH_SORT_SCATTER | (_capi.PUSH_SORT_COUNT if every_step else 0),
+             _capi.PUSH_SORT_SCATTER if every_step else 0]
+    n_retired_in_record = 0
+    for step, mode in enumerate(modes):
+        before, before_ids = host_copy(cur, npart)
+        want = oracle_push(before)
+        pv, dv = view_of(cur, npart), view_of(spare, npart)
+        if mode:
+            assert (product.push_sort_pending(ws, C.byref(pv)) == 1) == bool(mode & _capi.PUSH_SORT_SCATTER)
+            rc = product.push_sort_begin(ws, mode, C.byref(pv), C.byref(dv), plo, dinv, lo, nc, wrap, None)
+            assert rc == 0, product.last_error()
+        product.gather_push_ws(C.byref(pv), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt, order, 1,
+                               _capi.PUSHER_BORIS, 1, ws, None)
+        if mode:
+            rc = product.push_sort_end(ws, 1 if n_retired_in_record else 0, C.byref(live_i64), C.byref(app_i64), None)
+            assert rc == 0, product.last_error()
+        _sync(product)
+        if mode & _capi.PUSH_SORT_SCATTER:
+            live, appended = live_i64.value, app_i64.value
+            assert live == n_counted - n_retired_in_record and appended == npart - n_counted
+            got, got_ids = host_copy(spare, live + appended)
+            # every surviving particle arrived with its own pushed data; the retired ones of the record are gone, the
+            # ones retired since (id -1 as well) were kept where they had been counted
+            retired_of_record = (before_ids == -1) if n_retired_in_record else np.zeros(npart, bool)
+            assert retired_of_record.sum() == n_retired_in_record
+            keep = ~retired_of_record
+            assert keep.sum() == live + appended
+            lw, lg = (before_ids != -1) & keep, got_ids != -1
+            assert lw.sum() == lg.sum() and (keep & (before_ids == -1)).sum() == (got_ids == -1).sum()
+            ow, og = np.argsort(before_ids[lw]), np.argsort(got_ids[lg])
+            assert np.array_equal(before_ids[lw][ow], got_ids[lg][og])
+            for row in range(7):
+                assert H.max_rel_err(got[row][lg][og], want[row][lw][ow]) < 1e-12, row
+            assert np.all(got[3][got_ids == -1] == 0.0)
+            # the cell-sorted part: keys of the positions before this push (= after the previous one), non-decreasing
+            id_to_key = dict(zip(key_ids.tolist(), key_of.tolist()))
+            keys = np.array([id_to_key[i] for i in got_ids[:live].tolist() if i != -1])
+            assert np.all(np.diff(keys) >= 0)
+            # ... and the arrivals behind it in their order
+            assert np.array_equal(got_ids[live:], before_ids[n_counted:])
+            cur, spare = spare, cur
+            npart = live + appended
+        else:
+            got, got_ids = host_copy(cur, npart)
+            assert np.array_equal(got_ids, before_ids)
+            for row in range(7):
+                assert H.max_rel_err(got[row], want[row]) < 1e-12, row
+        if mode & _capi.PUSH_SORT_COUNT:   # what the record should hold: keys of the positions this push produced
+            after, after_ids = host_copy(cur, npart)
+            key_of = _tile_major_key(after[:3], ncell, dx, wrap_flags)
+            key_ids = after_ids
+            n_counted = npart
+            n_retired_in_record = int((after_ids == -1).sum())
+        keep_inside(cur, npart)
+        if step == 0:
+            if retire:   # Redistribute retires a few (after the COUNT: they stay where they were counted) ...
+                gone = torch.from_numpy(rng.random(npart) < 0.01).to(DEV)
+                cur.idcpu[:npart][gone] = -1
+                cur.data[3][:npart][gone] = 0.0
+            # ... and appends arrivals
+            arr = H.random_particles(n_arrive, ncell, 900, u_scale=30.0)
+            for r in range(7):
+                cur.data[r][npart:npart + n_arrive] = torch.from_numpy(np.asarray(arr[r])).to(DEV)
+            cur.idcpu[npart:npart + n_arrive] = torch.from_numpy(np.arange(10 ** 6, 10 ** 6 + n_arrive, dtype=np.int64)).to(DEV)
+            npart += n_arrive
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.skipif("dev" not in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", "") + os.environ.get("WXA_HIPCPU_LIB", "")),
                     reason="the fused kernel was measured and not adopted: -DWXA_DEV_VARIANTS builds only")
 @pytest.mark.parametrize("pusher", [_capi.PUSHER_BORIS, _capi.PUSHER_VAY])

@@ -274,6 +274,9 @@ _PRODUCT_SIGS = {
     "pack_leavers": (C.c_int, [_PPV, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _D3, _D3,
                                C.c_void_p]),
     "sort_live_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    "push_sort_begin": (C.c_int, [C.c_void_p, C.c_int32, _PPV, _PPV, _D3, _D3, _I32_3, _I32_3, _I32_3, C.c_void_p]),
+    "push_sort_end": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    "push_sort_pending": (C.c_int32, [C.c_void_p, _PPV]),
     "pack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "unpack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
     "copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -284,6 +287,7 @@ _PRODUCT_SIGS = {
     "sim_set_deposit_accumulator": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
 }
 ACC_FP64, ACC_FP32 = 0, 1
+PUSH_SORT_COUNT, PUSH_SORT_SCATTER = 1, 2
 
 # the library's own transport (rccl_comm.hip): product only
 _TRANSPORT_SIGS = {
@@ -323,7 +327,7 @@ class WxaError(RuntimeError):
 
 
 # int-returning entry points whose result is a value, not a status
-_RETURNS_A_VALUE = {"sim_max_step", "sim_num_species", "num_threads", "set_num_threads", "sim_halo_overlap"}
+_RETURNS_A_VALUE = {"sim_max_step", "sim_num_species", "num_threads", "set_num_threads", "sim_halo_overlap", "push_sort_pending"}
 
 
 class CLib:

@@ -17,6 +17,7 @@
 // cell per lane sharing the LDS reads, 9.95.  Counters, profiles/round2/r2g_pmc_128cube_gather_tile_kernel.txt: 8 LDS
 // cycles per ds instruction and 0.2 % bank conflicts, the LDS busy 60 % and the VALU 50 % of the kernel's time.)
 #include "gather_body.hpp"
+#include "push_sort.hpp"
 #include "workspace.hpp"
 
 #include <stdlib.h>
@@ -99,11 +100,15 @@ template <int PUSHER, bool MOVE, int ST = 0>
 __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, double yp, double zp, double ux, double uy,
                                                double uz, double Exp, double Eyp, double Ezp, double Bxp, double Byp,
                                                double Bzp, double q, double m, double dt, const ExtEB& ext,
+                                               const PushSort& hook,
                                                const unsigned long long here = 0ull,   // ST: the lanes that store in this trip
                                                const bool mine = true) {               // ST: ... this one among them
     add_external_fields(ext, ip, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
     push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
     if constexpr (MOVE) update_position(xp, yp, zp, ux, uy, uz, dt);
+    if constexpr (MOVE && ST == 0) {   // the cell sort folded into the push (push_sort.hpp): keyed, or written to the sorted tile
+        if (!push_sort_tail(hook, p, ip, xp, yp, zp, ux, uy, uz)) return;
+    }
     if constexpr (ST != 0 && MOVE) {
         // every lane of the trip takes part in the exchanges (a lane that does not store sends values nobody uses)
         const int lane = threadIdx.x & 63;
@@ -130,7 +135,8 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF, int ST = 0, int SL = WXA_GATHER_SL>
 __global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(G ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
-                        DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext) {
+                        DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext,
+                        PushSort hook) {
     constexpr int N = GatherTileDims<G>::N;
     constexpr int NPTS = GatherTileDims<G>::NPTS;
     __shared__ double F[6 * NPTS];
@@ -310,7 +316,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
             update_position(xp, yp, zp, ux0, uy0, uz0, dt);
             if (xp + ux0 == 1.2345e-300) p.x[ip] = yp + zp + uy0 + uz0;
         } else
-        push_and_store<PUSHER, MOVE, ST>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext, storing, staged);
+        push_and_store<PUSHER, MOVE, ST>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext, hook, storing, staged);
 #ifdef WXA_GATHER_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GPROF_CLOCK(prof_d);
@@ -334,7 +340,7 @@ template <int O, int G, int PUSHER, bool MOVE>
 __global__ void __launch_bounds__(256)
 gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned* __restrict__ count, DevF Ex,
                               DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Geom g, double q, double m, double dt,
-                              ExtEB ext) {
+                              ExtEB ext, PushSort hook) {
     const unsigned n = *count;
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const int ip = idx[t];
@@ -344,7 +350,7 @@ gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned*
         double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
         gather_global<O, G>(s, Ex, Ey, Ez, Bx, By, Bz, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
         push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, p.ux[ip], p.uy[ip], p.uz[ip], Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt,
-                                     ext);
+                                     ext, hook);
     }
 }
 
@@ -359,10 +365,10 @@ wxa_status gather_push_listed(const wxa_particle_view* p, const int* idx, const 
     const ExtEB ext{};
     if (pusher == WXA_PUSHER_VAY)
         hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, WXA_PUSHER_VAY, true>), dim3(512), dim3(256), 0, st, pv, idx,
-                           count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);
+                           count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, PushSort{});
     else
         hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, WXA_PUSHER_BORIS, true>), dim3(512), dim3(256), 0, st, pv, idx,
-                           count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);
+                           count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, PushSort{});
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
@@ -393,13 +399,14 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
     if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
     GatherStragglers sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p + 16};
     const ExtEB ext = ext_of(ws);
+    const PushSort hook = make_push_sort(ws, 0, MOVE);
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
 #define WXA_GT(O, G)                                                                                        \
     do {                                                                                                    \
         hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE, PART>), grid, block, 0, st, pv, offsets, ex, \
-                           ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
-                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);                     \
+                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, hook);                     \
     } while (0)
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/gather_variants.py): rows in flight per env, 0 = ds_read2_b64 rows
     if constexpr (PUSHER == WXA_PUSHER_BORIS && MOVE && PART == 0) {
@@ -414,25 +421,25 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
 #define WXA_GT_RB(RBV)                                                                                          \
     do {                                                                                                        \
         if (pf == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 1>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         else if (pf == 2) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 2>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         else if (pf == 3 && slv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 1>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         else if (pf == 3 && stv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 1, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         else if (pf == 3) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         else if (pf == 7) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 7>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         else if (pf == 8) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 8>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         else if (pf == 9) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 9>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         else hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
         hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
-                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext);                         \
+                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, hook);                         \
     } while (0)
             switch (atoi(e)) {
                 case 0: WXA_GT_RB(0); break;

@@ -228,6 +228,11 @@ public:
         m_fdtd_solver_fp = std::make_unique<FiniteDifferenceSolver>(&m_ctx, cfg.maxwell_solver, m_ctx.dx);
         sort_intervals = cfg.sort_interval;
         m_ctx.sort_intervals_on = sort_intervals > 0;
+        // the periodic sorts folded into the push (WarpXParticleContainer::ArmPushSort); WXA_SORT_IN_PUSH=0: the sort as
+        // passes of its own, for A/B timing and for bisecting
+        const char* fold = std::getenv("WXA_SORT_IN_PUSH");
+        m_ctx.sort_in_push = sort_intervals > 0 && !(fold && std::atoi(fold) == 0);
+        for (int d = 0; d < 3; ++d) m_ctx.sort_wrap[d] = m_comm->periodic(d) && m_comm->self_periodic(d) ? 1 : 0;
     }
 
     // WarpX::InitNCICorrector (Source/Initialization/WarpXInitData.cpp:858-890): the two Godfrey filters for
@@ -284,6 +289,7 @@ public:
             // warpx.sort_intervals (Source/WarpX.cpp:1335): the sort itself runs inside
             // PhysicalParticleContainer::Evolve, between push and deposition
             m_ctx.sort_now = sort_intervals > 0 && (istep % sort_intervals == 0);
+            m_ctx.count_now = sort_intervals > 0 && ((istep + 1) % sort_intervals == 0);   // the next step sorts
             // :157-166 ionization / collisions / QED: not on this path
             OneStep_nosub(cur_time);
             // :222-226 at the end of the last step, push p by 0.5*dt to synchronize

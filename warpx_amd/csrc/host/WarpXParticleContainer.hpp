@@ -34,7 +34,10 @@ struct WarpXContext {
     amrex::IntVect ng_alloc_EB, ng_depos_J;
     void* stream = nullptr;
     bool sort_now = false;             // this step re-sorts the tiles (sort_intervals)
+    bool count_now = false;            // the next step does: this step's push records the sort keys (sort_in_push)
     bool sort_intervals_on = false;    // warpx.sort_intervals > 0
+    bool sort_in_push = false;         // the periodic sorts are folded into PushPX (wxa_push_sort_begin, include/warpx_amd.h)
+    int32_t sort_wrap[3] = {0, 0, 0};  // directions along which this brick is its own periodic neighbour
     // boundary.particle_lo/hi resolved to WXA_PBOUNDARY_PERIODIC / _ABSORBING / _REFLECTING
     int32_t particle_bc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     int32_t particle_bc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
@@ -244,6 +247,7 @@ public:
               "sort_particles_by_cell");
         m_tile.swap(m_spare);
         m_steps_since_sort = 0;
+        m_count_nretired = 0;   // (the backend has dropped the record of a COUNT, if there was one)
         if (m_nretired > 0) {
             int64_t live = np;
             check(m_ctx->be->sort_live_count(m_ws, &live, m_ctx->stream), "sort_live_count");
@@ -251,6 +255,62 @@ public:
             m_tile.resize(live);
             m_nretired = 0;
         }
+    }
+
+    // The periodic cell sort folded into the push (wxa_push_sort_begin / _end, include/warpx_amd.h; csrc/push_sort.hpp): the
+    // push of the step before a sort step records every particle's cell key and rank (COUNT), the push of the sort
+    // step writes the particles straight into the sorted tile (SCATTER) -- no pass of its own over the eight arrays.
+    // Called before the first push of a step (PushInterior or Evolve), idempotent until FinishPushSort.
+    void ArmPushSort() {
+        const Backend* be = m_ctx->be;
+        if (m_push_sort_mode != 0 || !m_ctx->sort_in_push || !be->push_sort_begin || m_tile.numParticles() == 0) return;
+        // a species of the BackTransformed diagnostic is compared, index by index, with its copy from before the push
+        if (m_ctx->btd != nullptr && btd_species_id >= 0) return;
+        const wxa_particle_view p = m_tile.view();
+        int32_t mode = 0;
+        if (m_ctx->sort_now && be->push_sort_pending(m_ws, &p)) mode |= WXA_PUSH_SORT_SCATTER;
+        // a record is of no use when a sort of the classic kind follows this push (it replaces the order the record indexes)
+        if (m_ctx->count_now && (!m_ctx->sort_now || mode != 0)) mode |= WXA_PUSH_SORT_COUNT;
+        if (mode == 0) return;
+        wxa_particle_view dst{};
+        if (mode & WXA_PUSH_SORT_SCATTER) {
+            m_spare.resize(p.np);
+            dst = m_spare.view();
+        }
+        int32_t lo[3], nc[3];
+        for (int d = 0; d < 3; ++d) { lo[d] = m_ctx->brick_box.lo[d]; nc[d] = m_ctx->brick_box.length(d); }
+        check(be->push_sort_begin(m_ws, mode, &p, &dst, m_ctx->brick_plo.data(), m_ctx->dinv.data(), lo, nc, m_ctx->sort_wrap,
+                                  m_ctx->stream),
+              "push_sort_begin");
+        m_push_sort_mode = mode;
+    }
+    // after the last push of the step: the scan of a COUNT; after a SCATTER the sorted tile becomes the tile.
+    // Returns true when this step's sort has been done by the push.
+    bool FinishPushSort() {
+        if (m_push_sort_mode == 0) return false;
+        const int32_t mode = m_push_sort_mode;
+        m_push_sort_mode = 0;
+        // the record of a SCATTER was taken m_count_nretired retired particles into the cycle: they are dropped now
+        const bool scatter = (mode & WXA_PUSH_SORT_SCATTER) != 0;
+        int64_t live = 0, appended = 0;
+        check(m_ctx->be->push_sort_end(m_ws, scatter && m_count_nretired > 0 ? 1 : 0, &live, &appended, m_ctx->stream),
+              "push_sort_end");
+        if (scatter) {
+            const int64_t np = m_tile.numParticles();
+            if (live + appended > np || np - (live + appended) != m_count_nretired)
+                throw std::runtime_error("FinishPushSort: retired-particle count mismatch");
+            m_tile.swap(m_spare);
+            m_tile.resize(live + appended);
+            m_nretired -= m_count_nretired;
+            m_count_nretired = 0;
+            m_steps_since_sort = 1;   // the order is the cell order of the positions before this push
+        }
+        if (mode & WXA_PUSH_SORT_COUNT) m_count_nretired = m_nretired;   // the retired ones the record has put behind the cells
+        static const bool trace = std::getenv("WXA_PUSH_SORT_TRACE") != nullptr;
+        if (trace)
+            std::fprintf(stderr, "[push sort] mode %d: %lld particles, %lld cell-sorted + %lld appended, %lld retired in the tile\n",
+                         (int)mode, (long long)m_tile.numParticles(), (long long)live, (long long)appended, (long long)m_nretired);
+        return scatter;
     }
 
     // WarpXParticleContainer::ApplyBoundaryConditions (WarpXParticleContainer.cpp:1574-1660): reflecting and
@@ -458,6 +518,8 @@ public:
     int btd_species_id = -1;                    // >= 0: this species is written by the BackTransformed diagnostic
 protected:
     int64_t m_nretired = 0;            // retired by Redistribute since the last sort (still in the tile)
+    int32_t m_push_sort_mode = 0;      // WXA_PUSH_SORT_* armed for this step's push (ArmPushSort)
+    int64_t m_count_nretired = 0;      // retired particles in the tile when the last COUNT was taken
     int32_t m_steps_since_sort = -1;   // Redistribute calls since the last cell sort (-1: never sorted)
     void* m_ws = nullptr;
     bool m_do_crr = false;
@@ -627,6 +689,7 @@ public:
                 m_ctx->be->memcpy_async(m_btd_old[c].p, m_tile.comp(comp[c]), sizeof(double) * (size_t)np, m_ctx->stream);
             }
         }
+        ArmPushSort();
         {
             PhaseTimer t(m_ctx, kGatherAndPush);  // "PhysicalParticleContainer::Evolve::GatherAndPush"
             if (m_ctx->use_fdtd_nci_corr) {   // :1900-1911: filter E and B, gather from the filtered copies
@@ -649,9 +712,12 @@ public:
         // tile, so it is placed here, between push and deposition: the deposition then sees
         // positions that match the sort exactly (every stencil inside its LDS tile) and so does
         // the next step's gather.
-        if (m_ctx->sort_now) {
+        // With the sort folded into the push (ArmPushSort) the particles have been written into the sorted tile by the
+        // push itself, in the cell order of their positions before it.
+        {
             PhaseTimer t(m_ctx, kRedistribute);
-            SortParticlesByBin(amrex::IntVect(1));
+            const bool sorted_by_the_push = FinishPushSort();
+            if (m_ctx->sort_now && !sorted_by_the_push) SortParticlesByBin(amrex::IntVect(1));
         }
         if (!skip_deposition) {
             PhaseTimer t(m_ctx, kCurrentDeposition);  // "...::DepositCurrent::CurrentDeposition"
@@ -705,6 +771,7 @@ public:
     void PushInterior(ablastr::fields::MultiFabRegister& fields, amrex::Real dt) override {
         if (m_tile.numParticles() == 0 || !m_ctx->be->gather_push_part) return;
         using warpx::fields::FieldType;
+        ArmPushSort();
         PhaseTimer t(m_ctx, kGatherAndPush);
         auto Ef = fields.get_alldirs(FieldType::Efield_aux, 0);
         auto Bf = fields.get_alldirs(FieldType::Bfield_aux, 0);

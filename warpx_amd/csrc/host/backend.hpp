@@ -111,6 +111,12 @@ struct Backend {
     int (*pack_leavers)(const wxa_particle_view*, const int32_t* list, int64_t n, void* msg, int64_t row_len,
                         int64_t offset, int retire, const double* brick_lo, const double* brick_hi, void*);
     int (*sort_live_count)(void* ws, int64_t* n, void*);
+    // optional: the cell sort folded into PushPX (wxa_push_sort_begin / _end / _pending, include/warpx_amd.h); without
+    // them the container sorts with sort_particles_by_cell
+    int (*push_sort_begin)(void* ws, int32_t mode, const wxa_particle_view* p, const wxa_particle_view* dst, const double* plo,
+                           const double* dinv, const int32_t* cell_lo, const int32_t* ncell, const int32_t* wrap, void*) = nullptr;
+    int (*push_sort_end)(void* ws, int32_t read_live, int64_t* live, int64_t* appended, void*) = nullptr;
+    int (*push_sort_pending)(const void* ws, const wxa_particle_view* p) = nullptr;
     // WarpXParticleContainer::ApplyBoundaryConditions (reflecting / absorbing walls); *n_lost valid on return
     int (*apply_particle_boundaries)(const wxa_particle_view*, const double* prob_lo, const double* prob_hi,
                                      const int32_t* bc_lo, const int32_t* bc_hi, int64_t* n_lost, void* ws, void*);

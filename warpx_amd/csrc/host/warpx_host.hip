@@ -169,6 +169,14 @@ const Backend* hip_backend() {
             return wxa_apply_particle_boundaries(p, plo, phi, blo, bhi, n_lost, static_cast<wxa_workspace*>(ws), st); };
         b.sort_live_count = [](void* ws, int64_t* n, void* st) -> int {
             return wxa_sort_live_count(static_cast<wxa_workspace*>(ws), n, st); };
+        b.push_sort_begin = [](void* ws, int32_t mode, const wxa_particle_view* p, const wxa_particle_view* dst,
+                               const double* plo, const double* dinv, const int32_t* lo, const int32_t* nc,
+                               const int32_t* wrap, void* st) -> int {
+            return wxa_push_sort_begin(static_cast<wxa_workspace*>(ws), mode, p, dst, plo, dinv, lo, nc, wrap, st); };
+        b.push_sort_end = [](void* ws, int32_t read_live, int64_t* live, int64_t* appended, void* st) -> int {
+            return wxa_push_sort_end(static_cast<wxa_workspace*>(ws), read_live, live, appended, st); };
+        b.push_sort_pending = [](const void* ws, const wxa_particle_view* p) -> int {
+            return wxa_push_sort_pending(static_cast<const wxa_workspace*>(ws), p); };
         b.workspace_create = ws_create;
         b.workspace_destroy = ws_destroy;
         b.dmalloc = hip_dmalloc;

@@ -5,6 +5,7 @@
 #include <complex>
 
 #include "gather_body.hpp"
+#include "push_sort.hpp"
 #include "workspace.hpp"
 
 #include <hipcub/hipcub.hpp>
@@ -14,7 +15,7 @@ namespace wxa {
 template <int O, int G, int PUSHER, bool MOVE>
 __global__ void __launch_bounds__(256)
 gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Geom g, double q,
-                   double m, double dt, ExtEB ext) {
+                   double m, double dt, ExtEB ext, PushSort hook) {
     const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= p.np) return;
     double xp = p.x[ip], yp = p.y[ip], zp = p.z[ip];
@@ -26,11 +27,12 @@ gather_push_kernel(PV p, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, G
     add_external_fields(ext, ip, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
     double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
     push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
-    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
     if constexpr (MOVE) {
         update_position(xp, yp, zp, ux, uy, uz, dt);
+        if (!push_sort_tail(hook, p, ip, xp, yp, zp, ux, uy, uz)) return;   // written to the sorted tile instead
         p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp;
     }
+    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
 }
 
 // The repeated plasma lens seen by every particle before the push (add_lens_fields, shapes.hpp):
@@ -126,33 +128,7 @@ enforce_periodic_kernel(double* __restrict__ x, double* __restrict__ y, double* 
     if (pb.on[2]) { const double w = wrap_periodic(vz, pb.plo[2], pb.phi[2]); if (w != vz) z[ip] = w; }
 }
 
-// ---- counting sort by cell ---------------------------------------------------
-struct SortGeom {
-    double plo[3];
-    double dinv[3];
-    int nc[3];
-    int retired_bin;   // key of retired particles (= number of cell bins): they end up behind the live ones
-};
-
-// Tile-major cell key: tiles of WXA_TILE^3 cells, so that a tile's particles are contiguous
-// (LDS-tile kernels) and still grouped by cell.  Inside a tile the order is i fastest, then the
-// parity of k, then j, then k/2: any 16 consecutive cells (8 i x 2 k-parities) start on 16
-// different LDS banks of the deposition tile (deposit_tile.hip, plane stride = 8 mod 16), which
-// keeps its bank buckets evenly filled.
-__device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, double z) {
-    int i = (int)floor((x - s.plo[0]) * s.dinv[0]);
-    int j = (int)floor((y - s.plo[1]) * s.dinv[1]);
-    int k = (int)floor((z - s.plo[2]) * s.dinv[2]);
-    i = min(max(i, 0), s.nc[0] - 1);
-    j = min(max(j, 0), s.nc[1] - 1);
-    k = min(max(k, 0), s.nc[2] - 1);
-    constexpr int T = WXA_TILE;
-    const int nti = (s.nc[0] + T - 1) / T, ntj = (s.nc[1] + T - 1) / T;
-    const int tile = (i / T) + nti * ((j / T) + ntj * (k / T));
-    const int kt = k % T;
-    return tile * (T * T * T) + (i % T) + T * ((kt & 1) + 2 * ((j % T) + T * (kt >> 1)));
-}
-
+// ---- counting sort by cell (the key: SortGeom, cell_of in push_sort.hpp) ---------------
 // Histogram + rank.  The input is usually almost sorted (a few % of the particles changed cell
 // since the last sort), so equal keys sit in neighbouring lanes: each run of equal keys inside a
 // wave issues ONE atomic for the whole run instead of one per particle.
@@ -598,13 +574,13 @@ pack_leavers_kernel(PV p, const int* __restrict__ list, long n, double* __restri
 template <int PUSHER, bool MOVE>
 static wxa_status launch_gather_push(const PV& pv, const wxa_field_view E[3], const wxa_field_view B[3],
                                      const Geom& g, double q, double m, double dt, int order, int galerkin,
-                                     const ExtEB& ext, hipStream_t st) {
+                                     const ExtEB& ext, const PushSort& hook, hipStream_t st) {
     const DevF ex = make_devf(E[0]), ey = make_devf(E[1]), ez = make_devf(E[2]);
     const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
     const dim3 grid(blocks_for(pv.np)), block(256);
 #define WXA_GP(O, G)                                                                              \
     hipLaunchKernelGGL((gather_push_kernel<O, G, PUSHER, MOVE>), grid, block, 0, st, pv, ex, ey, ez, bx, by, \
-                       bz, g, q, m, dt, ext)
+                       bz, g, q, m, dt, ext, hook)
     if (galerkin) {
         if (order == 1) WXA_GP(1, 1); else if (order == 2) WXA_GP(2, 1); else if (order == 3) WXA_GP(3, 1); else WXA_GP(4, 1);
     } else {
@@ -656,23 +632,23 @@ extern "C" {
 // the global-memory kernel on `rest` with the external fields `ext`
 static wxa_status gather_push_global(const wxa_particle_view& rest, const wxa_field_view E[3], const wxa_field_view B[3],
                                      const wxa_grid_geom* geom, double q, double m, double dt, int order, int galerkin,
-                                     int pusher, int move, const ExtEB& ext, hipStream_t st) {
+                                     int pusher, int move, const ExtEB& ext, const PushSort& hook, hipStream_t st) {
     const PV pv = make_pv(rest);
     const Geom g = make_geom(*geom);
     if (pusher == WXA_PUSHER_BORIS) {
-        if (move) return launch_gather_push<WXA_PUSHER_BORIS, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
-        return launch_gather_push<WXA_PUSHER_BORIS, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+        if (move) return launch_gather_push<WXA_PUSHER_BORIS, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, hook, st);
+        return launch_gather_push<WXA_PUSHER_BORIS, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, hook, st);
     }
     if (pusher == WXA_PUSHER_VAY) {
-        if (move) return launch_gather_push<WXA_PUSHER_VAY, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
-        return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+        if (move) return launch_gather_push<WXA_PUSHER_VAY, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, hook, st);
+        return launch_gather_push<WXA_PUSHER_VAY, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, hook, st);
     }
     if (pusher == WXA_PUSHER_HC) {
-        if (move) return launch_gather_push<WXA_PUSHER_HC, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
-        return launch_gather_push<WXA_PUSHER_HC, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+        if (move) return launch_gather_push<WXA_PUSHER_HC, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, hook, st);
+        return launch_gather_push<WXA_PUSHER_HC, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, hook, st);
     }
-    if (move) return launch_gather_push<WXA_PUSHER_BORIS_RR, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
-    return launch_gather_push<WXA_PUSHER_BORIS_RR, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, st);
+    if (move) return launch_gather_push<WXA_PUSHER_BORIS_RR, true>(pv, E, B, g, q, m, dt, order, galerkin, ext, hook, st);
+    return launch_gather_push<WXA_PUSHER_BORIS_RR, false>(pv, E, B, g, q, m, dt, order, galerkin, ext, hook, st);
 }
 
 wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
@@ -697,7 +673,8 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E
         first = ws->sorted_np;
         if (rest.np == 0) return WXA_OK;
     }
-    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, move, ext_of(ws, first), (hipStream_t)stream);
+    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, move, ext_of(ws, first),
+                              make_push_sort(ws, first, move != 0), (hipStream_t)stream);
 }
 
 wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
@@ -710,7 +687,8 @@ wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view
     if ((rc = evaluate_particle_fields(p, ws, (hipStream_t)stream)) != WXA_OK) return rc;
     if (order > 3 || !gather_tile_available(ws, p)) {   // no tiles: the interior part is empty, the rest is everything
         if (part == WXA_PART_INTERIOR) return WXA_OK;
-        return gather_push_global(*p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws), (hipStream_t)stream);
+        return gather_push_global(*p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws), make_push_sort(ws, 0, true),
+                                  (hipStream_t)stream);
     }
     wxa_particle_view head = *p;
     head.np = ws->sorted_np;
@@ -721,7 +699,8 @@ wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view
     if (part == WXA_PART_INTERIOR) return WXA_OK;
     const wxa_particle_view rest = tail_view(*p, ws->sorted_np);   // arrivals since the sort may sit anywhere
     if (rest.np == 0) return WXA_OK;
-    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws, ws->sorted_np), (hipStream_t)stream);
+    return gather_push_global(rest, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws, ws->sorted_np),
+                              make_push_sort(ws, ws->sorted_np, true), (hipStream_t)stream);
 }
 
 wxa_status wxa_gather_push(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
@@ -938,6 +917,7 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     WXA_REQUIRE(ncells > 0 && ncells < (1L << 31) - 2 && src->np < (1L << 31) - 2, "sizes exceed 32-bit sort keys");
     hipStream_t st = (hipStream_t)stream;
     ws->sorted_valid = false;
+    ws->ps.pending = false;   // a record of wxa_push_sort_begin(COUNT) indexes the order this sort replaces
     if (src->np == 0) return WXA_OK;
     wxa_status rc;
     if ((rc = ws->cell.reserve(sizeof(int) * src->np)) != WXA_OK) return rc;
@@ -1006,6 +986,7 @@ wxa_status wxa_partition_particles(const wxa_particle_view* src, const wxa_parti
     hipStream_t st = (hipStream_t)stream;
     counts[0] = counts[1] = counts[2] = 0;
     ws->sorted_valid = false;
+    ws->ps.pending = false;
     if (src->np == 0) return WXA_OK;
     wxa_status rc;
     if ((rc = ws->cell.reserve(sizeof(int) * (src->np + 1))) != WXA_OK) return rc;
@@ -1212,6 +1193,110 @@ wxa_status wxa_apply_particle_boundaries(const wxa_particle_view* p, const doubl
         *n_lost = h;
     }
     return WXA_OK;
+}
+
+// ---- the cell sort folded into PushPX (push_sort.hpp) ----------------------------------------------------------------
+wxa_status wxa_push_sort_begin(wxa_workspace* ws, int32_t mode, const wxa_particle_view* p, const wxa_particle_view* dst,
+                               const double plo[3], const double dinv[3], const int32_t cell_lo[3], const int32_t ncell[3],
+                               const int32_t wrap[3], void* stream) {
+    WXA_REQUIRE(ws && pv_ok(p), "bad argument");
+    WXA_REQUIRE(mode == WXA_PUSH_SORT_COUNT || mode == WXA_PUSH_SORT_SCATTER || mode == (WXA_PUSH_SORT_COUNT | WXA_PUSH_SORT_SCATTER),
+                "mode must be WXA_PUSH_SORT_COUNT, WXA_PUSH_SORT_SCATTER or both");
+    auto& s = ws->ps;
+    WXA_REQUIRE(s.armed == 0, "wxa_push_sort_begin without the wxa_push_sort_end of the previous one");
+    WXA_REQUIRE(p->np < (1L << 31) - 2, "sizes exceed 32-bit sort keys");
+    hipStream_t st = (hipStream_t)stream;
+    wxa_status rc;
+    if (mode & WXA_PUSH_SORT_SCATTER) {
+        WXA_REQUIRE(s.pending && s.pending_x == p->x && s.pending_np <= p->np,
+                    "no record of a COUNT on these particle arrays (or they shrank since)");
+        WXA_REQUIRE(pv_ok(dst) && dst->np >= p->np && (p->np == 0 || dst->x != p->x), "the destination tile: out of place, at least as long");
+        WXA_REQUIRE((p->idcpu == nullptr) == (dst->idcpu == nullptr), "both tiles with ids or both without");
+        s.dst = *dst;
+        s.appended = p->np - s.pending_np;
+    }
+    if (mode & WXA_PUSH_SORT_COUNT) {
+        WXA_REQUIRE(plo && dinv && cell_lo && ncell && wrap, "null argument");
+        WXA_REQUIRE(ncell[0] > 0 && ncell[1] > 0 && ncell[2] > 0, "empty cell box");
+        const long ncells = (long)((ncell[0] + WXA_TILE - 1) / WXA_TILE) * ((ncell[1] + WXA_TILE - 1) / WXA_TILE) *
+                            ((ncell[2] + WXA_TILE - 1) / WXA_TILE) * (WXA_TILE * WXA_TILE * WXA_TILE);
+        WXA_REQUIRE(ncells > 0 && ncells < (1L << 31) - 2, "sizes exceed 32-bit sort keys");
+        s.out = (mode & WXA_PUSH_SORT_SCATTER) ? 1 - s.in : s.in;   // a record nobody used is overwritten
+        if (!(mode & WXA_PUSH_SORT_SCATTER)) s.pending = false;
+        if ((rc = s.kr[s.out].reserve(sizeof(unsigned long long) * (size_t)(p->np + 1))) != WXA_OK) return rc;
+        if ((rc = s.hist.reserve(sizeof(int) * (ncells + 2))) != WXA_OK) return rc;
+        if ((rc = s.offs[s.out].reserve(sizeof(int) * (ncells + 2))) != WXA_OK) return rc;
+        WXA_HIP_CHECK(hipMemsetAsync(s.hist.p, 0, sizeof(int) * (ncells + 2), st));
+        for (int d = 0; d < 3; ++d) {
+            s.plo[d] = plo[d]; s.dinv[d] = dinv[d]; s.nc[d] = ncell[d]; s.cell_lo[d] = cell_lo[d]; s.wrap[d] = wrap[d] ? 1 : 0;
+        }
+        s.bins = ncells;
+    }
+    s.np_armed = p->np;
+    s.count_x = p->x;
+    s.armed = mode;
+    return WXA_OK;
+}
+
+wxa_status wxa_push_sort_end(wxa_workspace* ws, int32_t read_live, int64_t* live, int64_t* appended, void* stream) {
+    WXA_REQUIRE(ws && live && appended, "null argument");
+    auto& s = ws->ps;
+    WXA_REQUIRE(s.armed != 0, "wxa_push_sort_end without wxa_push_sort_begin");
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t mode = s.armed;
+    s.armed = 0;
+    *live = s.np_armed;
+    *appended = 0;
+    const double* tile_x = nullptr;   // identity of the tile a new record indexes
+    int64_t tile_np = s.np_armed;
+    if (mode & WXA_PUSH_SORT_SCATTER) {
+        // the record's scan becomes the tile offsets of the LDS-tile kernels; the workspace now describes the destination tile
+        std::swap(ws->offsets.p, s.offs[s.in].p);
+        std::swap(ws->offsets.cap, s.offs[s.in].cap);
+        int64_t n_live = s.pending_np;
+        if (read_live) {   // retired particles were counted: the cell-sorted part ends where their bin starts
+            int v = 0;
+            WXA_HIP_CHECK(hipMemcpyAsync(&v, (const int*)ws->offsets.p + s.pending_bins, sizeof(int), hipMemcpyDeviceToHost, st));
+            WXA_HIP_CHECK(hipStreamSynchronize(st));
+            n_live = v;
+        }
+        ws->sorted_valid = true;
+        ws->sorted_np = n_live;
+        ws->sorted_bins = s.pending_bins;
+        ws->sorted_x = s.dst.x;
+        for (int d = 0; d < 3; ++d) {
+            ws->sort_nc[d] = s.p_nc[d]; ws->sort_cell_lo[d] = s.p_cell_lo[d];
+            ws->sort_plo[d] = s.p_plo[d]; ws->sort_dinv[d] = s.p_dinv[d];
+        }
+        s.pending = false;
+        *live = n_live;
+        *appended = s.appended;
+        tile_x = s.dst.x;
+        tile_np = n_live + s.appended;
+    }
+    if (mode & WXA_PUSH_SORT_COUNT) {
+        size_t tmp_bytes = 0;
+        int* hist = (int*)s.hist.p;
+        int* offs = (int*)s.offs[s.out].p;
+        WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hist, offs, (int)(s.bins + 2), st));
+        wxa_status rc;
+        if ((rc = ws->scan_tmp.reserve(tmp_bytes)) != WXA_OK) return rc;
+        WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, hist, offs, (int)(s.bins + 2), st));
+        s.in = s.out;
+        s.pending = true;
+        s.pending_np = tile_np;
+        s.pending_bins = s.bins;
+        s.pending_x = tile_x ? tile_x : nullptr;   // COUNT alone: set by the caller's view, below
+        for (int d = 0; d < 3; ++d) {
+            s.p_nc[d] = s.nc[d]; s.p_cell_lo[d] = s.cell_lo[d]; s.p_plo[d] = s.plo[d]; s.p_dinv[d] = s.dinv[d];
+        }
+        if (!tile_x) s.pending_x = s.count_x;
+    }
+    return WXA_OK;
+}
+
+int32_t wxa_push_sort_pending(const wxa_workspace* ws, const wxa_particle_view* p) {
+    return ws && p && ws->ps.pending && ws->ps.pending_x == p->x && ws->ps.pending_np <= p->np ? 1 : 0;
 }
 
 wxa_status wxa_sort_live_count(wxa_workspace* ws, int64_t* n, void* stream) {

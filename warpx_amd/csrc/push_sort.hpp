@@ -1,0 +1,140 @@
+// The cell sort folded into PushPX (wxa_push_sort_begin / _end, include/warpx_amd.h).
+//
+// amrex's SortParticlesByBin (MultiParticleContainer.cpp:615-621) only permutes a tile, and the push has every particle
+// in registers anyway.  So instead of a pass that reads the positions again to key them (sort_count_kernel) and a pass
+// that moves all eight arrays (sort_scatter_window_kernel: 152 B per particle, 20 GB at 256^3 x 8 per cell):
+//   * COUNT   -- the push of the step BEFORE a sort keys the particle's new position (tile-major cell key, the periodic
+//                directions wrapped the way Redistribute will wrap the position) and takes its rank among equal keys;
+//                the histogram is scanned when the push is done;
+//   * SCATTER -- the push of the sort step writes position and momentum to the destination tile at offsets[key] + rank
+//                instead of in place, and carries weight and id over.
+// The order that comes out is the cell order of the positions BEFORE the sort step's push: one push older than a sort
+// behind the push, which the LDS-tile kernels tolerate by construction (stale sorts: stragglers, deferred lists).
+// Particles retired since the count stay where they were counted (dead weight until the next cycle); particles appended
+// since the count keep their order behind the cell-sorted ones.
+#ifndef WXA_PUSH_SORT_HPP_
+#define WXA_PUSH_SORT_HPP_
+
+#include "gather_body.hpp"
+#include "workspace.hpp"
+
+namespace wxa {
+
+// ---- counting sort by cell: the key ---------------------------------------------------
+struct SortGeom {
+    double plo[3];
+    double dinv[3];
+    int nc[3];
+    int retired_bin;   // key of retired particles (= number of cell bins): they end up behind the live ones
+    int wrap[3] = {0, 0, 0};   // a cell index one period outside is brought back (the position is wrapped later); else clamped
+};
+
+// Tile-major cell key: tiles of WXA_TILE^3 cells, so that a tile's particles are contiguous
+// (LDS-tile kernels) and still grouped by cell.  Inside a tile the order is i fastest, then the
+// parity of k, then j, then k/2: any 16 consecutive cells (8 i x 2 k-parities) start on 16
+// different LDS banks of the deposition tile (deposit_tile.hip, plane stride = 8 mod 16), which
+// keeps its bank buckets evenly filled.
+__device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, double z) {
+    int i = (int)floor((x - s.plo[0]) * s.dinv[0]);
+    int j = (int)floor((y - s.plo[1]) * s.dinv[1]);
+    int k = (int)floor((z - s.plo[2]) * s.dinv[2]);
+    if (s.wrap[0]) i = i < 0 ? i + s.nc[0] : (i >= s.nc[0] ? i - s.nc[0] : i);
+    if (s.wrap[1]) j = j < 0 ? j + s.nc[1] : (j >= s.nc[1] ? j - s.nc[1] : j);
+    if (s.wrap[2]) k = k < 0 ? k + s.nc[2] : (k >= s.nc[2] ? k - s.nc[2] : k);
+    i = min(max(i, 0), s.nc[0] - 1);
+    j = min(max(j, 0), s.nc[1] - 1);
+    k = min(max(k, 0), s.nc[2] - 1);
+    constexpr int T = WXA_TILE;
+    const int nti = (s.nc[0] + T - 1) / T, ntj = (s.nc[1] + T - 1) / T;
+    const int tile = (i / T) + nti * ((j / T) + ntj * (k / T));
+    const int kt = k % T;
+    return tile * (T * T * T) + (i % T) + T * ((kt & 1) + 2 * ((j % T) + T * (kt >> 1)));
+}
+
+constexpr int PUSH_SORT_COUNT = WXA_PUSH_SORT_COUNT, PUSH_SORT_SCATTER = WXA_PUSH_SORT_SCATTER;
+
+// What the push kernels are handed (by value).  `first`: index, in the whole tile, of element 0 of the particle view the
+// kernel works on (the global-memory kernel of the appended tail gets a view that starts behind the sorted part).
+struct PushSort {
+    int mode = 0;                                   // 0, PUSH_SORT_COUNT, PUSH_SORT_SCATTER or both
+    long first = 0;
+    // COUNT
+    SortGeom sg{};
+    unsigned long long* __restrict__ kr_out = nullptr;   // (key << 32 | rank), indexed by the particle's index AFTER this push
+    int* __restrict__ hist = nullptr;
+    // SCATTER
+    const unsigned long long* __restrict__ kr_in = nullptr;   // indexed by the particle's index BEFORE this push
+    const int* __restrict__ offs = nullptr;                  // exclusive scan of the histogram kr_in was taken with
+    double* __restrict__ dx = nullptr; double* __restrict__ dy = nullptr; double* __restrict__ dz = nullptr;
+    double* __restrict__ dw = nullptr;
+    double* __restrict__ dux = nullptr; double* __restrict__ duy = nullptr; double* __restrict__ duz = nullptr;
+    unsigned long long* __restrict__ did = nullptr;
+    long np_counted = 0;      // particles kr_in covers; later ones were appended since the count
+    long n_appended = 0;      // particles behind np_counted
+    int retired_bin_in = 0;   // offs[retired_bin_in]: first index behind the cell-sorted particles
+};
+
+// index of particle `gi` (index in the whole tile before this push) in the destination tile
+__device__ __forceinline__ long push_sort_dest(const PushSort& h, const long gi) {
+    if (gi >= h.np_counted) return (long)h.offs[h.retired_bin_in] + (gi - h.np_counted);   // behind the live ones, in their order
+    const unsigned long long kr = h.kr_in[gi];
+    const int key = (int)(kr >> 32);
+    long d = (long)h.offs[key] + (long)(unsigned)(kr & 0xffffffffull);
+    if (key == h.retired_bin_in) d += h.n_appended;   // the retired ones behind the appended ones: dropped by the new count
+    return d;
+}
+
+// After the push of particle `ip` of view `p` (new position and momentum in registers; MOVE pushes only).
+// Returns true when the caller still has to store position and momentum in place.
+__device__ __forceinline__ bool push_sort_tail(const PushSort& h, const PV& p, const long ip, const double xp, const double yp,
+                                               const double zp, const double ux, const double uy, const double uz) {
+    if (h.mode == 0) return true;   // uniform
+    const long gi = h.first + ip;
+    long at = gi;                   // the particle's index after this push
+    bool in_place = true;
+    unsigned long long pid = p.id ? p.id[ip] : 0ull;
+    if (h.mode & PUSH_SORT_SCATTER) {
+        const double w = p.w[ip];
+        at = push_sort_dest(h, gi);
+        h.dx[at] = xp; h.dy[at] = yp; h.dz[at] = zp; h.dw[at] = w;
+        h.dux[at] = ux; h.duy[at] = uy; h.duz[at] = uz;
+        if (p.id && h.did) h.did[at] = pid;
+        in_place = false;
+    }
+    if (h.mode & PUSH_SORT_COUNT) {
+        const int key = (p.id && pid == WXA_IDCPU_RETIRED) ? h.sg.retired_bin : cell_of(h.sg, xp, yp, zp);
+        const int rank = atomicAdd(&h.hist[key], 1);
+        h.kr_out[at] = ((unsigned long long)(unsigned)key << 32) | (unsigned long long)(unsigned)rank;
+    }
+    return in_place;
+}
+
+// the hook of a push kernel whose particle view starts `first` particles into the tile (nothing armed, no workspace or
+// a push that does not move the particles: an inert hook)
+inline PushSort make_push_sort(const wxa_workspace* ws, const long first, const bool move) {
+    PushSort h{};
+    if (!ws || !move || ws->ps.armed == 0) return h;
+    const auto& s = ws->ps;
+    h.mode = s.armed;
+    h.first = first;
+    if (s.armed & PUSH_SORT_COUNT) {
+        for (int d = 0; d < 3; ++d) { h.sg.plo[d] = s.plo[d]; h.sg.dinv[d] = s.dinv[d]; h.sg.nc[d] = s.nc[d]; h.sg.wrap[d] = s.wrap[d]; }
+        h.sg.retired_bin = (int)s.bins;
+        h.kr_out = (unsigned long long*)s.kr[s.out].p;
+        h.hist = (int*)s.hist.p;
+    }
+    if (s.armed & PUSH_SORT_SCATTER) {
+        h.kr_in = (const unsigned long long*)s.kr[s.in].p;
+        h.offs = (const int*)s.offs[s.in].p;
+        h.dx = s.dst.x; h.dy = s.dst.y; h.dz = s.dst.z; h.dw = s.dst.w;
+        h.dux = s.dst.ux; h.duy = s.dst.uy; h.duz = s.dst.uz;
+        h.did = (unsigned long long*)s.dst.idcpu;
+        h.np_counted = s.pending_np;
+        h.n_appended = s.appended;
+        h.retired_bin_in = (int)s.pending_bins;
+    }
+    return h;
+}
+
+}  // namespace wxa
+#endif

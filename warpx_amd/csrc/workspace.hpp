@@ -51,6 +51,25 @@ struct wxa_workspace {
     int64_t ext_pp_stride = 0;
     // accumulator type of the LDS-tile Esirkepov deposition (wxa_workspace_set_deposit_accumulator)
     int32_t deposit_accumulator = WXA_ACC_FP64;
+    // the cell sort folded into PushPX (push_sort.hpp; wxa_push_sort_begin / _end): what is armed for the pushes between
+    // begin and end, and the record a COUNT left for the SCATTER of a later push
+    struct PushSortState {
+        int32_t armed = 0;                   // WXA_PUSH_SORT_* of the pushes between begin and end
+        wxa::DevBuf kr[2], offs[2], hist;    // (key, rank) per particle and the scanned histogram, double-buffered
+        int32_t in = 0, out = 0;             // kr[in], offs[in]: the pending record; [out]: what the armed COUNT writes
+        bool pending = false;
+        int64_t pending_np = 0, pending_bins = 0;
+        const double* pending_x = nullptr;   // identity of the tile the record indexes
+        int32_t p_nc[3] = {0, 0, 0}, p_cell_lo[3] = {0, 0, 0};   // geometry of the pending record
+        double p_plo[3] = {0, 0, 0}, p_dinv[3] = {0, 0, 0};
+        int32_t nc[3] = {0, 0, 0}, cell_lo[3] = {0, 0, 0}, wrap[3] = {0, 0, 0};   // geometry of the armed COUNT
+        double plo[3] = {0, 0, 0}, dinv[3] = {0, 0, 0};
+        int64_t bins = 0;
+        wxa_particle_view dst{};             // armed SCATTER: the destination tile
+        int64_t np_armed = 0;                // particles of the tile being pushed
+        const double* count_x = nullptr;     // ... and its identity
+        int64_t appended = 0;                // armed SCATTER: particles appended since the record was taken
+    } ps;
 };
 
 namespace wxa {
