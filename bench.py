@@ -27,6 +27,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_CU = 256          # MI355X_MICROARCH.md: 8 XCDs x 32 CUs
 CLOCK_GHZ = 2.4     # MI355X_MICROARCH.md: peak engine clock
+# what the deposition runs at: SQ_BUSY_CYCLES of its launch / its duration, and LDS-array cycles per ds_add_f64 wave
+# instruction of the shipped kernel (profiles/round4/README.md; the figures of the PMC file are used when its stamp matches)
+CLOCK_UNDER_LOAD_GHZ = 2.09
+LDS_CYCLES_PER_ATOMIC = 8.7
+# the N = 1 line an N > 1 run compares itself with when --n1-ms is not given (committed with the round's evidence)
+N1_REFERENCE_LINE = os.path.join("profiles", "round5", "n1_reference_line.json")
 
 # algorithmic bytes per unit, fp64 (SURVEY.md 8(d) / BASELINE.md section 3)
 BYTES = {
@@ -251,6 +257,9 @@ def main():
                     help="synchronise the momenta at the end of every evolve call like WarpX::Evolve(n) does (the timed "
                          "region then contains one PushP(-dt/2) / PushP(+dt/2) pair); default: one run advanced in pieces")
     ap.add_argument("--no-sanity", action="store_true", help="skip the energy / particle-count figures around the timed steps")
+    ap.add_argument("--n1-ms", type=float, default=0.0,
+                    help="N > 1: ms per step of the same per-GPU workload on one GPU, for weak_scaling.efficiency "
+                         "(default: the committed line " + N1_REFERENCE_LINE + ")")
     ap.add_argument("--dry-comm", action="store_true",
                     help="after the pre-roll, run ONLY the step's neighbour exchanges (FillBoundary E+B, SumBoundary J, "
                          "Redistribute) on the run's own arrays and print their milliseconds next to the message counts "
@@ -403,7 +412,14 @@ def main():
             transport.set_timing(True)
         sim.enable_timers(True)
         sim.timers(reset=True)
-        nph = min(args.steps, 4)
+        # whole sort cycles, so that every phase's average has its share of sort steps (and of the steps whose push
+        # records or applies the sort): 4 steps, rounded up to a multiple of the interval
+        cyc = max(args.sort_interval, 1)
+        nph = cyc * ((4 + cyc - 1) // cyc)
+        while sim.istep % cyc != 0:   # start the pass at a cycle boundary
+            sim.evolve(1)
+        torch.cuda.synchronize()
+        sim.timers(reset=True)
         sim.evolve(nph)
         torch.cuda.synchronize()
         phases = sim.timers(reset=True)
@@ -477,10 +493,16 @@ def main():
                 # order 3 Esirkepov: 2 particles share one set of 4x4x4(+1) rows; 144 ds_add_f64 per pair and lane
                 # (deposit_body.hpp).  One ds_add_f64 wave-instruction occupies a CU's LDS pipe for 8 cycles when
                 # conflict-free (scripts/microbench/lds_atomic_bench.hip, profiles/round3/lds_atomic_microbench.txt).
+                # at the clock the kernel runs at and the cycles its LDS array spends per instruction (both measured:
+                # 2.09 GHz, 8.7; round 3's line used the peak clock and the microbenchmark's 8.0 and read 1.97 ms)
+                d = sq_counters.get(dominant) or {}
+                cyc = d.get("lds_array_cycles_per_lds_instruction", LDS_CYCLES_PER_ATOMIC)
                 wave_instr = np_local / 2 * 144 / 64
-                floor_ms = wave_instr / N_CU * 8 / (CLOCK_GHZ * 1e9) * 1e3
+                floor_ms = wave_instr / N_CU * cyc / (CLOCK_UNDER_LOAD_GHZ * 1e9) * 1e3
                 roofline["lds_atomic_floor_ms"] = floor_ms
                 roofline["lds_atomic_floor_frac"] = floor_ms / k["avg_ms"]
+                roofline["lds_atomic_floor_note"] = (f"144 ds_add_f64 per merged pair and lane at {cyc:.2f} LDS-array cycles per "
+                                                     f"wave instruction and {CLOCK_UNDER_LOAD_GHZ} GHz under load")
             if dominant in ("GatherAndPush", "CurrentDeposition"):
                 d = sq_counters.get(dominant)
                 if d:   # the committed SQ passes of the kernel that ships, taken on these kernel sources
@@ -515,6 +537,41 @@ def main():
         }
         if comm_stats:
             out["exchange"] = comm_stats
+        if world > 1:
+            # What the field exchanges of a step put on the wire at most (allocated guard depths; the named depths of the
+            # exchanges are smaller or equal): per split direction two face slabs of E, B (FillBoundary) and J (SumBoundary).
+            pred = 0.0
+            for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz"):
+                v = sim.field_view(name)
+                for d in range(3):
+                    if nbricks[d] > 1:
+                        slab = 8.0 * v.ng[d]
+                        for e in range(3):
+                            if e != d:
+                                slab *= v.n[e]
+                        pred += 2 * slab
+            out.setdefault("exchange", {})["field_MB_per_step_upper_bound"] = pred / 1e6
+            out["exchange"]["note_links"] = ("on 2 x 2 x 2 both faces of a direction go to the same peer: a third of these "
+                                             "bytes per xGMI link and step, direction after direction")
+            # weak scaling against the same per-GPU workload on one GPU
+            n1_ms, src = args.n1_ms, "--n1-ms"
+            if n1_ms <= 0.0:
+                try:
+                    ref = json.load(open(os.path.join(ROOT, N1_REFERENCE_LINE)))
+                    same = (ref["config"]["cells_per_gpu"] == ncells_local and ref["config"]["particles_per_gpu"] == np_local
+                            and ref["config"]["workload"].split(",", 1)[1] == out["config"]["workload"].split(",", 1)[1])
+                    if same:
+                        n1_ms, src = float(ref["ms_per_step"]), N1_REFERENCE_LINE
+                    else:
+                        src = N1_REFERENCE_LINE + " is another workload: pass --n1-ms"
+                except Exception as e:
+                    src = f"no N = 1 line to compare with ({e}): pass --n1-ms"
+            out["weak_scaling"] = {"n1_ms_per_step": n1_ms if n1_ms > 0 else None,
+                                   "efficiency": (n1_ms / out["ms_per_step"]) if n1_ms > 0 else None,
+                                   "n1_source": src,
+                                   "exchange_ms_per_step": (comm_stats or {}).get("exchange_ms_per_step"),
+                                   "note": "efficiency = ms per step of this per-GPU workload on one GPU / ms per step here "
+                                           "(the driver computes its own from its N = 1 run; target >= 0.70)"}
         if sanity:
             out["sanity"] = sanity
         if world == 1 and not args.no_cpu_baseline:
@@ -526,6 +583,8 @@ def main():
     sim.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+    if sanity is not None and not sanity["ok"]:
+        raise SystemExit(3)   # a line whose particles or energy went wrong is not a measurement
 
 
 if __name__ == "__main__":

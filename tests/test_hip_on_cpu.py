@@ -131,7 +131,7 @@ def test_bench_control_flow_on_several_ranks(n, port):
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "bench_on_cpu.py"), "--gpus", str(n),
-           "--ncell", "16", "--steps", "3", "--warmup", "1", "--preroll", "2", "--no-cpu-baseline"]
+           "--ncell", "16", "--steps", "3", "--warmup", "1", "--preroll", "2", "--no-cpu-baseline", "--n1-ms", "1.0"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -140,7 +140,13 @@ def test_bench_control_flow_on_several_ranks(n, port):
     assert line["n_gpus"] == n and line["scaling"] == "weak" and line["steps"] == 3
     assert line["config"]["bricks"] == {2: [1, 1, 2], 4: [1, 2, 2], 8: [2, 2, 2]}[n]
     assert line["config"]["particles_per_gpu"] == 16 ** 3 * 8 and line["exchange"]["exchanges_per_step"] > 0
-    assert line["sanity"]["particles_after"] == n * 16 ** 3 * 8
+    assert line["sanity"]["particles_after"] == n * 16 ** 3 * 8 and line["sanity"]["ok"]
+    # the line judges itself: the second-stream overlap is on, the efficiency against the N = 1 figure it was handed, the
+    # field bytes a step puts on the wire at most (three split directions at N = 8)
+    assert line["config"]["overlap_halo"] is True
+    ws = line["weak_scaling"]
+    assert ws["n1_ms_per_step"] == 1.0 and abs(ws["efficiency"] - 1.0 / line["ms_per_step"]) < 1e-12
+    assert line["exchange"]["field_MB_per_step_upper_bound"] > 0
 
 
 def test_bench_control_flow_on_the_cpu_execution_model():

@@ -102,12 +102,13 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
                                                double Bzp, double q, double m, double dt, const ExtEB& ext,
                                                const PushSort& hook,
                                                const unsigned long long here = 0ull,   // ST: the lanes that store in this trip
-                                               const bool mine = true) {               // ST: ... this one among them
+                                               const bool mine = true,                 // ST: ... this one among them
+                                               int* lds_hist = nullptr, const long my_tile = -1) {   // push_sort_tail
     add_external_fields(ext, ip, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
     push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
     if constexpr (MOVE) update_position(xp, yp, zp, ux, uy, uz, dt);
     if constexpr (MOVE && ST == 0) {   // the cell sort folded into the push (push_sort.hpp): keyed, or written to the sorted tile
-        if (!push_sort_tail(hook, p, ip, xp, yp, zp, ux, uy, uz)) return;
+        if (!push_sort_tail(hook, p, ip, xp, yp, zp, ux, uy, uz, lds_hist, my_tile)) return;
     }
     if constexpr (ST != 0 && MOVE) {
         // every lane of the trip takes part in the exchanges (a lane that does not store sends values nobody uses)
@@ -172,6 +173,13 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     // SL: a tile's stragglers are collected in LDS and written to the global list as ONE contiguous block at the end of the
     // workgroup (one global atomic per tile instead of one per straggler): the straggler kernel's waves then hold
     // particles of one or two neighbouring tiles, whose 252 scattered loads share cache lines
+    // the sort folded into the push, COUNT alone: ranks from a histogram of the tile's own cells (push_sort.hpp)
+    static_assert(GT_THREADS == PUSH_SORT_TILE_CELLS, "one lane per cell of the tile");
+    __shared__ int lhist[MOVE ? PUSH_SORT_TILE_CELLS : 1];
+    const bool count_local = MOVE && hook.mode == PUSH_SORT_COUNT;   // uniform
+    if constexpr (MOVE) {
+        if (count_local) lhist[tid] = 0;   // visible after the staging barrier below
+    }
     constexpr int SCAP = 512;
     __shared__ int slist[SL ? SCAP : 1];
     __shared__ int sn, sbase;
@@ -316,7 +324,8 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
             update_position(xp, yp, zp, ux0, uy0, uz0, dt);
             if (xp + ux0 == 1.2345e-300) p.x[ip] = yp + zp + uy0 + uz0;
         } else
-        push_and_store<PUSHER, MOVE, ST>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext, hook, storing, staged);
+        push_and_store<PUSHER, MOVE, ST>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext, hook, storing, staged,
+                                         count_local ? lhist : nullptr, tile);
 #ifdef WXA_GATHER_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GPROF_CLOCK(prof_d);
@@ -333,6 +342,9 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         if (tid == 0 && n > 0) sbase = (int)atomicAdd(sq.count, (unsigned)n);
         __syncthreads();
         for (int i = tid; i < n; i += GT_THREADS) sq.idx[sbase + i] = slist[i];
+    }
+    if constexpr (MOVE) {
+        if (count_local) push_sort_tile_finish(hook, lhist, tile, start, end, tid);
     }
 }
 

@@ -84,10 +84,19 @@ __device__ __forceinline__ long push_sort_dest(const PushSort& h, const long gi)
     return d;
 }
 
+// COUNT in an LDS-tile kernel: a rank taken from the workgroup's own histogram of its tile's cells carries this bit until
+// the workgroup has added its counts to the global histogram and turns it into the rank among all particles of the cell
+// (one global atomic per cell and tile instead of one per particle: as lane-by-lane global atomics the counting push of
+// 256^3 x 8 particles took 17 ms instead of 4.7, profiles/round5/README.md)
+constexpr unsigned long long PUSH_SORT_LOCAL_RANK = 0x80000000ull;
+constexpr int PUSH_SORT_TILE_CELLS = WXA_TILE * WXA_TILE * WXA_TILE;
+
 // After the push of particle `ip` of view `p` (new position and momentum in registers; MOVE pushes only).
 // Returns true when the caller still has to store position and momentum in place.
+// lds_hist / my_tile: the LDS-tile kernel's histogram of the cells of its own tile (see push_sort_tile_finish).
 __device__ __forceinline__ bool push_sort_tail(const PushSort& h, const PV& p, const long ip, const double xp, const double yp,
-                                               const double zp, const double ux, const double uy, const double uz) {
+                                               const double zp, const double ux, const double uy, const double uz,
+                                               int* lds_hist = nullptr, const long my_tile = -1) {
     if (h.mode == 0) return true;   // uniform
     const long gi = h.first + ip;
     long at = gi;                   // the particle's index after this push
@@ -103,10 +112,32 @@ __device__ __forceinline__ bool push_sort_tail(const PushSort& h, const PV& p, c
     }
     if (h.mode & PUSH_SORT_COUNT) {
         const int key = (p.id && pid == WXA_IDCPU_RETIRED) ? h.sg.retired_bin : cell_of(h.sg, xp, yp, zp);
-        const int rank = atomicAdd(&h.hist[key], 1);
-        h.kr_out[at] = ((unsigned long long)(unsigned)key << 32) | (unsigned long long)(unsigned)rank;
+        unsigned long long rank;
+        if (lds_hist && key / PUSH_SORT_TILE_CELLS == my_tile)
+            rank = PUSH_SORT_LOCAL_RANK | (unsigned long long)(unsigned)atomicAdd(&lds_hist[key % PUSH_SORT_TILE_CELLS], 1);
+        else
+            rank = (unsigned long long)(unsigned)atomicAdd(&h.hist[key], 1);
+        h.kr_out[at] = ((unsigned long long)(unsigned)key << 32) | rank;
     }
     return in_place;
+}
+
+// End of an LDS-tile kernel's workgroup in COUNT mode (every lane of the workgroup, NT = PUSH_SORT_TILE_CELLS lanes): the
+// tile's counts go to the global histogram, one atomic per occupied cell, and the local ranks of the particles
+// [start, end) of the tile become global ones.  (Slots of particles this workgroup did not push -- its stragglers --
+// are written by the straggler kernel afterwards, whatever this pass made of their old contents.)
+__device__ __forceinline__ void push_sort_tile_finish(const PushSort& h, int* lds_hist, const long my_tile, const int start,
+                                                      const int end, const int tid) {
+    __syncthreads();
+    const int n = lds_hist[tid];
+    const int base = n > 0 ? atomicAdd(&h.hist[my_tile * PUSH_SORT_TILE_CELLS + tid], n) : 0;
+    lds_hist[tid] = base;
+    __syncthreads();
+    for (long j = h.first + start + tid; j < h.first + end; j += PUSH_SORT_TILE_CELLS) {
+        const unsigned long long kr = h.kr_out[j];
+        if (kr & PUSH_SORT_LOCAL_RANK)
+            h.kr_out[j] = (kr & ~PUSH_SORT_LOCAL_RANK) + (unsigned long long)(unsigned)lds_hist[(int)(kr >> 32) % PUSH_SORT_TILE_CELLS];
+    }
 }
 
 // the hook of a push kernel whose particle view starts `first` particles into the tile (nothing armed, no workspace or
