@@ -280,7 +280,8 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src,
  *   WXA_PUSH_SORT_COUNT:   keys each particle's NEW position with the tile-major cell key of wxa_sort_particles_by_cell
  *       (wrap[d] != 0: a cell index one period outside along d is brought back -- the key of the position that
  *       wxa_enforce_periodic will produce; otherwise clamped) and takes its rank among equal keys; _end scans the
- *       histogram.  Retired particles get the bin behind the cells.  The record stays in ws until a SCATTER uses it, a
+ *       histogram.  Retired particles get the bin behind the cells (check_retired != 0: the tile may hold some and the
+ *       ids are looked at; 0 saves the 8 bytes per particle).  The record stays in ws until a SCATTER uses it, a
  *       new COUNT replaces it or wxa_sort_particles_by_cell / wxa_partition_particles invalidates it;
  *   WXA_PUSH_SORT_SCATTER: writes the pushed particle (x y z ux uy uz, and w and idcpu carried over) to `dst` at the index
  *       the record of the last COUNT on the same arrays gives it, instead of in place: `dst` then holds the particles
@@ -297,7 +298,7 @@ enum { WXA_PUSH_SORT_COUNT = 1, WXA_PUSH_SORT_SCATTER = 2 };
 wxa_status wxa_push_sort_begin(wxa_workspace* ws, int32_t mode, const wxa_particle_view* p,
                                const wxa_particle_view* dst, const double plo[3], const double dinv[3],
                                const int32_t cell_lo[3], const int32_t ncell[3], const int32_t wrap[3],
-                               void* stream);
+                               int32_t check_retired, void* stream);
 wxa_status wxa_push_sort_end(wxa_workspace* ws, int32_t read_live, int64_t* live, int64_t* appended,
                              void* stream);
 /* 1 when ws holds a COUNT record that a SCATTER of exactly these arrays can use */

@@ -108,6 +108,7 @@ hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipStreamSynchronize(hipStream_t);
 hipError_t hipDeviceSynchronize();
 hipError_t hipGetLastError();
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }   // one "device"
 const char* hipGetErrorString(hipError_t);
 hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned);
 hipError_t hipStreamDestroy(hipStream_t);

@@ -748,7 +748,7 @@ def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, ret
         pv, dv = view_of(cur, npart), view_of(spare, npart)
         if mode:
             assert (product.push_sort_pending(ws, C.byref(pv)) == 1) == bool(mode & _capi.PUSH_SORT_SCATTER)
-            rc = product.push_sort_begin(ws, mode, C.byref(pv), C.byref(dv), plo, dinv, lo, nc, wrap, None)
+            rc = product.push_sort_begin(ws, mode, C.byref(pv), C.byref(dv), plo, dinv, lo, nc, wrap, 1 if retire else 0, None)
             assert rc == 0, product.last_error()
         product.gather_push_ws(C.byref(pv), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt, order, 1,
                                _capi.PUSHER_BORIS, 1, ws, None)

@@ -344,7 +344,10 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         for (int i = tid; i < n; i += GT_THREADS) sq.idx[sbase + i] = slist[i];
     }
     if constexpr (MOVE) {
-        if (count_local) push_sort_tile_finish(hook, lhist, tile, start, end, tid);
+        if (count_local) {
+            __syncthreads();
+            push_sort_tile_finish(hook, lhist, tile, tid);
+        }
     }
 }
 

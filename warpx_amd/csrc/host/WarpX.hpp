@@ -610,7 +610,19 @@ public:
     // the next step's deposition starts from zero anyway.
     void DryComm(int reps, double ms[4]) {
         using warpx::fields::FieldType;
-        reps = std::max(reps, 1);
+        reps = std::min(std::max(reps, 1), 64);
+        // every sum writes the total back into all images of a point: repeated on the live J the shared points double per
+        // call (2^40 after bench.py's 20 + 20 calls) and a plotfile, a BTD slice or a J query taken before the next
+        // deposition would read that.  The sums run on J as it is (real sizes, real strides); J is put back afterwards.
+        auto J = m_fields.get_alldirs(FieldType::current_fp, 0);
+        DeviceBuffer saved[3];
+        for (int c = 0; c < 3; ++c) {
+            const wxa_field_view v = J[c]->view();
+            const size_t bytes = sizeof(double) * (size_t)v.kstride * (size_t)v.n[2];
+            saved[c].be = m_be;
+            saved[c].reserve(bytes);
+            m_be->memcpy_async(saved[c].p, v.p, bytes, m_ctx.stream);
+        }
         auto timed = [&](auto&& f) {
             sync_stream();
             const auto t0 = std::chrono::steady_clock::now();
@@ -618,7 +630,6 @@ public:
             sync_stream();
             return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
         };
-        auto J = m_fields.get_alldirs(FieldType::current_fp, 0);
         auto fill = [&]() { FillBoundaryEB(guard_cells.ng_FieldGather); };
         auto sum = [&]() { SumBoundaryJ(J, 0); };
         auto redist = [&]() { for (int i = 0; i < mypc->nContainers(); ++i) mypc->GetParticleContainer(i).Redistribute(*m_comm); };
@@ -626,6 +637,11 @@ public:
         ms[1] = timed(sum);
         ms[2] = timed(redist);
         ms[3] = timed([&]() { fill(); sum(); redist(); });
+        for (int c = 0; c < 3; ++c) {
+            const wxa_field_view v = J[c]->view();
+            m_be->memcpy_async(v.p, saved[c].p, sizeof(double) * (size_t)v.kstride * (size_t)v.n[2], m_ctx.stream);
+        }
+        sync_stream();   // the copies are done before `saved` goes away
     }
 
     // Source/FieldSolver/WarpXPushFieldsEM.cpp:877-927

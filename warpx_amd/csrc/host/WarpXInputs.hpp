@@ -690,6 +690,9 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                 for (int d = 0; d < 3; ++d) { pp.queryWithParser(name + mk[d], um[d]); pp.queryWithParser(name + tk[d], uth[d]); }
                 std::string seed_word = "default";
                 pp.query("warpx.random_seed", seed_word);
+                if (seed_word == "random" && comm && comm->nranks > 1)   // each brick would seed its own stream
+                    throw std::runtime_error("inputs: warpx.random_seed = random with several bricks: the bricks of a run must share "
+                                             "the stream (a plasma that is the same on any brick layout): give a number");
                 const uint64_t seed = seed_word == "default" ? 1u : (seed_word == "random" ? (uint64_t)std::random_device{}()
                                                                                             : (uint64_t)pp.evaluate(seed_word));
                 pc->SetGaussianMomentum(um, uth, seed * 0x9E3779B97F4A7C15ull + 1000003ull * (uint64_t)sid);
@@ -765,6 +768,10 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
             }
             std::string seed_word = "default";
             pp.query("warpx.random_seed", seed_word);
+            // every brick draws the whole beam and keeps its share: all bricks need the same stream
+            if (seed_word == "random" && comm && comm->nranks > 1)
+                throw std::runtime_error("inputs: warpx.random_seed = random with several bricks would give every brick another beam "
+                                         "(each draws all of it and keeps its share): give a number");
             const uint64_t seed = seed_word == "default" ? 1u : (seed_word == "random" ? (uint64_t)std::random_device{}() : (uint64_t)pp.evaluate(seed_word));
             const uint64_t stream = seed * 0x9E3779B97F4A7C15ull + 1000003ull * (uint64_t)sid + 0x6A09E667F3BCC909ull;
             if (do_symmetrize) npart /= symmetrization_order;
@@ -837,10 +844,23 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         int fields_on = 1, nsnap = 0, buffer = 256;
         pp.queryWithParser(d + ".do_back_transformed_fields", fields_on);
         if (!fields_on) continue;
-        {   // formats this library does not write (openpmd ...): the diagnostic is left out, like a Full one of that format
+        bool in_memory_only = false;
+        {   // formats this library does not write (openpmd ...): the snapshots are still assembled and can be read through
+            // wxa_sim_btd_info / _data / _particles, only the files are not written -- said on stderr, not silently.  A
+            // second BackTransformed diagnostic (one only here) or one given by `intervals` is left out, also by name.
             std::string format = "plotfile";
             pp.query_word(d + ".format", format);
-            if (format != "plotfile") { pp.ignore_prefix(d + "."); continue; }
+            if (format != "plotfile") {
+                if (wx.btd() || pp.contains(d + ".intervals")) {
+                    std::fprintf(stderr, "[warpx_amd] diagnostic %s (BackTransformed, format = %s) is left out: this library writes "
+                                 "plotfiles and keeps one BackTransformed diagnostic\n", d.c_str(), format.c_str());
+                    pp.ignore_prefix(d + ".");
+                    continue;
+                }
+                std::fprintf(stderr, "[warpx_amd] diagnostic %s: format = %s is not written by this library; its snapshots stay in "
+                             "memory (wxa_sim_btd_info / _data / _particles)\n", d.c_str(), format.c_str());
+                in_memory_only = true;
+            }
         }
         if (pp.contains(d + ".intervals")) throw std::runtime_error("inputs: " + d + ".intervals is not on this path (num_snapshots_lab)");
         if (!pp.queryWithParser(d + ".num_snapshots_lab", nsnap)) throw std::runtime_error("inputs: " + d + ".num_snapshots_lab must be set");
@@ -858,12 +878,9 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         // are flushed to <file_prefix><i>/ buffer by buffer as plotfiles; absent, they stay in memory.  One directory per
         // brick: the bricks of a run do not share a file.
         std::string prefix;
-        if (pp.query(d + ".file_prefix", prefix) && write_diagnostics) {
+        if (pp.query(d + ".file_prefix", prefix) && write_diagnostics && !in_memory_only) {
             int digits = 6;                                        // Diagnostics.H: m_file_min_digits
             pp.queryWithParser(d + ".file_min_digits", digits);
-            std::string format = "plotfile";
-            pp.query_word(d + ".format", format);
-            if (format != "plotfile") throw std::runtime_error("inputs: " + d + ".format = " + format + " is not on this path (plotfile)");
             if (comm && comm->nranks > 1) prefix += "brick" + std::to_string(comm->rank) + "_";
             wx.btd()->SetFlush(prefix, digits);
         }

@@ -280,7 +280,7 @@ public:
         int32_t lo[3], nc[3];
         for (int d = 0; d < 3; ++d) { lo[d] = m_ctx->brick_box.lo[d]; nc[d] = m_ctx->brick_box.length(d); }
         check(be->push_sort_begin(m_ws, mode, &p, &dst, m_ctx->brick_plo.data(), m_ctx->dinv.data(), lo, nc, m_ctx->sort_wrap,
-                                  m_ctx->stream),
+                                  m_nretired > 0 ? 1 : 0, m_ctx->stream),
               "push_sort_begin");
         m_push_sort_mode = mode;
     }
@@ -369,6 +369,10 @@ public:
         // of its thickness per step): a list that overflows is not fatal -- the counts are exact whatever the capacity,
         // so the lists grow to what was counted and the scan runs again (the wrap is idempotent, nothing has been packed
         // or retired yet); the capacity reached is kept for the following steps.
+        if (m_be_release_lists) {   // decided by the previous call, whose packs have long read the lists
+            m_be_release_lists = false;
+            if (m_lists.p) { be->dfree(m_lists.p); m_lists.p = nullptr; m_lists.cap = 0; }
+        }
         int64_t cap = std::max<int64_t>(m_list_cap, np0 / 64 + 4096);
         int32_t* lists = nullptr;
         int64_t cnt[27];
@@ -388,6 +392,16 @@ public:
         }
         if (np0 == 0) { m_lists.reserve(sizeof(int32_t) * 27 * (size_t)cap); lists = static_cast<int32_t*>(m_lists.p); }
         m_list_cap = cap;
+        {   // a capacity that one crowded step needed is given back after 32 quiet ones (the lists are 27 x capacity ints:
+            // in a thin brick of a boosted-frame run more than the particles they list -- ADVICE round 4)
+            const int64_t most = *std::max_element(cnt, cnt + 27);
+            m_list_quiet_steps = 4 * (most + 64) < m_list_cap && m_list_cap > np0 / 64 + 4096 ? m_list_quiet_steps + 1 : 0;
+            if (m_list_quiet_steps >= 32) {
+                m_list_cap = std::max<int64_t>(2 * (most + 64), np0 / 64 + 4096);
+                m_be_release_lists = true;   // at the start of the next call: this step's packs still read them
+                m_list_quiet_steps = 0;
+            }
+        }
         // the distinct peers, in the same canonical order on both sides of every pair: ascending offset code on the
         // sender is descending code (the mirrored offset) on the receiver, so peers are ordered by rank instead
         struct Peer { int rank; int64_t nsend = 0, nrecv = 0; std::vector<int> codes; };
@@ -513,6 +527,8 @@ protected:
     ParticleTile m_tile, m_spare;
     DeviceBuffer m_sendbuf, m_recvbuf, m_lists, m_arrival_lists[3];
     int64_t m_list_cap = 0;   // entries per destination list that Redistribute has grown to (0: the default sizing)
+    int32_t m_list_quiet_steps = 0;      // consecutive steps that used less than a quarter of it
+    bool m_be_release_lists = false;     // the lists are freed at the start of the next Redistribute and reallocated smaller
     DeviceBuffer m_btd_old[6], m_btd_scratch;   // back-transformed diagnostics: attributes before the push, selection output
 public:
     int btd_species_id = -1;                    // >= 0: this species is written by the BackTransformed diagnostic

@@ -131,13 +131,19 @@ __global__ void __launch_bounds__(RED_NT) reduce_particles_kernel(PV p, double m
 // Scratch of the two reductions: RED_MAX_BLOCKS partial rows + the result, allocated once per host thread and kept
 // (with <rd>.intervals = 1 these entry points run inside the time loop every step, several times per row: a hipMalloc /
 // hipFree pair per call is an allocator round trip and an implicit device-wide sync each -- ADVICE round 3)
+// Keyed by the device that is current when the call is made (a host thread that drives simulations on two devices through
+// hipSetDevice gets a scratch on each), and never freed at thread or process exit: by then the HIP runtime may be gone,
+// and the few KB per device and thread are the process's to the end anyway.
 static double* red_scratch(size_t doubles) {
     struct Holder {
         double* p = nullptr;
         size_t n = 0;
-        ~Holder() { if (p) (void)hipFree(p); }
     };
-    static thread_local Holder h;
+    constexpr int MAX_DEV = 16;
+    static thread_local Holder held[MAX_DEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    Holder& h = held[dev];
     if (doubles > h.n) {
         if (h.p) (void)hipFree(h.p);
         h.p = nullptr; h.n = 0;

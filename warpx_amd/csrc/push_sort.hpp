@@ -52,19 +52,31 @@ __device__ __forceinline__ int cell_of(const SortGeom& s, double x, double y, do
 }
 
 constexpr int PUSH_SORT_COUNT = WXA_PUSH_SORT_COUNT, PUSH_SORT_SCATTER = WXA_PUSH_SORT_SCATTER;
+constexpr int PUSH_SORT_TILE_CELLS = WXA_TILE * WXA_TILE * WXA_TILE;
+// A cell's slots in the sorted tile: first the particles that an LDS-tile kernel counted in its OWN tile's histogram (rank
+// from an LDS atomic; the workgroup adds its counts to the global histogram once per cell and leaves them in `own`), then
+// the FOREIGN ones -- particles that changed tile, stragglers, the appended tail, every particle of a run without tiles --
+// whose rank comes from a global counter per cell and carries this bit: slot = own[cell] + rank.  (As one global atomic
+// per particle the counting push of 256^3 x 8 particles took 17 ms instead of 4.0; with local ranks turned into global
+// ones by a second pass over the tile's record, 5.0 -- profiles/round5/README.md.)
+constexpr unsigned long long PUSH_SORT_FOREIGN = 0x80000000ull;
 
 // What the push kernels are handed (by value).  `first`: index, in the whole tile, of element 0 of the particle view the
 // kernel works on (the global-memory kernel of the appended tail gets a view that starts behind the sorted part).
 struct PushSort {
     int mode = 0;                                   // 0, PUSH_SORT_COUNT, PUSH_SORT_SCATTER or both
+    int check_retired = 0;                          // COUNT: the tile may hold retired particles (their ids are looked at)
     long first = 0;
     // COUNT
     SortGeom sg{};
     unsigned long long* __restrict__ kr_out = nullptr;   // (key << 32 | rank), indexed by the particle's index AFTER this push
-    int* __restrict__ hist = nullptr;
+    int* __restrict__ hist = nullptr;               // particles per key: what wxa_push_sort_end scans
+    int* __restrict__ fcnt = nullptr;               // foreign particles per key so far
+    int* __restrict__ own_out = nullptr;            // own particles per key (written by the tile's workgroup)
     // SCATTER
     const unsigned long long* __restrict__ kr_in = nullptr;   // indexed by the particle's index BEFORE this push
     const int* __restrict__ offs = nullptr;                  // exclusive scan of the histogram kr_in was taken with
+    const int* __restrict__ own_in = nullptr;
     double* __restrict__ dx = nullptr; double* __restrict__ dy = nullptr; double* __restrict__ dz = nullptr;
     double* __restrict__ dw = nullptr;
     double* __restrict__ dux = nullptr; double* __restrict__ duy = nullptr; double* __restrict__ duz = nullptr;
@@ -79,17 +91,11 @@ __device__ __forceinline__ long push_sort_dest(const PushSort& h, const long gi)
     if (gi >= h.np_counted) return (long)h.offs[h.retired_bin_in] + (gi - h.np_counted);   // behind the live ones, in their order
     const unsigned long long kr = h.kr_in[gi];
     const int key = (int)(kr >> 32);
-    long d = (long)h.offs[key] + (long)(unsigned)(kr & 0xffffffffull);
+    long d = (long)h.offs[key] + (long)(unsigned)(kr & 0x7fffffffull);
+    if (kr & PUSH_SORT_FOREIGN) d += h.own_in[key];
     if (key == h.retired_bin_in) d += h.n_appended;   // the retired ones behind the appended ones: dropped by the new count
     return d;
 }
-
-// COUNT in an LDS-tile kernel: a rank taken from the workgroup's own histogram of its tile's cells carries this bit until
-// the workgroup has added its counts to the global histogram and turns it into the rank among all particles of the cell
-// (one global atomic per cell and tile instead of one per particle: as lane-by-lane global atomics the counting push of
-// 256^3 x 8 particles took 17 ms instead of 4.7, profiles/round5/README.md)
-constexpr unsigned long long PUSH_SORT_LOCAL_RANK = 0x80000000ull;
-constexpr int PUSH_SORT_TILE_CELLS = WXA_TILE * WXA_TILE * WXA_TILE;
 
 // After the push of particle `ip` of view `p` (new position and momentum in registers; MOVE pushes only).
 // Returns true when the caller still has to store position and momentum in place.
@@ -101,8 +107,10 @@ __device__ __forceinline__ bool push_sort_tail(const PushSort& h, const PV& p, c
     const long gi = h.first + ip;
     long at = gi;                   // the particle's index after this push
     bool in_place = true;
-    unsigned long long pid = p.id ? p.id[ip] : 0ull;
-    if (h.mode & PUSH_SORT_SCATTER) {
+    const bool scatter = (h.mode & PUSH_SORT_SCATTER) != 0;
+    unsigned long long pid = 0ull;
+    if (p.id && (scatter || h.check_retired)) pid = p.id[ip];
+    if (scatter) {
         const double w = p.w[ip];
         at = push_sort_dest(h, gi);
         h.dx[at] = xp; h.dy[at] = yp; h.dz[at] = zp; h.dw[at] = w;
@@ -111,32 +119,27 @@ __device__ __forceinline__ bool push_sort_tail(const PushSort& h, const PV& p, c
         in_place = false;
     }
     if (h.mode & PUSH_SORT_COUNT) {
-        const int key = (p.id && pid == WXA_IDCPU_RETIRED) ? h.sg.retired_bin : cell_of(h.sg, xp, yp, zp);
+        const int key = (h.check_retired && p.id && pid == WXA_IDCPU_RETIRED) ? h.sg.retired_bin : cell_of(h.sg, xp, yp, zp);
         unsigned long long rank;
-        if (lds_hist && key / PUSH_SORT_TILE_CELLS == my_tile)
-            rank = PUSH_SORT_LOCAL_RANK | (unsigned long long)(unsigned)atomicAdd(&lds_hist[key % PUSH_SORT_TILE_CELLS], 1);
-        else
-            rank = (unsigned long long)(unsigned)atomicAdd(&h.hist[key], 1);
+        if (lds_hist && key / PUSH_SORT_TILE_CELLS == my_tile) {
+            rank = (unsigned long long)(unsigned)atomicAdd(&lds_hist[key % PUSH_SORT_TILE_CELLS], 1);
+        } else {
+            rank = PUSH_SORT_FOREIGN | (unsigned long long)(unsigned)atomicAdd(&h.fcnt[key], 1);
+            atomicAdd(&h.hist[key], 1);
+        }
         h.kr_out[at] = ((unsigned long long)(unsigned)key << 32) | rank;
     }
     return in_place;
 }
 
-// End of an LDS-tile kernel's workgroup in COUNT mode (every lane of the workgroup, NT = PUSH_SORT_TILE_CELLS lanes): the
-// tile's counts go to the global histogram, one atomic per occupied cell, and the local ranks of the particles
-// [start, end) of the tile become global ones.  (Slots of particles this workgroup did not push -- its stragglers --
-// are written by the straggler kernel afterwards, whatever this pass made of their old contents.)
-__device__ __forceinline__ void push_sort_tile_finish(const PushSort& h, int* lds_hist, const long my_tile, const int start,
-                                                      const int end, const int tid) {
-    __syncthreads();
+// End of an LDS-tile kernel's workgroup in COUNT mode (every lane of the workgroup, PUSH_SORT_TILE_CELLS lanes, behind a
+// barrier that follows the last push_sort_tail): the tile's own counts go to the global histogram, one atomic per
+// occupied cell, and stay in `own` for the SCATTER, which puts the cell's foreign particles behind them.
+__device__ __forceinline__ void push_sort_tile_finish(const PushSort& h, const int* lds_hist, const long my_tile, const int tid) {
     const int n = lds_hist[tid];
-    const int base = n > 0 ? atomicAdd(&h.hist[my_tile * PUSH_SORT_TILE_CELLS + tid], n) : 0;
-    lds_hist[tid] = base;
-    __syncthreads();
-    for (long j = h.first + start + tid; j < h.first + end; j += PUSH_SORT_TILE_CELLS) {
-        const unsigned long long kr = h.kr_out[j];
-        if (kr & PUSH_SORT_LOCAL_RANK)
-            h.kr_out[j] = (kr & ~PUSH_SORT_LOCAL_RANK) + (unsigned long long)(unsigned)lds_hist[(int)(kr >> 32) % PUSH_SORT_TILE_CELLS];
+    if (n > 0) {
+        atomicAdd(&h.hist[my_tile * PUSH_SORT_TILE_CELLS + tid], n);
+        h.own_out[my_tile * PUSH_SORT_TILE_CELLS + tid] = n;
     }
 }
 
@@ -151,12 +154,16 @@ inline PushSort make_push_sort(const wxa_workspace* ws, const long first, const 
     if (s.armed & PUSH_SORT_COUNT) {
         for (int d = 0; d < 3; ++d) { h.sg.plo[d] = s.plo[d]; h.sg.dinv[d] = s.dinv[d]; h.sg.nc[d] = s.nc[d]; h.sg.wrap[d] = s.wrap[d]; }
         h.sg.retired_bin = (int)s.bins;
+        h.check_retired = s.check_retired;
         h.kr_out = (unsigned long long*)s.kr[s.out].p;
         h.hist = (int*)s.hist.p;
+        h.fcnt = (int*)s.hist.p + (s.bins + 2);
+        h.own_out = (int*)s.own[s.out].p;
     }
     if (s.armed & PUSH_SORT_SCATTER) {
         h.kr_in = (const unsigned long long*)s.kr[s.in].p;
         h.offs = (const int*)s.offs[s.in].p;
+        h.own_in = (const int*)s.own[s.in].p;
         h.dx = s.dst.x; h.dy = s.dst.y; h.dz = s.dst.z; h.dw = s.dst.w;
         h.dux = s.dst.ux; h.duy = s.dst.uy; h.duz = s.dst.uz;
         h.did = (unsigned long long*)s.dst.idcpu;

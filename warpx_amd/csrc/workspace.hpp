@@ -55,7 +55,9 @@ struct wxa_workspace {
     // begin and end, and the record a COUNT left for the SCATTER of a later push
     struct PushSortState {
         int32_t armed = 0;                   // WXA_PUSH_SORT_* of the pushes between begin and end
-        wxa::DevBuf kr[2], offs[2], hist;    // (key, rank) per particle and the scanned histogram, double-buffered
+        wxa::DevBuf kr[2], offs[2], own[2], hist;   // (key, rank) per particle, the scanned histogram and the own counts
+                                                    // per cell, double-buffered; hist: the histogram and the foreign counters
+        int32_t check_retired = 0;           // armed COUNT: the caller's tile may hold retired particles
         int32_t in = 0, out = 0;             // kr[in], offs[in]: the pending record; [out]: what the armed COUNT writes
         bool pending = false;
         int64_t pending_np = 0, pending_bins = 0;
