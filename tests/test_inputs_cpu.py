@@ -230,6 +230,38 @@ def test_back_transformed_snapshot_against_the_reference_golden_file(lib, deck):
     sim.close()
 
 
+def test_what_the_btd_golden_file_weighs(lib):
+    """Where the sums of test_3d_laser_acceleration_btd.json come from (round 5, looking for the 1e-5 ... 1e-3 left against
+    it).  Every lab-frame snapshot is swept from the top of the boosted domain to its bottom; its lowest slice (k_lab = 13 of
+    13 ... 62) is taken in the cell layer next to the lower PEC wall, where the plasma streams out at -beta c: that one
+    slice carries a fifth of sum|rho| and sum|jz| and a quarter of sum|Ex| and sum|By| -- and there rho_lab and jz_lab
+    are one quantity, gamma jz' (rho_lab c = beta jz_lab to 0.2 %: the boosted-frame charge next to the wall is nothing
+    against the unbalanced current), which is why the golden file's rho and jz miss by the same 1.25e-3 / 1.29e-3 while
+    the fields miss by 1e-5.  Also excluded in round 5 (scripts of profiles/round5/README.md): the beta of the Lorentz
+    transform (0.995 instead of sqrt(1 - 1/gamma^2) would explain rho and Ey at once -- it moves Ex by 6e-5 the wrong
+    way), and 1e-5 perturbations of amplitude, density, cfl, gamma_boost, t_peak, wavelength, antenna position, zmax:
+    none has the signature (rho and jz a hundred times the fields)."""
+    deck = BTD_DECKS[0]
+    sim = WarpXSim.from_inputs(lib, deck)
+    sim.evolve(sim.max_step)
+    c, beta = 299792458.0, math.sqrt(1.0 - 1.0 / 100.0)
+    share = {}
+    for name in ("rho", "jz", "Ex", "By", "Ey", "Bx", "Ez", "jx"):
+        prof = np.abs(sim.btd_snapshot(3, name)).sum(axis=(0, 1))
+        filled = np.nonzero(prof)[0]
+        assert filled.min() == 13 and filled.max() == 62
+        share[name] = prof[13] / prof.sum()
+    print("share of the slice next to the wall:", {k: round(float(v), 3) for k, v in share.items()})
+    assert 0.15 < share["rho"] < 0.3 and 0.15 < share["jz"] < 0.3 and abs(share["rho"] - share["jz"]) < 0.02
+    assert share["Ex"] > 0.2 and share["By"] > 0.2 and share["Ey"] > 0.12 and share["Bx"] > 0.12
+    assert share["Ez"] < 0.06 and share["jx"] < 0.03
+    rho, jz = sim.btd_snapshot(3, "rho"), sim.btd_snapshot(3, "jz")
+    wall = np.abs(rho[:, :, 13] * c - beta * jz[:, :, 13]).sum() / np.abs(rho[:, :, 13] * c).sum()
+    bulk = np.abs(rho[:, :, 30] * c - beta * jz[:, :, 30]).sum() / np.abs(rho[:, :, 30] * c).sum()
+    assert wall < 5e-3 and bulk > 1e-2, (wall, bulk)
+    sim.close()
+
+
 def test_the_gaussian_beam_is_not_what_limits_the_btd_pin(lib):
     """The deck without its 10^-14 C beam and with another seed: the field and electron sums of snapshot 3 move by less than
     1e-6 (measured: 5e-7 on the electrons' px without the beam, 1e-8 on the fields, 1e-10 between seeds) -- the

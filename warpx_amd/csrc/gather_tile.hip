@@ -28,6 +28,12 @@
 #ifndef WXA_GATHER_SL
 #define WXA_GATHER_SL 1   // 1: a tile's stragglers leave as one block of the global list (see the kernel); 0: one global atomic each
 #endif
+#ifndef WXA_STRAGGLER_BLOCKS
+// workgroups of 256 lanes of gather_push_stragglers_kernel (a grid-stride loop over a list whose length only the device
+// knows).  A straggler's 252 loads are scattered: the kernel lives on waves in flight, and 512 workgroups are two waves
+// per SIMD (0.56 ms for the 1.3e6 stragglers of the third stale step at 256^3 x 8 per cell)
+#define WXA_STRAGGLER_BLOCKS 2048
+#endif
 #ifndef WXA_GATHER_PF
 #define WXA_GATHER_PF 3   // 2: the next particle's position is requested a trip ahead, this particle's momentum at the top of its trip; 3: the same, chunks through an LDS counter
 #endif
@@ -420,7 +426,7 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
     do {                                                                                                    \
         hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE, PART>), grid, block, 0, st, pv, offsets, ex, \
                            ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
-        hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
+        hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(WXA_STRAGGLER_BLOCKS), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, hook);                     \
     } while (0)
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/gather_variants.py): rows in flight per env, 0 = ds_read2_b64 rows
