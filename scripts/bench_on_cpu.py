@@ -72,7 +72,16 @@ _dist.init_process_group = lambda backend=None, **kw: _init("gloo", **{k: v for 
 _Torch = _wd.TorchBrickTransport
 _wd.TorchBrickTransport = lambda on_device=True: _Torch(on_device=False)
 
-import bench  # noqa: E402
-
 if __name__ == "__main__":
-    bench.main()
+    # --script <path>: another bench script of the same kind (scripts/bench_lwfa_boosted.py) instead of bench.py
+    if len(sys.argv) > 2 and sys.argv[1] == "--script":
+        import importlib.util
+        path = sys.argv[2]
+        del sys.argv[1:3]
+        spec = importlib.util.spec_from_file_location("bench_script", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.main()
+    else:
+        import bench  # noqa: E402
+        bench.main()

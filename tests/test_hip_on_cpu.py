@@ -149,6 +149,22 @@ def test_bench_control_flow_on_several_ranks(n, port):
     assert line["exchange"]["field_MB_per_step_upper_bound"] > 0
 
 
+def test_boosted_wakefield_bench_control_flow_on_the_cpu_execution_model():
+    """scripts/bench_lwfa_boosted.py (BASELINE config 5 as a one-GPU throughput line: CKC, Vay, NCI corrector, window,
+    antenna, continuous injection) through scripts/bench_on_cpu.py on a tiny grid: the window gains particles while the
+    front crosses it and the JSON line carries the per-phase table.  Control flow only."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_on_cpu.py"), "--script",
+                        os.path.join(ROOT, "scripts", "bench_lwfa_boosted.py"), "--ncell", "16", "16", "64", "--ppc", "1",
+                        "--steps", "3", "--fill-steps", "4"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["metric"] == "particle_steps_per_s" and line["value"] > 0 and line["steps"] == 3
+    assert line["config"]["particles_after"] > line["config"]["particles_before"] > 0
+    assert {"EvolveB", "EvolveE", "GatherAndPush", "CurrentDeposition", "Redistribute"} <= set(line["kernels"])
+    assert line["kernels"]["GatherAndPush"]["launches_per_step"] == 2.0   # the electrons and the antenna
+
+
 def test_bench_control_flow_on_the_cpu_execution_model():
     """bench.py, unmodified, through scripts/bench_on_cpu.py (tiny grid): the JSON line carries the contract's keys.
     A dry run of the control flow only -- the numbers mean nothing."""
