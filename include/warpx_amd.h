@@ -281,7 +281,10 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src,
  *       (wrap[d] != 0: a cell index one period outside along d is brought back -- the key of the position that
  *       wxa_enforce_periodic will produce; otherwise clamped) and takes its rank among equal keys; _end scans the
  *       histogram.  Retired particles get the bin behind the cells (check_retired != 0: the tile may hold some and the
- *       ids are looked at; 0 saves the 8 bytes per particle).  The record stays in ws until a SCATTER uses it, a
+ *       ids are looked at; 0 saves the 8 bytes per particle).  predict_dt != 0: the key is that of the position after
+ *       predict_dt more seconds of free flight (x + u / gamma predict_dt) -- with the time step of the scattering push
+ *       the sorted tile is in the cell order of the positions that push produces, up to what the fields do to a
+ *       particle in one step, instead of the order of the positions it starts from.  The record stays in ws until a SCATTER uses it, a
  *       new COUNT replaces it or wxa_sort_particles_by_cell / wxa_partition_particles invalidates it;
  *   WXA_PUSH_SORT_SCATTER: writes the pushed particle (x y z ux uy uz, and w and idcpu carried over) to `dst` at the index
  *       the record of the last COUNT on the same arrays gives it, instead of in place: `dst` then holds the particles
@@ -298,7 +301,7 @@ enum { WXA_PUSH_SORT_COUNT = 1, WXA_PUSH_SORT_SCATTER = 2 };
 wxa_status wxa_push_sort_begin(wxa_workspace* ws, int32_t mode, const wxa_particle_view* p,
                                const wxa_particle_view* dst, const double plo[3], const double dinv[3],
                                const int32_t cell_lo[3], const int32_t ncell[3], const int32_t wrap[3],
-                               int32_t check_retired, void* stream);
+                               int32_t check_retired, double predict_dt, void* stream);
 wxa_status wxa_push_sort_end(wxa_workspace* ws, int32_t read_live, int64_t* live, int64_t* appended,
                              void* stream);
 /* 1 when ws holds a COUNT record that a SCATTER of exactly these arrays can use */

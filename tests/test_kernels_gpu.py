@@ -662,20 +662,22 @@ def _tile_major_key(pos, ncell, dx, wrap):
     return tile * T ** 3 + cell[0] % T + T * ((kt & 1) + 2 * (cell[1] % T + T * (kt >> 1)))
 
 
-@pytest.mark.parametrize("order,sort_first,tail,retire,every_step", [
-    (3, True, 0, False, False),     # the LDS-tile kernels (tile + stragglers)
-    (3, True, 700, True, False),    # ... with an appended tail (global-memory kernel), retired particles, arrivals after the count
-    (1, True, 0, True, True),       # COUNT and SCATTER in the same push (a sort every step)
-    (4, False, 0, False, False),    # no tiles at all: the global-memory kernel does everything
-    (2, True, 300, False, True),
+@pytest.mark.parametrize("order,sort_first,tail,retire,every_step,predict", [
+    (3, True, 0, False, False, False),     # the LDS-tile kernels (tile + stragglers)
+    (3, True, 0, False, False, True),      # ... keyed one free-flight step ahead (what the host layer does)
+    (3, True, 700, True, False, True),     # ... with an appended tail (global-memory kernel), retired particles, arrivals after the count
+    (1, True, 0, True, True, False),       # COUNT and SCATTER in the same push (a sort every step)
+    (4, False, 0, False, False, True),     # no tiles at all: the global-memory kernel does everything
+    (2, True, 300, False, True, False),
 ])
-def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, retire, every_step):
+def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, retire, every_step, predict):
     """wxa_push_sort_begin / _end (SortParticlesByBin folded into PushPX, csrc/push_sort.hpp): three pushes, the first
     records keys and ranks (COUNT), the second writes the particles into the sorted tile (SCATTER), the third runs on
     that tile through the workspace the SCATTER left.  Against the oracle's plain pushes of the same particles: every
     particle arrives with its own data (ids), pushed to 1e-12; the new order is the tile-major cell order of the
-    positions BEFORE the scattering push, wrapped along the periodic directions; retired particles of the record end up
-    behind everything and are dropped; particles appended after the COUNT follow the cell-sorted ones in their order."""
+    positions BEFORE the scattering push, wrapped along the periodic directions -- or, with predict_dt, of those positions
+    carried one time step further in free flight (x + u / gamma dt); retired particles of the record end up behind
+    everything and are dropped; particles appended after the COUNT follow the cell-sorted ones in their order."""
     import torch
     ncell = (24, 20, 16)
     ng, _, _ = H.guard_depths(order)
@@ -748,7 +750,8 @@ def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, ret
         pv, dv = view_of(cur, npart), view_of(spare, npart)
         if mode:
             assert (product.push_sort_pending(ws, C.byref(pv)) == 1) == bool(mode & _capi.PUSH_SORT_SCATTER)
-            rc = product.push_sort_begin(ws, mode, C.byref(pv), C.byref(dv), plo, dinv, lo, nc, wrap, 1 if retire else 0, None)
+            rc = product.push_sort_begin(ws, mode, C.byref(pv), C.byref(dv), plo, dinv, lo, nc, wrap, 1 if retire else 0,
+                                         dt if predict else 0.0, None)
             assert rc == 0, product.last_error()
         product.gather_push_ws(C.byref(pv), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt, order, 1,
                                _capi.PUSHER_BORIS, 1, ws, None)
@@ -788,7 +791,11 @@ def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, ret
                 assert H.max_rel_err(got[row], want[row]) < 1e-12, row
         if mode & _capi.PUSH_SORT_COUNT:   # what the record should hold: keys of the positions this push produced
             after, after_ids = host_copy(cur, npart)
-            key_of = _tile_major_key(after[:3], ncell, dx, wrap_flags)
+            where = after[:3]
+            if predict:
+                gam = np.sqrt(1.0 + (after[4] ** 2 + after[5] ** 2 + after[6] ** 2) / plasma.C_LIGHT ** 2)
+                where = [after[d] + after[4 + d] / gam * dt for d in range(3)]
+            key_of = _tile_major_key(where, ncell, dx, wrap_flags)
             key_ids = after_ids
             n_counted = npart
             n_retired_in_record = int((after_ids == -1).sum())

@@ -274,7 +274,7 @@ _PRODUCT_SIGS = {
     "pack_leavers": (C.c_int, [_PPV, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _D3, _D3,
                                C.c_void_p]),
     "sort_live_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
-    "push_sort_begin": (C.c_int, [C.c_void_p, C.c_int32, _PPV, _PPV, _D3, _D3, _I32_3, _I32_3, _I32_3, C.c_int32, C.c_void_p]),
+    "push_sort_begin": (C.c_int, [C.c_void_p, C.c_int32, _PPV, _PPV, _D3, _D3, _I32_3, _I32_3, _I32_3, C.c_int32, C.c_double, C.c_void_p]),
     "push_sort_end": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "push_sort_pending": (C.c_int32, [C.c_void_p, _PPV]),
     "pack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),

@@ -30,9 +30,9 @@
 #endif
 #ifndef WXA_STRAGGLER_BLOCKS
 // workgroups of 256 lanes of gather_push_stragglers_kernel (a grid-stride loop over a list whose length only the device
-// knows).  A straggler's 252 loads are scattered: the kernel lives on waves in flight, and 512 workgroups are two waves
-// per SIMD (0.56 ms for the 1.3e6 stragglers of the third stale step at 256^3 x 8 per cell)
-#define WXA_STRAGGLER_BLOCKS 2048
+// knows).  512 workgroups are two waves per SIMD; 2048 were measured and change nothing (0.19-0.62 ms per launch either
+// way at 256^3 x 8 per cell, profiles/round5/README.md): the kernel is not short of waves in flight
+#define WXA_STRAGGLER_BLOCKS 512
 #endif
 #ifndef WXA_GATHER_PF
 #define WXA_GATHER_PF 3   // 2: the next particle's position is requested a trip ahead, this particle's momentum at the top of its trip; 3: the same, chunks through an LDS counter

@@ -233,6 +233,10 @@ public:
         const char* fold = std::getenv("WXA_SORT_IN_PUSH");
         m_ctx.sort_in_push = sort_intervals > 0 && !(fold && std::atoi(fold) == 0);
         for (int d = 0; d < 3; ++d) m_ctx.sort_wrap[d] = m_comm->periodic(d) && m_comm->self_periodic(d) ? 1 : 0;
+        // the keys of the positions behind the scattering push (free flight over its time step): the deposition of the sort
+        // step and the next gather meet a fresh sort.  WXA_SORT_PREDICT=0: the keys of the positions in front of it.
+        const char* predict = std::getenv("WXA_SORT_PREDICT");
+        m_ctx.sort_predict_dt = predict && std::atoi(predict) == 0 ? 0.0 : dt[0];
     }
 
     // WarpX::InitNCICorrector (Source/Initialization/WarpXInitData.cpp:858-890): the two Godfrey filters for

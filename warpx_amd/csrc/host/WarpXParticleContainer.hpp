@@ -38,6 +38,7 @@ struct WarpXContext {
     bool sort_intervals_on = false;    // warpx.sort_intervals > 0
     bool sort_in_push = false;         // the periodic sorts are folded into PushPX (wxa_push_sort_begin, include/warpx_amd.h)
     int32_t sort_wrap[3] = {0, 0, 0};  // directions along which this brick is its own periodic neighbour
+    double sort_predict_dt = 0.0;      // the recorded keys are those of the positions one free-flight step ahead (0: of the positions)
     // boundary.particle_lo/hi resolved to WXA_PBOUNDARY_PERIODIC / _ABSORBING / _REFLECTING
     int32_t particle_bc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     int32_t particle_bc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
@@ -280,7 +281,7 @@ public:
         int32_t lo[3], nc[3];
         for (int d = 0; d < 3; ++d) { lo[d] = m_ctx->brick_box.lo[d]; nc[d] = m_ctx->brick_box.length(d); }
         check(be->push_sort_begin(m_ws, mode, &p, &dst, m_ctx->brick_plo.data(), m_ctx->dinv.data(), lo, nc, m_ctx->sort_wrap,
-                                  m_nretired > 0 ? 1 : 0, m_ctx->stream),
+                                  m_nretired > 0 ? 1 : 0, m_ctx->sort_predict_dt, m_ctx->stream),
               "push_sort_begin");
         m_push_sort_mode = mode;
     }

@@ -115,7 +115,7 @@ struct Backend {
     // them the container sorts with sort_particles_by_cell
     int (*push_sort_begin)(void* ws, int32_t mode, const wxa_particle_view* p, const wxa_particle_view* dst, const double* plo,
                            const double* dinv, const int32_t* cell_lo, const int32_t* ncell, const int32_t* wrap,
-                           int32_t check_retired, void*) = nullptr;
+                           int32_t check_retired, double predict_dt, void*) = nullptr;
     int (*push_sort_end)(void* ws, int32_t read_live, int64_t* live, int64_t* appended, void*) = nullptr;
     int (*push_sort_pending)(const void* ws, const wxa_particle_view* p) = nullptr;
     // WarpXParticleContainer::ApplyBoundaryConditions (reflecting / absorbing walls); *n_lost valid on return

@@ -171,8 +171,9 @@ const Backend* hip_backend() {
             return wxa_sort_live_count(static_cast<wxa_workspace*>(ws), n, st); };
         b.push_sort_begin = [](void* ws, int32_t mode, const wxa_particle_view* p, const wxa_particle_view* dst,
                                const double* plo, const double* dinv, const int32_t* lo, const int32_t* nc,
-                               const int32_t* wrap, int32_t check_retired, void* st) -> int {
-            return wxa_push_sort_begin(static_cast<wxa_workspace*>(ws), mode, p, dst, plo, dinv, lo, nc, wrap, check_retired, st); };
+                               const int32_t* wrap, int32_t check_retired, double predict_dt, void* st) -> int {
+            return wxa_push_sort_begin(static_cast<wxa_workspace*>(ws), mode, p, dst, plo, dinv, lo, nc, wrap, check_retired,
+                                       predict_dt, st); };
         b.push_sort_end = [](void* ws, int32_t read_live, int64_t* live, int64_t* appended, void* st) -> int {
             return wxa_push_sort_end(static_cast<wxa_workspace*>(ws), read_live, live, appended, st); };
         b.push_sort_pending = [](const void* ws, const wxa_particle_view* p) -> int {

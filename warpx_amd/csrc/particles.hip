@@ -1198,7 +1198,7 @@ wxa_status wxa_apply_particle_boundaries(const wxa_particle_view* p, const doubl
 // ---- the cell sort folded into PushPX (push_sort.hpp) ----------------------------------------------------------------
 wxa_status wxa_push_sort_begin(wxa_workspace* ws, int32_t mode, const wxa_particle_view* p, const wxa_particle_view* dst,
                                const double plo[3], const double dinv[3], const int32_t cell_lo[3], const int32_t ncell[3],
-                               const int32_t wrap[3], int32_t check_retired, void* stream) {
+                               const int32_t wrap[3], int32_t check_retired, double predict_dt, void* stream) {
     WXA_REQUIRE(ws && pv_ok(p), "bad argument");
     WXA_REQUIRE(mode == WXA_PUSH_SORT_COUNT || mode == WXA_PUSH_SORT_SCATTER || mode == (WXA_PUSH_SORT_COUNT | WXA_PUSH_SORT_SCATTER),
                 "mode must be WXA_PUSH_SORT_COUNT, WXA_PUSH_SORT_SCATTER or both");
@@ -1231,6 +1231,7 @@ wxa_status wxa_push_sort_begin(wxa_workspace* ws, int32_t mode, const wxa_partic
         WXA_HIP_CHECK(hipMemsetAsync(s.hist.p, 0, sizeof(int) * 2 * (ncells + 2), st));
         WXA_HIP_CHECK(hipMemsetAsync(s.own[s.out].p, 0, sizeof(int) * (ncells + 2), st));
         s.check_retired = check_retired && p->idcpu ? 1 : 0;
+        s.predict_dt = predict_dt;
         for (int d = 0; d < 3; ++d) {
             s.plo[d] = plo[d]; s.dinv[d] = dinv[d]; s.nc[d] = ncell[d]; s.cell_lo[d] = cell_lo[d]; s.wrap[d] = wrap[d] ? 1 : 0;
         }

@@ -66,6 +66,7 @@ constexpr unsigned long long PUSH_SORT_FOREIGN = 0x80000000ull;
 struct PushSort {
     int mode = 0;                                   // 0, PUSH_SORT_COUNT, PUSH_SORT_SCATTER or both
     int check_retired = 0;                          // COUNT: the tile may hold retired particles (their ids are looked at)
+    double predict_dt = 0.0;                        // COUNT: key the position this many seconds of free flight ahead
     long first = 0;
     // COUNT
     SortGeom sg{};
@@ -119,7 +120,17 @@ __device__ __forceinline__ bool push_sort_tail(const PushSort& h, const PV& p, c
         in_place = false;
     }
     if (h.mode & PUSH_SORT_COUNT) {
-        const int key = (h.check_retired && p.id && pid == WXA_IDCPU_RETIRED) ? h.sg.retired_bin : cell_of(h.sg, xp, yp, zp);
+        // predict_dt: the key of where the particle will be after the NEXT push if nothing accelerates it -- the push
+        // that scatters then writes the particles in (all but exactly) the cell order of the positions it produces, and
+        // the deposition behind it and the next gather meet a fresh sort instead of one that is a push old.  Any key
+        // gives a valid order; a particle the fields deflect into another cell is one more straggler.
+        double kx = xp, ky = yp, kz = zp;
+        if (h.predict_dt != 0.0) {
+            constexpr double inv_c2 = 1.0 / (PhysConst::c * PhysConst::c);
+            const double s_ = h.predict_dt / sqrt(1.0 + (ux * ux + uy * uy + uz * uz) * inv_c2);
+            kx += ux * s_; ky += uy * s_; kz += uz * s_;
+        }
+        const int key = (h.check_retired && p.id && pid == WXA_IDCPU_RETIRED) ? h.sg.retired_bin : cell_of(h.sg, kx, ky, kz);
         unsigned long long rank;
         if (lds_hist && key / PUSH_SORT_TILE_CELLS == my_tile) {
             rank = (unsigned long long)(unsigned)atomicAdd(&lds_hist[key % PUSH_SORT_TILE_CELLS], 1);
@@ -155,6 +166,7 @@ inline PushSort make_push_sort(const wxa_workspace* ws, const long first, const 
         for (int d = 0; d < 3; ++d) { h.sg.plo[d] = s.plo[d]; h.sg.dinv[d] = s.dinv[d]; h.sg.nc[d] = s.nc[d]; h.sg.wrap[d] = s.wrap[d]; }
         h.sg.retired_bin = (int)s.bins;
         h.check_retired = s.check_retired;
+        h.predict_dt = s.predict_dt;
         h.kr_out = (unsigned long long*)s.kr[s.out].p;
         h.hist = (int*)s.hist.p;
         h.fcnt = (int*)s.hist.p + (s.bins + 2);

@@ -58,6 +58,7 @@ struct wxa_workspace {
         wxa::DevBuf kr[2], offs[2], own[2], hist;   // (key, rank) per particle, the scanned histogram and the own counts
                                                     // per cell, double-buffered; hist: the histogram and the foreign counters
         int32_t check_retired = 0;           // armed COUNT: the caller's tile may hold retired particles
+        double predict_dt = 0.0;             // armed COUNT: keys of the positions this much free flight ahead
         int32_t in = 0, out = 0;             // kr[in], offs[in]: the pending record; [out]: what the armed COUNT writes
         bool pending = false;
         int64_t pending_np = 0, pending_bins = 0;
