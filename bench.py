@@ -85,7 +85,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_FILE = os.path.join("profiles", "round4", "r4_pmc_counters.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "round5", "r5_pmc_counters.json")
 
 
 def pmc_traffic(args):
@@ -234,9 +234,11 @@ def main():
     ap.add_argument("--deposition", choices=["esirkepov", "direct"], default="esirkepov")
     ap.add_argument("--pusher", choices=["boris", "vay"], default="boris")
     ap.add_argument("--no-filter", action="store_true")
-    ap.add_argument("--sort-interval", type=int, default=3,
-                    help="cell sort every N steps (warpx.sort_intervals); 3 measured best on MI355X (round 2 kernels): "
-                         "2: 15.9, 3: 15.75, 4: 16.4 ms/step")
+    ap.add_argument("--sort-interval", type=int, default=2,
+                    help="cell sort every N steps (warpx.sort_intervals).  With the sort folded into the push (round 5: "
+                         "the push before a sort step records keys and ranks, the sort step's push writes the sorted tile) "
+                         "2 and 3 are level, 2 a little ahead: 12.41-12.49 / 12.44-12.64 / 13.3 ms per step at 2 / 3 / 4 "
+                         "(profiles/round5/README.md); with the sort as passes of its own it was 3")
     ap.add_argument("--preroll", type=int, default=40,
                     help="untimed steps before the warmup: the regular-lattice start is atypically cheap "
                          "(no particle crosses a cell for ~20 steps), the timed region must see the "

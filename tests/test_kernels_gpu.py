@@ -604,11 +604,15 @@ def test_deposit_current_fp32_tiles(oracle, product, order, u_scale):
     product.workspace_destroy(ws)
 
 
-@pytest.mark.parametrize("order,galerkin", [(1, 1), (2, 1), (3, 1), (3, 0), (2, 0), (1, 0)])
+@pytest.mark.parametrize("order,galerkin,pusher", [(1, 1, _capi.PUSHER_BORIS), (2, 1, _capi.PUSHER_BORIS), (3, 1, _capi.PUSHER_BORIS),
+                                                   (3, 0, _capi.PUSHER_BORIS), (2, 0, _capi.PUSHER_BORIS), (1, 0, _capi.PUSHER_BORIS),
+                                                   (3, 1, _capi.PUSHER_VAY), (3, 0, _capi.PUSHER_VAY), (2, 1, _capi.PUSHER_VAY),
+                                                   (3, 1, _capi.PUSHER_HC), (1, 0, _capi.PUSHER_HC)])
 @pytest.mark.parametrize("stale", [False, True])
-def test_gather_push_lds_tiles(oracle, product, order, galerkin, stale):
+def test_gather_push_lds_tiles(oracle, product, order, galerkin, pusher, stale):
     """LDS-tile gather (needs a cell sort in the workspace) against the oracle; `stale` moves the
-    particles after the sort so that some stencils leave the staged range (global-load path)."""
+    particles after the sort so that some stencils leave the staged range (global-load path).  Boris, Vay and
+    Higuera-Cary on the tile kernel itself (until round 5 the other pushers met it only through the step tests)."""
     import torch
     ncell = (24, 20, 16)
     ng, _, _ = H.guard_depths(order)
@@ -636,9 +640,9 @@ def test_gather_push_lds_tiles(oracle, product, order, galerkin, stale):
     q, m = -plasma.Q_E, plasma.M_E
     for move, fn in ((1, "gather_push"), (0, "push_p")):
         getattr(oracle, fn)(C.byref(ph.view), field_triplet(E), field_triplet(B), C.byref(g), q, m, dt,
-                            order, galerkin, _capi.PUSHER_BORIS, None)
+                            order, galerkin, pusher, None)
         product.gather_push_ws(C.byref(srt.view), field_triplet(Ed), field_triplet(Bd), C.byref(g), q, m, dt,
-                               order, galerkin, _capi.PUSHER_BORIS, move, ws, None)
+                               order, galerkin, pusher, move, ws, None)
         _sync(product)
         a, b = srt.to_numpy(), ph.to_numpy()
         for row in range(7):
