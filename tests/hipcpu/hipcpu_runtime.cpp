@@ -2,7 +2,10 @@
 // synchronous runtime API of the HIP-on-CPU execution model.
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <signal.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -160,8 +163,35 @@ const uint64_t* wave_exchange(int kind, uint64_t v, uint64_t* mask, int* lane) {
     return w.buf[par];
 }
 
+// HIPCPU_BACKTRACE=1: a fault inside a kernel (a guard page, say) prints the faulting address, the work-item and the
+// frames of its fiber before the process dies (symbolise with addr2line -e libwarpx_amd_hipcpu.so <offsets>)
+static void fault_handler(int sig, siginfo_t* info, void*) {
+    char buf[256];
+    int n = std::snprintf(buf, sizeof(buf), "[hipcpu] signal %d at address %p in workgroup (%u,%u,%u) work-item %d\n", sig, info->si_addr,
+                          g_b.bid.x, g_b.bid.y, g_b.bid.z, g_b.cur);
+    if (write(2, buf, (size_t)n) < 0) {}
+    void* frames[48];
+    const int nf = backtrace(frames, 48);
+    backtrace_symbols_fd(frames, nf, 2);
+    _exit(139);
+}
+
 void run_grid(dim3 grid, dim3 block, void (*entry)(void*), void* closure, const char* name) {
     std::lock_guard<std::recursive_mutex> lock(g_launch_lock);
+    static const bool bt = [] {
+        if (!std::getenv("HIPCPU_BACKTRACE")) return false;
+        static char altstack[1 << 16];
+        stack_t ss{};
+        ss.ss_sp = altstack; ss.ss_size = sizeof(altstack);
+        sigaltstack(&ss, nullptr);
+        struct sigaction sa{};
+        sa.sa_sigaction = fault_handler;
+        sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, nullptr);
+        sigaction(SIGBUS, &sa, nullptr);
+        return true;
+    }();
+    (void)bt;
     static const bool trace = std::getenv("HIPCPU_TRACE") != nullptr;   // the last line names a crashing kernel
     if (trace)
         std::fprintf(stderr, "[hipcpu] %s grid (%u,%u,%u) block (%u,%u,%u)\n", name, grid.x, grid.y, grid.z, block.x,

@@ -422,11 +422,17 @@ def test_deposit_current_lds_tiles(oracle, product, order, algo, stale, u_scale)
 
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
-def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo):
+@pytest.mark.parametrize("drift", [0.0, 2.5])
+def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo, drift):
     """Cells with more particles than the tile kernel's work items cover (more than 24 in a cell: at 8 per cell on
     average about one cell in a million, i.e. only at the headline size -- found there, round 3, by
     test_direct_vay_ckc_256_against_the_oracle: the overflow list was deposited with the Esirkepov body whatever the
-    algorithm).  A few cells with 30 to 90 particles among ordinary ones, both algorithms, against the oracle."""
+    algorithm).  A few cells with 30 to 90 particles among ordinary ones, both algorithms, against the oracle.
+    drift: every particle moved by up to that many cells after the sort.  The particles of a crowded cell beyond the
+    24th reach the deposition by index only, unseen by the chunk loop and its range check -- until round 5 their wide
+    frame was written to the LDS tile wherever it lay, and a frame outside the tile overwrote the lists next to it in
+    LDS (found by the boosted wakefield deck at 8 particles per cell: a density spike, electrons moving a cell per step,
+    a memory fault on the MI355X; reproduced on the CPU execution model with guard pages)."""
     ncell = (16, 16, 16)
     _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
     parts = H.random_particles(20000, ncell, 77 + order, u_scale=1.0)
@@ -444,6 +450,11 @@ def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo):
     product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
                                    (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
     _sync(product)
+    if drift:
+        import torch
+        for d in range(3):
+            srt.data[d] += torch.from_numpy(dx[d] * drift * (2 * rng.random(srt.np) - 1)).to(DEV)
+            srt.data[d].clamp_(-H.LX / 2 + 0.01 * dx[d], H.LX / 2 - 0.01 * dx[d])
     ph = ParticleArrays.from_numpy(list(srt.to_numpy()), "cpu")
     J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
     Jd = H.clone_fields(J, DEV, True)

@@ -898,9 +898,9 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 const int bkt = (LONE ? NBANK : 0) + (lane & (NBANK - 1));
                 if (row < min(ndef[bkt], DCAP)) {
                     const unsigned ent = deferred[bkt * DCAP + row];
+                    const int ip = (int)(ent & 0x7fffffffu);
                     ParticleState p1;
                     if (ent & 0x80000000u) {
-                        const int ip = (int)(ent & 0x7fffffffu);
                         p1 = ParticleState{px[ip], py[ip], pz[ip], pw[ip], pux[ip], puy[ip], puz[ip]};
                     } else {
                         const int at = bkt * DKEEP + row;
@@ -924,7 +924,18 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                         esirkepov_single_fast<O, COMP>(c1, wq, es, sink);
                     } else {
                         const WideFrame<O> f = esirkepov_wide_frame<O>(c1, g);
-                        LdsSink<M, TSZ, ACC> sink(lds, f.b[0] - o0, f.b[1] - o1, f.b[2] - o2);
+                        // The particles that phase B deferred by index (beyond the 24th of a cell, a full tail table) were
+                        // never seen by the chunk loop and its range check: a frame that leaves the tile (the sort's age,
+                        // a particle moving a cell per step) goes to the global-atomics pass, once (the pass of component
+                        // 0 queues it), instead of into the lists that lie behind the tile in LDS.  (Found in round 5 by
+                        // the boosted wakefield deck at 8 per cell: a density spike, a corrupted deferred list, a memory
+                        // fault; test_deposit_current_lds_tiles_crowded_cells[drift].)
+                        const int wi = f.b[0] - o0, wj = f.b[1] - o1, wk = f.b[2] - o2;
+                        if (!(wi >= 0 && wj >= 0 && wk >= 0 && wi + O + 2 <= N && wj + O + 2 <= N && wk + O + 2 <= NZ)) {
+                            if constexpr (COMP == 0) sq.push(ip);
+                            continue;
+                        }
+                        LdsSink<M, TSZ, ACC> sink(lds, wi, wj, wk);
                         esirkepov_single_wide<O, COMP>(c1, f, wq, es, sink);
                     }
                 }
