@@ -439,7 +439,9 @@ def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo, d
     dx = H.LX / np.asarray(ncell)
     rng = np.random.default_rng(12)
     crowd = []
-    for cell, count in (((3, 4, 5), 30), ((8, 8, 8), 57), ((15, 0, 7), 90), ((9, 8, 8), 26)):
+    # ... and one cell like a wake's density spike: thousands of particles, which leave the tile kernel for the
+    # global-atomics pass as one block of the straggler list
+    for cell, count in (((3, 4, 5), 30), ((8, 8, 8), 57), ((15, 0, 7), 90), ((9, 8, 8), 26), ((5, 9, 2), 3000), ((6, 9, 2), 70)):
         pos = [-H.LX / 2 + (cell[d] + rng.random(count)) * dx[d] for d in range(3)]
         crowd.append(pos + [1e9 * (0.5 + rng.random(count))] + [plasma.C_LIGHT * rng.standard_normal(count) for _ in range(3)])
     parts = [np.concatenate([parts[r]] + [c[r] for c in crowd]) for r in range(7)]

@@ -303,6 +303,13 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     __shared__ int ndef[NBKT];
     __shared__ int nitems;
     __shared__ int next_chunk;
+    // Cells far beyond the tables (a wake's density spike: thousands of particles in a cell): what a cell holds beyond
+    // 2 RMAX + SOFT particles leaves for the global-atomics pass as ONE block of the straggler list per tile (one global
+    // atomic, the indices written by all lanes) -- as one lane's loop of returning global atomics on the list's counter
+    // the boosted wakefield deck at 8 per cell spent 600 ms per launch in this kernel (profiles/round5/README.md)
+    constexpr int SOFT = 32;
+    __shared__ int xs[FUSED ? 1 : CELLS + 1];
+    __shared__ int any_excess, xbase;
     // ... and their data, for the first DKEEP entries of every bucket: phase C has the particle in registers when it
     // defers it; fetched again by index in phase D each one costs seven cache lines from HBM (the tile's lines have left
     // the L2 by then: FETCH_SIZE 1.57 x the particle data, phase D 12 % of the kernel for 3 % of the particles)
@@ -395,7 +402,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     };
     constexpr int WAVES = NT / 64;
     // ---- A: cell counts, row masks; zero fill
-    if (tid == 0) { nitems = 0; next_chunk = 0; }
+    if (tid == 0) { nitems = 0; next_chunk = 0; any_excess = 0; }
     if (tid < NBKT) ndef[tid] = 0;
     int my_s = 0, my_n = 0, my_pairs = 0;
     unsigned long long my_mask[RT];   // wave-uniform: tail row r of this cell-wave
@@ -527,9 +534,36 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 }
             }
         }
-        for (int k = 2 * RMAX; k < my_n; ++k) defer_unloaded(my_s + k, tid & (NBANK - 1));   // beyond the table's rows (> 2 RMAX particles in a cell)
+        // beyond the table's rows (> 2 RMAX particles in a cell): the first SOFT of them one by one, the rest as a block
+        const int soft_end = FUSED ? my_n : min(my_n, 2 * RMAX + SOFT);
+        for (int k = 2 * RMAX; k < soft_end; ++k) defer_unloaded(my_s + k, tid & (NBANK - 1));
+        if constexpr (!FUSED) {
+            if (my_n > soft_end) any_excess = 1;
+        }
     }
     __syncthreads();
+    if constexpr (!FUSED && !HF) {
+        if (any_excess) {   // uniform
+            if (tid < CELLS) xs[tid] = max(0, my_n - (2 * RMAX + SOFT));
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0;
+                for (int c = 0; c < CELLS; ++c) { const int v = xs[c]; xs[c] = acc; acc += v; }
+                xs[CELLS] = acc;
+                xbase = (int)atomicAdd(sq.count, (unsigned)acc);
+            }
+            __syncthreads();
+            const int total = xs[CELLS];
+            for (int j = tid; j < total; j += NT) {
+                int lo = 0, hi = CELLS;   // the cell whose block holds entry j: xs[lo] <= j < xs[lo + 1]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (xs[mid] <= j) lo = mid; else hi = mid;
+                }
+                sq.idx[xbase + j] = cstart[lo] + 2 * RMAX + SOFT + (j - xs[lo]);
+            }
+        }
+    }
     DPROF(1);
     const int ti = (int)(tile % tg.nt[0]);
     const int tj = (int)((tile / tg.nt[0]) % tg.nt[1]);
