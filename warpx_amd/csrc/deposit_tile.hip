@@ -303,13 +303,15 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     __shared__ int ndef[NBKT];
     __shared__ int nitems;
     __shared__ int next_chunk;
-    // Cells far beyond the tables (a wake's density spike: thousands of particles in a cell): what a cell holds beyond
-    // 2 RMAX + SOFT particles leaves for the global-atomics pass as ONE block of the straggler list per tile (one global
-    // atomic, the indices written by all lanes) -- as one lane's loop of returning global atomics on the list's counter
-    // the boosted wakefield deck at 8 per cell spent 600 ms per launch in this kernel (profiles/round5/README.md)
-    constexpr int SOFT = 32;
-    __shared__ int xs[FUSED ? 1 : CELLS + 1];
-    __shared__ int any_excess, xbase;
+    // Cells beyond the tables (more than 2 RMAX particles: a wake's density spike holds thousands): their excess pairs are
+    // more chunks of the same loop -- item j of the excess is found through the running sums xs[] of the cells' excess
+    // pairs (binary search in LDS) -- so that they deposit on the tile like everybody else.  (Until round 5 one lane
+    // deferred them particle by particle, by index, and what the deferred list could not take went to the global-atomics
+    // pass: the boosted wakefield deck at 8 per cell spent 600 ms per launch there, thousands of particles of one cell
+    // adding to the same hundred addresses of J in L2.)  Tiles without such a cell: one LDS flag read.
+    constexpr bool XCH = !FUSED && CFG::HF == 0 && CFG::TI == 0 && CFG::COOP == 0;
+    __shared__ int xs[XCH ? CELLS + 1 : 1];
+    __shared__ int any_excess;
     // ... and their data, for the first DKEEP entries of every bucket: phase C has the particle in registers when it
     // defers it; fetched again by index in phase D each one costs seven cache lines from HBM (the tile's lines have left
     // the L2 by then: FETCH_SIZE 1.57 x the particle data, phase D 12 % of the kernel for 3 % of the particles)
@@ -534,34 +536,26 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 }
             }
         }
-        // beyond the table's rows (> 2 RMAX particles in a cell): the first SOFT of them one by one, the rest as a block
-        const int soft_end = FUSED ? my_n : min(my_n, 2 * RMAX + SOFT);
-        for (int k = 2 * RMAX; k < soft_end; ++k) defer_unloaded(my_s + k, tid & (NBANK - 1));
-        if constexpr (!FUSED) {
-            if (my_n > soft_end) any_excess = 1;
+        // beyond the table's rows (> 2 RMAX particles in a cell): chunks of their own (XCH), or one by one to the lists
+        if constexpr (XCH) {
+            if (my_n > 2 * RMAX) any_excess = 1;
+        } else {
+            for (int k = 2 * RMAX; k < my_n; ++k) defer_unloaded(my_s + k, tid & (NBANK - 1));
         }
     }
     __syncthreads();
-    if constexpr (!FUSED && !HF) {
+    int excess_pairs = 0;
+    if constexpr (XCH) {
         if (any_excess) {   // uniform
-            if (tid < CELLS) xs[tid] = max(0, my_n - (2 * RMAX + SOFT));
+            if (tid < CELLS) xs[tid] = (max(0, my_n - 2 * RMAX) + 1) >> 1;
             __syncthreads();
             if (tid == 0) {
                 int acc = 0;
                 for (int c = 0; c < CELLS; ++c) { const int v = xs[c]; xs[c] = acc; acc += v; }
                 xs[CELLS] = acc;
-                xbase = (int)atomicAdd(sq.count, (unsigned)acc);
             }
             __syncthreads();
-            const int total = xs[CELLS];
-            for (int j = tid; j < total; j += NT) {
-                int lo = 0, hi = CELLS;   // the cell whose block holds entry j: xs[lo] <= j < xs[lo + 1]
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (xs[mid] <= j) lo = mid; else hi = mid;
-                }
-                sq.idx[xbase + j] = cstart[lo] + 2 * RMAX + SOFT + (j - xs[lo]);
-            }
+            excess_pairs = xs[CELLS];
         }
     }
     DPROF(1);
@@ -578,7 +572,8 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
 #ifdef WXA_DEPOSIT_PROFILE
     const long long prof_l0 = clock64();
 #endif
-    const int nchunks = CFG::DBG == 5 ? 0 : NB + ((T + TPC - 1) / TPC);   // DBG 5 (timing): the phases around the loop alone
+    const int nregular = NB + ((T + TPC - 1) / TPC);
+    const int nchunks = CFG::DBG == 5 ? 0 : nregular + ((excess_pairs + 63) >> 6);   // DBG 5 (timing): the phases around the loop alone
     // DYN: a wave holds the chunk it works on and has already claimed the next one (the counter's round trip through the
     // LDS queue -- behind the other waves' atomics -- hides behind the chunk)
     auto claim = [&]() {
@@ -606,11 +601,26 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                     c = va ? (int)(ent & 511u) : c; r = va ? (int)(ent >> 9) : r;
                 }
             }
-        } else {
+        } else if (!XCH || ch < nregular) {
             const int I = (ch - NB) * TPC + (lane & (TPC - 1));
             va = I < T && lane < TPC;
             const unsigned ent = va ? table[I] : 0u;
             c = (int)(ent & 511u); r = (int)(ent >> 9);
+        } else {   // pair I of the cells' excess: the cell whose running sum holds it, xs[c] <= I < xs[c + 1]
+            const int I = ((ch - nregular) << 6) + lane;
+            va = I < excess_pairs;
+            int lo = 0, hi = CELLS;
+            if constexpr (XCH) {
+                const int J = va ? I : 0;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (xs[mid] <= J) lo = mid; else hi = mid;
+                }
+                r = RMAX + (J - xs[lo]);
+            } else {
+                r = 0;
+            }
+            c = lo;
         }
         int s0, n0;
         if (CFG::GIDX != 0 && ch < NB) { s0 = offsets[ucell0 + c]; n0 = offsets[ucell0 + c + 1] - s0; }
