@@ -125,6 +125,14 @@ wxa_status wxa_workspace_set_time(wxa_workspace* ws, double t);
 #define WXA_ACC_FP64 0
 #define WXA_ACC_FP32 1
 wxa_status wxa_workspace_set_deposit_accumulator(wxa_workspace* ws, int32_t accumulator);
+/* The container's plasma STREAMS through the grid: in a boosted-frame run (warpx.gamma_boost > 1, Source/Utils/WarpXUtil.cpp:
+ * 114-141) every particle of a plasma at rest in the lab moves c dt / dz cells per step against the boost and most of them
+ * cross a cell every step.  on != 0: the LDS-tile Esirkepov deposition (doEsirkepovDepositionShapeN,
+ * CurrentDeposition.H:642-907) takes every particle through its wide-frame body inside the tile loop -- the body of a
+ * particle that may cross a cell, 300 LDS atomics instead of 72 -- instead of deferring the crossing ones to a list
+ * sized for the 1-2 % of a plasma at rest (what overflows that list is deposited with global atomics: 660 ms per launch
+ * for the boosted wakefield deck at 256 x 256 x 512 x 8 per cell).  Same sums, another order of additions.  Default 0. */
+wxa_status wxa_workspace_set_streaming_plasma(wxa_workspace* ws, int32_t on);
 
 const char* wxa_version(void);
 const char* wxa_last_error(void);

@@ -471,6 +471,50 @@ def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo, d
     product.workspace_destroy(ws)
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("streaming", [0, 1])
+@pytest.mark.parametrize("drift", [0.0, 0.8])
+def test_deposit_current_of_a_streaming_plasma(oracle, product, order, streaming, drift):
+    """A plasma that streams through the grid (a boosted-frame run: every particle moves 0.76 cells per step against the
+    boost, three in four cross a cell) on the LDS tiles, against the oracle: with wxa_workspace_set_streaming_plasma every
+    particle goes through the wide-frame body inside the tile loop; without it the crossing particles go through the
+    deferred list and, what it cannot take (most of them here), the global-atomics pass -- the same J either way.
+    drift: moved by up to that many cells after the sort."""
+    ncell = (16, 16, 24)
+    _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    parts = H.random_particles(60000, ncell, 410 + order, u_scale=0.05)
+    dx = H.LX / np.asarray(ncell)
+    dt = H.yee_dt(dx)
+    beta = 0.76 * dx[2] / (plasma.C_LIGHT * dt)           # v dt = 0.76 dz along -z
+    beta = min(beta, 0.98)
+    parts[6] = parts[6] - beta / np.sqrt(1.0 - beta ** 2) * plasma.C_LIGHT
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    product.workspace_set_streaming_plasma(ws, streaming)
+    srt = ParticleArrays(pd0.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    if drift:
+        import torch
+        rng = np.random.default_rng(9)
+        for d in range(3):
+            srt.data[d] += torch.from_numpy(dx[d] * drift * (2 * rng.random(srt.np) - 1)).to(DEV)
+            srt.data[d].clamp_(-H.LX / 2 + 0.01 * dx[d], H.LX / 2 - 0.01 * dx[d])
+    ph = ParticleArrays.from_numpy(list(srt.to_numpy()), "cpu")
+    J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    Jd = H.clone_fields(J, DEV, True)
+    g, _ = H.geom_for(ncell, ng_depos)
+    q = -plasma.Q_E
+    oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order, _capi.DEPOSIT_ESIRKEPOV, None, None)
+    product.deposit_current(C.byref(srt.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, _capi.DEPOSIT_ESIRKEPOV, ws, None)
+    _sync(product)
+    for a, b in zip(Jd, J):
+        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.parametrize("algo,acc", [(_capi.DEPOSIT_ESIRKEPOV, _capi.ACC_FP64), (_capi.DEPOSIT_DIRECT, _capi.ACC_FP64),
                                       (_capi.DEPOSIT_ESIRKEPOV, _capi.ACC_FP32)])
 @pytest.mark.parametrize("ppc", [20, 40])

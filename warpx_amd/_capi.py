@@ -284,6 +284,7 @@ _PRODUCT_SIGS = {
     "device_synchronize": (C.c_int, []),
     "enforce_periodic_sorted": (C.c_int, [_PPV, _D3, _D3, _I3, C.c_void_p, C.c_int32, C.c_void_p]),
     "workspace_set_deposit_accumulator": (C.c_int, [C.c_void_p, C.c_int32]),
+    "workspace_set_streaming_plasma": (C.c_int, [C.c_void_p, C.c_int32]),
     "sim_set_deposit_accumulator": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
 }
 ACC_FP64, ACC_FP32 = 0, 1

@@ -183,8 +183,18 @@ constexpr int FUSED_GNPTS = FUSED_GN * FUSED_GN * FUSED_GN;
 // DBG (timing experiments only): 1 = the arithmetic without the LDS atomics, 2 = the LDS atomics without the arithmetic
 template <int NT_, int TSZ_, int WPE_, int PHASED_, int DBG_ = 0, class ACC_ = double, int BW_ = 0,
           int ALGO_ = WXA_DEPOSIT_ESIRKEPOV, int COOP_ = 0, int DYN_ = 0, int FUSED_ = 0, int PUSHER_ = WXA_PUSHER_BORIS,
-          int HF_ = 0, int PT_ = 0, int GIDX_ = 0, int FLUSH_ = 0, int ZF_ = 0, int SNG_ = 0, int PFD_ = 0, int TI_ = 0, int TB_ = 0, int LD16_ = 0>
+          int HF_ = 0, int PT_ = 0, int GIDX_ = 0, int FLUSH_ = 0, int ZF_ = 0, int SNG_ = 0, int PFD_ = 0, int TI_ = 0, int TB_ = 0, int LD16_ = 0,
+          int WL_ = 0>
 struct RowsCfg {
+    // WL (wide frames in the loop): every particle is deposited inside the chunk loop through the wide-frame single body
+    // (O + 2 slots per direction: correct whether it crosses a cell or not), nothing is merged, nothing deferred for
+    // crossing.  For a plasma that STREAMS through the grid -- a boosted-frame run: every particle moves c dt / dz = 0.76
+    // cells per step against the boost, three in four cross a cell -- where the fast body's premise (1-2 % cross) fails:
+    // the deferred list (2048 per tile) overflowed into the global-atomics pass and the boosted wakefield deck at
+    // 256 x 256 x 512 x 8 per cell spent 660 ms per launch there (profiles/round5/README.md).  300 LDS atomics per
+    // particle instead of 72: the price of a crossing particle, paid on the tile.  Chosen per workspace
+    // (wxa_workspace_set_streaming_plasma); the default kernel is untouched.
+    static constexpr int WL = WL_;
     // LD16: the lane's two particles -- neighbours in every array -- come as one 16-byte load per array (7 load instructions
     // per chunk instead of 14, each lane's bytes in one place)
     static constexpr int LD16 = LD16_;
@@ -793,6 +803,27 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             continue;
         }
         EsirkepovCoords c1 = esirkepov_coords(pa, g, es), c2 = esirkepov_coords(pb, g, es);
+        if constexpr (CFG::WL != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && !FUSED) {
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                if (!(h ? vb : va)) continue;
+                const EsirkepovCoords cc = h ? c2 : c1;
+                const WideFrame<O> f = esirkepov_wide_frame<O>(cc, g);
+                const int wi = f.b[0] - o0, wj = f.b[1] - o1, wk = f.b[2] - o2;
+                if (!(wi >= 0 && wj >= 0 && wk >= 0 && wi + O + 2 <= N && wj + O + 2 <= N && wk + O + 2 <= NZ)) {
+                    sq.push(h ? ib : ia);   // the frame leaves the tile: the global-atomics pass
+                    continue;
+                }
+                LdsSink<M, TSZ, ACC> sink(lds, wi, wj, wk);
+                const double wq = q * (h ? pb.w : pa.w);
+                esirkepov_single_wide<O, 0>(cc, f, wq, es, sink);
+                esirkepov_single_wide<O, 1>(cc, f, wq, es, sink);
+                esirkepov_single_wide<O, 2>(cc, f, wq, es, sink);
+            }
+            if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
+            else ch += WAVES;
+            continue;
+        }
         double wq1 = q * pa.w, wq2 = 0.0;
         const double wqb = q * pb.w;
         int ai, aj, ak, bi, bj, bk;
@@ -1135,6 +1166,7 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
 using RowsEsirkepov = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;
 using RowsEsirkepovF32 = RowsCfg<768, 8, 3, 1, 0, float, 0, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // fp32 tile accumulation (ds_add_f32), opt-in per workspace
 using RowsDirect = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;
+using RowsEsirkepovStreaming = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 1>;   // WL
 using RowsDirectSeq = RowsCfg<768, 8, 3, 1, 0, double, 32, WXA_DEPOSIT_DIRECT, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1>;   // 85 (dev builds): the lane's two particles one after the other, as until round 4 (32-cell chunks: 16.1 -> 14.9 ms in round 3)
 #ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/variants.py): WXA_DEPOSIT_VARIANT=<n>, order-3 Esirkepov
 using RowsB16 = RowsCfg<768, 8, 3, 1, 0, double, 16>;
@@ -1243,6 +1275,11 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
             if (order == 1) return launch_rows<1, RowsEsirkepovF32>(p, J, geom, q, dt, relative_time, ws, st);
             if (order == 2) return launch_rows<2, RowsEsirkepovF32>(p, J, geom, q, dt, relative_time, ws, st);
             return launch_rows<3, RowsEsirkepovF32>(p, J, geom, q, dt, relative_time, ws, st);
+        }
+        if (ws->streaming_plasma) {   // wxa_workspace_set_streaming_plasma: most particles cross a cell per step
+            if (order == 1) return launch_rows<1, RowsEsirkepovStreaming>(p, J, geom, q, dt, relative_time, ws, st);
+            if (order == 2) return launch_rows<2, RowsEsirkepovStreaming>(p, J, geom, q, dt, relative_time, ws, st);
+            return launch_rows<3, RowsEsirkepovStreaming>(p, J, geom, q, dt, relative_time, ws, st);
         }
         if (order == 1) return launch_rows<1, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
         if (order == 2) return launch_rows<2, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);

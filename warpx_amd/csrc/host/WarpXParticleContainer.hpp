@@ -579,6 +579,14 @@ public:
         if (!m_has_injector) return;
         m_inj.gamma_boost = m_ctx->gamma_boost;
         m_inj.t = m_ctx->t_new;
+        // a plasma injected in a boosted frame streams through the grid at -beta c (most particles cross a cell per step):
+        // its deposition takes the wide-frame body inside the tile loop (wxa_workspace_set_streaming_plasma).
+        // WXA_STREAMING_PLASMA=0: the default kernel, for A/B timing
+        if (m_ctx->gamma_boost > 1.0 && !m_streaming_set && m_ctx->be->ws_set_streaming_plasma) {
+            const char* e = std::getenv("WXA_STREAMING_PLASMA");
+            check(m_ctx->be->ws_set_streaming_plasma(m_ws, e && std::atoi(e) == 0 ? 0 : 1), "ws_set_streaming_plasma");
+            m_streaming_set = true;
+        }
         const wxa_plasma_injector& in = m_inj;
         double olo[3], ohi[3];
         int nov[3];
@@ -681,6 +689,7 @@ private:
     bool m_has_injector = false, m_do_continuous_injection = false;
     std::function<void(double, double, double, double*)> m_momentum;
     bool m_interior_pushed = false;
+    bool m_streaming_set = false;
     bool m_momentum_on_device = false;
     wxa_injected_momentum m_device_momentum{};
 

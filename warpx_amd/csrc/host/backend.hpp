@@ -39,6 +39,8 @@ struct Backend {
     int (*ws_set_time)(void* ws, double t) = nullptr;
     // optional: accumulator type of the LDS-tile deposition of that container (wxa_workspace_set_deposit_accumulator)
     int (*ws_set_deposit_accumulator)(void* ws, int32_t acc) = nullptr;
+    // optional: the container's plasma streams through the grid (wxa_workspace_set_streaming_plasma)
+    int (*ws_set_streaming_plasma)(void* ws, int32_t on) = nullptr;
     // gather + push; move != 0 -> PushPX, move == 0 -> PushP; ws = the container's workspace
     int (*gather_push)(const wxa_particle_view*, const wxa_field_view*, const wxa_field_view*,
                        const wxa_grid_geom*, double, double, double, int, int, int, int move, void* ws, void*);

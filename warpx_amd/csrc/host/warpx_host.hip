@@ -81,6 +81,8 @@ const Backend* hip_backend() {
         b.ws_set_time = [](void* ws, double t) -> int { return wxa_workspace_set_time(static_cast<wxa_workspace*>(ws), t); };
         b.ws_set_deposit_accumulator = [](void* ws, int32_t acc) -> int {
             return wxa_workspace_set_deposit_accumulator(static_cast<wxa_workspace*>(ws), acc); };
+        b.ws_set_streaming_plasma = [](void* ws, int32_t on) -> int {
+            return wxa_workspace_set_streaming_plasma(static_cast<wxa_workspace*>(ws), on); };
         b.ckc_stencil_coefficients = wxa_ckc_stencil_coefficients;
         b.ckc_max_dt = wxa_ckc_max_dt;
         b.evolve_b_ckc = [](const wxa_field_view* E, const wxa_field_view* B, double dt, const double* cx, const double* cy,

@@ -43,6 +43,12 @@ wxa_status wxa_workspace_set_external_particle_fields(wxa_workspace* ws, const d
     return WXA_OK;
 }
 
+wxa_status wxa_workspace_set_streaming_plasma(wxa_workspace* ws, int32_t on) {
+    WXA_REQUIRE(ws, "null argument");
+    ws->streaming_plasma = on ? 1 : 0;
+    return WXA_OK;
+}
+
 wxa_status wxa_workspace_set_repeated_plasma_lens(wxa_workspace* ws, const wxa_repeated_plasma_lens* lens) {
     WXA_REQUIRE(ws && lens, "null argument");
     WXA_REQUIRE(lens->n_lenses >= 0, "negative number of lenses");

@@ -51,6 +51,9 @@ struct wxa_workspace {
     int64_t ext_pp_stride = 0;
     // accumulator type of the LDS-tile Esirkepov deposition (wxa_workspace_set_deposit_accumulator)
     int32_t deposit_accumulator = WXA_ACC_FP64;
+    // the container's plasma streams through the grid (wxa_workspace_set_streaming_plasma): the LDS-tile Esirkepov
+    // deposition takes every particle through the wide-frame body inside its loop (deposit_tile.hip, RowsCfg::WL)
+    int32_t streaming_plasma = 0;
     // the cell sort folded into PushPX (push_sort.hpp; wxa_push_sort_begin / _end): what is armed for the pushes between
     // begin and end, and the record a COUNT left for the SCATTER of a later push
     struct PushSortState {
