@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--ppc", type=int, default=2, help="particles per cell per direction")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--fill-steps", type=int, default=0, help="steps before the timed ones (0: until the plasma front has crossed the window)")
-    ap.add_argument("--sort-interval", type=int, default=3)
+    ap.add_argument("--sort-interval", type=int, default=1,
+                    help="a streaming plasma moves 0.76 cells per step: sort every step (305 against 321 ms per step at 3, r5m)")
     args = ap.parse_args()
 
     import torch
