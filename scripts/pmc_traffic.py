@@ -24,7 +24,9 @@ KERNELS = {   # phase -> substring of the kernel name
     "EvolveB": "evolve_b_kernel<wxa::StencilCfg<1, 1, 3, 1",
     "EvolveE": "evolve_e_kernel<wxa::StencilCfg<1, 1, 3, 1",
 }
-bench_args = ["--steps", "6", "--warmup", "1", "--preroll", "40", "--no-cpu-baseline", "--no-phase-pass", "--no-sanity"]
+SORT_INTERVAL = 2   # bench.py's default: the last six pushes are three counting and three scattering ones (push_sort.hpp)
+bench_args = ["--steps", "6", "--warmup", "1", "--preroll", "40", "--sort-interval", str(SORT_INTERVAL), "--no-cpu-baseline",
+              "--no-phase-pass", "--no-sanity"]
 res = {k: {} for k in KERNELS}
 names = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -94,7 +96,7 @@ rec = {
               + "; mean of the last 6 dispatches per kernel, summed over the counter instances (XCDs)",
     "sources_sha16": kernel_sources_sha(),
     "workload": {"ncell": 256, "ppc": 2, "order": 3, "deposition": "esirkepov", "pusher": "boris", "filter": True,
-                 "sort_interval": 3},
+                 "sort_interval": SORT_INTERVAL},
     "correction": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 FETCH_SIZE counts 128-byte requests as 64 "
                   "bytes (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as reported",
     "KiB_per_dispatch": {k: {"kernel": names.get(k, "?"), **v} for k, v in res.items() if len(v) == 2},
