@@ -423,7 +423,8 @@ def test_deposit_current_lds_tiles(oracle, product, order, algo, stale, u_scale)
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
 @pytest.mark.parametrize("drift", [0.0, 2.5])
-def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo, drift):
+@pytest.mark.parametrize("heavy", [None, 1500])
+def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo, drift, heavy, monkeypatch):
     """Cells with more particles than the tile kernel's work items cover (more than 24 in a cell: at 8 per cell on
     average about one cell in a million, i.e. only at the headline size -- found there, round 3, by
     test_direct_vay_ckc_256_against_the_oracle: the overflow list was deposited with the Esirkepov body whatever the
@@ -432,7 +433,11 @@ def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo, d
     24th reach the deposition by index only, unseen by the chunk loop and its range check -- until round 5 their wide
     frame was written to the LDS tile wherever it lay, and a frame outside the tile overwrote the lists next to it in
     LDS (found by the boosted wakefield deck at 8 particles per cell: a density spike, electrons moving a cell per step,
-    a memory fault on the MI355X; reproduced on the CPU execution model with guard pages)."""
+    a memory fault on the MI355X; reproduced on the CPU execution model with guard pages).
+    heavy: WXA_HEAVY_TILE, the particle count beyond which a tile is shared by several workgroups (csrc/heavy_tiles.hpp;
+    32768 by default): at 1500 the tiles of the spike and of the other crowded cells are split into two to four units."""
+    if heavy is not None:
+        monkeypatch.setenv("WXA_HEAVY_TILE", str(heavy))
     ncell = (16, 16, 16)
     _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
     parts = H.random_particles(20000, ncell, 77 + order, u_scale=1.0)
@@ -666,10 +671,15 @@ def test_deposit_current_fp32_tiles(oracle, product, order, u_scale):
                                                    (3, 1, _capi.PUSHER_VAY), (3, 0, _capi.PUSHER_VAY), (2, 1, _capi.PUSHER_VAY),
                                                    (3, 1, _capi.PUSHER_HC), (1, 0, _capi.PUSHER_HC)])
 @pytest.mark.parametrize("stale", [False, True])
-def test_gather_push_lds_tiles(oracle, product, order, galerkin, pusher, stale):
+@pytest.mark.parametrize("heavy", [None, 700])
+def test_gather_push_lds_tiles(oracle, product, order, galerkin, pusher, stale, heavy, monkeypatch):
     """LDS-tile gather (needs a cell sort in the workspace) against the oracle; `stale` moves the
     particles after the sort so that some stencils leave the staged range (global-load path).  Boris, Vay and
-    Higuera-Cary on the tile kernel itself (until round 5 the other pushers met it only through the step tests)."""
+    Higuera-Cary on the tile kernel itself (until round 5 the other pushers met it only through the step tests).
+    heavy: WXA_HEAVY_TILE = 700 shares every tile of more than 700 particles (most of them here: 2000 on average) between
+    several workgroups, each with a part of the tile's particles (csrc/heavy_tiles.hpp)."""
+    if heavy is not None:
+        monkeypatch.setenv("WXA_HEAVY_TILE", str(heavy))
     import torch
     ncell = (24, 20, 16)
     ng, _, _ = H.guard_depths(order)
@@ -730,8 +740,9 @@ def _tile_major_key(pos, ncell, dx, wrap):
     (1, True, 0, True, True, False),       # COUNT and SCATTER in the same push (a sort every step)
     (4, False, 0, False, False, True),     # no tiles at all: the global-memory kernel does everything
     (2, True, 300, False, True, False),
+    (3, True, 700, True, False, "heavy"),  # tiles shared by several workgroups (WXA_HEAVY_TILE): unit 0 counts in LDS, the others globally
 ])
-def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, retire, every_step, predict):
+def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, retire, every_step, predict, monkeypatch):
     """wxa_push_sort_begin / _end (SortParticlesByBin folded into PushPX, csrc/push_sort.hpp): three pushes, the first
     records keys and ranks (COUNT), the second writes the particles into the sorted tile (SCATTER), the third runs on
     that tile through the workspace the SCATTER left.  Against the oracle's plain pushes of the same particles: every
@@ -740,6 +751,9 @@ def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, ret
     carried one time step further in free flight (x + u / gamma dt); retired particles of the record end up behind
     everything and are dropped; particles appended after the COUNT follow the cell-sorted ones in their order."""
     import torch
+    if predict == "heavy":
+        monkeypatch.setenv("WXA_HEAVY_TILE", "900")
+        predict = True
     ncell = (24, 20, 16)
     ng, _, _ = H.guard_depths(order)
     E = H.random_fields(("Ex", "Ey", "Ez"), ncell, ng, 10, scale=1e11)

@@ -20,6 +20,7 @@
 // never depends on the sort being fresh.  DESIGN.md section 3 has the measurements behind each step.
 #include "deposit_body.hpp"
 #include "gather_body.hpp"
+#include "heavy_tiles.hpp"
 #include "workspace.hpp"
 
 #include <stdlib.h>
@@ -263,7 +264,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                          const double* __restrict__ pux_, const double* __restrict__ puy_,
                          const double* __restrict__ puz_, const int* __restrict__ offsets, Geom g_, TileGeom tg, double q_,
                          EsirkepovStep es_, double relative_time_, StragglerQueue sq, FusedArgs fa,
-                         unsigned* __restrict__ tile_ctr) {
+                         unsigned* __restrict__ tile_ctr, HeavyUnits hu) {
     constexpr int NT = CFG::NT, TSZ = CFG::TSZ;
     constexpr bool FUSED = CFG::FUSED != 0;
     static_assert(!FUSED || (O == 3 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && CFG::TSZ == TS && sizeof(typename CFG::ACC) == 8),
@@ -338,6 +339,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     DPROF_INIT
     bool first_tile = true;        // PT: the tile has to be zeroed by phase A (later ones are left zeroed by the flush)
     unsigned xcd_done = 0;         // PT, thread 0: XCD ranges found exhausted
+  int unit_u = 0, unit_k = 1;   // this workgroup takes the chunks ch = unit_u (mod unit_k) of its tile
   for (;;) {
     long unit;
     if constexpr (PT) {
@@ -357,8 +359,8 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         unit = unit_s;
         if (unit < 0) break;
     } else {
-        unit = xcd_tile_id(blockIdx.x, ntiles * SUB);
-        if (unit >= ntiles * SUB) return;
+        // (a tile with far more particles than the others is shared by several workgroups: heavy_tiles.hpp)
+        if (!heavy_unit_of(hu, blockIdx.x, ntiles * SUB, unit, unit_u, unit_k)) return;
     }
     // PT: the launch's uniform doubles are made opaque per tile.  Anything derived from them would otherwise be hoisted
     // out of the tile loop into VGPR pairs (there is no scalar fp64 unit) that stay live through every phase of every
@@ -394,6 +396,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     // Esirkepov's body (until round 3 these particles went there whatever the algorithm: one cell in a million at 8 per
     // cell, seen first at 256^3).  The fused kernel, which pushes in the chunk loop: its own push + deposit list.
     auto defer_unloaded = [&](const int ip, const int bank) {
+        if (unit_u != 0) return;   // a tile shared by several workgroups: what is deferred by index is unit 0's
         if constexpr (FUSED) fa.gq.push(ip);
         else if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT) sq.push(ip);
         else defer(ip, bank);
@@ -582,6 +585,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
 #ifdef WXA_DEPOSIT_PROFILE
     const long long prof_l0 = clock64();
 #endif
+    const int CH0 = unit_u + unit_k * wave, CHS = unit_k * WAVES;   // the chunks of this unit, wave by wave
     const int nregular = NB + ((T + TPC - 1) / TPC);
     const int nchunks = CFG::DBG == 5 ? 0 : nregular + ((excess_pairs + 63) >> 6);   // DBG 5 (timing): the phases around the loop alone
     // DYN: a wave holds the chunk it works on and has already claimed the next one (the counter's round trip through the
@@ -653,18 +657,18 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         }
     };
     if constexpr (PFD != 0) {
-        has_next = wave < nchunks;
-        if (has_next) item_of(wave, nia, nib, nva, nvb);
+        has_next = CH0 < nchunks;
+        if (has_next) item_of(CH0, nia, nib, nva, nvb);
         request_next();
     }
-    for (int ch = CFG::DYN ? __builtin_amdgcn_readfirstlane(__shfl(claimed, 0)) : wave; ch < nchunks;) {   // wave-uniform
+    for (int ch = CFG::DYN ? __builtin_amdgcn_readfirstlane(__shfl(claimed, 0)) : CH0; ch < nchunks;) {   // wave-uniform
         if constexpr (CFG::DYN != 0) claimed = claim();
         int ia, ib;
         bool va, vb;
         if constexpr (PFD != 0) {
             ia = nia; ib = nib; va = nva; vb = nvb;
-            has_next = ch + WAVES < nchunks;
-            if (has_next) item_of(ch + WAVES, nia, nib, nva, nvb);
+            has_next = ch + CHS < nchunks;
+            if (has_next) item_of(ch + CHS, nia, nib, nva, nvb);
         } else {
             item_of(ch, ia, ib, va, vb);
         }
@@ -759,7 +763,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 direct_pair_component<O, 2>(da, db, sjz);
             }
             if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
-            else ch += WAVES;
+            else ch += CHS;
             continue;
         }
         if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT && !DPM) {
@@ -794,12 +798,12 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                         }
             }
             if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
-            else ch += WAVES;
+            else ch += CHS;
             continue;
         }
         if constexpr (CFG::DBG == 4) {   // timing: the loop's items and loads alone
             if (pa.x + pa.y + pa.z + pa.w + pa.ux + pa.uy + pa.uz + pb.x + pb.y + pb.z + pb.w + pb.ux + pb.uy + pb.uz == 1.2345e-300) lds[0] = (ACC)pa.x;
-            ch += WAVES;
+            ch += CHS;
             continue;
         }
         EsirkepovCoords c1 = esirkepov_coords(pa, g, es), c2 = esirkepov_coords(pb, g, es);
@@ -821,7 +825,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 esirkepov_single_wide<O, 2>(cc, f, wq, es, sink);
             }
             if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
-            else ch += WAVES;
+            else ch += CHS;
             continue;
         }
         double wq1 = q * pa.w, wq2 = 0.0;
@@ -863,7 +867,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 esirkepov_single_fast<O, 2>(cc, wq, es, sink);
             }
             if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
-            else ch += WAVES;
+            else ch += CHS;
             continue;
         }
         int key = -1;
@@ -937,7 +941,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         }
 #endif
         if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
-        else ch += WAVES;
+        else ch += CHS;
     }
 #ifdef WXA_DEPOSIT_PROFILE
     if (tid == 0) DCOUNT(9, clock64() - prof_l0);   // wave 0's own time in the loop; the rest of phase 2 is its wait at the barrier
@@ -1128,8 +1132,14 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
     const Geom g = make_geom(*geom);
     const int* offsets = (const int*)ws->offsets.p;
     // persistent tiles: one workgroup per CU (WXA_NUM_CU; more would only queue behind the LDS), tiles through tile_ctr
-    const dim3 grid((unsigned)(CFG::PT ? std::min<long>(xcd_grid_size(nunits), WXA_NUM_CU) : xcd_grid_size(nunits))), block(CFG::NT);
     wxa_status rc;
+    // tiles with far more particles than the others are shared by several workgroups (heavy_tiles.hpp)
+    HeavyUnits hu;
+    long extra_groups = 0;
+    if constexpr (CFG::PT == 0 && CFG::DYN == 0 && CFG::FUSED == 0 && CFG::TSZ == TS) {
+        if ((rc = plan_heavy_tiles(ws, offsets, nunits, (long)p->np, hu, extra_groups, st)) != WXA_OK) return rc;
+    }
+    const dim3 grid((unsigned)(CFG::PT ? std::min<long>(xcd_grid_size(nunits), WXA_NUM_CU) : xcd_grid_size(nunits) + extra_groups)), block(CFG::NT);
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
     if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
     StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
@@ -1139,7 +1149,7 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
     hipLaunchKernelGGL((deposit_tile_rows_kernel<O, MARGIN, CFG>), grid, block, 0, st, JTriple{jx, jy, jz}, p->x, p->y, p->z, p->w,
-                       p->ux, p->uy, p->uz, offsets, g, tg, q, es, relative_time, sq, FusedArgs{}, tile_ctr);
+                       p->ux, p->uy, p->uz, offsets, g, tg, q, es, relative_time, sq, FusedArgs{}, tile_ctr, hu);
     hipLaunchKernelGGL((deposit_stragglers_kernel<O, CFG::ALGO>), dim3(512), dim3(256), 0, st, p->x, p->y,
                        p->z, p->w, p->ux, p->uy, p->uz, sq.idx, sq.count, jx, jy, jz, g, q, es, relative_time);
     WXA_LAUNCH_CHECK();
@@ -1248,7 +1258,7 @@ static wxa_status launch_fused(const wxa_particle_view* p, const wxa_field_view 
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
     hipLaunchKernelGGL((deposit_tile_rows_kernel<3, MARGIN, CFG>), grid, block, 0, st, JTriple{jx, jy, jz}, p->x, p->y, p->z, p->w,
-                       p->ux, p->uy, p->uz, offsets, g, tg, q, es, relative_time, sq, fa, (unsigned*)nullptr);
+                       p->ux, p->uy, p->uz, offsets, g, tg, q, es, relative_time, sq, fa, (unsigned*)nullptr, HeavyUnits{});
     // the particles the tile kernel could not push: global-memory gather + push, then their deposit
     if ((rc = gather_push_listed(p, fa.gq.idx, fa.gq.count, E, B, geom_eb, q, m, dt, CFG::PUSHER, st)) != WXA_OK) return rc;
     hipLaunchKernelGGL((deposit_stragglers_kernel<3, WXA_DEPOSIT_ESIRKEPOV>), dim3(512), dim3(256), 0, st, p->x, p->y,

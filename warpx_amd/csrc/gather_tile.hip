@@ -17,6 +17,7 @@
 // cell per lane sharing the LDS reads, 9.95.  Counters, profiles/round2/r2g_pmc_128cube_gather_tile_kernel.txt: 8 LDS
 // cycles per ds instruction and 0.2 % bank conflicts, the LDS busy 60 % and the VALU 50 % of the kernel's time.)
 #include "gather_body.hpp"
+#include "heavy_tiles.hpp"
 #include "push_sort.hpp"
 #include "workspace.hpp"
 
@@ -143,16 +144,25 @@ template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER
 __global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(G ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext,
-                        PushSort hook) {
+                        PushSort hook, HeavyUnits hu) {
     constexpr int N = GatherTileDims<G>::N;
     constexpr int NPTS = GatherTileDims<G>::NPTS;
     __shared__ double F[6 * NPTS];
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
-    const long tile = xcd_tile_id(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
+    // a tile with far more particles than the others is shared by several workgroups, each with a part of its particles
+    // (heavy_tiles.hpp)
+    long tile;
+    int unit_u, unit_k;
+    if (!heavy_unit_of(hu, blockIdx.x, ntiles, tile, unit_u, unit_k)) return;
     constexpr int TC = GT_TS * GT_TS * GT_TS;
-    const int start = offsets[tile * TC];
-    const int end = offsets[(tile + 1) * TC];
+    int start = offsets[tile * TC];
+    int end = offsets[(tile + 1) * TC];
+    if (unit_k > 1) {   // parts of whole 64-particle chunks
+        const long chunks = ((long)(end - start) + 63) >> 6;
+        const int s0 = start;
+        start = s0 + (int)((chunks * unit_u / unit_k) << 6);
+        end = min(end, s0 + (int)((chunks * (unit_u + 1) / unit_k) << 6));
+    }
     if (end <= start) return;
     const int tid = threadIdx.x;
     GPROF_CLOCK(prof_t0);
@@ -182,7 +192,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     // the sort folded into the push, COUNT alone: ranks from a histogram of the tile's own cells (push_sort.hpp)
     static_assert(GT_THREADS == PUSH_SORT_TILE_CELLS, "one lane per cell of the tile");
     __shared__ int lhist[MOVE ? PUSH_SORT_TILE_CELLS : 1];
-    const bool count_local = MOVE && hook.mode == PUSH_SORT_COUNT;   // uniform
+    const bool count_local = MOVE && hook.mode == PUSH_SORT_COUNT && unit_u == 0;   // uniform (a shared tile: unit 0's histogram)
     if constexpr (MOVE) {
         if (count_local) lhist[tid] = 0;   // visible after the staging barrier below
     }
@@ -414,18 +424,21 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
     const int* offsets = (const int*)ws->offsets.p;
     const DevF ex = make_devf(E[0]), ey = make_devf(E[1]), ez = make_devf(E[2]);
     const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
-    const dim3 grid((unsigned)xcd_grid_size(ntiles)), block(GT_THREADS);
     wxa_status rc;
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
     if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
     GatherStragglers sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p + 16};
     const ExtEB ext = ext_of(ws);
     const PushSort hook = make_push_sort(ws, 0, MOVE);
+    HeavyUnits hu;
+    long extra_groups = 0;
+    if ((rc = plan_heavy_tiles(ws, offsets, ntiles, (long)p->np, hu, extra_groups, st)) != WXA_OK) return rc;
+    const dim3 grid((unsigned)(xcd_grid_size(ntiles) + extra_groups)), block(GT_THREADS);
     WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
 #define WXA_GT(O, G)                                                                                        \
     do {                                                                                                    \
         hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE, PART>), grid, block, 0, st, pv, offsets, ex, \
-                           ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(WXA_STRAGGLER_BLOCKS), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, hook);                     \
     } while (0)
@@ -442,23 +455,23 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
 #define WXA_GT_RB(RBV)                                                                                          \
     do {                                                                                                        \
         if (pf == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 1>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         else if (pf == 2) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 2>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         else if (pf == 3 && slv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 1>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         else if (pf == 3 && stv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 1, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         else if (pf == 3) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         else if (pf == 7) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 7>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         else if (pf == 8) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 8>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         else if (pf == 9) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 9>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         else hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook);                                   \
+                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
         hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, hook);                         \
     } while (0)

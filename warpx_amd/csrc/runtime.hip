@@ -33,7 +33,7 @@ void wxa_workspace_destroy(wxa_workspace* ws) {
     ws->cell.release(); ws->rank.release(); ws->hist.release(); ws->offsets.release();
     ws->scan_tmp.release(); ws->tile_offsets.release(); ws->stragglers.release(); ws->counters.release(); ws->lens_tab.release(); ws->ext_pp.release();
     for (int b = 0; b < 2; ++b) { ws->ps.kr[b].release(); ws->ps.offs[b].release(); ws->ps.own[b].release(); }
-    ws->ps.hist.release();
+    ws->ps.hist.release(); ws->heavy.release();
     delete ws;
 }
 

@@ -31,6 +31,7 @@ struct DevBuf {
 
 struct wxa_workspace {
     wxa::DevBuf cell, rank, hist, offsets, scan_tmp, tile_offsets, stragglers, counters;
+    wxa::DevBuf heavy;   // units per tile and the extra workgroups of the tiles that are split (heavy_tiles.hpp)
     // description of the last cell sort (consumed by the tile-based deposition)
     bool sorted_valid = false;
     int64_t sorted_np = 0;              // particles covered by the tile offsets (live ones after wxa_sort_live_count)
