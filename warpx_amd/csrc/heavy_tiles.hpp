@@ -60,10 +60,15 @@ plan_heavy_tiles_kernel(const int* __restrict__ offsets, long ntiles, int cells_
     kt[t] = k;
 }
 
-// particles a tile may hold before it is split (WXA_HEAVY_TILE: tests set it low; 0 switches the splitting off)
-inline int heavy_tile_threshold() {
-    const char* e = getenv("WXA_HEAVY_TILE");   // read per launch: a test sets it for one case
-    return e ? atoi(e) : 32768;                 // 8 x the uniform plasma's 4096 per tile at 8 per cell
+// Particles a tile may hold before it is split.  On for the workspaces of a streaming plasma (a boosted-frame wake is
+// where the spikes were met: 8192, twice the uniform plasma's 4096 per tile at 8 per cell -- 305 -> 170 ms per step for
+// BASELINE config 5 on one GPU, 235 at 32768) and wherever WXA_HEAVY_TILE says so (read per launch: a test sets it for one
+// case; 0 switches the splitting off).  Off otherwise: the np / heavy + 1 extra workgroups a launch appends exit at once
+// when no tile is heavy, but they cost the uniform-plasma headline 0.07 ms per step (profiles/round5/README.md).
+inline int heavy_tile_threshold(const wxa_workspace* ws) {
+    const char* e = getenv("WXA_HEAVY_TILE");
+    if (e) return atoi(e);
+    return ws->streaming_plasma ? 8192 : 0;
 }
 
 // Plans the units of a launch over `ntiles` tiles of `np` sorted particles; on return `hu` is what the kernel takes and
@@ -72,7 +77,7 @@ inline wxa_status plan_heavy_tiles(wxa_workspace* ws, const int* offsets, long n
                                    hipStream_t st) {
     hu = HeavyUnits{};
     extra_groups = 0;
-    const int heavy = heavy_tile_threshold();
+    const int heavy = heavy_tile_threshold(ws);
     if (heavy <= 0 || np <= heavy) return WXA_OK;   // no tile can be heavy
     const long max_extra = np / heavy + 1;
     wxa_status rc;
