@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round 5, the evidence session at the round's last kernel sources: smoke, the whole -m gpu suite, the PMC passes (traffic
+# Round 5, the evidence session at the round's last kernel sources (after the shared tiles): smoke, the whole -m gpu suite, the PMC passes (traffic
 # + SQ, stamped), the default bench line (with the CPU baseline) as the driver runs it, rocprofv3 --kernel-trace --stats of
 # the same command, the secondary configurations.
 set -u
-OUT=$(pwd)/gpurun_out/r5end
+OUT=$(pwd)/gpurun_out/r5fin
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
