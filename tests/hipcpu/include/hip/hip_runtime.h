@@ -219,6 +219,11 @@ inline double swap_add_halves(const double v_lo_planes, const double v_hi_planes
 inline int partner32(const int v) { return __shfl_xor(v, 32); }
 #define WXA_HAVE_LANE_XOR1
 inline double lane_xor1(const double v) { return __shfl_xor(v, 1); }
+#define WXA_HAVE_WAVE_SUM_F64
+inline double wave_sum_f64(double v) {   // every lane gets the sum (the product reads lane 63)
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
 }
 
 // HIP's unqualified min / max over mixed integer types

@@ -479,16 +479,29 @@ def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo, d
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("streaming", [0, 1])
 @pytest.mark.parametrize("drift", [0.0, 0.8])
-def test_deposit_current_of_a_streaming_plasma(oracle, product, order, streaming, drift):
+@pytest.mark.parametrize("spike", [0, 3000])
+@pytest.mark.parametrize("n", [60000, 160000])
+def test_deposit_current_of_a_streaming_plasma(oracle, product, order, streaming, drift, spike, n):
     """A plasma that streams through the grid (a boosted-frame run: every particle moves 0.76 cells per step against the
     boost, three in four cross a cell) on the LDS tiles, against the oracle: with wxa_workspace_set_streaming_plasma every
     particle goes through the wide-frame body inside the tile loop; without it the crossing particles go through the
     deferred list and, what it cannot take (most of them here), the global-atomics pass -- the same J either way.
-    drift: moved by up to that many cells after the sort."""
+    drift: moved by up to that many cells after the sort.
+    spike: that many particles in ONE cell and a tenth of it in its neighbour (a wake's density spike): with the streaming
+    body the lanes of a wave that share a frame sum every value over the wave before one lane adds it (wave_sum_f64).
+    n: 10 and 26 particles per cell on average; at 26 the pairs beyond a cell's fourth do not fit the tile's tail table and
+    all of them become excess chunks."""
     ncell = (16, 16, 24)
     _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
-    parts = H.random_particles(60000, ncell, 410 + order, u_scale=0.05)
+    parts = H.random_particles(n, ncell, 410 + order, u_scale=0.05)
     dx = H.LX / np.asarray(ncell)
+    if spike:
+        rng = np.random.default_rng(77)
+        crowd = []
+        for cell, count in (((5, 9, 11), spike), ((6, 9, 11), spike // 10), ((12, 3, 17), 150)):
+            pos = [-H.LX / 2 + (cell[d] + rng.random(count)) * dx[d] for d in range(3)]
+            crowd.append(pos + [1e9 * (0.5 + rng.random(count))] + [0.05 * plasma.C_LIGHT * rng.standard_normal(count) for _ in range(3)])
+        parts = [np.concatenate([parts[r]] + [c[r] for c in crowd]) for r in range(7)]
     dt = H.yee_dt(dx)
     beta = 0.76 * dx[2] / (plasma.C_LIGHT * dt)           # v dt = 0.76 dz along -z
     beta = min(beta, 0.98)

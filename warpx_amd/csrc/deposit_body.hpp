@@ -580,6 +580,41 @@ __device__ __forceinline__ void esirkepov_single_wide(const EsirkepovCoords& cc,
     }
 }
 
+// The sum of v over the wave's 64 lanes, valid in lanes 48 .. 63: six DPP steps (lane ^ 1, lane ^ 2, mirror of 8, mirror of
+// 16 -- every lane of a row of 16 then holds its row's sum -- lane 15 of the row before, lane 31), i.e. twelve v_mov_dpp
+// and six v_add_f64 on the VALU, nothing on the LDS pipe.  Rows 0 .. 2 end with partial sums (the broadcasts go to every
+// row, so no `old` operand has to be zeroed).  For waves whose lanes all deposit on the SAME points (the cells of a wake's
+// density spike hold 10^3 .. 10^5 particles): a ds_add_f64 whose 64 lanes share an address is served lane by lane, on the
+// one LDS pipe of the CU.
+#ifndef WXA_HAVE_WAVE_SUM_F64   // tests/hipcpu: wave shuffles
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#define WXA_DPP_ADD(ctrl)                                                                      \
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true),   \
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true))
+    WXA_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]
+    WXA_DPP_ADD(0x4E);    // quad_perm [2, 3, 0, 1]
+    WXA_DPP_ADD(0x141);   // row_half_mirror
+    WXA_DPP_ADD(0x140);   // row_mirror
+    WXA_DPP_ADD(0x142);   // row_bcast:15: row r += the sum of row r - 1
+    WXA_DPP_ADD(0x143);   // row_bcast:31: rows 2, 3 += rows 0 + 1 (lane 31)
+#undef WXA_DPP_ADD
+    return v;
+}
+#endif
+// LdsSink for a wave whose lanes share the frame: every value is summed over the wave, lane 63 adds it
+template <class Sink>
+struct WaveSumSink {
+    Sink inner;
+    bool last;
+    __device__ __forceinline__ WaveSumSink(const Sink& s, bool is_last_lane) : inner(s), last(is_last_lane) {}
+    __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
+        const double s = wave_sum_f64(v);
+        if (last) inner.add(c, i, j, k, s);
+        // one value after the other: left to itself the scheduler interleaves all the frame's sums and spills
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
 // One component of one particle that stays in its cell, on its own fast frame (slot 0 = the frame's first point, weights on
 // slots 1 .. O+1, like the pair body above with an empty partner): (O+1)^2 rows of O deposits.  Phase D of the tile kernel
 // for particles that could not be merged with their lane partner.

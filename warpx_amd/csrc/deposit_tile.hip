@@ -323,6 +323,11 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     constexpr bool XCH = !FUSED && CFG::HF == 0 && CFG::TI == 0 && CFG::COOP == 0;
     __shared__ int xs[XCH ? CELLS + 1 : 1];
     __shared__ int any_excess;
+    // ... and a tile whose pairs beyond the fourth do not fit the tail table (a compressed plasma: 16 particles per cell
+    // on average fill its 1024 entries) keeps no tail at all: every pair beyond a cell's fourth is an excess pair.  (What
+    // the table could not take used to go to the deferred list and on to the global-atomics pass: 12 % of the particles
+    // of the boosted wakefield deck, 41 ms per launch, profiles/round5/README.md.)
+    __shared__ int tail_off;
     // ... and their data, for the first DKEEP entries of every bucket: phase C has the particle in registers when it
     // defers it; fetched again by index in phase D each one costs seven cache lines from HBM (the tile's lines have left
     // the L2 by then: FETCH_SIZE 1.57 x the particle data, phase D 12 % of the kernel for 3 % of the particles)
@@ -417,7 +422,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     };
     constexpr int WAVES = NT / 64;
     // ---- A: cell counts, row masks; zero fill
-    if (tid == 0) { nitems = 0; next_chunk = 0; any_excess = 0; }
+    if (tid == 0) { nitems = 0; next_chunk = 0; any_excess = 0; tail_off = 0; }
     if (tid < NBKT) ndef[tid] = 0;
     int my_s = 0, my_n = 0, my_pairs = 0;
     unsigned long long my_mask[RT];   // wave-uniform: tail row r of this cell-wave
@@ -535,12 +540,13 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         }
         const int excl = incl - cnt;
         const int total = __shfl(incl, 63);
-        if (tid == 0) nitems = min(total, TCAP);
+        const bool no_tail = XCH && total > TCAP;   // the same in every wave
+        if (tid == 0) { nitems = no_tail ? 0 : min(total, TCAP); tail_off = no_tail; }
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int base = __shfl(excl, CFG::TI ? wave * RT + r : r * CW + wave);   // first item of (tail row r, this cell-wave)
-            if (my_pairs > 4 + r) {
+            if (my_pairs > 4 + r && !no_tail) {
                 const int at = base + __popcll(my_mask[r] & lt);
                 if (at < TCAP) table[at] = (unsigned short)(tid | ((4 + r) << 9));
                 else {   // any bucket is correct; the cell's place in the sort order is the bank of a particle that stayed
@@ -551,16 +557,17 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         }
         // beyond the table's rows (> 2 RMAX particles in a cell): chunks of their own (XCH), or one by one to the lists
         if constexpr (XCH) {
-            if (my_n > 2 * RMAX) any_excess = 1;
+            if (my_n > 2 * (no_tail ? 4 : RMAX)) any_excess = 1;
         } else {
             for (int k = 2 * RMAX; k < my_n; ++k) defer_unloaded(my_s + k, tid & (NBANK - 1));
         }
     }
     __syncthreads();
     int excess_pairs = 0;
+    const int rmax_t = XCH && __builtin_amdgcn_readfirstlane(tail_off) ? 4 : RMAX;   // pairs of a cell that the direct chunks and the tail table cover
     if constexpr (XCH) {
         if (any_excess) {   // uniform
-            if (tid < CELLS) xs[tid] = (max(0, my_n - 2 * RMAX) + 1) >> 1;
+            if (tid < CELLS) xs[tid] = (max(0, my_n - 2 * rmax_t) + 1) >> 1;
             __syncthreads();
             if (tid == 0) {
                 int acc = 0;
@@ -568,7 +575,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                 xs[CELLS] = acc;
             }
             __syncthreads();
-            excess_pairs = xs[CELLS];
+            excess_pairs = __builtin_amdgcn_readfirstlane(xs[CELLS]);
         }
     }
     DPROF(1);
@@ -621,7 +628,13 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             const unsigned ent = va ? table[I] : 0u;
             c = (int)(ent & 511u); r = (int)(ent >> 9);
         } else {   // pair I of the cells' excess: the cell whose running sum holds it, xs[c] <= I < xs[c + 1]
-            const int I = ((ch - nregular) << 6) + lane;
+            // Lane (r, s) = (lane / 16, lane % 16) of excess chunk j takes pair 4 j + r of stream s, the streams being
+            // sixteen equal ranges of the excess pairs: the 16 lanes that a step of a ds_add_f64 serves sit in sixteen
+            // different parts of the tile (consecutive pairs -- one cell, one frame, 64 lanes on the same addresses --
+            // made the excess chunks of a dense tile several times slower than its other chunks), and every stream
+            // still reads four neighbouring pairs = 64 contiguous bytes per array.
+            const int nexc = (excess_pairs + 63) >> 6;
+            const int I = (lane & 15) * (4 * nexc) + 4 * (ch - nregular) + (lane >> 4);
             va = I < excess_pairs;
             int lo = 0, hi = CELLS;
             if constexpr (XCH) {
@@ -630,7 +643,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                     const int mid = (lo + hi) >> 1;
                     if (xs[mid] <= J) lo = mid; else hi = mid;
                 }
-                r = RMAX + (J - xs[lo]);
+                r = rmax_t + (J - xs[lo]);
             } else {
                 r = 0;
             }
@@ -808,21 +821,48 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         }
         EsirkepovCoords c1 = esirkepov_coords(pa, g, es), c2 = esirkepov_coords(pb, g, es);
         if constexpr (CFG::WL != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV && !FUSED) {
+            // The chunks of the cells' excess pairs (a density spike: 10^3 .. 10^5 particles in a cell) are 64 lanes on one or
+            // two cells: the lanes that share a frame -- hu.wave_sum_min or more of them -- sum every value over the wave
+            // (wave_sum_f64, VALU only) and one lane adds it, instead of 64 lanes adding to one LDS address one after
+            // the other.  Wave-uniform control flow throughout: every lane computes, with weight 0 where it has no part.
+            const bool crowded = XCH && ch >= nregular;   // wave-uniform
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) {
-                if (!(h ? vb : va)) continue;
+                const bool valid = h ? vb : va;
                 const EsirkepovCoords cc = h ? c2 : c1;
                 const WideFrame<O> f = esirkepov_wide_frame<O>(cc, g);
                 const int wi = f.b[0] - o0, wj = f.b[1] - o1, wk = f.b[2] - o2;
-                if (!(wi >= 0 && wj >= 0 && wk >= 0 && wi + O + 2 <= N && wj + O + 2 <= N && wk + O + 2 <= NZ)) {
-                    sq.push(h ? ib : ia);   // the frame leaves the tile: the global-atomics pass
-                    continue;
-                }
-                LdsSink<M, TSZ, ACC> sink(lds, wi, wj, wk);
+                const bool fits = wi >= 0 && wj >= 0 && wk >= 0 && wi + O + 2 <= N && wj + O + 2 <= N && wk + O + 2 <= NZ;
+                if (valid && !fits) sq.push(h ? ib : ia);   // the frame leaves the tile: the global-atomics pass
+                bool on = valid && fits;
                 const double wq = q * (h ? pb.w : pa.w);
-                esirkepov_single_wide<O, 0>(cc, f, wq, es, sink);
-                esirkepov_single_wide<O, 1>(cc, f, wq, es, sink);
-                esirkepov_single_wide<O, 2>(cc, f, wq, es, sink);
+                if (crowded) {
+                    const int key = on ? (wi | (wj << 8) | (wk << 16)) : -1;
+                    unsigned long long rest = __ballot(on);
+                    while (rest) {   // one trip per large group; the first small one ends the search
+                        const int k0 = __shfl(key, __ffsll((long long)rest) - 1);
+                        const bool same = on && key == k0;
+                        const unsigned long long group = __ballot(same);
+                        rest &= ~group;
+                        if (__popcll(group) < hu.wave_sum_min) break;
+                        WaveSumSink<LdsSink<M, TSZ, ACC>> sink(LdsSink<M, TSZ, ACC>(lds, k0 & 255, (k0 >> 8) & 255, k0 >> 16), lane == 63);
+                        const double wqs = same ? wq : 0.0;
+                        // (its own copy of the coordinates: the weights are not to be kept for the lane's own pass below)
+                        EsirkepovCoords cr = cc;
+                        WXA_OPAQUE_F64(cr.x_new); WXA_OPAQUE_F64(cr.y_new); WXA_OPAQUE_F64(cr.z_new);
+                        WXA_OPAQUE_F64(cr.x_old); WXA_OPAQUE_F64(cr.y_old); WXA_OPAQUE_F64(cr.z_old);
+                        esirkepov_single_wide<O, 0>(cr, f, wqs, es, sink);
+                        esirkepov_single_wide<O, 1>(cr, f, wqs, es, sink);
+                        esirkepov_single_wide<O, 2>(cr, f, wqs, es, sink);
+                        on = on && !same;
+                    }
+                }
+                if (on) {
+                    LdsSink<M, TSZ, ACC> sink(lds, wi, wj, wk);
+                    esirkepov_single_wide<O, 0>(cc, f, wq, es, sink);
+                    esirkepov_single_wide<O, 1>(cc, f, wq, es, sink);
+                    esirkepov_single_wide<O, 2>(cc, f, wq, es, sink);
+                }
             }
             if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
             else ch += CHS;

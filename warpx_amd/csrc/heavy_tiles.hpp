@@ -23,6 +23,9 @@ struct HeavyUnits {
     const int* __restrict__ extra = nullptr;    // (tile, unit) of the extra workgroups, two ints each
     const unsigned* __restrict__ nextra = nullptr;
     long grid_tiles = 0;                        // workgroups of the regular grid (xcd_grid_size(ntiles)); extras follow
+    // streaming deposition: lanes of a wave that share a frame sum their values over the wave first when there are at
+    // least this many of them (deposit_tile.hip; WXA_WAVE_SUM_MIN, read per launch; 65: never)
+    int wave_sum_min = 16;
 };
 
 // the workgroup's tile and its share (u of k); false: nothing to do
@@ -77,6 +80,7 @@ inline wxa_status plan_heavy_tiles(wxa_workspace* ws, const int* offsets, long n
                                    hipStream_t st) {
     hu = HeavyUnits{};
     extra_groups = 0;
+    if (const char* e = getenv("WXA_WAVE_SUM_MIN")) hu.wave_sum_min = atoi(e);
     const int heavy = heavy_tile_threshold(ws);
     if (heavy <= 0 || np <= heavy) return WXA_OK;   // no tile can be heavy
     const long max_extra = np / heavy + 1;
