@@ -145,11 +145,12 @@ def test_filter_bit_exact(oracle, product):
 
 
 @pytest.mark.parametrize("name,lens", [("Ex", (1, 1, 5)), ("Bz", (1, 1, 5)), ("Ey", (2, 2, 2)), ("Bx", (3, 1, 4))])
-def test_filter_stencil_bit_exact(oracle, product, name, lens):
+@pytest.mark.parametrize("ncell", [(20, 12, 28), (9, 5, 131)])
+def test_filter_stencil_bit_exact(oracle, product, name, lens, ncell):
     """wxa_filter_stencil (Filter::DoFilter with any half stencils): the NCI corrector's 1 x 1 x 5 Godfrey stencil from
     wxa_nci_godfrey_stencil, the bilinear filter's 2 x 2 x 2 through the generic kernel, and an odd mix -- bit for bit
     against the CPU restatement (same loop and term order, no contraction)."""
-    (src,) = H.random_fields((name,), (20, 12, 28), 4, 51)
+    (src,) = H.random_fields((name,), ncell, 4, 51)   # (131 + guards along z: five segments of the 1 x 1 x 5 kernel's march)
     dst = src.like()
     srcd, dstd = src.copy_to(DEV, True), src.like(DEV, True)
     rng = np.random.default_rng(3)

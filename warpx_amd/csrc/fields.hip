@@ -824,6 +824,44 @@ filter_stencil_kernel(DevF src, DevF dst, FilterStencils fs) {
     }
 }
 
+// The same for stencil lengths (1, 1, N2) -- the NCI corrector's Godfrey filter, six fields per species and step of a
+// boosted-frame run: a lane marches KC points up its column with the 2 N2 - 1 values it needs in registers, so that every
+// point is read once (+ 2 (N2 - 1) / KC at the segment ends) instead of 2 N2 - 1 times through the caches (0.90 ms per field at
+// 256 x 256 x 512, 7 % of the HBM rate: 5.4 of BASELINE config 5's 94 ms per step, profiles/round5/README.md).  The
+// arithmetic is the generic kernel's, term by term: with i0 = i1 = 0 the eight mirrored taps are the point below four
+// times and the point above four times, summed left to right.
+template <int N2, int KC>
+__global__ void __launch_bounds__(256)
+filter_stencil_z_kernel(DevF src, DevF dst, FilterStencils fs) {
+    const long columns = (long)src.n0 * src.n1;
+    const int nseg = (src.n2 + KC - 1) / KC;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= columns * nseg) return;
+    const int i = src.lo0 + (int)(t % src.n0);
+    const int j = src.lo1 + (int)((t / src.n0) % src.n1);
+    const int k0 = src.lo2 + (int)(t / columns) * KC, k1 = min(k0 + KC, src.lo2 + src.n2);
+    auto zp = [&](int kk) -> double { return (kk >= src.lo2 && kk < src.lo2 + src.n2) ? src.p[src.off(i, j, kk)] : 0.0; };
+    double w[2 * N2 - 1];   // w[m] = the value at k - (N2 - 1) + m
+#pragma unroll
+    for (int m = 0; m < 2 * N2 - 1; ++m) w[m] = zp(k0 - (N2 - 1) + m);
+    double sss[N2];
+#pragma unroll
+    for (int i2 = 0; i2 < N2; ++i2) sss[i2] = fs.s[0][0] * fs.s[1][0] * fs.s[2][i2];
+    for (int k = k0; k < k1; ++k) {
+        const double next = zp(k + N2);
+        double d = 0.0;
+#pragma unroll
+        for (int i2 = 0; i2 < N2; ++i2) {
+            const double a = w[N2 - 1 - i2], b = w[N2 - 1 + i2];
+            d += sss[i2] * (a + a + a + a + b + b + b + b);
+        }
+        dst.p[dst.off(i, j, k)] = d;
+#pragma unroll
+        for (int m = 0; m + 1 < 2 * N2 - 1; ++m) w[m] = w[m + 1];
+        w[2 * N2 - 2] = next;
+    }
+}
+
 template <class CFG>
 __global__ void __launch_bounds__(CFG::NT)
 filter_bilinear_kernel(DevF src, DevF dst, TileGrid tg) {
@@ -1124,6 +1162,14 @@ wxa_status wxa_filter_stencil(const wxa_field_view* src, const wxa_field_view* d
     }
     const long total = (long)src->n[0] * src->n[1] * src->n[2];
     if (total == 0) return WXA_OK;
+    if (n0 == 1 && n1 == 1 && n2 == 5) {   // the Godfrey stencil
+        constexpr int KC = 32;
+        const long lanes = (long)src->n[0] * src->n[1] * ((src->n[2] + KC - 1) / KC);
+        hipLaunchKernelGGL((filter_stencil_z_kernel<5, KC>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, make_devf(*src), make_devf(*dst), fs);
+        WXA_LAUNCH_CHECK();
+        return WXA_OK;
+    }
     hipLaunchKernelGGL(filter_stencil_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(*src),
                        make_devf(*dst), fs);
     WXA_LAUNCH_CHECK();

@@ -232,6 +232,7 @@ public:
         // passes of its own, for A/B timing and for bisecting
         const char* fold = std::getenv("WXA_SORT_IN_PUSH");
         m_ctx.sort_in_push = sort_intervals > 0 && !(fold && std::atoi(fold) == 0);
+        if (const char* e = std::getenv("WXA_SORT_BEHIND_SHIFT")) m_ctx.skip_sort_behind_a_window_shift = std::atoi(e) == 0;
         for (int d = 0; d < 3; ++d) m_ctx.sort_wrap[d] = m_comm->periodic(d) && m_comm->self_periodic(d) ? 1 : 0;
         // the keys of the positions behind the scattering push (free flight over its time step): the deposition of the sort
         // step and the next gather meet a fresh sort.  WXA_SORT_PREDICT=0: the keys of the positions in front of it.
@@ -418,7 +419,10 @@ public:
         }
         // every particle's cell index along the window moved with the domain: the tile-major order of the
         // last sort no longer lines up with the tiles, so sort now instead of at the next interval
-        if (sort_intervals > 0) mypc->SortParticlesByBin(amrex::IntVect(1));
+        if (sort_intervals > 0) {
+            mypc->SortParticlesByBin(amrex::IntVect(1));
+            for (int i = 0; i < mypc->nContainers(); ++i) mypc->GetParticleContainer(i).m_sorted_by_window_shift = true;
+        }
         return num_shift_base;
     }
 

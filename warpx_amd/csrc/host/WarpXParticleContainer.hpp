@@ -36,6 +36,7 @@ struct WarpXContext {
     bool sort_now = false;             // this step re-sorts the tiles (sort_intervals)
     bool count_now = false;            // the next step does: this step's push records the sort keys (sort_in_push)
     bool sort_intervals_on = false;    // warpx.sort_intervals > 0
+    bool skip_sort_behind_a_window_shift = true;   // WXA_SORT_BEHIND_SHIFT=1 switches the skipping off (A/B runs)
     bool sort_in_push = false;         // the periodic sorts are folded into PushPX (wxa_push_sort_begin, include/warpx_amd.h)
     int32_t sort_wrap[3] = {0, 0, 0};  // directions along which this brick is its own periodic neighbour
     double sort_predict_dt = 0.0;      // the recorded keys are those of the positions one free-flight step ahead (0: of the positions)
@@ -538,6 +539,13 @@ protected:
     int32_t m_push_sort_mode = 0;      // WXA_PUSH_SORT_* armed for this step's push (ArmPushSort)
     int64_t m_count_nretired = 0;      // retired particles in the tile when the last COUNT was taken
     int32_t m_steps_since_sort = -1;   // Redistribute calls since the last cell sort (-1: never sorted)
+public:
+    // The window shift behind the last push has sorted the tile (WarpX::MoveWindow): this step's periodic sort -- between
+    // push and deposition, one push later -- would find the order that the folded sort delivers anyway (the cell order of
+    // the positions before the push) and is skipped.  A window that moves every step sorted twice per step at
+    // warpx.sort_intervals = 1: 8.4 of BASELINE config 5's 94 ms per step on one GPU (profiles/round5/README.md).
+    bool m_sorted_by_window_shift = false;
+protected:
     void* m_ws = nullptr;
     bool m_do_crr = false;
     bool m_time_dependent_ext = false;   // an external field on the particles that depends on the time (boosted lens)
@@ -743,7 +751,9 @@ public:
         {
             PhaseTimer t(m_ctx, kRedistribute);
             const bool sorted_by_the_push = FinishPushSort();
-            if (m_ctx->sort_now && !sorted_by_the_push) SortParticlesByBin(amrex::IntVect(1));
+            const bool fresh = m_sorted_by_window_shift && m_ctx->skip_sort_behind_a_window_shift;
+            m_sorted_by_window_shift = false;
+            if (m_ctx->sort_now && !sorted_by_the_push && !fresh) SortParticlesByBin(amrex::IntVect(1));
         }
         if (!skip_deposition) {
             PhaseTimer t(m_ctx, kCurrentDeposition);  // "...::DepositCurrent::CurrentDeposition"
