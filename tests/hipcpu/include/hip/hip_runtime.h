@@ -134,6 +134,8 @@ inline unsigned long long __ballot(int pred) {
     return r;
 }
 inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred); }
+inline int __any(int pred) { return __ballot(pred) != 0ull; }
+inline int __all(int pred) { return __ballot(!pred) == 0ull; }
 
 template <class T> inline T __shfl(T var, int src, int width = 64) {
     uint64_t mask; int lane;

@@ -857,6 +857,10 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                         on = on && !same;
                     }
                 }
+                // (A body that is wide along z only -- 4 x 4 x 5 points, 184 values instead of 300, for particles that stay in
+                // their cell in x and y -- was measured and dropped: inside the wake the laser shakes every particle across
+                // x, the deferred list overflowed with the crossing ones (61 -> 472 ms per launch for BASELINE config 5), and
+                // chosen wave by wave it changed nothing (60.9 ms): profiles/round5/README.md, sessions t and u.)
                 if (on) {
                     LdsSink<M, TSZ, ACC> sink(lds, wi, wj, wk);
                     esirkepov_single_wide<O, 0>(cc, f, wq, es, sink);
