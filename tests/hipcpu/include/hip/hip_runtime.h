@@ -199,6 +199,7 @@ template <class G, class L> inline void __builtin_amdgcn_global_load_lds(G, L, i
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // used on wave-uniform values only
 #define WXA_OPAQUE_F64(v) asm volatile("" : "+x"(v))
+#define WXA_OPAQUE_I32(v) asm volatile("" : "+r"(v))
 #define WXA_WAVES_PER_SIMD(n)
 #define WXA_LATE_KERNARG(T, first_param) (&(first_param))
 #define WXA_OPAQUE_UNIFORM_F64(v)

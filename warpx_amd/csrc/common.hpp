@@ -12,6 +12,7 @@
 // deliberate second evaluation with the first one).  tests/hipcpu defines its own for the host compiler.
 #ifndef WXA_OPAQUE_F64
 #define WXA_OPAQUE_F64(v) asm volatile("" : "+v"(v))
+#define WXA_OPAQUE_I32(v) asm volatile("" : "+v"(v))
 #endif
 
 // Register budget of a kernel as waves per SIMD (512 VGPRs per lane and SIMD: 4 -> 128, 3 -> 168 VGPRs)

@@ -580,6 +580,96 @@ __device__ __forceinline__ void esirkepov_single_wide(const EsirkepovCoords& cc,
     }
 }
 
+// A wide frame in four registers instead of fifteen: the new reference nodes and the six offset flags (slot 0, the old nodes
+// and the offsets follow from them).  The streaming loop of the tile kernel keeps its two particles' frames in this form
+// and unpacks them component by component.
+struct PackedWideFrame {
+    int jn[3];
+    int bits;   // bit d: sn[d], bit 3 + d: so[d]
+};
+template <int O>
+__device__ __forceinline__ PackedWideFrame pack_wide_frame(const WideFrame<O>& f) {
+    PackedWideFrame p;
+    p.bits = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        p.jn[d] = f.jn[d];
+        p.bits |= (f.sn[d] << d) | (f.so[d] << (3 + d));
+    }
+    return p;
+}
+template <int O>
+__device__ __forceinline__ WideFrame<O> unpack_wide_frame(const PackedWideFrame& p, const Geom& g) {
+    WideFrame<O> f;
+    const int lo[3] = {g.lo0, g.lo1, g.lo2};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        f.jn[d] = p.jn[d];
+        f.sn[d] = (p.bits >> d) & 1; f.so[d] = (p.bits >> (3 + d)) & 1;
+        const int jm = f.jn[d] - f.sn[d];
+        f.jo[d] = jm + f.so[d];
+        f.b[d] = lo[d] + (O >= 2 ? jm - 1 : jm);
+    }
+    return f;
+}
+
+// esirkepov_single_wide for two particles whose wide frames start at the same point (both frames' slot 0; the offsets of the
+// old and new weights inside the frame are each particle's own): every point receives the sum of the two values, half the
+// LDS atomics per particle.  wq2 = 0: particle 1 alone (particle 2's weights are computed and multiplied away).
+template <int O, int COMP, class Sink>
+__device__ __forceinline__ void esirkepov_pair_wide(const EsirkepovCoords& c1, const WideFrame<O>& f1, const double wq1,
+                                                    const EsirkepovCoords& c2, const WideFrame<O>& f2, const double wq2,
+                                                    const EsirkepovStep& es, Sink& sink) {
+    constexpr int NW = O + 2;
+    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
+    auto wide = [&](const EsirkepovCoords& cc, const WideFrame<O>& f, double (&wn)[NW], double (&wo)[NW], const int d) {
+        const double xn = d == 0 ? cc.x_new : d == 1 ? cc.y_new : cc.z_new, xo = d == 0 ? cc.x_old : d == 1 ? cc.y_old : cc.z_old;
+        double n[O + 1], o[O + 1];
+        bspline_weights<O, true>(n, xn, f.jn[d]);
+        bspline_weights<O, true>(o, xo, f.jo[d]);
+#pragma unroll
+        for (int a = 0; a < NW; ++a) {
+            const double n0 = a <= O ? n[a < O + 1 ? a : O] : 0.0, n1 = a >= 1 ? n[a - 1 < 0 ? 0 : a - 1] : 0.0;
+            const double o0 = a <= O ? o[a < O + 1 ? a : O] : 0.0, o1 = a >= 1 ? o[a - 1 < 0 ? 0 : a - 1] : 0.0;
+            wn[a] = f.sn[d] ? n1 : n0;
+            wo[a] = f.so[d] ? o1 : o0;
+        }
+    };
+    constexpr int dl = COMP, da = COMP == 0 ? 1 : 0, db = COMP == 2 ? 1 : 2;   // longitudinal, inner and outer transverse
+    double D1[O + 1], D2[O + 1];
+    auto running = [&](const EsirkepovCoords& cc, const WideFrame<O>& f, const double wq, double (&D)[O + 1]) {
+        double ln[NW], lo_[NW];
+        wide(cc, f, ln, lo_, dl);
+        double r = 0.0;
+#pragma unroll
+        for (int l = 0; l <= O; ++l) {
+            r += wq * es.invdtd[COMP] * sub_rn(lo_[l], ln[l]);
+            D[l] = r;
+        }
+    };
+    running(c1, f1, wq1, D1);
+    running(c2, f2, wq2, D2);
+    double a1n[NW], a1o[NW], b1n[NW], b1o[NW], a2n[NW], a2o[NW], b2n[NW], b2o[NW];
+    wide(c1, f1, a1n, a1o, da); wide(c1, f1, b1n, b1o, db);
+    wide(c2, f2, a2n, a2o, da); wide(c2, f2, b2n, b2o, db);
+#pragma unroll
+    for (int b = 0; b < NW; ++b) {
+        const double P1 = one_third * b1n[b] + one_sixth * b1o[b], Q1 = one_third * b1o[b] + one_sixth * b1n[b];
+        const double P2 = one_third * b2n[b] + one_sixth * b2o[b], Q2 = one_third * b2o[b] + one_sixth * b2n[b];
+#pragma unroll
+        for (int a = 0; a < NW; ++a) {
+            const double T1 = a1n[a] * P1 + a1o[a] * Q1, T2 = a2n[a] * P2 + a2o[a] * Q2;
+#pragma unroll
+            for (int l = 0; l <= O; ++l) {
+                const double v = D1[l] * T1 + D2[l] * T2;
+                if constexpr (COMP == 0) sink.add(0, l, a, b, v);
+                else if constexpr (COMP == 1) sink.add(1, a, l, b, v);
+                else sink.add(2, a, b, l, v);
+            }
+        }
+    }
+}
+
 // The sum of v over the wave's 64 lanes, valid in lanes 48 .. 63: six DPP steps (lane ^ 1, lane ^ 2, mirror of 8, mirror of
 // 16 -- every lane of a row of 16 then holds its row's sum -- lane 15 of the row before, lane 31), i.e. twelve v_mov_dpp
 // and six v_add_f64 on the VALU, nothing on the LDS pipe.  Rows 0 .. 2 end with partial sums (the broadcasts go to every

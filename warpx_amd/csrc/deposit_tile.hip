@@ -826,18 +826,23 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             // (wave_sum_f64, VALU only) and one lane adds it, instead of 64 lanes adding to one LDS address one after
             // the other.  Wave-uniform control flow throughout: every lane computes, with weight 0 where it has no part.
             const bool crowded = XCH && ch >= nregular;   // wave-uniform
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                const bool valid = h ? vb : va;
-                const EsirkepovCoords cc = h ? c2 : c1;
-                const WideFrame<O> f = esirkepov_wide_frame<O>(cc, g);
+            const WideFrame<O> fa = esirkepov_wide_frame<O>(c1, g), fb = esirkepov_wide_frame<O>(c2, g);
+            auto fits = [&](const WideFrame<O>& f) {
                 const int wi = f.b[0] - o0, wj = f.b[1] - o1, wk = f.b[2] - o2;
-                const bool fits = wi >= 0 && wj >= 0 && wk >= 0 && wi + O + 2 <= N && wj + O + 2 <= N && wk + O + 2 <= NZ;
-                if (valid && !fits) sq.push(h ? ib : ia);   // the frame leaves the tile: the global-atomics pass
-                bool on = valid && fits;
-                const double wq = q * (h ? pb.w : pa.w);
-                if (crowded) {
-                    const int key = on ? (wi | (wj << 8) | (wk << 16)) : -1;
+                return wi >= 0 && wj >= 0 && wk >= 0 && wi + O + 2 <= N && wj + O + 2 <= N && wk + O + 2 <= NZ;
+            };
+            bool on_a = va && fits(fa), on_b = vb && fits(fb);
+            if (va && !on_a) sq.push(ia);   // the frame leaves the tile: the global-atomics pass
+            if (vb && !on_b) sq.push(ib);
+            const double wqa = q * pa.w, wqb = q * pb.w;
+            if (crowded) {
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    const EsirkepovCoords cc = h ? c2 : c1;
+                    const WideFrame<O> f = h ? fb : fa;
+                    bool on = h ? on_b : on_a;
+                    const double wq = h ? wqb : wqa;
+                    const int key = on ? ((f.b[0] - o0) | ((f.b[1] - o1) << 8) | ((f.b[2] - o2) << 16)) : -1;
                     unsigned long long rest = __ballot(on);
                     while (rest) {   // one trip per large group; the first small one ends the search
                         const int k0 = __shfl(key, __ffsll((long long)rest) - 1);
@@ -856,17 +861,50 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
                         esirkepov_single_wide<O, 2>(cr, f, wqs, es, sink);
                         on = on && !same;
                     }
+                    if (h) on_b = on; else on_a = on;
                 }
-                // (A body that is wide along z only -- 4 x 4 x 5 points, 184 values instead of 300, for particles that stay in
-                // their cell in x and y -- was measured and dropped: inside the wake the laser shakes every particle across
-                // x, the deferred list overflowed with the crossing ones (61 -> 472 ms per launch for BASELINE config 5), and
-                // chosen wave by wave it changed nothing (60.9 ms): profiles/round5/README.md, sessions t and u.)
-                if (on) {
-                    LdsSink<M, TSZ, ACC> sink(lds, wi, wj, wk);
-                    esirkepov_single_wide<O, 0>(cc, f, wq, es, sink);
-                    esirkepov_single_wide<O, 1>(cc, f, wq, es, sink);
-                    esirkepov_single_wide<O, 2>(cc, f, wq, es, sink);
-                }
+            }
+            // The lane's two particles come from one cell; where their wide frames start at the same point -- the stream
+            // runs one way, so they mostly do -- every point takes the sum of the two values: 150 LDS atomics per particle
+            // instead of 300 (the LDS array is what this kernel waits for: 73 % busy, the fp64 VALU 14 %,
+            // profiles/round5/README.md).  Without a partner on its frame, particle a goes through the same body alone.
+            // (A body that is wide along z only -- 4 x 4 x 5 points, 184 values instead of 300, for particles that stay in
+            // their cell in x and y -- was measured and dropped: inside the wake the laser shakes every particle across
+            // x, the deferred list overflowed with the crossing ones (61 -> 472 ms per launch for BASELINE config 5), and
+            // chosen wave by wave it changed nothing (60.9 ms): sessions t and u.)
+            const bool merged = on_a && on_b && fa.b[0] == fb.b[0] && fa.b[1] == fb.b[1] && fa.b[2] == fb.b[2];
+            // (the frames packed, and unpacked again for every component behind a fence: registers)
+            PackedWideFrame qa = pack_wide_frame<O>(fa), qb = pack_wide_frame<O>(fb);
+            auto fence = [&]() {
+                WXA_OPAQUE_I32(qa.jn[0]); WXA_OPAQUE_I32(qa.jn[1]); WXA_OPAQUE_I32(qa.jn[2]); WXA_OPAQUE_I32(qa.bits);
+                WXA_OPAQUE_I32(qb.jn[0]); WXA_OPAQUE_I32(qb.jn[1]); WXA_OPAQUE_I32(qb.jn[2]); WXA_OPAQUE_I32(qb.bits);
+                WXA_OPAQUE_F64(c1.x_new); WXA_OPAQUE_F64(c1.y_new); WXA_OPAQUE_F64(c1.z_new);
+                WXA_OPAQUE_F64(c1.x_old); WXA_OPAQUE_F64(c1.y_old); WXA_OPAQUE_F64(c1.z_old);
+                WXA_OPAQUE_F64(c2.x_new); WXA_OPAQUE_F64(c2.y_new); WXA_OPAQUE_F64(c2.z_new);
+                WXA_OPAQUE_F64(c2.x_old); WXA_OPAQUE_F64(c2.y_old); WXA_OPAQUE_F64(c2.z_old);
+            };
+            if (on_a) {
+                const double wq2 = merged ? wqb : 0.0;
+                auto component = [&](auto comp) {
+                    fence();
+                    const WideFrame<O> f1 = unpack_wide_frame<O>(qa, g), f2 = unpack_wide_frame<O>(qb, g);
+                    LdsSink<M, TSZ, ACC> sink(lds, f1.b[0] - o0, f1.b[1] - o1, f1.b[2] - o2);
+                    esirkepov_pair_wide<O, decltype(comp)::value>(c1, f1, wqa, c2, f2, wq2, es, sink);
+                };
+                component(std::integral_constant<int, 0>{});
+                component(std::integral_constant<int, 1>{});
+                component(std::integral_constant<int, 2>{});
+            }
+            if (on_b && !merged) {
+                auto component = [&](auto comp) {
+                    fence();
+                    const WideFrame<O> f2 = unpack_wide_frame<O>(qb, g);
+                    LdsSink<M, TSZ, ACC> sink(lds, f2.b[0] - o0, f2.b[1] - o1, f2.b[2] - o2);
+                    esirkepov_single_wide<O, decltype(comp)::value>(c2, f2, wqb, es, sink);
+                };
+                component(std::integral_constant<int, 0>{});
+                component(std::integral_constant<int, 1>{});
+                component(std::integral_constant<int, 2>{});
             }
             if constexpr (CFG::DYN != 0) ch = __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
             else ch += CHS;
