@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round 5, the evidence session at the round's last kernel sources (after the shared tiles): smoke, the whole -m gpu suite, the PMC passes (traffic
 # + SQ, stamped), the default bench line (with the CPU baseline) as the driver runs it, rocprofv3 --kernel-trace --stats of
-# the same command, the secondary configurations.
+# the same command, the secondary configurations, BASELINE config 5 on one GPU.
 set -u
-OUT=$(pwd)/gpurun_out/r5fin
+OUT=$(pwd)/gpurun_out/r5fin2
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
@@ -26,3 +26,10 @@ d=json.load(open('$OUT/tmp.json'))
 print('$cfg:', 'ms/step %.3f value %.4e' % (d['ms_per_step'], d['value']), {k: round(v['avg_ms'],3) for k,v in d['kernels'].items()})"
 done | tee $OUT/secondary_configurations.txt
 rm -f $OUT/tmp.json
+timeout 400 python scripts/bench_lwfa_boosted.py > $OUT/lwfa_boosted.json 2> $OUT/lwfa_boosted.err; echo "config 5 rc=$?"
+python -c "
+import json
+d=json.load(open('$OUT/lwfa_boosted.json'))
+print('config 5: ms/step %.2f, %.3e particle-steps/s, %.3e cell-updates/s, particles %d -> %d' % (d['ms_per_step'], d['value'], d['cell_updates_per_s'], d['config']['particles_before'], d['config']['particles_after']))
+for k,v in d['kernels'].items(): print('  %-18s %.3f ms per launch, %.2f launches per step, %.3f ms per step %s' % (k, v['avg_ms'], v['launches_per_step'], v['ms_per_step'], ('hbm %.3f' % v['hbm_frac']) if 'hbm_frac' in v else ''))
+" | tee $OUT/lwfa_boosted.txt
