@@ -575,11 +575,16 @@ def test_boosted_frame_injection_through_a_moving_window_on_gpu(product):
     sim.close()
 
 
-def test_boosted_frame_laser_wakefield_deck_on_gpu(oracle, product):
+@pytest.mark.parametrize("sort_behind_shift", [False, True])
+def test_boosted_frame_laser_wakefield_deck_on_gpu(oracle, product, sort_behind_shift, monkeypatch):
     """tests/decks/laser_wakefield_boosted_3d.inputs (BASELINE config 5 in small, with the NCI corrector) on the HIP path
     against the INDEPENDENT oracle stepper set up call by call (tests/pec_case.make_boosted_lwfa_sim: its own window,
     injection front, antenna, walls, NCI filter, schedule): every regression checksum (fields, J, rho, particle sums)
-    at the reference's 1e-9.  (Round 2 compared with the same host layer on the CPU kernels only.)"""
+    at the reference's 1e-9.  (Round 2 compared with the same host layer on the CPU kernels only.)
+    sort_behind_shift: with the step's periodic sort also behind a window shift's sort (WXA_SORT_BEHIND_SHIFT=1; skipped by
+    default since round 5) -- the order of the particles is all that differs."""
+    if sort_behind_shift:
+        monkeypatch.setenv("WXA_SORT_BEHIND_SHIFT", "1")
     from tests import pec_case
     from tests.test_inputs_cpu import compare_with_golden
     from tests.test_pec_golden import _lwfa_report
