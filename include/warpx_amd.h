@@ -771,8 +771,10 @@ wxa_status  wxa_sim_btd_write_plotfile(wxa_sim* s, int32_t i, const char* dir);
  * <file_prefix><i, file_min_digits digits>/ while it is assembled -- every full buffer (buffer_size slices) becomes one more
  * grid of the snapshot's plotfile (Level_0/Cell_D_<n>, <species>/Level_0/DATA_<n>, headers rewritten for the grids so far)
  * and only the buffer being filled is kept in memory (wxa_sim_btd_data / _particles then have nothing to return).  After
- * wxa_sim_add_btd, before the first step; `<diag>.file_prefix` in a deck.  One prefix per brick.
- * wxa_sim_btd_flush: the forced flush after the last step (partly filled buffers go to disk as they are). */
+ * wxa_sim_add_btd, before the first step; `<diag>.file_prefix` in a deck.  On several bricks every brick is given the SAME
+ * prefix: brick 0 collects the bricks' shares of a buffer and writes the one plotfile of the snapshot, with the grids the run
+ * on one brick writes (the flushes are collective; the bricks meet them in the same step).
+ * wxa_sim_btd_flush: the forced flush after the last step (partly filled buffers go to disk as they are); collective. */
 wxa_status  wxa_sim_btd_set_flush(wxa_sim* s, const char* file_prefix, int32_t file_min_digits);
 wxa_status  wxa_sim_btd_flush(wxa_sim* s);
 /* Index box (inclusive) of this brick's share of snapshot i in the snapshot's (x, y, k_lab) index space: m_snapshot_box

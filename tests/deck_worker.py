@@ -29,12 +29,14 @@ def main():
     load = load_hip_on_cpu if os.environ.get("WXA_WORKER_LIB") == "hipcpu" else load_host_cpu
     # WXA_TEST_OVERRIDES: "a=b;c=d" appended to the deck, as on the reference's command line
     over = tuple(v for v in os.environ.get("WXA_TEST_OVERRIDES", "").split(";") if v)
+    # WXA_TEST_DIAGNOSTICS=1: the deck's diagnostics are written (the test suite's default is not to)
+    diags = os.environ.get("WXA_TEST_DIAGNOSTICS") == "1"
     if nb == (0, 0, 0):     # let the library choose the bricks for comm.nranks
-        sim = WarpXSim.from_inputs(load(), deck, overrides=over, comm=transport.comm)
+        sim = WarpXSim.from_inputs(load(), deck, overrides=over, comm=transport.comm, diagnostics=diags)
     else:
         assert world == nb[0] * nb[1] * nb[2]
         sim = WarpXSim.from_inputs(load(), deck, overrides=over, nbricks=nb, coord=brick_coord(rank, nb),
-                                   comm=transport.comm)
+                                   comm=transport.comm, diagnostics=diags)
     # WXA_TEST_MAX_STEP: a shorter run for brick-against-one-brick comparisons (both sides stop at the same step)
     sim.evolve(min(sim.max_step, int(os.environ.get("WXA_TEST_MAX_STEP", sim.max_step))))
     # WXA_TEST_PLOTFILE: one plotfile for all bricks (a collective call: every brick writes its grid, brick 0 the headers)

@@ -197,6 +197,66 @@ def test_overlapped_halo_exchange_is_the_same_arithmetic(nb, order, port, tmp_pa
         assert err < 1e-10, (name, err)
 
 
+@pytest.mark.parametrize("nb,nranks,port", [
+    ((2, 1, 2), 4, 29653),      # split across the window and along it
+    ((1, 1, 4), 4, 29654),      # a column of four bricks along z: every buffer holds slices of several bricks
+])
+def test_bricks_flush_one_back_transformed_plotfile(nb, nranks, port, tmp_path):
+    """<diag>.file_prefix on several bricks: ONE plotfile per lab-frame snapshot for the whole run, written by brick 0 from the
+    bricks' shares (BTDiagnostics::flush_bricks) -- the same grids, one per flushed buffer, as the run on one brick writes
+    (the reference's MergeBuffersForPlotfile, BTDiagnostics.cpp:1146-1314, leaves one plotfile per snapshot whatever the
+    number of ranks).  Until round 5 every brick wrote a plotfile of its own and a snapshot of bricks stacked along z was
+    the sum of them.  Fields at 1e-9 of their scale, the back-transformed electrons the single brick's."""
+    import numpy as np
+    from tests.oracle_lib import load_host_cpu
+    from tests.test_plotfile_cpu import read_plotfile
+    from warpx_amd.sim import WarpXSim
+    path = os.path.join(ROOT, "tests", "decks", "laser_wakefield_boosted_3d.inputs")
+    nsteps, nsnap = 50, 3
+    probe = WarpXSim.from_inputs(load_host_cpu(), path)
+    dt_snap = 12 * probe.dt * 5.0          # warpx.gamma_boost = 5: a new plane enters the domain every ~12 steps
+    probe.close()
+
+    def overrides(prefix):
+        return ("diagnostics.diags_names=d1", "d1.diag_type=BackTransformed", "d1.do_back_transformed_fields=1",
+                f"d1.num_snapshots_lab={nsnap}", f"d1.dt_snapshots_lab={dt_snap!r}", "d1.buffer_size=16", "d1.format=plotfile",
+                "d1.fields_to_plot=Ex Ey Ez Bx By Bz jx jy jz rho", f"d1.file_prefix={prefix}", "d1.file_min_digits=3",
+                f"max_step={nsteps}")
+    one_prefix, bricks_prefix = str(tmp_path / "one" / "lab"), str(tmp_path / "bricks" / "lab")
+    one = WarpXSim.from_inputs(load_host_cpu(), path, overrides=overrides(one_prefix), diagnostics=True)
+    one.evolve(one.max_step)               # the deck's max_step: the forced flush of the last time step included
+    one.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
+           *[str(v) for v in nb], path, str(tmp_path / "sum.json")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks), WXA_TEST_DIAGNOSTICS="1",
+                                WXA_TEST_OVERRIDES=";".join(overrides(bricks_prefix))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert sorted(os.listdir(str(tmp_path / "bricks"))) == sorted(os.listdir(str(tmp_path / "one"))) == ["lab%03d" % i for i in range(nsnap)]
+    some_particles = False
+    for i in range(nsnap):
+        a, b = read_plotfile(one_prefix + "%03d" % i), read_plotfile(bricks_prefix + "%03d" % i)
+        la, lb = (sorted(os.listdir(os.path.join(pfx + "%03d" % i, "Level_0"))) for pfx in (one_prefix, bricks_prefix))
+        assert la == lb and len(la) >= 2                    # the same grids, one per flushed buffer, + Cell_H
+        assert a["time"] == b["time"] and a["step"] == b["step"] == nsteps and a["names"] == b["names"]
+        for c in a["names"]:
+            assert a["fields"][c].shape == b["fields"][c].shape
+            scale = np.max(np.abs(a["fields"][c]))
+            assert scale > 0 and np.max(np.abs(a["fields"][c] - b["fields"][c])) <= 1e-9 * scale, (i, c)
+        assert list(a["species"]) == list(b["species"]) and len(a["species"]) == 1
+        for name in a["species"]:
+            keys = ["particle_position_x", "particle_position_y", "particle_position_z", "particle_weight",
+                    "particle_momentum_x", "particle_momentum_y", "particle_momentum_z"]
+            pa, pb = (np.array([sp[name][k] for k in keys]) for sp in (a["species"], b["species"]))
+            assert pa.shape == pb.shape
+            some_particles = some_particles or pa.shape[1] > 100
+            pa, pb = (q[:, np.lexsort((q[2], np.round(q[1] / 1e-10), np.round(q[0] / 1e-10)))] for q in (pa, pb))
+            for row in range(7):
+                assert np.max(np.abs(pa[row] - pb[row])) <= 1e-9 * max(np.max(np.abs(pa[row])), 1e-300), (i, name, row)
+    assert some_particles
+
+
 def test_random_momenta_do_not_depend_on_the_brick_layout(tmp_path):
     """Gaussian momenta come from a counter-based stream keyed by the particle's position: the headline deck (in
     small) starts from the same particles on 1 brick and on 4 -- the sums of |m u| agree to round-off."""

@@ -45,6 +45,7 @@ public:
         int counter = 0, last_valid = 0, full = 0;
         int n[3] = {0, 0, 0};                   // cells of the snapshot array (x, y, z): this brick's x-y cells, all of z
         int ilo[2] = {0, 0};                    // ... and where its first cell sits in the snapshot's index box
+        int glo[2] = {0, 0}, gn[2] = {0, 0};    // the snapshot's x-y box as a whole (all bricks)
         std::vector<double> data;               // [comp][k][j][i], zero until a slice arrives
         // back-transformed particles per species: rows x y z w ux uy uz (lab frame), in arrival order
         std::vector<std::array<std::vector<double>, 7>> particles;
@@ -135,6 +136,8 @@ public:
             // this brick's share: its own cells in x and y (the reference keeps one buffer box per boosted-frame box)
             const int nxy_lab[2] = {nx_lab, ny_lab};
             for (int d = 0; d < 2; ++d) {
+                s.glo[d] = lo[d];
+                s.gn[d] = nxy_lab[d];
                 s.ilo[d] = ctx.brick_box.lo[d];
                 s.n[d] = std::max(0, std::min(ctx.brick_box.hi[d] + 1, lo[d] + nxy_lab[d]) - ctx.brick_box.lo[d]);
             }
@@ -270,6 +273,10 @@ private:
     // next one starts below it (:1127-1137).  This brick's share, like wxa_sim_btd_write_plotfile.
     template <class WX>
     void flush(WX& wx, int i) {
+        {
+            const int* nb = wx.comm().nbricks();
+            if (nb[0] * nb[1] * nb[2] > 1) { flush_bricks(wx, i); return; }
+        }
         Snapshot& s = m_snap[(size_t)i];
         const auto& ctx = wx.context();
         const std::string dir = snapshot_path(i);
@@ -317,6 +324,138 @@ private:
         static const char* comp_names[NCOMP] = {"Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho"};
         write_cell_headers(dir, std::vector<std::string>(comp_names, comp_names + NCOMP), s.flushed, dom_lo, dom_hi, rlo, rhi,
                            dx, s.t_lab, wx.getistep());
+        s.buffer_counter = 0;
+        s.buffer_k_index_hi = s.buffer_klo - 1;
+        s.buffer_khi = s.buffer_klo - 1;   // no buffer until the next one is defined
+        s.data.clear();
+        s.data_nz = 0;
+    }
+
+    // The same on several bricks: ONE plotfile per snapshot, the buffer one grid of it, as on one brick.  Every brick holds
+    // its x-y share of the buffer with the slices whose plane lay in its cells (zeros in the planes another brick of its
+    // column filled); brick 0 collects the shares (GatherRealToRoot), adds them into the buffer's whole x-y box and writes
+    // grid, particle file and headers.  The flush conditions are global (the plane's index, the slice counters), so the
+    // bricks arrive here in the same step.  (Until round 5 every brick wrote a plotfile of its own, <prefix>brick<r>_<i>/,
+    // and the snapshot of a run with bricks stacked along z was the sum of them.)
+    template <class WX>
+    void flush_bricks(WX& wx, int i) {
+        Snapshot& s = m_snap[(size_t)i];
+        const auto& ctx = wx.context();
+        BrickComm& comm = wx.comm();
+        const Backend* be = ctx.be;
+        const int* nb = comm.nbricks();
+        const int nranks = nb[0] * nb[1] * nb[2], me = comm.rank_of(comm.coord());
+        const bool root = me == 0;
+        const std::string dir = snapshot_path(i);
+        const int id = (int)s.flushed.size();
+        const int nz = s.data_nz;
+        const int bc[2] = {ctx.brick_box.hi[0] - ctx.brick_box.lo[0] + 1, ctx.brick_box.hi[1] - ctx.brick_box.lo[1] + 1};
+        // brick r's share of the snapshot's x-y box (the formula of the set-up above, for every brick)
+        auto share_of = [&](int r, int lo[2], int n[2]) {
+            const int c[2] = {r % nb[0], (r / nb[0]) % nb[1]};
+            for (int d = 0; d < 2; ++d) {
+                lo[d] = wx.m_dom_lo[d] + c[d] * bc[d];
+                n[d] = std::max(0, std::min(lo[d] + bc[d], s.glo[d] + s.gn[d]) - lo[d]);
+            }
+        };
+        {
+            int lo[2], n[2];
+            share_of(me, lo, n);
+            if (lo[0] != s.ilo[0] || lo[1] != s.ilo[1] || n[0] != s.n[0] || n[1] != s.n[1])
+                throw std::runtime_error("BackTransformed diagnostic: brick numbering mismatch");
+        }
+        wx.sync_stream();
+        std::vector<int64_t> count((size_t)nranks);
+        for (int r = 0; r < nranks; ++r) {
+            int lo[2], n[2];
+            share_of(r, lo, n);
+            count[(size_t)r] = (int64_t)NCOMP * nz * n[1] * n[0];
+        }
+        std::vector<std::vector<double>> shares;
+        GatherRealToRoot(comm, be, s.data.data(), count, shares, ctx.stream);
+        PlotGrid g;
+        g.lo[0] = s.glo[0]; g.lo[1] = s.glo[1]; g.lo[2] = s.buffer_klo;
+        g.hi[0] = s.glo[0] + s.gn[0] - 1; g.hi[1] = s.glo[1] + s.gn[1] - 1; g.hi[2] = s.buffer_khi;
+        g.fab_file = numbered("Cell_D_", id, 5);
+        if (root) {
+            if (id == 0) { make_dirs(dir); make_dir(dir + "/Level_0"); }
+            const size_t gpl = (size_t)s.gn[0] * s.gn[1], gpts = gpl * (size_t)nz;
+            std::vector<double> whole((size_t)NCOMP * gpts, 0.0);
+            for (int r = 0; r < nranks; ++r) {
+                int lo[2], n[2];
+                share_of(r, lo, n);
+                const std::vector<double>& v = shares[(size_t)r];
+                if (v.empty()) continue;
+                const size_t spts = (size_t)n[0] * n[1] * (size_t)nz;
+                for (int c = 0; c < NCOMP; ++c)
+                    for (int k = 0; k < nz; ++k)
+                        for (int j = 0; j < n[1]; ++j) {
+                            const double* src = v.data() + (size_t)c * spts + ((size_t)k * n[1] + (size_t)j) * n[0];
+                            double* dst = whole.data() + (size_t)c * gpts + (size_t)k * gpl +
+                                          (size_t)(lo[1] - s.glo[1] + j) * s.gn[0] + (size_t)(lo[0] - s.glo[0]);
+                            for (int ii = 0; ii < n[0]; ++ii) dst[ii] += src[ii];
+                        }
+            }
+            std::vector<const double*> comps;
+            for (int c = 0; c < NCOMP; ++c) comps.push_back(whole.data() + (size_t)c * gpts);
+            write_fab(dir, g, comps);
+        }
+        s.flushed.push_back(g);   // (extrema on brick 0 only, which writes the headers)
+        // the particles the plane has met while this buffer was filled: brick after brick into one file.  (A brick whose
+        // species were empty so far has not met PackParticles: the bricks agree on the number of lists first.)
+        int nspecies = (int)s.particles.size();
+        {
+            std::vector<double> ns((size_t)nranks, 0.0);
+            ns[(size_t)me] = (double)nspecies;
+            ReduceRealSum(comm, be, ns, ctx.stream);
+            for (double v : ns) nspecies = std::max(nspecies, (int)v);
+            if ((int)s.particles.size() < nspecies) s.particles.resize((size_t)nspecies);
+        }
+        if ((int)s.flushed_particles.size() < nspecies) s.flushed_particles.resize((size_t)nspecies);
+        for (int sp = 0; sp < nspecies; ++sp) {
+            const std::string name = sp < (int)m_species_names.size() ? m_species_names[(size_t)sp] : "species" + std::to_string(sp);
+            auto& rows = s.particles[(size_t)sp];
+            const size_t np = rows[0].size();
+            const double mass = wx.GetPartContainer().GetParticleContainer(sp).mass;
+            std::vector<double> rec(7 * np);
+            for (size_t q = 0; q < np; ++q)
+                for (int c = 0; c < 7; ++c) rec[7 * q + (size_t)c] = c >= 4 ? rows[(size_t)c][q] * mass : rows[(size_t)c][q];
+            for (auto& r : rows) { r.clear(); r.shrink_to_fit(); }
+            std::vector<double> nper((size_t)nranks, 0.0);
+            nper[(size_t)me] = (double)np;
+            ReduceRealSum(comm, be, nper, ctx.stream);
+            std::vector<int64_t> pc((size_t)nranks);
+            int64_t total = 0;
+            for (int r = 0; r < nranks; ++r) { pc[(size_t)r] = 7 * (int64_t)nper[(size_t)r]; total += (int64_t)nper[(size_t)r]; }
+            std::vector<std::vector<double>> recs;
+            GatherRealToRoot(comm, be, rec.data(), pc, recs, ctx.stream);
+            ParticleGrid pg;
+            for (int d = 0; d < 3; ++d) { pg.lo[d] = g.lo[d]; pg.hi[d] = g.hi[d]; }
+            pg.which = id;
+            pg.count = total;
+            s.flushed_particles[(size_t)sp].push_back(pg);
+            if (root) {
+                if (id == 0) { make_dir(dir + "/" + name); make_dir(dir + "/" + name + "/Level_0"); }
+                std::vector<double> all;
+                all.reserve((size_t)(7 * total));
+                for (const auto& v : recs) all.insert(all.end(), v.begin(), v.end());
+                if (total) write_particle_records(dir, name, id, all, (size_t)total);   // no file for an empty grid (:1274, :1290)
+                write_species_headers(dir, name, s.flushed_particles[(size_t)sp]);
+            }
+        }
+        if (root) {
+            int dom_lo[3] = {g.lo[0], g.lo[1], g.lo[2]}, dom_hi[3] = {g.hi[0], g.hi[1], g.hi[2]};
+            for (const PlotGrid& q : s.flushed) { dom_lo[2] = std::min(dom_lo[2], q.lo[2]); dom_hi[2] = std::max(dom_hi[2], q.hi[2]); }
+            const double dzl = (s.zhi_lab - s.zlo_lab) / s.n[2];
+            const double dx[3] = {ctx.dx[0], ctx.dx[1], dzl};
+            const double rlo[3] = {ctx.prob_lo[0] + dom_lo[0] * dx[0], ctx.prob_lo[1] + dom_lo[1] * dx[1],
+                                   s.zlo_lab + (dom_lo[2] - s.ksmall) * dzl};
+            const double rhi[3] = {ctx.prob_lo[0] + (dom_hi[0] + 1) * dx[0], ctx.prob_lo[1] + (dom_hi[1] + 1) * dx[1],
+                                   s.zlo_lab + (dom_hi[2] + 1 - s.ksmall) * dzl};
+            static const char* comp_names[NCOMP] = {"Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz", "rho"};
+            write_cell_headers(dir, std::vector<std::string>(comp_names, comp_names + NCOMP), s.flushed, dom_lo, dom_hi, rlo, rhi,
+                               dx, s.t_lab, wx.getistep());
+        }
         s.buffer_counter = 0;
         s.buffer_k_index_hi = s.buffer_klo - 1;
         s.buffer_khi = s.buffer_klo - 1;   // no buffer until the next one is defined

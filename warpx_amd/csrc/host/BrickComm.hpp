@@ -335,5 +335,99 @@ private:
     DeviceBuffer m_send[2], m_recv[2];
 };
 
+
+// The per-brick sums of one row, added over the bricks of a run: ParallelDescriptor::ReduceRealSum
+// (e.g. ParticleEnergy.cpp:157).  One message each way with every other brick (ascending rank, as the particle
+// hand-off posts them), then the sum in rank order on every brick: all bricks hold the same bits.
+inline void ReduceRealSum(BrickComm& comm, const Backend* be, std::vector<double>& v, void* stream) {
+    const int* nb = comm.nbricks();
+    const int nranks = nb[0] * nb[1] * nb[2];
+    if (nranks == 1 || v.empty()) return;
+    const int me = comm.rank_of(comm.coord());
+    const size_t K = v.size(), bytes = sizeof(double) * K;
+    DeviceBuffer buf;
+    buf.be = be;
+    buf.reserve(bytes * (size_t)nranks);
+    char* base = static_cast<char*>(buf.p);
+    if (be->memcpy_h2d(base + bytes * (size_t)me, v.data(), bytes) != 0) throw std::runtime_error("ReduceRealSum: copy failed");
+    std::vector<int32_t> peer;
+    std::vector<void*> sb, rb;
+    std::vector<int64_t> nbytes;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == me) continue;
+        peer.push_back(r);
+        sb.push_back(base + bytes * (size_t)me);
+        rb.push_back(base + bytes * (size_t)r);
+        nbytes.push_back((int64_t)bytes);
+    }
+    comm.exchange_with((int)peer.size(), peer.data(), sb.data(), nbytes.data(), rb.data(), nbytes.data(), stream);
+    be->stream_sync(stream);
+    std::vector<double> all(K * (size_t)nranks);
+    if (be->memcpy_d2h(all.data(), base, bytes * (size_t)nranks) != 0) throw std::runtime_error("ReduceRealSum: copy failed");
+    for (size_t c = 0; c < K; ++c) {
+        double s = 0.0;
+        for (int r = 0; r < nranks; ++r) s += all[(size_t)r * K + c];
+        v[c] = s;
+    }
+}
+
+// Rank 0 collects a block of doubles from every brick (count[r] doubles from brick r; every brick knows its own count,
+// brick 0 all of them): one message per brick through the transport, staged like every other exchange.  On brick 0 `out[r]`
+// holds brick r's block (its own included); elsewhere `out` is left empty.  Collective.
+inline void GatherRealToRoot(BrickComm& comm, const Backend* be, const double* mine, const std::vector<int64_t>& count,
+                             std::vector<std::vector<double>>& out, void* stream) {
+    const int* nb = comm.nbricks();
+    const int nranks = nb[0] * nb[1] * nb[2];
+    const int me = comm.rank_of(comm.coord());
+    out.clear();
+    if (me != 0) {
+        const int64_t n = count[(size_t)me];
+        if (n == 0) return;   // (brick 0 skips an empty block too)
+        DeviceBuffer buf;
+        buf.be = be;
+        buf.reserve(sizeof(double) * (size_t)n);
+        if (be->memcpy_h2d(buf.p, mine, sizeof(double) * (size_t)n) != 0) throw std::runtime_error("GatherRealToRoot: copy failed");
+        const int32_t peer = 0;
+        void* sb = buf.p;
+        void* rb = buf.p;
+        const int64_t sbytes = (int64_t)sizeof(double) * n, rbytes = 0;
+        comm.exchange_with(1, &peer, &sb, &sbytes, &rb, &rbytes, stream);
+        be->stream_sync(stream);
+        return;
+    }
+    out.resize((size_t)nranks);
+    out[0].assign(mine, mine + count[0]);
+    int64_t total = 0;
+    for (int r = 1; r < nranks; ++r) total += count[(size_t)r];
+    if (total == 0) return;
+    DeviceBuffer buf;
+    buf.be = be;
+    buf.reserve(sizeof(double) * (size_t)total);
+    std::vector<int32_t> peer;
+    std::vector<void*> sb, rb;
+    std::vector<int64_t> sbytes, rbytes;
+    int64_t at = 0;
+    for (int r = 1; r < nranks; ++r) {
+        peer.push_back(r);
+        sb.push_back(buf.p);
+        sbytes.push_back(0);
+        rb.push_back(static_cast<char*>(buf.p) + sizeof(double) * (size_t)at);
+        rbytes.push_back((int64_t)sizeof(double) * count[(size_t)r]);
+        at += count[(size_t)r];
+    }
+    comm.exchange_with((int)peer.size(), peer.data(), sb.data(), sbytes.data(), rb.data(), rbytes.data(), stream);
+    be->stream_sync(stream);
+    at = 0;
+    for (int r = 1; r < nranks; ++r) {
+        out[(size_t)r].resize((size_t)count[(size_t)r]);
+        if (count[(size_t)r] > 0 &&
+            be->memcpy_d2h(out[(size_t)r].data(), static_cast<char*>(buf.p) + sizeof(double) * (size_t)at,
+                           sizeof(double) * (size_t)count[(size_t)r]) != 0)
+            throw std::runtime_error("GatherRealToRoot: copy failed");
+        at += count[(size_t)r];
+    }
+}
+
 }  // namespace wxa::host
+
 #endif

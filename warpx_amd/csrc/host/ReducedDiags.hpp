@@ -161,40 +161,7 @@ public:
     }
 };
 
-// The per-brick sums of one row, added over the bricks of a run: ParallelDescriptor::ReduceRealSum
-// (e.g. ParticleEnergy.cpp:157).  One message each way with every other brick (ascending rank, as the particle
-// hand-off posts them), then the sum in rank order on every brick: all bricks hold the same bits.
-inline void ReduceRealSum(BrickComm& comm, const Backend* be, std::vector<double>& v, void* stream) {
-    const int* nb = comm.nbricks();
-    const int nranks = nb[0] * nb[1] * nb[2];
-    if (nranks == 1 || v.empty()) return;
-    const int me = comm.rank_of(comm.coord());
-    const size_t K = v.size(), bytes = sizeof(double) * K;
-    DeviceBuffer buf;
-    buf.be = be;
-    buf.reserve(bytes * (size_t)nranks);
-    char* base = static_cast<char*>(buf.p);
-    if (be->memcpy_h2d(base + bytes * (size_t)me, v.data(), bytes) != 0) throw std::runtime_error("ReduceRealSum: copy failed");
-    std::vector<int32_t> peer;
-    std::vector<void*> sb, rb;
-    std::vector<int64_t> nbytes;
-    for (int r = 0; r < nranks; ++r) {
-        if (r == me) continue;
-        peer.push_back(r);
-        sb.push_back(base + bytes * (size_t)me);
-        rb.push_back(base + bytes * (size_t)r);
-        nbytes.push_back((int64_t)bytes);
-    }
-    comm.exchange_with((int)peer.size(), peer.data(), sb.data(), nbytes.data(), rb.data(), nbytes.data(), stream);
-    be->stream_sync(stream);
-    std::vector<double> all(K * (size_t)nranks);
-    if (be->memcpy_d2h(all.data(), base, bytes * (size_t)nranks) != 0) throw std::runtime_error("ReduceRealSum: copy failed");
-    for (size_t c = 0; c < K; ++c) {
-        double s = 0.0;
-        for (int r = 0; r < nranks; ++r) s += all[(size_t)r * K + c];
-        v[c] = s;
-    }
-}
+// (ReduceRealSum: BrickComm.hpp)
 
 // FieldEnergy.cpp: [total, E, B] of level 0
 class FieldEnergy : public ReducedDiags {

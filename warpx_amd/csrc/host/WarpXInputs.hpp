@@ -875,13 +875,12 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
         wx.AddBTDiagnostics(nsnap, dt_snap, buffer, write_species != 0);
         wx.btd()->SetSpeciesNames(info.species_names);
         // <diag>.file_prefix (BTDiagnostics.cpp:98-99 reads it through Diagnostics::BaseReadParameters): given, the snapshots
-        // are flushed to <file_prefix><i>/ buffer by buffer as plotfiles; absent, they stay in memory.  One directory per
-        // brick: the bricks of a run do not share a file.
+        // are flushed to <file_prefix><i>/ buffer by buffer as plotfiles; absent, they stay in memory.  On several bricks
+        // brick 0 writes, one plotfile per snapshot for the whole run (BTDiagnostics::flush_bricks).
         std::string prefix;
         if (pp.query(d + ".file_prefix", prefix) && write_diagnostics && !in_memory_only) {
             int digits = 6;                                        // Diagnostics.H: m_file_min_digits
             pp.queryWithParser(d + ".file_min_digits", digits);
-            if (comm && comm->nranks > 1) prefix += "brick" + std::to_string(comm->rank) + "_";
             wx.btd()->SetFlush(prefix, digits);
         }
     }
