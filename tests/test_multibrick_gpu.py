@@ -423,3 +423,74 @@ def test_back_transformed_diagnostics_on_bricks(product):
         a, b = (q[:, np.lexsort((q[2], np.round(q[1] / 1e-10), np.round(q[0] / 1e-10)))] for q in (a, b))
         for row in range(7):
             assert np.max(np.abs(a[row] - b[row])) <= 1e-9 * max(np.max(np.abs(b[row])), 1e-300), (i, row)
+
+
+def test_bricks_flush_one_back_transformed_plotfile_on_gpu(product, tmp_path):
+    """<diag>.file_prefix on the HIP path with two columns of two bricks (threads of one process): one plotfile per lab-frame
+    snapshot for the whole run, written by brick 0 from the bricks' shares (BTDiagnostics::flush_bricks; the shares travel
+    through the transport from device staging buffers, GatherRealToRoot) -- the grids, fields (1e-9) and back-transformed
+    electrons of the one-brick run of the same library.  tests/test_multibrick_cpu.py has the same over gloo on the CPU
+    kernels."""
+    from tests.test_plotfile_cpu import read_plotfile
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decks", "laser_wakefield_boosted_3d.inputs")
+    nb, nsteps, nsnap = (2, 1, 2), 50, 3
+    probe = WarpXSim.from_inputs(product, deck)
+    dt_snap = 12 * probe.dt * 5.0
+    probe.close()
+
+    def overrides(prefix):
+        return ("diagnostics.diags_names=d1", "d1.diag_type=BackTransformed", "d1.do_back_transformed_fields=1",
+                f"d1.num_snapshots_lab={nsnap}", f"d1.dt_snapshots_lab={dt_snap!r}", "d1.buffer_size=16", "d1.format=plotfile",
+                "d1.fields_to_plot=Ex Ey Ez Bx By Bz jx jy jz rho", f"d1.file_prefix={prefix}", "d1.file_min_digits=3",
+                f"max_step={nsteps}")
+    one_prefix, bricks_prefix = str(tmp_path / "one" / "lab"), str(tmp_path / "bricks" / "lab")
+    one = WarpXSim.from_inputs(product, deck, overrides=overrides(one_prefix), diagnostics=True)
+    one.evolve(one.max_step)
+    one.close()
+
+    nranks = nb[0] * nb[1] * nb[2]
+    shared = thread_transport_state()
+    errors = []
+
+    def brick(rank):
+        shared["turn"].acquire()
+        try:
+            tr = ThreadBrickTransport(rank, nranks, shared)
+            sim = WarpXSim.from_inputs(product, deck, overrides=overrides(bricks_prefix), nbricks=nb, coord=brick_coord(rank, nb),
+                                       comm=tr.comm, diagnostics=True)
+            sim.evolve(sim.max_step)
+            sim.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            thread_transport_abort(shared)
+        finally:
+            shared["turn"].release()
+
+    threads = [threading.Thread(target=brick, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert sorted(os.listdir(str(tmp_path / "bricks"))) == ["lab%03d" % i for i in range(nsnap)]
+    keys = ["particle_position_x", "particle_position_y", "particle_position_z", "particle_weight",
+            "particle_momentum_x", "particle_momentum_y", "particle_momentum_z"]
+    some_particles = False
+    for i in range(nsnap):
+        a, b = read_plotfile(one_prefix + "%03d" % i), read_plotfile(bricks_prefix + "%03d" % i)
+        la, lb = (sorted(os.listdir(os.path.join(pfx + "%03d" % i, "Level_0"))) for pfx in (one_prefix, bricks_prefix))
+        assert la == lb and len(la) >= 2
+        assert a["time"] == b["time"] and a["step"] == b["step"] == nsteps and a["names"] == b["names"]
+        for c in a["names"]:
+            scale = np.max(np.abs(a["fields"][c]))
+            assert a["fields"][c].shape == b["fields"][c].shape and scale > 0
+            assert np.max(np.abs(a["fields"][c] - b["fields"][c])) <= 1e-9 * scale, (i, c)
+        assert list(a["species"]) == list(b["species"]) and len(a["species"]) == 1
+        for name in a["species"]:
+            pa, pb = (np.array([sp[name][k] for k in keys]) for sp in (a["species"], b["species"]))
+            assert pa.shape == pb.shape
+            some_particles = some_particles or pa.shape[1] > 100
+            pa, pb = (q[:, np.lexsort((q[2], np.round(q[1] / 1e-10), np.round(q[0] / 1e-10)))] for q in (pa, pb))
+            for row in range(7):
+                assert np.max(np.abs(pa[row] - pb[row])) <= 1e-9 * max(np.max(np.abs(pa[row])), 1e-300), (i, name, row)
+    assert some_particles
