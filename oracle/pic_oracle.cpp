@@ -825,12 +825,15 @@ int orc_apply_pec_j(const wxa_field_view J[3], const int32_t dom_lo[3], const in
 }
 
 // PEC::ApplyReflectiveBoundarytoRhofield (:628-711): rho is treated like a tangential component along
-// every direction (:664-666).  One departure: the reference folds the valid points of each box only
-// (:697), although it runs before the guard sum -- charge deposited in a box's transverse guard
-// columns (towards a periodic image or a neighbour box) then misses its image, so its rho next to a
-// wall depends on the box decomposition.  Here the guard columns of the wall-free directions are
-// folded too, which is what the fold after the sum would give; the two agree whenever no particle
-// sits within a stencil of both a wall and a box edge (all of the reference's golden runs).
+// every direction (:664-666).  The reference folds the valid points of each box only (:697), although
+// it runs before the guard sum -- charge deposited in a box's transverse guard columns (towards a
+// periodic image or a neighbour box) then misses its image, so its rho next to a wall depends on the
+// box decomposition.  THIS entry point (the kernel-level one, mirrored by wxa_apply_pec_rho) folds the
+// guard columns of the wall-free directions too, which is what a fold after the sum would give; the
+// callers that want the reference's numbers -- the host layer's WarpX::ApplyRhofieldBoundary and the
+// stepper below -- leave those columns as they are.  (Round 5: the difference is 1.3e-3 of the sum of
+// |rho| in the reference's back-transformed golden run, whose plasma ends one cell from the periodic
+// faces and streams through the lower wall.)
 int orc_apply_pec_rho(const wxa_field_view* rho, const int32_t dom_lo[3], const int32_t dom_hi[3],
                       const int32_t pec_lo[3], const int32_t pec_hi[3], void*) {
     const bool tangent[3] = {true, true, true};
@@ -2515,7 +2518,12 @@ int orc_sim_compute_rho(orc_sim* s) {
     }
     // WarpXParticleContainer::DepositCharge (:1285-1290): each species' rho is reflected over the PEC walls
     // right after its deposition (linear: done once on the total), before the filter and the sum
-    if (s->any_pec) orc_apply_pec_rho(&s->rho.v, s->dom_lo, s->dom_hi, s->pec_lo, s->pec_hi, nullptr);
+    // (the stepper follows the reference: the valid points only, PEC::ApplyReflectiveBoundarytoRhofield :697-698 -- the
+    // guard columns of the wall-free directions keep their deposits, see orc_apply_pec_rho)
+    if (s->any_pec) {
+        const bool tangent[3] = {true, true, true};
+        reflect_over_pec(s->rho.v, tangent, s->dom_lo, s->dom_hi, s->pec_lo, s->pec_hi, /*transverse_guards=*/false);
+    }
     if (s->cfg.use_filter) {
         Field tmp; tmp.v = s->rho.v; tmp.data.assign(s->rho.data.size(), 0.0); tmp.v.p = tmp.data.data();
         orc_filter_bilinear(&s->rho.v, &tmp.v, nullptr);

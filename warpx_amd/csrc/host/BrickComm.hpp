@@ -77,6 +77,14 @@ public:
     // components at once: per exchanged direction ALL components travel in one message per
     // neighbour (3 exchanges for E and B together instead of 18) -- on xGMI the per-message
     // latency, not the bytes, is what a halo exchange costs.
+    // The guard points behind a wall AND beyond a face of another direction are left to the next PEC pass, as
+    // amrex::FillBoundary leaves them (see FillBoundary below): the reference's numbers on the same box layout.
+    // WXA_REFERENCE_CORNERS=0: they travel with the slabs of the other directions instead (results that do not depend on
+    // the brick layout; the default until round 5).
+    static bool reference_corners() {
+        static const bool on = [] { const char* e = std::getenv("WXA_REFERENCE_CORNERS"); return !(e && std::atoi(e) == 0); }();
+        return on;
+    }
     void FillBoundary(const std::vector<amrex::MultiFab*>& mfs, const amrex::IntVect& ng, bool nodal_sync,
                       void* stream) {
         const size_t nf = mfs.size();
@@ -87,15 +95,18 @@ public:
                 if (ng[d] > f.ng[d]) throw std::runtime_error("FillBoundary: ng exceeds allocated guard cells");
                 lo[c][d] = f.lo[d] + f.ng[d];
                 hi[c][d] = f.lo[d] + f.n[d] - f.ng[d];
-                // The guards behind a physical boundary belong to its boundary kernel, which has just written them on the
-                // neighbour too: they travel with the slabs of the other directions.  A point behind a wall AND beyond a
-                // brick face then holds what the same point holds in the middle of one brick (the mirror of the current
-                // field).  amrex::FillBoundary leaves such points to the next PEC pass, which mirrors guard values of the
-                // previous exchange: a box face next to a wall then sees a field one step old there, and the reference's
-                // result depends on the box layout (the CKC update of B and the gather read those points: 1e-6 of max|B|
-                // after one step of tests/decks/laser_wakefield_boosted_3d.inputs on two bricks).  Deliberate departure,
-                // DESIGN.md section 5; the periodic faces of a single brick are treated the same way, for consistency.
-                if (!m_periodic[d]) { lo[c][d] = f.lo[d]; hi[c][d] = f.lo[d] + f.n[d]; }
+                // A point behind a wall AND beyond a face of another direction (a brick face or the periodic face of a single
+                // brick) is no valid point of any box: amrex::FillBoundary does not fill it, the next PEC pass does, by
+                // mirroring the guard column's interior values -- those of the previous exchange, so that a face next to a
+                // wall sees a field one step old there (the CKC update of B and the gather read those points).  The
+                // reference's result therefore depends on the box layout across the wall-free directions (1e-6 of max|B|
+                // after one step of tests/decks/laser_wakefield_boosted_3d.inputs split along x), and its golden files hold
+                // the numbers of its own layout.  Followed since round 5: with the corners filled consistently instead (they
+                // travelled with the slabs of the other directions: the same point as in the middle of one brick) the
+                // reference's back-transformed golden file -- a plasma that ends one cell from the periodic faces and streams
+                // through a wall -- was missed by 1.5e-5 on E and B; with the reference's corners it is met at 3e-10
+                // (profiles/round5/README.md).  WXA_REFERENCE_CORNERS=0 brings the layout-independent fill back.
+                if (!m_periodic[d] && !reference_corners()) { lo[c][d] = f.lo[d]; hi[c][d] = f.lo[d] + f.n[d]; }
             }
         }
         for (int d = 0; d < 3; ++d) {
