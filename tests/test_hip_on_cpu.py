@@ -99,7 +99,9 @@ def test_boosted_wakefield_deck_on_bricks_with_the_hip_kernels(tmp_path):
     """BASELINE config 5 in small (tests/decks/laser_wakefield_boosted_3d.inputs, first 40 steps) on two bricks over gloo,
     every brick running the product's .hip sources on the execution model: device-side boosted injection per brick, the
     antenna split over the bricks, CKC next to the PEC walls, the windowed sort, the moving window -- against one brick on
-    the CPU kernels at the reference's 1e-9."""
+    the CPU kernels at the reference's 1e-9.  (Since round 5 the guard points behind a wall and beyond a DOMAIN face are
+    left to the next PEC pass as the reference leaves them; behind a wall and beyond a face between two bricks they still
+    travel with the exchange, and the charge in the guard columns there is still folded: two layouts, one result.)"""
     import json
     from tests.oracle_lib import load_host_cpu
     from tests.test_inputs_cpu import compare_with_golden

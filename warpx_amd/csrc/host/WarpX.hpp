@@ -599,10 +599,8 @@ public:
     // faces and streams through the lower wall, profiles/round5/README.md.)  WXA_PEC_RHO_FOLD_GUARD_COLUMNS=1: as before.
     void ApplyRhofieldBoundary(amrex::MultiFab& rho) {
         const wxa_field_view& v = rho.view();
-        static const bool fold_columns = [] {
-            const char* e = std::getenv("WXA_PEC_RHO_FOLD_GUARD_COLUMNS");
-            return e && std::atoi(e) != 0;
-        }();
+        const char* fold_env = std::getenv("WXA_PEC_RHO_FOLD_GUARD_COLUMNS");   // (read per call, like WXA_REFERENCE_CORNERS)
+        const bool fold_columns = fold_env && std::atoi(fold_env) != 0;
         struct Slab { int32_t lo[3], hi[3]; size_t at; };
         std::vector<Slab> slabs;
         size_t total = 0;
@@ -610,6 +608,9 @@ public:
             for (int d = 0; d < 3; ++d) {
                 if (m_pec_lo[d] || m_pec_hi[d] || v.ng[d] == 0) continue;   // (the backend grows its loop along wall-free directions)
                 for (int side = 0; side < 2; ++side) {
+                    // (the faces every box layout of the reference has: the domain's.  Behind a face between two bricks of
+                    // this run the columns are folded, so that the result does not depend on the brick layout.)
+                    if (!m_comm->domain_face(d, side)) continue;
                     Slab sl;
                     for (int e = 0; e < 3; ++e) { sl.lo[e] = v.lo[e]; sl.hi[e] = v.lo[e] + v.n[e]; }
                     if (side == 0) sl.hi[d] = v.lo[d] + v.ng[d];
