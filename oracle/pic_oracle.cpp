@@ -2070,7 +2070,8 @@ int orc_sim_compute_rho(orc_sim* s);
 //   z_boost = (t_i / gamma - t) c / beta     (BTDiagnostics.H:276-280),  lab position z_lab = (t_i - t / gamma) c / beta (:285-289)
 // which sweeps down through the boosted domain; each step contributes one lab-frame slice, dz_lab = c dt / (beta gamma)
 // apart (:885-890).  amrex::get_slice_data(interpolate = true) is restated as a linear interpolation between the two cell
-// centres around z_boost (AMReX is not on disk: unpinned).
+// centres around z_boost (AMReX is not on disk; pinned since round 5 by the reference's test_3d_laser_acceleration_btd.json,
+// which the host layer built on these routines meets at 3e-10).
 static double btd_dz_lab(const orc_sim* s) { return PhysConst::c * s->dt * 1.0 / s->beta_boost * 1.0 / s->gamma_boost; }
 static int btd_k_index(const orc_sim::BtdSnapshot& b, double dzl) {   // k_index_zlab (:892-905)
     return (int)std::floor((b.z_lab - b.zlo_lab) / dzl) + b.ksmall;
