@@ -160,7 +160,18 @@ public:
                 }
                 exchange_slabs(mfs, sl, d, /*mode=*/0, stream);
             }
-            if (!m_periodic[d]) continue;   // the later directions' slabs already span the whole allocation along d
+            if (!m_periodic[d]) {
+                // the later directions' slabs already span the whole allocation along d -- or, with the reference's corners,
+                // take along the guards beyond this direction's faces between bricks (just filled) and leave out the ones
+                // behind its walls
+                if (reference_corners())
+                    for (size_t c = 0; c < nf; ++c) {
+                        const wxa_field_view& f = mfs[c]->view();
+                        if (!domain_face(d, 0)) lo[c][d] = f.lo[d];
+                        if (!domain_face(d, 1)) hi[c][d] = f.lo[d] + f.n[d];
+                    }
+                continue;
+            }
             for (size_t c = 0; c < nf; ++c) {
                 const wxa_field_view& f = mfs[c]->view();
                 lo[c][d] = f.lo[d] + f.ng[d] - ng[d];
