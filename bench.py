@@ -250,6 +250,14 @@ def main():
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
                     help="N > 1: rccl = the library's own transport (ncclSend / ncclRecv groups on the library's streams, "
                          "csrc/rccl_comm.hip); torch = torch.distributed P2P through Python callbacks")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: nccl = RCCL over xGMI, one rank per GPU (the contract's path); gloo = the slabs staged "
+                         "through pinned host memory (D2H -> gloo -> H2D on the exchange's stream): the only way several "
+                         "ranks can share ONE GPU (RCCL refuses two ranks on a device) -- with --ranks-per-gpu it runs the "
+                         "whole multi-process path (bricks, count round, leaver lists, overlapped schedule) on a 1-GPU box")
+    ap.add_argument("--ranks-per-gpu", type=int, default=1,
+                    help="with --backend gloo: rank r runs on device LOCAL_RANK // ranks_per_gpu; the line's n_gpus is "
+                         "the number of devices, n_ranks the number of bricks")
     ap.add_argument("--deposit-acc", choices=["f64", "f32"], default="f64",
                     help="accumulators of the LDS deposition tiles: f64 = ds_add_f64 (the parity build, the headline line); "
                          "f32 = ds_add_f32, the throughput variant of BASELINE.json's north_star (2e-6 gate)")
@@ -279,8 +287,12 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    if args.ranks_per_gpu > 1 and args.backend != "gloo":
+        raise SystemExit("--ranks-per-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+    local_dev = local_rank // max(args.ranks_per_gpu, 1)
+    torch.cuda.set_device(local_dev)
+    device = f"cuda:{local_dev}"
+    red_dev = "cpu" if args.backend == "gloo" else device    # where the few-number reductions of the bench line live
     lib = load_product()  # raises when the HIP library is missing: no fallback
 
     transport = None
@@ -289,11 +301,16 @@ def main():
         import torch.distributed as dist
         from warpx_amd.distributed import RcclBrickTransport, TorchBrickTransport, brick_coord, brick_layout
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
         nbricks = brick_layout(world)
         coord = brick_coord(rank, nbricks)
         transport = None
-        if args.transport == "rccl":
+        if args.backend == "gloo":
+            transport = TorchBrickTransport(on_device=True, staged=True)
+        elif args.transport == "rccl":
             try:
                 transport = RcclBrickTransport(lib, timing=False)   # timed in the phase pass below, not in the headline
             except Exception as e:   # keep the run alive on the Python transport, and say so
@@ -351,14 +368,15 @@ def main():
         st = transport.stats() if rccl else None
         vals = [ms[k] for k in ("FillBoundaryEB", "SumBoundaryJ", "Redistribute", "all_three")]
         if world > 1:
-            t = torch.tensor(vals, dtype=torch.float64, device=device)
+            t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             vals = [float(v) for v in t.tolist()]
         if rank == 0:
             calls = 4 * reps   # each of the three exchanges ran `reps` times alone and `reps` times in a row
-            line = {"dry_comm": True, "n_gpus": world, "bricks": list(nbricks), "cells_per_gpu": ncells_local, "particles_per_gpu": np_local,
+            line = {"dry_comm": True, "n_gpus": world // max(args.ranks_per_gpu, 1), "n_ranks": world, "bricks": list(nbricks), "cells_per_gpu": ncells_local, "particles_per_gpu": np_local,
                     "ms_per_call_max_over_ranks": dict(zip(("FillBoundaryEB", "SumBoundaryJ", "Redistribute", "all_three"), vals)),
-                    "reps": reps, "transport": "rccl (in-library)" if rccl else ("none (one brick)" if transport is None else "torch.distributed"),
+                    "reps": reps, "transport": "rccl (in-library)" if rccl else ("none (one brick)" if transport is None else
+                                                                     ("torch.distributed gloo, host-staged" if args.backend == "gloo" else "torch.distributed")),
                     "note": "host clock around a stream sync, nothing computed between the exchanges; a step issues each of the "
                             "three once (E+B before the push, J after the deposition, particles at the end)"}
             if st:
@@ -378,7 +396,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -387,7 +405,7 @@ def main():
         e_after = energies(sim, 0)
         tot = [e_before[0], e_before[1], float(e_before[2]), e_after[0], e_after[1], float(e_after[2])]
         if world > 1:   # the job's totals, not rank 0's share
-            t = torch.tensor(tot, dtype=torch.float64, device=device)
+            t = torch.tensor(tot, dtype=torch.float64, device=red_dev)
             torch.distributed.all_reduce(t)
             tot = [float(v) for v in t.tolist()]
         tot0, tot1 = tot[0] + tot[1], tot[3] + tot[4]
@@ -442,7 +460,8 @@ def main():
                       "note": "counts over the whole run up to the end of the timed steps; milliseconds from HIP events "
                               "around every exchange in the separate phase pass (rank 0)"}
     elif transport is not None:
-        comm_stats = {"transport": "torch.distributed (Python callbacks)",
+        comm_stats = {"transport": "torch.distributed (Python callbacks)" + (", gloo, slabs staged through pinned host memory"
+                                                                             if args.backend == "gloo" else ""),
                       "exchanges_per_step": transport.n_exchanges / max(sim.istep, 1),
                       "MB_sent_per_step": transport.bytes_sent / max(sim.istep, 1) / 1e6}
     if rank == 0:
@@ -522,7 +541,7 @@ def main():
         out = {
             "metric": "particle_steps_per_s", "value": pps, "unit": "particle-steps/s",
             "cell_updates_per_s": cps,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world // max(args.ranks_per_gpu, 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.deposit_acc == "f64" else "f64 (fp32 deposition tiles)",
             "data": "synthetic",
@@ -530,7 +549,8 @@ def main():
                                    f"{args.ppc ** 3} ppc, Yee FDTD, order-{args.order} shape, {args.deposition}, "
                                    f"{args.pusher}, filter {'off' if args.no_filter else 'on'}",
                        "cells_per_gpu": ncells_local, "particles_per_gpu": np_local,
-                       "bricks": list(nbricks), "sort_interval": args.sort_interval,
+                       "bricks": list(nbricks), "n_ranks": world, "ranks_per_gpu": args.ranks_per_gpu,
+                       "backend": args.backend if world > 1 else None, "sort_interval": args.sort_interval,
                        "preroll_steps": args.preroll, "overlap_halo": bool(sim.halo_overlap),
                        "momentum_synchronisation": "inside the timed region (Evolve(K) as one run)" if args.sync_each_call
                        else "outside the timed region (the K steps are consecutive steps of one longer run)"},
@@ -574,6 +594,10 @@ def main():
                                    "exchange_ms_per_step": (comm_stats or {}).get("exchange_ms_per_step"),
                                    "note": "efficiency = ms per step of this per-GPU workload on one GPU / ms per step here "
                                            "(the driver computes its own from its N = 1 run; target >= 0.70)"}
+            if args.ranks_per_gpu > 1:   # the ranks share one device: their kernels take turns on it -- not a scaling figure
+                out["weak_scaling"]["efficiency"] = None
+                out["weak_scaling"]["note"] = (f"{args.ranks_per_gpu} ranks share each GPU (host-staged gloo): this line proves the "
+                                               "multi-process path end to end, it is not a scaling measurement")
         if sanity:
             out["sanity"] = sanity
         if world == 1 and not args.no_cpu_baseline:

@@ -37,7 +37,8 @@ def main():
     n_cell = tuple(int(v) for v in os.environ.get("WXA_TEST_NCELL", "16 16 16").split())
     prob_lo, prob_hi = (-L / 2,) * 3, (L / 2,) * 3
     # hot plasma so that particles cross brick boundaries within a few steps
-    parts = np.array(plasma.uniform_plasma(n_cell, prob_lo, prob_hi, (1, 2, 1), 1e25, 0.3, seed=11))
+    ppc = tuple(int(v) for v in os.environ.get("WXA_TEST_PPC", "1 2 1").split())
+    parts = np.array(plasma.uniform_plasma(n_cell, prob_lo, prob_hi, ppc, 1e25, float(os.environ.get("WXA_TEST_UTH", "0.3")), seed=11))
     coord = brick_coord(rank, nb)
     bn = [n_cell[d] // nb[d] for d in range(3)]
     dx = [L / n_cell[d] for d in range(3)]
@@ -46,9 +47,18 @@ def main():
     mine = np.ones(parts.shape[1], dtype=bool)
     for d in range(3):
         mine &= (parts[d] >= lo[d]) & (parts[d] < hi[d])
-    transport = TorchBrickTransport(on_device=False)
-    # WXA_WORKER_LIB=hipcpu: the HIP kernels themselves (tests/hipcpu execution model) instead of the oracle kernels
-    lib = load_hip_on_cpu() if os.environ.get("WXA_WORKER_LIB") == "hipcpu" else load_host_cpu()
+    # WXA_WORKER_LIB=hipcpu: the HIP kernels themselves (tests/hipcpu execution model) instead of the oracle kernels;
+    # WXA_WORKER_LIB=product: libwarpx_amd.so on the GPU -- every rank on cuda:0, device buffers staged through pinned host
+    # memory over gloo (RCCL refuses two ranks on one device): the product as N real processes on a 1-GPU box
+    which = os.environ.get("WXA_WORKER_LIB", "")
+    if which == "product":
+        from warpx_amd import load_product
+        torch.cuda.set_device(0)
+        lib = load_product()
+        transport = TorchBrickTransport(on_device=True, staged=True)
+    else:
+        transport = TorchBrickTransport(on_device=False)
+        lib = load_hip_on_cpu() if which == "hipcpu" else load_host_cpu()
     sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, sort_interval=int(os.environ.get("WXA_TEST_SORT", "2")),
                    nbricks=nb, coord=coord, comm=transport.comm, overlap_halo=overlap, maxwell_solver=solver)
     assert sim.halo_overlap == bool(overlap)
@@ -72,7 +82,9 @@ def main():
     p_local = sim.particles(sid)
     inside = all(np.all((p_local[d] >= lo[d]) & (p_local[d] < hi[d])) for d in range(3))
     payload = {"coord": coord, "fields": local, "ekin": mom["ekin"], "np": p_local.shape[1],
-               "abs_p": mom["abs_momentum"], "inside": bool(inside), "exchanges": transport.n_exchanges}
+               "abs_p": mom["abs_momentum"], "inside": bool(inside), "exchanges": transport.n_exchanges,
+               "bytes_sent": transport.bytes_sent, "pid": os.getpid()}
+    sim.close()
     gathered = [None] * world
     dist.gather_object(payload, gathered if rank == 0 else None, dst=0)
     if rank == 0:
@@ -89,16 +101,30 @@ def main():
                 digest.update(np.ascontiguousarray(g["fields"][n]).tobytes())
         report = {"ok": True, "errors": {}, "digest": digest.hexdigest(), "np_total": sum(g["np"] for g in gathered),
                   "np_ref": int(parts.shape[1]), "inside": all(g["inside"] for g in gathered),
-                  "exchanges": gathered[0]["exchanges"]}
-        for n in FIELDS:
-            full = ref.field_valid(n)
+                  "exchanges": gathered[0]["exchanges"], "bytes_sent": [g["bytes_sent"] for g in gathered],
+                  "pids": sorted(set(g["pid"] for g in gathered))}
+
+        def worst_over_bricks(full, n):
             worst = 0.0
             for g in gathered:
                 c = g["coord"]
                 a = g["fields"][n]
                 sl = tuple(slice(c[d] * bn[d], c[d] * bn[d] + a.shape[d]) for d in range(3))
                 worst = max(worst, float(np.max(np.abs(a - full[sl])) / max(np.max(np.abs(full)), 1e-300)))
-            report["errors"][n] = worst
+            return worst
+
+        for n in FIELDS:
+            report["errors"][n] = worst_over_bricks(ref.field_valid(n), n)
+        if which == "product":   # ... and against the single-domain run of the HIP path itself
+            one = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, maxwell_solver=solver,
+                           sort_interval=int(os.environ.get("WXA_TEST_SORT", "2")))
+            oid = one.add_species(-plasma.Q_E, plasma.M_E, list(parts))
+            one.evolve(steps)
+            one.compute_rho()
+            omom = particle_moments(one, oid)
+            report["errors_vs_one_hip_brick"] = {n: worst_over_bricks(one.field_valid(n), n) for n in FIELDS}
+            report["ekin_rel_vs_one_hip_brick"] = abs(sum(g["ekin"] for g in gathered) - omom["ekin"]) / omom["ekin"]
+            one.close()
         ek = sum(g["ekin"] for g in gathered)
         report["ekin_rel"] = abs(ek - rmom["ekin"]) / rmom["ekin"]
         ap = np.sum([g["abs_p"] for g in gathered], axis=0)

@@ -494,3 +494,47 @@ def test_bricks_flush_one_back_transformed_plotfile_on_gpu(product, tmp_path):
             for row in range(7):
                 assert np.max(np.abs(pa[row] - pb[row])) <= 1e-9 * max(np.max(np.abs(pa[row])), 1e-300), (i, name, row)
     assert some_particles
+
+
+# ---- the product as N REAL processes on the one MI355X of a box (round 6) ---------------------------------------------
+# Every rank is a process of its own with its own HIP context on cuda:0, one brick each; RCCL refuses two ranks on one
+# device, so the slabs travel device -> pinned host -> gloo -> pinned host -> device on the exchange's stream
+# (warpx_amd.distributed.TorchBrickTransport(staged=True)).  What the thread bricks above cannot cover: the count round,
+# the leaver lists and the overlapped schedule between processes that do not share an address space or a turn lock.
+def _spawn_bricks(nb, order, filt, overlap, ncell, port, tmp_path, steps=6, extra_env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "report.json")
+    n = nb[0] * nb[1] * nb[2]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "multibrick_worker.py"), *[str(v) for v in nb], str(order), str(filt), out, str(overlap)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(max(1, (os.cpu_count() or 8) // n)), WXA_WORKER_LIB="product",
+               WXA_TEST_NCELL=" ".join(str(v) for v in ncell), WXA_TEST_STEPS=str(steps), **(extra_env or {}))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.skipif(not H.ON_GPU, reason="processes that share the one GPU of the box")
+@pytest.mark.parametrize("nb,ncell,overlap,port", [
+    ((1, 1, 2), (64, 64, 128), 1, 29711),    # bench.py's 2-GPU layout, bricks of 64^3, the overlapped schedule
+    ((2, 2, 2), (128, 128, 128), 1, 29712),  # the 8-GPU layout (BASELINE config 4's), bricks of 64^3
+    ((2, 2, 2), (128, 128, 128), 0, 29713),  # ... and everything on one stream
+])
+def test_bricks_as_processes_on_one_gpu(nb, ncell, overlap, port, tmp_path):
+    """2 and 8 processes on cuda:0 against (a) the single-domain oracle and (b) the single-domain run of the HIP path, at
+    the step tests' gates: 1e-10 on the energies / moments, 1e-9 point-wise (relative to the field's maximum)."""
+    rep = _spawn_bricks(nb, 3, 1, overlap, ncell, port, tmp_path)
+    print(rep)
+    n = nb[0] * nb[1] * nb[2]
+    assert len(rep["pids"]) == n                      # really n processes
+    assert rep["np_total"] == rep["np_ref"] and rep["inside"]
+    assert rep["exchanges"] > 0 and all(b > 0 for b in rep["bytes_sent"])
+    for name, err in rep["errors"].items():
+        assert err < 1e-9, (name, err)
+    for name, err in rep["errors_vs_one_hip_brick"].items():
+        assert err < 1e-9, (name, err)
+    assert rep["ekin_rel"] < 1e-10 and rep["abs_p_rel"] < 1e-10 and rep["ekin_rel_vs_one_hip_brick"] < 1e-10

@@ -72,6 +72,30 @@ def test_uniform_plasma_parity(oracle, product, order, depos, pusher, filt):
         assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), name
 
 
+@pytest.mark.parametrize("filt", [1, 0])
+def test_baseline_config_1_exactly(oracle, product, filt):
+    """BASELINE.json configs[0] / SURVEY.md 8(d) C1 itself on the HIP path: 64^3 cells, L = 40 um, one electron per cell
+    at the cell centre, n = 1e25 m^-3, u_th = 0.01 c (seed 12345), order 1, Esirkepov, Boris, Yee, cfl 1, the bilinear
+    filter on (the reference's default) and off, 10 steps -- the case bench.py's cpu_baseline.serial leg times on the
+    oracle.  Gates: 1e-10 on energies and moments, 1e-9 point-wise."""
+    n_cell = (64, 64, 64)
+    L = 40e-6
+    parts = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (1, 1, 1), 1e25, 0.01, seed=12345)
+    assert len(parts[0]) == 64 ** 3
+    dx = L / 64
+    assert np.allclose((np.asarray(parts[0]) + L / 2) / dx % 1.0, 0.5)    # at the cell centre
+    species = [(-plasma.Q_E, plasma.M_E, parts)]
+    kw = dict(nox=1, galerkin=1, particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV,
+              use_filter=filt, cfl=1.0)
+    so, io = _run(oracle, n_cell, species, 10, **kw)
+    sg, ig = _run(product, n_cell, species, 10, **kw)
+    assert abs(so.dt - sg.dt) == 0.0
+    _compare(_metrics(sg, ig), _metrics(so, io))
+    for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz"):
+        a, b = sg.field_valid(name), so.field_valid(name)
+        assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), name
+
+
 def test_uniform_plasma_parity_in_the_benchmark_regime(oracle, product):
     """HIP path against the oracle stepper where bench.py runs: 8 particles per cell at random positions (Poisson
     cell occupancy: odd runs, unmergeable pairs, tile tails), u_th = 0.01 c with the thermalised crossing rate from the

@@ -70,15 +70,22 @@ def _as_tensor(ptr, nbytes, on_device):
 
 
 class TorchBrickTransport:
-    """Owns the ctypes callbacks (must outlive the simulation)."""
+    """Owns the ctypes callbacks (must outlive the simulation).
 
-    def __init__(self, on_device: bool, group=None):
+    staged=True (device buffers over a host backend, "gloo"): every message is copied to pinned host memory on the
+    exchange's stream, sent with torch.distributed, and copied back to the device on the same stream -- the transport of
+    several ranks that share ONE GPU (RCCL refuses two ranks on a device), i.e. the only way the multi-process path of
+    BASELINE configs 4 and 5 (bricks, leaver lists, the overlapped schedule) runs on a 1-GPU box."""
+
+    def __init__(self, on_device: bool, group=None, staged: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.nranks = dist.get_world_size(group)
         self.on_device = on_device
+        self.staged = bool(staged and on_device)
+        self._pinned = {}
         self.n_exchanges = 0
         self._streams = {}
         self.bytes_sent = 0
@@ -102,6 +109,8 @@ class TorchBrickTransport:
     def _exchange(self, ctx, nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf, recv_bytes, stream):
         try:
             import torch
+            if self.staged:
+                return self._exchange_staged(nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf, recv_bytes, stream)
             if self.on_device and stream:
                 # the library's exchange stream (overlap_halo): RCCL orders its transfers behind the *current*
                 # torch stream, so make that stream current for the duration of the call
@@ -151,11 +160,67 @@ class TorchBrickTransport:
             print(f"[warpx_amd.distributed] exchange failed: {e}", flush=True)
             return -1
 
+    def _pinned_like(self, kind, ptr, nbytes):
+        """Pinned host twin of the device buffer [ptr, ptr + nbytes): kept per buffer (the host layer's staging buffers keep
+        their addresses), so that a copy still in flight on the stream never loses its source."""
+        import torch
+        key = (kind, int(ptr), int(nbytes))
+        t = self._pinned.get(key)
+        if t is None:
+            if len(self._pinned) > 512:
+                torch.cuda.synchronize()
+                self._pinned.clear()
+            t = self._pinned[key] = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
+        return t
+
+    def _exchange_staged(self, nmsg, send_peer, send_buf, send_bytes, recv_peer, recv_buf, recv_bytes, stream):
+        """Device buffers over a host backend.  Stream-ordered like the RCCL transport: the packed slabs are read behind
+        whatever the stream holds (D2H on it), the host waits for that stream only, and the received slabs are written by
+        H2D copies on the same stream -- the unpack kernels the host layer enqueues next are ordered behind them."""
+        import torch
+        dist = self.dist
+        st = self._external_stream(stream) if stream else torch.cuda.current_stream()
+        sends = [(int(send_peer[i]), send_buf[i], int(send_bytes[i])) for i in range(nmsg)]
+        recvs = [(int(recv_peer[i]), recv_buf[i], int(recv_bytes[i])) for i in range(nmsg)]
+        ops, landing = [], []
+        with torch.cuda.stream(st):
+            nth = {}
+            for i, (sp, sb, sn) in enumerate(sends):
+                k = nth.get(("s", sp), 0)
+                nth[("s", sp)] = k + 1
+                if sn == 0:
+                    continue
+                if sp == self.rank:
+                    rp, rb, rn = recvs[i]
+                    assert rp == self.rank and rn == sn
+                    _as_tensor(rb, rn, True).copy_(_as_tensor(sb, sn, True), non_blocking=True)
+                    continue
+                h = self._pinned_like("s", sb, sn)
+                h.copy_(_as_tensor(sb, sn, True), non_blocking=True)
+                ops.append(dist.P2POp(dist.isend, h, sp, self.group, tag=k))
+                self.bytes_sent += sn
+            for (rp, rb, rn) in recvs:
+                k = nth.get(("r", rp), 0)
+                nth[("r", rp)] = k + 1
+                if rp != self.rank and rn > 0:
+                    h = self._pinned_like("r", rb, rn)
+                    landing.append((h, rb, rn))
+                    ops.append(dist.P2POp(dist.irecv, h, rp, self.group, tag=k))
+            # also the last exchange's H2D copies out of the pinned receive buffers have finished after this wait
+            st.synchronize()
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for (h, rb, rn) in landing:
+                _as_tensor(rb, rn, True).copy_(h, non_blocking=True)
+        self.n_exchanges += 1
+        return 0
+
     def _exchange_counts(self, ctx, nmsg, send_peer, send_val, recv_peer, recv_val):
         try:
             import torch
             dist = self.dist
-            dev = "cuda" if self.on_device else "cpu"
+            dev = "cuda" if (self.on_device and not self.staged) else "cpu"
             ops, outs = [], []
             for i in range(nmsg):
                 if int(send_peer[i]) == self.rank:
