@@ -258,6 +258,9 @@ def main():
     ap.add_argument("--ranks-per-gpu", type=int, default=1,
                     help="with --backend gloo: rank r runs on device LOCAL_RANK // ranks_per_gpu; the line's n_gpus is "
                          "the number of devices, n_ranks the number of bricks")
+    ap.add_argument("--single-precision-comms", action="store_true",
+                    help="N > 1: warpx.do_single_precision_comms -- float on the wire of the guard exchanges (half the xGMI "
+                         "bytes; the reference's own lever, ablastr/utils/Communication.cpp:37-56); off in the headline line")
     ap.add_argument("--deposit-acc", choices=["f64", "f32"], default="f64",
                     help="accumulators of the LDS deposition tiles: f64 = ds_add_f64 (the parity build, the headline line); "
                          "f32 = ds_add_f32, the throughput variant of BASELINE.json's north_star (2e-6 gate)")
@@ -330,6 +333,8 @@ def main():
                    sort_interval=args.sort_interval, nbricks=nbricks, coord=coord,
                    comm=transport.comm if transport else None,
                    overlap_halo=(1 if world > 1 else 0) if args.overlap < 0 else args.overlap)
+    if args.single_precision_comms and world > 1:
+        sim.set_single_precision_comms(True)
     box_lo = tuple(coord[d] * nb for d in range(3))
     parts = device_uniform_plasma(n_cell, prob_lo, prob_hi, (args.ppc,) * 3, 1e25, 0.01, 12345 + rank,
                                   box_lo, (nb,) * 3, device)
@@ -551,6 +556,7 @@ def main():
                        "cells_per_gpu": ncells_local, "particles_per_gpu": np_local,
                        "bricks": list(nbricks), "n_ranks": world, "ranks_per_gpu": args.ranks_per_gpu,
                        "backend": args.backend if world > 1 else None, "sort_interval": args.sort_interval,
+                       "single_precision_comms": bool(args.single_precision_comms and world > 1),
                        "preroll_steps": args.preroll, "overlap_halo": bool(sim.halo_overlap),
                        "momentum_synchronisation": "inside the timed region (Evolve(K) as one run)" if args.sync_each_call
                        else "outside the timed region (the K steps are consecutive steps of one longer run)"},

@@ -503,6 +503,16 @@ wxa_status wxa_pack_box(const wxa_field_view* f, const int32_t blo[3], const int
                         double* buf, void* stream);
 wxa_status wxa_unpack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
                           const double* buf, int mode, void* stream);
+/* ... with comm_float_type = float on the wire: warpx.do_single_precision_comms
+ * (Source/ablastr/utils/Communication.cpp:37-56 ParallelCopy, :90-106 FillBoundary, :159-170 SumBoundary;
+ * Communication.H:30 comm_float_type).  The slab is rounded to float when packed and widened when unpacked
+ * (mode 1 adds the widened value in double); the arrays themselves stay double.  The reference rounds the WHOLE
+ * array through a float copy at every exchange (mixedCopy of valid points and guards, both ways); here only what
+ * travels is rounded -- the points a brick owns keep their double values, a strictly smaller perturbation. */
+wxa_status wxa_pack_box_f32(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
+                            float* buf, void* stream);
+wxa_status wxa_unpack_box_f32(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
+                              const float* buf, int mode, void* stream);
 
 /* Zero a field including guards (MultiFab::setVal(0), MultiParticleContainer.cpp:470-472). */
 wxa_status wxa_field_set_zero(const wxa_field_view* f, void* stream);
@@ -710,6 +720,15 @@ wxa_status wxa_sim_evolve(wxa_sim* s, int32_t numsteps);
  * momenta are wanted at the time of the positions (diagnostics, checksums).  Default: on = 1, the reference's behaviour. */
 wxa_status wxa_sim_set_synchronize_at_end(wxa_sim* s, int32_t on);
 wxa_status wxa_sim_synchronize(wxa_sim* s);
+/* warpx.safe_guard_cells (Source/WarpX.cpp:625, Source/Parallelization/GuardCellManager.cpp:297-308,
+ * WarpXComm.cpp:759,824, WarpXEvolve.cpp:449-451): every FillBoundary exchanges all allocated guard cells and every
+ * exchange of the reference's schedule is issued; the valid points are unchanged.  Before the first step; refused
+ * together with overlap_halo. */
+wxa_status wxa_sim_set_safe_guard_cells(wxa_sim* s, int32_t on);
+/* warpx.do_single_precision_comms (Source/WarpX.cpp:614, ablastr/utils/Communication.cpp:37-56,90-106,159-170): float
+ * on the wire of every guard exchange between bricks (wxa_pack_box_f32 / wxa_unpack_box_f32), half the xGMI bytes.
+ * Every brick of a run must ask for the same (checked before the first step). */
+wxa_status wxa_sim_set_single_precision_comms(wxa_sim* s, int32_t on);
 /* particles.E_external_particle / particles.B_external_particle (constant external fields on the particles of
  * species `id`; the reference keeps them per container and reads them from the `particles.` block) */
 wxa_status wxa_sim_set_external_particle_fields(wxa_sim* s, int32_t id, const double E[3], const double B[3]);

@@ -1126,6 +1126,29 @@ int orc_unpack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t 
     return 0;
 }
 
+// warpx.do_single_precision_comms: comm_float_type on the wire (ablastr/utils/Communication.cpp:37-56,90-106,159-170)
+int orc_pack_box_f32(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], float* buf, void*) {
+    const Arr a(*f);
+    int64_t t = 0;
+    for (int k = blo[2]; k < bhi[2]; ++k)
+        for (int j = blo[1]; j < bhi[1]; ++j)
+            for (int i = blo[0]; i < bhi[0]; ++i) buf[t++] = static_cast<float>(a(i, j, k));
+    return 0;
+}
+
+int orc_unpack_box_f32(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], const float* buf,
+                       int mode, void*) {
+    const Arr a(*f);
+    int64_t t = 0;
+    for (int k = blo[2]; k < bhi[2]; ++k)
+        for (int j = blo[1]; j < bhi[1]; ++j)
+            for (int i = blo[0]; i < bhi[0]; ++i) {
+                if (mode == 0) a(i, j, k) = static_cast<double>(buf[t++]);
+                else a(i, j, k) += static_cast<double>(buf[t++]);
+            }
+    return 0;
+}
+
 int orc_partition_particles(const wxa_particle_view* src, const wxa_particle_view* dst, int dim, double lo,
                             double hi, int64_t counts[3], void*, void*) {
     const double* pos = dim == 0 ? src->x : (dim == 1 ? src->y : src->z);

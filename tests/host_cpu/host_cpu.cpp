@@ -36,6 +36,8 @@ int orc_sync_nodal_periodic(const wxa_field_view*, const int*, void*);
 int orc_sum_boundary_periodic(const wxa_field_view*, const int*, const int*, void*);
 int orc_pack_box(const wxa_field_view*, const int32_t*, const int32_t*, double*, void*);
 int orc_unpack_box(const wxa_field_view*, const int32_t*, const int32_t*, const double*, int, void*);
+int orc_pack_box_f32(const wxa_field_view*, const int32_t*, const int32_t*, float*, void*);
+int orc_unpack_box_f32(const wxa_field_view*, const int32_t*, const int32_t*, const float*, int, void*);
 int orc_field_set_zero(const wxa_field_view*, void*);
 int orc_enforce_periodic(const wxa_particle_view*, const double*, const double*, const int*, void*);
 int orc_sort_particles_by_cell(const wxa_particle_view*, const wxa_particle_view*, const double*, const double*,
@@ -147,6 +149,7 @@ const Backend* cpu_backend() {
         b.sync_nodal_periodic = orc_sync_nodal_periodic;
         b.sum_boundary_periodic = orc_sum_boundary_periodic;
         b.pack_box = orc_pack_box; b.unpack_box = orc_unpack_box;
+        b.pack_box_f32 = orc_pack_box_f32; b.unpack_box_f32 = orc_unpack_box_f32;
         b.field_set_zero = orc_field_set_zero;
         b.enforce_periodic = orc_enforce_periodic;
         b.sort_particles_by_cell = orc_sort_particles_by_cell;

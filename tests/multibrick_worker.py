@@ -62,6 +62,11 @@ def main():
     sim = WarpXSim(lib, n_cell, prob_lo, prob_hi, nox=order, use_filter=filt, sort_interval=int(os.environ.get("WXA_TEST_SORT", "2")),
                    nbricks=nb, coord=coord, comm=transport.comm, overlap_halo=overlap, maxwell_solver=solver)
     assert sim.halo_overlap == bool(overlap)
+    if os.environ.get("WXA_TEST_SAFE_GUARD_CELLS") == "1":
+        sim.set_safe_guard_cells(True)
+    wire = os.environ.get("WXA_TEST_F32_WIRE", "")
+    if wire == "1" or (wire == "rank0" and rank == 0):   # "rank0": the bricks disagree -- refused before the first step
+        sim.set_single_precision_comms(True)
     sid = sim.add_species(-plasma.Q_E, plasma.M_E, list(parts[:, mine]))
     dry = None
     if os.environ.get("WXA_TEST_DRY_COMM") == "1":   # bench.py --dry-comm in the middle of a run: it must not disturb it

@@ -253,6 +253,29 @@ def test_pack_unpack_roundtrip(product):
     assert np.array_equal(b[-2 + 3:5 + 3, 1 + 3:9 + 3, 0 + 3:16 + 3], 2 * want)
 
 
+def test_pack_unpack_f32_wire_against_the_oracle(oracle, product):
+    """warpx.do_single_precision_comms: the slab rounded to float when packed, widened (and, for SumBoundary, added in
+    double) when unpacked -- bit for bit what the oracle's host-side helpers do."""
+    import torch
+    (f,) = H.random_fields(("Ey",), NCELL, 3, 81)
+    fd = f.copy_to(DEV, True)
+    lo = (C.c_int32 * 3)(-2, 1, 0)
+    hi = (C.c_int32 * 3)(5, 9, 16)
+    n = 7 * 8 * 16
+    buf = torch.zeros(n, dtype=torch.float32, device=DEV)
+    ref = np.zeros(n, dtype=np.float32)
+    product.pack_box_f32(C.byref(fd.view), lo, hi, buf.data_ptr(), None)
+    oracle.pack_box_f32(C.byref(f.view), lo, hi, ref.ctypes.data, None)
+    got = buf.cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert not np.array_equal(got.astype(np.float64), f.to_numpy()[1:8, 4:12, 3:19].transpose(2, 1, 0).reshape(-1))   # it did round
+    for mode in (1, 0):
+        product.unpack_box_f32(C.byref(fd.view), lo, hi, buf.data_ptr(), mode, None)
+        oracle.unpack_box_f32(C.byref(f.view), lo, hi, ref.ctypes.data, mode, None)
+        _sync(product)
+        assert np.array_equal(fd.to_numpy(), f.to_numpy())
+
+
 def test_enforce_periodic_and_sort(oracle, product):
     import torch
     parts = H.random_particles(30000, NCELL, 90)

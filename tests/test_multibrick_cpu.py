@@ -324,3 +324,43 @@ def test_back_transformed_diagnostics_on_bricks_match_one_brick(nb, nranks, port
         a, b = (q[:, np.lexsort((q[2], np.round(q[1] / 1e-10), np.round(q[0] / 1e-10)))] for q in (a, b))
         for row in range(7):
             assert np.max(np.abs(a[row] - b[row])) <= 1e-9 * max(np.max(np.abs(b[row])), 1e-300), (i, row)
+
+
+def test_safe_guard_cells_leaves_the_valid_points_unchanged(tmp_path):
+    """warpx.safe_guard_cells (GuardCellManager.cpp:297-308, WarpXComm.cpp:759,824, WarpXEvolve.cpp:449-451): all
+    allocated guard cells in every FillBoundary and every exchange of the reference's schedule issued -- more exchanges,
+    the same valid points bit for bit (the CPU backend's deposition is reproducible)."""
+    fast = _run((1, 2, 2), 3, 1, tmp_path, 29661)
+    safe = _run((1, 2, 2), 3, 1, tmp_path, 29662, extra_env={"WXA_TEST_SAFE_GUARD_CELLS": "1"})
+    assert safe["exchanges"] > fast["exchanges"]
+    assert sum(safe["bytes_sent"]) > sum(fast["bytes_sent"])
+    assert safe["digest"] == fast["digest"]
+    assert safe["np_total"] == safe["np_ref"] and safe["inside"]
+
+
+def test_single_precision_comms_halves_the_wire_and_stays_inside_the_reference_gate(tmp_path):
+    """warpx.do_single_precision_comms (ablastr/utils/Communication.cpp:37-56,90-106,159-170): float on the wire of every
+    guard exchange.  Half the bytes of the field exchanges; against the fp64-wire run and the oracle the fields stay
+    within single precision (the reference's own gate for its single-precision runs is 2e-6 on the checksums)."""
+    f64 = _run((2, 2, 2), 3, 1, tmp_path, 29663)
+    f32 = _run((2, 2, 2), 3, 1, tmp_path, 29664, extra_env={"WXA_TEST_F32_WIRE": "1"})
+    assert f32["digest"] != f64["digest"]                      # it took effect ...
+    assert sum(f32["bytes_sent"]) < 0.62 * sum(f64["bytes_sent"])    # ... on the field slabs (the particles stay fp64)
+    assert f32["np_total"] == f32["np_ref"] and f32["inside"]
+    for name, err in f32["errors"].items():
+        assert err < 2e-6, (name, err)
+    assert f32["ekin_rel"] < 2e-6 and f32["abs_p_rel"] < 2e-6
+    for name, err in f64["errors"].items():                    # off: as before
+        assert err < 1e-10, (name, err)
+
+
+def test_bricks_that_disagree_on_a_switch_are_refused_before_the_first_step(tmp_path):
+    """a switch that changes the slab sizes set on some ranks only would hang or corrupt the exchanges.
+    The bricks compare their switches over the count round in their first Evolve: every rank fails with the reason."""
+    out = str(tmp_path / "r.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29665", os.path.join(ROOT, "tests", "multibrick_worker.py"), "1", "1", "2", "3", "1", out, "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", WXA_TEST_F32_WIRE="rank0"))
+    assert r.returncode != 0
+    assert "do not share their exchange switches" in r.stdout + r.stderr

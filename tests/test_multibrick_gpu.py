@@ -538,3 +538,16 @@ def test_bricks_as_processes_on_one_gpu(nb, ncell, overlap, port, tmp_path):
     for name, err in rep["errors_vs_one_hip_brick"].items():
         assert err < 1e-9, (name, err)
     assert rep["ekin_rel"] < 1e-10 and rep["abs_p_rel"] < 1e-10 and rep["ekin_rel_vs_one_hip_brick"] < 1e-10
+
+
+@pytest.mark.skipif(not H.ON_GPU, reason="processes that share the one GPU of the box")
+def test_single_precision_comms_between_processes(tmp_path):
+    """warpx.do_single_precision_comms on the HIP path between 8 real processes: wxa_pack_box_f32 / wxa_unpack_box_f32 on
+    the wire of every guard exchange, the fields inside single precision of the fp64 single-domain runs."""
+    rep = _spawn_bricks((2, 2, 2), 3, 1, 1, (128, 128, 128), 29714, tmp_path, extra_env={"WXA_TEST_F32_WIRE": "1"})
+    print(rep)
+    assert rep["np_total"] == rep["np_ref"] and rep["inside"]
+    for name, err in rep["errors"].items():
+        assert err < 2e-6, (name, err)
+    assert max(rep["errors"].values()) > 1e-12        # the wire really was float
+    assert rep["ekin_rel"] < 2e-6 and rep["abs_p_rel"] < 2e-6

@@ -213,6 +213,8 @@ _INPUTS_SIGS = {
     "sim_btd_box": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sim_set_synchronize_at_end": (C.c_int, [C.c_void_p, C.c_int32]),
     "sim_synchronize": (C.c_int, [C.c_void_p]),
+    "sim_set_safe_guard_cells": (C.c_int, [C.c_void_p, C.c_int32]),
+    "sim_set_single_precision_comms": (C.c_int, [C.c_void_p, C.c_int32]),
     "parser_eval": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
     "last_error": (C.c_char_p, []),
@@ -279,6 +281,8 @@ _PRODUCT_SIGS = {
     "push_sort_pending": (C.c_int32, [C.c_void_p, _PPV]),
     "pack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "unpack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
+    "pack_box_f32": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
+    "unpack_box_f32": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
     "copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "device_synchronize": (C.c_int, []),
@@ -308,6 +312,8 @@ _ORACLE_SIGS = {
     "cell_centered_abs_sum": (C.c_double, [_PFV]),
     "abs_sum": (C.c_double, [C.c_void_p, C.c_int64, C.c_double]),
 
+    "pack_box_f32": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
+    "unpack_box_f32": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
     "num_threads": (C.c_int, []),
     "set_num_threads": (C.c_int, [C.c_int]),
     "add_plasma": (C.c_int, [_PPV, C.POINTER(PlasmaInjector), _D3, _I32_3, _D3, _D3, _D3,

@@ -541,26 +541,30 @@ sum_periodic_multi_kernel(PeriodicSumSet a, int d) {
     }
 }
 
+// T = double: the slab as it is; T = float: warpx.do_single_precision_comms (ablastr/utils/Communication.cpp:37-56,
+// 90-106,159-170) -- the wire carries comm_float_type, the arrays stay double
+template <class T>
 __global__ void __launch_bounds__(256)
-pack_kernel(DevF f, BoxN box, double* __restrict__ buf) {
+pack_kernel(DevF f, BoxN box, T* __restrict__ buf) {
     const long total = (long)box.n[0] * box.n[1] * box.n[2];
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int a = (int)(t % box.n[0]);
         const int b = (int)((t / box.n[0]) % box.n[1]);
         const int c = (int)(t / ((long)box.n[0] * box.n[1]));
-        buf[t] = f.p[f.off(box.lo[0] + a, box.lo[1] + b, box.lo[2] + c)];
+        buf[t] = static_cast<T>(f.p[f.off(box.lo[0] + a, box.lo[1] + b, box.lo[2] + c)]);
     }
 }
 
+template <class T>
 __global__ void __launch_bounds__(256)
-unpack_kernel(DevF f, BoxN box, const double* __restrict__ buf, int mode) {
+unpack_kernel(DevF f, BoxN box, const T* __restrict__ buf, int mode) {
     const long total = (long)box.n[0] * box.n[1] * box.n[2];
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int a = (int)(t % box.n[0]);
         const int b = (int)((t / box.n[0]) % box.n[1]);
         const int c = (int)(t / ((long)box.n[0] * box.n[1]));
         double* q = &f.p[f.off(box.lo[0] + a, box.lo[1] + b, box.lo[2] + c)];
-        if (mode == 0) *q = buf[t]; else *q += buf[t];
+        if (mode == 0) *q = static_cast<double>(buf[t]); else *q += static_cast<double>(buf[t]);
     }
 }
 
@@ -1314,22 +1318,25 @@ wxa_status wxa_sum_boundary_periodic(const wxa_field_view* f, const int src_ng[3
     return WXA_OK;
 }
 
-wxa_status wxa_pack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], double* buf,
-                        void* stream) {
+}  // extern "C"
+
+template <class T>
+static wxa_status pack_box_t(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], T* buf, void* stream) {
     WXA_REQUIRE(f && view_ok(*f) && buf, "bad argument");
     WXA_REQUIRE(box_inside(*f, blo, bhi), "box outside the allocation");
     BoxN b;
     for (int d = 0; d < 3; ++d) { b.lo[d] = blo[d]; b.n[d] = bhi[d] - blo[d]; }
     const long total = (long)b.n[0] * b.n[1] * b.n[2];
     if (total == 0) return WXA_OK;
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(*f), b,
+    hipLaunchKernelGGL(pack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(*f), b,
                        buf);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
 
-wxa_status wxa_unpack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
-                          const double* buf, int mode, void* stream) {
+template <class T>
+static wxa_status unpack_box_t(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], const T* buf, int mode,
+                               void* stream) {
     WXA_REQUIRE(f && view_ok(*f) && buf, "bad argument");
     WXA_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (copy) or 1 (add)");
     WXA_REQUIRE(box_inside(*f, blo, bhi), "box outside the allocation");
@@ -1337,11 +1344,22 @@ wxa_status wxa_unpack_box(const wxa_field_view* f, const int32_t blo[3], const i
     for (int d = 0; d < 3; ++d) { b.lo[d] = blo[d]; b.n[d] = bhi[d] - blo[d]; }
     const long total = (long)b.n[0] * b.n[1] * b.n[2];
     if (total == 0) return WXA_OK;
-    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(*f), b,
+    hipLaunchKernelGGL(unpack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_devf(*f), b,
                        buf, mode);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
+
+extern "C" {
+
+wxa_status wxa_pack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], double* buf,
+                        void* stream) { return pack_box_t<double>(f, blo, bhi, buf, stream); }
+wxa_status wxa_unpack_box(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
+                          const double* buf, int mode, void* stream) { return unpack_box_t<double>(f, blo, bhi, buf, mode, stream); }
+wxa_status wxa_pack_box_f32(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3], float* buf,
+                            void* stream) { return pack_box_t<float>(f, blo, bhi, buf, stream); }
+wxa_status wxa_unpack_box_f32(const wxa_field_view* f, const int32_t blo[3], const int32_t bhi[3],
+                              const float* buf, int mode, void* stream) { return unpack_box_t<float>(f, blo, bhi, buf, mode, stream); }
 
 }  // extern "C"
 

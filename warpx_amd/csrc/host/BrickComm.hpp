@@ -48,6 +48,39 @@ public:
         const int total = m_nb[0] * m_nb[1] * m_nb[2];
         if (total > 1 && !m_has_comm) throw std::runtime_error("BrickComm: more than one brick needs a wxa_comm");
         if (m_has_comm && m_comm.nranks != total) throw std::runtime_error("BrickComm: nranks != number of bricks");
+        // read once, here: a switch that changes the slab sizes must not change in the middle of a run, and the bricks of
+        // a run compare theirs before the first step (switches_word / VerifySwitchesAgree)
+        const char* e = std::getenv("WXA_REFERENCE_CORNERS");
+        m_reference_corners = !(e && std::atoi(e) == 0);
+    }
+
+    // warpx.do_single_precision_comms (Source/WarpX.cpp:614; ablastr/utils/Communication.cpp:37-56,90-106,159-170):
+    // comm_float_type = float on the wire between bricks -- half the xGMI bytes of every FillBoundary and SumBoundary
+    void set_single_precision_comms(bool on) {
+        if (on && (!m_be->pack_box_f32 || !m_be->unpack_box_f32))
+            throw std::runtime_error("warpx.do_single_precision_comms: not in this backend");
+        m_f32_wire = on;
+    }
+    bool single_precision_comms() const { return m_f32_wire; }
+    void set_reference_corners(bool on) { m_reference_corners = on; }
+    // The switches every brick of a run must share (they decide which slabs travel and how many bytes a point takes):
+    // one word per brick, compared over the count round before the first step.  `extra`: the caller's own switches.
+    void VerifySwitchesAgree(int64_t extra) {
+        const int nranks = m_nb[0] * m_nb[1] * m_nb[2];
+        if (nranks == 1) return;
+        const int me = rank_of(m_coord);
+        const int64_t word = (m_reference_corners ? 1 : 0) | (m_f32_wire ? 2 : 0) | (extra << 2);
+        std::vector<int32_t> peer;
+        for (int r = 0; r < nranks; ++r) if (r != me) peer.push_back(r);
+        std::vector<int64_t> mine(peer.size(), word), theirs(peer.size(), -1);
+        exchange_counts_with((int)peer.size(), peer.data(), mine.data(), theirs.data());
+        for (size_t i = 0; i < peer.size(); ++i)
+            if (theirs[i] != word)
+                throw std::runtime_error("the bricks of this run do not share their exchange switches (brick " + std::to_string(me) +
+                                         ": " + std::to_string(word) + ", brick " + std::to_string(peer[i]) + ": " +
+                                         std::to_string(theirs[i]) + "): WXA_REFERENCE_CORNERS, warpx.do_single_precision_comms, "
+                                         "warpx.safe_guard_cells, WXA_NO_GUARD_LAYER and WXA_PEC_RHO_FOLD_GUARD_COLUMNS must be "
+                                         "the same on every rank");
     }
 
     bool self_periodic(int d) const { return m_nb[d] == 1; }
@@ -83,10 +116,7 @@ public:
     // the brick layout; the default until round 5).
     // is this brick's face `side` along d a face of the domain (0: low, 1: high)?
     bool domain_face(int d, int side) const { return side == 0 ? m_coord[d] == 0 : m_coord[d] == m_nb[d] - 1; }
-    static bool reference_corners() {   // (read per call: a test switches it between two runs of one process)
-        const char* e = std::getenv("WXA_REFERENCE_CORNERS");
-        return !(e && std::atoi(e) == 0);
-    }
+    bool reference_corners() const { return m_reference_corners; }   // WXA_REFERENCE_CORNERS, read at construction
     void FillBoundary(const std::vector<amrex::MultiFab*>& mfs, const amrex::IntVect& ng, bool nodal_sync,
                       void* stream) {
         const size_t nf = mfs.size();
@@ -339,24 +369,35 @@ private:
             nsm += box_pts(b.smlo, b.smhi); nsp += box_pts(b.splo, b.sphi);
             nrp += box_pts(b.rplo, b.rphi); nrm += box_pts(b.rmlo, b.rmhi);
         }
+        const int64_t B = m_f32_wire ? 4 : 8;   // bytes per point on the wire
         m_send[0].reserve(8 * nsm); m_send[1].reserve(8 * nsp);
         m_recv[0].reserve(8 * nrp); m_recv[1].reserve(8 * nrm);
         int64_t om = 0, op = 0;
         const bool minus = has_neighbor(d, 0), plus = has_neighbor(d, 1);
         for (size_t c = 0; c < mfs.size(); ++c) {
             const wxa_field_view& f = mfs[c]->view();
-            if (minus) check(m_be->pack_box(&f, sl[c].smlo, sl[c].smhi, (double*)m_send[0].p + om, stream));
-            if (plus) check(m_be->pack_box(&f, sl[c].splo, sl[c].sphi, (double*)m_send[1].p + op, stream));
+            if (m_f32_wire) {
+                if (minus) check(m_be->pack_box_f32(&f, sl[c].smlo, sl[c].smhi, (float*)m_send[0].p + om, stream));
+                if (plus) check(m_be->pack_box_f32(&f, sl[c].splo, sl[c].sphi, (float*)m_send[1].p + op, stream));
+            } else {
+                if (minus) check(m_be->pack_box(&f, sl[c].smlo, sl[c].smhi, (double*)m_send[0].p + om, stream));
+                if (plus) check(m_be->pack_box(&f, sl[c].splo, sl[c].sphi, (double*)m_send[1].p + op, stream));
+            }
             om += box_pts(sl[c].smlo, sl[c].smhi);
             op += box_pts(sl[c].splo, sl[c].sphi);
         }
-        exchange_raw(d, m_send[0].p, 8 * nsm, m_send[1].p, 8 * nsp, m_recv[0].p, 8 * nrp, m_recv[1].p, 8 * nrm,
+        exchange_raw(d, m_send[0].p, B * nsm, m_send[1].p, B * nsp, m_recv[0].p, B * nrp, m_recv[1].p, B * nrm,
                      stream);
         om = 0; op = 0;
         for (size_t c = 0; c < mfs.size(); ++c) {
             const wxa_field_view& f = mfs[c]->view();
-            if (plus) check(m_be->unpack_box(&f, sl[c].rplo, sl[c].rphi, (const double*)m_recv[0].p + op, mode, stream));
-            if (minus) check(m_be->unpack_box(&f, sl[c].rmlo, sl[c].rmhi, (const double*)m_recv[1].p + om, mode, stream));
+            if (m_f32_wire) {
+                if (plus) check(m_be->unpack_box_f32(&f, sl[c].rplo, sl[c].rphi, (const float*)m_recv[0].p + op, mode, stream));
+                if (minus) check(m_be->unpack_box_f32(&f, sl[c].rmlo, sl[c].rmhi, (const float*)m_recv[1].p + om, mode, stream));
+            } else {
+                if (plus) check(m_be->unpack_box(&f, sl[c].rplo, sl[c].rphi, (const double*)m_recv[0].p + op, mode, stream));
+                if (minus) check(m_be->unpack_box(&f, sl[c].rmlo, sl[c].rmhi, (const double*)m_recv[1].p + om, mode, stream));
+            }
             op += box_pts(sl[c].rplo, sl[c].rphi);
             om += box_pts(sl[c].rmlo, sl[c].rmhi);
         }
@@ -367,6 +408,8 @@ private:
     bool m_has_comm = false;
     int m_nb[3], m_coord[3];
     bool m_periodic[3] = {true, true, true};
+    bool m_reference_corners = true;   // WXA_REFERENCE_CORNERS (FillBoundary below)
+    bool m_f32_wire = false;           // warpx.do_single_precision_comms
     DeviceBuffer m_send[2], m_recv[2];
 };
 

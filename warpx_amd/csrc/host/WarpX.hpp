@@ -23,7 +23,7 @@ struct guardCellManager {
 
     void Init(const amrex::Real dt, const std::array<amrex::Real, 3>& dx, const int nox, const bool use_filter,
               const amrex::IntVect& bilinear_filter_stencil_length, const bool do_fdtd_nci_corr = false,
-              const int nci_corr_stencil = 0) {
+              const int nci_corr_stencil = 0, const bool safe_guard_cells = false) {
         constexpr double c = 299'792'458.;
         for (int d = 0; d < 3; ++d) {
             const int ng_tmp = nox;                                   // :62-64 (no subcycling / MR)
@@ -49,6 +49,11 @@ struct guardCellManager {
         }
         ng_FieldGather = amrex::min(ng_FieldGather, ng_alloc_EB);     // :333
         for (int d = 0; d < 3; ++d) ng_FieldGather[d] = std::max(ng_FieldGather[d], ng_FieldSolver[d]);   // :338
+        if (safe_guard_cells) {   // :297-308 "Run in safe mode: exchange all allocated guard cells at each call of FillBoundary"
+            ng_FieldSolver = ng_alloc_EB;
+            ng_FieldGather = ng_alloc_EB;
+            ng_UpdateAux = ng_alloc_EB;
+        }
     }
 };
 
@@ -121,6 +126,9 @@ public:
         using warpx::fields::FieldType;
         using ablastr::fields::Direction;
         if (cfg.nox < 1 || cfg.nox > 4) throw std::runtime_error("algo.particle_shape must be 1..4");
+        // the switches of the environment are read once, here; the bricks of a run compare theirs before the first step
+        m_env_no_guard_layer = std::getenv("WXA_NO_GUARD_LAYER") != nullptr;
+        if (const char* e = std::getenv("WXA_PEC_RHO_FOLD_GUARD_COLUMNS")) m_env_fold_rho_guard_columns = std::atoi(e) != 0;
         m_ctx.be = be;
         m_ctx.nox = cfg.nox;
         m_ctx.galerkin_interpolation = cfg.galerkin != 0;
@@ -282,6 +290,11 @@ public:
     // Source/Evolve/WarpXEvolve.cpp:94-347
     void Evolve(int numsteps) {
         const int numsteps_max = numsteps;
+        if (!m_switches_verified) {   // collective (the count round): every brick of a run is in its first Evolve here
+            m_switches_verified = true;
+            m_comm->VerifySwitchesAgree((safe_guard_cells ? 1 : 0) | (m_env_no_guard_layer ? 2 : 0) |
+                                        (m_env_fold_rho_guard_columns ? 4 : 0) | (m_overlap ? 8 : 0));
+        }
         if (!m_reduced_diags_started) {   // WarpX::InitData (WarpXInitData.cpp:612-619): full and reduced diagnostics before the first iteration
             m_reduced_diags_started = true;
             if (diag_hook) diag_hook((int)istep - 1, kDiagFlush);
@@ -480,9 +493,30 @@ public:
         // nothing), and FillBoundaryE/B(ng_FieldGather) refills every guard before the next reader (the gather).
         // Fields bit for bit the same (tests/test_multibrick_cpu.py).  The CKC update of B does read guard points of
         // E (the transverse neighbours of its extended differences): there the exchange is issued.
-        if (m_cfg.maxwell_solver == WXA_SOLVER_CKC) FillBoundaryE(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);
+        if (m_cfg.maxwell_solver == WXA_SOLVER_CKC || safe_guard_cells)
+            FillBoundaryE(guard_cells.ng_FieldSolver, WarpX::sync_nodal_points);
         EvolveB(0.5 * dt[0], DtType::SecondHalf);                // :437
+        // :447-451 "E and B are up-to-date in the domain, but all guard cells are outdated."
+        if (safe_guard_cells) FillBoundaryB(guard_cells.ng_alloc_EB);
     }
+
+    // warpx.safe_guard_cells (Source/WarpX.cpp:625; GuardCellManager.cpp:297-308; WarpXComm.cpp:759,824;
+    // WarpXEvolve.cpp:449-451): every FillBoundary exchanges all allocated guard cells, every exchange of the reference's
+    // schedule is issued (none replaced by the guard-layer update, none dropped), B's guards are refilled at the end of
+    // the step and J's after the guard sum.  A debugging mode: the valid points are the same bit for bit
+    // (tests/test_multibrick_cpu.py::test_safe_guard_cells).  Before the first step.
+    void SetSafeGuardCells(bool on) {
+        if (istep != 0 && on != safe_guard_cells) throw std::runtime_error("warpx.safe_guard_cells: before the first step");
+        safe_guard_cells = on;
+        guard_cells.Init(dt[0], m_ctx.dx, m_cfg.nox, use_filter, amrex::IntVect(2), m_cfg.use_fdtd_nci_corr != 0,
+                         NCIGodfreyFilter::m_stencil_width, safe_guard_cells);
+        if (on && m_overlap) throw std::runtime_error("warpx.safe_guard_cells with overlap_halo: the overlapped schedule relies on the "
+                                                      "guard-layer update the safe mode switches off");
+        if (on) m_grown_b = false;
+    }
+    // warpx.do_single_precision_comms (Source/WarpX.cpp:614): float on the wire between bricks (BrickComm)
+    void SetSinglePrecisionComms(bool on) { m_comm->set_single_precision_comms(on); }
+    bool do_single_precision_comms() const { return m_comm->single_precision_comms(); }
 
     // ---- exchanges of the field solve ---------------------------------------------------------
     // All-periodic runs issue none: the first half update of B is followed by the same update of the first guard layer, from the
@@ -496,7 +530,7 @@ public:
         // a wall's boundary kernel owns the guards behind it; WXA_NO_GUARD_LAYER=1 brings the exchange back (debugging)
         // (the guard-layer kernel is the Yee update: with CKC the reference's exchange stays)
         m_grown_b = !m_any_pec && m_be->evolve_b_guard_layer != nullptr && m_cfg.maxwell_solver == WXA_SOLVER_YEE &&
-                    !std::getenv("WXA_NO_GUARD_LAYER");
+                    !m_env_no_guard_layer;
         m_overlap = false;
         bool any_split = false;
         for (int d = 0; d < 3; ++d) any_split = any_split || !m_comm->self_periodic(d);
@@ -599,8 +633,7 @@ public:
     // faces and streams through the lower wall, profiles/round5/README.md.)  WXA_PEC_RHO_FOLD_GUARD_COLUMNS=1: as before.
     void ApplyRhofieldBoundary(amrex::MultiFab& rho) {
         const wxa_field_view& v = rho.view();
-        const char* fold_env = std::getenv("WXA_PEC_RHO_FOLD_GUARD_COLUMNS");   // (read per call, like WXA_REFERENCE_CORNERS)
-        const bool fold_columns = fold_env && std::atoi(fold_env) != 0;
+        const bool fold_columns = m_env_fold_rho_guard_columns;   // WXA_PEC_RHO_FOLD_GUARD_COLUMNS, read at construction
         struct Slab { int32_t lo[3], hi[3]; size_t at; };
         std::vector<Slab> slabs;
         size_t total = 0;
@@ -872,6 +905,7 @@ private:
     bool m_reduced_diags_started = false;
     // field-solve exchanges: guard layer of B computed redundantly; J's guard sum on a second stream
     bool m_grown_b = false, m_overlap = false;
+    bool m_env_no_guard_layer = false, m_env_fold_rho_guard_columns = false, m_switches_verified = false;
     void* m_comm_stream = nullptr;
     void* m_halo_events[4] = {nullptr, nullptr, nullptr, nullptr};
     bool m_eb_fill_in_flight = false;

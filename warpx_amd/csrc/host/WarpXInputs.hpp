@@ -468,6 +468,13 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
 
     auto h = std::make_unique<SimHandle>();
     h->warpx = std::make_unique<WarpX>(be, cfg, comm);
+    {   // Source/WarpX.cpp:614,625
+        int safe = 0, single = 0;
+        pp.queryWithParser("warpx.safe_guard_cells", safe);
+        pp.queryWithParser("warpx.do_single_precision_comms", single);
+        if (safe) h->warpx->SetSafeGuardCells(true);
+        if (single) h->warpx->SetSinglePrecisionComms(true);
+    }
     WarpX& wx = *h->warpx;
     const WarpXContext& ctx = wx.context();
 
@@ -1120,6 +1127,26 @@ inline void add_full_diagnostic(SimHandle& h, const std::string& name, const std
         if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \
         reinterpret_cast<wxa::host::SimHandle*>(s)->warpx->synchronize_at_end = on != 0;               \
         return (RET)WXA_OK;                                                                            \
+    }                                                                                                  \
+    RET PFX##sim_set_safe_guard_cells(SIMTYPE* s, int32_t on) {                                        \
+        if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \
+        try {                                                                                          \
+            reinterpret_cast<wxa::host::SimHandle*>(s)->warpx->SetSafeGuardCells(on != 0);             \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
+    }                                                                                                  \
+    RET PFX##sim_set_single_precision_comms(SIMTYPE* s, int32_t on) {                                  \
+        if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \
+        try {                                                                                          \
+            reinterpret_cast<wxa::host::SimHandle*>(s)->warpx->SetSinglePrecisionComms(on != 0);       \
+            return (RET)WXA_OK;                                                                        \
+        } catch (const std::exception& e) {                                                            \
+            SET_ERROR(e.what());                                                                       \
+            return (RET)WXA_ERR_INVALID_ARG;                                                           \
+        }                                                                                              \
     }                                                                                                  \
     RET PFX##sim_synchronize(SIMTYPE* s) {                                                             \
         if (!s) return (RET)WXA_ERR_INVALID_ARG;                                                       \

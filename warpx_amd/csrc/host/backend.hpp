@@ -89,6 +89,9 @@ struct Backend {
     int (*sum_boundary_periodic_multi)(const wxa_field_view*, int32_t, const int*, const int*, void*) = nullptr;
     int (*pack_box)(const wxa_field_view*, const int32_t*, const int32_t*, double*, void*);
     int (*unpack_box)(const wxa_field_view*, const int32_t*, const int32_t*, const double*, int, void*);
+    // optional: the same with float on the wire (warpx.do_single_precision_comms)
+    int (*pack_box_f32)(const wxa_field_view*, const int32_t*, const int32_t*, float*, void*) = nullptr;
+    int (*unpack_box_f32)(const wxa_field_view*, const int32_t*, const int32_t*, const float*, int, void*) = nullptr;
     int (*field_set_zero)(const wxa_field_view*, void*);
     int (*enforce_periodic)(const wxa_particle_view*, const double*, const double*, const int*, void*);
     // optional: the wrap restricted to the face tiles of the last sort (ws, steps since that sort)

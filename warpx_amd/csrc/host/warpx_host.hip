@@ -126,6 +126,10 @@ const Backend* hip_backend() {
             return wxa_pack_box(f, lo, hi, buf, st); };
         b.unpack_box = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, const double* buf, int mode,
                           void* st) -> int { return wxa_unpack_box(f, lo, hi, buf, mode, st); };
+        b.pack_box_f32 = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, float* buf, void* st) -> int {
+            return wxa_pack_box_f32(f, lo, hi, buf, st); };
+        b.unpack_box_f32 = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, const float* buf, int mode,
+                              void* st) -> int { return wxa_unpack_box_f32(f, lo, hi, buf, mode, st); };
         b.field_set_zero = [](const wxa_field_view* f, void* st) -> int { return wxa_field_set_zero(f, st); };
         b.enforce_periodic = [](const wxa_particle_view* p, const double* lo, const double* hi, const int* per,
                                 void* st) -> int { return wxa_enforce_periodic(p, lo, hi, per, st); };

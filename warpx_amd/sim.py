@@ -229,6 +229,14 @@ class WarpXSim:
         """WarpX::Synchronize: the momenta to the time of the positions, if they are not there already."""
         self.lib.sim_synchronize(self._h)
 
+    def set_safe_guard_cells(self, on: bool = True):
+        """warpx.safe_guard_cells: all allocated guard cells in every exchange, every exchange of the reference's schedule."""
+        self.lib.sim_set_safe_guard_cells(self._h, 1 if on else 0)
+
+    def set_single_precision_comms(self, on: bool = True):
+        """warpx.do_single_precision_comms: float on the wire of the guard exchanges between bricks."""
+        self.lib.sim_set_single_precision_comms(self._h, 1 if on else 0)
+
     def evolve(self, numsteps: int):
         self.lib.sim_evolve(self._h, int(numsteps))
 
