@@ -516,6 +516,8 @@ wxa_status wxa_unpack_box_f32(const wxa_field_view* f, const int32_t blo[3], con
 
 /* Zero a field including guards (MultiFab::setVal(0), MultiParticleContainer.cpp:470-472). */
 wxa_status wxa_field_set_zero(const wxa_field_view* f, void* stream);
+/* ... nf <= 6 fields in one launch (the three components of J, MultiParticleContainer.cpp:470-472) */
+wxa_status wxa_field_set_zero_multi(const wxa_field_view* f, int32_t nf, void* stream);
 
 /* Blocking device<->host copies for hosts without their own HIP binding. */
 wxa_status wxa_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes);

@@ -234,6 +234,18 @@ def test_sum_boundary_of_several_fields_in_one_launch(oracle, product, src_ng):
         assert np.array_equal(a.to_numpy(), b.to_numpy())
 
 
+def test_field_set_zero_multi(product):
+    """The three components of J zeroed by one launch (odd and even lengths, guards included); a fourth array is untouched."""
+    fs = H.random_fields(("jx", "jy", "jz", "Ex"), (13, 8, 9), 3, 83)
+    fds = [f.copy_to(DEV, True) for f in fs]
+    views = (_capi.FieldView * 3)(*[f.view for f in fds[:3]])
+    product.field_set_zero_multi(views, 3, None)
+    _sync(product)
+    for f in fds[:3]:
+        assert not np.any(f.to_numpy())
+    assert np.array_equal(fds[3].to_numpy(), fs[3].to_numpy())
+
+
 def test_pack_unpack_roundtrip(product):
     import torch
     (f,) = H.random_fields(("Ey",), NCELL, 3, 80)

@@ -283,6 +283,7 @@ _PRODUCT_SIGS = {
     "unpack_box": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
     "pack_box_f32": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_void_p]),
     "unpack_box_f32": (C.c_int, [_PFV, _I32_3, _I32_3, C.c_void_p, C.c_int, C.c_void_p]),
+    "field_set_zero_multi": (C.c_int, [_PFV, C.c_int32, C.c_void_p]),
     "copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "device_synchronize": (C.c_int, []),

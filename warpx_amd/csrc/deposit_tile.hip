@@ -145,6 +145,7 @@ constexpr int NBANK = 16;         // LDS banks (8-byte wide) seen by one step of
 struct StragglerQueue {
     int* __restrict__ idx;
     unsigned* __restrict__ count;
+    unsigned* __restrict__ next = nullptr;   // the next launch's counter, zeroed by this one (wxa::flip_counter)
     __device__ __forceinline__ void push(int ip) const { idx[atomicAdd(count, 1u)] = ip; }
 };
 
@@ -341,6 +342,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    if (blockIdx.x == 0 && tid == 0 && sq.next) *sq.next = 0u;
     DPROF_INIT
     bool first_tile = true;        // PT: the tile has to be zeroed by phase A (later ones are left zeroed by the flush)
     unsigned xcd_done = 0;         // PT, thread 0: XCD ranges found exhausted
@@ -692,6 +694,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
         ParticleState pa, pb;
         if constexpr (PFD != 0) {
             pa = na; pb = nb;
+            if constexpr (PFD == 3) request_next();   // the next chunk's fourteen loads travel behind the whole body
         } else if (CFG::LD16 != 0 && end - start >= 2) {   // (a tile with one particle: below)
             typedef double D2U __attribute__((ext_vector_type(2), aligned(8)));
             const int b2 = ia + 1 < end ? ia : ia - 1;   // the pair's first index; a last particle without a partner comes second
@@ -1012,7 +1015,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px_, const doubl
             } else {
                 esirkepov_pair_phased<O, CFG::PHASED == 2>(c1, c2, wq1, wq2, es, sink);
             }
-        } else if constexpr (PFD != 0) {
+        } else if constexpr (PFD == 1 || PFD == 2) {
             request_next();   // a lane without a fast item
         }
 #ifdef WXA_DEPOSIT_PROFILE
@@ -1223,10 +1226,11 @@ static wxa_status launch_rows(const wxa_particle_view* p, const wxa_field_view J
     }
     const dim3 grid((unsigned)(CFG::PT ? std::min<long>(xcd_grid_size(nunits), WXA_NUM_CU) : xcd_grid_size(nunits) + extra_groups)), block(CFG::NT);
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
-    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
-    StragglerQueue sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p};
-    unsigned* tile_ctr = (unsigned*)ws->counters.p + 96;   // words of ws->counters: see particles.hip (0 deposit, 16 gather, 32 classify, 48 walls, 56 injection, 64..90 destinations); 96..103: tile claims per XCD
-    WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
+    StragglerQueue sq{(int*)ws->stragglers.p, nullptr, nullptr};
+    unsigned *cnt_now = nullptr, *cnt_next = nullptr;
+    if ((rc = flip_counter(ws, 0, ws->deposit_flips, st, cnt_now, cnt_next)) != WXA_OK) return rc;
+    sq.count = cnt_now; sq.next = cnt_next;   // words 0, 1 of ws->counters
+    unsigned* tile_ctr = (unsigned*)ws->counters.p + 96;   // words of ws->counters: see particles.hip (0, 1 deposit, 16, 17 gather, 32 classify, 48 walls, 56 injection, 64..90 destinations); 96..103: tile claims per XCD
     if (CFG::PT) WXA_HIP_CHECK(hipMemsetAsync(tile_ctr, 0, 8 * sizeof(unsigned), st));
     const DevF jx = make_devf(J[0]), jy = make_devf(J[1]), jz = make_devf(J[2]);
     const EsirkepovStep es = make_esirkepov_step(g, dt, relative_time);
@@ -1293,6 +1297,11 @@ using RowsNoAluNew = RowsCfg<768, 8, 3, 1, 2, double, 32, WXA_DEPOSIT_ESIRKEPOV,
 using RowsLoadsOnly = RowsCfg<768, 8, 3, 1, 4, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 114
 using RowsPhasesOnly = RowsCfg<768, 8, 3, 1, 5, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 115
 using RowsSkeleton = RowsCfg<768, 8, 3, 1, 3, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;   // 113: neither (wrong J)
+// round 6: two waves per SIMD with the whole register file (256 VGPRs): room for the next chunk's particles in registers
+using RowsW8 = RowsCfg<512, 8, 2, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1>;            // 120
+using RowsW8Pfd1 = RowsCfg<512, 8, 2, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 1>;     // 121
+using RowsW8Pfd2 = RowsCfg<512, 8, 2, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 2>;     // 122
+using RowsW8Pfd3 = RowsCfg<512, 8, 2, 1, 0, double, 32, WXA_DEPOSIT_ESIRKEPOV, 0, 0, 0, WXA_PUSHER_BORIS, 0, 0, 0, 1, 1, 1, 3>;     // 123: requested at the top of the chunk
 #endif
 
 #ifdef WXA_DEV_VARIANTS   // measured and not adopted (wxa_debug_push_and_deposit, particles.hip): 14.8 ms against 4.7 + 6.8
@@ -1410,6 +1419,10 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
                 case 114: return launch_rows<3, RowsLoadsOnly>(p, J, geom, q, dt, relative_time, ws, st);
                 case 115: return launch_rows<3, RowsPhasesOnly>(p, J, geom, q, dt, relative_time, ws, st);
                 case 113: return launch_rows<3, RowsSkeleton>(p, J, geom, q, dt, relative_time, ws, st);
+                case 120: return launch_rows<3, RowsW8>(p, J, geom, q, dt, relative_time, ws, st);
+                case 121: return launch_rows<3, RowsW8Pfd1>(p, J, geom, q, dt, relative_time, ws, st);
+                case 122: return launch_rows<3, RowsW8Pfd2>(p, J, geom, q, dt, relative_time, ws, st);
+                case 123: return launch_rows<3, RowsW8Pfd3>(p, J, geom, q, dt, relative_time, ws, st);
                 default: break;
             }
         }

@@ -246,7 +246,46 @@ evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, D
 //   Round 4 (profiles/round4/r4b_stencil_loads_before_stores.txt, same box, two rounds): every load ahead of the first store
 //   (BATCH) 0.2414 -> 0.2326 / 0.3081 -> 0.3031 ms (62.5 -> 64.9 / 65.3 -> 66.4 %); two planes per lane the same.
 using StProduction = StencilCfg<1, 1, 3, 1, 1>;
-using StPlain = StencilCfg<1, 2, 4, 0>;   // the thin guard-layer launches (wxa_evolve_b_guard_layer): plain moves
+// (StPlain: the tiled kernel on thin boxes; the guard layer has its own kernel since round 6, evolve_b_faces_kernel)
+using StPlain = StencilCfg<1, 2, 4, 0>;
+
+// The first guard layer of B on every face of the brick (wxa_evolve_b_guard_layer): evolve_b_kernel's update, term by
+// term in the same order (bit-identical to the valid points the neighbour brick computes), one lane per point.
+struct FaceBoxes {
+    int n;
+    Box3 b[12];        // (face, component) boxes: one layer thick along the face's direction
+    int comp[12];
+    long first[13];    // running point counts
+};
+__global__ void __launch_bounds__(256)
+evolve_b_faces_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, FaceBoxes fb, double dt, double idx, double idy,
+                      double idz) {
+    long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= fb.first[fb.n]) return;
+    int f = 0;
+    while (t >= fb.first[f + 1]) ++f;
+    t -= fb.first[f];
+    const Box3 b = fb.b[f];
+    const int n0 = b.hi[0] - b.lo[0], n1 = b.hi[1] - b.lo[1];
+    const int i = b.lo[0] + (int)(t % n0), j = b.lo[1] + (int)((t / n0) % n1), k = b.lo[2] + (int)(t / ((long)n0 * n1));
+    const int c = fb.comp[f];
+    if (c == 0) {
+        const double* ey = Ey.p + Ey.off(i, j, k);
+        const double* ez = Ez.p + Ez.off(i, j, k);
+        double* bx = Bx.p + Bx.off(i, j, k);
+        *bx = *bx + (dt * (idz * (ey[Ey.ks] - ey[0])) - dt * (idy * (ez[Ez.js] - ez[0])));
+    } else if (c == 1) {
+        const double* ex = Ex.p + Ex.off(i, j, k);
+        const double* ez = Ez.p + Ez.off(i, j, k);
+        double* by = By.p + By.off(i, j, k);
+        *by = *by + (dt * (idx * (ez[1] - ez[0])) - dt * (idz * (ex[Ex.ks] - ex[0])));
+    } else {
+        const double* ex = Ex.p + Ex.off(i, j, k);
+        const double* ey = Ey.p + Ey.off(i, j, k);
+        double* bz = Bz.p + Bz.off(i, j, k);
+        *bz = *bz + (dt * (idy * (ex[Ex.js] - ex[0])) - dt * (idx * (ey[1] - ey[0])));
+    }
+}
 #ifdef WXA_DEV_VARIANTS   // the sweep above: WXA_STENCIL_VARIANT=<n> per launch (scripts/stencil_variants.py, dev builds only)
 using St1 = StencilCfg<1, 2, 4, 1>;
 using St2 = StencilCfg<1, 1, 4, 1>;
@@ -975,34 +1014,31 @@ wxa_status wxa_evolve_b_guard_layer(const wxa_field_view E[3], const wxa_field_v
     for (int c = 0; c < 3; ++c)
         for (int d = 0; d < 3; ++d)
             WXA_REQUIRE(!grow[d] || (E[c].ng[d] >= 2 && B[c].ng[d] >= 1), "guard layer update needs 2 guard points on E, 1 on B");
+    // One launch for all faces (round 6; until then one launch of the tiled kernel per face: six thin boxes, the two x
+    // faces on 1 lane in 64): a lane per guard point of a component, the boxes listed in the kernel argument.  The layer
+    // of a face spans the component's valid range along the other two directions, so no two boxes share a point.
+    FaceBoxes fb;
+    fb.n = 0;
+    fb.first[0] = 0;
     for (int d = 0; d < 3; ++d) {
         if (!grow[d]) continue;
-        for (int side = 0; side < 2; ++side) {
-            Box3 bc[3];
-            Box3 ub;
-            bool any = false;
+        for (int side = 0; side < 2; ++side)
             for (int c = 0; c < 3; ++c) {
-                bc[c] = valid_box(B[c]);
-                if (B[c].stag[d]) { bc[c].hi[d] = bc[c].lo[d]; continue; }   // nodal along d: no guard point is read
-                const int layer = side == 0 ? bc[c].lo[d] - 1 : bc[c].hi[d];
-                bc[c].lo[d] = layer; bc[c].hi[d] = layer + 1;
-                for (int e = 0; e < 3; ++e) {
-                    ub.lo[e] = any ? std::min(ub.lo[e], bc[c].lo[e]) : bc[c].lo[e];
-                    ub.hi[e] = any ? std::max(ub.hi[e], bc[c].hi[e]) : bc[c].hi[e];
-                }
-                any = true;
+                if (B[c].stag[d]) continue;   // nodal along d: no guard point is read
+                Box3 b = valid_box(B[c]);
+                const int layer = side == 0 ? b.lo[d] - 1 : b.hi[d];
+                b.lo[d] = layer; b.hi[d] = layer + 1;
+                const long pts = (long)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]);
+                if (pts <= 0) continue;
+                fb.b[fb.n] = b; fb.comp[fb.n] = c;
+                fb.first[fb.n + 1] = fb.first[fb.n] + pts;
+                ++fb.n;
             }
-            if (!any) continue;
-            for (int c = 0; c < 3; ++c)   // an empty box must still lie inside the union for the membership tests
-                if (bc[c].hi[d] == bc[c].lo[d]) bc[c].lo[d] = bc[c].hi[d] = ub.lo[d];
-            const TileGrid tg = make_tiles(ub);
-            if (tg.ntiles <= 0) continue;
-            hipLaunchKernelGGL((evolve_b_kernel<StPlain>), dim3((unsigned)xcd_grid_size(tg.ntiles)), dim3(TI, TJ), 0,
-                               (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]),
-                               make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bc[0], bc[1], bc[2], tg, dt,
-                               dinv[0], dinv[1], dinv[2]);
-        }
     }
+    if (fb.n > 0 && fb.first[fb.n] > 0)
+        hipLaunchKernelGGL(evolve_b_faces_kernel, dim3((unsigned)((fb.first[fb.n] + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           make_devf(E[0]), make_devf(E[1]), make_devf(E[2]), make_devf(B[0]), make_devf(B[1]), make_devf(B[2]),
+                           fb, dt, dinv[0], dinv[1], dinv[2]);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
@@ -1505,11 +1541,54 @@ wxa_status wxa_apply_pec_b(const wxa_field_view B[3], const int32_t dom_lo[3], c
     return apply_pec<false>(B, dom_lo, dom_hi, pec_lo, pec_hi, ng, stream);
 }
 
+// Several arrays zeroed by one launch (the three components of J at the top of every step: as three hipMemsetAsync they
+// were nine fill dispatches -- head, body and tail of each -- in the step's timeline).  blockIdx.y = array; 16-byte
+// non-temporal stores (the arrays are not read again before the deposition's atomics, a whole step's particle traffic later).
+struct ZeroSet {
+    double* p[6];
+    long n[6];   // doubles
+};
+__global__ void __launch_bounds__(256)
+zero_multi_kernel(ZeroSet z) {
+    typedef double D2 __attribute__((ext_vector_type(2)));
+    const int f = blockIdx.y;
+    double* p = z.p[f];
+    long n = z.n[f];
+    if (n <= 0) return;
+    if (reinterpret_cast<uintptr_t>(p) & 8u) {   // a caller's array that starts on an odd double: one scalar store in front
+        if (blockIdx.x == 0 && threadIdx.x == 0) p[0] = 0.0;
+        ++p; --n;
+    }
+    const long n2 = n >> 1;
+    D2* q = reinterpret_cast<D2*>(p);
+    const D2 zero = {0.0, 0.0};
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += (long)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(zero, q + t);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
+}
+
 extern "C" {
 
 wxa_status wxa_field_set_zero(const wxa_field_view* f, void* stream) {
     WXA_REQUIRE(f && view_ok(*f), "bad field view");
     WXA_HIP_CHECK(hipMemsetAsync(f->p, 0, sizeof(double) * (size_t)f->kstride * f->n[2], (hipStream_t)stream));
+    return WXA_OK;
+}
+
+wxa_status wxa_field_set_zero_multi(const wxa_field_view* f, int32_t nf, void* stream) {
+    WXA_REQUIRE(f && nf >= 1 && nf <= 6, "1 to 6 fields");
+    ZeroSet z{};
+    long most = 0;
+    for (int c = 0; c < nf; ++c) {
+        WXA_REQUIRE(view_ok(f[c]), "bad field view");
+        z.p[c] = f[c].p;
+        z.n[c] = (long)f[c].kstride * f[c].n[2];
+        most = std::max(most, z.n[c]);
+    }
+    if (most == 0) return WXA_OK;
+    const unsigned blocks = (unsigned)std::min<long>((most / 2 + 255) / 256, 8192);
+    hipLaunchKernelGGL(zero_multi_kernel, dim3(std::max(blocks, 1u), (unsigned)nf), dim3(256), 0, (hipStream_t)stream, z);
+    WXA_LAUNCH_CHECK();
     return WXA_OK;
 }
 

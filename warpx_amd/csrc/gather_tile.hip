@@ -78,6 +78,7 @@ struct LdsField {
 struct GatherStragglers {
     int* __restrict__ idx;
     unsigned* __restrict__ count;
+    unsigned* __restrict__ next = nullptr;   // the next launch's counter, zeroed by this one (wxa::flip_counter)
     __device__ __forceinline__ void push(int ip) const { idx[atomicAdd(count, 1u)] = ip; }
 };
 
@@ -149,6 +150,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     constexpr int NPTS = GatherTileDims<G>::NPTS;
     __shared__ double F[6 * NPTS];
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sq.next) *sq.next = 0u;
     // a tile with far more particles than the others is shared by several workgroups, each with a part of its particles
     // (heavy_tiles.hpp)
     long tile;
@@ -426,15 +428,16 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
     const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
     wxa_status rc;
     if ((rc = ws->stragglers.reserve(sizeof(int) * (size_t)p->np + 64)) != WXA_OK) return rc;
-    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
-    GatherStragglers sq{(int*)ws->stragglers.p, (unsigned*)ws->counters.p + 16};
+    GatherStragglers sq{(int*)ws->stragglers.p, nullptr, nullptr};
+    unsigned *cnt_now = nullptr, *cnt_next = nullptr;
+    if ((rc = flip_counter(ws, 16, ws->gather_flips, st, cnt_now, cnt_next)) != WXA_OK) return rc;
+    sq.count = cnt_now; sq.next = cnt_next;   // words 16, 17 of ws->counters
     const ExtEB ext = ext_of(ws);
     const PushSort hook = make_push_sort(ws, 0, MOVE);
     HeavyUnits hu;
     long extra_groups = 0;
     if ((rc = plan_heavy_tiles(ws, offsets, ntiles, (long)p->np, hu, extra_groups, st)) != WXA_OK) return rc;
     const dim3 grid((unsigned)(xcd_grid_size(ntiles) + extra_groups)), block(GT_THREADS);
-    WXA_HIP_CHECK(hipMemsetAsync(sq.count, 0, sizeof(unsigned), st));
 #define WXA_GT(O, G)                                                                                        \
     do {                                                                                                    \
         hipLaunchKernelGGL((gather_push_tile_kernel<O, G, PUSHER, MOVE, PART>), grid, block, 0, st, pv, offsets, ex, \

@@ -981,8 +981,13 @@ public:
                 PushType push_type = PushType::Explicit) {
         using warpx::fields::FieldType;
         if (!skip_deposition) {
-            for (int d = 0; d < 3; ++d)
-                fields.get(FieldType::current_fp, ablastr::fields::Direction{d}, lev)->setVal(0.0, m_ctx->stream);
+            auto J = fields.get_alldirs(FieldType::current_fp, lev);
+            if (m_ctx->be->field_set_zero_multi) {   // the three components in one launch
+                const wxa_field_view v[3] = {J[0]->view(), J[1]->view(), J[2]->view()};
+                check(m_ctx->be->field_set_zero_multi(v, 3, m_ctx->stream), "field_set_zero_multi");
+            } else {
+                for (int d = 0; d < 3; ++d) J[d]->setVal(0.0, m_ctx->stream);
+            }
         }
         for (auto& pc : allcontainers)
             pc->Evolve(fields, lev, current_fp_string, t, dt, a_dt_type, skip_deposition, push_type);

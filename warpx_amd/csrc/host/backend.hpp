@@ -93,6 +93,7 @@ struct Backend {
     int (*pack_box_f32)(const wxa_field_view*, const int32_t*, const int32_t*, float*, void*) = nullptr;
     int (*unpack_box_f32)(const wxa_field_view*, const int32_t*, const int32_t*, const float*, int, void*) = nullptr;
     int (*field_set_zero)(const wxa_field_view*, void*);
+    int (*field_set_zero_multi)(const wxa_field_view*, int32_t, void*) = nullptr;   // optional: several fields per launch
     int (*enforce_periodic)(const wxa_particle_view*, const double*, const double*, const int*, void*);
     // optional: the wrap restricted to the face tiles of the last sort (ws, steps since that sort)
     int (*enforce_periodic_sorted)(const wxa_particle_view*, const double*, const double*, const int*, void* ws, int32_t,

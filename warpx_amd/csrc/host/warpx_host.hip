@@ -131,6 +131,7 @@ const Backend* hip_backend() {
         b.unpack_box_f32 = [](const wxa_field_view* f, const int32_t* lo, const int32_t* hi, const float* buf, int mode,
                               void* st) -> int { return wxa_unpack_box_f32(f, lo, hi, buf, mode, st); };
         b.field_set_zero = [](const wxa_field_view* f, void* st) -> int { return wxa_field_set_zero(f, st); };
+        b.field_set_zero_multi = [](const wxa_field_view* f, int32_t nf, void* st) -> int { return wxa_field_set_zero_multi(f, nf, st); };
         b.enforce_periodic = [](const wxa_particle_view* p, const double* lo, const double* hi, const int* per,
                                 void* st) -> int { return wxa_enforce_periodic(p, lo, hi, per, st); };
         b.enforce_periodic_sorted = [](const wxa_particle_view* p, const double* lo, const double* hi, const int* per,

@@ -32,6 +32,11 @@ struct DevBuf {
 struct wxa_workspace {
     wxa::DevBuf cell, rank, hist, offsets, scan_tmp, tile_offsets, stragglers, counters;
     wxa::DevBuf heavy;   // units per tile and the extra workgroups of the tiles that are split (heavy_tiles.hpp)
+    // The straggler counts of the two LDS-tile kernels live in two slots each: launch n counts in slot n & 1, which launch
+    // n - 1's tile kernel left at zero, and zeroes the other one for launch n + 1 -- no fill dispatch in front of the kernel
+    // (round 6: a 4-byte hipMemsetAsync is a dispatch of 5 us; wxa::flip_counter below)
+    bool flip_ready = false;
+    unsigned gather_flips = 0, deposit_flips = 0;
     // description of the last cell sort (consumed by the tile-based deposition)
     bool sorted_valid = false;
     int64_t sorted_np = 0;              // particles covered by the tile offsets (live ones after wxa_sort_live_count)
@@ -80,6 +85,20 @@ struct wxa_workspace {
 };
 
 namespace wxa {
+// words `word`, `word + 1` of ws->counters as a two-slot counter (see wxa_workspace::flip_ready)
+inline wxa_status flip_counter(wxa_workspace* ws, int word, unsigned& flips, hipStream_t st, unsigned*& cur, unsigned*& next) {
+    wxa_status rc;
+    if ((rc = ws->counters.reserve(512)) != WXA_OK) return rc;
+    if (!ws->flip_ready) {   // once per workspace
+        WXA_HIP_CHECK(hipMemsetAsync(ws->counters.p, 0, 512, st));
+        ws->flip_ready = true;
+    }
+    unsigned* base = (unsigned*)ws->counters.p + word;
+    cur = base + (flips & 1u);
+    next = base + ((flips + 1u) & 1u);
+    ++flips;
+    return WXA_OK;
+}
 // external fields of a push: the constants, and the per-particle ones once evaluate_particle_fields (particles.hip) has run
 inline ExtEB ext_of(const wxa_workspace* ws) {
     ExtEB e{};
