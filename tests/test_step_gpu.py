@@ -96,6 +96,27 @@ def test_baseline_config_1_exactly(oracle, product, filt):
         assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), name
 
 
+@pytest.mark.parametrize("interval,merged", [(1, 1), (2, 1), (3, 1), (2, 0)])
+def test_sort_cycle_in_the_push_parity(oracle, product, interval, merged, monkeypatch):
+    """The periodic cell sort folded into the push, as one special push per cycle (round 6: the sort step's push scatters
+    with the last record and counts the next one, keys `interval` free-flight steps ahead; interval 1 -- a sort every step --
+    records in the step after the first classic sort instead of never starting) and as a counting and a scattering push
+    (round 5, WXA_SORT_MERGED=0): a warm plasma so that particles change cell and tile between sorts, ten steps = several
+    cycles, against the oracle stepper at the parity gate."""
+    monkeypatch.setenv("WXA_SORT_MERGED", str(merged))
+    n_cell = (32, 32, 32)
+    L = 40e-6
+    parts = plasma.uniform_plasma(n_cell, (-L / 2,) * 3, (L / 2,) * 3, (2, 1, 2), 1e25, 0.1, seed=4321)
+    species = [(-plasma.Q_E, plasma.M_E, parts)]
+    kw = dict(nox=3, galerkin=1, particle_pusher=_capi.PUSHER_BORIS, current_deposition=_capi.DEPOSIT_ESIRKEPOV, use_filter=1)
+    so, io = _run(oracle, n_cell, species, 10, sort_interval=4, **kw)
+    sg, ig = _run(product, n_cell, species, 10, sort_interval=interval, **kw)
+    _compare(_metrics(sg, ig), _metrics(so, io))
+    for name in ("Ex", "Ey", "Ez", "Bx", "By", "Bz", "jx", "jy", "jz"):
+        a, b = sg.field_valid(name), so.field_valid(name)
+        assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), name
+
+
 def test_uniform_plasma_parity_in_the_benchmark_regime(oracle, product):
     """HIP path against the oracle stepper where bench.py runs: 8 particles per cell at random positions (Poisson
     cell occupancy: odd runs, unmergeable pairs, tile tails), u_th = 0.01 c with the thermalised crossing rate from the

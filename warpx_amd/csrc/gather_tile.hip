@@ -194,7 +194,8 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     // the sort folded into the push, COUNT alone: ranks from a histogram of the tile's own cells (push_sort.hpp)
     static_assert(GT_THREADS == PUSH_SORT_TILE_CELLS, "one lane per cell of the tile");
     __shared__ int lhist[MOVE ? PUSH_SORT_TILE_CELLS : 1];
-    const bool count_local = MOVE && hook.mode == PUSH_SORT_COUNT && unit_u == 0;   // uniform (a shared tile: unit 0's histogram)
+    // (COUNT alone or together with SCATTER: the keys are those of the tile being read either way)
+    const bool count_local = MOVE && (hook.mode & PUSH_SORT_COUNT) != 0 && unit_u == 0;   // uniform (a shared tile: unit 0's histogram)
     if constexpr (MOVE) {
         if (count_local) lhist[tid] = 0;   // visible after the staging barrier below
     }

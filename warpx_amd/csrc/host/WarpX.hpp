@@ -246,6 +246,11 @@ public:
         // step and the next gather meet a fresh sort.  WXA_SORT_PREDICT=0: the keys of the positions in front of it.
         const char* predict = std::getenv("WXA_SORT_PREDICT");
         m_ctx.sort_predict_dt = predict && std::atoi(predict) == 0 ? 0.0 : dt[0];
+        // one special push per sort cycle (WarpXContext::sort_merged); WXA_SORT_MERGED=0: a counting and a scattering push
+        const char* merged = std::getenv("WXA_SORT_MERGED");
+        m_ctx.sort_merged = m_ctx.sort_in_push && !(merged && std::atoi(merged) == 0);
+        m_ctx.sort_interval_steps = (int32_t)sort_intervals;
+        m_ctx.step_dt = dt[0];
     }
 
     // WarpX::InitNCICorrector (Source/Initialization/WarpXInitData.cpp:858-890): the two Godfrey filters for
@@ -308,6 +313,7 @@ public:
             // PhysicalParticleContainer::Evolve, between push and deposition
             m_ctx.sort_now = sort_intervals > 0 && (istep % sort_intervals == 0);
             m_ctx.count_now = sort_intervals > 0 && ((istep + 1) % sort_intervals == 0);   // the next step sorts
+            m_ctx.steps_to_next_sort = sort_intervals > 0 ? (int32_t)(sort_intervals - istep % sort_intervals) : 0;
             // :157-166 ionization / collisions / QED: not on this path
             OneStep_nosub(cur_time);
             // :222-226 at the end of the last step, push p by 0.5*dt to synchronize

@@ -40,6 +40,15 @@ struct WarpXContext {
     bool sort_in_push = false;         // the periodic sorts are folded into PushPX (wxa_push_sort_begin, include/warpx_amd.h)
     int32_t sort_wrap[3] = {0, 0, 0};  // directions along which this brick is its own periodic neighbour
     double sort_predict_dt = 0.0;      // the recorded keys are those of the positions one free-flight step ahead (0: of the positions)
+    // One special push per sort cycle (round 6): the push of a sort step SCATTERs with the record of the previous sort step
+    // and COUNTs the record of the next one -- keys of the positions sort_intervals free-flight steps ahead -- in one pass;
+    // the pushes between two sort steps are plain.  (Separate COUNT and SCATTER pushes made every push of an interval-2
+    // cycle a special one.)  A run starts, and restarts after anything that drops the record (a classic sort, a window
+    // shift's sort), with a COUNT alone in the first push that finds no record.
+    bool sort_merged = false;
+    int32_t sort_interval_steps = 0;   // warpx.sort_intervals
+    int32_t steps_to_next_sort = 0;    // pushes behind this one up to and including the next sort step's
+    double step_dt = 0.0;
     // boundary.particle_lo/hi resolved to WXA_PBOUNDARY_PERIODIC / _ABSORBING / _REFLECTING
     int32_t particle_bc_lo[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
     int32_t particle_bc_hi[3] = {WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC, WXA_PBOUNDARY_PERIODIC};
@@ -270,9 +279,26 @@ public:
         if (m_ctx->btd != nullptr && btd_species_id >= 0) return;
         const wxa_particle_view p = m_tile.view();
         int32_t mode = 0;
-        if (m_ctx->sort_now && be->push_sort_pending(m_ws, &p)) mode |= WXA_PUSH_SORT_SCATTER;
-        // a record is of no use when a sort of the classic kind follows this push (it replaces the order the record indexes)
-        if (m_ctx->count_now && (!m_ctx->sort_now || mode != 0)) mode |= WXA_PUSH_SORT_COUNT;
+        double predict_dt = m_ctx->sort_predict_dt;
+        m_skip_classic_sort = false;
+        if (m_ctx->sort_merged) {
+            const bool pending = be->push_sort_pending(m_ws, &p) != 0;
+            const bool predict = m_ctx->sort_predict_dt != 0.0;
+            if (m_ctx->sort_now && pending) {
+                mode = WXA_PUSH_SORT_SCATTER | WXA_PUSH_SORT_COUNT;   // this cycle's scatter, the next cycle's record
+                predict_dt = predict ? m_ctx->sort_interval_steps * m_ctx->step_dt : 0.0;
+            } else if (!pending && (!m_ctx->sort_now || (m_ctx->sort_interval_steps == 1 && m_steps_since_sort == 1))) {
+                // no record: taken alone, for the next sort step.  (At an interval of 1 every step sorts: the step after a
+                // classic sort records instead of sorting again -- the tile is one push old, which every kernel tolerates.)
+                mode = WXA_PUSH_SORT_COUNT;
+                predict_dt = predict ? (m_ctx->sort_now ? 1 : m_ctx->steps_to_next_sort) * m_ctx->step_dt : 0.0;
+                m_skip_classic_sort = m_ctx->sort_now;
+            }
+        } else {
+            if (m_ctx->sort_now && be->push_sort_pending(m_ws, &p)) mode |= WXA_PUSH_SORT_SCATTER;
+            // a record is of no use when a sort of the classic kind follows this push (it replaces the order the record indexes)
+            if (m_ctx->count_now && (!m_ctx->sort_now || mode != 0)) mode |= WXA_PUSH_SORT_COUNT;
+        }
         if (mode == 0) return;
         wxa_particle_view dst{};
         if (mode & WXA_PUSH_SORT_SCATTER) {
@@ -282,7 +308,7 @@ public:
         int32_t lo[3], nc[3];
         for (int d = 0; d < 3; ++d) { lo[d] = m_ctx->brick_box.lo[d]; nc[d] = m_ctx->brick_box.length(d); }
         check(be->push_sort_begin(m_ws, mode, &p, &dst, m_ctx->brick_plo.data(), m_ctx->dinv.data(), lo, nc, m_ctx->sort_wrap,
-                                  m_nretired > 0 ? 1 : 0, m_ctx->sort_predict_dt, m_ctx->stream),
+                                  m_nretired > 0 ? 1 : 0, predict_dt, m_ctx->stream),
               "push_sort_begin");
         m_push_sort_mode = mode;
     }
@@ -537,6 +563,7 @@ public:
 protected:
     int64_t m_nretired = 0;            // retired by Redistribute since the last sort (still in the tile)
     int32_t m_push_sort_mode = 0;      // WXA_PUSH_SORT_* armed for this step's push (ArmPushSort)
+    bool m_skip_classic_sort = false;  // merged mode, interval 1: this sort step records instead of sorting
     int64_t m_count_nretired = 0;      // retired particles in the tile when the last COUNT was taken
     int32_t m_steps_since_sort = -1;   // Redistribute calls since the last cell sort (-1: never sorted)
 public:
@@ -753,7 +780,8 @@ public:
             const bool sorted_by_the_push = FinishPushSort();
             const bool fresh = m_sorted_by_window_shift && m_ctx->skip_sort_behind_a_window_shift;
             m_sorted_by_window_shift = false;
-            if (m_ctx->sort_now && !sorted_by_the_push && !fresh) SortParticlesByBin(amrex::IntVect(1));
+            if (m_ctx->sort_now && !sorted_by_the_push && !fresh && !m_skip_classic_sort) SortParticlesByBin(amrex::IntVect(1));
+            m_skip_classic_sort = false;
         }
         if (!skip_deposition) {
             PhaseTimer t(m_ctx, kCurrentDeposition);  // "...::DepositCurrent::CurrentDeposition"

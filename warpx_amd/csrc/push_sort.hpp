@@ -87,14 +87,16 @@ struct PushSort {
     int retired_bin_in = 0;   // offs[retired_bin_in]: first index behind the cell-sorted particles
 };
 
-// index of particle `gi` (index in the whole tile before this push) in the destination tile
-__device__ __forceinline__ long push_sort_dest(const PushSort& h, const long gi) {
+// index of particle `gi` (index in the whole tile before this push) in the destination tile; dropped: the record had it
+// retired -- it lands behind the tile's new end and is not a particle of the tile any more
+__device__ __forceinline__ long push_sort_dest(const PushSort& h, const long gi, bool& dropped) {
+    dropped = false;
     if (gi >= h.np_counted) return (long)h.offs[h.retired_bin_in] + (gi - h.np_counted);   // behind the live ones, in their order
     const unsigned long long kr = h.kr_in[gi];
     const int key = (int)(kr >> 32);
     long d = (long)h.offs[key] + (long)(unsigned)(kr & 0x7fffffffull);
     if (kr & PUSH_SORT_FOREIGN) d += h.own_in[key];
-    if (key == h.retired_bin_in) d += h.n_appended;   // the retired ones behind the appended ones: dropped by the new count
+    if (key == h.retired_bin_in) { d += h.n_appended; dropped = true; }   // the retired ones behind the appended ones: dropped by the new count
     return d;
 }
 
@@ -111,15 +113,19 @@ __device__ __forceinline__ bool push_sort_tail(const PushSort& h, const PV& p, c
     const bool scatter = (h.mode & PUSH_SORT_SCATTER) != 0;
     unsigned long long pid = 0ull;
     if (p.id && (scatter || h.check_retired)) pid = p.id[ip];
+    bool dropped = false;
     if (scatter) {
         const double w = p.w[ip];
-        at = push_sort_dest(h, gi);
+        at = push_sort_dest(h, gi, dropped);
         h.dx[at] = xp; h.dy[at] = yp; h.dz[at] = zp; h.dw[at] = w;
         h.dux[at] = ux; h.duy[at] = uy; h.duz[at] = uz;
         if (p.id && h.did) h.did[at] = pid;
         in_place = false;
     }
-    if (h.mode & PUSH_SORT_COUNT) {
+    // COUNT and SCATTER in one push: a particle the SCATTER drops (retired when the old record was taken: it lies behind
+    // the new tile's end) is not in the new record -- counted, it would push the ranks of the retired bin, and with them
+    // the next scatter's destinations, beyond the tile (found by the 2 x 2 x 2 bricks on the CPU execution model, round 6)
+    if ((h.mode & PUSH_SORT_COUNT) && !dropped) {
         // predict_dt: the key of where the particle will be after the NEXT push if nothing accelerates it -- the push
         // that scatters then writes the particles in (all but exactly) the cell order of the positions it produces, and
         // the deposition behind it and the next gather meet a fresh sort instead of one that is a push old.  Any key
