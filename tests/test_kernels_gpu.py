@@ -331,8 +331,8 @@ def test_sort_of_a_nearly_sorted_tile(product, drift, retire, monkeypatch):
     """The windowed scatter (a workgroup stages the particles that stay near their place in LDS and writes whole
     lines) on what it is built for -- a second sort after the particles drifted by a fraction of a cell -- and on what it
     must survive: no drift at all, a drift of several cells (most particles beyond the window margin), retired particles
-    (sorted behind the live ones).  Same permutation of the same particles, ids included, as the plain scatter
-    (WXA_SORT_SCATTER=0); keys non-decreasing."""
+    (sorted behind the live ones).  Keys non-decreasing, every particle once, ids with their particles; two sorts of the
+    same input give the same tile."""
     ncell = (24, 16, 40)
     n = 150000
     parts = H.random_particles(n, ncell, 95)
@@ -357,7 +357,6 @@ def test_sort_of_a_nearly_sorted_tile(product, drift, retire, monkeypatch):
         a[3] = np.where(gone, 0.0, a[3])
     results = []
     for mode in ("0", "1"):
-        monkeypatch.setenv("WXA_SORT_SCATTER", mode)
         src = ParticleArrays.from_numpy(list(a), DEV, aid)
         out = ParticleArrays(n, DEV, with_id=True)
         product.sort_particles_by_cell(C.byref(src.view), C.byref(out.view), *args)
@@ -641,19 +640,6 @@ def test_esirkepov_zero_displacement_deposits_exactly_zero(product, order, zero_
     product.workspace_destroy(ws)
 
 
-@pytest.fixture
-def deposit_variant(request):
-    """WXA_DEPOSIT_VARIANT selects one of the LDS-tile configurations of a -DWXA_DEV_VARIANTS build of deposit_tile.hip
-    (read per launch; the production library has no such switch)."""
-    old = os.environ.get("WXA_DEPOSIT_VARIANT")
-    os.environ["WXA_DEPOSIT_VARIANT"] = str(request.param)
-    yield request.param
-    if old is None:
-        del os.environ["WXA_DEPOSIT_VARIANT"]
-    else:
-        os.environ["WXA_DEPOSIT_VARIANT"] = old
-
-
 @pytest.mark.parametrize("stale", [False, True])
 @pytest.mark.parametrize("u_scale", [1.0, 0.003])
 def test_deposit_tiles_fast_and_crossing_paths(oracle, product, stale, u_scale):
@@ -661,19 +647,6 @@ def test_deposit_tiles_fast_and_crossing_paths(oracle, product, stale, u_scale):
     nearly every particle stays in its cell (pair body) and one where most cross (wide-frame body); and exact zeros."""
     test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_ESIRKEPOV, stale, u_scale)
     test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_DIRECT, stale, u_scale)
-    if not stale:
-        test_esirkepov_zero_displacement_deposits_exactly_zero(product, 3, 1, u_scale)
-
-
-@pytest.mark.skipif("dev" not in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", "")),
-                    reason="timing variants exist in -DWXA_DEV_VARIANTS builds only (WXA_PRODUCT_LIB=.../libwarpx_amd_dev.so)")
-@pytest.mark.parametrize("deposit_variant", [14, 20, 22, 30, 31, 40, 61, 62, 63, 64, 65, 66, 70, 71, 80, 81, 82, 83, 90, 91, 92, 93, 94, 95], indirect=True)
-@pytest.mark.parametrize("stale", [False, True])
-@pytest.mark.parametrize("u_scale", [1.0, 0.003])
-def test_deposit_tile_variants(oracle, product, deposit_variant, stale, u_scale):
-    """The A/B configurations of the order-3 Esirkepov tile deposition in a dev build (16-cell blocks, lane pairs that
-    share their deposits) against the oracle."""
-    test_deposit_current_lds_tiles(oracle, product, 3, _capi.DEPOSIT_ESIRKEPOV, stale, u_scale)
     if not stale:
         test_esirkepov_zero_displacement_deposits_exactly_zero(product, 3, 1, u_scale)
 
@@ -938,133 +911,6 @@ def test_sort_folded_into_the_push(oracle, product, order, sort_first, tail, ret
     product.workspace_destroy(ws)
 
 
-@pytest.mark.skipif("dev" not in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", "") + os.environ.get("WXA_HIPCPU_LIB", "")),
-                    reason="the fused kernel was measured and not adopted: -DWXA_DEV_VARIANTS builds only")
-@pytest.mark.parametrize("pusher", [_capi.PUSHER_BORIS, _capi.PUSHER_VAY])
-@pytest.mark.parametrize("stale,u_scale,tail", [(False, 1.0, 0), (True, 1.0, 0), (False, 0.003, 500), (True, 30.0, 500)])
-def test_push_and_deposit_in_one_kernel(oracle, product, pusher, stale, u_scale, tail):
-    """wxa_debug_push_and_deposit (dev builds: PhysicalParticleContainer::Evolve's PushPX + DepositCurrent,
-    PhysicalParticleContainer.cpp:1812-2095, on the LDS tiles as ONE kernel -- order 3, energy-conserving gather, Esirkepov;
-    30 % slower than the two kernels on the MI355X, profiles/round3/README.md) against the oracle's two
-    calls and against the product's own two kernels: pushed particles at 1e-12, J at 1e-12 of max|J| per component.
-    `stale` moves the particles after the sort (gather and deposit stencils leave the staged tiles: both straggler lists);
-    u_scale = 30 makes most particles cross a cell (deferred list, read back after the push); `tail` particles are
-    appended behind the sorted part (global-memory kernels)."""
-    import torch
-    order, galerkin = 3, 1
-    ncell = (24, 20, 16)
-    ng, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
-    E = H.random_fields(("Ex", "Ey", "Ez"), ncell, ng, 10, scale=1e9)
-    B = H.random_fields(("Bx", "By", "Bz"), ncell, ng, 11, scale=10.0)
-    Ed, Bd = H.clone_fields(E, DEV, True), H.clone_fields(B, DEV, True)
-    nsorted = 60000
-    parts = H.random_particles(nsorted + tail, ncell, 911, u_scale=u_scale)
-    dx = H.LX / np.asarray(ncell)
-    pd0 = ParticleArrays.from_numpy([a[:nsorted] for a in parts], DEV)
-    ws = C.c_void_p()
-    product.workspace_create(C.byref(ws))
-    srt = ParticleArrays(nsorted + tail, DEV)
-    head = srt.view
-    head.np = nsorted   # the sort fills the first nsorted slots; the rest of the arrays is the appended tail
-    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(head), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
-                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
-    _sync(product)
-    if stale:
-        rng = np.random.default_rng(6)
-        for d in range(3):
-            srt.data[d][:nsorted] += torch.from_numpy(dx[d] * 0.9 * (2 * rng.random(nsorted) - 1)).to(DEV)
-            srt.data[d][:nsorted].clamp_(-H.LX / 2, H.LX / 2 - 1e-12)
-    if tail:
-        for row in range(7):
-            srt.data[row][nsorted:] = torch.from_numpy(parts[row][nsorted:]).to(DEV)
-    start = [a.copy() for a in srt.to_numpy()]
-    ph = ParticleArrays.from_numpy(start, "cpu")
-    ge, _ = H.geom_for(ncell, ng)
-    gj, _ = H.geom_for(ncell, ng_depos)
-    dt = H.yee_dt(dx)
-    q, m = -plasma.Q_E, plasma.M_E
-    Jo = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
-    oracle.gather_push(C.byref(ph.view), field_triplet(E), field_triplet(B), C.byref(ge), q, m, dt, order, galerkin,
-                       pusher, None)
-    oracle.deposit_current(C.byref(ph.view), field_triplet(Jo), C.byref(gj), q, dt, -0.5 * dt, order,
-                           _capi.DEPOSIT_ESIRKEPOV, None, None)
-    # the product's two kernels on a copy of the same start
-    two = ParticleArrays.from_numpy(start, DEV)
-    J2 = H.clone_fields(Jo, DEV, True)
-    for f in J2:
-        f.storage.zero_()
-    # (the workspace describes `srt`; the two-kernel reference path runs on the global-memory kernels)
-    product.gather_push_ws(C.byref(two.view), field_triplet(Ed), field_triplet(Bd), C.byref(ge), q, m, dt, order, galerkin,
-                           pusher, 1, None, None)
-    product.deposit_current(C.byref(two.view), field_triplet(J2), C.byref(gj), q, dt, -0.5 * dt, order,
-                            _capi.DEPOSIT_ESIRKEPOV, None, None)
-    J1 = H.clone_fields(Jo, DEV, True)
-    for f in J1:
-        f.storage.zero_()
-    fused = product._dll.wxa_debug_push_and_deposit
-    fused.restype = C.c_int
-    fused.argtypes = [_capi._PPV, _capi._FV3, _capi._FV3, _capi._FV3, _capi._PGG, _capi._PGG, C.c_double, C.c_double,
-                      C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    assert fused(C.byref(srt.view), field_triplet(Ed), field_triplet(Bd), field_triplet(J1), C.byref(ge), C.byref(gj), q, m,
-                 dt, -0.5 * dt, order, galerkin, pusher, _capi.DEPOSIT_ESIRKEPOV, ws, None) == 0
-    _sync(product)
-    a, b, c = srt.to_numpy(), ph.to_numpy(), two.to_numpy()
-    for row in range(7):
-        assert H.max_rel_err(a[row], b[row]) < 1e-12, ("oracle", row)
-        assert H.max_rel_err(a[row], c[row]) < 1e-13, ("two kernels", row)
-    for f1, f2, fo in zip(J1, J2, Jo):
-        v1, v2, vo = f1.to_numpy(), f2.to_numpy(), fo.to_numpy()
-        scale = np.max(np.abs(vo))
-        assert scale > 0
-        assert np.max(np.abs(v1 - vo)) <= 1e-12 * scale
-        assert np.max(np.abs(v1 - v2)) <= 1e-12 * scale
-    product.workspace_destroy(ws)
-
-
-def test_btd_select_particles(oracle, product):
-    """wxa_btd_select_particles (BackTransformParticleFunctor.cpp:76-152, .H:49-62 and :106-168) against the oracle: the
-    particles that crossed the snapshot's plane during a step, interpolated to t_lab and transformed to the lab frame.
-    The device appends in no particular order: compared after sorting by the (unique) transformed x."""
-    import torch
-    rng = np.random.default_rng(99)
-    n = 20000
-    gamma = 4.0
-    c = plasma.C_LIGHT
-    dt = 2e-16
-    new = [rng.uniform(-1e-5, 1e-5, n), rng.uniform(-1e-5, 1e-5, n), rng.uniform(-1.03e-5, -0.97e-5, n), rng.uniform(1.0, 2.0, n),
-           c * rng.normal(0, 1, n), c * rng.normal(0, 1, n), c * rng.normal(-1.0, 2.0, n)]   # a slab around the plane
-    u_old = [new[4 + d] * (1.0 + 0.01 * rng.normal(0, 1, n)) for d in range(3)]
-    g_new = np.sqrt(1.0 + (new[4] ** 2 + new[5] ** 2 + new[6] ** 2) / c ** 2)
-    old_pos = [new[d] - dt * new[4 + d] / g_new for d in range(3)]
-    ph = ParticleArrays.from_numpy(new, "cpu")
-    pd = ParticleArrays.from_numpy(new, DEV)
-    old_h = [np.ascontiguousarray(a) for a in old_pos + u_old]
-    old_d = [torch.from_numpy(a).to(DEV) for a in old_h]
-    z_plane, z_plane_old = -1.0e-5, -1.0e-5 + 1.03 * c * dt
-    t_boost, t_lab = 40 * dt, 40 * dt * gamma * 0.9
-    cap = n
-    out_h = np.zeros((7, cap))
-    out_d = torch.zeros((7, cap), dtype=torch.float64, device=DEV)
-    nh, nd = C.c_int64(), C.c_int64()
-    ptr_h = (C.c_void_p * 6)(*[a.ctypes.data for a in old_h])
-    ptr_d = (C.c_void_p * 6)(*[a.data_ptr() for a in old_d])
-    oracle.btd_select_particles(C.byref(ph.view), ptr_h, z_plane, z_plane_old, t_boost, dt, t_lab, gamma,
-                                out_h.ctypes.data, cap, C.byref(nh), None)
-    product.btd_select_particles(C.byref(pd.view), ptr_d, z_plane, z_plane_old, t_boost, dt, t_lab, gamma,
-                                 out_d.data_ptr(), cap, C.byref(nd), None)
-    _sync(product)
-    assert nh.value == nd.value and 50 < nh.value < n // 4
-    a = out_d.cpu().numpy()[:, :nd.value]
-    b = out_h[:, :nh.value]
-    a, b = a[:, np.argsort(a[0])], b[:, np.argsort(b[0])]
-    for row in range(7):
-        assert H.max_rel_err(a[row], b[row]) < 1e-12, row
-    # a buffer that is too small: the count still says how many crossed
-    product.btd_select_particles(C.byref(pd.view), ptr_d, z_plane, z_plane_old, t_boost, dt, t_lab, gamma,
-                                 out_d.data_ptr(), 10, C.byref(nd), None)
-    assert nd.value == nh.value
-
-
 @pytest.mark.skipif(H.HIP_ON_CPU, reason="wraps a device pointer in a torch CUDA tensor")
 def test_device_pointer_wrapping(product):
     """The torch.distributed transport wraps raw device pointers handed out by the C++ host layer
@@ -1084,20 +930,10 @@ def test_device_pointer_wrapping(product):
     assert np.all(f.storage[f.front + 16:f.front + 32].cpu().numpy() == 3.5)
 
 
-DEV_BUILD = "dev" in os.path.basename(os.environ.get("WXA_PRODUCT_LIB", ""))   # a -DWXA_DEV_VARIANTS build of the library
-
-
 @pytest.mark.parametrize("ncell", [(24, 20, 16), (25, 9, 7), (130, 6, 5), (300, 8, 8)])
-@pytest.mark.parametrize("variant", [-1] + (list(range(10)) if DEV_BUILD else []))
-def test_evolve_stencil_configurations_bit_exact(oracle, product, ncell, variant):
-    """The EvolveB / EvolveE kernels on odd, even and multi-tile row lengths, bit for bit against the oracle: the
-    production configuration, and in a dev build every tile shape / non-temporal configuration of the timing sweep
-    (WXA_STENCIL_VARIANT, read per launch there; the production library has no such switch)."""
-    os.environ["WXA_STENCIL_VARIANT"] = str(variant)
-    try:
-        _two_point_body(oracle, product, ncell)
-    finally:
-        del os.environ["WXA_STENCIL_VARIANT"]
+def test_evolve_stencil_configurations_bit_exact(oracle, product, ncell):
+    """The EvolveB / EvolveE kernels on odd, even and multi-tile row lengths, bit for bit against the oracle."""
+    _two_point_body(oracle, product, ncell)
 
 
 def _two_point_body(oracle, product, ncell):
@@ -1596,7 +1432,7 @@ def test_add_plasma(oracle, product, ppc, u, uth, gamma_boost, t):
                                                   # several tiles along every direction, partial ones at the high ends,
                                                   # and the minimum guard depth: the staged halo reaches past the arrays
                                                   ((1.0, 1.0, 1.0), (70, 13, 21), 1, 0), ((1.1, 0.9, 1.0), (130, 9, 35), 3, 0),
-                                                  # the other tile shapes of the timing sweep (WXA_CKC_VARIANT)
+                                                  # further box shapes (the tile shapes of round 4's timing sweep ran on these)
                                                   ((1.0, 1.0, 1.0), (70, 13, 37), 1, -1), ((1.0, 1.0, 1.0), (70, 13, 37), 1, -3),
                                                   ((1.0, 1.0, 1.0), (70, 13, 37), 1, -4), ((1.0, 1.0, 1.0), (70, 21, 37), 1, -5),
                                                   ((1.0, 1.0, 1.0), (70, 13, 37), 1, -6),
@@ -1606,12 +1442,8 @@ def test_add_plasma(oracle, product, ppc, u, uth, gamma_boost, t):
                                                   ((1.0, 1.0, 1.0), (70, 13, 37), 1, -9), ((1.0, 1.0, 1.0), (70, 13, 67), 1, -10)])
 def test_evolve_b_ckc_bit_exact(oracle, product, cells, ncell, ng, plain, monkeypatch):
     """wxa_evolve_b_ckc (EvolveBCartesian<CartesianCKCAlgorithm>) and its coefficients against the CPU restatement:
-    same operation order, no contraction -> bit-identical, on cubic and on anisotropic cells; the LDS-tiled kernel
-    and, in a dev build, the plain one (WXA_CKC_PLAIN=1) and the tile shapes of the timing sweep (the production library
-    ignores both switches: those cases then exercise the production configuration on further box shapes)."""
-    monkeypatch.setenv("WXA_CKC_PLAIN", str(max(plain, 0)))
-    if plain < 0:
-        monkeypatch.setenv("WXA_CKC_VARIANT", str(-plain - 1))
+    same operation order, no contraction -> bit-identical, on cubic and on anisotropic cells, short, exact and long
+    marches along z, partial tiles at the high ends."""
     NCELL = ncell
     E = H.random_fields(("Ex", "Ey", "Ez"), NCELL, ng, 61)
     B = H.random_fields(("Bx", "By", "Bz"), NCELL, ng, 62, scale=1e-8)

@@ -403,104 +403,6 @@ __device__ __forceinline__ void esirkepov_pair_phased(const ParticleState& p1, c
                                           null2 ? 0.0 : q * p2.w, es, sink);
 }
 
-// esirkepov_pair_phased for two lanes that hold pairs of the SAME stencil frame (lanes l and l + 32 of a wave: pairs r and
-// r + 2 of one cell in the chunk layout of deposit_tile_rows_kernel): every lane evaluates all its values as before, the
-// two lanes exchange halves through v_permlane32_swap -- the lower lane keeps the planes b < NW/2 of both pairs, the upper
-// lane the planes b >= NW/2 -- and each deposits HALF the points with the sum of four particles: half the LDS atomics per
-// wave (the pipe that the pair body keeps busiest) for two swaps and one add per exchanged value.  A lane without
-// particles of its own takes part with zero weights (wq = 0) on its partner's frame.  `sink` of the upper lane must be
-// shifted by NW/2 planes along each component's outer transverse direction (Jx, Jy: k; Jz: j): `sink_jz` / `sink_jxy`.
-#ifndef WXA_HAVE_SWAP_ADD_HALVES   // tests/hipcpu brings its own (two wave shuffles)
-__device__ __forceinline__ double swap_add_halves(const double v_lo_planes, const double v_hi_planes) {
-    // lower lane: own v_lo + upper lane's v_lo; upper lane: lower lane's v_hi + own v_hi
-    const auto r0 = __builtin_amdgcn_permlane32_swap(__double2loint(v_lo_planes), __double2loint(v_hi_planes), false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(__double2hiint(v_lo_planes), __double2hiint(v_hi_planes), false, false);
-    return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
-}
-// the partner lane's (lane ^ 32) value of a wave-uniformly executed int
-__device__ __forceinline__ int partner32(const int v) {
-    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-    return (int)((threadIdx.x & 32) ? r[0] : r[1]);
-}
-#endif
-template <int O, class Sink>
-__device__ __forceinline__ void esirkepov_pair_phased_coop(EsirkepovCoords c1, EsirkepovCoords c2, const double wq1,
-                                                           const double wq2, const EsirkepovStep& es, Sink& sink_jxy,
-                                                           Sink& sink_jz) {
-    constexpr int NW = O + 1, H = NW / 2;
-    static_assert(NW % 2 == 0, "the planes split into two halves at odd orders only");
-    constexpr double one_third = 1.0 / 3.0, one_sixth = 1.0 / 6.0;
-    const int jx = shape_node_of<O>(c1.x_new), jy = shape_node_of<O>(c1.y_new), jz = shape_node_of<O>(c1.z_new);
-    auto running = [&](double (&D)[O], const double wq, const double invdtd, const double xn, const double xo, const int j) {
-        double n[NW], o[NW];
-        bspline_weights<O, true>(n, xn, j);
-        bspline_weights<O, true>(o, xo, j);
-        double r = 0.0;
-#pragma unroll
-        for (int l = 0; l < O; ++l) {
-            r += wq * invdtd * sub_rn(o[l], n[l]);
-            D[l] = r;
-        }
-    };
-    auto phase = [&](auto comp, Sink& sink, const double (&D1)[O], const double (&D2)[O], const double (&a1n)[NW],
-                     const double (&a1o)[NW], const double (&a2n)[NW], const double (&a2o)[NW], const double (&b1n)[NW],
-                     const double (&b1o)[NW], const double (&b2n)[NW], const double (&b2o)[NW]) {
-        constexpr int c = decltype(comp)::value;
-#pragma unroll
-        for (int b = 0; b < H; ++b) {
-            const double P1 = one_third * b1n[b] + one_sixth * b1o[b], Q1 = one_third * b1o[b] + one_sixth * b1n[b];
-            const double P2 = one_third * b2n[b] + one_sixth * b2o[b], Q2 = one_third * b2o[b] + one_sixth * b2n[b];
-            const double P1h = one_third * b1n[b + H] + one_sixth * b1o[b + H], Q1h = one_third * b1o[b + H] + one_sixth * b1n[b + H];
-            const double P2h = one_third * b2n[b + H] + one_sixth * b2o[b + H], Q2h = one_third * b2o[b + H] + one_sixth * b2n[b + H];
-#pragma unroll
-            for (int a = 0; a < NW; ++a) {
-                const double T1 = a1n[a] * P1 + a1o[a] * Q1, T2 = a2n[a] * P2 + a2o[a] * Q2;
-                const double T1h = a1n[a] * P1h + a1o[a] * Q1h, T2h = a2n[a] * P2h + a2o[a] * Q2h;
-#pragma unroll
-                for (int l = 0; l < O; ++l) {
-                    const double v = swap_add_halves(D1[l] * T1 + D2[l] * T2, D1[l] * T1h + D2[l] * T2h);
-                    if constexpr (c == 0) sink.add(0, l + 1, a + 1, b + 1, v);
-                    else if constexpr (c == 1) sink.add(1, a + 1, l + 1, b + 1, v);
-                    else sink.add(2, a + 1, b + 1, l + 1, v);
-                }
-            }
-        }
-    };
-    double x1n[NW], x1o[NW], x2n[NW], x2o[NW];
-    bspline_weights<O, true>(x1n, c1.x_new, jx); bspline_weights<O, true>(x1o, c1.x_old, jx);
-    bspline_weights<O, true>(x2n, c2.x_new, jx); bspline_weights<O, true>(x2o, c2.x_old, jx);
-    double y1n[NW], y1o[NW], y2n[NW], y2o[NW];
-    bspline_weights<O, true>(y1n, c1.y_new, jy); bspline_weights<O, true>(y1o, c1.y_old, jy);
-    bspline_weights<O, true>(y2n, c2.y_new, jy); bspline_weights<O, true>(y2o, c2.y_old, jy);
-    {   // Jz: rows (i, j), running along k
-        double D1[O], D2[O];
-        running(D1, wq1, es.invdtd[2], c1.z_new, c1.z_old, jz);
-        running(D2, wq2, es.invdtd[2], c2.z_new, c2.z_old, jz);
-        phase(std::integral_constant<int, 2>{}, sink_jz, D1, D2, x1n, x1o, x2n, x2o, y1n, y1o, y2n, y2o);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    double z1n[NW], z1o[NW], z2n[NW], z2o[NW];
-    bspline_weights<O, true>(z1n, c1.z_new, jz); bspline_weights<O, true>(z1o, c1.z_old, jz);
-    bspline_weights<O, true>(z2n, c2.z_new, jz); bspline_weights<O, true>(z2o, c2.z_old, jz);
-    double Dy1[O], Dy2[O];
-    {   // Jx: rows (j, k), running along i; Dy is taken here, before the y weights die
-        double D1[O], D2[O];
-        double r1 = 0.0, r2 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int l = 0; l < O; ++l) {
-            r1 += wq1 * es.invdtd[0] * sub_rn(x1o[l], x1n[l]);
-            r2 += wq2 * es.invdtd[0] * sub_rn(x2o[l], x2n[l]);
-            s1 += wq1 * es.invdtd[1] * sub_rn(y1o[l], y1n[l]);
-            s2 += wq2 * es.invdtd[1] * sub_rn(y2o[l], y2n[l]);
-            D1[l] = r1; D2[l] = r2; Dy1[l] = s1; Dy2[l] = s2;
-        }
-        phase(std::integral_constant<int, 0>{}, sink_jxy, D1, D2, y1n, y1o, y2n, y2o, z1n, z1o, z2n, z2o);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // Jy: rows (i, k), running along j
-    phase(std::integral_constant<int, 1>{}, sink_jxy, Dy1, Dy2, x1n, x1o, x2n, x2o, z1n, z1o, z2n, z2o);
-}
-
 // One component of one particle that may cross a cell face in any direction (but stays on the tile): the Esirkepov
 // sums of CurrentDeposition.H:777-824 on a frame of O+2 slots per direction that starts at the lower of the old and the
 // new reference node, with compile-time loop bounds -- weights outside a position's own O+1 slots are exact zeros, so the

@@ -36,7 +36,6 @@ template <int TW_, int TJ_, int KC_, int NT_, int BATCH_ = 0>
 struct StencilCfg {
     static constexpr int TW = TW_, TI = 64 * TW_, TJ = TJ_, KC = KC_, NT = NT_, BATCH = BATCH_;
 };
-constexpr int TI = 64, TJ = 2, KC = 4;   // the thin-box launches (guard layer) use the plain configuration
 
 struct TileGrid {
     int nti, ntj, ntk;
@@ -52,7 +51,6 @@ static TileGrid make_tiles_cfg(const Box3& ub) {
     t.ntiles = (long)t.nti * t.ntj * t.ntk;
     return t;
 }
-static TileGrid make_tiles(const Box3& ub) { return make_tiles_cfg<StencilCfg<1, TJ, KC, 0>>(ub); }
 
 __device__ inline bool in_ij(const Box3& b, int i, int j) {
     return i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1];
@@ -246,8 +244,6 @@ evolve_e_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, DevF Jx, D
 //   Round 4 (profiles/round4/r4b_stencil_loads_before_stores.txt, same box, two rounds): every load ahead of the first store
 //   (BATCH) 0.2414 -> 0.2326 / 0.3081 -> 0.3031 ms (62.5 -> 64.9 / 65.3 -> 66.4 %); two planes per lane the same.
 using StProduction = StencilCfg<1, 1, 3, 1, 1>;
-// (StPlain: the tiled kernel on thin boxes; the guard layer has its own kernel since round 6, evolve_b_faces_kernel)
-using StPlain = StencilCfg<1, 2, 4, 0>;
 
 // The first guard layer of B on every face of the brick (wxa_evolve_b_guard_layer): evolve_b_kernel's update, term by
 // term in the same order (bit-identical to the valid points the neighbour brick computes), one lane per point.
@@ -286,35 +282,7 @@ evolve_b_faces_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Face
         *bz = *bz + (dt * (idy * (ex[Ex.js] - ex[0])) - dt * (idx * (ey[1] - ey[0])));
     }
 }
-#ifdef WXA_DEV_VARIANTS   // the sweep above: WXA_STENCIL_VARIANT=<n> per launch (scripts/stencil_variants.py, dev builds only)
-using St1 = StencilCfg<1, 2, 4, 1>;
-using St2 = StencilCfg<1, 1, 4, 1>;
-using St4 = StencilCfg<1, 1, 2, 1>;
-using St5 = StencilCfg<1, 4, 2, 1>;
-using St6 = StencilCfg<1, 1, 3, 2>;
-using St7 = StencilCfg<4, 1, 4, 1>;
-using St8 = StencilCfg<1, 1, 3, 1, 0>;   // production until round 3: load -> wait -> store, plane by plane
-using St9 = StencilCfg<1, 1, 2, 1, 1>;   // ... two planes per lane (fewer registers, more waves)
-static int stencil_variant() {
-    const char* e = getenv("WXA_STENCIL_VARIANT");
-    return e ? atoi(e) : -1;
-}
-#define WXA_STENCIL_DISPATCH(CALL)          \
-    switch (stencil_variant()) {            \
-        case 0: CALL(StPlain); break;       \
-        case 1: CALL(St1); break;           \
-        case 2: CALL(St2); break;           \
-        case 4: CALL(St4); break;           \
-        case 5: CALL(St5); break;           \
-        case 6: CALL(St6); break;           \
-        case 7: CALL(St7); break;           \
-        case 8: CALL(St8); break;           \
-        case 9: CALL(St9); break;           \
-        default: CALL(StProduction); break; \
-    }
-#else
 #define WXA_STENCIL_DISPATCH(CALL) CALL(StProduction);
-#endif
 
 // generic box copy kernels -----------------------------------------------------
 struct BoxN {
@@ -656,22 +624,9 @@ __device__ inline bool in_box(const Box3& b, int i, int j, int k) {
     return i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1] && k >= b.lo[2] && k < b.hi[2];
 }
 
-// EvolveBCartesian<CartesianCKCAlgorithm> (EvolveB.cpp:164-186).  Plain version (WXA_CKC_PLAIN=1): one lane per point
-// of the union of the three valid boxes, i fastest (coalesced rows; the 3 x 18 neighbour reads of a point are served
-// by L1/L2: each E value is read by up to 16 points of three components).
-__global__ void __launch_bounds__(256)
-evolve_b_ckc_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, Box3 ub, Box3 bbx, Box3 bby, Box3 bbz,
-                    double dt, CkcCoefs c) {
-    const int i = ub.lo[0] + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int j = ub.lo[1] + (int)(blockIdx.y * blockDim.y + threadIdx.y);
-    const int k = ub.lo[2] + (int)blockIdx.z;
-    if (i >= ub.hi[0] || j >= ub.hi[1]) return;
-    if (in_box(bbx, i, j, k)) Bx(i, j, k) += dt * ckc_up_z(Ey, c.z, i, j, k) - dt * ckc_up_y(Ez, c.y, i, j, k);
-    if (in_box(bby, i, j, k)) By(i, j, k) += dt * ckc_up_x(Ez, c.x, i, j, k) - dt * ckc_up_z(Ex, c.z, i, j, k);
-    if (in_box(bbz, i, j, k)) Bz(i, j, k) += dt * ckc_up_y(Ex, c.y, i, j, k) - dt * ckc_up_x(Ey, c.x, i, j, k);
-}
-
-// The same update with the E planes staged in LDS (production).  A workgroup owns 64 x TJ points of KC consecutive
+// EvolveBCartesian<CartesianCKCAlgorithm> (EvolveB.cpp:164-186).  (A plain version -- one lane per point, the 3 x 18
+// neighbour reads of a point through L1 / L2 -- took 1.04 ms at 256^3; it is in the history of this file.)
+// The update with the E planes staged in LDS.  A workgroup owns 64 x TJ points of KC consecutive
 // planes; it keeps four planes of each E component, with one halo point on every side in i and j, in a ring: while
 // plane k is computed from k-1, k, k+1, plane k+2 replaces plane k-2 (one barrier per plane).  PIPE: the values of
 // plane k+2 are loaded into registers before plane k is computed and written to LDS after it, so the loads' latency
@@ -812,18 +767,6 @@ evolve_b_ckc_tiled_kernel(DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By, DevF Bz, 
 // 0.3379 ms (44.7 %); the same tile with the planes requested two steps ahead 0.3378 -- the loads' latency is not what
 // limits it; 4 rows x 16 planes, two steps ahead (38 KB of LDS: four workgroups per CU) 0.3172 ms (47.6 %), 4 x 32 0.341.
 using CkcProduction = CkcCfg<4, 16, 2>;
-#ifdef WXA_DEV_VARIANTS   // tile shapes of the timing sweep (WXA_CKC_VARIANT, scripts/ckc_timing.py; dev builds only)
-using Ckc0 = CkcCfg<8, 16, 0>;
-using Ckc2 = CkcCfg<8, 32, 1>;
-using Ckc3 = CkcCfg<4, 32, 1>;
-using Ckc4 = CkcCfg<16, 16, 1>;
-using Ckc5 = CkcCfg<8, 8, 1>;
-using Ckc6 = CkcCfg<8, 16, 2>;   // planes requested two steps ahead
-using Ckc7 = CkcCfg<8, 32, 2>;
-using Ckc8 = CkcCfg<8, 16, 1>;   // production until round 3
-using Ckc9 = CkcCfg<4, 32, 2>;
-#endif
-
 // Source/Filter/Filter.cpp:105-133 with the 1-pass stencil of BilinearFilter.cpp:26-60 ({0.25, 0.25} per direction);
 // same tap order as the reference -> bit-identical.  The staging of the CKC kernel above: a workgroup filters
 // 64 x TJ points of KC planes from a ring of four staged input planes (halo of one point, zero padding beyond the
@@ -1090,19 +1033,7 @@ wxa_status wxa_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3]
     }
     CkcCoefs cc;
     for (int n = 0; n < 5; ++n) { cc.x[n] = cx[n]; cc.y[n] = cy[n]; cc.z[n] = cz[n]; }
-#ifdef WXA_DEV_VARIANTS
-    const char* plain = getenv("WXA_CKC_PLAIN");   // the one-lane-per-point kernel (reference for the tiled one, timing)
-#else
-    const char* plain = nullptr;
-#endif
-    if (plain && atoi(plain) != 0) {
-        const dim3 block(64, 4);
-        const dim3 grid((unsigned)((ub.hi[0] - ub.lo[0] + 63) / 64), (unsigned)((ub.hi[1] - ub.lo[1] + 3) / 4),
-                        (unsigned)(ub.hi[2] - ub.lo[2]));
-        WXA_REQUIRE(grid.z <= 65535u, "more than 65535 planes");
-        hipLaunchKernelGGL(evolve_b_ckc_kernel, grid, block, 0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]),
-                           make_devf(E[2]), make_devf(B[0]), make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, dt, cc);
-    } else {
+    {
 #define WXA_CKC_LAUNCH(CFG)                                                                                            \
     do {                                                                                                               \
         const TileGrid tg = make_tiles_cfg<StencilCfg<1, CFG::TJ, CFG::KC, 1>>(ub);                                    \
@@ -1110,23 +1041,7 @@ wxa_status wxa_evolve_b_ckc(const wxa_field_view E[3], const wxa_field_view B[3]
                            0, (hipStream_t)stream, make_devf(E[0]), make_devf(E[1]), make_devf(E[2]), make_devf(B[0]),    \
                            make_devf(B[1]), make_devf(B[2]), ub, bx, by, bz, tg, dt, cc);                              \
     } while (0)
-#ifdef WXA_DEV_VARIANTS
-        const char* var = getenv("WXA_CKC_VARIANT");
-        switch (var ? atoi(var) : -1) {
-            case 0: WXA_CKC_LAUNCH(Ckc0); break;
-            case 2: WXA_CKC_LAUNCH(Ckc2); break;
-            case 3: WXA_CKC_LAUNCH(Ckc3); break;
-            case 4: WXA_CKC_LAUNCH(Ckc4); break;
-            case 5: WXA_CKC_LAUNCH(Ckc5); break;
-            case 6: WXA_CKC_LAUNCH(Ckc6); break;
-            case 7: WXA_CKC_LAUNCH(Ckc7); break;
-            case 8: WXA_CKC_LAUNCH(Ckc8); break;
-            case 9: WXA_CKC_LAUNCH(Ckc9); break;
-            default: WXA_CKC_LAUNCH(CkcProduction); break;
-        }
-#else
         WXA_CKC_LAUNCH(CkcProduction);
-#endif
 #undef WXA_CKC_LAUNCH
     }
     WXA_LAUNCH_CHECK();

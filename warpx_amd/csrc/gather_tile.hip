@@ -254,18 +254,12 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
             if (a < NPTS) F[c * NPTS + a] = r[n];
         }
     };
-    if constexpr (PF == 9) {   // timing experiment (dev builds): no staging, the tile holds a constant
-        for (int a = tid; a < 6 * NPTS; a += GT_THREADS) F[a] = 1.0;
-    } else {
+    {
         double r0[PER], r1[PER], r2[PER], r3[PER], r4[PER], r5[PER];
         fetch(Ex, r0); fetch(Ey, r1); fetch(Ez, r2); fetch(Bx, r3); fetch(By, r4); fetch(Bz, r5);
         put(0, r0); put(1, r1); put(2, r2); put(3, r3); put(4, r4); put(5, r5);
     }
     __syncthreads();
-    if constexpr (PF == 8) {   // timing experiment (dev builds): the staging alone
-        if (F[tid] == 1.2345e-300) p.x[start] = F[tid + 1];
-        return;
-    }
     GPROF_CLOCK(prof_t1);
     GPROF_ADD(0, prof_t1 - prof_t0);
     GPROF_ADD(2, 1);
@@ -336,13 +330,6 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
 #endif
         GPROF_CLOCK(prof_c);
         if constexpr (!PREFETCH) { ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip]; }
-        if constexpr (PF == 7) {   // timing experiment (dev builds): everything but the stores
-            double ex_ = Exp, ey_ = Eyp, ez_ = Ezp, bx_ = Bxp, by_ = Byp, bz_ = Bzp;
-            add_external_fields(ext, ip, ex_, ey_, ez_, bx_, by_, bz_);
-            push_momentum<PUSHER>(ux0, uy0, uz0, ex_, ey_, ez_, bx_, by_, bz_, q, m, dt);
-            update_position(xp, yp, zp, ux0, uy0, uz0, dt);
-            if (xp + ux0 == 1.2345e-300) p.x[ip] = yp + zp + uy0 + uz0;
-        } else
         push_and_store<PUSHER, MOVE, ST>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext, hook, storing, staged,
                                          count_local ? lhist : nullptr, tile);
 #ifdef WXA_GATHER_PROFILE
@@ -388,26 +375,6 @@ gather_push_stragglers_kernel(PV p, const int* __restrict__ idx, const unsigned*
     }
 }
 
-#ifdef WXA_DEV_VARIANTS   // for the fused kernel's stragglers (deposit_tile.hip, dev builds)
-wxa_status gather_push_listed(const wxa_particle_view* p, const int* idx, const unsigned* count, const wxa_field_view E[3],
-                              const wxa_field_view B[3], const wxa_grid_geom* geom, double q, double m, double dt, int pusher,
-                              hipStream_t st) {
-    const PV pv = make_pv(*p);
-    const Geom g = make_geom(*geom);
-    const DevF ex = make_devf(E[0]), ey = make_devf(E[1]), ez = make_devf(E[2]);
-    const DevF bx = make_devf(B[0]), by = make_devf(B[1]), bz = make_devf(B[2]);
-    const ExtEB ext{};
-    if (pusher == WXA_PUSHER_VAY)
-        hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, WXA_PUSHER_VAY, true>), dim3(512), dim3(256), 0, st, pv, idx,
-                           count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, PushSort{});
-    else
-        hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, WXA_PUSHER_BORIS, true>), dim3(512), dim3(256), 0, st, pv, idx,
-                           count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, PushSort{});
-    WXA_LAUNCH_CHECK();
-    return WXA_OK;
-}
-#endif
-
 bool gather_tile_available(const wxa_workspace* ws, const wxa_particle_view* p) {
     return ws && ws->sorted_valid && ws->sorted_x == p->x && ws->sorted_np <= p->np;
 }
@@ -446,51 +413,6 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
         hipLaunchKernelGGL((gather_push_stragglers_kernel<O, G, PUSHER, MOVE>), dim3(WXA_STRAGGLER_BLOCKS), dim3(256), 0, st, pv, \
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, hook);                     \
     } while (0)
-#ifdef WXA_DEV_VARIANTS   // A/B timing builds only (scripts/gather_variants.py): rows in flight per env, 0 = ds_read2_b64 rows
-    if constexpr (PUSHER == WXA_PUSHER_BORIS && MOVE && PART == 0) {
-        const char* e = getenv("WXA_GATHER_RB");
-        const char* epf = getenv("WXA_GATHER_PF");
-        const int pf = epf ? atoi(epf) : WXA_GATHER_PF;
-        const char* est = getenv("WXA_GATHER_ST");
-        const int stv = est ? atoi(est) : 0;
-        const char* esl = getenv("WXA_GATHER_SL");
-        const int slv = esl ? atoi(esl) : WXA_GATHER_SL;
-        if (e && galerkin && order == 3) {
-#define WXA_GT_RB(RBV)                                                                                          \
-    do {                                                                                                        \
-        if (pf == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 1>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        else if (pf == 2) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 2>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        else if (pf == 3 && slv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 1>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        else if (pf == 3 && stv == 1) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 1, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        else if (pf == 3) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 3, 0, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        else if (pf == 7) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 7>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        else if (pf == 8) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 8>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        else if (pf == 9) hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 9>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        else hipLaunchKernelGGL((gather_push_tile_kernel<3, 1, PUSHER, MOVE, PART, RBV, 0>), grid, block, 0, st, pv, offsets, \
-                           ex, ey, ez, bx, by, bz, g, tg, q, m, dt, sq, ext, hook, hu);                                   \
-        hipLaunchKernelGGL((gather_push_stragglers_kernel<3, 1, PUSHER, MOVE>), dim3(512), dim3(256), 0, st, pv, \
-                           sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, hook);                         \
-    } while (0)
-            switch (atoi(e)) {
-                case 0: WXA_GT_RB(0); break;
-                case 1: WXA_GT_RB(1); break;
-                case 3: WXA_GT_RB(3); break;
-                default: WXA_GT_RB(2); break;
-            }
-#undef WXA_GT_RB
-            WXA_LAUNCH_CHECK();
-            return WXA_OK;
-        }
-    }
-#endif
     if (galerkin) {
         if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else WXA_GT(3, 1);
     } else {

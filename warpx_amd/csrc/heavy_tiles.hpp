@@ -40,6 +40,7 @@ __device__ __forceinline__ bool heavy_unit_of(const HeavyUnits& hu, const long b
     const long e = bid - hu.grid_tiles;
     if (e >= (long)*hu.nextra) return false;
     tile = hu.extra[2 * e];
+    if (tile < 0) return false;   // an entry the planner withdrew (its overflow guard)
     u = hu.extra[2 * e + 1];
     k = hu.kt[tile];
     return true;
@@ -55,7 +56,11 @@ plan_heavy_tiles_kernel(const int* __restrict__ offsets, long ntiles, int cells_
     if (k > 1) {
         const unsigned base = atomicAdd(nextra, (unsigned)(k - 1));
         if ((long)base + (k - 1) > max_extra) {
-            k = 1;   // no room (cannot happen with max_extra = np / heavy + 1; kept as a guard): the tile stays whole
+            // no room (cannot happen with max_extra = np / heavy + 1; kept as a guard): the tile stays whole, and the
+            // entries it claimed -- as far as the table reaches -- name no tile, so that the extra workgroups that read
+            // them leave at once (heavy_unit_of) instead of working on whatever the table held
+            for (long e = base; e < (long)base + (k - 1) && e < max_extra; ++e) { extra[2 * e] = -1; extra[2 * e + 1] = 0; }
+            k = 1;
         } else {
             for (int u = 1; u < k; ++u) { extra[2 * (base + u - 1)] = (int)t; extra[2 * (base + u - 1) + 1] = u; }
         }

@@ -864,6 +864,18 @@ inline std::unique_ptr<SimHandle> sim_from_inputs(const Backend* be, const std::
                     pp.ignore_prefix(d + ".");
                     continue;
                 }
+                //  In memory only on request: assembling the snapshots costs a device-to-host pass over nine
+                // fields and a charge deposition every step, and whole lab-frame snapshots accumulate in host memory for the
+                // length of the run -- a production deck written for openPMD output must not pay that for files nobody gets.
+                int keep = 0;
+                pp.queryWithParser("warpx_amd.btd_in_memory", keep);
+                if (!keep) {
+                    std::fprintf(stderr, "[warpx_amd] diagnostic %s (BackTransformed, format = %s) is left out: this library writes "
+                                 "plotfiles (warpx_amd.btd_in_memory = 1 assembles the snapshots in host memory for "
+                                 "wxa_sim_btd_info / _data / _particles instead)\n", d.c_str(), format.c_str());
+                    pp.ignore_prefix(d + ".");
+                    continue;
+                }
                 std::fprintf(stderr, "[warpx_amd] diagnostic %s: format = %s is not written by this library; its snapshots stay in "
                              "memory (wxa_sim_btd_info / _data / _particles)\n", d.c_str(), format.c_str());
                 in_memory_only = true;

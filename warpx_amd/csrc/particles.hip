@@ -158,25 +158,7 @@ sort_count_kernel(const double* __restrict__ x, const double* __restrict__ y,
     }
 }
 
-__global__ void __launch_bounds__(256)
-sort_scatter_kernel(PV src, PV dst, const int* __restrict__ cell, const int* __restrict__ rank,
-                    const int* __restrict__ offsets) {
-    const long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ip >= src.np) return;
-    // every load before the first store: as `dst.x[d] = src.x[ip]; dst.y[d] = src.y[ip]; ...` the compiler keeps the
-    // order (the PV members' __restrict__ does not reach it) and a lane waits out eight memory latencies in a row
-    const int c = cell[ip], r = rank[ip];
-    const double x = src.x[ip], y = src.y[ip], z = src.z[ip], w = src.w[ip];
-    const double ux = src.ux[ip], uy = src.uy[ip], uz = src.uz[ip];
-    const bool has_id = src.id && dst.id;
-    const uint64_t id = has_id ? src.id[ip] : 0;
-    const long d = (long)offsets[c] + r;
-    dst.x[d] = x; dst.y[d] = y; dst.z[d] = z; dst.w[d] = w;
-    dst.ux[d] = ux; dst.uy[d] = uy; dst.uz[d] = uz;
-    if (has_id) dst.id[d] = id;
-}
-
-// The same scatter for an input that is nearly sorted already (every sort after the first: a particle moves less than
+// The scatter, for an input that is nearly sorted already (every sort after the first: a particle moves less than
 // a cell between sorts, so its destination index is within a few hundred of its source index).  A workgroup takes
 // SW_CHUNK consecutive source particles and a window of destination indices around them; a component at a time, the
 // particles whose destination lies inside the window are placed at their destination offset in LDS and the window is
@@ -283,7 +265,7 @@ partition_scatter_kernel(PV src, PV dst, const double* __restrict__ pos, double 
     if (v < lo) d = nstay + (long)atomicAdd(&cursors[1], 1ULL);
     else if (v >= hi) d = nstay + nminus + (long)atomicAdd(&cursors[2], 1ULL);
     else d = stay_scan[ip];
-    const double x = src.x[ip], y = src.y[ip], z = src.z[ip], w = src.w[ip];   // loads first, see sort_scatter_kernel
+    const double x = src.x[ip], y = src.y[ip], z = src.z[ip], w = src.w[ip];   // every load before the first store
     const double ux = src.ux[ip], uy = src.uy[ip], uz = src.uz[ip];
     const bool has_id = src.id && dst.id;
     const uint64_t id = has_id ? src.id[ip] : 0;
@@ -715,39 +697,6 @@ wxa_status wxa_push_p(const wxa_particle_view* p, const wxa_field_view E[3], con
     return wxa_gather_push_ws(p, E, B, geom, q, m, dt, order, galerkin, pusher, 0, nullptr, stream);
 }
 
-#ifdef WXA_DEV_VARIANTS
-// Measurement only (dev builds; scripts/fused_timing.py, tests/test_kernels_gpu.py::test_push_and_deposit_in_one_kernel):
-// PhysicalParticleContainer::Evolve's PushPX + DepositCurrent (PhysicalParticleContainer.cpp:1812-2095) of the sorted part
-// of a tile as ONE kernel over the LDS tiles (deposit_tile.hip, CFG::FUSED) -- order 3, energy-conserving gather,
-// Esirkepov, Boris or Vay, fp64 tiles, no external particle fields; the two calls one after the other otherwise.
-// Correct, and 30 % slower than the two kernels (profiles/round3/README.md): not in the C-ABI, not used by the host layer.
-wxa_status wxa_debug_push_and_deposit(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
-                                const wxa_field_view J[3], const wxa_grid_geom* geom_eb, const wxa_grid_geom* geom_j,
-                                double q, double m, double dt, double relative_time, int order, int galerkin, int pusher,
-                                int algo, wxa_workspace* ws, void* stream) {
-    wxa_status rc = check_gather_args(p, E, B, geom_eb, order, galerkin, pusher);
-    if (rc != WXA_OK) return rc;
-    WXA_REQUIRE(J && geom_j, "null argument");
-    if (p->np == 0) return WXA_OK;
-    if (ws && dt > 0.0 && yee_E(J) && push_deposit_tile_available(ws, p, order, galerkin, pusher, algo)) {
-        for (int c = 0; c < 3; ++c) WXA_REQUIRE(view_ok(J[c]), "bad field view");
-        // the sorted part on the LDS tiles in one kernel; particles appended since the sort through the global-memory kernels
-        wxa_particle_view head = *p;
-        head.np = ws->sorted_np;
-        if (head.np > 0 && (rc = push_deposit_tiled(&head, E, B, J, geom_eb, geom_j, q, m, dt, relative_time, pusher, ws,
-                                                    (hipStream_t)stream)) != WXA_OK)
-            return rc;
-        const wxa_particle_view rest = tail_view(*p, ws->sorted_np);
-        if (rest.np == 0) return WXA_OK;
-        if ((rc = wxa_gather_push_ws(&rest, E, B, geom_eb, q, m, dt, order, galerkin, pusher, 1, nullptr, stream)) != WXA_OK)
-            return rc;
-        return wxa_deposit_current(&rest, J, geom_j, q, dt, relative_time, order, algo, nullptr, stream);
-    }
-    if ((rc = wxa_gather_push_ws(p, E, B, geom_eb, q, m, dt, order, galerkin, pusher, 1, ws, stream)) != WXA_OK) return rc;
-    return wxa_deposit_current(p, J, geom_j, q, dt, relative_time, order, algo, ws, stream);
-}
-#endif
-
 wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view J[3], const wxa_grid_geom* geom,
                                double q, double dt, double relative_time, int order, int algo,
                                wxa_workspace* ws, void* stream) {
@@ -938,31 +887,18 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     sg.retired_bin = (int)ncells;
     (void)cell_lo;
     const PV s = make_pv(*src), d = make_pv(*dst);
-#ifdef WXA_DEV_VARIANTS   // WXA_SORT_SCATTER=0: the plain scatter (one lane per particle, 8-byte writes wherever they fall); 1: keys from the array
-    const char* scatter_env = std::getenv("WXA_SORT_SCATTER");
-    const bool plain_scatter = scatter_env && std::atoi(scatter_env) == 0;
-    const bool keys_from_array = plain_scatter || (scatter_env && std::atoi(scatter_env) == 1);
-#else
-    const bool plain_scatter = false, keys_from_array = false;
-#endif
     hipLaunchKernelGGL(sort_count_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s.x, s.y, s.z, s.id, s.np, sg,
-                       keys_from_array ? cell : (int*)nullptr, rank, hist);
+                       (int*)nullptr, rank, hist);
     size_t tmp_bytes = 0;
     WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
     if ((rc = ws->scan_tmp.reserve(tmp_bytes)) != WXA_OK) return rc;
     WXA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ws->scan_tmp.p, tmp_bytes, hist, offsets, (int)(ncells + 2), st));
-    if (plain_scatter)
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks_for(s.np)), dim3(256), 0, st, s, d, cell, rank, offsets);
-    else {
-        // window shapes timed at 256^3 x 8 ppc (Redistribute per step, plain scatter 1.47): 8 x 512 lanes + 512 margin
-        // 1.24, 4 x 512 + 512 1.29, 8 x 512 + 1024 1.25, 16 x 512 + 512 1.38
-        if (keys_from_array)
-            hipLaunchKernelGGL((sort_scatter_window_kernel<8, 512, false>), dim3(blocks_for(s.np, SW_THREADS * 8)), dim3(SW_THREADS), 0,
-                               st, s, d, cell, rank, offsets, sg);
-        else
-            hipLaunchKernelGGL((sort_scatter_window_kernel<8, 512, true>), dim3(blocks_for(s.np, SW_THREADS * 8)), dim3(SW_THREADS), 0,
-                               st, s, d, cell, rank, offsets, sg);
-    }
+    // the scatter works the keys out again from the positions it loads (round 4) and stages a chunk's near-stayers in LDS
+    // in destination order, so that it writes whole lines.  Window shapes timed at 256^3 x 8 ppc (Redistribute per step;
+    // the plain scatter -- one lane per particle, 8-byte writes wherever they fall -- 1.47): 8 x 512 lanes + 512 margin
+    // 1.24, 4 x 512 + 512 1.29, 8 x 512 + 1024 1.25, 16 x 512 + 512 1.38
+    hipLaunchKernelGGL((sort_scatter_window_kernel<8, 512, true>), dim3(blocks_for(s.np, SW_THREADS * 8)), dim3(SW_THREADS), 0,
+                       st, s, d, cell, rank, offsets, sg);
     WXA_LAUNCH_CHECK();
     ws->sorted_valid = true;
     ws->sorted_np = src->np;   // wxa_sort_live_count lowers it to the live count

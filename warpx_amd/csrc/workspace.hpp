@@ -131,16 +131,6 @@ bool deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p)
 wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_view J[3],
                                  const wxa_grid_geom* geom, double q, double dt, double relative_time,
                                  int order, int algo, wxa_workspace* ws, hipStream_t stream);
-// PushPX + DepositCurrent on the LDS tiles in one kernel (deposit_tile.hip, CFG::FUSED)
-bool push_deposit_tile_available(const wxa_workspace* ws, const wxa_particle_view* p, int order, int galerkin, int pusher,
-                                 int algo);
-wxa_status push_deposit_tiled(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
-                              const wxa_field_view J[3], const wxa_grid_geom* geom_eb, const wxa_grid_geom* geom_j, double q,
-                              double m, double dt, double relative_time, int pusher, wxa_workspace* ws, hipStream_t stream);
-// gather + push (order 3, energy-conserving, Boris or Vay) of the particles listed in idx[0 .. *count) (gather_tile.hip)
-wxa_status gather_push_listed(const wxa_particle_view* p, const int* idx, const unsigned* count, const wxa_field_view E[3],
-                              const wxa_field_view B[3], const wxa_grid_geom* geom, double q, double m, double dt, int pusher,
-                              hipStream_t stream);
 // LDS-tile gather + push (gather_tile.hip)
 bool gather_tile_available(const wxa_workspace* ws, const wxa_particle_view* p);
 wxa_status gather_push_tiled(const wxa_particle_view* p, const wxa_field_view E[3], const wxa_field_view B[3],
