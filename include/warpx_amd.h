@@ -539,7 +539,7 @@ typedef struct wxa_sim_config {
     double  prob_lo[3];          /* geometry.prob_lo                            */
     double  prob_hi[3];          /* geometry.prob_hi                            */
     double  cfl;                 /* warpx.cfl (CartesianYeeAlgorithm.H:48-56)   */
-    int32_t nox;                 /* algo.particle_shape, 1..4 (4: global-memory kernels) */
+    int32_t nox;                 /* algo.particle_shape, 1..4 (all on the LDS tiles; 4 since round 6) */
     int32_t galerkin;            /* WarpX::galerkin_interpolation (WarpX.cpp:154) */
     int32_t particle_pusher;     /* WXA_PUSHER_*                                */
     int32_t current_deposition;  /* WXA_DEPOSIT_*                               */

@@ -220,6 +220,8 @@ inline double swap_add_halves(const double v_lo_planes, const double v_hi_planes
     return (threadIdx.x & 32) ? phi + v_hi_planes : v_lo_planes + plo;
 }
 inline int partner32(const int v) { return __shfl_xor(v, 32); }
+#define WXA_HAVE_PARTNER32 1
+inline double partner32_f64(const double v) { return __shfl_xor(v, 32); }
 #define WXA_HAVE_LANE_XOR1
 inline double lane_xor1(const double v) { return __shfl_xor(v, 1); }
 #define WXA_HAVE_WAVE_SUM_F64

@@ -414,7 +414,7 @@ def test_enforce_periodic_through_the_sort(product, steps):
     product.workspace_destroy(ws)
 
 
-@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
 @pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
 @pytest.mark.parametrize("stale", [False, True])
 @pytest.mark.parametrize("u_scale", [1.0, 0.003])
@@ -455,7 +455,7 @@ def test_deposit_current_lds_tiles(oracle, product, order, algo, stale, u_scale)
     product.workspace_destroy(ws)
 
 
-@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
 @pytest.mark.parametrize("algo", [_capi.DEPOSIT_ESIRKEPOV, _capi.DEPOSIT_DIRECT])
 @pytest.mark.parametrize("drift", [0.0, 2.5])
 @pytest.mark.parametrize("heavy", [None, 1500])
@@ -691,7 +691,9 @@ def test_deposit_current_fp32_tiles(oracle, product, order, u_scale):
 @pytest.mark.parametrize("order,galerkin,pusher", [(1, 1, _capi.PUSHER_BORIS), (2, 1, _capi.PUSHER_BORIS), (3, 1, _capi.PUSHER_BORIS),
                                                    (3, 0, _capi.PUSHER_BORIS), (2, 0, _capi.PUSHER_BORIS), (1, 0, _capi.PUSHER_BORIS),
                                                    (3, 1, _capi.PUSHER_VAY), (3, 0, _capi.PUSHER_VAY), (2, 1, _capi.PUSHER_VAY),
-                                                   (3, 1, _capi.PUSHER_HC), (1, 0, _capi.PUSHER_HC)])
+                                                   (3, 1, _capi.PUSHER_HC), (1, 0, _capi.PUSHER_HC),
+                                                   # order 4 on the tiles (round 6): 13^3 / 14^3 staged points
+                                                   (4, 1, _capi.PUSHER_BORIS), (4, 0, _capi.PUSHER_BORIS), (4, 1, _capi.PUSHER_VAY)])
 @pytest.mark.parametrize("stale", [False, True])
 @pytest.mark.parametrize("heavy", [None, 700])
 def test_gather_push_lds_tiles(oracle, product, order, galerkin, pusher, stale, heavy, monkeypatch):

@@ -52,7 +52,7 @@ def _compare(a, b, rtol=RTOL):
     (3, _capi.DEPOSIT_ESIRKEPOV, _capi.PUSHER_BORIS, 1),   # config 2 shape
     (3, _capi.DEPOSIT_DIRECT, _capi.PUSHER_VAY, 0),
     (2, _capi.DEPOSIT_ESIRKEPOV, _capi.PUSHER_VAY, 0),
-    (4, _capi.DEPOSIT_ESIRKEPOV, _capi.PUSHER_BORIS, 1),   # order 4 (ShapeFactors.H:67-77, 138-149): the global-memory kernels
+    (4, _capi.DEPOSIT_ESIRKEPOV, _capi.PUSHER_BORIS, 1),   # order 4 (ShapeFactors.H:67-77, 138-149): on the LDS tiles since round 6
     (4, _capi.DEPOSIT_DIRECT, _capi.PUSHER_BORIS, 0),
 ])
 def test_uniform_plasma_parity(oracle, product, order, depos, pusher, filt):

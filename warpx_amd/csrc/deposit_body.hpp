@@ -211,7 +211,7 @@ struct EsirkepovNC {
 // index it (ShapeFactors.H:27-156): the crossing test i_old != i_new of CurrentDeposition.H:777-788.
 template <int O>
 __device__ __forceinline__ int shape_cell(double x) {
-    if constexpr (O == 2) return (int)(x + 0.5);
+    if constexpr (O % 2 == 0) return (int)(x + 0.5);   // even orders: the nearest node
     else return (int)floor(x);
 }
 
@@ -233,9 +233,9 @@ __device__ __forceinline__ void esirkepov_nc_shapes(const ParticleState& p, cons
 template <int O>
 __device__ __forceinline__ bool esirkepov_frame_cross(const EsirkepovCoords& cc, const Geom& g, int& bi, int& bj,
                                                       int& bk) {
-    bi = g.lo0 + shape_node_of<O>(cc.x_new) - (O == 1 ? 1 : 2);
-    bj = g.lo1 + shape_node_of<O>(cc.y_new) - (O == 1 ? 1 : 2);
-    bk = g.lo2 + shape_node_of<O>(cc.z_new) - (O == 1 ? 1 : 2);
+    bi = g.lo0 + shape_node_of<O>(cc.x_new) - (O / 2 + 1);   // one slot below the leftmost stencil point (j, j - 1, j - 1, j - 2 for orders 1 .. 4)
+    bj = g.lo1 + shape_node_of<O>(cc.y_new) - (O / 2 + 1);   // one slot below the leftmost stencil point (j, j - 1, j - 1, j - 2 for orders 1 .. 4)
+    bk = g.lo2 + shape_node_of<O>(cc.z_new) - (O / 2 + 1);   // one slot below the leftmost stencil point (j, j - 1, j - 1, j - 2 for orders 1 .. 4)
     return shape_cell<O>(cc.x_old) != shape_cell<O>(cc.x_new) || shape_cell<O>(cc.y_old) != shape_cell<O>(cc.y_new) ||
            shape_cell<O>(cc.z_old) != shape_cell<O>(cc.z_new);
 }
@@ -426,7 +426,7 @@ __device__ __forceinline__ WideFrame<O> esirkepov_wide_frame(const EsirkepovCoor
         f.jo[d] = O == 1 ? (int)floor(xo[d]) : shape_node_of<O>(xo[d]);   // ShapeFactors.H:112 floors at order 1
         const int jm = min(f.jn[d], f.jo[d]);
         f.sn[d] = f.jn[d] - jm; f.so[d] = f.jo[d] - jm;
-        f.b[d] = lo[d] + (O >= 2 ? jm - 1 : jm);
+        f.b[d] = lo[d] + jm - O / 2;   // the leftmost stencil point of the lower of the two nodes
     }
     return f;
 }
@@ -510,7 +510,7 @@ __device__ __forceinline__ WideFrame<O> unpack_wide_frame(const PackedWideFrame&
         f.sn[d] = (p.bits >> d) & 1; f.so[d] = (p.bits >> (3 + d)) & 1;
         const int jm = f.jn[d] - f.sn[d];
         f.jo[d] = jm + f.so[d];
-        f.b[d] = lo[d] + (O >= 2 ? jm - 1 : jm);
+        f.b[d] = lo[d] + jm - O / 2;   // the leftmost stencil point of the lower of the two nodes
     }
     return f;
 }
@@ -593,6 +593,36 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 #endif
+// Lanes l and l + 32 of a wave: the other lane's value of a wave-uniformly executed expression (v_permlane32_swap: the
+// upper 32 lanes of its first operand change places with the lower 32 of its second).
+#ifndef WXA_HAVE_PARTNER32   // tests/hipcpu: wave shuffles
+__device__ __forceinline__ int partner32(const int v) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ double partner32_f64(const double v) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return (threadIdx.x & 32) ? __hiloint2double((int)hi[0], (int)lo[0]) : __hiloint2double((int)hi[1], (int)lo[1]);
+}
+#endif
+// LdsSink for lanes l and l + 32 of the chunk layout -- two pairs of ONE cell -- in the streaming deposition: where the two
+// lanes deposit on the same wide frame (`shared`), every value is summed over the two and the lower lane adds it; elsewhere
+// each lane adds its own.  Half the LDS atomics of a shared frame, and none of the same-address conflicts that two lanes of
+// one instruction on one frame cost (37 % of the LDS-active cycles of BASELINE config 5, profiles/round5).  Executed by
+// every lane of the wave (the exchange is a wave operation): a lane without a particle takes part with zero weight.
+template <class Sink>
+struct PairSumSink {
+    Sink inner;
+    bool shared, adds;   // adds: this lane issues the atomic (its own frame, or the pair's as the lower lane)
+    __device__ __forceinline__ PairSumSink(const Sink& s, bool shared_, bool adds_) : inner(s), shared(shared_), adds(adds_) {}
+    __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
+        const double t = partner32_f64(v);
+        const double s = shared ? v + t : v;
+        if (adds) inner.add(c, i, j, k, s);
+    }
+};
+
 // LdsSink for a wave whose lanes share the frame: every value is summed over the wave, lane 63 adds it
 template <class Sink>
 struct WaveSumSink {

@@ -540,13 +540,19 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
                 WXA_OPAQUE_F64(c2.x_new); WXA_OPAQUE_F64(c2.y_new); WXA_OPAQUE_F64(c2.z_new);
                 WXA_OPAQUE_F64(c2.x_old); WXA_OPAQUE_F64(c2.y_old); WXA_OPAQUE_F64(c2.z_old);
             };
-            if (on_a) {
-                const double wq2 = merged ? wqb : 0.0;
+            {
+                // Lanes l and l + 32 hold two pairs of one cell: where both deposit on the same wide frame the two lanes'
+                // values are summed (PairSumSink) and the lower lane adds them -- every lane of the wave runs the body, a
+                // lane without a particle on the tile with zero weights (the exchange between the lanes is a wave operation).
+                const double wq1 = on_a ? wqa : 0.0, wq2 = on_a && merged ? wqb : 0.0;
+                const int key = on_a ? ((fa.b[0] - o0) | ((fa.b[1] - o1) << 8) | ((fa.b[2] - o2) << 16)) : -1 - lane;
+                const bool shared = partner32(key) == key;   // (a lane without a frame carries a key of its own)
+                const bool adds = on_a && !(shared && lane >= 32);
                 auto component = [&](auto comp) {
                     fence();
                     const WideFrame<O> f1 = unpack_wide_frame<O>(qa, g), f2 = unpack_wide_frame<O>(qb, g);
-                    LdsSink<M, TSZ, ACC> sink(lds, f1.b[0] - o0, f1.b[1] - o1, f1.b[2] - o2);
-                    esirkepov_pair_wide<O, decltype(comp)::value>(c1, f1, wqa, c2, f2, wq2, es, sink);
+                    PairSumSink<LdsSink<M, TSZ, ACC>> sink(LdsSink<M, TSZ, ACC>(lds, f1.b[0] - o0, f1.b[1] - o1, f1.b[2] - o2), shared, adds);
+                    esirkepov_pair_wide<O, decltype(comp)::value>(c1, f1, wq1, c2, f2, wq2, es, sink);
                 };
                 component(std::integral_constant<int, 0>{});
                 component(std::integral_constant<int, 1>{});
@@ -841,10 +847,16 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
         }
         if (order == 1) return launch_rows<1, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
         if (order == 2) return launch_rows<2, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
+        // order 4 (round 6): the tile's 15 points per direction are exactly the reach of the quartic stencil around a tile
+        // (nodes c - 2 .. c + 3 of the particle's cell c, one more each way for the old position) -- no point of drift
+        // margin is left, so a particle that has left its sort cell by more than the stencil's slack goes to the
+        // global-atomics pass; everything else deposits on the tile like the other even order
+        if (order == 4) return launch_rows<4, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
         return launch_rows<3, RowsEsirkepov>(p, J, geom, q, dt, relative_time, ws, st);
     }
     if (order == 1) return launch_rows<1, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
     if (order == 2) return launch_rows<2, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
+    if (order == 4) return launch_rows<4, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
     return launch_rows<3, RowsDirect>(p, J, geom, q, dt, relative_time, ws, st);
 }
 

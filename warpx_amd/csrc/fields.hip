@@ -1477,8 +1477,14 @@ zero_multi_kernel(ZeroSet z) {
     const long n2 = n >> 1;
     D2* q = reinterpret_cast<D2*>(p);
     const D2 zero = {0.0, 0.0};
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += (long)gridDim.x * blockDim.x)
-        __builtin_nontemporal_store(zero, q + t);
+    // four 16-byte stores per lane, each a whole 4 KB row of the workgroup (the first version -- one non-temporal store
+    // per trip of a grid-stride loop -- reached 3.5 TB/s, half of what the runtime's fill kernel does)
+    const long base = (long)blockIdx.x * (4 * 256) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long t = base + u * 256;
+        if (t < n2) q[t] = zero;
+    }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
 }
 
@@ -1501,8 +1507,9 @@ wxa_status wxa_field_set_zero_multi(const wxa_field_view* f, int32_t nf, void* s
         most = std::max(most, z.n[c]);
     }
     if (most == 0) return WXA_OK;
-    const unsigned blocks = (unsigned)std::min<long>((most / 2 + 255) / 256, 8192);
-    hipLaunchKernelGGL(zero_multi_kernel, dim3(std::max(blocks, 1u), (unsigned)nf), dim3(256), 0, (hipStream_t)stream, z);
+    const long blocks = (most / 2 + 1023) / 1024 + 1;   // 1024 16-byte stores per workgroup (+ 1: an array that starts on an odd double)
+    WXA_REQUIRE(blocks < (1L << 31), "array too long");
+    hipLaunchKernelGGL(zero_multi_kernel, dim3((unsigned)blocks, (unsigned)nf), dim3(256), 0, (hipStream_t)stream, z);
     WXA_LAUNCH_CHECK();
     return WXA_OK;
 }

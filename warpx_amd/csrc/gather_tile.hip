@@ -56,10 +56,15 @@ __device__ unsigned long long wxa_gather_prof[8];
 constexpr int GT_TS = WXA_TILE;
 constexpr int GT_THREADS = 512;
 
-template <int G>
+// Staged points per direction: the reach of the stencils of the particles of the tile's own cells, nothing more.
+// Orders 1 - 3 (the node below for odd orders; the widest is order 3): nodes c - 1 .. c + 2 of a particle's cell c, and
+// with the same shape at the staggered points (G = 0) c - 2 .. c + 2.  Order 4 (round 6; the nearest node): nodes
+// c - 2 .. c + 3, staggered points c - 2 .. c + 2 with the Galerkin gather's cubic shape there, c - 3 .. c + 2 without.
+// LDS per workgroup: 64 / 83 KB (orders <= 3: two workgroups per CU with G = 1), 105 / 132 KB (order 4: one).
+template <int G, int O = 3>
 struct GatherTileDims {
-    static constexpr int LO = G ? -1 : -2;           // first staged point relative to the tile's first cell
-    static constexpr int N = GT_TS + (G ? 3 : 4);    // staged points per direction
+    static constexpr int LO = O == 4 ? (G ? -2 : -3) : (G ? -1 : -2);   // first staged point relative to the tile's first cell
+    static constexpr int N = GT_TS + (O == 4 ? (G ? 5 : 6) : (G ? 3 : 4));   // staged points per direction
     static constexpr int NPTS = N * N * N;
 };
 
@@ -142,12 +147,12 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
 template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF, int ST = 0, int SL = WXA_GATHER_SL>
-__global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(G ? 4 : 2)   // what the staged tile lets a CU hold
+__global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD((G && O <= 3) ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext,
                         PushSort hook, HeavyUnits hu) {
-    constexpr int N = GatherTileDims<G>::N;
-    constexpr int NPTS = GatherTileDims<G>::NPTS;
+    constexpr int N = GatherTileDims<G, O>::N;
+    constexpr int NPTS = GatherTileDims<G, O>::NPTS;
     __shared__ double F[6 * NPTS];
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     if (blockIdx.x == 0 && threadIdx.x == 0 && sq.next) *sq.next = 0u;
@@ -175,9 +180,9 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const bool face = ti == 0 || ti == tg.nt[0] - 1 || tj == 0 || tj == tg.nt[1] - 1 || tk == 0 || tk == tg.nt[2] - 1;
         if (face != (PART == 2)) return;
     }
-    const int o0 = tg.cell_lo[0] + ti * GT_TS + GatherTileDims<G>::LO;
-    const int o1 = tg.cell_lo[1] + tj * GT_TS + GatherTileDims<G>::LO;
-    const int o2 = tg.cell_lo[2] + tk * GT_TS + GatherTileDims<G>::LO;
+    const int o0 = tg.cell_lo[0] + ti * GT_TS + GatherTileDims<G, O>::LO;
+    const int o1 = tg.cell_lo[1] + tj * GT_TS + GatherTileDims<G, O>::LO;
+    const int o2 = tg.cell_lo[2] + tk * GT_TS + GatherTileDims<G, O>::LO;
     // staging: all loads of a component pair are in flight before the first LDS write (as a plain
     // `for (a = tid; ...) F[a] = load` loop every lane had one load in flight at a time)
     // The lane's particle of the NEXT trip: loaded (volatile: the loads keep their place in front of the inline-asm LDS
@@ -314,7 +319,8 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const int jn = s.jn - o0, jc = s.jc - o0, kn = s.kn - o1, kc = s.kc - o1, ln = s.ln - o2, lc = s.lc - o2;
 #define GROWS(...)                                                                                         \
     [&](const double* b_, const double* sx_, const double* sy_, const double* sz_) {                       \
-        if constexpr (RB > 0) return gather_rows_lds<__VA_ARGS__, N, N * N, RB>(b_, sx_, sy_, sz_);        \
+        /* (order 4: rows of five points -- the compiler's own LDS reads; the hand-placed waits count rows of <= 4) */ \
+        if constexpr (RB > 0 && O <= 3) return gather_rows_lds<__VA_ARGS__, N, N * N, RB>(b_, sx_, sy_, sz_);        \
         else return gather_rows<__VA_ARGS__>(b_, N, N * N, sx_, sy_, sz_);                                 \
     }
         const double Exp = GROWS(NC, NN, NN)(F + 0 * NPTS + jc + N * (kn + N * ln), s.sxc, s.syn, s.szn);
@@ -414,9 +420,9 @@ static wxa_status launch(const wxa_particle_view* p, const wxa_field_view E[3], 
                            sq.idx, sq.count, ex, ey, ez, bx, by, bz, g, q, m, dt, ext, hook);                     \
     } while (0)
     if (galerkin) {
-        if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else WXA_GT(3, 1);
+        if (order == 1) WXA_GT(1, 1); else if (order == 2) WXA_GT(2, 1); else if (order == 3) WXA_GT(3, 1); else WXA_GT(4, 1);
     } else {
-        if (order == 1) WXA_GT(1, 0); else if (order == 2) WXA_GT(2, 0); else WXA_GT(3, 0);
+        if (order == 1) WXA_GT(1, 0); else if (order == 2) WXA_GT(2, 0); else if (order == 3) WXA_GT(3, 0); else WXA_GT(4, 0);
     }
 #undef WXA_GT
     WXA_LAUNCH_CHECK();

@@ -391,6 +391,12 @@ public:
         moving_window_dir = dir;
         moving_window_v = v_over_c * 299'792'458.;
         moving_window_x = m_ctx.prob_lo[dir];                                       // :649
+        // Behind every shift of the window the tiles are sorted afresh (the shift's sort stands for the periodic one), and
+        // that sort drops the push's record: with one special push per cycle every cycle would start over with a COUNT
+        // whose record is thrown away.  A counting and a scattering push as in round 5 then (BASELINE config 5 on one
+        // GPU: 88 against 93 ms per step, profiles/round6/README.md) -- unless WXA_SORT_MERGED=1 asks for it.
+        const char* merged = std::getenv("WXA_SORT_MERGED");
+        if (!(merged && std::atoi(merged) != 0)) m_ctx.sort_merged = false;
     }
 
     // WarpX::MoveWindow (Source/Utils/WarpXMovingWindow.cpp:138-476): window position, whole-cell field shift,

@@ -642,7 +642,7 @@ wxa_status wxa_gather_push_ws(const wxa_particle_view* p, const wxa_field_view E
     if ((rc = evaluate_particle_fields(p, ws, (hipStream_t)stream)) != WXA_OK) return rc;
     wxa_particle_view rest = *p;
     int64_t first = 0;
-    if (order <= 3 && gather_tile_available(ws, p)) {   // order 4: the global-memory kernels (the LDS tiles are sized for orders <= 3)
+    if (gather_tile_available(ws, p)) {   // orders 1 .. 4 (4 since round 6: a tile of 13^3 / 14^3 staged points)
         // sorted part on the LDS tiles; particles appended since the sort (arrivals from the
         // neighbouring bricks) take the global-memory kernel below
         wxa_particle_view head = *p;
@@ -667,7 +667,7 @@ wxa_status wxa_gather_push_part(const wxa_particle_view* p, const wxa_field_view
     WXA_REQUIRE(part == WXA_PART_INTERIOR || part == WXA_PART_REST, "part must be WXA_PART_INTERIOR or WXA_PART_REST");
     if (p->np == 0) return WXA_OK;
     if ((rc = evaluate_particle_fields(p, ws, (hipStream_t)stream)) != WXA_OK) return rc;
-    if (order > 3 || !gather_tile_available(ws, p)) {   // no tiles: the interior part is empty, the rest is everything
+    if (!gather_tile_available(ws, p)) {   // no tiles: the interior part is empty, the rest is everything
         if (part == WXA_PART_INTERIOR) return WXA_OK;
         return gather_push_global(*p, E, B, geom, q, m, dt, order, galerkin, pusher, 1, ext_of(ws), make_push_sort(ws, 0, true),
                                   (hipStream_t)stream);
@@ -712,7 +712,7 @@ wxa_status wxa_deposit_current(const wxa_particle_view* p, const wxa_field_view 
     }
     if (p->np == 0) return WXA_OK;
     wxa_particle_view rest = *p;
-    if (ws && order <= 3 && deposit_tile_available(ws, p)) {
+    if (ws && deposit_tile_available(ws, p)) {   // orders 1 .. 4 (4 since round 6: the tile's points are exactly the quartic stencil's reach)
         wxa_particle_view head = *p;
         head.np = ws->sorted_np;
         wxa_status rc;
