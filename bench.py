@@ -32,7 +32,7 @@ CLOCK_GHZ = 2.4     # MI355X_MICROARCH.md: peak engine clock
 CLOCK_UNDER_LOAD_GHZ = 2.09
 LDS_CYCLES_PER_ATOMIC = 8.7
 # the N = 1 line an N > 1 run compares itself with when --n1-ms is not given (committed with the round's evidence)
-N1_REFERENCE_LINE = os.path.join("profiles", "round5", "n1_reference_line.json")
+N1_REFERENCE_LINE = os.path.join("profiles", "round6", "n1_reference_line.json")
 
 # algorithmic bytes per unit, fp64 (SURVEY.md 8(d) / BASELINE.md section 3)
 BYTES = {
@@ -85,7 +85,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_FILE = os.path.join("profiles", "round5", "r5_pmc_counters.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "round6", "r6_pmc_counters.json")
 
 
 def pmc_traffic(args):
@@ -235,10 +235,10 @@ def main():
     ap.add_argument("--pusher", choices=["boris", "vay"], default="boris")
     ap.add_argument("--no-filter", action="store_true")
     ap.add_argument("--sort-interval", type=int, default=2,
-                    help="cell sort every N steps (warpx.sort_intervals).  With the sort folded into the push (round 5: "
-                         "the push before a sort step records keys and ranks, the sort step's push writes the sorted tile) "
-                         "2 and 3 are level, 2 a little ahead: 12.41-12.49 / 12.44-12.64 / 13.3 ms per step at 2 / 3 / 4 "
-                         "(profiles/round5/README.md); with the sort as passes of its own it was 3")
+                    help="cell sort every N steps (warpx.sort_intervals).  With the sort folded into the push as ONE special "
+                         "push per cycle (round 6: the sort step's push scatters with the last record and counts the next) "
+                         "2 and 3 are level: 12.6-13.0 / 12.8-13.0 ms per step on one box, 13.8 at 1, 13.1 at 4 "
+                         "(profiles/round6/README.md)")
     ap.add_argument("--preroll", type=int, default=40,
                     help="untimed steps before the warmup: the regular-lattice start is atypically cheap "
                          "(no particle crosses a cell for ~20 steps), the timed region must see the "

@@ -24,7 +24,7 @@ KERNELS = {   # phase -> substring of the kernel name
     "EvolveB": "evolve_b_kernel<wxa::StencilCfg<1, 1, 3, 1",
     "EvolveE": "evolve_e_kernel<wxa::StencilCfg<1, 1, 3, 1",
 }
-SORT_INTERVAL = 2   # bench.py's default: the last six pushes are three counting and three scattering ones (push_sort.hpp)
+SORT_INTERVAL = 2   # bench.py's default: of the last six pushes three are the cycle's special push (COUNT | SCATTER) and three plain (push_sort.hpp)
 bench_args = ["--steps", "6", "--warmup", "1", "--preroll", "40", "--sort-interval", str(SORT_INTERVAL), "--no-cpu-baseline",
               "--no-phase-pass", "--no-sanity"]
 res = {k: {} for k in KERNELS}
