@@ -230,6 +230,9 @@ def test_bricks_flush_one_back_transformed_plotfile(nb, nranks, port, tmp_path):
            *[str(v) for v in nb], path, str(tmp_path / "sum.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks), WXA_TEST_DIAGNOSTICS="1",
+                                # the bricks' shares travel to brick 0 in pieces through one kept staging buffer (64 MB pieces in
+                                # a run; 1000 doubles here, so that every share is many pieces)
+                                WXA_BTD_GATHER_PIECE="1000",
                                 WXA_TEST_OVERRIDES=";".join(overrides(bricks_prefix))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert sorted(os.listdir(str(tmp_path / "bricks"))) == sorted(os.listdir(str(tmp_path / "one"))) == ["lab%03d" % i for i in range(nsnap)]

@@ -372,7 +372,7 @@ private:
             count[(size_t)r] = (int64_t)NCOMP * nz * n[1] * n[0];
         }
         std::vector<std::vector<double>> shares;
-        GatherRealToRoot(comm, be, s.data.data(), count, shares, ctx.stream);
+        GatherRealToRoot(comm, be, s.data.data(), count, shares, ctx.stream, &m_gather_staging, gather_piece());
         PlotGrid g;
         g.lo[0] = s.glo[0]; g.lo[1] = s.glo[1]; g.lo[2] = s.buffer_klo;
         g.hi[0] = s.glo[0] + s.gn[0] - 1; g.hi[1] = s.glo[1] + s.gn[1] - 1; g.hi[2] = s.buffer_khi;
@@ -428,7 +428,7 @@ private:
             int64_t total = 0;
             for (int r = 0; r < nranks; ++r) { pc[(size_t)r] = 7 * (int64_t)nper[(size_t)r]; total += (int64_t)nper[(size_t)r]; }
             std::vector<std::vector<double>> recs;
-            GatherRealToRoot(comm, be, rec.data(), pc, recs, ctx.stream);
+            GatherRealToRoot(comm, be, rec.data(), pc, recs, ctx.stream, &m_gather_staging, gather_piece());
             ParticleGrid pg;
             for (int d = 0; d < 3; ++d) { pg.lo[d] = g.lo[d]; pg.hi[d] = g.hi[d]; }
             pg.which = id;
@@ -593,6 +593,12 @@ private:
     int m_file_min_digits = 6;
     std::vector<std::string> m_species_names;
     DeviceBuffer m_xbuf;                         // exchange_guard_planes
+    // doubles per piece of a brick's share on its way to brick 0 (WXA_BTD_GATHER_PIECE: a test makes the pieces small)
+    static int64_t gather_piece() {
+        static const int64_t v = [] { const char* e = std::getenv("WXA_BTD_GATHER_PIECE"); return e && std::atoll(e) > 0 ? (int64_t)std::atoll(e) : (int64_t(8) << 20); }();
+        return v;
+    }
+    DeviceBuffer m_gather_staging;   // flush_bricks: the pieces of the bricks' shares on their way to brick 0 (<= 64 MB, kept)
     std::vector<double> m_guard_lo, m_guard_hi;  // [comp][j][i] behind the low / high z face
 };
 

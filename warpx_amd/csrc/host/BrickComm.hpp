@@ -450,59 +450,57 @@ inline void ReduceRealSum(BrickComm& comm, const Backend* be, std::vector<double
 }
 
 // Rank 0 collects a block of doubles from every brick (count[r] doubles from brick r; every brick knows its own count,
-// brick 0 all of them): one message per brick through the transport, staged like every other exchange.  On brick 0 `out[r]`
-// holds brick r's block (its own included); elsewhere `out` is left empty.  Collective.
+// brick 0 all of them) through the transport, staged like every other exchange.  On brick 0 `out[r]` holds brick r's block
+// (its own included); elsewhere `out` is left empty.  Collective.
+// Bounded staging (round 6): the blocks travel brick after brick in pieces of at most `piece` doubles
+// through ONE device buffer that the caller may keep (`staging`) -- before, brick 0 allocated every other brick's whole
+// share on its device at once (several GB for the snapshot buffers of a 512^2 x 256 run) and freed it again, every flush.
 inline void GatherRealToRoot(BrickComm& comm, const Backend* be, const double* mine, const std::vector<int64_t>& count,
-                             std::vector<std::vector<double>>& out, void* stream) {
+                             std::vector<std::vector<double>>& out, void* stream, DeviceBuffer* staging = nullptr,
+                             int64_t piece = int64_t(8) << 20) {
     const int* nb = comm.nbricks();
     const int nranks = nb[0] * nb[1] * nb[2];
     const int me = comm.rank_of(comm.coord());
     out.clear();
+    DeviceBuffer local;
+    local.be = be;
+    DeviceBuffer& buf = staging ? *staging : local;
+    buf.be = be;
+    if (piece < 1) piece = 1;
     if (me != 0) {
         const int64_t n = count[(size_t)me];
         if (n == 0) return;   // (brick 0 skips an empty block too)
-        DeviceBuffer buf;
-        buf.be = be;
-        buf.reserve(sizeof(double) * (size_t)n);
-        if (be->memcpy_h2d(buf.p, mine, sizeof(double) * (size_t)n) != 0) throw std::runtime_error("GatherRealToRoot: copy failed");
-        const int32_t peer = 0;
-        void* sb = buf.p;
-        void* rb = buf.p;
-        const int64_t sbytes = (int64_t)sizeof(double) * n, rbytes = 0;
-        comm.exchange_with(1, &peer, &sb, &sbytes, &rb, &rbytes, stream);
-        be->stream_sync(stream);
+        buf.reserve(sizeof(double) * (size_t)std::min(n, piece));
+        for (int64_t off = 0; off < n; off += piece) {
+            const int64_t m = std::min(piece, n - off);
+            if (be->memcpy_h2d(buf.p, mine + off, sizeof(double) * (size_t)m) != 0) throw std::runtime_error("GatherRealToRoot: copy failed");
+            const int32_t peer = 0;
+            void* sb = buf.p;
+            void* rb = buf.p;
+            const int64_t sbytes = (int64_t)sizeof(double) * m, rbytes = 0;
+            comm.exchange_with(1, &peer, &sb, &sbytes, &rb, &rbytes, stream);
+            be->stream_sync(stream);   // the buffer is refilled by the next piece
+        }
         return;
     }
     out.resize((size_t)nranks);
     out[0].assign(mine, mine + count[0]);
-    int64_t total = 0;
-    for (int r = 1; r < nranks; ++r) total += count[(size_t)r];
-    if (total == 0) return;
-    DeviceBuffer buf;
-    buf.be = be;
-    buf.reserve(sizeof(double) * (size_t)total);
-    std::vector<int32_t> peer;
-    std::vector<void*> sb, rb;
-    std::vector<int64_t> sbytes, rbytes;
-    int64_t at = 0;
     for (int r = 1; r < nranks; ++r) {
-        peer.push_back(r);
-        sb.push_back(buf.p);
-        sbytes.push_back(0);
-        rb.push_back(static_cast<char*>(buf.p) + sizeof(double) * (size_t)at);
-        rbytes.push_back((int64_t)sizeof(double) * count[(size_t)r]);
-        at += count[(size_t)r];
-    }
-    comm.exchange_with((int)peer.size(), peer.data(), sb.data(), sbytes.data(), rb.data(), rbytes.data(), stream);
-    be->stream_sync(stream);
-    at = 0;
-    for (int r = 1; r < nranks; ++r) {
-        out[(size_t)r].resize((size_t)count[(size_t)r]);
-        if (count[(size_t)r] > 0 &&
-            be->memcpy_d2h(out[(size_t)r].data(), static_cast<char*>(buf.p) + sizeof(double) * (size_t)at,
-                           sizeof(double) * (size_t)count[(size_t)r]) != 0)
-            throw std::runtime_error("GatherRealToRoot: copy failed");
-        at += count[(size_t)r];
+        const int64_t n = count[(size_t)r];
+        out[(size_t)r].resize((size_t)n);
+        if (n == 0) continue;
+        buf.reserve(sizeof(double) * (size_t)std::min(n, piece));
+        for (int64_t off = 0; off < n; off += piece) {
+            const int64_t m = std::min(piece, n - off);
+            const int32_t peer = r;
+            void* sb = buf.p;
+            void* rb = buf.p;
+            const int64_t sbytes = 0, rbytes = (int64_t)sizeof(double) * m;
+            comm.exchange_with(1, &peer, &sb, &sbytes, &rb, &rbytes, stream);
+            be->stream_sync(stream);
+            if (be->memcpy_d2h(out[(size_t)r].data() + off, buf.p, sizeof(double) * (size_t)m) != 0)
+                throw std::runtime_error("GatherRealToRoot: copy failed");
+        }
     }
 }
 
