@@ -23,22 +23,12 @@
 
 #include <stdlib.h>
 
-#ifndef WXA_GATHER_RB
-#define WXA_GATHER_RB 2   // rows in flight ahead of the fma chain (gather_rows_lds); 0: the compiler's ds_read2_b64 rows
-#endif
-#ifndef WXA_GATHER_SL
-#define WXA_GATHER_SL 1   // 1: a tile's stragglers leave as one block of the global list (see the kernel); 0: one global atomic each
-#endif
 #ifndef WXA_STRAGGLER_BLOCKS
 // workgroups of 256 lanes of gather_push_stragglers_kernel (a grid-stride loop over a list whose length only the device
 // knows).  512 workgroups are two waves per SIMD; 2048 were measured and change nothing (0.19-0.62 ms per launch either
 // way at 256^3 x 8 per cell, profiles/round5/README.md): the kernel is not short of waves in flight
 #define WXA_STRAGGLER_BLOCKS 512
 #endif
-#ifndef WXA_GATHER_PF
-#define WXA_GATHER_PF 3   // 2: the next particle's position is requested a trip ahead, this particle's momentum at the top of its trip; 3: the same, chunks through an LDS counter
-#endif
-
 namespace wxa {
 
 // Clocks of the tile kernel (opt-in build, -DWXA_GATHER_PROFILE; read with scripts/gather_profile.py): thread 0 of every
@@ -87,54 +77,17 @@ struct GatherStragglers {
     __device__ __forceinline__ void push(int ip) const { idx[atomicAdd(count, 1u)] = ip; }
 };
 
-// ST = 1 (dev variant): lanes l and l ^ 1 hold consecutive particles; they exchange one value per pair of arrays through DPP
-// and each writes 16 bytes -- the even lane both particles' value of the first array, the odd lane both of the second:
-// three global_store_dwordx4 per lane instead of six global_store_dwordx2 (the kernel without its stores runs 1.1 ms
-// faster, profiles/round4/r4d_timing_experiments.txt; a store instruction of 8 bytes per lane costs the same issue slot
-// as one of 16).  A lane whose partner does not store (a straggler, the end of the tile) writes its own values as before.
-#ifndef WXA_HAVE_LANE_XOR1   // tests/hipcpu: a wave shuffle
-__device__ __forceinline__ double lane_xor1(const double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-#endif
-struct __attribute__((packed, aligned(8))) Pair8 { double a, b; };
-// recv = lane_xor1(odd ? a : b): the odd lane sends its a to the even one, the even lane its b
-__device__ __forceinline__ void store_pair(double* __restrict__ A, double* __restrict__ B, const int ip, const bool odd,
-                                           const double a, const double b, const double recv) {
-    Pair8 v;
-    v.a = odd ? recv : a;
-    v.b = odd ? b : recv;
-    *reinterpret_cast<Pair8*>(odd ? B + (ip - 1) : A + ip) = v;
-}
-
-template <int PUSHER, bool MOVE, int ST = 0>
+template <int PUSHER, bool MOVE>
 __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, double yp, double zp, double ux, double uy,
                                                double uz, double Exp, double Eyp, double Ezp, double Bxp, double Byp,
                                                double Bzp, double q, double m, double dt, const ExtEB& ext,
                                                const PushSort& hook,
-                                               const unsigned long long here = 0ull,   // ST: the lanes that store in this trip
-                                               const bool mine = true,                 // ST: ... this one among them
                                                int* lds_hist = nullptr, const long my_tile = -1) {   // push_sort_tail
     add_external_fields(ext, ip, Exp, Eyp, Ezp, Bxp, Byp, Bzp);
     push_momentum<PUSHER>(ux, uy, uz, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt);
     if constexpr (MOVE) update_position(xp, yp, zp, ux, uy, uz, dt);
-    if constexpr (MOVE && ST == 0) {   // the cell sort folded into the push (push_sort.hpp): keyed, or written to the sorted tile
+    if constexpr (MOVE) {   // the cell sort folded into the push (push_sort.hpp): keyed, or written to the sorted tile
         if (!push_sort_tail(hook, p, ip, xp, yp, zp, ux, uy, uz, lds_hist, my_tile)) return;
-    }
-    if constexpr (ST != 0 && MOVE) {
-        // every lane of the trip takes part in the exchanges (a lane that does not store sends values nobody uses)
-        const int lane = threadIdx.x & 63;
-        const bool odd = lane & 1;
-        const double r0 = lane_xor1(odd ? ux : uy), r1 = lane_xor1(odd ? uz : xp), r2 = lane_xor1(odd ? yp : zp);
-        if (!mine) return;
-        if ((here >> (lane ^ 1)) & 1ull) {   // lane ^ 1 holds particle ip ^ 1 of the same 64-particle chunk, and stores
-            store_pair(p.ux, p.uy, ip, odd, ux, uy, r0);
-            store_pair(p.uz, p.x, ip, odd, uz, xp, r1);
-            store_pair(p.y, p.z, ip, odd, yp, zp, r2);
-            return;
-        }
     }
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
     if constexpr (MOVE) { p.x[ip] = xp; p.y[ip] = yp; p.z[ip] = zp; }
@@ -146,7 +99,7 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // point, even as stragglers: a particle is at most a few cells from the tile it was sorted into); 2 = only
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
-template <int O, int G, int PUSHER, bool MOVE, int PART = 0, int RB = WXA_GATHER_RB, int PF = WXA_GATHER_PF, int ST = 0, int SL = WXA_GATHER_SL>
+template <int O, int G, int PUSHER, bool MOVE, int PART = 0>
 __global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD((G && O <= 3) ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext,
@@ -183,20 +136,20 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     const int o0 = tg.cell_lo[0] + ti * GT_TS + GatherTileDims<G, O>::LO;
     const int o1 = tg.cell_lo[1] + tj * GT_TS + GatherTileDims<G, O>::LO;
     const int o2 = tg.cell_lo[2] + tk * GT_TS + GatherTileDims<G, O>::LO;
-    // staging: all loads of a component pair are in flight before the first LDS write (as a plain
-    // `for (a = tid; ...) F[a] = load` loop every lane had one load in flight at a time)
-    // The lane's particle of the NEXT trip: loaded (volatile: the loads keep their place in front of the inline-asm LDS
-    // reads) while the current one gathers, the first one before the staging, so that no trip starts by waiting for
-    // HBM (counters of the kernel without it: waves parked in s_waitcnt 46 % of their cycles, VALU and LDS each < 50 %)
-    // PF == 3: PF == 2 with the 64-particle chunks of the tile handed out through an LDS counter instead of
-    // chunk = wave + k * 8 (the SIMD's arbiter favours its oldest waves; a workgroup's LDS is held until its slowest
-    // wave is done).  A wave works on one chunk, has the positions of the next one in flight and has claimed the one
-    // after that: the counter's round trip through the LDS queue hides behind a whole trip.  The first two chunks of
-    // every wave are the static ones, so no trip starts by waiting for the counter.
-    // SL: a tile's stragglers are collected in LDS and written to the global list as ONE contiguous block at the end of the
-    // workgroup (one global atomic per tile instead of one per straggler): the straggler kernel's waves then hold
-    // particles of one or two neighbouring tiles, whose 252 scattered loads share cache lines
-    // the sort folded into the push, COUNT alone: ranks from a histogram of the tile's own cells (push_sort.hpp)
+    // Staging: all loads of a component pair are in flight before the first LDS write (as a plain
+    // `for (a = tid; ...) F[a] = load` loop every lane had one load in flight at a time).
+    // The lane's particle of the NEXT trip is requested while the current one gathers (plain loads between compiler
+    // fences, so that they keep their place in front of the inline-asm LDS reads), the first one before the staging: no
+    // trip starts by waiting for HBM (without it the waves were parked in s_waitcnt 46 % of their cycles); this trip's
+    // momentum is requested at the top of the trip and used after the gather.
+    // The 64-particle chunks of the tile are handed out through an LDS counter instead of chunk = wave + 8 k (the SIMD's
+    // arbiter favours its oldest waves; a workgroup's LDS is held until its slowest wave is done): a wave works on one
+    // chunk, has the positions of the next one in flight and has claimed the one after that -- the counter's round trip
+    // through the LDS queue hides behind a whole trip.  The first two chunks of every wave are the static ones.
+    // A tile's stragglers are collected in LDS and written to the global list as ONE contiguous block at the end of the
+    // workgroup (one global atomic per tile): the straggler kernel's waves then hold particles of one or two neighbouring
+    // tiles, whose 252 scattered loads share cache lines.
+    // The sort folded into the push, COUNT: ranks from a histogram of the tile's own cells (push_sort.hpp).
     static_assert(GT_THREADS == PUSH_SORT_TILE_CELLS, "one lane per cell of the tile");
     __shared__ int lhist[MOVE ? PUSH_SORT_TILE_CELLS : 1];
     // (COUNT alone or together with SCATTER: the keys are those of the tile being read either way)
@@ -205,42 +158,29 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         if (count_local) lhist[tid] = 0;   // visible after the staging barrier below
     }
     constexpr int SCAP = 512;
-    __shared__ int slist[SL ? SCAP : 1];
+    __shared__ int slist[SCAP];
     __shared__ int sn, sbase;
-    if constexpr (SL != 0) {
-        if (tid == 0) sn = 0;   // visible after the staging barrier below
-    }
+    if (tid == 0) sn = 0;   // visible after the staging barrier below
     auto push_straggler = [&](const int i) {
-        if constexpr (SL != 0) {
-            const int n = atomicAdd(&sn, 1);
-            if (n < SCAP) slist[n] = i;
-            else sq.push(i);
-        } else {
-            sq.push(i);
-        }
+        const int n = atomicAdd(&sn, 1);
+        if (n < SCAP) slist[n] = i;
+        else sq.push(i);
     };
-    constexpr bool DYN = PF == 3;
-    constexpr bool PREFETCH = PF == 1 || PF == 2 || PF == 3;
     constexpr int WAVES = GT_THREADS / 64;
     __shared__ int next_chunk;
     const int lane = tid & 63;
     int cb_next = start + 64 * __builtin_amdgcn_readfirstlane(tid >> 6) + GT_THREADS;   // wave-uniform: first particle of the next chunk
-    if constexpr (DYN) {
-        if (tid == 0) next_chunk = 2 * WAVES;   // visible after the staging barrier below
-    }
+    if (tid == 0) next_chunk = 2 * WAVES;   // visible after the staging barrier below
     int ip = start + tid;
-    double nxt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double nxt[3] = {0.0, 0.0, 0.0};
     // plain loads between two compiler fences: they stay where they are written (in front of the inline-asm LDS reads) and
     // keep the L1/L2 path of ordinary loads (volatile loads become flat_load ... sc0 sc1: system-coherent, slower)
     auto load_particle = [&](const int i) {
         asm volatile("" ::: "memory");
         nxt[0] = p.x[i]; nxt[1] = p.y[i]; nxt[2] = p.z[i];
-        if constexpr (PF == 1) { nxt[3] = p.ux[i]; nxt[4] = p.uy[i]; nxt[5] = p.uz[i]; }
         asm volatile("" ::: "memory");
     };
-    if constexpr (PREFETCH) {
-        if (ip < end) load_particle(ip);
-    }
+    if (ip < end) load_particle(ip);
     constexpr int PER = (NPTS + GT_THREADS - 1) / GT_THREADS;
     auto fetch = [&](const DevF& f, double (&r)[PER]) {
 #pragma unroll
@@ -274,27 +214,16 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
     // it holds the chunk's first particle)
     auto advance = [&]() {
         ip = cb_next + lane;
-        if constexpr (DYN) cb_next = start + 64 * __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
-        else cb_next += GT_THREADS;
+        cb_next = start + 64 * __builtin_amdgcn_readfirstlane(__shfl(claimed, 0));
     };
     for (; ip < end; advance()) {
         GPROF_CLOCK(prof_a);
-        double xp, yp, zp, ux0, uy0, uz0;
-        if constexpr (PREFETCH) {
-            xp = nxt[0]; yp = nxt[1]; zp = nxt[2];
-            if constexpr (PF == 1) { ux0 = nxt[3]; uy0 = nxt[4]; uz0 = nxt[5]; }
-            else {   // PF == 2, 3: this particle's momentum is requested now and used after the gather
-                asm volatile("" ::: "memory");
-                ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip];
-                asm volatile("" ::: "memory");
-            }
-            if constexpr (DYN) {
-                if (lane == 0) claimed = atomicAdd(&next_chunk, 1);
-            }
-            if (cb_next + lane < end) load_particle(cb_next + lane);
-        } else {
-            xp = p.x[ip]; yp = p.y[ip]; zp = p.z[ip];
-        }
+        double xp = nxt[0], yp = nxt[1], zp = nxt[2], ux0, uy0, uz0;
+        asm volatile("" ::: "memory");
+        ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip];   // requested now, used after the gather
+        asm volatile("" ::: "memory");
+        if (lane == 0) claimed = atomicAdd(&next_chunk, 1);
+        if (cb_next + lane < end) load_particle(cb_next + lane);
 #ifdef WXA_GATHER_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xp), "+v"(yp), "+v"(zp));
 #endif
@@ -307,20 +236,16 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const int lo_j = min(s.kn, s.kc) - o1, hi_j = max(s.kn + NN, s.kc + NC) - 1 - o1;
         const int lo_k = min(s.ln, s.lc) - o2, hi_k = max(s.ln + NN, s.lc + NC) - 1 - o2;
         const bool staged = lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N;
-        unsigned long long storing = 0ull;
-        if constexpr (ST != 0) storing = __ballot(staged);   // taken while the trip's lanes are still together
         if (!staged) {
             push_straggler(ip);   // stencil leaves the staged tile: handled by gather_push_stragglers_kernel
-            if constexpr (ST == 0) continue;
-        }
-        if constexpr (ST != 0) {   // a lane that does not gather reads the tile's first points (its results are not stored)
-            if (!staged) { s.jn = s.jc = o0; s.kn = s.kc = o1; s.ln = s.lc = o2; }
+            continue;
         }
         const int jn = s.jn - o0, jc = s.jc - o0, kn = s.kn - o1, kc = s.kc - o1, ln = s.ln - o2, lc = s.lc - o2;
 #define GROWS(...)                                                                                         \
     [&](const double* b_, const double* sx_, const double* sy_, const double* sz_) {                       \
-        /* (order 4: rows of five points -- the compiler's own LDS reads; the hand-placed waits count rows of <= 4) */ \
-        if constexpr (RB > 0 && O <= 3) return gather_rows_lds<__VA_ARGS__, N, N * N, RB>(b_, sx_, sy_, sz_);        \
+        /* two rows in flight ahead of the fma chain (order 4: rows of five points -- the compiler's own LDS reads; the */ \
+        /* hand-placed waits count rows of <= 4) */                                                                    \
+        if constexpr (O <= 3) return gather_rows_lds<__VA_ARGS__, N, N * N, 2>(b_, sx_, sy_, sz_);        \
         else return gather_rows<__VA_ARGS__>(b_, N, N * N, sx_, sy_, sz_);                                 \
     }
         const double Exp = GROWS(NC, NN, NN)(F + 0 * NPTS + jc + N * (kn + N * ln), s.sxc, s.syn, s.szn);
@@ -335,9 +260,8 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(prof_e));
 #endif
         GPROF_CLOCK(prof_c);
-        if constexpr (!PREFETCH) { ux0 = p.ux[ip]; uy0 = p.uy[ip]; uz0 = p.uz[ip]; }
-        push_and_store<PUSHER, MOVE, ST>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext, hook, storing, staged,
-                                         count_local ? lhist : nullptr, tile);
+        push_and_store<PUSHER, MOVE>(p, ip, xp, yp, zp, ux0, uy0, uz0, Exp, Eyp, Ezp, Bxp, Byp, Bzp, q, m, dt, ext, hook,
+                                     count_local ? lhist : nullptr, tile);
 #ifdef WXA_GATHER_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GPROF_CLOCK(prof_d);
@@ -348,7 +272,7 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
 #ifdef WXA_GATHER_PROFILE
     { GPROF_CLOCK(prof_t2); GPROF_ADD(1, prof_t2 - prof_t1); }
 #endif
-    if constexpr (SL != 0) {
+    {
         __syncthreads();
         const int n = min(sn, SCAP);
         if (tid == 0 && n > 0) sbase = (int)atomicAdd(sq.count, (unsigned)n);
