@@ -869,12 +869,11 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     ws->ps.pending = false;   // a record of wxa_push_sort_begin(COUNT) indexes the order this sort replaces
     if (src->np == 0) return WXA_OK;
     wxa_status rc;
-    if ((rc = ws->cell.reserve(sizeof(int) * src->np)) != WXA_OK) return rc;
-    if ((rc = ws->rank.reserve(sizeof(int) * src->np)) != WXA_OK) return rc;
+    if ((rc = ws->rank.reserve(sizeof(int) * src->np)) != WXA_OK) return rc;   // (no key array: the scatter works the keys out again)
     // bins: the cells, the retired particles, and one closing entry for the scan
     if ((rc = ws->hist.reserve(sizeof(int) * (ncells + 2))) != WXA_OK) return rc;
     if ((rc = ws->offsets.reserve(sizeof(int) * (ncells + 2))) != WXA_OK) return rc;
-    int* cell = (int*)ws->cell.p; int* rank = (int*)ws->rank.p;
+    int* rank = (int*)ws->rank.p;
     int* hist = (int*)ws->hist.p; int* offsets = (int*)ws->offsets.p;
     WXA_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (ncells + 2), st));
     SortGeom sg;
@@ -898,7 +897,7 @@ wxa_status wxa_sort_particles_by_cell(const wxa_particle_view* src, const wxa_pa
     // the plain scatter -- one lane per particle, 8-byte writes wherever they fall -- 1.47): 8 x 512 lanes + 512 margin
     // 1.24, 4 x 512 + 512 1.29, 8 x 512 + 1024 1.25, 16 x 512 + 512 1.38
     hipLaunchKernelGGL((sort_scatter_window_kernel<8, 512, true>), dim3(blocks_for(s.np, SW_THREADS * 8)), dim3(SW_THREADS), 0,
-                       st, s, d, cell, rank, offsets, sg);
+                       st, s, d, (const int*)nullptr, rank, offsets, sg);
     WXA_LAUNCH_CHECK();
     ws->sorted_valid = true;
     ws->sorted_np = src->np;   // wxa_sort_live_count lowers it to the live count
