@@ -75,9 +75,6 @@ class ThreadBrickTransport:
             H.device_sync()
             # an empty message is no message, on either side (the RCCL and the torch.distributed transports skip them too:
             # a brick with nothing to hand to a peer and nothing to expect from it may not make the call at all)
-            if os.environ.get("WXA_TEST_TRACE_EXCHANGE"):
-                print(f"[exchange] rank {self.rank} nmsg {nmsg} send {[(int(send_peer[i]), int(send_bytes[i]), hex(send_buf[i] or 0)) for i in range(nmsg)]} "
-                      f"recv {[(int(recv_peer[i]), int(recv_bytes[i])) for i in range(nmsg)]}", flush=True)
             for i in range(nmsg):
                 n = int(send_bytes[i])
                 if n:
