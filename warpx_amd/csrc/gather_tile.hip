@@ -58,6 +58,21 @@ struct GatherTileDims {
     static constexpr int NPTS = N * N * N;
 };
 
+// Orders <= 3 without the Galerkin shapes (G = 0: what the reference pairs with direct deposition): a component needs the
+// twelve points -2 .. 9 only along the directions in which it is cell-centred, eleven (-1 .. 9) along the others.  With the
+// arrays sized per component the stage is 3 x 12 x 11 x 11 + 3 x 11 x 12 x 12 doubles = 73 KB instead of 6 x 12^3 = 83 KB:
+// two workgroups per CU again, like the Galerkin gather (round 6; the direct-deposition line's gather 7.6 ms before).
+struct SplitTile {
+    static constexpr int stag(int c, int d) {   // Ex Ey Ez Bx By Bz: cell-centred along d?
+        return c == 0 ? d == 0 : c == 1 ? d == 1 : c == 2 ? d == 2 : c == 3 ? d != 0 : c == 4 ? d != 1 : d != 2;
+    }
+    static constexpr int n(int c, int d) { return stag(c, d) ? GT_TS + 4 : GT_TS + 3; }
+    static constexpr int lo(int c, int d) { return stag(c, d) ? -2 : -1; }
+    static constexpr int pts(int c) { return n(c, 0) * n(c, 1) * n(c, 2); }
+    static constexpr int off(int c) { return c == 0 ? 0 : off(c - 1) + pts(c - 1); }
+    static constexpr int total() { return off(6); }
+};
+
 struct GTileGeom {
     int nt[3];
     int cell_lo[3];
@@ -100,13 +115,14 @@ __device__ __forceinline__ void push_and_store(const PV& p, int ip, double xp, d
 // the tiles that do.  1 and 2 let the guard exchange of E and B travel behind the interior tiles
 // (wxa_gather_push_part); the default path instantiates PART = 0 and is unchanged by them.
 template <int O, int G, int PUSHER, bool MOVE, int PART = 0>
-__global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD((G && O <= 3) ? 4 : 2)   // what the staged tile lets a CU hold
+__global__ void __launch_bounds__(GT_THREADS) WXA_WAVES_PER_SIMD(O <= 3 ? 4 : 2)   // what the staged tile lets a CU hold
 gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey, DevF Ez, DevF Bx, DevF By,
                         DevF Bz, Geom g, GTileGeom tg, double q, double m, double dt, GatherStragglers sq, ExtEB ext,
                         PushSort hook, HeavyUnits hu) {
     constexpr int N = GatherTileDims<G, O>::N;
     constexpr int NPTS = GatherTileDims<G, O>::NPTS;
-    __shared__ double F[6 * NPTS];
+    constexpr bool SPLIT = G == 0 && O <= 3;   // per-component stage (SplitTile)
+    __shared__ double F[SPLIT ? SplitTile::total() : 6 * NPTS];
     const long ntiles = (long)tg.nt[0] * tg.nt[1] * tg.nt[2];
     if (blockIdx.x == 0 && threadIdx.x == 0 && sq.next) *sq.next = 0u;
     // a tile with far more particles than the others is shared by several workgroups, each with a part of its particles
@@ -199,7 +215,36 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
             if (a < NPTS) F[c * NPTS + a] = r[n];
         }
     };
-    {
+    if constexpr (SPLIT) {
+        const int t0 = o0 - GatherTileDims<G, O>::LO, t1 = o1 - GatherTileDims<G, O>::LO, t2 = o2 - GatherTileDims<G, O>::LO;   // the tile's first cell
+        constexpr int PERS = (SplitTile::pts(3) + GT_THREADS - 1) / GT_THREADS;
+        auto fetch_c = [&](auto cc, const DevF& f, double (&r)[PERS]) {
+            constexpr int c = decltype(cc)::value, n0 = SplitTile::n(c, 0), n1 = SplitTile::n(c, 1);
+#pragma unroll
+            for (int n = 0; n < PERS; ++n) {
+                const int a = tid + n * GT_THREADS;
+                const int i = t0 + SplitTile::lo(c, 0) + a % n0, j = t1 + SplitTile::lo(c, 1) + (a / n0) % n1,
+                          k = t2 + SplitTile::lo(c, 2) + a / (n0 * n1);
+                const bool in = a < SplitTile::pts(c) && i >= f.lo0 && i < f.lo0 + f.n0 && j >= f.lo1 && j < f.lo1 + f.n1 &&
+                                k >= f.lo2 && k < f.lo2 + f.n2;
+                r[n] = in ? f.p[f.off(i, j, k)] : 0.0;
+            }
+        };
+        auto put_c = [&](auto cc, const double (&r)[PERS]) {
+            constexpr int c = decltype(cc)::value;
+#pragma unroll
+            for (int n = 0; n < PERS; ++n) {
+                const int a = tid + n * GT_THREADS;
+                if (a < SplitTile::pts(c)) F[SplitTile::off(c) + a] = r[n];
+            }
+        };
+        using std::integral_constant;
+        double r0[PERS], r1[PERS], r2[PERS], r3[PERS], r4[PERS], r5[PERS];
+        fetch_c(integral_constant<int, 0>{}, Ex, r0); fetch_c(integral_constant<int, 1>{}, Ey, r1); fetch_c(integral_constant<int, 2>{}, Ez, r2);
+        fetch_c(integral_constant<int, 3>{}, Bx, r3); fetch_c(integral_constant<int, 4>{}, By, r4); fetch_c(integral_constant<int, 5>{}, Bz, r5);
+        put_c(integral_constant<int, 0>{}, r0); put_c(integral_constant<int, 1>{}, r1); put_c(integral_constant<int, 2>{}, r2);
+        put_c(integral_constant<int, 3>{}, r3); put_c(integral_constant<int, 4>{}, r4); put_c(integral_constant<int, 5>{}, r5);
+    } else {
         double r0[PER], r1[PER], r2[PER], r3[PER], r4[PER], r5[PER];
         fetch(Ex, r0); fetch(Ey, r1); fetch(Ez, r2); fetch(Bx, r3); fetch(By, r4); fetch(Bz, r5);
         put(0, r0); put(1, r1); put(2, r2); put(3, r3); put(4, r4); put(5, r5);
@@ -235,12 +280,35 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         const int lo_i = min(s.jn, s.jc) - o0, hi_i = max(s.jn + NN, s.jc + NC) - 1 - o0;
         const int lo_j = min(s.kn, s.kc) - o1, hi_j = max(s.kn + NN, s.kc + NC) - 1 - o1;
         const int lo_k = min(s.ln, s.lc) - o2, hi_k = max(s.ln + NN, s.lc + NC) - 1 - o2;
-        const bool staged = lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N;
+        bool staged = lo_i >= 0 && lo_j >= 0 && lo_k >= 0 && hi_i < N && hi_j < N && hi_k < N;
+        if constexpr (SPLIT) {   // ... and the nodal stencils inside the eleven points -1 .. 9 (o = the tile's first cell - 2)
+            staged = staged && s.jn - o0 >= 1 && s.kn - o1 >= 1 && s.ln - o2 >= 1;
+        }
         if (!staged) {
             push_straggler(ip);   // stencil leaves the staged tile: handled by gather_push_stragglers_kernel
             continue;
         }
         const int jn = s.jn - o0, jc = s.jc - o0, kn = s.kn - o1, kc = s.kc - o1, ln = s.ln - o2, lc = s.lc - o2;
+        double Exp, Eyp, Ezp, Bxp, Byp, Bzp;
+        if constexpr (SPLIT) {
+            // component c's array: n(c, d) points from lo(c, d) along d; jn .. lc above count from -2
+            auto rows = [&](auto cc, auto nx, auto ny, auto nz, const int i, const int j, const int k, const double* sx_,
+                            const double* sy_, const double* sz_) {
+                constexpr int c = decltype(cc)::value, n0 = SplitTile::n(c, 0), n1 = SplitTile::n(c, 1);
+                const double* b_ = F + SplitTile::off(c) + (i - (SplitTile::lo(c, 0) + 2)) +
+                                   n0 * ((j - (SplitTile::lo(c, 1) + 2)) + n1 * (k - (SplitTile::lo(c, 2) + 2)));
+                return gather_rows_lds<decltype(nx)::value, decltype(ny)::value, decltype(nz)::value, n0, n0 * n1, 2>(b_, sx_, sy_, sz_);
+            };
+            using std::integral_constant;
+            constexpr integral_constant<int, NN> nn{};
+            constexpr integral_constant<int, NC> nc{};
+            Exp = rows(integral_constant<int, 0>{}, nc, nn, nn, jc, kn, ln, s.sxc, s.syn, s.szn);
+            Eyp = rows(integral_constant<int, 1>{}, nn, nc, nn, jn, kc, ln, s.sxn, s.syc, s.szn);
+            Ezp = rows(integral_constant<int, 2>{}, nn, nn, nc, jn, kn, lc, s.sxn, s.syn, s.szc);
+            Bzp = rows(integral_constant<int, 5>{}, nc, nc, nn, jc, kc, ln, s.sxc, s.syc, s.szn);
+            Byp = rows(integral_constant<int, 4>{}, nc, nn, nc, jc, kn, lc, s.sxc, s.syn, s.szc);
+            Bxp = rows(integral_constant<int, 3>{}, nn, nc, nc, jn, kc, lc, s.sxn, s.syc, s.szc);
+        } else {
 #define GROWS(...)                                                                                         \
     [&](const double* b_, const double* sx_, const double* sy_, const double* sz_) {                       \
         /* two rows in flight ahead of the fma chain (order 4: rows of five points -- the compiler's own LDS reads; the */ \
@@ -248,13 +316,14 @@ gather_push_tile_kernel(PV p, const int* __restrict__ offsets, DevF Ex, DevF Ey,
         if constexpr (O <= 3) return gather_rows_lds<__VA_ARGS__, N, N * N, 2>(b_, sx_, sy_, sz_);        \
         else return gather_rows<__VA_ARGS__>(b_, N, N * N, sx_, sy_, sz_);                                 \
     }
-        const double Exp = GROWS(NC, NN, NN)(F + 0 * NPTS + jc + N * (kn + N * ln), s.sxc, s.syn, s.szn);
-        const double Eyp = GROWS(NN, NC, NN)(F + 1 * NPTS + jn + N * (kc + N * ln), s.sxn, s.syc, s.szn);
-        const double Ezp = GROWS(NN, NN, NC)(F + 2 * NPTS + jn + N * (kn + N * lc), s.sxn, s.syn, s.szc);
-        const double Bzp = GROWS(NC, NC, NN)(F + 5 * NPTS + jc + N * (kc + N * ln), s.sxc, s.syc, s.szn);
-        const double Byp = GROWS(NC, NN, NC)(F + 4 * NPTS + jc + N * (kn + N * lc), s.sxc, s.syn, s.szc);
-        const double Bxp = GROWS(NN, NC, NC)(F + 3 * NPTS + jn + N * (kc + N * lc), s.sxn, s.syc, s.szc);
+            Exp = GROWS(NC, NN, NN)(F + 0 * NPTS + jc + N * (kn + N * ln), s.sxc, s.syn, s.szn);
+            Eyp = GROWS(NN, NC, NN)(F + 1 * NPTS + jn + N * (kc + N * ln), s.sxn, s.syc, s.szn);
+            Ezp = GROWS(NN, NN, NC)(F + 2 * NPTS + jn + N * (kn + N * lc), s.sxn, s.syn, s.szc);
+            Bzp = GROWS(NC, NC, NN)(F + 5 * NPTS + jc + N * (kc + N * ln), s.sxc, s.syc, s.szn);
+            Byp = GROWS(NC, NN, NC)(F + 4 * NPTS + jc + N * (kn + N * lc), s.sxc, s.syn, s.szc);
+            Bxp = GROWS(NN, NC, NC)(F + 3 * NPTS + jn + N * (kc + N * lc), s.sxn, s.syc, s.szc);
 #undef GROWS
+        }
 #ifdef WXA_GATHER_PROFILE
         double prof_e = Exp + Bxp;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(prof_e));
