@@ -17,6 +17,7 @@ import subprocess
 
 import pytest
 import sys
+from tests.ports import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -84,7 +85,7 @@ def test_bricks_over_gloo_with_the_hip_kernels(tmp_path, nb, port):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hipcpu"), "-j8"], stdout=subprocess.DEVNULL)
     n = nb[0] * nb[1] * nb[2]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "multibrick_worker.py"),
+           "127.0.0.1", "--master-port", str(free_port(port)), os.path.join(ROOT, "tests", "multibrick_worker.py"),
            *[str(v) for v in nb], "3", "1", out, "0"]
     env = dict(os.environ, OMP_NUM_THREADS="1", WXA_WORKER_LIB="hipcpu", HIPCPU_GUARD_PAGES="1", WXA_TEST_STEPS="8")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -116,7 +117,7 @@ def test_boosted_wakefield_deck_on_bricks_with_the_hip_kernels(tmp_path):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hipcpu"), "-j8"], stdout=subprocess.DEVNULL)
     out = str(tmp_path / "sum.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", "29664", os.path.join(ROOT, "tests", "deck_worker.py"), "2", "1", "1", deck, out]
+           "127.0.0.1", "--master-port", str(free_port(29664)), os.path.join(ROOT, "tests", "deck_worker.py"), "2", "1", "1", deck, out]
     env = dict(os.environ, OMP_NUM_THREADS="1", WXA_WORKER_LIB="hipcpu", WXA_HIP_ON_CPU="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -132,7 +133,7 @@ def test_bench_control_flow_on_several_ranks(n, port):
     and the JSON line of rank 0.  Control flow only."""
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "bench_on_cpu.py"), "--gpus", str(n),
+           "127.0.0.1", "--master-port", str(free_port(port)), os.path.join(ROOT, "scripts", "bench_on_cpu.py"), "--gpus", str(n),
            "--ncell", "16", "--steps", "3", "--warmup", "1", "--preroll", "2", "--no-cpu-baseline", "--n1-ms", "1.0"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]

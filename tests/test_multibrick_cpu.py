@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import pytest
+from tests.ports import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -26,7 +27,7 @@ def _run(nb, order, filt, tmp_path, port, overlap=0, extra_env=None):
     out = str(tmp_path / f"report{overlap}.json")
     n = nb[0] * nb[1] * nb[2]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port(port)),
            os.path.join(ROOT, "tests", "multibrick_worker.py"), *[str(v) for v in nb], str(order), str(filt), out, str(overlap)]
     env = dict(os.environ, OMP_NUM_THREADS="1", **(extra_env or {}))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -101,7 +102,7 @@ def test_deck_on_bricks_reaches_the_golden_checksums(nb, nranks, deck, golden, p
     out = str(tmp_path / "sum.json")
     n = nranks
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port(port)), os.path.join(ROOT, "tests", "deck_worker.py"),
            *[str(v) for v in nb], os.path.join(ROOT, "tests", "decks", deck), out]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -140,7 +141,7 @@ def test_boosted_frame_decks_on_bricks_match_one_brick(nb, nranks, deck, port, t
     want = _ONE_BRICK[deck]
     out = str(tmp_path / "sum.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port(port)), os.path.join(ROOT, "tests", "deck_worker.py"),
            *[str(v) for v in nb], path, out]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks), WXA_TEST_MAX_STEP=str(nsteps)))
@@ -175,7 +176,7 @@ def test_thin_bricks_along_the_boost_grow_their_leaver_lists(tmp_path):
     one.close()
     out = str(tmp_path / "sum.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
-           "--master-port", "29648", os.path.join(ROOT, "tests", "deck_worker.py"), "1", "1", "4", path, out]
+           "--master-port", str(free_port(29648)), os.path.join(ROOT, "tests", "deck_worker.py"), "1", "1", "4", path, out]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, OMP_NUM_THREADS=_threads(4), WXA_TEST_OVERRIDES=";".join(over)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -226,7 +227,7 @@ def test_bricks_flush_one_back_transformed_plotfile(nb, nranks, port, tmp_path):
     one.evolve(one.max_step)               # the deck's max_step: the forced flush of the last time step included
     one.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port(port)), os.path.join(ROOT, "tests", "deck_worker.py"),
            *[str(v) for v in nb], path, str(tmp_path / "sum.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks), WXA_TEST_DIAGNOSTICS="1",
@@ -272,7 +273,7 @@ def test_random_momenta_do_not_depend_on_the_brick_layout(tmp_path):
     one.close()
     out = str(tmp_path / "sum.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
-           "--master-addr", "127.0.0.1", "--master-port", "29627", os.path.join(ROOT, "tests", "deck_worker.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port(29627)), os.path.join(ROOT, "tests", "deck_worker.py"),
            "0", "0", "0", str(deck), out]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -308,7 +309,7 @@ def test_back_transformed_diagnostics_on_bricks_match_one_brick(nb, nranks, port
     one.close()
     out = str(tmp_path / "btd.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port(port)), os.path.join(ROOT, "tests", "deck_worker.py"),
            *[str(v) for v in nb], path, str(tmp_path / "sum.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, OMP_NUM_THREADS=_threads(nranks), WXA_TEST_MAX_STEP=str(nsteps),
@@ -362,7 +363,7 @@ def test_bricks_that_disagree_on_a_switch_are_refused_before_the_first_step(tmp_
     The bricks compare their switches over the count round in their first Evolve: every rank fails with the reason."""
     out = str(tmp_path / "r.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29665", os.path.join(ROOT, "tests", "multibrick_worker.py"), "1", "1", "2", "3", "1", out, "0"]
+           "--master-port", str(free_port(29665)), os.path.join(ROOT, "tests", "multibrick_worker.py"), "1", "1", "2", "3", "1", out, "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, OMP_NUM_THREADS="1", WXA_TEST_F32_WIRE="rank0"))
     assert r.returncode != 0

@@ -14,6 +14,7 @@ from tests import helpers as H
 from warpx_amd import _capi, plasma
 from warpx_amd.distributed import _as_tensor, brick_coord
 from warpx_amd.sim import WarpXSim, particle_moments
+from tests.ports import free_port
 
 pytestmark = pytest.mark.gpu
 L = 40e-6
@@ -509,7 +510,7 @@ def _spawn_bricks(nb, order, filt, overlap, ncell, port, tmp_path, steps=6, extr
     out = str(tmp_path / "report.json")
     n = nb[0] * nb[1] * nb[2]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port(port)),
            os.path.join(root, "tests", "multibrick_worker.py"), *[str(v) for v in nb], str(order), str(filt), out, str(overlap)]
     env = dict(os.environ, OMP_NUM_THREADS=str(max(1, (os.cpu_count() or 8) // n)), WXA_WORKER_LIB="product",
                WXA_TEST_NCELL=" ".join(str(v) for v in ncell), WXA_TEST_STEPS=str(steps), **(extra_env or {}))

@@ -18,6 +18,7 @@ import pytest
 from tests.test_inputs_cpu import DECKS, HERE, compare_with_golden
 from tests.test_inputs_cpu import lib  # noqa: F401  (fixture)
 from warpx_amd.sim import WarpXSim
+from tests.ports import free_port
 
 REFERENCE = "/root/reference"
 
@@ -176,7 +177,7 @@ def test_bricks_write_one_plotfile(tmp_path, nb, port):
     plt = str(tmp_path / "plt")
     n = nb[0] * nb[1] * nb[2]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "deck_worker.py"),
+           "127.0.0.1", "--master-port", str(free_port(port)), os.path.join(HERE, "deck_worker.py"),
            *[str(v) for v in nb], deck, str(tmp_path / "sum.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, OMP_NUM_THREADS="2", WXA_TEST_PLOTFILE=plt))

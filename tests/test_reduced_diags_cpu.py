@@ -15,6 +15,7 @@ import pytest
 from tests.oracle_lib import load_host_cpu
 from warpx_amd import _capi, plasma
 from warpx_amd.sim import WarpXSim, field_energy, particle_moments
+from tests.ports import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = 40e-6
@@ -217,7 +218,7 @@ def test_bricks_write_the_rows_of_one_brick(host_cpu, tmp_path, nb, port):
     sim.close()
     n = nb[0] * nb[1] * nb[2]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "deck_worker.py"),
+           "127.0.0.1", "--master-port", str(free_port(port)), os.path.join(ROOT, "tests", "deck_worker.py"),
            *[str(v) for v in nb], deck, str(tmp_path / "sum.json")]
     over = ";".join(base + [f"{d}.path={many}" for d in ("EF", "EP", "PP", "NP")])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
