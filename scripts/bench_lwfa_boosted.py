@@ -68,12 +68,38 @@ def main():
     # per-phase table: whole sort cycles
     cyc = max(args.sort_interval, 1)
     nph = cyc * ((6 + cyc - 1) // cyc)
+    prof = None
+    if os.environ.get("WXA_PRODUCT_LIB", "").endswith("_prof.so"):   # a WXA_DEPOSIT_PROFILE build: the tile kernel's phase clocks
+        import ctypes as C
+        raw = C.CDLL(os.environ["WXA_PRODUCT_LIB"])
+        prof = (C.c_ulonglong * 16)()
+        raw.wxa_debug_deposit_profile(prof, 1)
+        bins = (C.c_ulonglong * 128)()
+        raw.wxa_debug_deposit_profile_bins(bins, 1)
     sim.enable_timers(True)
     sim.timers(reset=True)
     sim.evolve(nph)
     torch.cuda.synchronize()
     phases = sim.timers(reset=True)
     sim.enable_timers(False)
+    if prof is not None:
+        raw.wxa_debug_deposit_profile(prof, 1)
+        raw.wxa_debug_deposit_profile_bins(bins, 1)
+        allc = sum(bins[4 * b] for b in range(32))
+        print("workgroups by the particles of their share (log2 bins): share of all workgroup cycles, workgroups per launch, "
+              "mean and longest in kilocycles, particles per launch", file=sys.stderr)
+        for b in range(32):
+            if bins[4 * b + 1]:
+                print("   2^%-2d  %5.1f %%  %8.0f  mean %8.1f  longest %8.1f  particles %.3e" % (
+                    b, 100.0 * bins[4 * b] / allc, bins[4 * b + 1] / nph, bins[4 * b] / bins[4 * b + 1] / 1e3, bins[4 * b + 2] / 1e3,
+                    bins[4 * b + 3] / nph), file=sys.stderr)
+        tot = sum(prof[:6])
+        print("deposition phase clocks (workgroup cycles, share):", [round(prof[i] / tot, 3) for i in range(6)], file=sys.stderr)
+        print("chunks %d, all lane pairs on one frame %d, all quads %d, second particles apart %d, lanes sharing %d of %d with a particle"
+              % tuple(int(prof[i]) for i in range(10, 16)), "in %d launches" % nph, file=sys.stderr)
+        if prof[8]:
+            print("wave 0 per chunk: loads %.0f cycles, body %.0f cycles, %.0f chunks per launch; in its loop %.2f of phase 2"
+                  % (prof[6] / prof[8], prof[7] / prof[8], prof[8] / nph, prof[9] / max(prof[2], 1)), file=sys.stderr)
     kernels = {}
     for name, (ms, cnt) in phases.items():
         if cnt:

@@ -568,6 +568,49 @@ def test_deposit_current_of_a_streaming_plasma(oracle, product, order, streaming
     product.workspace_destroy(ws)
 
 
+@pytest.mark.parametrize("order", [1, 3])
+@pytest.mark.parametrize("keep", [1.0, 0.7])
+@pytest.mark.parametrize("step_cells", [0.76, 0.5])
+def test_deposit_current_of_a_cold_stream_on_a_lattice(oracle, product, order, keep, step_cells):
+    """The plasma ahead of a boosted-frame wake: eight particles per cell on a 2 x 2 x 2 lattice, cold, every one of them
+    `step_cells` of a cell along -z per step.  At 0.76 all of them cross a cell face and the pairs of a cell share their
+    wide frame: whole waves take the streaming body's PairScatterSink (lanes l and l + 32 share the summing AND the
+    adding); at 0.5 half of a cell's particles cross and the lane pairs' frames differ (PairSumSink).  keep < 1: that
+    share of the particles, at random -- cells with odd counts, lanes and lane pairs without a particle."""
+    ncell = (16, 16, 24)
+    _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
+    dx = H.LX / np.asarray(ncell)
+    ax = [-H.LX / 2 + (np.arange(2 * ncell[d]) + 0.5) * dx[d] / 2 for d in range(3)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    rng = np.random.default_rng(5)
+    sel = rng.random(X.size) < keep
+    n = int(sel.sum())
+    dt = H.yee_dt(dx)
+    beta = min(step_cells * dx[2] / (plasma.C_LIGHT * dt), 0.98)
+    parts = [X.ravel()[sel], Y.ravel()[sel], Z.ravel()[sel], 1e9 * (0.5 + rng.random(n)),
+             np.zeros(n), np.zeros(n), np.full(n, -beta / np.sqrt(1.0 - beta ** 2) * plasma.C_LIGHT)]
+    pd0 = ParticleArrays.from_numpy(parts, DEV)
+    ws = C.c_void_p()
+    product.workspace_create(C.byref(ws))
+    product.workspace_set_streaming_plasma(ws, 1)
+    srt = ParticleArrays(pd0.np, DEV)
+    product.sort_particles_by_cell(C.byref(pd0.view), C.byref(srt.view), H.d3((-H.LX / 2,) * 3), H.d3(1.0 / dx),
+                                   (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(*ncell), ws, None)
+    _sync(product)
+    ph = ParticleArrays.from_numpy(list(srt.to_numpy()), "cpu")
+    J = [FieldArray(ncell, STAG[n], (ng_j,) * 3, "cpu") for n in ("jx", "jy", "jz")]
+    Jd = H.clone_fields(J, DEV, True)
+    g, _ = H.geom_for(ncell, ng_depos)
+    q = -plasma.Q_E
+    # the positions handed over are the ones after the push (the deposition steps back by v dt): inside the box either way
+    oracle.deposit_current(C.byref(ph.view), field_triplet(J), C.byref(g), q, dt, -0.5 * dt, order, _capi.DEPOSIT_ESIRKEPOV, None, None)
+    product.deposit_current(C.byref(srt.view), field_triplet(Jd), C.byref(g), q, dt, -0.5 * dt, order, _capi.DEPOSIT_ESIRKEPOV, ws, None)
+    _sync(product)
+    for a, b in zip(Jd, J):
+        assert H.max_rel_err(a.to_numpy(), b.to_numpy()) < 1e-12
+    product.workspace_destroy(ws)
+
+
 @pytest.mark.parametrize("algo,acc", [(_capi.DEPOSIT_ESIRKEPOV, _capi.ACC_FP64), (_capi.DEPOSIT_DIRECT, _capi.ACC_FP64),
                                       (_capi.DEPOSIT_ESIRKEPOV, _capi.ACC_FP32)])
 @pytest.mark.parametrize("ppc", [20, 40])

@@ -623,6 +623,40 @@ struct PairSumSink {
     }
 };
 
+// Two values per lane in, one sum per lane out: lane l < 32 gets a(l) + a(l + 32), lane l + 32 gets b(l) + b(l + 32) -- one
+// v_permlane32_swap per dword (the upper 32 lanes of a change places with the lower 32 of b) and one v_add_f64.
+#ifndef WXA_HAVE_SWAP_ADD_HALVES   // tests/hipcpu: wave shuffles
+__device__ __forceinline__ double swap_add_halves(const double a, const double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+#endif
+// PairSumSink with the adding shared out as well, for a wave whose lane pairs (l, l + 32) ALL deposit on one frame per pair:
+// the body's values arrive along the component's own direction (the running sums D[0 .. O], O odd: an even number), two
+// neighbouring points at a time; the pair's sums of the first go to the lower lane, of the second to the upper lane
+// (swap_add_halves), and ONE ds_add_f64 of the wave adds both -- the upper lane's sink starts one point further along that
+// direction.  Half the LDS-atomic instructions of PairSumSink, which is what the LDS charges for (an atomic instruction
+// costs the same with 32 or 64 active lanes, profiles/round6/README.md session j).
+template <class Sink>
+struct PairScatterSink {
+    Sink inner;
+    bool active;   // the lane pair has a frame (a lane without a particle joins its partner's with zero weights)
+    double held = 0.0;
+    int hi = 0, hj = 0, hk = 0;
+    bool full = false;
+    __device__ __forceinline__ PairScatterSink(const Sink& s, bool active_) : inner(s), active(active_) {}
+    __device__ __forceinline__ void add(int c, int i, int j, int k, double v) {
+        if (!full) {
+            held = v; hi = i; hj = j; hk = k; full = true;
+            return;
+        }
+        full = false;
+        const double s = swap_add_halves(held, v);
+        if (active) inner.add(c, hi, hj, hk, s);
+    }
+};
+
 // LdsSink for a wave whose lanes share the frame: every value is summed over the wave, lane 63 adds it
 template <class Sink>
 struct WaveSumSink {

@@ -89,10 +89,12 @@ struct LdsSink {
 // between marks; a barrier before the mark makes the interval the workgroup's, not wave 0's.
 #ifdef WXA_DEPOSIT_PROFILE
 __device__ unsigned long long wxa_dep_prof[16];
+__device__ unsigned long long wxa_dep_prof_bins[32][4];
 // accumulated in registers of thread 0, added to the global counters once per workgroup (a global
 // atomic per mark would serialise on the 16 addresses and distort the very thing measured)
 #define DPROF_INIT                                  \
     long long prof_t = clock64();                   \
+    const long long prof_t0 = prof_t;               \
     unsigned long long prof_acc[16];                \
     _Pragma("unroll") for (int prof_i = 0; prof_i < 16; ++prof_i) prof_acc[prof_i] = 0;
 #define DPROF(n)                                                  \
@@ -190,6 +192,12 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
     constexpr int NB = (CELLS / BW) * (4 / RPC);   // chunks of the direct part (the first four pairs of every cell)
     constexpr int RT = 64 / CW;                    // rows of the tail table (pairs 4 .. 3 + RT): RT CW = 64 counts = one wave scan
     constexpr int RMAX = 4 + RT;
+    // WL (a streaming plasma; lanes l and l + 32 of a chunk share their deposits where they sit in one cell): a work item
+    // of the tail table and of the excess is a cell's pairs (2 m, 2 m + 1) for the lanes l and l + 32, like the direct part's
+    // -- 32 items per chunk, RT / 2 table rows.  Otherwise an item is one pair, 64 per chunk (consecutive lanes in
+    // consecutive cells: the layout the uniform plasma's bank arithmetic is made for).
+    constexpr int TW = CFG::WL != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV ? 2 : 1;   // pairs per tail / excess item
+    constexpr int RTU = RT / TW;                                                    // table rows in use
     constexpr int TCAP = CELLS * 2;                // tail capacity (8 ppc: 0.66 tail items per cell on average)
     constexpr int DEFER = 2048;
     static_assert(NT >= CELLS && RT >= 8, "one lane per cell");
@@ -263,19 +271,21 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
         if constexpr (CFG::ALGO == WXA_DEPOSIT_DIRECT) sq.push(ip);
         else defer(ip, bank);
     };
-    auto defer_particle = [&](const int ip, const int bank, const ParticleState& pp) {
+    // (false: the bucket is full, nothing was done)
+    auto try_defer_particle = [&](const int ip, const int bank, const ParticleState& pp) {
         const int n = atomicAdd(&ndef[bank], 1);
-        if (n < DCAP) {
-            const bool keep = n < DKEEP;
-            deferred[bank * DCAP + n] = (unsigned)ip | (keep ? 0u : 0x80000000u);
-            if (keep) {
-                const int at = bank * DKEEP + n;
-                dkeep[0][at] = pp.x; dkeep[1][at] = pp.y; dkeep[2][at] = pp.z; dkeep[3][at] = pp.w;
-                dkeep[4][at] = pp.ux; dkeep[5][at] = pp.uy; dkeep[6][at] = pp.uz;
-            }
-        } else {
-            sq.push(ip);
+        if (n >= DCAP) return false;
+        const bool keep = n < DKEEP;
+        deferred[bank * DCAP + n] = (unsigned)ip | (keep ? 0u : 0x80000000u);
+        if (keep) {
+            const int at = bank * DKEEP + n;
+            dkeep[0][at] = pp.x; dkeep[1][at] = pp.y; dkeep[2][at] = pp.z; dkeep[3][at] = pp.w;
+            dkeep[4][at] = pp.ux; dkeep[5][at] = pp.uy; dkeep[6][at] = pp.uz;
         }
+        return true;
+    };
+    auto defer_particle = [&](const int ip, const int bank, const ParticleState& pp) {
+        if (!try_defer_particle(ip, bank, pp)) sq.push(ip);
     };
     constexpr int WAVES = NT / 64;
     // ---- A: cell counts, row masks; zero fill
@@ -295,7 +305,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
         my_pairs = min((my_n + 1) >> 1, RMAX);
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            my_mask[r] = __ballot(my_pairs > 4 + r);
+            my_mask[r] = __ballot(r < RTU && my_pairs > 4 + TW * r);
             if (lane == 0) masks[r][wave] = my_mask[r];
         }
     }
@@ -319,12 +329,12 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int base = __shfl(excl, r * CW + wave);   // first item of (tail row r, this cell-wave)
-            if (my_pairs > 4 + r && !no_tail) {
+            if (r < RTU && my_pairs > 4 + TW * r && !no_tail) {
                 const int at = base + __popcll(my_mask[r] & lt);
-                if (at < TCAP) table[at] = (unsigned short)(tid | ((4 + r) << 9));
+                if (at < TCAP) table[at] = (unsigned short)(tid | ((4 + TW * r) << 9));
                 else {   // any bucket is correct; the cell's place in the sort order is the bank of a particle that stayed
-                    defer_unloaded(my_s + 2 * (4 + r), tid & (NBANK - 1));
-                    if (2 * (4 + r) + 1 < my_n) defer_unloaded(my_s + 2 * (4 + r) + 1, tid & (NBANK - 1));
+                    for (int e = 2 * (4 + TW * r); e < min(2 * (4 + TW * r) + 2 * TW, my_n); ++e)
+                        defer_unloaded(my_s + e, tid & (NBANK - 1));
                 }
             }
         }
@@ -335,7 +345,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
     int excess_pairs = 0;
     const int rmax_t = __builtin_amdgcn_readfirstlane(tail_off) ? 4 : RMAX;   // pairs of a cell that the direct chunks and the tail table cover
     if (any_excess) {   // uniform
-        if (tid < CELLS) xs[tid] = (max(0, my_n - 2 * rmax_t) + 1) >> 1;
+        if (tid < CELLS) xs[tid] = (((max(0, my_n - 2 * rmax_t) + 1) >> 1) + TW - 1) / TW;   // items of the cell's excess
         __syncthreads();
         if (tid == 0) {
             int acc = 0;
@@ -354,13 +364,13 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
     const int o2 = tg.cell_lo[2] + tk * TS + TD::LO;
     // ---- C: the chunks (NB blocks of 16 cells x 4 pairs, then the tail table)
     const int T = min(nitems, TCAP);
-    constexpr int TPC = 64;   // tail items per chunk
+    constexpr int TPC = 64 / TW;   // tail / excess items per chunk
 #ifdef WXA_DEPOSIT_PROFILE
     const long long prof_l0 = clock64();
 #endif
     const int CH0 = unit_u + unit_k * wave, CHS = unit_k * WAVES;   // the chunks of this unit, wave by wave
     const int nregular = NB + ((T + TPC - 1) / TPC);
-    const int nchunks = nregular + ((excess_pairs + 63) >> 6);
+    const int nchunks = nregular + ((excess_pairs + TPC - 1) / TPC);   // (excess_pairs: the excess' items)
     // the lane's work item of chunk ch: its two particles (an empty lane reads the tile's first particle)
     auto item_of = [&](const int ch, int& ia, int& ib, bool& va, bool& vb) {
         int c, r;
@@ -368,17 +378,19 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
             c = BW * (ch / (4 / RPC)) + (lane % BW); r = RPC * (ch % (4 / RPC)) + lane / BW; va = true;
         } else if (ch < nregular) {
             const int I = (ch - NB) * TPC + (lane & (TPC - 1));
-            va = I < T && lane < TPC;
+            va = I < T;
             const unsigned ent = va ? table[I] : 0u;
-            c = (int)(ent & 511u); r = (int)(ent >> 9);
+            c = (int)(ent & 511u); r = (int)(ent >> 9) + lane / TPC;
         } else {   // pair I of the cells' excess: the cell whose running sum holds it, xs[c] <= I < xs[c + 1]
             // Lane (r, s) = (lane / 16, lane % 16) of excess chunk j takes pair 4 j + r of stream s, the streams being
             // sixteen equal ranges of the excess pairs: the 16 lanes that a step of a ds_add_f64 serves sit in sixteen
             // different parts of the tile (consecutive pairs -- one cell, one frame, 64 lanes on the same addresses --
             // made the excess chunks of a dense tile several times slower than its other chunks), and every stream
             // still reads four neighbouring pairs = 64 contiguous bytes per array.
-            const int nexc = (excess_pairs + 63) >> 6;
-            const int I = (lane & 15) * (4 * nexc) + 4 * (ch - nregular) + (lane >> 4);
+            // (WL: items of two pairs, lane (r, s) = (lane % 32 / 16, lane % 16) takes the first pair of item 2 j + r of stream s,
+            // lane + 32 the second)
+            const int nexc = (excess_pairs + TPC - 1) / TPC;
+            const int I = (lane & 15) * ((4 / TW) * nexc) + (4 / TW) * (ch - nregular) + ((lane & (TPC - 1)) >> 4);
             va = I < excess_pairs;
             int lo = 0, hi = CELLS;
             const int J = va ? I : 0;
@@ -386,7 +398,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
                 const int mid = (lo + hi) >> 1;
                 if (xs[mid] <= J) lo = mid; else hi = mid;
             }
-            r = rmax_t + (J - xs[lo]);
+            r = rmax_t + TW * (J - xs[lo]) + lane / TPC;
             c = lo;
         }
         const int s0 = cstart[c], n0 = cstart[c + 1] - s0;
@@ -483,7 +495,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
             // (wave_sum_f64, VALU only) and one lane adds it, instead of 64 lanes adding to one LDS address one after
             // the other.  Wave-uniform control flow throughout: every lane computes, with weight 0 where it has no part.
             const bool crowded = ch >= nregular;   // wave-uniform
-            const WideFrame<O> fa = esirkepov_wide_frame<O>(c1, g), fb = esirkepov_wide_frame<O>(c2, g);
+            WideFrame<O> fa = esirkepov_wide_frame<O>(c1, g), fb = esirkepov_wide_frame<O>(c2, g);
             auto fits = [&](const WideFrame<O>& f) {
                 const int wi = f.b[0] - o0, wj = f.b[1] - o1, wk = f.b[2] - o2;
                 return wi >= 0 && wj >= 0 && wk >= 0 && wi + O + 2 <= N && wj + O + 2 <= N && wk + O + 2 <= NZ;
@@ -491,7 +503,8 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
             bool on_a = va && fits(fa), on_b = vb && fits(fb);
             if (va && !on_a) sq.push(ia);   // the frame leaves the tile: the global-atomics pass
             if (vb && !on_b) sq.push(ib);
-            const double wqa = q * pa.w, wqb = q * pb.w;
+            if (__ballot(on_a || on_b) == 0ull) continue;   // (a fifth of the boosted wakefield's chunks: cells ahead of the plasma)
+            double wqa = q * pa.w, wqb = q * pb.w;
             if (crowded) {
 #pragma unroll 1
                 for (int h = 0; h < 2; ++h) {
@@ -529,7 +542,62 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
             // their cell in x and y -- was measured and dropped: inside the wake the laser shakes every particle across
             // x, the deferred list overflowed with the crossing ones (61 -> 472 ms per launch for BASELINE config 5), and
             // chosen wave by wave it changed nothing (60.9 ms): sessions t and u.)
-            const bool merged = on_a && on_b && fa.b[0] == fb.b[0] && fa.b[1] == fb.b[1] && fa.b[2] == fb.b[2];
+            // A particle that stays in its cell along d fills slots 0 .. O of its frame there (both offsets 0); it sits as well
+            // on slots 1 .. O + 1 of the frame that starts one point lower -- the frame of a neighbour that crosses downwards.
+            // So particles of one cell whose frames start one point apart along some directions are brought onto ONE frame
+            // where the higher one can be lowered (of a stream that moves 0.9 cells per step nine in ten cross and one does
+            // not: without this nearly every wave holds a lane whose two particles need a pass each, and no wave's lane
+            // pairs agree).  A frame lowered to another's start fits the tile where that one does.
+            auto can_lower = [](const WideFrame<O>& f, const int d) { return f.sn[d] == 0 && f.so[d] == 0; };
+            auto lower = [](WideFrame<O>& f, const int d) { f.sn[d] = f.so[d] = 1; f.b[d] -= 1; };
+            if (!on_a && on_b) {   // the second particle alone takes the first one's place (one pass instead of two)
+                c1 = c2; fa = fb; wqa = wqb;
+                on_a = true; on_b = false;
+            }
+            bool merged = on_a && on_b;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int diff = fa.b[d] - fb.b[d];
+                if (merged && diff == 1 && can_lower(fa, d)) lower(fa, d);
+                else if (merged && diff == -1 && can_lower(fb, d)) lower(fb, d);
+                else if (diff != 0) merged = false;
+            }
+            // Lanes l and l + 32 hold two pairs of one cell: the same between the two lanes' frames.  A frame's key: its start
+            // on the tile, a byte per direction, and in the top byte the directions along which it can still be lowered; a
+            // lane without a particle joins the other's frame.
+            constexpr int EMPTY = -1, BROKEN = -2;
+            int low[3] = {0, 0, 0};   // this lane's frame comes down along d to the pair's
+            auto unify = [&](const int mine, const int theirs) {
+                if (theirs < 0) return mine;
+                if (mine < 0) return theirs;
+                int out = mine & 0xffffff;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int mb = (mine >> (8 * d)) & 255, tb = (theirs >> (8 * d)) & 255;
+                    const int mc = (mine >> (24 + d)) & 1, tc = (theirs >> (24 + d)) & 1;
+                    if (mb == tb + 1 && mc) { out -= 1 << (8 * d); low[d] = 1; }
+                    else if (mb + 1 == tb && tc) { }   // (the other lane comes down)
+                    else if (mb != tb) return BROKEN;
+                }
+                return out;
+            };
+            int mine = EMPTY;
+            if (on_a) {
+                int cs = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) cs |= (can_lower(fa, d) && (!merged || can_lower(fb, d))) << d;
+                mine = (fa.b[0] - o0) | ((fa.b[1] - o1) << 8) | ((fa.b[2] - o2) << 16) | (cs << 24);
+            }
+            const int theirs = partner32(mine);
+            const int pairkey = unify(mine, theirs);
+            const bool shared = mine >= 0 && theirs >= 0 && pairkey != BROKEN;   // two particles' lanes on one frame
+            const bool pairs = (O & 1) && __ballot(pairkey == BROKEN) == 0ull;    // wave-uniform: which way of adding
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if (low[d] && on_a) {
+                    lower(fa, d);
+                    if (merged) lower(fb, d);
+                }
             // (the frames packed, and unpacked again for every component behind a fence: registers)
             PackedWideFrame qa = pack_wide_frame<O>(fa), qb = pack_wide_frame<O>(fb);
             auto fence = [&]() {
@@ -541,24 +609,60 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
                 WXA_OPAQUE_F64(c2.x_old); WXA_OPAQUE_F64(c2.y_old); WXA_OPAQUE_F64(c2.z_old);
             };
             {
-                // Lanes l and l + 32 hold two pairs of one cell: where both deposit on the same wide frame the two lanes'
-                // values are summed (PairSumSink) and the lower lane adds them -- every lane of the wave runs the body, a
-                // lane without a particle on the tile with zero weights (the exchange between the lanes is a wave operation).
+                // Where the two lanes deposit on one frame their values are summed: every lane of the wave runs the body,
+                // a lane without a particle on the tile with zero weights (the exchange between the lanes is a wave operation).
                 const double wq1 = on_a ? wqa : 0.0, wq2 = on_a && merged ? wqb : 0.0;
-                const int key = on_a ? ((fa.b[0] - o0) | ((fa.b[1] - o1) << 8) | ((fa.b[2] - o2) << 16)) : -1 - lane;
-                const bool shared = partner32(key) == key;   // (a lane without a frame carries a key of its own)
                 const bool adds = on_a && !(shared && lane >= 32);
-                auto component = [&](auto comp) {
-                    fence();
-                    const WideFrame<O> f1 = unpack_wide_frame<O>(qa, g), f2 = unpack_wide_frame<O>(qb, g);
-                    PairSumSink<LdsSink<M, TSZ, ACC>> sink(LdsSink<M, TSZ, ACC>(lds, f1.b[0] - o0, f1.b[1] - o1, f1.b[2] - o2), shared, adds);
-                    esirkepov_pair_wide<O, decltype(comp)::value>(c1, f1, wq1, c2, f2, wq2, es, sink);
-                };
-                component(std::integral_constant<int, 0>{});
-                component(std::integral_constant<int, 1>{});
-                component(std::integral_constant<int, 2>{});
+#ifdef WXA_DEPOSIT_PROFILE   // every wave's chunks: how many take which body, how many lanes hold a particle, how many share a frame
+                {
+                    const unsigned long long m_on = __ballot(on_a), m_sh = __ballot(shared), m_2 = __ballot(on_b && !merged);
+                    if (lane == 0) {
+                        atomicAdd(&wxa_dep_prof[10], 1ull);
+                        atomicAdd(&wxa_dep_prof[11], (unsigned long long)pairs);
+                        atomicAdd(&wxa_dep_prof[12], 0ull);
+                        atomicAdd(&wxa_dep_prof[13], (unsigned long long)__popcll(m_2));
+                        atomicAdd(&wxa_dep_prof[14], (unsigned long long)__popcll(m_sh));
+                        atomicAdd(&wxa_dep_prof[15], (unsigned long long)__popcll(m_on));
+                    }
+                }
+#endif
+                // Every lane pair of the wave on one frame (a lane without a particle joins its partner's with zero weights):
+                // the two lanes share the summing AND the adding, PairScatterSink -- half the LDS-atomic instructions.
+                // Otherwise the lower lane of a pair that shares a frame adds the pair's sums (PairSumSink).
+                if (pairs) {
+                    const bool active = pairkey >= 0;
+                    const int kk = active ? pairkey : 0, up = lane >> 5;
+                    auto component = [&](auto comp) {
+                        constexpr int COMP = decltype(comp)::value;
+                        fence();
+                        const WideFrame<O> f1 = unpack_wide_frame<O>(qa, g), f2 = unpack_wide_frame<O>(qb, g);
+                        PairScatterSink<LdsSink<M, TSZ, ACC>> sink(
+                            LdsSink<M, TSZ, ACC>(lds, (kk & 255) + (COMP == 0 ? up : 0), ((kk >> 8) & 255) + (COMP == 1 ? up : 0),
+                                                 ((kk >> 16) & 255) + (COMP == 2 ? up : 0)), active);
+                        esirkepov_pair_wide<O, COMP>(c1, f1, wq1, c2, f2, wq2, es, sink);
+                    };
+                    component(std::integral_constant<int, 0>{});
+                    component(std::integral_constant<int, 1>{});
+                    component(std::integral_constant<int, 2>{});
+                } else {
+                    auto component = [&](auto comp) {
+                        fence();
+                        const WideFrame<O> f1 = unpack_wide_frame<O>(qa, g), f2 = unpack_wide_frame<O>(qb, g);
+                        PairSumSink<LdsSink<M, TSZ, ACC>> sink(LdsSink<M, TSZ, ACC>(lds, f1.b[0] - o0, f1.b[1] - o1, f1.b[2] - o2), shared, adds);
+                        esirkepov_pair_wide<O, decltype(comp)::value>(c1, f1, wq1, c2, f2, wq2, es, sink);
+                    };
+                    component(std::integral_constant<int, 0>{});
+                    component(std::integral_constant<int, 1>{});
+                    component(std::integral_constant<int, 2>{});
+                }
             }
-            if (on_b && !merged) {
+            // A second particle that cannot share the first one's frame (2 % of the boosted wakefield's: the laser shakes
+            // them across x both ways) goes to the deferred list -- phase D's dense waves, one lane per component and
+            // particle -- as long as its bucket has room: a pass of its own through the wide body costs the whole wave 300
+            // LDS atomics for the four lanes in 64 that need it (a third of that deck's chunks hold such a lane).
+            bool second = on_b && !merged;
+            if (second) second = !try_defer_particle(ib, ((fb.b[0] - o0) + 8 * (fb.b[2] - o2)) & (NBANK - 1), pb);
+            if (second) {
                 auto component = [&](auto comp) {
                     fence();
                     const WideFrame<O> f2 = unpack_wide_frame<O>(qb, g);
@@ -752,6 +856,17 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
     }
     DPROF(4);
     DPROF_FINISH
+#ifdef WXA_DEPOSIT_PROFILE   // the workgroups' lengths by the size of their share: cycles, count, the longest (bins of log2 particles)
+    if (tid == 0) {
+        const int share = max(1, (end - start) / unit_k);
+        const int bin = 31 - __clz(share);
+        const unsigned long long cyc = (unsigned long long)(clock64() - prof_t0);
+        atomicAdd(&wxa_dep_prof_bins[bin][0], cyc);
+        atomicAdd(&wxa_dep_prof_bins[bin][1], 1ull);
+        atomicMax(&wxa_dep_prof_bins[bin][2], cyc);
+        atomicAdd(&wxa_dep_prof_bins[bin][3], (unsigned long long)share);
+    }
+#endif
 }
 
 template <int O, int ALGO>
@@ -863,6 +978,15 @@ wxa_status deposit_current_tiled(const wxa_particle_view* p, const wxa_field_vie
 }  // namespace wxa
 
 #ifdef WXA_DEPOSIT_PROFILE
+extern "C" int wxa_debug_deposit_profile_bins(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(wxa::wxa_dep_prof_bins), sizeof(wxa::wxa_dep_prof_bins)) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[32 * 4] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wxa::wxa_dep_prof_bins), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int wxa_debug_deposit_profile(unsigned long long* out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(wxa::wxa_dep_prof), sizeof(wxa::wxa_dep_prof)) != hipSuccess)
         return -1;
