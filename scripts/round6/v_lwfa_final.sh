@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 6, session v: the streaming deposition as committed (frames of a cell brought onto one, second particles deferred, lane pairs
+# round 6, sessions v, x and z (x: with the sparse tiles through the table; z: the tiles in turn over the XCDs): the streaming deposition as committed (frames of a cell brought onto one, second particles deferred, lane pairs
 # sharing the adding): the deposition / step / deck tests, BASELINE config 5 on one GPU twice, the headline, the kernel's SQ counters and
 # the profile build's population table
-cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; O=$(pwd)/gpurun_out/r6v; mkdir -p $O
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; O=$(pwd)/gpurun_out/r6z; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q -k "deposit or streaming or cold_stream or laser or btd or boost or golden or deck" 2>&1 | grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" | tail -3 | tee $O/pytest.txt
 for rep in 1 2; do
 timeout 500 python scripts/bench_lwfa_boosted.py > $O/lwfa_boosted.json 2> $O/lwfa_boosted.err; echo "config 5 rc=$?"

@@ -515,7 +515,7 @@ def test_deposit_current_lds_tiles_crowded_cells(oracle, product, order, algo, d
 @pytest.mark.parametrize("streaming", [0, 1])
 @pytest.mark.parametrize("drift", [0.0, 0.8])
 @pytest.mark.parametrize("spike", [0, 3000])
-@pytest.mark.parametrize("n", [60000, 160000])
+@pytest.mark.parametrize("n", [4000, 60000, 160000])
 def test_deposit_current_of_a_streaming_plasma(oracle, product, order, streaming, drift, spike, n):
     """A plasma that streams through the grid (a boosted-frame run: every particle moves 0.76 cells per step against the
     boost, three in four cross a cell) on the LDS tiles, against the oracle: with wxa_workspace_set_streaming_plasma every
@@ -524,8 +524,9 @@ def test_deposit_current_of_a_streaming_plasma(oracle, product, order, streaming
     drift: moved by up to that many cells after the sort.
     spike: that many particles in ONE cell and a tenth of it in its neighbour (a wake's density spike): with the streaming
     body the lanes of a wave that share a frame sum every value over the wave before one lane adds it (wave_sum_f64).
-    n: 10 and 26 particles per cell on average; at 26 the pairs beyond a cell's fourth do not fit the tile's tail table and
-    all of them become excess chunks."""
+    n: 0.65, 10 and 26 particles per cell on average; at 26 the pairs beyond a cell's fourth do not fit the tile's tail
+    table and all of them become excess chunks; at 0.65 (a sparse tile, with the streaming body) all pairs go through the
+    table and the direct part's chunks are skipped -- with the spike, one tile is sparse but for a cell of thousands."""
     ncell = (16, 16, 24)
     _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
     parts = H.random_particles(n, ncell, 410 + order, u_scale=0.05)
@@ -569,14 +570,15 @@ def test_deposit_current_of_a_streaming_plasma(oracle, product, order, streaming
 
 
 @pytest.mark.parametrize("order", [1, 3])
-@pytest.mark.parametrize("keep", [1.0, 0.7])
+@pytest.mark.parametrize("keep", [1.0, 0.7, 0.4, 0.12])
 @pytest.mark.parametrize("step_cells", [0.76, 0.5])
 def test_deposit_current_of_a_cold_stream_on_a_lattice(oracle, product, order, keep, step_cells):
     """The plasma ahead of a boosted-frame wake: eight particles per cell on a 2 x 2 x 2 lattice, cold, every one of them
     `step_cells` of a cell along -z per step.  At 0.76 all of them cross a cell face and the pairs of a cell share their
     wide frame: whole waves take the streaming body's PairScatterSink (lanes l and l + 32 share the summing AND the
     adding); at 0.5 half of a cell's particles cross and the lane pairs' frames differ (PairSumSink).  keep < 1: that
-    share of the particles, at random -- cells with odd counts, lanes and lane pairs without a particle."""
+    share of the particles, at random -- cells with odd counts, lanes and lane pairs without a particle; at 0.4 and 0.12 a
+    tile holds ~1600 / ~500 particles and lists all its pairs in the table instead of running the direct part's chunks."""
     ncell = (16, 16, 24)
     _, ng_depos, ng_j = H.guard_depths(order, use_filter=True)
     dx = H.LX / np.asarray(ncell)

@@ -197,8 +197,14 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
     // -- 32 items per chunk, RT / 2 table rows.  Otherwise an item is one pair, 64 per chunk (consecutive lanes in
     // consecutive cells: the layout the uniform plasma's bank arithmetic is made for).
     constexpr int TW = CFG::WL != 0 && CFG::ALGO == WXA_DEPOSIT_ESIRKEPOV ? 2 : 1;   // pairs per tail / excess item
-    constexpr int RTU = RT / TW;                                                    // table rows in use
+    // ... and a tile of a streaming plasma with few particles (the plasma's edge, the cavity behind the pulse: a twelfth of
+    // the boosted wakefield's particles, a third of its workgroups' time until round 6) lists ALL its pairs in the table
+    // and skips the direct part, whose 32 chunks would each run the whole body for the two or three lanes in 64 that hold
+    // a particle: SPARSE_MAX particles fill at most SPARSE_MAX / 4 + CELLS = 1024 entries, the table's capacity.
+    constexpr bool CAN_BE_SPARSE = TW == 2;
+    constexpr int SPARSE_MAX = 2048;
     constexpr int TCAP = CELLS * 2;                // tail capacity (8 ppc: 0.66 tail items per cell on average)
+    static_assert(!CAN_BE_SPARSE || SPARSE_MAX / 4 + CELLS <= TCAP, "a sparse tile's pairs fit the table");
     constexpr int DEFER = 2048;
     static_assert(NT >= CELLS && RT >= 8, "one lane per cell");
     __shared__ ACC lds[3 * NPTS];
@@ -256,6 +262,9 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
     const int start = offsets[ucell0];
     const int end = offsets[ucell0 + CELLS];
     if (end <= start) return;
+    const bool sparse = CAN_BE_SPARSE && end - start <= SPARSE_MAX;   // uniform
+    const int first_row_pair = sparse ? 0 : 4;                        // the table's rows start at this pair of a cell
+    const int RTU = (RMAX - first_row_pair) / TW;                     // table rows in use
     constexpr int DCAP = DEFER / NBKT;
     auto defer = [&](const int ip, const int bank) {   // phase B: by index only (the particle has not been loaded)
         const int n = atomicAdd(&ndef[bank], 1);
@@ -305,7 +314,7 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
         my_pairs = min((my_n + 1) >> 1, RMAX);
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            my_mask[r] = __ballot(r < RTU && my_pairs > 4 + TW * r);
+            my_mask[r] = __ballot(r < RTU && my_pairs > first_row_pair + TW * r);
             if (lane == 0) masks[r][wave] = my_mask[r];
         }
     }
@@ -329,11 +338,11 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int base = __shfl(excl, r * CW + wave);   // first item of (tail row r, this cell-wave)
-            if (r < RTU && my_pairs > 4 + TW * r && !no_tail) {
+            if (r < RTU && my_pairs > first_row_pair + TW * r && !no_tail) {
                 const int at = base + __popcll(my_mask[r] & lt);
-                if (at < TCAP) table[at] = (unsigned short)(tid | ((4 + TW * r) << 9));
+                if (at < TCAP) table[at] = (unsigned short)(tid | ((first_row_pair + TW * r) << 9));
                 else {   // any bucket is correct; the cell's place in the sort order is the bank of a particle that stayed
-                    for (int e = 2 * (4 + TW * r); e < min(2 * (4 + TW * r) + 2 * TW, my_n); ++e)
+                    for (int e = 2 * (first_row_pair + TW * r); e < min(2 * (first_row_pair + TW * r) + 2 * TW, my_n); ++e)
                         defer_unloaded(my_s + e, tid & (NBANK - 1));
                 }
             }
@@ -369,15 +378,16 @@ deposit_tile_rows_kernel(JTriple J3, const double* __restrict__ px, const double
     const long long prof_l0 = clock64();
 #endif
     const int CH0 = unit_u + unit_k * wave, CHS = unit_k * WAVES;   // the chunks of this unit, wave by wave
-    const int nregular = NB + ((T + TPC - 1) / TPC);
+    const int NBr = sparse ? 0 : NB;   // chunks of the direct part that run
+    const int nregular = NBr + ((T + TPC - 1) / TPC);
     const int nchunks = nregular + ((excess_pairs + TPC - 1) / TPC);   // (excess_pairs: the excess' items)
     // the lane's work item of chunk ch: its two particles (an empty lane reads the tile's first particle)
     auto item_of = [&](const int ch, int& ia, int& ib, bool& va, bool& vb) {
         int c, r;
-        if (ch < NB) {
+        if (ch < NBr) {
             c = BW * (ch / (4 / RPC)) + (lane % BW); r = RPC * (ch % (4 / RPC)) + lane / BW; va = true;
         } else if (ch < nregular) {
-            const int I = (ch - NB) * TPC + (lane & (TPC - 1));
+            const int I = (ch - NBr) * TPC + (lane & (TPC - 1));
             va = I < T;
             const unsigned ent = va ? table[I] : 0u;
             c = (int)(ent & 511u); r = (int)(ent >> 9) + lane / TPC;

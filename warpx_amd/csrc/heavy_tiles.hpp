@@ -26,13 +26,17 @@ struct HeavyUnits {
     // streaming deposition: lanes of a wave that share a frame sum their values over the wave first when there are at
     // least this many of them (deposit_tile.hip; WXA_WAVE_SUM_MIN, read per launch; 65: never)
     int wave_sum_min = 16;
+    // Tile t on workgroup t -- consecutive tiles on different XCDs -- instead of a contiguous eighth of the tiles per XCD
+    // (xcd_tile_id): where the work per tile follows the plasma's structure (a wake: the dense tiles sit in a few z slabs)
+    // an XCD's eighth of the domain can hold most of the launch's work, and the launch lasts as long as that XCD.
+    int interleave = 0;
 };
 
 // the workgroup's tile and its share (u of k); false: nothing to do
 __device__ __forceinline__ bool heavy_unit_of(const HeavyUnits& hu, const long bid, const long ntiles, long& tile, int& u, int& k) {
     u = 0; k = 1;
     if (!hu.kt || bid < hu.grid_tiles) {
-        tile = xcd_tile_id(bid, ntiles);
+        tile = hu.interleave ? bid : xcd_tile_id(bid, ntiles);
         if (tile >= ntiles) return false;
         if (hu.kt) k = hu.kt[tile];
         return true;
@@ -99,6 +103,8 @@ inline wxa_status plan_heavy_tiles(wxa_workspace* ws, const int* offsets, long n
                        WXA_TILE * WXA_TILE * WXA_TILE, heavy, max_extra, kt, extra, nextra);
     WXA_LAUNCH_CHECK();
     hu.kt = kt; hu.extra = extra; hu.nextra = nextra; hu.grid_tiles = xcd_grid_size(ntiles);
+    if (const char* e = getenv("WXA_TILE_INTERLEAVE")) hu.interleave = atoi(e);   // (read per launch: the A/B of profiles/round6)
+    else hu.interleave = ws->streaming_plasma ? 1 : 0;
     extra_groups = max_extra;
     return WXA_OK;
 }
