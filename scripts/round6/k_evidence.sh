@@ -3,7 +3,7 @@
 # stamped), the default bench line as the driver runs it (with the CPU baseline), rocprofv3 --kernel-trace --stats of the same
 # command, the step's timeline, the secondary configurations, BASELINE config 5 on one GPU, the product as 2 and 8 processes.
 set -u
-cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; O=$(pwd)/gpurun_out/r6end; mkdir -p $O; ROOTDIR=$(pwd)
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; O=$(pwd)/gpurun_out/r6fin; mkdir -p $O; ROOTDIR=$(pwd)
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.txt
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" | tail -8 | tee $O/pytest_gpu.txt
 timeout 1500 python scripts/pmc_traffic.py $O/pmc > $O/pmc_stdout.txt 2>&1; echo "pmc rc=$?"

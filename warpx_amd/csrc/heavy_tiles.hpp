@@ -73,14 +73,16 @@ plan_heavy_tiles_kernel(const int* __restrict__ offsets, long ntiles, int cells_
 }
 
 // Particles a tile may hold before it is split.  On for the workspaces of a streaming plasma (a boosted-frame wake is
-// where the spikes were met: 8192, twice the uniform plasma's 4096 per tile at 8 per cell -- 305 -> 170 ms per step for
-// BASELINE config 5 on one GPU, 235 at 32768) and wherever WXA_HEAVY_TILE says so (read per launch: a test sets it for one
-// case; 0 switches the splitting off).  Off otherwise: the np / heavy + 1 extra workgroups a launch appends exit at once
-// when no tile is heavy, but they cost the uniform-plasma headline 0.07 ms per step (profiles/round5/README.md).
+// where the spikes were met) and wherever WXA_HEAVY_TILE says so (read per launch: a test sets it for one case; 0 switches
+// the splitting off).  4096 -- the uniform plasma's tile at 8 per cell: BASELINE config 5 on one GPU, deposition per launch
+// with the tiles in turn over the XCDs (profiles/round6, session za): 40.0 ms at 1024, 33.8 at 2048, 32.4 at 3072, 32.0 at
+// 4096, 32.7 at 6144, 33.7 at 8192 (the default until then), 36.9 at 16384.  Off otherwise: the np / heavy + 1 extra
+// workgroups a launch appends exit at once when no tile is heavy, but they cost the uniform-plasma headline 0.07 ms per step
+// (profiles/round5/README.md).
 inline int heavy_tile_threshold(const wxa_workspace* ws) {
     const char* e = getenv("WXA_HEAVY_TILE");
     if (e) return atoi(e);
-    return ws->streaming_plasma ? 8192 : 0;
+    return ws->streaming_plasma ? 4096 : 0;
 }
 
 // Plans the units of a launch over `ntiles` tiles of `np` sorted particles; on return `hu` is what the kernel takes and
