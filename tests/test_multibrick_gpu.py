@@ -514,9 +514,26 @@ def _spawn_bricks(nb, order, filt, overlap, ncell, port, tmp_path, steps=6, extr
            os.path.join(root, "tests", "multibrick_worker.py"), *[str(v) for v in nb], str(order), str(filt), out, str(overlap)]
     env = dict(os.environ, OMP_NUM_THREADS=str(max(1, (os.cpu_count() or 8) // n)), WXA_WORKER_LIB="product",
                WXA_TEST_NCELL=" ".join(str(v) for v in ncell), WXA_TEST_STEPS=str(steps), **(extra_env or {}))
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return json.load(open(out))
+    # One more attempt when a child was killed by a GPU exception: seen twice in ~25 runs of the whole suite on the pool's
+    # boxes (a "GPU core dump" in one of eight processes, in the first sort of a brick, the parent pytest process holding
+    # its own context on the same device), never in 40 runs of these tests on their own (profiles/round6/README.md,
+    # session zf) -- not understood; the retry is reported, not hidden.
+    for attempt in (1, 2):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        text = r.stdout + r.stderr
+        if r.returncode != 0 and attempt == 1 and ("GPU core dump" in text or "Memory access fault" in text):
+            head = text[max(0, text.find("GPU core dump") - 1500):][:3000] if "GPU core dump" in text else text[-3000:]
+            print(f"[test_multibrick_gpu] a child died of a GPU exception, running the {n} processes once more:\n{head}", flush=True)
+            log_dir = os.path.join(root, "gpurun_out")   # (kept across a gpurun call: what the exception was)
+            if os.path.isdir(log_dir):
+                with open(os.path.join(log_dir, "gpu_exception_retries.txt"), "a") as fh:
+                    fh.write(f"==== {nb} overlap {overlap} port {port} ====\n{head}\n")
+            continue
+        break
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    rep = json.load(open(out))
+    rep["gpu_exception_retries"] = attempt - 1
+    return rep
 
 
 @pytest.mark.skipif(not H.ON_GPU, reason="processes that share the one GPU of the box")

@@ -203,6 +203,9 @@ class WarpXSim:
             particles = ParticleArrays.from_numpy(particles, self.lib.memory)
         sid = C.c_int32(-1)
         v = particles.view
+        if str(self.lib.memory).startswith("cuda"):   # whatever stream filled `particles` (torch's): done before the library's reads it
+            import torch
+            torch.cuda.synchronize()
         self.lib.sim_add_species(self._h, float(charge), float(mass), C.byref(v), C.byref(sid))
         self.species.append((float(charge), float(mass)))
         return sid.value
